@@ -1,0 +1,302 @@
+/*
+ * svtvp9_hip.h -- C-ABI of the MI355X (gfx950) implementation of SVT-VP9's block-level DSP hot path.
+ *
+ * Plain C, plain pointers and sizes; no C++/torch types.  This is the boundary a maintainer of the
+ * reference binds: three *batched* entry points that replace the places where the
+ * reference calls its per-block x86 kernels, plus context management.
+ *
+ *   svt_hip_me_picture   replaces the SB loop of eb_vp9_motion_estimation_kernel
+ *                        (Source/Lib/Codec/EbMotionEstimationProcess.c:964-1044 -> motion_estimate_sb,
+ *                         Source/Lib/Codec/EbMotionEstimation.c:4524-5305)
+ *   svt_hip_tq_batch     replaces perform_coding_loop's residual -> fwd txfm -> quant -> (inv txfm + recon)
+ *                        (Source/Lib/Codec/EbEncDecProcess.c:365-587; kernels VPX/fwd_txfm.c, vp9_dct.c,
+ *                         quantize.c, inv_txfm.c, vp9_idct.c)
+ *   svt_hip_lf_frame     replaces eb_vp9_loop_filter_frame (Source/Lib/VPX/vp9_loopfilter.c:1521,
+ *                        called at Source/Lib/Codec/EbEncDecProcess.c:5678)
+ *
+ * All functions return 0 on success or a negative svt_hip_status.  Host buffers are caller-owned;
+ * device buffers are owned by the context.  A context is bound to one HIP device and one stream;
+ * calls on different contexts are independent (the reference runs up to 20 ME threads).
+ *
+ * Every pointer parameter named d_* is a DEVICE pointer (HBM resident); the *_host convenience
+ * wrappers take host pointers and stage through the context's own device buffers.
+ */
+#ifndef SVTVP9_HIP_H
+#define SVTVP9_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------ */
+/* status codes (negative = error; values mirror the sign convention of EbErrorType,                 */
+/* Source/API/EbSvtVp9Enc.h:100-120, without reusing its 0x8000xxxx numbering)                        */
+/* ------------------------------------------------------------------------------------------------ */
+typedef enum svt_hip_status {
+    SVT_HIP_OK                 = 0,
+    SVT_HIP_ERR_BAD_PARAMETER  = -1, /* EB_ErrorBadParameter */
+    SVT_HIP_ERR_NO_RESOURCES   = -2, /* EB_ErrorInsufficientResources */
+    SVT_HIP_ERR_DEVICE         = -3, /* HIP runtime failure (message via svt_hip_last_error) */
+    SVT_HIP_ERR_UNSUPPORTED    = -4
+} svt_hip_status;
+
+typedef struct svt_hip_ctx svt_hip_ctx; /* opaque */
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Motion estimation                                                                                  */
+/* ------------------------------------------------------------------------------------------------ */
+
+#define SVT_ME_PU_COUNT 85 /* MAX_ME_PU_COUNT, Codec/EbMotionEstimationLcuResults.h:14 */
+#define SVT_SB_SIZE 64     /* MAX_SB_SIZE */
+
+/* One padded 8-bit luma plane.  Mirrors the fields of EbPictureBufferDesc that ME reads
+ * (Codec/EbPictureBufferDesc.h:27-59): buffer_y, stride_y, origin_x/y (= padding), width, height. */
+typedef struct svt_plane {
+    const uint8_t *buf;      /* first byte of the padded buffer (top-left of the padding) */
+    int32_t        stride;   /* bytes per row */
+    int32_t        origin_x; /* left padding  (picture column 0 is at buf[origin_y*stride+origin_x]) */
+    int32_t        origin_y; /* top padding */
+    int32_t        width;    /* unpadded width  */
+    int32_t        height;   /* unpadded height */
+} svt_plane;
+
+/* The three planes of an EbPaReferenceObject (Codec/EbReferenceObject.h:39-49):
+ * padded input, 1/4 (2x2 point-decimated) and 1/16 (4x4 point-decimated) luma. */
+typedef struct svt_pa_picture {
+    svt_plane full;
+    svt_plane quarter;
+    svt_plane sixteenth;
+} svt_pa_picture;
+
+/* Fractional search method, Codec/EbDefinitions.h:664-666 */
+#define SVT_SUB_SAD_SEARCH 0
+#define SVT_FULL_SAD_SEARCH 1
+#define SVT_SSD_SEARCH 2
+
+/* Everything motion_estimate_sb reads from PictureParentControlSet / SequenceControlSet / MeContext.
+ * Field names follow the reference (Codec/EbMotionEstimationContext.h:372-398,
+ * Codec/EbMotionEstimation.c:4584-4631). */
+typedef struct svt_me_params {
+    /* picture level */
+    uint8_t  num_ref_lists;        /* 1 = P_SLICE (list 0 only), 2 = B_SLICE */
+    uint8_t  temporal_layer_index;
+    uint8_t  hierarchical_levels;  /* selects the HME-L0 multiplier row, Codec/EbDefinitions.h:989-1005 */
+    uint8_t  enable_hme_flag;
+    uint8_t  enable_hme_level_0_flag;
+    uint8_t  enable_hme_level_1_flag;
+    uint8_t  enable_hme_level_2_flag;
+    uint8_t  cu8x8_mode;           /* 0: refine + bipred 8x8 PUs, 1: full-pel only (Codec/EbDefinitions.h:943) */
+    uint8_t  cu16x16_mode;         /* 0: refine + bipred 16x16 PUs */
+    uint8_t  same_ref_poc;         /* ref_pic_poc_array[0] == ref_pic_poc_array[1] (EbMotionEstimation.c:4952) */
+    uint8_t  rate_control_mode;    /* != 0 -> rcme_distortion is produced */
+    /* MeContext multi-mode signals */
+    uint8_t  fractional_search_method; /* SVT_SUB_SAD_SEARCH / SVT_FULL_SAD_SEARCH / SVT_SSD_SEARCH */
+    uint8_t  fractional_search_model;  /* 0 all, 1 selective (su_pel_enable), 2 off */
+    uint8_t  fractional_search64x64;
+    uint8_t  single_hme_quadrant;
+    /* full-pel search area */
+    uint8_t  search_area_width;
+    uint8_t  search_area_height;
+    /* HME */
+    uint16_t number_hme_search_region_in_width;  /* 1 or 2 */
+    uint16_t number_hme_search_region_in_height; /* 1 or 2 */
+    uint16_t hme_level0_total_search_area_width;
+    uint16_t hme_level0_total_search_area_height;
+    uint16_t hme_level0_search_area_in_width_array[2];
+    uint16_t hme_level0_search_area_in_height_array[2];
+    uint16_t hme_level1_search_area_in_width_array[2];
+    uint16_t hme_level1_search_area_in_height_array[2];
+    uint16_t hme_level2_search_area_in_width_array[2];
+    uint16_t hme_level2_search_area_in_height_array[2];
+} svt_me_params;
+
+/* Result record per (SB, PU); same field order and size (40 bytes) as MeCuResults
+ * (Codec/EbMotionEstimationLcuResults.h:39-56).  The reference's 2-bit `direction` bit-field is
+ * widened to a full uint32 here (value 0 = UNI_PRED_LIST_0, 1 = UNI_PRED_LIST_1, 2 = BI_PRED);
+ * INTEGRATION.md shows the field-wise copy into MeCuResults. */
+typedef struct svt_me_dist_dir {
+    uint32_t distortion;
+    uint32_t direction;
+} svt_me_dist_dir;
+
+typedef struct svt_me_pu_result {
+    int16_t         x_mv_l0, y_mv_l0, x_mv_l1, y_mv_l1; /* quarter-pel units */
+    svt_me_dist_dir distortion_direction[3];
+    uint8_t         total_me_candidate_index;
+    uint8_t         pad_[7];
+} svt_me_pu_result;
+
+/* Geometry helper: number of SBs of a picture (ceil(w/64)*ceil(h/64)). */
+int32_t svt_hip_sb_count(int32_t pic_width, int32_t pic_height);
+
+/* Fill `p` exactly as eb_vp9_signal_derivation_me_kernel_{oq,sq} + eb_vp9_set_me_hme_params_{oq,sq}
+ * (Codec/EbMotionEstimationProcess.c:55-324, 541-720) and picture_decision's picture-level signals
+ * (Codec/EbPictureDecisionProcess.c:682-703, 856-870, Codec/EbResourceCoordinationProcess.c:343-457)
+ * do for the BASELINE configurations: tune 1 (OQ) enc_mode 8/9 at <=576p / 1080p / 2160p and
+ * tune 0 (SQ) enc_mode 3 at 2160p.  Returns SVT_HIP_ERR_UNSUPPORTED for other combinations (callers
+ * then fill svt_me_params themselves -- every field is a plain copy of a reference field). */
+int32_t svt_hip_me_params_preset(svt_me_params *p, int32_t pic_width, int32_t pic_height, int32_t enc_mode,
+                                 int32_t tune, int32_t num_ref_lists, int32_t temporal_layer_index,
+                                 int32_t hierarchical_levels);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* context                                                                                            */
+/* ------------------------------------------------------------------------------------------------ */
+int32_t svt_hip_ctx_create(svt_hip_ctx **ctx, int32_t device_ordinal);
+/* Same, but all work is enqueued on a caller-provided hipStream_t (passed as void*). */
+int32_t svt_hip_ctx_create_on_stream(svt_hip_ctx **ctx, int32_t device_ordinal, void *hip_stream);
+void    svt_hip_ctx_destroy(svt_hip_ctx *ctx);
+int32_t svt_hip_ctx_synchronize(svt_hip_ctx *ctx);
+const char *svt_hip_last_error(void);
+/* Timing of the kernels launched by the most recent *_device call on this context, measured with
+ * hipEvents recorded on the context's stream (ms).  Valid after svt_hip_ctx_synchronize(). */
+float   svt_hip_last_kernel_ms(svt_hip_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* ME entry points                                                                                    */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* Device-resident form (the one that is benchmarked): every svt_plane.buf in cur/ref0/ref1 is a
+ * device pointer, d_results is a device array [n_sb][85].  ref1 may be NULL when num_ref_lists==1.
+ * d_rcme_distortion (uint32 per SB) may be NULL.  Asynchronous on the context's stream. */
+int32_t svt_hip_me_picture_device(svt_hip_ctx *ctx, const svt_pa_picture *cur, const svt_pa_picture *ref0,
+                                  const svt_pa_picture *ref1, const svt_me_params *params,
+                                  svt_me_pu_result *d_results, uint32_t *d_rcme_distortion);
+
+/* Batched device-resident form: ME of n_pics independent pictures in ONE launch (ME reads source
+ * pictures only -- Codec/EbMotionEstimation.c:4638-4642 -- so all pictures of a mini-GOP are
+ * independent).  Arrays of n_pics descriptors (host memory); d_results[i] / d_rcme[i] device arrays. */
+int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture *cur,
+                                const svt_pa_picture *ref0, const svt_pa_picture *ref1,
+                                const svt_me_params *params, svt_me_pu_result *const *d_results,
+                                uint32_t *const *d_rcme_distortion);
+
+/* Host-pointer convenience form (what the reference's ME thread would call): uploads the planes,
+ * runs svt_hip_me_picture_device, downloads results[n_sb][85], synchronous. */
+int32_t svt_hip_me_picture(svt_hip_ctx *ctx, const svt_pa_picture *cur, const svt_pa_picture *ref0,
+                           const svt_pa_picture *ref1, const svt_me_params *params, svt_me_pu_result *results,
+                           uint32_t *rcme_distortion);
+
+/* Stand-alone HME level-0 search = eb_vp9_sad_loop_kernel (C_DEFAULT/EbComputeSAD_C.c:132-169)
+ * batched over n independent (block, window) problems; device pointers. Exposed for unit parity tests.
+ * Each problem: block w x h (rows already at src_stride), window search_w x search_h; ref row step
+ * for the block rows = ref_stride, for successive search rows = ref_stride_raw. */
+typedef struct svt_sad_loop_job {
+    uint64_t src_off;   /* byte offset into d_src */
+    uint64_t ref_off;   /* byte offset into d_ref */
+    int32_t  src_stride, ref_stride, ref_stride_raw;
+    int32_t  width, height;       /* block */
+    int32_t  search_w, search_h;  /* window */
+} svt_sad_loop_job;
+typedef struct svt_sad_loop_result {
+    uint32_t best_sad;
+    int16_t  x, y;
+} svt_sad_loop_result;
+int32_t svt_hip_sad_loop_batch_device(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_ref,
+                                      const svt_sad_loop_job *d_jobs, int32_t n_jobs,
+                                      svt_sad_loop_result *d_out);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Transform / quantisation                                                                           */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* TX sizes / types follow VPX/vp9_enums.h (TX_4X4..TX_32X32; DCT_DCT, ADST_DCT, DCT_ADST, ADST_ADST). */
+#define SVT_TX_4X4 0
+#define SVT_TX_8X8 1
+#define SVT_TX_16X16 2
+#define SVT_TX_32X32 3
+#define SVT_DCT_DCT 0
+#define SVT_ADST_DCT 1
+#define SVT_DCT_ADST 2
+#define SVT_ADST_ADST 3
+
+/* Quantiser tables of one (qindex, plane): the [0]=DC,[1]=AC pairs eb_vp9_init_quantizer produces
+ * (VPX/vp9_quantize.c:206-265); passed to eb_vp9_quantize_b[_32x32] (VPX/quantize.c:112-254). */
+typedef struct svt_quant_tables {
+    int16_t zbin[2], round[2], quant[2], quant_shift[2], dequant[2];
+} svt_quant_tables;
+
+/* One transform block of perform_coding_loop (Codec/EbEncDecProcess.c:365-587). */
+typedef struct svt_tq_block {
+    uint32_t src_off;    /* byte offset of the block's top-left in the source plane  */
+    uint32_t pred_off;   /* byte offset in the prediction plane                       */
+    uint32_t recon_off;  /* byte offset in the recon plane (written when do_recon)    */
+    uint32_t coeff_off;  /* element offset into qcoeff / dqcoeff (n*n contiguous)     */
+    uint16_t src_stride, pred_stride, recon_stride;
+    uint8_t  tx_size;    /* SVT_TX_* */
+    uint8_t  tx_type;    /* SVT_DCT_DCT.. (ADST only for <=16x16) */
+    uint8_t  qtab;       /* index into the quant-table array */
+    uint8_t  do_recon;   /* run inverse transform + add into recon */
+    uint8_t  partial32;  /* 32x32 only: use eb_vpx_partial_fdct32x32 (low 16x16 kept, rest zero) */
+    uint8_t  pad_;
+} svt_tq_block;
+
+/* residual = src - pred (eb_vp9_residual_kernel, C_DEFAULT/EbPictureOperators_C.c:204-223)
+ * -> forward DCT/ADST (VPX/fwd_txfm.c, VPX/vp9_dct.c) -> eb_vp9_quantize_b[_32x32]
+ * -> if do_recon: recon = pred; inverse transform of dqcoeff added into recon
+ *    (eb_vp9_idct*_add / eb_vp9_iht*_add, VPX/vp9_idct.c:111-189).
+ * Outputs: qcoeff, dqcoeff (int16, raster within block), eob per block.  Device pointers. */
+int32_t svt_hip_tq_batch_device(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *d_recon,
+                                const svt_tq_block *d_blocks, int32_t n_blocks, const svt_quant_tables *d_qtabs,
+                                int32_t n_qtabs, int16_t *d_qcoeff, int16_t *d_dqcoeff, uint16_t *d_eob);
+
+/* Host-pointer convenience form. plane_bytes = size of each of src/pred/recon; coeff_count = total coeffs. */
+int32_t svt_hip_tq_batch(svt_hip_ctx *ctx, const uint8_t *src, const uint8_t *pred, uint8_t *recon,
+                         size_t plane_bytes, const svt_tq_block *blocks, int32_t n_blocks,
+                         const svt_quant_tables *qtabs, int32_t n_qtabs, int16_t *qcoeff, int16_t *dqcoeff,
+                         size_t coeff_count, uint16_t *eob);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* In-loop deblocking                                                                                 */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* Bit-for-bit the reference's LOOP_FILTER_MASK (VPX/vp9_loopfilter.h; 160 bytes):
+ * built on the host by eb_vp9_build_mask_frame (VPX/vp9_loopfilter.c:1548) and uploaded as is. */
+typedef struct svt_lf_mask {
+    uint64_t left_y[4];   /* per TX size */
+    uint64_t above_y[4];
+    uint64_t int_4x4_y;
+    uint16_t left_uv[4];
+    uint16_t above_uv[4];
+    uint16_t int_4x4_uv;
+    uint8_t  lfl_y[64];
+} svt_lf_mask;
+
+/* Per-level thresholds = loop_filter_info_n.lfthr[] (VPX/vp9_loopfilter.h: mblim/lim/hev_thr, each
+ * SIMD_WIDTH=16 replicated bytes); only byte 0 of each is meaningful to the C kernels. */
+typedef struct svt_lf_thresh {
+    uint8_t mblim[64];
+    uint8_t lim[64];
+    uint8_t hev_thr[64];
+} svt_lf_thresh;
+
+/* Compute the thresholds exactly as eb_vp9_loop_filter_init/update_sharpness
+ * (VPX/vp9_loopfilter.c:221-262) for a given sharpness level. */
+void svt_hip_lf_thresh_init(svt_lf_thresh *t, int32_t sharpness_level);
+/* eb_vp9_pick_filter_level's level-from-q rule (VPX/vp9_picklpf.c:37-89), 8-bit. */
+int32_t svt_hip_lf_level_from_q(int32_t ac_q, int32_t is_key_frame);
+
+/* 4:2:0 recon picture, planes filtered in place. */
+typedef struct svt_yuv_planes {
+    uint8_t *y, *u, *v;    /* pointers to picture sample (0,0) of each plane */
+    int32_t  y_stride, uv_stride;
+    int32_t  width, height; /* luma dimensions (multiples of 8) */
+} svt_yuv_planes;
+
+/* = eb_vp9_loop_filter_frame(frame, cm, xd, lfm_base, filter_level, y_only=0, partial=0)
+ * (VPX/vp9_loopfilter.c:1521-1546 -> loop_filter_rows :1456).  lfm: one mask per SB in raster order
+ * [ceil(mi_rows/8)][lfm_stride].  Device pointers.  mi_rows/mi_cols in 8x8 units. */
+int32_t svt_hip_lf_frame_device(svt_hip_ctx *ctx, const svt_yuv_planes *d_recon, const svt_lf_mask *d_lfm,
+                                int32_t lfm_stride, const svt_lf_thresh *thr, int32_t mi_rows, int32_t mi_cols,
+                                int32_t y_only);
+/* Host-pointer convenience form (planes are tightly described by recon; rows*stride bytes copied). */
+int32_t svt_hip_lf_frame(svt_hip_ctx *ctx, const svt_yuv_planes *recon, const svt_lf_mask *lfm, int32_t lfm_stride,
+                         const svt_lf_thresh *thr, int32_t mi_rows, int32_t mi_cols, int32_t y_only);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVTVP9_HIP_H */

@@ -1,0 +1,23 @@
+/* oracle.h -- entry points of the CPU parity oracle (TEST INFRASTRUCTURE ONLY; see oracle_me.c). */
+#ifndef SVT_ORACLE_H
+#define SVT_ORACLE_H
+#include <stdint.h>
+#include "../include/svtvp9_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* leaf kernels */
+uint32_t oracle_sad_nxm(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int h, int w);
+uint32_t oracle_avg_sad(const uint8_t *src, int src_stride, const uint8_t *r1, int s1, const uint8_t *r2, int s2,
+                        int h, int w);
+void oracle_sad_loop(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int height, int width,
+                     uint64_t *best_sad, int16_t *xc, int16_t *yc, int ref_stride_raw, int search_w, int search_h);
+/* motion_estimate_sb over SBs [sb_begin, sb_end) of a picture (sb_end < 0 = all).
+ * results is indexed [sb][85] over the WHOLE picture. */
+int32_t svt_oracle_me_picture(const svt_pa_picture *cur, const svt_pa_picture *ref0, const svt_pa_picture *ref1,
+                              const svt_me_params *params, svt_me_pu_result *results, uint32_t *rcme_distortion,
+                              int32_t sb_begin, int32_t sb_end);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,912 @@
+/*
+ * oracle_me.c -- CPU restatement of SVT-VP9's motion_estimate_sb (C_DEFAULT path).
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle for the HIP motion-estimation kernels.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The product
+ * (svt-vp9_amd/) never links, imports or calls anything in oracle/.
+ *
+ * Pinning status: the leaf arithmetic (sad_loop, 8-point 85-PU SAD update, AVC 4-tap half-pel filters,
+ * averaging SAD) is checked bit-exact against the reference's own C kernels compiled into
+ * oracle/_ref/libsvtref_kernels.so, and the whole per-SB flow is checked against the reference's
+ * motion_estimate_sb through oracle/_ref/ref_me_sb (tests/test_oracle_vs_ref.py).  The reference holds
+ * no unit tests / golden vectors of its own for this path.
+ *
+ * Each function cites the reference lines it restates (paths relative to /root/reference/Source/Lib).
+ * "Bug-compatible" behaviours that are deliberately preserved are marked [quirk].
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/svtvp9_hip.h"
+#include "oracle.h"
+
+#define SB 64
+#define FT 2 /* ME_FILTER_TAP >> 1, Codec/EbDefinitions.h:662 */
+#define MAX_SAD_VALUE (64 * 64 * 255)
+
+/* Codec/EbMotionEstimation.c:51-54 -- raster index -> search (z-order) index */
+static const uint8_t tab32x32[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
+static const uint8_t tab8x8[64]   = {0,  1,  4,  5,  16, 17, 20, 21, 2,  3,  6,  7,  18, 19, 22, 23, 8,  9,  12, 13, 24, 25,
+                                     28, 29, 10, 11, 14, 15, 26, 27, 30, 31, 32, 33, 36, 37, 48, 49, 52, 53, 34, 35, 38, 39,
+                                     50, 51, 54, 55, 40, 41, 44, 45, 56, 57, 60, 61, 42, 43, 46, 47, 58, 59, 62, 63};
+
+/* Codec/EbDefinitions.h:989-1005 (x and y tables are identical) */
+static const int32_t hme_l0_mult[6][6] = {{100, 0, 0, 0, 0, 0},       {100, 100, 0, 0, 0, 0},
+                                          {100, 100, 100, 0, 0, 0},   {200, 140, 100, 70, 0, 0},
+                                          {350, 200, 100, 100, 100, 0}, {525, 350, 200, 100, 100, 100}};
+
+static inline const uint8_t *pix(const svt_plane *p, int x, int y) {
+    return p->buf + (ptrdiff_t)(p->origin_y + y) * p->stride + p->origin_x + x;
+}
+static inline int absdiff(int a, int b) { return a > b ? a - b : b - a; }
+static inline int16_t mvx(uint32_t mv) { return (int16_t)(mv & 0xFFFF); }
+static inline int16_t mvy(uint32_t mv) { return (int16_t)(mv >> 16); }
+static inline uint32_t pack_mv(int x, int y) { return ((uint32_t)(uint16_t)y << 16) | (uint16_t)x; }
+
+/* C_DEFAULT/EbComputeSAD_C.c:113-130 eb_vp9_fast_loop_nx_m_sad_kernel */
+uint32_t oracle_sad_nxm(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int h, int w) {
+    uint32_t sad = 0;
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) sad += absdiff(src[x], ref[x]);
+        src += src_stride;
+        ref += ref_stride;
+    }
+    return sad;
+}
+
+/* C_DEFAULT/EbComputeSAD_C.c:14-31 eb_vp9_combined_averaging_sad */
+uint32_t oracle_avg_sad(const uint8_t *src, int src_stride, const uint8_t *r1, int s1, const uint8_t *r2, int s2,
+                        int h, int w) {
+    uint32_t sad = 0;
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            int avg = (r1[x] + r2[x] + 1) >> 1;
+            sad += absdiff(src[x], avg);
+        }
+        src += src_stride;
+        r1 += s1;
+        r2 += s2;
+    }
+    return sad;
+}
+
+/* C_DEFAULT/EbComputeSAD_C.c:132-169 eb_vp9_sad_loop_kernel: exhaustive search, strict '<' => first
+ * minimum in (y, x) raster order; best initialised to 0xffffff. */
+void oracle_sad_loop(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int height, int width,
+                     uint64_t *best_sad, int16_t *xc, int16_t *yc, int ref_stride_raw, int search_w, int search_h) {
+    *best_sad = 0xffffff;
+    for (int ys = 0; ys < search_h; ys++) {
+        for (int xs = 0; xs < search_w; xs++) {
+            uint32_t sad = 0;
+            for (int y = 0; y < height; y++)
+                for (int x = 0; x < width; x++) sad += absdiff(src[y * src_stride + x], ref[xs + y * ref_stride + x]);
+            if (sad < *best_sad) {
+                *best_sad = sad;
+                *xc       = (int16_t)xs;
+                *yc       = (int16_t)ys;
+            }
+        }
+        ref += ref_stride_raw;
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* per-SB working state                                                                             */
+/* ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    /* inputs */
+    const svt_pa_picture *cur;
+    const svt_pa_picture *ref[2];
+    const svt_me_params  *p;
+    int                   pic_w, pic_h;
+    int                   sb_x, sb_y, sb_w, sb_h;
+    const uint8_t        *src; /* sb_src_ptr: SB top-left in the padded source, stride = cur->full.stride */
+    int                   src_stride;
+    uint8_t               sixteenth_sb[16 * 8];  /* rows 0,2,4.. of the 1/16 SB, stride 16 (EbMotionEstimationProcess.c:1020-1035) */
+    uint8_t               quarter_sb[32 * 32];   /* stride 32 (EbMotionEstimationProcess.c:1003-1017) */
+    /* per list */
+    uint32_t best_sad[2][85]; /* search (z-order) index */
+    uint32_t best_mv[2][85];
+    uint32_t best_ssd[2][85];
+    uint8_t  dir[85];         /* psub_pel_direction*, shared by both lists like the reference's context */
+    int16_t  sa_origin_x[2], sa_origin_y[2]; /* x/y_search_area_origin[list][0] */
+    int      sa_w[2], sa_h[2];               /* clipped full-pel search area */
+    /* half-pel planes of the search region of each list; natural coordinates relative to the search
+       region top-left: B(x,y) = sample at (x+1/2, y), H(x,y) = (x, y+1/2), J = (x+1/2, y+1/2).
+       Stored with a 2-sample guard band on every side (index = (y+2)*hp_stride + x + 2). */
+    uint8_t *hb[2], *hh[2], *hj[2];
+    int      hp_stride, hp_rows;
+    uint32_t bipred_sad[85];
+} me_sb_t;
+
+/* [quirk] the reference updates the origin first and then re-tests the same condition for the width,
+ * so the left/top clipping never shrinks the area (Codec/EbMotionEstimation.c:5022-5054 and the four
+ * HME copies :2760-2796, :2939-2975, :3098-3133, :3227-3262).  int16_t truncation mirrored. */
+static void clip_area(int origin, int16_t *area_origin, int16_t *area_size, int pad, int pic_dim) {
+    int16_t o = *area_origin, s = *area_size;
+    o = (int16_t)(((origin + o) < -pad) ? -pad - origin : o);
+    s = (int16_t)(((origin + o) < -pad) ? s - (-pad - (origin + o)) : s);
+    o = (int16_t)(((origin + o) > pic_dim - 1) ? o - ((origin + o) - (pic_dim - 1)) : o);
+    if ((origin + o + s) > pic_dim) {
+        int t = s - ((origin + o + s) - pic_dim);
+        s     = (int16_t)(t > 1 ? t : 1);
+    }
+    *area_origin = o;
+    *area_size   = s;
+}
+
+static int16_t clip_center(int origin, int16_t c, int pad, int pic_dim) {
+    c = (int16_t)(((origin + c) < -pad) ? -pad - origin : c);
+    c = (int16_t)(((origin + c) > pic_dim - 1) ? c - ((origin + c) - (pic_dim - 1)) : c);
+    return c;
+}
+
+/* 64 x (h/2) row-subsampled SAD of the source SB against the full-res reference displaced by (dx,dy),
+ * result doubled: the pattern used by test_search_area_bounds / check_zero_zero_center. */
+static uint32_t sb_sub_sad(const me_sb_t *s, const svt_plane *ref, int dx, int dy) {
+    const uint8_t *r = pix(ref, s->sb_x + dx, s->sb_y + dy);
+    return oracle_sad_nxm(s->src, s->src_stride << 1, r, ref->stride << 1, s->sb_h >> 1, s->sb_w) << 1;
+}
+
+/* Codec/EbMotionEstimation.c:4260-4518 test_search_area_bounds */
+static void test_search_area_bounds(const me_sb_t *s, const svt_plane *ref, int list, int16_t *xsc, int16_t *ysc) {
+    const int pad = SB - 1;
+    const int W = ref->width, H = ref->height;
+    const int ox = (int16_t)s->sb_x, oy = (int16_t)s->sb_y;
+    const int tw = s->p->hme_level0_total_search_area_width, th = s->p->hme_level0_total_search_area_height;
+
+    uint64_t zero_cost = sb_sub_sad(s, ref, 0, 0);
+    /* [quirk] position A: the clipped centre is computed but the SAD is taken at the zero-MV address
+       again (:4302-4327), so mv_a_cost == zero_mv_cost and A can never be selected. */
+    uint64_t a_cost = zero_cost;
+    int16_t  cx, cy;
+    cx = clip_center(ox, (int16_t)tw, pad, W);
+    cy = clip_center(oy, 0, pad, H);
+    uint64_t b_cost = sb_sub_sad(s, ref, cx, cy);
+    cx = clip_center(ox, 0, pad, W);
+    cy = clip_center(oy, (int16_t)(0 - th), pad, H);
+    uint64_t c_cost = sb_sub_sad(s, ref, cx, cy);
+    cx = clip_center(ox, 0, pad, W);
+    cy = clip_center(oy, (int16_t)th, pad, H);
+    uint64_t d_cost = sb_sub_sad(s, ref, cx, cy);
+    uint64_t direct_cost = 0xFFFFFFFFFFFFFull;
+    int16_t  dirx = 0, diry = 0;
+    if (list == 1) {
+        /* L1 starts from the mirrored L0 64x64 MV (:4450-4451) */
+        dirx = (int16_t)(0 - (mvx(s->best_mv[0][0]) >> 2));
+        diry = (int16_t)(0 - (mvy(s->best_mv[0][0]) >> 2));
+        cx = clip_center(ox, dirx, pad, W);
+        cy = clip_center(oy, diry, pad, H);
+        direct_cost = sb_sub_sad(s, ref, cx, cy);
+    }
+    uint64_t best = zero_cost;
+    if (a_cost < best) best = a_cost;
+    if (b_cost < best) best = b_cost;
+    if (c_cost < best) best = c_cost;
+    if (d_cost < best) best = d_cost;
+    if (direct_cost < best) best = direct_cost;
+    /* [quirk] the returned centre is the UN-clipped candidate (:4492-4510); priority order
+       zero, A, B, C, direct, D */
+    if (best == zero_cost) { *xsc = 0; *ysc = 0; }
+    else if (best == a_cost) { *xsc = (int16_t)(0 - tw); *ysc = 0; }
+    else if (best == b_cost) { *xsc = (int16_t)tw; *ysc = 0; }
+    else if (best == c_cost) { *xsc = 0; *ysc = (int16_t)(0 - th); }
+    else if (best == direct_cost) { *xsc = list ? dirx : 0; *ysc = list ? diry : 0; }
+    else { *xsc = 0; *ysc = (int16_t)th; }
+}
+
+/* Codec/EbMotionEstimation.c:3758-3837 check_zero_zero_center */
+static void check_zero_zero_center(const me_sb_t *s, const svt_plane *ref, int16_t *xsc, int16_t *ysc) {
+    const int pad = SB - 1;
+    const int ox = (int16_t)s->sb_x, oy = (int16_t)s->sb_y;
+    uint64_t  zero_cost = sb_sub_sad(s, ref, 0, 0);
+    *xsc = clip_center(ox, *xsc, pad, ref->width);
+    *ysc = clip_center(oy, *ysc, pad, ref->height);
+    uint64_t hme_cost = sb_sub_sad(s, ref, *xsc, *ysc);
+    uint64_t best     = zero_cost < hme_cost ? zero_cost : hme_cost;
+    if (best == zero_cost) { *xsc = 0; *ysc = 0; }
+}
+
+/* One HME search = window placement + eb_vp9_sad_loop_kernel + result scaling.
+ * level 0: Codec/EbMotionEstimation.c:2872-3056 (hme_level0) and :2717-2870 (single quadrant)
+ * level 1: :3058-3181, level 2: :3183-3308.  At `-asm 0` every branch of the reference ends in
+ * eb_vp9_sad_loop_kernel, so only window geometry differs between the levels. */
+typedef struct {
+    const svt_plane *ref;     /* plane searched (1/16, 1/4 or full) */
+    const uint8_t   *blk;     /* block rows (already subsampled: every other row) */
+    int              blk_stride;
+    int              blk_w, blk_h; /* sb_width, sb_height at that resolution (h is halved inside) */
+    int              ox, oy;  /* SB origin at that resolution */
+    int              pad_w, pad_h;
+} hme_geom_t;
+
+static void hme_search(const hme_geom_t *g, int16_t sa_ox, int16_t sa_oy, int16_t sa_w, int16_t sa_h, int floor16,
+                       uint64_t *best_sad, int16_t *xc, int16_t *yc, int scale) {
+    clip_area(g->ox, &sa_ox, &sa_w, g->pad_w, g->ref->width);
+    clip_area(g->oy, &sa_oy, &sa_h, g->pad_h, g->ref->height);
+    const uint8_t *r = pix(g->ref, g->ox + sa_ox, g->oy + sa_oy);
+    if (floor16 && (sa_w & 15) != 0) sa_w = (int16_t)((sa_w >> 4) << 4); /* :2803-2805 */
+    oracle_sad_loop(g->blk, g->blk_stride, r, g->ref->stride * 2, g->blk_h >> 1, g->blk_w, best_sad, xc, yc,
+                    g->ref->stride, sa_w, sa_h);
+    *best_sad *= 2;
+    *xc = (int16_t)(*xc + sa_ox);
+    *xc = (int16_t)(*xc * scale);
+    *yc = (int16_t)(*yc + sa_oy);
+    *yc = (int16_t)(*yc * scale);
+}
+
+/* width rounding rule of HME level 1 / 2 (:3083-3086, :3211-3214) */
+static int16_t hme_round_w(int16_t w) {
+    return (int16_t)((w < 8) ? 8 : (w & 7) ? w + (w - ((w >> 3) << 3)) : w);
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* full-pel 85-PU search                                                                            */
+/* ---------------------------------------------------------------------------------------------- */
+
+/* 8 rows-subsampled 8x8 SAD: rows 0,2,4,6 (C_DEFAULT/EbComputeSAD_C.c:172-188 Subsad8x8,
+ * C_DEFAULT/EbComputeSAD_C.c:37-59 compute8x4_sad_kernel with doubled strides) */
+static uint32_t sad8x4_sub(const uint8_t *src, int ss, const uint8_t *ref, int rs) {
+    uint32_t sad = 0;
+    for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 8; x++) sad += absdiff(src[2 * y * ss + x], ref[2 * y * rs + x]);
+    return sad;
+}
+
+/* offsets (x,y) of the 16 16x16 blocks in search (z) order: index k -> raster position */
+static void blk16_pos(int k, int *bx, int *by) {
+    int r = 0;
+    for (int i = 0; i < 16; i++)
+        if (tab32x32[i] == k) r = i;
+    *bx = (r & 3) * 16;
+    *by = (r >> 2) * 16;
+}
+
+/* One integer search position for all 85 PUs.
+ * 8-aligned columns: eb_vp9_get_eight_horizontal_search_point_results_all85_p_us_c (Codec/EbMotionEstimation.c:90-354)
+ *   -> C_DEFAULT/EbComputeSAD_C.c:193-375 (16x16 SAD kept in uint16 before doubling).
+ * tail columns (search_area_width & 7): get_search_point_results (:662-946) -> C_DEFAULT/EbMeSadCalculation_C.c:16-99.
+ * Both visit positions in raster order with strict '<', so per-PU the result is "first minimum in raster
+ * order" -- except that the tail path has an address bug, reproduced below. */
+static void fullpel_position(me_sb_t *s, int list, const uint8_t *ref_tl, int rs, int xi, int yi, int x_mv_int,
+                             int y_mv_int, int tail) {
+    uint32_t *bs = s->best_sad[list], *bm = s->best_mv[list];
+    /* curr_mv = (y << 18) | (uint16)(x << 2) (:108-110, :683-685) */
+    uint32_t mv = (((uint32_t)(uint16_t)y_mv_int) << 18) | (uint16_t)((uint16_t)x_mv_int << 2);
+    uint32_t sad16[16];
+    for (int k = 0; k < 16; k++) {
+        int bx, by;
+        blk16_pos(k, &bx, &by);
+        int rbx = bx;
+        /* [quirk] tail path: "16x16 : 12" advances the reference pointer by 16 twice (:855-856), so blocks
+           12 and 13 are compared against the reference 16 columns further right. */
+        if (tail && (k == 12 || k == 13)) rbx += 16;
+        const uint8_t *sp = s->src + by * s->src_stride + bx;
+        const uint8_t *rp = ref_tl + (ptrdiff_t)(yi + by) * rs + xi + rbx;
+        uint32_t       s0 = sad8x4_sub(sp, s->src_stride, rp, rs);
+        uint32_t       s1 = sad8x4_sub(sp + 8, s->src_stride, rp + 8, rs);
+        uint32_t       s2 = sad8x4_sub(sp + 8 * s->src_stride, s->src_stride, rp + 8 * rs, rs);
+        uint32_t       s3 = sad8x4_sub(sp + 8 * s->src_stride + 8, s->src_stride, rp + 8 * rs + 8, rs);
+        uint32_t       q[4] = {s0, s1, s2, s3};
+        for (int i = 0; i < 4; i++) {
+            if (2 * q[i] < bs[21 + 4 * k + i]) {
+                bs[21 + 4 * k + i] = 2 * q[i];
+                bm[21 + 4 * k + i] = mv;
+            }
+        }
+        uint32_t t = s0 + s1 + s2 + s3;
+        if (!tail) t = (uint16_t)t; /* uint16 storage in the 8-point path (EbComputeSAD_C.c:201,276) */
+        sad16[k] = t;
+        if (2 * t < bs[5 + k]) {
+            bs[5 + k] = 2 * t;
+            bm[5 + k] = mv;
+        }
+    }
+    uint32_t s32[4], s64 = 0;
+    for (int j = 0; j < 4; j++) {
+        s32[j] = sad16[4 * j] + sad16[4 * j + 1] + sad16[4 * j + 2] + sad16[4 * j + 3];
+        if (2 * s32[j] < bs[1 + j]) {
+            bs[1 + j] = 2 * s32[j];
+            bm[1 + j] = mv;
+        }
+        s64 += s32[j];
+    }
+    if (2 * s64 < bs[0]) {
+        bs[0] = 2 * s64;
+        bm[0] = mv;
+    }
+}
+
+/* Codec/EbMotionEstimation.c:951-980 full_pel_search_sb.  ref_tl = top-left of the search region. */
+static void full_pel_search_sb(me_sb_t *s, int list, const uint8_t *ref_tl, int rs) {
+    int w = s->sa_w[list], h = s->sa_h[list];
+    int w8 = w - (w & 7);
+    for (int yi = 0; yi < h; yi++) {
+        for (int xi = 0; xi < w8; xi++)
+            fullpel_position(s, list, ref_tl, rs, xi, yi, xi + s->sa_origin_x[list], yi + s->sa_origin_y[list], 0);
+        for (int xi = w8; xi < w; xi++)
+            fullpel_position(s, list, ref_tl, rs, xi, yi, xi + s->sa_origin_x[list], yi + s->sa_origin_y[list], 1);
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* half-pel planes                                                                                  */
+/* ---------------------------------------------------------------------------------------------- */
+static inline uint8_t clip8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+/* C_DEFAULT/EbAvcStyleMcp_C.c:11-73, frac_pos = 2: taps {-2,18,18,-2}, (sum+16)>>5, clip */
+static inline uint8_t tap4(int a, int b, int c, int d) { return clip8((-2 * a + 18 * b + 18 * c - 2 * d + 16) >> 5); }
+
+/* Codec/EbMotionEstimation.c:992-1070 interpolate_search_region_avc, re-expressed in natural
+ * coordinates (see me_sb_t).  The reference fills b over x in [-1.5 .. ), y in [-2 .. H+2); h over
+ * x in [-1, ..), y in [-1.5, ..); j from b.  We compute the same samples for every position the
+ * refinement stages can touch: x,y in [-2, W+1] x [-2, H+1] (guard band 2). */
+static void interpolate_region(me_sb_t *s, int list, const uint8_t *tl, int rs) {
+    int W = s->sa_w[list] + SB - 1, H = s->sa_h[list] + SB - 1;
+    int st = s->hp_stride;
+    uint8_t *B = s->hb[list], *Hh = s->hh[list], *J = s->hj[list];
+    /* B(x,y) for x in [-2, W+1], y in [-2, H+1]; needs integer samples x-1..x+2 */
+    for (int y = -2; y < H + 2; y++)
+        for (int x = -2; x < W + 2; x++) {
+            const uint8_t *r = tl + (ptrdiff_t)y * rs + x;
+            B[(y + 2) * st + x + 2] = tap4(r[-1], r[0], r[1], r[2]);
+        }
+    for (int y = -2; y < H + 2; y++)
+        for (int x = -2; x < W + 2; x++) {
+            const uint8_t *r = tl + (ptrdiff_t)y * rs + x;
+            Hh[(y + 2) * st + x + 2] = tap4(r[-rs], r[0], r[rs], r[2 * rs]);
+        }
+    /* J(x,y) = vertical filter over B(x, y-1..y+2); B rows outside [-2, H+1] are not available in the
+       reference either (posb has rows -2..H+1), so J is defined for y in [-1, H-1]. */
+    for (int y = -1; y < H; y++)
+        for (int x = -2; x < W + 2; x++) {
+            const uint8_t *b = &B[(y + 2) * st + x + 2];
+            J[(y + 2) * st + x + 2] = tap4(b[-st], b[0], b[st], b[2 * st]);
+        }
+}
+
+/* plane ids for the refinement tables */
+enum { PF = 0, PB = 1, PH = 2, PJ = 3 };
+typedef struct { const uint8_t *p; int stride; } pl_t;
+
+/* sample pointer of plane `id` at natural position (x,y) relative to the search-region top-left */
+static pl_t plane_at(const me_sb_t *s, int list, const uint8_t *tl, int rs, int id, int x, int y) {
+    pl_t r;
+    if (id == PF) { r.p = tl + (ptrdiff_t)y * rs + x; r.stride = rs; return r; }
+    const uint8_t *base = id == PB ? s->hb[list] : id == PH ? s->hh[list] : s->hj[list];
+    r.p      = base + (y + 2) * s->hp_stride + x + 2;
+    r.stride = s->hp_stride;
+    return r;
+}
+
+/* distortion of one candidate block per fractional_search_method */
+static uint64_t cand_dist(const me_sb_t *s, const uint8_t *src, int ss, pl_t c, int w, int h) {
+    int m = s->p->fractional_search_method;
+    if (m == SVT_SSD_SEARCH) { /* C_DEFAULT/EbPictureOperators_C.c:337-356 */
+        uint64_t d = 0;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int e = (int)src[y * ss + x] - (int)c.p[y * c.stride + x];
+                d += (uint64_t)(e * e);
+            }
+        return d;
+    }
+    if (m == SVT_SUB_SAD_SEARCH) return (uint64_t)(oracle_sad_nxm(src, ss << 1, c.p, c.stride << 1, h >> 1, w)) << 1;
+    return oracle_sad_nxm(src, ss, c.p, c.stride, h, w);
+}
+
+/* Codec/EbMotionEstimation.c:1076-1559 pu_half_pel_refinement.
+ * Positions in test order L,R,T,B,TL,TR,BR,BL; direction codes (:34-41). */
+enum { D_TL = 0, D_T = 1, D_TR = 2, D_R = 3, D_BR = 4, D_B = 5, D_BL = 6, D_L = 7 };
+static void pu_half_pel(me_sb_t *s, int list, const uint8_t *tl, int rs, int pu_x, int pu_y, int w, int h, int idx) {
+    uint32_t *best_sad = &s->best_sad[list][idx], *best_mv = &s->best_mv[list][idx], *best_ssd = &s->best_ssd[list][idx];
+    const uint8_t *src = s->src + pu_y * s->src_stride + pu_x;
+    int ss = s->src_stride;
+    int16_t xm = mvx(*best_mv), ym = mvy(*best_mv);
+    int xs = (int16_t)((xm >> 2) - s->sa_origin_x[list]) + pu_x;
+    int ys = (int16_t)((ym >> 2) - s->sa_origin_y[list]) + pu_y;
+    /* candidate = (plane, dx, dy) in natural coords relative to integer position (xs,ys) */
+    static const int8_t cand[8][3] = {{PB, -1, 0}, {PB, 0, 0}, {PH, 0, -1}, {PH, 0, 0},
+                                      {PJ, -1, -1}, {PJ, 0, -1}, {PJ, 0, 0}, {PJ, -1, 0}};
+    static const int8_t dmv[8][2]  = {{-2, 0}, {2, 0}, {0, -2}, {0, 2}, {-2, -2}, {2, -2}, {2, 2}, {-2, 2}};
+    const int ssd_mode = s->p->fractional_search_method == SVT_SSD_SEARCH;
+    if (ssd_mode) *best_ssd = (uint32_t)cand_dist(s, src, ss, plane_at(s, list, tl, rs, PF, xs, ys), w, h);
+    uint64_t d[8];
+    for (int i = 0; i < 8; i++) {
+        pl_t c = plane_at(s, list, tl, rs, cand[i][0], xs + cand[i][1], ys + cand[i][2]);
+        d[i]   = cand_dist(s, src, ss, c, w, h);
+        if (ssd_mode) {
+            if (d[i] < *best_ssd) {
+                *best_sad = oracle_sad_nxm(src, ss, c.p, c.stride, h, w);
+                *best_mv  = pack_mv(xm + dmv[i][0], ym + dmv[i][1]);
+                *best_ssd = (uint32_t)d[i];
+            }
+        } else if (d[i] < *best_sad) {
+            *best_sad = (uint32_t)d[i];
+            *best_mv  = pack_mv(xm + dmv[i][0], ym + dmv[i][1]);
+        }
+    }
+    /* direction of the best half position, tie order L,R,T,B,TL,TR,BL,BR (:1531-1556) */
+    uint64_t m = d[0];
+    for (int i = 1; i < 8; i++)
+        if (d[i] < m) m = d[i];
+    uint8_t dir;
+    if (m == d[0]) dir = D_L;
+    else if (m == d[1]) dir = D_R;
+    else if (m == d[2]) dir = D_T;
+    else if (m == d[3]) dir = D_B;
+    else if (m == d[4]) dir = D_TL;
+    else if (m == d[5]) dir = D_TR;
+    else if (m == d[7]) dir = D_BL;
+    else dir = D_BR;
+    s->dir[idx] = dir;
+}
+
+/* Quarter-pel candidates: average of two planes.  Table = set_quarter_pel_refinement_inputs_on_the_fly
+ * (Codec/EbMotionEstimation.c:2290-2465) translated to natural coordinates relative to the integer
+ * position P = ((mv+2)>>2): method = (y_mv&2) + ((x_mv&2)>>1); 8 positions L,R,T,B,TL,TR,BR,BL;
+ * each entry {plane1,dx1,dy1, plane2,dx2,dy2}. */
+static const int8_t qtab[4][8][6] = {
+    /* EB_QUARTER_IN_FULL */
+    {{PB, -1, 0, PF, 0, 0}, {PF, 0, 0, PB, 0, 0}, {PH, 0, -1, PF, 0, 0}, {PF, 0, 0, PH, 0, 0},
+     {PB, -1, 0, PH, 0, -1}, {PH, 0, -1, PB, 0, 0}, {PH, 0, 0, PB, 0, 0}, {PB, -1, 0, PH, 0, 0}},
+    /* EB_QUARTER_IN_HALF_HORIZONTAL */
+    {{PF, -1, 0, PB, -1, 0}, {PB, -1, 0, PF, 0, 0}, {PJ, -1, -1, PB, -1, 0}, {PB, -1, 0, PJ, -1, 0},
+     {PH, -1, -1, PB, -1, 0}, {PB, -1, 0, PH, 0, -1}, {PB, -1, 0, PH, 0, 0}, {PH, -1, 0, PB, -1, 0}},
+    /* EB_QUARTER_IN_HALF_VERTICAL */
+    {{PJ, -1, -1, PH, 0, -1}, {PH, 0, -1, PJ, 0, -1}, {PF, 0, -1, PH, 0, -1}, {PH, 0, -1, PF, 0, 0},
+     {PB, -1, -1, PH, 0, -1}, {PH, 0, -1, PB, 0, -1}, {PH, 0, -1, PB, 0, 0}, {PB, -1, 0, PH, 0, -1}},
+    /* EB_QUARTER_IN_HALF_DIAGONAL */
+    {{PH, -1, -1, PJ, -1, -1}, {PJ, -1, -1, PH, 0, -1}, {PB, -1, -1, PJ, -1, -1}, {PJ, -1, -1, PB, -1, 0},
+     {PH, -1, -1, PB, -1, -1}, {PB, -1, -1, PH, 0, -1}, {PB, -1, 0, PH, 0, -1}, {PH, -1, -1, PB, -1, 0}}};
+
+/* Codec/EbMotionEstimation.c:1731-2283 pu_quarter_pel_refinement_on_the_fly */
+static void pu_quarter_pel(me_sb_t *s, int list, const uint8_t *tl, int rs, int pu_x, int pu_y, int w, int h, int idx) {
+    uint32_t *best_sad = &s->best_sad[list][idx], *best_mv = &s->best_mv[list][idx], *best_ssd = &s->best_ssd[list][idx];
+    /* [quirk] source comes from the 64x64 copy sb_buffer (stride 64) -- same samples as sb_src_ptr */
+    const uint8_t *src = s->src + pu_y * s->src_stride + pu_x;
+    int ss = s->src_stride;
+    int16_t xm = mvx(*best_mv), ym = mvy(*best_mv);
+    int xs = (int16_t)(((xm + 2) >> 2) - s->sa_origin_x[list]) + pu_x;
+    int ys = (int16_t)(((ym + 2) >> 2) - s->sa_origin_y[list]) + pu_y;
+    int method = (ym & 2) + ((xm & 2) >> 1);
+    int dir = s->dir[idx];
+    int in_half = method != 0;
+    /* validity of the 8 quarter positions given the half-pel direction (:1761-1796) */
+    int v_tl, v_t, v_tr, v_r, v_br, v_b, v_bl, v_l;
+    if (in_half) {
+        v_tl = dir == D_R || dir == D_BR || dir == D_B;
+        v_t  = dir == D_BR || dir == D_B || dir == D_BL;
+        v_tr = dir == D_B || dir == D_BL || dir == D_L;
+        v_r  = dir == D_BL || dir == D_L || dir == D_TL;
+        v_br = dir == D_L || dir == D_TL || dir == D_T;
+        v_b  = dir == D_TL || dir == D_T || dir == D_TR;
+        v_bl = dir == D_T || dir == D_TR || dir == D_R;
+        v_l  = dir == D_TR || dir == D_R || dir == D_BR;
+    } else {
+        v_tl = dir == D_L || dir == D_TL || dir == D_T;
+        v_t  = dir == D_TL || dir == D_T || dir == D_TR;
+        v_tr = dir == D_T || dir == D_TR || dir == D_R;
+        v_r  = dir == D_TR || dir == D_R || dir == D_BR;
+        v_br = dir == D_R || dir == D_BR || dir == D_B;
+        v_b  = dir == D_BR || dir == D_B || dir == D_BL;
+        v_bl = dir == D_B || dir == D_BL || dir == D_L;
+        v_l  = dir == D_BL || dir == D_L || dir == D_TL;
+    }
+    const int valid[8] = {v_l, v_r, v_t, v_b, v_tl, v_tr, v_br, v_bl};
+    static const int8_t dmv[8][2] = {{-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
+    const int m = s->p->fractional_search_method;
+    for (int i = 0; i < 8; i++) {
+        if (!valid[i]) continue;
+        const int8_t *e = qtab[method][i];
+        pl_t a = plane_at(s, list, tl, rs, e[0], xs + e[1], ys + e[2]);
+        pl_t b = plane_at(s, list, tl, rs, e[3], xs + e[4], ys + e[5]);
+        uint64_t dist;
+        if (m == SVT_SSD_SEARCH) { /* eb_vp9_combined_averaging_ssd :1708-1725 */
+            uint32_t ssd = 0;
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++) {
+                    int avg = (a.p[y * a.stride + x] + b.p[y * b.stride + x] + 1) >> 1;
+                    int d   = (int)src[y * ss + x] - avg;
+                    ssd += (uint32_t)(d * d);
+                }
+            dist = ssd;
+            if (dist < *best_ssd) {
+                *best_sad = oracle_avg_sad(src, ss, a.p, a.stride, b.p, b.stride, h, w);
+                *best_mv  = pack_mv(xm + dmv[i][0], ym + dmv[i][1]);
+                *best_ssd = (uint32_t)dist;
+            }
+            continue;
+        }
+        if (m == SVT_SUB_SAD_SEARCH)
+            dist = (uint64_t)oracle_avg_sad(src, ss << 1, a.p, a.stride << 1, b.p, b.stride << 1, h >> 1, w) << 1;
+        else
+            dist = oracle_avg_sad(src, ss, a.p, a.stride, b.p, b.stride, h, w);
+        if (dist < *best_sad) {
+            *best_sad = (uint32_t)dist;
+            *best_mv  = pack_mv(xm + dmv[i][0], ym + dmv[i][1]);
+        }
+    }
+}
+
+/* Codec/EbMotionEstimation.c:3839-4258 su_pel_enable */
+static void su_pel_enable(const me_sb_t *s, int list, int *en32, int *en16, int *en8) {
+    const uint32_t *bs = s->best_sad[list], *bm = s->best_mv[list];
+    int sx = 0, sy = 0;
+    uint32_t ssum = 0;
+    for (int i = 1; i <= 4; i++) { sx += mvx(bm[i]); sy += mvy(bm[i]); ssum += bs[i]; }
+    uint32_t ax = (uint32_t)(sx >> 2), ay = (uint32_t)(sy >> 2);
+    uint32_t mag32 = ax * ax + ay * ay, sad32 = ssum >> 2;
+    sx = sy = 0; ssum = 0;
+    for (int i = 5; i <= 20; i++) { sx += mvx(bm[i]); sy += mvy(bm[i]); ssum += bs[i]; }
+    ax = (uint32_t)(sx >> 4); ay = (uint32_t)(sy >> 4);
+    uint32_t mag16 = ax * ax + ay * ay, sad16 = ssum >> 4;
+    sx = sy = 0; ssum = 0;
+    for (int i = 21; i < 85; i++) { sx += mvx(bm[i]); sy += mvy(bm[i]); ssum += bs[i]; }
+    ax = (uint32_t)(sx >> 6); ay = (uint32_t)(sy >> 6);
+    uint32_t mag8 = ax * ax + ay * ay, sad8 = ssum >> 6;
+    /* class = 2*(mag >= thr^2) + (sad >= limit); per temporal layer enable tables */
+    static const int thr[4]      = {48, 32, 80, 48};
+    static const int t32[4][4]   = {{1, 0, 1, 0}, {1, 0, 1, 1}, {1, 0, 1, 0}, {1, 1, 1, 0}};
+    static const int t16[4][4]   = {{0, 1, 0, 1}, {0, 1, 0, 1}, {0, 1, 0, 1}, {0, 1, 0, 1}};
+    static const int t8[4][4]    = {{0, 1, 0, 1}, {0, 1, 0, 1}, {0, 1, 0, 1}, {0, 1, 0, 0}};
+    int tl = s->p->temporal_layer_index > 3 ? 3 : s->p->temporal_layer_index;
+    uint32_t t2 = (uint32_t)(thr[tl] * thr[tl]);
+    *en32 = t32[tl][2 * !(mag32 < t2) + !(sad32 < 32 * 32 * 6)];
+    *en16 = t16[tl][2 * !(mag16 < t2) + !(sad16 < 16 * 16 * 2)];
+    *en8  = t8[tl][2 * !(mag8 < t2) + !(sad8 < 8 * 8 * 2)];
+}
+
+/* PU geometry in RASTER order within each size class (pu_search_index_map, :70-81) */
+static void pu_geom(int pu, int *x, int *y, int *w) {
+    if (pu == 0) { *x = 0; *y = 0; *w = 64; }
+    else if (pu < 5) { *x = ((pu - 1) & 1) * 32; *y = ((pu - 1) >> 1) * 32; *w = 32; }
+    else if (pu < 21) { *x = ((pu - 5) & 3) * 16; *y = ((pu - 5) >> 2) * 16; *w = 16; }
+    else { *x = ((pu - 21) & 7) * 8; *y = ((pu - 21) >> 3) * 8; *w = 8; }
+}
+static int pu_nidx(int pu) { return pu > 20 ? tab8x8[pu - 21] + 21 : pu > 4 ? tab32x32[pu - 5] + 5 : pu; }
+
+/* Codec/EbMotionEstimation.c:1565-1702 half_pel_search_sb + :2471-2715 quarter_pel_search_sb */
+static void subpel_search_sb(me_sb_t *s, int list, const uint8_t *tl, int rs, int en32, int en16, int en8, int enq) {
+    const int dis8 = s->p->cu8x8_mode == 1;
+    en16 = en16 && s->p->cu16x16_mode == 0;
+    /* half-pel */
+    if (s->p->fractional_search64x64) pu_half_pel(s, list, tl, rs, 0, 0, 64, 64, 0);
+    for (int pu = 1; pu < 85; pu++) {
+        int x, y, w;
+        pu_geom(pu, &x, &y, &w);
+        if ((w == 32 && !en32) || (w == 16 && !en16) || (w == 8 && (!en8 || dis8))) continue;
+        pu_half_pel(s, list, tl, rs, x, y, w, w, pu_nidx(pu));
+    }
+    /* quarter-pel.  [quirk] the 64x64 PU is refined with a 32x32 block (:2525-2526) */
+    if (s->p->fractional_search64x64) pu_quarter_pel(s, list, tl, rs, 0, 0, 32, 32, 0);
+    for (int pu = 1; pu < 85; pu++) {
+        int x, y, w;
+        pu_geom(pu, &x, &y, &w);
+        if (!enq) continue;
+        if ((w == 32 && !en32) || (w == 16 && !en16) || (w == 8 && (!en8 || dis8))) continue;
+        pu_quarter_pel(s, list, tl, rs, x, y, w, w, pu_nidx(pu));
+    }
+}
+
+/* Prediction block of one list at its best (quarter-pel) MV for bi-pred:
+ * select_buffer :3310-3356 / quarter_pel_compensation :3358-3453 (natural coordinates). */
+static pl_t bipred_pred(const me_sb_t *s, int list, const uint8_t *tl, int rs, uint32_t mv, int pu_x, int pu_y, int w,
+                        int h, uint8_t *tmp) {
+    int16_t px = mvx(mv), py = mvy(mv);
+    int xi = (int16_t)(px >> 2) - s->sa_origin_x[list] + pu_x;
+    int yi = (int16_t)(py >> 2) - s->sa_origin_y[list] + pu_y;
+    int frac = ((uint8_t)px & 3) + (((uint8_t)py & 3) << 2);
+    switch (frac) {
+    case 0: return plane_at(s, list, tl, rs, PF, xi, yi);
+    case 2: return plane_at(s, list, tl, rs, PB, xi, yi);
+    case 8: return plane_at(s, list, tl, rs, PH, xi, yi);
+    case 10: return plane_at(s, list, tl, rs, PJ, xi, yi);
+    default: break;
+    }
+    static const int8_t t[16][6] = {
+        {0}, {PF, 0, 0, PB, 0, 0}, {0}, {PB, 0, 0, PF, 1, 0}, {PF, 0, 0, PH, 0, 0}, {PB, 0, 0, PH, 0, 0},
+        {PB, 0, 0, PJ, 0, 0}, {PB, 0, 0, PH, 1, 0}, {0}, {PH, 0, 0, PJ, 0, 0}, {0}, {PJ, 0, 0, PH, 1, 0},
+        {PH, 0, 0, PF, 0, 1}, {PH, 0, 0, PB, 0, 1}, {PJ, 0, 0, PB, 0, 1}, {PH, 1, 0, PB, 0, 1}};
+    const int8_t *e = t[frac];
+    pl_t a = plane_at(s, list, tl, rs, e[0], xi + e[1], yi + e[2]);
+    pl_t b = plane_at(s, list, tl, rs, e[3], xi + e[4], yi + e[5]);
+    /* eb_vp9_picture_average_kernel, C_DEFAULT/EbPictureOperators_C.c:12-22 */
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) tmp[y * SB + x] = (uint8_t)((a.p[y * a.stride + x] + b.p[y * b.stride + x] + 1) >> 1);
+    pl_t r = {tmp, SB};
+    return r;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* motion_estimate_sb, Codec/EbMotionEstimation.c:4524-5305                                         */
+/* ---------------------------------------------------------------------------------------------- */
+static int sb_alloc(me_sb_t *s) {
+    int W = 127 + SB - 1 + 4 + 8, H = 127 + SB - 1 + 4;
+    s->hp_stride = W;
+    s->hp_rows   = H;
+    for (int l = 0; l < 2; l++) {
+        s->hb[l] = (uint8_t *)calloc((size_t)W * H, 1);
+        s->hh[l] = (uint8_t *)calloc((size_t)W * H, 1);
+        s->hj[l] = (uint8_t *)calloc((size_t)W * H, 1);
+        if (!s->hb[l] || !s->hh[l] || !s->hj[l]) return -1;
+    }
+    return 0;
+}
+static void sb_free(me_sb_t *s) {
+    for (int l = 0; l < 2; l++) { free(s->hb[l]); free(s->hh[l]); free(s->hj[l]); }
+}
+
+static void me_sb(me_sb_t *s, svt_me_pu_result *out, uint32_t *rcme) {
+    const svt_me_params *p = s->p;
+    const int nlist = p->num_ref_lists;
+    const int NW = p->number_hme_search_region_in_width, NH = p->number_hme_search_region_in_height;
+    const uint8_t *region_tl[2] = {0, 0};
+    int            region_rs[2] = {0, 0};
+    /* HME state that survives across the list loop in the reference (:4561-4577) */
+    int16_t  xl0[2][2], yl0[2][2], xl1[2][2], yl1[2][2], xl2[2][2], yl2[2][2];
+    uint64_t sl0[2][2], sl1[2][2], sl2[2][2];
+    memset(xl0, 0, sizeof xl0); memset(yl0, 0, sizeof yl0); memset(xl1, 0, sizeof xl1);
+    memset(yl1, 0, sizeof yl1); memset(xl2, 0, sizeof xl2); memset(yl2, 0, sizeof yl2);
+    memset(sl0, 0, sizeof sl0); memset(sl1, 0, sizeof sl1); memset(sl2, 0, sizeof sl2);
+    int      rw = 0, rh = 0; /* search_region_number_in_width / _height, NOT reset per list [quirk] */
+    int16_t  x_hme_c = 0, y_hme_c = 0;
+    int16_t  xsc = 0, ysc = 0;
+
+    /* load the decimated SB copies (Codec/EbMotionEstimationProcess.c:1003-1035) */
+    if (p->enable_hme_level_1_flag)
+        for (int r = 0; r < (s->sb_h >> 1); r++)
+            memcpy(&s->quarter_sb[r * 32], pix(&s->cur->quarter, s->sb_x >> 1, (s->sb_y >> 1) + r), (size_t)(s->sb_w >> 1));
+    if (p->enable_hme_level_0_flag) {
+        uint8_t *l = s->sixteenth_sb;
+        for (int r = 0; r < (s->sb_h >> 2); r += 2) {
+            memcpy(l, pix(&s->cur->sixteenth, s->sb_x >> 2, (s->sb_y >> 2) + r), (size_t)(s->sb_w >> 2));
+            l += 16;
+        }
+    }
+
+    for (int list = 0; list < nlist; list++) {
+        const svt_plane *rf = &s->ref[list]->full, *rq = &s->ref[list]->quarter, *r16 = &s->ref[list]->sixteenth;
+        if (p->temporal_layer_index > 0 || list == 0) {
+            test_search_area_bounds(s, rf, list, &xsc, &ysc);
+            if (p->enable_hme_flag && s->sb_h == SB) {
+                while (rh < NH) {
+                    while (rw < NW) {
+                        xl0[rw][rh] = (int16_t)(xsc >> 2); yl0[rw][rh] = (int16_t)(ysc >> 2);
+                        xl1[rw][rh] = (int16_t)(xsc >> 1); yl1[rw][rh] = (int16_t)(ysc >> 1);
+                        xl2[rw][rh] = xsc; yl2[rw][rh] = ysc;
+                        rw++;
+                    }
+                    rw = 0;
+                    rh++;
+                }
+                const int mult = hme_l0_mult[p->hierarchical_levels][p->temporal_layer_index];
+                if (p->enable_hme_level_0_flag) {
+                    hme_geom_t g = {r16, s->sixteenth_sb, 16, s->sb_w >> 2, s->sb_h >> 2, (int16_t)(s->sb_x >> 2),
+                                    (int16_t)(s->sb_y >> 2), r16->origin_x - 1, r16->origin_y - 1};
+                    if (p->single_hme_quadrant && !p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag) {
+                        rh = 0; rw = 0;
+                        int16_t w = (int16_t)((p->hme_level0_total_search_area_width * mult) / 100);
+                        int16_t h = (int16_t)((p->hme_level0_total_search_area_height * mult) / 100);
+                        int16_t ox = (int16_t)(-(int16_t)(w >> 1) + (int16_t)(xsc >> 2));
+                        int16_t oy = (int16_t)(-(int16_t)(h >> 1) + (int16_t)(ysc >> 2));
+                        hme_search(&g, ox, oy, w, h, 1, &sl0[0][0], &xl0[0][0], &yl0[0][0], 4);
+                    } else {
+                        rh = 0; rw = 0;
+                        while (rh < NH) {
+                            while (rw < NW) {
+                                int16_t w = (int16_t)((p->hme_level0_search_area_in_width_array[rw] * mult) / 100);
+                                int16_t h = (int16_t)((p->hme_level0_search_area_in_height_array[rh] * mult) / 100);
+                                int16_t dx = (int16_t)(xsc >> 2), dy = (int16_t)(ysc >> 2);
+                                for (int k = rw; k > 0; k--)
+                                    dx = (int16_t)(dx + (int16_t)((p->hme_level0_search_area_in_width_array[k - 1] * mult) / 100));
+                                for (int k = rh; k > 0; k--)
+                                    dy = (int16_t)(dy + (int16_t)((p->hme_level0_search_area_in_height_array[k - 1] * mult) / 100));
+                                int16_t ox = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_width * mult) / 100) >> 1) + dx);
+                                int16_t oy = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_height * mult) / 100) >> 1) + dy);
+                                hme_search(&g, ox, oy, w, h, 0, &sl0[rw][rh], &xl0[rw][rh], &yl0[rw][rh], 4);
+                                rw++;
+                            }
+                            rw = 0;
+                            rh++;
+                        }
+                    }
+                }
+                if (p->enable_hme_level_1_flag) {
+                    hme_geom_t g = {rq, s->quarter_sb, 32 * 2, s->sb_w >> 1, s->sb_h >> 1, (int16_t)(s->sb_x >> 1),
+                                    (int16_t)(s->sb_y >> 1), rq->origin_x - 1, rq->origin_y - 1};
+                    rh = 0; rw = 0;
+                    while (rh < NH) {
+                        while (rw < NW) {
+                            int16_t w = hme_round_w((int16_t)p->hme_level1_search_area_in_width_array[rw]);
+                            int16_t h = (int16_t)p->hme_level1_search_area_in_height_array[rh];
+                            int16_t ox = (int16_t)(-(w >> 1) + (int16_t)(xl0[rw][rh] >> 1));
+                            int16_t oy = (int16_t)(-(h >> 1) + (int16_t)(yl0[rw][rh] >> 1));
+                            hme_search(&g, ox, oy, w, h, 0, &sl1[rw][rh], &xl1[rw][rh], &yl1[rw][rh], 2);
+                            rw++;
+                        }
+                        rw = 0;
+                        rh++;
+                    }
+                }
+                if (p->enable_hme_level_2_flag) {
+                    hme_geom_t g = {rf, s->src, s->src_stride * 2, s->sb_w, s->sb_h, (int16_t)s->sb_x, (int16_t)s->sb_y,
+                                    SB - 1, SB - 1};
+                    rh = 0; rw = 0;
+                    while (rh < NH) {
+                        while (rw < NW) {
+                            int16_t w = hme_round_w((int16_t)p->hme_level2_search_area_in_width_array[rw]);
+                            int16_t h = (int16_t)p->hme_level2_search_area_in_height_array[rh];
+                            int16_t ox = (int16_t)(-(w >> 1) + xl1[rw][rh]);
+                            int16_t oy = (int16_t)(-(h >> 1) + yl1[rw][rh]);
+                            hme_search(&g, ox, oy, w, h, 0, &sl2[rw][rh], &xl2[rw][rh], &yl2[rw][rh], 1);
+                            rw++;
+                        }
+                        rw = 0;
+                        rh++;
+                    }
+                }
+                /* pick the best quadrant (:4841-4995) */
+                uint64_t hme_sad = 0;
+                if (p->enable_hme_level_0_flag && !p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag) {
+                    x_hme_c = xl0[0][0]; y_hme_c = yl0[0][0]; hme_sad = sl0[0][0];
+                    if (!p->single_hme_quadrant) {
+                        rw = 1; rh = 0;
+                        while (rh < NH) {
+                            while (rw < NW) {
+                                if (sl0[rw][rh] < hme_sad) { x_hme_c = xl0[rw][rh]; y_hme_c = yl0[rw][rh]; hme_sad = sl0[rw][rh]; }
+                                rw++;
+                            }
+                            rw = 0;
+                            rh++;
+                        }
+                    }
+                }
+                if (p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag) {
+                    x_hme_c = xl1[0][0]; y_hme_c = yl1[0][0]; hme_sad = sl1[0][0];
+                    rw = 1; rh = 0;
+                    while (rh < NH) {
+                        while (rw < NW) {
+                            if (sl1[rw][rh] < hme_sad) { x_hme_c = xl1[rw][rh]; y_hme_c = yl1[rw][rh]; hme_sad = sl1[rw][rh]; }
+                            rw++;
+                        }
+                        rw = 0;
+                        rh++;
+                    }
+                }
+                if (p->enable_hme_level_2_flag) {
+                    x_hme_c = xl2[0][0]; y_hme_c = yl2[0][0]; hme_sad = sl2[0][0];
+                    rw = 1; rh = 0;
+                    while (rh < NH) {
+                        while (rw < NW) {
+                            if (sl2[rw][rh] < hme_sad) { x_hme_c = xl2[rw][rh]; y_hme_c = yl2[rw][rh]; hme_sad = sl2[rw][rh]; }
+                            rw++;
+                        }
+                        rw = 0;
+                        rh++;
+                    }
+                    int nq = NW, tot = NH * NW;
+                    if (p->same_ref_poc && list == 1 && tot > 1) {
+                        /* [quirk] selection sort indexed [q / nq][q % nq] on arrays laid out [width][height];
+                           the second-best quadrant [0][1] becomes the centre (:4952-4994) */
+                        for (int q = 0; q < tot - 1; q++)
+                            for (int n = q + 1; n < tot; n++)
+                                if (sl2[q / nq][q % nq] > sl2[n / nq][n % nq]) {
+                                    int16_t tx = xl2[q / nq][q % nq], ty = yl2[q / nq][q % nq];
+                                    uint64_t td = sl2[q / nq][q % nq];
+                                    xl2[q / nq][q % nq] = xl2[n / nq][n % nq];
+                                    yl2[q / nq][q % nq] = yl2[n / nq][n % nq];
+                                    sl2[q / nq][q % nq] = sl2[n / nq][n % nq];
+                                    xl2[n / nq][n % nq] = tx; yl2[n / nq][n % nq] = ty; sl2[n / nq][n % nq] = td;
+                                }
+                        x_hme_c = xl2[0][1]; y_hme_c = yl2[0][1];
+                    }
+                }
+                xsc = x_hme_c; ysc = y_hme_c;
+            }
+        } else {
+            xsc = 0; ysc = 0;
+        }
+
+        int16_t saw = (int16_t)(p->search_area_width < 127 ? p->search_area_width : 127);
+        int16_t sah = (int16_t)(p->search_area_height < 127 ? p->search_area_height : 127);
+        if (xsc != 0 || ysc != 0) check_zero_zero_center(s, rf, &xsc, &ysc);
+        int16_t sox = (int16_t)(xsc - (saw >> 1)), soy = (int16_t)(ysc - (sah >> 1));
+        clip_area((int16_t)s->sb_x, &sox, &saw, SB - 1, s->pic_w);
+        clip_area((int16_t)s->sb_y, &soy, &sah, SB - 1, s->pic_h);
+        s->sa_origin_x[list] = sox; s->sa_origin_y[list] = soy;
+        s->sa_w[list] = saw; s->sa_h[list] = sah;
+        const uint8_t *tl = pix(rf, s->sb_x + sox, s->sb_y + soy);
+        region_tl[list] = tl; region_rs[list] = rf->stride;
+
+        for (int i = 0; i < 85; i++) s->best_sad[list][i] = MAX_SAD_VALUE;
+        full_pel_search_sb(s, list, tl, rf->stride);
+
+        int en32 = 0, en16 = 0, en8 = 0, enq = 0;
+        if (p->fractional_search_model == 0) { en32 = en16 = en8 = enq = 1; }
+        else if (p->fractional_search_model == 1) { su_pel_enable(s, list, &en32, &en16, &en8); enq = 1; }
+        if (en32 || en16 || en8 || enq) {
+            interpolate_region(s, list, tl, rf->stride);
+            subpel_search_sb(s, list, tl, rf->stride, en32, en16, en8, enq);
+        }
+    }
+
+    /* bi-pred + candidate ordering (:5186-5293) */
+    uint8_t tmp0[SB * SB], tmp1[SB * SB];
+    for (int pu = 0; pu < 85; pu++) {
+        int n = pu_nidx(pu);
+        int total = nlist;
+        if (nlist == 2) {
+            int cond = (p->cu8x8_mode == 0 || pu < 21) && (p->cu16x16_mode == 0 || pu < 5);
+            if (cond) {
+                int x, y, w;
+                pu_geom(pu, &x, &y, &w);
+                pl_t a = bipred_pred(s, 0, region_tl[0], region_rs[0], s->best_mv[0][n], x, y, w, w, tmp0);
+                pl_t b = bipred_pred(s, 1, region_tl[1], region_rs[1], s->best_mv[1][n], x, y, w, w, tmp1);
+                const uint8_t *src = s->src + y * s->src_stride + x;
+                uint32_t d;
+                if (p->fractional_search_method == SVT_SUB_SAD_SEARCH)
+                    d = oracle_avg_sad(src, s->src_stride << 1, a.p, a.stride << 1, b.p, b.stride << 1, w >> 1, w) << 1;
+                else
+                    d = oracle_avg_sad(src, s->src_stride, a.p, a.stride, b.p, b.stride, w, w);
+                s->bipred_sad[n] = d;
+                total = 3;
+            }
+        }
+        svt_me_pu_result *r = &out[pu];
+        memset(r, 0, sizeof *r);
+        r->total_me_candidate_index = (uint8_t)total;
+        r->x_mv_l0 = mvx(s->best_mv[0][n]); r->y_mv_l0 = mvy(s->best_mv[0][n]);
+        if (nlist == 2) { r->x_mv_l1 = mvx(s->best_mv[1][n]); r->y_mv_l1 = mvy(s->best_mv[1][n]); }
+        uint32_t l0 = s->best_sad[0][n], l1 = nlist == 2 ? s->best_sad[1][n] : 0, bi = s->bipred_sad[n];
+        if (total == 3) {
+            /* sort3_elements :3734-3756 ('<=' everywhere => stable order l0, l1, bi) */
+            uint32_t v[3] = {l0, l1, bi};
+            int o[3];
+            if (l0 <= l1 && l0 <= bi) { o[0] = 0; if (l1 <= bi) { o[1] = 1; o[2] = 2; } else { o[1] = 2; o[2] = 1; } }
+            else if (l1 <= l0 && l1 <= bi) { o[0] = 1; if (l0 <= bi) { o[1] = 0; o[2] = 2; } else { o[1] = 2; o[2] = 0; } }
+            else if (l0 <= l1) { o[0] = 2; o[1] = 0; o[2] = 1; }
+            else { o[0] = 2; o[1] = 1; o[2] = 0; }
+            for (int i = 0; i < 3; i++) { r->distortion_direction[i].distortion = v[o[i]]; r->distortion_direction[i].direction = (uint32_t)o[i]; }
+        } else if (total == 2) {
+            if (l0 <= l1) {
+                r->distortion_direction[0].distortion = l0; r->distortion_direction[0].direction = 0;
+                r->distortion_direction[1].distortion = l1; r->distortion_direction[1].direction = 1;
+            } else {
+                r->distortion_direction[0].distortion = l1; r->distortion_direction[0].direction = 1;
+                r->distortion_direction[1].distortion = l0; r->distortion_direction[1].direction = 0;
+            }
+        } else {
+            r->distortion_direction[0].distortion = l0; r->distortion_direction[0].direction = 0;
+        }
+    }
+    if (rcme) {
+        uint32_t acc = 0;
+        for (int i = 0; i < 16; i++) acc += out[5 + i].distortion_direction[0].distortion;
+        *rcme = acc;
+    }
+}
+
+int32_t svt_oracle_me_picture(const svt_pa_picture *cur, const svt_pa_picture *ref0, const svt_pa_picture *ref1,
+                              const svt_me_params *params, svt_me_pu_result *results, uint32_t *rcme_distortion,
+                              int32_t sb_begin, int32_t sb_end) {
+    if (!cur || !ref0 || !params || !results) return -1;
+    if (params->num_ref_lists == 2 && !ref1) return -1;
+    me_sb_t *s = (me_sb_t *)calloc(1, sizeof *s);
+    if (!s || sb_alloc(s)) return -2;
+    int W = cur->full.width, H = cur->full.height;
+    int nx = (W + SB - 1) / SB, ny = (H + SB - 1) / SB;
+    if (sb_end < 0 || sb_end > nx * ny) sb_end = nx * ny;
+    s->cur = cur; s->ref[0] = ref0; s->ref[1] = ref1; s->p = params; s->pic_w = W; s->pic_h = H;
+    for (int sb = sb_begin; sb < sb_end; sb++) {
+        s->sb_x = (sb % nx) * SB; s->sb_y = (sb / nx) * SB;
+        s->sb_w = (W - s->sb_x) < SB ? W - s->sb_x : SB;
+        s->sb_h = (H - s->sb_y) < SB ? H - s->sb_y : SB;
+        s->src = pix(&cur->full, s->sb_x, s->sb_y);
+        s->src_stride = cur->full.stride;
+        me_sb(s, results + (size_t)sb * 85, rcme_distortion ? &rcme_distortion[sb] : NULL);
+    }
+    sb_free(s);
+    free(s);
+    return 0;
+}

@@ -1,0 +1,137 @@
+"""ctypes view of include/svtvp9_hip.h -- used by tests/, bench.py and __graft_entry__.py.
+
+This module only declares the C structs of the public header and loads the product library
+(svt-vp9_amd/libsvtvp9_hip.so).  It contains no compute and no fallback: if the library (or, for a
+compute call, a GPU) is missing, the call fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsvtvp9_hip.so")
+
+SVT_ME_PU_COUNT = 85
+
+
+class Plane(C.Structure):
+    _fields_ = [("buf", C.c_void_p), ("stride", C.c_int32), ("origin_x", C.c_int32), ("origin_y", C.c_int32),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class PaPicture(C.Structure):
+    _fields_ = [("full", Plane), ("quarter", Plane), ("sixteenth", Plane)]
+
+
+class MeParams(C.Structure):
+    _fields_ = [(n, C.c_uint8) for n in (
+        "num_ref_lists", "temporal_layer_index", "hierarchical_levels", "enable_hme_flag",
+        "enable_hme_level_0_flag", "enable_hme_level_1_flag", "enable_hme_level_2_flag", "cu8x8_mode",
+        "cu16x16_mode", "same_ref_poc", "rate_control_mode", "fractional_search_method",
+        "fractional_search_model", "fractional_search64x64", "single_hme_quadrant", "search_area_width",
+        "search_area_height")] + [
+        ("number_hme_search_region_in_width", C.c_uint16), ("number_hme_search_region_in_height", C.c_uint16),
+        ("hme_level0_total_search_area_width", C.c_uint16), ("hme_level0_total_search_area_height", C.c_uint16),
+        ("hme_level0_search_area_in_width_array", C.c_uint16 * 2),
+        ("hme_level0_search_area_in_height_array", C.c_uint16 * 2),
+        ("hme_level1_search_area_in_width_array", C.c_uint16 * 2),
+        ("hme_level1_search_area_in_height_array", C.c_uint16 * 2),
+        ("hme_level2_search_area_in_width_array", C.c_uint16 * 2),
+        ("hme_level2_search_area_in_height_array", C.c_uint16 * 2)]
+
+
+# numpy view of svt_me_pu_result (40 bytes)
+ME_RESULT_DTYPE = np.dtype([("x_mv_l0", "<i2"), ("y_mv_l0", "<i2"), ("x_mv_l1", "<i2"), ("y_mv_l1", "<i2"),
+                            ("dist0", "<u4"), ("dir0", "<u4"), ("dist1", "<u4"), ("dir1", "<u4"),
+                            ("dist2", "<u4"), ("dir2", "<u4"), ("total", "u1"), ("pad", "u1", (7,))])
+assert ME_RESULT_DTYPE.itemsize == 40
+
+
+class SadLoopJob(C.Structure):
+    _fields_ = [("src_off", C.c_uint64), ("ref_off", C.c_uint64), ("src_stride", C.c_int32),
+                ("ref_stride", C.c_int32), ("ref_stride_raw", C.c_int32), ("width", C.c_int32),
+                ("height", C.c_int32), ("search_w", C.c_int32), ("search_h", C.c_int32)]
+
+
+SAD_LOOP_JOB_DTYPE = np.dtype([("src_off", "<u8"), ("ref_off", "<u8"), ("src_stride", "<i4"), ("ref_stride", "<i4"),
+                               ("ref_stride_raw", "<i4"), ("width", "<i4"), ("height", "<i4"),
+                               ("search_w", "<i4"), ("search_h", "<i4")], align=True)
+SAD_LOOP_RESULT_DTYPE = np.dtype([("best_sad", "<u4"), ("x", "<i2"), ("y", "<i2")])
+
+
+class QuantTables(C.Structure):
+    _fields_ = [("zbin", C.c_int16 * 2), ("round", C.c_int16 * 2), ("quant", C.c_int16 * 2),
+                ("quant_shift", C.c_int16 * 2), ("dequant", C.c_int16 * 2)]
+
+
+QUANT_DTYPE = np.dtype([("zbin", "<i2", (2,)), ("round", "<i2", (2,)), ("quant", "<i2", (2,)),
+                        ("quant_shift", "<i2", (2,)), ("dequant", "<i2", (2,))])
+
+TQ_BLOCK_DTYPE = np.dtype([("src_off", "<u4"), ("pred_off", "<u4"), ("recon_off", "<u4"), ("coeff_off", "<u4"),
+                           ("src_stride", "<u2"), ("pred_stride", "<u2"), ("recon_stride", "<u2"),
+                           ("tx_size", "u1"), ("tx_type", "u1"), ("qtab", "u1"), ("do_recon", "u1"),
+                           ("partial32", "u1"), ("pad", "u1")])
+assert TQ_BLOCK_DTYPE.itemsize == 28
+
+LF_MASK_DTYPE = np.dtype([("left_y", "<u8", (4,)), ("above_y", "<u8", (4,)), ("int_4x4_y", "<u8"),
+                          ("left_uv", "<u2", (4,)), ("above_uv", "<u2", (4,)), ("int_4x4_uv", "<u2"),
+                          ("lfl_y", "u1", (64,))], align=True)
+
+
+class LfThresh(C.Structure):
+    _fields_ = [("mblim", C.c_uint8 * 64), ("lim", C.c_uint8 * 64), ("hev_thr", C.c_uint8 * 64)]
+
+
+class YuvPlanes(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("y_stride", C.c_int32),
+                ("uv_stride", C.c_int32), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+# every symbol include/svtvp9_hip.h declares
+EXPORTS = [
+    "svt_hip_sb_count", "svt_hip_me_params_preset", "svt_hip_ctx_create", "svt_hip_ctx_create_on_stream",
+    "svt_hip_ctx_destroy", "svt_hip_ctx_synchronize", "svt_hip_last_error", "svt_hip_last_kernel_ms",
+    "svt_hip_me_picture_device", "svt_hip_me_batch_device", "svt_hip_me_picture", "svt_hip_sad_loop_batch_device",
+    "svt_hip_tq_batch_device", "svt_hip_tq_batch", "svt_hip_lf_thresh_init", "svt_hip_lf_level_from_q",
+    "svt_hip_lf_frame_device", "svt_hip_lf_frame",
+]
+
+_lib = None
+
+
+def load():
+    """Load the product library.  Raises if it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.svt_hip_last_error.restype = C.c_char_p
+        _lib.svt_hip_last_kernel_ms.restype = C.c_float
+        _lib.svt_hip_last_kernel_ms.argtypes = [C.c_void_p]
+        _lib.svt_hip_lf_thresh_init.restype = None
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f"svt_hip call failed rc={rc}: {load().svt_hip_last_error().decode()}")
+
+
+def me_params_preset(width, height, enc_mode, tune, num_ref_lists, temporal_layer, hierarchical_levels):
+    p = MeParams()
+    check(load().svt_hip_me_params_preset(C.byref(p), width, height, enc_mode, tune, num_ref_lists,
+                                          temporal_layer, hierarchical_levels))
+    return p
+
+
+def plane_desc(arr, origin_x, origin_y, ptr=None):
+    """svt_plane for a padded 2-D uint8 array (numpy, or a device pointer given via ptr)."""
+    h, w = arr.shape
+    p = Plane()
+    p.buf = ptr if ptr is not None else arr.ctypes.data
+    p.stride = arr.strides[0] if hasattr(arr, "strides") and ptr is None else w
+    p.origin_x, p.origin_y = origin_x, origin_y
+    p.width, p.height = w - 2 * origin_x, h - 2 * origin_y
+    return p
