@@ -1,0 +1,108 @@
+/*
+ * api.hip -- context management and small host-side helpers of the C ABI (include/svtvp9_hip.h).
+ * There is no CPU fallback anywhere in this library: every compute entry point launches HIP kernels
+ * and fails with SVT_HIP_ERR_DEVICE when no gfx950 device is usable.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "svt_ctx.h"
+
+static thread_local char g_err[512] = "";
+
+int32_t svt_set_error(int32_t code, const char *msg) {
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+int32_t svt_set_hip_error(hipError_t e, const char *file, int line) {
+    snprintf(g_err, sizeof g_err, "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), file, line);
+    return SVT_HIP_ERR_DEVICE;
+}
+extern "C" const char *svt_hip_last_error(void) { return g_err; }
+
+extern "C" int32_t svt_hip_sb_count(int32_t w, int32_t h) { return ((w + 63) / 64) * ((h + 63) / 64); }
+
+static int32_t ctx_create(svt_hip_ctx **out, int32_t device, void *stream, int owns) {
+    if (!out) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "ctx: null");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return svt_set_error(SVT_HIP_ERR_DEVICE, "ctx: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    svt_hip_ctx *c = (svt_hip_ctx *)calloc(1, sizeof *c);
+    if (!c) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "ctx: malloc");
+    c->device = device;
+    if (owns) {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { free(c); return svt_set_error(SVT_HIP_ERR_DEVICE, "ctx: stream"); }
+    } else {
+        c->stream = (hipStream_t)stream;
+    }
+    c->owns_stream = owns;
+    if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) { free(c); return svt_set_error(SVT_HIP_ERR_DEVICE, "ctx: events"); }
+    *out = c;
+    return SVT_HIP_OK;
+}
+extern "C" int32_t svt_hip_ctx_create(svt_hip_ctx **ctx, int32_t device) { return ctx_create(ctx, device, nullptr, 1); }
+extern "C" int32_t svt_hip_ctx_create_on_stream(svt_hip_ctx **ctx, int32_t device, void *s) { return ctx_create(ctx, device, s, 0); }
+
+extern "C" void svt_hip_ctx_destroy(svt_hip_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < SVT_CTX_SLOTS; i++) if (c->slot[i]) (void)hipFree(c->slot[i]);
+    if (c->dev_scratch) (void)hipFree(c->dev_scratch);
+    if (c->host_scratch) (void)hipHostFree(c->host_scratch);
+    (void)hipEventDestroy(c->ev_start);
+    (void)hipEventDestroy(c->ev_stop);
+    if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+    free(c);
+}
+extern "C" int32_t svt_hip_ctx_synchronize(svt_hip_ctx *c) {
+    if (!c) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "ctx: null");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SVT_HIP_OK;
+}
+extern "C" float svt_hip_last_kernel_ms(svt_hip_ctx *c) {
+    float ms = -1.f;
+    if (!c || !c->timed) return ms;
+    if (hipEventSynchronize(c->ev_stop) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) != hipSuccess) return -1.f;
+    return ms;
+}
+
+void *svt_ctx_host_scratch(svt_hip_ctx *c, size_t bytes) {
+    if (bytes > c->host_scratch_bytes) {
+        /* the previous buffer may still be the source of an in-flight copy */
+        (void)hipStreamSynchronize(c->stream);
+        if (c->host_scratch) (void)hipHostFree(c->host_scratch);
+        c->host_scratch = nullptr; c->host_scratch_bytes = 0;
+        size_t cap = bytes < 65536 ? 65536 : bytes * 2;
+        if (hipHostMalloc(&c->host_scratch, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+        c->host_scratch_bytes = cap;
+    } else {
+        /* single staging buffer: wait until the previous call's copy has consumed it */
+        (void)hipStreamSynchronize(c->stream);
+    }
+    return c->host_scratch;
+}
+void *svt_ctx_dev_scratch(svt_hip_ctx *c, size_t bytes) {
+    if (bytes > c->dev_scratch_bytes) {
+        (void)hipStreamSynchronize(c->stream);
+        if (c->dev_scratch) (void)hipFree(c->dev_scratch);
+        c->dev_scratch = nullptr; c->dev_scratch_bytes = 0;
+        size_t cap = bytes < 65536 ? 65536 : bytes * 2;
+        if (hipMalloc(&c->dev_scratch, cap) != hipSuccess) return nullptr;
+        c->dev_scratch_bytes = cap;
+    }
+    return c->dev_scratch;
+}
+void *svt_ctx_slot(svt_hip_ctx *c, int s, size_t bytes) {
+    if (s < 0 || s >= SVT_CTX_SLOTS) return nullptr;
+    if (bytes > c->slot_bytes[s]) {
+        (void)hipStreamSynchronize(c->stream);
+        if (c->slot[s]) (void)hipFree(c->slot[s]);
+        c->slot[s] = nullptr; c->slot_bytes[s] = 0;
+        if (hipMalloc(&c->slot[s], bytes) != hipSuccess) return nullptr;
+        c->slot_bytes[s] = bytes;
+    }
+    return c->slot[s];
+}

@@ -1,0 +1,1129 @@
+/*
+ * me_core.h -- motion estimation of one 64x64 super-block by one 256-thread workgroup (CDNA4 / gfx950).
+ *
+ * Implements, bit-exactly, the per-SB flow of the reference's motion_estimate_sb
+ * (Source/Lib/Codec/EbMotionEstimation.c:4524-5305) for the C_DEFAULT kernels:
+ *   test_search_area_bounds (:4260) -> HME level 0/1/2 (:2717-3308, eb_vp9_sad_loop_kernel
+ *   C_DEFAULT/EbComputeSAD_C.c:132) -> check_zero_zero_center (:3758) -> full_pel_search_sb (:951,
+ *   C_DEFAULT/EbComputeSAD_C.c:193-375, EbMeSadCalculation_C.c:16-99) -> su_pel_enable (:3839) ->
+ *   interpolate_search_region_avc (:992, C_DEFAULT/EbAvcStyleMcp_C.c) -> half_pel_search_sb (:1565) ->
+ *   quarter_pel_search_sb (:2471) -> bi_prediction_search (:3695) -> candidate ordering (:5186-5293).
+ *
+ * MI355X mapping
+ *   - one workgroup (4 wave64) per SB; both reference lists are processed inside the workgroup because
+ *     list 1 starts from list 0's 64x64 motion vector (:4450);
+ *   - the 64x64 source SB, the reference search region (+ halo) and its three half-pel planes live in
+ *     LDS; every SAD runs out of LDS;
+ *   - SADs use v_qsad_pk_u16_u8: one instruction = 4 neighbouring search positions x 4 pixels;
+ *     operands are dword-aligned by construction of the LDS layouts (search position 0 sits on a
+ *     dword boundary), sub-pel candidates are fetched with v_alignbyte_b32;
+ *   - arg-min with the reference's "first minimum in raster order" rule is an order-independent
+ *     unsigned min over keys (sad << 32 | raster_index), reduced with ds_min_u64 (LDS atomics);
+ *   - integer pixel work, no MFMA.
+ *
+ * The code is written as a sequence of PHASES.  Inside a phase each of the 256 threads runs a
+ * grid-stride loop over independent tasks; phases communicate only through LDS, separated by
+ * workgroup barriers.  The uniform control flow between phases reads its inputs from LDS.  This lets
+ * the identical source be compiled (a) by hipcc as the device kernel and (b) by a host compiler as a
+ * serial emulation used only by the CPU test-suite to debug the kernel logic (tests/emu/).
+ */
+#ifndef SVT_ME_CORE_H
+#define SVT_ME_CORE_H
+
+#include <stdint.h>
+#include "../../include/svtvp9_hip.h"
+
+#ifdef SVT_HOST_EMU
+#define SVT_DEV static inline
+#define SVT_NT 256
+static inline uint64_t svt_qsad(uint64_t ref8, uint32_t src4, uint64_t acc) {
+    uint64_t out = 0;
+    for (int o = 0; o < 4; o++) {
+        uint32_t s = 0;
+        for (int b = 0; b < 4; b++) {
+            int r = (int)((ref8 >> (8 * (o + b))) & 0xff), c = (int)((src4 >> (8 * b)) & 0xff);
+            s += (uint32_t)(r > c ? r - c : c - r);
+        }
+        out |= (uint64_t)((uint16_t)(((acc >> (16 * o)) & 0xffff) + s)) << (16 * o);
+    }
+    return out;
+}
+static inline uint32_t svt_sad4(uint32_t a, uint32_t b, uint32_t acc) {
+    for (int i = 0; i < 4; i++) {
+        int x = (int)((a >> (8 * i)) & 0xff), y = (int)((b >> (8 * i)) & 0xff);
+        acc += (uint32_t)(x > y ? x - y : y - x);
+    }
+    return acc;
+}
+static inline uint32_t svt_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3)));
+}
+static inline void svt_lds_min_u64(uint64_t *p, uint64_t v) { if (v < *p) *p = v; }
+static inline void svt_lds_add_u32(uint32_t *p, uint32_t v) { *p += v; }
+#else
+#include <hip/hip_runtime.h>
+#define SVT_DEV __device__ __forceinline__
+#define SVT_NT 256
+SVT_DEV uint64_t svt_qsad(uint64_t ref8, uint32_t src4, uint64_t acc) {
+    return __builtin_amdgcn_qsad_pk_u16_u8(ref8, src4, acc);
+}
+SVT_DEV uint32_t svt_sad4(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
+SVT_DEV uint32_t svt_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+SVT_DEV void svt_lds_min_u64(uint64_t *p, uint64_t v) { atomicMin((unsigned long long *)p, (unsigned long long)v); }
+SVT_DEV void svt_lds_add_u32(uint32_t *p, uint32_t v) { atomicAdd(p, v); }
+#endif
+
+#define ME_SB 64
+#define ME_MAX_SAD_VALUE (64 * 64 * 255)
+
+/* raster index -> search (z-order) index, Codec/EbMotionEstimation.c:51-54 */
+__attribute__((unused)) static
+#ifndef SVT_HOST_EMU
+    __device__
+#endif
+    const uint8_t me_tab32x32[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
+__attribute__((unused)) static
+#ifndef SVT_HOST_EMU
+    __device__
+#endif
+    const uint8_t me_tab8x8[64] = {0,  1,  4,  5,  16, 17, 20, 21, 2,  3,  6,  7,  18, 19, 22, 23, 8,  9,  12, 13, 24, 25,
+                                   28, 29, 10, 11, 14, 15, 26, 27, 30, 31, 32, 33, 36, 37, 48, 49, 52, 53, 34, 35, 38, 39,
+                                   50, 51, 54, 55, 40, 41, 44, 45, 56, 57, 60, 61, 42, 43, 46, 47, 58, 59, 62, 63};
+
+/* inverse maps: search (z-order) index -> raster index */
+__attribute__((unused)) static
+#ifndef SVT_HOST_EMU
+    __device__
+#endif
+    const uint8_t me_inv32x32[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
+__attribute__((unused)) static
+#ifndef SVT_HOST_EMU
+    __device__
+#endif
+    const uint8_t me_inv8x8[64] = {0,  1,  8,  9,  2,  3,  10, 11, 16, 17, 24, 25, 18, 19, 26, 27, 4,  5,  12, 13, 6,  7,
+                                   14, 15, 20, 21, 28, 29, 22, 23, 30, 31, 32, 33, 40, 41, 34, 35, 42, 43, 48, 49, 56, 57,
+                                   50, 51, 58, 59, 36, 37, 44, 45, 38, 39, 46, 47, 52, 53, 60, 61, 54, 55, 62, 63};
+
+/* Picture descriptor as seen by the kernel (device pointers inside the planes). */
+typedef struct me_pic_dev {
+    svt_pa_picture    cur, ref[2];
+    svt_me_pu_result *results;
+    uint32_t         *rcme;
+} me_pic_dev;
+
+/* LDS layout (byte offsets), computed on the host from the parameters (me_lds_layout) */
+typedef struct me_lds_layout {
+    int32_t off_state;   /* me_state_t */
+    int32_t off_src;     /* 64 x 64 source SB, stride 64 */
+    int32_t off_region;  /* integer reference samples of the current list's search region */
+    int32_t off_planes;  /* B, H, J half-pel planes (3 x plane_bytes); aliased by HME window / SAD scratch */
+    int32_t off_pred0;   /* list-0 prediction blocks kept for bi-pred (85 PUs max: 16 KB) */
+    int32_t region_stride, region_rows;
+    int32_t plane_bytes;
+    int32_t scratch_bytes; /* bytes available at off_planes */
+    int32_t total_bytes;
+} me_lds_layout;
+
+#define ME_RGN_GX 4 /* left guard columns of the region buffer (search position 0 is dword aligned) */
+#define ME_RGN_GY 3 /* top guard rows */
+#define ME_PL_G 2   /* guard of the half-pel planes */
+
+/* per-SB state in LDS */
+typedef struct me_state_t {
+    uint64_t key[85];          /* full-pel arg-min keys of the current list */
+    uint64_t hme_key;          /* arg-min key of the running HME search */
+    uint32_t best_sad[2][85];  /* search (z-order) index */
+    uint32_t best_mv[2][85];
+    uint32_t bipred_sad[85];
+    uint32_t cand[85 * 8];     /* sub-pel candidate distortions [pu][8] */
+    uint32_t red[8];           /* small sum reductions */
+    uint32_t supel[9];         /* su_pel_enable sums: sx,sy,ssad for 32/16/8 */
+    uint8_t  dir[85];
+    uint8_t  sixteenth_sb[16 * 8];
+    uint8_t  quarter_sb[32 * 32];
+} me_state_t;
+
+SVT_DEV int16_t me_mvx(uint32_t mv) { return (int16_t)(mv & 0xFFFF); }
+SVT_DEV int16_t me_mvy(uint32_t mv) { return (int16_t)(mv >> 16); }
+SVT_DEV uint32_t me_pack_mv(int x, int y) { return ((uint32_t)(uint16_t)y << 16) | (uint16_t)x; }
+SVT_DEV const uint8_t *me_pix(const svt_plane *p, int x, int y) {
+    return p->buf + (ptrdiff_t)(p->origin_y + y) * p->stride + p->origin_x + x;
+}
+SVT_DEV int me_pu_nidx(int pu) { return pu > 20 ? me_tab8x8[pu - 21] + 21 : pu > 4 ? me_tab32x32[pu - 5] + 5 : pu; }
+SVT_DEV void me_pu_geom(int pu, int *x, int *y, int *w) {
+    if (pu == 0) { *x = 0; *y = 0; *w = 64; }
+    else if (pu < 5) { *x = ((pu - 1) & 1) * 32; *y = ((pu - 1) >> 1) * 32; *w = 32; }
+    else if (pu < 21) { *x = ((pu - 5) & 3) * 16; *y = ((pu - 5) >> 2) * 16; *w = 16; }
+    else { *x = ((pu - 21) & 7) * 8; *y = ((pu - 21) >> 3) * 8; *w = 8; }
+}
+
+/* unaligned 32-bit fetch from a byte address (LDS or global): two aligned loads + v_alignbyte */
+SVT_DEV uint32_t me_ld32u(const uint8_t *p) {
+    uint32_t        sh = (uint32_t)((uintptr_t)p & 3);
+    const uint32_t *q  = (const uint32_t *)(p - sh);
+    uint32_t        lo = q[0];
+    if (sh == 0) return lo;
+    return svt_alignbyte(q[1], lo, sh);
+}
+
+/* [quirk] origin is updated first and the width test re-evaluated afterwards, so left/top clipping never
+ * shrinks the area (Codec/EbMotionEstimation.c:5022-5054 and the HME copies). */
+SVT_DEV void me_clip_area(int origin, int16_t *area_origin, int16_t *area_size, int pad, int pic_dim) {
+    int16_t o = *area_origin, s = *area_size;
+    o = (int16_t)(((origin + o) < -pad) ? -pad - origin : o);
+    s = (int16_t)(((origin + o) < -pad) ? s - (-pad - (origin + o)) : s);
+    o = (int16_t)(((origin + o) > pic_dim - 1) ? o - ((origin + o) - (pic_dim - 1)) : o);
+    if ((origin + o + s) > pic_dim) {
+        int t = s - ((origin + o + s) - pic_dim);
+        s     = (int16_t)(t > 1 ? t : 1);
+    }
+    *area_origin = o;
+    *area_size   = s;
+}
+SVT_DEV int16_t me_clip_center(int origin, int16_t c, int pad, int pic_dim) {
+    c = (int16_t)(((origin + c) < -pad) ? -pad - origin : c);
+    c = (int16_t)(((origin + c) > pic_dim - 1) ? c - ((origin + c) - (pic_dim - 1)) : c);
+    return c;
+}
+
+/* everything a phase needs */
+typedef struct me_ctx_t {
+    const me_pic_dev    *pic;
+    const svt_me_params *p;
+    me_lds_layout        L;
+    uint8_t             *lds;
+    me_state_t          *st;
+    uint8_t             *src;    /* LDS */
+    uint8_t             *region; /* LDS */
+    uint8_t             *planes; /* LDS */
+    uint8_t             *pred0;  /* LDS */
+    int                  pic_w, pic_h, sb_x, sb_y, sb_w, sb_h, sb_index;
+} me_ctx_t;
+
+/* ------------------------------------------------------------------------------------------------ */
+/* phases (each: grid-stride loop over tasks; tid in [0,256))                                         */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* copy a w_bytes x rows rectangle from global memory (any alignment) into LDS (dst 4-byte aligned rows) */
+SVT_DEV void ph_load_rect(int tid, uint8_t *dst, int dst_stride, const uint8_t *src, int src_stride, int w_bytes, int rows) {
+    int nd = (w_bytes + 3) >> 2;
+    for (int t = tid; t < nd * rows; t += SVT_NT) {
+        int r = t / nd, i = t - r * nd;
+        *(uint32_t *)(dst + r * dst_stride + 4 * i) = me_ld32u(src + (ptrdiff_t)r * src_stride + 4 * i);
+    }
+}
+
+/* initial state + decimated SB copies (Codec/EbMotionEstimationProcess.c:984-1035) */
+SVT_DEV void ph_init(const me_ctx_t *c, int tid) {
+    me_state_t *st = c->st;
+    for (int t = tid; t < 85; t += SVT_NT) {
+        st->bipred_sad[t] = 0;
+        st->best_mv[0][t] = 0; st->best_mv[1][t] = 0;
+        st->best_sad[0][t] = 0; st->best_sad[1][t] = 0;
+        st->dir[t] = 0;
+    }
+    if (tid < 8) st->red[tid] = 0;
+    /* source SB: always 64x64 from the padded picture */
+    ph_load_rect(tid, c->src, ME_SB, me_pix(&c->pic->cur.full, c->sb_x, c->sb_y), c->pic->cur.full.stride, ME_SB, ME_SB);
+    if (c->p->enable_hme_level_0_flag) {
+        /* rows 0,2,4,.. of the 1/16 SB, stride 16 */
+        int rows = (c->sb_h >> 2) >> 1, wq = c->sb_w >> 2;
+        for (int t = tid; t < rows * 16; t += SVT_NT) {
+            int r = t >> 4, x = t & 15;
+            st->sixteenth_sb[t] = x < wq ? *me_pix(&c->pic->cur.sixteenth, (c->sb_x >> 2) + x, (c->sb_y >> 2) + 2 * r) : 0;
+        }
+    }
+    if (c->p->enable_hme_level_1_flag) {
+        int rows = c->sb_h >> 1, wq = c->sb_w >> 1;
+        for (int t = tid; t < rows * 32; t += SVT_NT) {
+            int r = t >> 5, x = t & 31;
+            st->quarter_sb[t] = x < wq ? *me_pix(&c->pic->cur.quarter, (c->sb_x >> 1) + x, (c->sb_y >> 1) + r) : 0;
+        }
+    }
+}
+
+/* Row-subsampled 64-wide SADs of the source SB against up to 5 displaced reference blocks read from
+ * global memory (test_search_area_bounds / check_zero_zero_center).  Each thread: one (row, 8-byte) piece.
+ * Results accumulate in st->red[k]; caller doubles them. */
+SVT_DEV void ph_center_sads(const me_ctx_t *c, int tid, const svt_plane *ref, int ncand, const int16_t *dx, const int16_t *dy) {
+    int rows = c->sb_h >> 1, wd = c->sb_w >> 2; /* dwords per row */
+    for (int t = tid; t < rows * wd; t += SVT_NT) {
+        int      r = t / wd, i = t - r * wd;
+        uint32_t s = *(const uint32_t *)(c->src + (2 * r) * ME_SB + 4 * i);
+        for (int k = 0; k < ncand; k++) {
+            const uint8_t *rp = me_pix(ref, c->sb_x + dx[k] + 4 * i, c->sb_y + dy[k] + 2 * r);
+            uint32_t       d  = svt_sad4(me_ld32u(rp), s, 0);
+            svt_lds_add_u32(&c->st->red[k], d);
+        }
+    }
+}
+
+/* Generic exhaustive SAD search (= eb_vp9_sad_loop_kernel) over a window staged in LDS.
+ * blk: block rows (already subsampled) in LDS, stride bstride, bw x bh.  win: LDS window whose row r holds
+ * reference row (window_top + r) and column 0 = search x position 0; a search row y uses window rows
+ * y + mul*j (j = block row; mul = 2 in every reference use).  Key = (sad << 32) | (y * sw + x).  bw multiple of 4 uses QSAD. */
+SVT_DEV void ph_sad_search(const me_ctx_t *c, int tid, const uint8_t *blk, int bstride, int bw, int bh, const uint8_t *win,
+                           int wstride, int sw, int sh, int mul) {
+    int      ng   = (sw + 3) >> 2;
+    uint64_t best = ~0ull;
+    if ((bw & 3) == 0) {
+        int nd = bw >> 2;
+        for (int t = tid; t < ng * sh; t += SVT_NT) {
+            int      y = t / ng, g = t - y * ng;
+            uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            for (int j = 0; j < bh; j++) {
+                const uint32_t *wr  = (const uint32_t *)(win + (y + mul * j) * wstride + 4 * g);
+                const uint32_t *br  = (const uint32_t *)(blk + j * bstride);
+                uint64_t        acc = 0;
+                uint32_t        lo  = wr[0];
+                for (int i = 0; i < nd; i++) {
+                    uint32_t hi = wr[i + 1];
+                    acc         = svt_qsad(((uint64_t)hi << 32) | lo, br[i], acc);
+                    lo          = hi;
+                }
+                a0 += (uint32_t)(acc & 0xffff); a1 += (uint32_t)((acc >> 16) & 0xffff);
+                a2 += (uint32_t)((acc >> 32) & 0xffff); a3 += (uint32_t)(acc >> 48);
+            }
+            uint32_t a[4] = {a0, a1, a2, a3};
+            for (int o = 0; o < 4; o++) {
+                int x = 4 * g + o;
+                if (x < sw) {
+                    uint64_t k = ((uint64_t)a[o] << 32) | (uint32_t)(y * sw + x);
+                    if (k < best) best = k;
+                }
+            }
+        }
+    } else {
+        for (int t = tid; t < sw * sh; t += SVT_NT) {
+            int      y = t / sw, x = t - y * sw;
+            uint32_t s = 0;
+            for (int j = 0; j < bh; j++)
+                for (int i = 0; i < bw; i++) {
+                    int a = blk[j * bstride + i], b = win[(y + mul * j) * wstride + x + i];
+                    s += (uint32_t)(a > b ? a - b : b - a);
+                }
+            uint64_t k = ((uint64_t)s << 32) | (uint32_t)t;
+            if (k < best) best = k;
+        }
+    }
+    if (best != ~0ull) svt_lds_min_u64(&c->st->hme_key, best);
+}
+
+/* full-pel: sub-sampled 8x8 SADs of every (position, 8x8 block) of a chunk of search rows.
+ * Task = (8x8 block b in raster order, 4-position group g, search row y).  Output u16 s8[pos][64]
+ * (pos = y_local * sw + x) into scratch.  tail columns (x >= w8) reproduce the reference's address bug
+ * for 16x16 blocks 12 and 13 (Codec/EbMotionEstimation.c:855-856). */
+SVT_DEV void ph_fullpel_sad8(const me_ctx_t *c, int tid, uint16_t *s8, int sw, int y0, int ny, int w8) {
+    int ng = (sw + 3) >> 2;
+    int rs = c->L.region_stride;
+    for (int t = tid; t < ng * ny * 64; t += SVT_NT) {
+        int b = t & 63, q = t >> 6;
+        int yl = q / ng, g = q - yl * ng;
+        int bx = (b & 7) * 8, by = (b >> 3) * 8;
+        int rbx = bx;
+        if (4 * g >= w8) {
+            /* 16x16 block (raster) containing b: z-order 12 -> raster 10 (x=32,y=32), 13 -> raster 11 (x=48,y=32) */
+            if (by >= 32 && by < 48 && bx >= 32) rbx += 16;
+        }
+        const uint8_t *rp = c->region + (ME_RGN_GY + y0 + yl + by) * rs + ME_RGN_GX + 4 * g + rbx;
+        const uint8_t *sp = c->src + by * ME_SB + bx;
+        uint64_t       acc = 0;
+        for (int r = 0; r < 4; r++) {
+            const uint32_t *w = (const uint32_t *)(rp + 2 * r * rs);
+            const uint32_t *s = (const uint32_t *)(sp + 2 * r * ME_SB);
+            uint32_t        d0 = w[0], d1 = w[1], d2 = w[2];
+            acc = svt_qsad(((uint64_t)d1 << 32) | d0, s[0], acc);
+            acc = svt_qsad(((uint64_t)d2 << 32) | d1, s[1], acc);
+        }
+        for (int o = 0; o < 4; o++) {
+            int x = 4 * g + o;
+            if (x < sw) s8[(yl * sw + x) * 64 + b] = (uint16_t)(acc >> (16 * o));
+        }
+    }
+}
+
+/* full-pel: per-PU arg-min over the positions of the chunk.  Task = (pu in search order, slice). */
+SVT_DEV void ph_fullpel_argmin(const me_ctx_t *c, int tid, const uint16_t *s8, int sw, int y0, int ny, int w8, int nslice) {
+    int npos = sw * ny;
+    int per  = (npos + nslice - 1) / nslice;
+    for (int t = tid; t < 85 * nslice; t += SVT_NT) {
+        int pu = t % 85, sl = t / 85;
+        int p0 = sl * per, p1 = p0 + per < npos ? p0 + per : npos;
+        /* 8x8 blocks (raster ids) covered by this PU */
+        int bx0, by0, nb;
+        if (pu == 0) { bx0 = 0; by0 = 0; nb = 8; }
+        else if (pu < 5) { bx0 = ((pu - 1) & 1) * 4; by0 = ((pu - 1) >> 1) * 4; nb = 4; }
+        else if (pu < 21) {
+            int r = me_inv32x32[pu - 5]; /* search index -> raster 16x16 */
+            bx0 = (r & 3) * 2; by0 = (r >> 2) * 2; nb = 2;
+        } else {
+            int r = me_inv8x8[pu - 21];
+            bx0 = r & 7; by0 = r >> 3; nb = 1;
+        }
+        uint64_t best = ~0ull;
+        for (int pos = p0; pos < p1; pos++) {
+            const uint16_t *row = s8 + pos * 64;
+            int             x   = pos % sw;
+            uint32_t        sad;
+            if (nb == 1) sad = row[by0 * 8 + bx0];
+            else {
+                /* sum 16x16 units; in the 8-point path each 16x16 sum is kept in uint16
+                   (C_DEFAULT/EbComputeSAD_C.c:201,276), in the tail path it is 32-bit */
+                sad = 0;
+                for (int uy = 0; uy < nb; uy += 2)
+                    for (int ux = 0; ux < nb; ux += 2) {
+                        const uint16_t *q = row + (by0 + uy) * 8 + bx0 + ux;
+                        uint32_t        u = (uint32_t)q[0] + q[1] + q[8] + q[9];
+                        if (x < w8) u = (uint16_t)u;
+                        sad += u;
+                    }
+            }
+            uint64_t k = ((uint64_t)(2 * sad) << 32) | (uint32_t)((y0 * sw) + pos);
+            if (k < best) best = k;
+        }
+        if (best != ~0ull) svt_lds_min_u64(&c->st->key[pu], best);
+    }
+}
+
+SVT_DEV uint8_t me_clip8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+SVT_DEV uint8_t me_tap4(int a, int b, int d, int e) { return me_clip8((-2 * a + 18 * b + 18 * d - 2 * e + 16) >> 5); }
+
+/* half-pel planes B (x+1/2,y) and H (x,y+1/2) from the region; natural coordinates, guard ME_PL_G
+ * (interpolate_search_region_avc, Codec/EbMotionEstimation.c:992-1070; C_DEFAULT/EbAvcStyleMcp_C.c:25-73) */
+SVT_DEV void ph_interp_bh(const me_ctx_t *c, int tid, int W, int H) {
+    int      rs = c->L.region_stride, pw = W + 2 * ME_PL_G, ph = H + 2 * ME_PL_G;
+    uint8_t *B = c->planes, *Hh = c->planes + c->L.plane_bytes;
+    for (int t = tid; t < pw * ph; t += SVT_NT) {
+        int            py = t / pw, px = t - py * pw;
+        int            x = px - ME_PL_G, y = py - ME_PL_G;
+        const uint8_t *r = c->region + (ME_RGN_GY + y) * rs + ME_RGN_GX + x;
+        B[py * rs + px]  = me_tap4(r[-1], r[0], r[1], r[2]);
+        Hh[py * rs + px] = me_tap4(r[-rs], r[0], r[rs], r[2 * rs]);
+    }
+}
+/* J (x+1/2, y+1/2) = vertical filter over B; defined for y in [-1, H-1] */
+SVT_DEV void ph_interp_j(const me_ctx_t *c, int tid, int W, int H) {
+    int      rs = c->L.region_stride, pw = W + 2 * ME_PL_G;
+    uint8_t *B = c->planes, *J = c->planes + 2 * c->L.plane_bytes;
+    for (int t = tid; t < pw * H; t += SVT_NT) {
+        int            yy = t / pw, px = t - yy * pw;
+        int            py = yy + ME_PL_G - 1; /* y = yy - 1 */
+        const uint8_t *b  = B + py * rs + px;
+        J[py * rs + px]   = me_tap4(b[-rs], b[0], b[rs], b[2 * rs]);
+    }
+}
+
+enum { ME_PF = 0, ME_PB = 1, ME_PH = 2, ME_PJ = 3 };
+/* byte pointer (LDS) of plane `id` at natural position (x, y) relative to the region's top-left */
+SVT_DEV const uint8_t *me_plane_at(const me_ctx_t *c, int id, int x, int y) {
+    int rs = c->L.region_stride;
+    if (id == ME_PF) return c->region + (ME_RGN_GY + y) * rs + ME_RGN_GX + x;
+    return c->planes + (id - 1) * c->L.plane_bytes + (y + ME_PL_G) * rs + x + ME_PL_G;
+}
+
+/* SAD of a w x rows block: src rows at stride ss (LDS, dword aligned) vs candidate at any byte
+ * alignment (stride cs), optionally averaged with a second candidate plane (b != 0). */
+SVT_DEV uint32_t me_block_sad_rows(const uint8_t *src, int ss, const uint8_t *a, const uint8_t *b, int cs, int w, int r0, int r1) {
+    uint32_t sad = 0;
+    for (int r = r0; r < r1; r++) {
+        const uint32_t *s = (const uint32_t *)(src + r * ss);
+        for (int i = 0; i < (w >> 2); i++) {
+            uint32_t va = me_ld32u(a + r * cs + 4 * i);
+            if (b) {
+                uint32_t vb = me_ld32u(b + r * cs + 4 * i);
+                /* per-byte (a + b + 1) >> 1 without carries crossing bytes */
+                va = (va | vb) - (((va ^ vb) >> 1) & 0x7f7f7f7fu);
+            }
+            sad = svt_sad4(va, s[i], sad);
+        }
+    }
+    return sad;
+}
+
+/* candidate tables ---------------------------------------------------------------------------------- */
+/* half-pel candidates L,R,T,B,TL,TR,BR,BL relative to the integer position (pu_half_pel_refinement,
+ * Codec/EbMotionEstimation.c:1076-1559), natural coordinates */
+__attribute__((unused)) static
+#ifndef SVT_HOST_EMU
+    __device__
+#endif
+    const int8_t me_hcand[8][3] = {{ME_PB, -1, 0}, {ME_PB, 0, 0}, {ME_PH, 0, -1}, {ME_PH, 0, 0},
+                                   {ME_PJ, -1, -1}, {ME_PJ, 0, -1}, {ME_PJ, 0, 0}, {ME_PJ, -1, 0}};
+__attribute__((unused)) static
+#ifndef SVT_HOST_EMU
+    __device__
+#endif
+    const int8_t me_hdmv[8][2] = {{-2, 0}, {2, 0}, {0, -2}, {0, 2}, {-2, -2}, {2, -2}, {2, 2}, {-2, 2}};
+/* quarter-pel pairs (set_quarter_pel_refinement_inputs_on_the_fly, :2290-2465), natural coordinates
+ * relative to P = (mv + 2) >> 2; [method][position L,R,T,B,TL,TR,BR,BL][plane1,dx1,dy1,plane2,dx2,dy2] */
+__attribute__((unused)) static
+#ifndef SVT_HOST_EMU
+    __device__
+#endif
+    const int8_t me_qtab[4][8][6] = {
+        {{ME_PB, -1, 0, ME_PF, 0, 0}, {ME_PF, 0, 0, ME_PB, 0, 0}, {ME_PH, 0, -1, ME_PF, 0, 0}, {ME_PF, 0, 0, ME_PH, 0, 0},
+         {ME_PB, -1, 0, ME_PH, 0, -1}, {ME_PH, 0, -1, ME_PB, 0, 0}, {ME_PH, 0, 0, ME_PB, 0, 0}, {ME_PB, -1, 0, ME_PH, 0, 0}},
+        {{ME_PF, -1, 0, ME_PB, -1, 0}, {ME_PB, -1, 0, ME_PF, 0, 0}, {ME_PJ, -1, -1, ME_PB, -1, 0}, {ME_PB, -1, 0, ME_PJ, -1, 0},
+         {ME_PH, -1, -1, ME_PB, -1, 0}, {ME_PB, -1, 0, ME_PH, 0, -1}, {ME_PB, -1, 0, ME_PH, 0, 0}, {ME_PH, -1, 0, ME_PB, -1, 0}},
+        {{ME_PJ, -1, -1, ME_PH, 0, -1}, {ME_PH, 0, -1, ME_PJ, 0, -1}, {ME_PF, 0, -1, ME_PH, 0, -1}, {ME_PH, 0, -1, ME_PF, 0, 0},
+         {ME_PB, -1, -1, ME_PH, 0, -1}, {ME_PH, 0, -1, ME_PB, 0, -1}, {ME_PH, 0, -1, ME_PB, 0, 0}, {ME_PB, -1, 0, ME_PH, 0, -1}},
+        {{ME_PH, -1, -1, ME_PJ, -1, -1}, {ME_PJ, -1, -1, ME_PH, 0, -1}, {ME_PB, -1, -1, ME_PJ, -1, -1}, {ME_PJ, -1, -1, ME_PB, -1, 0},
+         {ME_PH, -1, -1, ME_PB, -1, -1}, {ME_PB, -1, -1, ME_PH, 0, -1}, {ME_PB, -1, 0, ME_PH, 0, -1}, {ME_PH, -1, -1, ME_PB, -1, 0}}};
+__attribute__((unused)) static
+#ifndef SVT_HOST_EMU
+    __device__
+#endif
+    const int8_t me_qdmv[8][2] = {{-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
+/* bi-pred quarter-pel compensation pairs (quarter_pel_compensation, :3358-3453), by frac_pos */
+__attribute__((unused)) static
+#ifndef SVT_HOST_EMU
+    __device__
+#endif
+    const int8_t me_btab[16][6] = {
+        {ME_PF, 0, 0, -1, 0, 0}, {ME_PF, 0, 0, ME_PB, 0, 0}, {ME_PB, 0, 0, -1, 0, 0}, {ME_PB, 0, 0, ME_PF, 1, 0},
+        {ME_PF, 0, 0, ME_PH, 0, 0}, {ME_PB, 0, 0, ME_PH, 0, 0}, {ME_PB, 0, 0, ME_PJ, 0, 0}, {ME_PB, 0, 0, ME_PH, 1, 0},
+        {ME_PH, 0, 0, -1, 0, 0}, {ME_PH, 0, 0, ME_PJ, 0, 0}, {ME_PJ, 0, 0, -1, 0, 0}, {ME_PJ, 0, 0, ME_PH, 1, 0},
+        {ME_PH, 0, 0, ME_PF, 0, 1}, {ME_PH, 0, 0, ME_PB, 0, 1}, {ME_PJ, 0, 0, ME_PB, 0, 1}, {ME_PH, 1, 0, ME_PB, 0, 1}};
+
+/* direction codes, Codec/EbMotionEstimation.c:34-41 */
+enum { ME_D_TL = 0, ME_D_T = 1, ME_D_TR = 2, ME_D_R = 3, ME_D_BR = 4, ME_D_B = 5, ME_D_BL = 6, ME_D_L = 7 };
+
+/* which PUs are refined for the current list (half_pel_search_sb :1565-1702 gating) */
+SVT_DEV int me_pu_refined(const me_ctx_t *c, int pu, int en32, int en16, int en8) {
+    if (pu == 0) return c->p->fractional_search64x64;
+    if (pu < 5) return en32;
+    if (pu < 21) return en16 && c->p->cu16x16_mode == 0;
+    return en8 && c->p->cu8x8_mode != 1;
+}
+
+/* lanes cooperating on one candidate block (row-interleaved) */
+#define ME_SUB_LANES 8
+
+/* half-pel: task = (pu raster 0..84, cand 0..7, sub-lane).  Distortion accumulates in st->cand[pu*8+cand]
+ * (pre-zeroed).  SUB_SAD: rows 0,2,4.. only, doubled by the consumer; FULL_SAD: all rows. */
+SVT_DEV void ph_halfpel(const me_ctx_t *c, int tid, int list, int sox, int soy, int en32, int en16, int en8) {
+    const int sub_sad = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH;
+    for (int t = tid; t < 85 * 8 * ME_SUB_LANES; t += SVT_NT) {
+        int sl = t % ME_SUB_LANES, q = t / ME_SUB_LANES;
+        int cand = q & 7, pu = q >> 3;
+        if (!me_pu_refined(c, pu, en32, en16, en8)) continue;
+        int px, py, w;
+        me_pu_geom(pu, &px, &py, &w);
+        int      n  = me_pu_nidx(pu);
+        uint32_t mv = c->st->best_mv[list][n];
+        int      xs = (int16_t)((me_mvx(mv) >> 2) - (int16_t)sox) + px;
+        int      ys = (int16_t)((me_mvy(mv) >> 2) - (int16_t)soy) + py;
+        const int8_t  *e  = me_hcand[cand];
+        const uint8_t *cp = me_plane_at(c, e[0], xs + e[1], ys + e[2]);
+        const uint8_t *sp = c->src + py * ME_SB + px;
+        int            rows = sub_sad ? (w >> 1) : w, step = sub_sad ? 2 : 1;
+        /* rows split over ME_SUB_LANES lanes */
+        int per = (rows + ME_SUB_LANES - 1) / ME_SUB_LANES;
+        int r0 = sl * per, r1 = r0 + per < rows ? r0 + per : rows;
+        if (r0 >= r1) continue;
+        uint32_t d = me_block_sad_rows(sp, ME_SB * step, cp, 0, c->L.region_stride * step, w, r0, r1);
+        svt_lds_add_u32(&c->st->cand[pu * 8 + cand], d);
+    }
+}
+
+/* half-pel decision per PU: sequential strict '<' updates in test order, then direction with the tie
+ * order L,R,T,B,TL,TR,BL,BR (:1531-1556) */
+SVT_DEV void ph_halfpel_decide(const me_ctx_t *c, int tid, int list, int en32, int en16, int en8) {
+    const int sub_sad = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH;
+    for (int pu = tid; pu < 85; pu += SVT_NT) {
+        if (!me_pu_refined(c, pu, en32, en16, en8)) continue;
+        int      n    = me_pu_nidx(pu);
+        uint32_t best = c->st->best_sad[list][n], mv = c->st->best_mv[list][n];
+        int16_t  xm = me_mvx(mv), ym = me_mvy(mv);
+        uint32_t d[8];
+        for (int i = 0; i < 8; i++) {
+            d[i] = c->st->cand[pu * 8 + i];
+            if (sub_sad) d[i] <<= 1;
+            if (d[i] < best) { best = d[i]; mv = me_pack_mv(xm + me_hdmv[i][0], ym + me_hdmv[i][1]); }
+        }
+        uint32_t m = d[0];
+        for (int i = 1; i < 8; i++) if (d[i] < m) m = d[i];
+        uint8_t dir;
+        if (m == d[0]) dir = ME_D_L;
+        else if (m == d[1]) dir = ME_D_R;
+        else if (m == d[2]) dir = ME_D_T;
+        else if (m == d[3]) dir = ME_D_B;
+        else if (m == d[4]) dir = ME_D_TL;
+        else if (m == d[5]) dir = ME_D_TR;
+        else if (m == d[7]) dir = ME_D_BL;
+        else dir = ME_D_BR;
+        c->st->best_sad[list][n] = best;
+        c->st->best_mv[list][n]  = mv;
+        c->st->dir[n]            = dir;
+    }
+}
+
+SVT_DEV int me_qvalid(int in_half, int dir, int pos) {
+    /* pos: 0 L,1 R,2 T,3 B,4 TL,5 TR,6 BR,7 BL (:1761-1796) */
+    int v_tl, v_t, v_tr, v_r, v_br, v_b, v_bl, v_l;
+    if (in_half) {
+        v_tl = dir == ME_D_R || dir == ME_D_BR || dir == ME_D_B;
+        v_t  = dir == ME_D_BR || dir == ME_D_B || dir == ME_D_BL;
+        v_tr = dir == ME_D_B || dir == ME_D_BL || dir == ME_D_L;
+        v_r  = dir == ME_D_BL || dir == ME_D_L || dir == ME_D_TL;
+        v_br = dir == ME_D_L || dir == ME_D_TL || dir == ME_D_T;
+        v_b  = dir == ME_D_TL || dir == ME_D_T || dir == ME_D_TR;
+        v_bl = dir == ME_D_T || dir == ME_D_TR || dir == ME_D_R;
+        v_l  = dir == ME_D_TR || dir == ME_D_R || dir == ME_D_BR;
+    } else {
+        v_tl = dir == ME_D_L || dir == ME_D_TL || dir == ME_D_T;
+        v_t  = dir == ME_D_TL || dir == ME_D_T || dir == ME_D_TR;
+        v_tr = dir == ME_D_T || dir == ME_D_TR || dir == ME_D_R;
+        v_r  = dir == ME_D_TR || dir == ME_D_R || dir == ME_D_BR;
+        v_br = dir == ME_D_R || dir == ME_D_BR || dir == ME_D_B;
+        v_b  = dir == ME_D_BR || dir == ME_D_B || dir == ME_D_BL;
+        v_bl = dir == ME_D_B || dir == ME_D_BL || dir == ME_D_L;
+        v_l  = dir == ME_D_BL || dir == ME_D_L || dir == ME_D_TL;
+    }
+    switch (pos) {
+    case 0: return v_l; case 1: return v_r; case 2: return v_t; case 3: return v_b;
+    case 4: return v_tl; case 5: return v_tr; case 6: return v_br; default: return v_bl;
+    }
+}
+
+/* quarter-pel: task = (pu, pos 0..7, sub-lane); only valid positions are evaluated.
+ * [quirk] the 64x64 PU is evaluated on its top-left 32x32 (:2525-2526). */
+SVT_DEV void ph_quarterpel(const me_ctx_t *c, int tid, int list, int sox, int soy, int en32, int en16, int en8) {
+    const int sub_sad = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH;
+    for (int t = tid; t < 85 * 8 * ME_SUB_LANES; t += SVT_NT) {
+        int sl = t % ME_SUB_LANES, q = t / ME_SUB_LANES;
+        int pos = q & 7, pu = q >> 3;
+        if (!me_pu_refined(c, pu, en32, en16, en8)) continue;
+        int px, py, w;
+        me_pu_geom(pu, &px, &py, &w);
+        if (pu == 0) w = 32;
+        int      n  = me_pu_nidx(pu);
+        uint32_t mv = c->st->best_mv[list][n];
+        int16_t  xm = me_mvx(mv), ym = me_mvy(mv);
+        int      method = (ym & 2) + ((xm & 2) >> 1);
+        if (!me_qvalid(method != 0, c->st->dir[n], pos)) continue;
+        int xs = (int16_t)(((xm + 2) >> 2) - (int16_t)sox) + px;
+        int ys = (int16_t)(((ym + 2) >> 2) - (int16_t)soy) + py;
+        const int8_t  *e  = me_qtab[method][pos];
+        const uint8_t *a  = me_plane_at(c, e[0], xs + e[1], ys + e[2]);
+        const uint8_t *b  = me_plane_at(c, e[3], xs + e[4], ys + e[5]);
+        const uint8_t *sp = c->src + py * ME_SB + px;
+        int            rows = sub_sad ? (w >> 1) : w, step = sub_sad ? 2 : 1;
+        int            per = (rows + ME_SUB_LANES - 1) / ME_SUB_LANES;
+        int            r0 = sl * per, r1 = r0 + per < rows ? r0 + per : rows;
+        if (r0 >= r1) continue;
+        uint32_t d = me_block_sad_rows(sp, ME_SB * step, a, b, c->L.region_stride * step, w, r0, r1);
+        svt_lds_add_u32(&c->st->cand[pu * 8 + pos], d);
+    }
+}
+
+SVT_DEV void ph_quarterpel_decide(const me_ctx_t *c, int tid, int list, int en32, int en16, int en8) {
+    const int sub_sad = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH;
+    for (int pu = tid; pu < 85; pu += SVT_NT) {
+        if (!me_pu_refined(c, pu, en32, en16, en8)) continue;
+        int      n    = me_pu_nidx(pu);
+        uint32_t best = c->st->best_sad[list][n], mv = c->st->best_mv[list][n];
+        int16_t  xm = me_mvx(mv), ym = me_mvy(mv);
+        int      method = (ym & 2) + ((xm & 2) >> 1);
+        int      dir = c->st->dir[n];
+        for (int i = 0; i < 8; i++) {
+            if (!me_qvalid(method != 0, dir, i)) continue;
+            uint32_t d = c->st->cand[pu * 8 + i];
+            if (sub_sad) d <<= 1;
+            if (d < best) { best = d; mv = me_pack_mv(xm + me_qdmv[i][0], ym + me_qdmv[i][1]); }
+        }
+        c->st->best_sad[list][n] = best;
+        c->st->best_mv[list][n]  = mv;
+    }
+}
+
+/* Build the prediction block of the current list for every PU that takes part in bi-prediction
+ * (select_buffer :3310 / quarter_pel_compensation :3358): task = (pu, row).  Output pred[pu_off + r*w + x].
+ * Layout of pred blocks: pu 0 at 0 (64x64), 32x32 at 4096 + i*1024, 16x16 at 8192 + i*256, 8x8 at 12288 + i*64. */
+SVT_DEV int me_pu_bipred(const me_ctx_t *c, int pu) {
+    return (c->p->cu8x8_mode == 0 || pu < 21) && (c->p->cu16x16_mode == 0 || pu < 5);
+}
+/* one row of the prediction of `list` for pu at its best mv: 4 bytes at column 4*i */
+SVT_DEV uint32_t me_pred_dword(const me_ctx_t *c, int list, int sox, int soy, int pu, int r, int i) {
+    int px, py, w;
+    me_pu_geom(pu, &px, &py, &w);
+    uint32_t mv = c->st->best_mv[list][me_pu_nidx(pu)];
+    int16_t  mx = me_mvx(mv), my = me_mvy(mv);
+    int      xi = (int16_t)(mx >> 2) - (int16_t)sox + px;
+    int      yi = (int16_t)(my >> 2) - (int16_t)soy + py;
+    int      frac = ((uint8_t)mx & 3) + (((uint8_t)my & 3) << 2);
+    const int8_t  *e = me_btab[frac];
+    int            rs = c->L.region_stride;
+    const uint8_t *a = me_plane_at(c, e[0], xi + e[1], yi + e[2]) + r * rs + 4 * i;
+    uint32_t       va = me_ld32u(a);
+    if (e[3] >= 0) {
+        const uint8_t *b  = me_plane_at(c, e[3], xi + e[4], yi + e[5]) + r * rs + 4 * i;
+        uint32_t       vb = me_ld32u(b);
+        va = (va | vb) - (((va ^ vb) >> 1) & 0x7f7f7f7fu); /* (a + b + 1) >> 1 per byte */
+    }
+    return va;
+}
+/* dword-granular enumeration of the bi-pred blocks: t in [0, 1024*levels): level 0 = 64x64, 1 = 32x32 x4,
+ * 2 = 16x16 x16, 3 = 8x8 x64; byte offset inside pred0 = 4*t */
+SVT_DEV void me_bipred_task(int t, int *pu, int *r, int *i) {
+    int lv = t >> 10, o = t & 1023;
+    if (lv == 0) { *pu = 0; *r = o >> 4; *i = o & 15; }
+    else if (lv == 1) { *pu = 1 + (o >> 8); *r = (o & 255) >> 3; *i = o & 7; }
+    else if (lv == 2) { *pu = 5 + (o >> 6); *r = (o & 63) >> 2; *i = o & 3; }
+    else { *pu = 21 + (o >> 4); *r = (o & 15) >> 1; *i = o & 1; }
+}
+SVT_DEV int me_bipred_levels(const me_ctx_t *c) { return c->p->cu16x16_mode != 0 ? 2 : c->p->cu8x8_mode != 0 ? 3 : 4; }
+SVT_DEV void ph_store_pred0(const me_ctx_t *c, int tid, int sox, int soy) {
+    int n = 1024 * me_bipred_levels(c);
+    for (int t = tid; t < n; t += SVT_NT) {
+        int pu, r, i;
+        me_bipred_task(t, &pu, &r, &i);
+        *(uint32_t *)(c->pred0 + 4 * t) = me_pred_dword(c, 0, sox, soy, pu, r, i);
+    }
+}
+/* bi-pred distortion: avg-SAD of (list0 pred, list1 pred) vs source (bi_pred_averging :3466-3560) */
+SVT_DEV void ph_bipred(const me_ctx_t *c, int tid, int sox, int soy) {
+    const int sub_sad = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH;
+    int       n = 1024 * me_bipred_levels(c);
+    for (int t = tid; t < n; t += SVT_NT) {
+        int pu, r, i;
+        me_bipred_task(t, &pu, &r, &i);
+        if (sub_sad && (r & 1)) continue;
+        int px, py, w;
+        me_pu_geom(pu, &px, &py, &w);
+        uint32_t s  = *(const uint32_t *)(c->src + (py + r) * ME_SB + px + 4 * i);
+        uint32_t va = *(const uint32_t *)(c->pred0 + 4 * t), vb = me_pred_dword(c, 1, sox, soy, pu, r, i);
+        uint32_t av = (va | vb) - (((va ^ vb) >> 1) & 0x7f7f7f7fu);
+        svt_lds_add_u32(&c->st->cand[pu], svt_sad4(av, s, 0));
+    }
+}
+
+/* candidate ordering + result record (Codec/EbMotionEstimation.c:5186-5293), one thread per PU */
+SVT_DEV void ph_output(const me_ctx_t *c, int tid, svt_me_pu_result *out, uint32_t *out_words) {
+    const int sub_sad = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH;
+    const int nlist   = c->p->num_ref_lists;
+    (void)out;
+    for (int pu = tid; pu < 85; pu += SVT_NT) {
+        int      n = me_pu_nidx(pu);
+        int      total = nlist;
+        uint32_t l0 = c->st->best_sad[0][n], l1 = nlist == 2 ? c->st->best_sad[1][n] : 0, bi = 0;
+        if (nlist == 2 && me_pu_bipred(c, pu)) {
+            bi = c->st->cand[pu];
+            if (sub_sad) bi <<= 1;
+            total = 3;
+        }
+        uint32_t w[10];
+        uint32_t mv0 = c->st->best_mv[0][n], mv1 = nlist == 2 ? c->st->best_mv[1][n] : 0;
+        w[0] = mv0;
+        w[1] = mv1;
+        for (int i = 2; i < 10; i++) w[i] = 0;
+        if (total == 3) {
+            uint32_t v[3] = {l0, l1, bi};
+            int      o[3];
+            if (l0 <= l1 && l0 <= bi) { o[0] = 0; if (l1 <= bi) { o[1] = 1; o[2] = 2; } else { o[1] = 2; o[2] = 1; } }
+            else if (l1 <= l0 && l1 <= bi) { o[0] = 1; if (l0 <= bi) { o[1] = 0; o[2] = 2; } else { o[1] = 2; o[2] = 0; } }
+            else if (l0 <= l1) { o[0] = 2; o[1] = 0; o[2] = 1; }
+            else { o[0] = 2; o[1] = 1; o[2] = 0; }
+            for (int i = 0; i < 3; i++) { w[2 + 2 * i] = v[o[i]]; w[3 + 2 * i] = (uint32_t)o[i]; }
+        } else if (total == 2) {
+            if (l0 <= l1) { w[2] = l0; w[3] = 0; w[4] = l1; w[5] = 1; }
+            else { w[2] = l1; w[3] = 1; w[4] = l0; w[5] = 0; }
+        } else {
+            w[2] = l0; w[3] = 0;
+        }
+        w[8] = (uint32_t)total;
+        for (int i = 0; i < 10; i++) out_words[pu * 10 + i] = w[i];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* driver: uniform control flow; PHASE(x) runs x for every thread and ends with a workgroup barrier     */
+/* ------------------------------------------------------------------------------------------------ */
+#ifdef SVT_HOST_EMU
+#define ME_PHASE(...) do { for (int tid = 0; tid < SVT_NT; tid++) { __VA_ARGS__; } } while (0)
+#define ME_UNIFORM_WRITE(...) do { __VA_ARGS__; } while (0)
+#else
+#define ME_PHASE(...) do { __VA_ARGS__; __syncthreads(); } while (0)
+/* uniform state written to LDS by one thread, followed by a barrier */
+#define ME_UNIFORM_WRITE(...) do { if (tid == 0) { __VA_ARGS__; } __syncthreads(); } while (0)
+#endif
+
+typedef struct me_hme_geom {
+    const svt_plane *ref;
+    const uint8_t   *blk; /* LDS */
+    int              bstride, bw, bh, ox, oy, pad_w, pad_h;
+} me_hme_geom;
+
+/* one HME search: window placement (hme_level0/1/2), LDS staging, exhaustive search, scaling */
+#ifdef SVT_HOST_EMU
+static inline
+#else
+__device__
+#endif
+void me_hme_search(const me_ctx_t *c, int tid_, const me_hme_geom *g, int16_t sa_ox, int16_t sa_oy, int16_t sa_w, int16_t sa_h,
+                   int floor16, uint64_t *best_sad, int16_t *xc, int16_t *yc, int scale) {
+    int tid = tid_;
+    (void)tid;
+    me_clip_area(g->ox, &sa_ox, &sa_w, g->pad_w, g->ref->width);
+    me_clip_area(g->oy, &sa_oy, &sa_h, g->pad_h, g->ref->height);
+    if (floor16 && (sa_w & 15) != 0) sa_w = (int16_t)((sa_w >> 4) << 4);
+    uint64_t sad = 0xffffff;
+    int16_t  x = *xc, y = *yc;
+    if (sa_w > 0 && sa_h > 0) {
+        /* window: columns [0, sa_w + bw + 3), rows [0, sa_h + 2*(bh-1)]; staged in row bands that fit the scratch */
+        int wbytes  = sa_w + g->bw + 3;
+        int wstride = ((wbytes + 3) & ~3) + 4;
+        if (((wstride >> 2) & 1) == 0) wstride += 4;
+        int span      = 2 * (g->bh - 1);                 /* extra rows needed below a search row */
+        int max_rows  = c->L.scratch_bytes / wstride;    /* rows that fit */
+        int band_rows = max_rows - span;                 /* search rows per band */
+        if (band_rows > sa_h) band_rows = sa_h;
+        ME_UNIFORM_WRITE(c->st->hme_key = ~0ull);
+        for (int y0 = 0; y0 < sa_h; y0 += band_rows) {
+            int nr = y0 + band_rows <= sa_h ? band_rows : sa_h - y0;
+            ME_PHASE(ph_load_rect(tid, c->planes, wstride, me_pix(g->ref, g->ox + sa_ox, g->oy + sa_oy + y0), g->ref->stride, wbytes, nr + span));
+            /* keys inside a band are relative to the band; fold the band offset in through a second min stage */
+            ME_PHASE(ph_sad_search(c, tid, g->blk, g->bstride, g->bw, g->bh, c->planes, wstride, sa_w, nr, 2));
+            /* convert the band-relative index to a global raster index: done by keeping per-band best */
+            uint64_t k = c->st->hme_key;
+            if (k != ~0ull) {
+                uint32_t idx = (uint32_t)k, s = (uint32_t)(k >> 32);
+                uint64_t kk  = ((uint64_t)s << 32) | (uint32_t)(idx + y0 * sa_w);
+                /* bands are visited in increasing y, a later band only wins with a strictly smaller SAD */
+                if (s < sad) { sad = s; x = (int16_t)((kk & 0xffffffffu) % (uint32_t)sa_w); y = (int16_t)((kk & 0xffffffffu) / (uint32_t)sa_w); }
+            }
+            ME_PHASE((void)0);
+            ME_UNIFORM_WRITE(c->st->hme_key = ~0ull);
+        }
+    }
+    *best_sad = sad * 2;
+    x = (int16_t)(x + sa_ox); x = (int16_t)(x * scale);
+    y = (int16_t)(y + sa_oy); y = (int16_t)(y * scale);
+    *xc = x; *yc = y;
+}
+
+SVT_DEV int16_t me_hme_round_w(int16_t w) { return (int16_t)((w < 8) ? 8 : (w & 7) ? w + (w - ((w >> 3) << 3)) : w); }
+
+/* Codec/EbDefinitions.h:989-1005 */
+__attribute__((unused)) static
+#ifndef SVT_HOST_EMU
+    __device__
+#endif
+    const int32_t me_hme_l0_mult[6][6] = {{100, 0, 0, 0, 0, 0},       {100, 100, 0, 0, 0, 0},
+                                          {100, 100, 100, 0, 0, 0},   {200, 140, 100, 70, 0, 0},
+                                          {350, 200, 100, 100, 100, 0}, {525, 350, 200, 100, 100, 100}};
+
+#ifdef SVT_HOST_EMU
+static inline
+#else
+__device__
+#endif
+void me_sb_run(const me_ctx_t *c, int tid_) {
+    int tid = tid_;
+    (void)tid;
+    const svt_me_params *p  = c->p;
+    me_state_t          *st = c->st;
+    const int            nlist = p->num_ref_lists;
+    const int            NW = p->number_hme_search_region_in_width, NH = p->number_hme_search_region_in_height;
+    int16_t  xl0[2][2] = {{0, 0}, {0, 0}}, yl0[2][2] = {{0, 0}, {0, 0}}, xl1[2][2] = {{0, 0}, {0, 0}}, yl1[2][2] = {{0, 0}, {0, 0}};
+    int16_t  xl2[2][2] = {{0, 0}, {0, 0}}, yl2[2][2] = {{0, 0}, {0, 0}};
+    uint64_t sl0[2][2] = {{0, 0}, {0, 0}}, sl1[2][2] = {{0, 0}, {0, 0}}, sl2[2][2] = {{0, 0}, {0, 0}};
+    int      rw = 0, rh = 0;
+    int16_t  x_hme_c = 0, y_hme_c = 0, xsc = 0, ysc = 0;
+
+    ME_PHASE(ph_init(c, tid));
+
+    for (int list = 0; list < nlist; list++) {
+        const svt_plane *rf = &c->pic->ref[list].full, *rq = &c->pic->ref[list].quarter, *r16 = &c->pic->ref[list].sixteenth;
+        const int        ox = (int16_t)c->sb_x, oy = (int16_t)c->sb_y;
+        if (p->temporal_layer_index > 0 || list == 0) {
+            /* ---- test_search_area_bounds ---- */
+            {
+                const int pad = ME_SB - 1, W = rf->width, H = rf->height;
+                const int tw = p->hme_level0_total_search_area_width, th = p->hme_level0_total_search_area_height;
+                int16_t   dx[5], dy[5];
+                dx[0] = 0; dy[0] = 0;
+                dx[1] = me_clip_center(ox, (int16_t)tw, pad, W); dy[1] = me_clip_center(oy, 0, pad, H);
+                dx[2] = me_clip_center(ox, 0, pad, W); dy[2] = me_clip_center(oy, (int16_t)(0 - th), pad, H);
+                dx[3] = me_clip_center(ox, 0, pad, W); dy[3] = me_clip_center(oy, (int16_t)th, pad, H);
+                int16_t dirx = 0, diry = 0;
+                int     nc = 4;
+                if (list == 1) {
+                    dirx = (int16_t)(0 - (me_mvx(st->best_mv[0][0]) >> 2));
+                    diry = (int16_t)(0 - (me_mvy(st->best_mv[0][0]) >> 2));
+                    dx[4] = me_clip_center(ox, dirx, pad, W); dy[4] = me_clip_center(oy, diry, pad, H);
+                    nc = 5;
+                }
+                ME_PHASE(if (tid < 8) st->red[tid] = 0);
+                ME_PHASE(ph_center_sads(c, tid, rf, nc, dx, dy));
+                uint64_t zero_c = (uint64_t)st->red[0] << 1, b_c = (uint64_t)st->red[1] << 1, c_c = (uint64_t)st->red[2] << 1,
+                         d_c = (uint64_t)st->red[3] << 1;
+                uint64_t a_c = zero_c; /* [quirk] A is evaluated at the zero-MV address (:4302-4327) */
+                uint64_t dir_c = list == 1 ? (uint64_t)st->red[4] << 1 : 0xFFFFFFFFFFFFFull;
+                uint64_t best = zero_c;
+                if (a_c < best) best = a_c;
+                if (b_c < best) best = b_c;
+                if (c_c < best) best = c_c;
+                if (d_c < best) best = d_c;
+                if (dir_c < best) best = dir_c;
+                if (best == zero_c) { xsc = 0; ysc = 0; }
+                else if (best == a_c) { xsc = (int16_t)(0 - tw); ysc = 0; }
+                else if (best == b_c) { xsc = (int16_t)tw; ysc = 0; }
+                else if (best == c_c) { xsc = 0; ysc = (int16_t)(0 - th); }
+                else if (best == dir_c) { xsc = list ? dirx : 0; ysc = list ? diry : 0; }
+                else { xsc = 0; ysc = (int16_t)th; }
+                ME_PHASE((void)0); /* everyone has read red[] */
+            }
+            /* ---- HME ---- */
+            if (p->enable_hme_flag && c->sb_h == ME_SB) {
+                while (rh < NH) {
+                    while (rw < NW) {
+                        xl0[rw][rh] = (int16_t)(xsc >> 2); yl0[rw][rh] = (int16_t)(ysc >> 2);
+                        xl1[rw][rh] = (int16_t)(xsc >> 1); yl1[rw][rh] = (int16_t)(ysc >> 1);
+                        xl2[rw][rh] = xsc; yl2[rw][rh] = ysc;
+                        rw++;
+                    }
+                    rw = 0; rh++;
+                }
+                const int mult = me_hme_l0_mult[p->hierarchical_levels][p->temporal_layer_index];
+                if (p->enable_hme_level_0_flag) {
+                    me_hme_geom g = {r16, st->sixteenth_sb, 16, c->sb_w >> 2, (c->sb_h >> 2) >> 1, (int16_t)(c->sb_x >> 2),
+                                     (int16_t)(c->sb_y >> 2), r16->origin_x - 1, r16->origin_y - 1};
+                    if (p->single_hme_quadrant && !p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag) {
+                        rh = 0; rw = 0;
+                        int16_t w = (int16_t)((p->hme_level0_total_search_area_width * mult) / 100);
+                        int16_t h = (int16_t)((p->hme_level0_total_search_area_height * mult) / 100);
+                        int16_t sx = (int16_t)(-(int16_t)(w >> 1) + (int16_t)(xsc >> 2));
+                        int16_t sy = (int16_t)(-(int16_t)(h >> 1) + (int16_t)(ysc >> 2));
+                        me_hme_search(c, tid, &g, sx, sy, w, h, 1, &sl0[0][0], &xl0[0][0], &yl0[0][0], 4);
+                    } else {
+                        rh = 0; rw = 0;
+                        while (rh < NH) {
+                            while (rw < NW) {
+                                int16_t w = (int16_t)((p->hme_level0_search_area_in_width_array[rw] * mult) / 100);
+                                int16_t h = (int16_t)((p->hme_level0_search_area_in_height_array[rh] * mult) / 100);
+                                int16_t ddx = (int16_t)(xsc >> 2), ddy = (int16_t)(ysc >> 2);
+                                for (int k = rw; k > 0; k--) ddx = (int16_t)(ddx + (int16_t)((p->hme_level0_search_area_in_width_array[k - 1] * mult) / 100));
+                                for (int k = rh; k > 0; k--) ddy = (int16_t)(ddy + (int16_t)((p->hme_level0_search_area_in_height_array[k - 1] * mult) / 100));
+                                int16_t sx = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_width * mult) / 100) >> 1) + ddx);
+                                int16_t sy = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_height * mult) / 100) >> 1) + ddy);
+                                me_hme_search(c, tid, &g, sx, sy, w, h, 0, &sl0[rw][rh], &xl0[rw][rh], &yl0[rw][rh], 4);
+                                rw++;
+                            }
+                            rw = 0; rh++;
+                        }
+                    }
+                }
+                if (p->enable_hme_level_1_flag) {
+                    me_hme_geom g = {rq, st->quarter_sb, 64, c->sb_w >> 1, (c->sb_h >> 1) >> 1, (int16_t)(c->sb_x >> 1),
+                                     (int16_t)(c->sb_y >> 1), rq->origin_x - 1, rq->origin_y - 1};
+                    rh = 0; rw = 0;
+                    while (rh < NH) {
+                        while (rw < NW) {
+                            int16_t w = me_hme_round_w((int16_t)p->hme_level1_search_area_in_width_array[rw]);
+                            int16_t h = (int16_t)p->hme_level1_search_area_in_height_array[rh];
+                            int16_t sx = (int16_t)(-(w >> 1) + (int16_t)(xl0[rw][rh] >> 1));
+                            int16_t sy = (int16_t)(-(h >> 1) + (int16_t)(yl0[rw][rh] >> 1));
+                            me_hme_search(c, tid, &g, sx, sy, w, h, 0, &sl1[rw][rh], &xl1[rw][rh], &yl1[rw][rh], 2);
+                            rw++;
+                        }
+                        rw = 0; rh++;
+                    }
+                }
+                if (p->enable_hme_level_2_flag) {
+                    me_hme_geom g = {rf, c->src, 2 * ME_SB, c->sb_w, c->sb_h >> 1, (int16_t)c->sb_x, (int16_t)c->sb_y, ME_SB - 1, ME_SB - 1};
+                    rh = 0; rw = 0;
+                    while (rh < NH) {
+                        while (rw < NW) {
+                            int16_t w = me_hme_round_w((int16_t)p->hme_level2_search_area_in_width_array[rw]);
+                            int16_t h = (int16_t)p->hme_level2_search_area_in_height_array[rh];
+                            int16_t sx = (int16_t)(-(w >> 1) + xl1[rw][rh]);
+                            int16_t sy = (int16_t)(-(h >> 1) + yl1[rw][rh]);
+                            me_hme_search(c, tid, &g, sx, sy, w, h, 0, &sl2[rw][rh], &xl2[rw][rh], &yl2[rw][rh], 1);
+                            rw++;
+                        }
+                        rw = 0; rh++;
+                    }
+                }
+                uint64_t hme_sad = 0;
+                if (p->enable_hme_level_0_flag && !p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag) {
+                    x_hme_c = xl0[0][0]; y_hme_c = yl0[0][0]; hme_sad = sl0[0][0];
+                    if (!p->single_hme_quadrant) {
+                        rw = 1; rh = 0;
+                        while (rh < NH) {
+                            while (rw < NW) {
+                                if (sl0[rw][rh] < hme_sad) { x_hme_c = xl0[rw][rh]; y_hme_c = yl0[rw][rh]; hme_sad = sl0[rw][rh]; }
+                                rw++;
+                            }
+                            rw = 0; rh++;
+                        }
+                    }
+                }
+                if (p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag) {
+                    x_hme_c = xl1[0][0]; y_hme_c = yl1[0][0]; hme_sad = sl1[0][0];
+                    rw = 1; rh = 0;
+                    while (rh < NH) {
+                        while (rw < NW) {
+                            if (sl1[rw][rh] < hme_sad) { x_hme_c = xl1[rw][rh]; y_hme_c = yl1[rw][rh]; hme_sad = sl1[rw][rh]; }
+                            rw++;
+                        }
+                        rw = 0; rh++;
+                    }
+                }
+                if (p->enable_hme_level_2_flag) {
+                    x_hme_c = xl2[0][0]; y_hme_c = yl2[0][0]; hme_sad = sl2[0][0];
+                    rw = 1; rh = 0;
+                    while (rh < NH) {
+                        while (rw < NW) {
+                            if (sl2[rw][rh] < hme_sad) { x_hme_c = xl2[rw][rh]; y_hme_c = yl2[rw][rh]; hme_sad = sl2[rw][rh]; }
+                            rw++;
+                        }
+                        rw = 0; rh++;
+                    }
+                    int nq = NW, tot = NH * NW;
+                    if (p->same_ref_poc && list == 1 && tot > 1) {
+                        for (int q = 0; q < tot - 1; q++)
+                            for (int n = q + 1; n < tot; n++)
+                                if (sl2[q / nq][q % nq] > sl2[n / nq][n % nq]) {
+                                    int16_t  tx = xl2[q / nq][q % nq], ty = yl2[q / nq][q % nq];
+                                    uint64_t td = sl2[q / nq][q % nq];
+                                    xl2[q / nq][q % nq] = xl2[n / nq][n % nq]; yl2[q / nq][q % nq] = yl2[n / nq][n % nq];
+                                    sl2[q / nq][q % nq] = sl2[n / nq][n % nq];
+                                    xl2[n / nq][n % nq] = tx; yl2[n / nq][n % nq] = ty; sl2[n / nq][n % nq] = td;
+                                }
+                        x_hme_c = xl2[0][1]; y_hme_c = yl2[0][1];
+                    }
+                }
+                xsc = x_hme_c; ysc = y_hme_c;
+            }
+        } else {
+            xsc = 0; ysc = 0;
+        }
+
+        int16_t saw = (int16_t)(p->search_area_width < 127 ? p->search_area_width : 127);
+        int16_t sah = (int16_t)(p->search_area_height < 127 ? p->search_area_height : 127);
+        if (xsc != 0 || ysc != 0) {
+            /* ---- check_zero_zero_center ---- */
+            int16_t dx[2], dy[2];
+            xsc = me_clip_center(ox, xsc, ME_SB - 1, rf->width);
+            ysc = me_clip_center(oy, ysc, ME_SB - 1, rf->height);
+            dx[0] = 0; dy[0] = 0; dx[1] = xsc; dy[1] = ysc;
+            ME_PHASE(if (tid < 8) st->red[tid] = 0);
+            ME_PHASE(ph_center_sads(c, tid, rf, 2, dx, dy));
+            uint64_t z = (uint64_t)st->red[0] << 1, h = (uint64_t)st->red[1] << 1;
+            uint64_t m = z < h ? z : h;
+            if (m == z) { xsc = 0; ysc = 0; }
+            ME_PHASE((void)0);
+        }
+        int16_t sox = (int16_t)(xsc - (saw >> 1)), soy = (int16_t)(ysc - (sah >> 1));
+        me_clip_area(ox, &sox, &saw, ME_SB - 1, c->pic_w);
+        me_clip_area(oy, &soy, &sah, ME_SB - 1, c->pic_h);
+        const int W = saw + ME_SB - 1, H = sah + ME_SB - 1;
+        const int w8 = saw - (saw & 7);
+        const int tail_extra = (saw & 7) ? 16 : 0;
+
+        /* ---- stage the search region (+ halo) of this list in LDS ---- */
+        ME_PHASE(ph_load_rect(tid, c->region, c->L.region_stride, me_pix(rf, c->sb_x + sox - ME_RGN_GX, c->sb_y + soy - ME_RGN_GY),
+                              rf->stride, W + ME_RGN_GX + 4 + tail_extra, H + 2 * ME_RGN_GY + 1);
+                 for (int t = tid; t < 85; t += SVT_NT) st->key[t] = ((uint64_t)ME_MAX_SAD_VALUE << 32);
+                 );
+
+        /* ---- full-pel search, in chunks of search rows ---- */
+        {
+            int max_pos   = c->L.scratch_bytes / 128; /* s8: 64 x u16 per position */
+            int rows_chunk = max_pos / saw;
+            if (rows_chunk < 1) rows_chunk = 1;
+            if (rows_chunk > sah) rows_chunk = sah;
+            uint16_t *s8 = (uint16_t *)c->planes;
+            for (int y0 = 0; y0 < sah; y0 += rows_chunk) {
+                int ny = y0 + rows_chunk <= sah ? rows_chunk : sah - y0;
+                int npos = ny * saw;
+                int nslice = npos >= 96 ? 3 : 1;
+                if (npos >= 1024) nslice = 12;
+                ME_PHASE(ph_fullpel_sad8(c, tid, s8, saw, y0, ny, w8));
+                ME_PHASE(ph_fullpel_argmin(c, tid, s8, saw, y0, ny, w8, nslice));
+            }
+            /* keys -> best sad / mv (curr_mv = (y << 18) | (uint16)(x << 2), :108-110) */
+            ME_PHASE(for (int t = tid; t < 85; t += SVT_NT) {
+                uint64_t k = st->key[t];
+                uint32_t idx = (uint32_t)k;
+                st->best_sad[list][t] = (uint32_t)(k >> 32);
+                if ((uint32_t)(k >> 32) != (uint32_t)ME_MAX_SAD_VALUE) {
+                    int xi = (int)(idx % (uint32_t)saw) + sox, yi = (int)(idx / (uint32_t)saw) + soy;
+                    st->best_mv[list][t] = (((uint32_t)(uint16_t)yi) << 18) | (uint16_t)((uint16_t)xi << 2);
+                }
+            });
+        }
+
+        /* ---- sub-pel ---- */
+        int en32 = 0, en16 = 0, en8 = 0, enq = 0;
+        if (p->fractional_search_model == 0) { en32 = en16 = en8 = enq = 1; }
+        else if (p->fractional_search_model == 1) {
+            /* su_pel_enable (:3839-4258): average MV magnitude / SAD per size class */
+            int      sx = 0, sy = 0;
+            uint32_t ss = 0;
+            for (int i = 1; i <= 4; i++) { sx += me_mvx(st->best_mv[list][i]); sy += me_mvy(st->best_mv[list][i]); ss += st->best_sad[list][i]; }
+            uint32_t ax = (uint32_t)(sx >> 2), ay = (uint32_t)(sy >> 2);
+            uint32_t mag32 = ax * ax + ay * ay, sad32 = ss >> 2;
+            sx = sy = 0; ss = 0;
+            for (int i = 5; i <= 20; i++) { sx += me_mvx(st->best_mv[list][i]); sy += me_mvy(st->best_mv[list][i]); ss += st->best_sad[list][i]; }
+            ax = (uint32_t)(sx >> 4); ay = (uint32_t)(sy >> 4);
+            uint32_t mag16 = ax * ax + ay * ay, sad16 = ss >> 4;
+            sx = sy = 0; ss = 0;
+            for (int i = 21; i < 85; i++) { sx += me_mvx(st->best_mv[list][i]); sy += me_mvy(st->best_mv[list][i]); ss += st->best_sad[list][i]; }
+            ax = (uint32_t)(sx >> 6); ay = (uint32_t)(sy >> 6);
+            uint32_t mag8 = ax * ax + ay * ay, sad8 = ss >> 6;
+            const int thr_[4]    = {48, 32, 80, 48};
+            const int t32_[4][4] = {{1, 0, 1, 0}, {1, 0, 1, 1}, {1, 0, 1, 0}, {1, 1, 1, 0}};
+            const int t16_[4]    = {0, 1, 0, 1};
+            const int t8_[4][4]  = {{0, 1, 0, 1}, {0, 1, 0, 1}, {0, 1, 0, 1}, {0, 1, 0, 0}};
+            int       tl = p->temporal_layer_index > 3 ? 3 : p->temporal_layer_index;
+            uint32_t  t2 = (uint32_t)(thr_[tl] * thr_[tl]);
+            en32 = t32_[tl][2 * !(mag32 < t2) + !(sad32 < 32 * 32 * 6)];
+            en16 = t16_[2 * !(mag16 < t2) + !(sad16 < 16 * 16 * 2)];
+            en8  = t8_[tl][2 * !(mag8 < t2) + !(sad8 < 8 * 8 * 2)];
+            enq  = 1;
+        }
+        const int need_planes = en32 || en16 || en8 || enq || (nlist == 2);
+        if (need_planes) {
+            ME_PHASE(ph_interp_bh(c, tid, W, H));
+            ME_PHASE(ph_interp_j(c, tid, W, H));
+        }
+        if (en32 || en16 || en8 || enq) {
+            ME_PHASE(for (int t = tid; t < 85 * 8; t += SVT_NT) st->cand[t] = 0);
+            ME_PHASE(ph_halfpel(c, tid, list, sox, soy, en32, en16, en8));
+            ME_PHASE(ph_halfpel_decide(c, tid, list, en32, en16, en8));
+            if (enq) {
+                ME_PHASE(for (int t = tid; t < 85 * 8; t += SVT_NT) st->cand[t] = 0);
+                ME_PHASE(ph_quarterpel(c, tid, list, sox, soy, en32, en16, en8));
+                ME_PHASE(ph_quarterpel_decide(c, tid, list, en32, en16, en8));
+            }
+        }
+        if (nlist == 2) {
+            if (list == 0) ME_PHASE(ph_store_pred0(c, tid, sox, soy));
+            else {
+                ME_PHASE(for (int t = tid; t < 85; t += SVT_NT) st->cand[t] = 0);
+                ME_PHASE(ph_bipred(c, tid, sox, soy));
+            }
+        }
+    }
+
+    /* ---- results ---- */
+    uint32_t *ow = (uint32_t *)c->planes;
+    ME_PHASE(ph_output(c, tid, 0, ow));
+    {
+        uint32_t *g = (uint32_t *)(c->pic->results + (size_t)c->sb_index * 85);
+#ifdef SVT_HOST_EMU
+        for (int t = 0; t < 850; t++) g[t] = ow[t];
+#else
+        for (int t = tid; t < 850; t += SVT_NT) g[t] = ow[t];
+#endif
+        if (c->pic->rcme && tid == 0) {
+            uint32_t acc = 0;
+            for (int i = 0; i < 16; i++) acc += ow[(5 + i) * 10 + 2];
+            c->pic->rcme[c->sb_index] = acc;
+        }
+    }
+}
+
+#endif /* SVT_ME_CORE_H */

@@ -1,0 +1,195 @@
+/*
+ * me_kernel.hip -- gfx950 kernels for the motion-estimation path and their launchers.
+ * The per-SB algorithm lives in me_core.h (shared verbatim with the CPU test emulation).
+ */
+#include <hip/hip_runtime.h>
+#include "me_core.h"
+#include "me_layout.h"
+#include "svt_ctx.h"
+
+extern __shared__ __align__(16) uint8_t svt_lds[];
+
+/* One workgroup per (picture, SB).  blockIdx -> work item mapping is XCD-aware: consecutive work items
+ * (neighbouring SBs, which share most of their reference window) are placed on the same XCD so that the
+ * window re-reads hit that XCD's L2 (block b runs on XCD b % 8). */
+__global__ __launch_bounds__(256) void svt_me_sb_kernel(const me_pic_dev *__restrict__ pics, svt_me_params p, me_lds_layout L,
+                                                        int n_sb, int nx, int pic_w, int pic_h, int total, int chunk) {
+    const int b = blockIdx.x;
+    const int l = (b & 7) * chunk + (b >> 3);
+    if (l >= total) return;
+    const int pic = l / n_sb, sb = l - pic * n_sb;
+    me_ctx_t  c;
+    c.pic = &pics[pic];
+    c.p   = &p;
+    c.L   = L;
+    c.lds = svt_lds;
+    c.st     = (me_state_t *)(svt_lds + L.off_state);
+    c.src    = svt_lds + L.off_src;
+    c.region = svt_lds + L.off_region;
+    c.planes = svt_lds + L.off_planes;
+    c.pred0  = svt_lds + L.off_pred0;
+    c.pic_w = pic_w; c.pic_h = pic_h; c.sb_index = sb;
+    c.sb_x = (sb % nx) * ME_SB; c.sb_y = (sb / nx) * ME_SB;
+    c.sb_w = (pic_w - c.sb_x) < ME_SB ? pic_w - c.sb_x : ME_SB;
+    c.sb_h = (pic_h - c.sb_y) < ME_SB ? pic_h - c.sb_y : ME_SB;
+    me_sb_run(&c, threadIdx.x);
+}
+
+/* Stand-alone exhaustive SAD search = eb_vp9_sad_loop_kernel (C_DEFAULT/EbComputeSAD_C.c:132-169), one
+ * workgroup per job; block and window are staged in LDS, the search is ph_sad_search. */
+__global__ __launch_bounds__(256) void svt_sad_loop_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ ref,
+                                                           const svt_sad_loop_job *__restrict__ jobs, int n_jobs,
+                                                           svt_sad_loop_result *__restrict__ out, int lds_bytes) {
+    const int j = blockIdx.x;
+    if (j >= n_jobs) return;
+    const svt_sad_loop_job job = jobs[j];
+    const int              tid = threadIdx.x;
+    me_ctx_t               c;
+    me_state_t            &st_s = *(me_state_t *)svt_lds;
+    c.st = &st_s;
+    /* block rows: stride rounded to dwords */
+    const int bstride = (job.width + 3) & ~3;
+    uint8_t  *blk     = svt_lds + ((sizeof(me_state_t) + 15) & ~(size_t)15);
+    uint8_t  *win     = blk + ((bstride * job.height + 15) & ~15);
+    const int wbytes  = job.search_w + job.width + 3;
+    int       wstride = ((wbytes + 3) & ~3) + 4;
+    if (((wstride >> 2) & 1) == 0) wstride += 4;
+    /* a search row y uses reference rows y*raw + j*ref_stride; the LDS window keeps rows at unit pitch
+       `raw`, which requires ref_stride to be a multiple of ref_stride_raw (2 in every reference use) */
+    const int mul      = job.ref_stride / job.ref_stride_raw;
+    const int span     = mul * (job.height - 1);
+    const int avail    = (lds_bytes - (int)(win - svt_lds)) / wstride;
+    int       band     = avail - span;
+    if (band > job.search_h) band = job.search_h;
+    uint64_t  sad = 0xffffff;
+    int       bx = 0, by = 0;
+    ph_load_rect(tid, blk, bstride, src + job.src_off, job.src_stride, job.width, job.height);
+    if (tid == 0) st_s.hme_key = ~0ull;
+    __syncthreads();
+    for (int y0 = 0; y0 < job.search_h && band > 0; y0 += band) {
+        const int nr = y0 + band <= job.search_h ? band : job.search_h - y0;
+        ph_load_rect(tid, win, wstride, ref + job.ref_off + (ptrdiff_t)y0 * job.ref_stride_raw, job.ref_stride_raw, wbytes, nr + span);
+        __syncthreads();
+        ph_sad_search(&c, tid, blk, bstride, job.width, job.height, win, wstride, job.search_w, nr, mul);
+        __syncthreads();
+        const uint64_t k = st_s.hme_key;
+        if (k != ~0ull) {
+            const uint32_t s = (uint32_t)(k >> 32), idx = (uint32_t)k + (uint32_t)(y0 * job.search_w);
+            if (s < sad) { sad = s; bx = (int)(idx % (uint32_t)job.search_w); by = (int)(idx / (uint32_t)job.search_w); }
+        }
+        __syncthreads();
+        if (tid == 0) st_s.hme_key = ~0ull;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[j].best_sad = (uint32_t)sad;
+        out[j].x = (int16_t)bx;
+        out[j].y = (int16_t)by;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* launchers                                                                                          */
+/* ------------------------------------------------------------------------------------------------ */
+extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture *cur,
+                                           const svt_pa_picture *ref0, const svt_pa_picture *ref1,
+                                           const svt_me_params *params, svt_me_pu_result *const *d_results,
+                                           uint32_t *const *d_rcme) {
+    if (!ctx || !cur || !ref0 || !params || !d_results || n_pics < 1) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: null argument");
+    if (params->num_ref_lists < 1 || params->num_ref_lists > 2) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: num_ref_lists");
+    if (params->num_ref_lists == 2 && !ref1) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: ref1 missing for B picture");
+    if (params->fractional_search_method == SVT_SSD_SEARCH)
+        return svt_set_error(SVT_HIP_ERR_UNSUPPORTED, "me: SSD fractional search (enc_mode <= 4) not implemented yet");
+    if (params->hierarchical_levels > 5 || params->temporal_layer_index > 5 || params->number_hme_search_region_in_width > 2 ||
+        params->number_hme_search_region_in_height > 2)
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: parameter out of range");
+    me_lds_layout L;
+    if (me_lds_layout_compute(params, &L)) return svt_set_error(SVT_HIP_ERR_UNSUPPORTED, "me: search area does not fit in LDS");
+    const int W = cur[0].full.width, H = cur[0].full.height;
+    if (W < 64 || H < 64 || (W & 7) || (H & 7)) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: picture size");
+    const int nx = (W + 63) / 64, ny = (H + 63) / 64, n_sb = nx * ny;
+    HIP_TRY(hipSetDevice(ctx->device));
+    /* picture descriptors -> device (pinned staging ring so that the copy is truly asynchronous) */
+    me_pic_dev *h = (me_pic_dev *)svt_ctx_host_scratch(ctx, sizeof(me_pic_dev) * (size_t)n_pics);
+    me_pic_dev *d = (me_pic_dev *)svt_ctx_dev_scratch(ctx, sizeof(me_pic_dev) * (size_t)n_pics);
+    if (!h || !d) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "me: descriptor buffers");
+    for (int i = 0; i < n_pics; i++) {
+        if (cur[i].full.width != W || cur[i].full.height != H) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: batch pictures differ in size");
+        memset(&h[i], 0, sizeof h[i]);
+        h[i].cur    = cur[i];
+        h[i].ref[0] = ref0[i];
+        if (ref1) h[i].ref[1] = ref1[i];
+        h[i].results = d_results[i];
+        h[i].rcme    = d_rcme ? d_rcme[i] : nullptr;
+    }
+    HIP_TRY(hipMemcpyAsync(d, h, sizeof(me_pic_dev) * (size_t)n_pics, hipMemcpyHostToDevice, ctx->stream));
+    const int total = n_sb * n_pics, chunk = (total + 7) / 8;
+    if (L.total_bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)svt_me_sb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L.total_bytes));
+    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    hipLaunchKernelGGL(svt_me_sb_kernel, dim3(chunk * 8), dim3(256), L.total_bytes, ctx->stream, d, *params, L, n_sb, nx, W, H, total, chunk);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->timed = 1;
+    return SVT_HIP_OK;
+}
+
+extern "C" int32_t svt_hip_me_picture_device(svt_hip_ctx *ctx, const svt_pa_picture *cur, const svt_pa_picture *ref0,
+                                             const svt_pa_picture *ref1, const svt_me_params *params,
+                                             svt_me_pu_result *d_results, uint32_t *d_rcme) {
+    svt_me_pu_result *r[1] = {d_results};
+    uint32_t         *c[1] = {d_rcme};
+    return svt_hip_me_batch_device(ctx, 1, cur, ref0, ref1, params, r, d_rcme ? c : nullptr);
+}
+
+static int upload_plane(svt_hip_ctx *ctx, const svt_plane *h, svt_plane *d, int slot) {
+    const size_t bytes = (size_t)h->stride * (size_t)(h->height + 2 * h->origin_y);
+    uint8_t     *dev   = (uint8_t *)svt_ctx_slot(ctx, slot, bytes + 64);
+    if (!dev) return -1;
+    if (hipMemcpyAsync(dev, h->buf, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return -1;
+    *d     = *h;
+    d->buf = dev;
+    return 0;
+}
+
+extern "C" int32_t svt_hip_me_picture(svt_hip_ctx *ctx, const svt_pa_picture *cur, const svt_pa_picture *ref0,
+                                      const svt_pa_picture *ref1, const svt_me_params *params, svt_me_pu_result *results,
+                                      uint32_t *rcme) {
+    if (!ctx || !cur || !ref0 || !params || !results) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    svt_pa_picture        dc, d0, d1;
+    const svt_pa_picture *hp[3] = {cur, ref0, ref1};
+    svt_pa_picture       *dp[3] = {&dc, &d0, &d1};
+    memset(&d1, 0, sizeof d1);
+    for (int i = 0; i < 3; i++) {
+        if (!hp[i]) continue;
+        const int need_q = params->enable_hme_level_1_flag, need_s = params->enable_hme_level_0_flag;
+        *dp[i] = *hp[i];
+        if (upload_plane(ctx, &hp[i]->full, &dp[i]->full, 3 * i)) return svt_set_error(SVT_HIP_ERR_DEVICE, "me: upload");
+        if (need_q && upload_plane(ctx, &hp[i]->quarter, &dp[i]->quarter, 3 * i + 1)) return svt_set_error(SVT_HIP_ERR_DEVICE, "me: upload");
+        if (need_s && upload_plane(ctx, &hp[i]->sixteenth, &dp[i]->sixteenth, 3 * i + 2)) return svt_set_error(SVT_HIP_ERR_DEVICE, "me: upload");
+    }
+    const int         n_sb = svt_hip_sb_count(cur->full.width, cur->full.height);
+    svt_me_pu_result *dr   = (svt_me_pu_result *)svt_ctx_slot(ctx, 9, sizeof(svt_me_pu_result) * 85 * (size_t)n_sb);
+    uint32_t         *drc  = rcme ? (uint32_t *)svt_ctx_slot(ctx, 10, sizeof(uint32_t) * (size_t)n_sb) : nullptr;
+    if (!dr || (rcme && !drc)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "me: result buffers");
+    int32_t rc = svt_hip_me_picture_device(ctx, &dc, &d0, ref1 ? &d1 : nullptr, params, dr, drc);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(results, dr, sizeof(svt_me_pu_result) * 85 * (size_t)n_sb, hipMemcpyDeviceToHost, ctx->stream));
+    if (rcme) HIP_TRY(hipMemcpyAsync(rcme, drc, sizeof(uint32_t) * (size_t)n_sb, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_HIP_OK;
+}
+
+extern "C" int32_t svt_hip_sad_loop_batch_device(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_ref,
+                                                 const svt_sad_loop_job *d_jobs, int32_t n_jobs, svt_sad_loop_result *d_out) {
+    if (!ctx || !d_src || !d_ref || !d_jobs || !d_out || n_jobs < 1) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "sad_loop: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int lds = 64 * 1024;
+    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    hipLaunchKernelGGL(svt_sad_loop_kernel, dim3(n_jobs), dim3(256), lds, ctx->stream, d_src, d_ref, d_jobs, n_jobs, d_out, lds);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->timed = 1;
+    return SVT_HIP_OK;
+}

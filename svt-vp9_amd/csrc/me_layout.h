@@ -1,0 +1,31 @@
+/* me_layout.h -- host-side computation of the ME kernel's LDS layout from the search parameters. */
+#ifndef SVT_ME_LAYOUT_H
+#define SVT_ME_LAYOUT_H
+#include "me_core.h"
+
+static inline int me_round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+/* Sizes follow the largest search area the parameters allow (clipping at picture borders only
+ * shrinks it).  Returns 0, or -1 when the configuration does not fit in 160 KiB of LDS. */
+static inline int me_lds_layout_compute(const svt_me_params *p, me_lds_layout *L) {
+    int saw = p->search_area_width < 127 ? p->search_area_width : 127;
+    int sah = p->search_area_height < 127 ? p->search_area_height : 127;
+    if (saw < 1) saw = 1;
+    if (sah < 1) sah = 1;
+    int W = saw + ME_SB - 1, H = sah + ME_SB - 1;
+    int rs = me_round_up(W + ME_RGN_GX + 4 + 16, 4);
+    if (((rs >> 2) & 1) == 0) rs += 4; /* odd number of dwords per row: rows spread over LDS banks */
+    L->region_stride = rs;
+    L->region_rows   = H + 2 * ME_RGN_GY + 1;
+    L->plane_bytes   = me_round_up((H + 2 * ME_PL_G) * rs, 16);
+    int off          = 0;
+    L->off_state     = off; off += me_round_up((int)sizeof(me_state_t), 16);
+    L->off_src       = off; off += ME_SB * ME_SB;
+    L->off_region    = off; off += me_round_up(L->region_rows * rs, 16);
+    L->off_planes    = off; L->scratch_bytes = 3 * L->plane_bytes; off += L->scratch_bytes;
+    L->off_pred0     = off;
+    if (p->num_ref_lists == 2) off += 4096 * (p->cu16x16_mode != 0 ? 2 : p->cu8x8_mode != 0 ? 3 : 4);
+    L->total_bytes = off;
+    return off <= 160 * 1024 ? 0 : -1;
+}
+#endif

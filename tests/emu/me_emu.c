@@ -1,0 +1,38 @@
+/*
+ * me_emu.c -- serial host emulation of the HIP ME kernel (svt-vp9_amd/csrc/me_core.h compiled with
+ * SVT_HOST_EMU).  TEST INFRASTRUCTURE ONLY: it lets the CPU test-suite exercise the kernel's phase logic
+ * against the oracle without a GPU.  It is never loaded by the product or by bench.py.
+ */
+#define SVT_HOST_EMU 1
+#include <stdlib.h>
+#include <string.h>
+#include "../../svt-vp9_amd/csrc/me_core.h"
+#include "../../svt-vp9_amd/csrc/me_layout.h"
+
+int32_t svt_emu_me_picture(const svt_pa_picture *cur, const svt_pa_picture *ref0, const svt_pa_picture *ref1,
+                           const svt_me_params *params, svt_me_pu_result *results, uint32_t *rcme, int32_t sb_begin,
+                           int32_t sb_end) {
+    me_lds_layout L;
+    if (me_lds_layout_compute(params, &L)) return -4;
+    if (params->fractional_search_method == SVT_SSD_SEARCH) return -4;
+    uint8_t *lds = (uint8_t *)aligned_alloc(16, (size_t)L.total_bytes + 64);
+    me_pic_dev pic;
+    memset(&pic, 0, sizeof pic);
+    pic.cur = *cur; pic.ref[0] = *ref0; if (ref1) pic.ref[1] = *ref1;
+    pic.results = results; pic.rcme = rcme;
+    int W = cur->full.width, H = cur->full.height, nx = (W + 63) / 64, ny = (H + 63) / 64;
+    if (sb_end < 0 || sb_end > nx * ny) sb_end = nx * ny;
+    for (int sb = sb_begin; sb < sb_end; sb++) {
+        memset(lds, 0xA5, (size_t)L.total_bytes); /* poison: nothing may depend on stale LDS */
+        me_ctx_t c;
+        c.pic = &pic; c.p = params; c.L = L; c.lds = lds;
+        c.st = (me_state_t *)(lds + L.off_state); c.src = lds + L.off_src; c.region = lds + L.off_region;
+        c.planes = lds + L.off_planes; c.pred0 = lds + L.off_pred0;
+        c.pic_w = W; c.pic_h = H; c.sb_index = sb;
+        c.sb_x = (sb % nx) * 64; c.sb_y = (sb / nx) * 64;
+        c.sb_w = (W - c.sb_x) < 64 ? W - c.sb_x : 64; c.sb_h = (H - c.sb_y) < 64 ? H - c.sb_y : 64;
+        me_sb_run(&c, 0);
+    }
+    free(lds);
+    return 0;
+}

@@ -1,0 +1,44 @@
+"""ME parameter sets of the BASELINE configurations (via the product's own preset function) and a few
+hand-built variants that exercise the remaining control-flow branches."""
+import svt_testlib as T
+
+B = T.B
+
+# (name, pic size used for the preset lookup, enc_mode, tune)
+PRESETS = {
+    "c1_360p_m9": (640, 360, 9, 1),
+    "c2_1080p_m8": (1920, 1080, 8, 1),
+    "c3_2160p_m8": (3840, 2160, 8, 1),
+}
+
+
+def preset(name, num_lists, temporal_layer, hierarchical_levels=4):
+    w, h, mode, tune = PRESETS[name]
+    return B.me_params_preset(w, h, mode, tune, num_lists, temporal_layer, hierarchical_levels)
+
+
+def variant_full_sad_all_pus(num_lists, temporal_layer):
+    """1080p preset with FULL_SAD metric, 8x8 PUs refined + bi-predicted, all-PU refinement, 64x64 refinement,
+    rate-control distortion on: covers the branches the M8/M9 presets leave cold."""
+    p = preset("c2_1080p_m8", num_lists, temporal_layer)
+    p.fractional_search_method = 1
+    p.fractional_search_model = 0
+    p.fractional_search64x64 = 1
+    p.cu8x8_mode = 0
+    p.rate_control_mode = 1
+    p.search_area_width = 21   # odd width -> tail columns incl. the reference's address quirk
+    p.search_area_height = 5
+    return p
+
+
+def variant_same_poc(temporal_layer):
+    p = preset("c2_1080p_m8", 2, temporal_layer)
+    p.same_ref_poc = 1
+    return p
+
+
+def variant_l0_only_4quadrants(num_lists, temporal_layer):
+    p = preset("c2_1080p_m8", num_lists, temporal_layer)
+    p.enable_hme_level_1_flag = 0
+    p.enable_hme_level_2_flag = 0
+    return p

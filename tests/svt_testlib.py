@@ -190,3 +190,37 @@ def gen_clip_subpel(width, height, n_frames, seed, noise=2):
         out += rng.integers(-noise, noise + 1, out.shape)
         frames.append(np.clip(np.rint(out), 0, 255).astype(np.uint8))
     return frames
+
+
+# ---------------------------------------------------------------------------------------------------
+# host emulation of the HIP ME kernel (tests/emu; debugging aid for the CPU suite, never the product)
+# ---------------------------------------------------------------------------------------------------
+_emu = None
+
+
+def emu():
+    global _emu
+    if _emu is None:
+        d = os.path.join(ROOT, "tests", "emu")
+        so = os.path.join(d, "libme_emu.so")
+        srcs = [os.path.join(d, "me_emu.c"), os.path.join(ROOT, "svt-vp9_amd", "csrc", "me_core.h"),
+                os.path.join(ROOT, "svt-vp9_amd", "csrc", "me_layout.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-fPIC", "-shared", "-Wno-unused-function", "-o", so,
+                                   srcs[0]])
+        _emu = C.CDLL(so)
+    return _emu
+
+
+def emu_me_picture(cur, ref0, ref1, params, sb_begin=0, sb_end=-1):
+    w, h = cur.luma.shape[1], cur.luma.shape[0]
+    nsb = n_sb(w, h)
+    res = np.zeros((nsb, 85), dtype=B.ME_RESULT_DTYPE)
+    rcme = np.zeros(nsb, dtype=np.uint32)
+    dc, d0 = cur.desc(), ref0.desc()
+    d1 = ref1.desc() if ref1 is not None else None
+    rc = emu().svt_emu_me_picture(C.byref(dc), C.byref(d0), C.byref(d1) if d1 is not None else None,
+                                  C.byref(params), res.ctypes.data_as(C.c_void_p),
+                                  rcme.ctypes.data_as(C.c_void_p), sb_begin, sb_end)
+    assert rc == 0, rc
+    return res, rcme

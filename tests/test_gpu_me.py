@@ -1,0 +1,71 @@
+"""GPU parity: HIP motion estimation (through the C ABI) vs the oracle, bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import me_configs as MC
+import svt_testlib as T
+
+B = T.B
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    lib = B.load()
+    c = C.c_void_p()
+    B.check(lib.svt_hip_ctx_create(C.byref(c), 0))
+    yield c
+    lib.svt_hip_ctx_destroy(c)
+
+
+def hip_me_picture(ctx, cur, ref0, ref1, params):
+    lib = B.load()
+    w, h = cur.luma.shape[1], cur.luma.shape[0]
+    nsb = T.n_sb(w, h)
+    res = np.zeros((nsb, 85), dtype=B.ME_RESULT_DTYPE)
+    rcme = np.zeros(nsb, dtype=np.uint32)
+    dc, d0 = cur.desc(), ref0.desc()
+    d1 = ref1.desc() if ref1 is not None else None
+    B.check(lib.svt_hip_me_picture(ctx, C.byref(dc), C.byref(d0), C.byref(d1) if d1 is not None else None,
+                                   C.byref(params), res.ctypes.data_as(C.c_void_p), rcme.ctypes.data_as(C.c_void_p)))
+    return res, rcme
+
+
+def _check(ctx, pics, p, nl):
+    ref1 = pics[2] if nl == 2 else None
+    o, orc = T.oracle_me_picture(pics[1], pics[0], ref1, p)
+    g, grc = hip_me_picture(ctx, pics[1], pics[0], ref1, p)
+    bad = T.me_results_equal(o, g, nl)
+    assert not bad, bad
+    if p.rate_control_mode:
+        assert np.array_equal(orc, grc)
+
+
+@pytest.mark.parametrize("name", list(MC.PRESETS))
+@pytest.mark.parametrize("nl,tl", [(1, 0), (2, 1), (2, 3), (1, 2)])
+@pytest.mark.parametrize("clip", ["int", "subpel"])
+def test_me_presets_vs_oracle(ctx, name, nl, tl, clip):
+    w, h = (328, 200) if name != "c3_2160p_m8" else (384, 256)
+    gen = T.gen_clip if clip == "int" else T.gen_clip_subpel
+    pics = [T.PaPic(f) for f in gen(w, h, 3, 11)]
+    _check(ctx, pics, MC.preset(name, nl, tl), nl)
+
+
+@pytest.mark.parametrize("nl,tl", [(1, 0), (2, 2)])
+def test_me_variants_vs_oracle(ctx, nl, tl):
+    pics = [T.PaPic(f) for f in T.gen_clip_subpel(264, 200, 3, 5)]
+    _check(ctx, pics, MC.variant_full_sad_all_pus(nl, tl), nl)
+    _check(ctx, pics, MC.variant_l0_only_4quadrants(nl, tl), nl)
+    if nl == 2:
+        _check(ctx, pics, MC.variant_same_poc(tl), nl)
+
+
+def test_me_random_content(ctx):
+    """Uniform random pictures: worst case for ties/early outs (there are none in the SAD paths)."""
+    rng = np.random.default_rng(3)
+    pics = [T.PaPic(rng.integers(0, 256, (192, 256), dtype=np.uint8)) for _ in range(3)]
+    _check(ctx, pics, MC.preset("c3_2160p_m8", 2, 1), 2)
+    flat = [T.PaPic(np.full((192, 256), v, dtype=np.uint8)) for v in (10, 10, 12)]
+    _check(ctx, flat, MC.preset("c2_1080p_m8", 2, 1), 2)  # all-tie case: first minimum in raster order
