@@ -401,11 +401,11 @@ SVT_DEV void ph_interp_bh(const me_ctx_t *c, int tid, int W, int H) {
         Hh[py * rs + px] = me_tap4(r[-rs], r[0], r[rs], r[2 * rs]);
     }
 }
-/* J (x+1/2, y+1/2) = vertical filter over B; defined for y in [-1, H-1] */
+/* J (x+1/2, y+1/2) = vertical filter over B; defined for y in [-1, H-1] (H + 1 rows) */
 SVT_DEV void ph_interp_j(const me_ctx_t *c, int tid, int W, int H) {
     int      rs = c->L.region_stride, pw = W + 2 * ME_PL_G;
     uint8_t *B = c->planes, *J = c->planes + 2 * c->L.plane_bytes;
-    for (int t = tid; t < pw * H; t += SVT_NT) {
+    for (int t = tid; t < pw * (H + 1); t += SVT_NT) {
         int            yy = t / pw, px = t - yy * pw;
         int            py = yy + ME_PL_G - 1; /* y = yy - 1 */
         const uint8_t *b  = B + py * rs + px;

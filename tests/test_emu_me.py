@@ -63,3 +63,22 @@ def test_oracle_vs_reference_me_variants(nl, tl):
     _cmp(T.ref_me_picture, T.oracle_me_picture, rnd, MC.preset("c3_2160p_m8", nl, tl), nl)
     flat = [T.PaPic(np.full((192, 256), v, dtype=np.uint8)) for v in (10, 10, 12)]
     _cmp(T.ref_me_picture, T.oracle_me_picture, flat, MC.preset("c2_1080p_m8", nl, tl), nl)
+
+
+def test_kernel_emulation_is_independent_of_stale_lds(monkeypatch):
+    """Real LDS is inherited from whatever workgroup ran before.  Run the emulation with its LDS image kept
+    across SBs/calls (warmed with other pictures) and with several fill patterns: results must not change.
+    (Caught a one-row-short J plane that only showed on the GPU.)"""
+    pics = [T.PaPic(f) for f in T.gen_clip_subpel(264, 200, 3, 5)]
+    warm = [T.PaPic(f) for f in T.gen_clip_subpel(328, 200, 3, 11)]
+    for nl, tl in ((1, 0), (2, 2)):
+        p = MC.variant_full_sad_all_pus(nl, tl)
+        ref1 = pics[2] if nl == 2 else None
+        o, _ = T.oracle_me_picture(pics[1], pics[0], ref1, p)
+        for mode in ("keep", "0", "255", "src"):
+            monkeypatch.setenv("SVT_EMU_POISON", mode)
+            if mode == "keep":
+                for name in MC.PRESETS:
+                    T.emu_me_picture(warm[1], warm[0], warm[2], MC.preset(name, 2, 1))
+            e, _ = T.emu_me_picture(pics[1], pics[0], ref1, p)
+            assert not T.me_results_equal(o, e, nl), mode

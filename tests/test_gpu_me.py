@@ -38,7 +38,11 @@ def _check(ctx, pics, p, nl):
     o, orc = T.oracle_me_picture(pics[1], pics[0], ref1, p)
     g, grc = hip_me_picture(ctx, pics[1], pics[0], ref1, p)
     bad = T.me_results_equal(o, g, nl)
-    assert not bad, bad
+    if bad:
+        f = bad[0]
+        idx = np.argwhere(o[f] != g[f])
+        detail = [(int(sb), int(pu), o[sb, pu].tolist()[:11], g[sb, pu].tolist()[:11]) for sb, pu in idx[:4]]
+        raise AssertionError(f"{bad} mismatches={len(idx)} first={idx[:16].tolist()} detail={detail}")
     if p.rate_control_mode:
         assert np.array_equal(orc, grc)
 
