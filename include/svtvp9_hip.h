@@ -225,29 +225,39 @@ typedef struct svt_tq_block {
     uint32_t pred_off;   /* byte offset in the prediction plane                       */
     uint32_t recon_off;  /* byte offset in the recon plane (written when do_recon)    */
     uint32_t coeff_off;  /* element offset into qcoeff / dqcoeff (n*n contiguous)     */
+    uint32_t iscan_off;  /* element offset of this block's iscan table inside the iscan array */
     uint16_t src_stride, pred_stride, recon_stride;
     uint8_t  tx_size;    /* SVT_TX_* */
     uint8_t  tx_type;    /* SVT_DCT_DCT.. (ADST only for <=16x16) */
     uint8_t  qtab;       /* index into the quant-table array */
     uint8_t  do_recon;   /* run inverse transform + add into recon */
     uint8_t  partial32;  /* 32x32 only: use eb_vpx_partial_fdct32x32 (low 16x16 kept, rest zero) */
-    uint8_t  pad_;
-} svt_tq_block;
+    uint8_t  pad_[1];
+} svt_tq_block;          /* 32 bytes */
 
-/* residual = src - pred (eb_vp9_residual_kernel, C_DEFAULT/EbPictureOperators_C.c:204-223)
+/* Scan tables: the caller passes the reference's own iscan tables (scan_order->iscan of
+ * eb_vp9_scan_orders[tx_size][tx_type] / eb_vp9_default_scan_orders[TX_32X32], VPX/vp9_scan.c) concatenated
+ * in one int16 array; every block names its table by element offset (iscan_off).  iscan[rc] = position of
+ * raster coefficient rc in scan order, which is all the quantiser needs to produce eob.
+ *
+ * residual = src - pred (eb_vp9_residual_kernel, C_DEFAULT/EbPictureOperators_C.c:204-223)
  * -> forward DCT/ADST (VPX/fwd_txfm.c, VPX/vp9_dct.c) -> eb_vp9_quantize_b[_32x32]
  * -> if do_recon: recon = pred; inverse transform of dqcoeff added into recon
  *    (eb_vp9_idct*_add / eb_vp9_iht*_add, VPX/vp9_idct.c:111-189).
- * Outputs: qcoeff, dqcoeff (int16, raster within block), eob per block.  Device pointers. */
+ * Outputs: qcoeff, dqcoeff (int16, raster within block), eob per block.  Device pointers.
+ * d_blocks must be GROUPED by transform size in the order 4x4, 8x8, 16x16, 32x32 with size_count[s] blocks of
+ * size s (size_count is a host array), and do_recon must be uniform within a size group (the encode pass
+ * reconstructs every block, mode decision none). */
 int32_t svt_hip_tq_batch_device(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *d_recon,
-                                const svt_tq_block *d_blocks, int32_t n_blocks, const svt_quant_tables *d_qtabs,
-                                int32_t n_qtabs, int16_t *d_qcoeff, int16_t *d_dqcoeff, uint16_t *d_eob);
+                                const svt_tq_block *d_blocks, const int32_t size_count[4],
+                                const svt_quant_tables *d_qtabs, const int16_t *d_iscan, int16_t *d_qcoeff,
+                                int16_t *d_dqcoeff, uint16_t *d_eob);
 
 /* Host-pointer convenience form. plane_bytes = size of each of src/pred/recon; coeff_count = total coeffs. */
 int32_t svt_hip_tq_batch(svt_hip_ctx *ctx, const uint8_t *src, const uint8_t *pred, uint8_t *recon,
                          size_t plane_bytes, const svt_tq_block *blocks, int32_t n_blocks,
-                         const svt_quant_tables *qtabs, int32_t n_qtabs, int16_t *qcoeff, int16_t *dqcoeff,
-                         size_t coeff_count, uint16_t *eob);
+                         const svt_quant_tables *qtabs, int32_t n_qtabs, const int16_t *iscan, size_t iscan_count,
+                         int16_t *qcoeff, int16_t *dqcoeff, size_t coeff_count, uint16_t *eob);
 
 /* ------------------------------------------------------------------------------------------------ */
 /* In-loop deblocking                                                                                 */

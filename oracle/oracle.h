@@ -17,6 +17,14 @@ void oracle_sad_loop(const uint8_t *src, int src_stride, const uint8_t *ref, int
 int32_t svt_oracle_me_picture(const svt_pa_picture *cur, const svt_pa_picture *ref0, const svt_pa_picture *ref1,
                               const svt_me_params *params, svt_me_pu_result *results, uint32_t *rcme_distortion,
                               int32_t sb_begin, int32_t sb_end);
+/* transform / quantisation */
+void oracle_fwd_txfm(const int16_t *residual, int stride, int16_t *coeff, int tx_size, int tx_type, int partial32);
+void oracle_quantize(const int16_t *coeff, int n, const svt_quant_tables *q, int16_t *qcoeff, int16_t *dqcoeff,
+                     uint16_t *eob_out, const int16_t *iscan, int is32);
+void oracle_inv_txfm_add(const int16_t *dqcoeff, uint8_t *dst, int stride, int tx_size, int tx_type, int eob);
+int32_t svt_oracle_tq_batch(const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks,
+                            int32_t n_blocks, const svt_quant_tables *qtabs, const int16_t *iscan, int16_t *qcoeff,
+                            int16_t *dqcoeff, uint16_t *eob);
 #ifdef __cplusplus
 }
 #endif

@@ -69,10 +69,10 @@ QUANT_DTYPE = np.dtype([("zbin", "<i2", (2,)), ("round", "<i2", (2,)), ("quant",
                         ("quant_shift", "<i2", (2,)), ("dequant", "<i2", (2,))])
 
 TQ_BLOCK_DTYPE = np.dtype([("src_off", "<u4"), ("pred_off", "<u4"), ("recon_off", "<u4"), ("coeff_off", "<u4"),
-                           ("src_stride", "<u2"), ("pred_stride", "<u2"), ("recon_stride", "<u2"),
+                           ("iscan_off", "<u4"), ("src_stride", "<u2"), ("pred_stride", "<u2"), ("recon_stride", "<u2"),
                            ("tx_size", "u1"), ("tx_type", "u1"), ("qtab", "u1"), ("do_recon", "u1"),
-                           ("partial32", "u1"), ("pad", "u1")])
-assert TQ_BLOCK_DTYPE.itemsize == 28
+                           ("partial32", "u1"), ("pad", "u1", (1,))])
+assert TQ_BLOCK_DTYPE.itemsize == 32
 
 LF_MASK_DTYPE = np.dtype([("left_y", "<u8", (4,)), ("above_y", "<u8", (4,)), ("int_4x4_y", "<u8"),
                           ("left_uv", "<u2", (4,)), ("above_uv", "<u2", (4,)), ("int_4x4_uv", "<u2"),

@@ -1,0 +1,280 @@
+/*
+ * tq_kernel.hip -- residual -> forward DCT/ADST -> quantise/dequantise -> inverse transform + reconstruction
+ * for batches of VP9 transform blocks (gfx950).
+ *
+ * Replaces the per-block body of perform_coding_loop (Source/Lib/Codec/EbEncDecProcess.c:365-587):
+ *   eb_vp9_residual_kernel (C_DEFAULT/EbPictureOperators_C.c:204) -> eb_vp9_fdct32x32 / eb_vpx_partial_fdct32x32 /
+ *   eb_vp9_fht16x16 / fht8x8 / fht4x4 / eb_vpx_fdct4x4 (VPX/fwd_txfm.c, VPX/vp9_dct.c) -> eb_vp9_quantize_b[_32x32]
+ *   (VPX/quantize.c:112-254) -> pic_copy + eb_vp9_idct*_add / eb_vp9_iht*_add (VPX/vp9_idct.c:111-189, VPX/inv_txfm.c).
+ *
+ * Mapping: one N-point 1-D transform per lane, N lanes per NxN block, 64/N blocks per wave64 and 256/N per
+ * workgroup; the column pass keeps a whole column in VGPRs, the transposition between the passes goes through a
+ * padded (N+1 dwords per row) LDS tile so both passes are bank-conflict free; the eob is a max-reduction of
+ * iscan positions over the block's N lanes (DPP/shuffle).  Integer butterflies on VALU -- no MFMA (these are
+ * 32-bit integer rotations with data-dependent rounding/truncation, not dense contractions).
+ * Global traffic per block: N*N source + N*N prediction bytes in, 2*N*N int16 (qcoeff, dqcoeff) + N*N recon out.
+ */
+#include <hip/hip_runtime.h>
+#include "svt_ctx.h"
+#include "txfm1d.h"
+
+namespace {
+
+template <int N> struct txcfg;
+template <> struct txcfg<4> { static constexpr int size = SVT_TX_4X4, shift = 4; };
+template <> struct txcfg<8> { static constexpr int size = SVT_TX_8X8, shift = 5; };
+template <> struct txcfg<16> { static constexpr int size = SVT_TX_16X16, shift = 6; };
+template <> struct txcfg<32> { static constexpr int size = SVT_TX_32X32, shift = 6; };
+
+/* forward 1-D for the hybrid (vp9_dct.c) path: DCT outputs are stored to int16 */
+template <int N> __device__ __forceinline__ void fwd1d_hybrid(const int32_t *v, int32_t *o, bool adst) {
+    if constexpr (N == 4) {
+        if (adst) tx_fadst4(v, o);
+        else { tx_fdct4(v, o); _Pragma("unroll") for (int i = 0; i < 4; i++) o[i] = (int16_t)o[i]; }
+    } else if constexpr (N == 8) {
+        if (adst) tx_adst8(v, o);
+        else { tx_fdct8(v, o, 1); _Pragma("unroll") for (int i = 0; i < 8; i++) o[i] = (int16_t)o[i]; }
+    } else {
+        if (adst) tx_adst16(v, o);
+        else { tx_fdct16(v, o); _Pragma("unroll") for (int i = 0; i < 16; i++) o[i] = (int16_t)o[i]; }
+    }
+}
+/* forward 1-D for the DCT_DCT (fwd_txfm.c) path */
+template <int N> __device__ __forceinline__ void fwd1d_dct(const int32_t *v, int32_t *o) {
+    if constexpr (N == 4) tx_fdct4(v, o);
+    else if constexpr (N == 8) tx_fdct8(v, o, 0);
+    else if constexpr (N == 16) tx_fdct16(v, o);
+    else tx_fdct32(v, o);
+}
+template <int N> __device__ __forceinline__ void inv1d(const int32_t *v, int32_t *o, bool adst) {
+    if constexpr (N == 4) { if (adst) tx_iadst4(v, o); else tx_idct4(v, o); }
+    else if constexpr (N == 8) { if (adst) tx_adst8(v, o); else tx_idct8(v, o); }
+    else if constexpr (N == 16) { if (adst) tx_adst16(v, o); else tx_idct16(v, o); }
+    else tx_idct32(v, o);
+}
+
+__device__ __forceinline__ int clamp16(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
+__device__ __forceinline__ uint8_t clip_add(int d, int t) { int v = d + t; return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+template <int N>
+__global__ __launch_bounds__(256) void svt_tq_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ pred,
+                                                     uint8_t *__restrict__ recon, const svt_tq_block *__restrict__ blocks,
+                                                     int n_blocks, const svt_quant_tables *__restrict__ qtabs,
+                                                     const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,
+                                                     int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out) {
+    constexpr int BPW = 256 / N;          /* blocks per workgroup */
+    constexpr int LS  = N + 1;            /* padded LDS row stride in dwords */
+    __shared__ int32_t tile[BPW][N * LS];
+    const int lb  = threadIdx.x / N;      /* block slot inside the workgroup */
+    const int i   = threadIdx.x % N;      /* column (pass 1) / row (pass 2) owned by this lane */
+    const int blk = blockIdx.x * BPW + lb;
+    const bool active = blk < n_blocks;
+    svt_tq_block k;
+    if (active) k = blocks[blk];
+    else { k = blocks[0]; }
+    int32_t *t = tile[lb];
+    const int  tx_type = (N == 32) ? SVT_DCT_DCT : k.tx_type;
+    const bool col_adst = tx_type == SVT_ADST_DCT || tx_type == SVT_ADST_ADST;
+    const bool row_adst = tx_type == SVT_DCT_ADST || tx_type == SVT_ADST_ADST;
+
+    int32_t v[N], o[N];
+    uint8_t pcol[N]; /* prediction column, reused by the reconstruction */
+    /* ---- residual (column i) and column transform ---- */
+    {
+        const uint8_t *s = src + k.src_off + i, *p = pred + k.pred_off + i;
+        _Pragma("unroll") for (int r = 0; r < N; r++) {
+            const int sv = active ? s[r * k.src_stride] : 0, pv = active ? p[r * k.pred_stride] : 0;
+            pcol[r] = (uint8_t)pv;
+            v[r]    = (int16_t)(sv - pv);
+        }
+    }
+    if (tx_type == SVT_DCT_DCT) {
+        _Pragma("unroll") for (int r = 0; r < N; r++) v[r] *= (N == 4 ? 16 : 4);
+        if (N == 4 && i == 0 && v[0]) ++v[0];
+        fwd1d_dct<N>(v, o);
+        _Pragma("unroll") for (int kk = 0; kk < N; kk++) {
+            int32_t m;
+            if constexpr (N == 32) m = (o[kk] + 1 + (o[kk] > 0)) >> 2;
+            else m = (int16_t)o[kk];
+            if (N == 32 && k.partial32 && kk >= 16) m = 0;
+            t[kk * LS + i] = m;
+        }
+    } else {
+        _Pragma("unroll") for (int r = 0; r < N; r++) v[r] = (int16_t)(v[r] * (N == 4 ? 16 : 4));
+        if (N == 4 && i == 0 && v[0]) v[0] = (int16_t)(v[0] + 1);
+        if constexpr (N < 32) fwd1d_hybrid<N>(v, o, col_adst);
+        _Pragma("unroll") for (int kk = 0; kk < N; kk++)
+            t[kk * LS + i] = (N == 16) ? (int16_t)((o[kk] + 1 + (o[kk] < 0)) >> 2) : (int16_t)o[kk];
+    }
+    __syncthreads();
+    /* ---- row transform (row i = vertical frequency i) ---- */
+    _Pragma("unroll") for (int kk = 0; kk < N; kk++) v[kk] = t[i * LS + kk];
+    int32_t c[N]; /* coefficients of row i */
+    if (tx_type == SVT_DCT_DCT) {
+        if constexpr (N == 16) { _Pragma("unroll") for (int kk = 0; kk < N; kk++) v[kk] = (v[kk] + 1) >> 2; }
+        fwd1d_dct<N>(v, o);
+        _Pragma("unroll") for (int kk = 0; kk < N; kk++) {
+            if constexpr (N == 4) c[kk] = (int16_t)(((int16_t)o[kk] + 1) >> 2);
+            else if constexpr (N == 8) c[kk] = (int16_t)((int16_t)o[kk] / 2);
+            else if constexpr (N == 16) c[kk] = (int16_t)o[kk];
+            else c[kk] = (int16_t)((o[kk] + 1 + (o[kk] < 0)) >> 2);
+        }
+        if (N == 32 && k.partial32) {
+            _Pragma("unroll") for (int kk = 0; kk < N; kk++) if (i >= 16 || kk >= 16) c[kk] = 0;
+        }
+    } else {
+        if constexpr (N < 32) fwd1d_hybrid<N>(v, o, row_adst);
+        _Pragma("unroll") for (int kk = 0; kk < N; kk++) {
+            const int32_t tt = o[kk];
+            c[kk] = (N == 4) ? (int16_t)((tt + 1) >> 2) : (N == 8) ? (int16_t)((tt + (tt < 0)) >> 1) : (int16_t)tt;
+        }
+    }
+    /* ---- quantise row i; eob = 1 + max scan position of a non-zero level ---- */
+    const svt_quant_tables q = qtabs[k.qtab];
+    const int16_t *iscan = iscan_all + k.iscan_off + i * N;
+    int eob = 0;
+    int32_t dq[N];
+    int16_t *qo = qcoeff + k.coeff_off + i * N, *dqo = dqcoeff + k.coeff_off + i * N;
+    _Pragma("unroll") for (int kk = 0; kk < N; kk++) {
+        const int ac = (i | kk) != 0, cv = c[kk], sign = cv >> 31;
+        int       a = (cv ^ sign) - sign, level = 0, qv = 0, dv = 0;
+        if constexpr (N < 32) {
+            if (a >= q.zbin[ac]) {
+                const int tmp = clamp16(a + q.round[ac]);
+                level = ((((tmp * q.quant[ac]) >> 16) + tmp) * q.quant_shift[ac]) >> 16;
+                qv = (int16_t)((level ^ sign) - sign);
+                dv = (int16_t)(qv * q.dequant[ac]);
+            }
+        } else {
+            const int zbin = (q.zbin[ac] + 1) >> 1;
+            if (cv >= zbin || cv <= -zbin) {
+                a = clamp16(a + ((q.round[ac] + 1) >> 1));
+                level = ((((a * q.quant[ac]) >> 16) + a) * q.quant_shift[ac]) >> 15;
+                qv = (int16_t)((level ^ sign) - sign);
+                dv = (int16_t)(qv * q.dequant[ac] / 2);
+            }
+        }
+        dq[kk] = dv;
+        if (active) { qo[kk] = (int16_t)qv; dqo[kk] = (int16_t)dv; }
+        if (level && active) { const int pos = iscan[kk] + 1; eob = pos > eob ? pos : eob; }
+    }
+    _Pragma("unroll") for (int off = 1; off < N; off <<= 1) { const int other = __shfl_xor(eob, off); eob = other > eob ? other : eob; }
+    if (active && i == 0) eob_out[blk] = (uint16_t)eob;
+    if (!k.do_recon) return; /* uniform per block; blocks of one workgroup may differ but no barrier follows for them */
+    /* NOTE: the barrier below is reached by every lane whose block reconstructs; to keep it workgroup-uniform the
+       host launches reconstructing and non-reconstructing blocks in separate grids (see launcher). */
+    /* ---- reconstruction: recon = pred + inverse transform (rows first, then columns) ---- */
+    int32_t res[N];
+    _Pragma("unroll") for (int r = 0; r < N; r++) res[r] = 0;
+    const bool dct_path = tx_type == SVT_DCT_DCT;
+    bool dc_only = false;
+    int  nrows = N;
+    if (dct_path) {
+        if (N == 4) dc_only = eob <= 1;
+        else dc_only = eob == 1;
+        if (N == 8) nrows = eob <= 12 ? 4 : 8;
+        if (N == 16) nrows = eob <= 10 ? 4 : eob <= 38 ? 8 : 16;
+        if (N == 32) nrows = eob <= 34 ? 8 : eob <= 135 ? 16 : 32;
+    }
+    __syncthreads(); /* tile is reused */
+    if (eob != 0 && !dc_only) {
+        if (i < nrows) inv1d<N>(dq, o, row_adst);
+        else { _Pragma("unroll") for (int kk = 0; kk < N; kk++) o[kk] = 0; }
+        _Pragma("unroll") for (int kk = 0; kk < N; kk++) t[i * LS + kk] = (int16_t)o[kk];
+    } else if (eob != 0 && i == 0) {
+        t[0] = dq[0];
+    }
+    __syncthreads();
+    if (eob != 0 && !dc_only) {
+        _Pragma("unroll") for (int r = 0; r < N; r++) v[r] = t[r * LS + i];
+        inv1d<N>(v, o, col_adst);
+        _Pragma("unroll") for (int r = 0; r < N; r++) res[r] = ((int16_t)o[r] + (1 << (txcfg<N>::shift - 1))) >> txcfg<N>::shift;
+    } else if (eob != 0) {
+        /* eb_vp9_idct*_1_add_c: inv_txfm.c:174, 368, 784, 1241 */
+        int32_t d = tx_rsw((int16_t)t[0] * TX_C16);
+        d = tx_rsw(d * TX_C16);
+        const int32_t a1 = (d + (1 << (txcfg<N>::shift - 1))) >> txcfg<N>::shift;
+        _Pragma("unroll") for (int r = 0; r < N; r++) res[r] = a1;
+    }
+    if (active) {
+        uint8_t *d = recon + k.recon_off + i;
+        _Pragma("unroll") for (int r = 0; r < N; r++) d[r * k.recon_stride] = clip_add(pcol[r], res[r]);
+    }
+}
+
+template <int N>
+int launch_tq(svt_hip_ctx *ctx, const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks, int n,
+              const svt_quant_tables *q, const int16_t *iscan, int16_t *qc, int16_t *dqc, uint16_t *eob) {
+    if (n <= 0) return 0;
+    constexpr int BPW = 256 / N;
+    hipLaunchKernelGGL(svt_tq_kernel<N>, dim3((n + BPW - 1) / BPW), dim3(256), 0, ctx->stream, src, pred, recon, blocks, n, q, iscan,
+                       qc, dqc, eob);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+} // namespace
+
+/* Blocks must be grouped by transform size: size_count[s] blocks of SVT_TX_<s>, in the order 4x4, 8x8, 16x16,
+ * 32x32, and within a size all blocks must share the same do_recon flag (the encode pass reconstructs every
+ * block; mode decision none) -- the kernel keeps its barriers workgroup-uniform that way. */
+extern "C" int32_t svt_hip_tq_batch_device(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *d_recon,
+                                           const svt_tq_block *d_blocks, const int32_t size_count[4],
+                                           const svt_quant_tables *d_qtabs, const int16_t *d_iscan, int16_t *d_qcoeff,
+                                           int16_t *d_dqcoeff, uint16_t *d_eob) {
+    if (!ctx || !d_src || !d_pred || !d_blocks || !size_count || !d_qtabs || !d_iscan || !d_qcoeff || !d_dqcoeff || !d_eob)
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    int off = 0, rc = 0;
+    rc |= launch_tq<4>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[0], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off);
+    off += size_count[0];
+    rc |= launch_tq<8>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[1], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off);
+    off += size_count[1];
+    rc |= launch_tq<16>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[2], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off);
+    off += size_count[2];
+    rc |= launch_tq<32>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[3], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off);
+    if (rc) return svt_set_hip_error(hipGetLastError(), __FILE__, __LINE__);
+    HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->timed = 1;
+    return SVT_HIP_OK;
+}
+
+extern "C" int32_t svt_hip_tq_batch(svt_hip_ctx *ctx, const uint8_t *src, const uint8_t *pred, uint8_t *recon, size_t plane_bytes,
+                                    const svt_tq_block *blocks, int32_t n_blocks, const svt_quant_tables *qtabs, int32_t n_qtabs,
+                                    const int16_t *iscan, size_t iscan_count, int16_t *qcoeff, int16_t *dqcoeff,
+                                    size_t coeff_count, uint16_t *eob) {
+    if (!ctx || !src || !pred || !recon || !blocks || n_blocks < 1 || !qtabs || !iscan || !qcoeff || !dqcoeff || !eob)
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq: null argument");
+    int32_t cnt[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n_blocks; i++) {
+        if (blocks[i].tx_size > 3 || blocks[i].qtab >= n_qtabs) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq: bad block");
+        if (i && blocks[i].tx_size < blocks[i - 1].tx_size) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq: blocks not grouped by tx_size");
+        if (i && blocks[i].tx_size == blocks[i - 1].tx_size && (blocks[i].do_recon != 0) != (blocks[i - 1].do_recon != 0))
+            return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq: do_recon must be uniform within a tx_size group");
+        cnt[blocks[i].tx_size]++;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint8_t *ds = (uint8_t *)svt_ctx_slot(ctx, 11, plane_bytes + 64), *dp = (uint8_t *)svt_ctx_slot(ctx, 12, plane_bytes + 64);
+    uint8_t *dr = (uint8_t *)svt_ctx_slot(ctx, 13, plane_bytes + 64);
+    svt_tq_block *db = (svt_tq_block *)svt_ctx_slot(ctx, 14, sizeof(svt_tq_block) * (size_t)n_blocks);
+    svt_quant_tables *dqt = (svt_quant_tables *)svt_ctx_slot(ctx, 15, sizeof(svt_quant_tables) * (size_t)n_qtabs);
+    int16_t *dis = (int16_t *)svt_ctx_slot(ctx, 16, sizeof(int16_t) * iscan_count);
+    int16_t *dq = (int16_t *)svt_ctx_slot(ctx, 17, sizeof(int16_t) * coeff_count), *ddq = (int16_t *)svt_ctx_slot(ctx, 18, sizeof(int16_t) * coeff_count);
+    uint16_t *de = (uint16_t *)svt_ctx_slot(ctx, 19, sizeof(uint16_t) * (size_t)n_blocks);
+    if (!ds || !dp || !dr || !db || !dqt || !dis || !dq || !ddq || !de) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "tq: device buffers");
+    HIP_TRY(hipMemcpyAsync(ds, src, plane_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dp, pred, plane_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dr, recon, plane_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(db, blocks, sizeof(svt_tq_block) * (size_t)n_blocks, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dqt, qtabs, sizeof(svt_quant_tables) * (size_t)n_qtabs, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dis, iscan, sizeof(int16_t) * iscan_count, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(dq, 0, sizeof(int16_t) * coeff_count, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ddq, 0, sizeof(int16_t) * coeff_count, ctx->stream));
+    int32_t rc = svt_hip_tq_batch_device(ctx, ds, dp, dr, db, cnt, dqt, dis, dq, ddq, de);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(recon, dr, plane_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(qcoeff, dq, sizeof(int16_t) * coeff_count, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dqcoeff, ddq, sizeof(int16_t) * coeff_count, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(eob, de, sizeof(uint16_t) * (size_t)n_blocks, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_HIP_OK;
+}

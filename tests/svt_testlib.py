@@ -224,3 +224,225 @@ def emu_me_picture(cur, ref0, ref1, params, sb_begin=0, sb_end=-1):
                                   rcme.ctypes.data_as(C.c_void_p), sb_begin, sb_end)
     assert rc == 0, rc
     return res, rcme
+
+
+# ---------------------------------------------------------------------------------------------------
+# transform / quantisation helpers
+# ---------------------------------------------------------------------------------------------------
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+TX_N = {0: 4, 1: 8, 2: 16, 3: 32}
+
+
+class _ScanOrder(C.Structure):
+    _fields_ = [("scan", C.POINTER(C.c_int16)), ("iscan", C.POINTER(C.c_int16)), ("neighbors", C.POINTER(C.c_int16))]
+
+
+def ref_scan_tables():
+    """Read the reference's scan / iscan tables (VPX/vp9_scan.c) out of oracle/_ref/libsvtref_kernels.so."""
+    lib = ref_kernels()
+    so = (_ScanOrder * 4 * 4).in_dll(lib, "eb_vp9_scan_orders")  # [TX_SIZES][TX_TYPES]
+    out = {}
+    for ts in range(4):
+        n = TX_N[ts] ** 2
+        for tt in range(4):
+            out[f"scan_{ts}_{tt}"] = np.ctypeslib.as_array(so[ts][tt].scan, (n,)).copy()
+            out[f"iscan_{ts}_{tt}"] = np.ctypeslib.as_array(so[ts][tt].iscan, (n,)).copy()
+    return out
+
+
+_scan_cache = None
+
+
+def scan_tables():
+    """Scan tables as committed test data (tests/golden/vp9_scan_tables.npz; generated by tests/gen_golden.py)."""
+    global _scan_cache
+    if _scan_cache is None:
+        _scan_cache = dict(np.load(os.path.join(GOLDEN_DIR, "vp9_scan_tables.npz")))
+    return _scan_cache
+
+
+def iscan_array():
+    """All iscan tables concatenated + {(tx_size, tx_type): element offset}.  32x32 always uses tx_type 0."""
+    t = scan_tables()
+    parts, offs, pos = [], {}, 0
+    for ts in range(4):
+        for tt in range(4):
+            a = t[f"iscan_{ts}_{tt if ts < 3 else 0}"]
+            offs[(ts, tt)] = pos
+            parts.append(a)
+            pos += a.size
+    return np.concatenate(parts).astype(np.int16), offs
+
+
+def quant_table(q_dc, q_ac):
+    """[DC, AC] quantiser rows as eb_vp9_init_quantizer derives them from the step sizes
+    (VPX/vp9_quantize.c:182-265: invert_quant, zbin = ROUND_POWER_OF_TWO(qzbin_factor * q, 7), round = 48*q>>7)."""
+    rec = np.zeros((), dtype=B.QUANT_DTYPE)
+    for i, q in enumerate((q_dc, q_ac)):
+        t = 1 << 16
+        l = 0
+        tt = q
+        while tt > 1:
+            l += 1
+            tt >>= 1
+        m = 1 + (1 << (16 + l)) // q
+        rec["quant"][i] = np.int16(np.uint16((m - t) & 0xFFFF).view(np.int16)) if False else np.array(m - t).astype(np.int16)
+        rec["quant_shift"][i] = 1 << (16 - l)
+        qzbin_factor = 84 if q_ac == 0 else (64 if q < 148 else 80)
+        rec["zbin"][i] = (qzbin_factor * q + 64) >> 7
+        rec["round"][i] = (48 * q) >> 7
+        rec["dequant"][i] = q
+    return rec
+
+
+def _p16(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int16))
+
+
+def ref_fwd_txfm(res, tx_size, tx_type, partial32=False):
+    lib = ref_kernels()
+    n = TX_N[tx_size]
+    res = np.ascontiguousarray(res, dtype=np.int16)
+    out = np.zeros(n * n, dtype=np.int16)
+    if tx_size == 3:
+        (lib.eb_vpx_partial_fdct32x32_c if partial32 else lib.eb_vp9_fdct32x32_c)(_p16(res), _p16(out), n)
+    else:
+        fn = {0: lib.eb_vp9_fht4x4_c, 1: lib.eb_vp9_fht8x8_c, 2: lib.eb_vp9_fht16x16_c}[tx_size]
+        fn(_p16(res), _p16(out), n, tx_type)
+    return out
+
+
+def oracle_fwd_txfm(res, tx_size, tx_type, partial32=False):
+    n = TX_N[tx_size]
+    res = np.ascontiguousarray(res, dtype=np.int16)
+    out = np.zeros(n * n, dtype=np.int16)
+    oracle().oracle_fwd_txfm(_p16(res), n, _p16(out), tx_size, tx_type, int(partial32))
+    return out
+
+
+def ref_quantize(coeff, tx_size, tx_type, qrec):
+    lib = ref_kernels()
+    t = scan_tables()
+    n = coeff.size
+    scan = np.ascontiguousarray(t[f"scan_{tx_size}_{tx_type if tx_size < 3 else 0}"], dtype=np.int16)
+    iscan = np.ascontiguousarray(t[f"iscan_{tx_size}_{tx_type if tx_size < 3 else 0}"], dtype=np.int16)
+    q, dq = np.zeros(n, np.int16), np.zeros(n, np.int16)
+    eob = C.c_uint16(0)
+    f = lambda k: _p16(np.ascontiguousarray(qrec[k], dtype=np.int16))
+    arrs = {k: np.ascontiguousarray(qrec[k], dtype=np.int16) for k in ("zbin", "round", "quant", "quant_shift", "dequant")}
+    fn = lib.eb_vp9_quantize_b_32x32_c if tx_size == 3 else lib.eb_vp9_quantize_b_c
+    fn(_p16(coeff), C.c_long(n), 0, _p16(arrs["zbin"]), _p16(arrs["round"]), _p16(arrs["quant"]), _p16(arrs["quant_shift"]),
+       _p16(q), _p16(dq), _p16(arrs["dequant"]), C.byref(eob), _p16(scan), _p16(iscan))
+    return q, dq, eob.value
+
+
+def oracle_quantize(coeff, tx_size, tx_type, qrec):
+    t = scan_tables()
+    n = coeff.size
+    iscan = np.ascontiguousarray(t[f"iscan_{tx_size}_{tx_type if tx_size < 3 else 0}"], dtype=np.int16)
+    q, dq = np.zeros(n, np.int16), np.zeros(n, np.int16)
+    eob = C.c_uint16(0)
+    rec = np.ascontiguousarray(qrec)
+    oracle().oracle_quantize(_p16(coeff), n, rec.ctypes.data_as(C.c_void_p), _p16(q), _p16(dq), C.byref(eob), _p16(iscan),
+                             int(tx_size == 3))
+    return q, dq, eob.value
+
+
+def ref_inv_add(dq, pred, tx_size, tx_type, eob):
+    """The reference's wrapper logic (VPX/vp9_idct.c:111-189) applied with its own *_add_c kernels."""
+    lib = ref_kernels()
+    n = TX_N[tx_size]
+    dst = np.ascontiguousarray(pred, dtype=np.uint8).copy()
+    p8 = dst.ctypes.data_as(C.POINTER(C.c_uint8))
+    d = _p16(np.ascontiguousarray(dq, dtype=np.int16))
+    if tx_type != 0 and tx_size < 3:
+        fn = {0: lib.eb_vp9_iht4x4_16_add_c, 1: lib.eb_vp9_iht8x8_64_add_c, 2: lib.eb_vp9_iht16x16_256_add_c}[tx_size]
+        fn(d, p8, n, tx_type)
+    elif tx_size == 0:
+        (lib.eb_vp9_idct4x4_16_add_c if eob > 1 else lib.eb_vp9_idct4x4_1_add_c)(d, p8, n)
+    elif tx_size == 1:
+        (lib.eb_vp9_idct8x8_1_add_c if eob == 1 else lib.eb_vp9_idct8x8_12_add_c if eob <= 12 else lib.eb_vp9_idct8x8_64_add_c)(d, p8, n)
+    elif tx_size == 2:
+        (lib.eb_vp9_idct16x16_1_add_c if eob == 1 else lib.eb_vp9_idct16x16_10_add_c if eob <= 10 else
+         lib.eb_vp9_idct16x16_38_add_c if eob <= 38 else lib.eb_vp9_idct16x16_256_add_c)(d, p8, n)
+    else:
+        (lib.eb_vp9_idct32x32_1_add_c if eob == 1 else lib.eb_vp9_idct32x32_34_add_c if eob <= 34 else
+         lib.eb_vp9_idct32x32_135_add_c if eob <= 135 else lib.eb_vp9_idct32x32_1024_add_c)(d, p8, n)
+    return dst
+
+
+def oracle_inv_add(dq, pred, tx_size, tx_type, eob):
+    n = TX_N[tx_size]
+    dst = np.ascontiguousarray(pred, dtype=np.uint8).copy()
+    oracle().oracle_inv_txfm_add(_p16(np.ascontiguousarray(dq, dtype=np.int16)), dst.ctypes.data_as(C.POINTER(C.c_uint8)), n,
+                                 tx_size, tx_type, int(eob))
+    return dst
+
+
+def make_tq_case(seed, width=256, height=128, do_recon=True, qsteps=((40, 48), (8, 9), (200, 260)), extreme=False):
+    """A plane pair (source, prediction) tiled with transform blocks of every size / type, grouped by size as the
+    C ABI requires.  Returns dict(src, pred, blocks, counts, qtabs, iscan, n_coeff)."""
+    rng = np.random.default_rng(seed)
+    src = gen_clip(width, height, 1, seed)[0]
+    if extreme:
+        pred = np.where(rng.integers(0, 2, src.shape) > 0, 255, 0).astype(np.uint8)
+        src = (255 - pred).astype(np.uint8) if seed % 2 else src
+    else:
+        pred = np.clip(np.roll(src, (1, 2), (0, 1)).astype(np.int16) + rng.integers(-12, 13, src.shape), 0, 255).astype(np.uint8)
+        flat = rng.integers(0, 4, (height // 32, width // 32))
+        for by in range(height // 32):     # some blocks with tiny residual (eob 0/1, reduced-eob inverse variants)
+            for bx in range(width // 32):
+                if flat[by, bx] == 0:
+                    pred[by * 32:by * 32 + 32, bx * 32:bx * 32 + 32] = src[by * 32:by * 32 + 32, bx * 32:bx * 32 + 32]
+                elif flat[by, bx] == 1:
+                    pred[by * 32:by * 32 + 32, bx * 32:bx * 32 + 32] = np.clip(
+                        src[by * 32:by * 32 + 32, bx * 32:bx * 32 + 32].astype(np.int16) + rng.integers(-2, 3), 0, 255)
+    iscan, offs = iscan_array()
+    qtabs = np.array([quant_table(a, b) for a, b in qsteps], dtype=B.QUANT_DTYPE)
+    blocks = []
+    # quadrant layout: every 32x32 area is assigned one transform size
+    for by in range(height // 32):
+        for bx in range(width // 32):
+            ts = int(rng.integers(0, 4))
+            n = TX_N[ts]
+            for yy in range(0, 32, n):
+                for xx in range(0, 32, n):
+                    tt = int(rng.integers(0, 4)) if ts < 3 else 0
+                    blocks.append((ts, tt, by * 32 + yy, bx * 32 + xx, int(rng.integers(0, len(qsteps))),
+                                   int(ts == 3 and rng.integers(0, 4) == 0)))
+    blocks.sort(key=lambda b: b[0])
+    arr = np.zeros(len(blocks), dtype=B.TQ_BLOCK_DTYPE)
+    pos = 0
+    for i, (ts, tt, y, x, qi, part) in enumerate(blocks):
+        n = TX_N[ts]
+        arr[i] = (y * width + x, y * width + x, y * width + x, pos, offs[(ts, tt)], width, width, width, ts, tt, qi,
+                  int(do_recon), part, 0)
+        pos += n * n
+    counts = np.array([sum(1 for b in blocks if b[0] == s) for s in range(4)], dtype=np.int32)
+    return dict(src=src, pred=pred, blocks=arr, counts=counts, qtabs=qtabs, iscan=iscan, n_coeff=pos)
+
+
+def oracle_tq_batch(case):
+    recon = np.zeros_like(case["src"])
+    q = np.zeros(case["n_coeff"], np.int16)
+    dq = np.zeros(case["n_coeff"], np.int16)
+    eob = np.zeros(len(case["blocks"]), np.uint16)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = oracle().svt_oracle_tq_batch(vp(case["src"]), vp(case["pred"]), vp(recon), vp(case["blocks"]), len(case["blocks"]),
+                                      vp(case["qtabs"]), vp(case["iscan"]), vp(q), vp(dq), vp(eob))
+    assert rc == 0
+    return recon, q, dq, eob
+
+
+def hip_tq_batch(ctx, case):
+    lib = B.load()
+    recon = np.zeros_like(case["src"])
+    q = np.zeros(case["n_coeff"], np.int16)
+    dq = np.zeros(case["n_coeff"], np.int16)
+    eob = np.zeros(len(case["blocks"]), np.uint16)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    B.check(lib.svt_hip_tq_batch(ctx, vp(case["src"]), vp(case["pred"]), vp(recon), C.c_size_t(case["src"].size),
+                                 vp(case["blocks"]), len(case["blocks"]), vp(case["qtabs"]), len(case["qtabs"]),
+                                 vp(case["iscan"]), C.c_size_t(case["iscan"].size), vp(q), vp(dq),
+                                 C.c_size_t(case["n_coeff"]), vp(eob)))
+    return recon, q, dq, eob

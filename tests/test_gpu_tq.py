@@ -1,0 +1,50 @@
+"""GPU parity: HIP transform/quant/recon batch (through the C ABI) vs the oracle, bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import svt_testlib as T
+
+B = T.B
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    lib = B.load()
+    c = C.c_void_p()
+    B.check(lib.svt_hip_ctx_create(C.byref(c), 0))
+    yield c
+    lib.svt_hip_ctx_destroy(c)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+@pytest.mark.parametrize("do_recon", [True, False])
+def test_tq_vs_oracle(ctx, seed, do_recon):
+    case = T.make_tq_case(seed, do_recon=do_recon)
+    o = T.oracle_tq_batch(case)
+    g = T.hip_tq_batch(ctx, case)
+    names = ("recon", "qcoeff", "dqcoeff", "eob")
+    for n, a, b in zip(names, o, g):
+        if n == "recon" and not do_recon:
+            continue
+        assert np.array_equal(a, b), (n, int(np.sum(a != b)), np.argwhere(a != b)[:8].ravel().tolist())
+    assert len(set(o[3].tolist())) > 8  # the case really exercises many eob classes
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_tq_extreme_residuals(ctx, seed):
+    """+-255 residuals, tiny and huge quantiser steps: saturation / clamp paths."""
+    case = T.make_tq_case(seed, extreme=True, qsteps=((4, 4), (1336, 1828), (40, 48)))
+    o = T.oracle_tq_batch(case)
+    g = T.hip_tq_batch(ctx, case)
+    for n, a, b in zip(("recon", "qcoeff", "dqcoeff", "eob"), o, g):
+        assert np.array_equal(a, b), (n, int(np.sum(a != b)))
+
+
+def test_tq_rejects_ungrouped_blocks(ctx):
+    case = T.make_tq_case(5)
+    case["blocks"] = case["blocks"][::-1].copy()
+    with pytest.raises(RuntimeError):
+        T.hip_tq_batch(ctx, case)
