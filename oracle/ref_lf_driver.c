@@ -1,0 +1,76 @@
+/*
+ * ref_lf_driver.c -- harness that runs the REFERENCE's eb_vp9_loop_filter_frame
+ * (/root/reference/Source/Lib/VPX/vp9_loopfilter.c:1521) on a frame described by a binary request file.
+ * TEST INFRASTRUCTURE ONLY; compiled only in the build container against the reference's headers, linked with
+ * the reference's own objects into oracle/_ref/ref_lf_frame (see ref_me_driver.c for the rules followed).
+ *
+ * This translation unit plays the role Codec/EbEncHandle.c plays in the reference for the RTCD dispatch:
+ * it includes VPX/vpx_dsp_rtcd.h / VPX/vp9_rtcd.h with RTCD_C (which defines the function pointers and the
+ * reference's own setup_rtcd_internal()) and calls setup_rtcd_internal(0) = `-asm 0`, so every eb_vpx_lpf_*
+ * pointer is bound to the reference's C kernel by the reference's own code.
+ *
+ * request: int32 magic 'SVLF', int32 width, height, y_stride, uv_stride, mi_rows, mi_cols, lfm_stride, n_lfm, y_only,
+ *          svt_lf_thresh, n_lfm * svt_lf_mask (= LOOP_FILTER_MASK), Y plane (y_stride*height), U, V (uv_stride*height/2)
+ * response: the three filtered planes, same layout.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+
+#define RTCD_C
+#include "vpx_dsp_rtcd.h"
+#include "vp9_rtcd.h"
+#include "vp9_onyxc_int.h"
+#include "vp9_blockd.h"
+#include "vp9_loopfilter.h"
+
+#include "../include/svtvp9_hip.h"
+
+uint32_t eb_vp9_ASM_TYPES = 0;
+
+static int rd(FILE *f, void *p, size_t n) { return fread(p, 1, n, f) == n ? 0 : -1; }
+
+int main(int argc, char **argv) {
+    if (argc < 3) return 2;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    int32_t h[10];
+    if (rd(f, h, sizeof h) || h[0] != 0x464C5653) return 3;
+    const int W = h[1], H = h[2], ys = h[3], uvs = h[4], mi_rows = h[5], mi_cols = h[6], lfm_stride = h[7], n_lfm = h[8], y_only = h[9];
+    (void)W;
+    svt_lf_thresh thr;
+    if (rd(f, &thr, sizeof thr)) return 3;
+    if (sizeof(LOOP_FILTER_MASK) != sizeof(svt_lf_mask)) { fprintf(stderr, "LOOP_FILTER_MASK size mismatch\n"); return 4; }
+    LOOP_FILTER_MASK *lfm = (LOOP_FILTER_MASK *)calloc((size_t)n_lfm, sizeof *lfm);
+    if (rd(f, lfm, sizeof(*lfm) * (size_t)n_lfm)) return 3;
+    const size_t ysz = (size_t)ys * H, uvsz = (size_t)uvs * (H / 2);
+    uint8_t *y = (uint8_t *)malloc(ysz + 64), *u = (uint8_t *)malloc(uvsz + 64), *v = (uint8_t *)malloc(uvsz + 64);
+    if (rd(f, y, ysz) || rd(f, u, uvsz) || rd(f, v, uvsz)) return 3;
+    fclose(f);
+
+    setup_rtcd_internal(0);      /* the reference's own dispatch set-up, C kernels */
+    setup_rtcd_internal_vp9(0);
+
+    VP9_COMMON  *cm = (VP9_COMMON *)calloc(1, sizeof *cm);
+    MACROBLOCKD *xd = (MACROBLOCKD *)calloc(1, sizeof *xd);
+    cm->mi_rows = mi_rows;
+    cm->mi_cols = mi_cols;
+    cm->lf.lfm = lfm;
+    cm->lf.lfm_stride = lfm_stride;
+    for (int l = 0; l < 64; l++) {
+        memset(cm->lf_info.lfthr[l].mblim, thr.mblim[l], SIMD_WIDTH);
+        memset(cm->lf_info.lfthr[l].lim, thr.lim[l], SIMD_WIDTH);
+        memset(cm->lf_info.lfthr[l].hev_thr, thr.hev_thr[l], SIMD_WIDTH);
+    }
+    xd->plane[0].dst.buf = y; xd->plane[0].dst.stride = ys; xd->plane[0].subsampling_x = 0; xd->plane[0].subsampling_y = 0;
+    xd->plane[1].dst.buf = u; xd->plane[1].dst.stride = uvs; xd->plane[1].subsampling_x = 1; xd->plane[1].subsampling_y = 1;
+    xd->plane[2].dst.buf = v; xd->plane[2].dst.stride = uvs; xd->plane[2].subsampling_x = 1; xd->plane[2].subsampling_y = 1;
+    eb_vp9_loop_filter_frame(cm, xd, 1 /* any non-zero level: per-block levels come from lfl_y */, y_only, 0);
+
+    FILE *o = fopen(argv[2], "wb");
+    if (!o) return 2;
+    fwrite(y, 1, ysz, o); fwrite(u, 1, uvsz, o); fwrite(v, 1, uvsz, o);
+    fclose(o);
+    return 0;
+}

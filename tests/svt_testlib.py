@@ -446,3 +446,165 @@ def hip_tq_batch(ctx, case):
                                  vp(case["iscan"]), C.c_size_t(case["iscan"].size), vp(q), vp(dq),
                                  C.c_size_t(case["n_coeff"]), vp(eob)))
     return recon, q, dq, eob
+
+
+# ---------------------------------------------------------------------------------------------------
+# deblocking helpers
+# ---------------------------------------------------------------------------------------------------
+_LEFT_TX = {0: 0xFFFFFFFFFFFFFFFF, 1: 0xFFFFFFFFFFFFFFFF, 2: 0x5555555555555555, 3: 0x1111111111111111}
+_ABOVE_TX = {0: 0xFFFFFFFFFFFFFFFF, 1: 0xFFFFFFFFFFFFFFFF, 2: 0x00FF00FF00FF00FF, 3: 0x000000FF000000FF}
+_LEFT_TX_UV = {0: 0xFFFF, 1: 0xFFFF, 2: 0x5555, 3: 0x1111}
+_ABOVE_TX_UV = {0: 0xFFFF, 1: 0xFFFF, 2: 0x0F0F, 3: 0x000F}
+
+
+def _rect_mask(r, c, h, w, cols):
+    m = 0
+    for y in range(r, r + h):
+        for x in range(c, c + w):
+            m |= 1 << (y * cols + x)
+    return m
+
+
+def gen_lf_masks(rng, sb_rows, sb_cols, level_choices=(0, 8, 20, 33, 63)):
+    """Random but well-formed LOOP_FILTER_MASKs (one per SB): a random quad-tree of prediction blocks per SB, each
+    with a transform size <= its size, a skip flag and a filter level -- the bits are set with the same rules the
+    reference's eb_vp9_build_mask uses (VPX/vp9_loopfilter.c:1587-1689), so no position carries two filter widths."""
+    lfm = np.zeros((sb_rows, sb_cols), dtype=B.LF_MASK_DTYPE)
+    for sr in range(sb_rows):
+        for sc in range(sb_cols):
+            left, above, i4 = [0, 0, 0, 0], [0, 0, 0, 0], 0
+            lfl = np.zeros(64, np.uint8)
+
+            def leaf(r, c, n, masks, tx_left, tx_above, cols, i4acc, maxtx):
+                tx = int(rng.integers(0, min(maxtx, {1: 1, 2: 2, 4: 3, 8: 3}[n]) + 1))
+                skip_inter = rng.integers(0, 3) == 0
+                lvl = int(rng.choice(level_choices))
+                if lvl == 0:
+                    return 0, lvl
+                size = _rect_mask(r, c, n, n, cols)
+                masks[0][tx] |= _rect_mask(r, c, n, 1, cols)      # left edge of the prediction block
+                masks[1][tx] |= _rect_mask(r, c, 1, n, cols)      # above edge
+                if not skip_inter:
+                    masks[0][tx] |= size & tx_left[tx]
+                    masks[1][tx] |= size & tx_above[tx]
+                    if tx == 0:
+                        i4acc[0] |= size
+                return size, lvl
+
+            def split(r, c, n, fn):
+                if n > 1 and rng.integers(0, 3) > 0:
+                    h = n // 2
+                    for dr in (0, h):
+                        for dc in (0, h):
+                            split(r + dr, c + dc, h, fn)
+                else:
+                    fn(r, c, n)
+
+            acc_y = [0]
+            my = ([0, 0, 0, 0], [0, 0, 0, 0])
+
+            def fy(r, c, n):
+                size, lvl = leaf(r, c, n, my, _LEFT_TX, _ABOVE_TX, 8, acc_y, 3)
+                for y in range(r, r + n):
+                    lfl[y * 8 + c:y * 8 + c + n] = lvl
+
+            split(0, 0, 8, fy)
+            acc_uv = [0]
+            muv = ([0, 0, 0, 0], [0, 0, 0, 0])
+
+            def fuv(r, c, n):
+                # chroma filtering needs a non-zero level at the co-located luma position
+                if lfl[(2 * r) * 8 + 2 * c] == 0:
+                    return
+                leaf(r, c, n, muv, _LEFT_TX_UV, _ABOVE_TX_UV, 4, acc_uv, 3)
+
+            split(0, 0, 4, fuv)
+            # a filter may only sit where the level is non-zero (the reference skips blocks with level 0)
+            nz = 0
+            for i in range(64):
+                if lfl[i]:
+                    nz |= 1 << i
+            rec = lfm[sr, sc]
+            for t in range(4):
+                rec["left_y"][t] = my[0][t] & nz
+                rec["above_y"][t] = my[1][t] & nz
+                rec["left_uv"][t] = muv[0][t]
+                rec["above_uv"][t] = muv[1][t]
+            rec["int_4x4_y"] = acc_y[0] & nz
+            rec["int_4x4_uv"] = acc_uv[0]
+            rec["lfl_y"] = lfl
+    return lfm
+
+
+def make_lf_case(seed, width, height, sharpness=0):
+    rng = np.random.default_rng(seed)
+    y, u, v = gen_yuv(width, height, seed)
+    # blocky reconstruction: quantise 8x8 / 16x16 means so that edges really get filtered (incl. flat / flat2 paths)
+    hp, wp = (height + 15) // 16 * 16, (width + 15) // 16 * 16
+    yb = np.pad(y.astype(np.int32), ((0, hp - height), (0, wp - width)), mode="edge")
+    for n, frac in ((16, 0.5), (8, 0.5)):
+        m = yb.reshape(hp // n, n, wp // n, n).mean(axis=(1, 3), keepdims=True)
+        yb = np.where(rng.random((hp // n, 1, wp // n, 1)) < frac, m + rng.integers(-2, 3, (hp // n, n, wp // n, n)),
+                      yb.reshape(hp // n, n, wp // n, n)).reshape(hp, wp)
+    yb = yb[:height, :width]
+    y = np.clip(yb, 0, 255).astype(np.uint8)
+    u = np.clip((u.astype(np.int32) // 4) * 4 + rng.integers(-1, 2, u.shape), 0, 255).astype(np.uint8)
+    v = np.clip(128 + rng.integers(-3, 4, v.shape) + (np.arange(v.shape[1]) // 8 % 2) * 6, 0, 255).astype(np.uint8)
+    mi_rows, mi_cols = height // 8, width // 8
+    sb_rows, sb_cols = (mi_rows + 7) // 8, (mi_cols + 7) // 8
+    lfm = gen_lf_masks(rng, sb_rows, sb_cols)
+    thr = B.LfThresh()
+    oracle().svt_oracle_lf_thresh_init(C.byref(thr), sharpness)
+    return dict(y=y, u=u, v=v, lfm=lfm, thr=thr, mi_rows=mi_rows, mi_cols=mi_cols)
+
+
+def _yuv_desc(y, u, v):
+    d = B.YuvPlanes()
+    d.y, d.u, d.v = y.ctypes.data, u.ctypes.data, v.ctypes.data
+    d.y_stride, d.uv_stride = y.strides[0], u.strides[0]
+    d.width, d.height = y.shape[1], y.shape[0]
+    return d
+
+
+def oracle_lf_frame(case, y_only=False):
+    y, u, v = case["y"].copy(), case["u"].copy(), case["v"].copy()
+    d = _yuv_desc(y, u, v)
+    lfm = np.ascontiguousarray(case["lfm"])
+    rc = oracle().svt_oracle_lf_frame(C.byref(d), lfm.ctypes.data_as(C.c_void_p), lfm.shape[1], C.byref(case["thr"]),
+                                      case["mi_rows"], case["mi_cols"], int(y_only))
+    assert rc == 0
+    return y, u, v
+
+
+def ref_lf_frame(case, y_only=False):
+    exe = os.path.join(REF_DIR, "ref_lf_frame")
+    # the reference filters whole 8-sample groups and relies on the recon buffer's padding where a chroma block is
+    # only 4 samples wide/high: give it padded planes and crop afterwards
+    H0, W0 = case["y"].shape
+    y = np.ascontiguousarray(np.pad(case["y"], ((0, 32), (0, 32)), mode="edge"))
+    u = np.ascontiguousarray(np.pad(case["u"], ((0, 16), (0, 16)), mode="edge"))
+    v = np.ascontiguousarray(np.pad(case["v"], ((0, 16), (0, 16)), mode="edge"))
+    lfm = np.ascontiguousarray(case["lfm"])
+    with tempfile.TemporaryDirectory() as td:
+        req, rsp = os.path.join(td, "req.bin"), os.path.join(td, "rsp.bin")
+        with open(req, "wb") as f:
+            f.write(struct.pack("<10i", 0x464C5653, y.shape[1], y.shape[0], y.shape[1], u.shape[1], case["mi_rows"],
+                                case["mi_cols"], lfm.shape[1], lfm.size, int(y_only)))
+            f.write(bytes(case["thr"]))
+            f.write(lfm.tobytes())
+            f.write(y.tobytes()); f.write(u.tobytes()); f.write(v.tobytes())
+        subprocess.check_call([exe, req, rsp])
+        raw = open(rsp, "rb").read()
+    ys, us = y.size, u.size
+    return (np.frombuffer(raw, np.uint8, ys).reshape(y.shape)[:H0, :W0].copy(),
+            np.frombuffer(raw, np.uint8, us, ys).reshape(u.shape)[:H0 // 2, :W0 // 2].copy(),
+            np.frombuffer(raw, np.uint8, us, ys + us).reshape(v.shape)[:H0 // 2, :W0 // 2].copy())
+
+
+def hip_lf_frame(ctx, case, y_only=False):
+    y, u, v = case["y"].copy(), case["u"].copy(), case["v"].copy()
+    d = _yuv_desc(y, u, v)
+    lfm = np.ascontiguousarray(case["lfm"])
+    B.check(B.load().svt_hip_lf_frame(ctx, C.byref(d), lfm.ctypes.data_as(C.c_void_p), lfm.shape[1], C.byref(case["thr"]),
+                                      case["mi_rows"], case["mi_cols"], int(y_only)))
+    return y, u, v
