@@ -302,6 +302,11 @@ typedef struct svt_yuv_planes {
 int32_t svt_hip_lf_frame_device(svt_hip_ctx *ctx, const svt_yuv_planes *d_recon, const svt_lf_mask *d_lfm,
                                 int32_t lfm_stride, const svt_lf_thresh *thr, int32_t mi_rows, int32_t mi_cols,
                                 int32_t y_only);
+/* Several independent frames in one launch (their SB-row wavefronts interleave and fill the GPU).  Host arrays of
+ * n_pics entries; every pointer inside them is a device pointer. */
+int32_t svt_hip_lf_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_yuv_planes *d_recon,
+                                const svt_lf_mask *const *d_lfm, const int32_t *lfm_stride, const svt_lf_thresh *thr,
+                                const int32_t *mi_rows, const int32_t *mi_cols, int32_t y_only);
 /* Host-pointer convenience form (planes are tightly described by recon; rows*stride bytes copied). */
 int32_t svt_hip_lf_frame(svt_hip_ctx *ctx, const svt_yuv_planes *recon, const svt_lf_mask *lfm, int32_t lfm_stride,
                          const svt_lf_thresh *thr, int32_t mi_rows, int32_t mi_cols, int32_t y_only);

@@ -94,7 +94,7 @@ EXPORTS = [
     "svt_hip_ctx_destroy", "svt_hip_ctx_synchronize", "svt_hip_last_error", "svt_hip_last_kernel_ms",
     "svt_hip_me_picture_device", "svt_hip_me_batch_device", "svt_hip_me_picture", "svt_hip_sad_loop_batch_device",
     "svt_hip_tq_batch_device", "svt_hip_tq_batch", "svt_hip_lf_thresh_init", "svt_hip_lf_level_from_q",
-    "svt_hip_lf_frame_device", "svt_hip_lf_frame",
+    "svt_hip_lf_frame_device", "svt_hip_lf_batch_device", "svt_hip_lf_frame",
 ]
 
 _lib = None
@@ -111,6 +111,7 @@ def load():
         _lib.svt_hip_last_kernel_ms.restype = C.c_float
         _lib.svt_hip_last_kernel_ms.argtypes = [C.c_void_p]
         _lib.svt_hip_lf_thresh_init.restype = None
+        _lib.svt_hip_lf_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     return _lib
 
 
