@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by running the REFERENCE (oracle/_ref, built from /root/reference by oracle/Makefile)
+on seeded inputs.  Run in the build container only:  python tests/gen_golden.py
+The fixtures hold inputs' seeds/parameters and the reference's outputs (data only)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import me_configs as MC  # noqa: E402
+import svt_testlib as T  # noqa: E402
+
+G = T.GOLDEN_DIR
+
+
+def main():
+    assert T.ref_kernels() is not None and T.have_ref("ref_me_sb") and T.have_ref("ref_lf_frame"), "build oracle/_ref first"
+    np.savez_compressed(os.path.join(G, "vp9_scan_tables.npz"), **T.ref_scan_tables())
+    # ---- ME: reference motion_estimate_sb results ----
+    me = {}
+    for name in MC.PRESETS:
+        for nl, tl, clip in ((2, 1, "subpel"), (1, 0, "int"), (2, 3, "subpel")):
+            gen = T.gen_clip if clip == "int" else T.gen_clip_subpel
+            pics = [T.PaPic(f) for f in gen(264, 200, 3, 11)]
+            res, rc = T.ref_me_picture(pics[1], pics[0], pics[2] if nl == 2 else None, MC.preset(name, nl, tl))
+            me[f"{name}|{nl}|{tl}|{clip}"] = res
+    np.savez_compressed(os.path.join(G, "me_reference.npz"), **me)
+    # ---- TQ: reference kernels on the seeded block list of make_tq_case ----
+    tq = {}
+    for seed in (1, 2):
+        case = T.make_tq_case(seed)
+        n_blocks = len(case["blocks"])
+        q_all = np.zeros(case["n_coeff"], np.int16)
+        dq_all = np.zeros(case["n_coeff"], np.int16)
+        eobs = np.zeros(n_blocks, np.uint16)
+        recon = np.zeros_like(case["src"])
+        for i, b in enumerate(case["blocks"]):
+            ts, tt = int(b["tx_size"]), int(b["tx_type"]) if b["tx_size"] < 3 else 0
+            n = T.TX_N[ts]
+            y, x = divmod(int(b["src_off"]), case["src"].shape[1])
+            res = case["src"][y:y + n, x:x + n].astype(np.int16) - case["pred"][y:y + n, x:x + n].astype(np.int16)
+            co = T.ref_fwd_txfm(res, ts, tt, bool(b["partial32"]))
+            q, dq, eob = T.ref_quantize(co, ts, tt, case["qtabs"][int(b["qtab"])])
+            off = int(b["coeff_off"])
+            q_all[off:off + n * n], dq_all[off:off + n * n], eobs[i] = q, dq, eob
+            pred = case["pred"][y:y + n, x:x + n]
+            recon[y:y + n, x:x + n] = T.ref_inv_add(dq, pred, ts, tt, eob) if eob else pred
+        tq[f"q{seed}"], tq[f"dq{seed}"], tq[f"eob{seed}"], tq[f"recon{seed}"] = q_all, dq_all, eobs, recon
+    np.savez_compressed(os.path.join(G, "tq_reference.npz"), **tq)
+    # ---- LF: reference eb_vp9_loop_filter_frame ----
+    lf = {}
+    for (w, h, seed, sharp) in ((200, 136, 2, 0), (328, 200, 3, 4), (72, 72, 5, 0)):
+        y, u, v = T.ref_lf_frame(T.make_lf_case(seed, w, h, sharp))
+        lf[f"y|{w}|{h}|{seed}|{sharp}"], lf[f"u|{w}|{h}|{seed}|{sharp}"], lf[f"v|{w}|{h}|{seed}|{sharp}"] = y, u, v
+    np.savez_compressed(os.path.join(G, "lf_reference.npz"), **lf)
+    for f in sorted(os.listdir(G)):
+        print(f, os.path.getsize(os.path.join(G, f)))
+
+
+if __name__ == "__main__":
+    main()
