@@ -76,11 +76,17 @@ def main():
     # ---- synthetic mini-GOP (+ the previous base-layer picture), resident in HBM ----
     frames = T.gen_clip(Wd, Hd, MINIGOP + 1, seed=11 + rank)
     dev = torch.device("cuda", local_rank)
+    keep = []  # keeps device tensors alive
+
+    def to_dev(a):
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        keep.append(t)
+        return t
 
     class DevPic:
         def __init__(self, luma):
             pa = T.PaPic(luma)
-            self.t = [torch.from_numpy(a).to(dev) for a, _ in pa.planes()]
+            self.t = [to_dev(a) for a, _ in pa.planes()]
             self.pads = [p for _, p in pa.planes()]
 
         def desc(self):
@@ -95,7 +101,7 @@ def main():
             return d
 
     pics = [DevPic(f) for f in frames]  # index 0 = previous base picture, 1..16 = the mini-GOP
-    results = [torch.zeros((nsb, 85 * 10), dtype=torch.int32, device=dev) for _ in range(MINIGOP + 1)]
+    results = [to_dev(np.zeros((nsb, 85 * 10), np.int32)) for _ in range(MINIGOP + 1)]
 
     # references inside the mini-GOP (display order): picture i at layer l is predicted from the nearest
     # lower-layer pictures on both sides; the base-layer picture (16) from the previous base picture (0).
@@ -106,26 +112,116 @@ def main():
         span = MINIGOP >> l
         return i - span, i + span
 
-    # group pictures by temporal layer: one batched launch per layer (parameters differ per layer)
-    launches = []
+    # ---- stage 1: motion estimation, one batched launch per temporal layer (parameters differ per layer) ----
+    ctx_me, ctx_tq, ctx_lf = ctx, C.c_void_p(), C.c_void_p()
+    B.check(lib.svt_hip_ctx_create(C.byref(ctx_tq), local_rank))
+    B.check(lib.svt_hip_ctx_create(C.byref(ctx_lf), local_rank))
+    me_launches = []
     for layer in range(5):
         idx = [i for i in range(1, MINIGOP + 1) if LAYER[i - 1] == layer]
-        nl = 2
-        p = MC.preset(preset_name, nl, layer, 4)
+        p = MC.preset(preset_name, 2, layer, 4)
         p.same_ref_poc = 1 if layer == 0 else 0
         n = len(idx)
         cur = (B.PaPicture * n)(*[pics[i].desc() for i in idx])
         r0 = (B.PaPicture * n)(*[pics[refs(i)[0]].desc() for i in idx])
         r1 = (B.PaPicture * n)(*[pics[refs(i)[1]].desc() for i in idx])
         res = (C.c_void_p * n)(*[results[i].data_ptr() for i in idx])
-        launches.append((n, cur, r0, r1, p, res))
+        me_launches.append((n, cur, r0, r1, p, res))
+
+    # ---- stage 2: transform / quantisation / reconstruction of the encode pass: every sample of the 4:2:0 picture
+    # is covered by exactly one transform block (sizes 4x4..32x32 mixed per 32x32 area, DCT/ADST types mixed) ----
+    rng = np.random.default_rng(5)
+    plane_w = Wd  # Y rows followed by U rows and V rows (half width, stored at stride Wd) in one buffer
+    yuv_rows = Hd + Hd // 2
+    iscan, offs = T.iscan_array()
+    qtabs = np.array([T.quant_table(a, b) for a, b in ((40, 48), (44, 52), (36, 44))], dtype=B.QUANT_DTYPE)
+    areas = [(0, 0, Wd // 32, Hd // 32)] + [(Hd, 0, Wd // 64, Hd // 64), (Hd, Wd // 2, Wd // 64, Hd // 64)]
+    blist = []
+    for (row0, col0, aw, ah) in areas:
+        ts_area = rng.integers(0, 4, (ah, aw))
+        for ay in range(ah):
+            for ax in range(aw):
+                ts = int(ts_area[ay, ax])
+                n = T.TX_N[ts]
+                k = 32 // n
+                ys = (row0 + ay * 32 + np.arange(k) * n)[:, None].repeat(k, 1).ravel()
+                xs = (col0 + ax * 32 + np.arange(k) * n)[None, :].repeat(k, 0).ravel()
+                blist.append((ts, ys, xs))
+    tq_arr = []
+    counts = np.zeros(4, np.int32)
+    pos = 0
+    for ts in range(4):
+        ys = np.concatenate([b[1] for b in blist if b[0] == ts])
+        xs = np.concatenate([b[2] for b in blist if b[0] == ts])
+        n = T.TX_N[ts]
+        a = np.zeros(len(ys), dtype=B.TQ_BLOCK_DTYPE)
+        off = (ys * plane_w + xs).astype(np.uint32)
+        a["src_off"] = a["pred_off"] = a["recon_off"] = off
+        a["coeff_off"] = pos + np.arange(len(ys), dtype=np.uint32) * (n * n)
+        tt = rng.integers(0, 4, len(ys)) if ts < 3 else np.zeros(len(ys), int)
+        a["iscan_off"] = np.array([offs[(ts, int(t))] for t in range(4)], dtype=np.uint32)[tt]
+        a["src_stride"] = a["pred_stride"] = a["recon_stride"] = plane_w
+        a["tx_size"], a["tx_type"], a["qtab"], a["do_recon"] = ts, tt, rng.integers(0, 3, len(ys)), 1
+        pos += len(ys) * n * n
+        counts[ts] = len(ys)
+        tq_arr.append(a)
+    tq_blocks = np.concatenate(tq_arr)
+    n_coeff = pos
+    d_blocks, d_qt, d_iscan = to_dev(tq_blocks.view(np.uint8)), to_dev(qtabs.view(np.uint8)), to_dev(iscan)
+    d_q, d_dq = to_dev(np.zeros(n_coeff, np.int16)), to_dev(np.zeros(n_coeff, np.int16))
+    d_eob = to_dev(np.zeros(len(tq_blocks), np.uint16))
+    tq_pics = []
+    for i in range(1, MINIGOP + 1):
+        y = frames[i]
+        yuv = np.zeros((yuv_rows, plane_w), np.uint8)
+        yuv[:Hd] = y
+        yuv[Hd:, :Wd // 2] = y[::2, ::2] // 2 + 32
+        yuv[Hd:, Wd // 2:] = 128
+        pred = np.clip(np.roll(yuv, (1, 2), (0, 1)).astype(np.int16) + rng.integers(-6, 7, yuv.shape, dtype=np.int16), 0, 255).astype(np.uint8)
+        tq_pics.append((to_dev(yuv), to_dev(pred), to_dev(np.zeros_like(yuv))))
+    cnt_c = (C.c_int32 * 4)(*counts.tolist())
+
+    # ---- stage 3: in-loop deblocking of the 16 reconstructed pictures, one batched launch ----
+    mi_rows, mi_cols = Hd // 8, Wd // 8
+    lfm = T.gen_lf_masks(np.random.default_rng(9), (mi_rows + 7) // 8, (mi_cols + 7) // 8)
+    d_lfm = to_dev(np.ascontiguousarray(lfm).view(np.uint8))
+    thr = B.LfThresh()
+    lib.svt_hip_lf_thresh_init(C.byref(thr), 0)
+    lf_desc = (B.YuvPlanes * MINIGOP)()
+    for k, (_, _, rec) in enumerate(tq_pics):
+        base = rec.data_ptr()
+        d = lf_desc[k]
+        d.y, d.u, d.v = base, base + Hd * plane_w, base + Hd * plane_w + Wd // 2
+        d.y_stride, d.uv_stride, d.width, d.height = plane_w, plane_w, Wd, Hd
+    lfm_ptrs = (C.c_void_p * MINIGOP)(*[d_lfm.data_ptr()] * MINIGOP)
+    i32 = lambda v: (C.c_int32 * MINIGOP)(*[v] * MINIGOP)
+    lfs, mrs, mcs = i32(lfm.shape[1]), i32(mi_rows), i32(mi_cols)
+
+    def run_me():
+        for n, cur, r0, r1, p, res in me_launches:
+            B.check(lib.svt_hip_me_batch_device(ctx_me, n, cur, r0, r1, C.byref(p), res, None))
+
+    def run_tq():
+        for (s_, p_, r_) in tq_pics:
+            B.check(lib.svt_hip_tq_batch_device(ctx_tq, C.c_void_p(s_.data_ptr()), C.c_void_p(p_.data_ptr()), C.c_void_p(r_.data_ptr()),
+                                                C.c_void_p(d_blocks.data_ptr()), cnt_c, C.c_void_p(d_qt.data_ptr()),
+                                                C.c_void_p(d_iscan.data_ptr()), C.c_void_p(d_q.data_ptr()), C.c_void_p(d_dq.data_ptr()),
+                                                C.c_void_p(d_eob.data_ptr())))
+
+    def run_lf():
+        B.check(lib.svt_hip_lf_batch_device(ctx_lf, MINIGOP, lf_desc, lfm_ptrs, lfs, C.byref(thr), mrs, mcs, 0))
 
     def step():
-        for n, cur, r0, r1, p, res in launches:
-            B.check(lib.svt_hip_me_batch_device(ctx, n, cur, r0, r1, C.byref(p), res, None))
+        # the three stages work on different pictures of the pipeline (as the reference's ME / EncDec threads do), so
+        # they are issued on three streams; deblocking of a step's pictures is ordered after their reconstruction
+        run_me()
+        run_tq()
+        B.check(lib.svt_hip_ctx_synchronize(ctx_tq))
+        run_lf()
 
     def sync():
-        B.check(lib.svt_hip_ctx_synchronize(ctx))
+        for c_ in (ctx_me, ctx_tq, ctx_lf):
+            B.check(lib.svt_hip_ctx_synchronize(c_))
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -145,24 +241,36 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # ---- per-kernel timing (HIP events on the context's stream), outside the timed region ----
-    kern_ms, kern_bytes = 0.0, 0
-    l1_on = bool(launches[0][4].enable_hme_level_1_flag)
-    reps = 5
-    for n, cur, r0, r1, p, res in launches:
+    # ---- per-kernel timing with HIP events recorded on each context's own stream, outside the timed region ----
+    def timed(ctx_, fn, reps=3):
+        tot = 0.0
         for _ in range(reps):
-            B.check(lib.svt_hip_me_batch_device(ctx, n, cur, r0, r1, C.byref(p), res, None))
-            B.check(lib.svt_hip_ctx_synchronize(ctx))
-            kern_ms += lib.svt_hip_last_kernel_ms(ctx)
-        kern_bytes += n * algorithmic_bytes_me(Wd, Hd, 2, l1_on)
-    kern_ms /= reps
-    achieved = kern_bytes / (kern_ms * 1e-3) / 1e9  # GB/s
+            fn()
+            B.check(lib.svt_hip_ctx_synchronize(ctx_))
+            tot += lib.svt_hip_last_kernel_ms(ctx_)
+        return tot / reps
+
+    l1_on = bool(me_launches[0][4].enable_hme_level_1_flag)
+    me_ms = 0.0
+    for n, cur, r0, r1, p, res in me_launches:
+        me_ms += timed(ctx_me, lambda: B.check(lib.svt_hip_me_batch_device(ctx_me, n, cur, r0, r1, C.byref(p), res, None)))
+    me_bytes = MINIGOP * algorithmic_bytes_me(Wd, Hd, 2, l1_on)
+    s0, p0, r0_ = tq_pics[0]
+    tq_ms = MINIGOP * timed(ctx_tq, lambda: B.check(lib.svt_hip_tq_batch_device(
+        ctx_tq, C.c_void_p(s0.data_ptr()), C.c_void_p(p0.data_ptr()), C.c_void_p(r0_.data_ptr()), C.c_void_p(d_blocks.data_ptr()), cnt_c,
+        C.c_void_p(d_qt.data_ptr()), C.c_void_p(d_iscan.data_ptr()), C.c_void_p(d_q.data_ptr()), C.c_void_p(d_dq.data_ptr()),
+        C.c_void_p(d_eob.data_ptr()))))
+    L = Wd * Hd
+    tq_bytes = MINIGOP * int(7.5 * L)                      # src 1.5L + pred 1.5L + qcoeff 3L + recon 1.5L
+    lf_ms = timed(ctx_lf, run_lf)
+    lf_bytes = MINIGOP * (3 * L + 160 * nsb)               # recon read + write (3L) + masks
+    achieved = me_bytes / (me_ms * 1e-3) / 1e9  # GB/s
 
     if rank != 0:
         return
     fps = MINIGOP * args.steps * world / dt
     out = {
-        "metric": "encoded frames/sec (block-level DSP hot path: motion estimation), 4Kp60 yuv420p enc-mode 8",
+        "metric": "encoded frames/sec (block-level DSP hot path: ME + DCT/quant/recon + deblock), 4Kp60 yuv420p enc-mode 8",
         "value": round(fps, 2),
         "unit": "frames/s",
         "mpixels_per_s": round(fps * Wd * Hd / 1e6, 1),
@@ -177,10 +285,15 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{Wd}x{Hd} 8-bit yuv420p, -enc-mode 8 -tune 1, 1xMI355X per rank; step = one 16-picture "
                                "mini-GOP (5 temporal layers, B pictures, 2 reference lists) through the hot path",
-                   "stages": ["motion_estimation"], "pictures_per_step": MINIGOP, "parallelism": f"gop-shard x{world}"},
+                   "stages": ["motion_estimation", "transform_quant_recon", "deblocking"], "pictures_per_step": MINIGOP,
+                   "parallelism": f"gop-shard x{world}"},
         "roofline": {"bound": "hbm", "kernel": "svt_me_sb_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
                      "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
-                     "kernel_ms_per_step": round(kern_ms, 3), "algorithmic_bytes_per_step": kern_bytes},
+                     "kernel_ms_per_step": round(me_ms, 3), "algorithmic_bytes_per_step": me_bytes},
+        "kernels": {k: {"ms_per_step": round(ms, 3), "algorithmic_bytes_per_step": b, "GB_per_s": round(b / (ms * 1e-3) / 1e9, 2),
+                        "frac_of_8TBps": round(b / (ms * 1e-3) / 8e12, 5)}
+                    for k, ms, b in (("svt_me_sb_kernel", me_ms, me_bytes), ("svt_tq_kernel<4|8|16|32>", tq_ms, tq_bytes),
+                                     ("svt_lf_kernel", lf_ms, lf_bytes))},
     }
     if not args.no_cpu_baseline:
         # oracle (scalar C restatement of the reference C path), single thread, on a bounded sample of the same
@@ -202,7 +315,8 @@ def main():
                                "sample": f"oracle ME (scalar C restatement, gcc -O2) on {n_done} whole {Wd}x{Hd} B pictures "
                                          f"(mini-GOP positions {used}) in {cdt:.1f} s, one thread"}
     print(json.dumps(out))
-    lib.svt_hip_ctx_destroy(ctx)
+    for c_ in (ctx_me, ctx_tq, ctx_lf):
+        lib.svt_hip_ctx_destroy(c_)
 
 
 if __name__ == "__main__":

@@ -38,6 +38,8 @@ static int32_t ctx_create(svt_hip_ctx **out, int32_t device, void *stream, int o
     }
     c->owns_stream = owns;
     if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) { free(c); return svt_set_error(SVT_HIP_ERR_DEVICE, "ctx: events"); }
+    for (int i = 0; i < SVT_CTX_RING; i++)
+        if (hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming) != hipSuccess) { free(c); return svt_set_error(SVT_HIP_ERR_DEVICE, "ctx: events"); }
     *out = c;
     return SVT_HIP_OK;
 }
@@ -49,8 +51,11 @@ extern "C" void svt_hip_ctx_destroy(svt_hip_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < SVT_CTX_SLOTS; i++) if (c->slot[i]) (void)hipFree(c->slot[i]);
-    if (c->dev_scratch) (void)hipFree(c->dev_scratch);
-    if (c->host_scratch) (void)hipHostFree(c->host_scratch);
+    for (int i = 0; i < SVT_CTX_RING; i++) {
+        if (c->ring_dev[i]) (void)hipFree(c->ring_dev[i]);
+        if (c->ring_host[i]) (void)hipHostFree(c->ring_host[i]);
+        (void)hipEventDestroy(c->ring_ev[i]);
+    }
     (void)hipEventDestroy(c->ev_start);
     (void)hipEventDestroy(c->ev_stop);
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
@@ -69,31 +74,27 @@ extern "C" float svt_hip_last_kernel_ms(svt_hip_ctx *c) {
     return ms;
 }
 
-void *svt_ctx_host_scratch(svt_hip_ctx *c, size_t bytes) {
-    if (bytes > c->host_scratch_bytes) {
-        /* the previous buffer may still be the source of an in-flight copy */
-        (void)hipStreamSynchronize(c->stream);
-        if (c->host_scratch) (void)hipHostFree(c->host_scratch);
-        c->host_scratch = nullptr; c->host_scratch_bytes = 0;
+int svt_ctx_stage(svt_hip_ctx *c, size_t bytes, void **host, void **dev) {
+    const int s = c->ring_pos;
+    if (c->ring_used[s]) { if (hipEventSynchronize(c->ring_ev[s]) != hipSuccess) return -1; c->ring_used[s] = 0; }
+    if (bytes > c->ring_bytes[s]) {
+        if (c->ring_host[s]) (void)hipHostFree(c->ring_host[s]);
+        if (c->ring_dev[s]) (void)hipFree(c->ring_dev[s]);
+        c->ring_host[s] = nullptr; c->ring_dev[s] = nullptr; c->ring_bytes[s] = 0;
         size_t cap = bytes < 65536 ? 65536 : bytes * 2;
-        if (hipHostMalloc(&c->host_scratch, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
-        c->host_scratch_bytes = cap;
-    } else {
-        /* single staging buffer: wait until the previous call's copy has consumed it */
-        (void)hipStreamSynchronize(c->stream);
+        if (hipHostMalloc(&c->ring_host[s], cap, hipHostMallocDefault) != hipSuccess) return -1;
+        if (hipMalloc(&c->ring_dev[s], cap) != hipSuccess) return -1;
+        c->ring_bytes[s] = cap;
     }
-    return c->host_scratch;
+    *host = c->ring_host[s];
+    *dev  = c->ring_dev[s];
+    return 0;
 }
-void *svt_ctx_dev_scratch(svt_hip_ctx *c, size_t bytes) {
-    if (bytes > c->dev_scratch_bytes) {
-        (void)hipStreamSynchronize(c->stream);
-        if (c->dev_scratch) (void)hipFree(c->dev_scratch);
-        c->dev_scratch = nullptr; c->dev_scratch_bytes = 0;
-        size_t cap = bytes < 65536 ? 65536 : bytes * 2;
-        if (hipMalloc(&c->dev_scratch, cap) != hipSuccess) return nullptr;
-        c->dev_scratch_bytes = cap;
-    }
-    return c->dev_scratch;
+void svt_ctx_stage_commit(svt_hip_ctx *c) {
+    const int s = c->ring_pos;
+    (void)hipEventRecord(c->ring_ev[s], c->stream);
+    c->ring_used[s] = 1;
+    c->ring_pos = (s + 1) % SVT_CTX_RING;
 }
 void *svt_ctx_slot(svt_hip_ctx *c, int s, size_t bytes) {
     if (s < 0 || s >= SVT_CTX_SLOTS) return nullptr;

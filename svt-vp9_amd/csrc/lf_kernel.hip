@@ -310,9 +310,9 @@ static int32_t lf_launch(svt_hip_ctx *ctx, int n_pics, const svt_yuv_planes *d_r
     /* descriptors + progress counters + ticket in one device scratch block */
     const size_t desc_bytes = (sizeof(lf_pic_dev) * (size_t)n_pics + 15) & ~(size_t)15;
     const size_t cnt_words  = (size_t)n_pics * max_rows + 4;
-    lf_pic_dev  *h = (lf_pic_dev *)svt_ctx_host_scratch(ctx, desc_bytes);
-    uint8_t     *d = (uint8_t *)svt_ctx_dev_scratch(ctx, desc_bytes + cnt_words * 4);
-    if (!h || !d) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "lf: scratch");
+    lf_pic_dev  *h = nullptr;
+    uint8_t     *d = nullptr;
+    if (svt_ctx_stage(ctx, desc_bytes + cnt_words * 4, (void **)&h, (void **)&d)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "lf: scratch");
     uint32_t *cnt = (uint32_t *)(d + desc_bytes);
     for (int i = 0; i < n_pics; i++) {
         h[i].planes = d_recon[i]; h[i].lfm = d_lfm[i]; h[i].lfm_stride = lfm_stride[i]; h[i].mi_rows = mi_rows[i]; h[i].mi_cols = mi_cols[i];
@@ -324,6 +324,7 @@ static int32_t lf_launch(svt_hip_ctx *ctx, int n_pics, const svt_yuv_planes *d_r
     hipLaunchKernelGGL(svt_lf_kernel, dim3(n_pics * max_rows), dim3(128), 0, ctx->stream, (const lf_pic_dev *)d, n_pics, *thr, cnt, max_rows);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    svt_ctx_stage_commit(ctx);
     ctx->timed = 1;
     return SVT_HIP_OK;
 }

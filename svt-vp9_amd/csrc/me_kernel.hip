@@ -110,9 +110,8 @@ extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, con
     const int nx = (W + 63) / 64, ny = (H + 63) / 64, n_sb = nx * ny;
     HIP_TRY(hipSetDevice(ctx->device));
     /* picture descriptors -> device (pinned staging ring so that the copy is truly asynchronous) */
-    me_pic_dev *h = (me_pic_dev *)svt_ctx_host_scratch(ctx, sizeof(me_pic_dev) * (size_t)n_pics);
-    me_pic_dev *d = (me_pic_dev *)svt_ctx_dev_scratch(ctx, sizeof(me_pic_dev) * (size_t)n_pics);
-    if (!h || !d) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "me: descriptor buffers");
+    me_pic_dev *h = nullptr, *d = nullptr;
+    if (svt_ctx_stage(ctx, sizeof(me_pic_dev) * (size_t)n_pics, (void **)&h, (void **)&d)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "me: descriptor buffers");
     for (int i = 0; i < n_pics; i++) {
         if (cur[i].full.width != W || cur[i].full.height != H) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: batch pictures differ in size");
         memset(&h[i], 0, sizeof h[i]);
@@ -130,6 +129,7 @@ extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, con
     hipLaunchKernelGGL(svt_me_sb_kernel, dim3(chunk * 8), dim3(256), L.total_bytes, ctx->stream, d, *params, L, n_sb, nx, W, H, total, chunk);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    svt_ctx_stage_commit(ctx);
     ctx->timed = 1;
     return SVT_HIP_OK;
 }

@@ -7,6 +7,7 @@
 #include "../../include/svtvp9_hip.h"
 
 #define SVT_CTX_SLOTS 24
+#define SVT_CTX_RING 16
 
 struct svt_hip_ctx {
     int         device;
@@ -14,18 +15,24 @@ struct svt_hip_ctx {
     int         owns_stream;
     hipEvent_t  ev_start, ev_stop;
     int         timed;
-    void       *host_scratch;  /* pinned */
-    size_t      host_scratch_bytes;
-    void       *dev_scratch;
-    size_t      dev_scratch_bytes;
+    /* ring of staging slots (pinned host + device twin) for launch descriptors: a slot is reused only after the
+       event recorded behind its last consumer has completed, so launches never synchronise the stream */
+    void       *ring_host[SVT_CTX_RING];
+    void       *ring_dev[SVT_CTX_RING];
+    size_t      ring_bytes[SVT_CTX_RING];
+    hipEvent_t  ring_ev[SVT_CTX_RING];
+    int         ring_used[SVT_CTX_RING];
+    int         ring_pos;
     void       *slot[SVT_CTX_SLOTS]; /* grow-only device buffers of the host-pointer convenience entry points */
     size_t      slot_bytes[SVT_CTX_SLOTS];
 };
 
 int32_t svt_set_error(int32_t code, const char *msg);
 int32_t svt_set_hip_error(hipError_t e, const char *file, int line);
-void   *svt_ctx_host_scratch(svt_hip_ctx *ctx, size_t bytes);
-void   *svt_ctx_dev_scratch(svt_hip_ctx *ctx, size_t bytes);
+/* next staging slot with at least `bytes` in both twins; returns 0 on success */
+int     svt_ctx_stage(svt_hip_ctx *ctx, size_t bytes, void **host, void **dev);
+/* call after the last operation that reads the slot has been enqueued on ctx->stream */
+void    svt_ctx_stage_commit(svt_hip_ctx *ctx);
 void   *svt_ctx_slot(svt_hip_ctx *ctx, int slot, size_t bytes);
 
 #define HIP_TRY(expr)                                                        \
