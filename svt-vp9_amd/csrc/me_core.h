@@ -198,6 +198,7 @@ typedef struct me_ctx_t {
     uint8_t             *planes; /* LDS */
     uint8_t             *pred0;  /* LDS */
     int                  pic_w, pic_h, sb_x, sb_y, sb_w, sb_h, sb_index;
+    unsigned long long  *prof;   /* optional per-phase cycle accumulators (profiling builds), else NULL */
 } me_ctx_t;
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -739,6 +740,13 @@ SVT_DEV void ph_output(const me_ctx_t *c, int tid, svt_me_pu_result *out, uint32
 /* ------------------------------------------------------------------------------------------------ */
 /* driver: uniform control flow; PHASE(x) runs x for every thread and ends with a workgroup barrier     */
 /* ------------------------------------------------------------------------------------------------ */
+/* ME_MARK(i): when profiling is enabled, thread 0 adds the shader cycles since the previous mark to prof[i] */
+#if defined(SVT_HOST_EMU)
+#define ME_MARK(i) ((void)0)
+#else
+#define ME_MARK(i) do { if (c->prof && tid == 0) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        atomicAdd(&c->prof[(i)], now_ - mark_t_); mark_t_ = now_; } } while (0)
+#endif
 #ifdef SVT_HOST_EMU
 #define ME_PHASE(...) do { for (int tid = 0; tid < SVT_NT; tid++) { __VA_ARGS__; } } while (0)
 #define ME_UNIFORM_WRITE(...) do { __VA_ARGS__; } while (0)
@@ -830,8 +838,12 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
     uint64_t sl0[2][2] = {{0, 0}, {0, 0}}, sl1[2][2] = {{0, 0}, {0, 0}}, sl2[2][2] = {{0, 0}, {0, 0}};
     int      rw = 0, rh = 0;
     int16_t  x_hme_c = 0, y_hme_c = 0, xsc = 0, ysc = 0;
+#ifndef SVT_HOST_EMU
+    unsigned long long mark_t_ = c->prof ? __builtin_amdgcn_s_memtime() : 0;
+#endif
 
     ME_PHASE(ph_init(c, tid));
+    ME_MARK(0);
 
     for (int list = 0; list < nlist; list++) {
         const svt_plane *rf = &c->pic->ref[list].full, *rq = &c->pic->ref[list].quarter, *r16 = &c->pic->ref[list].sixteenth;
@@ -874,6 +886,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                 else { xsc = 0; ysc = (int16_t)th; }
                 ME_PHASE((void)0); /* everyone has read red[] */
             }
+            ME_MARK(1);
             /* ---- HME ---- */
             if (p->enable_hme_flag && c->sb_h == ME_SB) {
                 while (rh < NH) {
@@ -996,6 +1009,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                 }
                 xsc = x_hme_c; ysc = y_hme_c;
             }
+            ME_MARK(2);
         } else {
             xsc = 0; ysc = 0;
         }
@@ -1015,6 +1029,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
             if (m == z) { xsc = 0; ysc = 0; }
             ME_PHASE((void)0);
         }
+        ME_MARK(3);
         int16_t sox = (int16_t)(xsc - (saw >> 1)), soy = (int16_t)(ysc - (sah >> 1));
         me_clip_area(ox, &sox, &saw, ME_SB - 1, c->pic_w);
         me_clip_area(oy, &soy, &sah, ME_SB - 1, c->pic_h);
@@ -1028,6 +1043,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                  for (int t = tid; t < 85; t += SVT_NT) st->key[t] = ((uint64_t)ME_MAX_SAD_VALUE << 32);
                  );
 
+        ME_MARK(4);
         /* ---- full-pel search, in chunks of search rows ---- */
         {
             int max_pos   = c->L.scratch_bytes / 128; /* s8: 64 x u16 per position */
@@ -1041,7 +1057,9 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                 int nslice = npos >= 96 ? 3 : 1;
                 if (npos >= 1024) nslice = 12;
                 ME_PHASE(ph_fullpel_sad8(c, tid, s8, saw, y0, ny, w8));
+                ME_MARK(5);
                 ME_PHASE(ph_fullpel_argmin(c, tid, s8, saw, y0, ny, w8, nslice));
+                ME_MARK(6);
             }
             /* keys -> best sad / mv (curr_mv = (y << 18) | (uint16)(x << 2), :108-110) */
             ME_PHASE(for (int t = tid; t < 85; t += SVT_NT) {
@@ -1055,6 +1073,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
             });
         }
 
+        ME_MARK(7);
         /* ---- sub-pel ---- */
         int en32 = 0, en16 = 0, en8 = 0, enq = 0;
         if (p->fractional_search_model == 0) { en32 = en16 = en8 = enq = 1; }
@@ -1085,19 +1104,23 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
             enq  = 1;
         }
         const int need_planes = en32 || en16 || en8 || enq || (nlist == 2);
+        ME_MARK(8);
         if (need_planes) {
             ME_PHASE(ph_interp_bh(c, tid, W, H));
             ME_PHASE(ph_interp_j(c, tid, W, H));
         }
+        ME_MARK(9);
         if (en32 || en16 || en8 || enq) {
             ME_PHASE(for (int t = tid; t < 85 * 8; t += SVT_NT) st->cand[t] = 0);
             ME_PHASE(ph_halfpel(c, tid, list, sox, soy, en32, en16, en8));
             ME_PHASE(ph_halfpel_decide(c, tid, list, en32, en16, en8));
+            ME_MARK(10);
             if (enq) {
                 ME_PHASE(for (int t = tid; t < 85 * 8; t += SVT_NT) st->cand[t] = 0);
                 ME_PHASE(ph_quarterpel(c, tid, list, sox, soy, en32, en16, en8));
                 ME_PHASE(ph_quarterpel_decide(c, tid, list, en32, en16, en8));
             }
+            ME_MARK(11);
         }
         if (nlist == 2) {
             if (list == 0) ME_PHASE(ph_store_pred0(c, tid, sox, soy));
@@ -1105,6 +1128,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                 ME_PHASE(for (int t = tid; t < 85; t += SVT_NT) st->cand[t] = 0);
                 ME_PHASE(ph_bipred(c, tid, sox, soy));
             }
+            ME_MARK(12);
         }
     }
 
@@ -1124,6 +1148,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
             c->pic->rcme[c->sb_index] = acc;
         }
     }
+    ME_MARK(13);
 }
 
 #endif /* SVT_ME_CORE_H */

@@ -6,6 +6,8 @@
 #include "me_core.h"
 #include "me_layout.h"
 #include "svt_ctx.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 extern __shared__ __align__(16) uint8_t svt_lds[];
 
@@ -13,7 +15,7 @@ extern __shared__ __align__(16) uint8_t svt_lds[];
  * (neighbouring SBs, which share most of their reference window) are placed on the same XCD so that the
  * window re-reads hit that XCD's L2 (block b runs on XCD b % 8). */
 __global__ __launch_bounds__(256) void svt_me_sb_kernel(const me_pic_dev *__restrict__ pics, svt_me_params p, me_lds_layout L,
-                                                        int n_sb, int nx, int pic_w, int pic_h, int total, int chunk) {
+                                                        int n_sb, int nx, int pic_w, int pic_h, int total, int chunk, unsigned long long *prof) {
     const int b = blockIdx.x;
     const int l = (b & 7) * chunk + (b >> 3);
     if (l >= total) return;
@@ -28,7 +30,7 @@ __global__ __launch_bounds__(256) void svt_me_sb_kernel(const me_pic_dev *__rest
     c.region = svt_lds + L.off_region;
     c.planes = svt_lds + L.off_planes;
     c.pred0  = svt_lds + L.off_pred0;
-    c.pic_w = pic_w; c.pic_h = pic_h; c.sb_index = sb;
+    c.pic_w = pic_w; c.pic_h = pic_h; c.sb_index = sb; c.prof = prof;
     c.sb_x = (sb % nx) * ME_SB; c.sb_y = (sb / nx) * ME_SB;
     c.sb_w = (pic_w - c.sb_x) < ME_SB ? pic_w - c.sb_x : ME_SB;
     c.sb_h = (pic_h - c.sb_y) < ME_SB ? pic_h - c.sb_y : ME_SB;
@@ -125,10 +127,29 @@ extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, con
     const int total = n_sb * n_pics, chunk = (total + 7) / 8;
     if (L.total_bytes > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)svt_me_sb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L.total_bytes));
+    /* SVT_HIP_ME_PROFILE=1: per-phase shader-cycle breakdown (thread 0 of every workgroup), printed to stderr */
+    static const bool want_prof = getenv("SVT_HIP_ME_PROFILE") != nullptr;
+    unsigned long long *d_prof = nullptr;
+    if (want_prof) {
+        d_prof = (unsigned long long *)svt_ctx_slot(ctx, 9 + 14, 16 * sizeof(unsigned long long));
+        if (d_prof) HIP_TRY(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    }
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
-    hipLaunchKernelGGL(svt_me_sb_kernel, dim3(chunk * 8), dim3(256), L.total_bytes, ctx->stream, d, *params, L, n_sb, nx, W, H, total, chunk);
+    hipLaunchKernelGGL(svt_me_sb_kernel, dim3(chunk * 8), dim3(256), L.total_bytes, ctx->stream, d, *params, L, n_sb, nx, W, H, total, chunk, d_prof);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    if (d_prof) {
+        unsigned long long hp[16];
+        HIP_TRY(hipMemcpyAsync(hp, d_prof, sizeof hp, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        static const char *nm[14] = {"init", "center_sads", "hme", "zero_check", "region_load", "fullpel_sad8", "fullpel_argmin",
+                                     "keys2best", "supel_enable", "interp", "halfpel", "quarterpel", "pred0_bipred", "output"};
+        unsigned long long tot = 0;
+        for (int i = 0; i < 14; i++) tot += hp[i];
+        fprintf(stderr, "[me-profile] tl=%d pics=%d WGs=%d avg cycles/WG=%llu :", params->temporal_layer_index, n_pics, total, tot / (unsigned long long)total);
+        for (int i = 0; i < 14; i++) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * (double)hp[i] / (double)tot);
+        fprintf(stderr, "\n");
+    }
     svt_ctx_stage_commit(ctx);
     ctx->timed = 1;
     return SVT_HIP_OK;
