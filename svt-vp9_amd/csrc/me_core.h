@@ -60,6 +60,10 @@ static inline uint32_t svt_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
 }
 static inline void svt_lds_min_u64(uint64_t *p, uint64_t v) { if (v < *p) *p = v; }
 static inline void svt_lds_add_u32(uint32_t *p, uint32_t v) { *p += v; }
+/* host emulation runs lanes one after the other: a "wave reduction" degenerates to the per-lane update */
+static inline void svt_wave_add_u32(uint32_t *p, uint32_t v, int uniform_dst) { (void)uniform_dst; *p += v; }
+static inline void svt_wave_min_u64(uint64_t *p, uint64_t v) { if (v < *p) *p = v; }
+static inline void svt_group_add_u32(uint32_t *p, uint32_t v, int group) { (void)group; *p += v; }
 #else
 #include <hip/hip_runtime.h>
 #define SVT_DEV __device__ __forceinline__
@@ -71,6 +75,26 @@ SVT_DEV uint32_t svt_sad4(uint32_t a, uint32_t b, uint32_t acc) { return __built
 SVT_DEV uint32_t svt_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
 SVT_DEV void svt_lds_min_u64(uint64_t *p, uint64_t v) { atomicMin((unsigned long long *)p, (unsigned long long)v); }
 SVT_DEV void svt_lds_add_u32(uint32_t *p, uint32_t v) { atomicAdd(p, v); }
+/* sum over the 64 lanes of the wave (all lanes must call; inactive contributions pass 0) then ONE LDS atomic */
+SVT_DEV void svt_wave_add_u32(uint32_t *p, uint32_t v, int uniform_dst) {
+    (void)uniform_dst;
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(p, v);
+}
+/* min over the wave of 64-bit keys (pass ~0 for "nothing"), then ONE LDS atomic */
+SVT_DEV void svt_wave_min_u64(uint64_t *p, uint64_t v) {
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)v, o), hi = __shfl_xor((uint32_t)(v >> 32), o);
+        const uint64_t w = ((uint64_t)hi << 32) | lo;
+        v = w < v ? w : v;
+    }
+    if ((threadIdx.x & 63) == 0 && v != ~0ull) atomicMin((unsigned long long *)p, (unsigned long long)v);
+}
+/* sum over aligned groups of `group` (power of two <= 64) consecutive lanes that share one destination */
+SVT_DEV void svt_group_add_u32(uint32_t *p, uint32_t v, int group) {
+    for (int o = group >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & (group - 1)) == 0 && v) atomicAdd(p, v);
+}
 #endif
 
 #define ME_SB 64
@@ -248,15 +272,24 @@ SVT_DEV void ph_init(const me_ctx_t *c, int tid) {
  * Results accumulate in st->red[k]; caller doubles them. */
 SVT_DEV void ph_center_sads(const me_ctx_t *c, int tid, const svt_plane *ref, int ncand, const int16_t *dx, const int16_t *dy) {
     int rows = c->sb_h >> 1, wd = c->sb_w >> 2; /* dwords per row */
-    for (int t = tid; t < rows * wd; t += SVT_NT) {
-        int      r = t / wd, i = t - r * wd;
-        uint32_t s = *(const uint32_t *)(c->src + (2 * r) * ME_SB + 4 * i);
-        for (int k = 0; k < ncand; k++) {
-            const uint8_t *rp = me_pix(ref, c->sb_x + dx[k] + 4 * i, c->sb_y + dy[k] + 2 * r);
-            uint32_t       d  = svt_sad4(me_ld32u(rp), s, 0);
-            svt_lds_add_u32(&c->st->red[k], d);
+    int n = rows * wd;
+    uint32_t acc[5] = {0, 0, 0, 0, 0};
+    /* every thread takes part in the wave reductions below, so the loop bound is rounded up to the block size */
+    for (int t0 = 0; t0 < n; t0 += SVT_NT) {
+        int t = t0 + tid;
+        if (t < n) {
+            int      r = t / wd, i = t - r * wd;
+            uint32_t s = *(const uint32_t *)(c->src + (2 * r) * ME_SB + 4 * i);
+            uint32_t v[5];
+            /* issue all (independent) global loads before the first use */
+            _Pragma("unroll") for (int k = 0; k < 5; k++)
+                if (k < ncand) v[k] = me_ld32u(me_pix(ref, c->sb_x + dx[k] + 4 * i, c->sb_y + dy[k] + 2 * r));
+            _Pragma("unroll") for (int k = 0; k < 5; k++)
+                if (k < ncand) acc[k] = svt_sad4(v[k], s, acc[k]);
         }
     }
+    _Pragma("unroll") for (int k = 0; k < 5; k++)
+        if (k < ncand) svt_wave_add_u32(&c->st->red[k], acc[k], 1);
 }
 
 /* Generic exhaustive SAD search (= eb_vp9_sad_loop_kernel) over a window staged in LDS.
@@ -307,7 +340,7 @@ SVT_DEV void ph_sad_search(const me_ctx_t *c, int tid, const uint8_t *blk, int b
             if (k < best) best = k;
         }
     }
-    if (best != ~0ull) svt_lds_min_u64(&c->st->hme_key, best);
+    svt_wave_min_u64(&c->st->hme_key, best);
 }
 
 /* full-pel: sub-sampled 8x8 SADs of every (position, 8x8 block) of a chunk of search rows.
@@ -343,46 +376,41 @@ SVT_DEV void ph_fullpel_sad8(const me_ctx_t *c, int tid, uint16_t *s8, int sw, i
     }
 }
 
-/* full-pel: per-PU arg-min over the positions of the chunk.  Task = (pu in search order, slice). */
-SVT_DEV void ph_fullpel_argmin(const me_ctx_t *c, int tid, const uint16_t *s8, int sw, int y0, int ny, int w8, int nslice) {
+/* full-pel: 16x16 sums of every position of the chunk: s16[pos][k], k = raster 16x16 index.  In the 8-point path
+ * (x < w8) the reference keeps this sum in uint16 (C_DEFAULT/EbComputeSAD_C.c:201,276), in the tail path in 32 bits. */
+SVT_DEV void ph_fullpel_sum16(const me_ctx_t *c, int tid, const uint16_t *s8, uint32_t *s16, int sw, int ny, int w8) {
+    (void)c;
     int npos = sw * ny;
-    int per  = (npos + nslice - 1) / nslice;
-    for (int t = tid; t < 85 * nslice; t += SVT_NT) {
-        int pu = t % 85, sl = t / 85;
-        int p0 = sl * per, p1 = p0 + per < npos ? p0 + per : npos;
-        /* 8x8 blocks (raster ids) covered by this PU */
-        int bx0, by0, nb;
-        if (pu == 0) { bx0 = 0; by0 = 0; nb = 8; }
-        else if (pu < 5) { bx0 = ((pu - 1) & 1) * 4; by0 = ((pu - 1) >> 1) * 4; nb = 4; }
-        else if (pu < 21) {
-            int r = me_inv32x32[pu - 5]; /* search index -> raster 16x16 */
-            bx0 = (r & 3) * 2; by0 = (r >> 2) * 2; nb = 2;
-        } else {
-            int r = me_inv8x8[pu - 21];
-            bx0 = r & 7; by0 = r >> 3; nb = 1;
-        }
+    for (int t = tid; t < npos * 16; t += SVT_NT) {
+        int             pos = t >> 4, k = t & 15;
+        const uint16_t *q   = s8 + pos * 64 + (k >> 2) * 16 + (k & 3) * 2;
+        uint32_t        u   = (uint32_t)q[0] + q[1] + q[8] + q[9];
+        if ((pos % sw) < w8) u = (uint16_t)u;
+        s16[t] = u;
+    }
+}
+
+/* full-pel: per-PU arg-min.  One wave per PU (PUs round-robin over the 4 waves), lanes = search positions, then a
+ * wave-wide min of (2*sad << 32 | raster index): the unsigned min is exactly the reference's "first minimum in
+ * raster order" (strict '<' while scanning positions in raster order). */
+SVT_DEV void ph_fullpel_argmin(const me_ctx_t *c, int tid, const uint16_t *s8, const uint32_t *s16, int sw, int y0, int ny) {
+    int npos = sw * ny;
+    int wave = tid >> 6, lane = tid & 63;
+    for (int pu = wave; pu < 85; pu += SVT_NT / 64) {
         uint64_t best = ~0ull;
-        for (int pos = p0; pos < p1; pos++) {
-            const uint16_t *row = s8 + pos * 64;
-            int             x   = pos % sw;
-            uint32_t        sad;
-            if (nb == 1) sad = row[by0 * 8 + bx0];
+        for (int pos = lane; pos < npos; pos += 64) {
+            uint32_t sad;
+            if (pu >= 21) sad = s8[pos * 64 + me_inv8x8[pu - 21]];
             else {
-                /* sum 16x16 units; in the 8-point path each 16x16 sum is kept in uint16
-                   (C_DEFAULT/EbComputeSAD_C.c:201,276), in the tail path it is 32-bit */
-                sad = 0;
-                for (int uy = 0; uy < nb; uy += 2)
-                    for (int ux = 0; ux < nb; ux += 2) {
-                        const uint16_t *q = row + (by0 + uy) * 8 + bx0 + ux;
-                        uint32_t        u = (uint32_t)q[0] + q[1] + q[8] + q[9];
-                        if (x < w8) u = (uint16_t)u;
-                        sad += u;
-                    }
+                const uint32_t *q = s16 + pos * 16;
+                if (pu >= 5) sad = q[me_inv32x32[pu - 5]];
+                else if (pu >= 1) { int b = ((pu - 1) >> 1) * 8 + ((pu - 1) & 1) * 2; sad = q[b] + q[b + 1] + q[b + 4] + q[b + 5]; }
+                else { sad = 0; _Pragma("unroll") for (int i = 0; i < 16; i++) sad += q[i]; }
             }
             uint64_t k = ((uint64_t)(2 * sad) << 32) | (uint32_t)((y0 * sw) + pos);
             if (k < best) best = k;
         }
-        if (best != ~0ull) svt_lds_min_u64(&c->st->key[pu], best);
+        svt_wave_min_u64(&c->st->key[pu], best);
     }
 }
 
@@ -521,9 +549,8 @@ SVT_DEV void ph_halfpel(const me_ctx_t *c, int tid, int list, int sox, int soy, 
         /* rows split over ME_SUB_LANES lanes */
         int per = (rows + ME_SUB_LANES - 1) / ME_SUB_LANES;
         int r0 = sl * per, r1 = r0 + per < rows ? r0 + per : rows;
-        if (r0 >= r1) continue;
-        uint32_t d = me_block_sad_rows(sp, ME_SB * step, cp, 0, c->L.region_stride * step, w, r0, r1);
-        svt_lds_add_u32(&c->st->cand[pu * 8 + cand], d);
+        uint32_t d = r0 < r1 ? me_block_sad_rows(sp, ME_SB * step, cp, 0, c->L.region_stride * step, w, r0, r1) : 0;
+        svt_group_add_u32(&c->st->cand[pu * 8 + cand], d, ME_SUB_LANES); /* the 8 lanes of a task are consecutive */
     }
 }
 
@@ -612,9 +639,8 @@ SVT_DEV void ph_quarterpel(const me_ctx_t *c, int tid, int list, int sox, int so
         int            rows = sub_sad ? (w >> 1) : w, step = sub_sad ? 2 : 1;
         int            per = (rows + ME_SUB_LANES - 1) / ME_SUB_LANES;
         int            r0 = sl * per, r1 = r0 + per < rows ? r0 + per : rows;
-        if (r0 >= r1) continue;
-        uint32_t d = me_block_sad_rows(sp, ME_SB * step, a, b, c->L.region_stride * step, w, r0, r1);
-        svt_lds_add_u32(&c->st->cand[pu * 8 + pos], d);
+        uint32_t d = r0 < r1 ? me_block_sad_rows(sp, ME_SB * step, a, b, c->L.region_stride * step, w, r0, r1) : 0;
+        svt_group_add_u32(&c->st->cand[pu * 8 + pos], d, ME_SUB_LANES);
     }
 }
 
@@ -689,13 +715,17 @@ SVT_DEV void ph_bipred(const me_ctx_t *c, int tid, int sox, int soy) {
     for (int t = tid; t < n; t += SVT_NT) {
         int pu, r, i;
         me_bipred_task(t, &pu, &r, &i);
-        if (sub_sad && (r & 1)) continue;
-        int px, py, w;
-        me_pu_geom(pu, &px, &py, &w);
-        uint32_t s  = *(const uint32_t *)(c->src + (py + r) * ME_SB + px + 4 * i);
-        uint32_t va = *(const uint32_t *)(c->pred0 + 4 * t), vb = me_pred_dword(c, 1, sox, soy, pu, r, i);
-        uint32_t av = (va | vb) - (((va ^ vb) >> 1) & 0x7f7f7f7fu);
-        svt_lds_add_u32(&c->st->cand[pu], svt_sad4(av, s, 0));
+        uint32_t d = 0;
+        if (!(sub_sad && (r & 1))) {
+            int px, py, w;
+            me_pu_geom(pu, &px, &py, &w);
+            uint32_t s  = *(const uint32_t *)(c->src + (py + r) * ME_SB + px + 4 * i);
+            uint32_t va = *(const uint32_t *)(c->pred0 + 4 * t), vb = me_pred_dword(c, 1, sox, soy, pu, r, i);
+            uint32_t av = (va | vb) - (((va ^ vb) >> 1) & 0x7f7f7f7fu);
+            d = svt_sad4(av, s, 0);
+        }
+        /* consecutive tasks share the PU in runs of >= 64 (levels 0-2) or 16 (8x8 level) */
+        svt_group_add_u32(&c->st->cand[pu], d, (t >> 10) == 3 ? 16 : 64);
     }
 }
 
@@ -1046,19 +1076,18 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         ME_MARK(4);
         /* ---- full-pel search, in chunks of search rows ---- */
         {
-            int max_pos   = c->L.scratch_bytes / 128; /* s8: 64 x u16 per position */
+            int max_pos   = c->L.scratch_bytes / 192; /* s8: 64 x u16 + s16: 16 x u32 per position */
             int rows_chunk = max_pos / saw;
             if (rows_chunk < 1) rows_chunk = 1;
             if (rows_chunk > sah) rows_chunk = sah;
             uint16_t *s8 = (uint16_t *)c->planes;
             for (int y0 = 0; y0 < sah; y0 += rows_chunk) {
                 int ny = y0 + rows_chunk <= sah ? rows_chunk : sah - y0;
-                int npos = ny * saw;
-                int nslice = npos >= 96 ? 3 : 1;
-                if (npos >= 1024) nslice = 12;
+                uint32_t *s16 = (uint32_t *)(c->planes + (size_t)rows_chunk * saw * 128);
                 ME_PHASE(ph_fullpel_sad8(c, tid, s8, saw, y0, ny, w8));
+                ME_PHASE(ph_fullpel_sum16(c, tid, s8, s16, saw, ny, w8));
                 ME_MARK(5);
-                ME_PHASE(ph_fullpel_argmin(c, tid, s8, saw, y0, ny, w8, nslice));
+                ME_PHASE(ph_fullpel_argmin(c, tid, s8, s16, saw, y0, ny));
                 ME_MARK(6);
             }
             /* keys -> best sad / mv (curr_mv = (y << 18) | (uint16)(x << 2), :108-110) */
