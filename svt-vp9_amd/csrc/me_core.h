@@ -64,6 +64,13 @@ static inline void svt_lds_add_u32(uint32_t *p, uint32_t v) { *p += v; }
 static inline void svt_wave_add_u32(uint32_t *p, uint32_t v, int uniform_dst) { (void)uniform_dst; *p += v; }
 static inline void svt_wave_min_u64(uint64_t *p, uint64_t v) { if (v < *p) *p = v; }
 static inline void svt_group_add_u32(uint32_t *p, uint32_t v, int group) { (void)group; *p += v; }
+/* per 16-bit lane: min(max(v, 32), 287) - 32 */
+static inline uint32_t svt_pk_clamp_sub32(uint32_t v) {
+    uint32_t lo = v & 0xffffu, hi = v >> 16;
+    lo = (lo < 32 ? 32 : lo > 287 ? 287 : lo) - 32;
+    hi = (hi < 32 ? 32 : hi > 287 ? 287 : hi) - 32;
+    return lo | (hi << 16);
+}
 #else
 #include <hip/hip_runtime.h>
 #define SVT_DEV __device__ __forceinline__
@@ -73,6 +80,14 @@ SVT_DEV uint64_t svt_qsad(uint64_t ref8, uint32_t src4, uint64_t acc) {
 }
 SVT_DEV uint32_t svt_sad4(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
 SVT_DEV uint32_t svt_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+/* per 16-bit lane: min(max(v, 32), 287) - 32 (v_pk_max_u16 / v_pk_min_u16 / v_pk_sub_u16) */
+typedef unsigned short svt_u16x2 __attribute__((ext_vector_type(2)));
+SVT_DEV uint32_t svt_pk_clamp_sub32(uint32_t v) {
+    svt_u16x2 x = __builtin_bit_cast(svt_u16x2, v);
+    const svt_u16x2 lo = {32, 32}, hi = {287, 287};
+    x = __builtin_elementwise_min(__builtin_elementwise_max(x, lo), hi) - lo;
+    return __builtin_bit_cast(uint32_t, x);
+}
 SVT_DEV void svt_lds_min_u64(uint64_t *p, uint64_t v) { atomicMin((unsigned long long *)p, (unsigned long long)v); }
 SVT_DEV void svt_lds_add_u32(uint32_t *p, uint32_t v) { atomicAdd(p, v); }
 /* sum over the 64 lanes of the wave (all lanes must call; inactive contributions pass 0) then ONE LDS atomic */
@@ -390,56 +405,98 @@ SVT_DEV void ph_fullpel_sum16(const me_ctx_t *c, int tid, const uint16_t *s8, ui
     }
 }
 
-/* full-pel: per-PU arg-min.  One wave per PU (PUs round-robin over the 4 waves), lanes = search positions, then a
- * wave-wide min of (2*sad << 32 | raster index): the unsigned min is exactly the reference's "first minimum in
- * raster order" (strict '<' while scanning positions in raster order). */
-SVT_DEV void ph_fullpel_argmin(const me_ctx_t *c, int tid, const uint16_t *s8, const uint32_t *s16, int sw, int y0, int ny) {
+/* full-pel: 32x32 and 64x64 sums per position: s32[pos][5] = {four 32x32 in raster order, 64x64} */
+SVT_DEV void ph_fullpel_sum32(const me_ctx_t *c, int tid, const uint32_t *s16, uint32_t *s32, int npos) {
+    (void)c;
+    for (int t = tid; t < npos * 4; t += SVT_NT) {
+        int             pos = t >> 2, j = t & 3;
+        const uint32_t *q   = s16 + pos * 16 + (j >> 1) * 8 + (j & 1) * 2;
+        s32[pos * 5 + j]    = q[0] + q[1] + q[4] + q[5];
+    }
+}
+/* full-pel: per-PU arg-min, one thread per PU scanning the chunk's positions in raster order with the
+ * reference's strict '<' (first minimum wins); pu = search-order index. */
+SVT_DEV void ph_fullpel_argmin(const me_ctx_t *c, int tid, const uint16_t *s8, const uint32_t *s16, const uint32_t *s32, int sw,
+                               int y0, int ny) {
     int npos = sw * ny;
-    int wave = tid >> 6, lane = tid & 63;
-    for (int pu = wave; pu < 85; pu += SVT_NT / 64) {
-        uint64_t best = ~0ull;
-        for (int pos = lane; pos < npos; pos += 64) {
-            uint32_t sad;
-            if (pu >= 21) sad = s8[pos * 64 + me_inv8x8[pu - 21]];
-            else {
-                const uint32_t *q = s16 + pos * 16;
-                if (pu >= 5) sad = q[me_inv32x32[pu - 5]];
-                else if (pu >= 1) { int b = ((pu - 1) >> 1) * 8 + ((pu - 1) & 1) * 2; sad = q[b] + q[b + 1] + q[b + 4] + q[b + 5]; }
-                else { sad = 0; _Pragma("unroll") for (int i = 0; i < 16; i++) sad += q[i]; }
+    for (int pu = tid; pu < 85; pu += SVT_NT) {
+        uint64_t best = c->st->key[pu];
+        uint32_t bsad = (uint32_t)(best >> 32);
+        uint32_t bidx = (uint32_t)best;
+        if (pu >= 21) {
+            const uint16_t *q = s8 + me_inv8x8[pu - 21];
+            for (int pos = 0; pos < npos; pos++) { uint32_t v = 2u * q[pos * 64]; if (v < bsad) { bsad = v; bidx = (uint32_t)(y0 * sw + pos); } }
+        } else if (pu >= 5) {
+            const uint32_t *q = s16 + me_inv32x32[pu - 5];
+            for (int pos = 0; pos < npos; pos++) { uint32_t v = 2u * q[pos * 16]; if (v < bsad) { bsad = v; bidx = (uint32_t)(y0 * sw + pos); } }
+        } else if (pu >= 1) {
+            const uint32_t *q = s32 + (pu - 1);
+            for (int pos = 0; pos < npos; pos++) { uint32_t v = 2u * q[pos * 5]; if (v < bsad) { bsad = v; bidx = (uint32_t)(y0 * sw + pos); } }
+        } else {
+            for (int pos = 0; pos < npos; pos++) {
+                const uint32_t *q = s32 + pos * 5;
+                uint32_t        v = 2u * (q[0] + q[1] + q[2] + q[3]);
+                if (v < bsad) { bsad = v; bidx = (uint32_t)(y0 * sw + pos); }
             }
-            uint64_t k = ((uint64_t)(2 * sad) << 32) | (uint32_t)((y0 * sw) + pos);
-            if (k < best) best = k;
         }
-        svt_wave_min_u64(&c->st->key[pu], best);
+        c->st->key[pu] = ((uint64_t)bsad << 32) | bidx;
     }
 }
 
 SVT_DEV uint8_t me_clip8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
 SVT_DEV uint8_t me_tap4(int a, int b, int d, int e) { return me_clip8((-2 * a + 18 * b + 18 * d - 2 * e + 16) >> 5); }
 
+/* 4-tap {-2,18,18,-2} (+16)>>5 with clipping on 4 packed samples: a,b,d,e hold the 4 taps of 4 neighbouring
+ * outputs.  Even and odd bytes are processed as two 16-bit lanes of one register; a bias of 1024 (= 32 << 5) keeps
+ * every lane non-negative so nothing borrows across lanes: floor((S + 1024) / 32) = floor(S / 32) + 32. */
+SVT_DEV uint32_t me_tap4_half(uint32_t a, uint32_t b, uint32_t d, uint32_t e) {
+    uint32_t v = (b + d) * 18u + 0x04100410u - 2u * (a + e); /* per lane: 18(b+d) + 16 + 1024 - 2(a+e) in [20, 10220] */
+    v = (v >> 5) & 0x07ff07ffu;
+    return svt_pk_clamp_sub32(v); /* per lane: min(max(v, 32), 287) - 32 */
+}
+SVT_DEV uint32_t me_tap4_x4(uint32_t a, uint32_t b, uint32_t d, uint32_t e) {
+    const uint32_t M = 0x00ff00ffu;
+    uint32_t ev = me_tap4_half(a & M, b & M, d & M, e & M);
+    uint32_t od = me_tap4_half((a >> 8) & M, (b >> 8) & M, (d >> 8) & M, (e >> 8) & M);
+    return ev | (od << 8);
+}
+
 /* half-pel planes B (x+1/2,y) and H (x,y+1/2) from the region; natural coordinates, guard ME_PL_G
- * (interpolate_search_region_avc, Codec/EbMotionEstimation.c:992-1070; C_DEFAULT/EbAvcStyleMcp_C.c:25-73) */
+ * (interpolate_search_region_avc, Codec/EbMotionEstimation.c:992-1070; C_DEFAULT/EbAvcStyleMcp_C.c:25-73).
+ * One task = one dword (4 samples) of both planes: plane column px is region column px + 2 (ME_RGN_GX - ME_PL_G),
+ * so the 7 region bytes a B dword needs sit in two aligned region dwords. */
+#define ME_ILANES 32 /* lanes per plane row (a row has at most (127 + 63 + 4 + 3) / 4 = 50 dwords: two passes) */
 SVT_DEV void ph_interp_bh(const me_ctx_t *c, int tid, int W, int H) {
-    int      rs = c->L.region_stride, pw = W + 2 * ME_PL_G, ph = H + 2 * ME_PL_G;
-    uint8_t *B = c->planes, *Hh = c->planes + c->L.plane_bytes;
-    for (int t = tid; t < pw * ph; t += SVT_NT) {
-        int            py = t / pw, px = t - py * pw;
-        int            x = px - ME_PL_G, y = py - ME_PL_G;
-        const uint8_t *r = c->region + (ME_RGN_GY + y) * rs + ME_RGN_GX + x;
-        B[py * rs + px]  = me_tap4(r[-1], r[0], r[1], r[2]);
-        Hh[py * rs + px] = me_tap4(r[-rs], r[0], r[rs], r[2 * rs]);
-    }
+    int       rs = c->L.region_stride, pwd = (W + 2 * ME_PL_G + 3) >> 2, ph = H + 2 * ME_PL_G;
+    uint8_t  *B = c->planes, *Hh = c->planes + c->L.plane_bytes;
+    const int lane = tid & (ME_ILANES - 1), row0 = tid / ME_ILANES;
+    for (int py = row0; py < ph; py += SVT_NT / ME_ILANES)
+        for (int j = lane; j < pwd; j += ME_ILANES) {
+            /* region row of this plane row: y = py - ME_PL_G -> region row ME_RGN_GY + y */
+            const uint8_t  *rr = c->region + (ME_RGN_GY - ME_PL_G + py) * rs + 4 * j;
+            const uint32_t *r0 = (const uint32_t *)rr;
+            uint32_t        lo = r0[0], hi = r0[1];
+            /* bytes b0..b7 = lo,hi; output k uses b[k+1..k+4] */
+            uint32_t t1 = svt_alignbyte(hi, lo, 1), t2 = svt_alignbyte(hi, lo, 2), t3 = svt_alignbyte(hi, lo, 3);
+            *(uint32_t *)(B + py * rs + 4 * j) = me_tap4_x4(t1, t2, t3, hi);
+            /* vertical: samples at region byte offset 4j+2 of rows y-1, y, y+1, y+2 */
+            const uint32_t *ra = (const uint32_t *)(rr - rs), *rb = (const uint32_t *)(rr + rs), *rc = (const uint32_t *)(rr + 2 * rs);
+            uint32_t va = svt_alignbyte(ra[1], ra[0], 2), vc = svt_alignbyte(rb[1], rb[0], 2), vd = svt_alignbyte(rc[1], rc[0], 2);
+            *(uint32_t *)(Hh + py * rs + 4 * j) = me_tap4_x4(va, t2, vc, vd);
+        }
 }
 /* J (x+1/2, y+1/2) = vertical filter over B; defined for y in [-1, H-1] (H + 1 rows) */
 SVT_DEV void ph_interp_j(const me_ctx_t *c, int tid, int W, int H) {
-    int      rs = c->L.region_stride, pw = W + 2 * ME_PL_G;
-    uint8_t *B = c->planes, *J = c->planes + 2 * c->L.plane_bytes;
-    for (int t = tid; t < pw * (H + 1); t += SVT_NT) {
-        int            yy = t / pw, px = t - yy * pw;
-        int            py = yy + ME_PL_G - 1; /* y = yy - 1 */
-        const uint8_t *b  = B + py * rs + px;
-        J[py * rs + px]   = me_tap4(b[-rs], b[0], b[rs], b[2 * rs]);
-    }
+    int       rs = c->L.region_stride, pwd = (W + 2 * ME_PL_G + 3) >> 2;
+    uint8_t  *B = c->planes, *J = c->planes + 2 * c->L.plane_bytes;
+    const int lane = tid & (ME_ILANES - 1), row0 = tid / ME_ILANES;
+    for (int yy = row0; yy < H + 1; yy += SVT_NT / ME_ILANES)
+        for (int j = lane; j < pwd; j += ME_ILANES) {
+            int             py = yy + ME_PL_G - 1; /* y = yy - 1 */
+            const uint32_t *b  = (const uint32_t *)(B + py * rs + 4 * j);
+            const int       st = rs >> 2;
+            *(uint32_t *)(J + py * rs + 4 * j) = me_tap4_x4(b[-st], b[0], b[st], b[2 * st]);
+        }
 }
 
 enum { ME_PF = 0, ME_PB = 1, ME_PH = 2, ME_PJ = 3 };
@@ -450,18 +507,27 @@ SVT_DEV const uint8_t *me_plane_at(const me_ctx_t *c, int id, int x, int y) {
     return c->planes + (id - 1) * c->L.plane_bytes + (y + ME_PL_G) * rs + x + ME_PL_G;
 }
 
-/* SAD of a w x rows block: src rows at stride ss (LDS, dword aligned) vs candidate at any byte
- * alignment (stride cs), optionally averaged with a second candidate plane (b != 0). */
+/* SAD of a w x rows block: src rows at stride ss (LDS, dword aligned) vs candidate at any byte alignment (stride cs,
+ * a multiple of 4), optionally averaged with a second candidate plane (b != 0).  Each candidate row is fetched as
+ * w/4 + 1 aligned dwords and shifted into place with v_alignbyte. */
 SVT_DEV uint32_t me_block_sad_rows(const uint8_t *src, int ss, const uint8_t *a, const uint8_t *b, int cs, int w, int r0, int r1) {
-    uint32_t sad = 0;
+    uint32_t        sad = 0;
+    const uint32_t  sha = (uint32_t)((uintptr_t)a & 3), shb = b ? (uint32_t)((uintptr_t)b & 3) : 0;
+    const uint8_t  *a0 = a - sha, *b0 = b ? b - shb : a0;
+    const int       n = w >> 2;
     for (int r = r0; r < r1; r++) {
-        const uint32_t *s = (const uint32_t *)(src + r * ss);
-        for (int i = 0; i < (w >> 2); i++) {
-            uint32_t va = me_ld32u(a + r * cs + 4 * i);
+        const uint32_t *s  = (const uint32_t *)(src + r * ss);
+        const uint32_t *pa = (const uint32_t *)(a0 + r * cs), *pb = (const uint32_t *)(b0 + r * cs);
+        uint32_t        la = pa[0], lb = b ? pb[0] : 0;
+        for (int i = 0; i < n; i++) {
+            uint32_t ha = pa[i + 1];
+            uint32_t va = svt_alignbyte(ha, la, sha);
+            la = ha;
             if (b) {
-                uint32_t vb = me_ld32u(b + r * cs + 4 * i);
-                /* per-byte (a + b + 1) >> 1 without carries crossing bytes */
-                va = (va | vb) - (((va ^ vb) >> 1) & 0x7f7f7f7fu);
+                uint32_t hb = pb[i + 1];
+                uint32_t vb = svt_alignbyte(hb, lb, shb);
+                lb = hb;
+                va = (va | vb) - (((va ^ vb) >> 1) & 0x7f7f7f7fu); /* per-byte (a + b + 1) >> 1 */
             }
             sad = svt_sad4(va, s[i], sad);
         }
@@ -528,14 +594,31 @@ SVT_DEV int me_pu_refined(const me_ctx_t *c, int pu, int en32, int en16, int en8
 /* lanes cooperating on one candidate block (row-interleaved) */
 #define ME_SUB_LANES 8
 
-/* half-pel: task = (pu raster 0..84, cand 0..7, sub-lane).  Distortion accumulates in st->cand[pu*8+cand]
+/* the refined PUs of the current list as a dense index space: k in [0, me_active_count) -> raster pu */
+SVT_DEV int me_active_count(const me_ctx_t *c, int en32, int en16, int en8, int *n64, int *n32, int *n16) {
+    *n64 = c->p->fractional_search64x64 ? 1 : 0;
+    *n32 = en32 ? 4 : 0;
+    *n16 = (en16 && c->p->cu16x16_mode == 0) ? 16 : 0;
+    return *n64 + *n32 + *n16 + ((en8 && c->p->cu8x8_mode != 1) ? 64 : 0);
+}
+SVT_DEV int me_active_pu(int k, int n64, int n32, int n16) {
+    if (k < n64) return 0;
+    k -= n64;
+    if (k < n32) return 1 + k;
+    k -= n32;
+    if (k < n16) return 5 + k;
+    return 21 + k - n16;
+}
+
+/* half-pel: task = (refined pu, cand 0..7, sub-lane).  Distortion accumulates in st->cand[pu*8+cand]
  * (pre-zeroed).  SUB_SAD: rows 0,2,4.. only, doubled by the consumer; FULL_SAD: all rows. */
 SVT_DEV void ph_halfpel(const me_ctx_t *c, int tid, int list, int sox, int soy, int en32, int en16, int en8) {
     const int sub_sad = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH;
-    for (int t = tid; t < 85 * 8 * ME_SUB_LANES; t += SVT_NT) {
+    int       n64, n32, n16;
+    const int nact = me_active_count(c, en32, en16, en8, &n64, &n32, &n16);
+    for (int t = tid; t < nact * 8 * ME_SUB_LANES; t += SVT_NT) {
         int sl = t % ME_SUB_LANES, q = t / ME_SUB_LANES;
-        int cand = q & 7, pu = q >> 3;
-        if (!me_pu_refined(c, pu, en32, en16, en8)) continue;
+        int cand = q & 7, pu = me_active_pu(q >> 3, n64, n32, n16);
         int px, py, w;
         me_pu_geom(pu, &px, &py, &w);
         int      n  = me_pu_nidx(pu);
@@ -614,14 +697,17 @@ SVT_DEV int me_qvalid(int in_half, int dir, int pos) {
     }
 }
 
-/* quarter-pel: task = (pu, pos 0..7, sub-lane); only valid positions are evaluated.
+/* quarter-pel: task = (refined pu, j 0..2, sub-lane): the three positions around the half-pel direction.
+ * The direction codes TL,T,TR,R,BR,B,BL,L run clockwise, and me_qvalid() accepts position X when
+ * X is within one step of dir (integer best) or of the opposite of dir (half-pel best) (:1761-1796).
  * [quirk] the 64x64 PU is evaluated on its top-left 32x32 (:2525-2526). */
 SVT_DEV void ph_quarterpel(const me_ctx_t *c, int tid, int list, int sox, int soy, int en32, int en16, int en8) {
     const int sub_sad = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH;
-    for (int t = tid; t < 85 * 8 * ME_SUB_LANES; t += SVT_NT) {
+    int       n64, n32, n16;
+    const int nact = me_active_count(c, en32, en16, en8, &n64, &n32, &n16);
+    for (int t = tid; t < nact * 3 * ME_SUB_LANES; t += SVT_NT) {
         int sl = t % ME_SUB_LANES, q = t / ME_SUB_LANES;
-        int pos = q & 7, pu = q >> 3;
-        if (!me_pu_refined(c, pu, en32, en16, en8)) continue;
+        int k = q / 3, j = q - 3 * k, pu = me_active_pu(k, n64, n32, n16);
         int px, py, w;
         me_pu_geom(pu, &px, &py, &w);
         if (pu == 0) w = 32;
@@ -629,7 +715,8 @@ SVT_DEV void ph_quarterpel(const me_ctx_t *c, int tid, int list, int sox, int so
         uint32_t mv = c->st->best_mv[list][n];
         int16_t  xm = me_mvx(mv), ym = me_mvy(mv);
         int      method = (ym & 2) + ((xm & 2) >> 1);
-        if (!me_qvalid(method != 0, c->st->dir[n], pos)) continue;
+        int      dirx = ((method != 0 ? c->st->dir[n] ^ 4 : c->st->dir[n]) + j - 1) & 7;
+        int      pos  = (int)(0x07361524u >> (4 * dirx)) & 7; /* direction code -> L,R,T,B,TL,TR,BR,BL index */
         int xs = (int16_t)(((xm + 2) >> 2) - (int16_t)sox) + px;
         int ys = (int16_t)(((ym + 2) >> 2) - (int16_t)soy) + py;
         const int8_t  *e  = me_qtab[method][pos];
@@ -796,7 +883,7 @@ typedef struct me_hme_geom {
 #ifdef SVT_HOST_EMU
 static inline
 #else
-__device__
+__device__ __forceinline__
 #endif
 void me_hme_search(const me_ctx_t *c, int tid_, const me_hme_geom *g, int16_t sa_ox, int16_t sa_oy, int16_t sa_w, int16_t sa_h,
                    int floor16, uint64_t *best_sad, int16_t *xc, int16_t *yc, int scale) {
@@ -854,7 +941,7 @@ __attribute__((unused)) static
 #ifdef SVT_HOST_EMU
 static inline
 #else
-__device__
+__device__ __forceinline__
 #endif
 void me_sb_run(const me_ctx_t *c, int tid_) {
     int tid = tid_;
@@ -1076,7 +1163,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         ME_MARK(4);
         /* ---- full-pel search, in chunks of search rows ---- */
         {
-            int max_pos   = c->L.scratch_bytes / 192; /* s8: 64 x u16 + s16: 16 x u32 per position */
+            int max_pos   = c->L.scratch_bytes / 212; /* s8: 64 x u16 + s16: 16 x u32 + s32: 5 x u32 per position */
             int rows_chunk = max_pos / saw;
             if (rows_chunk < 1) rows_chunk = 1;
             if (rows_chunk > sah) rows_chunk = sah;
@@ -1084,10 +1171,12 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
             for (int y0 = 0; y0 < sah; y0 += rows_chunk) {
                 int ny = y0 + rows_chunk <= sah ? rows_chunk : sah - y0;
                 uint32_t *s16 = (uint32_t *)(c->planes + (size_t)rows_chunk * saw * 128);
+                uint32_t *s32 = s16 + (size_t)rows_chunk * saw * 16;
                 ME_PHASE(ph_fullpel_sad8(c, tid, s8, saw, y0, ny, w8));
                 ME_PHASE(ph_fullpel_sum16(c, tid, s8, s16, saw, ny, w8));
+                ME_PHASE(ph_fullpel_sum32(c, tid, s16, s32, ny * saw));
                 ME_MARK(5);
-                ME_PHASE(ph_fullpel_argmin(c, tid, s8, s16, saw, y0, ny));
+                ME_PHASE(ph_fullpel_argmin(c, tid, s8, s16, s32, saw, y0, ny));
                 ME_MARK(6);
             }
             /* keys -> best sad / mv (curr_mv = (y << 18) | (uint16)(x << 2), :108-110) */
