@@ -64,6 +64,7 @@ static inline void svt_lds_add_u32(uint32_t *p, uint32_t v) { *p += v; }
 static inline void svt_wave_add_u32(uint32_t *p, uint32_t v, int uniform_dst) { (void)uniform_dst; *p += v; }
 static inline void svt_wave_min_u64(uint64_t *p, uint64_t v) { if (v < *p) *p = v; }
 static inline void svt_group_add_u32(uint32_t *p, uint32_t v, int group) { (void)group; *p += v; }
+#define SVT_SCHED_FENCE() ((void)0)
 /* per 16-bit lane: min(max(v, 32), 287) - 32 */
 static inline uint32_t svt_pk_clamp_sub32(uint32_t v) {
     uint32_t lo = v & 0xffffu, hi = v >> 16;
@@ -88,6 +89,8 @@ SVT_DEV uint32_t svt_pk_clamp_sub32(uint32_t v) {
     x = __builtin_elementwise_min(__builtin_elementwise_max(x, lo), hi) - lo;
     return __builtin_bit_cast(uint32_t, x);
 }
+/* keeps the instruction scheduler from interleaving unrolled iterations (and their live registers) */
+#define SVT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 SVT_DEV void svt_lds_min_u64(uint64_t *p, uint64_t v) { atomicMin((unsigned long long *)p, (unsigned long long)v); }
 SVT_DEV void svt_lds_add_u32(uint32_t *p, uint32_t v) { atomicAdd(p, v); }
 /* sum over the 64 lanes of the wave (all lanes must call; inactive contributions pass 0) then ONE LDS atomic */
@@ -115,33 +118,51 @@ SVT_DEV void svt_group_add_u32(uint32_t *p, uint32_t v, int group) {
 #define ME_SB 64
 #define ME_MAX_SAD_VALUE (64 * 64 * 255)
 
+#ifdef SVT_HOST_EMU /* reference tables: the kernel derives them arithmetically, the emulation checks that */
 /* raster index -> search (z-order) index, Codec/EbMotionEstimation.c:51-54 */
 __attribute__((unused)) static
-#ifndef SVT_HOST_EMU
-    __device__
-#endif
     const uint8_t me_tab32x32[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
 __attribute__((unused)) static
-#ifndef SVT_HOST_EMU
-    __device__
-#endif
     const uint8_t me_tab8x8[64] = {0,  1,  4,  5,  16, 17, 20, 21, 2,  3,  6,  7,  18, 19, 22, 23, 8,  9,  12, 13, 24, 25,
                                    28, 29, 10, 11, 14, 15, 26, 27, 30, 31, 32, 33, 36, 37, 48, 49, 52, 53, 34, 35, 38, 39,
                                    50, 51, 54, 55, 40, 41, 44, 45, 56, 57, 60, 61, 42, 43, 46, 47, 58, 59, 62, 63};
 
 /* inverse maps: search (z-order) index -> raster index */
 __attribute__((unused)) static
-#ifndef SVT_HOST_EMU
-    __device__
-#endif
     const uint8_t me_inv32x32[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
 __attribute__((unused)) static
-#ifndef SVT_HOST_EMU
-    __device__
-#endif
     const uint8_t me_inv8x8[64] = {0,  1,  8,  9,  2,  3,  10, 11, 16, 17, 24, 25, 18, 19, 26, 27, 4,  5,  12, 13, 6,  7,
                                    14, 15, 20, 21, 28, 29, 22, 23, 30, 31, 32, 33, 40, 41, 34, 35, 42, 43, 48, 49, 56, 57,
                                    50, 51, 58, 59, 36, 37, 44, 45, 38, 39, 46, 47, 52, 53, 60, 61, 54, 55, 62, 63};
+#endif
+
+/* raster index -> search (z-order) index of the 8x8 / 16x16 PUs (Codec/EbMotionEstimation.c:51-54) by bit
+ * interleaving: raster = y*8 + x (3+3 bits) or y*4 + x (2+2 bits), z = ... y1 x1 y0 x0 */
+SVT_DEV int me_z8(int b) { return (b & 1) | ((b & 2) << 1) | ((b & 4) << 2) | ((b & 8) >> 2) | (b & 16) >> 1 | (b & 32); }
+SVT_DEV int me_z4(int b) { return (b & 1) | ((b & 2) << 1) | ((b & 4) >> 1) | (b & 8); }
+
+/* The sub-pel candidate tables are packed into immediates so that no phase has to fetch them from memory:
+ * a nibble holds plane (2 bits) | dx flag << 2 | dy flag << 3 (flag = -1 for the search tables, +1 for bi-pred). */
+#define ME_HCAND_PACK 0x73BF2A15u
+SVT_DEV void me_hcand_get(int cand, int *plane, int *dx, int *dy) {
+    uint32_t n = (ME_HCAND_PACK >> (4 * cand)) & 15u;
+    *plane = (int)(n & 3); *dx = -(int)((n >> 2) & 1); *dy = -(int)(n >> 3);
+}
+SVT_DEV uint32_t me_qtab_get(int method, int pos) { /* byte: first source nibble | second source nibble << 4 */
+    const uint64_t v = method == 0 ? 0x25121AA5200A1005ull : method == 1 ? 0x5625A55E755F0554ull
+                     : method == 2 ? 0xA51A9AAD0AA8BAAFull : 0x5EA5ADDE5FFDAFFEull;
+    return (uint32_t)(v >> (8 * pos)) & 0xffu;
+}
+SVT_DEV uint32_t me_btab_get(int frac, int *has_b) {
+    const uint64_t v = frac < 8 ? 0x6131212041011000ull : 0x9693928263033202ull;
+    *has_b = (int)((0xFAFAu >> frac) & 1u);
+    return (uint32_t)(v >> (8 * (frac & 7))) & 0xffu;
+}
+/* sign of the candidate displacement (L,R,T,B,TL,TR,BR,BL): half-pel moves by 2, quarter-pel by 1 quarter sample */
+SVT_DEV void me_dmv_get(int i, int *sx, int *sy) {
+    uint32_t n = (0x8A209164u >> (4 * i)) & 15u;
+    *sx = (int)(n & 3) - 1; *sy = (int)(n >> 2) - 1;
+}
 
 /* Picture descriptor as seen by the kernel (device pointers inside the planes). */
 typedef struct me_pic_dev {
@@ -156,7 +177,8 @@ typedef struct me_lds_layout {
     int32_t off_src;     /* 64 x 64 source SB, stride 64 */
     int32_t off_region;  /* integer reference samples of the current list's search region */
     int32_t off_planes;  /* B, H, J half-pel planes (3 x plane_bytes); aliased by HME window / SAD scratch */
-    int32_t off_pred0;   /* list-0 prediction blocks kept for bi-pred (85 PUs max: 16 KB) */
+    int32_t off_quarter; /* 32x32 quarter-resolution SB (only when HME level 1 is enabled) */
+    int32_t off_pred0;   /* list 0 prediction of the bi-pred lanes: levels * K * 256 dwords */
     int32_t region_stride, region_rows;
     int32_t plane_bytes;
     int32_t scratch_bytes; /* bytes available at off_planes */
@@ -169,17 +191,18 @@ typedef struct me_lds_layout {
 
 /* per-SB state in LDS */
 typedef struct me_state_t {
-    uint64_t key[85];          /* full-pel arg-min keys of the current list */
+    union {                    /* the full-pel keys are dead once the best MVs are extracted, before the first cand use */
+        uint64_t key[85];      /* full-pel arg-min keys of the current list */
+        uint32_t cand[85 * 8]; /* sub-pel candidate distortions [pu][8]; bi-pred distortion [pu] */
+    };
     uint64_t hme_key;          /* arg-min key of the running HME search */
+    uint64_t hme_keys[2][4];   /* arg-min keys of a batch of HME region searches, double buffered by batch parity */
     uint32_t best_sad[2][85];  /* search (z-order) index */
     uint32_t best_mv[2][85];
-    uint32_t bipred_sad[85];
-    uint32_t cand[85 * 8];     /* sub-pel candidate distortions [pu][8] */
     uint32_t red[8];           /* small sum reductions */
     uint32_t supel[9];         /* su_pel_enable sums: sx,sy,ssad for 32/16/8 */
     uint8_t  dir[85];
     uint8_t  sixteenth_sb[16 * 8];
-    uint8_t  quarter_sb[32 * 32];
 } me_state_t;
 
 SVT_DEV int16_t me_mvx(uint32_t mv) { return (int16_t)(mv & 0xFFFF); }
@@ -188,7 +211,7 @@ SVT_DEV uint32_t me_pack_mv(int x, int y) { return ((uint32_t)(uint16_t)y << 16)
 SVT_DEV const uint8_t *me_pix(const svt_plane *p, int x, int y) {
     return p->buf + (ptrdiff_t)(p->origin_y + y) * p->stride + p->origin_x + x;
 }
-SVT_DEV int me_pu_nidx(int pu) { return pu > 20 ? me_tab8x8[pu - 21] + 21 : pu > 4 ? me_tab32x32[pu - 5] + 5 : pu; }
+SVT_DEV int me_pu_nidx(int pu) { return pu > 20 ? me_z8(pu - 21) + 21 : pu > 4 ? me_z4(pu - 5) + 5 : pu; }
 SVT_DEV void me_pu_geom(int pu, int *x, int *y, int *w) {
     if (pu == 0) { *x = 0; *y = 0; *w = 64; }
     else if (pu < 5) { *x = ((pu - 1) & 1) * 32; *y = ((pu - 1) >> 1) * 32; *w = 32; }
@@ -235,7 +258,8 @@ typedef struct me_ctx_t {
     uint8_t             *src;    /* LDS */
     uint8_t             *region; /* LDS */
     uint8_t             *planes; /* LDS */
-    uint8_t             *pred0;  /* LDS */
+    uint8_t             *quarter_sb; /* LDS, valid when HME level 1 is enabled */
+    uint32_t            *pred0;  /* LDS: list 0 prediction dwords of the bi-pred lanes */
     int                  pic_w, pic_h, sb_x, sb_y, sb_w, sb_h, sb_index;
     unsigned long long  *prof;   /* optional per-phase cycle accumulators (profiling builds), else NULL */
 } me_ctx_t;
@@ -257,7 +281,6 @@ SVT_DEV void ph_load_rect(int tid, uint8_t *dst, int dst_stride, const uint8_t *
 SVT_DEV void ph_init(const me_ctx_t *c, int tid) {
     me_state_t *st = c->st;
     for (int t = tid; t < 85; t += SVT_NT) {
-        st->bipred_sad[t] = 0;
         st->best_mv[0][t] = 0; st->best_mv[1][t] = 0;
         st->best_sad[0][t] = 0; st->best_sad[1][t] = 0;
         st->dir[t] = 0;
@@ -277,7 +300,7 @@ SVT_DEV void ph_init(const me_ctx_t *c, int tid) {
         int rows = c->sb_h >> 1, wq = c->sb_w >> 1;
         for (int t = tid; t < rows * 32; t += SVT_NT) {
             int r = t >> 5, x = t & 31;
-            st->quarter_sb[t] = x < wq ? *me_pix(&c->pic->cur.quarter, (c->sb_x >> 1) + x, (c->sb_y >> 1) + r) : 0;
+            c->quarter_sb[t] = x < wq ? *me_pix(&c->pic->cur.quarter, (c->sb_x >> 1) + x, (c->sb_y >> 1) + r) : 0;
         }
     }
 }
@@ -358,11 +381,17 @@ SVT_DEV void ph_sad_search(const me_ctx_t *c, int tid, const uint8_t *blk, int b
     svt_wave_min_u64(&c->st->hme_key, best);
 }
 
+/* full-pel search tables.  All 85 PU SADs of a search position live in one row of ME_PU_STRIDE dwords indexed by
+ * the PU's search-order index (0 = 64x64, 1..4 = 32x32, 5..20 = 16x16, 21..84 = 8x8; children of a block are the 4
+ * consecutive entries 4*z .. 4*z+3 of the next level, i.e. nested z-order).  The odd stride keeps the per-position
+ * rows on different LDS banks. */
+#define ME_PU_STRIDE 85
+
 /* full-pel: sub-sampled 8x8 SADs of every (position, 8x8 block) of a chunk of search rows.
- * Task = (8x8 block b in raster order, 4-position group g, search row y).  Output u16 s8[pos][64]
- * (pos = y_local * sw + x) into scratch.  tail columns (x >= w8) reproduce the reference's address bug
+ * Task = (8x8 block b in raster order, 4-position group g, search row y).  Output U[pos][21 + z(b)]
+ * (pos = y_local * sw + x).  tail columns (x >= w8) reproduce the reference's address bug
  * for 16x16 blocks 12 and 13 (Codec/EbMotionEstimation.c:855-856). */
-SVT_DEV void ph_fullpel_sad8(const me_ctx_t *c, int tid, uint16_t *s8, int sw, int y0, int ny, int w8) {
+SVT_DEV void ph_fullpel_sad8(const me_ctx_t *c, int tid, uint32_t *U, int sw, int y0, int ny, int w8) {
     int ng = (sw + 3) >> 2;
     int rs = c->L.region_stride;
     for (int t = tid; t < ng * ny * 64; t += SVT_NT) {
@@ -377,69 +406,61 @@ SVT_DEV void ph_fullpel_sad8(const me_ctx_t *c, int tid, uint16_t *s8, int sw, i
         const uint8_t *rp = c->region + (ME_RGN_GY + y0 + yl + by) * rs + ME_RGN_GX + 4 * g + rbx;
         const uint8_t *sp = c->src + by * ME_SB + bx;
         uint64_t       acc = 0;
-        for (int r = 0; r < 4; r++) {
+        _Pragma("unroll") for (int r = 0; r < 4; r++) {
             const uint32_t *w = (const uint32_t *)(rp + 2 * r * rs);
             const uint32_t *s = (const uint32_t *)(sp + 2 * r * ME_SB);
             uint32_t        d0 = w[0], d1 = w[1], d2 = w[2];
             acc = svt_qsad(((uint64_t)d1 << 32) | d0, s[0], acc);
             acc = svt_qsad(((uint64_t)d2 << 32) | d1, s[1], acc);
         }
-        for (int o = 0; o < 4; o++) {
-            int x = 4 * g + o;
-            if (x < sw) s8[(yl * sw + x) * 64 + b] = (uint16_t)(acc >> (16 * o));
-        }
+        uint32_t *u = U + (yl * sw + 4 * g) * ME_PU_STRIDE + 21 + me_z8(b);
+        _Pragma("unroll") for (int o = 0; o < 4; o++)
+            if (4 * g + o < sw) u[o * ME_PU_STRIDE] = (uint32_t)(acc >> (16 * o)) & 0xffffu;
     }
 }
 
-/* full-pel: 16x16 sums of every position of the chunk: s16[pos][k], k = raster 16x16 index.  In the 8-point path
- * (x < w8) the reference keeps this sum in uint16 (C_DEFAULT/EbComputeSAD_C.c:201,276), in the tail path in 32 bits. */
-SVT_DEV void ph_fullpel_sum16(const me_ctx_t *c, int tid, const uint16_t *s8, uint32_t *s16, int sw, int ny, int w8) {
+/* full-pel: 16x16 sums of every position of the chunk.  In the 8-point path (x < w8) the reference keeps this sum
+ * in uint16 (C_DEFAULT/EbComputeSAD_C.c:201,276), in the tail path in 32 bits. */
+SVT_DEV void ph_fullpel_sum16(const me_ctx_t *c, int tid, uint32_t *U, int sw, int ny, int w8) {
     (void)c;
     int npos = sw * ny;
     for (int t = tid; t < npos * 16; t += SVT_NT) {
-        int             pos = t >> 4, k = t & 15;
-        const uint16_t *q   = s8 + pos * 64 + (k >> 2) * 16 + (k & 3) * 2;
-        uint32_t        u   = (uint32_t)q[0] + q[1] + q[8] + q[9];
+        int             pos = t >> 4, z = t & 15;
+        const uint32_t *q   = U + pos * ME_PU_STRIDE + 21 + 4 * z;
+        uint32_t        u   = q[0] + q[1] + q[2] + q[3];
         if ((pos % sw) < w8) u = (uint16_t)u;
-        s16[t] = u;
+        U[pos * ME_PU_STRIDE + 5 + z] = u;
     }
 }
 
-/* full-pel: 32x32 and 64x64 sums per position: s32[pos][5] = {four 32x32 in raster order, 64x64} */
-SVT_DEV void ph_fullpel_sum32(const me_ctx_t *c, int tid, const uint32_t *s16, uint32_t *s32, int npos) {
+/* full-pel: 32x32 sums (entries 1..4) and the 64x64 sum (entry 0) per position */
+SVT_DEV void ph_fullpel_sum32(const me_ctx_t *c, int tid, uint32_t *U, int npos) {
     (void)c;
-    for (int t = tid; t < npos * 4; t += SVT_NT) {
-        int             pos = t >> 2, j = t & 3;
-        const uint32_t *q   = s16 + pos * 16 + (j >> 1) * 8 + (j & 1) * 2;
-        s32[pos * 5 + j]    = q[0] + q[1] + q[4] + q[5];
+    for (int t = tid; t < npos * 5; t += SVT_NT) {
+        int             pos = t / 5, j = t - 5 * pos;
+        const uint32_t *q   = U + pos * ME_PU_STRIDE + 5;
+        uint32_t        u   = 0;
+        if (j < 4) u = q[4 * j] + q[4 * j + 1] + q[4 * j + 2] + q[4 * j + 3];
+        else _Pragma("unroll") for (int i = 0; i < 16; i++) u += q[i];
+        U[pos * ME_PU_STRIDE + (j < 4 ? 1 + j : 0)] = u;
     }
 }
-/* full-pel: per-PU arg-min, one thread per PU scanning the chunk's positions in raster order with the
- * reference's strict '<' (first minimum wins); pu = search-order index. */
-SVT_DEV void ph_fullpel_argmin(const me_ctx_t *c, int tid, const uint16_t *s8, const uint32_t *s16, const uint32_t *s32, int sw,
-                               int y0, int ny) {
-    int npos = sw * ny;
-    for (int pu = tid; pu < 85; pu += SVT_NT) {
-        uint64_t best = c->st->key[pu];
-        uint32_t bsad = (uint32_t)(best >> 32);
-        uint32_t bidx = (uint32_t)best;
-        if (pu >= 21) {
-            const uint16_t *q = s8 + me_inv8x8[pu - 21];
-            for (int pos = 0; pos < npos; pos++) { uint32_t v = 2u * q[pos * 64]; if (v < bsad) { bsad = v; bidx = (uint32_t)(y0 * sw + pos); } }
-        } else if (pu >= 5) {
-            const uint32_t *q = s16 + me_inv32x32[pu - 5];
-            for (int pos = 0; pos < npos; pos++) { uint32_t v = 2u * q[pos * 16]; if (v < bsad) { bsad = v; bidx = (uint32_t)(y0 * sw + pos); } }
-        } else if (pu >= 1) {
-            const uint32_t *q = s32 + (pu - 1);
-            for (int pos = 0; pos < npos; pos++) { uint32_t v = 2u * q[pos * 5]; if (v < bsad) { bsad = v; bidx = (uint32_t)(y0 * sw + pos); } }
-        } else {
-            for (int pos = 0; pos < npos; pos++) {
-                const uint32_t *q = s32 + pos * 5;
-                uint32_t        v = 2u * (q[0] + q[1] + q[2] + q[3]);
-                if (v < bsad) { bsad = v; bidx = (uint32_t)(y0 * sw + pos); }
-            }
+
+/* full-pel: per-PU arg-min.  Thread = (PU, one of 3 interleaved position slices); every PU reads the same table
+ * layout, so the scan is branch-free and its loads are independent.  The slices meet in an LDS 64-bit min of
+ * (2*sad << 32 | raster index): the unsigned min is exactly the reference's "first minimum in raster order"
+ * (strict '<' while scanning positions in raster order). */
+SVT_DEV void ph_fullpel_argmin(const me_ctx_t *c, int tid, const uint32_t *U, int sw, int y0, int ny) {
+    const int npos = sw * ny;
+    const int slice = tid / 85, pu = tid - 85 * slice;
+    if (slice < 3) {
+        uint32_t bsad = 0xffffffffu, bpos = 0;
+        const uint32_t *q = U + pu;
+        for (int pos = slice; pos < npos; pos += 3) {
+            uint32_t v = q[pos * ME_PU_STRIDE];
+            if (v < bsad) { bsad = v; bpos = (uint32_t)pos; }
         }
-        c->st->key[pu] = ((uint64_t)bsad << 32) | bidx;
+        if (bsad != 0xffffffffu) svt_lds_min_u64(&c->st->key[pu], ((uint64_t)(2u * bsad) << 32) | (uint32_t)(y0 * sw + (int)bpos));
     }
 }
 
@@ -535,26 +556,18 @@ SVT_DEV uint32_t me_block_sad_rows(const uint8_t *src, int ss, const uint8_t *a,
     return sad;
 }
 
+#ifdef SVT_HOST_EMU /* reference form of the packed candidate tables (checked by me_tables_selfcheck) */
 /* candidate tables ---------------------------------------------------------------------------------- */
 /* half-pel candidates L,R,T,B,TL,TR,BR,BL relative to the integer position (pu_half_pel_refinement,
  * Codec/EbMotionEstimation.c:1076-1559), natural coordinates */
 __attribute__((unused)) static
-#ifndef SVT_HOST_EMU
-    __device__
-#endif
     const int8_t me_hcand[8][3] = {{ME_PB, -1, 0}, {ME_PB, 0, 0}, {ME_PH, 0, -1}, {ME_PH, 0, 0},
                                    {ME_PJ, -1, -1}, {ME_PJ, 0, -1}, {ME_PJ, 0, 0}, {ME_PJ, -1, 0}};
 __attribute__((unused)) static
-#ifndef SVT_HOST_EMU
-    __device__
-#endif
     const int8_t me_hdmv[8][2] = {{-2, 0}, {2, 0}, {0, -2}, {0, 2}, {-2, -2}, {2, -2}, {2, 2}, {-2, 2}};
 /* quarter-pel pairs (set_quarter_pel_refinement_inputs_on_the_fly, :2290-2465), natural coordinates
  * relative to P = (mv + 2) >> 2; [method][position L,R,T,B,TL,TR,BR,BL][plane1,dx1,dy1,plane2,dx2,dy2] */
 __attribute__((unused)) static
-#ifndef SVT_HOST_EMU
-    __device__
-#endif
     const int8_t me_qtab[4][8][6] = {
         {{ME_PB, -1, 0, ME_PF, 0, 0}, {ME_PF, 0, 0, ME_PB, 0, 0}, {ME_PH, 0, -1, ME_PF, 0, 0}, {ME_PF, 0, 0, ME_PH, 0, 0},
          {ME_PB, -1, 0, ME_PH, 0, -1}, {ME_PH, 0, -1, ME_PB, 0, 0}, {ME_PH, 0, 0, ME_PB, 0, 0}, {ME_PB, -1, 0, ME_PH, 0, 0}},
@@ -565,20 +578,44 @@ __attribute__((unused)) static
         {{ME_PH, -1, -1, ME_PJ, -1, -1}, {ME_PJ, -1, -1, ME_PH, 0, -1}, {ME_PB, -1, -1, ME_PJ, -1, -1}, {ME_PJ, -1, -1, ME_PB, -1, 0},
          {ME_PH, -1, -1, ME_PB, -1, -1}, {ME_PB, -1, -1, ME_PH, 0, -1}, {ME_PB, -1, 0, ME_PH, 0, -1}, {ME_PH, -1, -1, ME_PB, -1, 0}}};
 __attribute__((unused)) static
-#ifndef SVT_HOST_EMU
-    __device__
-#endif
     const int8_t me_qdmv[8][2] = {{-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
 /* bi-pred quarter-pel compensation pairs (quarter_pel_compensation, :3358-3453), by frac_pos */
 __attribute__((unused)) static
-#ifndef SVT_HOST_EMU
-    __device__
-#endif
     const int8_t me_btab[16][6] = {
         {ME_PF, 0, 0, -1, 0, 0}, {ME_PF, 0, 0, ME_PB, 0, 0}, {ME_PB, 0, 0, -1, 0, 0}, {ME_PB, 0, 0, ME_PF, 1, 0},
         {ME_PF, 0, 0, ME_PH, 0, 0}, {ME_PB, 0, 0, ME_PH, 0, 0}, {ME_PB, 0, 0, ME_PJ, 0, 0}, {ME_PB, 0, 0, ME_PH, 1, 0},
         {ME_PH, 0, 0, -1, 0, 0}, {ME_PH, 0, 0, ME_PJ, 0, 0}, {ME_PJ, 0, 0, -1, 0, 0}, {ME_PJ, 0, 0, ME_PH, 1, 0},
         {ME_PH, 0, 0, ME_PF, 0, 1}, {ME_PH, 0, 0, ME_PB, 0, 1}, {ME_PJ, 0, 0, ME_PB, 0, 1}, {ME_PH, 1, 0, ME_PB, 0, 1}};
+
+/* returns 0 when every packed / arithmetic table decodes to the reference tables above */
+static inline int me_tables_selfcheck(void) {
+    for (int i = 0; i < 64; i++) if (me_z8(i) != me_tab8x8[i] || me_inv8x8[me_z8(i)] != i) return 1;
+    for (int i = 0; i < 16; i++) if (me_z4(i) != me_tab32x32[i] || me_inv32x32[me_z4(i)] != i) return 2;
+    for (int i = 0; i < 8; i++) {
+        int pl, dx, dy, sx, sy;
+        me_hcand_get(i, &pl, &dx, &dy);
+        if (pl != me_hcand[i][0] || dx != me_hcand[i][1] || dy != me_hcand[i][2]) return 3;
+        me_dmv_get(i, &sx, &sy);
+        if (2 * sx != me_hdmv[i][0] || 2 * sy != me_hdmv[i][1] || sx != me_qdmv[i][0] || sy != me_qdmv[i][1]) return 4;
+    }
+    for (int m = 0; m < 4; m++)
+        for (int i = 0; i < 8; i++) {
+            uint32_t       v = me_qtab_get(m, i);
+            const int8_t *e = me_qtab[m][i];
+            if ((int)(v & 3) != e[0] || -(int)((v >> 2) & 1) != e[1] || -(int)((v >> 3) & 1) != e[2]) return 5;
+            if ((int)((v >> 4) & 3) != e[3] || -(int)((v >> 6) & 1) != e[4] || -(int)((v >> 7) & 1) != e[5]) return 6;
+        }
+    for (int f = 0; f < 16; f++) {
+        int            hb;
+        uint32_t       v = me_btab_get(f, &hb);
+        const int8_t *e = me_btab[f];
+        if ((int)(v & 3) != e[0] || (int)((v >> 2) & 1) != e[1] || (int)((v >> 3) & 1) != e[2]) return 7;
+        if (hb != (e[3] >= 0)) return 8;
+        if (hb && ((int)((v >> 4) & 3) != e[3] || (int)((v >> 6) & 1) != e[4] || (int)((v >> 7) & 1) != e[5])) return 9;
+    }
+    return 0;
+}
+#endif
 
 /* direction codes, Codec/EbMotionEstimation.c:34-41 */
 enum { ME_D_TL = 0, ME_D_T = 1, ME_D_TR = 2, ME_D_R = 3, ME_D_BR = 4, ME_D_B = 5, ME_D_BL = 6, ME_D_L = 7 };
@@ -625,8 +662,9 @@ SVT_DEV void ph_halfpel(const me_ctx_t *c, int tid, int list, int sox, int soy, 
         uint32_t mv = c->st->best_mv[list][n];
         int      xs = (int16_t)((me_mvx(mv) >> 2) - (int16_t)sox) + px;
         int      ys = (int16_t)((me_mvy(mv) >> 2) - (int16_t)soy) + py;
-        const int8_t  *e  = me_hcand[cand];
-        const uint8_t *cp = me_plane_at(c, e[0], xs + e[1], ys + e[2]);
+        int            hpl, hdx, hdy;
+        me_hcand_get(cand, &hpl, &hdx, &hdy);
+        const uint8_t *cp = me_plane_at(c, hpl, xs + hdx, ys + hdy);
         const uint8_t *sp = c->src + py * ME_SB + px;
         int            rows = sub_sad ? (w >> 1) : w, step = sub_sad ? 2 : 1;
         /* rows split over ME_SUB_LANES lanes */
@@ -650,7 +688,7 @@ SVT_DEV void ph_halfpel_decide(const me_ctx_t *c, int tid, int list, int en32, i
         for (int i = 0; i < 8; i++) {
             d[i] = c->st->cand[pu * 8 + i];
             if (sub_sad) d[i] <<= 1;
-            if (d[i] < best) { best = d[i]; mv = me_pack_mv(xm + me_hdmv[i][0], ym + me_hdmv[i][1]); }
+            if (d[i] < best) { int sx, sy; me_dmv_get(i, &sx, &sy); best = d[i]; mv = me_pack_mv(xm + 2 * sx, ym + 2 * sy); }
         }
         uint32_t m = d[0];
         for (int i = 1; i < 8; i++) if (d[i] < m) m = d[i];
@@ -719,9 +757,9 @@ SVT_DEV void ph_quarterpel(const me_ctx_t *c, int tid, int list, int sox, int so
         int      pos  = (int)(0x07361524u >> (4 * dirx)) & 7; /* direction code -> L,R,T,B,TL,TR,BR,BL index */
         int xs = (int16_t)(((xm + 2) >> 2) - (int16_t)sox) + px;
         int ys = (int16_t)(((ym + 2) >> 2) - (int16_t)soy) + py;
-        const int8_t  *e  = me_qtab[method][pos];
-        const uint8_t *a  = me_plane_at(c, e[0], xs + e[1], ys + e[2]);
-        const uint8_t *b  = me_plane_at(c, e[3], xs + e[4], ys + e[5]);
+        const uint32_t e  = me_qtab_get(method, pos);
+        const uint8_t *a  = me_plane_at(c, (int)(e & 3), xs - (int)((e >> 2) & 1), ys - (int)((e >> 3) & 1));
+        const uint8_t *b  = me_plane_at(c, (int)((e >> 4) & 3), xs - (int)((e >> 6) & 1), ys - (int)((e >> 7) & 1));
         const uint8_t *sp = c->src + py * ME_SB + px;
         int            rows = sub_sad ? (w >> 1) : w, step = sub_sad ? 2 : 1;
         int            per = (rows + ME_SUB_LANES - 1) / ME_SUB_LANES;
@@ -744,7 +782,7 @@ SVT_DEV void ph_quarterpel_decide(const me_ctx_t *c, int tid, int list, int en32
             if (!me_qvalid(method != 0, dir, i)) continue;
             uint32_t d = c->st->cand[pu * 8 + i];
             if (sub_sad) d <<= 1;
-            if (d < best) { best = d; mv = me_pack_mv(xm + me_qdmv[i][0], ym + me_qdmv[i][1]); }
+            if (d < best) { int sx, sy; me_dmv_get(i, &sx, &sy); best = d; mv = me_pack_mv(xm + sx, ym + sy); }
         }
         c->st->best_sad[list][n] = best;
         c->st->best_mv[list][n]  = mv;
@@ -757,62 +795,73 @@ SVT_DEV void ph_quarterpel_decide(const me_ctx_t *c, int tid, int list, int en32
 SVT_DEV int me_pu_bipred(const me_ctx_t *c, int pu) {
     return (c->p->cu8x8_mode == 0 || pu < 21) && (c->p->cu16x16_mode == 0 || pu < 5);
 }
-/* one row of the prediction of `list` for pu at its best mv: 4 bytes at column 4*i */
-SVT_DEV uint32_t me_pred_dword(const me_ctx_t *c, int list, int sox, int soy, int pu, int r, int i) {
-    int px, py, w;
-    me_pu_geom(pu, &px, &py, &w);
+/* prediction of `list` for a PU at its best mv: up to two source planes averaged (select_buffer :3310 /
+ * quarter_pel_compensation :3358) */
+SVT_DEV void me_pred_ptrs(const me_ctx_t *c, int list, int sox, int soy, int pu, int px, int py, const uint8_t **a, const uint8_t **b) {
     uint32_t mv = c->st->best_mv[list][me_pu_nidx(pu)];
     int16_t  mx = me_mvx(mv), my = me_mvy(mv);
     int      xi = (int16_t)(mx >> 2) - (int16_t)sox + px;
     int      yi = (int16_t)(my >> 2) - (int16_t)soy + py;
     int      frac = ((uint8_t)mx & 3) + (((uint8_t)my & 3) << 2);
-    const int8_t  *e = me_btab[frac];
-    int            rs = c->L.region_stride;
-    const uint8_t *a = me_plane_at(c, e[0], xi + e[1], yi + e[2]) + r * rs + 4 * i;
-    uint32_t       va = me_ld32u(a);
-    if (e[3] >= 0) {
-        const uint8_t *b  = me_plane_at(c, e[3], xi + e[4], yi + e[5]) + r * rs + 4 * i;
-        uint32_t       vb = me_ld32u(b);
+    int            has_b;
+    const uint32_t e = me_btab_get(frac, &has_b);
+    *a = me_plane_at(c, (int)(e & 3), xi + (int)((e >> 2) & 1), yi + (int)((e >> 3) & 1));
+    *b = has_b ? me_plane_at(c, (int)((e >> 4) & 3), xi + (int)((e >> 6) & 1), yi + (int)((e >> 7) & 1)) : 0;
+}
+SVT_DEV uint32_t me_pred_fetch(const uint8_t *a, const uint8_t *b, int off) {
+    uint32_t va = me_ld32u(a + off);
+    if (b) {
+        uint32_t vb = me_ld32u(b + off);
         va = (va | vb) - (((va ^ vb) >> 1) & 0x7f7f7f7fu); /* (a + b + 1) >> 1 per byte */
     }
     return va;
 }
-/* dword-granular enumeration of the bi-pred blocks: t in [0, 1024*levels): level 0 = 64x64, 1 = 32x32 x4,
- * 2 = 16x16 x16, 3 = 8x8 x64; byte offset inside pred0 = 4*t */
-SVT_DEV void me_bipred_task(int t, int *pu, int *r, int *i) {
-    int lv = t >> 10, o = t & 1023;
-    if (lv == 0) { *pu = 0; *r = o >> 4; *i = o & 15; }
-    else if (lv == 1) { *pu = 1 + (o >> 8); *r = (o & 255) >> 3; *i = o & 7; }
-    else if (lv == 2) { *pu = 5 + (o >> 6); *r = (o & 63) >> 2; *i = o & 3; }
-    else { *pu = 21 + (o >> 4); *r = (o & 15) >> 1; *i = o & 1; }
-}
 SVT_DEV int me_bipred_levels(const me_ctx_t *c) { return c->p->cu16x16_mode != 0 ? 2 : c->p->cu8x8_mode != 0 ? 3 : 4; }
-SVT_DEV void ph_store_pred0(const me_ctx_t *c, int tid, int sox, int soy) {
-    int n = 1024 * me_bipred_levels(c);
-    for (int t = tid; t < n; t += SVT_NT) {
-        int pu, r, i;
-        me_bipred_task(t, &pu, &r, &i);
-        *(uint32_t *)(c->pred0 + 4 * t) = me_pred_dword(c, 0, sox, soy, pu, r, i);
+
+/* Bi-pred work split: level L (0 = 64x64 ... 3 = 8x8) has 4^L PUs of (1024 >> 2L) dwords; 256 >> 2L consecutive lanes
+ * own one PU and each lane handles K dwords of it (K = 4, or 2 with SUB_SAD where only even rows count).  A lane meets
+ * the same (level, k) dwords again when list 1 is searched: list 0's dword of (level, k, thread) waits in
+ * pred0[(L*K + k)*256 + tid]. */
+SVT_DEV void ph_store_pred0(const me_ctx_t *c, int tid, int sox, int soy, uint32_t *pr) {
+    const int sub = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH, K = sub ? 2 : 4, levels = me_bipred_levels(c);
+    const int rs  = c->L.region_stride;
+    for (int L = 0; L < levels; L++) {
+        const int sh = 8 - 2 * L, l = tid & ((1 << sh) - 1), pu = (int)((0x15050100u >> (8 * L)) & 0xff) + (tid >> sh);
+        int       px, py, w;
+        me_pu_geom(pu, &px, &py, &w);
+        const uint8_t *a, *b;
+        me_pred_ptrs(c, 0, sox, soy, pu, px, py, &a, &b);
+        _Pragma("unroll") for (int k = 0; k < 4; k++) {
+            if (k < K) {
+                int d = l + (k << sh), r = (d >> (4 - L)) << sub, i = d & ((16 >> L) - 1);
+                pr[(L * K + k) * SVT_NT] = me_pred_fetch(a, b, r * rs + 4 * i);
+            }
+        }
+        SVT_SCHED_FENCE();
     }
 }
 /* bi-pred distortion: avg-SAD of (list0 pred, list1 pred) vs source (bi_pred_averging :3466-3560) */
-SVT_DEV void ph_bipred(const me_ctx_t *c, int tid, int sox, int soy) {
-    const int sub_sad = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH;
-    int       n = 1024 * me_bipred_levels(c);
-    for (int t = tid; t < n; t += SVT_NT) {
-        int pu, r, i;
-        me_bipred_task(t, &pu, &r, &i);
-        uint32_t d = 0;
-        if (!(sub_sad && (r & 1))) {
-            int px, py, w;
-            me_pu_geom(pu, &px, &py, &w);
-            uint32_t s  = *(const uint32_t *)(c->src + (py + r) * ME_SB + px + 4 * i);
-            uint32_t va = *(const uint32_t *)(c->pred0 + 4 * t), vb = me_pred_dword(c, 1, sox, soy, pu, r, i);
-            uint32_t av = (va | vb) - (((va ^ vb) >> 1) & 0x7f7f7f7fu);
-            d = svt_sad4(av, s, 0);
+SVT_DEV void ph_bipred(const me_ctx_t *c, int tid, int sox, int soy, const uint32_t *pr) {
+    const int sub = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH, K = sub ? 2 : 4, levels = me_bipred_levels(c);
+    const int rs  = c->L.region_stride;
+    for (int L = 0; L < levels; L++) {
+        const int sh = 8 - 2 * L, l = tid & ((1 << sh) - 1), pu = (int)((0x15050100u >> (8 * L)) & 0xff) + (tid >> sh);
+        int       px, py, w;
+        me_pu_geom(pu, &px, &py, &w);
+        const uint8_t *a, *b;
+        me_pred_ptrs(c, 1, sox, soy, pu, px, py, &a, &b);
+        uint32_t dsum = 0;
+        _Pragma("unroll") for (int k = 0; k < 4; k++) {
+            if (k < K) {
+                int      d = l + (k << sh), r = (d >> (4 - L)) << sub, i = d & ((16 >> L) - 1);
+                uint32_t s  = *(const uint32_t *)(c->src + (py + r) * ME_SB + px + 4 * i);
+                uint32_t va = pr[(L * K + k) * SVT_NT], vb = me_pred_fetch(a, b, r * rs + 4 * i);
+                uint32_t av = (va | vb) - (((va ^ vb) >> 1) & 0x7f7f7f7fu);
+                dsum = svt_sad4(av, s, dsum);
+            }
         }
-        /* consecutive tasks share the PU in runs of >= 64 (levels 0-2) or 16 (8x8 level) */
-        svt_group_add_u32(&c->st->cand[pu], d, (t >> 10) == 3 ? 16 : 64);
+        svt_group_add_u32(&c->st->cand[pu], dsum, sh > 6 ? 64 : 1 << sh);
+        SVT_SCHED_FENCE();
     }
 }
 
@@ -873,6 +922,126 @@ SVT_DEV void ph_output(const me_ctx_t *c, int tid, svt_me_pu_result *out, uint32
 #define ME_UNIFORM_WRITE(...) do { if (tid == 0) { __VA_ARGS__; } __syncthreads(); } while (0)
 #endif
 
+/* ---- batched HME: the (up to 4) search regions of one level are staged and searched together -------------- */
+typedef struct me_hme_win {
+    int32_t off;      /* byte offset of the window inside the scratch */
+    int32_t wstride;  /* window row stride (bytes, odd number of dwords) */
+    int32_t nd, rows; /* window dwords per row, rows */
+    int32_t sw, sh;   /* search positions */
+    int32_t gx, gy;   /* reference-picture coordinates of window column 0 / row 0 */
+} me_hme_win;
+
+#define ME_SEL4(a, r) ((r) == 0 ? (a)[0] : (r) == 1 ? (a)[1] : (r) == 2 ? (a)[2] : (a)[3])
+
+/* copy the windows of all regions of a batch: flattened (region,row,dword) tasks, four global loads in flight per
+ * thread before the LDS stores */
+SVT_DEV void ph_hme_load_multi(const me_ctx_t *c, int tid, const svt_plane *ref, const me_hme_win *wn) {
+    int tb[5];
+    tb[0] = 0;
+    _Pragma("unroll") for (int r = 0; r < 4; r++) tb[r + 1] = tb[r] + wn[r].nd * wn[r].rows;
+    const int total = tb[4];
+    for (int t0 = tid; t0 < total; t0 += 4 * SVT_NT) {
+        uint32_t v[4];
+        int      dst[4];
+        _Pragma("unroll") for (int u = 0; u < 4; u++) {
+            int T = t0 + u * SVT_NT;
+            dst[u] = -1;
+            if (T < total) {
+                int r = 0;
+                _Pragma("unroll") for (int q = 1; q < 4; q++) if (T >= tb[q]) r = q;
+                const int t = T - ME_SEL4(tb, r);
+                int       nd = 0, off = 0, ws = 0, gx = 0, gy = 0;
+                _Pragma("unroll") for (int q = 0; q < 4; q++) if (q == r) { nd = wn[q].nd; off = wn[q].off; ws = wn[q].wstride; gx = wn[q].gx; gy = wn[q].gy; }
+                int row = t / nd, i = t - row * nd;
+                v[u]   = me_ld32u(me_pix(ref, gx + 4 * i, gy + row));
+                dst[u] = off + row * ws + 4 * i;
+            }
+        }
+        _Pragma("unroll") for (int u = 0; u < 4; u++) if (dst[u] >= 0) *(uint32_t *)(c->planes + dst[u]) = v[u];
+    }
+}
+
+/* SADs of 4 consecutive search positions (window dwords wr..) against a bw x bh block; window row of block row j is
+ * mul*j rows further down.  The packed u16 accumulators are flushed before they can overflow. */
+SVT_DEV void me_qsad_block(const uint8_t *blk, int bstride, int nd, int bh, const uint8_t *win, int wstride, int mul, uint32_t a[4]) {
+    const int flush = nd <= 4 ? 16 : nd <= 8 ? 8 : 4; /* rows whose sums (4*nd*255 each) still fit 16 bits */
+    a[0] = a[1] = a[2] = a[3] = 0;
+    for (int j0 = 0; j0 < bh; j0 += flush) {
+        uint64_t  acc = 0;
+        const int j1  = j0 + flush < bh ? j0 + flush : bh;
+        for (int j = j0; j < j1; j++) {
+            const uint32_t *wr = (const uint32_t *)(win + mul * j * wstride);
+            const uint32_t *br = (const uint32_t *)(blk + j * bstride);
+            uint32_t        lo = wr[0];
+            int             i  = 0;
+            for (; i + 4 <= nd; i += 4) {
+                uint32_t h0 = wr[i + 1], h1 = wr[i + 2], h2 = wr[i + 3], h3 = wr[i + 4];
+                uint32_t b0 = br[i], b1 = br[i + 1], b2 = br[i + 2], b3 = br[i + 3];
+                acc = svt_qsad(((uint64_t)h0 << 32) | lo, b0, acc);
+                acc = svt_qsad(((uint64_t)h1 << 32) | h0, b1, acc);
+                acc = svt_qsad(((uint64_t)h2 << 32) | h1, b2, acc);
+                acc = svt_qsad(((uint64_t)h3 << 32) | h2, b3, acc);
+                lo  = h3;
+            }
+            for (; i < nd; i++) {
+                uint32_t hi = wr[i + 1];
+                acc         = svt_qsad(((uint64_t)hi << 32) | lo, br[i], acc);
+                lo          = hi;
+            }
+        }
+        a[0] += (uint32_t)(acc & 0xffff); a[1] += (uint32_t)((acc >> 16) & 0xffff);
+        a[2] += (uint32_t)((acc >> 32) & 0xffff); a[3] += (uint32_t)(acc >> 48);
+    }
+}
+
+/* exhaustive search of every region of a batch (4 slots, empty ones have sw*sh = 0) in one phase; keys[r] = min over (sad << 32 | y*sw + x) */
+SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk, int bstride, int bw, int bh, const me_hme_win *wn,
+                                 uint64_t *keys) {
+    const int qs = (bw & 3) == 0; /* QSAD path: task = 4 positions */
+    int       tb[5];
+    tb[0] = 0;
+    _Pragma("unroll") for (int r = 0; r < 4; r++) tb[r + 1] = tb[r] + (qs ? ((wn[r].sw + 3) >> 2) : wn[r].sw) * wn[r].sh;
+    const int total = tb[4];
+    int       cur = -1;
+    uint64_t  best = ~0ull;
+    for (int T = tid; T < total; T += SVT_NT) {
+        int r = 0;
+        _Pragma("unroll") for (int q = 1; q < 4; q++) if (T >= tb[q]) r = q;
+        if (r != cur) {
+            if (cur >= 0 && best != ~0ull) svt_lds_min_u64(&keys[cur], best);
+            cur = r; best = ~0ull;
+        }
+        const int t = T - ME_SEL4(tb, r);
+        int       off = 0, ws = 0, sw = 1;
+        _Pragma("unroll") for (int q = 0; q < 4; q++) if (q == r) { off = wn[q].off; ws = wn[q].wstride; sw = wn[q].sw; }
+        const uint8_t *win = c->planes + off;
+        if (qs) {
+            const int ng = (sw + 3) >> 2;
+            const int y = t / ng, g = t - y * ng;
+            uint32_t  a[4];
+            me_qsad_block(blk, bstride, bw >> 2, bh, win + y * ws + 4 * g, ws, 2, a);
+            _Pragma("unroll") for (int o = 0; o < 4; o++) {
+                int x = 4 * g + o;
+                if (x < sw) {
+                    uint64_t k = ((uint64_t)a[o] << 32) | (uint32_t)(y * sw + x);
+                    if (k < best) best = k;
+                }
+            }
+        } else {
+            const int y = t / sw, x = t - y * sw;
+            uint32_t  sd = 0;
+            for (int j = 0; j < bh; j++)
+                for (int i = 0; i < bw; i++) {
+                    int p0 = blk[j * bstride + i], p1 = win[(y + 2 * j) * ws + x + i];
+                    sd += (uint32_t)(p0 > p1 ? p0 - p1 : p1 - p0);
+                }
+            uint64_t k = ((uint64_t)sd << 32) | (uint32_t)t;
+            if (k < best) best = k;
+        }
+    }
+    if (cur >= 0 && best != ~0ull) svt_lds_min_u64(&keys[cur], best);
+}
+
 typedef struct me_hme_geom {
     const svt_plane *ref;
     const uint8_t   *blk; /* LDS */
@@ -927,6 +1096,94 @@ void me_hme_search(const me_ctx_t *c, int tid_, const me_hme_geom *g, int16_t sa
     *xc = x; *yc = y;
 }
 
+/* the (up to 4) region searches of one HME level: slot = rh*2 + rw; every array is indexed with compile-time
+ * constants only so that the whole batch lives in registers */
+typedef struct me_hme_batch {
+    int      valid[4];
+    int16_t  ox[4], oy[4], w[4], h[4]; /* search area before clipping, relative to the block origin */
+    int16_t  xc[4], yc[4];             /* in: previous centre; out: best position (scaled) */
+    uint64_t sad[4];                   /* out */
+} me_hme_batch;
+
+/* Consecutive slots whose windows fit the scratch together are staged and searched as one batch (one global-load
+ * phase + one search phase); a region too big for the scratch goes through the banded single-region path.
+ * Results are identical to one me_hme_search() per valid slot. */
+#ifdef SVT_HOST_EMU
+static inline
+#else
+__device__ __forceinline__
+#endif
+void me_hme_multi(const me_ctx_t *c, int tid_, const me_hme_geom *g, me_hme_batch *B, int floor16, int scale, int *parity) {
+    int tid = tid_;
+    (void)tid;
+    const int span = 2 * (g->bh - 1);
+    int16_t   cox[4], coy[4], cw[4], ch[4];
+    int       need[4], wst[4], wnd[4];
+    _Pragma("unroll") for (int r = 0; r < 4; r++) {
+        int16_t ox = B->ox[r], oy = B->oy[r], w = B->w[r], h = B->h[r];
+        need[r] = 0; wst[r] = 0; wnd[r] = 0;
+        if (B->valid[r]) {
+            me_clip_area(g->ox, &ox, &w, g->pad_w, g->ref->width);
+            me_clip_area(g->oy, &oy, &h, g->pad_h, g->ref->height);
+            if (floor16 && (w & 15) != 0) w = (int16_t)((w >> 4) << 4);
+            if (w > 0 && h > 0) {
+                int wbytes = w + g->bw + 3;
+                int ws     = ((wbytes + 3) & ~3) + 4;
+                if (((ws >> 2) & 1) == 0) ws += 4;
+                wst[r] = ws; wnd[r] = (wbytes + 3) >> 2; need[r] = ws * (h + span);
+            }
+        } else { w = 0; h = 0; }
+        cox[r] = ox; coy[r] = oy; cw[r] = w; ch[r] = h;
+    }
+    int r0 = 0;
+    while (r0 < 4) {
+        me_hme_win wn[4];
+        int        r1 = r0, bytes = 0;
+        _Pragma("unroll") for (int r = 0; r < 4; r++) {
+            const int take = r >= r0 && r == r1 && bytes + need[r] <= c->L.scratch_bytes;
+            wn[r].off = bytes; wn[r].wstride = wst[r]; wn[r].gx = g->ox + cox[r]; wn[r].gy = g->oy + coy[r];
+            wn[r].nd = 0; wn[r].rows = 0; wn[r].sw = 0; wn[r].sh = 0;
+            if (take) {
+                if (need[r]) { wn[r].nd = wnd[r]; wn[r].rows = ch[r] + span; wn[r].sw = cw[r]; wn[r].sh = ch[r]; }
+                bytes += need[r];
+                r1 = r + 1;
+            }
+        }
+        if (r1 == r0) { /* does not fit on its own: banded path */
+            uint64_t sd = 0;
+            int16_t  x = ME_SEL4(B->xc, r0), y = ME_SEL4(B->yc, r0);
+            me_hme_search(c, tid, g, ME_SEL4(B->ox, r0), ME_SEL4(B->oy, r0), ME_SEL4(B->w, r0), ME_SEL4(B->h, r0), floor16, &sd, &x, &y, scale);
+            _Pragma("unroll") for (int r = 0; r < 4; r++) if (r == r0) { B->sad[r] = sd; B->xc[r] = x; B->yc[r] = y; }
+            r0++;
+            continue;
+        }
+        uint64_t *keys = c->st->hme_keys[*parity];
+        *parity ^= 1;
+        if (bytes) {
+            ME_PHASE(if (tid < 4) keys[tid] = ~0ull; ph_hme_load_multi(c, tid, g->ref, wn));
+            ME_PHASE(ph_hme_search_multi(c, tid, g->blk, g->bstride, g->bw, g->bh, wn, keys));
+        }
+        _Pragma("unroll") for (int r = 0; r < 4; r++) {
+            if (r >= r0 && r < r1 && B->valid[r]) {
+                uint64_t sad = 0xffffff;
+                int16_t  x = B->xc[r], y = B->yc[r];
+                if (need[r]) {
+                    uint64_t k = keys[r];
+                    if (k != ~0ull) {
+                        uint32_t idx = (uint32_t)k, sd = (uint32_t)(k >> 32);
+                        if (sd < sad) { sad = sd; x = (int16_t)(idx % (uint32_t)cw[r]); y = (int16_t)(idx / (uint32_t)cw[r]); }
+                    }
+                }
+                B->sad[r] = sad * 2;
+                x = (int16_t)(x + cox[r]); x = (int16_t)(x * scale);
+                y = (int16_t)(y + coy[r]); y = (int16_t)(y * scale);
+                B->xc[r] = x; B->yc[r] = y;
+            }
+        }
+        r0 = r1;
+    }
+}
+
 SVT_DEV int16_t me_hme_round_w(int16_t w) { return (int16_t)((w < 8) ? 8 : (w & 7) ? w + (w - ((w >> 3) << 3)) : w); }
 
 /* Codec/EbDefinitions.h:989-1005 */
@@ -950,10 +1207,11 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
     me_state_t          *st = c->st;
     const int            nlist = p->num_ref_lists;
     const int            NW = p->number_hme_search_region_in_width, NH = p->number_hme_search_region_in_height;
-    int16_t  xl0[2][2] = {{0, 0}, {0, 0}}, yl0[2][2] = {{0, 0}, {0, 0}}, xl1[2][2] = {{0, 0}, {0, 0}}, yl1[2][2] = {{0, 0}, {0, 0}};
-    int16_t  xl2[2][2] = {{0, 0}, {0, 0}}, yl2[2][2] = {{0, 0}, {0, 0}};
-    uint64_t sl0[2][2] = {{0, 0}, {0, 0}}, sl1[2][2] = {{0, 0}, {0, 0}}, sl2[2][2] = {{0, 0}, {0, 0}};
-    int      rw = 0, rh = 0;
+    int16_t  xl0[4] = {0, 0, 0, 0}, yl0[4] = {0, 0, 0, 0}, xl1[4] = {0, 0, 0, 0}, yl1[4] = {0, 0, 0, 0};
+    int16_t  xl2[4] = {0, 0, 0, 0}, yl2[4] = {0, 0, 0, 0};
+    uint64_t sl0[4] = {0, 0, 0, 0}, sl1[4] = {0, 0, 0, 0}, sl2[4] = {0, 0, 0, 0};
+    int      rh = 0, hme_parity = 0;
+#define ME_PRED0_REGS (c->pred0 + tid)
     int16_t  x_hme_c = 0, y_hme_c = 0, xsc = 0, ysc = 0;
 #ifndef SVT_HOST_EMU
     unsigned long long mark_t_ = c->prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -1006,124 +1264,113 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
             ME_MARK(1);
             /* ---- HME ---- */
             if (p->enable_hme_flag && c->sb_h == ME_SB) {
-                while (rh < NH) {
-                    while (rw < NW) {
-                        xl0[rw][rh] = (int16_t)(xsc >> 2); yl0[rw][rh] = (int16_t)(ysc >> 2);
-                        xl1[rw][rh] = (int16_t)(xsc >> 1); yl1[rw][rh] = (int16_t)(ysc >> 1);
-                        xl2[rw][rh] = xsc; yl2[rw][rh] = ysc;
-                        rw++;
-                    }
-                    rw = 0; rh++;
-                }
+                /* region (rw, rh) lives in slot rh*2 + rw of the arrays below; all slot indices are compile-time constants.
+                 * [quirk] the reference's region counters are not reset between the lists, so the centres are only
+                 * initialised on the first visit (rh still 0) */
+#define ME_FOR_SLOTS(...) _Pragma("unroll") for (int rh_ = 0; rh_ < 2; rh_++) _Pragma("unroll") for (int rw_ = 0; rw_ < 2; rw_++) \
+        if (rh_ < NH && rw_ < NW) { const int k_ = rh_ * 2 + rw_; (void)k_; __VA_ARGS__ }
+                ME_FOR_SLOTS(if (rh_ >= rh) {
+                    xl0[k_] = (int16_t)(xsc >> 2); yl0[k_] = (int16_t)(ysc >> 2);
+                    xl1[k_] = (int16_t)(xsc >> 1); yl1[k_] = (int16_t)(ysc >> 1);
+                    xl2[k_] = xsc; yl2[k_] = ysc;
+                });
+                if (rh < NH) rh = NH;
                 const int mult = me_hme_l0_mult[p->hierarchical_levels][p->temporal_layer_index];
+                me_hme_batch B;
                 if (p->enable_hme_level_0_flag) {
                     me_hme_geom g = {r16, st->sixteenth_sb, 16, c->sb_w >> 2, (c->sb_h >> 2) >> 1, (int16_t)(c->sb_x >> 2),
                                      (int16_t)(c->sb_y >> 2), r16->origin_x - 1, r16->origin_y - 1};
+                    _Pragma("unroll") for (int k = 0; k < 4; k++) { B.valid[k] = 0; B.ox[k] = B.oy[k] = B.w[k] = B.h[k] = 0; B.xc[k] = xl0[k]; B.yc[k] = yl0[k]; B.sad[k] = 0; }
                     if (p->single_hme_quadrant && !p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag) {
-                        rh = 0; rw = 0;
+                        rh = 0;
                         int16_t w = (int16_t)((p->hme_level0_total_search_area_width * mult) / 100);
                         int16_t h = (int16_t)((p->hme_level0_total_search_area_height * mult) / 100);
-                        int16_t sx = (int16_t)(-(int16_t)(w >> 1) + (int16_t)(xsc >> 2));
-                        int16_t sy = (int16_t)(-(int16_t)(h >> 1) + (int16_t)(ysc >> 2));
-                        me_hme_search(c, tid, &g, sx, sy, w, h, 1, &sl0[0][0], &xl0[0][0], &yl0[0][0], 4);
+                        B.valid[0] = 1; B.w[0] = w; B.h[0] = h;
+                        B.ox[0] = (int16_t)(-(int16_t)(w >> 1) + (int16_t)(xsc >> 2));
+                        B.oy[0] = (int16_t)(-(int16_t)(h >> 1) + (int16_t)(ysc >> 2));
+                        me_hme_multi(c, tid, &g, &B, 1, 4, &hme_parity);
+                        sl0[0] = B.sad[0]; xl0[0] = B.xc[0]; yl0[0] = B.yc[0];
                     } else {
-                        rh = 0; rw = 0;
-                        while (rh < NH) {
-                            while (rw < NW) {
-                                int16_t w = (int16_t)((p->hme_level0_search_area_in_width_array[rw] * mult) / 100);
-                                int16_t h = (int16_t)((p->hme_level0_search_area_in_height_array[rh] * mult) / 100);
-                                int16_t ddx = (int16_t)(xsc >> 2), ddy = (int16_t)(ysc >> 2);
-                                for (int k = rw; k > 0; k--) ddx = (int16_t)(ddx + (int16_t)((p->hme_level0_search_area_in_width_array[k - 1] * mult) / 100));
-                                for (int k = rh; k > 0; k--) ddy = (int16_t)(ddy + (int16_t)((p->hme_level0_search_area_in_height_array[k - 1] * mult) / 100));
-                                int16_t sx = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_width * mult) / 100) >> 1) + ddx);
-                                int16_t sy = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_height * mult) / 100) >> 1) + ddy);
-                                me_hme_search(c, tid, &g, sx, sy, w, h, 0, &sl0[rw][rh], &xl0[rw][rh], &yl0[rw][rh], 4);
-                                rw++;
-                            }
-                            rw = 0; rh++;
-                        }
+                        ME_FOR_SLOTS({
+                            int16_t w = (int16_t)((p->hme_level0_search_area_in_width_array[rw_] * mult) / 100);
+                            int16_t h = (int16_t)((p->hme_level0_search_area_in_height_array[rh_] * mult) / 100);
+                            int16_t ddx = (int16_t)(xsc >> 2), ddy = (int16_t)(ysc >> 2);
+                            if (rw_ > 0) ddx = (int16_t)(ddx + (int16_t)((p->hme_level0_search_area_in_width_array[0] * mult) / 100));
+                            if (rh_ > 0) ddy = (int16_t)(ddy + (int16_t)((p->hme_level0_search_area_in_height_array[0] * mult) / 100));
+                            B.valid[k_] = 1; B.w[k_] = w; B.h[k_] = h;
+                            B.ox[k_] = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_width * mult) / 100) >> 1) + ddx);
+                            B.oy[k_] = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_height * mult) / 100) >> 1) + ddy);
+                        });
+                        me_hme_multi(c, tid, &g, &B, 0, 4, &hme_parity);
+                        ME_FOR_SLOTS({ sl0[k_] = B.sad[k_]; xl0[k_] = B.xc[k_]; yl0[k_] = B.yc[k_]; });
                     }
                 }
                 if (p->enable_hme_level_1_flag) {
-                    me_hme_geom g = {rq, st->quarter_sb, 64, c->sb_w >> 1, (c->sb_h >> 1) >> 1, (int16_t)(c->sb_x >> 1),
+                    me_hme_geom g = {rq, c->quarter_sb, 64, c->sb_w >> 1, (c->sb_h >> 1) >> 1, (int16_t)(c->sb_x >> 1),
                                      (int16_t)(c->sb_y >> 1), rq->origin_x - 1, rq->origin_y - 1};
-                    rh = 0; rw = 0;
-                    while (rh < NH) {
-                        while (rw < NW) {
-                            int16_t w = me_hme_round_w((int16_t)p->hme_level1_search_area_in_width_array[rw]);
-                            int16_t h = (int16_t)p->hme_level1_search_area_in_height_array[rh];
-                            int16_t sx = (int16_t)(-(w >> 1) + (int16_t)(xl0[rw][rh] >> 1));
-                            int16_t sy = (int16_t)(-(h >> 1) + (int16_t)(yl0[rw][rh] >> 1));
-                            me_hme_search(c, tid, &g, sx, sy, w, h, 0, &sl1[rw][rh], &xl1[rw][rh], &yl1[rw][rh], 2);
-                            rw++;
-                        }
-                        rw = 0; rh++;
-                    }
+                    _Pragma("unroll") for (int k = 0; k < 4; k++) { B.valid[k] = 0; B.ox[k] = B.oy[k] = B.w[k] = B.h[k] = 0; B.xc[k] = xl1[k]; B.yc[k] = yl1[k]; B.sad[k] = 0; }
+                    ME_FOR_SLOTS({
+                        int16_t w = me_hme_round_w((int16_t)p->hme_level1_search_area_in_width_array[rw_]);
+                        int16_t h = (int16_t)p->hme_level1_search_area_in_height_array[rh_];
+                        B.valid[k_] = 1; B.w[k_] = w; B.h[k_] = h;
+                        B.ox[k_] = (int16_t)(-(w >> 1) + (int16_t)(xl0[k_] >> 1));
+                        B.oy[k_] = (int16_t)(-(h >> 1) + (int16_t)(yl0[k_] >> 1));
+                    });
+                    me_hme_multi(c, tid, &g, &B, 0, 2, &hme_parity);
+                    ME_FOR_SLOTS({ sl1[k_] = B.sad[k_]; xl1[k_] = B.xc[k_]; yl1[k_] = B.yc[k_]; });
+                    rh = NH;
                 }
                 if (p->enable_hme_level_2_flag) {
                     me_hme_geom g = {rf, c->src, 2 * ME_SB, c->sb_w, c->sb_h >> 1, (int16_t)c->sb_x, (int16_t)c->sb_y, ME_SB - 1, ME_SB - 1};
-                    rh = 0; rw = 0;
-                    while (rh < NH) {
-                        while (rw < NW) {
-                            int16_t w = me_hme_round_w((int16_t)p->hme_level2_search_area_in_width_array[rw]);
-                            int16_t h = (int16_t)p->hme_level2_search_area_in_height_array[rh];
-                            int16_t sx = (int16_t)(-(w >> 1) + xl1[rw][rh]);
-                            int16_t sy = (int16_t)(-(h >> 1) + yl1[rw][rh]);
-                            me_hme_search(c, tid, &g, sx, sy, w, h, 0, &sl2[rw][rh], &xl2[rw][rh], &yl2[rw][rh], 1);
-                            rw++;
-                        }
-                        rw = 0; rh++;
-                    }
+                    _Pragma("unroll") for (int k = 0; k < 4; k++) { B.valid[k] = 0; B.ox[k] = B.oy[k] = B.w[k] = B.h[k] = 0; B.xc[k] = xl2[k]; B.yc[k] = yl2[k]; B.sad[k] = 0; }
+                    ME_FOR_SLOTS({
+                        int16_t w = me_hme_round_w((int16_t)p->hme_level2_search_area_in_width_array[rw_]);
+                        int16_t h = (int16_t)p->hme_level2_search_area_in_height_array[rh_];
+                        B.valid[k_] = 1; B.w[k_] = w; B.h[k_] = h;
+                        B.ox[k_] = (int16_t)(-(w >> 1) + xl1[k_]);
+                        B.oy[k_] = (int16_t)(-(h >> 1) + yl1[k_]);
+                    });
+                    me_hme_multi(c, tid, &g, &B, 0, 1, &hme_parity);
+                    ME_FOR_SLOTS({ sl2[k_] = B.sad[k_]; xl2[k_] = B.xc[k_]; yl2[k_] = B.yc[k_]; });
+                    rh = NH;
                 }
                 uint64_t hme_sad = 0;
                 if (p->enable_hme_level_0_flag && !p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag) {
-                    x_hme_c = xl0[0][0]; y_hme_c = yl0[0][0]; hme_sad = sl0[0][0];
+                    x_hme_c = xl0[0]; y_hme_c = yl0[0]; hme_sad = sl0[0];
                     if (!p->single_hme_quadrant) {
-                        rw = 1; rh = 0;
-                        while (rh < NH) {
-                            while (rw < NW) {
-                                if (sl0[rw][rh] < hme_sad) { x_hme_c = xl0[rw][rh]; y_hme_c = yl0[rw][rh]; hme_sad = sl0[rw][rh]; }
-                                rw++;
-                            }
-                            rw = 0; rh++;
-                        }
+                        ME_FOR_SLOTS(if (k_ != 0 && sl0[k_] < hme_sad) { x_hme_c = xl0[k_]; y_hme_c = yl0[k_]; hme_sad = sl0[k_]; });
+                        rh = NH;
                     }
                 }
                 if (p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag) {
-                    x_hme_c = xl1[0][0]; y_hme_c = yl1[0][0]; hme_sad = sl1[0][0];
-                    rw = 1; rh = 0;
-                    while (rh < NH) {
-                        while (rw < NW) {
-                            if (sl1[rw][rh] < hme_sad) { x_hme_c = xl1[rw][rh]; y_hme_c = yl1[rw][rh]; hme_sad = sl1[rw][rh]; }
-                            rw++;
-                        }
-                        rw = 0; rh++;
-                    }
+                    x_hme_c = xl1[0]; y_hme_c = yl1[0]; hme_sad = sl1[0];
+                    ME_FOR_SLOTS(if (k_ != 0 && sl1[k_] < hme_sad) { x_hme_c = xl1[k_]; y_hme_c = yl1[k_]; hme_sad = sl1[k_]; });
                 }
                 if (p->enable_hme_level_2_flag) {
-                    x_hme_c = xl2[0][0]; y_hme_c = yl2[0][0]; hme_sad = sl2[0][0];
-                    rw = 1; rh = 0;
-                    while (rh < NH) {
-                        while (rw < NW) {
-                            if (sl2[rw][rh] < hme_sad) { x_hme_c = xl2[rw][rh]; y_hme_c = yl2[rw][rh]; hme_sad = sl2[rw][rh]; }
-                            rw++;
-                        }
-                        rw = 0; rh++;
-                    }
-                    int nq = NW, tot = NH * NW;
+                    x_hme_c = xl2[0]; y_hme_c = yl2[0]; hme_sad = sl2[0];
+                    ME_FOR_SLOTS(if (k_ != 0 && sl2[k_] < hme_sad) { x_hme_c = xl2[k_]; y_hme_c = yl2[k_]; hme_sad = sl2[k_]; });
+                    /* [quirk] the reference sorts with the index pair (q / NW, q % NW) applied to its [rw][rh] arrays
+                     * (:4943-4975): element q is region rw = q / NW, rh = q % NW, i.e. slot (q % NW) * 2 + q / NW */
+                    const int tot = NH * NW;
                     if (p->same_ref_poc && list == 1 && tot > 1) {
-                        for (int q = 0; q < tot - 1; q++)
-                            for (int n = q + 1; n < tot; n++)
-                                if (sl2[q / nq][q % nq] > sl2[n / nq][n % nq]) {
-                                    int16_t  tx = xl2[q / nq][q % nq], ty = yl2[q / nq][q % nq];
-                                    uint64_t td = sl2[q / nq][q % nq];
-                                    xl2[q / nq][q % nq] = xl2[n / nq][n % nq]; yl2[q / nq][q % nq] = yl2[n / nq][n % nq];
-                                    sl2[q / nq][q % nq] = sl2[n / nq][n % nq];
-                                    xl2[n / nq][n % nq] = tx; yl2[n / nq][n % nq] = ty; sl2[n / nq][n % nq] = td;
+                        _Pragma("unroll") for (int q = 0; q < 3; q++)
+                            _Pragma("unroll") for (int n = q + 1; n < 4; n++)
+                                if (n < tot) {
+                                    const int kq = (q % NW) * 2 + q / NW, kn = (n % NW) * 2 + n / NW;
+                                    uint64_t  sq = ME_SEL4(sl2, kq), sn = ME_SEL4(sl2, kn);
+                                    if (sq > sn) {
+                                        int16_t xq = ME_SEL4(xl2, kq), yq = ME_SEL4(yl2, kq), xn = ME_SEL4(xl2, kn), yn = ME_SEL4(yl2, kn);
+                                        _Pragma("unroll") for (int k = 0; k < 4; k++) {
+                                            if (k == kq) { xl2[k] = xn; yl2[k] = yn; sl2[k] = sn; }
+                                            else if (k == kn) { xl2[k] = xq; yl2[k] = yq; sl2[k] = sq; }
+                                        }
+                                    }
                                 }
-                        x_hme_c = xl2[0][1]; y_hme_c = yl2[0][1];
+                        /* element [0][1] of the reference's arrays: rw = 0, rh = 1 */
+                        x_hme_c = xl2[2]; y_hme_c = yl2[2];
                     }
                 }
+#undef ME_FOR_SLOTS
                 xsc = x_hme_c; ysc = y_hme_c;
             }
             ME_MARK(2);
@@ -1163,20 +1410,18 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         ME_MARK(4);
         /* ---- full-pel search, in chunks of search rows ---- */
         {
-            int max_pos   = c->L.scratch_bytes / 212; /* s8: 64 x u16 + s16: 16 x u32 + s32: 5 x u32 per position */
+            int max_pos   = c->L.scratch_bytes / (4 * ME_PU_STRIDE);
             int rows_chunk = max_pos / saw;
             if (rows_chunk < 1) rows_chunk = 1;
             if (rows_chunk > sah) rows_chunk = sah;
-            uint16_t *s8 = (uint16_t *)c->planes;
+            uint32_t *U = (uint32_t *)c->planes;
             for (int y0 = 0; y0 < sah; y0 += rows_chunk) {
                 int ny = y0 + rows_chunk <= sah ? rows_chunk : sah - y0;
-                uint32_t *s16 = (uint32_t *)(c->planes + (size_t)rows_chunk * saw * 128);
-                uint32_t *s32 = s16 + (size_t)rows_chunk * saw * 16;
-                ME_PHASE(ph_fullpel_sad8(c, tid, s8, saw, y0, ny, w8));
-                ME_PHASE(ph_fullpel_sum16(c, tid, s8, s16, saw, ny, w8));
-                ME_PHASE(ph_fullpel_sum32(c, tid, s16, s32, ny * saw));
+                ME_PHASE(ph_fullpel_sad8(c, tid, U, saw, y0, ny, w8));
+                ME_PHASE(ph_fullpel_sum16(c, tid, U, saw, ny, w8));
+                ME_PHASE(ph_fullpel_sum32(c, tid, U, ny * saw));
                 ME_MARK(5);
-                ME_PHASE(ph_fullpel_argmin(c, tid, s8, s16, s32, saw, y0, ny));
+                ME_PHASE(ph_fullpel_argmin(c, tid, U, saw, y0, ny));
                 ME_MARK(6);
             }
             /* keys -> best sad / mv (curr_mv = (y << 18) | (uint16)(x << 2), :108-110) */
@@ -1241,10 +1486,10 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
             ME_MARK(11);
         }
         if (nlist == 2) {
-            if (list == 0) ME_PHASE(ph_store_pred0(c, tid, sox, soy));
+            if (list == 0) ME_PHASE(ph_store_pred0(c, tid, sox, soy, ME_PRED0_REGS));
             else {
                 ME_PHASE(for (int t = tid; t < 85; t += SVT_NT) st->cand[t] = 0);
-                ME_PHASE(ph_bipred(c, tid, sox, soy));
+                ME_PHASE(ph_bipred(c, tid, sox, soy, ME_PRED0_REGS));
             }
             ME_MARK(12);
         }

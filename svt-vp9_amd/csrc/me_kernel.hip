@@ -11,10 +11,13 @@
 
 extern __shared__ __align__(16) uint8_t svt_lds[];
 
+#ifndef ME_WAVES_PER_EU
+#define ME_WAVES_PER_EU 3 /* 3 workgroups of 4 waves per CU: <= 168 VGPRs, <= 53 KB of LDS */
+#endif
 /* One workgroup per (picture, SB).  blockIdx -> work item mapping is XCD-aware: consecutive work items
  * (neighbouring SBs, which share most of their reference window) are placed on the same XCD so that the
  * window re-reads hit that XCD's L2 (block b runs on XCD b % 8). */
-__global__ __launch_bounds__(256) void svt_me_sb_kernel(const me_pic_dev *__restrict__ pics, svt_me_params p, me_lds_layout L,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ME_WAVES_PER_EU))) void svt_me_sb_kernel(const me_pic_dev *__restrict__ pics, svt_me_params p, me_lds_layout L,
                                                         int n_sb, int nx, int pic_w, int pic_h, int total, int chunk, unsigned long long *prof) {
     const int b = blockIdx.x;
     const int l = (b & 7) * chunk + (b >> 3);
@@ -29,7 +32,8 @@ __global__ __launch_bounds__(256) void svt_me_sb_kernel(const me_pic_dev *__rest
     c.src    = svt_lds + L.off_src;
     c.region = svt_lds + L.off_region;
     c.planes = svt_lds + L.off_planes;
-    c.pred0  = svt_lds + L.off_pred0;
+    c.quarter_sb  = svt_lds + L.off_quarter;
+    c.pred0       = (uint32_t *)(svt_lds + L.off_pred0);
     c.pic_w = pic_w; c.pic_h = pic_h; c.sb_index = sb; c.prof = prof;
     c.sb_x = (sb % nx) * ME_SB; c.sb_y = (sb / nx) * ME_SB;
     c.sb_w = (pic_w - c.sb_x) < ME_SB ? pic_w - c.sb_x : ME_SB;

@@ -23,8 +23,10 @@ static inline int me_lds_layout_compute(const svt_me_params *p, me_lds_layout *L
     L->off_src       = off; off += ME_SB * ME_SB;
     L->off_region    = off; off += me_round_up(L->region_rows * rs, 16);
     L->off_planes    = off; L->scratch_bytes = 3 * L->plane_bytes; off += L->scratch_bytes;
+    L->off_quarter   = off; if (p->enable_hme_level_1_flag) off += 32 * 32;
     L->off_pred0     = off;
-    if (p->num_ref_lists == 2) off += 4096 * (p->cu16x16_mode != 0 ? 2 : p->cu8x8_mode != 0 ? 3 : 4);
+    if (p->num_ref_lists == 2) /* [level][k][thread] dwords, k < K = 2 (SUB_SAD: even rows only) or 4 */
+        off += (p->fractional_search_method == SVT_SUB_SAD_SEARCH ? 2048 : 4096) * (p->cu16x16_mode != 0 ? 2 : p->cu8x8_mode != 0 ? 3 : 4);
     L->total_bytes = off;
     return off <= 160 * 1024 ? 0 : -1;
 }
