@@ -91,27 +91,53 @@ SVT_DEV uint32_t svt_pk_clamp_sub32(uint32_t v) {
 }
 /* keeps the instruction scheduler from interleaving unrolled iterations (and their live registers) */
 #define SVT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-SVT_DEV void svt_lds_min_u64(uint64_t *p, uint64_t v) { atomicMin((unsigned long long *)p, (unsigned long long)v); }
+SVT_DEV void svt_lds_min_u64(uint64_t *p, uint64_t v) { /* lanes of one instruction must target different addresses */
+    __hip_atomic_fetch_min((unsigned long long *)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 SVT_DEV void svt_lds_add_u32(uint32_t *p, uint32_t v) { atomicAdd(p, v); }
+/* Cross-lane reductions use DPP row shifts (a few cycles each) instead of ds_bpermute shuffles (~90 cycles each,
+ * measured), and never let several lanes of one instruction hit the same LDS address with an atomic (~100 cycles
+ * per lane, measured with tools/ubench_me.hip). */
+#define SVT_DPP_ADD(v, ctrl) ((v) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xf, 0xf, true))
+/* inclusive prefix sum inside each row of 16 lanes, up to `span` lanes back (span = 4, 8 or 16) */
+SVT_DEV uint32_t svt_row_prefix_add(uint32_t v, int span) {
+    v = SVT_DPP_ADD(v, 0x111); /* row_shr:1 */
+    v = SVT_DPP_ADD(v, 0x112); /* row_shr:2 */
+    if (span >= 8) v = SVT_DPP_ADD(v, 0x114);
+    if (span >= 16) v = SVT_DPP_ADD(v, 0x118);
+    return v;
+}
 /* sum over the 64 lanes of the wave (all lanes must call; inactive contributions pass 0) then ONE LDS atomic */
 SVT_DEV void svt_wave_add_u32(uint32_t *p, uint32_t v, int uniform_dst) {
     (void)uniform_dst;
-    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(p, v);
+    v = svt_row_prefix_add(v, 16);
+    const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)v, 15) + (uint32_t)__builtin_amdgcn_readlane((int)v, 31) +
+                       (uint32_t)__builtin_amdgcn_readlane((int)v, 47) + (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    if ((threadIdx.x & 63) == 0 && t) atomicAdd(p, t);
 }
-/* min over the wave of 64-bit keys (pass ~0 for "nothing"), then ONE LDS atomic */
+/* min over the wave of 64-bit keys (all lanes must call; pass ~0 for "nothing"), then ONE LDS atomic */
 SVT_DEV void svt_wave_min_u64(uint64_t *p, uint64_t v) {
-    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t lo = __shfl_xor((uint32_t)v, o), hi = __shfl_xor((uint32_t)(v >> 32), o);
-        const uint64_t w = ((uint64_t)hi << 32) | lo;
-        v = w < v ? w : v;
+#define SVT_DPP_MIN64(ctrl) do { \
+        const uint32_t oh_ = (uint32_t)__builtin_amdgcn_update_dpp((int)(v >> 32), (int)(v >> 32), (ctrl), 0xf, 0xf, false); \
+        const uint32_t ol_ = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, (ctrl), 0xf, 0xf, false); \
+        const uint64_t w_ = ((uint64_t)oh_ << 32) | ol_; v = w_ < v ? w_ : v; } while (0)
+    SVT_DPP_MIN64(0x111); SVT_DPP_MIN64(0x112); SVT_DPP_MIN64(0x114); SVT_DPP_MIN64(0x118);
+#undef SVT_DPP_MIN64
+    uint64_t m = ~0ull;
+    _Pragma("unroll") for (int l = 15; l < 64; l += 16) {
+        const uint64_t w = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+        m = w < m ? w : m;
     }
-    if ((threadIdx.x & 63) == 0 && v != ~0ull) atomicMin((unsigned long long *)p, (unsigned long long)v);
+    if ((threadIdx.x & 63) == 0 && m != ~0ull) __hip_atomic_fetch_min((unsigned long long *)p, (unsigned long long)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-/* sum over aligned groups of `group` (power of two <= 64) consecutive lanes that share one destination */
+/* sum over aligned groups of `group` (4, 8, 16 or 64) consecutive lanes that share one destination; whole groups are
+ * active or inactive together.  The last lane of the group holds the sum and issues the LDS add. */
 SVT_DEV void svt_group_add_u32(uint32_t *p, uint32_t v, int group) {
-    for (int o = group >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & (group - 1)) == 0 && v) atomicAdd(p, v);
+    v = svt_row_prefix_add(v, group);
+    if (group == 64)
+        v = (uint32_t)__builtin_amdgcn_readlane((int)v, 15) + (uint32_t)__builtin_amdgcn_readlane((int)v, 31) +
+            (uint32_t)__builtin_amdgcn_readlane((int)v, 47) + (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    if ((threadIdx.x & (group - 1)) == (unsigned)(group - 1) && v) atomicAdd(p, v);
 }
 #endif
 
@@ -909,7 +935,13 @@ SVT_DEV void ph_output(const me_ctx_t *c, int tid, svt_me_pu_result *out, uint32
 /* ME_MARK(i): when profiling is enabled, thread 0 adds the shader cycles since the previous mark to prof[i] */
 #if defined(SVT_HOST_EMU)
 #define ME_MARK(i) ((void)0)
+#define ME_SUBMARK_BEGIN() ((void)0)
+#define ME_SUBMARK(i) ((void)0)
 #else
+/* sub-phase marks (slots 14, 15): informational, not part of the per-phase total */
+#define ME_SUBMARK_BEGIN() unsigned long long sub_t_ = c->prof ? __builtin_amdgcn_s_memtime() : 0
+#define ME_SUBMARK(i) do { if (c->prof && tid == 0) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        atomicAdd(&c->prof[(i)], now_ - sub_t_); sub_t_ = now_; } } while (0)
 #define ME_MARK(i) do { if (c->prof && tid == 0) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
         atomicAdd(&c->prof[(i)], now_ - mark_t_); mark_t_ = now_; } } while (0)
 #endif
@@ -929,6 +961,8 @@ typedef struct me_hme_win {
     int32_t nd, rows; /* window dwords per row, rows */
     int32_t sw, sh;   /* search positions */
     int32_t gx, gy;   /* reference-picture coordinates of window column 0 / row 0 */
+    int32_t slot;     /* region (key) this window belongs to */
+    int32_t idx0;     /* raster index of the window's first search position inside its region (row band offset) */
 } me_hme_win;
 
 #define ME_SEL4(a, r) ((r) == 0 ? (a)[0] : (r) == 1 ? (a)[1] : (r) == 2 ? (a)[2] : (a)[3])
@@ -994,7 +1028,8 @@ SVT_DEV void me_qsad_block(const uint8_t *blk, int bstride, int nd, int bh, cons
     }
 }
 
-/* exhaustive search of every region of a batch (4 slots, empty ones have sw*sh = 0) in one phase; keys[r] = min over (sad << 32 | y*sw + x) */
+/* exhaustive search of every window of a batch (4 entries, empty ones have sw*sh = 0) in one phase;
+ * keys[slot] = min over (sad << 32 | raster index inside the region) */
 SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk, int bstride, int bw, int bh, const me_hme_win *wn,
                                  uint64_t *keys) {
     const int qs = (bw & 3) == 0; /* QSAD path: task = 4 positions */
@@ -1002,19 +1037,15 @@ SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk,
     tb[0] = 0;
     _Pragma("unroll") for (int r = 0; r < 4; r++) tb[r + 1] = tb[r] + (qs ? ((wn[r].sw + 3) >> 2) : wn[r].sw) * wn[r].sh;
     const int total = tb[4];
-    int       cur = -1;
-    uint64_t  best = ~0ull;
+    uint64_t  best[4] = {~0ull, ~0ull, ~0ull, ~0ull}; /* per key slot */
     for (int T = tid; T < total; T += SVT_NT) {
         int r = 0;
         _Pragma("unroll") for (int q = 1; q < 4; q++) if (T >= tb[q]) r = q;
-        if (r != cur) {
-            if (cur >= 0 && best != ~0ull) svt_lds_min_u64(&keys[cur], best);
-            cur = r; best = ~0ull;
-        }
         const int t = T - ME_SEL4(tb, r);
-        int       off = 0, ws = 0, sw = 1;
-        _Pragma("unroll") for (int q = 0; q < 4; q++) if (q == r) { off = wn[q].off; ws = wn[q].wstride; sw = wn[q].sw; }
+        int       off = 0, ws = 0, sw = 1, slot = 0, idx0 = 0;
+        _Pragma("unroll") for (int q = 0; q < 4; q++) if (q == r) { off = wn[q].off; ws = wn[q].wstride; sw = wn[q].sw; slot = wn[q].slot; idx0 = wn[q].idx0; }
         const uint8_t *win = c->planes + off;
+        uint64_t       kb = ~0ull;
         if (qs) {
             const int ng = (sw + 3) >> 2;
             const int y = t / ng, g = t - y * ng;
@@ -1023,8 +1054,8 @@ SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk,
             _Pragma("unroll") for (int o = 0; o < 4; o++) {
                 int x = 4 * g + o;
                 if (x < sw) {
-                    uint64_t k = ((uint64_t)a[o] << 32) | (uint32_t)(y * sw + x);
-                    if (k < best) best = k;
+                    uint64_t k = ((uint64_t)a[o] << 32) | (uint32_t)(idx0 + y * sw + x);
+                    if (k < kb) kb = k;
                 }
             }
         } else {
@@ -1035,11 +1066,12 @@ SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk,
                     int p0 = blk[j * bstride + i], p1 = win[(y + 2 * j) * ws + x + i];
                     sd += (uint32_t)(p0 > p1 ? p0 - p1 : p1 - p0);
                 }
-            uint64_t k = ((uint64_t)sd << 32) | (uint32_t)t;
-            if (k < best) best = k;
+            kb = ((uint64_t)sd << 32) | (uint32_t)(idx0 + t);
         }
+        _Pragma("unroll") for (int q = 0; q < 4; q++) if (q == slot && kb < best[q]) best[q] = kb;
     }
-    if (cur >= 0 && best != ~0ull) svt_lds_min_u64(&keys[cur], best);
+    /* every lane takes part in the 4 wave reductions (lanes without work contribute ~0) */
+    _Pragma("unroll") for (int q = 0; q < 4; q++) svt_wave_min_u64(&keys[q], best[q]);
 }
 
 typedef struct me_hme_geom {
@@ -1047,54 +1079,6 @@ typedef struct me_hme_geom {
     const uint8_t   *blk; /* LDS */
     int              bstride, bw, bh, ox, oy, pad_w, pad_h;
 } me_hme_geom;
-
-/* one HME search: window placement (hme_level0/1/2), LDS staging, exhaustive search, scaling */
-#ifdef SVT_HOST_EMU
-static inline
-#else
-__device__ __forceinline__
-#endif
-void me_hme_search(const me_ctx_t *c, int tid_, const me_hme_geom *g, int16_t sa_ox, int16_t sa_oy, int16_t sa_w, int16_t sa_h,
-                   int floor16, uint64_t *best_sad, int16_t *xc, int16_t *yc, int scale) {
-    int tid = tid_;
-    (void)tid;
-    me_clip_area(g->ox, &sa_ox, &sa_w, g->pad_w, g->ref->width);
-    me_clip_area(g->oy, &sa_oy, &sa_h, g->pad_h, g->ref->height);
-    if (floor16 && (sa_w & 15) != 0) sa_w = (int16_t)((sa_w >> 4) << 4);
-    uint64_t sad = 0xffffff;
-    int16_t  x = *xc, y = *yc;
-    if (sa_w > 0 && sa_h > 0) {
-        /* window: columns [0, sa_w + bw + 3), rows [0, sa_h + 2*(bh-1)]; staged in row bands that fit the scratch */
-        int wbytes  = sa_w + g->bw + 3;
-        int wstride = ((wbytes + 3) & ~3) + 4;
-        if (((wstride >> 2) & 1) == 0) wstride += 4;
-        int span      = 2 * (g->bh - 1);                 /* extra rows needed below a search row */
-        int max_rows  = c->L.scratch_bytes / wstride;    /* rows that fit */
-        int band_rows = max_rows - span;                 /* search rows per band */
-        if (band_rows > sa_h) band_rows = sa_h;
-        ME_UNIFORM_WRITE(c->st->hme_key = ~0ull);
-        for (int y0 = 0; y0 < sa_h; y0 += band_rows) {
-            int nr = y0 + band_rows <= sa_h ? band_rows : sa_h - y0;
-            ME_PHASE(ph_load_rect(tid, c->planes, wstride, me_pix(g->ref, g->ox + sa_ox, g->oy + sa_oy + y0), g->ref->stride, wbytes, nr + span));
-            /* keys inside a band are relative to the band; fold the band offset in through a second min stage */
-            ME_PHASE(ph_sad_search(c, tid, g->blk, g->bstride, g->bw, g->bh, c->planes, wstride, sa_w, nr, 2));
-            /* convert the band-relative index to a global raster index: done by keeping per-band best */
-            uint64_t k = c->st->hme_key;
-            if (k != ~0ull) {
-                uint32_t idx = (uint32_t)k, s = (uint32_t)(k >> 32);
-                uint64_t kk  = ((uint64_t)s << 32) | (uint32_t)(idx + y0 * sa_w);
-                /* bands are visited in increasing y, a later band only wins with a strictly smaller SAD */
-                if (s < sad) { sad = s; x = (int16_t)((kk & 0xffffffffu) % (uint32_t)sa_w); y = (int16_t)((kk & 0xffffffffu) / (uint32_t)sa_w); }
-            }
-            ME_PHASE((void)0);
-            ME_UNIFORM_WRITE(c->st->hme_key = ~0ull);
-        }
-    }
-    *best_sad = sad * 2;
-    x = (int16_t)(x + sa_ox); x = (int16_t)(x * scale);
-    y = (int16_t)(y + sa_oy); y = (int16_t)(y * scale);
-    *xc = x; *yc = y;
-}
 
 /* the (up to 4) region searches of one HME level: slot = rh*2 + rw; every array is indexed with compile-time
  * constants only so that the whole batch lives in registers */
@@ -1105,9 +1089,11 @@ typedef struct me_hme_batch {
     uint64_t sad[4];                   /* out */
 } me_hme_batch;
 
-/* Consecutive slots whose windows fit the scratch together are staged and searched as one batch (one global-load
- * phase + one search phase); a region too big for the scratch goes through the banded single-region path.
- * Results are identical to one me_hme_search() per valid slot. */
+/* One HME level: window placement (hme_level0/1/2 of Codec/EbMotionEstimation.c), LDS staging, exhaustive search,
+ * scaling.  The reference windows are staged in the scratch as a work list of (region, band of search rows); as many
+ * entries as fit (at most 4) form a batch = one global-load phase + one search phase.  A region too tall for the
+ * scratch is split into bands; the 64-bit key carries the raster index inside the region, so the minimum over all
+ * bands is exactly the reference's first minimum in raster order. */
 #ifdef SVT_HOST_EMU
 static inline
 #else
@@ -1118,10 +1104,10 @@ void me_hme_multi(const me_ctx_t *c, int tid_, const me_hme_geom *g, me_hme_batc
     (void)tid;
     const int span = 2 * (g->bh - 1);
     int16_t   cox[4], coy[4], cw[4], ch[4];
-    int       need[4], wst[4], wnd[4];
+    int       wst[4], wnd[4];
     _Pragma("unroll") for (int r = 0; r < 4; r++) {
         int16_t ox = B->ox[r], oy = B->oy[r], w = B->w[r], h = B->h[r];
-        need[r] = 0; wst[r] = 0; wnd[r] = 0;
+        wst[r] = 4; wnd[r] = 0;
         if (B->valid[r]) {
             me_clip_area(g->ox, &ox, &w, g->pad_w, g->ref->width);
             me_clip_area(g->oy, &oy, &h, g->pad_h, g->ref->height);
@@ -1130,57 +1116,61 @@ void me_hme_multi(const me_ctx_t *c, int tid_, const me_hme_geom *g, me_hme_batc
                 int wbytes = w + g->bw + 3;
                 int ws     = ((wbytes + 3) & ~3) + 4;
                 if (((ws >> 2) & 1) == 0) ws += 4;
-                wst[r] = ws; wnd[r] = (wbytes + 3) >> 2; need[r] = ws * (h + span);
-            }
+                wst[r] = ws; wnd[r] = (wbytes + 3) >> 2;
+            } else { w = 0; h = 0; }
         } else { w = 0; h = 0; }
         cox[r] = ox; coy[r] = oy; cw[r] = w; ch[r] = h;
     }
-    int r0 = 0;
-    while (r0 < 4) {
+    uint64_t *keys = c->st->hme_keys[*parity];
+    *parity ^= 1;
+    int r = 0, y = 0, first = 1;
+    for (;;) {
         me_hme_win wn[4];
-        int        r1 = r0, bytes = 0;
-        _Pragma("unroll") for (int r = 0; r < 4; r++) {
-            const int take = r >= r0 && r == r1 && bytes + need[r] <= c->L.scratch_bytes;
-            wn[r].off = bytes; wn[r].wstride = wst[r]; wn[r].gx = g->ox + cox[r]; wn[r].gy = g->oy + coy[r];
-            wn[r].nd = 0; wn[r].rows = 0; wn[r].sw = 0; wn[r].sh = 0;
-            if (take) {
-                if (need[r]) { wn[r].nd = wnd[r]; wn[r].rows = ch[r] + span; wn[r].sw = cw[r]; wn[r].sh = ch[r]; }
-                bytes += need[r];
-                r1 = r + 1;
-            }
-        }
-        if (r1 == r0) { /* does not fit on its own: banded path */
-            uint64_t sd = 0;
-            int16_t  x = ME_SEL4(B->xc, r0), y = ME_SEL4(B->yc, r0);
-            me_hme_search(c, tid, g, ME_SEL4(B->ox, r0), ME_SEL4(B->oy, r0), ME_SEL4(B->w, r0), ME_SEL4(B->h, r0), floor16, &sd, &x, &y, scale);
-            _Pragma("unroll") for (int r = 0; r < 4; r++) if (r == r0) { B->sad[r] = sd; B->xc[r] = x; B->yc[r] = y; }
-            r0++;
-            continue;
-        }
-        uint64_t *keys = c->st->hme_keys[*parity];
-        *parity ^= 1;
-        if (bytes) {
-            ME_PHASE(if (tid < 4) keys[tid] = ~0ull; ph_hme_load_multi(c, tid, g->ref, wn));
-            ME_PHASE(ph_hme_search_multi(c, tid, g->blk, g->bstride, g->bw, g->bh, wn, keys));
-        }
-        _Pragma("unroll") for (int r = 0; r < 4; r++) {
-            if (r >= r0 && r < r1 && B->valid[r]) {
-                uint64_t sad = 0xffffff;
-                int16_t  x = B->xc[r], y = B->yc[r];
-                if (need[r]) {
-                    uint64_t k = keys[r];
-                    if (k != ~0ull) {
-                        uint32_t idx = (uint32_t)k, sd = (uint32_t)(k >> 32);
-                        if (sd < sad) { sad = sd; x = (int16_t)(idx % (uint32_t)cw[r]); y = (int16_t)(idx / (uint32_t)cw[r]); }
-                    }
+        int        bytes = 0, ne = 0, full = 0;
+        _Pragma("unroll") for (int e = 0; e < 4; e++) {
+            wn[e].off = 0; wn[e].wstride = 4; wn[e].nd = 0; wn[e].rows = 0; wn[e].sw = 0; wn[e].sh = 0;
+            wn[e].gx = 0; wn[e].gy = 0; wn[e].slot = 0; wn[e].idx0 = 0;
+            while (r < 4 && y >= ME_SEL4(ch, r)) { r++; y = 0; }
+            if (r < 4 && !full) {
+                const int ws = ME_SEL4(wst, r), h = ME_SEL4(ch, r), sw = ME_SEL4(cw, r);
+                int       nr = (c->L.scratch_bytes - bytes) / ws - span;
+                if (nr > h - y) nr = h - y;
+                if (nr >= 1) {
+                    wn[e].off = bytes; wn[e].wstride = ws; wn[e].nd = ME_SEL4(wnd, r); wn[e].rows = nr + span;
+                    wn[e].sw = sw; wn[e].sh = nr;
+                    wn[e].gx = g->ox + ME_SEL4(cox, r); wn[e].gy = g->oy + ME_SEL4(coy, r) + y;
+                    wn[e].slot = r; wn[e].idx0 = y * sw;
+                    bytes += ws * (nr + span); y += nr; ne++;
+                } else {
+                    full = 1;
+                    if (bytes == 0) { r++; y = 0; } /* cannot happen with the scratch sizes of me_lds_layout_compute */
                 }
-                B->sad[r] = sad * 2;
-                x = (int16_t)(x + cox[r]); x = (int16_t)(x * scale);
-                y = (int16_t)(y + coy[r]); y = (int16_t)(y * scale);
-                B->xc[r] = x; B->yc[r] = y;
             }
         }
-        r0 = r1;
+        if (ne == 0) break;
+        ME_SUBMARK_BEGIN();
+        ME_PHASE(if (first && tid < 4) keys[tid] = ~0ull; ph_hme_load_multi(c, tid, g->ref, wn));
+        first = 0;
+        ME_SUBMARK(14);
+        ME_PHASE(ph_hme_search_multi(c, tid, g->blk, g->bstride, g->bw, g->bh, wn, keys));
+        ME_SUBMARK(15);
+    }
+    _Pragma("unroll") for (int q = 0; q < 4; q++) {
+        if (B->valid[q]) {
+            uint64_t sad = 0xffffff;
+            int16_t  x = B->xc[q], yv = B->yc[q];
+            if (cw[q] > 0 && !first) {
+                uint64_t k = keys[q];
+                if (k != ~0ull) {
+                    uint32_t idx = (uint32_t)k, sd = (uint32_t)(k >> 32);
+                    if (sd < sad) { sad = sd; x = (int16_t)(idx % (uint32_t)cw[q]); yv = (int16_t)(idx / (uint32_t)cw[q]); }
+                }
+            }
+            B->sad[q] = sad * 2;
+            x = (int16_t)(x + cox[q]); x = (int16_t)(x * scale);
+            yv = (int16_t)(yv + coy[q]); yv = (int16_t)(yv * scale);
+            B->xc[q] = x; B->yc[q] = yv;
+        }
     }
 }
 
@@ -1276,63 +1266,71 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                 });
                 if (rh < NH) rh = NH;
                 const int mult = me_hme_l0_mult[p->hierarchical_levels][p->temporal_layer_index];
-                me_hme_batch B;
-                if (p->enable_hme_level_0_flag) {
-                    me_hme_geom g = {r16, st->sixteenth_sb, 16, c->sb_w >> 2, (c->sb_h >> 2) >> 1, (int16_t)(c->sb_x >> 2),
-                                     (int16_t)(c->sb_y >> 2), r16->origin_x - 1, r16->origin_y - 1};
-                    _Pragma("unroll") for (int k = 0; k < 4; k++) { B.valid[k] = 0; B.ox[k] = B.oy[k] = B.w[k] = B.h[k] = 0; B.xc[k] = xl0[k]; B.yc[k] = yl0[k]; B.sad[k] = 0; }
-                    if (p->single_hme_quadrant && !p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag) {
-                        rh = 0;
-                        int16_t w = (int16_t)((p->hme_level0_total_search_area_width * mult) / 100);
-                        int16_t h = (int16_t)((p->hme_level0_total_search_area_height * mult) / 100);
-                        B.valid[0] = 1; B.w[0] = w; B.h[0] = h;
-                        B.ox[0] = (int16_t)(-(int16_t)(w >> 1) + (int16_t)(xsc >> 2));
-                        B.oy[0] = (int16_t)(-(int16_t)(h >> 1) + (int16_t)(ysc >> 2));
-                        me_hme_multi(c, tid, &g, &B, 1, 4, &hme_parity);
-                        sl0[0] = B.sad[0]; xl0[0] = B.xc[0]; yl0[0] = B.yc[0];
-                    } else {
+                /* the three levels share one instance of the search code (instruction-cache footprint) */
+                for (int lvl = 0; lvl < 3; lvl++) {
+                    if (!(lvl == 0 ? p->enable_hme_level_0_flag : lvl == 1 ? p->enable_hme_level_1_flag : p->enable_hme_level_2_flag)) continue;
+                    me_hme_geom  g;
+                    me_hme_batch B;
+                    int          floor16 = 0, scale = 4 >> lvl;
+                    _Pragma("unroll") for (int k = 0; k < 4; k++) { B.valid[k] = 0; B.ox[k] = B.oy[k] = B.w[k] = B.h[k] = 0; B.sad[k] = 0; }
+                    if (lvl == 0) {
+                        g.ref = r16; g.blk = st->sixteenth_sb; g.bstride = 16; g.bw = c->sb_w >> 2; g.bh = (c->sb_h >> 2) >> 1;
+                        g.ox = (int16_t)(c->sb_x >> 2); g.oy = (int16_t)(c->sb_y >> 2); g.pad_w = r16->origin_x - 1; g.pad_h = r16->origin_y - 1;
+                        _Pragma("unroll") for (int k = 0; k < 4; k++) { B.xc[k] = xl0[k]; B.yc[k] = yl0[k]; }
+                        if (p->single_hme_quadrant && !p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag) {
+                            rh = 0;
+                            floor16 = 1;
+                            int16_t w = (int16_t)((p->hme_level0_total_search_area_width * mult) / 100);
+                            int16_t h = (int16_t)((p->hme_level0_total_search_area_height * mult) / 100);
+                            B.valid[0] = 1; B.w[0] = w; B.h[0] = h;
+                            B.ox[0] = (int16_t)(-(int16_t)(w >> 1) + (int16_t)(xsc >> 2));
+                            B.oy[0] = (int16_t)(-(int16_t)(h >> 1) + (int16_t)(ysc >> 2));
+                        } else {
+                            ME_FOR_SLOTS({
+                                int16_t w = (int16_t)((p->hme_level0_search_area_in_width_array[rw_] * mult) / 100);
+                                int16_t h = (int16_t)((p->hme_level0_search_area_in_height_array[rh_] * mult) / 100);
+                                int16_t ddx = (int16_t)(xsc >> 2), ddy = (int16_t)(ysc >> 2);
+                                if (rw_ > 0) ddx = (int16_t)(ddx + (int16_t)((p->hme_level0_search_area_in_width_array[0] * mult) / 100));
+                                if (rh_ > 0) ddy = (int16_t)(ddy + (int16_t)((p->hme_level0_search_area_in_height_array[0] * mult) / 100));
+                                B.valid[k_] = 1; B.w[k_] = w; B.h[k_] = h;
+                                B.ox[k_] = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_width * mult) / 100) >> 1) + ddx);
+                                B.oy[k_] = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_height * mult) / 100) >> 1) + ddy);
+                            });
+                            rh = NH;
+                        }
+                    } else if (lvl == 1) {
+                        g.ref = rq; g.blk = c->quarter_sb; g.bstride = 64; g.bw = c->sb_w >> 1; g.bh = (c->sb_h >> 1) >> 1;
+                        g.ox = (int16_t)(c->sb_x >> 1); g.oy = (int16_t)(c->sb_y >> 1); g.pad_w = rq->origin_x - 1; g.pad_h = rq->origin_y - 1;
+                        _Pragma("unroll") for (int k = 0; k < 4; k++) { B.xc[k] = xl1[k]; B.yc[k] = yl1[k]; }
                         ME_FOR_SLOTS({
-                            int16_t w = (int16_t)((p->hme_level0_search_area_in_width_array[rw_] * mult) / 100);
-                            int16_t h = (int16_t)((p->hme_level0_search_area_in_height_array[rh_] * mult) / 100);
-                            int16_t ddx = (int16_t)(xsc >> 2), ddy = (int16_t)(ysc >> 2);
-                            if (rw_ > 0) ddx = (int16_t)(ddx + (int16_t)((p->hme_level0_search_area_in_width_array[0] * mult) / 100));
-                            if (rh_ > 0) ddy = (int16_t)(ddy + (int16_t)((p->hme_level0_search_area_in_height_array[0] * mult) / 100));
+                            int16_t w = me_hme_round_w((int16_t)p->hme_level1_search_area_in_width_array[rw_]);
+                            int16_t h = (int16_t)p->hme_level1_search_area_in_height_array[rh_];
                             B.valid[k_] = 1; B.w[k_] = w; B.h[k_] = h;
-                            B.ox[k_] = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_width * mult) / 100) >> 1) + ddx);
-                            B.oy[k_] = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_height * mult) / 100) >> 1) + ddy);
+                            B.ox[k_] = (int16_t)(-(w >> 1) + (int16_t)(xl0[k_] >> 1));
+                            B.oy[k_] = (int16_t)(-(h >> 1) + (int16_t)(yl0[k_] >> 1));
                         });
-                        me_hme_multi(c, tid, &g, &B, 0, 4, &hme_parity);
-                        ME_FOR_SLOTS({ sl0[k_] = B.sad[k_]; xl0[k_] = B.xc[k_]; yl0[k_] = B.yc[k_]; });
+                        rh = NH;
+                    } else {
+                        g.ref = rf; g.blk = c->src; g.bstride = 2 * ME_SB; g.bw = c->sb_w; g.bh = c->sb_h >> 1;
+                        g.ox = (int16_t)c->sb_x; g.oy = (int16_t)c->sb_y; g.pad_w = ME_SB - 1; g.pad_h = ME_SB - 1;
+                        _Pragma("unroll") for (int k = 0; k < 4; k++) { B.xc[k] = xl2[k]; B.yc[k] = yl2[k]; }
+                        ME_FOR_SLOTS({
+                            int16_t w = me_hme_round_w((int16_t)p->hme_level2_search_area_in_width_array[rw_]);
+                            int16_t h = (int16_t)p->hme_level2_search_area_in_height_array[rh_];
+                            B.valid[k_] = 1; B.w[k_] = w; B.h[k_] = h;
+                            B.ox[k_] = (int16_t)(-(w >> 1) + xl1[k_]);
+                            B.oy[k_] = (int16_t)(-(h >> 1) + yl1[k_]);
+                        });
+                        rh = NH;
                     }
-                }
-                if (p->enable_hme_level_1_flag) {
-                    me_hme_geom g = {rq, c->quarter_sb, 64, c->sb_w >> 1, (c->sb_h >> 1) >> 1, (int16_t)(c->sb_x >> 1),
-                                     (int16_t)(c->sb_y >> 1), rq->origin_x - 1, rq->origin_y - 1};
-                    _Pragma("unroll") for (int k = 0; k < 4; k++) { B.valid[k] = 0; B.ox[k] = B.oy[k] = B.w[k] = B.h[k] = 0; B.xc[k] = xl1[k]; B.yc[k] = yl1[k]; B.sad[k] = 0; }
-                    ME_FOR_SLOTS({
-                        int16_t w = me_hme_round_w((int16_t)p->hme_level1_search_area_in_width_array[rw_]);
-                        int16_t h = (int16_t)p->hme_level1_search_area_in_height_array[rh_];
-                        B.valid[k_] = 1; B.w[k_] = w; B.h[k_] = h;
-                        B.ox[k_] = (int16_t)(-(w >> 1) + (int16_t)(xl0[k_] >> 1));
-                        B.oy[k_] = (int16_t)(-(h >> 1) + (int16_t)(yl0[k_] >> 1));
-                    });
-                    me_hme_multi(c, tid, &g, &B, 0, 2, &hme_parity);
-                    ME_FOR_SLOTS({ sl1[k_] = B.sad[k_]; xl1[k_] = B.xc[k_]; yl1[k_] = B.yc[k_]; });
-                    rh = NH;
-                }
-                if (p->enable_hme_level_2_flag) {
-                    me_hme_geom g = {rf, c->src, 2 * ME_SB, c->sb_w, c->sb_h >> 1, (int16_t)c->sb_x, (int16_t)c->sb_y, ME_SB - 1, ME_SB - 1};
-                    _Pragma("unroll") for (int k = 0; k < 4; k++) { B.valid[k] = 0; B.ox[k] = B.oy[k] = B.w[k] = B.h[k] = 0; B.xc[k] = xl2[k]; B.yc[k] = yl2[k]; B.sad[k] = 0; }
-                    ME_FOR_SLOTS({
-                        int16_t w = me_hme_round_w((int16_t)p->hme_level2_search_area_in_width_array[rw_]);
-                        int16_t h = (int16_t)p->hme_level2_search_area_in_height_array[rh_];
-                        B.valid[k_] = 1; B.w[k_] = w; B.h[k_] = h;
-                        B.ox[k_] = (int16_t)(-(w >> 1) + xl1[k_]);
-                        B.oy[k_] = (int16_t)(-(h >> 1) + yl1[k_]);
-                    });
-                    me_hme_multi(c, tid, &g, &B, 0, 1, &hme_parity);
-                    ME_FOR_SLOTS({ sl2[k_] = B.sad[k_]; xl2[k_] = B.xc[k_]; yl2[k_] = B.yc[k_]; });
-                    rh = NH;
+                    me_hme_multi(c, tid, &g, &B, floor16, scale, &hme_parity);
+                    _Pragma("unroll") for (int k = 0; k < 4; k++) {
+                        if (B.valid[k]) {
+                            if (lvl == 0) { sl0[k] = B.sad[k]; xl0[k] = B.xc[k]; yl0[k] = B.yc[k]; }
+                            else if (lvl == 1) { sl1[k] = B.sad[k]; xl1[k] = B.xc[k]; yl1[k] = B.yc[k]; }
+                            else { sl2[k] = B.sad[k]; xl2[k] = B.xc[k]; yl2[k] = B.yc[k]; }
+                        }
+                    }
                 }
                 uint64_t hme_sad = 0;
                 if (p->enable_hme_level_0_flag && !p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag) {

@@ -152,7 +152,7 @@ extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, con
         for (int i = 0; i < 14; i++) tot += hp[i];
         fprintf(stderr, "[me-profile] tl=%d pics=%d WGs=%d avg cycles/WG=%llu :", params->temporal_layer_index, n_pics, total, tot / (unsigned long long)total);
         for (int i = 0; i < 14; i++) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * (double)hp[i] / (double)tot);
-        fprintf(stderr, "\n");
+        fprintf(stderr, " | hme_load=%.1f%% hme_search=%.1f%%\n", 100.0 * (double)hp[14] / (double)tot, 100.0 * (double)hp[15] / (double)tot);
     }
     svt_ctx_stage_commit(ctx);
     ctx->timed = 1;
