@@ -179,10 +179,36 @@ __device__ __forceinline__ void horiz_col(uint8_t *s, int st, int cb, unsigned m
     if (inner) filter_px(s + 4 * st, st, 4, t.mblim[ilvl], t.lim[ilvl], t.hev_thr[ilvl]);
 }
 
-/* copy a tile between global memory and LDS, clipped to the part of the plane that exists */
+/* copy a tile between global memory and LDS, clipped to the part of the plane that exists.
+ * tile sample (tx, ty) <-> plane sample (x0 + tx, y0 + ty); only tx in [0,nx), ty in [0,ny).  x0, nx and the LDS
+ * offsets are multiples of 8; when the plane rows are 8-byte aligned the copy moves 8 bytes per lane and keeps up to
+ * UNITS loads in flight before the first store (a tile is a handful of units per lane). */
+template <int UNITS>
 __device__ __forceinline__ void tile_io(bool load, uint8_t *g, int gstride, uint8_t *l, int lstride, int x0, int y0, int nx, int ny,
                                         int tid, int nthreads) {
-    /* tile sample (tx, ty) <-> plane sample (x0 + tx, y0 + ty); only tx in [0,nx), ty in [0,ny) */
+    if ((((uintptr_t)g | (uintptr_t)gstride) & 7) == 0) {
+        const int nu = nx >> 3, total = nu * ny; /* 8-byte units per row */
+        for (int t0 = tid; t0 < total; t0 += UNITS * nthreads) {
+            uint2 v[UNITS];
+            int   lo[UNITS];
+            _Pragma("unroll") for (int u = 0; u < UNITS; u++) {
+                const int t = t0 + u * nthreads;
+                lo[u] = -1;
+                if (t < total) {
+                    const int ty = t / nu, tu = t - ty * nu;
+                    uint2    *gp = (uint2 *)(g + (ptrdiff_t)(y0 + ty) * gstride + x0 + 8 * tu);
+                    lo[u] = ty * lstride + 8 * tu;
+                    if (load) v[u] = *gp;
+                    else { const uint32_t *lp = (const uint32_t *)(l + lo[u]); *gp = make_uint2(lp[0], lp[1]); }
+                }
+            }
+            if (load) {
+                _Pragma("unroll") for (int u = 0; u < UNITS; u++)
+                    if (lo[u] >= 0) { uint32_t *lp = (uint32_t *)(l + lo[u]); lp[0] = v[u].x; lp[1] = v[u].y; }
+            }
+        }
+        return;
+    }
     for (int t = tid; t < nx * ny; t += nthreads) {
         const int ty = t / nx, tx = t - ty * nx;
         uint8_t  *gp = g + (ptrdiff_t)(y0 + ty) * gstride + x0 + tx;
@@ -228,10 +254,10 @@ __global__ __launch_bounds__(128) void svt_lf_kernel(const lf_pic_dev *__restric
         const int vw = (W - x0) < 64 ? W - x0 : 64, vh = (H - y0) < 64 ? H - y0 : 64;
         const int cvw = (CW - cx0) < 32 ? CW - cx0 : 32, cvh = (CH - cy0) < 32 ? CH - cy0 : 32;
         uint8_t *yl = ytile + (8 - hy) * YS + (8 - hx); /* LDS address of tile sample (x0-hx, y0-hy) */
-        tile_io(true, P.planes.y, P.planes.y_stride, yl, YS, x0 - hx, y0 - hy, vw + hx, vh + hy, tid, 128);
+        tile_io<6>(true, P.planes.y, P.planes.y_stride, yl, YS, x0 - hx, y0 - hy, vw + hx, vh + hy, tid, 128);
         if (!P.y_only) {
-            tile_io(true, P.planes.u, P.planes.uv_stride, ctile[0] + (8 - hy) * CS + (8 - hx), CS, cx0 - hx, cy0 - hy, cvw + hx, cvh + hy, tid, 128);
-            tile_io(true, P.planes.v, P.planes.uv_stride, ctile[1] + (8 - hy) * CS + (8 - hx), CS, cx0 - hx, cy0 - hy, cvw + hx, cvh + hy, tid, 128);
+            tile_io<2>(true, P.planes.u, P.planes.uv_stride, ctile[0] + (8 - hy) * CS + (8 - hx), CS, cx0 - hx, cy0 - hy, cvw + hx, cvh + hy, tid, 128);
+            tile_io<2>(true, P.planes.v, P.planes.uv_stride, ctile[1] + (8 - hy) * CS + (8 - hx), CS, cx0 - hx, cy0 - hy, cvw + hx, cvh + hy, tid, 128);
         }
         __syncthreads();
         /* ---- vertical edges ---- */
@@ -280,10 +306,10 @@ __global__ __launch_bounds__(128) void svt_lf_kernel(const lf_pic_dev *__restric
         }
         __syncthreads();
         /* ---- write back ---- */
-        tile_io(false, P.planes.y, P.planes.y_stride, yl, YS, x0 - hx, y0 - hy, vw + hx, vh + hy, tid, 128);
+        tile_io<6>(false, P.planes.y, P.planes.y_stride, yl, YS, x0 - hx, y0 - hy, vw + hx, vh + hy, tid, 128);
         if (!P.y_only) {
-            tile_io(false, P.planes.u, P.planes.uv_stride, ctile[0] + (8 - hy) * CS + (8 - hx), CS, cx0 - hx, cy0 - hy, cvw + hx, cvh + hy, tid, 128);
-            tile_io(false, P.planes.v, P.planes.uv_stride, ctile[1] + (8 - hy) * CS + (8 - hx), CS, cx0 - hx, cy0 - hy, cvw + hx, cvh + hy, tid, 128);
+            tile_io<2>(false, P.planes.u, P.planes.uv_stride, ctile[0] + (8 - hy) * CS + (8 - hx), CS, cx0 - hx, cy0 - hy, cvw + hx, cvh + hy, tid, 128);
+            tile_io<2>(false, P.planes.v, P.planes.uv_stride, ctile[1] + (8 - hy) * CS + (8 - hx), CS, cx0 - hx, cy0 - hy, cvw + hx, cvh + hy, tid, 128);
         }
         /* ---- publish: all stores of this workgroup -> agent-scope release -> progress counter ---- */
         __syncthreads();
