@@ -215,14 +215,34 @@ typedef struct me_lds_layout {
 #define ME_RGN_GY 3 /* top guard rows */
 #define ME_PL_G 2   /* guard of the half-pel planes */
 
+/* ---- HME work list: (region, band of search rows) windows staged in the scratch and searched batch by batch ---- */
+#define ME_HME_MAX_WIN 16
+typedef struct me_hme_win {
+    int32_t off;      /* byte offset of the window inside the scratch */
+    int32_t wstride;  /* window row stride (bytes, odd number of dwords) */
+    int32_t nd, rows; /* window dwords per row, rows */
+    int32_t sw, sh;   /* search positions */
+    int32_t gx, gy;   /* reference-picture coordinates of window column 0 / row 0 */
+    int32_t slot;     /* region (key) this window belongs to */
+    int32_t idx0;     /* raster index of the window's first search position inside its region (row band offset) */
+    int32_t tl, ts;   /* first load task / first search task of this window inside its batch */
+} me_hme_win;
+
 /* per-SB state in LDS */
 typedef struct me_state_t {
     union {                    /* the full-pel keys are dead once the best MVs are extracted, before the first cand use */
         uint64_t key[85];      /* full-pel arg-min keys of the current list */
         uint32_t cand[85 * 8]; /* sub-pel candidate distortions [pu][8]; bi-pred distortion [pu] */
     };
-    uint64_t hme_key;          /* arg-min key of the running HME search */
-    uint64_t hme_keys[2][4];   /* arg-min keys of a batch of HME region searches, double buffered by batch parity */
+    uint64_t hme_key;          /* arg-min key of the stand-alone SAD-loop kernel */
+    uint64_t hme_keys[4];      /* arg-min keys of the region searches of the current HME level */
+    uint64_t hme_sad[3][4];    /* per level, per region slot (rh*2 + rw): best SAD * 2 */
+    int16_t  hme_x[3][4], hme_y[3][4]; /* per level, per region slot: search centre in / best position out */
+    int16_t  hme_cox[4], hme_coy[4], hme_cw[4], hme_ch[4]; /* clipped search areas of the current level */
+    int16_t  hme_xc, hme_yc;   /* HME result; persists from list 0 to list 1 when no level runs */
+    int32_t  hme_rh;           /* [quirk] the reference's region-row counter, not reset between the lists */
+    int32_t  hme_nbatch, hme_bstart[ME_HME_MAX_WIN + 1]; /* batches of windows that fit the scratch together */
+    me_hme_win hme_win[ME_HME_MAX_WIN];
     uint32_t best_sad[2][85];  /* search (z-order) index */
     uint32_t best_mv[2][85];
     uint32_t red[8];           /* small sum reductions */
@@ -312,6 +332,8 @@ SVT_DEV void ph_init(const me_ctx_t *c, int tid) {
         st->dir[t] = 0;
     }
     if (tid < 8) st->red[tid] = 0;
+    if (tid < 12) { st->hme_x[tid >> 2][tid & 3] = 0; st->hme_y[tid >> 2][tid & 3] = 0; st->hme_sad[tid >> 2][tid & 3] = 0; }
+    if (tid == 0) { st->hme_rh = 0; st->hme_xc = 0; st->hme_yc = 0; }
     /* source SB: always 64x64 from the padded picture */
     ph_load_rect(tid, c->src, ME_SB, me_pix(&c->pic->cur.full, c->sb_x, c->sb_y), c->pic->cur.full.stride, ME_SB, ME_SB);
     if (c->p->enable_hme_level_0_flag) {
@@ -948,47 +970,31 @@ SVT_DEV void ph_output(const me_ctx_t *c, int tid, svt_me_pu_result *out, uint32
 #ifdef SVT_HOST_EMU
 #define ME_PHASE(...) do { for (int tid = 0; tid < SVT_NT; tid++) { __VA_ARGS__; } } while (0)
 #define ME_UNIFORM_WRITE(...) do { __VA_ARGS__; } while (0)
+#define ME_UNI(x) (x)
 #else
 #define ME_PHASE(...) do { __VA_ARGS__; __syncthreads(); } while (0)
 /* uniform state written to LDS by one thread, followed by a barrier */
 #define ME_UNIFORM_WRITE(...) do { if (tid == 0) { __VA_ARGS__; } __syncthreads(); } while (0)
+/* a value every lane holds identically (read from LDS): move it to a scalar register */
+#define ME_UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
 #endif
 
-/* ---- batched HME: the (up to 4) search regions of one level are staged and searched together -------------- */
-typedef struct me_hme_win {
-    int32_t off;      /* byte offset of the window inside the scratch */
-    int32_t wstride;  /* window row stride (bytes, odd number of dwords) */
-    int32_t nd, rows; /* window dwords per row, rows */
-    int32_t sw, sh;   /* search positions */
-    int32_t gx, gy;   /* reference-picture coordinates of window column 0 / row 0 */
-    int32_t slot;     /* region (key) this window belongs to */
-    int32_t idx0;     /* raster index of the window's first search position inside its region (row band offset) */
-} me_hme_win;
-
-#define ME_SEL4(a, r) ((r) == 0 ? (a)[0] : (r) == 1 ? (a)[1] : (r) == 2 ? (a)[2] : (a)[3])
-
-/* copy the windows of all regions of a batch: flattened (region,row,dword) tasks, four global loads in flight per
- * thread before the LDS stores */
-SVT_DEV void ph_hme_load_multi(const me_ctx_t *c, int tid, const svt_plane *ref, const me_hme_win *wn) {
-    int tb[5];
-    tb[0] = 0;
-    _Pragma("unroll") for (int r = 0; r < 4; r++) tb[r + 1] = tb[r] + wn[r].nd * wn[r].rows;
-    const int total = tb[4];
-    for (int t0 = tid; t0 < total; t0 += 4 * SVT_NT) {
+/* copy the windows [e0, e1) of a batch: flattened (window,row,dword) tasks, four global loads in flight per thread
+ * before the LDS stores; ntask = total load tasks of the batch */
+SVT_DEV void ph_hme_load_multi(const me_ctx_t *c, int tid, const svt_plane *ref, const me_hme_win *wn, int e0, int e1, int ntask) {
+    for (int t0 = tid; t0 < ntask; t0 += 4 * SVT_NT) {
         uint32_t v[4];
         int      dst[4];
         _Pragma("unroll") for (int u = 0; u < 4; u++) {
             int T = t0 + u * SVT_NT;
             dst[u] = -1;
-            if (T < total) {
-                int r = 0;
-                _Pragma("unroll") for (int q = 1; q < 4; q++) if (T >= tb[q]) r = q;
-                const int t = T - ME_SEL4(tb, r);
-                int       nd = 0, off = 0, ws = 0, gx = 0, gy = 0;
-                _Pragma("unroll") for (int q = 0; q < 4; q++) if (q == r) { nd = wn[q].nd; off = wn[q].off; ws = wn[q].wstride; gx = wn[q].gx; gy = wn[q].gy; }
-                int row = t / nd, i = t - row * nd;
-                v[u]   = me_ld32u(me_pix(ref, gx + 4 * i, gy + row));
-                dst[u] = off + row * ws + 4 * i;
+            if (T < ntask) {
+                int e = e0;
+                while (e + 1 < e1 && T >= wn[e + 1].tl) e++;
+                const int t = T - wn[e].tl, nd = wn[e].nd;
+                const int row = t / nd, i = t - row * nd;
+                v[u]   = me_ld32u(me_pix(ref, wn[e].gx + 4 * i, wn[e].gy + row));
+                dst[u] = wn[e].off + row * wn[e].wstride + 4 * i;
             }
         }
         _Pragma("unroll") for (int u = 0; u < 4; u++) if (dst[u] >= 0) *(uint32_t *)(c->planes + dst[u]) = v[u];
@@ -1028,23 +1034,17 @@ SVT_DEV void me_qsad_block(const uint8_t *blk, int bstride, int nd, int bh, cons
     }
 }
 
-/* exhaustive search of every window of a batch (4 entries, empty ones have sw*sh = 0) in one phase;
- * keys[slot] = min over (sad << 32 | raster index inside the region) */
+/* exhaustive search of the windows [e0, e1) of a batch in one phase; keys[slot] = min over
+ * (sad << 32 | raster index inside the region) */
 SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk, int bstride, int bw, int bh, const me_hme_win *wn,
-                                 uint64_t *keys) {
+                                 int e0, int e1, int ntask, uint64_t *keys) {
     const int qs = (bw & 3) == 0; /* QSAD path: task = 4 positions */
-    int       tb[5];
-    tb[0] = 0;
-    _Pragma("unroll") for (int r = 0; r < 4; r++) tb[r + 1] = tb[r] + (qs ? ((wn[r].sw + 3) >> 2) : wn[r].sw) * wn[r].sh;
-    const int total = tb[4];
     uint64_t  best[4] = {~0ull, ~0ull, ~0ull, ~0ull}; /* per key slot */
-    for (int T = tid; T < total; T += SVT_NT) {
-        int r = 0;
-        _Pragma("unroll") for (int q = 1; q < 4; q++) if (T >= tb[q]) r = q;
-        const int t = T - ME_SEL4(tb, r);
-        int       off = 0, ws = 0, sw = 1, slot = 0, idx0 = 0;
-        _Pragma("unroll") for (int q = 0; q < 4; q++) if (q == r) { off = wn[q].off; ws = wn[q].wstride; sw = wn[q].sw; slot = wn[q].slot; idx0 = wn[q].idx0; }
-        const uint8_t *win = c->planes + off;
+    for (int T = tid; T < ntask; T += SVT_NT) {
+        int e = e0;
+        while (e + 1 < e1 && T >= wn[e + 1].ts) e++;
+        const int      t = T - wn[e].ts, ws = wn[e].wstride, sw = wn[e].sw, slot = wn[e].slot, idx0 = wn[e].idx0;
+        const uint8_t *win = c->planes + wn[e].off;
         uint64_t       kb = ~0ull;
         if (qs) {
             const int ng = (sw + 3) >> 2;
@@ -1080,100 +1080,6 @@ typedef struct me_hme_geom {
     int              bstride, bw, bh, ox, oy, pad_w, pad_h;
 } me_hme_geom;
 
-/* the (up to 4) region searches of one HME level: slot = rh*2 + rw; every array is indexed with compile-time
- * constants only so that the whole batch lives in registers */
-typedef struct me_hme_batch {
-    int      valid[4];
-    int16_t  ox[4], oy[4], w[4], h[4]; /* search area before clipping, relative to the block origin */
-    int16_t  xc[4], yc[4];             /* in: previous centre; out: best position (scaled) */
-    uint64_t sad[4];                   /* out */
-} me_hme_batch;
-
-/* One HME level: window placement (hme_level0/1/2 of Codec/EbMotionEstimation.c), LDS staging, exhaustive search,
- * scaling.  The reference windows are staged in the scratch as a work list of (region, band of search rows); as many
- * entries as fit (at most 4) form a batch = one global-load phase + one search phase.  A region too tall for the
- * scratch is split into bands; the 64-bit key carries the raster index inside the region, so the minimum over all
- * bands is exactly the reference's first minimum in raster order. */
-#ifdef SVT_HOST_EMU
-static inline
-#else
-__device__ __forceinline__
-#endif
-void me_hme_multi(const me_ctx_t *c, int tid_, const me_hme_geom *g, me_hme_batch *B, int floor16, int scale, int *parity) {
-    int tid = tid_;
-    (void)tid;
-    const int span = 2 * (g->bh - 1);
-    int16_t   cox[4], coy[4], cw[4], ch[4];
-    int       wst[4], wnd[4];
-    _Pragma("unroll") for (int r = 0; r < 4; r++) {
-        int16_t ox = B->ox[r], oy = B->oy[r], w = B->w[r], h = B->h[r];
-        wst[r] = 4; wnd[r] = 0;
-        if (B->valid[r]) {
-            me_clip_area(g->ox, &ox, &w, g->pad_w, g->ref->width);
-            me_clip_area(g->oy, &oy, &h, g->pad_h, g->ref->height);
-            if (floor16 && (w & 15) != 0) w = (int16_t)((w >> 4) << 4);
-            if (w > 0 && h > 0) {
-                int wbytes = w + g->bw + 3;
-                int ws     = ((wbytes + 3) & ~3) + 4;
-                if (((ws >> 2) & 1) == 0) ws += 4;
-                wst[r] = ws; wnd[r] = (wbytes + 3) >> 2;
-            } else { w = 0; h = 0; }
-        } else { w = 0; h = 0; }
-        cox[r] = ox; coy[r] = oy; cw[r] = w; ch[r] = h;
-    }
-    uint64_t *keys = c->st->hme_keys[*parity];
-    *parity ^= 1;
-    int r = 0, y = 0, first = 1;
-    for (;;) {
-        me_hme_win wn[4];
-        int        bytes = 0, ne = 0, full = 0;
-        _Pragma("unroll") for (int e = 0; e < 4; e++) {
-            wn[e].off = 0; wn[e].wstride = 4; wn[e].nd = 0; wn[e].rows = 0; wn[e].sw = 0; wn[e].sh = 0;
-            wn[e].gx = 0; wn[e].gy = 0; wn[e].slot = 0; wn[e].idx0 = 0;
-            while (r < 4 && y >= ME_SEL4(ch, r)) { r++; y = 0; }
-            if (r < 4 && !full) {
-                const int ws = ME_SEL4(wst, r), h = ME_SEL4(ch, r), sw = ME_SEL4(cw, r);
-                int       nr = (c->L.scratch_bytes - bytes) / ws - span;
-                if (nr > h - y) nr = h - y;
-                if (nr >= 1) {
-                    wn[e].off = bytes; wn[e].wstride = ws; wn[e].nd = ME_SEL4(wnd, r); wn[e].rows = nr + span;
-                    wn[e].sw = sw; wn[e].sh = nr;
-                    wn[e].gx = g->ox + ME_SEL4(cox, r); wn[e].gy = g->oy + ME_SEL4(coy, r) + y;
-                    wn[e].slot = r; wn[e].idx0 = y * sw;
-                    bytes += ws * (nr + span); y += nr; ne++;
-                } else {
-                    full = 1;
-                    if (bytes == 0) { r++; y = 0; } /* cannot happen with the scratch sizes of me_lds_layout_compute */
-                }
-            }
-        }
-        if (ne == 0) break;
-        ME_SUBMARK_BEGIN();
-        ME_PHASE(if (first && tid < 4) keys[tid] = ~0ull; ph_hme_load_multi(c, tid, g->ref, wn));
-        first = 0;
-        ME_SUBMARK(14);
-        ME_PHASE(ph_hme_search_multi(c, tid, g->blk, g->bstride, g->bw, g->bh, wn, keys));
-        ME_SUBMARK(15);
-    }
-    _Pragma("unroll") for (int q = 0; q < 4; q++) {
-        if (B->valid[q]) {
-            uint64_t sad = 0xffffff;
-            int16_t  x = B->xc[q], yv = B->yc[q];
-            if (cw[q] > 0 && !first) {
-                uint64_t k = keys[q];
-                if (k != ~0ull) {
-                    uint32_t idx = (uint32_t)k, sd = (uint32_t)(k >> 32);
-                    if (sd < sad) { sad = sd; x = (int16_t)(idx % (uint32_t)cw[q]); yv = (int16_t)(idx / (uint32_t)cw[q]); }
-                }
-            }
-            B->sad[q] = sad * 2;
-            x = (int16_t)(x + cox[q]); x = (int16_t)(x * scale);
-            yv = (int16_t)(yv + coy[q]); yv = (int16_t)(yv * scale);
-            B->xc[q] = x; B->yc[q] = yv;
-        }
-    }
-}
-
 SVT_DEV int16_t me_hme_round_w(int16_t w) { return (int16_t)((w < 8) ? 8 : (w & 7) ? w + (w - ((w >> 3) << 3)) : w); }
 
 /* Codec/EbDefinitions.h:989-1005 */
@@ -1184,6 +1090,171 @@ __attribute__((unused)) static
     const int32_t me_hme_l0_mult[6][6] = {{100, 0, 0, 0, 0, 0},       {100, 100, 0, 0, 0, 0},
                                           {100, 100, 100, 0, 0, 0},   {200, 140, 100, 70, 0, 0},
                                           {350, 200, 100, 100, 100, 0}, {525, 350, 200, 100, 100, 100}};
+
+/* geometry of an HME level for one reference list (hme_level0/1/2 of Codec/EbMotionEstimation.c) */
+SVT_DEV void me_hme_geom_of(const me_ctx_t *c, int list, int lvl, me_hme_geom *g) {
+    if (lvl == 0) {
+        g->ref = &c->pic->ref[list].sixteenth; g->blk = c->st->sixteenth_sb; g->bstride = 16; g->bw = c->sb_w >> 2; g->bh = (c->sb_h >> 2) >> 1;
+        g->ox = (int16_t)(c->sb_x >> 2); g->oy = (int16_t)(c->sb_y >> 2);
+    } else if (lvl == 1) {
+        g->ref = &c->pic->ref[list].quarter; g->blk = c->quarter_sb; g->bstride = 64; g->bw = c->sb_w >> 1; g->bh = (c->sb_h >> 1) >> 1;
+        g->ox = (int16_t)(c->sb_x >> 1); g->oy = (int16_t)(c->sb_y >> 1);
+    } else {
+        g->ref = &c->pic->ref[list].full; g->blk = c->src; g->bstride = 2 * ME_SB; g->bw = c->sb_w; g->bh = c->sb_h >> 1;
+        g->ox = (int16_t)c->sb_x; g->oy = (int16_t)c->sb_y;
+    }
+    g->pad_w = lvl == 2 ? ME_SB - 1 : g->ref->origin_x - 1;
+    g->pad_h = lvl == 2 ? ME_SB - 1 : g->ref->origin_y - 1;
+}
+
+/* Plan one HME level (run by ONE thread): place the search areas of the level's regions (slot = rh*2 + rw), clip them,
+ * and cut them into the work list of (region, band of search rows) windows.  Consecutive windows that fit the scratch
+ * together form a batch = one global-load phase + one search phase; a region too tall for the scratch is split into
+ * bands -- the 64-bit key carries the raster index inside the region, so the minimum over all bands is exactly the
+ * reference's first minimum in raster order.  [quirk] region-row counter semantics: see me_sb_run. */
+SVT_DEV void me_hme_plan_level(const me_ctx_t *c, int list, int lvl, int16_t xsc, int16_t ysc, int first) {
+    const svt_me_params *p  = c->p;
+    me_state_t          *st = c->st;
+    const int            NW = p->number_hme_search_region_in_width, NH = p->number_hme_search_region_in_height;
+    me_hme_geom          g;
+    me_hme_geom_of(c, list, lvl, &g);
+    const int mult   = me_hme_l0_mult[p->hierarchical_levels][p->temporal_layer_index];
+    const int single = lvl == 0 && p->single_hme_quadrant && !p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag;
+    const int span   = 2 * (g.bh - 1);
+    int       ne = 0, nb = 0, bytes = 0, tl = 0, ts = 0;
+    if (first && st->hme_rh < NH) { /* [quirk] centres are only initialised while the reference's row counter is below NH */
+        for (int k = 0; k < 4; k++)
+            if ((k & 1) < NW && (k >> 1) < NH && (k >> 1) >= st->hme_rh) {
+                st->hme_x[0][k] = (int16_t)(xsc >> 2); st->hme_y[0][k] = (int16_t)(ysc >> 2);
+                st->hme_x[1][k] = (int16_t)(xsc >> 1); st->hme_y[1][k] = (int16_t)(ysc >> 1);
+                st->hme_x[2][k] = xsc; st->hme_y[2][k] = ysc;
+            }
+        st->hme_rh = NH;
+    }
+    st->hme_rh = single ? 0 : NH;
+    st->hme_bstart[0] = 0;
+    for (int k = 0; k < 4; k++) {
+        const int rw = k & 1, rh = k >> 1;
+        st->hme_keys[k] = ~0ull;
+        st->hme_cw[k] = 0; st->hme_ch[k] = 0; st->hme_cox[k] = 0; st->hme_coy[k] = 0;
+        if (single ? k != 0 : (rw >= NW || rh >= NH)) continue;
+        int16_t w, h, ox, oy;
+        if (lvl == 0) {
+            if (single) {
+                w  = (int16_t)((p->hme_level0_total_search_area_width * mult) / 100);
+                h  = (int16_t)((p->hme_level0_total_search_area_height * mult) / 100);
+                ox = (int16_t)(-(int16_t)(w >> 1) + (int16_t)(xsc >> 2));
+                oy = (int16_t)(-(int16_t)(h >> 1) + (int16_t)(ysc >> 2));
+            } else {
+                w = (int16_t)((p->hme_level0_search_area_in_width_array[rw] * mult) / 100);
+                h = (int16_t)((p->hme_level0_search_area_in_height_array[rh] * mult) / 100);
+                int16_t ddx = (int16_t)(xsc >> 2), ddy = (int16_t)(ysc >> 2);
+                if (rw > 0) ddx = (int16_t)(ddx + (int16_t)((p->hme_level0_search_area_in_width_array[0] * mult) / 100));
+                if (rh > 0) ddy = (int16_t)(ddy + (int16_t)((p->hme_level0_search_area_in_height_array[0] * mult) / 100));
+                ox = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_width * mult) / 100) >> 1) + ddx);
+                oy = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_height * mult) / 100) >> 1) + ddy);
+            }
+        } else if (lvl == 1) {
+            w  = me_hme_round_w((int16_t)p->hme_level1_search_area_in_width_array[rw]);
+            h  = (int16_t)p->hme_level1_search_area_in_height_array[rh];
+            ox = (int16_t)(-(w >> 1) + (int16_t)(st->hme_x[0][k] >> 1));
+            oy = (int16_t)(-(h >> 1) + (int16_t)(st->hme_y[0][k] >> 1));
+        } else {
+            w  = me_hme_round_w((int16_t)p->hme_level2_search_area_in_width_array[rw]);
+            h  = (int16_t)p->hme_level2_search_area_in_height_array[rh];
+            ox = (int16_t)(-(w >> 1) + st->hme_x[1][k]);
+            oy = (int16_t)(-(h >> 1) + st->hme_y[1][k]);
+        }
+        me_clip_area(g.ox, &ox, &w, g.pad_w, g.ref->width);
+        me_clip_area(g.oy, &oy, &h, g.pad_h, g.ref->height);
+        if (single && (w & 15) != 0) w = (int16_t)((w >> 4) << 4);
+        st->hme_cox[k] = ox; st->hme_coy[k] = oy; /* kept even when nothing is searched: the centre still moves by them */
+        if (w <= 0 || h <= 0) continue;
+        st->hme_cw[k] = w; st->hme_ch[k] = h;
+        const int wbytes = w + g.bw + 3;
+        int       ws     = ((wbytes + 3) & ~3) + 4;
+        if (((ws >> 2) & 1) == 0) ws += 4;
+        const int ng = (g.bw & 3) == 0 ? (w + 3) >> 2 : w;
+        for (int y = 0; y < h && ne < ME_HME_MAX_WIN;) {
+            int nr = (c->L.scratch_bytes - bytes) / ws - span;
+            if (nr < 1 && bytes > 0) { /* close the batch and retry with an empty scratch */
+                st->hme_bstart[++nb] = ne; bytes = 0; tl = 0; ts = 0;
+                continue;
+            }
+            if (nr < 1) break; /* cannot happen with the scratch sizes of me_lds_layout_compute */
+            if (nr > h - y) nr = h - y;
+            me_hme_win *wn = &st->hme_win[ne++];
+            wn->off = bytes; wn->wstride = ws; wn->nd = (wbytes + 3) >> 2; wn->rows = nr + span; wn->sw = w; wn->sh = nr;
+            wn->gx = g.ox + ox; wn->gy = g.oy + oy + y; wn->slot = k; wn->idx0 = y * w; wn->tl = tl; wn->ts = ts;
+            tl += wn->nd * wn->rows; ts += ng * nr;
+            bytes += ws * (nr + span); y += nr;
+        }
+    }
+    if (ne > st->hme_bstart[nb]) st->hme_bstart[++nb] = ne;
+    st->hme_nbatch = nb;
+}
+
+/* results of one HME level (run by ONE thread): position scaling and SAD*2 as in hme_level0/1/2 */
+SVT_DEV void me_hme_finish_level(const me_ctx_t *c, int lvl) {
+    const svt_me_params *p  = c->p;
+    me_state_t          *st = c->st;
+    const int            NW = p->number_hme_search_region_in_width, NH = p->number_hme_search_region_in_height;
+    const int single = lvl == 0 && p->single_hme_quadrant && !p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag;
+    const int scale  = 4 >> lvl;
+    for (int k = 0; k < 4; k++) {
+        if (single ? k != 0 : ((k & 1) >= NW || (k >> 1) >= NH)) continue;
+        uint64_t sad = 0xffffff;
+        int16_t  x = st->hme_x[lvl][k], y = st->hme_y[lvl][k];
+        if (st->hme_cw[k] > 0) {
+            const uint64_t key = st->hme_keys[k];
+            if (key != ~0ull) {
+                const uint32_t idx = (uint32_t)key, sd = (uint32_t)(key >> 32);
+                if (sd < sad) { sad = sd; x = (int16_t)(idx % (uint32_t)st->hme_cw[k]); y = (int16_t)(idx / (uint32_t)st->hme_cw[k]); }
+            }
+        }
+        st->hme_sad[lvl][k] = sad * 2;
+        x = (int16_t)(x + st->hme_cox[k]); x = (int16_t)(x * scale);
+        y = (int16_t)(y + st->hme_coy[k]); y = (int16_t)(y * scale);
+        st->hme_x[lvl][k] = x; st->hme_y[lvl][k] = y;
+    }
+}
+
+/* pick the search centre from the last enabled level (run by ONE thread), Codec/EbMotionEstimation.c:4880-4980 */
+SVT_DEV void me_hme_select(const me_ctx_t *c, int list) {
+    const svt_me_params *p  = c->p;
+    me_state_t          *st = c->st;
+    const int            NW = p->number_hme_search_region_in_width, NH = p->number_hme_search_region_in_height;
+    const int            lvl = p->enable_hme_level_2_flag ? 2 : p->enable_hme_level_1_flag ? 1 : 0;
+    if (!p->enable_hme_level_0_flag && lvl == 0) return; /* no level ran: the previous result stays */
+    int16_t  xc = st->hme_x[lvl][0], yc = st->hme_y[lvl][0];
+    uint64_t sd = st->hme_sad[lvl][0];
+    if (!(lvl == 0 && p->single_hme_quadrant)) {
+        for (int k = 1; k < 4; k++) {
+            if ((k & 1) >= NW || (k >> 1) >= NH) continue;
+            if (st->hme_sad[lvl][k] < sd) { xc = st->hme_x[lvl][k]; yc = st->hme_y[lvl][k]; sd = st->hme_sad[lvl][k]; }
+        }
+        st->hme_rh = NH;
+    }
+    if (lvl == 2) {
+        /* [quirk] the reference sorts with the index pair (q / NW, q % NW) applied to its [rw][rh] arrays (:4943-4975):
+         * element q is region rw = q / NW, rh = q % NW, i.e. slot (q % NW) * 2 + q / NW */
+        const int tot = NH * NW;
+        if (p->same_ref_poc && list == 1 && tot > 1) {
+            for (int q = 0; q < tot - 1; q++)
+                for (int n = q + 1; n < tot; n++) {
+                    const int kq = (q % NW) * 2 + q / NW, kn = (n % NW) * 2 + n / NW;
+                    if (st->hme_sad[2][kq] > st->hme_sad[2][kn]) {
+                        const int16_t  tx = st->hme_x[2][kq], ty = st->hme_y[2][kq];
+                        const uint64_t td = st->hme_sad[2][kq];
+                        st->hme_x[2][kq] = st->hme_x[2][kn]; st->hme_y[2][kq] = st->hme_y[2][kn]; st->hme_sad[2][kq] = st->hme_sad[2][kn];
+                        st->hme_x[2][kn] = tx; st->hme_y[2][kn] = ty; st->hme_sad[2][kn] = td;
+                    }
+                }
+            xc = st->hme_x[2][2]; yc = st->hme_y[2][2]; /* element [0][1] of the reference's arrays: rw = 0, rh = 1 */
+        }
+    }
+    st->hme_xc = xc; st->hme_yc = yc;
+}
 
 #ifdef SVT_HOST_EMU
 static inline
@@ -1197,12 +1268,8 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
     me_state_t          *st = c->st;
     const int            nlist = p->num_ref_lists;
     const int            NW = p->number_hme_search_region_in_width, NH = p->number_hme_search_region_in_height;
-    int16_t  xl0[4] = {0, 0, 0, 0}, yl0[4] = {0, 0, 0, 0}, xl1[4] = {0, 0, 0, 0}, yl1[4] = {0, 0, 0, 0};
-    int16_t  xl2[4] = {0, 0, 0, 0}, yl2[4] = {0, 0, 0, 0};
-    uint64_t sl0[4] = {0, 0, 0, 0}, sl1[4] = {0, 0, 0, 0}, sl2[4] = {0, 0, 0, 0};
-    int      rh = 0, hme_parity = 0;
 #define ME_PRED0_REGS (c->pred0 + tid)
-    int16_t  x_hme_c = 0, y_hme_c = 0, xsc = 0, ysc = 0;
+    int16_t  xsc = 0, ysc = 0;
 #ifndef SVT_HOST_EMU
     unsigned long long mark_t_ = c->prof ? __builtin_amdgcn_s_memtime() : 0;
 #endif
@@ -1254,122 +1321,32 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
             ME_MARK(1);
             /* ---- HME ---- */
             if (p->enable_hme_flag && c->sb_h == ME_SB) {
-                /* region (rw, rh) lives in slot rh*2 + rw of the arrays below; all slot indices are compile-time constants.
-                 * [quirk] the reference's region counters are not reset between the lists, so the centres are only
-                 * initialised on the first visit (rh still 0) */
-#define ME_FOR_SLOTS(...) _Pragma("unroll") for (int rh_ = 0; rh_ < 2; rh_++) _Pragma("unroll") for (int rw_ = 0; rw_ < 2; rw_++) \
-        if (rh_ < NH && rw_ < NW) { const int k_ = rh_ * 2 + rw_; (void)k_; __VA_ARGS__ }
-                ME_FOR_SLOTS(if (rh_ >= rh) {
-                    xl0[k_] = (int16_t)(xsc >> 2); yl0[k_] = (int16_t)(ysc >> 2);
-                    xl1[k_] = (int16_t)(xsc >> 1); yl1[k_] = (int16_t)(ysc >> 1);
-                    xl2[k_] = xsc; yl2[k_] = ysc;
-                });
-                if (rh < NH) rh = NH;
-                const int mult = me_hme_l0_mult[p->hierarchical_levels][p->temporal_layer_index];
-                /* the three levels share one instance of the search code (instruction-cache footprint) */
+                /* The control flow of the hierarchical search (area placement, clipping, batching, scaling, the choice
+                 * between the regions) runs on one thread and lives in LDS; the 256 threads only execute the load and
+                 * search phases of each batch of windows.  The three levels share one instance of that code. */
+                const int last_lvl = p->enable_hme_level_2_flag ? 2 : p->enable_hme_level_1_flag ? 1 : 0;
+                int       first = 1;
                 for (int lvl = 0; lvl < 3; lvl++) {
                     if (!(lvl == 0 ? p->enable_hme_level_0_flag : lvl == 1 ? p->enable_hme_level_1_flag : p->enable_hme_level_2_flag)) continue;
-                    me_hme_geom  g;
-                    me_hme_batch B;
-                    int          floor16 = 0, scale = 4 >> lvl;
-                    _Pragma("unroll") for (int k = 0; k < 4; k++) { B.valid[k] = 0; B.ox[k] = B.oy[k] = B.w[k] = B.h[k] = 0; B.sad[k] = 0; }
-                    if (lvl == 0) {
-                        g.ref = r16; g.blk = st->sixteenth_sb; g.bstride = 16; g.bw = c->sb_w >> 2; g.bh = (c->sb_h >> 2) >> 1;
-                        g.ox = (int16_t)(c->sb_x >> 2); g.oy = (int16_t)(c->sb_y >> 2); g.pad_w = r16->origin_x - 1; g.pad_h = r16->origin_y - 1;
-                        _Pragma("unroll") for (int k = 0; k < 4; k++) { B.xc[k] = xl0[k]; B.yc[k] = yl0[k]; }
-                        if (p->single_hme_quadrant && !p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag) {
-                            rh = 0;
-                            floor16 = 1;
-                            int16_t w = (int16_t)((p->hme_level0_total_search_area_width * mult) / 100);
-                            int16_t h = (int16_t)((p->hme_level0_total_search_area_height * mult) / 100);
-                            B.valid[0] = 1; B.w[0] = w; B.h[0] = h;
-                            B.ox[0] = (int16_t)(-(int16_t)(w >> 1) + (int16_t)(xsc >> 2));
-                            B.oy[0] = (int16_t)(-(int16_t)(h >> 1) + (int16_t)(ysc >> 2));
-                        } else {
-                            ME_FOR_SLOTS({
-                                int16_t w = (int16_t)((p->hme_level0_search_area_in_width_array[rw_] * mult) / 100);
-                                int16_t h = (int16_t)((p->hme_level0_search_area_in_height_array[rh_] * mult) / 100);
-                                int16_t ddx = (int16_t)(xsc >> 2), ddy = (int16_t)(ysc >> 2);
-                                if (rw_ > 0) ddx = (int16_t)(ddx + (int16_t)((p->hme_level0_search_area_in_width_array[0] * mult) / 100));
-                                if (rh_ > 0) ddy = (int16_t)(ddy + (int16_t)((p->hme_level0_search_area_in_height_array[0] * mult) / 100));
-                                B.valid[k_] = 1; B.w[k_] = w; B.h[k_] = h;
-                                B.ox[k_] = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_width * mult) / 100) >> 1) + ddx);
-                                B.oy[k_] = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_height * mult) / 100) >> 1) + ddy);
-                            });
-                            rh = NH;
-                        }
-                    } else if (lvl == 1) {
-                        g.ref = rq; g.blk = c->quarter_sb; g.bstride = 64; g.bw = c->sb_w >> 1; g.bh = (c->sb_h >> 1) >> 1;
-                        g.ox = (int16_t)(c->sb_x >> 1); g.oy = (int16_t)(c->sb_y >> 1); g.pad_w = rq->origin_x - 1; g.pad_h = rq->origin_y - 1;
-                        _Pragma("unroll") for (int k = 0; k < 4; k++) { B.xc[k] = xl1[k]; B.yc[k] = yl1[k]; }
-                        ME_FOR_SLOTS({
-                            int16_t w = me_hme_round_w((int16_t)p->hme_level1_search_area_in_width_array[rw_]);
-                            int16_t h = (int16_t)p->hme_level1_search_area_in_height_array[rh_];
-                            B.valid[k_] = 1; B.w[k_] = w; B.h[k_] = h;
-                            B.ox[k_] = (int16_t)(-(w >> 1) + (int16_t)(xl0[k_] >> 1));
-                            B.oy[k_] = (int16_t)(-(h >> 1) + (int16_t)(yl0[k_] >> 1));
-                        });
-                        rh = NH;
-                    } else {
-                        g.ref = rf; g.blk = c->src; g.bstride = 2 * ME_SB; g.bw = c->sb_w; g.bh = c->sb_h >> 1;
-                        g.ox = (int16_t)c->sb_x; g.oy = (int16_t)c->sb_y; g.pad_w = ME_SB - 1; g.pad_h = ME_SB - 1;
-                        _Pragma("unroll") for (int k = 0; k < 4; k++) { B.xc[k] = xl2[k]; B.yc[k] = yl2[k]; }
-                        ME_FOR_SLOTS({
-                            int16_t w = me_hme_round_w((int16_t)p->hme_level2_search_area_in_width_array[rw_]);
-                            int16_t h = (int16_t)p->hme_level2_search_area_in_height_array[rh_];
-                            B.valid[k_] = 1; B.w[k_] = w; B.h[k_] = h;
-                            B.ox[k_] = (int16_t)(-(w >> 1) + xl1[k_]);
-                            B.oy[k_] = (int16_t)(-(h >> 1) + yl1[k_]);
-                        });
-                        rh = NH;
+                    ME_UNIFORM_WRITE(me_hme_plan_level(c, list, lvl, xsc, ysc, first));
+                    first = 0;
+                    me_hme_geom g;
+                    me_hme_geom_of(c, list, lvl, &g);
+                    const int nbatch = ME_UNI(st->hme_nbatch);
+                    for (int b = 0; b < nbatch; b++) {
+                        const int         e0 = ME_UNI(st->hme_bstart[b]), e1 = ME_UNI(st->hme_bstart[b + 1]);
+                        const me_hme_win *wl = &st->hme_win[e1 - 1];
+                        const int         ntl = ME_UNI(wl->tl + wl->nd * wl->rows);
+                        const int         nts = ME_UNI(wl->ts + ((g.bw & 3) == 0 ? (wl->sw + 3) >> 2 : wl->sw) * wl->sh);
+                        ME_SUBMARK_BEGIN();
+                        ME_PHASE(ph_hme_load_multi(c, tid, g.ref, st->hme_win, e0, e1, ntl));
+                        ME_SUBMARK(14);
+                        ME_PHASE(ph_hme_search_multi(c, tid, g.blk, g.bstride, g.bw, g.bh, st->hme_win, e0, e1, nts, st->hme_keys));
+                        ME_SUBMARK(15);
                     }
-                    me_hme_multi(c, tid, &g, &B, floor16, scale, &hme_parity);
-                    _Pragma("unroll") for (int k = 0; k < 4; k++) {
-                        if (B.valid[k]) {
-                            if (lvl == 0) { sl0[k] = B.sad[k]; xl0[k] = B.xc[k]; yl0[k] = B.yc[k]; }
-                            else if (lvl == 1) { sl1[k] = B.sad[k]; xl1[k] = B.xc[k]; yl1[k] = B.yc[k]; }
-                            else { sl2[k] = B.sad[k]; xl2[k] = B.xc[k]; yl2[k] = B.yc[k]; }
-                        }
-                    }
+                    ME_UNIFORM_WRITE(me_hme_finish_level(c, lvl); if (lvl == last_lvl) me_hme_select(c, list));
                 }
-                uint64_t hme_sad = 0;
-                if (p->enable_hme_level_0_flag && !p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag) {
-                    x_hme_c = xl0[0]; y_hme_c = yl0[0]; hme_sad = sl0[0];
-                    if (!p->single_hme_quadrant) {
-                        ME_FOR_SLOTS(if (k_ != 0 && sl0[k_] < hme_sad) { x_hme_c = xl0[k_]; y_hme_c = yl0[k_]; hme_sad = sl0[k_]; });
-                        rh = NH;
-                    }
-                }
-                if (p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag) {
-                    x_hme_c = xl1[0]; y_hme_c = yl1[0]; hme_sad = sl1[0];
-                    ME_FOR_SLOTS(if (k_ != 0 && sl1[k_] < hme_sad) { x_hme_c = xl1[k_]; y_hme_c = yl1[k_]; hme_sad = sl1[k_]; });
-                }
-                if (p->enable_hme_level_2_flag) {
-                    x_hme_c = xl2[0]; y_hme_c = yl2[0]; hme_sad = sl2[0];
-                    ME_FOR_SLOTS(if (k_ != 0 && sl2[k_] < hme_sad) { x_hme_c = xl2[k_]; y_hme_c = yl2[k_]; hme_sad = sl2[k_]; });
-                    /* [quirk] the reference sorts with the index pair (q / NW, q % NW) applied to its [rw][rh] arrays
-                     * (:4943-4975): element q is region rw = q / NW, rh = q % NW, i.e. slot (q % NW) * 2 + q / NW */
-                    const int tot = NH * NW;
-                    if (p->same_ref_poc && list == 1 && tot > 1) {
-                        _Pragma("unroll") for (int q = 0; q < 3; q++)
-                            _Pragma("unroll") for (int n = q + 1; n < 4; n++)
-                                if (n < tot) {
-                                    const int kq = (q % NW) * 2 + q / NW, kn = (n % NW) * 2 + n / NW;
-                                    uint64_t  sq = ME_SEL4(sl2, kq), sn = ME_SEL4(sl2, kn);
-                                    if (sq > sn) {
-                                        int16_t xq = ME_SEL4(xl2, kq), yq = ME_SEL4(yl2, kq), xn = ME_SEL4(xl2, kn), yn = ME_SEL4(yl2, kn);
-                                        _Pragma("unroll") for (int k = 0; k < 4; k++) {
-                                            if (k == kq) { xl2[k] = xn; yl2[k] = yn; sl2[k] = sn; }
-                                            else if (k == kn) { xl2[k] = xq; yl2[k] = yq; sl2[k] = sq; }
-                                        }
-                                    }
-                                }
-                        /* element [0][1] of the reference's arrays: rw = 0, rh = 1 */
-                        x_hme_c = xl2[2]; y_hme_c = yl2[2];
-                    }
-                }
-#undef ME_FOR_SLOTS
-                xsc = x_hme_c; ysc = y_hme_c;
+                xsc = (int16_t)ME_UNI(st->hme_xc); ysc = (int16_t)ME_UNI(st->hme_yc);
             }
             ME_MARK(2);
         } else {
