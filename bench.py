@@ -66,8 +66,15 @@ def main():
     import svt_testlib as T
     B = T.B
     lib = B.load()
-    ctx = C.c_void_p()
-    B.check(lib.svt_hip_ctx_create(C.byref(ctx), local_rank))
+    # one context per pipeline stage, each on its own torch stream so that torch events can bracket that stage's
+    # launches inside the timed region
+    streams = [torch.cuda.Stream(device=local_rank) for _ in range(3)]
+    ctxs = []
+    for st_ in streams:
+        c_ = C.c_void_p()
+        B.check(lib.svt_hip_ctx_create_on_stream(C.byref(c_), local_rank, C.c_void_p(st_.cuda_stream)))
+        ctxs.append(c_)
+    ctx = ctxs[0]
 
     Wd, Hd = args.width, args.height
     nsb = T.n_sb(Wd, Hd)
@@ -113,9 +120,7 @@ def main():
         return i - span, i + span
 
     # ---- stage 1: motion estimation, one batched launch per temporal layer (parameters differ per layer) ----
-    ctx_me, ctx_tq, ctx_lf = ctx, C.c_void_p(), C.c_void_p()
-    B.check(lib.svt_hip_ctx_create(C.byref(ctx_tq), local_rank))
-    B.check(lib.svt_hip_ctx_create(C.byref(ctx_lf), local_rank))
+    ctx_me, ctx_tq, ctx_lf = ctxs
     me_launches = []
     for layer in range(5):
         idx = [i for i in range(1, MINIGOP + 1) if LAYER[i - 1] == layer]
@@ -211,13 +216,24 @@ def main():
     def run_lf():
         B.check(lib.svt_hip_lf_batch_device(ctx_lf, MINIGOP, lf_desc, lfm_ptrs, lfs, C.byref(thr), mrs, mcs, 0))
 
-    def step():
+    ev = []  # (stage, start event, stop event) of every stage of every timed step
+
+    def staged(k, fn, record):
+        if not record:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(streams[k])
+        fn()
+        e1.record(streams[k])
+        ev.append((k, e0, e1))
+
+    def step(record=False):
         # the three stages work on different pictures of the pipeline (as the reference's ME / EncDec threads do), so
         # they are issued on three streams; deblocking of a step's pictures is ordered after their reconstruction
-        run_me()
-        run_tq()
-        B.check(lib.svt_hip_ctx_synchronize(ctx_tq))
-        run_lf()
+        staged(0, run_me, record)
+        staged(1, run_tq, record)
+        streams[2].wait_stream(streams[1])
+        staged(2, run_lf, record)
 
     def sync():
         for c_ in (ctx_me, ctx_tq, ctx_lf):
@@ -231,7 +247,7 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(record=True)
     sync()
     if world > 1:
         dist.barrier()
@@ -241,33 +257,26 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # ---- per-kernel timing with HIP events recorded on each context's own stream, outside the timed region ----
-    def timed(ctx_, fn, reps=3):
-        tot = 0.0
-        for _ in range(reps):
-            fn()
-            B.check(lib.svt_hip_ctx_synchronize(ctx_))
-            tot += lib.svt_hip_last_kernel_ms(ctx_)
-        return tot / reps
-
+    # ---- per-kernel time: HIP events on each stage's own stream, bracketing that stage's launches of every timed
+    # step (so it includes whatever slowdown the overlap with the other stages causes, like a rocprofv3 trace) ----
+    stage_ms = [0.0, 0.0, 0.0]
+    for k, e0, e1 in ev:
+        stage_ms[k] += e0.elapsed_time(e1)
+    me_ms, tq_ms, lf_ms = [v / args.steps for v in stage_ms]
     l1_on = bool(me_launches[0][4].enable_hme_level_1_flag)
-    me_ms = 0.0
-    for n, cur, r0, r1, p, res in me_launches:
-        me_ms += timed(ctx_me, lambda: B.check(lib.svt_hip_me_batch_device(ctx_me, n, cur, r0, r1, C.byref(p), res, None)))
     me_bytes = MINIGOP * algorithmic_bytes_me(Wd, Hd, 2, l1_on)
-    s0, p0, r0_ = tq_pics[0]
-    tq_ms = MINIGOP * timed(ctx_tq, lambda: B.check(lib.svt_hip_tq_batch_device(
-        ctx_tq, C.c_void_p(s0.data_ptr()), C.c_void_p(p0.data_ptr()), C.c_void_p(r0_.data_ptr()), C.c_void_p(d_blocks.data_ptr()), cnt_c,
-        C.c_void_p(d_qt.data_ptr()), C.c_void_p(d_iscan.data_ptr()), C.c_void_p(d_q.data_ptr()), C.c_void_p(d_dq.data_ptr()),
-        C.c_void_p(d_eob.data_ptr()))))
     L = Wd * Hd
-    tq_bytes = MINIGOP * int(7.5 * L)                      # src 1.5L + pred 1.5L + qcoeff 3L + recon 1.5L
-    lf_ms = timed(ctx_lf, run_lf)
+    tq_bytes = MINIGOP * int(10.5 * L)                     # src 1.5L + pred 1.5L + qcoeff 3L + dqcoeff 3L + recon 1.5L
     lf_bytes = MINIGOP * (3 * L + 160 * nsb)               # recon read + write (3L) + masks
     achieved = me_bytes / (me_ms * 1e-3) / 1e9  # GB/s
 
     if rank != 0:
         return
+    # HBM traffic of the dominant kernel per step, from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.md)
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tj) and (Wd, Hd) == (W4K, H4K):
+        traffic = json.load(open(tj)).get("svt_me_sb_kernel", {}).get("bytes_per_step")
     fps = MINIGOP * args.steps * world / dt
     out = {
         "metric": "encoded frames/sec (block-level DSP hot path: ME + DCT/quant/recon + deblock), 4Kp60 yuv420p enc-mode 8",
@@ -288,7 +297,8 @@ def main():
                    "stages": ["motion_estimation", "transform_quant_recon", "deblocking"], "pictures_per_step": MINIGOP,
                    "parallelism": f"gop-shard x{world}"},
         "roofline": {"bound": "hbm", "kernel": "svt_me_sb_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
-                     "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+                     "launches_per_step": len(me_launches),
                      "kernel_ms_per_step": round(me_ms, 3), "algorithmic_bytes_per_step": me_bytes},
         "kernels": {k: {"ms_per_step": round(ms, 3), "algorithmic_bytes_per_step": b, "GB_per_s": round(b / (ms * 1e-3) / 1e9, 2),
                         "frac_of_8TBps": round(b / (ms * 1e-3) / 8e12, 5)}
@@ -297,23 +307,43 @@ def main():
     }
     if not args.no_cpu_baseline:
         # oracle (scalar C restatement of the reference C path), single thread, on a bounded sample of the same
-        # workload: whole B pictures of the mini-GOP until >= 10 s of CPU time has been spent
-        n_done, cdt, used = 0, 0.0, []
-        for i in (8, 4, 2, 1, 12, 6, 3, 5):
+        # workload: whole pictures of the mini-GOP through each of the three stages (about 10-20 s of CPU time)
+        orc = T.oracle()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        n_me, t_me, used = 0, 0.0, []
+        for i in (8, 4, 2, 1, 12, 6):
             l = LAYER[i - 1]
             a, b = refs(i)
             cur, r0, r1 = T.PaPic(frames[i]), T.PaPic(frames[a]), T.PaPic(frames[b])
             p = MC.preset(preset_name, 2, l, 4)
             t1 = time.perf_counter()
             T.oracle_me_picture(cur, r0, r1, p)
-            cdt += time.perf_counter() - t1
-            n_done += 1
+            t_me += time.perf_counter() - t1
+            n_me += 1
             used.append(i)
-            if cdt >= 10.0:
+            if t_me >= 6.0:
                 break
-        out["cpu_baseline"] = {"value": round(n_done / cdt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
-                               "sample": f"oracle ME (scalar C restatement, gcc -O2) on {n_done} whole {Wd}x{Hd} B pictures "
-                                         f"(mini-GOP positions {used}) in {cdt:.1f} s, one thread"}
+        src_h, pred_h = tq_pics[0][0].cpu().numpy(), tq_pics[0][1].cpu().numpy()
+        rec_h = np.zeros_like(src_h)
+        q_h, dq_h, eob_h = np.zeros(n_coeff, np.int16), np.zeros(n_coeff, np.int16), np.zeros(len(tq_blocks), np.uint16)
+        t1 = time.perf_counter()
+        rc = orc.svt_oracle_tq_batch(vp(src_h), vp(pred_h), vp(rec_h), vp(tq_blocks), len(tq_blocks), vp(qtabs), vp(iscan), vp(q_h),
+                                     vp(dq_h), vp(eob_h))
+        t_tq = time.perf_counter() - t1
+        assert rc == 0
+        yd = B.YuvPlanes()
+        yd.y, yd.u, yd.v = rec_h.ctypes.data, rec_h.ctypes.data + Hd * plane_w, rec_h.ctypes.data + Hd * plane_w + Wd // 2
+        yd.y_stride, yd.uv_stride, yd.width, yd.height = plane_w, plane_w, Wd, Hd
+        lfm_h = np.ascontiguousarray(lfm)
+        t1 = time.perf_counter()
+        rc = orc.svt_oracle_lf_frame(C.byref(yd), vp(lfm_h), lfm_h.shape[1], C.byref(thr), mi_rows, mi_cols, 0)
+        t_lf = time.perf_counter() - t1
+        assert rc == 0
+        per_pic = t_me / n_me + t_tq + t_lf
+        out["cpu_baseline"] = {"value": round(1.0 / per_pic, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": f"oracle (scalar C restatement, gcc -O2, one thread) on whole {Wd}x{Hd} pictures: ME of "
+                                         f"{n_me} B pictures (mini-GOP positions {used}) {t_me / n_me:.2f} s/picture, transform/quant/"
+                                         f"recon of 1 picture {t_tq:.2f} s, deblocking of 1 picture {t_lf:.2f} s"}
     print(json.dumps(out))
     for c_ in (ctx_me, ctx_tq, ctx_lf):
         lib.svt_hip_ctx_destroy(c_)
