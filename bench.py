@@ -62,8 +62,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")
 
+    import importlib.util
     import me_configs as MC
     import svt_testlib as T
+    _sp = importlib.util.spec_from_file_location("gop_shard", os.path.join(ROOT, "svt-vp9_amd", "gop_shard.py"))
+    GS = importlib.util.module_from_spec(_sp)
+    _sp.loader.exec_module(GS)
     B = T.B
     lib = B.load()
     # one context per pipeline stage, each on its own torch stream so that torch events can bracket that stage's
@@ -81,7 +85,7 @@ def main():
     preset_name = "c3_2160p_m8" if Wd * Hd > 1920 * 1080 else ("c2_1080p_m8" if Wd * Hd > 720 * 576 else "c1_360p_m9")
 
     # ---- synthetic mini-GOP (+ the previous base-layer picture), resident in HBM ----
-    frames = T.gen_clip(Wd, Hd, MINIGOP + 1, seed=11 + rank)
+    frames = T.gen_clip(Wd, Hd, MINIGOP + 1, seed=GS.gop_seed(11, rank))  # rank r encodes its own GOP segment(s)
     dev = torch.device("cuda", local_rank)
     keep = []  # keeps device tensors alive
 
@@ -252,10 +256,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = GS.reduce_elapsed(dt, dist if world > 1 else None, dev)
 
     # ---- per-kernel time: HIP events on each stage's own stream, bracketing that stage's launches of every timed
     # step (so it includes whatever slowdown the overlap with the other stages causes, like a rocprofv3 trace) ----
@@ -266,7 +267,7 @@ def main():
     l1_on = bool(me_launches[0][4].enable_hme_level_1_flag)
     me_bytes = MINIGOP * algorithmic_bytes_me(Wd, Hd, 2, l1_on)
     L = Wd * Hd
-    tq_bytes = MINIGOP * int(10.5 * L)                     # src 1.5L + pred 1.5L + qcoeff 3L + dqcoeff 3L + recon 1.5L
+    tq_bytes = MINIGOP * int(7.5 * L)                      # src 1.5L + pred 1.5L + qcoeff 3L + recon 1.5L (the kernel also writes dqcoeff, +3L)
     lf_bytes = MINIGOP * (3 * L + 160 * nsb)               # recon read + write (3L) + masks
     achieved = me_bytes / (me_ms * 1e-3) / 1e9  # GB/s
 
@@ -277,7 +278,7 @@ def main():
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj) and (Wd, Hd) == (W4K, H4K):
         traffic = json.load(open(tj)).get("svt_me_sb_kernel", {}).get("bytes_per_step")
-    fps = MINIGOP * args.steps * world / dt
+    fps = GS.aggregate_rate(MINIGOP, args.steps, world, dt)
     out = {
         "metric": "encoded frames/sec (block-level DSP hot path: ME + DCT/quant/recon + deblock), 4Kp60 yuv420p enc-mode 8",
         "value": round(fps, 2),
