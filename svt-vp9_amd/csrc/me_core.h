@@ -48,6 +48,13 @@ static inline uint64_t svt_qsad(uint64_t ref8, uint32_t src4, uint64_t acc) {
     }
     return out;
 }
+static inline uint32_t svt_ssd4(uint32_t a, uint32_t b, uint32_t acc) {
+    for (int i = 0; i < 4; i++) {
+        int d = (int)((a >> (8 * i)) & 0xff) - (int)((b >> (8 * i)) & 0xff);
+        acc += (uint32_t)(d * d);
+    }
+    return acc;
+}
 static inline uint32_t svt_sad4(uint32_t a, uint32_t b, uint32_t acc) {
     for (int i = 0; i < 4; i++) {
         int x = (int)((a >> (8 * i)) & 0xff), y = (int)((b >> (8 * i)) & 0xff);
@@ -80,6 +87,12 @@ SVT_DEV uint64_t svt_qsad(uint64_t ref8, uint32_t src4, uint64_t acc) {
     return __builtin_amdgcn_qsad_pk_u16_u8(ref8, src4, acc);
 }
 SVT_DEV uint32_t svt_sad4(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
+/* sum of squared differences of 4 packed samples: a.a + b.b - 2 a.b with three v_dot4_u32_u8 */
+SVT_DEV uint32_t svt_ssd4(uint32_t a, uint32_t b, uint32_t acc) {
+    acc = __builtin_amdgcn_udot4(a, a, acc, false);
+    acc = __builtin_amdgcn_udot4(b, b, acc, false);
+    return acc - 2u * __builtin_amdgcn_udot4(a, b, 0u, false);
+}
 SVT_DEV uint32_t svt_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
 /* per 16-bit lane: min(max(v, 32), 287) - 32 (v_pk_max_u16 / v_pk_min_u16 / v_pk_sub_u16) */
 typedef unsigned short svt_u16x2 __attribute__((ext_vector_type(2)));
@@ -204,6 +217,7 @@ typedef struct me_lds_layout {
     int32_t off_region;  /* integer reference samples of the current list's search region */
     int32_t off_planes;  /* B, H, J half-pel planes (3 x plane_bytes); aliased by HME window / SAD scratch */
     int32_t off_quarter; /* 32x32 quarter-resolution SB (only when HME level 1 is enabled) */
+    int32_t off_ssd;     /* SSD_SEARCH only: candidate SSDs [85][9] */
     int32_t off_pred0;   /* list 0 prediction of the bi-pred lanes: levels * K * 256 dwords */
     int32_t region_stride, region_rows;
     int32_t plane_bytes;
@@ -247,6 +261,7 @@ typedef struct me_state_t {
     uint32_t best_mv[2][85];
     uint32_t red[8];           /* small sum reductions */
     uint32_t supel[9];         /* su_pel_enable sums: sx,sy,ssad for 32/16/8 */
+    uint32_t best_ssd[85];     /* SSD_SEARCH: SSD of the current best sub-pel position of each PU (current list) */
     uint8_t  dir[85];
     uint8_t  sixteenth_sb[16 * 8];
 } me_state_t;
@@ -305,6 +320,7 @@ typedef struct me_ctx_t {
     uint8_t             *region; /* LDS */
     uint8_t             *planes; /* LDS */
     uint8_t             *quarter_sb; /* LDS, valid when HME level 1 is enabled */
+    uint32_t            *ssdc;       /* LDS, SSD_SEARCH only: SSD of the sub-pel candidates [pu][9] (8 = integer position) */
     uint32_t            *pred0;  /* LDS: list 0 prediction dwords of the bi-pred lanes */
     int                  pic_w, pic_h, sb_x, sb_y, sb_w, sb_h, sb_index;
     unsigned long long  *prof;   /* optional per-phase cycle accumulators (profiling builds), else NULL */
@@ -578,9 +594,11 @@ SVT_DEV const uint8_t *me_plane_at(const me_ctx_t *c, int id, int x, int y) {
 
 /* SAD of a w x rows block: src rows at stride ss (LDS, dword aligned) vs candidate at any byte alignment (stride cs,
  * a multiple of 4), optionally averaged with a second candidate plane (b != 0).  Each candidate row is fetched as
- * w/4 + 1 aligned dwords and shifted into place with v_alignbyte. */
-SVT_DEV uint32_t me_block_sad_rows(const uint8_t *src, int ss, const uint8_t *a, const uint8_t *b, int cs, int w, int r0, int r1) {
-    uint32_t        sad = 0;
+ * w/4 + 1 aligned dwords and shifted into place with v_alignbyte.  ssd_out != 0: also the sum of squared differences
+ * (eb_vp9_spatial_full_distortion_kernel, C_DEFAULT/EbPictureOperators_C.c:337-356; averaging form
+ * Codec/EbMotionEstimation.c:1708-1725). */
+SVT_DEV uint32_t me_block_sad_rows(const uint8_t *src, int ss, const uint8_t *a, const uint8_t *b, int cs, int w, int r0, int r1, uint32_t *ssd_out) {
+    uint32_t        sad = 0, ssd = 0;
     const uint32_t  sha = (uint32_t)((uintptr_t)a & 3), shb = b ? (uint32_t)((uintptr_t)b & 3) : 0;
     const uint8_t  *a0 = a - sha, *b0 = b ? b - shb : a0;
     const int       n = w >> 2;
@@ -599,8 +617,10 @@ SVT_DEV uint32_t me_block_sad_rows(const uint8_t *src, int ss, const uint8_t *a,
                 va = (va | vb) - (((va ^ vb) >> 1) & 0x7f7f7f7fu); /* per-byte (a + b + 1) >> 1 */
             }
             sad = svt_sad4(va, s[i], sad);
+            if (ssd_out) ssd = svt_ssd4(va, s[i], ssd);
         }
     }
+    if (ssd_out) *ssd_out = ssd;
     return sad;
 }
 
@@ -695,48 +715,62 @@ SVT_DEV int me_active_pu(int k, int n64, int n32, int n16) {
     return 21 + k - n16;
 }
 
-/* half-pel: task = (refined pu, cand 0..7, sub-lane).  Distortion accumulates in st->cand[pu*8+cand]
- * (pre-zeroed).  SUB_SAD: rows 0,2,4.. only, doubled by the consumer; FULL_SAD: all rows. */
+/* half-pel: task = (refined pu, cand, sub-lane).  Distortion accumulates in st->cand[pu*8+cand] (pre-zeroed).
+ * SUB_SAD: rows 0,2,4.. only, doubled by the consumer; FULL_SAD: all rows.  SSD_SEARCH: 9 candidates per PU (8 = the
+ * integer position, whose SSD seeds the comparison, :1107-1160), all rows, SAD in st->cand and SSD in c->ssdc. */
 SVT_DEV void ph_halfpel(const me_ctx_t *c, int tid, int list, int sox, int soy, int en32, int en16, int en8) {
     const int sub_sad = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH;
+    const int ssd     = c->p->fractional_search_method == SVT_SSD_SEARCH;
+    const int ncand   = ssd ? 9 : 8;
     int       n64, n32, n16;
     const int nact = me_active_count(c, en32, en16, en8, &n64, &n32, &n16);
-    for (int t = tid; t < nact * 8 * ME_SUB_LANES; t += SVT_NT) {
+    for (int t = tid; t < nact * ncand * ME_SUB_LANES; t += SVT_NT) {
         int sl = t % ME_SUB_LANES, q = t / ME_SUB_LANES;
-        int cand = q & 7, pu = me_active_pu(q >> 3, n64, n32, n16);
+        int k = ssd ? q / 9 : q >> 3, cand = q - k * ncand, pu = me_active_pu(k, n64, n32, n16);
         int px, py, w;
         me_pu_geom(pu, &px, &py, &w);
         int      n  = me_pu_nidx(pu);
         uint32_t mv = c->st->best_mv[list][n];
         int      xs = (int16_t)((me_mvx(mv) >> 2) - (int16_t)sox) + px;
         int      ys = (int16_t)((me_mvy(mv) >> 2) - (int16_t)soy) + py;
-        int            hpl, hdx, hdy;
-        me_hcand_get(cand, &hpl, &hdx, &hdy);
+        int            hpl = ME_PF, hdx = 0, hdy = 0;
+        if (cand < 8) me_hcand_get(cand, &hpl, &hdx, &hdy);
         const uint8_t *cp = me_plane_at(c, hpl, xs + hdx, ys + hdy);
         const uint8_t *sp = c->src + py * ME_SB + px;
         int            rows = sub_sad ? (w >> 1) : w, step = sub_sad ? 2 : 1;
         /* rows split over ME_SUB_LANES lanes */
         int per = (rows + ME_SUB_LANES - 1) / ME_SUB_LANES;
         int r0 = sl * per, r1 = r0 + per < rows ? r0 + per : rows;
-        uint32_t d = r0 < r1 ? me_block_sad_rows(sp, ME_SB * step, cp, 0, c->L.region_stride * step, w, r0, r1) : 0;
-        svt_group_add_u32(&c->st->cand[pu * 8 + cand], d, ME_SUB_LANES); /* the 8 lanes of a task are consecutive */
+        uint32_t e = 0;
+        uint32_t d = r0 < r1 ? me_block_sad_rows(sp, ME_SB * step, cp, 0, c->L.region_stride * step, w, r0, r1, ssd ? &e : 0) : 0;
+        if (cand < 8) svt_group_add_u32(&c->st->cand[pu * 8 + cand], d, ME_SUB_LANES); /* the 8 lanes of a task are consecutive */
+        if (ssd) svt_group_add_u32(&c->ssdc[pu * 9 + cand], e, ME_SUB_LANES);
     }
 }
 
 /* half-pel decision per PU: sequential strict '<' updates in test order, then direction with the tie
- * order L,R,T,B,TL,TR,BL,BR (:1531-1556) */
+ * order L,R,T,B,TL,TR,BL,BR (:1531-1556).  SSD_SEARCH compares SSDs and records the winner's SAD. */
 SVT_DEV void ph_halfpel_decide(const me_ctx_t *c, int tid, int list, int en32, int en16, int en8) {
     const int sub_sad = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH;
+    const int ssd     = c->p->fractional_search_method == SVT_SSD_SEARCH;
     for (int pu = tid; pu < 85; pu += SVT_NT) {
         if (!me_pu_refined(c, pu, en32, en16, en8)) continue;
         int      n    = me_pu_nidx(pu);
         uint32_t best = c->st->best_sad[list][n], mv = c->st->best_mv[list][n];
+        uint32_t bssd = ssd ? c->ssdc[pu * 9 + 8] : 0;
         int16_t  xm = me_mvx(mv), ym = me_mvy(mv);
         uint32_t d[8];
         for (int i = 0; i < 8; i++) {
-            d[i] = c->st->cand[pu * 8 + i];
-            if (sub_sad) d[i] <<= 1;
-            if (d[i] < best) { int sx, sy; me_dmv_get(i, &sx, &sy); best = d[i]; mv = me_pack_mv(xm + 2 * sx, ym + 2 * sy); }
+            int sx, sy;
+            me_dmv_get(i, &sx, &sy);
+            if (ssd) {
+                d[i] = c->ssdc[pu * 9 + i];
+                if (d[i] < bssd) { bssd = d[i]; best = c->st->cand[pu * 8 + i]; mv = me_pack_mv(xm + 2 * sx, ym + 2 * sy); }
+            } else {
+                d[i] = c->st->cand[pu * 8 + i];
+                if (sub_sad) d[i] <<= 1;
+                if (d[i] < best) { best = d[i]; mv = me_pack_mv(xm + 2 * sx, ym + 2 * sy); }
+            }
         }
         uint32_t m = d[0];
         for (int i = 1; i < 8; i++) if (d[i] < m) m = d[i];
@@ -752,6 +786,7 @@ SVT_DEV void ph_halfpel_decide(const me_ctx_t *c, int tid, int list, int en32, i
         c->st->best_sad[list][n] = best;
         c->st->best_mv[list][n]  = mv;
         c->st->dir[n]            = dir;
+        if (ssd) c->st->best_ssd[n] = bssd;
     }
 }
 
@@ -789,6 +824,7 @@ SVT_DEV int me_qvalid(int in_half, int dir, int pos) {
  * [quirk] the 64x64 PU is evaluated on its top-left 32x32 (:2525-2526). */
 SVT_DEV void ph_quarterpel(const me_ctx_t *c, int tid, int list, int sox, int soy, int en32, int en16, int en8) {
     const int sub_sad = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH;
+    const int ssd     = c->p->fractional_search_method == SVT_SSD_SEARCH;
     int       n64, n32, n16;
     const int nact = me_active_count(c, en32, en16, en8, &n64, &n32, &n16);
     for (int t = tid; t < nact * 3 * ME_SUB_LANES; t += SVT_NT) {
@@ -812,28 +848,40 @@ SVT_DEV void ph_quarterpel(const me_ctx_t *c, int tid, int list, int sox, int so
         int            rows = sub_sad ? (w >> 1) : w, step = sub_sad ? 2 : 1;
         int            per = (rows + ME_SUB_LANES - 1) / ME_SUB_LANES;
         int            r0 = sl * per, r1 = r0 + per < rows ? r0 + per : rows;
-        uint32_t d = r0 < r1 ? me_block_sad_rows(sp, ME_SB * step, a, b, c->L.region_stride * step, w, r0, r1) : 0;
+        uint32_t sq = 0;
+        uint32_t d = r0 < r1 ? me_block_sad_rows(sp, ME_SB * step, a, b, c->L.region_stride * step, w, r0, r1, ssd ? &sq : 0) : 0;
         svt_group_add_u32(&c->st->cand[pu * 8 + pos], d, ME_SUB_LANES);
+        if (ssd) svt_group_add_u32(&c->ssdc[pu * 9 + pos], sq, ME_SUB_LANES);
     }
 }
 
 SVT_DEV void ph_quarterpel_decide(const me_ctx_t *c, int tid, int list, int en32, int en16, int en8) {
     const int sub_sad = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH;
+    const int ssd     = c->p->fractional_search_method == SVT_SSD_SEARCH;
     for (int pu = tid; pu < 85; pu += SVT_NT) {
         if (!me_pu_refined(c, pu, en32, en16, en8)) continue;
         int      n    = me_pu_nidx(pu);
         uint32_t best = c->st->best_sad[list][n], mv = c->st->best_mv[list][n];
+        uint32_t bssd = ssd ? c->st->best_ssd[n] : 0;
         int16_t  xm = me_mvx(mv), ym = me_mvy(mv);
         int      method = (ym & 2) + ((xm & 2) >> 1);
         int      dir = c->st->dir[n];
         for (int i = 0; i < 8; i++) {
             if (!me_qvalid(method != 0, dir, i)) continue;
-            uint32_t d = c->st->cand[pu * 8 + i];
-            if (sub_sad) d <<= 1;
-            if (d < best) { int sx, sy; me_dmv_get(i, &sx, &sy); best = d; mv = me_pack_mv(xm + sx, ym + sy); }
+            int sx, sy;
+            me_dmv_get(i, &sx, &sy);
+            if (ssd) {
+                uint32_t e = c->ssdc[pu * 9 + i];
+                if (e < bssd) { bssd = e; best = c->st->cand[pu * 8 + i]; mv = me_pack_mv(xm + sx, ym + sy); }
+            } else {
+                uint32_t d = c->st->cand[pu * 8 + i];
+                if (sub_sad) d <<= 1;
+                if (d < best) { best = d; mv = me_pack_mv(xm + sx, ym + sy); }
+            }
         }
         c->st->best_sad[list][n] = best;
         c->st->best_mv[list][n]  = mv;
+        if (ssd) c->st->best_ssd[n] = bssd;
     }
 }
 
@@ -1449,12 +1497,12 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         }
         ME_MARK(9);
         if (en32 || en16 || en8 || enq) {
-            ME_PHASE(for (int t = tid; t < 85 * 8; t += SVT_NT) st->cand[t] = 0);
+            ME_PHASE(for (int t = tid; t < 85 * 9; t += SVT_NT) { if (t < 85 * 8) st->cand[t] = 0; if (c->ssdc) c->ssdc[t] = 0; });
             ME_PHASE(ph_halfpel(c, tid, list, sox, soy, en32, en16, en8));
             ME_PHASE(ph_halfpel_decide(c, tid, list, en32, en16, en8));
             ME_MARK(10);
             if (enq) {
-                ME_PHASE(for (int t = tid; t < 85 * 8; t += SVT_NT) st->cand[t] = 0);
+                ME_PHASE(for (int t = tid; t < 85 * 9; t += SVT_NT) { if (t < 85 * 8) st->cand[t] = 0; if (c->ssdc) c->ssdc[t] = 0; });
                 ME_PHASE(ph_quarterpel(c, tid, list, sox, soy, en32, en16, en8));
                 ME_PHASE(ph_quarterpel_decide(c, tid, list, en32, en16, en8));
             }

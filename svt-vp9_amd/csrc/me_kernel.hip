@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ME_WAVES_PE
     c.region = svt_lds + L.off_region;
     c.planes = svt_lds + L.off_planes;
     c.quarter_sb  = svt_lds + L.off_quarter;
+    c.ssdc        = p.fractional_search_method == SVT_SSD_SEARCH ? (uint32_t *)(svt_lds + L.off_ssd) : nullptr;
     c.pred0       = (uint32_t *)(svt_lds + L.off_pred0);
     c.pic_w = pic_w; c.pic_h = pic_h; c.sb_index = sb; c.prof = prof;
     c.sb_x = (sb % nx) * ME_SB; c.sb_y = (sb / nx) * ME_SB;
@@ -104,8 +105,6 @@ extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, con
     if (!ctx || !cur || !ref0 || !params || !d_results || n_pics < 1) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: null argument");
     if (params->num_ref_lists < 1 || params->num_ref_lists > 2) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: num_ref_lists");
     if (params->num_ref_lists == 2 && !ref1) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: ref1 missing for B picture");
-    if (params->fractional_search_method == SVT_SSD_SEARCH)
-        return svt_set_error(SVT_HIP_ERR_UNSUPPORTED, "me: SSD fractional search (enc_mode <= 4) not implemented yet");
     if (params->hierarchical_levels > 5 || params->temporal_layer_index > 5 || params->number_hme_search_region_in_width > 2 ||
         params->number_hme_search_region_in_height > 2)
         return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: parameter out of range");

@@ -24,6 +24,7 @@ static inline int me_lds_layout_compute(const svt_me_params *p, me_lds_layout *L
     L->off_region    = off; off += me_round_up(L->region_rows * rs, 16);
     L->off_planes    = off; L->scratch_bytes = 3 * L->plane_bytes; off += L->scratch_bytes;
     L->off_quarter   = off; if (p->enable_hme_level_1_flag) off += 32 * 32;
+    L->off_ssd       = off; if (p->fractional_search_method == SVT_SSD_SEARCH) off += me_round_up(85 * 9 * 4, 16);
     L->off_pred0     = off;
     if (p->num_ref_lists == 2) /* [level][k][thread] dwords, k < K = 2 (SUB_SAD: even rows only) or 4 */
         off += (p->fractional_search_method == SVT_SUB_SAD_SEARCH ? 2048 : 4096) * (p->cu16x16_mode != 0 ? 2 : p->cu8x8_mode != 0 ? 3 : 4);

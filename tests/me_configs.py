@@ -10,6 +10,15 @@ PRESETS = {
     "c2_1080p_m8": (1920, 1080, 8, 1),
     "c3_2160p_m8": (3840, 2160, 8, 1),
 }
+# C5: 2160p enc-mode 3 tune 0 (SQ): SSD fractional search, 64x64 search area, HME levels 0-2 with 4 regions.  Its SSD
+# path cannot be pinned against the reference build (the reference's SSD code calls the yasm-only Log2f), so it is
+# checked HIP/emulation vs oracle only; everything else it exercises is pinned through the other configurations.
+PRESET_C5 = ("c5_2160p_m3", (3840, 2160, 3, 0))
+
+
+def preset_c5(num_lists, temporal_layer):
+    w, h, mode, tune = PRESET_C5[1]
+    return B.me_params_preset(w, h, mode, tune, num_lists, temporal_layer, 3)
 
 
 def preset(name, num_lists, temporal_layer, hierarchical_levels=4):

@@ -40,6 +40,13 @@ def test_kernel_emulation_variants(nl, tl):
         _cmp(T.oracle_me_picture, T.emu_me_picture, pics, MC.variant_same_poc(tl), nl)
 
 
+@pytest.mark.parametrize("nl,tl", [(1, 0), (2, 2)])
+def test_kernel_emulation_c5_ssd_search(nl, tl):
+    """BASELINE config C5 (SSD fractional search, 64x64 search area, 4 HME regions x 3 levels)."""
+    pics = [T.PaPic(f) for f in T.gen_clip_subpel(200, 136, 3, 23)]
+    _cmp(T.oracle_me_picture, T.emu_me_picture, pics, MC.preset_c5(nl, tl), nl)
+
+
 needs_ref = pytest.mark.skipif(not T.have_ref("ref_me_sb"), reason="oracle/_ref/ref_me_sb not built (reference absent)")
 
 

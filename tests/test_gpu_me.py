@@ -66,6 +66,13 @@ def test_me_variants_vs_oracle(ctx, nl, tl):
         _check(ctx, pics, MC.variant_same_poc(tl), nl)
 
 
+@pytest.mark.parametrize("nl,tl", [(1, 0), (2, 1), (2, 3)])
+def test_me_c5_ssd_search_vs_oracle(ctx, nl, tl):
+    """BASELINE config C5: SSD fractional search, 64x64 search area, 4 HME regions x 3 levels, 8x8 PUs refined."""
+    pics = [T.PaPic(f) for f in T.gen_clip_subpel(328, 200, 3, 23)]
+    _check(ctx, pics, MC.preset_c5(nl, tl), nl)
+
+
 def test_me_random_content(ctx):
     """Uniform random pictures: worst case for ties/early outs (there are none in the SAD paths)."""
     rng = np.random.default_rng(3)
