@@ -254,6 +254,16 @@ int32_t svt_hip_tq_batch_device(svt_hip_ctx *ctx, const uint8_t *d_src, const ui
                                 int16_t *d_dqcoeff, uint16_t *d_eob);
 
 /* Host-pointer convenience form. plane_bytes = size of each of src/pred/recon; coeff_count = total coeffs. */
+/* Same, additionally producing the coefficient-domain distortion pair of every block as the reference's
+ * full_distortion_kernel32bit does right after the transform/quantisation in mode decision
+ * (C_DEFAULT/EbPictureOperators_C.c:288-311; function table Codec/EbPictureOperators.h:240):
+ * d_dist[2*b] = sum (coeff - dqcoeff)^2, d_dist[2*b+1] = sum coeff^2 over the NxN block, with the reference's
+ * int16/uint32 wrap-around.  (The _intra and _eob_zero variants of the reference return one of the two values twice.) */
+int32_t svt_hip_tq_batch_dist_device(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *d_recon,
+                                     const svt_tq_block *d_blocks, const int32_t size_count[4],
+                                     const svt_quant_tables *d_qtabs, const int16_t *d_iscan, int16_t *d_qcoeff,
+                                     int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist);
+
 int32_t svt_hip_tq_batch(svt_hip_ctx *ctx, const uint8_t *src, const uint8_t *pred, uint8_t *recon,
                          size_t plane_bytes, const svt_tq_block *blocks, int32_t n_blocks,
                          const svt_quant_tables *qtabs, int32_t n_qtabs, const int16_t *iscan, size_t iscan_count,
@@ -288,6 +298,26 @@ typedef struct svt_lf_thresh {
 void svt_hip_lf_thresh_init(svt_lf_thresh *t, int32_t sharpness_level);
 /* eb_vp9_pick_filter_level's level-from-q rule (VPX/vp9_picklpf.c:37-89), 8-bit. */
 int32_t svt_hip_lf_level_from_q(int32_t ac_q, int32_t is_key_frame);
+
+/* The fields of ModeInfo (VPX/vp9_blockd.h) that the mask builder reads, one record per 8x8 unit of the picture
+ * (mi_rows x mi_stride grid).  Every 8x8 unit covered by a prediction block carries that block's values, exactly as
+ * every entry of cm->mi_grid_visible[] points at the block's ModeInfo in the reference. */
+typedef struct svt_lf_mode_info {
+    uint8_t sb_type;      /* BLOCK_SIZE: 0 4x4, 1 4x8, 2 8x4, 3 8x8, 4 8x16, 5 16x8, 6 16x16, 7 16x32, 8 32x16, 9 32x32,
+                             10 32x64, 11 64x32, 12 64x64 (VPX/vp9_enums.h) */
+    uint8_t tx_size;      /* TX_4X4 .. TX_32X32 */
+    uint8_t skip;         /* no coefficients coded */
+    uint8_t is_inter;     /* ref_frame[0] > INTRA_FRAME */
+    uint8_t filter_level; /* get_filter_level(): lf_info.lvl[segment_id][ref_frame[0]][mode_lf_lut[mode]] */
+    uint8_t pad_[3];
+} svt_lf_mode_info;
+
+/* Host-side: builds the LOOP_FILTER_MASK of every SB from the mode-info grid = eb_vp9_build_mask_frame
+ * (VPX/vp9_loopfilter.c:1548-1571 -> eb_vp9_setup_mask :901-1040 / per block eb_vp9_build_mask :1587-1689).
+ * lfm[(mi_row >> 3) * lfm_stride + (mi_col >> 3)] is written for every SB (zeroed first, like eb_vp9_setup_mask).
+ * The result is the input of svt_hip_lf_frame (eb_vp9_adjust_mask is applied inside the filter, as in the reference). */
+int32_t svt_hip_lf_build_masks(const svt_lf_mode_info *mi, int32_t mi_stride, int32_t mi_rows, int32_t mi_cols,
+                               svt_lf_mask *lfm, int32_t lfm_stride);
 
 /* 4:2:0 recon picture, planes filtered in place. */
 typedef struct svt_yuv_planes {

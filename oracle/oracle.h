@@ -28,4 +28,12 @@ int32_t svt_oracle_tq_batch(const uint8_t *src, const uint8_t *pred, uint8_t *re
 #ifdef __cplusplus
 }
 #endif
+/* L2: eb_vp9_build_mask_frame / eb_vp9_setup_mask (VPX/vp9_loopfilter.c:901-1040, 1548-1571) */
+int32_t svt_oracle_lf_build_masks(const svt_lf_mode_info *mi, int32_t mi_stride, int32_t mi_rows, int32_t mi_cols,
+                                  svt_lf_mask *lfm, int32_t lfm_stride);
+/* T3: full_distortion_kernel32bit (C_DEFAULT/EbPictureOperators_C.c:288-311) and the batch with distortions */
+void    svt_oracle_full_distortion32(const int16_t *coeff, const int16_t *recon_coeff, int32_t count, uint64_t out[2]);
+int32_t svt_oracle_tq_batch_dist(const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks,
+                                 int32_t n_blocks, const svt_quant_tables *qtabs, const int16_t *iscan, int16_t *qcoeff,
+                                 int16_t *dqcoeff, uint16_t *eob, uint64_t *dist);
 #endif

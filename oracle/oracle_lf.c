@@ -267,3 +267,96 @@ int32_t svt_oracle_lf_frame(const svt_yuv_planes *recon, const svt_lf_mask *lfm,
         }
     return 0;
 }
+
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* L2: LOOP_FILTER_MASK construction, frame-level formulation: eb_vp9_build_mask_frame (VPX/vp9_loopfilter.c:1548-1571) */
+/* -> eb_vp9_setup_mask (:901-1040): walk the 64/32/16/8 partition tree of every SB, build_masks (:706-783) for blocks   */
+/* that carry chroma edges, build_y_mask (:788-825) for the second/third/fourth block of a 16x16 area.                  */
+/* ------------------------------------------------------------------------------------------------------------------ */
+static const uint8_t lf_w8[13] = {1, 1, 1, 1, 1, 2, 2, 2, 4, 4, 4, 8, 8}; /* eb_vp9_num_8x8_blocks_wide_lookup */
+static const uint8_t lf_h8[13] = {1, 1, 1, 1, 2, 1, 2, 4, 2, 4, 8, 4, 8}; /* eb_vp9_num_8x8_blocks_high_lookup */
+
+static uint64_t lf_rect(int w, int h, int cols) {
+    uint64_t m = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) m |= (uint64_t)1 << (y * cols + x);
+    return m;
+}
+/* left_64x64_txform_mask / above_64x64_txform_mask and their uv versions (:95-157) */
+static uint64_t lf_txmask(int tx, int left, int cols) {
+    uint64_t m = 0;
+    const int step = tx < 2 ? 1 : tx == 2 ? 2 : 4;
+    for (int y = 0; y < cols; y++)
+        for (int x = 0; x < cols; x++)
+            if ((left ? x : y) % step == 0) m |= (uint64_t)1 << (y * cols + x);
+    return m;
+}
+/* eb_vp9_uv_txsize_lookup[bsize][tx][1][1] (VPX/vp9_common_data.c): min(tx, largest tx of the 4:2:0 chroma block) */
+static int lf_uv_tx(int bs, int tx) {
+    static const uint8_t max_uv[13] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 2, 2, 2, 3};
+    return tx < max_uv[bs] ? tx : max_uv[bs];
+}
+
+static void lf_build(const svt_lf_mode_info *b, int shift_y, int shift_uv, int with_uv, svt_lf_mask *m) {
+    const int bs = b->sb_type, txy = b->tx_size, txuv = lf_uv_tx(bs, txy), w = lf_w8[bs], h = lf_h8[bs];
+    const int wuv = (w + 1) >> 1, huv = (h + 1) >> 1;
+    if (!b->filter_level) return;
+    for (int i = 0; i < h; i++) memset(&m->lfl_y[shift_y + 8 * i], b->filter_level, (size_t)w);
+    m->above_y[txy] |= lf_rect(w, 1, 8) << shift_y;
+    m->left_y[txy] |= lf_rect(1, h, 8) << shift_y;
+    if (with_uv) {
+        m->above_uv[txuv] |= (uint16_t)(lf_rect(wuv, 1, 4) << shift_uv);
+        m->left_uv[txuv] |= (uint16_t)(lf_rect(1, huv, 4) << shift_uv);
+    }
+    if (b->skip && b->is_inter) return;
+    m->above_y[txy] |= (lf_rect(w, h, 8) & lf_txmask(txy, 0, 8)) << shift_y;
+    m->left_y[txy] |= (lf_rect(w, h, 8) & lf_txmask(txy, 1, 8)) << shift_y;
+    if (txy == 0) m->int_4x4_y |= lf_rect(w, h, 8) << shift_y;
+    if (with_uv) {
+        m->above_uv[txuv] |= (uint16_t)((lf_rect(wuv, huv, 4) & lf_txmask(txuv, 0, 4)) << shift_uv);
+        m->left_uv[txuv] |= (uint16_t)((lf_rect(wuv, huv, 4) & lf_txmask(txuv, 1, 4)) << shift_uv);
+        if (txuv == 0) m->int_4x4_uv |= (uint16_t)(lf_rect(wuv, huv, 4) << shift_uv);
+    }
+}
+
+int32_t svt_oracle_lf_build_masks(const svt_lf_mode_info *mi, int32_t mi_stride, int32_t mi_rows, int32_t mi_cols,
+                                  svt_lf_mask *lfm, int32_t lfm_stride) {
+    enum { B64X64 = 12, B64X32 = 11, B32X64 = 10, B32X32 = 9, B32X16 = 8, B16X32 = 7, B16X16 = 6, B16X8 = 5, B8X16 = 4 };
+    for (int mi_row = 0; mi_row < mi_rows; mi_row += 8)
+        for (int mi_col = 0; mi_col < mi_cols; mi_col += 8) {
+            svt_lf_mask            *m = &lfm[(mi_row >> 3) * lfm_stride + (mi_col >> 3)];
+            const svt_lf_mode_info *p = mi + (size_t)mi_row * mi_stride + mi_col;
+            const int max_rows = mi_rows - mi_row < 8 ? mi_rows - mi_row : 8, max_cols = mi_cols - mi_col < 8 ? mi_cols - mi_col : 8;
+#define AT(r, c) (&p[(r) * mi_stride + (c)])
+            memset(m, 0, sizeof *m);
+            const int t64 = AT(0, 0)->sb_type;
+            if (t64 == B64X64) { lf_build(AT(0, 0), 0, 0, 1, m); continue; }
+            if (t64 == B64X32) { lf_build(AT(0, 0), 0, 0, 1, m); if (4 < max_rows) lf_build(AT(4, 0), 32, 8, 1, m); continue; }
+            if (t64 == B32X64) { lf_build(AT(0, 0), 0, 0, 1, m); if (4 < max_cols) lf_build(AT(0, 4), 4, 2, 1, m); continue; }
+            for (int q32 = 0; q32 < 4; q32++) {
+                const int r32 = (q32 >> 1) * 4, c32 = (q32 & 1) * 4;
+                if (c32 >= max_cols || r32 >= max_rows) continue;
+                const int t32 = AT(r32, c32)->sb_type, sy32 = r32 * 8 + c32, suv32 = (r32 >> 1) * 4 + (c32 >> 1);
+                if (t32 == B32X32) { lf_build(AT(r32, c32), sy32, suv32, 1, m); continue; }
+                if (t32 == B32X16) { lf_build(AT(r32, c32), sy32, suv32, 1, m); if (r32 + 2 < max_rows) lf_build(AT(r32 + 2, c32), sy32 + 16, suv32 + 4, 1, m); continue; }
+                if (t32 == B16X32) { lf_build(AT(r32, c32), sy32, suv32, 1, m); if (c32 + 2 < max_cols) lf_build(AT(r32, c32 + 2), sy32 + 2, suv32 + 1, 1, m); continue; }
+                for (int q16 = 0; q16 < 4; q16++) {
+                    const int r16 = r32 + (q16 >> 1) * 2, c16 = c32 + (q16 & 1) * 2;
+                    if (c16 >= max_cols || r16 >= max_rows) continue;
+                    const int t16 = AT(r16, c16)->sb_type, sy16 = r16 * 8 + c16, suv16 = (r16 >> 1) * 4 + (c16 >> 1);
+                    if (t16 == B16X16) { lf_build(AT(r16, c16), sy16, suv16, 1, m); continue; }
+                    if (t16 == B16X8) { lf_build(AT(r16, c16), sy16, suv16, 1, m); if (r16 + 1 < max_rows) lf_build(AT(r16 + 1, c16), sy16 + 8, 0, 0, m); continue; }
+                    if (t16 == B8X16) { lf_build(AT(r16, c16), sy16, suv16, 1, m); if (c16 + 1 < max_cols) lf_build(AT(r16, c16 + 1), sy16 + 1, 0, 0, m); continue; }
+                    lf_build(AT(r16, c16), sy16, suv16, 1, m);
+                    for (int q8 = 1; q8 < 4; q8++) {
+                        const int r8 = r16 + (q8 >> 1), c8 = c16 + (q8 & 1);
+                        if (c8 >= max_cols || r8 >= max_rows) continue;
+                        lf_build(AT(r8, c8), r8 * 8 + c8, 0, 0, m);
+                    }
+                }
+            }
+#undef AT
+        }
+    return 0;
+}

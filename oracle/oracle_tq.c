@@ -214,10 +214,35 @@ void oracle_inv_txfm_add(const int16_t *dqcoeff, uint8_t *dst, int stride, int t
     inv2d_add(dqcoeff, dst, stride, n, rows, cols, n, shift);
 }
 
+int32_t svt_oracle_tq_batch_dist(const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks,
+                                 int32_t n_blocks, const svt_quant_tables *qtabs, const int16_t *iscan, int16_t *qcoeff,
+                                 int16_t *dqcoeff, uint16_t *eob, uint64_t *dist);
+
+/* T3: full_distortion_kernel32bit (C_DEFAULT/EbPictureOperators_C.c:288-311): out[0] = sum of squared differences
+ * between the transform coefficients and the dequantised coefficients, out[1] = sum of squared coefficients.
+ * [quirk] each difference is passed through an int16_t parameter (sq_r16to32, :264) and the sums are uint32_t. */
+void svt_oracle_full_distortion32(const int16_t *coeff, const int16_t *recon_coeff, int32_t count, uint64_t out[2]) {
+    uint32_t residual = 0, prediction = 0;
+    for (int i = 0; i < count; i++) {
+        const int16_t d = (int16_t)(coeff[i] - recon_coeff[i]);
+        residual += (uint32_t)((int32_t)d * d);
+        prediction += (uint32_t)((int32_t)coeff[i] * coeff[i]);
+    }
+    out[0] = residual;
+    out[1] = prediction;
+}
+
 /* ---- batch driver: same contract as svt_hip_tq_batch (include/svtvp9_hip.h) ---- */
 int32_t svt_oracle_tq_batch(const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks,
                             int32_t n_blocks, const svt_quant_tables *qtabs, const int16_t *iscan, int16_t *qcoeff,
                             int16_t *dqcoeff, uint16_t *eob) {
+    return svt_oracle_tq_batch_dist(src, pred, recon, blocks, n_blocks, qtabs, iscan, qcoeff, dqcoeff, eob, 0);
+}
+
+/* as above, plus the coefficient-domain distortion pair of every block (dist[2*b], dist[2*b+1]) when dist != 0 */
+int32_t svt_oracle_tq_batch_dist(const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks,
+                                 int32_t n_blocks, const svt_quant_tables *qtabs, const int16_t *iscan, int16_t *qcoeff,
+                                 int16_t *dqcoeff, uint16_t *eob, uint64_t *dist) {
     int16_t res[1024], coeff[1024];
     for (int b = 0; b < n_blocks; b++) {
         const svt_tq_block *k = &blocks[b];
@@ -229,6 +254,7 @@ int32_t svt_oracle_tq_batch(const uint8_t *src, const uint8_t *pred, uint8_t *re
         oracle_fwd_txfm(res, n, coeff, k->tx_size, k->tx_size == SVT_TX_32X32 ? SVT_DCT_DCT : k->tx_type, k->partial32);
         oracle_quantize(coeff, n * n, &qtabs[k->qtab], qcoeff + k->coeff_off, dqcoeff + k->coeff_off, &eob[b], iscan + k->iscan_off,
                         k->tx_size == SVT_TX_32X32);
+        if (dist) svt_oracle_full_distortion32(coeff, dqcoeff + k->coeff_off, n * n, &dist[2 * b]);
         if (k->do_recon) {
             /* pic_copy pred -> recon, then inverse transform added (EbEncDecProcess.c:430-437) */
             for (int r = 0; r < n; r++) memcpy(recon + k->recon_off + r * k->recon_stride, pred + k->pred_off + r * k->pred_stride, (size_t)n);

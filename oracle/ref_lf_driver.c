@@ -12,6 +12,11 @@
  * request: int32 magic 'SVLF', int32 width, height, y_stride, uv_stride, mi_rows, mi_cols, lfm_stride, n_lfm, y_only,
  *          svt_lf_thresh, n_lfm * svt_lf_mask (= LOOP_FILTER_MASK), Y plane (y_stride*height), U, V (uv_stride*height/2)
  * response: the three filtered planes, same layout.
+ *
+ * Second request kind (mask construction, eb_vp9_setup_mask :901 for every SB as eb_vp9_build_mask_frame :1548 does):
+ * request: int32 magic 'SVLM', mi_rows, mi_cols, mi_stride, lfm_stride, then lf_info.lvl[8][4][2] bytes, then
+ *          mi_rows*mi_stride cells of 6 bytes {sb_type, tx_size, skip, ref_frame[0], mode, segment_id}
+ * response: (sb_rows * lfm_stride) LOOP_FILTER_MASKs.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -36,7 +41,39 @@ int main(int argc, char **argv) {
     FILE *f = fopen(argv[1], "rb");
     if (!f) return 2;
     int32_t h[10];
-    if (rd(f, h, sizeof h) || h[0] != 0x464C5653) return 3;
+    if (rd(f, h, 5 * sizeof(int32_t))) return 3;
+    if (h[0] == 0x4D4C5653) { /* 'SVLM' */
+        const int mi_rows = h[1], mi_cols = h[2], mi_stride = h[3], lfm_stride = h[4];
+        const int sb_rows = (mi_rows + 7) / 8;
+        VP9_COMMON *cm = (VP9_COMMON *)calloc(1, sizeof *cm);
+        cm->mi_rows = mi_rows; cm->mi_cols = mi_cols; cm->mi_stride = mi_stride;
+        if (rd(f, cm->lf_info.lvl, sizeof cm->lf_info.lvl)) return 3;
+        if (sizeof cm->lf_info.lvl != 8 * 4 * 2) { fprintf(stderr, "lf_info.lvl layout\n"); return 4; }
+        const size_t n = (size_t)mi_rows * mi_stride;
+        uint8_t     *cells = (uint8_t *)malloc(n * 6);
+        if (rd(f, cells, n * 6)) return 3;
+        fclose(f);
+        ModeInfo  *mis  = (ModeInfo *)calloc(n, sizeof *mis);
+        ModeInfo **grid = (ModeInfo **)calloc(n, sizeof *grid);
+        for (size_t i = 0; i < n; i++) {
+            mis[i].sb_type = (BLOCK_SIZE)cells[6 * i]; mis[i].tx_size = (TX_SIZE)cells[6 * i + 1]; mis[i].skip = cells[6 * i + 2];
+            mis[i].ref_frame[0] = (MV_REFERENCE_FRAME)cells[6 * i + 3]; mis[i].mode = (PREDICTION_MODE)cells[6 * i + 4];
+            mis[i].segment_id = cells[6 * i + 5];
+            grid[i] = &mis[i];
+        }
+        LOOP_FILTER_MASK *lfm = (LOOP_FILTER_MASK *)calloc((size_t)sb_rows * lfm_stride, sizeof *lfm);
+        cm->lf.lfm = lfm; cm->lf.lfm_stride = lfm_stride;
+        for (int mi_row = 0; mi_row < mi_rows; mi_row += 8)
+            for (int mi_col = 0; mi_col < mi_cols; mi_col += 8)
+                eb_vp9_setup_mask(cm, mi_row, mi_col, grid + (size_t)mi_row * mi_stride + mi_col, mi_stride,
+                                  &lfm[(mi_row >> 3) * lfm_stride + (mi_col >> 3)]);
+        FILE *o = fopen(argv[2], "wb");
+        if (!o) return 2;
+        fwrite(lfm, sizeof *lfm, (size_t)sb_rows * lfm_stride, o);
+        fclose(o);
+        return 0;
+    }
+    if (rd(f, h + 5, 5 * sizeof(int32_t)) || h[0] != 0x464C5653) return 3;
     const int W = h[1], H = h[2], ys = h[3], uvs = h[4], mi_rows = h[5], mi_cols = h[6], lfm_stride = h[7], n_lfm = h[8], y_only = h[9];
     (void)W;
     svt_lf_thresh thr;

@@ -79,6 +79,11 @@ LF_MASK_DTYPE = np.dtype([("left_y", "<u8", (4,)), ("above_y", "<u8", (4,)), ("i
                           ("lfl_y", "u1", (64,))], align=True)
 
 
+LF_MODE_INFO_DTYPE = np.dtype([("sb_type", "u1"), ("tx_size", "u1"), ("skip", "u1"), ("is_inter", "u1"),
+                               ("filter_level", "u1"), ("pad", "u1", (3,))])
+assert LF_MODE_INFO_DTYPE.itemsize == 8
+
+
 class LfThresh(C.Structure):
     _fields_ = [("mblim", C.c_uint8 * 64), ("lim", C.c_uint8 * 64), ("hev_thr", C.c_uint8 * 64)]
 
@@ -93,8 +98,8 @@ EXPORTS = [
     "svt_hip_sb_count", "svt_hip_me_params_preset", "svt_hip_ctx_create", "svt_hip_ctx_create_on_stream",
     "svt_hip_ctx_destroy", "svt_hip_ctx_synchronize", "svt_hip_last_error", "svt_hip_last_kernel_ms",
     "svt_hip_me_picture_device", "svt_hip_me_batch_device", "svt_hip_me_picture", "svt_hip_sad_loop_batch_device",
-    "svt_hip_tq_batch_device", "svt_hip_tq_batch", "svt_hip_lf_thresh_init", "svt_hip_lf_level_from_q",
-    "svt_hip_lf_frame_device", "svt_hip_lf_batch_device", "svt_hip_lf_frame",
+    "svt_hip_tq_batch_device", "svt_hip_tq_batch_dist_device", "svt_hip_tq_batch", "svt_hip_lf_thresh_init", "svt_hip_lf_level_from_q",
+    "svt_hip_lf_frame_device", "svt_hip_lf_batch_device", "svt_hip_lf_frame", "svt_hip_lf_build_masks",
 ]
 
 _lib = None

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void svt_tq_kernel(const uint8_t *__restrict__
                                                      uint8_t *__restrict__ recon, const svt_tq_block *__restrict__ blocks,
                                                      int n_blocks, const svt_quant_tables *__restrict__ qtabs,
                                                      const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,
-                                                     int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out) {
+                                                     int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out,
+                                                     uint64_t *__restrict__ dist_out) {
     constexpr int BPW = 256 / N;          /* blocks per workgroup */
     constexpr int LS  = N + 1;            /* padded LDS row stride in dwords */
     __shared__ int32_t tile[BPW][N * LS];
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(256) void svt_tq_kernel(const uint8_t *__restrict__
     const svt_quant_tables q = qtabs[k.qtab];
     const int16_t *iscan = iscan_all + k.iscan_off + i * N;
     int eob = 0;
+    uint32_t rdist = 0, pdist = 0;
     int32_t dq[N];
     int16_t *qo = qcoeff + k.coeff_off + i * N, *dqo = dqcoeff + k.coeff_off + i * N;
     _Pragma("unroll") for (int kk = 0; kk < N; kk++) {
@@ -155,11 +157,20 @@ __global__ __launch_bounds__(256) void svt_tq_kernel(const uint8_t *__restrict__
             }
         }
         dq[kk] = dv;
+        /* full_distortion_kernel32bit (C_DEFAULT/EbPictureOperators_C.c:288-311): the difference goes through an int16_t
+           parameter, the sums wrap in uint32_t */
+        const int dd = (int16_t)(cv - dv);
+        rdist += (uint32_t)(dd * dd);
+        pdist += (uint32_t)(cv * cv);
         if (active) { qo[kk] = (int16_t)qv; dqo[kk] = (int16_t)dv; }
         if (level && active) { const int pos = iscan[kk] + 1; eob = pos > eob ? pos : eob; }
     }
     _Pragma("unroll") for (int off = 1; off < N; off <<= 1) { const int other = __shfl_xor(eob, off); eob = other > eob ? other : eob; }
     if (active && i == 0) eob_out[blk] = (uint16_t)eob;
+    if (dist_out) { /* T3: coefficient-domain distortion of the block, summed over its N lanes */
+        _Pragma("unroll") for (int off = 1; off < N; off <<= 1) { rdist += __shfl_xor(rdist, off); pdist += __shfl_xor(pdist, off); }
+        if (active && i == 0) { dist_out[2 * blk] = rdist; dist_out[2 * blk + 1] = pdist; }
+    }
     if (!k.do_recon) return; /* uniform per block; blocks of one workgroup may differ but no barrier follows for them */
     /* NOTE: the barrier below is reached by every lane whose block reconstructs; to keep it workgroup-uniform the
        host launches reconstructing and non-reconstructing blocks in separate grids (see launcher). */
@@ -204,11 +215,11 @@ __global__ __launch_bounds__(256) void svt_tq_kernel(const uint8_t *__restrict__
 
 template <int N>
 int launch_tq(svt_hip_ctx *ctx, const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks, int n,
-              const svt_quant_tables *q, const int16_t *iscan, int16_t *qc, int16_t *dqc, uint16_t *eob) {
+              const svt_quant_tables *q, const int16_t *iscan, int16_t *qc, int16_t *dqc, uint16_t *eob, uint64_t *dist) {
     if (n <= 0) return 0;
     constexpr int BPW = 256 / N;
     hipLaunchKernelGGL(svt_tq_kernel<N>, dim3((n + BPW - 1) / BPW), dim3(256), 0, ctx->stream, src, pred, recon, blocks, n, q, iscan,
-                       qc, dqc, eob);
+                       qc, dqc, eob, dist);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 } // namespace
@@ -220,18 +231,28 @@ extern "C" int32_t svt_hip_tq_batch_device(svt_hip_ctx *ctx, const uint8_t *d_sr
                                            const svt_tq_block *d_blocks, const int32_t size_count[4],
                                            const svt_quant_tables *d_qtabs, const int16_t *d_iscan, int16_t *d_qcoeff,
                                            int16_t *d_dqcoeff, uint16_t *d_eob) {
+    return svt_hip_tq_batch_dist_device(ctx, d_src, d_pred, d_recon, d_blocks, size_count, d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob,
+                                        nullptr);
+}
+
+/* as svt_hip_tq_batch_device, plus d_dist[2*b], d_dist[2*b+1] = full_distortion_kernel32bit's result pair of block b
+ * (residual distortion, prediction distortion); d_dist may be NULL */
+extern "C" int32_t svt_hip_tq_batch_dist_device(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *d_recon,
+                                                const svt_tq_block *d_blocks, const int32_t size_count[4],
+                                                const svt_quant_tables *d_qtabs, const int16_t *d_iscan, int16_t *d_qcoeff,
+                                                int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist) {
     if (!ctx || !d_src || !d_pred || !d_blocks || !size_count || !d_qtabs || !d_iscan || !d_qcoeff || !d_dqcoeff || !d_eob)
         return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq: null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
     int off = 0, rc = 0;
-    rc |= launch_tq<4>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[0], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off);
+    rc |= launch_tq<4>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[0], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr);
     off += size_count[0];
-    rc |= launch_tq<8>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[1], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off);
+    rc |= launch_tq<8>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[1], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr);
     off += size_count[1];
-    rc |= launch_tq<16>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[2], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off);
+    rc |= launch_tq<16>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[2], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr);
     off += size_count[2];
-    rc |= launch_tq<32>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[3], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off);
+    rc |= launch_tq<32>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[3], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr);
     if (rc) return svt_set_hip_error(hipGetLastError(), __FILE__, __LINE__);
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->timed = 1;

@@ -54,6 +54,14 @@ def main():
         y, u, v = T.ref_lf_frame(T.make_lf_case(seed, w, h, sharp))
         lf[f"y|{w}|{h}|{seed}|{sharp}"], lf[f"u|{w}|{h}|{seed}|{sharp}"], lf[f"v|{w}|{h}|{seed}|{sharp}"] = y, u, v
     np.savez_compressed(os.path.join(G, "lf_reference.npz"), **lf)
+    # ---- LF masks: reference eb_vp9_setup_mask on random mode-info grids (same cases as tests/test_lf_masks.py) ----
+    lm = {}
+    for (seed, mi_rows, mi_cols) in ((1, 8, 8), (2, 27, 41), (3, 17, 9), (4, 5, 3), (5, 34, 60)):
+        cells, lvl, _ = T.gen_mode_info_grid(seed, mi_rows, mi_cols)
+        r = T.ref_lf_build_masks(cells, lvl, mi_rows, mi_cols)
+        for n in r.dtype.names:
+            lm[f"lfm_{seed}_{n}"] = np.ascontiguousarray(r[n])
+    np.savez_compressed(os.path.join(G, "lf_masks_reference.npz"), **lm)
     for f in sorted(os.listdir(G)):
         print(f, os.path.getsize(os.path.join(G, f)))
 

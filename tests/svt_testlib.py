@@ -608,3 +608,126 @@ def hip_lf_frame(ctx, case, y_only=False):
     B.check(B.load().svt_hip_lf_frame(ctx, C.byref(d), lfm.ctypes.data_as(C.c_void_p), lfm.shape[1], C.byref(case["thr"]),
                                       case["mi_rows"], case["mi_cols"], int(y_only)))
     return y, u, v
+
+
+# ---------------------------------------------------------------------------------------------------
+# mask construction (L2): mode-info grids
+# ---------------------------------------------------------------------------------------------------
+_BS_W4 = [1, 1, 2, 2, 2, 4, 4, 4, 8, 8, 8, 16, 16]   # block width / height in 4-sample units by BLOCK_SIZE
+_BS_H4 = [1, 2, 1, 2, 4, 2, 4, 8, 4, 8, 16, 8, 16]
+_MODE_LF_LUT = [0] * 10 + [1, 1, 0, 1]                 # VPX/vp9_loopfilter.c mode_lf_lut: intra modes, NEAREST, NEAR, ZERO, NEW
+
+
+def gen_mode_info_grid(seed, mi_rows, mi_cols, mi_stride=None):
+    """A consistent random partition of every SB (all 13 block sizes incl. rectangular and sub-8x8) with transform
+    size, skip, reference frame, mode and segment per block.  Returns (cells[mi_rows, mi_stride, 6] for the reference
+    driver = {sb_type, tx_size, skip, ref_frame0, mode, segment_id}, lvl[8][4][2], mode-info records for the ABI)."""
+    rng = np.random.default_rng(seed)
+    mi_stride = mi_stride or mi_cols + 3
+    cells = np.zeros((mi_rows, mi_stride, 6), np.uint8)
+    lvl = rng.choice(np.array([0, 0, 3, 9, 17, 30, 47, 63], np.uint8), size=(8, 4, 2)).astype(np.uint8)
+
+    def put(r, c, h8, w8, bs):
+        maxtx = {1: 0, 2: 1, 4: 2, 8: 3, 16: 3}[min(_BS_W4[bs], _BS_H4[bs])]
+        inter = int(rng.integers(0, 3) > 0)
+        rec = (bs, int(rng.integers(0, maxtx + 1)), int(rng.integers(0, 2)), int(rng.integers(1, 4)) if inter else 0,
+               int(rng.integers(10, 14)) if inter else int(rng.integers(0, 10)), int(rng.integers(0, 8)))
+        cells[r:min(r + h8, mi_rows), c:min(c + w8, mi_cols)] = rec
+
+    def part(r, c, n):              # n = size in 8x8 units (8, 4, 2, 1)
+        if r >= mi_rows or c >= mi_cols:
+            return
+        sq = {8: 12, 4: 9, 2: 6, 1: 3}[n]
+        k = int(rng.integers(0, 4)) if n > 1 else int(rng.integers(0, 4)) + 4
+        if n > 1 and k == 0:        # split
+            h = n // 2
+            for dr in (0, h):
+                for dc in (0, h):
+                    part(r + dr, c + dc, h)
+        elif n > 1 and k == 1:      # horizontal pair (w x h/2): 64x32 / 32x16 / 16x8
+            put(r, c, n // 2, n, sq - 1 if n != 2 else 5)
+            if r + n // 2 < mi_rows:
+                put(r + n // 2, c, n // 2, n, sq - 1 if n != 2 else 5)
+        elif n > 1 and k == 2:      # vertical pair: 32x64 / 16x32 / 8x16
+            put(r, c, n, n // 2, sq - 2 if n != 2 else 4)
+            if c + n // 2 < mi_cols:
+                put(r, c + n // 2, n, n // 2, sq - 2 if n != 2 else 4)
+        elif n > 1:
+            put(r, c, n, n, sq)
+        else:                       # 8x8 unit: 8x8, 8x4, 4x8 or 4x4 (one record per unit)
+            put(r, c, 1, 1, [3, 2, 1, 0][k - 4])
+
+    for r in range(0, mi_rows, 8):
+        for c in range(0, mi_cols, 8):
+            part(r, c, 8)
+    mi = np.zeros((mi_rows, mi_stride), dtype=B.LF_MODE_INFO_DTYPE)
+    mi["sb_type"], mi["tx_size"], mi["skip"] = cells[..., 0], cells[..., 1], cells[..., 2]
+    mi["is_inter"] = cells[..., 3] > 0
+    lut = np.array(_MODE_LF_LUT, np.uint8)
+    # the reference is built without segmentation support: get_filter_level() always reads segment 0 (:242-248)
+    mi["filter_level"] = lvl[0, cells[..., 3], lut[cells[..., 4]]]
+    return cells, lvl, mi
+
+
+def _build_masks(fn, mi, mi_rows, mi_cols):
+    sb_rows, lfm_stride = (mi_rows + 7) // 8, (mi_cols + 7) // 8 + 1
+    lfm = np.zeros((sb_rows, lfm_stride), dtype=B.LF_MASK_DTYPE)
+    rc = fn(mi.ctypes.data_as(C.c_void_p), mi.shape[1], mi_rows, mi_cols, lfm.ctypes.data_as(C.c_void_p), lfm_stride)
+    assert rc == 0
+    return lfm[:, :lfm_stride - 1].copy()
+
+
+def oracle_lf_build_masks(mi, mi_rows, mi_cols):
+    return _build_masks(oracle().svt_oracle_lf_build_masks, mi, mi_rows, mi_cols)
+
+
+def product_lf_build_masks(mi, mi_rows, mi_cols):
+    return _build_masks(B.load().svt_hip_lf_build_masks, mi, mi_rows, mi_cols)
+
+
+def ref_lf_build_masks(cells, lvl, mi_rows, mi_cols):
+    exe = os.path.join(REF_DIR, "ref_lf_frame")
+    sb_rows, lfm_stride = (mi_rows + 7) // 8, (mi_cols + 7) // 8 + 1
+    with tempfile.TemporaryDirectory() as td:
+        req, rsp = os.path.join(td, "req.bin"), os.path.join(td, "rsp.bin")
+        with open(req, "wb") as f:
+            f.write(struct.pack("<5i", 0x4D4C5653, mi_rows, mi_cols, cells.shape[1], lfm_stride))
+            f.write(np.ascontiguousarray(lvl).tobytes())
+            f.write(np.ascontiguousarray(cells).tobytes())
+        subprocess.check_call([exe, req, rsp])
+        raw = np.fromfile(rsp, dtype=B.LF_MASK_DTYPE)
+    return raw.reshape(sb_rows, lfm_stride)[:, :lfm_stride - 1].copy()
+
+
+def oracle_tq_batch_dist(case):
+    """oracle_tq_batch + the per-block coefficient-domain distortion pairs (T3)."""
+    recon = np.zeros_like(case["src"])
+    q = np.zeros(case["n_coeff"], np.int16)
+    dq = np.zeros(case["n_coeff"], np.int16)
+    eob = np.zeros(len(case["blocks"]), np.uint16)
+    dist = np.zeros((len(case["blocks"]), 2), np.uint64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = oracle().svt_oracle_tq_batch_dist(vp(case["src"]), vp(case["pred"]), vp(recon), vp(case["blocks"]), len(case["blocks"]),
+                                           vp(case["qtabs"]), vp(case["iscan"]), vp(q), vp(dq), vp(eob), vp(dist))
+    assert rc == 0
+    return recon, q, dq, eob, dist
+
+
+def hip_tq_batch_dist_device(ctx, case):
+    """svt_hip_tq_batch_dist_device on device buffers allocated with torch (GPU tests only)."""
+    import torch
+    lib = B.load()
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
+    src, pred, blocks, qt, isc = up(case["src"]), up(case["pred"]), up(case["blocks"]), up(case["qtabs"]), up(case["iscan"])
+    recon = torch.zeros(case["src"].size, dtype=torch.uint8, device=dev)
+    q = torch.zeros(case["n_coeff"], dtype=torch.int16, device=dev)
+    dq = torch.zeros(case["n_coeff"], dtype=torch.int16, device=dev)
+    eob = torch.zeros(len(case["blocks"]), dtype=torch.int16, device=dev)
+    dist = torch.zeros(2 * len(case["blocks"]), dtype=torch.int64, device=dev)
+    cnt = (C.c_int32 * 4)(*[int(v) for v in case["counts"]])
+    p = lambda t: C.c_void_p(t.data_ptr())
+    B.check(lib.svt_hip_tq_batch_dist_device(ctx, p(src), p(pred), p(recon), p(blocks), cnt, p(qt), p(isc), p(q), p(dq), p(eob), p(dist)))
+    B.check(lib.svt_hip_ctx_synchronize(ctx))
+    return (recon.cpu().numpy().reshape(case["src"].shape), q.cpu().numpy(), dq.cpu().numpy(), eob.cpu().numpy().view(np.uint16),
+            dist.cpu().numpy().view(np.uint64).reshape(-1, 2))

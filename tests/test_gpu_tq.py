@@ -48,3 +48,14 @@ def test_tq_rejects_ungrouped_blocks(ctx):
     case["blocks"] = case["blocks"][::-1].copy()
     with pytest.raises(RuntimeError):
         T.hip_tq_batch(ctx, case)
+
+
+@pytest.mark.parametrize("seed,extreme", [(1, False), (3, False), (11, True)])
+def test_tq_distortion_pairs_vs_oracle(ctx, seed, extreme):
+    """T3: coefficient-domain distortion (full_distortion_kernel32bit) fused into the TQ batch, device-pointer ABI."""
+    case = T.make_tq_case(seed, extreme=extreme, qsteps=((4, 4), (1336, 1828), (40, 48)) if extreme else ((40, 48), (8, 9), (200, 260)))
+    o = T.oracle_tq_batch_dist(case)
+    g = T.hip_tq_batch_dist_device(ctx, case)
+    for n, a, b in zip(("recon", "qcoeff", "dqcoeff", "eob", "dist"), o, g):
+        assert np.array_equal(a, b), (n, int(np.sum(a != b)))
+    assert (o[4][:, 0] != o[4][:, 1]).any() and o[4].max() > 0

@@ -1,5 +1,7 @@
 """CPU: the oracle (our restatement) against (a) the committed golden vectors produced by the reference
 (tests/golden/*.npz, generator tests/gen_golden.py) and (b) the reference itself when oracle/_ref is present."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -121,3 +123,22 @@ def test_lf_frame_vs_reference(w, h, seed, sharp):
     for y_only in (False, True):
         o, r = T.oracle_lf_frame(case, y_only), T.ref_lf_frame(case, y_only)
         assert all(np.array_equal(a, b) for a, b in zip(o, r))
+
+
+@live
+def test_full_distortion_vs_reference_leaf():
+    """T3: the oracle's coefficient-domain distortion vs the reference's full_distortion_kernel32bit, including
+    differences that do not fit int16 (the reference squares them after an int16 truncation)."""
+    ref = T.ref_kernels()
+    rng = np.random.default_rng(21)
+    for n in (4, 8, 16, 32):
+        for hi in (300, 32767):
+            a = rng.integers(-hi, hi + 1, (n, n)).astype(np.int16)
+            b = rng.integers(-hi, hi + 1, (n, n)).astype(np.int16)
+            want = np.zeros(2, np.uint64)
+            ref.full_distortion_kernel32bit(a.ctypes.data_as(C.c_void_p), n, b.ctypes.data_as(C.c_void_p), n,
+                                            want.ctypes.data_as(C.c_void_p), n, n)
+            got = np.zeros(2, np.uint64)
+            T.oracle().svt_oracle_full_distortion32(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), n * n,
+                                                    got.ctypes.data_as(C.c_void_p))
+            assert np.array_equal(want, got), (n, hi, want, got)
