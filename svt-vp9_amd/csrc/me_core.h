@@ -262,6 +262,7 @@ typedef struct me_state_t {
     uint32_t red[8];           /* small sum reductions */
     uint32_t supel[9];         /* su_pel_enable sums: sx,sy,ssad for 32/16/8 */
     uint32_t best_ssd[85];     /* SSD_SEARCH: SSD of the current best sub-pel position of each PU (current list) */
+    svt_plane refd[3];         /* descriptors (full, 1/4, 1/16) of the current list's reference picture, copied from HBM once */
     uint8_t  dir[85];
     uint8_t  sixteenth_sb[16 * 8];
 } me_state_t;
@@ -280,13 +281,14 @@ SVT_DEV void me_pu_geom(int pu, int *x, int *y, int *w) {
     else { *x = ((pu - 21) & 7) * 8; *y = ((pu - 21) >> 3) * 8; *w = 8; }
 }
 
-/* unaligned 32-bit fetch from a byte address (LDS or global): two aligned loads + v_alignbyte */
+/* unaligned 32-bit fetch from a byte address (LDS or global): two aligned loads + v_alignbyte.  Branch-free on
+ * purpose: a conditional second load serialises the two memory round trips and keeps the compiler from batching the
+ * loads of unrolled callers.  An aligned address re-reads its own dword, so nothing beyond the 4 bytes is touched. */
 SVT_DEV uint32_t me_ld32u(const uint8_t *p) {
-    uint32_t        sh = (uint32_t)((uintptr_t)p & 3);
+    const uint32_t  sh = (uint32_t)((uintptr_t)p & 3);
     const uint32_t *q  = (const uint32_t *)(p - sh);
-    uint32_t        lo = q[0];
-    if (sh == 0) return lo;
-    return svt_alignbyte(q[1], lo, sh);
+    const uint32_t  lo = q[0], hi = q[sh ? 1 : 0];
+    return svt_alignbyte(hi, lo, sh);
 }
 
 /* [quirk] origin is updated first and the width test re-evaluated afterwards, so left/top clipping never
@@ -1012,8 +1014,16 @@ SVT_DEV void ph_output(const me_ctx_t *c, int tid, svt_me_pu_result *out, uint32
 #define ME_SUBMARK_BEGIN() unsigned long long sub_t_ = c->prof ? __builtin_amdgcn_s_memtime() : 0
 #define ME_SUBMARK(i) do { if (c->prof && tid == 0) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
         atomicAdd(&c->prof[(i)], now_ - sub_t_); sub_t_ = now_; } } while (0)
+#ifdef ME_FINE_PROF
+/* instruction-count profiling builds: the kernel stops (all threads) at mark g_me_stop_after of the first list, so
+ * that per-dispatch SQ counters of successive launches give cumulative instruction counts per phase */
+__device__ int g_me_stop_after = -1;
+#define ME_MARK(i) do { if (c->prof && tid == 0) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        atomicAdd(&c->prof[(i)], now_ - mark_t_); mark_t_ = now_; } if (g_me_stop_after == (i)) return; } while (0)
+#else
 #define ME_MARK(i) do { if (c->prof && tid == 0) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
         atomicAdd(&c->prof[(i)], now_ - mark_t_); mark_t_ = now_; } } while (0)
+#endif
 #endif
 #ifdef SVT_HOST_EMU
 #define ME_PHASE(...) do { for (int tid = 0; tid < SVT_NT; tid++) { __VA_ARGS__; } } while (0)
@@ -1050,35 +1060,59 @@ SVT_DEV void ph_hme_load_multi(const me_ctx_t *c, int tid, const svt_plane *ref,
 }
 
 /* SADs of 4 consecutive search positions (window dwords wr..) against a bw x bh block; window row of block row j is
- * mul*j rows further down.  The packed u16 accumulators are flushed before they can overflow. */
+ * mul*j rows further down.  The packed u16 accumulators are flushed before they can overflow.  Two block rows are
+ * processed per step with independent accumulators and all their LDS loads issued up front: the QSAD chain of one
+ * row overlaps the other's (a dependent v_qsad_pk_u16_u8 costs ~26 cycles, an LDS round trip ~64+). */
+SVT_DEV void me_qsad_row4(const uint32_t *wr, const uint32_t *br, uint64_t *acc) {
+    const uint32_t w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3], w4 = wr[4];
+    const uint32_t b0 = br[0], b1 = br[1], b2 = br[2], b3 = br[3];
+    uint64_t       a = *acc;
+    a = svt_qsad(((uint64_t)w1 << 32) | w0, b0, a);
+    a = svt_qsad(((uint64_t)w2 << 32) | w1, b1, a);
+    a = svt_qsad(((uint64_t)w3 << 32) | w2, b2, a);
+    a = svt_qsad(((uint64_t)w4 << 32) | w3, b3, a);
+    *acc = a;
+}
 SVT_DEV void me_qsad_block(const uint8_t *blk, int bstride, int nd, int bh, const uint8_t *win, int wstride, int mul, uint32_t a[4]) {
     const int flush = nd <= 4 ? 16 : nd <= 8 ? 8 : 4; /* rows whose sums (4*nd*255 each) still fit 16 bits */
     a[0] = a[1] = a[2] = a[3] = 0;
     for (int j0 = 0; j0 < bh; j0 += flush) {
-        uint64_t  acc = 0;
+        uint64_t  acc0 = 0, acc1 = 0; /* even / odd rows of the group: each holds at most flush/2 rows */
         const int j1  = j0 + flush < bh ? j0 + flush : bh;
-        for (int j = j0; j < j1; j++) {
-            const uint32_t *wr = (const uint32_t *)(win + mul * j * wstride);
-            const uint32_t *br = (const uint32_t *)(blk + j * bstride);
-            uint32_t        lo = wr[0];
-            int             i  = 0;
-            for (; i + 4 <= nd; i += 4) {
-                uint32_t h0 = wr[i + 1], h1 = wr[i + 2], h2 = wr[i + 3], h3 = wr[i + 4];
-                uint32_t b0 = br[i], b1 = br[i + 1], b2 = br[i + 2], b3 = br[i + 3];
-                acc = svt_qsad(((uint64_t)h0 << 32) | lo, b0, acc);
-                acc = svt_qsad(((uint64_t)h1 << 32) | h0, b1, acc);
-                acc = svt_qsad(((uint64_t)h2 << 32) | h1, b2, acc);
-                acc = svt_qsad(((uint64_t)h3 << 32) | h2, b3, acc);
-                lo  = h3;
-            }
-            for (; i < nd; i++) {
-                uint32_t hi = wr[i + 1];
-                acc         = svt_qsad(((uint64_t)hi << 32) | lo, br[i], acc);
-                lo          = hi;
+        int       j   = j0;
+        if (nd == 4) { /* 16-sample rows (1/16-resolution level): the whole row pair is loaded before the first QSAD */
+            for (; j + 2 <= j1; j += 2) {
+                const uint32_t *wa = (const uint32_t *)(win + mul * j * wstride), *wb = (const uint32_t *)(win + mul * (j + 1) * wstride);
+                const uint32_t *ba = (const uint32_t *)(blk + j * bstride), *bb = (const uint32_t *)(blk + (j + 1) * bstride);
+                const uint32_t  x0 = wa[0], x1 = wa[1], x2 = wa[2], x3 = wa[3], x4 = wa[4];
+                const uint32_t  y0 = wb[0], y1 = wb[1], y2 = wb[2], y3 = wb[3], y4 = wb[4];
+                const uint32_t  p0 = ba[0], p1 = ba[1], p2 = ba[2], p3 = ba[3], q0 = bb[0], q1 = bb[1], q2 = bb[2], q3 = bb[3];
+                acc0 = svt_qsad(((uint64_t)x1 << 32) | x0, p0, acc0); acc1 = svt_qsad(((uint64_t)y1 << 32) | y0, q0, acc1);
+                acc0 = svt_qsad(((uint64_t)x2 << 32) | x1, p1, acc0); acc1 = svt_qsad(((uint64_t)y2 << 32) | y1, q1, acc1);
+                acc0 = svt_qsad(((uint64_t)x3 << 32) | x2, p2, acc0); acc1 = svt_qsad(((uint64_t)y3 << 32) | y2, q2, acc1);
+                acc0 = svt_qsad(((uint64_t)x4 << 32) | x3, p3, acc0); acc1 = svt_qsad(((uint64_t)y4 << 32) | y3, q3, acc1);
             }
         }
-        a[0] += (uint32_t)(acc & 0xffff); a[1] += (uint32_t)((acc >> 16) & 0xffff);
-        a[2] += (uint32_t)((acc >> 32) & 0xffff); a[3] += (uint32_t)(acc >> 48);
+        for (; j < j1; j++) {
+            const uint32_t *wr = (const uint32_t *)(win + mul * j * wstride);
+            const uint32_t *br = (const uint32_t *)(blk + j * bstride);
+            uint64_t        acc = (j & 1) ? acc1 : acc0;
+            int             i = 0;
+            for (; i + 4 <= nd; i += 4) me_qsad_row4(wr + i, br + i, &acc);
+            if (i < nd) {
+                uint32_t lo = wr[i];
+                for (; i < nd; i++) {
+                    uint32_t hi = wr[i + 1];
+                    acc         = svt_qsad(((uint64_t)hi << 32) | lo, br[i], acc);
+                    lo          = hi;
+                }
+            }
+            if (j & 1) acc1 = acc; else acc0 = acc;
+        }
+        a[0] += (uint32_t)(acc0 & 0xffff) + (uint32_t)(acc1 & 0xffff);
+        a[1] += (uint32_t)((acc0 >> 16) & 0xffff) + (uint32_t)((acc1 >> 16) & 0xffff);
+        a[2] += (uint32_t)((acc0 >> 32) & 0xffff) + (uint32_t)((acc1 >> 32) & 0xffff);
+        a[3] += (uint32_t)(acc0 >> 48) + (uint32_t)(acc1 >> 48);
     }
 }
 
@@ -1088,17 +1122,25 @@ SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk,
                                  int e0, int e1, int ntask, uint64_t *keys) {
     const int qs = (bw & 3) == 0; /* QSAD path: task = 4 positions */
     uint64_t  best[4] = {~0ull, ~0ull, ~0ull, ~0ull}; /* per key slot */
+#ifdef ME_FINE_PROF
+    unsigned long long ft_ = __builtin_amdgcn_s_memtime();
+#define FP(i) do { if (c->prof && tid == 0) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&c->prof[i], n_ - ft_); ft_ = n_; } } while (0)
+#else
+#define FP(i) ((void)0)
+#endif
     for (int T = tid; T < ntask; T += SVT_NT) {
         int e = e0;
         while (e + 1 < e1 && T >= wn[e + 1].ts) e++;
         const int      t = T - wn[e].ts, ws = wn[e].wstride, sw = wn[e].sw, slot = wn[e].slot, idx0 = wn[e].idx0;
         const uint8_t *win = c->planes + wn[e].off;
         uint64_t       kb = ~0ull;
+        FP(16);
         if (qs) {
             const int ng = (sw + 3) >> 2;
             const int y = t / ng, g = t - y * ng;
             uint32_t  a[4];
             me_qsad_block(blk, bstride, bw >> 2, bh, win + y * ws + 4 * g, ws, 2, a);
+            FP(17);
             _Pragma("unroll") for (int o = 0; o < 4; o++) {
                 int x = 4 * g + o;
                 if (x < sw) {
@@ -1117,9 +1159,12 @@ SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk,
             kb = ((uint64_t)sd << 32) | (uint32_t)(idx0 + t);
         }
         _Pragma("unroll") for (int q = 0; q < 4; q++) if (q == slot && kb < best[q]) best[q] = kb;
+        FP(18);
     }
     /* every lane takes part in the 4 wave reductions (lanes without work contribute ~0) */
     _Pragma("unroll") for (int q = 0; q < 4; q++) svt_wave_min_u64(&keys[q], best[q]);
+    FP(19);
+#undef FP
 }
 
 typedef struct me_hme_geom {
@@ -1142,13 +1187,13 @@ __attribute__((unused)) static
 /* geometry of an HME level for one reference list (hme_level0/1/2 of Codec/EbMotionEstimation.c) */
 SVT_DEV void me_hme_geom_of(const me_ctx_t *c, int list, int lvl, me_hme_geom *g) {
     if (lvl == 0) {
-        g->ref = &c->pic->ref[list].sixteenth; g->blk = c->st->sixteenth_sb; g->bstride = 16; g->bw = c->sb_w >> 2; g->bh = (c->sb_h >> 2) >> 1;
+        g->ref = &c->st->refd[2]; g->blk = c->st->sixteenth_sb; g->bstride = 16; g->bw = c->sb_w >> 2; g->bh = (c->sb_h >> 2) >> 1;
         g->ox = (int16_t)(c->sb_x >> 2); g->oy = (int16_t)(c->sb_y >> 2);
     } else if (lvl == 1) {
-        g->ref = &c->pic->ref[list].quarter; g->blk = c->quarter_sb; g->bstride = 64; g->bw = c->sb_w >> 1; g->bh = (c->sb_h >> 1) >> 1;
+        g->ref = &c->st->refd[1]; g->blk = c->quarter_sb; g->bstride = 64; g->bw = c->sb_w >> 1; g->bh = (c->sb_h >> 1) >> 1;
         g->ox = (int16_t)(c->sb_x >> 1); g->oy = (int16_t)(c->sb_y >> 1);
     } else {
-        g->ref = &c->pic->ref[list].full; g->blk = c->src; g->bstride = 2 * ME_SB; g->bw = c->sb_w; g->bh = c->sb_h >> 1;
+        g->ref = &c->st->refd[0]; g->blk = c->src; g->bstride = 2 * ME_SB; g->bw = c->sb_w; g->bh = c->sb_h >> 1;
         g->ox = (int16_t)c->sb_x; g->oy = (int16_t)c->sb_y;
     }
     g->pad_w = lvl == 2 ? ME_SB - 1 : g->ref->origin_x - 1;
@@ -1326,7 +1371,9 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
     ME_MARK(0);
 
     for (int list = 0; list < nlist; list++) {
-        const svt_plane *rf = &c->pic->ref[list].full, *rq = &c->pic->ref[list].quarter, *r16 = &c->pic->ref[list].sixteenth;
+        /* the reference's plane descriptors are read many times (address arithmetic, clipping): keep them in LDS */
+        ME_PHASE(if (tid < (int)(3 * sizeof(svt_plane) / 4)) ((uint32_t *)st->refd)[tid] = ((const uint32_t *)&c->pic->ref[list])[tid]);
+        const svt_plane *rf = &st->refd[0];
         const int        ox = (int16_t)c->sb_x, oy = (int16_t)c->sb_y;
         if (p->temporal_layer_index > 0 || list == 0) {
             /* ---- test_search_area_bounds ---- */

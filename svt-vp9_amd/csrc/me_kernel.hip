@@ -134,15 +134,18 @@ extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, con
     static const bool want_prof = getenv("SVT_HIP_ME_PROFILE") != nullptr;
     unsigned long long *d_prof = nullptr;
     if (want_prof) {
-        d_prof = (unsigned long long *)svt_ctx_slot(ctx, 9 + 14, 16 * sizeof(unsigned long long));
-        if (d_prof) HIP_TRY(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), ctx->stream));
+        d_prof = (unsigned long long *)svt_ctx_slot(ctx, 9 + 14, 32 * sizeof(unsigned long long));
+        if (d_prof) HIP_TRY(hipMemsetAsync(d_prof, 0, 32 * sizeof(unsigned long long), ctx->stream));
     }
+#ifdef ME_FINE_PROF
+    { const char *sa = getenv("SVT_HIP_ME_STOP"); int v = sa ? atoi(sa) : -1; HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_me_stop_after), &v, sizeof v, 0, hipMemcpyHostToDevice, ctx->stream)); }
+#endif
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
     hipLaunchKernelGGL(svt_me_sb_kernel, dim3(chunk * 8), dim3(256), L.total_bytes, ctx->stream, d, *params, L, n_sb, nx, W, H, total, chunk, d_prof);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     if (d_prof) {
-        unsigned long long hp[16];
+        unsigned long long hp[32];
         HIP_TRY(hipMemcpyAsync(hp, d_prof, sizeof hp, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         static const char *nm[14] = {"init", "center_sads", "hme", "zero_check", "region_load", "fullpel_sad8", "fullpel_argmin",
@@ -151,7 +154,11 @@ extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, con
         for (int i = 0; i < 14; i++) tot += hp[i];
         fprintf(stderr, "[me-profile] tl=%d pics=%d WGs=%d avg cycles/WG=%llu :", params->temporal_layer_index, n_pics, total, tot / (unsigned long long)total);
         for (int i = 0; i < 14; i++) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * (double)hp[i] / (double)tot);
-        fprintf(stderr, " | hme_load=%.1f%% hme_search=%.1f%%\n", 100.0 * (double)hp[14] / (double)tot, 100.0 * (double)hp[15] / (double)tot);
+        fprintf(stderr, " | hme_load=%.1f%% hme_search=%.1f%%", 100.0 * (double)hp[14] / (double)tot, 100.0 * (double)hp[15] / (double)tot);
+        if (hp[16] | hp[17] | hp[18] | hp[19]) /* fine marks (builds with -DME_FINE_PROF): entry lookup, qsad block, key update, wave reductions */
+            fprintf(stderr, " fine[lookup=%.1f%% qsad=%.1f%% keys=%.1f%% reduce=%.1f%%]", 100.0 * (double)hp[16] / (double)tot,
+                    100.0 * (double)hp[17] / (double)tot, 100.0 * (double)hp[18] / (double)tot, 100.0 * (double)hp[19] / (double)tot);
+        fprintf(stderr, "\n");
     }
     svt_ctx_stage_commit(ctx);
     ctx->timed = 1;
