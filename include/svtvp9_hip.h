@@ -199,6 +199,24 @@ int32_t svt_hip_sad_loop_batch_device(svt_hip_ctx *ctx, const uint8_t *d_src, co
                                       const svt_sad_loop_job *d_jobs, int32_t n_jobs,
                                       svt_sad_loop_result *d_out);
 
+/* Per-SB side outputs of the ME stage (row M12 of the scope table).
+ *
+ * svt_hip_me_zz_sad_device = compute_zz_sad (Codec/EbMotionEstimationProcess.c:431-534): for every complete SB the
+ * 16x16 SAD between the current picture's 1/16 plane and the 4x4 point-decimated collocated SB of the PREVIOUS
+ * picture's input (eb_vp9_decimation_2d, Codec/EbPictureAnalysisProcess.c:102-122); incomplete SBs get 0xffffffff.
+ * d_non_moving_index[sb] = NON_MOVING_SCORE_{0,1,2,3} = 0/10/20/30 from the thresholds 2,4,8 x (16*16) >>
+ * non_moving_th_shift[input_resolution] (:353; input_resolution 0..3 = <=576p, 720p, 1080p, 2160p) -- the value the
+ * reference stores into the previous picture's non_moving_index_array.  Planes are device resident. */
+int32_t svt_hip_me_zz_sad_device(svt_hip_ctx *ctx, const svt_plane *cur_sixteenth, const svt_plane *prev_input,
+                                 int32_t input_resolution, uint32_t *d_zz_sad, uint8_t *d_non_moving_index);
+
+/* Host-side: eb_vp9_derive_similar_collocated_flag (Codec/EbMotionEstimationProcess.c:747-783) for n SBs: compares the
+ * 64x64 mean / variance of each SB (picture analysis outputs) with the list-0 reference's.  similar[sb] is only set
+ * when the picture is used as a reference, similar_all_layers[sb] always. */
+void svt_hip_me_similar_collocated(const uint8_t *cur_mean, const uint16_t *cur_var, const uint8_t *ref_mean,
+                                   const uint16_t *ref_var, int32_t n_sb, int32_t is_i_slice,
+                                   int32_t is_used_as_reference, uint8_t *similar, uint8_t *similar_all_layers);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* Transform / quantisation                                                                           */
 /* ------------------------------------------------------------------------------------------------ */

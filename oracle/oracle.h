@@ -36,4 +36,8 @@ void    svt_oracle_full_distortion32(const int16_t *coeff, const int16_t *recon_
 int32_t svt_oracle_tq_batch_dist(const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks,
                                  int32_t n_blocks, const svt_quant_tables *qtabs, const int16_t *iscan, int16_t *qcoeff,
                                  int16_t *dqcoeff, uint16_t *eob, uint64_t *dist);
+/* M12: compute_zz_sad and eb_vp9_derive_similar_collocated_flag (Codec/EbMotionEstimationProcess.c:431-534, 747-783) */
+int32_t svt_oracle_me_zz_sad(const svt_plane *cur16, const svt_plane *prev, int32_t input_resolution, uint32_t *zz, uint8_t *nmi);
+void    svt_oracle_me_similar_collocated(const uint8_t *cur_mean, const uint16_t *cur_var, const uint8_t *ref_mean, const uint16_t *ref_var,
+                                         int32_t n_sb, int32_t is_i_slice, int32_t is_used_as_reference, uint8_t *similar, uint8_t *similar_all);
 #endif

@@ -910,3 +910,45 @@ int32_t svt_oracle_me_picture(const svt_pa_picture *cur, const svt_pa_picture *r
     free(s);
     return 0;
 }
+
+
+/* M12: compute_zz_sad (Codec/EbMotionEstimationProcess.c:431-534) with eb_vp9_decimation_2d
+ * (Codec/EbPictureAnalysisProcess.c:102-122, step 4) and the 16x16 SAD (C_DEFAULT/EbComputeSAD_C.c:113-130). */
+int32_t svt_oracle_me_zz_sad(const svt_plane *cur16, const svt_plane *prev, int32_t input_resolution, uint32_t *zz, uint8_t *nmi) {
+    static const int th_shift[4] = {4, 2, 0, 0};
+    const int nx = (prev->width + 63) / 64, ny = (prev->height + 63) / 64;
+    for (int sy = 0; sy < ny; sy++)
+        for (int sx = 0; sx < nx; sx++) {
+            const int sb = sy * nx + sx, ox = sx * 64, oy = sy * 64;
+            const int bw = (prev->width - ox < 64 ? prev->width - ox : 64) >> 2, bh = (prev->height - oy < 64 ? prev->height - oy : 64) >> 2;
+            uint32_t  v = 0xffffffffu;
+            if (ox + 64 <= prev->width && oy + 64 <= prev->height) {
+                uint8_t dec[16 * 16];
+                const uint8_t *in = prev->buf + (size_t)(prev->origin_y + oy) * prev->stride + prev->origin_x + ox;
+                for (int y = 0; y < 64; y += 4)
+                    for (int x = 0; x < 64; x += 4) dec[(y >> 2) * 16 + (x >> 2)] = in[(size_t)y * prev->stride + x];
+                const uint8_t *c = cur16->buf + (size_t)(cur16->origin_y + (oy >> 2)) * cur16->stride + cur16->origin_x + (ox >> 2);
+                v = oracle_sad_nxm(c, cur16->stride, dec, 16, 16, 16);
+            }
+            zz[sb] = v;
+            const uint32_t base = (uint32_t)(bw * bh);
+            const int      sh = th_shift[input_resolution];
+            nmi[sb] = v < ((base * 2) >> sh) ? 0 : v < ((base * 4) >> sh) ? 10 : v < ((base * 8) >> sh) ? 20 : 30;
+        }
+    return 0;
+}
+
+/* eb_vp9_derive_similar_collocated_flag (Codec/EbMotionEstimationProcess.c:747-783) */
+void svt_oracle_me_similar_collocated(const uint8_t *cur_mean, const uint16_t *cur_var, const uint8_t *ref_mean, const uint16_t *ref_var,
+                                      int32_t n_sb, int32_t is_i_slice, int32_t is_used_as_reference, uint8_t *similar, uint8_t *similar_all) {
+    for (int sb = 0; sb < n_sb; sb++) {
+        similar[sb] = 0; similar_all[sb] = 0;
+        if (is_i_slice) continue;
+        int64_t rv = ref_var[sb] > 1 ? ref_var[sb] : 1;
+        int64_t a = (int64_t)cur_mean[sb] - ref_mean[sb], b = (int64_t)cur_var[sb] * 100 / rv - 100, c = (int64_t)cur_var[sb] - rv;
+        if ((a < 0 ? -a : a) < 10 && ((b < 0 ? -b : b) < 10 || (c < 0 ? -c : c) < 10)) {
+            if (is_used_as_reference) similar[sb] = 1;
+            similar_all[sb] = 1;
+        }
+    }
+}

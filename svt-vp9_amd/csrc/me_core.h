@@ -128,6 +128,12 @@ SVT_DEV void svt_wave_add_u32(uint32_t *p, uint32_t v, int uniform_dst) {
                        (uint32_t)__builtin_amdgcn_readlane((int)v, 47) + (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
     if ((threadIdx.x & 63) == 0 && t) atomicAdd(p, t);
 }
+/* sum over the wave, result in every lane's *v (all lanes must call) */
+SVT_DEV void svt_wave_add_u32_to_lane0(uint32_t *v) {
+    uint32_t x = svt_row_prefix_add(*v, 16);
+    *v = (uint32_t)__builtin_amdgcn_readlane((int)x, 15) + (uint32_t)__builtin_amdgcn_readlane((int)x, 31) +
+         (uint32_t)__builtin_amdgcn_readlane((int)x, 47) + (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
 /* min over the wave of 64-bit keys (all lanes must call; pass ~0 for "nothing"), then ONE LDS atomic */
 SVT_DEV void svt_wave_min_u64(uint64_t *p, uint64_t v) {
 #define SVT_DPP_MIN64(ctrl) do { \

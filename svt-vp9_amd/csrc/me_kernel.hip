@@ -212,6 +212,45 @@ extern "C" int32_t svt_hip_me_picture(svt_hip_ctx *ctx, const svt_pa_picture *cu
     return SVT_HIP_OK;
 }
 
+/* compute_zz_sad (Codec/EbMotionEstimationProcess.c:431-534): one wave per SB, lane = 4 samples of the 16x16 block */
+__global__ __launch_bounds__(256) void svt_me_zz_sad_kernel(svt_plane cur16, svt_plane prev, int nx, int n_sb, int shift,
+                                                            uint32_t *__restrict__ zz, uint8_t *__restrict__ nmi) {
+    const int sb = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (sb >= n_sb) return;
+    const int sx = (sb % nx) * ME_SB, sy = (sb / nx) * ME_SB;
+    const int complete = sx + ME_SB <= prev.width && sy + ME_SB <= prev.height;
+    uint32_t  sad = 0;
+    if (complete) {
+        const int r = lane >> 2, c4 = (lane & 3) * 4; /* row of the 16x16 block, first of 4 columns */
+        const uint8_t *a = cur16.buf + (size_t)(cur16.origin_y + (sy >> 2) + r) * cur16.stride + cur16.origin_x + (sx >> 2) + c4;
+        const uint8_t *b = prev.buf + (size_t)(prev.origin_y + sy + 4 * r) * prev.stride + prev.origin_x + sx + 4 * c4;
+        _Pragma("unroll") for (int k = 0; k < 4; k++) { const int d = (int)a[k] - (int)b[4 * k]; sad += (uint32_t)(d < 0 ? -d : d); }
+    }
+    svt_wave_add_u32_to_lane0(&sad);
+    if (lane == 0) {
+        const uint32_t v = complete ? sad : 0xffffffffu;
+        zz[sb] = v;
+        const uint32_t base = 16 * 16; /* block_width * block_height of a complete SB's 1/16 block */
+        nmi[sb] = v < ((base * 2) >> shift) ? 0 : v < ((base * 4) >> shift) ? 10 : v < ((base * 8) >> shift) ? 20 : 30;
+    }
+}
+
+extern "C" int32_t svt_hip_me_zz_sad_device(svt_hip_ctx *ctx, const svt_plane *cur_sixteenth, const svt_plane *prev_input,
+                                            int32_t input_resolution, uint32_t *d_zz_sad, uint8_t *d_non_moving_index) {
+    if (!ctx || !cur_sixteenth || !prev_input || !d_zz_sad || !d_non_moving_index || input_resolution < 0 || input_resolution > 3)
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "zz_sad: bad argument");
+    static const int th_shift[4] = {4, 2, 0, 0}; /* non_moving_th_shift, Codec/EbMotionEstimationProcess.c:353 */
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int nx = (prev_input->width + ME_SB - 1) / ME_SB, ny = (prev_input->height + ME_SB - 1) / ME_SB, n_sb = nx * ny;
+    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    hipLaunchKernelGGL(svt_me_zz_sad_kernel, dim3((n_sb + 3) / 4), dim3(256), 0, ctx->stream, *cur_sixteenth, *prev_input, nx, n_sb,
+                       th_shift[input_resolution], d_zz_sad, d_non_moving_index);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->timed = 1;
+    return SVT_HIP_OK;
+}
+
 extern "C" int32_t svt_hip_sad_loop_batch_device(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_ref,
                                                  const svt_sad_loop_job *d_jobs, int32_t n_jobs, svt_sad_loop_result *d_out) {
     if (!ctx || !d_src || !d_ref || !d_jobs || !d_out || n_jobs < 1) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "sad_loop: null argument");

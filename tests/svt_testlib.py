@@ -731,3 +731,31 @@ def hip_tq_batch_dist_device(ctx, case):
     B.check(lib.svt_hip_ctx_synchronize(ctx))
     return (recon.cpu().numpy().reshape(case["src"].shape), q.cpu().numpy(), dq.cpu().numpy(), eob.cpu().numpy().view(np.uint16),
             dist.cpu().numpy().view(np.uint64).reshape(-1, 2))
+
+
+# ---------------------------------------------------------------------------------------------------
+# M12 side outputs
+# ---------------------------------------------------------------------------------------------------
+def oracle_me_zz_sad(cur, prev, input_resolution):
+    """cur, prev: PaPic of the current and the previous picture.  Returns (zz_sad[n_sb], non_moving_index[n_sb])."""
+    dc, dp = cur.desc(), prev.desc()
+    n = n_sb(prev.luma.shape[1], prev.luma.shape[0])
+    zz, nmi = np.zeros(n, np.uint32), np.zeros(n, np.uint8)
+    rc = oracle().svt_oracle_me_zz_sad(C.byref(dc.sixteenth), C.byref(dp.full), input_resolution, zz.ctypes.data_as(C.c_void_p),
+                                       nmi.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return zz, nmi
+
+
+def hip_me_zz_sad(ctx, cur, prev, input_resolution):
+    import torch
+    lib = B.load()
+    dev = torch.device("cuda", 0)
+    (c16, pad16), (pf, padf) = cur.planes()[2], prev.planes()[0]
+    t16, tf = torch.from_numpy(np.ascontiguousarray(c16)).to(dev), torch.from_numpy(np.ascontiguousarray(pf)).to(dev)
+    n = n_sb(prev.luma.shape[1], prev.luma.shape[0])
+    zz, nmi = torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)
+    a, b = B.plane_desc(c16, pad16, pad16, ptr=t16.data_ptr()), B.plane_desc(pf, padf, padf, ptr=tf.data_ptr())
+    B.check(lib.svt_hip_me_zz_sad_device(ctx, C.byref(a), C.byref(b), input_resolution, C.c_void_p(zz.data_ptr()), C.c_void_p(nmi.data_ptr())))
+    B.check(lib.svt_hip_ctx_synchronize(ctx))
+    return zz.cpu().numpy().view(np.uint32), nmi.cpu().numpy()

@@ -1,0 +1,78 @@
+"""M12 per-SB side outputs: ZZ-SAD / non-moving index (GPU kernel vs oracle) and the similar-collocated flag (host C vs
+oracle).  The oracle's ZZ-SAD is checked against an independent numpy formulation of compute_zz_sad and its SAD leaf
+against the reference kernel when oracle/_ref is present."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import svt_testlib as T
+
+B = T.B
+
+
+def _numpy_zz(cur, prev, shift):
+    h, w = prev.shape
+    ny, nx = (h + 63) // 64, (w + 63) // 64
+    zz, nmi = np.zeros(ny * nx, np.uint32), np.zeros(ny * nx, np.uint8)
+    c16 = cur[::4, ::4].astype(np.int32)
+    for sy in range(ny):
+        for sx in range(nx):
+            sb = sy * nx + sx
+            if sx * 64 + 64 <= w and sy * 64 + 64 <= h:
+                d = prev[sy * 64:sy * 64 + 64:4, sx * 64:sx * 64 + 64:4].astype(np.int32)
+                v = int(np.abs(c16[sy * 16:sy * 16 + 16, sx * 16:sx * 16 + 16] - d).sum())
+                base = 256
+            else:
+                v = 0xFFFFFFFF
+                base = (min(64, w - sx * 64) >> 2) * (min(64, h - sy * 64) >> 2)
+            zz[sb] = v
+            nmi[sb] = 0 if v < (base * 2) >> shift else 10 if v < (base * 4) >> shift else 20 if v < (base * 8) >> shift else 30
+    return zz, nmi
+
+
+@pytest.mark.parametrize("res", [0, 2, 3])
+def test_oracle_zz_sad_vs_numpy(res):
+    f = T.gen_clip(328, 200, 2, 31)
+    f[1][:64, :128] = f[0][:64, :128]            # two static SBs -> score 0
+    f[1][64:128, :64] = np.clip(f[0][64:128, :64].astype(np.int16) + 3, 0, 255).astype(np.uint8)
+    zz, nmi = T.oracle_me_zz_sad(T.PaPic(f[1]), T.PaPic(f[0]), res)
+    wz, wn = _numpy_zz(f[1], f[0], [4, 2, 0, 0][res])
+    assert np.array_equal(zz, wz) and np.array_equal(nmi, wn)
+    assert zz[0] == 0 and nmi[0] == 0 and (zz == 0xFFFFFFFF).any() and len(set(nmi.tolist())) >= 2
+
+
+def test_similar_collocated_host_vs_oracle():
+    rng = np.random.default_rng(4)
+    n = 4000
+    cm, rm = rng.integers(0, 256, n).astype(np.uint8), rng.integers(0, 256, n).astype(np.uint8)
+    rm[: n // 2] = np.clip(cm[: n // 2].astype(np.int16) + rng.integers(-12, 13, n // 2), 0, 255).astype(np.uint8)
+    cv = rng.integers(0, 3000, n).astype(np.uint16)
+    rv = np.clip(cv.astype(np.int32) + rng.integers(-40, 41, n), 0, 65535).astype(np.uint16)
+    rv[::7] = 0
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    for i_slice in (0, 1):
+        for is_ref in (0, 1):
+            a, b, c, d = (np.zeros(n, np.uint8) for _ in range(4))
+            B.load().svt_hip_me_similar_collocated(vp(cm), vp(cv), vp(rm), vp(rv), n, i_slice, is_ref, vp(a), vp(b))
+            T.oracle().svt_oracle_me_similar_collocated(vp(cm), vp(cv), vp(rm), vp(rv), n, i_slice, is_ref, vp(c), vp(d))
+            assert np.array_equal(a, c) and np.array_equal(b, d)
+            if not i_slice:
+                assert 0 < b.sum() < n and (a.sum() > 0) == bool(is_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,res", [(328, 200, 0), (1920, 1080, 2), (3840, 2160, 3)])
+def test_gpu_zz_sad_vs_oracle(w, h, res):
+    lib = B.load()
+    ctx = C.c_void_p()
+    B.check(lib.svt_hip_ctx_create(C.byref(ctx), 0))
+    try:
+        f = T.gen_clip(w, h, 2, 33)
+        f[1][:64, :192] = f[0][:64, :192]
+        cur, prev = T.PaPic(f[1]), T.PaPic(f[0])
+        o = T.oracle_me_zz_sad(cur, prev, res)
+        g = T.hip_me_zz_sad(ctx, cur, prev, res)
+        assert np.array_equal(o[0], g[0]) and np.array_equal(o[1], g[1])
+    finally:
+        lib.svt_hip_ctx_destroy(ctx)
