@@ -71,6 +71,7 @@ static inline void svt_lds_add_u32(uint32_t *p, uint32_t v) { *p += v; }
 static inline void svt_wave_add_u32(uint32_t *p, uint32_t v, int uniform_dst) { (void)uniform_dst; *p += v; }
 static inline void svt_wave_min_u64(uint64_t *p, uint64_t v) { if (v < *p) *p = v; }
 static inline void svt_group_add_u32(uint32_t *p, uint32_t v, int group) { (void)group; *p += v; }
+#define ME_MUL(a, b) ((a) * (b))
 #define SVT_SCHED_FENCE() ((void)0)
 /* per 16-bit lane: min(max(v, 32), 287) - 32 */
 static inline uint32_t svt_pk_clamp_sub32(uint32_t v) {
@@ -108,6 +109,8 @@ SVT_DEV void svt_lds_min_u64(uint64_t *p, uint64_t v) { /* lanes of one instruct
     __hip_atomic_fetch_min((unsigned long long *)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 SVT_DEV void svt_lds_add_u32(uint32_t *p, uint32_t v) { atomicAdd(p, v); }
+/* products of small offsets (rows, strides: far below 2^23): full-rate 24-bit multiply instead of v_mul_lo_u32 */
+#define ME_MUL(a, b) __mul24((int)(a), (int)(b))
 /* Cross-lane reductions use DPP row shifts (a few cycles each) instead of ds_bpermute shuffles (~90 cycles each,
  * measured), and never let several lanes of one instruction hit the same LDS address with an atomic (~100 cycles
  * per lane, measured with tools/ubench_me.hip). */
@@ -246,6 +249,7 @@ typedef struct me_hme_win {
     int32_t slot;     /* region (key) this window belongs to */
     int32_t idx0;     /* raster index of the window's first search position inside its region (row band offset) */
     int32_t tl, ts;   /* first load task / first search task of this window inside its batch */
+    uint32_t inv_nd, inv_ng; /* ceil(2^32 / nd), ceil(2^32 / tasks-per-search-row): t / d = mulhi(t, inv) for t * d < 2^32 */
 } me_hme_win;
 
 /* per-SB state in LDS */
@@ -266,6 +270,7 @@ typedef struct me_state_t {
     uint32_t best_sad[2][85];  /* search (z-order) index */
     uint32_t best_mv[2][85];
     uint32_t red[8];           /* small sum reductions */
+    uint32_t spu[85];          /* refined PUs of the current list, dense: pu | n << 7 | (px>>3) << 14 | (py>>3) << 17 | log2(w/8) << 20 */
     uint32_t supel[9];         /* su_pel_enable sums: sx,sy,ssad for 32/16/8 */
     uint32_t best_ssd[85];     /* SSD_SEARCH: SSD of the current best sub-pel position of each PU (current list) */
     svt_plane refd[3];         /* descriptors (full, 1/4, 1/16) of the current list's reference picture, copied from HBM once */
@@ -475,7 +480,7 @@ SVT_DEV void ph_fullpel_sad8(const me_ctx_t *c, int tid, uint32_t *U, int sw, in
             /* 16x16 block (raster) containing b: z-order 12 -> raster 10 (x=32,y=32), 13 -> raster 11 (x=48,y=32) */
             if (by >= 32 && by < 48 && bx >= 32) rbx += 16;
         }
-        const uint8_t *rp = c->region + (ME_RGN_GY + y0 + yl + by) * rs + ME_RGN_GX + 4 * g + rbx;
+        const uint8_t *rp = c->region + ME_MUL(ME_RGN_GY + y0 + yl + by, rs) + ME_RGN_GX + 4 * g + rbx;
         const uint8_t *sp = c->src + by * ME_SB + bx;
         uint64_t       acc = 0;
         _Pragma("unroll") for (int r = 0; r < 4; r++) {
@@ -485,7 +490,7 @@ SVT_DEV void ph_fullpel_sad8(const me_ctx_t *c, int tid, uint32_t *U, int sw, in
             acc = svt_qsad(((uint64_t)d1 << 32) | d0, s[0], acc);
             acc = svt_qsad(((uint64_t)d2 << 32) | d1, s[1], acc);
         }
-        uint32_t *u = U + (yl * sw + 4 * g) * ME_PU_STRIDE + 21 + me_z8(b);
+        uint32_t *u = U + ME_MUL(ME_MUL(yl, sw) + 4 * g, ME_PU_STRIDE) + 21 + me_z8(b);
         _Pragma("unroll") for (int o = 0; o < 4; o++)
             if (4 * g + o < sw) u[o * ME_PU_STRIDE] = (uint32_t)(acc >> (16 * o)) & 0xffffu;
     }
@@ -543,7 +548,8 @@ SVT_DEV uint8_t me_tap4(int a, int b, int d, int e) { return me_clip8((-2 * a + 
  * outputs.  Even and odd bytes are processed as two 16-bit lanes of one register; a bias of 1024 (= 32 << 5) keeps
  * every lane non-negative so nothing borrows across lanes: floor((S + 1024) / 32) = floor(S / 32) + 32. */
 SVT_DEV uint32_t me_tap4_half(uint32_t a, uint32_t b, uint32_t d, uint32_t e) {
-    uint32_t v = (b + d) * 18u + 0x04100410u - 2u * (a + e); /* per lane: 18(b+d) + 16 + 1024 - 2(a+e) in [20, 10220] */
+    const uint32_t s2 = (b + d) << 1;                          /* 18 x = 16 x + 2 x: shifts, no quarter-rate multiply */
+    uint32_t       v = (s2 << 3) + s2 + 0x04100410u - ((a + e) << 1); /* per lane: 18(b+d) + 16 + 1024 - 2(a+e) in [20, 10220] */
     v = (v >> 5) & 0x07ff07ffu;
     return svt_pk_clamp_sub32(v); /* per lane: min(max(v, 32), 287) - 32 */
 }
@@ -558,46 +564,50 @@ SVT_DEV uint32_t me_tap4_x4(uint32_t a, uint32_t b, uint32_t d, uint32_t e) {
  * (interpolate_search_region_avc, Codec/EbMotionEstimation.c:992-1070; C_DEFAULT/EbAvcStyleMcp_C.c:25-73).
  * One task = one dword (4 samples) of both planes: plane column px is region column px + 2 (ME_RGN_GX - ME_PL_G),
  * so the 7 region bytes a B dword needs sit in two aligned region dwords. */
-#define ME_ILANES 32 /* lanes per plane row (a row has at most (127 + 63 + 4 + 3) / 4 = 50 dwords: two passes) */
+/* task = one dword of one plane row; the (row, dword) pair of a thread advances by 256 tasks per step without a
+ * division (one division per thread up front), so every lane has work whatever the row length is */
 SVT_DEV void ph_interp_bh(const me_ctx_t *c, int tid, int W, int H) {
     int       rs = c->L.region_stride, pwd = (W + 2 * ME_PL_G + 3) >> 2, ph = H + 2 * ME_PL_G;
     uint8_t  *B = c->planes, *Hh = c->planes + c->L.plane_bytes;
-    const int lane = tid & (ME_ILANES - 1), row0 = tid / ME_ILANES;
-    for (int py = row0; py < ph; py += SVT_NT / ME_ILANES)
-        for (int j = lane; j < pwd; j += ME_ILANES) {
-            /* region row of this plane row: y = py - ME_PL_G -> region row ME_RGN_GY + y */
-            const uint8_t  *rr = c->region + (ME_RGN_GY - ME_PL_G + py) * rs + 4 * j;
-            const uint32_t *r0 = (const uint32_t *)rr;
-            uint32_t        lo = r0[0], hi = r0[1];
-            /* bytes b0..b7 = lo,hi; output k uses b[k+1..k+4] */
-            uint32_t t1 = svt_alignbyte(hi, lo, 1), t2 = svt_alignbyte(hi, lo, 2), t3 = svt_alignbyte(hi, lo, 3);
-            *(uint32_t *)(B + py * rs + 4 * j) = me_tap4_x4(t1, t2, t3, hi);
-            /* vertical: samples at region byte offset 4j+2 of rows y-1, y, y+1, y+2 */
-            const uint32_t *ra = (const uint32_t *)(rr - rs), *rb = (const uint32_t *)(rr + rs), *rc = (const uint32_t *)(rr + 2 * rs);
-            uint32_t va = svt_alignbyte(ra[1], ra[0], 2), vc = svt_alignbyte(rb[1], rb[0], 2), vd = svt_alignbyte(rc[1], rc[0], 2);
-            *(uint32_t *)(Hh + py * rs + 4 * j) = me_tap4_x4(va, t2, vc, vd);
-        }
+    const int dpy = SVT_NT / pwd, dj = SVT_NT - dpy * pwd;
+    int       py = tid / pwd, j = tid - py * pwd;
+    while (py < ph) {
+        /* region row of this plane row: y = py - ME_PL_G -> region row ME_RGN_GY + y */
+        const uint8_t  *rr = c->region + ME_MUL(ME_RGN_GY - ME_PL_G + py, rs) + 4 * j;
+        const uint32_t *r0 = (const uint32_t *)rr;
+        uint32_t        lo = r0[0], hi = r0[1];
+        /* bytes b0..b7 = lo,hi; output k uses b[k+1..k+4] */
+        uint32_t t1 = svt_alignbyte(hi, lo, 1), t2 = svt_alignbyte(hi, lo, 2), t3 = svt_alignbyte(hi, lo, 3);
+        *(uint32_t *)(B + ME_MUL(py, rs) + 4 * j) = me_tap4_x4(t1, t2, t3, hi);
+        /* vertical: samples at region byte offset 4j+2 of rows y-1, y, y+1, y+2 */
+        const uint32_t *ra = (const uint32_t *)(rr - rs), *rb = (const uint32_t *)(rr + rs), *rc = (const uint32_t *)(rr + 2 * rs);
+        uint32_t va = svt_alignbyte(ra[1], ra[0], 2), vc = svt_alignbyte(rb[1], rb[0], 2), vd = svt_alignbyte(rc[1], rc[0], 2);
+        *(uint32_t *)(Hh + ME_MUL(py, rs) + 4 * j) = me_tap4_x4(va, t2, vc, vd);
+        j += dj; py += dpy;
+        if (j >= pwd) { j -= pwd; py++; }
+    }
 }
 /* J (x+1/2, y+1/2) = vertical filter over B; defined for y in [-1, H-1] (H + 1 rows) */
 SVT_DEV void ph_interp_j(const me_ctx_t *c, int tid, int W, int H) {
     int       rs = c->L.region_stride, pwd = (W + 2 * ME_PL_G + 3) >> 2;
     uint8_t  *B = c->planes, *J = c->planes + 2 * c->L.plane_bytes;
-    const int lane = tid & (ME_ILANES - 1), row0 = tid / ME_ILANES;
-    for (int yy = row0; yy < H + 1; yy += SVT_NT / ME_ILANES)
-        for (int j = lane; j < pwd; j += ME_ILANES) {
-            int             py = yy + ME_PL_G - 1; /* y = yy - 1 */
-            const uint32_t *b  = (const uint32_t *)(B + py * rs + 4 * j);
-            const int       st = rs >> 2;
-            *(uint32_t *)(J + py * rs + 4 * j) = me_tap4_x4(b[-st], b[0], b[st], b[2 * st]);
-        }
+    const int dyy = SVT_NT / pwd, dj = SVT_NT - dyy * pwd, st = rs >> 2;
+    int       yy = tid / pwd, j = tid - yy * pwd;
+    while (yy < H + 1) {
+        const int       py = yy + ME_PL_G - 1; /* y = yy - 1 */
+        const uint32_t *b  = (const uint32_t *)(B + ME_MUL(py, rs) + 4 * j);
+        *(uint32_t *)(J + ME_MUL(py, rs) + 4 * j) = me_tap4_x4(b[-st], b[0], b[st], b[2 * st]);
+        j += dj; yy += dyy;
+        if (j >= pwd) { j -= pwd; yy++; }
+    }
 }
 
 enum { ME_PF = 0, ME_PB = 1, ME_PH = 2, ME_PJ = 3 };
 /* byte pointer (LDS) of plane `id` at natural position (x, y) relative to the region's top-left */
 SVT_DEV const uint8_t *me_plane_at(const me_ctx_t *c, int id, int x, int y) {
     int rs = c->L.region_stride;
-    if (id == ME_PF) return c->region + (ME_RGN_GY + y) * rs + ME_RGN_GX + x;
-    return c->planes + (id - 1) * c->L.plane_bytes + (y + ME_PL_G) * rs + x + ME_PL_G;
+    if (id == ME_PF) return c->region + ME_MUL(ME_RGN_GY + y, rs) + ME_RGN_GX + x;
+    return c->planes + ME_MUL(id - 1, c->L.plane_bytes) + ME_MUL(y + ME_PL_G, rs) + x + ME_PL_G;
 }
 
 /* SAD of a w x rows block: src rows at stride ss (LDS, dword aligned) vs candidate at any byte alignment (stride cs,
@@ -611,8 +621,8 @@ SVT_DEV uint32_t me_block_sad_rows(const uint8_t *src, int ss, const uint8_t *a,
     const uint8_t  *a0 = a - sha, *b0 = b ? b - shb : a0;
     const int       n = w >> 2;
     for (int r = r0; r < r1; r++) {
-        const uint32_t *s  = (const uint32_t *)(src + r * ss);
-        const uint32_t *pa = (const uint32_t *)(a0 + r * cs), *pb = (const uint32_t *)(b0 + r * cs);
+        const uint32_t *s  = (const uint32_t *)(src + ME_MUL(r, ss));
+        const uint32_t *pa = (const uint32_t *)(a0 + ME_MUL(r, cs)), *pb = (const uint32_t *)(b0 + ME_MUL(r, cs));
         uint32_t        la = pa[0], lb = b ? pb[0] : 0;
         for (int i = 0; i < n; i++) {
             uint32_t ha = pa[i + 1];
@@ -723,6 +733,25 @@ SVT_DEV int me_active_pu(int k, int n64, int n32, int n16) {
     return 21 + k - n16;
 }
 
+/* one record per refined PU so that the candidate tasks start from two LDS reads instead of re-deriving the PU from
+ * its dense index (range tests, z-order interleave) under divergent branches */
+SVT_DEV void ph_subpel_prep(const me_ctx_t *c, int tid, int en32, int en16, int en8) {
+    int       n64, n32, n16;
+    const int nact = me_active_count(c, en32, en16, en8, &n64, &n32, &n16);
+    for (int k = tid; k < nact; k += SVT_NT) {
+        const int pu = me_active_pu(k, n64, n32, n16);
+        int       px, py, w;
+        me_pu_geom(pu, &px, &py, &w);
+        c->st->spu[k] = (uint32_t)pu | ((uint32_t)me_pu_nidx(pu) << 7) | ((uint32_t)(px >> 3) << 14) | ((uint32_t)(py >> 3) << 17) |
+                        ((uint32_t)(w == 8 ? 0 : w == 16 ? 1 : w == 32 ? 2 : 3) << 20);
+    }
+}
+#define ME_SPU_PU(i) ((int)((i) & 127))
+#define ME_SPU_N(i) ((int)(((i) >> 7) & 127))
+#define ME_SPU_PX(i) ((int)(((i) >> 14) & 7) << 3)
+#define ME_SPU_PY(i) ((int)(((i) >> 17) & 7) << 3)
+#define ME_SPU_W(i) (8 << (((i) >> 20) & 3))
+
 /* half-pel: task = (refined pu, cand, sub-lane).  Distortion accumulates in st->cand[pu*8+cand] (pre-zeroed).
  * SUB_SAD: rows 0,2,4.. only, doubled by the consumer; FULL_SAD: all rows.  SSD_SEARCH: 9 candidates per PU (8 = the
  * integer position, whose SSD seeds the comparison, :1107-1160), all rows, SAD in st->cand and SSD in c->ssdc. */
@@ -734,10 +763,9 @@ SVT_DEV void ph_halfpel(const me_ctx_t *c, int tid, int list, int sox, int soy, 
     const int nact = me_active_count(c, en32, en16, en8, &n64, &n32, &n16);
     for (int t = tid; t < nact * ncand * ME_SUB_LANES; t += SVT_NT) {
         int sl = t % ME_SUB_LANES, q = t / ME_SUB_LANES;
-        int k = ssd ? q / 9 : q >> 3, cand = q - k * ncand, pu = me_active_pu(k, n64, n32, n16);
-        int px, py, w;
-        me_pu_geom(pu, &px, &py, &w);
-        int      n  = me_pu_nidx(pu);
+        int k = ssd ? q / 9 : q >> 3, cand = q - k * ncand;
+        const uint32_t info = c->st->spu[k];
+        const int      pu = ME_SPU_PU(info), n = ME_SPU_N(info), px = ME_SPU_PX(info), py = ME_SPU_PY(info), w = ME_SPU_W(info);
         uint32_t mv = c->st->best_mv[list][n];
         int      xs = (int16_t)((me_mvx(mv) >> 2) - (int16_t)sox) + px;
         int      ys = (int16_t)((me_mvy(mv) >> 2) - (int16_t)soy) + py;
@@ -837,11 +865,10 @@ SVT_DEV void ph_quarterpel(const me_ctx_t *c, int tid, int list, int sox, int so
     const int nact = me_active_count(c, en32, en16, en8, &n64, &n32, &n16);
     for (int t = tid; t < nact * 3 * ME_SUB_LANES; t += SVT_NT) {
         int sl = t % ME_SUB_LANES, q = t / ME_SUB_LANES;
-        int k = q / 3, j = q - 3 * k, pu = me_active_pu(k, n64, n32, n16);
-        int px, py, w;
-        me_pu_geom(pu, &px, &py, &w);
-        if (pu == 0) w = 32;
-        int      n  = me_pu_nidx(pu);
+        int k = q / 3, j = q - 3 * k;
+        const uint32_t info = c->st->spu[k];
+        const int      pu = ME_SPU_PU(info), n = ME_SPU_N(info), px = ME_SPU_PX(info), py = ME_SPU_PY(info);
+        const int      w = pu == 0 ? 32 : ME_SPU_W(info);
         uint32_t mv = c->st->best_mv[list][n];
         int16_t  xm = me_mvx(mv), ym = me_mvy(mv);
         int      method = (ym & 2) + ((xm & 2) >> 1);
@@ -1043,6 +1070,9 @@ __device__ int g_me_stop_after = -1;
 #define ME_UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
 #endif
 
+/* t / d through the precomputed inv = floor((2^32 - 1) / d) + 1 (exact while t * d < 2^32; d = 1 gives inv = 0 -> t) */
+SVT_DEV int me_div_magic(int t, uint32_t inv) { return inv ? (int)(((uint64_t)(uint32_t)t * inv) >> 32) : t; }
+
 /* copy the windows [e0, e1) of a batch: flattened (window,row,dword) tasks, four global loads in flight per thread
  * before the LDS stores; ntask = total load tasks of the batch */
 SVT_DEV void ph_hme_load_multi(const me_ctx_t *c, int tid, const svt_plane *ref, const me_hme_win *wn, int e0, int e1, int ntask) {
@@ -1056,7 +1086,7 @@ SVT_DEV void ph_hme_load_multi(const me_ctx_t *c, int tid, const svt_plane *ref,
                 int e = e0;
                 while (e + 1 < e1 && T >= wn[e + 1].tl) e++;
                 const int t = T - wn[e].tl, nd = wn[e].nd;
-                const int row = t / nd, i = t - row * nd;
+                const int row = me_div_magic(t, wn[e].inv_nd), i = t - row * nd;
                 v[u]   = me_ld32u(me_pix(ref, wn[e].gx + 4 * i, wn[e].gy + row));
                 dst[u] = wn[e].off + row * wn[e].wstride + 4 * i;
             }
@@ -1125,7 +1155,7 @@ SVT_DEV void me_qsad_block(const uint8_t *blk, int bstride, int nd, int bh, cons
 /* exhaustive search of the windows [e0, e1) of a batch in one phase; keys[slot] = min over
  * (sad << 32 | raster index inside the region) */
 SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk, int bstride, int bw, int bh, const me_hme_win *wn,
-                                 int e0, int e1, int ntask, uint64_t *keys) {
+                                 int e0, int e1, int ntask, uint64_t *keys, int slot_mask) {
     const int qs = (bw & 3) == 0; /* QSAD path: task = 4 positions */
     uint64_t  best[4] = {~0ull, ~0ull, ~0ull, ~0ull}; /* per key slot */
 #ifdef ME_FINE_PROF
@@ -1143,7 +1173,7 @@ SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk,
         FP(16);
         if (qs) {
             const int ng = (sw + 3) >> 2;
-            const int y = t / ng, g = t - y * ng;
+            const int y = me_div_magic(t, wn[e].inv_ng), g = t - y * ng;
             uint32_t  a[4];
             me_qsad_block(blk, bstride, bw >> 2, bh, win + y * ws + 4 * g, ws, 2, a);
             FP(17);
@@ -1155,7 +1185,7 @@ SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk,
                 }
             }
         } else {
-            const int y = t / sw, x = t - y * sw;
+            const int y = me_div_magic(t, wn[e].inv_ng), x = t - y * sw;
             uint32_t  sd = 0;
             for (int j = 0; j < bh; j++)
                 for (int i = 0; i < bw; i++) {
@@ -1167,8 +1197,8 @@ SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk,
         _Pragma("unroll") for (int q = 0; q < 4; q++) if (q == slot && kb < best[q]) best[q] = kb;
         FP(18);
     }
-    /* every lane takes part in the 4 wave reductions (lanes without work contribute ~0) */
-    _Pragma("unroll") for (int q = 0; q < 4; q++) svt_wave_min_u64(&keys[q], best[q]);
+    /* every lane takes part in the wave reductions of the slots this batch touches (lanes without work contribute ~0) */
+    _Pragma("unroll") for (int q = 0; q < 4; q++) if ((slot_mask >> q) & 1) svt_wave_min_u64(&keys[q], best[q]);
     FP(19);
 #undef FP
 }
@@ -1285,6 +1315,7 @@ SVT_DEV void me_hme_plan_level(const me_ctx_t *c, int list, int lvl, int16_t xsc
             me_hme_win *wn = &st->hme_win[ne++];
             wn->off = bytes; wn->wstride = ws; wn->nd = (wbytes + 3) >> 2; wn->rows = nr + span; wn->sw = w; wn->sh = nr;
             wn->gx = g.ox + ox; wn->gy = g.oy + oy + y; wn->slot = k; wn->idx0 = y * w; wn->tl = tl; wn->ts = ts;
+            wn->inv_nd = (uint32_t)(0xffffffffu / (uint32_t)wn->nd) + 1u; wn->inv_ng = (uint32_t)(0xffffffffu / (uint32_t)ng) + 1u;
             tl += wn->nd * wn->rows; ts += ng * nr;
             bytes += ws * (nr + span); y += nr;
         }
@@ -1439,10 +1470,13 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                         const me_hme_win *wl = &st->hme_win[e1 - 1];
                         const int         ntl = ME_UNI(wl->tl + wl->nd * wl->rows);
                         const int         nts = ME_UNI(wl->ts + ((g.bw & 3) == 0 ? (wl->sw + 3) >> 2 : wl->sw) * wl->sh);
+                        int               slot_mask = 0;
+                        for (int e = e0; e < e1; e++) slot_mask |= 1 << st->hme_win[e].slot;
+                        slot_mask = ME_UNI(slot_mask);
                         ME_SUBMARK_BEGIN();
                         ME_PHASE(ph_hme_load_multi(c, tid, g.ref, st->hme_win, e0, e1, ntl));
                         ME_SUBMARK(14);
-                        ME_PHASE(ph_hme_search_multi(c, tid, g.blk, g.bstride, g.bw, g.bh, st->hme_win, e0, e1, nts, st->hme_keys));
+                        ME_PHASE(ph_hme_search_multi(c, tid, g.blk, g.bstride, g.bw, g.bh, st->hme_win, e0, e1, nts, st->hme_keys, slot_mask));
                         ME_SUBMARK(15);
                     }
                     ME_UNIFORM_WRITE(me_hme_finish_level(c, lvl); if (lvl == last_lvl) me_hme_select(c, list));
@@ -1501,7 +1535,8 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                 ME_MARK(6);
             }
             /* keys -> best sad / mv (curr_mv = (y << 18) | (uint16)(x << 2), :108-110) */
-            ME_PHASE(for (int t = tid; t < 85; t += SVT_NT) {
+            ME_PHASE(if (tid >= 128 && tid < 137) st->supel[tid - 128] = 0;
+                     for (int t = tid; t < 85; t += SVT_NT) {
                 uint64_t k = st->key[t];
                 uint32_t idx = (uint32_t)k;
                 st->best_sad[list][t] = (uint32_t)(k >> 32);
@@ -1517,18 +1552,26 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         int en32 = 0, en16 = 0, en8 = 0, enq = 0;
         if (p->fractional_search_model == 0) { en32 = en16 = en8 = enq = 1; }
         else if (p->fractional_search_model == 1) {
-            /* su_pel_enable (:3839-4258): average MV magnitude / SAD per size class */
-            int      sx = 0, sy = 0;
-            uint32_t ss = 0;
-            for (int i = 1; i <= 4; i++) { sx += me_mvx(st->best_mv[list][i]); sy += me_mvy(st->best_mv[list][i]); ss += st->best_sad[list][i]; }
+            /* su_pel_enable (:3839-4258): average MV magnitude / SAD per size class; the nine sums come from one
+             * element per lane and wave reductions (st->supel was zeroed with the keys) */
+            ME_PHASE(if (tid < 128) {
+                const int      i = tid;
+                const int      cls = i >= 85 ? -1 : i >= 21 ? 2 : i >= 5 ? 1 : i >= 1 ? 0 : -1;
+                const uint32_t mv = i < 85 ? st->best_mv[list][i] : 0, sd = i < 85 ? st->best_sad[list][i] : 0;
+                _Pragma("unroll") for (int k = 0; k < 3; k++) {
+                    svt_wave_add_u32(&st->supel[3 * k + 0], cls == k ? (uint32_t)(int32_t)me_mvx(mv) : 0u, 1);
+                    svt_wave_add_u32(&st->supel[3 * k + 1], cls == k ? (uint32_t)(int32_t)me_mvy(mv) : 0u, 1);
+                    svt_wave_add_u32(&st->supel[3 * k + 2], cls == k ? sd : 0u, 1);
+                }
+            });
+            int      sx = (int)st->supel[0], sy = (int)st->supel[1];
+            uint32_t ss = st->supel[2];
             uint32_t ax = (uint32_t)(sx >> 2), ay = (uint32_t)(sy >> 2);
             uint32_t mag32 = ax * ax + ay * ay, sad32 = ss >> 2;
-            sx = sy = 0; ss = 0;
-            for (int i = 5; i <= 20; i++) { sx += me_mvx(st->best_mv[list][i]); sy += me_mvy(st->best_mv[list][i]); ss += st->best_sad[list][i]; }
+            sx = (int)st->supel[3]; sy = (int)st->supel[4]; ss = st->supel[5];
             ax = (uint32_t)(sx >> 4); ay = (uint32_t)(sy >> 4);
             uint32_t mag16 = ax * ax + ay * ay, sad16 = ss >> 4;
-            sx = sy = 0; ss = 0;
-            for (int i = 21; i < 85; i++) { sx += me_mvx(st->best_mv[list][i]); sy += me_mvy(st->best_mv[list][i]); ss += st->best_sad[list][i]; }
+            sx = (int)st->supel[6]; sy = (int)st->supel[7]; ss = st->supel[8];
             ax = (uint32_t)(sx >> 6); ay = (uint32_t)(sy >> 6);
             uint32_t mag8 = ax * ax + ay * ay, sad8 = ss >> 6;
             const int thr_[4]    = {48, 32, 80, 48};
@@ -1550,7 +1593,8 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         }
         ME_MARK(9);
         if (en32 || en16 || en8 || enq) {
-            ME_PHASE(for (int t = tid; t < 85 * 9; t += SVT_NT) { if (t < 85 * 8) st->cand[t] = 0; if (c->ssdc) c->ssdc[t] = 0; });
+            ME_PHASE(for (int t = tid; t < 85 * 9; t += SVT_NT) { if (t < 85 * 8) st->cand[t] = 0; if (c->ssdc) c->ssdc[t] = 0; }
+                     ph_subpel_prep(c, tid, en32, en16, en8));
             ME_PHASE(ph_halfpel(c, tid, list, sox, soy, en32, en16, en8));
             ME_PHASE(ph_halfpel_decide(c, tid, list, en32, en16, en8));
             ME_MARK(10);

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include "me_core.h"
 #include "me_layout.h"
+#include "me_spec.h"
 #include "svt_ctx.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -17,6 +18,7 @@ extern __shared__ __align__(16) uint8_t svt_lds[];
 /* One workgroup per (picture, SB).  blockIdx -> work item mapping is XCD-aware: consecutive work items
  * (neighbouring SBs, which share most of their reference window) are placed on the same XCD so that the
  * window re-reads hit that XCD's L2 (block b runs on XCD b % 8). */
+template <int SPEC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ME_WAVES_PER_EU))) void svt_me_sb_kernel(const me_pic_dev *__restrict__ pics, svt_me_params p, me_lds_layout L,
                                                         int n_sb, int nx, int pic_w, int pic_h, int total, int chunk, unsigned long long *prof) {
     const int b = blockIdx.x;
@@ -25,7 +27,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ME_WAVES_PE
     const int pic = l / n_sb, sb = l - pic * n_sb;
     me_ctx_t  c;
     c.pic = &pics[pic];
-    c.p   = &p;
+    svt_me_params pp = p;
+    if constexpr (SPEC != 0) me_spec_apply<SPEC>(&pp); /* constants equal to the caller's values (me_spec_match) */
+    c.p   = &pp;
     c.L   = L;
     c.lds = svt_lds;
     c.st     = (me_state_t *)(svt_lds + L.off_state);
@@ -128,8 +132,6 @@ extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, con
     }
     HIP_TRY(hipMemcpyAsync(d, h, sizeof(me_pic_dev) * (size_t)n_pics, hipMemcpyHostToDevice, ctx->stream));
     const int total = n_sb * n_pics, chunk = (total + 7) / 8;
-    if (L.total_bytes > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)svt_me_sb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L.total_bytes));
     /* SVT_HIP_ME_PROFILE=1: per-phase shader-cycle breakdown (thread 0 of every workgroup), printed to stderr */
     static const bool want_prof = getenv("SVT_HIP_ME_PROFILE") != nullptr;
     unsigned long long *d_prof = nullptr;
@@ -141,7 +143,19 @@ extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, con
     { const char *sa = getenv("SVT_HIP_ME_STOP"); int v = sa ? atoi(sa) : -1; HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_me_stop_after), &v, sizeof v, 0, hipMemcpyHostToDevice, ctx->stream)); }
 #endif
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
-    hipLaunchKernelGGL(svt_me_sb_kernel, dim3(chunk * 8), dim3(256), L.total_bytes, ctx->stream, d, *params, L, n_sb, nx, W, H, total, chunk, d_prof);
+    /* the instance specialised for the caller's parameter set when there is one (me_spec.h), else the generic one */
+    static const bool no_spec = getenv("SVT_HIP_ME_GENERIC") != nullptr;
+    switch (no_spec ? 0 : me_spec_match(params)) {
+#define ME_LAUNCH(S) \
+    if (L.total_bytes > 64 * 1024) \
+        HIP_TRY(hipFuncSetAttribute((const void *)svt_me_sb_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total_bytes)); \
+    hipLaunchKernelGGL(svt_me_sb_kernel<S>, dim3(chunk * 8), dim3(256), L.total_bytes, ctx->stream, d, *params, L, n_sb, nx, W, H, total, chunk, d_prof)
+    case 1: ME_LAUNCH(1); break;
+    case 2: ME_LAUNCH(2); break;
+    case 3: ME_LAUNCH(3); break;
+    default: ME_LAUNCH(0); break;
+#undef ME_LAUNCH
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     if (d_prof) {
