@@ -29,10 +29,12 @@ struct lf_pic_dev {
     const svt_lf_mask *lfm;
     int32_t            lfm_stride, mi_rows, mi_cols, y_only;
     uint32_t          *progress; /* [sb_rows] SBs completed per SB row */
+    const uint32_t    *desc;     /* [sb_rows][sb_cols][LF_DESC_WORDS] edge descriptors (svt_lf_desc_kernel) */
 };
 
 __device__ unsigned long long g_lf_prof[8]; /* SVT_HIP_LF_PROFILE: cycles per stage, thread 0 of every workgroup */
 
+constexpr int LF_DESC_WORDS = 160;
 constexpr int YS = 76, YROWS = 72;   /* luma tile stride / rows (8 halo + 64) */
 constexpr int CS = 44, CROWS = 40;   /* chroma tile stride / rows (8 halo + 32) */
 
@@ -238,54 +240,120 @@ __device__ __forceinline__ void lf_line(uint8_t *s, int st, int nblk, const uint
     if (ROW) row_store8(s + 8 * nblk - 8, p, true); else col_store8(s + (8 * nblk - 8) * st, st, p, true);
 }
 
-/* copy a tile between global memory and LDS, clipped to the part of the plane that exists.
- * tile sample (tx, ty) <-> plane sample (x0 + tx, y0 + ty); only tx in [0,nx), ty in [0,ny).  x0, nx and the LDS
- * offsets are multiples of 8; when the plane rows are 8-byte aligned the copy moves 8 bytes per lane and keeps up to
- * UNITS loads in flight before the first store (a tile is a handful of units per lane). */
-template <int UNITS>
-__device__ __forceinline__ void tile_io(bool load, uint8_t *g, int gstride, uint8_t *l, int lstride, int x0, int y0, int nx, int ny,
-                                        int tid, int nthreads) {
-    if ((((uintptr_t)g | (uintptr_t)gstride) & 7) == 0) {
-        const int nu = nx >> 3, total = nu * ny; /* 8-byte units per row */
-        for (int t0 = tid; t0 < total; t0 += UNITS * nthreads) {
-            uint2 v[UNITS];
-            int   lo[UNITS];
-            _Pragma("unroll") for (int u = 0; u < UNITS; u++) {
-                const int t = t0 + u * nthreads;
-                lo[u] = -1;
-                if (t < total) {
-                    const int ty = t / nu, tu = t - ty * nu;
-                    uint2    *gp = (uint2 *)(g + (ptrdiff_t)(y0 + ty) * gstride + x0 + 8 * tu);
-                    lo[u] = ty * lstride + 8 * tu;
-                    if (load) v[u] = *gp;
-                    else { const uint32_t *lp = (const uint32_t *)(l + lo[u]); *gp = make_uint2(lp[0], lp[1]); }
+/* Copy a rectangle of 8-byte units between global memory and an LDS tile.  Tile sample (tx, ty) <-> plane sample
+ * (x0 + tx, y0 + ty); tx in [tx0, tx0 + nx), ty in [ty0, ty0 + ny); x0 + tx0, nx and the LDS offsets are multiples of 8.
+ * Rows with seam[ty] != 0 belong to a seam between two SB rows: they are written by one workgroup and read by the
+ * workgroup of the next SB row inside the same launch, so they move with agent-scope (sc1, write-through / L2-bypass)
+ * 8-byte accesses -- no release/acquire fence is needed for them (cdna_hip_programming.md, guideline 16).  Up to UNITS
+ * loads per lane are in flight before the first store.  Plane rows must be 8-byte (wide) or 4-byte aligned. */
+template <int UNITS, typename UT>
+__device__ __forceinline__ void tile_io_t(bool load, uint8_t *g, int gstride, uint8_t *l, int lstride, int x0, int y0, int tx0, int ty0,
+                                          int nx, int ny, int seam_lo_end, int seam_hi_begin, int lane, int nlanes) {
+    constexpr int UB = (int)sizeof(UT);      /* unit = 8 bytes, or 4 when the plane rows are only 4-byte aligned */
+    const int nu = nx / UB, total = nu * ny;
+    for (int t0 = lane; t0 < total; t0 += UNITS * nlanes) {
+        UT  v[UNITS];
+        int lo[UNITS];
+        _Pragma("unroll") for (int u = 0; u < UNITS; u++) {
+            const int t = t0 + u * nlanes;
+            lo[u] = -1;
+            if (t < total) {
+                const int  r = t / nu, ty = ty0 + r, tx = tx0 + UB * (t - r * nu);
+                UT        *gp = (UT *)(g + (ptrdiff_t)(y0 + ty) * gstride + x0 + tx);
+                const bool seam = ty < seam_lo_end || ty >= seam_hi_begin;
+                lo[u] = ty * lstride + tx;
+                if (load) v[u] = seam ? __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *gp;
+                else {
+                    const uint32_t *lp = (const uint32_t *)(l + lo[u]);
+                    UT              w = (UT)lp[0];
+                    if constexpr (UB == 8) w |= (UT)lp[1] << 32;
+                    if (seam) __hip_atomic_store(gp, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else *gp = w;
                 }
             }
-            if (load) {
-                _Pragma("unroll") for (int u = 0; u < UNITS; u++)
-                    if (lo[u] >= 0) { uint32_t *lp = (uint32_t *)(l + lo[u]); lp[0] = v[u].x; lp[1] = v[u].y; }
-            }
         }
-        return;
+        if (load) {
+            _Pragma("unroll") for (int u = 0; u < UNITS; u++)
+                if (lo[u] >= 0) {
+                    uint32_t *lp = (uint32_t *)(l + lo[u]);
+                    lp[0] = (uint32_t)v[u];
+                    if constexpr (UB == 8) lp[1] = (uint32_t)(v[u] >> 32);
+                }
+        }
     }
-    for (int t = tid; t < nx * ny; t += nthreads) {
-        const int ty = t / nx, tx = t - ty * nx;
-        uint8_t  *gp = g + (ptrdiff_t)(y0 + ty) * gstride + x0 + tx;
-        if (load) l[ty * lstride + tx] = *gp;
-        else *gp = l[ty * lstride + tx];
+}
+template <int UNITS>
+__device__ __forceinline__ void tile_io(bool wide, bool load, uint8_t *g, int gstride, uint8_t *l, int lstride, int x0, int y0, int tx0,
+                                        int ty0, int nx, int ny, int seam_lo_end, int seam_hi_begin, int lane, int nlanes) {
+    if (wide) tile_io_t<UNITS, unsigned long long>(load, g, gstride, l, lstride, x0, y0, tx0, ty0, nx, ny, seam_lo_end, seam_hi_begin, lane, nlanes);
+    else tile_io_t<2 * UNITS, unsigned int>(load, g, gstride, l, lstride, x0, y0, tx0, ty0, nx, ny, seam_lo_end, seam_hi_begin, lane, nlanes);
+}
+
+struct lf_geom { /* per (SB row, SB column): what exists of the tile */
+    int x0, y0, cx0, cy0, hx, hy, vw, vh, cvw, cvh;
+};
+__device__ __forceinline__ lf_geom lf_geometry(int sb_row, int sc, int W, int H) {
+    lf_geom g;
+    const int CW = W >> 1, CH = H >> 1;
+    g.x0 = sc * 64; g.y0 = sb_row * 64; g.cx0 = sc * 32; g.cy0 = sb_row * 32;
+    g.hx = sc > 0 ? 8 : 0; g.hy = sb_row > 0 ? 8 : 0; /* halo of 8 up/left where there is a neighbour */
+    g.vw = (W - g.x0) < 64 ? W - g.x0 : 64; g.vh = (H - g.y0) < 64 ? H - g.y0 : 64;
+    g.cvw = (CW - g.cx0) < 32 ? CW - g.cx0 : 32; g.cvh = (CH - g.cy0) < 32 ? CH - g.cy0 : 32;
+    return g;
+}
+
+/* Edge descriptors of every SB of every picture: no dependencies, one 128-thread workgroup per SB */
+__global__ __launch_bounds__(128) void svt_lf_desc_kernel(const lf_pic_dev *__restrict__ pics, int rows_per_pic, int max_cols) {
+    const int pic = blockIdx.x / (rows_per_pic * max_cols), rem = blockIdx.x - pic * rows_per_pic * max_cols;
+    const int sb_row = rem / max_cols, sc = rem - sb_row * max_cols;
+    const lf_pic_dev P = pics[pic];
+    const int sb_cols = (P.mi_cols + 7) >> 3, sb_rows = (P.mi_rows + 7) >> 3;
+    if (sb_row >= sb_rows || sc >= sb_cols) return;
+    const int tid = threadIdx.x, mi_row = sb_row * 8;
+    uint32_t *d = const_cast<uint32_t *>(P.desc) + ((size_t)sb_row * sb_cols + sc) * LF_DESC_WORDS;
+    svt_lf_mask m = P.lfm[sb_row * P.lfm_stride + sc];
+    adjust_mask(m, mi_row, sc * 8, P.mi_rows, P.mi_cols);
+    if (tid < 64) {
+        const int rr = tid >> 3, c = tid & 7, pair = rr >> 1, half = rr & 1;
+        d[tid] = vert_entry(c, 8, (unsigned)(m.left_y[2] >> (16 * pair)) & 0xffff, (unsigned)(m.left_y[1] >> (16 * pair)) & 0xffff,
+                            (unsigned)(m.left_y[0] >> (16 * pair)) & 0xffff, (unsigned)(m.int_4x4_y >> (16 * pair)) & 0xffff, half,
+                            m.lfl_y[(2 * pair) * 8 + c], m.lfl_y[(2 * pair + 1) * 8 + c]);
+        const int r = rr;
+        unsigned  a16 = 0, a8 = 0, a4 = 0;
+        if (mi_row + r != 0) { a16 = (unsigned)(m.above_y[2] >> (8 * r)) & 0xff; a8 = (unsigned)(m.above_y[1] >> (8 * r)) & 0xff; a4 = (unsigned)(m.above_y[0] >> (8 * r)) & 0xff; }
+        d[64 + tid] = horiz_entry(c, a16, a8, a4, (unsigned)(m.int_4x4_y >> (8 * r)) & 0xff, &m.lfl_y[r * 8], 1);
+    } else if (tid < 80) {
+        const int t = tid - 64, rr = t >> 2, c = t & 3, pair = rr >> 1, half = rr & 1;
+        d[128 + t] = vert_entry(c, 4, (unsigned)(m.left_uv[2] >> (8 * pair)) & 0xff, (unsigned)(m.left_uv[1] >> (8 * pair)) & 0xff,
+                                (unsigned)(m.left_uv[0] >> (8 * pair)) & 0xff, (unsigned)(m.int_4x4_uv >> (8 * pair)) & 0xff, half,
+                                m.lfl_y[(4 * pair) * 8 + 2 * c], m.lfl_y[(4 * pair + 2) * 8 + 2 * c]);
+    } else if (tid < 96) {
+        const int t = tid - 80, ru = t >> 2, c = t & 3, r = 2 * ru;
+        unsigned  a16 = 0, a8 = 0, a4 = 0;
+        if (mi_row + r != 0) { a16 = (unsigned)(m.above_uv[2] >> (4 * ru)) & 0xf; a8 = (unsigned)(m.above_uv[1] >> (4 * ru)) & 0xf; a4 = (unsigned)(m.above_uv[0] >> (4 * ru)) & 0xf; }
+        const unsigned mi4 = (mi_row + r == P.mi_rows - 1) ? 0u : ((unsigned)(m.int_4x4_uv >> (4 * ru)) & 0xf);
+        d[144 + t] = horiz_entry(c, a16, a8, a4, mi4, &m.lfl_y[r * 8], 2);
     }
 }
 
-__global__ __launch_bounds__(128) void svt_lf_kernel(const lf_pic_dev *__restrict__ pics, int n_pics, svt_lf_thresh thr,
+/* Workgroup = one SB row, three waves with fixed roles:
+ *   wave 0  filters luma, wave 1 filters Cb (lanes 0-31) and Cr (lanes 32-63): vertical edges, then horizontal edges of the
+ *           SB in tile buffer (sc & 1); the 8 rightmost columns (not final yet: the next SB's left edge filters modify
+ *           them) are handed to the other buffer as the next SB's left halo -- every sample crosses HBM once per SB row;
+ *   wave 2  stages the NEXT SB meanwhile (waits for the SB row above, loads the 64 new columns + top halo, builds the edge
+ *           descriptors), and afterwards writes the finished columns of the current tile back and publishes progress.
+ * One workgroup barrier per SB.  Tile rows 0-7 (top halo) and the SB's last 8 rows are seam rows (sc1 accesses). */
+__global__ __launch_bounds__(192) void svt_lf_kernel(const lf_pic_dev *__restrict__ pics, int n_pics, svt_lf_thresh thr,
                                                      uint32_t *__restrict__ ticket, int rows_per_pic, int prof) {
-    __shared__ __align__(16) uint8_t ytile[YROWS * YS];
-    __shared__ __align__(16) uint8_t ctile[2][CROWS * CS];
-    __shared__ uint32_t              s_thr[64];      /* mblim | lim << 8 | hev_thr << 16 per filter level */
-    __shared__ uint32_t              s_vy[64], s_hy[64]; /* luma edge descriptors [8-row band][column block] */
-    __shared__ uint32_t              s_vc[16], s_hc[16]; /* chroma */
+    __shared__ __align__(16) uint8_t ytile[2][YROWS * YS];
+    __shared__ __align__(16) uint8_t ctile[2][2][CROWS * CS];
+    __shared__ uint32_t              s_thr[64];             /* mblim | lim << 8 | hev_thr << 16 per filter level */
+    __shared__ uint32_t              s_desc[2][LF_DESC_WORDS]; /* edge descriptors: luma vertical [band][block] 64, luma horizontal 64,
+                                                                  chroma vertical 16, chroma horizontal 16 */
     __shared__ int                   s_job;
+    __shared__ volatile int          s_stored;              /* last SB whose tile wave 2 has read back out of LDS */
     const int tid = threadIdx.x;
-    if (tid == 0) s_job = (int)atomicAdd(ticket, 1u);
+    if (tid == 0) { s_job = (int)atomicAdd(ticket, 1u); s_stored = -1; }
     if (tid < 64) s_thr[tid] = (uint32_t)thr.mblim[tid] | ((uint32_t)thr.lim[tid] << 8) | ((uint32_t)thr.hev_thr[tid] << 16);
     __syncthreads();
     const int job = s_job;
@@ -294,99 +362,97 @@ __global__ __launch_bounds__(128) void svt_lf_kernel(const lf_pic_dev *__restric
     const int sb_row = job % rows_per_pic;
     const int sb_cols = (P.mi_cols + 7) >> 3, sb_rows = (P.mi_rows + 7) >> 3;
     if (sb_row >= sb_rows) return;
-    const int W = P.planes.width, H = P.planes.height, CW = W >> 1, CH = H >> 1;
+    const int W = P.planes.width, H = P.planes.height;
     const int mi_row = sb_row * 8;
     const int wave = tid >> 6, lane = tid & 63;
     const int nrows = P.mi_rows - mi_row < 8 ? P.mi_rows - mi_row : 8; /* 8-row bands of this SB row */
-
+    const bool wide_y = (((uintptr_t)P.planes.y | (uintptr_t)P.planes.y_stride) & 7) == 0;
+    const bool wide_c = (((uintptr_t)P.planes.u | (uintptr_t)P.planes.v | (uintptr_t)P.planes.uv_stride) & 7) == 0;
     unsigned long long tm_ = prof ? __builtin_amdgcn_s_memtime() : 0;
-#define LF_MARK(i) do { if (prof && tid == 0) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_lf_prof[i], n_ - tm_); tm_ = n_; } } while (0)
-    for (int sc = 0; sc < sb_cols; sc++) {
-        /* ---- wait for (sb_row-1, sc+1) ---- */
-        if (sb_row > 0) {
+#define LF_MARK(i, who) do { if (prof && tid == (who)) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_lf_prof[i], n_ - tm_); tm_ = n_; } } while (0)
+
+    /* wave 2: stage SB `sc` into buffer sc & 1 (new columns + top halo + descriptors); the left halo comes from the
+     * filter waves, except for SB 0 which has none */
+    auto stage = [&](int sc) {
+        const int     buf = sc & 1;
+        const lf_geom g = lf_geometry(sb_row, sc, W, H);
+        if (sb_row > 0) { /* wait for (sb_row-1, sc+1): its tiles up to sc+1 have been written back */
             const uint32_t need = (uint32_t)(sc + 2 < sb_cols ? sc + 2 : sb_cols);
-            if (tid == 0) {
+            if (lane == 0)
                 while (__hip_atomic_load(&P.progress[sb_row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            __syncthreads();
         }
-        LF_MARK(0);
-        const int mi_col = sc * 8;
-        const int x0 = sc * 64, y0 = sb_row * 64, cx0 = sc * 32, cy0 = sb_row * 32;
-        /* tile extents that exist in the planes (halo of 8 up/left where there is a neighbour) */
-        const int hx = sc > 0 ? 8 : 0, hy = sb_row > 0 ? 8 : 0;
-        const int vw = (W - x0) < 64 ? W - x0 : 64, vh = (H - y0) < 64 ? H - y0 : 64;
-        const int cvw = (CW - cx0) < 32 ? CW - cx0 : 32, cvh = (CH - cy0) < 32 ? CH - cy0 : 32;
-        uint8_t *yl = ytile + (8 - hy) * YS + (8 - hx); /* LDS address of tile sample (x0-hx, y0-hy) */
-        tile_io<6>(true, P.planes.y, P.planes.y_stride, yl, YS, x0 - hx, y0 - hy, vw + hx, vh + hy, tid, 128);
+        LF_MARK(0, 128);
+        /* tile columns 8.. hold the SB's own samples; rows 8-hy.. ; seam rows: ty < 8 (top halo) and the SB's last 8 rows */
+        tile_io<11>(wide_y, true, P.planes.y, P.planes.y_stride, ytile[buf], YS, g.x0 - 8, g.y0 - 8, 8, 8 - g.hy, g.vw, g.vh + g.hy, 8, 8 + g.vh - 8, lane, 64);
         if (!P.y_only) {
-            tile_io<2>(true, P.planes.u, P.planes.uv_stride, ctile[0] + (8 - hy) * CS + (8 - hx), CS, cx0 - hx, cy0 - hy, cvw + hx, cvh + hy, tid, 128);
-            tile_io<2>(true, P.planes.v, P.planes.uv_stride, ctile[1] + (8 - hy) * CS + (8 - hx), CS, cx0 - hx, cy0 - hy, cvw + hx, cvh + hy, tid, 128);
+            tile_io<3>(wide_c, true, P.planes.u, P.planes.uv_stride, ctile[buf][0], CS, g.cx0 - 8, g.cy0 - 8, 8, 8 - g.hy, g.cvw, g.cvh + g.hy, 8, 8 + g.cvh - 8, lane, 64);
+            tile_io<3>(wide_c, true, P.planes.v, P.planes.uv_stride, ctile[buf][1], CS, g.cx0 - 8, g.cy0 - 8, 8, 8 - g.hy, g.cvw, g.cvh + g.hy, 8, 8 + g.cvh - 8, lane, 64);
         }
-        LF_MARK(1);
-        /* ---- edge descriptors of this SB: one (band, block) per lane ---- */
+        LF_MARK(1, 128);
+        /* edge descriptors of this SB (built by svt_lf_desc_kernel): luma vertical 64, luma horizontal 64, chroma 16 + 16 */
         {
-            svt_lf_mask m = P.lfm[sb_row * P.lfm_stride + sc];
-            adjust_mask(m, mi_row, mi_col, P.mi_rows, P.mi_cols);
-            if (tid < 64) {
-                const int rr = tid >> 3, c = tid & 7, pair = rr >> 1, half = rr & 1;
-                s_vy[tid] = vert_entry(c, 8, (unsigned)(m.left_y[2] >> (16 * pair)) & 0xffff, (unsigned)(m.left_y[1] >> (16 * pair)) & 0xffff,
-                                       (unsigned)(m.left_y[0] >> (16 * pair)) & 0xffff, (unsigned)(m.int_4x4_y >> (16 * pair)) & 0xffff, half,
-                                       m.lfl_y[(2 * pair) * 8 + c], m.lfl_y[(2 * pair + 1) * 8 + c]);
-                const int r = rr;
-                unsigned  a16 = 0, a8 = 0, a4 = 0;
-                if (mi_row + r != 0) { a16 = (unsigned)(m.above_y[2] >> (8 * r)) & 0xff; a8 = (unsigned)(m.above_y[1] >> (8 * r)) & 0xff; a4 = (unsigned)(m.above_y[0] >> (8 * r)) & 0xff; }
-                s_hy[tid] = horiz_entry(c, a16, a8, a4, (unsigned)(m.int_4x4_y >> (8 * r)) & 0xff, &m.lfl_y[r * 8], 1);
-            } else if (tid < 80) {
-                const int t = tid - 64, rr = t >> 2, c = t & 3, pair = rr >> 1, half = rr & 1;
-                s_vc[t] = vert_entry(c, 4, (unsigned)(m.left_uv[2] >> (8 * pair)) & 0xff, (unsigned)(m.left_uv[1] >> (8 * pair)) & 0xff,
-                                     (unsigned)(m.left_uv[0] >> (8 * pair)) & 0xff, (unsigned)(m.int_4x4_uv >> (8 * pair)) & 0xff, half,
-                                     m.lfl_y[(4 * pair) * 8 + 2 * c], m.lfl_y[(4 * pair + 2) * 8 + 2 * c]);
-            } else if (tid < 96) {
-                const int t = tid - 80, ru = t >> 2, c = t & 3, r = 2 * ru;
-                unsigned  a16 = 0, a8 = 0, a4 = 0;
-                if (mi_row + r != 0) { a16 = (unsigned)(m.above_uv[2] >> (4 * ru)) & 0xf; a8 = (unsigned)(m.above_uv[1] >> (4 * ru)) & 0xf; a4 = (unsigned)(m.above_uv[0] >> (4 * ru)) & 0xf; }
-                const unsigned mi4 = (mi_row + r == P.mi_rows - 1) ? 0u : ((unsigned)(m.int_4x4_uv >> (4 * ru)) & 0xf);
-                s_hc[t] = horiz_entry(c, a16, a8, a4, mi4, &m.lfl_y[r * 8], 2);
+            const uint32_t *d = P.desc + ((size_t)sb_row * sb_cols + sc) * LF_DESC_WORDS;
+            s_desc[buf][lane] = d[lane];
+            s_desc[buf][64 + lane] = d[64 + lane];
+            if (lane < 32) s_desc[buf][128 + lane] = d[128 + lane];
+        }
+        LF_MARK(2, 128);
+    };
+
+    if (wave == 2) stage(0);
+    __syncthreads();
+    for (int sc = 0; sc < sb_cols; sc++) {
+        const int     buf = sc & 1;
+        const lf_geom g = lf_geometry(sb_row, sc, W, H);
+        const bool    last = sc + 1 == sb_cols;
+        if (wave == 2) {
+            if (!last) stage(sc + 1);
+        } else if (wave == 0) {
+            /* vertical edges: lane = sample row; horizontal edges: lane = sample column (LDS accesses of one wave are
+             * ordered, no barrier between the two passes) */
+            if (lane < g.vh) lf_line<true>(ytile[buf] + (8 + lane) * YS + 8, 1, 8, &s_desc[buf][(lane >> 3) * 8], 1, s_thr);
+            LF_MARK(3, 0);
+            if (lane < g.vw) lf_line<false>(ytile[buf] + 8 * YS + 8 + lane, YS, nrows, &s_desc[buf][64 + (lane >> 3)], 8, s_thr);
+            LF_MARK(4, 0);
+            if (!last) {
+                while (s_stored < sc - 1) __builtin_amdgcn_s_sleep(1); /* the other buffer has been written back */
+                for (int r = lane; r < YROWS; r += 64) {
+                    const uint32_t *src = (const uint32_t *)(ytile[buf] + r * YS + 64);
+                    uint32_t       *dst = (uint32_t *)(ytile[buf ^ 1] + r * YS);
+                    dst[0] = src[0]; dst[1] = src[1];
+                }
+            }
+        } else if (!P.y_only) {
+            const int pl = lane >> 5, l5 = lane & 31;
+            if (l5 < g.cvh) lf_line<true>(ctile[buf][pl] + (8 + l5) * CS + 8, 1, 4, &s_desc[buf][128 + (l5 >> 3) * 4], 1, s_thr);
+            if (l5 < g.cvw) lf_line<false>(ctile[buf][pl] + 8 * CS + 8 + l5, CS, (nrows + 1) >> 1, &s_desc[buf][144 + (l5 >> 3)], 4, s_thr);
+            if (!last) {
+                while (s_stored < sc - 1) __builtin_amdgcn_s_sleep(1);
+                for (int r = l5; r < CROWS; r += 32) {
+                    const uint32_t *src = (const uint32_t *)(ctile[buf][pl] + r * CS + 32);
+                    uint32_t       *dst = (uint32_t *)(ctile[buf ^ 1][pl] + r * CS);
+                    dst[0] = src[0]; dst[1] = src[1];
+                }
             }
         }
         __syncthreads();
-        LF_MARK(2);
-        /* ---- vertical edges: lane = sample row ---- */
-        if (wave == 0) {
-            if (lane < vh) lf_line<true>(ytile + (8 + lane) * YS + 8, 1, 8, &s_vy[(lane >> 3) * 8], 1, s_thr);
-        } else if (!P.y_only) {
-            const int pl = lane >> 5, r = lane & 31;
-            if (r < cvh) lf_line<true>(ctile[pl] + (8 + r) * CS + 8, 1, 4, &s_vc[(r >> 3) * 4], 1, s_thr);
-        }
-        __syncthreads();
-        LF_MARK(3);
-        /* ---- horizontal edges: lane = sample column; a band's descriptor sits at [band*8 + column block] ---- */
-        if (wave == 0) {
-            if (lane < vw) lf_line<false>(ytile + 8 * YS + 8 + lane, YS, nrows, &s_hy[lane >> 3], 8, s_thr);
-        } else if (!P.y_only) {
-            const int pl = lane >> 5, x = lane & 31;
-            if (x < cvw) lf_line<false>(ctile[pl] + 8 * CS + 8 + x, CS, (nrows + 1) >> 1, &s_hc[x >> 3], 4, s_thr);
-        }
-        __syncthreads();
-        LF_MARK(4);
-        /* ---- write back ---- */
-        tile_io<6>(false, P.planes.y, P.planes.y_stride, yl, YS, x0 - hx, y0 - hy, vw + hx, vh + hy, tid, 128);
-        if (!P.y_only) {
-            tile_io<2>(false, P.planes.u, P.planes.uv_stride, ctile[0] + (8 - hy) * CS + (8 - hx), CS, cx0 - hx, cy0 - hy, cvw + hx, cvh + hy, tid, 128);
-            tile_io<2>(false, P.planes.v, P.planes.uv_stride, ctile[1] + (8 - hy) * CS + (8 - hx), CS, cx0 - hx, cy0 - hy, cvw + hx, cvh + hy, tid, 128);
-        }
-        /* ---- publish: all stores of this workgroup -> agent-scope release -> progress counter ---- */
-        __syncthreads();
-        LF_MARK(5);
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        LF_MARK(5, 0);
+        if (wave == 2) {
+            /* write back what is final: tile columns 8-hx .. 8+56 (.. 8+vw for the last SB), rows 8-hy .. 8+vh */
+            const int nxs = (last ? g.vw : 56) + g.hx, nxc = (last ? g.cvw : 24) + g.hx;
+            tile_io<11>(wide_y, false, P.planes.y, P.planes.y_stride, ytile[buf], YS, g.x0 - 8, g.y0 - 8, 8 - g.hx, 8 - g.hy, nxs, g.vh + g.hy, 8, 8 + g.vh - 8, lane, 64);
+            if (!P.y_only) {
+                tile_io<3>(wide_c, false, P.planes.u, P.planes.uv_stride, ctile[buf][0], CS, g.cx0 - 8, g.cy0 - 8, 8 - g.hx, 8 - g.hy, nxc, g.cvh + g.hy, 8, 8 + g.cvh - 8, lane, 64);
+                tile_io<3>(wide_c, false, P.planes.v, P.planes.uv_stride, ctile[buf][1], CS, g.cx0 - 8, g.cy0 - 8, 8 - g.hx, 8 - g.hy, nxc, g.cvh + g.hy, 8, 8 + g.cvh - 8, lane, 64);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the tile has left LDS: the buffer may be refilled */
+            if (lane == 0) s_stored = sc;
+            LF_MARK(6, 128);
+            /* publish: every store of this wave has completed (seam rows were written through) -> progress counter */
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&P.progress[sb_row], (uint32_t)(sc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(&P.progress[sb_row], (uint32_t)(sc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            LF_MARK(7, 128);
         }
-        __syncthreads();
-        LF_MARK(6);
     }
 #undef LF_MARK
 }
@@ -394,12 +460,16 @@ __global__ __launch_bounds__(128) void svt_lf_kernel(const lf_pic_dev *__restric
 
 static int32_t lf_launch(svt_hip_ctx *ctx, int n_pics, const svt_yuv_planes *d_recon, const svt_lf_mask *const *d_lfm, const int32_t *lfm_stride,
                          const svt_lf_thresh *thr, const int32_t *mi_rows, const int32_t *mi_cols, int32_t y_only) {
-    int max_rows = 0;
+    int max_rows = 0, max_cols = 0;
     for (int i = 0; i < n_pics; i++) {
         if (mi_rows[i] < 1 || mi_cols[i] < 1 || d_recon[i].width != mi_cols[i] * 8 || d_recon[i].height != mi_rows[i] * 8)
             return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "lf: plane size must be mi_cols*8 x mi_rows*8");
-        const int r = (mi_rows[i] + 7) / 8;
+        const svt_yuv_planes &pl = d_recon[i];
+        if ((((uintptr_t)pl.y | (uintptr_t)pl.y_stride) & 3) || (!y_only && (((uintptr_t)pl.u | (uintptr_t)pl.v | (uintptr_t)pl.uv_stride) & 3)))
+            return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "lf: plane pointers and strides must be multiples of 4 bytes");
+        const int r = (mi_rows[i] + 7) / 8, cc = (mi_cols[i] + 7) / 8;
         if (r > max_rows) max_rows = r;
+        if (cc > max_cols) max_cols = cc;
     }
     HIP_TRY(hipSetDevice(ctx->device));
     /* descriptors + progress counters + ticket in one device scratch block */
@@ -409,28 +479,34 @@ static int32_t lf_launch(svt_hip_ctx *ctx, int n_pics, const svt_yuv_planes *d_r
     uint8_t     *d = nullptr;
     if (svt_ctx_stage(ctx, desc_bytes + cnt_words * 4, (void **)&h, (void **)&d)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "lf: scratch");
     uint32_t *cnt = (uint32_t *)(d + desc_bytes);
+    /* per-SB edge descriptors of all pictures (grow-only context buffer) */
+    uint32_t *edesc = (uint32_t *)svt_ctx_slot(ctx, 24, (size_t)n_pics * max_rows * max_cols * LF_DESC_WORDS * sizeof(uint32_t));
+    if (!edesc) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "lf: descriptor buffer");
     for (int i = 0; i < n_pics; i++) {
         h[i].planes = d_recon[i]; h[i].lfm = d_lfm[i]; h[i].lfm_stride = lfm_stride[i]; h[i].mi_rows = mi_rows[i]; h[i].mi_cols = mi_cols[i];
         h[i].y_only = y_only; h[i].progress = cnt + 4 + (size_t)i * max_rows;
+        h[i].desc = edesc + (size_t)i * max_rows * max_cols * LF_DESC_WORDS;
     }
     HIP_TRY(hipMemcpyAsync(d, h, sizeof(lf_pic_dev) * (size_t)n_pics, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync(cnt, 0, cnt_words * 4, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
     static const bool want_prof = getenv("SVT_HIP_LF_PROFILE") != nullptr;
     if (want_prof) { unsigned long long z[8] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lf_prof), z, sizeof z)); }
-    hipLaunchKernelGGL(svt_lf_kernel, dim3(n_pics * max_rows), dim3(128), 0, ctx->stream, (const lf_pic_dev *)d, n_pics, *thr, cnt, max_rows, want_prof ? 1 : 0);
+    hipLaunchKernelGGL(svt_lf_desc_kernel, dim3(n_pics * max_rows * max_cols), dim3(128), 0, ctx->stream, (const lf_pic_dev *)d, max_rows, max_cols);
+    hipLaunchKernelGGL(svt_lf_kernel, dim3(n_pics * max_rows), dim3(192), 0, ctx->stream, (const lf_pic_dev *)d, n_pics, *thr, cnt, max_rows, want_prof ? 1 : 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     if (want_prof) {
         unsigned long long hp[8];
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         HIP_TRY(hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_lf_prof), sizeof hp));
-        static const char *nm[7] = {"wait", "tile_load", "descriptors", "vertical", "horizontal", "tile_store", "publish"};
+        static const char *nm[8] = {"io:wait", "io:tile_load", "io:descriptors", "filter:vertical", "filter:horizontal+halo", "filter:barrier",
+                                    "io:tile_store", "io:publish"};
         unsigned long long tot = 0, steps = 0;
-        for (int i = 0; i < 7; i++) tot += hp[i];
+        for (int i = 3; i < 6; i++) tot += hp[i]; /* critical path = the luma filter wave */
         for (int i = 0; i < n_pics; i++) steps += (unsigned long long)((mi_rows[i] + 7) / 8) * ((mi_cols[i] + 7) / 8);
         fprintf(stderr, "[lf-profile] pics=%d SB steps=%llu avg cycles/SB=%llu :", n_pics, steps, tot / (steps ? steps : 1));
-        for (int i = 0; i < 7; i++) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * (double)hp[i] / (double)tot);
+        for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * (double)hp[i] / (double)tot);
         fprintf(stderr, "\n");
     }
     svt_ctx_stage_commit(ctx);

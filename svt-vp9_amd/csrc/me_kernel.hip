@@ -136,7 +136,7 @@ extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, con
     static const bool want_prof = getenv("SVT_HIP_ME_PROFILE") != nullptr;
     unsigned long long *d_prof = nullptr;
     if (want_prof) {
-        d_prof = (unsigned long long *)svt_ctx_slot(ctx, 9 + 14, 32 * sizeof(unsigned long long));
+        d_prof = (unsigned long long *)svt_ctx_slot(ctx, 25, 32 * sizeof(unsigned long long));
         if (d_prof) HIP_TRY(hipMemsetAsync(d_prof, 0, 32 * sizeof(unsigned long long), ctx->stream));
     }
 #ifdef ME_FINE_PROF
