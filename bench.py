@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--height", type=int, default=H4K)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", default="me,tq,lf", help="profiling aid: run only these stages (the contract run uses all three)")
     args = ap.parse_args()
 
     import torch
@@ -220,6 +221,7 @@ def main():
     def run_lf():
         B.check(lib.svt_hip_lf_batch_device(ctx_lf, MINIGOP, lf_desc, lfm_ptrs, lfs, C.byref(thr), mrs, mcs, 0))
 
+    stages = set(args.stages.split(","))
     ev = []  # (stage, start event, stop event) of every stage of every timed step
 
     def staged(k, fn, record):
@@ -234,10 +236,13 @@ def main():
     def step(record=False):
         # the three stages work on different pictures of the pipeline (as the reference's ME / EncDec threads do), so
         # they are issued on three streams; deblocking of a step's pictures is ordered after their reconstruction
-        staged(0, run_me, record)
-        staged(1, run_tq, record)
+        if "me" in stages:
+            staged(0, run_me, record)
+        if "tq" in stages:
+            staged(1, run_tq, record)
         streams[2].wait_stream(streams[1])
-        staged(2, run_lf, record)
+        if "lf" in stages:
+            staged(2, run_lf, record)
 
     def sync():
         for c_ in (ctx_me, ctx_tq, ctx_lf):
@@ -269,6 +274,7 @@ def main():
     L = Wd * Hd
     tq_bytes = MINIGOP * int(7.5 * L)                      # src 1.5L + pred 1.5L + qcoeff 3L + recon 1.5L (the kernel also writes dqcoeff, +3L)
     lf_bytes = MINIGOP * (3 * L + 160 * nsb)               # recon read + write (3L) + masks
+    me_ms, tq_ms, lf_ms = max(me_ms, 1e-9), max(tq_ms, 1e-9), max(lf_ms, 1e-9)
     achieved = me_bytes / (me_ms * 1e-3) / 1e9  # GB/s
 
     if rank != 0:

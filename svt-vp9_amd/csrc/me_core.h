@@ -71,6 +71,7 @@ static inline void svt_lds_add_u32(uint32_t *p, uint32_t v) { *p += v; }
 static inline void svt_wave_add_u32(uint32_t *p, uint32_t v, int uniform_dst) { (void)uniform_dst; *p += v; }
 static inline void svt_wave_min_u64(uint64_t *p, uint64_t v) { if (v < *p) *p = v; }
 static inline void svt_group_add_u32(uint32_t *p, uint32_t v, int group) { (void)group; *p += v; }
+static inline void svt_group_add_var(uint32_t *p, uint32_t v, int group) { (void)group; *p += v; }
 #define ME_MUL(a, b) ((a) * (b))
 #define SVT_SCHED_FENCE() ((void)0)
 /* per 16-bit lane: min(max(v, 32), 287) - 32 */
@@ -160,6 +161,16 @@ SVT_DEV void svt_group_add_u32(uint32_t *p, uint32_t v, int group) {
         v = (uint32_t)__builtin_amdgcn_readlane((int)v, 15) + (uint32_t)__builtin_amdgcn_readlane((int)v, 31) +
             (uint32_t)__builtin_amdgcn_readlane((int)v, 47) + (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
     if ((threadIdx.x & (group - 1)) == (unsigned)(group - 1) && v) atomicAdd(p, v);
+}
+/* as svt_group_add_u32, but the group size (1, 4 or 16 consecutive lanes, aligned) may differ from lane to lane inside a
+ * wave: every lane runs the four row-shift steps and picks the partial sum that covers its own group */
+SVT_DEV void svt_group_add_var(uint32_t *p, uint32_t v, int group) {
+    const uint32_t s1 = SVT_DPP_ADD(v, 0x111);
+    const uint32_t s2 = SVT_DPP_ADD(s1, 0x112); /* 4 lanes */
+    const uint32_t s3 = SVT_DPP_ADD(s2, 0x114);
+    const uint32_t s4 = SVT_DPP_ADD(s3, 0x118); /* 16 lanes */
+    const uint32_t t = group == 1 ? v : group == 4 ? s2 : s4;
+    if ((threadIdx.x & (group - 1)) == (unsigned)(group - 1) && t) atomicAdd(p, t);
 }
 #endif
 
@@ -752,7 +763,22 @@ SVT_DEV void ph_subpel_prep(const me_ctx_t *c, int tid, int en32, int en16, int 
 #define ME_SPU_PY(i) ((int)(((i) >> 17) & 7) << 3)
 #define ME_SPU_W(i) (8 << (((i) >> 20) & 3))
 
-/* half-pel: task = (refined pu, cand, sub-lane).  Distortion accumulates in st->cand[pu*8+cand] (pre-zeroed).
+/* Sub-pel work split: a candidate block of a 64x64 PU is shared by 16 lanes, of a 32x32 PU by 4 lanes, a 16x16 or 8x8
+ * candidate is one lane's job (8 or 4 rows of 16 or 8 samples) -- at the BASELINE settings that is exactly 256 tasks of
+ * equal size per half-pel pass.  The dense PU index k runs 64x64, 32x32, 16x16, 8x8 (me_active_pu), so the task ranges of
+ * the three lane counts are contiguous.  t -> (k, candidate index, sub-lane, lanes per candidate); returns 0 past the end. */
+SVT_DEV int me_subpel_task(int t, int ncand, int n64, int n32, int nrest, int *k, int *ci, int *sl, int *nl) {
+    const int T64 = n64 * ncand * 16, T32 = n32 * ncand * 4;
+    int       q, base;
+    if (t < T64) { *nl = 16; *sl = t & 15; q = t >> 4; base = 0; }
+    else if (t < T64 + T32) { const int u = t - T64; *nl = 4; *sl = u & 3; q = u >> 2; base = n64; }
+    else { q = t - T64 - T32; *nl = 1; *sl = 0; base = n64 + n32; if (q >= nrest * ncand) return 0; }
+    const int kk = ncand == 8 ? q >> 3 : ncand == 3 ? q / 3 : q / 9;
+    *k = base + kk; *ci = q - kk * ncand;
+    return 1;
+}
+
+/* half-pel: distortion of every candidate accumulates in st->cand[pu*8+cand] (pre-zeroed).
  * SUB_SAD: rows 0,2,4.. only, doubled by the consumer; FULL_SAD: all rows.  SSD_SEARCH: 9 candidates per PU (8 = the
  * integer position, whose SSD seeds the comparison, :1107-1160), all rows, SAD in st->cand and SSD in c->ssdc. */
 SVT_DEV void ph_halfpel(const me_ctx_t *c, int tid, int list, int sox, int soy, int en32, int en16, int en8) {
@@ -761,9 +787,10 @@ SVT_DEV void ph_halfpel(const me_ctx_t *c, int tid, int list, int sox, int soy, 
     const int ncand   = ssd ? 9 : 8;
     int       n64, n32, n16;
     const int nact = me_active_count(c, en32, en16, en8, &n64, &n32, &n16);
-    for (int t = tid; t < nact * ncand * ME_SUB_LANES; t += SVT_NT) {
-        int sl = t % ME_SUB_LANES, q = t / ME_SUB_LANES;
-        int k = ssd ? q / 9 : q >> 3, cand = q - k * ncand;
+    const int total = ncand * (n64 * 16 + n32 * 4 + (nact - n64 - n32));
+    for (int t = tid; t < total; t += SVT_NT) {
+        int k, cand, sl, nl;
+        if (!me_subpel_task(t, ncand, n64, n32, nact - n64 - n32, &k, &cand, &sl, &nl)) break;
         const uint32_t info = c->st->spu[k];
         const int      pu = ME_SPU_PU(info), n = ME_SPU_N(info), px = ME_SPU_PX(info), py = ME_SPU_PY(info), w = ME_SPU_W(info);
         uint32_t mv = c->st->best_mv[list][n];
@@ -773,14 +800,12 @@ SVT_DEV void ph_halfpel(const me_ctx_t *c, int tid, int list, int sox, int soy, 
         if (cand < 8) me_hcand_get(cand, &hpl, &hdx, &hdy);
         const uint8_t *cp = me_plane_at(c, hpl, xs + hdx, ys + hdy);
         const uint8_t *sp = c->src + py * ME_SB + px;
-        int            rows = sub_sad ? (w >> 1) : w, step = sub_sad ? 2 : 1;
-        /* rows split over ME_SUB_LANES lanes */
-        int per = (rows + ME_SUB_LANES - 1) / ME_SUB_LANES;
-        int r0 = sl * per, r1 = r0 + per < rows ? r0 + per : rows;
+        const int      rows = sub_sad ? (w >> 1) : w, step = sub_sad ? 2 : 1;
+        const int      per = nl == 16 ? rows >> 4 : nl == 4 ? rows >> 2 : rows, r0 = sl * per;
         uint32_t e = 0;
-        uint32_t d = r0 < r1 ? me_block_sad_rows(sp, ME_SB * step, cp, 0, c->L.region_stride * step, w, r0, r1, ssd ? &e : 0) : 0;
-        if (cand < 8) svt_group_add_u32(&c->st->cand[pu * 8 + cand], d, ME_SUB_LANES); /* the 8 lanes of a task are consecutive */
-        if (ssd) svt_group_add_u32(&c->ssdc[pu * 9 + cand], e, ME_SUB_LANES);
+        uint32_t d = me_block_sad_rows(sp, ME_SB * step, cp, 0, c->L.region_stride * step, w, r0, r0 + per, ssd ? &e : 0);
+        if (cand < 8) svt_group_add_var(&c->st->cand[pu * 8 + cand], d, nl);
+        if (ssd) svt_group_add_var(&c->ssdc[pu * 9 + cand], e, nl);
     }
 }
 
@@ -863,9 +888,9 @@ SVT_DEV void ph_quarterpel(const me_ctx_t *c, int tid, int list, int sox, int so
     const int ssd     = c->p->fractional_search_method == SVT_SSD_SEARCH;
     int       n64, n32, n16;
     const int nact = me_active_count(c, en32, en16, en8, &n64, &n32, &n16);
+    /* few candidates (3 per PU): 8 lanes share one candidate block so that the pass stays short */
     for (int t = tid; t < nact * 3 * ME_SUB_LANES; t += SVT_NT) {
-        int sl = t % ME_SUB_LANES, q = t / ME_SUB_LANES;
-        int k = q / 3, j = q - 3 * k;
+        const int sl = t % ME_SUB_LANES, q = t / ME_SUB_LANES, k = q / 3, j = q - 3 * k, nl = ME_SUB_LANES;
         const uint32_t info = c->st->spu[k];
         const int      pu = ME_SPU_PU(info), n = ME_SPU_N(info), px = ME_SPU_PX(info), py = ME_SPU_PY(info);
         const int      w = pu == 0 ? 32 : ME_SPU_W(info);
@@ -880,13 +905,12 @@ SVT_DEV void ph_quarterpel(const me_ctx_t *c, int tid, int list, int sox, int so
         const uint8_t *a  = me_plane_at(c, (int)(e & 3), xs - (int)((e >> 2) & 1), ys - (int)((e >> 3) & 1));
         const uint8_t *b  = me_plane_at(c, (int)((e >> 4) & 3), xs - (int)((e >> 6) & 1), ys - (int)((e >> 7) & 1));
         const uint8_t *sp = c->src + py * ME_SB + px;
-        int            rows = sub_sad ? (w >> 1) : w, step = sub_sad ? 2 : 1;
-        int            per = (rows + ME_SUB_LANES - 1) / ME_SUB_LANES;
-        int            r0 = sl * per, r1 = r0 + per < rows ? r0 + per : rows;
+        const int      rows = sub_sad ? (w >> 1) : w, step = sub_sad ? 2 : 1;
+        const int      per = (rows + nl - 1) / nl, r0 = sl * per, r1 = r0 + per < rows ? r0 + per : rows;
         uint32_t sq = 0;
         uint32_t d = r0 < r1 ? me_block_sad_rows(sp, ME_SB * step, a, b, c->L.region_stride * step, w, r0, r1, ssd ? &sq : 0) : 0;
-        svt_group_add_u32(&c->st->cand[pu * 8 + pos], d, ME_SUB_LANES);
-        if (ssd) svt_group_add_u32(&c->ssdc[pu * 9 + pos], sq, ME_SUB_LANES);
+        svt_group_add_u32(&c->st->cand[pu * 8 + pos], d, nl);
+        if (ssd) svt_group_add_u32(&c->ssdc[pu * 9 + pos], sq, nl);
     }
 }
 
@@ -1061,7 +1085,7 @@ __device__ int g_me_stop_after = -1;
 #ifdef SVT_HOST_EMU
 #define ME_PHASE(...) do { for (int tid = 0; tid < SVT_NT; tid++) { __VA_ARGS__; } } while (0)
 #define ME_UNIFORM_WRITE(...) do { __VA_ARGS__; } while (0)
-#define ME_UNI(x) (x)
+#define ME_UNI(x) ((int)(x))
 #else
 #define ME_PHASE(...) do { __VA_ARGS__; __syncthreads(); } while (0)
 /* uniform state written to LDS by one thread, followed by a barrier */
@@ -1425,17 +1449,18 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                 int16_t dirx = 0, diry = 0;
                 int     nc = 4;
                 if (list == 1) {
-                    dirx = (int16_t)(0 - (me_mvx(st->best_mv[0][0]) >> 2));
-                    diry = (int16_t)(0 - (me_mvy(st->best_mv[0][0]) >> 2));
+                    const uint32_t mv00 = (uint32_t)ME_UNI(st->best_mv[0][0]);
+                    dirx = (int16_t)(0 - (me_mvx(mv00) >> 2));
+                    diry = (int16_t)(0 - (me_mvy(mv00) >> 2));
                     dx[4] = me_clip_center(ox, dirx, pad, W); dy[4] = me_clip_center(oy, diry, pad, H);
                     nc = 5;
                 }
                 ME_PHASE(if (tid < 8) st->red[tid] = 0);
                 ME_PHASE(ph_center_sads(c, tid, rf, nc, dx, dy));
-                uint64_t zero_c = (uint64_t)st->red[0] << 1, b_c = (uint64_t)st->red[1] << 1, c_c = (uint64_t)st->red[2] << 1,
-                         d_c = (uint64_t)st->red[3] << 1;
+                uint64_t zero_c = (uint64_t)(uint32_t)ME_UNI(st->red[0]) << 1, b_c = (uint64_t)(uint32_t)ME_UNI(st->red[1]) << 1,
+                         c_c = (uint64_t)(uint32_t)ME_UNI(st->red[2]) << 1, d_c = (uint64_t)(uint32_t)ME_UNI(st->red[3]) << 1;
                 uint64_t a_c = zero_c; /* [quirk] A is evaluated at the zero-MV address (:4302-4327) */
-                uint64_t dir_c = list == 1 ? (uint64_t)st->red[4] << 1 : 0xFFFFFFFFFFFFFull;
+                uint64_t dir_c = list == 1 ? (uint64_t)(uint32_t)ME_UNI(st->red[4]) << 1 : 0xFFFFFFFFFFFFFull;
                 uint64_t best = zero_c;
                 if (a_c < best) best = a_c;
                 if (b_c < best) best = b_c;
@@ -1498,7 +1523,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
             dx[0] = 0; dy[0] = 0; dx[1] = xsc; dy[1] = ysc;
             ME_PHASE(if (tid < 8) st->red[tid] = 0);
             ME_PHASE(ph_center_sads(c, tid, rf, 2, dx, dy));
-            uint64_t z = (uint64_t)st->red[0] << 1, h = (uint64_t)st->red[1] << 1;
+            uint64_t z = (uint64_t)(uint32_t)ME_UNI(st->red[0]) << 1, h = (uint64_t)(uint32_t)ME_UNI(st->red[1]) << 1;
             uint64_t m = z < h ? z : h;
             if (m == z) { xsc = 0; ysc = 0; }
             ME_PHASE((void)0);
@@ -1564,14 +1589,14 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                     svt_wave_add_u32(&st->supel[3 * k + 2], cls == k ? sd : 0u, 1);
                 }
             });
-            int      sx = (int)st->supel[0], sy = (int)st->supel[1];
-            uint32_t ss = st->supel[2];
+            int      sx = ME_UNI(st->supel[0]), sy = ME_UNI(st->supel[1]);
+            uint32_t ss = (uint32_t)ME_UNI(st->supel[2]);
             uint32_t ax = (uint32_t)(sx >> 2), ay = (uint32_t)(sy >> 2);
             uint32_t mag32 = ax * ax + ay * ay, sad32 = ss >> 2;
-            sx = (int)st->supel[3]; sy = (int)st->supel[4]; ss = st->supel[5];
+            sx = ME_UNI(st->supel[3]); sy = ME_UNI(st->supel[4]); ss = (uint32_t)ME_UNI(st->supel[5]);
             ax = (uint32_t)(sx >> 4); ay = (uint32_t)(sy >> 4);
             uint32_t mag16 = ax * ax + ay * ay, sad16 = ss >> 4;
-            sx = (int)st->supel[6]; sy = (int)st->supel[7]; ss = st->supel[8];
+            sx = ME_UNI(st->supel[6]); sy = ME_UNI(st->supel[7]); ss = (uint32_t)ME_UNI(st->supel[8]);
             ax = (uint32_t)(sx >> 6); ay = (uint32_t)(sy >> 6);
             uint32_t mag8 = ax * ax + ay * ay, sad8 = ss >> 6;
             const int thr_[4]    = {48, 32, 80, 48};
