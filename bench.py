@@ -175,21 +175,35 @@ def main():
         pos += len(ys) * n * n
         counts[ts] = len(ys)
         tq_arr.append(a)
-    tq_blocks = np.concatenate(tq_arr)
+    tq_blocks = np.concatenate(tq_arr)   # one picture's blocks, grouped by transform size
     n_coeff = pos
-    d_blocks, d_qt, d_iscan = to_dev(tq_blocks.view(np.uint8)), to_dev(qtabs.view(np.uint8)), to_dev(iscan)
-    d_q, d_dq = to_dev(np.zeros(n_coeff, np.int16)), to_dev(np.zeros(n_coeff, np.int16))
-    d_eob = to_dev(np.zeros(len(tq_blocks), np.uint16))
-    tq_pics = []
+    # the whole mini-GOP is one batch (like ME's per-layer and LF's per-GOP launches): the 16 pictures live in one
+    # buffer per plane set, picture k at byte offset k * pic_bytes, and the block list holds every picture's blocks,
+    # grouped by transform size across pictures -> 4 launches per step, each big enough to fill the GPU
+    pic_bytes = yuv_rows * plane_w
+    all_arr = []
+    for ts in range(4):
+        for k in range(MINIGOP):
+            a = tq_arr[ts].copy()
+            for f in ("src_off", "pred_off", "recon_off"):
+                a[f] += np.uint32(k * pic_bytes)
+            a["coeff_off"] += np.uint32(k * n_coeff)
+            all_arr.append(a)
+    tq_blocks_all = np.concatenate(all_arr)
+    d_blocks, d_qt, d_iscan = to_dev(tq_blocks_all.view(np.uint8)), to_dev(qtabs.view(np.uint8)), to_dev(iscan)
+    d_q, d_dq = to_dev(np.zeros(MINIGOP * n_coeff, np.int16)), to_dev(np.zeros(MINIGOP * n_coeff, np.int16))
+    d_eob = to_dev(np.zeros(len(tq_blocks_all), np.uint16))
+    src_all = np.zeros((MINIGOP, yuv_rows, plane_w), np.uint8)
+    pred_all = np.zeros_like(src_all)
     for i in range(1, MINIGOP + 1):
         y = frames[i]
-        yuv = np.zeros((yuv_rows, plane_w), np.uint8)
+        yuv = src_all[i - 1]
         yuv[:Hd] = y
         yuv[Hd:, :Wd // 2] = y[::2, ::2] // 2 + 32
         yuv[Hd:, Wd // 2:] = 128
-        pred = np.clip(np.roll(yuv, (1, 2), (0, 1)).astype(np.int16) + rng.integers(-6, 7, yuv.shape, dtype=np.int16), 0, 255).astype(np.uint8)
-        tq_pics.append((to_dev(yuv), to_dev(pred), to_dev(np.zeros_like(yuv))))
-    cnt_c = (C.c_int32 * 4)(*counts.tolist())
+        pred_all[i - 1] = np.clip(np.roll(yuv, (1, 2), (0, 1)).astype(np.int16) + rng.integers(-6, 7, yuv.shape, dtype=np.int16), 0, 255).astype(np.uint8)
+    d_src, d_pred, d_rec = to_dev(src_all), to_dev(pred_all), to_dev(np.zeros_like(src_all))
+    cnt_c = (C.c_int32 * 4)(*[int(v) * MINIGOP for v in counts.tolist()])
 
     # ---- stage 3: in-loop deblocking of the 16 reconstructed pictures, one batched launch ----
     mi_rows, mi_cols = Hd // 8, Wd // 8
@@ -198,8 +212,8 @@ def main():
     thr = B.LfThresh()
     lib.svt_hip_lf_thresh_init(C.byref(thr), 0)
     lf_desc = (B.YuvPlanes * MINIGOP)()
-    for k, (_, _, rec) in enumerate(tq_pics):
-        base = rec.data_ptr()
+    for k in range(MINIGOP):
+        base = d_rec.data_ptr() + k * pic_bytes
         d = lf_desc[k]
         d.y, d.u, d.v = base, base + Hd * plane_w, base + Hd * plane_w + Wd // 2
         d.y_stride, d.uv_stride, d.width, d.height = plane_w, plane_w, Wd, Hd
@@ -212,11 +226,10 @@ def main():
             B.check(lib.svt_hip_me_batch_device(ctx_me, n, cur, r0, r1, C.byref(p), res, None))
 
     def run_tq():
-        for (s_, p_, r_) in tq_pics:
-            B.check(lib.svt_hip_tq_batch_device(ctx_tq, C.c_void_p(s_.data_ptr()), C.c_void_p(p_.data_ptr()), C.c_void_p(r_.data_ptr()),
-                                                C.c_void_p(d_blocks.data_ptr()), cnt_c, C.c_void_p(d_qt.data_ptr()),
-                                                C.c_void_p(d_iscan.data_ptr()), C.c_void_p(d_q.data_ptr()), C.c_void_p(d_dq.data_ptr()),
-                                                C.c_void_p(d_eob.data_ptr())))
+        B.check(lib.svt_hip_tq_batch_device(ctx_tq, C.c_void_p(d_src.data_ptr()), C.c_void_p(d_pred.data_ptr()), C.c_void_p(d_rec.data_ptr()),
+                                            C.c_void_p(d_blocks.data_ptr()), cnt_c, C.c_void_p(d_qt.data_ptr()),
+                                            C.c_void_p(d_iscan.data_ptr()), C.c_void_p(d_q.data_ptr()), C.c_void_p(d_dq.data_ptr()),
+                                            C.c_void_p(d_eob.data_ptr())))
 
     def run_lf():
         B.check(lib.svt_hip_lf_batch_device(ctx_lf, MINIGOP, lf_desc, lfm_ptrs, lfs, C.byref(thr), mrs, mcs, 0))
@@ -330,7 +343,7 @@ def main():
             used.append(i)
             if t_me >= 6.0:
                 break
-        src_h, pred_h = tq_pics[0][0].cpu().numpy(), tq_pics[0][1].cpu().numpy()
+        src_h, pred_h = src_all[0], pred_all[0]
         rec_h = np.zeros_like(src_h)
         q_h, dq_h, eob_h = np.zeros(n_coeff, np.int16), np.zeros(n_coeff, np.int16), np.zeros(len(tq_blocks), np.uint16)
         t1 = time.perf_counter()

@@ -12,7 +12,8 @@
  * padded (N+1 dwords per row) LDS tile so both passes are bank-conflict free; the eob is a max-reduction of
  * iscan positions over the block's N lanes (DPP/shuffle).  Integer butterflies on VALU -- no MFMA (these are
  * 32-bit integer rotations with data-dependent rounding/truncation, not dense contractions).
- * Global traffic per block: N*N source + N*N prediction bytes in, 2*N*N int16 (qcoeff, dqcoeff) + N*N recon out.
+ * Source, prediction and reconstruction move as dword rows (lane i owns row i); the row <-> column changes go through the
+ * same LDS tile.  Global traffic per block: N*N source + N*N prediction bytes in, 2*N*N int16 (qcoeff, dqcoeff) + N*N recon out.
  */
 #include <hip/hip_runtime.h>
 #include "svt_ctx.h"
@@ -78,16 +79,19 @@ __global__ __launch_bounds__(256) void svt_tq_kernel(const uint8_t *__restrict__
     const bool col_adst = tx_type == SVT_ADST_DCT || tx_type == SVT_ADST_ADST;
     const bool row_adst = tx_type == SVT_DCT_ADST || tx_type == SVT_ADST_ADST;
 
-    int32_t v[N], o[N];
-    uint8_t pcol[N]; /* prediction column, reused by the reconstruction */
-    /* ---- residual (column i) and column transform ---- */
+    int32_t  v[N], o[N];
+    uint32_t prow[N / 4]; /* prediction row i (packed), reused by the reconstruction */
+    /* ---- residual: lane i fetches ROW i of source and prediction as dwords (coalesced: the N lanes of a block read N
+     * consecutive rows of N bytes), the residual row goes through the LDS tile and comes back as COLUMN i ---- */
     {
-        const uint8_t *s = src + k.src_off + i, *p = pred + k.pred_off + i;
-        _Pragma("unroll") for (int r = 0; r < N; r++) {
-            const int sv = active ? s[r * k.src_stride] : 0, pv = active ? p[r * k.pred_stride] : 0;
-            pcol[r] = (uint8_t)pv;
-            v[r]    = (int16_t)(sv - pv);
-        }
+        const uint32_t *sp = (const uint32_t *)(src + k.src_off + (size_t)i * k.src_stride);
+        const uint32_t *pp = (const uint32_t *)(pred + k.pred_off + (size_t)i * k.pred_stride);
+        uint32_t        srow[N / 4];
+        _Pragma("unroll") for (int q = 0; q < N / 4; q++) { srow[q] = active ? sp[q] : 0u; prow[q] = active ? pp[q] : 0u; }
+        _Pragma("unroll") for (int cc = 0; cc < N; cc++)
+            t[i * LS + cc] = (int16_t)((int)((srow[cc >> 2] >> (8 * (cc & 3))) & 0xff) - (int)((prow[cc >> 2] >> (8 * (cc & 3))) & 0xff));
+        /* the N lanes of a block sit in one wave and LDS accesses of a wave are ordered: no barrier needed here */
+        _Pragma("unroll") for (int r = 0; r < N; r++) v[r] = t[r * LS + i];
     }
     if (tx_type == SVT_DCT_DCT) {
         _Pragma("unroll") for (int r = 0; r < N; r++) v[r] *= (N == 4 ? 16 : 4);
@@ -132,7 +136,12 @@ __global__ __launch_bounds__(256) void svt_tq_kernel(const uint8_t *__restrict__
     }
     /* ---- quantise row i; eob = 1 + max scan position of a non-zero level ---- */
     const svt_quant_tables q = qtabs[k.qtab];
-    const int16_t *iscan = iscan_all + k.iscan_off + i * N;
+    /* row i of the inverse scan, fetched as dwords up front (its latency hides behind the transforms) */
+    uint32_t isw[N / 2];
+    {
+        const uint32_t *ip = (const uint32_t *)(iscan_all + k.iscan_off + i * N);
+        _Pragma("unroll") for (int q = 0; q < N / 2; q++) isw[q] = ip[q];
+    }
     int eob = 0;
     uint32_t rdist = 0, pdist = 0;
     int32_t dq[N];
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(256) void svt_tq_kernel(const uint8_t *__restrict__
         rdist += (uint32_t)(dd * dd);
         pdist += (uint32_t)(cv * cv);
         if (active) { qo[kk] = (int16_t)qv; dqo[kk] = (int16_t)dv; }
-        if (level && active) { const int pos = iscan[kk] + 1; eob = pos > eob ? pos : eob; }
+        if (level && active) { const int pos = (int)((isw[kk >> 1] >> (16 * (kk & 1))) & 0xffff) + 1; eob = pos > eob ? pos : eob; }
     }
     _Pragma("unroll") for (int off = 1; off < N; off <<= 1) { const int other = __shfl_xor(eob, off); eob = other > eob ? other : eob; }
     if (active && i == 0) eob_out[blk] = (uint16_t)eob;
@@ -207,9 +216,16 @@ __global__ __launch_bounds__(256) void svt_tq_kernel(const uint8_t *__restrict__
         const int32_t a1 = (d + (1 << (txcfg<N>::shift - 1))) >> txcfg<N>::shift;
         _Pragma("unroll") for (int r = 0; r < N; r++) res[r] = a1;
     }
+    /* residual column i -> LDS -> row i; reconstruction = clip(pred row + residual row), stored as dwords */
+    _Pragma("unroll") for (int r = 0; r < N; r++) t[r * LS + i] = res[r];
     if (active) {
-        uint8_t *d = recon + k.recon_off + i;
-        _Pragma("unroll") for (int r = 0; r < N; r++) d[r * k.recon_stride] = clip_add(pcol[r], res[r]);
+        uint32_t *d = (uint32_t *)(recon + k.recon_off + (size_t)i * k.recon_stride);
+        _Pragma("unroll") for (int q = 0; q < N / 4; q++) {
+            uint32_t w = 0;
+            _Pragma("unroll") for (int b = 0; b < 4; b++)
+                w |= (uint32_t)clip_add((int)((prow[q] >> (8 * b)) & 0xff), t[i * LS + 4 * q + b]) << (8 * b);
+            d[q] = w;
+        }
     }
 }
 
