@@ -13,13 +13,18 @@
 extern __shared__ __align__(16) uint8_t svt_lds[];
 
 #ifndef ME_WAVES_PER_EU
-#define ME_WAVES_PER_EU 3 /* 3 workgroups of 4 waves per CU: <= 168 VGPRs, <= 53 KB of LDS */
+#define ME_WAVES_PER_EU 3 /* generic instance: 3 workgroups of 4 waves per CU: <= 168 VGPRs, <= 53 KB of LDS */
+#endif
+#ifndef ME_WAVES_PER_EU_SPEC
+/* specialised instances fit 128 VGPRs (a dozen spills): LDS still admits 3 workgroups per CU, but a SIMD then has room for
+ * a wave of the deblocking kernel (96 VGPRs) next to its three ME waves when the stages overlap */
+#define ME_WAVES_PER_EU_SPEC 4
 #endif
 /* One workgroup per (picture, SB).  blockIdx -> work item mapping is XCD-aware: consecutive work items
  * (neighbouring SBs, which share most of their reference window) are placed on the same XCD so that the
  * window re-reads hit that XCD's L2 (block b runs on XCD b % 8). */
 template <int SPEC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ME_WAVES_PER_EU))) void svt_me_sb_kernel(const me_pic_dev *__restrict__ pics, svt_me_params p, me_lds_layout L,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC != 0 ? ME_WAVES_PER_EU_SPEC : ME_WAVES_PER_EU))) void svt_me_sb_kernel(const me_pic_dev *__restrict__ pics, svt_me_params p, me_lds_layout L,
                                                         int n_sb, int nx, int pic_w, int pic_h, int total, int chunk, unsigned long long *prof) {
     const int b = blockIdx.x;
     const int l = (b & 7) * chunk + (b >> 3);
