@@ -290,6 +290,20 @@ def main():
     me_ms, tq_ms, lf_ms = max(me_ms, 1e-9), max(tq_ms, 1e-9), max(lf_ms, 1e-9)
     achieved = me_bytes / (me_ms * 1e-3) / 1e9  # GB/s
 
+    # ---- picture-analysis pre-ME stage (row f-1, not part of `value`): rebuild the three padded planes of the 16
+    # pictures from their luma in one batched launch, timed on its own with HIP events ----
+    d_lumas = [to_dev(frames[i]) for i in range(1, MINIGOP + 1)]
+    pa_out = (B.PaPicture * MINIGOP)(*[pics[i].desc() for i in range(1, MINIGOP + 1)])
+    pa_ptrs = (C.c_void_p * MINIGOP)(*[t.data_ptr() for t in d_lumas])
+    pa_strides = (C.c_int32 * MINIGOP)(*[Wd] * MINIGOP)
+    pa_ms = 0.0
+    for rep in range(4):
+        B.check(lib.svt_hip_pa_prepare_batch_device(ctx_me, MINIGOP, pa_ptrs, pa_strides, pa_out, 1 if l1_on else 0))
+        B.check(lib.svt_hip_ctx_synchronize(ctx_me))
+        if rep:
+            pa_ms += lib.svt_hip_last_kernel_ms(ctx_me) / 3
+    pa_bytes = MINIGOP * int(Wd * Hd + (Wd + 136) * (Hd + 136) + (Wd // 4 + 32) * (Hd // 4 + 32) + (((Wd // 2 + 64) * (Hd // 2 + 64)) if l1_on else 0))
+
     if rank != 0:
         return
     # HBM traffic of the dominant kernel per step, from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.md)
@@ -323,7 +337,7 @@ def main():
         "kernels": {k: {"ms_per_step": round(ms, 3), "algorithmic_bytes_per_step": b, "GB_per_s": round(b / (ms * 1e-3) / 1e9, 2),
                         "frac_of_8TBps": round(b / (ms * 1e-3) / 8e12, 5)}
                     for k, ms, b in (("svt_me_sb_kernel", me_ms, me_bytes), ("svt_tq_kernel<4|8|16|32>", tq_ms, tq_bytes),
-                                     ("svt_lf_kernel", lf_ms, lf_bytes))},
+                                     ("svt_lf_kernel", lf_ms, lf_bytes), ("svt_pa_plane_kernel (pre-ME stage, outside value)", pa_ms, pa_bytes))},
     }
     if not args.no_cpu_baseline:
         # oracle (scalar C restatement of the reference C path), single thread, on a bounded sample of the same

@@ -218,6 +218,20 @@ void svt_hip_me_similar_collocated(const uint8_t *cur_mean, const uint16_t *cur_
                                    int32_t is_used_as_reference, uint8_t *similar, uint8_t *similar_all_layers);
 
 /* ------------------------------------------------------------------------------------------------ */
+/* Picture-analysis pre-ME stage ("next" row f-1 of the scope table)                                  */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* Builds the three planes of an EbPaReferenceObject from a picture's W x H luma, all on the device:
+ *   full      = copy + edge replication by origin_x/origin_y samples (eb_vp9_generate_padding, Codec/EbMcp.c:17-58,
+ *               called by pad_picture_to_multiple_of_sb_dimensions, Codec/EbPictureAnalysisProcess.c:5010-5020)
+ *   quarter   = 2x2 point decimation (eb_vp9_decimation_2d, :102-122, step 2) + edge replication, only if make_quarter
+ *   sixteenth = 4x4 point decimation (step 4) + edge replication       (decimate_input_picture, :5025-5088)
+ * `out[i]` describes the destination planes of picture i (device buffers; buf, stride, origin, width, height as the
+ * ME entry points expect them: quarter = W/2 x H/2, sixteenth = W/4 x H/4).  W and H must be multiples of 8. */
+int32_t svt_hip_pa_prepare_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const uint8_t *const *d_luma,
+                                        const int32_t *luma_stride, const svt_pa_picture *out, int32_t make_quarter);
+
+/* ------------------------------------------------------------------------------------------------ */
 /* Transform / quantisation                                                                           */
 /* ------------------------------------------------------------------------------------------------ */
 

@@ -1,0 +1,89 @@
+/*
+ * pa_kernel.hip -- picture-analysis pre-ME stage on gfx950: border replication and 1/4, 1/16 point decimation of the
+ * input luma, producing the three padded planes motion estimation reads (an EbPaReferenceObject).
+ *
+ * Replaces pad_picture_to_multiple_of_sb_dimensions + decimate_input_picture of eb_vp9_picture_analysis_kernel
+ * (Source/Lib/Codec/EbPictureAnalysisProcess.c:5010-5088 -> eb_vp9_decimation_2d :102-122, eb_vp9_generate_padding
+ * Codec/EbMcp.c:17-58).  Pure streaming: every destination sample is src[step*clamp(y - pad)][step*clamp(x - pad)], so
+ * one kernel writes all planes of all pictures of a batch; a thread produces 4 consecutive destination bytes.
+ * HBM bound: reads W*H (the decimated planes re-read lines that the L2 still holds), writes ~1.4 W*H.
+ */
+#include <hip/hip_runtime.h>
+#include "svt_ctx.h"
+
+namespace {
+struct pa_job {
+    const uint8_t *src; /* luma sample (0,0) */
+    uint8_t       *dst; /* first byte of the padded destination buffer */
+    int32_t        sstride, dstride, step, pad_x, pad_y, dw, dh; /* dw x dh = decimated size (without padding) */
+    int32_t        row0; /* first workgroup row of this job in the flattened grid */
+};
+
+constexpr int PA_ROWS = 4; /* destination rows per workgroup */
+
+__global__ __launch_bounds__(256) void svt_pa_plane_kernel(const pa_job *__restrict__ jobs, int n_jobs) {
+    /* find the job of this workgroup row (a handful of jobs: linear scan) */
+    int j = 0;
+    while (j + 1 < n_jobs && (int)blockIdx.x >= jobs[j + 1].row0) j++;
+    const pa_job J = jobs[j];
+    const int tw = J.dw + 2 * J.pad_x, th = J.dh + 2 * J.pad_y; /* padded size */
+    const int py0 = ((int)blockIdx.x - J.row0) * PA_ROWS;
+    const int nq = (tw + 3) >> 2; /* dwords per destination row */
+    for (int t = threadIdx.x; t < nq * PA_ROWS; t += 256) {
+        const int r = t / nq, q = t - r * nq, py = py0 + r;
+        if (py >= th) break;
+        int sy = py - J.pad_y;
+        sy = sy < 0 ? 0 : sy > J.dh - 1 ? J.dh - 1 : sy;
+        const uint8_t *srow = J.src + (size_t)(sy * J.step) * J.sstride;
+        uint8_t       *drow = J.dst + (size_t)py * J.dstride + 4 * q;
+        const int      px0 = 4 * q - J.pad_x;
+        uint32_t       w;
+        if (J.step == 1 && px0 >= 0 && px0 + 3 < J.dw && ((((uintptr_t)srow + px0) & 3) == 0)) {
+            w = *(const uint32_t *)(srow + px0); /* interior of the full-resolution plane: aligned dword copy */
+        } else {
+            w = 0;
+            _Pragma("unroll") for (int b = 0; b < 4; b++) {
+                int sx = px0 + b;
+                sx = sx < 0 ? 0 : sx > J.dw - 1 ? J.dw - 1 : sx;
+                w |= (uint32_t)srow[sx * J.step] << (8 * b);
+            }
+        }
+        if (4 * q + 3 < tw && (((uintptr_t)drow) & 3) == 0) *(uint32_t *)drow = w;
+        else
+            for (int b = 0; b < 4 && 4 * q + b < tw; b++) drow[b] = (uint8_t)(w >> (8 * b));
+    }
+}
+} // namespace
+
+extern "C" int32_t svt_hip_pa_prepare_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const uint8_t *const *d_luma,
+                                                   const int32_t *luma_stride, const svt_pa_picture *out, int32_t make_quarter) {
+    if (!ctx || n_pics < 1 || !d_luma || !luma_stride || !out) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "pa: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int per = make_quarter ? 3 : 2, n_jobs = n_pics * per;
+    pa_job *h = nullptr, *d = nullptr;
+    if (svt_ctx_stage(ctx, sizeof(pa_job) * (size_t)n_jobs, (void **)&h, (void **)&d)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "pa: scratch");
+    int rows = 0, k = 0;
+    for (int i = 0; i < n_pics; i++) {
+        const svt_plane *pl[3] = {&out[i].full, &out[i].quarter, &out[i].sixteenth};
+        const int        W = out[i].full.width, H = out[i].full.height;
+        if (!d_luma[i] || W < 8 || H < 8 || (W & 7) || (H & 7)) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "pa: width/height must be multiples of 8");
+        for (int s = 0; s < 3; s++) {
+            if (s == 1 && !make_quarter) continue;
+            const int step = 1 << s;
+            if (!pl[s]->buf || pl[s]->width != W / step || pl[s]->height != H / step || pl[s]->stride < W / step + 2 * pl[s]->origin_x)
+                return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "pa: destination plane geometry");
+            pa_job &J = h[k++];
+            J.src = d_luma[i]; J.dst = (uint8_t *)pl[s]->buf; J.sstride = luma_stride[i]; J.dstride = pl[s]->stride; J.step = step;
+            J.pad_x = pl[s]->origin_x; J.pad_y = pl[s]->origin_y; J.dw = W / step; J.dh = H / step; J.row0 = rows;
+            rows += (J.dh + 2 * J.pad_y + PA_ROWS - 1) / PA_ROWS;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(d, h, sizeof(pa_job) * (size_t)n_jobs, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    hipLaunchKernelGGL(svt_pa_plane_kernel, dim3(rows), dim3(256), 0, ctx->stream, (const pa_job *)d, n_jobs);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    svt_ctx_stage_commit(ctx);
+    ctx->timed = 1;
+    return SVT_HIP_OK;
+}
