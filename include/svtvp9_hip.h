@@ -231,6 +231,14 @@ void svt_hip_me_similar_collocated(const uint8_t *cur_mean, const uint16_t *cur_
 int32_t svt_hip_pa_prepare_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const uint8_t *const *d_luma,
                                         const int32_t *luma_stride, const svt_pa_picture *out, int32_t make_quarter);
 
+/* 8x8 .. 64x64 block mean and variance of every SB of a padded luma plane = compute_block_mean_compute_variance
+ * (Codec/EbPictureAnalysisProcess.c:2115-3356; 8x8 sums on rows 0,2,4,6 with the SSE2 kernels the reference calls at
+ * `-asm 0`, ASM_SSE2/EbComputeMean_Intrinsic_SSE2.c:10-53; larger blocks are >>2 averages of their four children).
+ * d_mean[sb*85 + pu] = (uint8_t)(mean >> 8), d_var[sb*85 + pu] = (uint16_t)((mean_of_squares - mean^2) >> 16), pu in
+ * raster order per size: 0 = 64x64, 1-4 = 32x32, 5-20 = 16x16, 21-84 = 8x8 (ME_TIER_ZERO_PU_*,
+ * Codec/EbMotionEstimationContext.h:45-131).  SBs at the right/bottom border read the replicated padding. */
+int32_t svt_hip_pa_mean_variance_device(svt_hip_ctx *ctx, const svt_plane *full, uint8_t *d_mean, uint16_t *d_var);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* Transform / quantisation                                                                           */
 /* ------------------------------------------------------------------------------------------------ */

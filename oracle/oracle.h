@@ -42,4 +42,7 @@ void    svt_oracle_me_similar_collocated(const uint8_t *cur_mean, const uint16_t
                                          int32_t n_sb, int32_t is_i_slice, int32_t is_used_as_reference, uint8_t *similar, uint8_t *similar_all);
 /* picture-analysis pre-ME stage: decimate_input_picture + padding (Codec/EbPictureAnalysisProcess.c:5010-5088) */
 int32_t svt_oracle_pa_prepare(const uint8_t *luma, int32_t luma_stride, const svt_pa_picture *out, int32_t make_quarter);
+/* compute_block_mean_compute_variance (Codec/EbPictureAnalysisProcess.c:2115-3356) */
+void    svt_oracle_pa_mean8x8(const uint8_t *p, int32_t stride, uint64_t *mean, uint64_t *mean_sq);
+int32_t svt_oracle_pa_mean_variance(const svt_plane *full, uint8_t *mean_out, uint16_t *var_out);
 #endif

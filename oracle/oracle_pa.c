@@ -41,3 +41,41 @@ int32_t svt_oracle_pa_prepare(const uint8_t *luma, int32_t luma_stride, const sv
     }
     return 0;
 }
+
+
+/* compute_block_mean_compute_variance (Codec/EbPictureAnalysisProcess.c:2115-3356), the path taken without AVX2:
+ * eb_vp9_compute_sub_mean8x8_sse2_intrin / eb_vp9_compute_subd_mean_of_squared_values8x8_sse2_intrin
+ * (ASM_SSE2/EbComputeMean_Intrinsic_SSE2.c:10-53): rows 0,2,4,6 of each 8x8; sum << 3 and sum of squares << 11 */
+void svt_oracle_pa_mean8x8(const uint8_t *p, int32_t stride, uint64_t *mean, uint64_t *mean_sq) {
+    uint32_t s = 0, q = 0;
+    for (int r = 0; r < 8; r += 2)
+        for (int x = 0; x < 8; x++) { s += p[r * stride + x]; q += (uint32_t)p[r * stride + x] * p[r * stride + x]; }
+    *mean = (uint64_t)s << 3;
+    *mean_sq = (uint64_t)q << 11;
+}
+
+int32_t svt_oracle_pa_mean_variance(const svt_plane *full, uint8_t *mean_out, uint16_t *var_out) {
+    const int nx = (full->width + 63) / 64, ny = (full->height + 63) / 64;
+    for (int sb = 0; sb < nx * ny; sb++) {
+        uint64_t m[85], q[85];
+        const uint8_t *o = full->buf + (size_t)(full->origin_y + (sb / nx) * 64) * full->stride + full->origin_x + (sb % nx) * 64;
+        for (int b = 0; b < 64; b++) svt_oracle_pa_mean8x8(o + (size_t)(b >> 3) * 8 * full->stride + (b & 7) * 8, full->stride, &m[21 + b], &q[21 + b]);
+        for (int k = 0; k < 16; k++) {
+            const int b = 21 + (k >> 2) * 16 + (k & 3) * 2;
+            m[5 + k] = (m[b] + m[b + 1] + m[b + 8] + m[b + 9]) >> 2;
+            q[5 + k] = (q[b] + q[b + 1] + q[b + 8] + q[b + 9]) >> 2;
+        }
+        for (int k = 0; k < 4; k++) {
+            const int b = 5 + (k >> 1) * 8 + (k & 1) * 2;
+            m[1 + k] = (m[b] + m[b + 1] + m[b + 4] + m[b + 5]) >> 2;
+            q[1 + k] = (q[b] + q[b + 1] + q[b + 4] + q[b + 5]) >> 2;
+        }
+        m[0] = (m[1] + m[2] + m[3] + m[4]) >> 2;
+        q[0] = (q[1] + q[2] + q[3] + q[4]) >> 2;
+        for (int i = 0; i < 85; i++) {
+            mean_out[(size_t)sb * 85 + i] = (uint8_t)(m[i] >> 8);
+            var_out[(size_t)sb * 85 + i]  = (uint16_t)((q[i] - m[i] * m[i]) >> 16);
+        }
+    }
+    return 0;
+}

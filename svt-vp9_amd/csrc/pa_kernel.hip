@@ -55,6 +55,59 @@ __global__ __launch_bounds__(256) void svt_pa_plane_kernel(const pa_job *__restr
 }
 } // namespace
 
+namespace {
+/* one wave per SB: lane b = 8x8 block b (raster); 16x16 / 32x32 / 64x64 by the first 16 / 4 / 1 lanes through LDS */
+__global__ __launch_bounds__(256) void svt_pa_meanvar_kernel(svt_plane pl, int nx, int n_sb, uint8_t *__restrict__ mean_out,
+                                                             uint16_t *__restrict__ var_out) {
+    __shared__ uint64_t s_m[4][85], s_q[4][85]; /* mean << 8 and mean of squares << 16, per wave */
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, sb = blockIdx.x * 4 + w;
+    if (sb >= n_sb) return;
+    const uint8_t *p = pl.buf + (size_t)(pl.origin_y + (sb / nx) * 64 + (lane >> 3) * 8) * pl.stride + pl.origin_x + (sb % nx) * 64 + (lane & 7) * 8;
+    uint32_t sum = 0, sq = 0;
+    _Pragma("unroll") for (int r = 0; r < 8; r += 2) { /* rows 0, 2, 4, 6 */
+        const uint8_t *row = p + (size_t)r * pl.stride;
+        _Pragma("unroll") for (int x = 0; x < 8; x++) { const uint32_t v = row[x]; sum += v; sq += v * v; }
+    }
+    uint64_t *m = s_m[w], *q = s_q[w];
+    m[21 + lane] = (uint64_t)sum << 3;
+    q[21 + lane] = (uint64_t)sq << 11;
+    /* LDS accesses of one wave are ordered: the levels can follow each other without a workgroup barrier */
+    if (lane < 16) {
+        const int b = 21 + (lane >> 2) * 16 + (lane & 3) * 2;
+        m[5 + lane] = (m[b] + m[b + 1] + m[b + 8] + m[b + 9]) >> 2;
+        q[5 + lane] = (q[b] + q[b + 1] + q[b + 8] + q[b + 9]) >> 2;
+    }
+    if (lane < 4) {
+        const int b = 5 + (lane >> 1) * 8 + (lane & 1) * 2;
+        m[1 + lane] = (m[b] + m[b + 1] + m[b + 4] + m[b + 5]) >> 2;
+        q[1 + lane] = (q[b] + q[b + 1] + q[b + 4] + q[b + 5]) >> 2;
+    }
+    if (lane == 0) {
+        m[0] = (m[1] + m[2] + m[3] + m[4]) >> 2;
+        q[0] = (q[1] + q[2] + q[3] + q[4]) >> 2;
+    }
+    for (int i = lane; i < 85; i += 64) {
+        mean_out[(size_t)sb * 85 + i] = (uint8_t)(m[i] >> 8);
+        var_out[(size_t)sb * 85 + i]  = (uint16_t)((q[i] - m[i] * m[i]) >> 16);
+    }
+}
+} // namespace
+
+extern "C" int32_t svt_hip_pa_mean_variance_device(svt_hip_ctx *ctx, const svt_plane *full, uint8_t *d_mean, uint16_t *d_var) {
+    if (!ctx || !full || !full->buf || !d_mean || !d_var) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "pa: null argument");
+    const int nx = (full->width + 63) / 64, ny = (full->height + 63) / 64, n_sb = nx * ny;
+    if (full->stride < full->width + 2 * full->origin_x) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "pa: plane geometry");
+    if (nx * 64 - full->width > full->origin_x || ny * 64 - full->height > full->origin_y)
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "pa: padding smaller than the partial SB");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    hipLaunchKernelGGL(svt_pa_meanvar_kernel, dim3((n_sb + 3) / 4), dim3(256), 0, ctx->stream, *full, nx, n_sb, d_mean, d_var);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->timed = 1;
+    return SVT_HIP_OK;
+}
+
 extern "C" int32_t svt_hip_pa_prepare_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const uint8_t *const *d_luma,
                                                    const int32_t *luma_stride, const svt_pa_picture *out, int32_t make_quarter) {
     if (!ctx || n_pics < 1 || !d_luma || !luma_stride || !out) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "pa: null argument");

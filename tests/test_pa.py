@@ -83,3 +83,79 @@ def test_gpu_pa_vs_oracle(w, h, quarter):
                 assert np.array_equal(d_p[i][s].cpu().numpy(), want[i][s]), (i, s)
     finally:
         lib.svt_hip_ctx_destroy(ctx)
+
+
+def _numpy_meanvar(padded, pad, w, h):
+    nx, ny = (w + 63) // 64, (h + 63) // 64
+    mean, var = np.zeros((nx * ny, 85), np.uint8), np.zeros((nx * ny, 85), np.uint16)
+    for sb in range(nx * ny):
+        y0, x0 = pad + (sb // nx) * 64, pad + (sb % nx) * 64
+        blk = padded[y0:y0 + 64:2, x0:x0 + 64].astype(np.uint64)          # rows 0,2,4,.. of the SB
+        s8 = blk.reshape(8, 4, 8, 8).sum(axis=(1, 3)) << np.uint64(3)     # [by][bx]
+        q8 = (blk * blk).reshape(8, 4, 8, 8).sum(axis=(1, 3)) << np.uint64(11)
+        def up(a):
+            n = a.shape[0] // 2
+            return a.reshape(n, 2, n, 2).sum(axis=(1, 3)) >> np.uint64(2)
+        m = {8: s8, 16: up(s8)}; q = {8: q8, 16: up(q8)}
+        m[32], q[32] = up(m[16]), up(q[16]); m[64], q[64] = up(m[32]), up(q[32])
+        mm = np.concatenate([m[64].ravel(), m[32].ravel(), m[16].ravel(), m[8].ravel()])
+        qq = np.concatenate([q[64].ravel(), q[32].ravel(), q[16].ravel(), q[8].ravel()])
+        mean[sb] = (mm >> np.uint64(8)).astype(np.uint8)
+        var[sb] = ((qq - mm * mm) >> np.uint64(16)).astype(np.uint16)
+    return mean, var
+
+
+def _oracle_meanvar(pic, w, h):
+    n = T.n_sb(w, h)
+    mean, var = np.zeros((n, 85), np.uint8), np.zeros((n, 85), np.uint16)
+    d = pic.desc()
+    assert T.oracle().svt_oracle_pa_mean_variance(C.byref(d.full), mean.ctypes.data_as(C.c_void_p), var.ctypes.data_as(C.c_void_p)) == 0
+    return mean, var
+
+
+@pytest.mark.parametrize("w,h", [(128, 64), (328, 200)])
+def test_oracle_meanvar_vs_numpy(w, h):
+    pic = T.PaPic(T.gen_clip(w, h, 1, 9)[0])
+    om, ov = _oracle_meanvar(pic, w, h)
+    nm, nv = _numpy_meanvar(pic.full, 68, w, h)
+    assert np.array_equal(om, nm) and np.array_equal(ov, nv)
+    assert ov.max() > 100
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(T.REF_DIR, "libsvtref_pa.so")), reason="oracle/_ref/libsvtref_pa.so not built")
+def test_oracle_mean8x8_vs_reference_sse2_leaf():
+    ref = C.CDLL(os.path.join(T.REF_DIR, "libsvtref_pa.so"), mode=1)
+    ref.eb_vp9_compute_sub_mean8x8_sse2_intrin.restype = C.c_uint64
+    ref.eb_vp9_compute_subd_mean_of_squared_values8x8_sse2_intrin.restype = C.c_uint64
+    rng = np.random.default_rng(2)
+    for _ in range(50):
+        a = rng.integers(0, 256, (8, 24), dtype=np.uint8)
+        if rng.integers(0, 4) == 0:
+            a[:] = 255
+        m, q = C.c_uint64(), C.c_uint64()
+        T.oracle().svt_oracle_pa_mean8x8(C.c_void_p(a.ctypes.data + 5), a.strides[0], C.byref(m), C.byref(q))
+        assert m.value == ref.eb_vp9_compute_sub_mean8x8_sse2_intrin(C.c_void_p(a.ctypes.data + 5), C.c_uint16(a.strides[0]))
+        assert q.value == ref.eb_vp9_compute_subd_mean_of_squared_values8x8_sse2_intrin(C.c_void_p(a.ctypes.data + 5), C.c_uint16(a.strides[0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(328, 200), (3840, 2160)])
+def test_gpu_meanvar_vs_oracle(w, h):
+    import torch
+    lib = B.load()
+    ctx = C.c_void_p()
+    B.check(lib.svt_hip_ctx_create(C.byref(ctx), 0))
+    try:
+        dev = torch.device("cuda", 0)
+        pic = T.PaPic(T.gen_clip(w, h, 1, 12)[0])
+        om, ov = _oracle_meanvar(pic, w, h)
+        t = torch.from_numpy(pic.full).to(dev)
+        n = T.n_sb(w, h)
+        dm, dv = torch.zeros(n * 85, dtype=torch.uint8, device=dev), torch.zeros(n * 85, dtype=torch.int16, device=dev)
+        pl = B.plane_desc(pic.full, 68, 68, ptr=t.data_ptr())
+        B.check(lib.svt_hip_pa_mean_variance_device(ctx, C.byref(pl), C.c_void_p(dm.data_ptr()), C.c_void_p(dv.data_ptr())))
+        B.check(lib.svt_hip_ctx_synchronize(ctx))
+        assert np.array_equal(dm.cpu().numpy().reshape(n, 85), om)
+        assert np.array_equal(dv.cpu().numpy().view(np.uint16).reshape(n, 85), ov)
+    finally:
+        lib.svt_hip_ctx_destroy(ctx)
