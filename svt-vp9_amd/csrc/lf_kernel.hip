@@ -41,63 +41,68 @@ constexpr int CS = 44, CROWS = 40;   /* chroma tile stride / rows (8 halo + 32) 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int sclamp(int t) { return t < -128 ? -128 : t > 127 ? 127 : t; }
 
-/* One sample position across an edge (VPX/loopfilter.c filter4 / filter8 / filter16 with their masks), on registers:
- * p[0] = p0 (nearest the edge) ... p[7] = p7, q[0] = q0 ... q[7] = q7.  kind 4 and 8 only look at p[0..3], q[0..3]. */
+/* One sample position across an edge (VPX/loopfilter.c filter_mask :31, flat_mask4/5 :44-63, hev_mask :65, filter4 :72,
+ * filter8 :147, filter16 :209), on registers: p[0] = p0 (nearest the edge) ... p[7] = p7, q[0] = q0 ... q[7] = q7; kind 4
+ * and 8 only look at p[0..3], q[0..3].
+ * Branch-free per lane: the three candidate results are independent dependency chains (a lone wave issues one dependent
+ * VALU op every ~5 cycles, so instruction-level parallelism is what shortens an edge), the 8- and 16-tap results are
+ * running sums (each output = previous sum - 2 leaving taps + 2 entering taps) and are skipped wave-wide when no lane
+ * of the wave needs them. */
+__device__ __forceinline__ int lf_ad(int a, int b) { return (int)__builtin_amdgcn_sad_u8((unsigned)a, (unsigned)b, 0u); } /* |a - b|, 0..255 */
+__device__ __forceinline__ int lf_max3(int a, int b, int c) { return max(max(a, b), c); }
+
 __device__ __forceinline__ void filter_regs(int (&p)[8], int (&q)[8], int kind, uint32_t th) {
     const int mblim = (int)(th & 0xff), lim = (int)((th >> 8) & 0xff), hev_thr = (int)((th >> 16) & 0xff);
     const int p3 = p[3], p2 = p[2], p1 = p[1], p0 = p[0], q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-    const bool mask = !(iabs(p3 - p2) > lim || iabs(p2 - p1) > lim || iabs(p1 - p0) > lim || iabs(q1 - q0) > lim ||
-                        iabs(q2 - q1) > lim || iabs(q3 - q2) > lim || iabs(p0 - q0) * 2 + iabs(p1 - q1) / 2 > mblim);
-    bool flat = false;
-    if (kind >= 8)
-        flat = !(iabs(p1 - p0) > 1 || iabs(q1 - q0) > 1 || iabs(p2 - p0) > 1 || iabs(q2 - q0) > 1 || iabs(p3 - p0) > 1 || iabs(q3 - q0) > 1);
-    if (kind == 16 && flat && mask) {
-        const int p7 = p[7], p6 = p[6], p5 = p[5], p4 = p[4], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];
-        const bool flat2 = !(iabs(p4 - p0) > 1 || iabs(q4 - q0) > 1 || iabs(p5 - p0) > 1 || iabs(q5 - q0) > 1 || iabs(p6 - p0) > 1 ||
-                             iabs(q6 - q0) > 1 || iabs(p7 - p0) > 1 || iabs(q7 - q0) > 1);
-        if (flat2) {
-#define R4(x) (((x) + 8) >> 4)
-            p[6] = R4(p7 * 7 + p6 * 2 + p5 + p4 + p3 + p2 + p1 + p0 + q0);
-            p[5] = R4(p7 * 6 + p6 + p5 * 2 + p4 + p3 + p2 + p1 + p0 + q0 + q1);
-            p[4] = R4(p7 * 5 + p6 + p5 + p4 * 2 + p3 + p2 + p1 + p0 + q0 + q1 + q2);
-            p[3] = R4(p7 * 4 + p6 + p5 + p4 + p3 * 2 + p2 + p1 + p0 + q0 + q1 + q2 + q3);
-            p[2] = R4(p7 * 3 + p6 + p5 + p4 + p3 + p2 * 2 + p1 + p0 + q0 + q1 + q2 + q3 + q4);
-            p[1] = R4(p7 * 2 + p6 + p5 + p4 + p3 + p2 + p1 * 2 + p0 + q0 + q1 + q2 + q3 + q4 + q5);
-            p[0] = R4(p7 + p6 + p5 + p4 + p3 + p2 + p1 + p0 * 2 + q0 + q1 + q2 + q3 + q4 + q5 + q6);
-            q[0] = R4(p6 + p5 + p4 + p3 + p2 + p1 + p0 + q0 * 2 + q1 + q2 + q3 + q4 + q5 + q6 + q7);
-            q[1] = R4(p5 + p4 + p3 + p2 + p1 + p0 + q0 + q1 * 2 + q2 + q3 + q4 + q5 + q6 + q7 * 2);
-            q[2] = R4(p4 + p3 + p2 + p1 + p0 + q0 + q1 + q2 * 2 + q3 + q4 + q5 + q6 + q7 * 3);
-            q[3] = R4(p3 + p2 + p1 + p0 + q0 + q1 + q2 + q3 * 2 + q4 + q5 + q6 + q7 * 4);
-            q[4] = R4(p2 + p1 + p0 + q0 + q1 + q2 + q3 + q4 * 2 + q5 + q6 + q7 * 5);
-            q[5] = R4(p1 + p0 + q0 + q1 + q2 + q3 + q4 + q5 * 2 + q6 + q7 * 6);
-            q[6] = R4(p0 + q0 + q1 + q2 + q3 + q4 + q5 + q6 * 2 + q7 * 7);
-#undef R4
-            return;
-        }
+    const int d10 = lf_ad(p1, p0), e10 = lf_ad(q1, q0);
+    const bool mask = max(lf_max3(lf_ad(p3, p2), lf_ad(p2, p1), d10), lf_max3(e10, lf_ad(q2, q1), lf_ad(q3, q2))) <= lim &&
+                      lf_ad(p0, q0) * 2 + (lf_ad(p1, q1) >> 1) <= mblim;
+    const bool flat = kind >= 8 && lf_max3(max(d10, e10), max(lf_ad(p2, p0), lf_ad(q2, q0)), max(lf_ad(p3, p0), lf_ad(q3, q0))) <= 1;
+    const bool use_flat = flat && mask;
+    bool       use16 = false;
+    if (kind == 16) {
+        const int f2 = max(lf_max3(lf_ad(p[4], p0), lf_ad(p[5], p0), lf_ad(p[6], p0)), lf_max3(lf_ad(p[7], p0), lf_ad(q[4], q0), lf_ad(q[5], q0)));
+        use16 = use_flat && max(f2, max(lf_ad(q[6], q0), lf_ad(q[7], q0))) <= 1;
     }
-    if (flat && mask) {
-#define R3(x) (((x) + 4) >> 3)
-        p[2] = R3(p3 + p3 + p3 + 2 * p2 + p1 + p0 + q0);
-        p[1] = R3(p3 + p3 + p2 + 2 * p1 + p0 + q0 + q1);
-        p[0] = R3(p3 + p2 + p1 + 2 * p0 + q0 + q1 + q2);
-        q[0] = R3(p2 + p1 + p0 + 2 * q0 + q1 + q2 + q3);
-        q[1] = R3(p1 + p0 + q0 + 2 * q1 + q2 + q3 + q3);
-        q[2] = R3(p0 + q0 + q1 + 2 * q2 + q3 + q3 + q3);
-#undef R3
-        return;
-    }
-    /* filter4: signed 8-bit arithmetic */
+    /* filter4: signed 8-bit arithmetic; with mask = 0 every step yields 0 and the samples come out unchanged */
     const int m = mask ? -1 : 0;
-    const int hev = (iabs(p1 - p0) > hev_thr || iabs(q1 - q0) > hev_thr) ? -1 : 0;
+    const int hev = max(d10, e10) > hev_thr ? -1 : 0;
     const int ps1 = (int8_t)(p1 ^ 0x80), ps0 = (int8_t)(p0 ^ 0x80), qs0 = (int8_t)(q0 ^ 0x80), qs1 = (int8_t)(q1 ^ 0x80);
     int f = sclamp(ps1 - qs1) & hev;
     f = sclamp(f + 3 * (qs0 - ps0)) & m;
-    const int f1 = sclamp(f + 4) >> 3, f2 = sclamp(f + 3) >> 3;
-    q[0] = (uint8_t)(sclamp(qs0 - f1) ^ 0x80);
-    p[0] = (uint8_t)(sclamp(ps0 + f2) ^ 0x80);
+    const int f1 = sclamp(f + 4) >> 3, f2_ = sclamp(f + 3) >> 3;
+    int       o_q0 = (uint8_t)(sclamp(qs0 - f1) ^ 0x80), o_p0 = (uint8_t)(sclamp(ps0 + f2_) ^ 0x80);
     f = ((f1 + 1) >> 1) & ~hev;
-    q[1] = (uint8_t)(sclamp(qs1 - f) ^ 0x80);
-    p[1] = (uint8_t)(sclamp(ps1 + f) ^ 0x80);
+    int o_q1 = (uint8_t)(sclamp(qs1 - f) ^ 0x80), o_p1 = (uint8_t)(sclamp(ps1 + f) ^ 0x80);
+    int o_p2 = p2, o_q2 = q2;
+    if (__builtin_amdgcn_ballot_w64(use_flat && !use16)) { /* filter8 for the lanes that take it */
+        int s = 3 * p3 + 2 * p2 + p1 + p0 + q0 + 4, r;
+        r = s >> 3; o_p2 = (use_flat && !use16) ? r : o_p2;
+        s += p1 + q1 - p3 - p2; r = s >> 3; o_p1 = (use_flat && !use16) ? r : o_p1;
+        s += p0 + q2 - p3 - p1; r = s >> 3; o_p0 = (use_flat && !use16) ? r : o_p0;
+        s += q0 + q3 - p3 - p0; r = s >> 3; o_q0 = (use_flat && !use16) ? r : o_q0;
+        s += q1 + q3 - p2 - q0; r = s >> 3; o_q1 = (use_flat && !use16) ? r : o_q1;
+        s += q2 + q3 - p1 - q1; r = s >> 3; o_q2 = (use_flat && !use16) ? r : o_q2;
+    }
+    if (__builtin_amdgcn_ballot_w64(use16)) { /* filter16 for the lanes that take it */
+        const int p7 = p[7], p6 = p[6], p5 = p[5], p4 = p[4], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];
+        int       s = 7 * p7 + 2 * p6 + p5 + p4 + p3 + p2 + p1 + p0 + q0 + 8, r;
+        r = s >> 4; p[6] = use16 ? r : p6;
+        s += p5 + q1 - p7 - p6; r = s >> 4; p[5] = use16 ? r : p5;
+        s += p4 + q2 - p7 - p5; r = s >> 4; p[4] = use16 ? r : p4;
+        s += p3 + q3 - p7 - p4; r = s >> 4; p[3] = use16 ? r : p3;
+        s += p2 + q4 - p7 - p3; r = s >> 4; o_p2 = use16 ? r : o_p2;
+        s += p1 + q5 - p7 - p2; r = s >> 4; o_p1 = use16 ? r : o_p1;
+        s += p0 + q6 - p7 - p1; r = s >> 4; o_p0 = use16 ? r : o_p0;
+        s += q0 + q7 - p7 - p0; r = s >> 4; o_q0 = use16 ? r : o_q0;
+        s += q1 + q7 - p6 - q0; r = s >> 4; o_q1 = use16 ? r : o_q1;
+        s += q2 + q7 - p5 - q1; r = s >> 4; o_q2 = use16 ? r : o_q2;
+        s += q3 + q7 - p4 - q2; r = s >> 4; q[3] = use16 ? r : q3;
+        s += q4 + q7 - p3 - q3; r = s >> 4; q[4] = use16 ? r : q4;
+        s += q5 + q7 - p2 - q4; r = s >> 4; q[5] = use16 ? r : q5;
+        s += q6 + q7 - p1 - q5; r = s >> 4; q[6] = use16 ? r : q6;
+    }
+    p[2] = o_p2; p[1] = o_p1; p[0] = o_p0; q[0] = o_q0; q[1] = o_q1; q[2] = o_q2;
 }
 
 /* Edge descriptor of one 8x8 block along the filtering direction: which filters run on its leading edge and on
