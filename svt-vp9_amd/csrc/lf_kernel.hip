@@ -253,7 +253,8 @@ __device__ __forceinline__ void lf_line(uint8_t *s, int st, int nblk, const uint
  * loads per lane are in flight before the first store.  Plane rows must be 8-byte (wide) or 4-byte aligned. */
 template <int UNITS, typename UT>
 __device__ __forceinline__ void tile_io_t(bool load, uint8_t *g, int gstride, uint8_t *l, int lstride, int x0, int y0, int tx0, int ty0,
-                                          int nx, int ny, int seam_lo_end, int seam_hi_begin, int lane, int nlanes) {
+                                          int nx, int ny, int seam_lo_end, int seam_hi_begin, int lane, int nlanes,
+                                          const volatile int *wait_flag, int wait_val) {
     constexpr int UB = (int)sizeof(UT);      /* unit = 8 bytes, or 4 when the plane rows are only 4-byte aligned */
     const int nu = nx / UB, total = nu * ny;
     for (int t0 = lane; t0 < total; t0 += UNITS * nlanes) {
@@ -278,6 +279,8 @@ __device__ __forceinline__ void tile_io_t(bool load, uint8_t *g, int gstride, ui
             }
         }
         if (load) {
+            /* the loads are in flight; the LDS buffer they land in may still be read by the write-back wave */
+            if (wait_flag) while (*wait_flag < wait_val) __builtin_amdgcn_s_sleep(1);
             _Pragma("unroll") for (int u = 0; u < UNITS; u++)
                 if (lo[u] >= 0) {
                     uint32_t *lp = (uint32_t *)(l + lo[u]);
@@ -289,9 +292,10 @@ __device__ __forceinline__ void tile_io_t(bool load, uint8_t *g, int gstride, ui
 }
 template <int UNITS>
 __device__ __forceinline__ void tile_io(bool wide, bool load, uint8_t *g, int gstride, uint8_t *l, int lstride, int x0, int y0, int tx0,
-                                        int ty0, int nx, int ny, int seam_lo_end, int seam_hi_begin, int lane, int nlanes) {
-    if (wide) tile_io_t<UNITS, unsigned long long>(load, g, gstride, l, lstride, x0, y0, tx0, ty0, nx, ny, seam_lo_end, seam_hi_begin, lane, nlanes);
-    else tile_io_t<2 * UNITS, unsigned int>(load, g, gstride, l, lstride, x0, y0, tx0, ty0, nx, ny, seam_lo_end, seam_hi_begin, lane, nlanes);
+                                        int ty0, int nx, int ny, int seam_lo_end, int seam_hi_begin, int lane, int nlanes,
+                                        const volatile int *wait_flag = nullptr, int wait_val = 0) {
+    if (wide) tile_io_t<UNITS, unsigned long long>(load, g, gstride, l, lstride, x0, y0, tx0, ty0, nx, ny, seam_lo_end, seam_hi_begin, lane, nlanes, wait_flag, wait_val);
+    else tile_io_t<2 * UNITS, unsigned int>(load, g, gstride, l, lstride, x0, y0, tx0, ty0, nx, ny, seam_lo_end, seam_hi_begin, lane, nlanes, wait_flag, wait_val);
 }
 
 struct lf_geom { /* per (SB row, SB column): what exists of the tile */
@@ -341,14 +345,15 @@ __global__ __launch_bounds__(128) void svt_lf_desc_kernel(const lf_pic_dev *__re
     }
 }
 
-/* Workgroup = one SB row, three waves with fixed roles:
+/* Workgroup = one SB row, four waves with fixed roles:
  *   wave 0  filters luma, wave 1 filters Cb (lanes 0-31) and Cr (lanes 32-63): vertical edges, then horizontal edges of the
  *           SB in tile buffer (sc & 1); the 8 rightmost columns (not final yet: the next SB's left edge filters modify
  *           them) are handed to the other buffer as the next SB's left halo -- every sample crosses HBM once per SB row;
- *   wave 2  stages the NEXT SB meanwhile (waits for the SB row above, loads the 64 new columns + top halo, builds the edge
- *           descriptors), and afterwards writes the finished columns of the current tile back and publishes progress.
- * One workgroup barrier per SB.  Tile rows 0-7 (top halo) and the SB's last 8 rows are seam rows (sc1 accesses). */
-__global__ __launch_bounds__(192) void svt_lf_kernel(const lf_pic_dev *__restrict__ pics, int n_pics, svt_lf_thresh thr,
+ *   wave 2  stages the NEXT SB meanwhile: waits for the SB row above, loads the 64 new columns + top halo and the edge
+ *           descriptors (svt_lf_desc_kernel) into the other buffer;
+ *   wave 3  writes the finished columns of the tile filtered in the previous step back and publishes the row's progress.
+ * One workgroup barrier per SB; wave 2 lets its loads fly while wave 3 is still reading the buffer they will land in.  Tile rows 0-7 (top halo) and the SB's last 8 rows are seam rows (sc1 accesses). */
+__global__ __launch_bounds__(256) void svt_lf_kernel(const lf_pic_dev *__restrict__ pics, int n_pics, svt_lf_thresh thr,
                                                      uint32_t *__restrict__ ticket, int rows_per_pic, int prof) {
     __shared__ __align__(16) uint8_t ytile[2][YROWS * YS];
     __shared__ __align__(16) uint8_t ctile[2][2][CROWS * CS];
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(192) void svt_lf_kernel(const lf_pic_dev *__restric
         }
         LF_MARK(0, 128);
         /* tile columns 8.. hold the SB's own samples; rows 8-hy.. ; seam rows: ty < 8 (top halo) and the SB's last 8 rows */
-        tile_io<11>(wide_y, true, P.planes.y, P.planes.y_stride, ytile[buf], YS, g.x0 - 8, g.y0 - 8, 8, 8 - g.hy, g.vw, g.vh + g.hy, 8, 8 + g.vh - 8, lane, 64);
+        tile_io<11>(wide_y, true, P.planes.y, P.planes.y_stride, ytile[buf], YS, g.x0 - 8, g.y0 - 8, 8, 8 - g.hy, g.vw, g.vh + g.hy, 8, 8 + g.vh - 8, lane, 64, &s_stored, sc - 2);
         if (!P.y_only) {
             tile_io<3>(wide_c, true, P.planes.u, P.planes.uv_stride, ctile[buf][0], CS, g.cx0 - 8, g.cy0 - 8, 8, 8 - g.hy, g.cvw, g.cvh + g.hy, 8, 8 + g.cvh - 8, lane, 64);
             tile_io<3>(wide_c, true, P.planes.v, P.planes.uv_stride, ctile[buf][1], CS, g.cx0 - 8, g.cy0 - 8, 8, 8 - g.hy, g.cvw, g.cvh + g.hy, 8, 8 + g.cvh - 8, lane, 64);
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(192) void svt_lf_kernel(const lf_pic_dev *__restric
                     dst[0] = src[0]; dst[1] = src[1];
                 }
             }
-        } else if (!P.y_only) {
+        } else if (wave == 1 && !P.y_only) {
             const int pl = lane >> 5, l5 = lane & 31;
             if (l5 < g.cvh) lf_line<true>(ctile[buf][pl] + (8 + l5) * CS + 8, 1, 4, &s_desc[buf][128 + (l5 >> 3) * 4], 1, s_thr);
             if (l5 < g.cvw) lf_line<false>(ctile[buf][pl] + 8 * CS + 8 + l5, CS, (nrows + 1) >> 1, &s_desc[buf][144 + (l5 >> 3)], 4, s_thr);
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(192) void svt_lf_kernel(const lf_pic_dev *__restric
         }
         __syncthreads();
         LF_MARK(5, 0);
-        if (wave == 2) {
+        if (wave == 3) {
             /* write back what is final: tile columns 8-hx .. 8+56 (.. 8+vw for the last SB), rows 8-hy .. 8+vh */
             const int nxs = (last ? g.vw : 56) + g.hx, nxc = (last ? g.cvw : 24) + g.hx;
             tile_io<11>(wide_y, false, P.planes.y, P.planes.y_stride, ytile[buf], YS, g.x0 - 8, g.y0 - 8, 8 - g.hx, 8 - g.hy, nxs, g.vh + g.hy, 8, 8 + g.vh - 8, lane, 64);
@@ -452,11 +457,11 @@ __global__ __launch_bounds__(192) void svt_lf_kernel(const lf_pic_dev *__restric
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the tile has left LDS: the buffer may be refilled */
             if (lane == 0) s_stored = sc;
-            LF_MARK(6, 128);
+            LF_MARK(6, 192);
             /* publish: every store of this wave has completed (seam rows were written through) -> progress counter */
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(&P.progress[sb_row], (uint32_t)(sc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            LF_MARK(7, 128);
+            LF_MARK(7, 192);
         }
     }
 #undef LF_MARK
@@ -498,7 +503,7 @@ static int32_t lf_launch(svt_hip_ctx *ctx, int n_pics, const svt_yuv_planes *d_r
     static const bool want_prof = getenv("SVT_HIP_LF_PROFILE") != nullptr;
     if (want_prof) { unsigned long long z[8] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lf_prof), z, sizeof z)); }
     hipLaunchKernelGGL(svt_lf_desc_kernel, dim3(n_pics * max_rows * max_cols), dim3(128), 0, ctx->stream, (const lf_pic_dev *)d, max_rows, max_cols);
-    hipLaunchKernelGGL(svt_lf_kernel, dim3(n_pics * max_rows), dim3(192), 0, ctx->stream, (const lf_pic_dev *)d, n_pics, *thr, cnt, max_rows, want_prof ? 1 : 0);
+    hipLaunchKernelGGL(svt_lf_kernel, dim3(n_pics * max_rows), dim3(256), 0, ctx->stream, (const lf_pic_dev *)d, n_pics, *thr, cnt, max_rows, want_prof ? 1 : 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     if (want_prof) {
