@@ -320,28 +320,34 @@ __global__ __launch_bounds__(128) void svt_lf_desc_kernel(const lf_pic_dev *__re
     if (sb_row >= sb_rows || sc >= sb_cols) return;
     const int tid = threadIdx.x, mi_row = sb_row * 8;
     uint32_t *d = const_cast<uint32_t *>(P.desc) + ((size_t)sb_row * sb_cols + sc) * LF_DESC_WORDS;
-    svt_lf_mask m = P.lfm[sb_row * P.lfm_stride + sc];
+    /* the masks are adjusted on a register copy; the per-8x8 levels are read straight from HBM (indexing them in the
+     * copy would push the whole struct to scratch memory) */
+    const svt_lf_mask *gm = &P.lfm[sb_row * P.lfm_stride + sc];
+    const uint8_t     *lfl = gm->lfl_y;
+    svt_lf_mask        m;
+    _Pragma("unroll") for (int i = 0; i < 4; i++) { m.left_y[i] = gm->left_y[i]; m.above_y[i] = gm->above_y[i]; m.left_uv[i] = gm->left_uv[i]; m.above_uv[i] = gm->above_uv[i]; }
+    m.int_4x4_y = gm->int_4x4_y; m.int_4x4_uv = gm->int_4x4_uv;
     adjust_mask(m, mi_row, sc * 8, P.mi_rows, P.mi_cols);
     if (tid < 64) {
         const int rr = tid >> 3, c = tid & 7, pair = rr >> 1, half = rr & 1;
         d[tid] = vert_entry(c, 8, (unsigned)(m.left_y[2] >> (16 * pair)) & 0xffff, (unsigned)(m.left_y[1] >> (16 * pair)) & 0xffff,
                             (unsigned)(m.left_y[0] >> (16 * pair)) & 0xffff, (unsigned)(m.int_4x4_y >> (16 * pair)) & 0xffff, half,
-                            m.lfl_y[(2 * pair) * 8 + c], m.lfl_y[(2 * pair + 1) * 8 + c]);
+                            lfl[(2 * pair) * 8 + c], lfl[(2 * pair + 1) * 8 + c]);
         const int r = rr;
         unsigned  a16 = 0, a8 = 0, a4 = 0;
         if (mi_row + r != 0) { a16 = (unsigned)(m.above_y[2] >> (8 * r)) & 0xff; a8 = (unsigned)(m.above_y[1] >> (8 * r)) & 0xff; a4 = (unsigned)(m.above_y[0] >> (8 * r)) & 0xff; }
-        d[64 + tid] = horiz_entry(c, a16, a8, a4, (unsigned)(m.int_4x4_y >> (8 * r)) & 0xff, &m.lfl_y[r * 8], 1);
+        d[64 + tid] = horiz_entry(c, a16, a8, a4, (unsigned)(m.int_4x4_y >> (8 * r)) & 0xff, &lfl[r * 8], 1);
     } else if (tid < 80) {
         const int t = tid - 64, rr = t >> 2, c = t & 3, pair = rr >> 1, half = rr & 1;
         d[128 + t] = vert_entry(c, 4, (unsigned)(m.left_uv[2] >> (8 * pair)) & 0xff, (unsigned)(m.left_uv[1] >> (8 * pair)) & 0xff,
                                 (unsigned)(m.left_uv[0] >> (8 * pair)) & 0xff, (unsigned)(m.int_4x4_uv >> (8 * pair)) & 0xff, half,
-                                m.lfl_y[(4 * pair) * 8 + 2 * c], m.lfl_y[(4 * pair + 2) * 8 + 2 * c]);
+                                lfl[(4 * pair) * 8 + 2 * c], lfl[(4 * pair + 2) * 8 + 2 * c]);
     } else if (tid < 96) {
         const int t = tid - 80, ru = t >> 2, c = t & 3, r = 2 * ru;
         unsigned  a16 = 0, a8 = 0, a4 = 0;
         if (mi_row + r != 0) { a16 = (unsigned)(m.above_uv[2] >> (4 * ru)) & 0xf; a8 = (unsigned)(m.above_uv[1] >> (4 * ru)) & 0xf; a4 = (unsigned)(m.above_uv[0] >> (4 * ru)) & 0xf; }
         const unsigned mi4 = (mi_row + r == P.mi_rows - 1) ? 0u : ((unsigned)(m.int_4x4_uv >> (4 * ru)) & 0xf);
-        d[144 + t] = horiz_entry(c, a16, a8, a4, mi4, &m.lfl_y[r * 8], 2);
+        d[144 + t] = horiz_entry(c, a16, a8, a4, mi4, &lfl[r * 8], 2);
     }
 }
 
