@@ -243,6 +243,9 @@ typedef struct me_lds_layout {
     int32_t plane_bytes;
     int32_t scratch_bytes; /* bytes available at off_planes */
     int32_t total_bytes;
+    /* HME level-0 search areas already scaled by the temporal layer's multiplier (Codec/EbDefinitions.h:989-1005): the
+     * divisions by 100 are done once per launch on the host instead of by the planning thread of every SB */
+    int16_t hme_w0[2], hme_h0[2], hme_tw0, hme_th0;
 } me_lds_layout;
 
 #define ME_RGN_GX 4 /* left guard columns of the region buffer (search position 0 is dword aligned) */
@@ -258,9 +261,8 @@ typedef struct me_hme_win {
     int32_t sw, sh;   /* search positions */
     int32_t gx, gy;   /* reference-picture coordinates of window column 0 / row 0 */
     int32_t slot;     /* region (key) this window belongs to */
-    int32_t idx0;     /* raster index of the window's first search position inside its region (row band offset) */
+    int32_t y0;       /* first search row of this window inside its region (row band offset) */
     int32_t tl, ts;   /* first load task / first search task of this window inside its batch */
-    uint32_t inv_nd, inv_ng; /* ceil(2^32 / nd), ceil(2^32 / tasks-per-search-row): t / d = mulhi(t, inv) for t * d < 2^32 */
 } me_hme_win;
 
 /* per-SB state in LDS */
@@ -1094,12 +1096,16 @@ __device__ int g_me_stop_after = -1;
 #define ME_UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
 #endif
 
-/* t / d through the precomputed inv = floor((2^32 - 1) / d) + 1 (exact while t * d < 2^32; d = 1 gives inv = 0 -> t) */
+/* t / d through inv = floor((2^32 - 1) / d) + 1 (exact while t * d < 2^32; d = 1 gives inv = 0 -> t).  Every thread derives
+ * inv itself when it enters a window: the (slow) division runs in parallel instead of on the planning thread */
+SVT_DEV uint32_t me_magic_of(int d) { return (uint32_t)(0xffffffffu / (uint32_t)d) + 1u; }
 SVT_DEV int me_div_magic(int t, uint32_t inv) { return inv ? (int)(((uint64_t)(uint32_t)t * inv) >> 32) : t; }
 
 /* copy the windows [e0, e1) of a batch: flattened (window,row,dword) tasks, four global loads in flight per thread
  * before the LDS stores; ntask = total load tasks of the batch */
 SVT_DEV void ph_hme_load_multi(const me_ctx_t *c, int tid, const svt_plane *ref, const me_hme_win *wn, int e0, int e1, int ntask) {
+    int      cur = -1;
+    uint32_t inv = 0;
     for (int t0 = tid; t0 < ntask; t0 += 4 * SVT_NT) {
         uint32_t v[4];
         int      dst[4];
@@ -1110,7 +1116,8 @@ SVT_DEV void ph_hme_load_multi(const me_ctx_t *c, int tid, const svt_plane *ref,
                 int e = e0;
                 while (e + 1 < e1 && T >= wn[e + 1].tl) e++;
                 const int t = T - wn[e].tl, nd = wn[e].nd;
-                const int row = me_div_magic(t, wn[e].inv_nd), i = t - row * nd;
+                if (e != cur) { cur = e; inv = me_magic_of(nd); }
+                const int row = me_div_magic(t, inv), i = t - row * nd;
                 v[u]   = me_ld32u(me_pix(ref, wn[e].gx + 4 * i, wn[e].gy + row));
                 dst[u] = wn[e].off + row * wn[e].wstride + 4 * i;
             }
@@ -1177,11 +1184,13 @@ SVT_DEV void me_qsad_block(const uint8_t *blk, int bstride, int nd, int bh, cons
 }
 
 /* exhaustive search of the windows [e0, e1) of a batch in one phase; keys[slot] = min over
- * (sad << 32 | raster index inside the region) */
+ * (sad << 32 | y << 16 | x inside the region): ordered like the raster index, no division to take it apart */
 SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk, int bstride, int bw, int bh, const me_hme_win *wn,
                                  int e0, int e1, int ntask, uint64_t *keys, int slot_mask) {
     const int qs = (bw & 3) == 0; /* QSAD path: task = 4 positions */
     uint64_t  best[4] = {~0ull, ~0ull, ~0ull, ~0ull}; /* per key slot */
+    int       cur = -1;
+    uint32_t  inv = 0;
 #ifdef ME_FINE_PROF
     unsigned long long ft_ = __builtin_amdgcn_s_memtime();
 #define FP(i) do { if (c->prof && tid == 0) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&c->prof[i], n_ - ft_); ft_ = n_; } } while (0)
@@ -1191,32 +1200,33 @@ SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk,
     for (int T = tid; T < ntask; T += SVT_NT) {
         int e = e0;
         while (e + 1 < e1 && T >= wn[e + 1].ts) e++;
-        const int      t = T - wn[e].ts, ws = wn[e].wstride, sw = wn[e].sw, slot = wn[e].slot, idx0 = wn[e].idx0;
+        const int      t = T - wn[e].ts, ws = wn[e].wstride, sw = wn[e].sw, slot = wn[e].slot, y0 = wn[e].y0;
+        if (e != cur) { cur = e; inv = me_magic_of(qs ? (sw + 3) >> 2 : sw); }
         const uint8_t *win = c->planes + wn[e].off;
         uint64_t       kb = ~0ull;
         FP(16);
         if (qs) {
             const int ng = (sw + 3) >> 2;
-            const int y = me_div_magic(t, wn[e].inv_ng), g = t - y * ng;
+            const int y = me_div_magic(t, inv), g = t - y * ng;
             uint32_t  a[4];
             me_qsad_block(blk, bstride, bw >> 2, bh, win + y * ws + 4 * g, ws, 2, a);
             FP(17);
             _Pragma("unroll") for (int o = 0; o < 4; o++) {
                 int x = 4 * g + o;
                 if (x < sw) {
-                    uint64_t k = ((uint64_t)a[o] << 32) | (uint32_t)(idx0 + y * sw + x);
+                    uint64_t k = ((uint64_t)a[o] << 32) | ((uint32_t)(y0 + y) << 16) | (uint32_t)x;
                     if (k < kb) kb = k;
                 }
             }
         } else {
-            const int y = me_div_magic(t, wn[e].inv_ng), x = t - y * sw;
+            const int y = me_div_magic(t, inv), x = t - y * sw;
             uint32_t  sd = 0;
             for (int j = 0; j < bh; j++)
                 for (int i = 0; i < bw; i++) {
                     int p0 = blk[j * bstride + i], p1 = win[(y + 2 * j) * ws + x + i];
                     sd += (uint32_t)(p0 > p1 ? p0 - p1 : p1 - p0);
                 }
-            kb = ((uint64_t)sd << 32) | (uint32_t)(idx0 + t);
+            kb = ((uint64_t)sd << 32) | ((uint32_t)(y0 + y) << 16) | (uint32_t)x;
         }
         _Pragma("unroll") for (int q = 0; q < 4; q++) if (q == slot && kb < best[q]) best[q] = kb;
         FP(18);
@@ -1234,15 +1244,6 @@ typedef struct me_hme_geom {
 } me_hme_geom;
 
 SVT_DEV int16_t me_hme_round_w(int16_t w) { return (int16_t)((w < 8) ? 8 : (w & 7) ? w + (w - ((w >> 3) << 3)) : w); }
-
-/* Codec/EbDefinitions.h:989-1005 */
-__attribute__((unused)) static
-#ifndef SVT_HOST_EMU
-    __device__
-#endif
-    const int32_t me_hme_l0_mult[6][6] = {{100, 0, 0, 0, 0, 0},       {100, 100, 0, 0, 0, 0},
-                                          {100, 100, 100, 0, 0, 0},   {200, 140, 100, 70, 0, 0},
-                                          {350, 200, 100, 100, 100, 0}, {525, 350, 200, 100, 100, 100}};
 
 /* geometry of an HME level for one reference list (hme_level0/1/2 of Codec/EbMotionEstimation.c) */
 SVT_DEV void me_hme_geom_of(const me_ctx_t *c, int list, int lvl, me_hme_geom *g) {
@@ -1271,7 +1272,6 @@ SVT_DEV void me_hme_plan_level(const me_ctx_t *c, int list, int lvl, int16_t xsc
     const int            NW = p->number_hme_search_region_in_width, NH = p->number_hme_search_region_in_height;
     me_hme_geom          g;
     me_hme_geom_of(c, list, lvl, &g);
-    const int mult   = me_hme_l0_mult[p->hierarchical_levels][p->temporal_layer_index];
     const int single = lvl == 0 && p->single_hme_quadrant && !p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag;
     const int span   = 2 * (g.bh - 1);
     int       ne = 0, nb = 0, bytes = 0, tl = 0, ts = 0;
@@ -1293,19 +1293,20 @@ SVT_DEV void me_hme_plan_level(const me_ctx_t *c, int list, int lvl, int16_t xsc
         if (single ? k != 0 : (rw >= NW || rh >= NH)) continue;
         int16_t w, h, ox, oy;
         if (lvl == 0) {
+            /* c->L.hme_* = (area * multiplier) / 100 of hme_level0 / single_hme_quadrant_level0 (:2717-2760, 2872-2920) */
             if (single) {
-                w  = (int16_t)((p->hme_level0_total_search_area_width * mult) / 100);
-                h  = (int16_t)((p->hme_level0_total_search_area_height * mult) / 100);
+                w  = c->L.hme_tw0;
+                h  = c->L.hme_th0;
                 ox = (int16_t)(-(int16_t)(w >> 1) + (int16_t)(xsc >> 2));
                 oy = (int16_t)(-(int16_t)(h >> 1) + (int16_t)(ysc >> 2));
             } else {
-                w = (int16_t)((p->hme_level0_search_area_in_width_array[rw] * mult) / 100);
-                h = (int16_t)((p->hme_level0_search_area_in_height_array[rh] * mult) / 100);
+                w = c->L.hme_w0[rw];
+                h = c->L.hme_h0[rh];
                 int16_t ddx = (int16_t)(xsc >> 2), ddy = (int16_t)(ysc >> 2);
-                if (rw > 0) ddx = (int16_t)(ddx + (int16_t)((p->hme_level0_search_area_in_width_array[0] * mult) / 100));
-                if (rh > 0) ddy = (int16_t)(ddy + (int16_t)((p->hme_level0_search_area_in_height_array[0] * mult) / 100));
-                ox = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_width * mult) / 100) >> 1) + ddx);
-                oy = (int16_t)(-(int16_t)(((p->hme_level0_total_search_area_height * mult) / 100) >> 1) + ddy);
+                if (rw > 0) ddx = (int16_t)(ddx + c->L.hme_w0[0]);
+                if (rh > 0) ddy = (int16_t)(ddy + c->L.hme_h0[0]);
+                ox = (int16_t)(-(int16_t)(c->L.hme_tw0 >> 1) + ddx);
+                oy = (int16_t)(-(int16_t)(c->L.hme_th0 >> 1) + ddy);
             }
         } else if (lvl == 1) {
             w  = me_hme_round_w((int16_t)p->hme_level1_search_area_in_width_array[rw]);
@@ -1329,17 +1330,17 @@ SVT_DEV void me_hme_plan_level(const me_ctx_t *c, int list, int lvl, int16_t xsc
         if (((ws >> 2) & 1) == 0) ws += 4;
         const int ng = (g.bw & 3) == 0 ? (w + 3) >> 2 : w;
         for (int y = 0; y < h && ne < ME_HME_MAX_WIN;) {
-            int nr = (c->L.scratch_bytes - bytes) / ws - span;
+            /* search rows that still fit the scratch: usually all of them -- the division only runs otherwise */
+            int nr = h - y;
+            if (ws * (nr + span) > c->L.scratch_bytes - bytes) nr = (c->L.scratch_bytes - bytes) / ws - span;
             if (nr < 1 && bytes > 0) { /* close the batch and retry with an empty scratch */
                 st->hme_bstart[++nb] = ne; bytes = 0; tl = 0; ts = 0;
                 continue;
             }
             if (nr < 1) break; /* cannot happen with the scratch sizes of me_lds_layout_compute */
-            if (nr > h - y) nr = h - y;
             me_hme_win *wn = &st->hme_win[ne++];
             wn->off = bytes; wn->wstride = ws; wn->nd = (wbytes + 3) >> 2; wn->rows = nr + span; wn->sw = w; wn->sh = nr;
-            wn->gx = g.ox + ox; wn->gy = g.oy + oy + y; wn->slot = k; wn->idx0 = y * w; wn->tl = tl; wn->ts = ts;
-            wn->inv_nd = (uint32_t)(0xffffffffu / (uint32_t)wn->nd) + 1u; wn->inv_ng = (uint32_t)(0xffffffffu / (uint32_t)ng) + 1u;
+            wn->gx = g.ox + ox; wn->gy = g.oy + oy + y; wn->slot = k; wn->y0 = y; wn->tl = tl; wn->ts = ts;
             tl += wn->nd * wn->rows; ts += ng * nr;
             bytes += ws * (nr + span); y += nr;
         }
@@ -1363,7 +1364,7 @@ SVT_DEV void me_hme_finish_level(const me_ctx_t *c, int lvl) {
             const uint64_t key = st->hme_keys[k];
             if (key != ~0ull) {
                 const uint32_t idx = (uint32_t)key, sd = (uint32_t)(key >> 32);
-                if (sd < sad) { sad = sd; x = (int16_t)(idx % (uint32_t)st->hme_cw[k]); y = (int16_t)(idx / (uint32_t)st->hme_cw[k]); }
+                if (sd < sad) { sad = sd; x = (int16_t)(idx & 0xffffu); y = (int16_t)(idx >> 16); }
             }
         }
         st->hme_sad[lvl][k] = sad * 2;

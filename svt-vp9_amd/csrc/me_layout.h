@@ -29,6 +29,19 @@ static inline int me_lds_layout_compute(const svt_me_params *p, me_lds_layout *L
     if (p->num_ref_lists == 2) /* [level][k][thread] dwords, k < K = 2 (SUB_SAD: even rows only) or 4 */
         off += (p->fractional_search_method == SVT_SUB_SAD_SEARCH ? 2048 : 4096) * (p->cu16x16_mode != 0 ? 2 : p->cu8x8_mode != 0 ? 3 : 4);
     L->total_bytes = off;
+    {   /* HME level-0 search area multipliers, Codec/EbDefinitions.h:989-1005, indexed [hierarchical_levels][temporal_layer] */
+        static const int32_t mult_tab[6][6] = {{100, 0, 0, 0, 0, 0},       {100, 100, 0, 0, 0, 0},
+                                               {100, 100, 100, 0, 0, 0},   {200, 140, 100, 70, 0, 0},
+                                               {350, 200, 100, 100, 100, 0}, {525, 350, 200, 100, 100, 100}};
+        const int hl = p->hierarchical_levels < 6 ? p->hierarchical_levels : 5, tl = p->temporal_layer_index < 6 ? p->temporal_layer_index : 5;
+        const int mult = mult_tab[hl][tl];
+        for (int i = 0; i < 2; i++) {
+            L->hme_w0[i] = (int16_t)((p->hme_level0_search_area_in_width_array[i] * mult) / 100);
+            L->hme_h0[i] = (int16_t)((p->hme_level0_search_area_in_height_array[i] * mult) / 100);
+        }
+        L->hme_tw0 = (int16_t)((p->hme_level0_total_search_area_width * mult) / 100);
+        L->hme_th0 = (int16_t)((p->hme_level0_total_search_area_height * mult) / 100);
+    }
     return off <= 160 * 1024 ? 0 : -1;
 }
 #endif
