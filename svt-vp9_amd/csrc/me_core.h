@@ -240,6 +240,7 @@ typedef struct me_lds_layout {
     int32_t off_ssd;     /* SSD_SEARCH only: candidate SSDs [85][9] */
     int32_t off_pred0;   /* list 0 prediction of the bi-pred lanes: levels * K * 256 dwords */
     int32_t region_stride, region_rows;
+    int32_t plane_stride; /* row stride of the half-pel planes: they are narrower than the region (no search tail) */
     int32_t plane_bytes;
     int32_t scratch_bytes; /* bytes available at off_planes */
     int32_t total_bytes;
@@ -270,6 +271,10 @@ typedef struct me_state_t {
     union {                    /* the full-pel keys are dead once the best MVs are extracted, before the first cand use */
         uint64_t key[85];      /* full-pel arg-min keys of the current list */
         uint32_t cand[85 * 8]; /* sub-pel candidate distortions [pu][8]; bi-pred distortion [pu] */
+        struct {               /* HME work list: dead once the level's results are in hme_x/y/sad, before the keys are set */
+            int32_t    hme_nbatch, hme_bstart[ME_HME_MAX_WIN + 1]; /* batches of windows that fit the scratch together */
+            me_hme_win hme_win[ME_HME_MAX_WIN];
+        };
     };
     uint64_t hme_key;          /* arg-min key of the stand-alone SAD-loop kernel */
     uint64_t hme_keys[4];      /* arg-min keys of the region searches of the current HME level */
@@ -278,8 +283,6 @@ typedef struct me_state_t {
     int16_t  hme_cox[4], hme_coy[4], hme_cw[4], hme_ch[4]; /* clipped search areas of the current level */
     int16_t  hme_xc, hme_yc;   /* HME result; persists from list 0 to list 1 when no level runs */
     int32_t  hme_rh;           /* [quirk] the reference's region-row counter, not reset between the lists */
-    int32_t  hme_nbatch, hme_bstart[ME_HME_MAX_WIN + 1]; /* batches of windows that fit the scratch together */
-    me_hme_win hme_win[ME_HME_MAX_WIN];
     uint32_t best_sad[2][85];  /* search (z-order) index */
     uint32_t best_mv[2][85];
     uint32_t red[8];           /* small sum reductions */
@@ -580,7 +583,7 @@ SVT_DEV uint32_t me_tap4_x4(uint32_t a, uint32_t b, uint32_t d, uint32_t e) {
 /* task = one dword of one plane row; the (row, dword) pair of a thread advances by 256 tasks per step without a
  * division (one division per thread up front), so every lane has work whatever the row length is */
 SVT_DEV void ph_interp_bh(const me_ctx_t *c, int tid, int W, int H) {
-    int       rs = c->L.region_stride, pwd = (W + 2 * ME_PL_G + 3) >> 2, ph = H + 2 * ME_PL_G;
+    int       rs = c->L.region_stride, ps = c->L.plane_stride, pwd = (W + 2 * ME_PL_G + 3) >> 2, ph = H + 2 * ME_PL_G;
     uint8_t  *B = c->planes, *Hh = c->planes + c->L.plane_bytes;
     const int dpy = SVT_NT / pwd, dj = SVT_NT - dpy * pwd;
     int       py = tid / pwd, j = tid - py * pwd;
@@ -591,25 +594,25 @@ SVT_DEV void ph_interp_bh(const me_ctx_t *c, int tid, int W, int H) {
         uint32_t        lo = r0[0], hi = r0[1];
         /* bytes b0..b7 = lo,hi; output k uses b[k+1..k+4] */
         uint32_t t1 = svt_alignbyte(hi, lo, 1), t2 = svt_alignbyte(hi, lo, 2), t3 = svt_alignbyte(hi, lo, 3);
-        *(uint32_t *)(B + ME_MUL(py, rs) + 4 * j) = me_tap4_x4(t1, t2, t3, hi);
+        *(uint32_t *)(B + ME_MUL(py, ps) + 4 * j) = me_tap4_x4(t1, t2, t3, hi);
         /* vertical: samples at region byte offset 4j+2 of rows y-1, y, y+1, y+2 */
         const uint32_t *ra = (const uint32_t *)(rr - rs), *rb = (const uint32_t *)(rr + rs), *rc = (const uint32_t *)(rr + 2 * rs);
         uint32_t va = svt_alignbyte(ra[1], ra[0], 2), vc = svt_alignbyte(rb[1], rb[0], 2), vd = svt_alignbyte(rc[1], rc[0], 2);
-        *(uint32_t *)(Hh + ME_MUL(py, rs) + 4 * j) = me_tap4_x4(va, t2, vc, vd);
+        *(uint32_t *)(Hh + ME_MUL(py, ps) + 4 * j) = me_tap4_x4(va, t2, vc, vd);
         j += dj; py += dpy;
         if (j >= pwd) { j -= pwd; py++; }
     }
 }
 /* J (x+1/2, y+1/2) = vertical filter over B; defined for y in [-1, H-1] (H + 1 rows) */
 SVT_DEV void ph_interp_j(const me_ctx_t *c, int tid, int W, int H) {
-    int       rs = c->L.region_stride, pwd = (W + 2 * ME_PL_G + 3) >> 2;
+    int       ps = c->L.plane_stride, pwd = (W + 2 * ME_PL_G + 3) >> 2;
     uint8_t  *B = c->planes, *J = c->planes + 2 * c->L.plane_bytes;
-    const int dyy = SVT_NT / pwd, dj = SVT_NT - dyy * pwd, st = rs >> 2;
+    const int dyy = SVT_NT / pwd, dj = SVT_NT - dyy * pwd, st = ps >> 2;
     int       yy = tid / pwd, j = tid - yy * pwd;
     while (yy < H + 1) {
         const int       py = yy + ME_PL_G - 1; /* y = yy - 1 */
-        const uint32_t *b  = (const uint32_t *)(B + ME_MUL(py, rs) + 4 * j);
-        *(uint32_t *)(J + ME_MUL(py, rs) + 4 * j) = me_tap4_x4(b[-st], b[0], b[st], b[2 * st]);
+        const uint32_t *b  = (const uint32_t *)(B + ME_MUL(py, ps) + 4 * j);
+        *(uint32_t *)(J + ME_MUL(py, ps) + 4 * j) = me_tap4_x4(b[-st], b[0], b[st], b[2 * st]);
         j += dj; yy += dyy;
         if (j >= pwd) { j -= pwd; yy++; }
     }
@@ -617,25 +620,25 @@ SVT_DEV void ph_interp_j(const me_ctx_t *c, int tid, int W, int H) {
 
 enum { ME_PF = 0, ME_PB = 1, ME_PH = 2, ME_PJ = 3 };
 /* byte pointer (LDS) of plane `id` at natural position (x, y) relative to the region's top-left */
+SVT_DEV int me_plane_stride(const me_ctx_t *c, int id) { return id == ME_PF ? c->L.region_stride : c->L.plane_stride; }
 SVT_DEV const uint8_t *me_plane_at(const me_ctx_t *c, int id, int x, int y) {
-    int rs = c->L.region_stride;
-    if (id == ME_PF) return c->region + ME_MUL(ME_RGN_GY + y, rs) + ME_RGN_GX + x;
-    return c->planes + ME_MUL(id - 1, c->L.plane_bytes) + ME_MUL(y + ME_PL_G, rs) + x + ME_PL_G;
+    if (id == ME_PF) return c->region + ME_MUL(ME_RGN_GY + y, c->L.region_stride) + ME_RGN_GX + x;
+    return c->planes + ME_MUL(id - 1, c->L.plane_bytes) + ME_MUL(y + ME_PL_G, c->L.plane_stride) + x + ME_PL_G;
 }
 
-/* SAD of a w x rows block: src rows at stride ss (LDS, dword aligned) vs candidate at any byte alignment (stride cs,
- * a multiple of 4), optionally averaged with a second candidate plane (b != 0).  Each candidate row is fetched as
+/* SAD of a w x rows block: src rows at stride ss (LDS, dword aligned) vs candidate at any byte alignment (stride csa,
+ * a multiple of 4), optionally averaged with a second candidate plane (b != 0, stride csb).  Each candidate row is fetched as
  * w/4 + 1 aligned dwords and shifted into place with v_alignbyte.  ssd_out != 0: also the sum of squared differences
  * (eb_vp9_spatial_full_distortion_kernel, C_DEFAULT/EbPictureOperators_C.c:337-356; averaging form
  * Codec/EbMotionEstimation.c:1708-1725). */
-SVT_DEV uint32_t me_block_sad_rows(const uint8_t *src, int ss, const uint8_t *a, const uint8_t *b, int cs, int w, int r0, int r1, uint32_t *ssd_out) {
+SVT_DEV uint32_t me_block_sad_rows(const uint8_t *src, int ss, const uint8_t *a, const uint8_t *b, int csa, int csb, int w, int r0, int r1, uint32_t *ssd_out) {
     uint32_t        sad = 0, ssd = 0;
     const uint32_t  sha = (uint32_t)((uintptr_t)a & 3), shb = b ? (uint32_t)((uintptr_t)b & 3) : 0;
     const uint8_t  *a0 = a - sha, *b0 = b ? b - shb : a0;
     const int       n = w >> 2;
     for (int r = r0; r < r1; r++) {
         const uint32_t *s  = (const uint32_t *)(src + ME_MUL(r, ss));
-        const uint32_t *pa = (const uint32_t *)(a0 + ME_MUL(r, cs)), *pb = (const uint32_t *)(b0 + ME_MUL(r, cs));
+        const uint32_t *pa = (const uint32_t *)(a0 + ME_MUL(r, csa)), *pb = (const uint32_t *)(b0 + ME_MUL(r, csb));
         uint32_t        la = pa[0], lb = b ? pb[0] : 0;
         for (int i = 0; i < n; i++) {
             uint32_t ha = pa[i + 1];
@@ -805,7 +808,8 @@ SVT_DEV void ph_halfpel(const me_ctx_t *c, int tid, int list, int sox, int soy, 
         const int      rows = sub_sad ? (w >> 1) : w, step = sub_sad ? 2 : 1;
         const int      per = nl == 16 ? rows >> 4 : nl == 4 ? rows >> 2 : rows, r0 = sl * per;
         uint32_t e = 0;
-        uint32_t d = me_block_sad_rows(sp, ME_SB * step, cp, 0, c->L.region_stride * step, w, r0, r0 + per, ssd ? &e : 0);
+        const int cs = me_plane_stride(c, hpl) * step;
+        uint32_t d = me_block_sad_rows(sp, ME_SB * step, cp, 0, cs, cs, w, r0, r0 + per, ssd ? &e : 0);
         if (cand < 8) svt_group_add_var(&c->st->cand[pu * 8 + cand], d, nl);
         if (ssd) svt_group_add_var(&c->ssdc[pu * 9 + cand], e, nl);
     }
@@ -910,7 +914,8 @@ SVT_DEV void ph_quarterpel(const me_ctx_t *c, int tid, int list, int sox, int so
         const int      rows = sub_sad ? (w >> 1) : w, step = sub_sad ? 2 : 1;
         const int      per = (rows + nl - 1) / nl, r0 = sl * per, r1 = r0 + per < rows ? r0 + per : rows;
         uint32_t sq = 0;
-        uint32_t d = r0 < r1 ? me_block_sad_rows(sp, ME_SB * step, a, b, c->L.region_stride * step, w, r0, r1, ssd ? &sq : 0) : 0;
+        uint32_t d = r0 < r1 ? me_block_sad_rows(sp, ME_SB * step, a, b, me_plane_stride(c, (int)(e & 3)) * step,
+                                                 me_plane_stride(c, (int)((e >> 4) & 3)) * step, w, r0, r1, ssd ? &sq : 0) : 0;
         svt_group_add_u32(&c->st->cand[pu * 8 + pos], d, nl);
         if (ssd) svt_group_add_u32(&c->ssdc[pu * 9 + pos], sq, nl);
     }
@@ -954,7 +959,7 @@ SVT_DEV int me_pu_bipred(const me_ctx_t *c, int pu) {
 }
 /* prediction of `list` for a PU at its best mv: up to two source planes averaged (select_buffer :3310 /
  * quarter_pel_compensation :3358) */
-SVT_DEV void me_pred_ptrs(const me_ctx_t *c, int list, int sox, int soy, int pu, int px, int py, const uint8_t **a, const uint8_t **b) {
+SVT_DEV void me_pred_ptrs(const me_ctx_t *c, int list, int sox, int soy, int pu, int px, int py, const uint8_t **a, const uint8_t **b, int *sa, int *sb) {
     uint32_t mv = c->st->best_mv[list][me_pu_nidx(pu)];
     int16_t  mx = me_mvx(mv), my = me_mvy(mv);
     int      xi = (int16_t)(mx >> 2) - (int16_t)sox + px;
@@ -964,11 +969,12 @@ SVT_DEV void me_pred_ptrs(const me_ctx_t *c, int list, int sox, int soy, int pu,
     const uint32_t e = me_btab_get(frac, &has_b);
     *a = me_plane_at(c, (int)(e & 3), xi + (int)((e >> 2) & 1), yi + (int)((e >> 3) & 1));
     *b = has_b ? me_plane_at(c, (int)((e >> 4) & 3), xi + (int)((e >> 6) & 1), yi + (int)((e >> 7) & 1)) : 0;
+    *sa = me_plane_stride(c, (int)(e & 3)); *sb = me_plane_stride(c, (int)((e >> 4) & 3));
 }
-SVT_DEV uint32_t me_pred_fetch(const uint8_t *a, const uint8_t *b, int off) {
-    uint32_t va = me_ld32u(a + off);
+SVT_DEV uint32_t me_pred_fetch(const uint8_t *a, const uint8_t *b, int offa, int offb) {
+    uint32_t va = me_ld32u(a + offa);
     if (b) {
-        uint32_t vb = me_ld32u(b + off);
+        uint32_t vb = me_ld32u(b + offb);
         va = (va | vb) - (((va ^ vb) >> 1) & 0x7f7f7f7fu); /* (a + b + 1) >> 1 per byte */
     }
     return va;
@@ -981,17 +987,17 @@ SVT_DEV int me_bipred_levels(const me_ctx_t *c) { return c->p->cu16x16_mode != 0
  * pred0[(L*K + k)*256 + tid]. */
 SVT_DEV void ph_store_pred0(const me_ctx_t *c, int tid, int sox, int soy, uint32_t *pr) {
     const int sub = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH, K = sub ? 2 : 4, levels = me_bipred_levels(c);
-    const int rs  = c->L.region_stride;
     for (int L = 0; L < levels; L++) {
         const int sh = 8 - 2 * L, l = tid & ((1 << sh) - 1), pu = (int)((0x15050100u >> (8 * L)) & 0xff) + (tid >> sh);
         int       px, py, w;
         me_pu_geom(pu, &px, &py, &w);
         const uint8_t *a, *b;
-        me_pred_ptrs(c, 0, sox, soy, pu, px, py, &a, &b);
+        int sa, sb;
+        me_pred_ptrs(c, 0, sox, soy, pu, px, py, &a, &b, &sa, &sb);
         _Pragma("unroll") for (int k = 0; k < 4; k++) {
             if (k < K) {
                 int d = l + (k << sh), r = (d >> (4 - L)) << sub, i = d & ((16 >> L) - 1);
-                pr[(L * K + k) * SVT_NT] = me_pred_fetch(a, b, r * rs + 4 * i);
+                pr[(L * K + k) * SVT_NT] = me_pred_fetch(a, b, ME_MUL(r, sa) + 4 * i, ME_MUL(r, sb) + 4 * i);
             }
         }
         SVT_SCHED_FENCE();
@@ -1000,19 +1006,19 @@ SVT_DEV void ph_store_pred0(const me_ctx_t *c, int tid, int sox, int soy, uint32
 /* bi-pred distortion: avg-SAD of (list0 pred, list1 pred) vs source (bi_pred_averging :3466-3560) */
 SVT_DEV void ph_bipred(const me_ctx_t *c, int tid, int sox, int soy, const uint32_t *pr) {
     const int sub = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH, K = sub ? 2 : 4, levels = me_bipred_levels(c);
-    const int rs  = c->L.region_stride;
     for (int L = 0; L < levels; L++) {
         const int sh = 8 - 2 * L, l = tid & ((1 << sh) - 1), pu = (int)((0x15050100u >> (8 * L)) & 0xff) + (tid >> sh);
         int       px, py, w;
         me_pu_geom(pu, &px, &py, &w);
         const uint8_t *a, *b;
-        me_pred_ptrs(c, 1, sox, soy, pu, px, py, &a, &b);
+        int sa, sb;
+        me_pred_ptrs(c, 1, sox, soy, pu, px, py, &a, &b, &sa, &sb);
         uint32_t dsum = 0;
         _Pragma("unroll") for (int k = 0; k < 4; k++) {
             if (k < K) {
                 int      d = l + (k << sh), r = (d >> (4 - L)) << sub, i = d & ((16 >> L) - 1);
                 uint32_t s  = *(const uint32_t *)(c->src + (py + r) * ME_SB + px + 4 * i);
-                uint32_t va = pr[(L * K + k) * SVT_NT], vb = me_pred_fetch(a, b, r * rs + 4 * i);
+                uint32_t va = pr[(L * K + k) * SVT_NT], vb = me_pred_fetch(a, b, ME_MUL(r, sa) + 4 * i, ME_MUL(r, sb) + 4 * i);
                 uint32_t av = (va | vb) - (((va ^ vb) >> 1) & 0x7f7f7f7fu);
                 dsum = svt_sad4(av, s, dsum);
             }

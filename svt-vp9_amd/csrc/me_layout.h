@@ -17,7 +17,11 @@ static inline int me_lds_layout_compute(const svt_me_params *p, me_lds_layout *L
     if (((rs >> 2) & 1) == 0) rs += 4; /* odd number of dwords per row: rows spread over LDS banks */
     L->region_stride = rs;
     L->region_rows   = H + 2 * ME_RGN_GY + 1;
-    L->plane_bytes   = me_round_up((H + 2 * ME_PL_G) * rs, 16);
+    int pd = (W + 2 * ME_PL_G + 3) >> 2; /* plane dwords per row (ph_interp_bh); kept odd like the region's */
+    pd |= 1;
+    L->plane_stride  = 4 * pd;
+    /* + 16: the aligned-dword fetches of me_block_sad_rows may touch the dword after a row's last sample */
+    L->plane_bytes   = me_round_up((H + 2 * ME_PL_G) * L->plane_stride + 16, 16);
     int off          = 0;
     L->off_state     = off; off += me_round_up((int)sizeof(me_state_t), 16);
     L->off_src       = off; off += ME_SB * ME_SB;
