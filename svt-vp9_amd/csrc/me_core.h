@@ -476,9 +476,9 @@ SVT_DEV void ph_sad_search(const me_ctx_t *c, int tid, const uint8_t *blk, int b
 
 /* full-pel search tables.  All 85 PU SADs of a search position live in one row of ME_PU_STRIDE dwords indexed by
  * the PU's search-order index (0 = 64x64, 1..4 = 32x32, 5..20 = 16x16, 21..84 = 8x8; children of a block are the 4
- * consecutive entries 4*z .. 4*z+3 of the next level, i.e. nested z-order).  The odd stride keeps the per-position
- * rows on different LDS banks. */
-#define ME_PU_STRIDE 85
+ * consecutive entries 4*z .. 4*z+3 of the next level, i.e. nested z-order).  Entries 0..20 are dwords; the 64 8x8 SADs
+ * (sub-sampled, < 2^16) follow as halfwords.  The odd stride keeps the per-position rows on different LDS banks. */
+#define ME_PU_STRIDE 53
 
 /* full-pel: sub-sampled 8x8 SADs of every (position, 8x8 block) of a chunk of search rows.
  * Task = (8x8 block b in raster order, 4-position group g, search row y).  Output U[pos][21 + z(b)]
@@ -506,9 +506,9 @@ SVT_DEV void ph_fullpel_sad8(const me_ctx_t *c, int tid, uint32_t *U, int sw, in
             acc = svt_qsad(((uint64_t)d1 << 32) | d0, s[0], acc);
             acc = svt_qsad(((uint64_t)d2 << 32) | d1, s[1], acc);
         }
-        uint32_t *u = U + ME_MUL(ME_MUL(yl, sw) + 4 * g, ME_PU_STRIDE) + 21 + me_z8(b);
+        uint16_t *u = (uint16_t *)(U + ME_MUL(ME_MUL(yl, sw) + 4 * g, ME_PU_STRIDE) + 21) + me_z8(b);
         _Pragma("unroll") for (int o = 0; o < 4; o++)
-            if (4 * g + o < sw) u[o * ME_PU_STRIDE] = (uint32_t)(acc >> (16 * o)) & 0xffffu;
+            if (4 * g + o < sw) u[o * 2 * ME_PU_STRIDE] = (uint16_t)(acc >> (16 * o));
     }
 }
 
@@ -519,8 +519,9 @@ SVT_DEV void ph_fullpel_sum16(const me_ctx_t *c, int tid, uint32_t *U, int sw, i
     int npos = sw * ny;
     for (int t = tid; t < npos * 16; t += SVT_NT) {
         int             pos = t >> 4, z = t & 15;
-        const uint32_t *q   = U + pos * ME_PU_STRIDE + 21 + 4 * z;
-        uint32_t        u   = q[0] + q[1] + q[2] + q[3];
+        const uint32_t *q   = U + pos * ME_PU_STRIDE + 21 + 2 * z;
+        const uint32_t  q0 = q[0], q1 = q[1];
+        uint32_t        u   = (q0 & 0xffffu) + (q0 >> 16) + (q1 & 0xffffu) + (q1 >> 16);
         if ((pos % sw) < w8) u = (uint16_t)u;
         U[pos * ME_PU_STRIDE + 5 + z] = u;
     }
@@ -548,9 +549,11 @@ SVT_DEV void ph_fullpel_argmin(const me_ctx_t *c, int tid, const uint32_t *U, in
     const int slice = tid / 85, pu = tid - 85 * slice;
     if (slice < 3) {
         uint32_t bsad = 0xffffffffu, bpos = 0;
-        const uint32_t *q = U + pu;
+        /* dword and bit field of this PU inside a table row */
+        const uint32_t *q  = U + (pu < 21 ? pu : 21 + ((pu - 21) >> 1));
+        const uint32_t  sh = pu < 21 ? 0u : (uint32_t)((pu - 21) & 1) * 16u, mk = pu < 21 ? 0xffffffffu : 0xffffu;
         for (int pos = slice; pos < npos; pos += 3) {
-            uint32_t v = q[pos * ME_PU_STRIDE];
+            uint32_t v = (q[pos * ME_PU_STRIDE] >> sh) & mk;
             if (v < bsad) { bsad = v; bpos = (uint32_t)pos; }
         }
         if (bsad != 0xffffffffu) svt_lds_min_u64(&c->st->key[pu], ((uint64_t)(2u * bsad) << 32) | (uint32_t)(y0 * sw + (int)bpos));
