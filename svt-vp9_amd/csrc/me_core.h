@@ -1098,7 +1098,10 @@ __device__ int g_me_stop_after = -1;
 #define ME_UNIFORM_WRITE(...) do { __VA_ARGS__; } while (0)
 #define ME_UNI(x) ((int)(x))
 #else
-#define ME_PHASE(...) do { __VA_ARGS__; __syncthreads(); } while (0)
+/* the thread index is re-read through an opaque move at every phase: whatever a phase derives from it (lane roles,
+ * LDS addresses) is computed where it is used and dies with the phase, instead of being hoisted to the top of the
+ * kernel and kept (or spilled) across all the others */
+#define ME_PHASE(...) do { __asm__ volatile("" : "+v"(tid)); __VA_ARGS__; __syncthreads(); } while (0)
 /* uniform state written to LDS by one thread, followed by a barrier */
 #define ME_UNIFORM_WRITE(...) do { if (tid == 0) { __VA_ARGS__; } __syncthreads(); } while (0)
 /* a value every lane holds identically (read from LDS): move it to a scalar register */
