@@ -264,7 +264,7 @@ typedef struct svt_tq_block {
     uint32_t src_off;    /* byte offset of the block's top-left in the source plane  */
     uint32_t pred_off;   /* byte offset in the prediction plane                       */
     uint32_t recon_off;  /* byte offset in the recon plane (written when do_recon)    */
-    uint32_t coeff_off;  /* element offset into qcoeff / dqcoeff (n*n contiguous)     */
+    uint32_t coeff_off;  /* element offset into qcoeff / dqcoeff (n*n contiguous); multiple of 8 */
     uint32_t iscan_off;  /* element offset of this block's iscan table inside the iscan array */
     uint16_t src_stride, pred_stride, recon_stride;
     uint8_t  tx_size;    /* SVT_TX_* */
@@ -287,7 +287,9 @@ typedef struct svt_tq_block {
  * Outputs: qcoeff, dqcoeff (int16, raster within block), eob per block.  Device pointers.
  * d_blocks must be GROUPED by transform size in the order 4x4, 8x8, 16x16, 32x32 with size_count[s] blocks of
  * size s (size_count is a host array), and do_recon must be uniform within a size group (the encode pass
- * reconstructs every block, mode decision none). */
+ * reconstructs every block, mode decision none).  d_qcoeff / d_dqcoeff are 16-byte aligned and every coeff_off is a
+ * multiple of 8 (rows are stored as 16-byte vectors; the reference's per-SB coefficient buffers advance by whole
+ * blocks of >= 16 coefficients, so its offsets always are). */
 int32_t svt_hip_tq_batch_device(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *d_recon,
                                 const svt_tq_block *d_blocks, const int32_t size_count[4],
                                 const svt_quant_tables *d_qtabs, const int16_t *d_iscan, int16_t *d_qcoeff,

@@ -13,7 +13,8 @@
  * iscan positions over the block's N lanes (DPP/shuffle).  Integer butterflies on VALU -- no MFMA (these are
  * 32-bit integer rotations with data-dependent rounding/truncation, not dense contractions).
  * Source, prediction and reconstruction move as dword rows (lane i owns row i); the row <-> column changes go through the
- * same LDS tile.  Global traffic per block: N*N source + N*N prediction bytes in, 2*N*N int16 (qcoeff, dqcoeff) + N*N recon out.
+ * same LDS tile; coefficient rows leave as 8/16-byte vectors (coeff_off and the two coefficient arrays must be 16-byte
+ * aligned: every block starts on a multiple of 8 coefficients).  Global traffic per block: N*N source + N*N prediction bytes in, 2*N*N int16 (qcoeff, dqcoeff) + N*N recon out.
  */
 #include <hip/hip_runtime.h>
 #include "svt_ctx.h"
@@ -135,7 +136,15 @@ __global__ __launch_bounds__(256) void svt_tq_kernel(const uint8_t *__restrict__
         }
     }
     /* ---- quantise row i; eob = 1 + max scan position of a non-zero level ---- */
-    const svt_quant_tables q = qtabs[k.qtab];
+    svt_quant_tables q;
+    {   /* the 20-byte table as five dwords instead of ten halfword loads */
+        const uint32_t *qp = (const uint32_t *)(qtabs + k.qtab);
+        uint32_t        qw5[5];
+        _Pragma("unroll") for (int j = 0; j < 5; j++) qw5[j] = qp[j];
+        q.zbin[0] = (int16_t)qw5[0]; q.zbin[1] = (int16_t)(qw5[0] >> 16); q.round[0] = (int16_t)qw5[1]; q.round[1] = (int16_t)(qw5[1] >> 16);
+        q.quant[0] = (int16_t)qw5[2]; q.quant[1] = (int16_t)(qw5[2] >> 16); q.quant_shift[0] = (int16_t)qw5[3]; q.quant_shift[1] = (int16_t)(qw5[3] >> 16);
+        q.dequant[0] = (int16_t)qw5[4]; q.dequant[1] = (int16_t)(qw5[4] >> 16);
+    }
     /* row i of the inverse scan, fetched as dwords up front (its latency hides behind the transforms) */
     uint32_t isw[N / 2];
     {
@@ -145,7 +154,9 @@ __global__ __launch_bounds__(256) void svt_tq_kernel(const uint8_t *__restrict__
     int eob = 0;
     uint32_t rdist = 0, pdist = 0;
     int32_t dq[N];
-    int16_t *qo = qcoeff + k.coeff_off + i * N, *dqo = dqcoeff + k.coeff_off + i * N;
+    /* row i of qcoeff / dqcoeff leaves as packed dwords: 2N bytes per lane, consecutive lanes consecutive rows */
+    uint32_t qw[N / 2], dqw[N / 2];
+    _Pragma("unroll") for (int j = 0; j < N / 2; j++) { qw[j] = 0; dqw[j] = 0; }
     _Pragma("unroll") for (int kk = 0; kk < N; kk++) {
         const int ac = (i | kk) != 0, cv = c[kk], sign = cv >> 31;
         int       a = (cv ^ sign) - sign, level = 0, qv = 0, dv = 0;
@@ -171,8 +182,20 @@ __global__ __launch_bounds__(256) void svt_tq_kernel(const uint8_t *__restrict__
         const int dd = (int16_t)(cv - dv);
         rdist += (uint32_t)(dd * dd);
         pdist += (uint32_t)(cv * cv);
-        if (active) { qo[kk] = (int16_t)qv; dqo[kk] = (int16_t)dv; }
+        qw[kk >> 1] |= (uint32_t)(uint16_t)qv << (16 * (kk & 1));
+        dqw[kk >> 1] |= (uint32_t)(uint16_t)dv << (16 * (kk & 1));
         if (level && active) { const int pos = (int)((isw[kk >> 1] >> (16 * (kk & 1))) & 0xffff) + 1; eob = pos > eob ? pos : eob; }
+    }
+    if (active) {
+        int16_t *qo = qcoeff + k.coeff_off + i * N, *dqo = dqcoeff + k.coeff_off + i * N;
+        if constexpr (N == 4) {
+            *(uint2 *)qo = make_uint2(qw[0], qw[1]); *(uint2 *)dqo = make_uint2(dqw[0], dqw[1]);
+        } else {
+            _Pragma("unroll") for (int j = 0; j < N / 8; j++) {
+                ((uint4 *)qo)[j]  = make_uint4(qw[4 * j], qw[4 * j + 1], qw[4 * j + 2], qw[4 * j + 3]);
+                ((uint4 *)dqo)[j] = make_uint4(dqw[4 * j], dqw[4 * j + 1], dqw[4 * j + 2], dqw[4 * j + 3]);
+            }
+        }
     }
     _Pragma("unroll") for (int off = 1; off < N; off <<= 1) { const int other = __shfl_xor(eob, off); eob = other > eob ? other : eob; }
     if (active && i == 0) eob_out[blk] = (uint16_t)eob;
@@ -259,6 +282,7 @@ extern "C" int32_t svt_hip_tq_batch_dist_device(svt_hip_ctx *ctx, const uint8_t 
                                                 int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist) {
     if (!ctx || !d_src || !d_pred || !d_blocks || !size_count || !d_qtabs || !d_iscan || !d_qcoeff || !d_dqcoeff || !d_eob)
         return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq: null argument");
+    if (((uintptr_t)d_qcoeff | (uintptr_t)d_dqcoeff) & 15) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq: coefficient arrays must be 16-byte aligned");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
     int off = 0, rc = 0;
@@ -284,6 +308,7 @@ extern "C" int32_t svt_hip_tq_batch(svt_hip_ctx *ctx, const uint8_t *src, const 
     int32_t cnt[4] = {0, 0, 0, 0};
     for (int i = 0; i < n_blocks; i++) {
         if (blocks[i].tx_size > 3 || blocks[i].qtab >= n_qtabs) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq: bad block");
+        if (blocks[i].coeff_off & 7) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq: coeff_off must be a multiple of 8 coefficients");
         if (i && blocks[i].tx_size < blocks[i - 1].tx_size) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq: blocks not grouped by tx_size");
         if (i && blocks[i].tx_size == blocks[i - 1].tx_size && (blocks[i].do_recon != 0) != (blocks[i - 1].do_recon != 0))
             return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq: do_recon must be uniform within a tx_size group");
