@@ -37,8 +37,12 @@ template <int N> __device__ __forceinline__ void fwd1d_hybrid(const int32_t *v, 
         if (adst) tx_adst8(v, o);
         else { tx_fdct8(v, o, 1); _Pragma("unroll") for (int i = 0; i < 8; i++) o[i] = (int16_t)o[i]; }
     } else {
-        if (adst) tx_adst16(v, o);
-        else { tx_fdct16(v, o); _Pragma("unroll") for (int i = 0; i < 16; i++) o[i] = (int16_t)o[i]; }
+        /* each branch fills its own array and the results meet in selects: with one shared output array the compiler
+         * turns the two-way merge into an indexed private-memory (scratch) access */
+        int32_t oa[16], od[16];
+        if (adst) tx_adst16(v, oa);
+        else { tx_fdct16(v, od); _Pragma("unroll") for (int i = 0; i < 16; i++) od[i] = (int16_t)od[i]; }
+        _Pragma("unroll") for (int i = 0; i < 16; i++) o[i] = adst ? oa[i] : od[i];
     }
 }
 /* forward 1-D for the DCT_DCT (fwd_txfm.c) path */
@@ -51,15 +55,42 @@ template <int N> __device__ __forceinline__ void fwd1d_dct(const int32_t *v, int
 template <int N> __device__ __forceinline__ void inv1d(const int32_t *v, int32_t *o, bool adst) {
     if constexpr (N == 4) { if (adst) tx_iadst4(v, o); else tx_idct4(v, o); }
     else if constexpr (N == 8) { if (adst) tx_adst8(v, o); else tx_idct8(v, o); }
-    else if constexpr (N == 16) { if (adst) tx_adst16(v, o); else tx_idct16(v, o); }
+    else if constexpr (N == 16) {
+        int32_t oa[16], od[16]; /* see fwd1d_hybrid */
+        if (adst) tx_adst16(v, oa); else tx_idct16(v, od);
+        _Pragma("unroll") for (int i = 0; i < 16; i++) o[i] = adst ? oa[i] : od[i];
+    }
     else tx_idct32(v, o);
+}
+
+/* one N-byte row as N/4 dwords: a single 8/16-byte access (two for N = 32) when the row is aligned to it, dwords otherwise */
+template <int N> __device__ __forceinline__ void row_load(const uint8_t *p, bool vec, uint32_t *w) {
+    if constexpr (N == 4) { w[0] = *(const uint32_t *)p; }
+    else if constexpr (N == 8) {
+        if (vec) { const uint2 t = *(const uint2 *)p; w[0] = t.x; w[1] = t.y; }
+        else { w[0] = ((const uint32_t *)p)[0]; w[1] = ((const uint32_t *)p)[1]; }
+    } else {
+        if (vec) { _Pragma("unroll") for (int j = 0; j < N / 16; j++) { const uint4 t = ((const uint4 *)p)[j]; w[4 * j] = t.x; w[4 * j + 1] = t.y; w[4 * j + 2] = t.z; w[4 * j + 3] = t.w; } }
+        else { _Pragma("unroll") for (int j = 0; j < N / 4; j++) w[j] = ((const uint32_t *)p)[j]; }
+    }
+}
+template <int N> __device__ __forceinline__ void row_store(uint8_t *p, bool vec, const uint32_t *w) {
+    if constexpr (N == 4) { *(uint32_t *)p = w[0]; }
+    else if constexpr (N == 8) {
+        if (vec) *(uint2 *)p = make_uint2(w[0], w[1]);
+        else { ((uint32_t *)p)[0] = w[0]; ((uint32_t *)p)[1] = w[1]; }
+    } else {
+        if (vec) { _Pragma("unroll") for (int j = 0; j < N / 16; j++) ((uint4 *)p)[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]); }
+        else { _Pragma("unroll") for (int j = 0; j < N / 4; j++) ((uint32_t *)p)[j] = w[j]; }
+    }
 }
 
 __device__ __forceinline__ int clamp16(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
 __device__ __forceinline__ uint8_t clip_add(int d, int t) { int v = d + t; return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
 
+/* 32x32: 33 KB of LDS per workgroup allow four workgroups per CU; the register budget is held to the matching 128 */
 template <int N>
-__global__ __launch_bounds__(256) void svt_tq_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ pred,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 4 : 1))) void svt_tq_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ pred,
                                                      uint8_t *__restrict__ recon, const svt_tq_block *__restrict__ blocks,
                                                      int n_blocks, const svt_quant_tables *__restrict__ qtabs,
                                                      const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,
@@ -85,10 +116,12 @@ __global__ __launch_bounds__(256) void svt_tq_kernel(const uint8_t *__restrict__
     /* ---- residual: lane i fetches ROW i of source and prediction as dwords (coalesced: the N lanes of a block read N
      * consecutive rows of N bytes), the residual row goes through the LDS tile and comes back as COLUMN i ---- */
     {
-        const uint32_t *sp = (const uint32_t *)(src + k.src_off + (size_t)i * k.src_stride);
-        const uint32_t *pp = (const uint32_t *)(pred + k.pred_off + (size_t)i * k.pred_stride);
+        const uint8_t *sp = src + k.src_off + (size_t)i * k.src_stride;
+        const uint8_t *pp = pred + k.pred_off + (size_t)i * k.pred_stride;
+        constexpr uintptr_t AM = N >= 16 ? 15 : N - 1;
         uint32_t        srow[N / 4];
-        _Pragma("unroll") for (int q = 0; q < N / 4; q++) { srow[q] = active ? sp[q] : 0u; prow[q] = active ? pp[q] : 0u; }
+        _Pragma("unroll") for (int q = 0; q < N / 4; q++) { srow[q] = 0u; prow[q] = 0u; }
+        if (active) { row_load<N>(sp, ((uintptr_t)sp & AM) == 0, srow); row_load<N>(pp, ((uintptr_t)pp & AM) == 0, prow); }
         _Pragma("unroll") for (int cc = 0; cc < N; cc++)
             t[i * LS + cc] = (int16_t)((int)((srow[cc >> 2] >> (8 * (cc & 3))) & 0xff) - (int)((prow[cc >> 2] >> (8 * (cc & 3))) & 0xff));
         /* the N lanes of a block sit in one wave and LDS accesses of a wave are ordered: no barrier needed here */
@@ -155,8 +188,9 @@ __global__ __launch_bounds__(256) void svt_tq_kernel(const uint8_t *__restrict__
     uint32_t rdist = 0, pdist = 0;
     int32_t dq[N];
     /* row i of qcoeff / dqcoeff leaves as packed dwords: 2N bytes per lane, consecutive lanes consecutive rows */
-    uint32_t qw[N / 2], dqw[N / 2];
-    _Pragma("unroll") for (int j = 0; j < N / 2; j++) { qw[j] = 0; dqw[j] = 0; }
+    constexpr int VC = N == 4 ? 4 : 8; /* coefficients per vector store */
+    uint32_t qw[VC / 2], dqw[VC / 2];
+    int16_t *qo = qcoeff + k.coeff_off + i * N, *dqo = dqcoeff + k.coeff_off + i * N;
     _Pragma("unroll") for (int kk = 0; kk < N; kk++) {
         const int ac = (i | kk) != 0, cv = c[kk], sign = cv >> 31;
         int       a = (cv ^ sign) - sign, level = 0, qv = 0, dv = 0;
@@ -182,20 +216,20 @@ __global__ __launch_bounds__(256) void svt_tq_kernel(const uint8_t *__restrict__
         const int dd = (int16_t)(cv - dv);
         rdist += (uint32_t)(dd * dd);
         pdist += (uint32_t)(cv * cv);
-        qw[kk >> 1] |= (uint32_t)(uint16_t)qv << (16 * (kk & 1));
-        dqw[kk >> 1] |= (uint32_t)(uint16_t)dv << (16 * (kk & 1));
-        if (level && active) { const int pos = (int)((isw[kk >> 1] >> (16 * (kk & 1))) & 0xffff) + 1; eob = pos > eob ? pos : eob; }
-    }
-    if (active) {
-        int16_t *qo = qcoeff + k.coeff_off + i * N, *dqo = dqcoeff + k.coeff_off + i * N;
-        if constexpr (N == 4) {
-            *(uint2 *)qo = make_uint2(qw[0], qw[1]); *(uint2 *)dqo = make_uint2(dqw[0], dqw[1]);
-        } else {
-            _Pragma("unroll") for (int j = 0; j < N / 8; j++) {
-                ((uint4 *)qo)[j]  = make_uint4(qw[4 * j], qw[4 * j + 1], qw[4 * j + 2], qw[4 * j + 3]);
-                ((uint4 *)dqo)[j] = make_uint4(dqw[4 * j], dqw[4 * j + 1], dqw[4 * j + 2], dqw[4 * j + 3]);
+        {   /* the row leaves in vectors of VC coefficients as soon as they are complete (few live registers) */
+            const int j = (kk % VC) >> 1;
+            if (kk & 1) { qw[j] |= (uint32_t)(uint16_t)qv << 16; dqw[j] |= (uint32_t)(uint16_t)dv << 16; }
+            else { qw[j] = (uint16_t)qv; dqw[j] = (uint16_t)dv; }
+            if ((kk % VC) == VC - 1 && active) {
+                if constexpr (N == 4) {
+                    *(uint2 *)qo = make_uint2(qw[0], qw[1]); *(uint2 *)dqo = make_uint2(dqw[0], dqw[1]);
+                } else {
+                    ((uint4 *)qo)[kk / VC]  = make_uint4(qw[0], qw[1], qw[2], qw[3]);
+                    ((uint4 *)dqo)[kk / VC] = make_uint4(dqw[0], dqw[1], dqw[2], dqw[3]);
+                }
             }
         }
+        if (level && active) { const int pos = (int)((isw[kk >> 1] >> (16 * (kk & 1))) & 0xffff) + 1; eob = pos > eob ? pos : eob; }
     }
     _Pragma("unroll") for (int off = 1; off < N; off <<= 1) { const int other = __shfl_xor(eob, off); eob = other > eob ? other : eob; }
     if (active && i == 0) eob_out[blk] = (uint16_t)eob;
@@ -242,13 +276,15 @@ __global__ __launch_bounds__(256) void svt_tq_kernel(const uint8_t *__restrict__
     /* residual column i -> LDS -> row i; reconstruction = clip(pred row + residual row), stored as dwords */
     _Pragma("unroll") for (int r = 0; r < N; r++) t[r * LS + i] = res[r];
     if (active) {
-        uint32_t *d = (uint32_t *)(recon + k.recon_off + (size_t)i * k.recon_stride);
+        uint8_t *d = recon + k.recon_off + (size_t)i * k.recon_stride;
+        uint32_t rw[N / 4];
         _Pragma("unroll") for (int q = 0; q < N / 4; q++) {
             uint32_t w = 0;
             _Pragma("unroll") for (int b = 0; b < 4; b++)
                 w |= (uint32_t)clip_add((int)((prow[q] >> (8 * b)) & 0xff), t[i * LS + 4 * q + b]) << (8 * b);
-            d[q] = w;
+            rw[q] = w;
         }
+        row_store<N>(d, ((uintptr_t)d & (N >= 16 ? 15 : N - 1)) == 0, rw);
     }
 }
 

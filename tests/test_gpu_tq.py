@@ -33,6 +33,16 @@ def test_tq_vs_oracle(ctx, seed, do_recon):
     assert len(set(o[3].tolist())) > 8  # the case really exercises many eob classes
 
 
+@pytest.mark.parametrize("width", [264, 260])
+def test_tq_rows_not_vector_aligned(ctx, width):
+    """plane stride = 8 / 4 mod 16: the rows of a block alternate between the 16-byte vector path and the dword path"""
+    case = T.make_tq_case(7, width=width)
+    o = T.oracle_tq_batch(case)
+    g = T.hip_tq_batch(ctx, case)
+    for n, a, b in zip(("recon", "qcoeff", "dqcoeff", "eob"), o, g):
+        assert np.array_equal(a, b), (n, int(np.sum(a != b)))
+
+
 @pytest.mark.parametrize("seed", [11, 12])
 def test_tq_extreme_residuals(ctx, seed):
     """+-255 residuals, tiny and huge quantiser steps: saturation / clamp paths."""
