@@ -383,6 +383,57 @@ int32_t svt_hip_lf_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_yuv_
 int32_t svt_hip_lf_frame(svt_hip_ctx *ctx, const svt_yuv_planes *recon, const svt_lf_mask *lfm, int32_t lfm_stride,
                          const svt_lf_thresh *thr, int32_t mi_rows, int32_t mi_cols, int32_t y_only);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Inter prediction (8-tap motion compensation) of a whole picture -- SURVEY 8(f) row 2.
+ *
+ * Replaces the inter branch of prediction_fun_table (Codec/EbEncDecProcess.c:132, called per block and plane at
+ * :277 / :3800): inter_prediction (Codec/EbIntraPrediction.c:49-72) -> build_inter_predictors
+ * (VPX/vp9_reconinter.c:102-252) -> eb_vp9_clamp_mv_to_umv_border_sb (:72-92) -> inter_predictor
+ * (VPX/vp9_reconinter.h:23-28) -> eb_vpx_convolve_copy / eb_vp9_convolve8[_horiz|_vert] and their _avg forms for the
+ * second reference of a compound block (VPX/vpx_convolve.c:20-215) with the regular 8-tap kernel
+ * (VPX/vp9_filter.c:32-47; the reference hard-wires eb_vp9_filter_kernels[0], vp9_reconinter.c:107-109).
+ * Unscaled references only (sf->x_step_q4 == y_step_q4 == 16, the only case the reference's scale setup keeps,
+ * VPX/vp9_scale.c:76-84, 126-128).  The prediction written here is the d_pred input of svt_hip_tq_batch_device.
+ *
+ * The picture is described the way the reference describes it after mode decision: one record per 8x8 unit of the
+ * mode-info grid (cm->mi_grid_visible), every unit of a block carrying the block's values.  Blocks are the
+ * reference's >= 8x8 partitions (inter_prediction asserts that no sub-8x8 inter block exists, :62-64), aligned to
+ * their own size. */
+typedef struct svt_mc_mode_info {
+    int16_t mv_row[2], mv_col[2]; /* mi->mv[ref].as_mv, 1/8 luma sample (MV_PRECISION_Q3) */
+    int8_t  ref_list[2];          /* reference list of ref 0 / ref 1: 0 = REF_LIST_0 (LAST_FRAME), 1 = REF_LIST_1, -1 = none;
+                                     ref_list[0] < 0: not an inter block, nothing is written for this unit;
+                                     ref_list[1] >= 0: compound (has_second_ref) */
+    uint8_t bw8, bh8;             /* block width / height in 8x8 units (1, 2, 4, 8): num_8x8_blocks_wide/high_lookup[sb_type] */
+} svt_mc_mode_info;               /* 12 bytes */
+
+/* One picture: d_mi[mi_row * mi_stride + mi_col]; ref[l] = ref_pic_list[l] (planes need the reference's padding of
+ * at least 64 + 16 samples around the luma picture and half of it around chroma, Codec/EbEncHandle.c:968-970: a
+ * clamped MV reaches bw + 4 samples beyond the edge and the filter 4 more); pred = the prediction picture (sample
+ * (0,0) pointers).  use_subpel = context_ptr->use_subpel_flag (0: the MVs are rounded to full samples the way
+ * vp9_reconinter.c:175-188 does).  All pointers are device pointers. */
+typedef struct svt_mc_picture {
+    const svt_mc_mode_info *d_mi;
+    int32_t        mi_stride, mi_rows, mi_cols;
+    svt_yuv_planes ref[2];
+    svt_yuv_planes pred;
+    int32_t        use_subpel;
+} svt_mc_picture;
+
+/* n_pics independent pictures in one launch (host array of descriptors holding device pointers). */
+int32_t svt_hip_inter_pred_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_mc_picture *pics);
+/* Host-pointer convenience form for one picture: plane buffers are given WITH their padding (buf = first byte of the
+ * padded plane, org_x/org_y = padding of the luma plane; chroma planes have half of it); the three prediction planes
+ * are tight (width x height, width/2 x height/2) and are read back. */
+typedef struct svt_mc_host_ref {
+    const uint8_t *y, *u, *v;        /* padded planes */
+    int32_t        y_stride, uv_stride;
+    int32_t        org_x, org_y;     /* luma padding (even) */
+} svt_mc_host_ref;
+int32_t svt_hip_inter_pred_frame(svt_hip_ctx *ctx, const svt_mc_mode_info *mi, int32_t mi_stride, int32_t mi_rows,
+                                 int32_t mi_cols, const svt_mc_host_ref ref[2], int32_t use_subpel, uint8_t *pred_y,
+                                 uint8_t *pred_u, uint8_t *pred_v);
+
 #ifdef __cplusplus
 }
 #endif

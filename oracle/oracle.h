@@ -45,4 +45,8 @@ int32_t svt_oracle_pa_prepare(const uint8_t *luma, int32_t luma_stride, const sv
 /* compute_block_mean_compute_variance (Codec/EbPictureAnalysisProcess.c:2115-3356) */
 void    svt_oracle_pa_mean8x8(const uint8_t *p, int32_t stride, uint64_t *mean, uint64_t *mean_sq);
 int32_t svt_oracle_pa_mean_variance(const svt_plane *full, uint8_t *mean_out, uint16_t *var_out);
+/* inter prediction of a picture from its mode-info grid (Codec/EbIntraPrediction.c:49-72 -> VPX/vp9_reconinter.c:102-252) */
+int32_t svt_oracle_inter_pred_frame(const svt_mc_mode_info *mi, int32_t mi_stride, int32_t mi_rows, int32_t mi_cols,
+                                    const svt_mc_host_ref ref[2], int32_t use_subpel, uint8_t *pred_y, uint8_t *pred_u,
+                                    uint8_t *pred_v);
 #endif

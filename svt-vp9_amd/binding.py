@@ -84,6 +84,10 @@ LF_MODE_INFO_DTYPE = np.dtype([("sb_type", "u1"), ("tx_size", "u1"), ("skip", "u
 assert LF_MODE_INFO_DTYPE.itemsize == 8
 
 
+MC_MODE_INFO_DTYPE = np.dtype([("mv_row", "<i2", (2,)), ("mv_col", "<i2", (2,)), ("ref_list", "i1", (2,)), ("bw8", "u1"), ("bh8", "u1")])
+assert MC_MODE_INFO_DTYPE.itemsize == 12
+
+
 class LfThresh(C.Structure):
     _fields_ = [("mblim", C.c_uint8 * 64), ("lim", C.c_uint8 * 64), ("hev_thr", C.c_uint8 * 64)]
 
@@ -91,6 +95,16 @@ class LfThresh(C.Structure):
 class YuvPlanes(C.Structure):
     _fields_ = [("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("y_stride", C.c_int32),
                 ("uv_stride", C.c_int32), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class McHostRef(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("y_stride", C.c_int32), ("uv_stride", C.c_int32),
+                ("org_x", C.c_int32), ("org_y", C.c_int32)]
+
+
+class McPicture(C.Structure):
+    _fields_ = [("d_mi", C.c_void_p), ("mi_stride", C.c_int32), ("mi_rows", C.c_int32), ("mi_cols", C.c_int32),
+                ("ref", YuvPlanes * 2), ("pred", YuvPlanes), ("use_subpel", C.c_int32)]
 
 
 # every symbol include/svtvp9_hip.h declares
@@ -101,6 +115,7 @@ EXPORTS = [
     "svt_hip_me_zz_sad_device", "svt_hip_me_similar_collocated", "svt_hip_pa_prepare_batch_device", "svt_hip_pa_mean_variance_device",
     "svt_hip_tq_batch_device", "svt_hip_tq_batch_dist_device", "svt_hip_tq_batch", "svt_hip_lf_thresh_init", "svt_hip_lf_level_from_q",
     "svt_hip_lf_frame_device", "svt_hip_lf_batch_device", "svt_hip_lf_frame", "svt_hip_lf_build_masks",
+    "svt_hip_inter_pred_batch_device", "svt_hip_inter_pred_frame",
 ]
 
 _lib = None

@@ -6,7 +6,7 @@
 #include <string.h>
 #include "../../include/svtvp9_hip.h"
 
-#define SVT_CTX_SLOTS 32
+#define SVT_CTX_SLOTS 40
 #define SVT_CTX_RING 16
 
 struct svt_hip_ctx {

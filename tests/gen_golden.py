@@ -12,6 +12,7 @@ import me_configs as MC  # noqa: E402
 import svt_testlib as T  # noqa: E402
 
 G = T.GOLDEN_DIR
+MC_GOLDEN_CASES = ((1, 192, 128, 1), (2, 128, 72, 1), (3, 64, 64, 0), (4, 200, 136, 1))
 
 
 def main():
@@ -62,6 +63,14 @@ def main():
         for n in r.dtype.names:
             lm[f"lfm_{seed}_{n}"] = np.ascontiguousarray(r[n])
     np.savez_compressed(os.path.join(G, "lf_masks_reference.npz"), **lm)
+    # ---- inter prediction: the reference's inter_prediction() on seeded mode-info grids (tests/test_mc.py) ----
+    assert T.have_ref("ref_mc_frame")
+    mc = {}
+    for (seed, w, h, sub) in MC_GOLDEN_CASES:
+        case = T.make_mc_case(seed, width=w, height=h, use_subpel=sub)
+        y, u, v = T.ref_mc_frame(case)
+        mc[f"y|{seed}|{w}|{h}|{sub}"], mc[f"u|{seed}|{w}|{h}|{sub}"], mc[f"v|{seed}|{w}|{h}|{sub}"] = y, u, v
+    np.savez_compressed(os.path.join(G, "mc_reference.npz"), **mc)
     for f in sorted(os.listdir(G)):
         print(f, os.path.getsize(os.path.join(G, f)))
 

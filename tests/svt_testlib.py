@@ -759,3 +759,120 @@ def hip_me_zz_sad(ctx, cur, prev, input_resolution):
     B.check(lib.svt_hip_me_zz_sad_device(ctx, C.byref(a), C.byref(b), input_resolution, C.c_void_p(zz.data_ptr()), C.c_void_p(nmi.data_ptr())))
     B.check(lib.svt_hip_ctx_synchronize(ctx))
     return zz.cpu().numpy().view(np.uint32), nmi.cpu().numpy()
+
+
+# ---- inter prediction (8-tap motion compensation) -------------------------------------------------------------
+def make_mc_case(seed, width=192, height=128, pad=80, mv_range=48, use_subpel=1, rect=True, intra_share=0.1):
+    """Two padded reference pictures, a mode-info grid cut into VP9 partitions (64..8, optionally rectangular) with a
+    mix of single-list / compound blocks, zero / full-sample / sub-sample / far-out-of-picture MVs, some intra units."""
+    rng = np.random.default_rng(seed)
+    mi_rows, mi_cols = height // 8, width // 8
+    refs = []
+    for l in range(2):
+        y, u, v = gen_yuv(width, height, seed * 7 + l)
+        v = (255 - u[::-1, ::-1] // 2 - v // 4).astype(np.uint8)   # gen_yuv's V plane is nearly flat: give it texture
+        y = np.ascontiguousarray(np.pad(y, pad, mode="edge"))
+        u = np.ascontiguousarray(np.pad(u, pad // 2, mode="edge"))
+        v = np.ascontiguousarray(np.pad(v, pad // 2, mode="edge"))
+        refs.append((y, u, v))
+    mi = np.zeros((mi_rows, mi_cols), dtype=B.MC_MODE_INFO_DTYPE)
+    mi["ref_list"] = -1
+
+    def fill(r, c, h8, w8):
+        kind = rng.random()
+        cell = np.zeros((), dtype=B.MC_MODE_INFO_DTYPE)
+        cell["bw8"], cell["bh8"] = w8, h8
+        if kind < intra_share:
+            cell["ref_list"] = (-1, -1)
+        else:
+            comp = rng.random() < 0.4
+            l0 = int(rng.integers(0, 2))
+            cell["ref_list"] = (l0, (1 - l0 if rng.random() < 0.8 else l0) if comp else -1)
+            for k in range(2):
+                t = rng.random()
+                if t < 0.15: mv = (0, 0)
+                elif t < 0.35: mv = tuple(int(x) * 8 for x in rng.integers(-mv_range // 8, mv_range // 8 + 1, 2))
+                elif t < 0.9: mv = tuple(int(x) for x in rng.integers(-mv_range * 8, mv_range * 8 + 1, 2))
+                else: mv = tuple(int(x) for x in rng.integers(-4000, 4001, 2))  # far outside: clamp_mv_to_umv_border_sb
+                cell["mv_row"][k], cell["mv_col"][k] = mv
+        mi[r:r + h8, c:c + w8] = cell
+
+    def split(r, c, n8):
+        if r >= mi_rows or c >= mi_cols:
+            return
+        fits = r + n8 <= mi_rows and c + n8 <= mi_cols
+        t = rng.random()
+        if n8 > 1 and (not fits or t < 0.55):
+            h = n8 // 2
+            for dr, dc in ((0, 0), (0, h), (h, 0), (h, h)):
+                split(r + dr, c + dc, h)
+        elif rect and n8 > 1 and t < 0.7:
+            fill(r, c, n8 // 2, n8); fill(r + n8 // 2, c, n8 // 2, n8)       # PARTITION_HORZ
+        elif rect and n8 > 1 and t < 0.85:
+            fill(r, c, n8, n8 // 2); fill(r, c + n8 // 2, n8, n8 // 2)       # PARTITION_VERT
+        else:
+            fill(r, c, n8, n8)
+
+    for r in range(0, mi_rows, 8):
+        for c in range(0, mi_cols, 8):
+            split(r, c, 8)
+    return dict(mi=mi, mi_rows=mi_rows, mi_cols=mi_cols, refs=refs, pad=pad, use_subpel=use_subpel, width=width, height=height)
+
+
+def _mc_host_refs(case):
+    arr = (B.McHostRef * 2)()
+    for l, (y, u, v) in enumerate(case["refs"]):
+        arr[l].y, arr[l].u, arr[l].v = y.ctypes.data, u.ctypes.data, v.ctypes.data
+        arr[l].y_stride, arr[l].uv_stride = y.shape[1], u.shape[1]
+        arr[l].org_x = arr[l].org_y = case["pad"]
+    return arr
+
+
+def _mc_out(case, fill=0x5A):
+    W, H = case["width"], case["height"]
+    return [np.full((H, W), fill, np.uint8), np.full((H // 2, W // 2), fill, np.uint8), np.full((H // 2, W // 2), fill, np.uint8)]
+
+
+def oracle_mc_frame(case):
+    lib = oracle()
+    mi = np.ascontiguousarray(case["mi"])
+    out = _mc_out(case)
+    rc = lib.svt_oracle_inter_pred_frame(C.c_void_p(mi.ctypes.data), case["mi_cols"], case["mi_rows"], case["mi_cols"], _mc_host_refs(case),
+                                         case["use_subpel"], *[C.c_void_p(o.ctypes.data) for o in out])
+    assert rc == 0
+    return out
+
+
+def hip_mc_frame(ctx, case):
+    lib = B.load()
+    mi = np.ascontiguousarray(case["mi"])
+    out = _mc_out(case)
+    B.check(lib.svt_hip_inter_pred_frame(ctx, C.c_void_p(mi.ctypes.data), case["mi_cols"], case["mi_rows"], case["mi_cols"], _mc_host_refs(case),
+                                         case["use_subpel"], *[C.c_void_p(o.ctypes.data) for o in out]))
+    return out
+
+
+def ref_mc_frame(case, asm_type=0):
+    """the reference's own inter_prediction() for every block (oracle/_ref/ref_mc_frame); units it does not predict are 0"""
+    exe = os.path.join(REF_DIR, "ref_mc_frame")
+    mi = np.ascontiguousarray(case["mi"])
+    W, H = case["width"], case["height"]
+    with tempfile.TemporaryDirectory() as td:
+        req, rsp = os.path.join(td, "req.bin"), os.path.join(td, "rsp.bin")
+        with open(req, "wb") as f:
+            f.write(struct.pack("<6i", 0x434D5653, case["mi_rows"], case["mi_cols"], case["mi_cols"], case["use_subpel"], asm_type))
+            for (y, u, v) in case["refs"]:
+                f.write(struct.pack("<6i", y.shape[1], u.shape[1], case["pad"], case["pad"], y.shape[0], u.shape[0]))
+                f.write(y.tobytes()); f.write(u.tobytes()); f.write(v.tobytes())
+            f.write(mi.tobytes())
+        subprocess.check_call([exe, req, rsp])
+        raw = open(rsp, "rb").read()
+    return [np.frombuffer(raw, np.uint8, W * H).reshape(H, W).copy(),
+            np.frombuffer(raw, np.uint8, W * H // 4, W * H).reshape(H // 2, W // 2).copy(),
+            np.frombuffer(raw, np.uint8, W * H // 4, W * H + W * H // 4).reshape(H // 2, W // 2).copy()]
+
+
+def mc_inter_masks(case):
+    """boolean masks (luma, chroma) of the samples that belong to inter blocks"""
+    inter = case["mi"]["ref_list"][:, :, 0] >= 0
+    return np.kron(inter, np.ones((8, 8), bool)), np.kron(inter, np.ones((4, 4), bool))
