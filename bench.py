@@ -304,6 +304,40 @@ def main():
             pa_ms += lib.svt_hip_last_kernel_ms(ctx_me) / 3
     pa_bytes = MINIGOP * int(Wd * Hd + (Wd + 136) * (Hd + 136) + (Wd // 4 + 32) * (Hd // 4 + 32) + (((Wd // 2 + 64) * (Hd // 2 + 64)) if l1_on else 0))
 
+    # ---- inter prediction (row f-2, not part of `value`): 8-tap motion compensation of the 16 pictures from a mode-info
+    # grid (64..8 partitions, ~40 % compound, sub-sample MVs), two padded reference pictures, one batched launch ----
+    mcase = T.make_mc_case(3, width=Wd, height=Hd, mv_range=24, intra_share=0.1)
+    mc_keep = [to_dev(np.ascontiguousarray(mcase["mi"]).view(np.uint8))]
+    mc_refs = []
+    for (y, u, v) in mcase["refs"]:
+        ty, tu, tv = to_dev(y), to_dev(u), to_dev(v)
+        mc_keep += [ty, tu, tv]
+        pad = mcase["pad"]
+        mc_refs.append((ty.data_ptr() + pad * y.shape[1] + pad, tu.data_ptr() + (pad // 2) * u.shape[1] + pad // 2,
+                        tv.data_ptr() + (pad // 2) * v.shape[1] + pad // 2, y.shape[1], u.shape[1]))
+    d_mcpred = to_dev(np.zeros((MINIGOP, Hd * 3 // 2, Wd), np.uint8))
+    mc_pics = (B.McPicture * MINIGOP)()
+    for k in range(MINIGOP):
+        mp = mc_pics[k]
+        mp.d_mi, mp.mi_stride, mp.mi_rows, mp.mi_cols, mp.use_subpel = mc_keep[0].data_ptr(), mcase["mi_cols"], mcase["mi_rows"], mcase["mi_cols"], 1
+        for l in range(2):
+            r = mp.ref[l]
+            r.y, r.u, r.v, r.y_stride, r.uv_stride = mc_refs[l]
+            r.width, r.height = Wd, Hd
+        base = d_mcpred.data_ptr() + k * (Hd * 3 // 2) * Wd
+        mp.pred.y, mp.pred.u, mp.pred.v = base, base + Hd * Wd, base + Hd * Wd + (Hd // 2) * (Wd // 2)
+        mp.pred.y_stride, mp.pred.uv_stride, mp.pred.width, mp.pred.height = Wd, Wd // 2, Wd, Hd
+    mc_ms = 0.0
+    for rep in range(4):
+        B.check(lib.svt_hip_inter_pred_batch_device(ctx_me, MINIGOP, mc_pics))
+        B.check(lib.svt_hip_ctx_synchronize(ctx_me))
+        if rep:
+            mc_ms += lib.svt_hip_last_kernel_ms(ctx_me) / 3
+    inter = mcase["mi"]["ref_list"][:, :, 0] >= 0
+    comp = mcase["mi"]["ref_list"][:, :, 1] >= 0
+    # per 8x8 unit: 96 bytes (64 luma + 2 x 16 chroma) read per reference and written once, + the 12-byte mode-info record
+    mc_bytes = MINIGOP * int(96 * (inter.sum() + (inter & comp).sum()) + 96 * inter.sum() + 12 * inter.size)
+
     if rank != 0:
         return
     # HBM traffic of the dominant kernel per step, from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.md)
@@ -337,7 +371,8 @@ def main():
         "kernels": {k: {"ms_per_step": round(ms, 3), "algorithmic_bytes_per_step": b, "GB_per_s": round(b / (ms * 1e-3) / 1e9, 2),
                         "frac_of_8TBps": round(b / (ms * 1e-3) / 8e12, 5)}
                     for k, ms, b in (("svt_me_sb_kernel", me_ms, me_bytes), ("svt_tq_kernel<4|8|16|32>", tq_ms, tq_bytes),
-                                     ("svt_lf_kernel", lf_ms, lf_bytes), ("svt_pa_plane_kernel (pre-ME stage, outside value)", pa_ms, pa_bytes))},
+                                     ("svt_lf_kernel", lf_ms, lf_bytes), ("svt_pa_plane_kernel (pre-ME stage, outside value)", pa_ms, pa_bytes),
+                                     ("svt_mc_kernel (inter prediction in front of TQ, outside value)", max(mc_ms, 1e-9), mc_bytes))},
     }
     if not args.no_cpu_baseline:
         # oracle (scalar C restatement of the reference C path), single thread, on a bounded sample of the same
