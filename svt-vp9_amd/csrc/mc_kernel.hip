@@ -7,12 +7,14 @@
  * eb_vp9_clamp_mv_to_umv_border_sb (:72-92) and the eb_vp9_convolve8* / copy / avg kernels inter_predictor picks
  * (VPX/vp9_reconinter.h:23-28, VPX/vp9_scale.c:76-84,126-128, VPX/vpx_convolve.c:20-215).
  *
- * Mapping.  The work unit is a 4x4 tile of one plane: a lane loads 11 rows of 16 bytes around its tile, filters them
- * horizontally into 11 packed rows (uint8, rounded and clipped exactly like the reference's intermediate buffer),
- * filters those vertically into 4 rows and writes 4 dwords.  Everything stays in registers -- no LDS, no barrier, no
- * cross-lane traffic -- because neighbouring 8x8 units may belong to blocks with unrelated motion vectors.  A
- * workgroup of 192 lanes covers 32 units of one mode-info row: wave 0 the upper luma tiles (64 consecutive dwords of a
- * sample row), wave 1 the lower ones, wave 2 the Cb and Cr tiles, so loads and stores of a wave are contiguous.
+ * Mapping.  The work unit is a 4-sample-wide tile of one plane, NR = 8 rows high in luma (half an 8x8 unit) and 4 in
+ * chroma: a lane loads NR + 7 rows of 16 bytes around its tile, filters them horizontally into NR + 7 packed rows
+ * (uint8, rounded and clipped exactly like the reference's intermediate buffer), filters those vertically into NR rows
+ * and writes NR dwords.  Everything stays in registers -- no LDS, no barrier, no cross-lane traffic -- because
+ * neighbouring 8x8 units may belong to blocks with unrelated motion vectors.  A workgroup of 128 lanes covers 32 units
+ * of one mode-info row: wave 0 the luma tiles (64 consecutive dwords of a sample row), wave 1 the Cb and Cr tiles, so
+ * the loads and stores of a wave are contiguous.  Workgroups are numbered so that each XCD works on one contiguous band
+ * of mode-info rows: the rows above/below a tile that the 8-tap filter needs are then found in that XCD's own L2.
  * Filter phase 0 of the VP9 kernel is {0,0,0,128,0,0,0,0}: (128 p + 64) >> 7 == p, so the copy / horizontal-only /
  * vertical-only variants of the reference are the same computation with that phase and need no branches; phase 0 is
  * taken by a select because its tap 128 does not fit the signed-byte dot product.
@@ -55,14 +57,16 @@ __device__ __forceinline__ uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, ui
     return __builtin_amdgcn_perm(c | (d << 8), a | (b << 8), 0x05040100u);
 }
 
-/* 4x4 tile at plane position (x, y) displaced by (s_col, s_row) sixteenths, VP9 regular filter */
-__device__ __forceinline__ void mc_tile(const uint8_t *plane, int stride, int x, int y, int s_row, int s_col, int sx, int sy, uint32_t out[4]) {
+/* 4 x NR tile at plane position (x, y) displaced by (s_col, s_row) sixteenths, VP9 regular filter */
+template <int NR>
+__device__ __forceinline__ void mc_tile(const uint8_t *plane, int stride, int x, int y, int s_row, int s_col, int sx, int sy, uint32_t out[NR]) {
+    constexpr int NM = NR + 7, NG = (NM + 3) / 4;
     const uint8_t *p0 = plane + (ptrdiff_t)(y + (s_row >> 4) - 3) * stride + (x + (s_col >> 4) - 3);
     const uint32_t sh = (uint32_t)((uintptr_t)p0 & 3);
     p0 -= sh;
     const uint32_t tl = c_tap_lo[sx], th = c_tap_hi[sx];
-    uint32_t       mid[11];
-    _Pragma("unroll") for (int r = 0; r < 11; r++) {
+    uint32_t       mid[NM];
+    _Pragma("unroll") for (int r = 0; r < NM; r++) {
         const u32x4a4 d = *(const u32x4a4 *)(p0 + (ptrdiff_t)r * stride);
         /* bytes 0..11 of the row window (sample x - 3 first) */
         const uint32_t e0 = alignbyte(d.y, d.x, sh), e1 = alignbyte(d.z, d.y, sh), e2 = alignbyte(d.w, d.z, sh);
@@ -75,36 +79,30 @@ __device__ __forceinline__ void mc_tile(const uint8_t *plane, int stride, int x,
         const uint32_t f = pack4(finish(a0), finish(a1), finish(a2), finish(a3));
         mid[r] = sx ? f : alignbyte(e1, e0, 3); /* phase 0: the samples themselves (bytes 3..6) */
     }
-    /* columns of the 11 intermediate rows as byte streams: col[j][g] = rows 4g .. 4g+3 of column j (row 11 = padding) */
-    uint32_t col[4][3];
-    _Pragma("unroll") for (int g = 0; g < 3; g++) {
+    /* columns of the NM intermediate rows as byte streams: col[j][g] = rows 4g .. 4g+3 of column j (row NM = padding) */
+    uint32_t col[4][NG];
+    _Pragma("unroll") for (int g = 0; g < NG; g++) {
         const uint32_t r0 = mid[4 * g] ^ 0x80808080u, r1 = mid[4 * g + 1] ^ 0x80808080u, r2 = mid[4 * g + 2] ^ 0x80808080u;
-        const uint32_t r3 = g < 2 ? mid[4 * g + 3] ^ 0x80808080u : 0u;
+        const uint32_t r3 = 4 * g + 3 < NM ? mid[4 * g + 3] ^ 0x80808080u : 0u;
         const uint32_t a0 = __builtin_amdgcn_perm(r1, r0, 0x05010400u), a1 = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
         const uint32_t q0 = __builtin_amdgcn_perm(r3, r2, 0x05010400u), q1 = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
         col[0][g] = __builtin_amdgcn_perm(q0, a0, 0x05040100u); col[1][g] = __builtin_amdgcn_perm(q0, a0, 0x07060302u);
         col[2][g] = __builtin_amdgcn_perm(q1, a1, 0x05040100u); col[3][g] = __builtin_amdgcn_perm(q1, a1, 0x07060302u);
     }
     const uint32_t vl = c_tap_lo[sy], vh = c_tap_hi[sy];
-    _Pragma("unroll") for (int yy = 0; yy < 4; yy++) {
+    _Pragma("unroll") for (int yy = 0; yy < NR; yy++) {
         uint32_t o[4];
+        const int g0 = yy >> 2, sft = yy & 3;
         _Pragma("unroll") for (int j = 0; j < 4; j++) {
-            const uint32_t lo = yy ? alignbyte(col[j][1], col[j][0], yy) : col[j][0], hi = yy ? alignbyte(col[j][2], col[j][1], yy) : col[j][1];
+            const uint32_t lo = sft ? alignbyte(col[j][g0 + 1], col[j][g0], sft) : col[j][g0], hi = sft ? alignbyte(col[j][g0 + 2], col[j][g0 + 1], sft) : col[j][g0 + 1];
             o[j] = finish(__builtin_amdgcn_sdot4((int)hi, (int)vh, __builtin_amdgcn_sdot4((int)lo, (int)vl, 128 * 128 + 64, false), false));
         }
         out[yy] = sy ? pack4(o[0], o[1], o[2], o[3]) : mid[yy + 3];
     }
 }
 
-__global__ __launch_bounds__(192) void svt_mc_kernel(const mc_pic_dev *__restrict__ pics) {
-    const mc_pic_dev &P = pics[blockIdx.z];
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    const int mi_row = blockIdx.y;
-    /* wave 0 / 1: luma tile (unit lane >> 1, tile column lane & 1, tile row = wave); wave 2: Cb (lanes 0..31) | Cr */
-    const int plane  = wave < 2 ? 0 : 1 + (lane >> 5);
-    const int unit   = wave < 2 ? lane >> 1 : lane & 31;
-    const int mi_col = blockIdx.x * 32 + unit;
-    if (mi_row >= P.mi_rows || mi_col >= P.mi_cols) return;
+template <int NR>
+__device__ __forceinline__ void mc_unit(const mc_pic_dev &P, int plane, int mi_row, int mi_col, int x, int y) {
     const uint32_t *mp = (const uint32_t *)(P.mi + (size_t)mi_row * P.mi_stride + mi_col);
     const uint32_t  m0 = mp[0], m1 = mp[1], m2 = mp[2];
     const int       rl0 = (int8_t)(m2 & 0xff), rl1 = (int8_t)((m2 >> 8) & 0xff), bw8 = (int)((m2 >> 16) & 0xff), bh8 = (int)(m2 >> 24);
@@ -117,9 +115,7 @@ __global__ __launch_bounds__(192) void svt_mc_kernel(const mc_pic_dev *__restric
     const int bw = (bw8 * 8) >> ss, bh = (bh8 * 8) >> ss;
     const int spel_left = (4 + bw) << 4, spel_right = spel_left - 16, spel_top = (4 + bh) << 4, spel_bottom = spel_top - 16;
     const int sc = 1 << (1 - ss);
-    /* tile position inside its plane */
-    const int x = plane ? mi_col * 4 : mi_col * 8 + 4 * (lane & 1), y = plane ? mi_row * 4 : mi_row * 8 + 4 * wave;
-    uint32_t  acc[4] = {0, 0, 0, 0};
+    uint32_t  acc[NR];
     const int nref = rl1 >= 0 ? 2 : 1;
     for (int k = 0; k < nref; k++) {
         const svt_yuv_planes &R = P.ref[(k ? rl1 : rl0) ? 1 : 0];
@@ -131,14 +127,32 @@ __global__ __launch_bounds__(192) void svt_mc_kernel(const mc_pic_dev *__restric
         else if (plane) { s_row = (mv_row + 4) & ~7; s_col = (mv_col + 4) & ~7; sx = s_col & 7; sy = s_row & 7; } /* [quirk] vp9_reconinter.c:176-180 */
         else { s_row = (mv_row + 8) & ~15; s_col = (mv_col + 8) & ~15; sx = s_col & 15; sy = s_row & 15; }
         const uint8_t *pl = plane == 0 ? R.y : plane == 1 ? R.u : R.v;
-        uint32_t       o[4];
-        mc_tile(pl, plane ? R.uv_stride : R.y_stride, x, y, s_row, s_col, sx, sy, o);
-        _Pragma("unroll") for (int r = 0; r < 4; r++)
+        uint32_t       o[NR];
+        mc_tile<NR>(pl, plane ? R.uv_stride : R.y_stride, x, y, s_row, s_col, sx, sy, o);
+        _Pragma("unroll") for (int r = 0; r < NR; r++)
             acc[r] = k ? (acc[r] | o[r]) - (((acc[r] ^ o[r]) >> 1) & 0x7f7f7f7fu) : o[r]; /* ROUND_POWER_OF_TWO(dst + p, 1) per byte */
     }
     uint8_t  *dp = plane == 0 ? P.pred.y : plane == 1 ? P.pred.u : P.pred.v;
     const int ds = plane ? P.pred.uv_stride : P.pred.y_stride;
-    _Pragma("unroll") for (int r = 0; r < 4; r++) *(uint32_t *)(dp + (size_t)(y + r) * ds + x) = acc[r];
+    _Pragma("unroll") for (int r = 0; r < NR; r++) *(uint32_t *)(dp + (size_t)(y + r) * ds + x) = acc[r];
+}
+
+__global__ __launch_bounds__(128) void svt_mc_kernel(const mc_pic_dev *__restrict__ pics, int max_rows, int xblocks, int total, int chunk) {
+    /* consecutive workgroup ids go to consecutive XCDs: id b works on item (b & 7) * chunk + (b >> 3), so that XCD k
+     * owns the contiguous items [k * chunk, (k + 1) * chunk) = a band of mode-info rows */
+    const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (item >= total) return;
+    const int xb = item % xblocks, rowpic = item / xblocks, mi_row = rowpic % max_rows;
+    const mc_pic_dev &P = pics[rowpic / max_rows];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    if (mi_row >= P.mi_rows) return;
+    if (wave == 0) { /* luma: unit lane >> 1, tile column lane & 1, 4 x 8 samples */
+        const int mi_col = xb * 32 + (lane >> 1);
+        if (mi_col < P.mi_cols) mc_unit<8>(P, 0, mi_row, mi_col, mi_col * 8 + 4 * (lane & 1), mi_row * 8);
+    } else {         /* Cb (lanes 0..31) | Cr: 4 x 4 samples */
+        const int mi_col = xb * 32 + (lane & 31);
+        if (mi_col < P.mi_cols) mc_unit<4>(P, 1 + (lane >> 5), mi_row, mi_col, mi_col * 4, mi_row * 4);
+    }
 }
 
 int mc_launch(svt_hip_ctx *ctx, int n_pics, const svt_mc_picture *pics) {
@@ -162,7 +176,8 @@ int mc_launch(svt_hip_ctx *ctx, int n_pics, const svt_mc_picture *pics) {
     }
     HIP_TRY(hipMemcpyAsync(d, h, sizeof(mc_pic_dev) * (size_t)n_pics, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
-    hipLaunchKernelGGL(svt_mc_kernel, dim3((max_cols + 31) / 32, max_rows, n_pics), dim3(192), 0, ctx->stream, (const mc_pic_dev *)d);
+    const int xblocks = (max_cols + 31) / 32, total = xblocks * max_rows * n_pics, chunk = (total + 7) / 8;
+    hipLaunchKernelGGL(svt_mc_kernel, dim3(chunk * 8), dim3(128), 0, ctx->stream, (const mc_pic_dev *)d, max_rows, xblocks, total, chunk);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     svt_ctx_stage_commit(ctx);

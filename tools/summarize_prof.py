@@ -13,7 +13,7 @@ prof = os.path.join(root, "profiles")
 
 
 def short(name):
-    for k in ("svt_me_sb_kernel", "svt_tq_kernel", "svt_lf_kernel", "svt_lf_desc_kernel", "svt_pa_plane_kernel", "svt_pa_meanvar_kernel", "svt_me_zz_sad_kernel"):
+    for k in ("svt_me_sb_kernel", "svt_tq_kernel", "svt_lf_kernel", "svt_lf_desc_kernel", "svt_pa_plane_kernel", "svt_pa_meanvar_kernel", "svt_me_zz_sad_kernel", "svt_mc_kernel"):
         if re.search(r"(?<![A-Za-z_0-9])" + k + r"(?![A-Za-z_0-9])", name):
             return k
     return None
