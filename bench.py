@@ -73,7 +73,9 @@ def main():
     lib = B.load()
     # one context per pipeline stage, each on its own torch stream so that torch events can bracket that stage's
     # launches inside the timed region
-    streams = [torch.cuda.Stream(device=local_rank) for _ in range(3)]
+    # ME is the long pole of the step: its stream gets the higher priority so that freed CU slots go to it first
+    prio = [int(x) for x in os.environ.get("SVT_BENCH_PRIO", "-1,0,0").split(",")]
+    streams = [torch.cuda.Stream(device=local_rank, priority=prio[i]) for i in range(3)]
     ctxs = []
     for st_ in streams:
         c_ = C.c_void_p()
