@@ -361,10 +361,25 @@ typedef struct me_ctx_t {
 
 /* copy a w_bytes x rows rectangle from global memory (any alignment) into LDS (dst 4-byte aligned rows) */
 SVT_DEV void ph_load_rect(int tid, uint8_t *dst, int dst_stride, const uint8_t *src, int src_stride, int w_bytes, int rows) {
-    int nd = (w_bytes + 3) >> 2;
-    for (int t = tid; t < nd * rows; t += SVT_NT) {
-        int r = t / nd, i = t - r * nd;
-        *(uint32_t *)(dst + r * dst_stride + 4 * i) = me_ld32u(src + (ptrdiff_t)r * src_stride + 4 * i);
+    /* task = one dword; a thread's (row, dword) pair advances by SVT_NT tasks per step without a division, and the
+     * global loads of 8 steps are all issued before the first LDS store (one memory round trip per 8 steps) */
+    const int nd = (w_bytes + 3) >> 2, n = nd * rows;
+    const int dr = SVT_NT / nd, di = SVT_NT - dr * nd;
+    int       r = tid / nd, i = tid - r * nd;
+    for (int t0 = tid; t0 < n; t0 += 8 * SVT_NT) {
+        uint32_t v[8];
+        int      o[8];
+        _Pragma("unroll") for (int u = 0; u < 8; u++) {
+            o[u] = -1;
+            if (t0 + u * SVT_NT < n) {
+                v[u] = me_ld32u(src + (ptrdiff_t)r * src_stride + 4 * i);
+                o[u] = r * dst_stride + 4 * i;
+            }
+            i += di; r += dr;
+            if (i >= nd) { i -= nd; r++; }
+        }
+        _Pragma("unroll") for (int u = 0; u < 8; u++)
+            if (o[u] >= 0) *(uint32_t *)(dst + o[u]) = v[u];
     }
 }
 
@@ -403,22 +418,28 @@ SVT_DEV void ph_init(const me_ctx_t *c, int tid) {
  * Results accumulate in st->red[k]; caller doubles them. */
 SVT_DEV void ph_center_sads(const me_ctx_t *c, int tid, const svt_plane *ref, int ncand, const int16_t *dx, const int16_t *dy) {
     int rows = c->sb_h >> 1, wd = c->sb_w >> 2; /* dwords per row */
-    int n = rows * wd;
+    int n = rows * wd;                           /* <= 512: two pieces per thread */
     uint32_t acc[5] = {0, 0, 0, 0, 0};
-    /* every thread takes part in the wave reductions below, so the loop bound is rounded up to the block size */
-    for (int t0 = 0; t0 < n; t0 += SVT_NT) {
-        int t = t0 + tid;
+    uint32_t v[2][5], s[2];
+    /* every thread takes part in the wave reductions below; all (independent) global loads of both pieces are issued
+     * before the first use: one memory round trip for the phase */
+    _Pragma("unroll") for (int h = 0; h < 2; h++) {
+        const int t = tid + h * SVT_NT;
+        s[h] = 0;
+        _Pragma("unroll") for (int k = 0; k < 5; k++) v[h][k] = 0;
         if (t < n) {
-            int      r = t / wd, i = t - r * wd;
-            uint32_t s = *(const uint32_t *)(c->src + (2 * r) * ME_SB + 4 * i);
-            uint32_t v[5];
-            /* issue all (independent) global loads before the first use */
+            const int r = t / wd, i = t - r * wd;
+            s[h] = *(const uint32_t *)(c->src + (2 * r) * ME_SB + 4 * i);
             _Pragma("unroll") for (int k = 0; k < 5; k++)
-                if (k < ncand) v[k] = me_ld32u(me_pix(ref, c->sb_x + dx[k] + 4 * i, c->sb_y + dy[k] + 2 * r));
-            _Pragma("unroll") for (int k = 0; k < 5; k++)
-                if (k < ncand) acc[k] = svt_sad4(v[k], s, acc[k]);
+                if (k < ncand) v[h][k] = me_ld32u(me_pix(ref, c->sb_x + dx[k] + 4 * i, c->sb_y + dy[k] + 2 * r));
+                else v[h][k] = s[h];
+        } else {
+            _Pragma("unroll") for (int k = 0; k < 5; k++) v[h][k] = s[h];
         }
     }
+    _Pragma("unroll") for (int h = 0; h < 2; h++)
+        _Pragma("unroll") for (int k = 0; k < 5; k++)
+            if (k < ncand) acc[k] = svt_sad4(v[h][k], s[h], acc[k]);
     _Pragma("unroll") for (int k = 0; k < 5; k++)
         if (k < ncand) svt_wave_add_u32(&c->st->red[k], acc[k], 1);
 }
