@@ -290,8 +290,10 @@ typedef struct me_state_t {
     uint32_t supel[9];         /* su_pel_enable sums: sx,sy,ssad for 32/16/8 */
     uint32_t best_ssd[85];     /* SSD_SEARCH: SSD of the current best sub-pel position of each PU (current list) */
     svt_plane refd[3];         /* descriptors (full, 1/4, 1/16) of the current list's reference picture, copied from HBM once */
-    uint8_t  dir[85];
-    uint8_t  sixteenth_sb[16 * 8];
+    uint8_t  dir[88];          /* 85 used; padded so that the block below stays dword aligned */
+    /* rows 0,2,4.. of the 1/16-resolution SB, read as dwords by the HME search: a misaligned ds_read is replayed at ~64
+     * cycles per wave-instruction (SQ_LDS_UNALIGNED_STALL was 2/3 of all LDS cycles of the kernel before this was aligned) */
+    uint8_t  sixteenth_sb[16 * 8] __attribute__((aligned(16)));
 } me_state_t;
 
 SVT_DEV int16_t me_mvx(uint32_t mv) { return (int16_t)(mv & 0xFFFF); }
@@ -1098,11 +1100,17 @@ SVT_DEV void ph_output(const me_ctx_t *c, int tid, svt_me_pu_result *out, uint32
 #define ME_MARK(i) ((void)0)
 #define ME_SUBMARK_BEGIN() ((void)0)
 #define ME_SUBMARK(i) ((void)0)
+#define ME_STOP_AT(i) ((void)0)
 #else
 /* sub-phase marks (slots 14, 15): informational, not part of the per-phase total */
 #define ME_SUBMARK_BEGIN() unsigned long long sub_t_ = c->prof ? __builtin_amdgcn_s_memtime() : 0
 #define ME_SUBMARK(i) do { if (c->prof && tid == 0) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
         atomicAdd(&c->prof[(i)], now_ - sub_t_); sub_t_ = now_; } } while (0)
+#ifdef ME_FINE_PROF
+#define ME_STOP_AT(i) do { if (g_me_stop_after == (i)) return; } while (0)
+#else
+#define ME_STOP_AT(i) ((void)0)
+#endif
 #ifdef ME_FINE_PROF
 /* instruction-count profiling builds: the kernel stops (all threads) at mark g_me_stop_after of the first list, so
  * that per-dispatch SQ counters of successive launches give cumulative instruction counts per phase */
@@ -1520,6 +1528,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                 for (int lvl = 0; lvl < 3; lvl++) {
                     if (!(lvl == 0 ? p->enable_hme_level_0_flag : lvl == 1 ? p->enable_hme_level_1_flag : p->enable_hme_level_2_flag)) continue;
                     ME_UNIFORM_WRITE(me_hme_plan_level(c, list, lvl, xsc, ysc, first));
+                    ME_STOP_AT(19);
                     first = 0;
                     me_hme_geom g;
                     me_hme_geom_of(c, list, lvl, &g);
@@ -1535,8 +1544,10 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                         ME_SUBMARK_BEGIN();
                         ME_PHASE(ph_hme_load_multi(c, tid, g.ref, st->hme_win, e0, e1, ntl));
                         ME_SUBMARK(14);
+                        ME_STOP_AT(20);
                         ME_PHASE(ph_hme_search_multi(c, tid, g.blk, g.bstride, g.bw, g.bh, st->hme_win, e0, e1, nts, st->hme_keys, slot_mask));
                         ME_SUBMARK(15);
+                        ME_STOP_AT(21);
                     }
                     ME_UNIFORM_WRITE(me_hme_finish_level(c, lvl); if (lvl == last_lvl) me_hme_select(c, list));
                 }
