@@ -238,7 +238,7 @@ typedef struct me_lds_layout {
     int32_t off_planes;  /* B, H, J half-pel planes (3 x plane_bytes); aliased by HME window / SAD scratch */
     int32_t off_quarter; /* 32x32 quarter-resolution SB (only when HME level 1 is enabled) */
     int32_t off_ssd;     /* SSD_SEARCH only: candidate SSDs [85][9] */
-    int32_t off_pred0;   /* list 0 prediction of the bi-pred lanes: levels * K * 256 dwords */
+    int32_t off_pred0;   /* host emulation only (the kernel keeps them in registers): list 0 prediction of the bi-pred lanes */
     int32_t region_stride, region_rows;
     int32_t plane_stride; /* row stride of the half-pel planes: they are narrower than the region (no search tail) */
     int32_t plane_bytes;
@@ -352,7 +352,7 @@ typedef struct me_ctx_t {
     uint8_t             *planes; /* LDS */
     uint8_t             *quarter_sb; /* LDS, valid when HME level 1 is enabled */
     uint32_t            *ssdc;       /* LDS, SSD_SEARCH only: SSD of the sub-pel candidates [pu][9] (8 = integer position) */
-    uint32_t            *pred0;  /* LDS: list 0 prediction dwords of the bi-pred lanes */
+    uint32_t            *pred0;  /* host emulation only: list 0 prediction dwords of the bi-pred lanes [16][256] */
     int                  pic_w, pic_h, sb_x, sb_y, sb_w, sb_h, sb_index;
     unsigned long long  *prof;   /* optional per-phase cycle accumulators (profiling builds), else NULL */
 } me_ctx_t;
@@ -1009,11 +1009,18 @@ SVT_DEV int me_bipred_levels(const me_ctx_t *c) { return c->p->cu16x16_mode != 0
 
 /* Bi-pred work split: level L (0 = 64x64 ... 3 = 8x8) has 4^L PUs of (1024 >> 2L) dwords; 256 >> 2L consecutive lanes
  * own one PU and each lane handles K dwords of it (K = 4, or 2 with SUB_SAD where only even rows count).  A lane meets
- * the same (level, k) dwords again when list 1 is searched: list 0's dword of (level, k, thread) waits in
- * pred0[(L*K + k)*256 + tid]. */
+ * the same (level, k) dwords again when list 1 is searched: list 0's dword of (level, k) waits in the lane's own
+ * registers pr[4 L + k] (at most 16; every index is a compile-time constant after unrolling).  The serial host
+ * emulation keeps them in memory instead: ME_PR(j) = pred0[j * 256 + tid]. */
+#ifdef SVT_HOST_EMU
+#define ME_PR(j) pr[(j) * SVT_NT]
+#else
+#define ME_PR(j) pr[(j)]
+#endif
 SVT_DEV void ph_store_pred0(const me_ctx_t *c, int tid, int sox, int soy, uint32_t *pr) {
     const int sub = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH, K = sub ? 2 : 4, levels = me_bipred_levels(c);
-    for (int L = 0; L < levels; L++) {
+    _Pragma("unroll") for (int L = 0; L < 4; L++) {
+        if (L >= levels) break;
         const int sh = 8 - 2 * L, l = tid & ((1 << sh) - 1), pu = (int)((0x15050100u >> (8 * L)) & 0xff) + (tid >> sh);
         int       px, py, w;
         me_pu_geom(pu, &px, &py, &w);
@@ -1023,7 +1030,7 @@ SVT_DEV void ph_store_pred0(const me_ctx_t *c, int tid, int sox, int soy, uint32
         _Pragma("unroll") for (int k = 0; k < 4; k++) {
             if (k < K) {
                 int d = l + (k << sh), r = (d >> (4 - L)) << sub, i = d & ((16 >> L) - 1);
-                pr[(L * K + k) * SVT_NT] = me_pred_fetch(a, b, ME_MUL(r, sa) + 4 * i, ME_MUL(r, sb) + 4 * i);
+                ME_PR(4 * L + k) = me_pred_fetch(a, b, ME_MUL(r, sa) + 4 * i, ME_MUL(r, sb) + 4 * i);
             }
         }
         SVT_SCHED_FENCE();
@@ -1032,7 +1039,8 @@ SVT_DEV void ph_store_pred0(const me_ctx_t *c, int tid, int sox, int soy, uint32
 /* bi-pred distortion: avg-SAD of (list0 pred, list1 pred) vs source (bi_pred_averging :3466-3560) */
 SVT_DEV void ph_bipred(const me_ctx_t *c, int tid, int sox, int soy, const uint32_t *pr) {
     const int sub = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH, K = sub ? 2 : 4, levels = me_bipred_levels(c);
-    for (int L = 0; L < levels; L++) {
+    _Pragma("unroll") for (int L = 0; L < 4; L++) {
+        if (L >= levels) break;
         const int sh = 8 - 2 * L, l = tid & ((1 << sh) - 1), pu = (int)((0x15050100u >> (8 * L)) & 0xff) + (tid >> sh);
         int       px, py, w;
         me_pu_geom(pu, &px, &py, &w);
@@ -1044,7 +1052,7 @@ SVT_DEV void ph_bipred(const me_ctx_t *c, int tid, int sox, int soy, const uint3
             if (k < K) {
                 int      d = l + (k << sh), r = (d >> (4 - L)) << sub, i = d & ((16 >> L) - 1);
                 uint32_t s  = *(const uint32_t *)(c->src + (py + r) * ME_SB + px + 4 * i);
-                uint32_t va = pr[(L * K + k) * SVT_NT], vb = me_pred_fetch(a, b, ME_MUL(r, sa) + 4 * i, ME_MUL(r, sb) + 4 * i);
+                uint32_t va = ME_PR(4 * L + k), vb = me_pred_fetch(a, b, ME_MUL(r, sa) + 4 * i, ME_MUL(r, sb) + 4 * i);
                 uint32_t av = (va | vb) - (((va ^ vb) >> 1) & 0x7f7f7f7fu);
                 dsum = svt_sad4(av, s, dsum);
             }
@@ -1464,7 +1472,12 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
     me_state_t          *st = c->st;
     const int            nlist = p->num_ref_lists;
     const int            NW = p->number_hme_search_region_in_width, NH = p->number_hme_search_region_in_height;
+#ifdef SVT_HOST_EMU
 #define ME_PRED0_REGS (c->pred0 + tid)
+#else
+    uint32_t pred0_regs[16]; /* list 0 prediction dwords of this lane's bi-pred work, see ph_store_pred0 */
+#define ME_PRED0_REGS pred0_regs
+#endif
     int16_t  xsc = 0, ysc = 0;
 #ifndef SVT_HOST_EMU
     unsigned long long mark_t_ = c->prof ? __builtin_amdgcn_s_memtime() : 0;

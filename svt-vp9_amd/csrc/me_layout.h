@@ -30,8 +30,9 @@ static inline int me_lds_layout_compute(const svt_me_params *p, me_lds_layout *L
     L->off_quarter   = off; if (p->enable_hme_level_1_flag) off += 32 * 32;
     L->off_ssd       = off; if (p->fractional_search_method == SVT_SSD_SEARCH) off += me_round_up(85 * 9 * 4, 16);
     L->off_pred0     = off;
-    if (p->num_ref_lists == 2) /* [level][k][thread] dwords, k < K = 2 (SUB_SAD: even rows only) or 4 */
-        off += (p->fractional_search_method == SVT_SUB_SAD_SEARCH ? 2048 : 4096) * (p->cu16x16_mode != 0 ? 2 : p->cu8x8_mode != 0 ? 3 : 4);
+#ifdef SVT_HOST_EMU /* the kernel keeps list 0's prediction dwords in registers */
+    if (p->num_ref_lists == 2) off += 16 * 256 * 4;
+#endif
     L->total_bytes = off;
     {   /* HME level-0 search area multipliers, Codec/EbDefinitions.h:989-1005, indexed [hierarchical_levels][temporal_layer] */
         static const int32_t mult_tab[6][6] = {{100, 0, 0, 0, 0, 0},       {100, 100, 0, 0, 0, 0},
