@@ -446,6 +446,21 @@ SVT_DEV void ph_center_sads(const me_ctx_t *c, int tid, const svt_plane *ref, in
         if (k < ncand) svt_wave_add_u32(&c->st->red[k], acc[k], 1);
 }
 
+/* the same row-subsampled SAD for ONE displaced block that already sits in the LDS search region (region byte
+ * (col, row) = its top-left sample); result accumulates in st->red[1] */
+SVT_DEV void ph_region_center_sad(const me_ctx_t *c, int tid, int col, int row) {
+    const int rows = c->sb_h >> 1, wd = c->sb_w >> 2, n = rows * wd, rs = c->L.region_stride;
+    uint32_t  acc = 0;
+    _Pragma("unroll") for (int h = 0; h < 2; h++) {
+        const int t = tid + h * SVT_NT;
+        if (t < n) {
+            const int r = t / wd, i = t - r * wd;
+            acc = svt_sad4(me_ld32u(c->region + ME_MUL(row + 2 * r, rs) + col + 4 * i), *(const uint32_t *)(c->src + (2 * r) * ME_SB + 4 * i), acc);
+        }
+    }
+    svt_wave_add_u32(&c->st->red[1], acc, 1);
+}
+
 /* Generic exhaustive SAD search (= eb_vp9_sad_loop_kernel) over a window staged in LDS.
  * blk: block rows (already subsampled) in LDS, stride bstride, bw x bh.  win: LDS window whose row r holds
  * reference row (window_top + r) and column 0 = search x position 0; a search row y uses window rows
@@ -1491,6 +1506,8 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         ME_PHASE(if (tid < (int)(3 * sizeof(svt_plane) / 4)) ((uint32_t *)st->refd)[tid] = ((const uint32_t *)&c->pic->ref[list])[tid]);
         const svt_plane *rf = &st->refd[0];
         const int        ox = (int16_t)c->sb_x, oy = (int16_t)c->sb_y;
+        uint64_t         zero_c = 0; /* 2 * SAD of the block at (0, 0) of this list, when test_search_area_bounds ran */
+        int              have_zero = 0;
         if (p->temporal_layer_index > 0 || list == 0) {
             /* ---- test_search_area_bounds ---- */
             {
@@ -1512,7 +1529,8 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                 }
                 ME_PHASE(if (tid < 8) st->red[tid] = 0);
                 ME_PHASE(ph_center_sads(c, tid, rf, nc, dx, dy));
-                uint64_t zero_c = (uint64_t)(uint32_t)ME_UNI(st->red[0]) << 1, b_c = (uint64_t)(uint32_t)ME_UNI(st->red[1]) << 1,
+                zero_c = (uint64_t)(uint32_t)ME_UNI(st->red[0]) << 1; have_zero = 1;
+                uint64_t b_c = (uint64_t)(uint32_t)ME_UNI(st->red[1]) << 1,
                          c_c = (uint64_t)(uint32_t)ME_UNI(st->red[2]) << 1, d_c = (uint64_t)(uint32_t)ME_UNI(st->red[3]) << 1;
                 uint64_t a_c = zero_c; /* [quirk] A is evaluated at the zero-MV address (:4302-4327) */
                 uint64_t dir_c = list == 1 ? (uint64_t)(uint32_t)ME_UNI(st->red[4]) << 1 : 0xFFFFFFFFFFFFFull;
@@ -1573,32 +1591,59 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
 
         int16_t saw = (int16_t)(p->search_area_width < 127 ? p->search_area_width : 127);
         int16_t sah = (int16_t)(p->search_area_height < 127 ? p->search_area_height : 127);
+        int16_t sox, soy;
+        int     W, H, w8, tail_extra, loaded = 0;
+        /* search area of a centre: position, clipping, derived sizes (Codec/EbMotionEstimation.c:5008-5060) */
+#define ME_SET_AREA()                                                                                               \
+    do {                                                                                                            \
+        saw = (int16_t)(p->search_area_width < 127 ? p->search_area_width : 127);                                    \
+        sah = (int16_t)(p->search_area_height < 127 ? p->search_area_height : 127);                                  \
+        sox = (int16_t)(xsc - (saw >> 1)); soy = (int16_t)(ysc - (sah >> 1));                                        \
+        me_clip_area(ox, &sox, &saw, ME_SB - 1, c->pic_w);                                                           \
+        me_clip_area(oy, &soy, &sah, ME_SB - 1, c->pic_h);                                                           \
+        W = saw + ME_SB - 1; H = sah + ME_SB - 1; w8 = saw - (saw & 7); tail_extra = (saw & 7) ? 16 : 0;             \
+    } while (0)
+        /* stage the search region (+ halo) of this list in LDS; the full-pel keys are reset on the way */
+#define ME_LOAD_REGION()                                                                                            \
+    ME_PHASE(ph_load_rect(tid, c->region, c->L.region_stride, me_pix(rf, c->sb_x + sox - ME_RGN_GX, c->sb_y + soy - ME_RGN_GY), \
+                          rf->stride, W + ME_RGN_GX + 4 + tail_extra, H + 2 * ME_RGN_GY + 1);                        \
+             for (int t = tid; t < 85; t += SVT_NT) st->key[t] = ((uint64_t)ME_MAX_SAD_VALUE << 32);                  \
+             if (tid < 8) st->red[tid] = 0)
         if (xsc != 0 || ysc != 0) {
-            /* ---- check_zero_zero_center ---- */
-            int16_t dx[2], dy[2];
+            /* ---- check_zero_zero_center (:4420-4500): the centre found above against (0, 0).  The SAD at (0, 0) is the
+             * one test_search_area_bounds already computed for this list (same function, same block); the SAD at the
+             * centre is taken from the search region, which is staged around that centre first -- when the centre
+             * wins (the usual case) the region is already in place and no separate global pass is needed ---- */
             xsc = me_clip_center(ox, xsc, ME_SB - 1, rf->width);
             ysc = me_clip_center(oy, ysc, ME_SB - 1, rf->height);
-            dx[0] = 0; dy[0] = 0; dx[1] = xsc; dy[1] = ysc;
-            ME_PHASE(if (tid < 8) st->red[tid] = 0);
-            ME_PHASE(ph_center_sads(c, tid, rf, 2, dx, dy));
-            uint64_t z = (uint64_t)(uint32_t)ME_UNI(st->red[0]) << 1, h = (uint64_t)(uint32_t)ME_UNI(st->red[1]) << 1;
+            ME_SET_AREA();
+            const int col = ME_RGN_GX + (xsc - sox), row = ME_RGN_GY + (ysc - soy);
+            const int inside = have_zero && col >= 0 && row >= 0 && col + c->sb_w <= W + ME_RGN_GX + 4 + tail_extra &&
+                               row + c->sb_h <= H + 2 * ME_RGN_GY + 1;
+            uint64_t z, h;
+            if (inside) {
+                ME_LOAD_REGION();
+                ME_PHASE(ph_region_center_sad(c, tid, col, row));
+                z = zero_c; h = (uint64_t)(uint32_t)ME_UNI(st->red[1]) << 1;
+                loaded = 1;
+            } else {
+                int16_t dx[2], dy[2];
+                dx[0] = 0; dy[0] = 0; dx[1] = xsc; dy[1] = ysc;
+                ME_PHASE(if (tid < 8) st->red[tid] = 0);
+                ME_PHASE(ph_center_sads(c, tid, rf, 2, dx, dy));
+                z = (uint64_t)(uint32_t)ME_UNI(st->red[0]) << 1; h = (uint64_t)(uint32_t)ME_UNI(st->red[1]) << 1;
+            }
             uint64_t m = z < h ? z : h;
-            if (m == z) { xsc = 0; ysc = 0; }
+            if (m == z) { xsc = 0; ysc = 0; loaded = 0; }
             ME_PHASE((void)0);
         }
         ME_MARK(3);
-        int16_t sox = (int16_t)(xsc - (saw >> 1)), soy = (int16_t)(ysc - (sah >> 1));
-        me_clip_area(ox, &sox, &saw, ME_SB - 1, c->pic_w);
-        me_clip_area(oy, &soy, &sah, ME_SB - 1, c->pic_h);
-        const int W = saw + ME_SB - 1, H = sah + ME_SB - 1;
-        const int w8 = saw - (saw & 7);
-        const int tail_extra = (saw & 7) ? 16 : 0;
-
-        /* ---- stage the search region (+ halo) of this list in LDS ---- */
-        ME_PHASE(ph_load_rect(tid, c->region, c->L.region_stride, me_pix(rf, c->sb_x + sox - ME_RGN_GX, c->sb_y + soy - ME_RGN_GY),
-                              rf->stride, W + ME_RGN_GX + 4 + tail_extra, H + 2 * ME_RGN_GY + 1);
-                 for (int t = tid; t < 85; t += SVT_NT) st->key[t] = ((uint64_t)ME_MAX_SAD_VALUE << 32);
-                 );
+        if (!loaded) {
+            ME_SET_AREA();
+            ME_LOAD_REGION();
+        }
+#undef ME_SET_AREA
+#undef ME_LOAD_REGION
 
         ME_MARK(4);
         /* ---- full-pel search, in chunks of search rows ---- */
