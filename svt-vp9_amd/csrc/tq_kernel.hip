@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 4
                                                      const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,
                                                      int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out,
                                                      uint64_t *__restrict__ dist_out) {
-    constexpr int BPW = 256 / N;          /* blocks per workgroup */
+    constexpr int BPW = (N == 32 ? 128 : 256) / N; /* blocks per workgroup (32x32: 4 blocks = 17 KB of LDS, small enough to
+                                                      share a CU with four ME workgroups) */
     constexpr int LS  = N + 1;            /* padded LDS row stride in dwords */
     __shared__ int32_t tile[BPW][N * LS];
     const int lb  = threadIdx.x / N;      /* block slot inside the workgroup */
@@ -292,8 +293,8 @@ template <int N>
 int launch_tq(svt_hip_ctx *ctx, const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks, int n,
               const svt_quant_tables *q, const int16_t *iscan, int16_t *qc, int16_t *dqc, uint16_t *eob, uint64_t *dist) {
     if (n <= 0) return 0;
-    constexpr int BPW = 256 / N;
-    hipLaunchKernelGGL(svt_tq_kernel<N>, dim3((n + BPW - 1) / BPW), dim3(256), 0, ctx->stream, src, pred, recon, blocks, n, q, iscan,
+    constexpr int NT = N == 32 ? 128 : 256, BPW = NT / N;
+    hipLaunchKernelGGL(svt_tq_kernel<N>, dim3((n + BPW - 1) / BPW), dim3(NT), 0, ctx->stream, src, pred, recon, blocks, n, q, iscan,
                        qc, dqc, eob, dist);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

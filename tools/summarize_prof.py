@@ -34,23 +34,25 @@ def pmc(sub, prefix):
 fetch, nf = pmc("fetch", "f")
 write, nw = pmc("write", "w")
 sq, ns = pmc("sq", "s")
+REPS = {"svt_pa_plane_kernel": 4, "svt_mc_kernel": 4}  # bench.py times these stages in 4 repetitions of their own, once per run
 traffic = {"_comment": "HBM traffic per 16-picture step from rocprofv3 PMC passes on MI355X (tools/profile_round.sh, "
                        "tools/summarize_prof.py): bytes = 1024 * (2 x FETCH_SIZE + WRITE_SIZE)"}
 print("| kernel | launches/step | FETCH_SIZE raw (KiB) | WRITE_SIZE (KiB) | traffic (MB) |")
 print("|---|---|---|---|---|")
 for k in sorted(set(fetch) | set(write)):
-    fk, wk = fetch[k].get("FETCH_SIZE", 0.0), write[k].get("WRITE_SIZE", 0.0)
+    rep = REPS.get(k, 1)
+    fk, wk = fetch[k].get("FETCH_SIZE", 0.0) / rep, write[k].get("WRITE_SIZE", 0.0) / rep
     b = int(1024 * (2 * fk + wk))
     traffic[k] = {"fetch_size_kb_raw_per_step": round(fk), "write_size_kb_per_step": round(wk), "bytes_per_step": b,
-                  "launches_per_step": nf[(k, "FETCH_SIZE")]}
-    print(f"| {k} | {nf[(k, 'FETCH_SIZE')]} | {fk:.0f} | {wk:.0f} | {b / 1e6:.1f} |")
+                  "launches_per_step": nf[(k, "FETCH_SIZE")] // rep}
+    print(f"| {k} | {nf[(k, 'FETCH_SIZE')] // rep} | {fk:.0f} | {wk:.0f} | {b / 1e6:.1f} |")
 json.dump(traffic, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
 for k, v in sq.items():
     print("SQ", k, {c: f"{x:.4g}" for c, x in v.items()})
 for name in ("kernel_stats", "domain_stats"):
     src = glob.glob(os.path.join(out, f"prof_{tag}", "**", f"{tag}_{name}.csv"), recursive=True)
     if src:
-        shutil.copy(src[0], os.path.join(prof, f"{tag}_{name}.csv"))
+        shutil.copy(src[0], os.path.join(prof, f"{tag[:3]}_{name}.csv"))  # profiles are named per round: r01_*
 src = glob.glob(os.path.join(out, f"prof_{tag}", "**", f"{tag}_kernel_stats.csv"), recursive=True)
 if src:
     print("\n| kernel | calls | avg (us) | total (ms) |\n|---|---|---|---|")
