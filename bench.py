@@ -76,6 +76,12 @@ def main():
     # ME is the long pole of the step: its stream gets the higher priority so that freed CU slots go to it first
     prio = [int(x) for x in os.environ.get("SVT_BENCH_PRIO", "-1,0,0").split(",")]
     streams = [torch.cuda.Stream(device=local_rank, priority=prio[i]) for i in range(3)]
+    # ME of different pictures is independent (it references source pictures, not reconstructions): the launch of the
+    # deepest temporal layer and the launches of the other layers go to two ME streams so that the tail of one launch
+    # is filled by the other
+    n_me_streams = max(1, int(os.environ.get("SVT_BENCH_ME_STREAMS", "2")))
+    for _ in range(n_me_streams - 1):
+        streams.append(torch.cuda.Stream(device=local_rank, priority=prio[0]))
     ctxs = []
     for st_ in streams:
         c_ = C.c_void_p()
@@ -127,7 +133,8 @@ def main():
         return i - span, i + span
 
     # ---- stage 1: motion estimation, one batched launch per temporal layer (parameters differ per layer) ----
-    ctx_me, ctx_tq, ctx_lf = ctxs
+    ctx_me, ctx_tq, ctx_lf = ctxs[:3]
+    me_ctxs = [ctx_me] + ctxs[3:]
     me_launches = []
     for layer in range(5):
         idx = [i for i in range(1, MINIGOP + 1) if LAYER[i - 1] == layer]
@@ -139,6 +146,12 @@ def main():
         r1 = (B.PaPicture * n)(*[pics[refs(i)[1]].desc() for i in idx])
         res = (C.c_void_p * n)(*[results[i].data_ptr() for i in idx])
         me_launches.append((n, cur, r0, r1, p, res))
+    # launches -> ME streams: largest first onto the least loaded stream
+    me_slot, load = [0] * len(me_launches), [0] * len(me_ctxs)
+    for li in sorted(range(len(me_launches)), key=lambda j: -me_launches[j][0]):
+        k_ = load.index(min(load))
+        me_slot[li] = k_
+        load[k_] += me_launches[li][0]
 
     # ---- stage 2: transform / quantisation / reconstruction of the encode pass: every sample of the 4:2:0 picture
     # is covered by exactly one transform block (sizes 4x4..32x32 mixed per 32x32 area, DCT/ADST types mixed) ----
@@ -224,8 +237,12 @@ def main():
     lfs, mrs, mcs = i32(lfm.shape[1]), i32(mi_rows), i32(mi_cols)
 
     def run_me():
-        for n, cur, r0, r1, p, res in me_launches:
-            B.check(lib.svt_hip_me_batch_device(ctx_me, n, cur, r0, r1, C.byref(p), res, None))
+        for st_ in streams[3:]:
+            st_.wait_stream(streams[0])
+        for li, (n, cur, r0, r1, p, res) in enumerate(me_launches):
+            B.check(lib.svt_hip_me_batch_device(me_ctxs[me_slot[li]], n, cur, r0, r1, C.byref(p), res, None))
+        for st_ in streams[3:]:
+            streams[0].wait_stream(st_)
 
     def run_tq():
         B.check(lib.svt_hip_tq_batch_device(ctx_tq, C.c_void_p(d_src.data_ptr()), C.c_void_p(d_pred.data_ptr()), C.c_void_p(d_rec.data_ptr()),
@@ -260,7 +277,7 @@ def main():
             staged(2, run_lf, record)
 
     def sync():
-        for c_ in (ctx_me, ctx_tq, ctx_lf):
+        for c_ in ctxs:
             B.check(lib.svt_hip_ctx_synchronize(c_))
         torch.cuda.synchronize()
 
@@ -416,7 +433,7 @@ def main():
                                          f"{n_me} B pictures (mini-GOP positions {used}) {t_me / n_me:.2f} s/picture, transform/quant/"
                                          f"recon of 1 picture {t_tq:.2f} s, deblocking of 1 picture {t_lf:.2f} s"}
     print(json.dumps(out))
-    for c_ in (ctx_me, ctx_tq, ctx_lf):
+    for c_ in ctxs:
         lib.svt_hip_ctx_destroy(c_)
 
 

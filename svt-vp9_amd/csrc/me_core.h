@@ -340,6 +340,29 @@ SVT_DEV int16_t me_clip_center(int origin, int16_t c, int pad, int pic_dim) {
     return c;
 }
 
+/* A rectangle of global memory whose rows all start at the same byte alignment (row stride a multiple of 4): one
+ * uniform dword-aligned base (scalar registers -> the loads use the scalar-base addressing form and a 32-bit lane
+ * offset, no 64-bit address arithmetic per lane) and one uniform byte shift.  ok = 0: the stride breaks the
+ * assumption, callers fall back to me_ld32u on per-lane pointers. */
+typedef struct me_gsrc { const uint8_t *lo, *hi; uint32_t sh; int ok; } me_gsrc;
+SVT_DEV me_gsrc me_gsrc_of(const uint8_t *p, int stride) {
+    me_gsrc   g;
+    uintptr_t a = (uintptr_t)p;
+    uint32_t  sh = (uint32_t)(a & 3);
+    a -= sh;
+#ifndef SVT_HOST_EMU
+    a  = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    sh = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh);
+#endif
+    g.lo = (const uint8_t *)a; g.hi = g.lo + (sh ? 4 : 0); /* an aligned rectangle re-reads its own dword: nothing beyond it is touched */
+    g.sh = sh; g.ok = (stride & 3) == 0;
+    return g;
+}
+/* the 4 bytes at byte offset off (a multiple of 4 plus whole rows) of the rectangle */
+SVT_DEV uint32_t me_gld(const me_gsrc g, uint32_t off) {
+    return svt_alignbyte(*(const uint32_t *)(g.hi + off), *(const uint32_t *)(g.lo + off), g.sh);
+}
+
 /* everything a phase needs */
 typedef struct me_ctx_t {
     const me_pic_dev    *pic;
@@ -368,13 +391,14 @@ SVT_DEV void ph_load_rect(int tid, uint8_t *dst, int dst_stride, const uint8_t *
     const int nd = (w_bytes + 3) >> 2, n = nd * rows;
     const int dr = SVT_NT / nd, di = SVT_NT - dr * nd;
     int       r = tid / nd, i = tid - r * nd;
+    const me_gsrc g = me_gsrc_of(src, src_stride);
     for (int t0 = tid; t0 < n; t0 += 8 * SVT_NT) {
         uint32_t v[8];
         int      o[8];
         _Pragma("unroll") for (int u = 0; u < 8; u++) {
             o[u] = -1;
             if (t0 + u * SVT_NT < n) {
-                v[u] = me_ld32u(src + (ptrdiff_t)r * src_stride + 4 * i);
+                v[u] = g.ok ? me_gld(g, (uint32_t)(ME_MUL(r, src_stride) + 4 * i)) : me_ld32u(src + (ptrdiff_t)r * src_stride + 4 * i);
                 o[u] = r * dst_stride + 4 * i;
             }
             i += di; r += dr;
@@ -423,6 +447,10 @@ SVT_DEV void ph_center_sads(const me_ctx_t *c, int tid, const svt_plane *ref, in
     int n = rows * wd;                           /* <= 512: two pieces per thread */
     uint32_t acc[5] = {0, 0, 0, 0, 0};
     uint32_t v[2][5], s[2];
+    me_gsrc  g[5];
+    _Pragma("unroll") for (int k = 0; k < 5; k++)
+        g[k] = me_gsrc_of(me_pix(ref, c->sb_x + dx[k < ncand ? k : 0], c->sb_y + dy[k < ncand ? k : 0]), ref->stride);
+    const int rstride = ref->stride;
     /* every thread takes part in the wave reductions below; all (independent) global loads of both pieces are issued
      * before the first use: one memory round trip for the phase */
     _Pragma("unroll") for (int h = 0; h < 2; h++) {
@@ -433,7 +461,8 @@ SVT_DEV void ph_center_sads(const me_ctx_t *c, int tid, const svt_plane *ref, in
             const int r = t / wd, i = t - r * wd;
             s[h] = *(const uint32_t *)(c->src + (2 * r) * ME_SB + 4 * i);
             _Pragma("unroll") for (int k = 0; k < 5; k++)
-                if (k < ncand) v[h][k] = me_ld32u(me_pix(ref, c->sb_x + dx[k] + 4 * i, c->sb_y + dy[k] + 2 * r));
+                if (k < ncand) v[h][k] = g[k].ok ? me_gld(g[k], (uint32_t)(ME_MUL(2 * r, rstride) + 4 * i))
+                                                 : me_ld32u(me_pix(ref, c->sb_x + dx[k] + 4 * i, c->sb_y + dy[k] + 2 * r));
                 else v[h][k] = s[h];
         } else {
             _Pragma("unroll") for (int k = 0; k < 5; k++) v[h][k] = s[h];
