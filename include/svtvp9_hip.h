@@ -434,6 +434,47 @@ int32_t svt_hip_inter_pred_frame(svt_hip_ctx *ctx, const svt_mc_mode_info *mi, i
                                  int32_t mi_cols, const svt_mc_host_ref ref[2], int32_t use_subpel, uint8_t *pred_y,
                                  uint8_t *pred_u, uint8_t *pred_v);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Coefficient rate estimation -- SURVEY 8(f) row 4 (with T3, svt_hip_tq_batch_dist_device, this completes what
+ * perform_dist_rate_calc computes per transform block, Codec/EbEncDecProcess.c:700-745).
+ *
+ * Replaces coeff_rate_estimate (Codec/EbRateDistortionCost.c:55-172, libvpx's cost_coeffs) with
+ * use_fast_coef_costing = 0, the only way the reference calls it (:736-745): the bits (scaled by 2^9, vp9_cost.h) of
+ * the tokens of one quantised transform block under the frame's coefficient probabilities.
+ * Tables are the reference's own, handed over by the caller the way the scan tables are for TQ:
+ *   token_costs   = x->token_costs (VPX/vp9_block.h:140, filled by fill_token_costs, VPX/vp9_rd.c:93-107)
+ *   value_cost    = eb_vp9_dct_cat_lt_10_value_cost[v], v = -66 .. 66, stored at index v + 66 (VPX/vp9_tokenize.c:52)
+ *   cat6_low_cost = eb_vp9_cat6_low_cost[256], cat6_high_cost = eb_vp9_cat6_high_cost[64] (VPX/vp9_tokenize.c:82, 97)
+ * and per (tx_size, tx_type) the scan order's `scan` (n entries) followed by its `neighbors` (2 (n + 1) entries)
+ * (VPX/vp9_scan.c), concatenated in one int16 array; a block names its table by element offset (scan_off). */
+typedef struct svt_rate_tables {
+    uint32_t token_costs[4][2][2][6][2][6][12]; /* [tx_size][plane_type][is_inter][band][prev token == 0][ctx][token] */
+    int32_t  value_cost[133];
+    uint16_t cat6_low_cost[256];
+    uint16_t cat6_high_cost[64];
+    uint16_t pad_[2];
+} svt_rate_tables;                            /* 56472 bytes */
+
+typedef struct svt_rate_block {
+    uint32_t coeff_off;  /* element offset of the block's n*n quantised coefficients (raster) in d_qcoeff */
+    uint32_t scan_off;   /* element offset of {scan[n], neighbors[2 (n + 1)]} of the block's scan order */
+    uint16_t eob;
+    uint8_t  tx_size;    /* SVT_TX_* */
+    uint8_t  plane_type; /* 0 luma, 1 chroma (get_plane_type) */
+    uint8_t  is_inter;   /* is_inter_block(mi) */
+    uint8_t  ctx;        /* combine_entropy_contexts(left, above): 0..2 (EbEncDecProcess.c:734) */
+    uint8_t  pad_[2];
+} svt_rate_block;        /* 16 bytes */
+
+/* d_bits[b] = coeff_rate_estimate(...) of block b.  Device pointers; blocks in any order. */
+int32_t svt_hip_coeff_rate_batch_device(svt_hip_ctx *ctx, const int16_t *d_qcoeff, const svt_rate_block *d_blocks,
+                                        int32_t n_blocks, const svt_rate_tables *d_tables, const int16_t *d_scan,
+                                        int32_t *d_bits);
+/* Host-pointer convenience form. */
+int32_t svt_hip_coeff_rate_batch(svt_hip_ctx *ctx, const int16_t *qcoeff, size_t coeff_count, const svt_rate_block *blocks,
+                                 int32_t n_blocks, const svt_rate_tables *tables, const int16_t *scan, size_t scan_count,
+                                 int32_t *bits);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,4 +49,7 @@ int32_t svt_oracle_pa_mean_variance(const svt_plane *full, uint8_t *mean_out, ui
 int32_t svt_oracle_inter_pred_frame(const svt_mc_mode_info *mi, int32_t mi_stride, int32_t mi_rows, int32_t mi_cols,
                                     const svt_mc_host_ref ref[2], int32_t use_subpel, uint8_t *pred_y, uint8_t *pred_u,
                                     uint8_t *pred_v);
+/* coefficient rate estimation (Codec/EbRateDistortionCost.c:55-172) */
+int32_t svt_oracle_coeff_rate_batch(const int16_t *qcoeff, const svt_rate_block *blocks, int32_t n_blocks, const svt_rate_tables *t,
+                                    const int16_t *scan_all, int32_t *bits);
 #endif

@@ -88,6 +88,14 @@ MC_MODE_INFO_DTYPE = np.dtype([("mv_row", "<i2", (2,)), ("mv_col", "<i2", (2,)),
 assert MC_MODE_INFO_DTYPE.itemsize == 12
 
 
+RATE_BLOCK_DTYPE = np.dtype([("coeff_off", "<u4"), ("scan_off", "<u4"), ("eob", "<u2"), ("tx_size", "u1"), ("plane_type", "u1"),
+                             ("is_inter", "u1"), ("ctx", "u1"), ("pad", "u1", (2,))])
+assert RATE_BLOCK_DTYPE.itemsize == 16
+RATE_TABLES_DTYPE = np.dtype([("token_costs", "<u4", (4, 2, 2, 6, 2, 6, 12)), ("value_cost", "<i4", (133,)), ("cat6_low_cost", "<u2", (256,)),
+                              ("cat6_high_cost", "<u2", (64,)), ("pad", "<u2", (2,))])
+assert RATE_TABLES_DTYPE.itemsize == 56472, RATE_TABLES_DTYPE.itemsize
+
+
 class LfThresh(C.Structure):
     _fields_ = [("mblim", C.c_uint8 * 64), ("lim", C.c_uint8 * 64), ("hev_thr", C.c_uint8 * 64)]
 
@@ -115,7 +123,7 @@ EXPORTS = [
     "svt_hip_me_zz_sad_device", "svt_hip_me_similar_collocated", "svt_hip_pa_prepare_batch_device", "svt_hip_pa_mean_variance_device",
     "svt_hip_tq_batch_device", "svt_hip_tq_batch_dist_device", "svt_hip_tq_batch", "svt_hip_lf_thresh_init", "svt_hip_lf_level_from_q",
     "svt_hip_lf_frame_device", "svt_hip_lf_batch_device", "svt_hip_lf_frame", "svt_hip_lf_build_masks",
-    "svt_hip_inter_pred_batch_device", "svt_hip_inter_pred_frame",
+    "svt_hip_inter_pred_batch_device", "svt_hip_inter_pred_frame", "svt_hip_coeff_rate_batch_device", "svt_hip_coeff_rate_batch",
 ]
 
 _lib = None

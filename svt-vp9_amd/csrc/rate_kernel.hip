@@ -1,0 +1,113 @@
+/*
+ * rate_kernel.hip -- coefficient rate estimation of batches of quantised transform blocks (gfx950).
+ *
+ * Replaces coeff_rate_estimate (Source/Lib/Codec/EbRateDistortionCost.c:55-172 = libvpx cost_coeffs, the
+ * use_fast_coef_costing = 0 branch :131-169) as perform_dist_rate_calc calls it for every transform block
+ * (Codec/EbEncDecProcess.c:734-745).
+ *
+ * The reference walks the scan serially, but nothing in the walk is a true chain: the token of a position depends on
+ * its own coefficient only, its context on the energy classes of two earlier-scanned neighbours (= their
+ * coefficients), the "previous token was ZERO" switch on the previous position's coefficient, the band on the
+ * position.  So one wave takes one block, lane l the scan positions l, l + 64, ..; position eob (if the block is not
+ * full) contributes the EOB token; a wave reduction gives the block's bits.  Table reads are gathers from the 55 KB
+ * cost table (L1/L2 resident); coefficient reads stay inside the block's own lines.
+ */
+#include <hip/hip_runtime.h>
+#include "svt_ctx.h"
+
+namespace {
+
+__device__ __forceinline__ int token_of(int v) { /* VPX/vp9_tokenize.c:36-50, VPX/vp9_entropy.h:28-52 */
+    const int a = v < 0 ? -v : v;
+    return a < 5 ? a : a < 7 ? 5 : a < 11 ? 6 : a < 19 ? 7 : a < 35 ? 8 : a < 67 ? 9 : 10;
+}
+/* eb_vp9_pt_energy_class {0,1,2,3,3,4,4,5,5,5,5,5} packed 4 bits per token */
+__device__ __forceinline__ int energy_of(int tok) { return (int)((0x555554433210ull >> (4 * tok)) & 0xf); }
+__device__ __forceinline__ int band_of(int c, int tx4x4) { return c == 0 ? 0 : c < 3 ? 1 : c < 6 ? 2 : c < 10 ? 3 : c < (tx4x4 ? 13 : 21) ? 4 : 5; }
+
+__global__ __launch_bounds__(256) void svt_rate_kernel(const int16_t *__restrict__ qcoeff, const svt_rate_block *__restrict__ blocks, int n_blocks,
+                                                       const svt_rate_tables *__restrict__ T, const int16_t *__restrict__ scan_all,
+                                                       int32_t *__restrict__ bits) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= n_blocks) return;
+    const uint4          kw = *(const uint4 *)(blocks + b);
+    const uint32_t       coeff_off = kw.x, scan_off = kw.y;
+    const int            eob = (int)(kw.z & 0xffff), ts = (int)((kw.z >> 16) & 0xff), ptype = (int)(kw.z >> 24);
+    const int            inter = (int)(kw.w & 0xff), ctx0 = (int)((kw.w >> 8) & 0xff);
+    const int            n = 16 << (2 * ts);
+    const int16_t       *q = qcoeff + coeff_off, *scan = scan_all + scan_off, *nb = scan + n;
+    const uint32_t      *tc = &T->token_costs[ts][ptype][inter][0][0][0][0]; /* [band][prev zero][ctx][token] */
+    int                  sum = 0;
+    for (int c = lane; c <= eob && c < n; c += 64) {
+        if (c == eob) { /* EOB token (the block is not full) */
+            int pt = ctx0, band = 0;
+            if (eob) {
+                const uint32_t nn = *(const uint32_t *)(nb + 2 * c);
+                pt   = (1 + energy_of(token_of(q[(int16_t)(nn & 0xffff)])) + energy_of(token_of(q[(int16_t)(nn >> 16)]))) >> 1;
+                band = band_of(c, ts == 0);
+            }
+            sum += (int)tc[((band * 2 + 0) * 6 + pt) * 12 + 11];
+        } else {
+            const int v = q[c ? scan[c] : 0], tok = token_of(v);
+            int       cost;
+            if (tok == 10) { /* vp9_get_token_cost, VPX/vp9_tokenize.h:118-127 */
+                const int extra = (v < 0 ? -v : v) - 67;
+                cost = T->cat6_low_cost[extra & 0xff] + T->cat6_high_cost[extra >> 8];
+            } else {
+                cost = T->value_cost[v + 66];
+            }
+            int pt = ctx0, pz = 0, band = 0;
+            if (c) {
+                const uint32_t nn = *(const uint32_t *)(nb + 2 * c);
+                pt   = (1 + energy_of(token_of(q[(int16_t)(nn & 0xffff)])) + energy_of(token_of(q[(int16_t)(nn >> 16)]))) >> 1;
+                pz   = q[scan[c - 1]] == 0;
+                band = band_of(c, ts == 0);
+            }
+            sum += cost + (int)tc[((band * 2 + pz) * 6 + pt) * 12 + tok];
+        }
+    }
+    _Pragma("unroll") for (int off = 32; off; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) bits[b] = sum;
+}
+} // namespace
+
+extern "C" int32_t svt_hip_coeff_rate_batch_device(svt_hip_ctx *ctx, const int16_t *d_qcoeff, const svt_rate_block *d_blocks, int32_t n_blocks,
+                                                   const svt_rate_tables *d_tables, const int16_t *d_scan, int32_t *d_bits) {
+    if (!ctx || !d_qcoeff || !d_blocks || n_blocks < 1 || !d_tables || !d_scan || !d_bits)
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "rate: null argument");
+    if (((uintptr_t)d_scan & 3) || ((uintptr_t)d_blocks & 15)) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "rate: scan / block arrays must be 4 / 16-byte aligned");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    hipLaunchKernelGGL(svt_rate_kernel, dim3((n_blocks + 3) / 4), dim3(256), 0, ctx->stream, d_qcoeff, d_blocks, n_blocks, d_tables, d_scan, d_bits);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->timed = 1;
+    return SVT_HIP_OK;
+}
+
+extern "C" int32_t svt_hip_coeff_rate_batch(svt_hip_ctx *ctx, const int16_t *qcoeff, size_t coeff_count, const svt_rate_block *blocks, int32_t n_blocks,
+                                            const svt_rate_tables *tables, const int16_t *scan, size_t scan_count, int32_t *bits) {
+    if (!ctx || !qcoeff || !blocks || n_blocks < 1 || !tables || !scan || !bits) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "rate: null argument");
+    for (int i = 0; i < n_blocks; i++) {
+        const size_t n = (size_t)16 << (2 * blocks[i].tx_size);
+        if (blocks[i].tx_size > 3 || blocks[i].plane_type > 1 || blocks[i].is_inter > 1 || blocks[i].ctx > 2 || blocks[i].eob > n ||
+            blocks[i].coeff_off + n > coeff_count || blocks[i].scan_off + 3 * n + 2 > scan_count || (blocks[i].scan_off & 1))
+            return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "rate: bad block");
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    int16_t          *dq = (int16_t *)svt_ctx_slot(ctx, 34, sizeof(int16_t) * coeff_count);
+    svt_rate_block   *db = (svt_rate_block *)svt_ctx_slot(ctx, 35, sizeof(svt_rate_block) * (size_t)n_blocks);
+    svt_rate_tables  *dt = (svt_rate_tables *)svt_ctx_slot(ctx, 36, sizeof(svt_rate_tables));
+    int16_t          *ds = (int16_t *)svt_ctx_slot(ctx, 37, sizeof(int16_t) * scan_count);
+    int32_t          *dbits = (int32_t *)svt_ctx_slot(ctx, 38, sizeof(int32_t) * (size_t)n_blocks);
+    if (!dq || !db || !dt || !ds || !dbits) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "rate: device buffers");
+    HIP_TRY(hipMemcpyAsync(dq, qcoeff, sizeof(int16_t) * coeff_count, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(db, blocks, sizeof(svt_rate_block) * (size_t)n_blocks, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dt, tables, sizeof(svt_rate_tables), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ds, scan, sizeof(int16_t) * scan_count, hipMemcpyHostToDevice, ctx->stream));
+    int32_t rc = svt_hip_coeff_rate_batch_device(ctx, dq, db, n_blocks, dt, ds, dbits);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(bits, dbits, sizeof(int32_t) * (size_t)n_blocks, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_HIP_OK;
+}

@@ -12,6 +12,7 @@ import me_configs as MC  # noqa: E402
 import svt_testlib as T  # noqa: E402
 
 G = T.GOLDEN_DIR
+RATE_GOLDEN_CASES = ((1, 256, 128, False), (2, 128, 64, False), (11, 128, 64, True))
 MC_GOLDEN_CASES = ((1, 192, 128, 1), (2, 128, 72, 1), (3, 64, 64, 0), (4, 200, 136, 1))
 
 
@@ -71,6 +72,17 @@ def main():
         y, u, v = T.ref_mc_frame(case)
         mc[f"y|{seed}|{w}|{h}|{sub}"], mc[f"u|{seed}|{w}|{h}|{sub}"], mc[f"v|{seed}|{w}|{h}|{sub}"] = y, u, v
     np.savez_compressed(os.path.join(G, "mc_reference.npz"), **mc)
+    # ---- coefficient rate estimation: the reference's tables (token costs of the default coefficient probabilities, value
+    # / cat6 cost tables, scan orders with neighbours) and its coeff_rate_estimate() on the blocks of tests/test_rate.py ----
+    assert T.have_ref("ref_rate_blocks")
+    dummy = dict(qcoeff=np.zeros(16, np.int16), blocks=np.zeros(1, dtype=T.B.RATE_BLOCK_DTYPE), tx_type=np.zeros(1, np.int32))
+    _, tab, scan = T.ref_rate_run(dummy)
+    rate = {k: np.ascontiguousarray(tab[k]) for k in ("token_costs", "value_cost", "cat6_low_cost", "cat6_high_cost")}
+    rate["scan"] = scan
+    for (seed, w, h, ext) in RATE_GOLDEN_CASES:
+        case = T.make_rate_case(seed, width=w, height=h, scan=scan, extreme=ext)
+        rate[f"bits|{seed}|{w}|{h}|{int(ext)}"] = T.ref_rate_run(case)[0]
+    np.savez_compressed(os.path.join(G, "rate_reference.npz"), **rate)
     for f in sorted(os.listdir(G)):
         print(f, os.path.getsize(os.path.join(G, f)))
 

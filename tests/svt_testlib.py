@@ -876,3 +876,115 @@ def mc_inter_masks(case):
     """boolean masks (luma, chroma) of the samples that belong to inter blocks"""
     inter = case["mi"]["ref_list"][:, :, 0] >= 0
     return np.kron(inter, np.ones((8, 8), bool)), np.kron(inter, np.ones((4, 4), bool))
+
+
+# ---- coefficient rate estimation ---------------------------------------------------------------------------------
+RATE_GOLD = os.path.join(GOLDEN_DIR, "rate_reference.npz")
+
+
+def _rate_request(case):
+    """request file of oracle/_ref/ref_rate_blocks"""
+    out = [struct.pack("<2i", 0x54525653, len(case["blocks"]))]
+    for b, tt in zip(case["blocks"], case["tx_type"]):
+        n = 16 << (2 * int(b["tx_size"]))
+        plane = 0 if b["plane_type"] == 0 else 1
+        out.append(struct.pack("<6i", int(b["tx_size"]), plane, int(b["is_inter"]), int(tt), int(b["ctx"]), int(b["eob"])))
+        out.append(case["qcoeff"][int(b["coeff_off"]):int(b["coeff_off"]) + n].astype("<i2").tobytes())
+    return b"".join(out)
+
+
+def ref_rate_run(case):
+    """the reference's coeff_rate_estimate() for every block + the tables it used (tables, scan array, offsets)"""
+    exe = os.path.join(REF_DIR, "ref_rate_blocks")
+    with tempfile.TemporaryDirectory() as td:
+        req, rsp = os.path.join(td, "req.bin"), os.path.join(td, "rsp.bin")
+        open(req, "wb").write(_rate_request(case))
+        subprocess.check_call([exe, req, rsp])
+        raw = open(rsp, "rb").read()
+    nb = len(case["blocks"])
+    bits = np.frombuffer(raw, "<i4", nb).copy()
+    pos = 4 * nb
+    t = np.zeros((), dtype=B.RATE_TABLES_DTYPE)
+    t["token_costs"] = np.frombuffer(raw, "<u4", 13824, pos).reshape(4, 2, 2, 6, 2, 6, 12); pos += 4 * 13824
+    t["value_cost"] = np.frombuffer(raw, "<i4", 133, pos); pos += 4 * 133
+    t["cat6_low_cost"] = np.frombuffer(raw, "<u2", 256, pos); pos += 512
+    t["cat6_high_cost"] = np.frombuffer(raw, "<u2", 64, pos); pos += 128
+    scan = np.frombuffer(raw, "<i2", (len(raw) - pos) // 2, pos).copy()
+    return bits, t, scan
+
+
+def rate_scan_offsets():
+    offs, pos = {}, 0
+    for ts in range(4):
+        n = 16 << (2 * ts)
+        for tt in range(4):
+            offs[(ts, tt)] = pos
+            pos += n + 2 * (n + 1)
+    return offs, pos
+
+
+_rate_tab_cache = None
+
+
+def rate_tables():
+    """(svt_rate_tables, scan array) as committed test data (tests/golden/rate_reference.npz, written by gen_golden.py from
+    the reference's own tables)"""
+    global _rate_tab_cache
+    if _rate_tab_cache is None:
+        g = np.load(RATE_GOLD)
+        t = np.zeros((), dtype=B.RATE_TABLES_DTYPE)
+        for k in ("token_costs", "value_cost", "cat6_low_cost", "cat6_high_cost"):
+            t[k] = g[k]
+        _rate_tab_cache = (t, g["scan"].astype(np.int16))
+    return _rate_tab_cache
+
+
+def make_rate_case(seed, width=256, height=128, scan=None, extreme=False):
+    """quantised transform blocks out of the TQ oracle (realistic sparsity and eob spread) + per-block plane type, inter flag,
+    entropy context; tx_type of inter / chroma blocks is DCT_DCT as get_tx_type() has it.  A few blocks get huge levels
+    (CAT6 tokens) and dense 32x32 content."""
+    rng = np.random.default_rng(seed)
+    tq = make_tq_case(seed, width=width, height=height, qsteps=((8, 9), (16, 20), (40, 48)) if not extreme else ((4, 4), (4, 4), (8, 8)), extreme=extreme)
+    _, q, _, _ = oracle_tq_batch(tq)
+    q = q.copy()
+    offs, total = rate_scan_offsets()
+    if scan is None:
+        scan = rate_tables()[1]
+    assert scan.size == total
+    nb = len(tq["blocks"])
+    blocks = np.zeros(nb, dtype=B.RATE_BLOCK_DTYPE)
+    tx_type = np.zeros(nb, np.int32)
+    for i, b in enumerate(tq["blocks"]):
+        ts = int(b["tx_size"])
+        n = 16 << (2 * ts)
+        off = int(b["coeff_off"])
+        pt, inter = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        tt = int(b["tx_type"]) if (pt == 0 and not inter and ts < 3) else 0
+        if rng.random() < 0.02:
+            q[off:off + n][rng.integers(0, n, 3)] = rng.integers(-3000, 3000, 3)   # CAT6 / large tokens
+        so = offs[(ts, tt)]
+        sc = scan[so:so + n]
+        nz = np.nonzero(q[off:off + n][sc])[0]
+        blocks[i] = (off, so, (int(nz[-1]) + 1) if len(nz) else 0, ts, pt, inter, int(rng.integers(0, 3)), (0, 0))
+        tx_type[i] = tt
+    return dict(qcoeff=q, blocks=blocks, tx_type=tx_type)
+
+
+def oracle_rate_batch(case, tables=None, scan=None):
+    t, s = (tables, scan) if tables is not None else rate_tables()
+    bits = np.zeros(len(case["blocks"]), np.int32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    tb = np.ascontiguousarray(t).reshape(1)
+    rc = oracle().svt_oracle_coeff_rate_batch(vp(case["qcoeff"]), vp(case["blocks"]), len(case["blocks"]), vp(tb), vp(s), vp(bits))
+    assert rc == 0
+    return bits
+
+
+def hip_rate_batch(ctx, case):
+    t, s = rate_tables()
+    bits = np.zeros(len(case["blocks"]), np.int32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    tb = np.ascontiguousarray(t).reshape(1)
+    B.check(B.load().svt_hip_coeff_rate_batch(ctx, vp(case["qcoeff"]), C.c_size_t(case["qcoeff"].size), vp(case["blocks"]), len(case["blocks"]),
+                                              vp(tb), vp(s), C.c_size_t(s.size), vp(bits)))
+    return bits
