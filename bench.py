@@ -357,6 +357,30 @@ def main():
     # per 8x8 unit: 96 bytes (64 luma + 2 x 16 chroma) read per reference and written once, + the 12-byte mode-info record
     mc_bytes = MINIGOP * int(96 * (inter.sum() + (inter & comp).sum()) + 96 * inter.sum() + 12 * inter.size)
 
+    # ---- coefficient rate estimation (row f-4, not part of `value`): bits of every transform block of the mini-GOP from
+    # the quantised coefficients the TQ stage just wrote (d_q), one launch ----
+    rtab, rscan = T.rate_tables()
+    roffs, _ = T.rate_scan_offsets()
+    rb = np.zeros(len(tq_blocks_all), dtype=B.RATE_BLOCK_DTYPE)
+    rb["coeff_off"] = tq_blocks_all["coeff_off"]
+    rb["tx_size"] = tq_blocks_all["tx_size"]
+    rb["scan_off"] = np.array([roffs[(int(a), int(b) if a < 3 else 0)] for a, b in zip(tq_blocks_all["tx_size"], tq_blocks_all["tx_type"])], np.uint32)
+    rb["plane_type"] = (tq_blocks_all["src_off"] % pic_bytes >= Hd * plane_w).astype(np.uint8)
+    rb["is_inter"] = 0     # the bench's TQ blocks carry intra tx types (ADST mixes), so they are costed as intra blocks
+    rb["ctx"] = np.random.default_rng(8).integers(0, 3, len(rb))
+    rb["eob"] = d_eob.cpu().numpy().view(np.uint16)[:len(rb)]
+    d_rb, d_rt, d_rs = to_dev(rb.view(np.uint8)), to_dev(np.ascontiguousarray(rtab).reshape(1).view(np.uint8)), to_dev(rscan)
+    d_bits = to_dev(np.zeros(len(rb), np.int32))
+    rate_ms = 0.0
+    for rep in range(4):
+        B.check(lib.svt_hip_coeff_rate_batch_device(ctx_me, C.c_void_p(d_q.data_ptr()), C.c_void_p(d_rb.data_ptr()), len(rb), C.c_void_p(d_rt.data_ptr()),
+                                                    C.c_void_p(d_rs.data_ptr()), C.c_void_p(d_bits.data_ptr())))
+        B.check(lib.svt_hip_ctx_synchronize(ctx_me))
+        if rep:
+            rate_ms += lib.svt_hip_last_kernel_ms(ctx_me) / 3
+    # per block: the n*n coefficients up to eob are read (2 bytes each, whole 64-byte lines), 16-byte descriptor, 4-byte result
+    rate_bytes = int(np.sum(np.minimum((16 << (2 * rb["tx_size"].astype(np.int64))), ((rb["eob"].astype(np.int64) * 2 + 63) // 64 + 1) * 32)) * 2 + 20 * len(rb))
+
     if rank != 0:
         return
     # HBM traffic of the dominant kernel per step, from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.md)
@@ -391,7 +415,8 @@ def main():
                         "frac_of_8TBps": round(b / (ms * 1e-3) / 8e12, 5)}
                     for k, ms, b in (("svt_me_sb_kernel", me_ms, me_bytes), ("svt_tq_kernel<4|8|16|32>", tq_ms, tq_bytes),
                                      ("svt_lf_kernel", lf_ms, lf_bytes), ("svt_pa_plane_kernel (pre-ME stage, outside value)", pa_ms, pa_bytes),
-                                     ("svt_mc_kernel (inter prediction in front of TQ, outside value)", max(mc_ms, 1e-9), mc_bytes))},
+                                     ("svt_mc_kernel (inter prediction in front of TQ, outside value)", max(mc_ms, 1e-9), mc_bytes),
+                                     ("svt_rate_kernel (coefficient rate after TQ, outside value)", max(rate_ms, 1e-9), rate_bytes))},
     }
     if not args.no_cpu_baseline:
         # oracle (scalar C restatement of the reference C path), single thread, on a bounded sample of the same

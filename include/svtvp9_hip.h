@@ -456,7 +456,8 @@ typedef struct svt_rate_tables {
 } svt_rate_tables;                            /* 56472 bytes */
 
 typedef struct svt_rate_block {
-    uint32_t coeff_off;  /* element offset of the block's n*n quantised coefficients (raster) in d_qcoeff */
+    uint32_t coeff_off;  /* element offset of the block's n*n quantised coefficients (raster) in d_qcoeff; multiple of 8
+                            (the TQ batch's coeff_off) */
     uint32_t scan_off;   /* element offset of {scan[n], neighbors[2 (n + 1)]} of the block's scan order */
     uint16_t eob;
     uint8_t  tx_size;    /* SVT_TX_* */

@@ -8,9 +8,11 @@
  * The reference walks the scan serially, but nothing in the walk is a true chain: the token of a position depends on
  * its own coefficient only, its context on the energy classes of two earlier-scanned neighbours (= their
  * coefficients), the "previous token was ZERO" switch on the previous position's coefficient, the band on the
- * position.  So one wave takes one block, lane l the scan positions l, l + 64, ..; position eob (if the block is not
- * full) contributes the EOB token; a wave reduction gives the block's bits.  Table reads are gathers from the 55 KB
- * cost table (L1/L2 resident); coefficient reads stay inside the block's own lines.
+ * position.  So 16 lanes take one block (most blocks are 4x4 / 8x8 with a short scan; a wave holds four blocks), lane l
+ * the scan positions l, l + 16, ..; position eob (if the block is not full) contributes the EOB token; a reduction
+ * over the 16 lanes gives the block's bits.  The block's coefficients are first copied to LDS with 16-byte loads (the
+ * three coefficient gathers per position then cost an LDS access instead of a global one); table reads are gathers
+ * from the 55 KB cost table (L1/L2 resident).
  */
 #include <hip/hip_runtime.h>
 #include "svt_ctx.h"
@@ -25,30 +27,24 @@ __device__ __forceinline__ int token_of(int v) { /* VPX/vp9_tokenize.c:36-50, VP
 __device__ __forceinline__ int energy_of(int tok) { return (int)((0x555554433210ull >> (4 * tok)) & 0xf); }
 __device__ __forceinline__ int band_of(int c, int tx4x4) { return c == 0 ? 0 : c < 3 ? 1 : c < 6 ? 2 : c < 10 ? 3 : c < (tx4x4 ? 13 : 21) ? 4 : 5; }
 
-__global__ __launch_bounds__(256) void svt_rate_kernel(const int16_t *__restrict__ qcoeff, const svt_rate_block *__restrict__ blocks, int n_blocks,
-                                                       const svt_rate_tables *__restrict__ T, const int16_t *__restrict__ scan_all,
-                                                       int32_t *__restrict__ bits) {
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (b >= n_blocks) return;
-    const uint4          kw = *(const uint4 *)(blocks + b);
-    const uint32_t       coeff_off = kw.x, scan_off = kw.y;
-    const int            eob = (int)(kw.z & 0xffff), ts = (int)((kw.z >> 16) & 0xff), ptype = (int)(kw.z >> 24);
-    const int            inter = (int)(kw.w & 0xff), ctx0 = (int)((kw.w >> 8) & 0xff);
-    const int            n = 16 << (2 * ts);
-    const int16_t       *q = qcoeff + coeff_off, *scan = scan_all + scan_off, *nb = scan + n;
-    const uint32_t      *tc = &T->token_costs[ts][ptype][inter][0][0][0][0]; /* [band][prev zero][ctx][token] */
-    int                  sum = 0;
-    for (int c = lane; c <= eob && c < n; c += 64) {
+/* bits of the scan positions lane, lane + 16, .. (< n, <= eob) of one block; q = the block's coefficients (LDS or global) */
+__device__ __forceinline__ int rate_positions(const int16_t *q, const int16_t *scan, const int16_t *nb, const uint32_t *tc, const svt_rate_tables *T,
+                                              int lane, int eob, int n, int ts, int ctx0) {
+    int sum = 0;
+    _Pragma("unroll 2") for (int c = lane; c <= eob && c < n; c += 16) {
+        /* the three table reads of a position are independent of each other: issue them before the coefficient reads */
+        const uint32_t nn = c ? *(const uint32_t *)(nb + 2 * c) : 0u;
+        const int      rc = c ? scan[c] : 0, rp = c ? scan[c - 1] : 0;
+        int            pt = ctx0, pz = 0, band = 0;
+        if (c) {
+            pt   = (1 + energy_of(token_of(q[(int16_t)(nn & 0xffff)])) + energy_of(token_of(q[(int16_t)(nn >> 16)]))) >> 1;
+            pz   = q[rp] == 0;
+            band = band_of(c, ts == 0);
+        }
         if (c == eob) { /* EOB token (the block is not full) */
-            int pt = ctx0, band = 0;
-            if (eob) {
-                const uint32_t nn = *(const uint32_t *)(nb + 2 * c);
-                pt   = (1 + energy_of(token_of(q[(int16_t)(nn & 0xffff)])) + energy_of(token_of(q[(int16_t)(nn >> 16)]))) >> 1;
-                band = band_of(c, ts == 0);
-            }
             sum += (int)tc[((band * 2 + 0) * 6 + pt) * 12 + 11];
         } else {
-            const int v = q[c ? scan[c] : 0], tok = token_of(v);
+            const int v = q[rc], tok = token_of(v);
             int       cost;
             if (tok == 10) { /* vp9_get_token_cost, VPX/vp9_tokenize.h:118-127 */
                 const int extra = (v < 0 ? -v : v) - 67;
@@ -56,17 +52,36 @@ __global__ __launch_bounds__(256) void svt_rate_kernel(const int16_t *__restrict
             } else {
                 cost = T->value_cost[v + 66];
             }
-            int pt = ctx0, pz = 0, band = 0;
-            if (c) {
-                const uint32_t nn = *(const uint32_t *)(nb + 2 * c);
-                pt   = (1 + energy_of(token_of(q[(int16_t)(nn & 0xffff)])) + energy_of(token_of(q[(int16_t)(nn >> 16)]))) >> 1;
-                pz   = q[scan[c - 1]] == 0;
-                band = band_of(c, ts == 0);
-            }
             sum += cost + (int)tc[((band * 2 + pz) * 6 + pt) * 12 + tok];
         }
     }
-    _Pragma("unroll") for (int off = 32; off; off >>= 1) sum += __shfl_xor(sum, off);
+    return sum;
+}
+
+__global__ __launch_bounds__(256) void svt_rate_kernel(const int16_t *__restrict__ qcoeff, const svt_rate_block *__restrict__ blocks, int n_blocks,
+                                                       const svt_rate_tables *__restrict__ T, const int16_t *__restrict__ scan_all,
+                                                       int32_t *__restrict__ bits) {
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 4), lane = threadIdx.x & 15;
+    if (b >= n_blocks) return;
+    const uint4          kw = *(const uint4 *)(blocks + b);
+    const uint32_t       coeff_off = kw.x, scan_off = kw.y;
+    const int            eob = (int)(kw.z & 0xffff), ts = (int)((kw.z >> 16) & 0xff), ptype = (int)(kw.z >> 24);
+    const int            inter = (int)(kw.w & 0xff), ctx0 = (int)((kw.w >> 8) & 0xff);
+    const int            n = 16 << (2 * ts);
+    const int16_t       *scan = scan_all + scan_off, *nb = scan + n;
+    const uint32_t      *tc = &T->token_costs[ts][ptype][inter][0][0][0][0]; /* [band][prev zero][ctx][token] */
+    /* 4x4 and 8x8 blocks (the bulk of a batch) are staged in LDS with 16-byte loads, the group's lanes in turn (LDS accesses
+     * of one wave are ordered, the 16 lanes of a group sit in one wave: no barrier); bigger blocks are read in place, their
+     * 0.5 / 2 KB stay in L1 while the group walks them */
+    __shared__ uint4 s_q[16][8];
+    int              sum;
+    if (ts <= 1) {
+        if (eob && lane < (n >> 3)) s_q[threadIdx.x >> 4][lane] = ((const uint4 *)(qcoeff + coeff_off))[lane];
+        sum = rate_positions((const int16_t *)s_q[threadIdx.x >> 4], scan, nb, tc, T, lane, eob, n, ts, ctx0);
+    } else {
+        sum = rate_positions(qcoeff + coeff_off, scan, nb, tc, T, lane, eob, n, ts, ctx0);
+    }
+    _Pragma("unroll") for (int off = 8; off; off >>= 1) sum += __shfl_xor(sum, off);
     if (lane == 0) bits[b] = sum;
 }
 } // namespace
@@ -75,10 +90,11 @@ extern "C" int32_t svt_hip_coeff_rate_batch_device(svt_hip_ctx *ctx, const int16
                                                    const svt_rate_tables *d_tables, const int16_t *d_scan, int32_t *d_bits) {
     if (!ctx || !d_qcoeff || !d_blocks || n_blocks < 1 || !d_tables || !d_scan || !d_bits)
         return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "rate: null argument");
-    if (((uintptr_t)d_scan & 3) || ((uintptr_t)d_blocks & 15)) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "rate: scan / block arrays must be 4 / 16-byte aligned");
+    if (((uintptr_t)d_scan & 3) || ((uintptr_t)d_blocks & 15) || ((uintptr_t)d_qcoeff & 15))
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "rate: scan / block / coefficient arrays must be 4 / 16 / 16-byte aligned");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
-    hipLaunchKernelGGL(svt_rate_kernel, dim3((n_blocks + 3) / 4), dim3(256), 0, ctx->stream, d_qcoeff, d_blocks, n_blocks, d_tables, d_scan, d_bits);
+    hipLaunchKernelGGL(svt_rate_kernel, dim3((n_blocks + 15) / 16), dim3(256), 0, ctx->stream, d_qcoeff, d_blocks, n_blocks, d_tables, d_scan, d_bits);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->timed = 1;
@@ -91,7 +107,7 @@ extern "C" int32_t svt_hip_coeff_rate_batch(svt_hip_ctx *ctx, const int16_t *qco
     for (int i = 0; i < n_blocks; i++) {
         const size_t n = (size_t)16 << (2 * blocks[i].tx_size);
         if (blocks[i].tx_size > 3 || blocks[i].plane_type > 1 || blocks[i].is_inter > 1 || blocks[i].ctx > 2 || blocks[i].eob > n ||
-            blocks[i].coeff_off + n > coeff_count || blocks[i].scan_off + 3 * n + 2 > scan_count || (blocks[i].scan_off & 1))
+            blocks[i].coeff_off + n > coeff_count || (blocks[i].coeff_off & 7) || blocks[i].scan_off + 3 * n + 2 > scan_count || (blocks[i].scan_off & 1))
             return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "rate: bad block");
     }
     HIP_TRY(hipSetDevice(ctx->device));
