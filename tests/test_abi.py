@@ -23,6 +23,16 @@ def test_struct_sizes_match_header():
     assert C.sizeof(B.Plane) == 32 and C.sizeof(B.PaPicture) == 96
     assert B.ME_RESULT_DTYPE.itemsize == 40 and B.TQ_BLOCK_DTYPE.itemsize == 32
     assert B.LF_MASK_DTYPE.itemsize == 160 and C.sizeof(B.LfThresh) == 192 and B.QUANT_DTYPE.itemsize == 20
+    assert B.MC_MODE_INFO_DTYPE.itemsize == 12 and B.RATE_BLOCK_DTYPE.itemsize == 16 and B.RATE_TABLES_DTYPE.itemsize == 56472
+    # the same sizes as the C compiler sees them
+    import subprocess, tempfile, os
+    src = ('#include <stdio.h>\n#include "svtvp9_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu",sizeof(svt_plane),sizeof(svt_me_pu_result),'
+           'sizeof(svt_tq_block),sizeof(svt_lf_mask),sizeof(svt_mc_mode_info),sizeof(svt_rate_block),sizeof(svt_rate_tables),sizeof(svt_mc_picture));return 0;}')
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", f"{T.ROOT}/include", os.path.join(td, "s.c"), "-o", os.path.join(td, "s")])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(td, "s")]).split()]
+    assert sizes == [32, 40, 32, 160, 12, 16, 56472, C.sizeof(B.McPicture)], sizes
 
 
 def test_me_presets_follow_reference_tables():
