@@ -47,7 +47,8 @@ __device__ __forceinline__ int sclamp(int t) { return t < -128 ? -128 : t > 127 
  * Branch-free per lane: the three candidate results are independent dependency chains (a lone wave issues one dependent
  * VALU op every ~5 cycles, so instruction-level parallelism is what shortens an edge), the 8- and 16-tap results are
  * running sums (each output = previous sum - 2 leaving taps + 2 entering taps) and are skipped wave-wide when no lane
- * of the wave needs them. */
+ * of the wave needs them.  `kind` is per lane (0 = no edge here, 4, 8, 16): the lanes of a wave sit on different blocks
+ * whose edges carry different filter widths, and one pass serves them all instead of one pass per width. */
 __device__ __forceinline__ int lf_ad(int a, int b) { return (int)__builtin_amdgcn_sad_u8((unsigned)a, (unsigned)b, 0u); } /* |a - b|, 0..255 */
 __device__ __forceinline__ int lf_max3(int a, int b, int c) { return max(max(a, b), c); }
 
@@ -55,14 +56,14 @@ __device__ __forceinline__ void filter_regs(int (&p)[8], int (&q)[8], int kind, 
     const int mblim = (int)(th & 0xff), lim = (int)((th >> 8) & 0xff), hev_thr = (int)((th >> 16) & 0xff);
     const int p3 = p[3], p2 = p[2], p1 = p[1], p0 = p[0], q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     const int d10 = lf_ad(p1, p0), e10 = lf_ad(q1, q0);
-    const bool mask = max(lf_max3(lf_ad(p3, p2), lf_ad(p2, p1), d10), lf_max3(e10, lf_ad(q2, q1), lf_ad(q3, q2))) <= lim &&
+    const bool mask = kind != 0 && max(lf_max3(lf_ad(p3, p2), lf_ad(p2, p1), d10), lf_max3(e10, lf_ad(q2, q1), lf_ad(q3, q2))) <= lim &&
                       lf_ad(p0, q0) * 2 + (lf_ad(p1, q1) >> 1) <= mblim;
     const bool flat = kind >= 8 && lf_max3(max(d10, e10), max(lf_ad(p2, p0), lf_ad(q2, q0)), max(lf_ad(p3, p0), lf_ad(q3, q0))) <= 1;
     const bool use_flat = flat && mask;
     bool       use16 = false;
-    if (kind == 16) {
+    if (__builtin_amdgcn_ballot_w64(kind == 16)) {
         const int f2 = max(lf_max3(lf_ad(p[4], p0), lf_ad(p[5], p0), lf_ad(p[6], p0)), lf_max3(lf_ad(p[7], p0), lf_ad(q[4], q0), lf_ad(q[5], q0)));
-        use16 = use_flat && max(f2, max(lf_ad(q[6], q0), lf_ad(q[7], q0))) <= 1;
+        use16 = kind == 16 && use_flat && max(f2, max(lf_ad(q[6], q0), lf_ad(q[7], q0))) <= 1;
     }
     /* filter4: signed 8-bit arithmetic; with mask = 0 every step yields 0 and the samples come out unchanged */
     const int m = mask ? -1 : 0;
@@ -114,14 +115,14 @@ __device__ __forceinline__ uint32_t lf_entry(int flags, int lvl16, int lvl84, in
 
 /* all filters of one block: leading edge between p and q, then the inner edge inside q (q[3..0] | q[4..7]) */
 __device__ __forceinline__ void lf_block_edges(int (&p)[8], int (&q)[8], uint32_t e, const uint32_t *thr) {
-    if (e & LF_K16) filter_regs(p, q, 16, thr[(e >> 8) & 63]);
-    if (e & LF_K8) filter_regs(p, q, 8, thr[(e >> 14) & 63]);
-    if (e & LF_K4) filter_regs(p, q, 4, thr[(e >> 14) & 63]);
+    /* a position carries at most one width (eb_vp9_build_mask puts an edge into exactly one of the 16/8/4 masks) */
+    const int kind = (e & LF_K16) ? 16 : (e & LF_K8) ? 8 : (e & LF_K4) ? 4 : 0;
+    if (__builtin_amdgcn_ballot_w64(kind != 0)) filter_regs(p, q, kind, thr[((e & LF_K16) ? e >> 8 : e >> 14) & 63]);
 }
 __device__ __forceinline__ void lf_inner_edge(int (&q)[8], uint32_t e, const uint32_t *thr) {
-    if (e & LF_KI) {
+    if (__builtin_amdgcn_ballot_w64((e & LF_KI) != 0)) {
         int ip[8] = {q[3], q[2], q[1], q[0], 0, 0, 0, 0}, iq[8] = {q[4], q[5], q[6], q[7], 0, 0, 0, 0};
-        filter_regs(ip, iq, 4, thr[(e >> 20) & 63]);
+        filter_regs(ip, iq, (e & LF_KI) ? 4 : 0, thr[(e >> 20) & 63]);
         q[3] = ip[0]; q[2] = ip[1]; q[4] = iq[0]; q[5] = iq[1];
     }
 }
