@@ -20,14 +20,22 @@
 namespace {
 
 __device__ __forceinline__ int token_of(int v) { /* VPX/vp9_tokenize.c:36-50, VPX/vp9_entropy.h:28-52 */
+    /* 0..4 -> the value; 5-6, 7-10, 11-18, 19-34, 35-66 -> CAT1..CAT5 (5..9), >= 67 -> CAT6 (10): the categories are the
+     * octaves of |v| - 3 */
     const int a = v < 0 ? -v : v;
-    return a < 5 ? a : a < 7 ? 5 : a < 11 ? 6 : a < 19 ? 7 : a < 35 ? 8 : a < 67 ? 9 : 10;
+    const int oct = 35 - __builtin_clz((unsigned)(a - 3) | 1u); /* 4 + floor(log2(a - 3)) for a >= 5 */
+    return a < 5 ? a : (oct < 10 ? oct : 10);
 }
-/* eb_vp9_pt_energy_class {0,1,2,3,3,4,4,5,5,5,5,5} packed 4 bits per token */
-__device__ __forceinline__ int energy_of(int tok) { return (int)((0x555554433210ull >> (4 * tok)) & 0xf); }
+/* eb_vp9_pt_energy_class[token] = {0,1,2,3,3,4,4,5,5,5,5,5}: straight from |v| (0, 1, 2, 3-4, 5-10, >= 11) */
+__device__ __forceinline__ int energy_of_value(int v) {
+    int a = v < 0 ? -v : v;
+    a = a < 11 ? a : 11;
+    return (int)((0x544444433210ull >> (4 * a)) & 0xf);
+}
 __device__ __forceinline__ int band_of(int c, int tx4x4) { return c == 0 ? 0 : c < 3 ? 1 : c < 6 ? 2 : c < 10 ? 3 : c < (tx4x4 ? 13 : 21) ? 4 : 5; }
 
-/* bits of the scan positions lane, lane + 16, .. (< n, <= eob) of one block; q = the block's coefficients (LDS or global) */
+/* bits of the scan positions lane, lane + 16, .. (< n, <= eob) of one block; q = the block's coefficients, scan / nb / tc =
+ * its scan order and cost slice (each either in LDS or in global memory) */
 __device__ __forceinline__ int rate_positions(const int16_t *q, const int16_t *scan, const int16_t *nb, const uint32_t *tc, const svt_rate_tables *T,
                                               int lane, int eob, int n, int ts, int ctx0) {
     int sum = 0;
@@ -37,7 +45,7 @@ __device__ __forceinline__ int rate_positions(const int16_t *q, const int16_t *s
         const int      rc = c ? scan[c] : 0, rp = c ? scan[c - 1] : 0;
         int            pt = ctx0, pz = 0, band = 0;
         if (c) {
-            pt   = (1 + energy_of(token_of(q[(int16_t)(nn & 0xffff)])) + energy_of(token_of(q[(int16_t)(nn >> 16)]))) >> 1;
+            pt   = (1 + energy_of_value(q[(int16_t)(nn & 0xffff)]) + energy_of_value(q[(int16_t)(nn >> 16)])) >> 1;
             pz   = q[rp] == 0;
             band = band_of(c, ts == 0);
         }
@@ -58,31 +66,54 @@ __device__ __forceinline__ int rate_positions(const int16_t *q, const int16_t *s
     return sum;
 }
 
+constexpr int RATE_SLICE = 6 * 2 * 6 * 12;           /* dwords of one token_costs[tx_size][plane_type][is_inter] slice */
+constexpr int RATE_SCAN4 = 16 + 2 * 17, RATE_SCAN8 = 64 + 2 * 65; /* int16 entries of a 4x4 / 8x8 {scan, neighbors} table */
+
+/* Persistent workgroups: a workgroup first copies what the small blocks need -- the eight cost slices of 4x4 / 8x8 blocks
+ * (27 KB), their eight scan orders (2 KB, when the caller's scan array has the canonical layout of
+ * [tx_size][tx_type] tables) -- into LDS once, then walks chunks of 16 blocks.  For a 4x4 / 8x8 block the only global
+ * reads left are its descriptor and its coefficients. */
 __global__ __launch_bounds__(256) void svt_rate_kernel(const int16_t *__restrict__ qcoeff, const svt_rate_block *__restrict__ blocks, int n_blocks,
                                                        const svt_rate_tables *__restrict__ T, const int16_t *__restrict__ scan_all,
                                                        int32_t *__restrict__ bits) {
-    const int b = blockIdx.x * 16 + (threadIdx.x >> 4), lane = threadIdx.x & 15;
-    if (b >= n_blocks) return;
-    const uint4          kw = *(const uint4 *)(blocks + b);
-    const uint32_t       coeff_off = kw.x, scan_off = kw.y;
-    const int            eob = (int)(kw.z & 0xffff), ts = (int)((kw.z >> 16) & 0xff), ptype = (int)(kw.z >> 24);
-    const int            inter = (int)(kw.w & 0xff), ctx0 = (int)((kw.w >> 8) & 0xff);
-    const int            n = 16 << (2 * ts);
-    const int16_t       *scan = scan_all + scan_off, *nb = scan + n;
-    const uint32_t      *tc = &T->token_costs[ts][ptype][inter][0][0][0][0]; /* [band][prev zero][ctx][token] */
-    /* 4x4 and 8x8 blocks (the bulk of a batch) are staged in LDS with 16-byte loads, the group's lanes in turn (LDS accesses
-     * of one wave are ordered, the 16 lanes of a group sit in one wave: no barrier); bigger blocks are read in place, their
-     * 0.5 / 2 KB stay in L1 while the group walks them */
-    __shared__ uint4 s_q[16][8];
-    int              sum;
-    if (ts <= 1) {
-        if (eob && lane < (n >> 3)) s_q[threadIdx.x >> 4][lane] = ((const uint4 *)(qcoeff + coeff_off))[lane];
-        sum = rate_positions((const int16_t *)s_q[threadIdx.x >> 4], scan, nb, tc, T, lane, eob, n, ts, ctx0);
-    } else {
-        sum = rate_positions(qcoeff + coeff_off, scan, nb, tc, T, lane, eob, n, ts, ctx0);
+    __shared__ uint32_t s_tc[8 * RATE_SLICE];
+    __shared__ int16_t  s_scan[4 * RATE_SCAN4 + 4 * RATE_SCAN8];
+    __shared__ uint4    s_q[16][8];
+    {
+        const uint32_t *g = &T->token_costs[0][0][0][0][0][0][0]; /* slices of tx_size 0 and 1 are the first 8 */
+        for (int i = threadIdx.x; i < 8 * RATE_SLICE; i += 256) s_tc[i] = g[i];
+        const uint32_t *gs = (const uint32_t *)scan_all;          /* canonical layout: the 4x4 tables first, then the 8x8 ones */
+        for (int i = threadIdx.x; i < (4 * RATE_SCAN4 + 4 * RATE_SCAN8) / 2; i += 256) ((uint32_t *)s_scan)[i] = gs[i];
     }
-    _Pragma("unroll") for (int off = 8; off; off >>= 1) sum += __shfl_xor(sum, off);
-    if (lane == 0) bits[b] = sum;
+    __syncthreads();
+    const int grp = threadIdx.x >> 4, lane = threadIdx.x & 15;
+    for (int base = blockIdx.x * 16; base < n_blocks; base += gridDim.x * 16) {
+        const int b = base + grp;
+        if (b < n_blocks) { /* no barrier inside: the 16 lanes of a group sit in one wave, whose LDS accesses are ordered */
+            const uint4     kw = *(const uint4 *)(blocks + b);
+            const uint32_t  coeff_off = kw.x, scan_off = kw.y;
+            const int       eob = (int)(kw.z & 0xffff), ts = (int)((kw.z >> 16) & 0xff), ptype = (int)(kw.z >> 24);
+            const int       inter = (int)(kw.w & 0xff), ctx0 = (int)((kw.w >> 8) & 0xff);
+            const int       n = 16 << (2 * ts);
+            const int       slice = (ts * 2 + ptype) * 2 + inter;
+            int             sum;
+            if (ts <= 1) {
+                /* canonical scan offsets: 4x4 table tt at tt * 50, 8x8 table tt at 200 + tt * 194; anything else is read in place */
+                const int       tt = ts == 0 ? (int)scan_off / RATE_SCAN4 : ((int)scan_off - 4 * RATE_SCAN4) / RATE_SCAN8;
+                const bool      canon = ts == 0 ? (scan_off == (uint32_t)(tt * RATE_SCAN4) && tt < 4)
+                                                : (scan_off == (uint32_t)(4 * RATE_SCAN4 + tt * RATE_SCAN8) && tt >= 0 && tt < 4);
+                const int16_t  *sc_l = s_scan + scan_off, *sc_g = scan_all + scan_off;
+                if (eob && lane < (n >> 3)) s_q[grp][lane] = ((const uint4 *)(qcoeff + coeff_off))[lane];
+                if (canon) sum = rate_positions((const int16_t *)s_q[grp], sc_l, sc_l + n, s_tc + slice * RATE_SLICE, T, lane, eob, n, ts, ctx0);
+                else sum = rate_positions((const int16_t *)s_q[grp], sc_g, sc_g + n, s_tc + slice * RATE_SLICE, T, lane, eob, n, ts, ctx0);
+            } else {
+                const int16_t *sc_g = scan_all + scan_off;
+                sum = rate_positions(qcoeff + coeff_off, sc_g, sc_g + n, &T->token_costs[0][0][0][0][0][0][0] + slice * RATE_SLICE, T, lane, eob, n, ts, ctx0);
+            }
+            _Pragma("unroll") for (int off = 8; off; off >>= 1) sum += __shfl_xor(sum, off);
+            if (lane == 0) bits[b] = sum;
+        }
+    }
 }
 } // namespace
 
@@ -94,7 +125,10 @@ extern "C" int32_t svt_hip_coeff_rate_batch_device(svt_hip_ctx *ctx, const int16
         return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "rate: scan / block / coefficient arrays must be 4 / 16 / 16-byte aligned");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
-    hipLaunchKernelGGL(svt_rate_kernel, dim3((n_blocks + 15) / 16), dim3(256), 0, ctx->stream, d_qcoeff, d_blocks, n_blocks, d_tables, d_scan, d_bits);
+    int dev_cus = 256;
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess && pr.multiProcessorCount > 0) dev_cus = pr.multiProcessorCount; }
+    const int want = (n_blocks + 15) / 16, cap = dev_cus * 5; /* 31 KB of LDS per workgroup: five per CU */
+    hipLaunchKernelGGL(svt_rate_kernel, dim3(want < cap ? want : cap), dim3(256), 0, ctx->stream, d_qcoeff, d_blocks, n_blocks, d_tables, d_scan, d_bits);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->timed = 1;
