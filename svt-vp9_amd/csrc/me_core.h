@@ -363,6 +363,23 @@ SVT_DEV uint32_t me_gld(const me_gsrc g, uint32_t off) {
     return svt_alignbyte(*(const uint32_t *)(g.hi + off), *(const uint32_t *)(g.lo + off), g.sh);
 }
 
+/* a plane descriptor read from LDS (or HBM) into scalar registers: every lane holds the same values, and with them in
+ * SGPRs the address arithmetic built on them (clipping, me_pix, row offsets) runs on the scalar unit */
+SVT_DEV svt_plane me_plane_uni(const svt_plane *p) {
+    svt_plane u;
+#ifdef SVT_HOST_EMU
+    u = *p;
+#else
+    const uintptr_t a = (uintptr_t)p->buf;
+    u.buf = (const uint8_t *)(((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32) |
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
+    u.stride = __builtin_amdgcn_readfirstlane(p->stride); u.origin_x = __builtin_amdgcn_readfirstlane(p->origin_x);
+    u.origin_y = __builtin_amdgcn_readfirstlane(p->origin_y); u.width = __builtin_amdgcn_readfirstlane(p->width);
+    u.height = __builtin_amdgcn_readfirstlane(p->height);
+#endif
+    return u;
+}
+
 /* everything a phase needs */
 typedef struct me_ctx_t {
     const me_pic_dev    *pic;
@@ -1196,7 +1213,9 @@ SVT_DEV int me_div_magic(int t, uint32_t inv) { return inv ? (int)(((uint64_t)(u
 
 /* copy the windows [e0, e1) of a batch: flattened (window,row,dword) tasks, four global loads in flight per thread
  * before the LDS stores; ntask = total load tasks of the batch */
-SVT_DEV void ph_hme_load_multi(const me_ctx_t *c, int tid, const svt_plane *ref, const me_hme_win *wn, int e0, int e1, int ntask) {
+SVT_DEV void ph_hme_load_multi(const me_ctx_t *c, int tid, const svt_plane *ref_lds, const me_hme_win *wn, int e0, int e1, int ntask) {
+    const svt_plane  ref_u = me_plane_uni(ref_lds);
+    const svt_plane *ref = &ref_u;
     int      cur = -1;
     uint32_t inv = 0;
     for (int t0 = tid; t0 < ntask; t0 += 4 * SVT_NT) {
@@ -1533,7 +1552,8 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
     for (int list = 0; list < nlist; list++) {
         /* the reference's plane descriptors are read many times (address arithmetic, clipping): keep them in LDS */
         ME_PHASE(if (tid < (int)(3 * sizeof(svt_plane) / 4)) ((uint32_t *)st->refd)[tid] = ((const uint32_t *)&c->pic->ref[list])[tid]);
-        const svt_plane *rf = &st->refd[0];
+        const svt_plane  rf_u = me_plane_uni(&st->refd[0]); /* full-resolution reference plane of this list */
+        const svt_plane *rf = &rf_u;
         const int        ox = (int16_t)c->sb_x, oy = (int16_t)c->sb_y;
         uint64_t         zero_c = 0; /* 2 * SAD of the block at (0, 0) of this list, when test_search_area_bounds ran */
         int              have_zero = 0;
