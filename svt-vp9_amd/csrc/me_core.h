@@ -651,16 +651,35 @@ SVT_DEV uint8_t me_tap4(int a, int b, int d, int e) { return me_clip8((-2 * a + 
  * outputs.  Even and odd bytes are processed as two 16-bit lanes of one register; a bias of 1024 (= 32 << 5) keeps
  * every lane non-negative so nothing borrows across lanes: floor((S + 1024) / 32) = floor(S / 32) + 32. */
 SVT_DEV uint32_t me_tap4_half(uint32_t a, uint32_t b, uint32_t d, uint32_t e) {
-    const uint32_t s2 = (b + d) << 1;                          /* 18 x = 16 x + 2 x: shifts, no quarter-rate multiply */
+#ifdef SVT_HOST_EMU
+    const uint32_t s2 = (b + d) << 1;                          /* 18 x = 16 x + 2 x */
     uint32_t       v = (s2 << 3) + s2 + 0x04100410u - ((a + e) << 1); /* per lane: 18(b+d) + 16 + 1024 - 2(a+e) in [20, 10220] */
     v = (v >> 5) & 0x07ff07ffu;
     return svt_pk_clamp_sub32(v); /* per lane: min(max(v, 32), 287) - 32 */
+#else
+    /* the same per-lane arithmetic on the packed 16-bit ALU: two adds, two multiply-adds, a shift, the clamp */
+    const svt_u16x2 A = __builtin_bit_cast(svt_u16x2, a), B = __builtin_bit_cast(svt_u16x2, b), D = __builtin_bit_cast(svt_u16x2, d),
+                    E = __builtin_bit_cast(svt_u16x2, e);
+    const svt_u16x2 k18 = {18, 18}, kb = {1040, 1040}, km2 = {0xfffe, 0xfffe}, k5 = {5, 5};
+    svt_u16x2       v = (B + D) * k18 + kb;
+    v = (A + E) * km2 + v; /* - 2 (a + e), modulo 2^16: the true value is in [20, 10220] */
+    v = v >> k5;
+    return svt_pk_clamp_sub32(__builtin_bit_cast(uint32_t, v));
+#endif
 }
 SVT_DEV uint32_t me_tap4_x4(uint32_t a, uint32_t b, uint32_t d, uint32_t e) {
+#ifdef SVT_HOST_EMU
     const uint32_t M = 0x00ff00ffu;
     uint32_t ev = me_tap4_half(a & M, b & M, d & M, e & M);
     uint32_t od = me_tap4_half((a >> 8) & M, (b >> 8) & M, (d >> 8) & M, (e >> 8) & M);
     return ev | (od << 8);
+#else
+    /* even / odd bytes zero-extended into the two 16-bit lanes with one v_perm_b32 each (selector 0x0c = constant 0) */
+    const uint32_t SE = 0x0c020c00u, SO = 0x0c030c01u;
+    const uint32_t ev = me_tap4_half(__builtin_amdgcn_perm(0, a, SE), __builtin_amdgcn_perm(0, b, SE), __builtin_amdgcn_perm(0, d, SE), __builtin_amdgcn_perm(0, e, SE));
+    const uint32_t od = me_tap4_half(__builtin_amdgcn_perm(0, a, SO), __builtin_amdgcn_perm(0, b, SO), __builtin_amdgcn_perm(0, d, SO), __builtin_amdgcn_perm(0, e, SO));
+    return ev | (od << 8);
+#endif
 }
 
 /* half-pel planes B (x+1/2,y) and H (x,y+1/2) from the region; natural coordinates, guard ME_PL_G
