@@ -13,7 +13,7 @@ prof = os.path.join(root, "profiles")
 
 
 def short(name):
-    for k in ("svt_me_sb_kernel", "svt_tq_kernel", "svt_lf_kernel", "svt_lf_desc_kernel", "svt_pa_plane_kernel", "svt_pa_meanvar_kernel", "svt_me_zz_sad_kernel", "svt_mc_kernel"):
+    for k in ("svt_me_sb_kernel", "svt_tq_kernel", "svt_lf_kernel", "svt_lf_desc_kernel", "svt_pa_plane_kernel", "svt_pa_meanvar_kernel", "svt_me_zz_sad_kernel", "svt_mc_kernel", "svt_rate_kernel"):
         if re.search(r"(?<![A-Za-z_0-9])" + k + r"(?![A-Za-z_0-9])", name):
             return k
     return None
@@ -34,7 +34,7 @@ def pmc(sub, prefix):
 fetch, nf = pmc("fetch", "f")
 write, nw = pmc("write", "w")
 sq, ns = pmc("sq", "s")
-REPS = {"svt_pa_plane_kernel": 4, "svt_mc_kernel": 4}  # bench.py times these stages in 4 repetitions of their own, once per run
+REPS = {"svt_pa_plane_kernel": 4, "svt_mc_kernel": 4, "svt_rate_kernel": 4}  # bench.py times these stages in 4 repetitions of their own, once per run
 traffic = {"_comment": "HBM traffic per 16-picture step from rocprofv3 PMC passes on MI355X (tools/profile_round.sh, "
                        "tools/summarize_prof.py): bytes = 1024 * (2 x FETCH_SIZE + WRITE_SIZE)"}
 print("| kernel | launches/step | FETCH_SIZE raw (KiB) | WRITE_SIZE (KiB) | traffic (MB) |")
