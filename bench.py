@@ -388,6 +388,14 @@ def main():
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj) and (Wd, Hd) == (W4K, H4K):
         traffic = json.load(open(tj)).get("svt_me_sb_kernel", {}).get("bytes_per_step")
+    valu = None
+    if os.path.exists(tj) and (Wd, Hd) == (W4K, H4K):
+        vi = json.load(open(tj)).get("svt_me_sb_kernel", {}).get("valu_wave_insts_per_step")
+        if vi:
+            # the kernel's real roof: 64-lane VALU instructions issued (rocprofv3 SQ_INSTS_VALU, profiles/) per second against
+            # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (MI355X_MICROARCH.md)
+            ach = vi * 64 / (me_ms * 1e-3) / 1e12
+            valu = {"achieved": round(ach, 2), "peak": 39.3, "unit": "T lane-ops/s", "frac": round(ach / 39.3, 4), "wave_insts_per_step": vi}
     fps = GS.aggregate_rate(MINIGOP, args.steps, world, dt)
     out = {
         "metric": "encoded frames/sec (block-level DSP hot path: ME + DCT/quant/recon + deblock), 4Kp60 yuv420p enc-mode 8",
@@ -410,7 +418,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "svt_me_sb_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
                      "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                      "launches_per_step": len(me_launches),
-                     "kernel_ms_per_step": round(me_ms, 3), "algorithmic_bytes_per_step": me_bytes},
+                     "kernel_ms_per_step": round(me_ms, 3), "algorithmic_bytes_per_step": me_bytes, "valu": valu},
         "kernels": {k: {"ms_per_step": round(ms, 3), "algorithmic_bytes_per_step": b, "GB_per_s": round(b / (ms * 1e-3) / 1e9, 2),
                         "frac_of_8TBps": round(b / (ms * 1e-3) / 8e12, 5)}
                     for k, ms, b in (("svt_me_sb_kernel", me_ms, me_bytes), ("svt_tq_kernel<4|8|16|32>", tq_ms, tq_bytes),

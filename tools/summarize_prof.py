@@ -46,6 +46,9 @@ for k in sorted(set(fetch) | set(write)):
     traffic[k] = {"fetch_size_kb_raw_per_step": round(fk), "write_size_kb_per_step": round(wk), "bytes_per_step": b,
                   "launches_per_step": nf[(k, "FETCH_SIZE")] // rep}
     print(f"| {k} | {nf[(k, 'FETCH_SIZE')] // rep} | {fk:.0f} | {wk:.0f} | {b / 1e6:.1f} |")
+for k, v in sq.items():  # instruction counts of the SQ pass (ME stage alone): per step for ME
+    if k in traffic and "SQ_INSTS_VALU" in v:
+        traffic[k]["valu_wave_insts_per_step"] = int(v["SQ_INSTS_VALU"] / REPS.get(k, 1))
 json.dump(traffic, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
 for k, v in sq.items():
     print("SQ", k, {c: f"{x:.4g}" for c, x in v.items()})
