@@ -369,8 +369,9 @@ __global__ __launch_bounds__(256) void svt_lf_kernel(const lf_pic_dev *__restric
                                                                   chroma vertical 16, chroma horizontal 16 */
     __shared__ int                   s_job;
     __shared__ volatile int          s_stored;              /* last SB whose tile wave 2 has read back out of LDS */
+    __shared__ volatile int          s_halo;                /* last SB whose top halo rows (the SB row above's bottom rows) are in LDS */
     const int tid = threadIdx.x;
-    if (tid == 0) { s_job = (int)atomicAdd(ticket, 1u); s_stored = -1; }
+    if (tid == 0) { s_job = (int)atomicAdd(ticket, 1u); s_stored = -1; s_halo = -1; }
     if (tid < 64) s_thr[tid] = (uint32_t)thr.mblim[tid] | ((uint32_t)thr.lim[tid] << 8) | ((uint32_t)thr.hev_thr[tid] << 16);
     __syncthreads();
     const int job = s_job;
@@ -388,22 +389,37 @@ __global__ __launch_bounds__(256) void svt_lf_kernel(const lf_pic_dev *__restric
     unsigned long long tm_ = prof ? __builtin_amdgcn_s_memtime() : 0;
 #define LF_MARK(i, who) do { if (prof && tid == (who)) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_lf_prof[i], n_ - tm_); tm_ = n_; } } while (0)
 
-    /* wave 2: stage SB `sc` into buffer sc & 1 (new columns + top halo + descriptors); the left halo comes from the
-     * filter waves, except for SB 0 which has none */
-    auto stage = [&](int sc) {
+    /* wave 2 stages SB `sc` into buffer sc & 1 in two parts.  stage(sc): the SB's own rows and its edge descriptors --
+     * nothing of it depends on another SB row, it runs one SB ahead of the filter waves.  stage_halo(sc): the 8 rows
+     * above the SB, which the SB row above finishes with (sb_row-1, sc+1); only the horizontal-edge pass needs them, so
+     * they are fetched while the vertical-edge pass of the same SB runs: the hand-over between SB rows has the poll, 8
+     * rows and one pass on its critical path instead of a whole tile and both passes.  The left halo comes from the
+     * filter waves, except for SB 0 which has none. */
+    auto stage_halo = [&](int sc) {
         const int     buf = sc & 1;
         const lf_geom g = lf_geometry(sb_row, sc, W, H);
         if (sb_row > 0) { /* wait for (sb_row-1, sc+1): its tiles up to sc+1 have been written back */
             const uint32_t need = (uint32_t)(sc + 2 < sb_cols ? sc + 2 : sb_cols);
             if (lane == 0)
                 while (__hip_atomic_load(&P.progress[sb_row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(1);
+            LF_MARK(0, 128);
+            tile_io<2>(wide_y, true, P.planes.y, P.planes.y_stride, ytile[buf], YS, g.x0 - 8, g.y0 - 8, 8, 0, g.vw, 8, 8, 8 + g.vh - 8, lane, 64);
+            if (!P.y_only) {
+                tile_io<1>(wide_c, true, P.planes.u, P.planes.uv_stride, ctile[buf][0], CS, g.cx0 - 8, g.cy0 - 8, 8, 0, g.cvw, 8, 8, 8 + g.cvh - 8, lane, 64);
+                tile_io<1>(wide_c, true, P.planes.v, P.planes.uv_stride, ctile[buf][1], CS, g.cx0 - 8, g.cy0 - 8, 8, 0, g.cvw, 8, 8, 8 + g.cvh - 8, lane, 64);
+            }
         }
-        LF_MARK(0, 128);
-        /* tile columns 8.. hold the SB's own samples; rows 8-hy.. ; seam rows: ty < 8 (top halo) and the SB's last 8 rows */
-        tile_io<11>(wide_y, true, P.planes.y, P.planes.y_stride, ytile[buf], YS, g.x0 - 8, g.y0 - 8, 8, 8 - g.hy, g.vw, g.vh + g.hy, 8, 8 + g.vh - 8, lane, 64, &s_stored, sc - 2);
+        /* LDS accesses of one wave are ordered: the flag lands after the rows */
+        if (lane == 0) s_halo = sc;
+    };
+    auto stage = [&](int sc) {
+        const int     buf = sc & 1;
+        const lf_geom g = lf_geometry(sb_row, sc, W, H);
+        /* tile columns 8.. hold the SB's own samples, rows 8..; seam rows: the SB's last 8 rows */
+        tile_io<11>(wide_y, true, P.planes.y, P.planes.y_stride, ytile[buf], YS, g.x0 - 8, g.y0 - 8, 8, 8, g.vw, g.vh, 8, 8 + g.vh - 8, lane, 64, &s_stored, sc - 2);
         if (!P.y_only) {
-            tile_io<3>(wide_c, true, P.planes.u, P.planes.uv_stride, ctile[buf][0], CS, g.cx0 - 8, g.cy0 - 8, 8, 8 - g.hy, g.cvw, g.cvh + g.hy, 8, 8 + g.cvh - 8, lane, 64);
-            tile_io<3>(wide_c, true, P.planes.v, P.planes.uv_stride, ctile[buf][1], CS, g.cx0 - 8, g.cy0 - 8, 8, 8 - g.hy, g.cvw, g.cvh + g.hy, 8, 8 + g.cvh - 8, lane, 64);
+            tile_io<3>(wide_c, true, P.planes.u, P.planes.uv_stride, ctile[buf][0], CS, g.cx0 - 8, g.cy0 - 8, 8, 8, g.cvw, g.cvh, 8, 8 + g.cvh - 8, lane, 64);
+            tile_io<3>(wide_c, true, P.planes.v, P.planes.uv_stride, ctile[buf][1], CS, g.cx0 - 8, g.cy0 - 8, 8, 8, g.cvw, g.cvh, 8, 8 + g.cvh - 8, lane, 64);
         }
         LF_MARK(1, 128);
         /* edge descriptors of this SB (built by svt_lf_desc_kernel): luma vertical 64, luma horizontal 64, chroma 16 + 16 */
@@ -423,12 +439,14 @@ __global__ __launch_bounds__(256) void svt_lf_kernel(const lf_pic_dev *__restric
         const lf_geom g = lf_geometry(sb_row, sc, W, H);
         const bool    last = sc + 1 == sb_cols;
         if (wave == 2) {
+            stage_halo(sc);
             if (!last) stage(sc + 1);
         } else if (wave == 0) {
             /* vertical edges: lane = sample row; horizontal edges: lane = sample column (LDS accesses of one wave are
              * ordered, no barrier between the two passes) */
             if (lane < g.vh) lf_line<true>(ytile[buf] + (8 + lane) * YS + 8, 1, 8, &s_desc[buf][(lane >> 3) * 8], 1, s_thr);
             LF_MARK(3, 0);
+            while (s_halo < sc) __builtin_amdgcn_s_sleep(1); /* the rows above the SB have arrived */
             if (lane < g.vw) lf_line<false>(ytile[buf] + 8 * YS + 8 + lane, YS, nrows, &s_desc[buf][64 + (lane >> 3)], 8, s_thr);
             LF_MARK(4, 0);
             if (!last) {
@@ -442,6 +460,7 @@ __global__ __launch_bounds__(256) void svt_lf_kernel(const lf_pic_dev *__restric
         } else if (wave == 1 && !P.y_only) {
             const int pl = lane >> 5, l5 = lane & 31;
             if (l5 < g.cvh) lf_line<true>(ctile[buf][pl] + (8 + l5) * CS + 8, 1, 4, &s_desc[buf][128 + (l5 >> 3) * 4], 1, s_thr);
+            while (s_halo < sc) __builtin_amdgcn_s_sleep(1);
             if (l5 < g.cvw) lf_line<false>(ctile[buf][pl] + 8 * CS + 8 + l5, CS, (nrows + 1) >> 1, &s_desc[buf][144 + (l5 >> 3)], 4, s_thr);
             if (!last) {
                 while (s_stored < sc - 1) __builtin_amdgcn_s_sleep(1);
