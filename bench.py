@@ -140,12 +140,15 @@ def main():
         idx = [i for i in range(1, MINIGOP + 1) if LAYER[i - 1] == layer]
         p = MC.preset(preset_name, 2, layer, 4)
         p.same_ref_poc = 1 if layer == 0 else 0
-        n = len(idx)
-        cur = (B.PaPicture * n)(*[pics[i].desc() for i in idx])
-        r0 = (B.PaPicture * n)(*[pics[refs(i)[0]].desc() for i in idx])
-        r1 = (B.PaPicture * n)(*[pics[refs(i)[1]].desc() for i in idx])
-        res = (C.c_void_p * n)(*[results[i].data_ptr() for i in idx])
-        me_launches.append((n, cur, r0, r1, p, res))
+        chunk = max(1, int(os.environ.get("SVT_BENCH_ME_CHUNK", "8")))   # pictures per launch (a layer may be split)
+        for j0 in range(0, len(idx), chunk):
+            sub = idx[j0:j0 + chunk]
+            n = len(sub)
+            cur = (B.PaPicture * n)(*[pics[i].desc() for i in sub])
+            r0 = (B.PaPicture * n)(*[pics[refs(i)[0]].desc() for i in sub])
+            r1 = (B.PaPicture * n)(*[pics[refs(i)[1]].desc() for i in sub])
+            res = (C.c_void_p * n)(*[results[i].data_ptr() for i in sub])
+            me_launches.append((n, cur, r0, r1, p, res))
     # launches -> ME streams: largest first onto the least loaded stream
     me_slot, load = [0] * len(me_launches), [0] * len(me_ctxs)
     for li in sorted(range(len(me_launches)), key=lambda j: -me_launches[j][0]):
