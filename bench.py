@@ -82,11 +82,32 @@ def main():
     n_me_streams = max(1, int(os.environ.get("SVT_BENCH_ME_STREAMS", "2")))
     for _ in range(n_me_streams - 1):
         streams.append(torch.cuda.Stream(device=local_rank, priority=prio[0]))
+    # optional: disjoint CU sets for the stages (SVT_BENCH_CU_SPLIT = CUs out of every 4 that ME gets, e.g. "3"): the contexts
+    # then own CU-masked streams and torch wraps them for events / cross-stream waits
+    cu_split = int(os.environ.get("SVT_BENCH_CU_SPLIT", "0"))
     ctxs = []
-    for st_ in streams:
-        c_ = C.c_void_p()
-        B.check(lib.svt_hip_ctx_create_on_stream(C.byref(c_), local_rank, C.c_void_p(st_.cuda_stream)))
-        ctxs.append(c_)
+    if cu_split:
+        n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        words = (n_cu + 31) // 32
+
+        def mask(pred):
+            m = (C.c_uint32 * words)()
+            for i in range(n_cu):
+                if pred((i // 8) % 4):   # a quarter granule of every XCD whichever way the driver enumerates the CUs
+                    m[i // 32] |= 1 << (i % 32)
+            return m
+
+        m_me, m_rest = mask(lambda q: q < cu_split), mask(lambda q: q >= cu_split)
+        for k_ in range(len(streams)):
+            c_ = C.c_void_p()
+            B.check(lib.svt_hip_ctx_create_cu_mask(C.byref(c_), local_rank, m_me if k_ in (0, 3) or k_ > 3 else m_rest, words))
+            ctxs.append(c_)
+            streams[k_] = torch.cuda.ExternalStream(lib.svt_hip_ctx_stream(c_), device=local_rank)
+    else:
+        for st_ in streams:
+            c_ = C.c_void_p()
+            B.check(lib.svt_hip_ctx_create_on_stream(C.byref(c_), local_rank, C.c_void_p(st_.cuda_stream)))
+            ctxs.append(c_)
     ctx = ctxs[0]
 
     Wd, Hd = args.width, args.height

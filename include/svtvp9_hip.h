@@ -148,6 +148,12 @@ int32_t svt_hip_me_params_preset(svt_me_params *p, int32_t pic_width, int32_t pi
 int32_t svt_hip_ctx_create(svt_hip_ctx **ctx, int32_t device_ordinal);
 /* Same, but all work is enqueued on a caller-provided hipStream_t (passed as void*). */
 int32_t svt_hip_ctx_create_on_stream(svt_hip_ctx **ctx, int32_t device_ordinal, void *hip_stream);
+/* A context whose own stream is restricted to a set of compute units (hipExtStreamCreateWithCUMask; bit i of the mask
+ * words = CU i in the driver's enumeration).  Stages of a pipeline that run concurrently can be given disjoint CU sets
+ * so that each CU executes one kernel (its LDS, instruction cache and issue slots are not shared between stages). */
+int32_t svt_hip_ctx_create_cu_mask(svt_hip_ctx **ctx, int32_t device, const uint32_t *cu_mask, int32_t mask_words);
+/* the context's HIP stream (hipStream_t), e.g. to record events on it or to make other streams wait for it */
+void *svt_hip_ctx_stream(svt_hip_ctx *ctx);
 void    svt_hip_ctx_destroy(svt_hip_ctx *ctx);
 int32_t svt_hip_ctx_synchronize(svt_hip_ctx *ctx);
 const char *svt_hip_last_error(void);

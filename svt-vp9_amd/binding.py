@@ -117,7 +117,7 @@ class McPicture(C.Structure):
 
 # every symbol include/svtvp9_hip.h declares
 EXPORTS = [
-    "svt_hip_sb_count", "svt_hip_me_params_preset", "svt_hip_ctx_create", "svt_hip_ctx_create_on_stream",
+    "svt_hip_sb_count", "svt_hip_me_params_preset", "svt_hip_ctx_create", "svt_hip_ctx_create_on_stream", "svt_hip_ctx_create_cu_mask", "svt_hip_ctx_stream",
     "svt_hip_ctx_destroy", "svt_hip_ctx_synchronize", "svt_hip_last_error", "svt_hip_last_kernel_ms",
     "svt_hip_me_picture_device", "svt_hip_me_batch_device", "svt_hip_me_picture", "svt_hip_sad_loop_batch_device",
     "svt_hip_me_zz_sad_device", "svt_hip_me_similar_collocated", "svt_hip_pa_prepare_batch_device", "svt_hip_pa_mean_variance_device",
@@ -137,6 +137,8 @@ def load():
             raise RuntimeError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
         _lib = C.CDLL(LIB_PATH)
         _lib.svt_hip_last_error.restype = C.c_char_p
+        _lib.svt_hip_ctx_stream.restype = C.c_void_p
+        _lib.svt_hip_ctx_stream.argtypes = [C.c_void_p]
         _lib.svt_hip_last_kernel_ms.restype = C.c_float
         _lib.svt_hip_last_kernel_ms.argtypes = [C.c_void_p]
         _lib.svt_hip_lf_thresh_init.restype = None

@@ -22,7 +22,7 @@ extern "C" const char *svt_hip_last_error(void) { return g_err; }
 
 extern "C" int32_t svt_hip_sb_count(int32_t w, int32_t h) { return ((w + 63) / 64) * ((h + 63) / 64); }
 
-static int32_t ctx_create(svt_hip_ctx **out, int32_t device, void *stream, int owns) {
+static int32_t ctx_create(svt_hip_ctx **out, int32_t device, void *stream, int owns, const uint32_t *cu_mask = nullptr, int mask_words = 0) {
     if (!out) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "ctx: null");
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
@@ -31,7 +31,9 @@ static int32_t ctx_create(svt_hip_ctx **out, int32_t device, void *stream, int o
     svt_hip_ctx *c = (svt_hip_ctx *)calloc(1, sizeof *c);
     if (!c) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "ctx: malloc");
     c->device = device;
-    if (owns) {
+    if (owns && cu_mask) {
+        if (hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask_words, cu_mask) != hipSuccess) { free(c); return svt_set_error(SVT_HIP_ERR_DEVICE, "ctx: CU-masked stream"); }
+    } else if (owns) {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { free(c); return svt_set_error(SVT_HIP_ERR_DEVICE, "ctx: stream"); }
     } else {
         c->stream = (hipStream_t)stream;
@@ -45,6 +47,12 @@ static int32_t ctx_create(svt_hip_ctx **out, int32_t device, void *stream, int o
 }
 extern "C" int32_t svt_hip_ctx_create(svt_hip_ctx **ctx, int32_t device) { return ctx_create(ctx, device, nullptr, 1); }
 extern "C" int32_t svt_hip_ctx_create_on_stream(svt_hip_ctx **ctx, int32_t device, void *s) { return ctx_create(ctx, device, s, 0); }
+
+extern "C" int32_t svt_hip_ctx_create_cu_mask(svt_hip_ctx **ctx, int32_t device, const uint32_t *cu_mask, int32_t mask_words) {
+    if (!cu_mask || mask_words < 1) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "ctx: empty CU mask");
+    return ctx_create(ctx, device, nullptr, 1, cu_mask, mask_words);
+}
+extern "C" void *svt_hip_ctx_stream(svt_hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 extern "C" void svt_hip_ctx_destroy(svt_hip_ctx *c) {
     if (!c) return;
