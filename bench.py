@@ -84,7 +84,9 @@ def main():
         streams.append(torch.cuda.Stream(device=local_rank, priority=prio[0]))
     # optional: disjoint CU sets for the stages (SVT_BENCH_CU_SPLIT = CUs out of every 4 that ME gets, e.g. "3"): the contexts
     # then own CU-masked streams and torch wraps them for events / cross-stream waits
-    cu_split = int(os.environ.get("SVT_BENCH_CU_SPLIT", "0"))
+    cu_env = os.environ.get("SVT_BENCH_CU_SPLIT", "0").split(",")
+    cu_split = int(cu_env[0])
+    rest_from = int(cu_env[1]) if len(cu_env) > 1 else cu_split   # "4,2": ME everywhere, TQ / LF on the upper half of each XCD
     ctxs = []
     if cu_split:
         n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
@@ -97,7 +99,7 @@ def main():
                     m[i // 32] |= 1 << (i % 32)
             return m
 
-        m_me, m_rest = mask(lambda q: q < cu_split), mask(lambda q: q >= cu_split)
+        m_me, m_rest = mask(lambda q: q < cu_split), mask(lambda q: q >= rest_from)
         for k_ in range(len(streams)):
             c_ = C.c_void_p()
             B.check(lib.svt_hip_ctx_create_cu_mask(C.byref(c_), local_rank, m_me if k_ in (0, 3) or k_ > 3 else m_rest, words))
