@@ -7,6 +7,7 @@
 extern "C" {
 #endif
 /* leaf kernels */
+uint64_t oracle_spatial_full_distortion(const uint8_t *src, int ss, const uint8_t *rec, int rs, int w, int h);
 uint32_t oracle_sad_nxm(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int h, int w);
 uint32_t oracle_avg_sad(const uint8_t *src, int src_stride, const uint8_t *r1, int s1, const uint8_t *r2, int s2,
                         int h, int w);

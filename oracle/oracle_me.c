@@ -379,18 +379,22 @@ static pl_t plane_at(const me_sb_t *s, int list, const uint8_t *tl, int rs, int 
     return r;
 }
 
+/* eb_vp9_spatial_full_distortion_kernel, C_DEFAULT/EbPictureOperators_C.c:337-356 (exported so that the tests can pin it
+ * against the reference leaf: the SSD search around it cannot be run in the reference build) */
+uint64_t oracle_spatial_full_distortion(const uint8_t *src, int ss, const uint8_t *rec, int rs, int w, int h) {
+    uint64_t d = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int e = (int)src[y * ss + x] - (int)rec[y * rs + x];
+            d += (uint64_t)(e * e);
+        }
+    return d;
+}
+
 /* distortion of one candidate block per fractional_search_method */
 static uint64_t cand_dist(const me_sb_t *s, const uint8_t *src, int ss, pl_t c, int w, int h) {
     int m = s->p->fractional_search_method;
-    if (m == SVT_SSD_SEARCH) { /* C_DEFAULT/EbPictureOperators_C.c:337-356 */
-        uint64_t d = 0;
-        for (int y = 0; y < h; y++)
-            for (int x = 0; x < w; x++) {
-                int e = (int)src[y * ss + x] - (int)c.p[y * c.stride + x];
-                d += (uint64_t)(e * e);
-            }
-        return d;
-    }
+    if (m == SVT_SSD_SEARCH) return oracle_spatial_full_distortion(src, ss, c.p, c.stride, w, h);
     if (m == SVT_SUB_SAD_SEARCH) return (uint64_t)(oracle_sad_nxm(src, ss << 1, c.p, c.stride << 1, h >> 1, w)) << 1;
     return oracle_sad_nxm(src, ss, c.p, c.stride, h, w);
 }

@@ -126,6 +126,23 @@ def test_lf_frame_vs_reference(w, h, seed, sharp):
 
 
 @live
+def test_spatial_full_distortion_vs_reference_leaf():
+    """the SSD metric of the fractional search (config C5): the oracle's leaf vs eb_vp9_spatial_full_distortion_kernel
+    (the SSD search loop itself cannot run in the reference build: it indexes its table with the yasm-only Log2f)"""
+    ref, ora = T.ref_kernels(), T.oracle()
+    ref.eb_vp9_spatial_full_distortion_kernel.restype = C.c_uint64
+    ora.oracle_spatial_full_distortion.restype = C.c_uint64
+    rng = np.random.default_rng(33)
+    for n in (8, 16, 32, 64):
+        for lo, hi in ((0, 256), (0, 2), (254, 256)):
+            a = rng.integers(lo, hi, (n, n + 8), dtype=np.uint8)
+            b = rng.integers(0, 256, (n, n + 24), dtype=np.uint8) if lo == 0 else (255 - a[:, :n]).repeat(2, 1)[:, :n + 24].copy()
+            want = ref.eb_vp9_spatial_full_distortion_kernel(a.ctypes.data_as(C.c_void_p), a.shape[1], b.ctypes.data_as(C.c_void_p), b.shape[1], n, n)
+            got = ora.oracle_spatial_full_distortion(a.ctypes.data_as(C.c_void_p), a.shape[1], b.ctypes.data_as(C.c_void_p), b.shape[1], n, n)
+            assert want == got, (n, lo, hi, want, got)
+
+
+@live
 def test_full_distortion_vs_reference_leaf():
     """T3: the oracle's coefficient-domain distortion vs the reference's full_distortion_kernel32bit, including
     differences that do not fit int16 (the reference squares them after an int16 truncation)."""
