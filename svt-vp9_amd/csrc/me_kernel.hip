@@ -16,9 +16,11 @@ extern __shared__ __align__(16) uint8_t svt_lds[];
 #define ME_WAVES_PER_EU 3 /* generic instance: 3 workgroups of 4 waves per CU: <= 168 VGPRs, <= 53 KB of LDS */
 #endif
 #ifndef ME_WAVES_PER_EU_SPEC
-/* specialised instances fit 128 VGPRs (a dozen spills): LDS still admits 3 workgroups per CU, but a SIMD then has room for
- * a wave of the deblocking kernel (96 VGPRs) next to its three ME waves when the stages overlap */
-#define ME_WAVES_PER_EU_SPEC 4
+/* specialised instances are held to 96 VGPRs (no spills, or two): their LDS admits 4 workgroups per CU = 4 waves per
+ * SIMD = 384 of a SIMD's 512 registers, and the remaining 128 are exactly what one wave of the 32x32 transform kernel
+ * (128), of the deblocking kernel (96) or of the 16x16 transform kernel (80) needs to sit beside them when the stages
+ * overlap -- at 112 VGPRs per ME wave none of them fitted and every such wave had to displace an ME workgroup */
+#define ME_WAVES_PER_EU_SPEC 5
 #endif
 /* One workgroup per (picture, SB).  blockIdx -> work item mapping is XCD-aware: consecutive work items
  * (neighbouring SBs, which share most of their reference window) are placed on the same XCD so that the
