@@ -1419,7 +1419,10 @@ SVT_DEV void me_hme_plan_level(const me_ctx_t *c, int list, int lvl, int16_t xsc
     st->hme_bstart[0] = 0;
     for (int k = 0; k < 4; k++) {
         const int rw = k & 1, rh = k >> 1;
-        st->hme_keys[k] = ~0ull;
+        {   /* written as two dwords: as a 64-bit constant the compiler hoists the pair out of the SB's whole life and spills it */
+            uint32_t *kw_ = (uint32_t *)&st->hme_keys[k];
+            kw_[0] = ~0u; kw_[1] = ~0u;
+        }
         st->hme_cw[k] = 0; st->hme_ch[k] = 0; st->hme_cox[k] = 0; st->hme_coy[k] = 0;
         if (single ? k != 0 : (rw >= NW || rh >= NH)) continue;
         int16_t w, h, ox, oy;
