@@ -265,6 +265,11 @@ typedef struct svt_quant_tables {
     int16_t zbin[2], round[2], quant[2], quant_shift[2], dequant[2];
 } svt_quant_tables;
 
+/* Host-side: the tables of one (q index, plane) as eb_vp9_init_quantizer derives them (sharpness 0): q_index 0..255;
+ * y_dc_step = eb_vp9_dc_quant(q_index, 0) (it selects the zero-bin factor, get_qzbin_factor :192-204); dc_step / ac_step =
+ * eb_vp9_dc_quant / eb_vp9_ac_quant with the plane's deltas (VPX/vp9_quant_common.c). */
+int32_t svt_hip_quant_tables_init(int32_t q_index, int32_t y_dc_step, int32_t dc_step, int32_t ac_step, svt_quant_tables *out);
+
 /* One transform block of perform_coding_loop (Codec/EbEncDecProcess.c:365-587). */
 typedef struct svt_tq_block {
     uint32_t src_off;    /* byte offset of the block's top-left in the source plane  */

@@ -12,6 +12,7 @@ import me_configs as MC  # noqa: E402
 import svt_testlib as T  # noqa: E402
 
 G = T.GOLDEN_DIR
+QUANT_GOLDEN_DELTAS = ((0, 0, 0), (-3, 4, -5))
 RATE_GOLDEN_CASES = ((1, 256, 128, False), (2, 128, 64, False), (11, 128, 64, True))
 MC_GOLDEN_CASES = ((1, 192, 128, 1), (2, 128, 72, 1), (3, 64, 64, 0), (4, 200, 136, 1))
 
@@ -83,6 +84,13 @@ def main():
         case = T.make_rate_case(seed, width=w, height=h, scan=scan, extreme=ext)
         rate[f"bits|{seed}|{w}|{h}|{int(ext)}"] = T.ref_rate_run(case)[0]
     np.savez_compressed(os.path.join(G, "rate_reference.npz"), **rate)
+    # ---- quantiser tables: the reference's eb_vp9_init_quantizer for all 256 q indices, two delta settings ----
+    import subprocess
+    qt = {}
+    for deltas in QUANT_GOLDEN_DELTAS:
+        out = subprocess.check_output([os.path.join(T.REF_DIR, "ref_quant_tables")] + [str(d) for d in deltas]).decode()
+        qt["|".join(map(str, deltas))] = np.array([[int(x) for x in line.split()] for line in out.strip().splitlines()], np.int32)
+    np.savez_compressed(os.path.join(G, "quant_reference.npz"), **qt)
     for f in sorted(os.listdir(G)):
         print(f, os.path.getsize(os.path.join(G, f)))
 
