@@ -66,10 +66,16 @@ __device__ __forceinline__ void mc_tile(const uint8_t *plane, int stride, int x,
     p0 -= sh;
     const uint32_t tl = c_tap_lo[sx], th = c_tap_hi[sx];
     uint32_t       mid[NM];
+    /* wave-uniform shortcuts (whole waves of zero / full-sample motion are the common case in real pictures): without a
+     * vertical phase in the wave the 7 extra rows are neither fetched nor filtered, without a horizontal phase the taps
+     * are skipped.  Branches on ballots: every lane of the wave takes the same side. */
+    const bool any_sx = __builtin_amdgcn_ballot_w64(sx != 0) != 0, any_sy = __builtin_amdgcn_ballot_w64(sy != 0) != 0;
     _Pragma("unroll") for (int r = 0; r < NM; r++) {
+        if (!any_sy && (r < 3 || r >= 3 + NR)) { mid[r] = 0; continue; }
         const u32x4a4 d = *(const u32x4a4 *)(p0 + (ptrdiff_t)r * stride);
         /* bytes 0..11 of the row window (sample x - 3 first) */
         const uint32_t e0 = alignbyte(d.y, d.x, sh), e1 = alignbyte(d.z, d.y, sh), e2 = alignbyte(d.w, d.z, sh);
+        if (!any_sx) { mid[r] = alignbyte(e1, e0, 3); continue; }
         const uint32_t b0 = e0 ^ 0x80808080u, b1 = e1 ^ 0x80808080u, b2 = e2 ^ 0x80808080u;
         const int      bias = 128 * 128 + 64;
         int            a0 = __builtin_amdgcn_sdot4((int)b1, (int)th, __builtin_amdgcn_sdot4((int)b0, (int)tl, bias, false), false);
@@ -78,6 +84,10 @@ __device__ __forceinline__ void mc_tile(const uint8_t *plane, int stride, int x,
         int            a3 = __builtin_amdgcn_sdot4((int)alignbyte(b2, b1, 3), (int)th, __builtin_amdgcn_sdot4((int)alignbyte(b1, b0, 3), (int)tl, bias, false), false);
         const uint32_t f = pack4(finish(a0), finish(a1), finish(a2), finish(a3));
         mid[r] = sx ? f : alignbyte(e1, e0, 3); /* phase 0: the samples themselves (bytes 3..6) */
+    }
+    if (!any_sy) {
+        _Pragma("unroll") for (int yy = 0; yy < NR; yy++) out[yy] = mid[yy + 3];
+        return;
     }
     /* columns of the NM intermediate rows as byte streams: col[j][g] = rows 4g .. 4g+3 of column j (row NM = padding) */
     uint32_t col[4][NG];
