@@ -988,3 +988,24 @@ def hip_rate_batch(ctx, case):
     B.check(B.load().svt_hip_coeff_rate_batch(ctx, vp(case["qcoeff"]), C.c_size_t(case["qcoeff"].size), vp(case["blocks"]), len(case["blocks"]),
                                               vp(tb), vp(s), C.c_size_t(s.size), vp(bits)))
     return bits
+
+
+def ref_me_side(cur, prev, input_resolution, cur_mean, cur_var, ref_mean, ref_var, is_i_slice, is_used_as_reference):
+    """the reference's compute_zz_sad + eb_vp9_derive_similar_collocated_flag (oracle/_ref/ref_me_side).
+    Returns (non_moving_index, similar, similar_all_layers)."""
+    exe = os.path.join(REF_DIR, "ref_me_side")
+    h, w = prev.luma.shape
+    n = n_sb(w, h)
+    with tempfile.TemporaryDirectory() as td:
+        req, rsp = os.path.join(td, "req.bin"), os.path.join(td, "rsp.bin")
+        with open(req, "wb") as f:
+            f.write(struct.pack("<6i", 0x534D5653, w, h, input_resolution, int(is_i_slice), int(is_used_as_reference)))
+            for plane, org in ((cur.sixteenth, 16), (prev.full, 68)):
+                f.write(struct.pack("<4i", plane.shape[1], org, org, plane.shape[0]))
+                f.write(plane.tobytes())
+            f.write(struct.pack("<i", n))
+            f.write(cur_mean.astype(np.uint8).tobytes()); f.write(cur_var.astype("<u2").tobytes())
+            f.write(ref_mean.astype(np.uint8).tobytes()); f.write(ref_var.astype("<u2").tobytes())
+        subprocess.check_call([exe, req, rsp])
+        raw = np.frombuffer(open(rsp, "rb").read(), np.uint8)
+    return raw[:n].copy(), raw[n:2 * n].copy(), raw[2 * n:3 * n].copy()

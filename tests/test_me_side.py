@@ -76,3 +76,33 @@ def test_gpu_zz_sad_vs_oracle(w, h, res):
         assert np.array_equal(o[0], g[0]) and np.array_equal(o[1], g[1])
     finally:
         lib.svt_hip_ctx_destroy(ctx)
+
+
+@pytest.mark.skipif(not T.have_ref("ref_me_side"), reason="oracle/_ref/ref_me_side not built (reference absent)")
+@pytest.mark.parametrize("res,w,h", [(0, 328, 200), (2, 384, 256), (3, 640, 384), (1, 200, 72)])
+def test_oracle_and_host_vs_reference_me_side(res, w, h):
+    """compute_zz_sad and eb_vp9_derive_similar_collocated_flag of the reference built from source: non-moving index per SB
+    (incl. incomplete SBs) and both similarity flags, for I / non-I slices and referenced / unreferenced pictures"""
+    f = T.gen_clip(w, h, 2, 31 + res)
+    f[1][:64, :128] = f[0][:64, :128]
+    f[1][64:128, :64] = np.clip(f[0][64:128, :64].astype(np.int16) + 3, 0, 255).astype(np.uint8)
+    cur, prev = T.PaPic(f[1]), T.PaPic(f[0])
+    n = T.n_sb(w, h)
+    rng = np.random.default_rng(5 + res)
+    cm = rng.integers(0, 256, n).astype(np.uint8)
+    rm = np.clip(cm.astype(np.int16) + rng.integers(-14, 15, n), 0, 255).astype(np.uint8)
+    cv = rng.integers(0, 3000, n).astype(np.uint16)
+    rv = np.clip(cv.astype(np.int32) + rng.integers(-40, 41, n), 0, 65535).astype(np.uint16)
+    rv[::5] = 0
+    _, nmi = T.oracle_me_zz_sad(cur, prev, res)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    for i_slice in (0, 1):
+        for is_ref in (0, 1):
+            r_nmi, r_sim, r_all = T.ref_me_side(cur, prev, res, cm, cv, rm, rv, i_slice, is_ref)
+            assert np.array_equal(r_nmi, nmi)
+            a, b = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+            B.load().svt_hip_me_similar_collocated(vp(cm), vp(cv), vp(rm), vp(rv), n, i_slice, is_ref, vp(a), vp(b))
+            assert np.array_equal(a, r_sim) and np.array_equal(b, r_all)
+            T.oracle().svt_oracle_me_similar_collocated(vp(cm), vp(cv), vp(rm), vp(rv), n, i_slice, is_ref, vp(a), vp(b))
+            assert np.array_equal(a, r_sim) and np.array_equal(b, r_all)
+    assert len(set(nmi.tolist())) >= 2
