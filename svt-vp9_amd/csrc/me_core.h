@@ -237,7 +237,9 @@ typedef struct me_lds_layout {
     int32_t off_region;  /* integer reference samples of the current list's search region */
     int32_t off_planes;  /* B, H, J half-pel planes (3 x plane_bytes); aliased by HME window / SAD scratch */
     int32_t off_quarter; /* 32x32 quarter-resolution SB (only when HME level 1 is enabled) */
-    int32_t off_ssd;     /* SSD_SEARCH only: candidate SSDs [85][9] */
+    int32_t off_ssd;     /* SSD_SEARCH only: candidate SSDs [85][9], then the best SSD per PU [85] */
+    int32_t off_cand;    /* sub-pel candidate distortions [pu][8] / bi-pred distortion [pu]: cand_dwords dwords */
+    int32_t cand_dwords; /* 8 x (21 when the 8x8 PUs are never refined nor bi-predicted, else 85) */
     int32_t off_pred0;   /* host emulation only (the kernel keeps them in registers): list 0 prediction of the bi-pred lanes */
     int32_t region_stride, region_rows;
     int32_t plane_stride; /* row stride of the half-pel planes: they are narrower than the region (no search tail) */
@@ -268,9 +270,8 @@ typedef struct me_hme_win {
 
 /* per-SB state in LDS */
 typedef struct me_state_t {
-    union {                    /* the full-pel keys are dead once the best MVs are extracted, before the first cand use */
+    union {
         uint64_t key[85];      /* full-pel arg-min keys of the current list */
-        uint32_t cand[85 * 8]; /* sub-pel candidate distortions [pu][8]; bi-pred distortion [pu] */
         struct {               /* HME work list: dead once the level's results are in hme_x/y/sad, before the keys are set */
             int32_t    hme_nbatch, hme_bstart[ME_HME_MAX_WIN + 1]; /* batches of windows that fit the scratch together */
             me_hme_win hme_win[ME_HME_MAX_WIN];
@@ -288,7 +289,6 @@ typedef struct me_state_t {
     uint32_t red[8];           /* small sum reductions */
     uint32_t spu[85];          /* refined PUs of the current list, dense: pu | n << 7 | (px>>3) << 14 | (py>>3) << 17 | log2(w/8) << 20 */
     uint32_t supel[9];         /* su_pel_enable sums: sx,sy,ssad for 32/16/8 */
-    uint32_t best_ssd[85];     /* SSD_SEARCH: SSD of the current best sub-pel position of each PU (current list) */
     svt_plane refd[3];         /* descriptors (full, 1/4, 1/16) of the current list's reference picture, copied from HBM once */
     uint8_t  dir[88];          /* 85 used; padded so that the block below stays dword aligned */
     /* rows 0,2,4.. of the 1/16-resolution SB, read as dwords by the HME search: a misaligned ds_read is replayed at ~64
@@ -392,6 +392,8 @@ typedef struct me_ctx_t {
     uint8_t             *planes; /* LDS */
     uint8_t             *quarter_sb; /* LDS, valid when HME level 1 is enabled */
     uint32_t            *ssdc;       /* LDS, SSD_SEARCH only: SSD of the sub-pel candidates [pu][9] (8 = integer position) */
+    uint32_t            *best_ssd;   /* LDS, SSD_SEARCH only: SSD of the current best sub-pel position of each PU (current list) */
+    uint32_t            *cand;       /* LDS: sub-pel candidate distortions [pu][8]; bi-pred distortion [pu] */
     uint32_t            *pred0;  /* host emulation only: list 0 prediction dwords of the bi-pred lanes [16][256] */
     int                  pic_w, pic_h, sb_x, sb_y, sb_w, sb_h, sb_index;
     unsigned long long  *prof;   /* optional per-phase cycle accumulators (profiling builds), else NULL */
@@ -916,7 +918,7 @@ SVT_DEV void ph_halfpel(const me_ctx_t *c, int tid, int list, int sox, int soy, 
         uint32_t e = 0;
         const int cs = me_plane_stride(c, hpl) * step;
         uint32_t d = me_block_sad_rows(sp, ME_SB * step, cp, 0, cs, cs, w, r0, r0 + per, ssd ? &e : 0);
-        if (cand < 8) svt_group_add_var(&c->st->cand[pu * 8 + cand], d, nl);
+        if (cand < 8) svt_group_add_var(&c->cand[pu * 8 + cand], d, nl);
         if (ssd) svt_group_add_var(&c->ssdc[pu * 9 + cand], e, nl);
     }
 }
@@ -938,9 +940,9 @@ SVT_DEV void ph_halfpel_decide(const me_ctx_t *c, int tid, int list, int en32, i
             me_dmv_get(i, &sx, &sy);
             if (ssd) {
                 d[i] = c->ssdc[pu * 9 + i];
-                if (d[i] < bssd) { bssd = d[i]; best = c->st->cand[pu * 8 + i]; mv = me_pack_mv(xm + 2 * sx, ym + 2 * sy); }
+                if (d[i] < bssd) { bssd = d[i]; best = c->cand[pu * 8 + i]; mv = me_pack_mv(xm + 2 * sx, ym + 2 * sy); }
             } else {
-                d[i] = c->st->cand[pu * 8 + i];
+                d[i] = c->cand[pu * 8 + i];
                 if (sub_sad) d[i] <<= 1;
                 if (d[i] < best) { best = d[i]; mv = me_pack_mv(xm + 2 * sx, ym + 2 * sy); }
             }
@@ -959,7 +961,7 @@ SVT_DEV void ph_halfpel_decide(const me_ctx_t *c, int tid, int list, int en32, i
         c->st->best_sad[list][n] = best;
         c->st->best_mv[list][n]  = mv;
         c->st->dir[n]            = dir;
-        if (ssd) c->st->best_ssd[n] = bssd;
+        if (ssd) c->best_ssd[n] = bssd;
     }
 }
 
@@ -1022,7 +1024,7 @@ SVT_DEV void ph_quarterpel(const me_ctx_t *c, int tid, int list, int sox, int so
         uint32_t sq = 0;
         uint32_t d = r0 < r1 ? me_block_sad_rows(sp, ME_SB * step, a, b, me_plane_stride(c, (int)(e & 3)) * step,
                                                  me_plane_stride(c, (int)((e >> 4) & 3)) * step, w, r0, r1, ssd ? &sq : 0) : 0;
-        svt_group_add_u32(&c->st->cand[pu * 8 + pos], d, nl);
+        svt_group_add_u32(&c->cand[pu * 8 + pos], d, nl);
         if (ssd) svt_group_add_u32(&c->ssdc[pu * 9 + pos], sq, nl);
     }
 }
@@ -1034,7 +1036,7 @@ SVT_DEV void ph_quarterpel_decide(const me_ctx_t *c, int tid, int list, int en32
         if (!me_pu_refined(c, pu, en32, en16, en8)) continue;
         int      n    = me_pu_nidx(pu);
         uint32_t best = c->st->best_sad[list][n], mv = c->st->best_mv[list][n];
-        uint32_t bssd = ssd ? c->st->best_ssd[n] : 0;
+        uint32_t bssd = ssd ? c->best_ssd[n] : 0;
         int16_t  xm = me_mvx(mv), ym = me_mvy(mv);
         int      method = (ym & 2) + ((xm & 2) >> 1);
         int      dir = c->st->dir[n];
@@ -1044,16 +1046,16 @@ SVT_DEV void ph_quarterpel_decide(const me_ctx_t *c, int tid, int list, int en32
             me_dmv_get(i, &sx, &sy);
             if (ssd) {
                 uint32_t e = c->ssdc[pu * 9 + i];
-                if (e < bssd) { bssd = e; best = c->st->cand[pu * 8 + i]; mv = me_pack_mv(xm + sx, ym + sy); }
+                if (e < bssd) { bssd = e; best = c->cand[pu * 8 + i]; mv = me_pack_mv(xm + sx, ym + sy); }
             } else {
-                uint32_t d = c->st->cand[pu * 8 + i];
+                uint32_t d = c->cand[pu * 8 + i];
                 if (sub_sad) d <<= 1;
                 if (d < best) { best = d; mv = me_pack_mv(xm + sx, ym + sy); }
             }
         }
         c->st->best_sad[list][n] = best;
         c->st->best_mv[list][n]  = mv;
-        if (ssd) c->st->best_ssd[n] = bssd;
+        if (ssd) c->best_ssd[n] = bssd;
     }
 }
 
@@ -1137,7 +1139,7 @@ SVT_DEV void ph_bipred(const me_ctx_t *c, int tid, int sox, int soy, const uint3
                 dsum = svt_sad4(av, s, dsum);
             }
         }
-        svt_group_add_u32(&c->st->cand[pu], dsum, sh > 6 ? 64 : 1 << sh);
+        svt_group_add_u32(&c->cand[pu], dsum, sh > 6 ? 64 : 1 << sh);
         SVT_SCHED_FENCE();
     }
 }
@@ -1152,7 +1154,7 @@ SVT_DEV void ph_output(const me_ctx_t *c, int tid, svt_me_pu_result *out, uint32
         int      total = nlist;
         uint32_t l0 = c->st->best_sad[0][n], l1 = nlist == 2 ? c->st->best_sad[1][n] : 0, bi = 0;
         if (nlist == 2 && me_pu_bipred(c, pu)) {
-            bi = c->st->cand[pu];
+            bi = c->cand[pu];
             if (sub_sad) bi <<= 1;
             total = 3;
         }
@@ -1792,13 +1794,13 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         }
         ME_MARK(9);
         if (en32 || en16 || en8 || enq) {
-            ME_PHASE(for (int t = tid; t < 85 * 9; t += SVT_NT) { if (t < 85 * 8) st->cand[t] = 0; if (c->ssdc) c->ssdc[t] = 0; }
+            ME_PHASE(for (int t = tid; t < 85 * 9; t += SVT_NT) { if (t < c->L.cand_dwords) c->cand[t] = 0; if (c->ssdc) c->ssdc[t] = 0; }
                      ph_subpel_prep(c, tid, en32, en16, en8));
             ME_PHASE(ph_halfpel(c, tid, list, sox, soy, en32, en16, en8));
             ME_PHASE(ph_halfpel_decide(c, tid, list, en32, en16, en8));
             ME_MARK(10);
             if (enq) {
-                ME_PHASE(for (int t = tid; t < 85 * 9; t += SVT_NT) { if (t < 85 * 8) st->cand[t] = 0; if (c->ssdc) c->ssdc[t] = 0; });
+                ME_PHASE(for (int t = tid; t < 85 * 9; t += SVT_NT) { if (t < c->L.cand_dwords) c->cand[t] = 0; if (c->ssdc) c->ssdc[t] = 0; });
                 ME_PHASE(ph_quarterpel(c, tid, list, sox, soy, en32, en16, en8));
                 ME_PHASE(ph_quarterpel_decide(c, tid, list, en32, en16, en8));
             }
@@ -1807,7 +1809,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         if (nlist == 2) {
             if (list == 0) ME_PHASE(ph_store_pred0(c, tid, sox, soy, ME_PRED0_REGS));
             else {
-                ME_PHASE(for (int t = tid; t < 85; t += SVT_NT) st->cand[t] = 0);
+                ME_PHASE(for (int t = tid; t < 85; t += SVT_NT) c->cand[t] = 0);
                 ME_PHASE(ph_bipred(c, tid, sox, soy, ME_PRED0_REGS));
             }
             ME_MARK(12);

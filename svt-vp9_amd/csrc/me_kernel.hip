@@ -45,6 +45,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC != 0 ?
     c.planes = svt_lds + L.off_planes;
     c.quarter_sb  = svt_lds + L.off_quarter;
     c.ssdc        = p.fractional_search_method == SVT_SSD_SEARCH ? (uint32_t *)(svt_lds + L.off_ssd) : nullptr;
+    c.best_ssd    = c.ssdc ? c.ssdc + 85 * 9 : nullptr;
+    c.cand        = (uint32_t *)(svt_lds + L.off_cand);
     c.pred0       = (uint32_t *)(svt_lds + L.off_pred0);
     c.pic_w = pic_w; c.pic_h = pic_h; c.sb_index = sb; c.prof = prof;
     c.sb_x = (sb % nx) * ME_SB; c.sb_y = (sb / nx) * ME_SB;

@@ -28,7 +28,13 @@ static inline int me_lds_layout_compute(const svt_me_params *p, me_lds_layout *L
     L->off_region    = off; off += me_round_up(L->region_rows * rs, 16);
     L->off_planes    = off; L->scratch_bytes = 3 * L->plane_bytes; off += L->scratch_bytes;
     L->off_quarter   = off; if (p->enable_hme_level_1_flag) off += 32 * 32;
-    L->off_ssd       = off; if (p->fractional_search_method == SVT_SSD_SEARCH) off += me_round_up(85 * 9 * 4, 16);
+    L->off_ssd       = off; if (p->fractional_search_method == SVT_SSD_SEARCH) off += me_round_up(85 * 10 * 4, 16);
+    /* cu8x8_mode == 1: PUs 21..84 are neither refined (me_pu_refined) nor bi-predicted (me_pu_bipred) */
+    L->cand_dwords   = 8 * (p->cu8x8_mode == 1 ? 21 : 85);
+    /* a short table lives in the bytes of the state's first union (full-pel keys / HME work list: neither is live while the
+     * sub-pel and bi-pred candidates are) */
+    if ((size_t)L->cand_dwords * 4 <= sizeof(((me_state_t *)0)->key)) L->off_cand = L->off_state;
+    else { L->off_cand = off; off += me_round_up(L->cand_dwords * 4, 16); }
     L->off_pred0     = off;
 #ifdef SVT_HOST_EMU /* the kernel keeps list 0's prediction dwords in registers */
     if (p->num_ref_lists == 2) off += 16 * 256 * 4;
