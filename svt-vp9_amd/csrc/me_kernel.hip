@@ -16,10 +16,11 @@ extern __shared__ __align__(16) uint8_t svt_lds[];
 #define ME_WAVES_PER_EU 3 /* generic instance: 3 workgroups of 4 waves per CU: <= 168 VGPRs, <= 53 KB of LDS */
 #endif
 #ifndef ME_WAVES_PER_EU_SPEC
-/* specialised instances are held to 96 VGPRs (no spills, or two): their LDS admits 4 workgroups per CU = 4 waves per
- * SIMD = 384 of a SIMD's 512 registers, and the remaining 128 are exactly what one wave of the 32x32 transform kernel
- * (128), of the deblocking kernel (96) or of the 16x16 transform kernel (80) needs to sit beside them when the stages
- * overlap -- at 112 VGPRs per ME wave none of them fitted and every such wave had to displace an ME workgroup */
+/* specialised instances are held to 96 VGPRs (no spills): the 2160p instance needs 31.9 KB of LDS = 25 allocation
+ * granules of 1280 bytes, so five workgroups fit a CU = 5 waves per SIMD = 480 of its 512 registers.  (The 1080p / 360p
+ * instances need ~36 KB: four workgroups, and then the 128 registers left on a SIMD are exactly one wave of the 32x32
+ * transform kernel, of the deblocking kernel (96) or of the 16x16 transform kernel (80) beside them when the stages
+ * overlap -- at 112 VGPRs per ME wave none of them fitted.) */
 #define ME_WAVES_PER_EU_SPEC 5
 #endif
 /* One workgroup per (picture, SB).  blockIdx -> work item mapping is XCD-aware: consecutive work items
