@@ -371,15 +371,22 @@ __global__ __launch_bounds__(256) void svt_lf_kernel(const lf_pic_dev *__restric
     __shared__ volatile int          s_stored;              /* last SB whose tile wave 2 has read back out of LDS */
     __shared__ volatile int          s_halo;                /* last SB whose top halo rows (the SB row above's bottom rows) are in LDS */
     const int tid = threadIdx.x;
-    if (tid == 0) { s_job = (int)atomicAdd(ticket, 1u); s_stored = -1; s_halo = -1; }
     if (tid < 64) s_thr[tid] = (uint32_t)thr.mblim[tid] | ((uint32_t)thr.lim[tid] << 8) | ((uint32_t)thr.hev_thr[tid] << 16);
+    /* Persistent workgroups: each takes SB rows by ticket until none is left.  Tickets run over the rows of all pictures
+     * interleaved (row 0 of every picture, then row 1, ...): the row a workgroup depends on, (pic, sb_row - 1), always
+     * holds an earlier ticket and is therefore being worked on -- no residency assumption, no deadlock -- and only as
+     * many rows are resident as the wavefront can keep busy, instead of every row of every picture spinning on its
+     * predecessor while it occupies LDS and registers other kernels could use. */
+    for (;;) {
+    __syncthreads(); /* the previous row of this workgroup is complete (its last write-back included) */
+    if (tid == 0) { s_job = (int)atomicAdd(ticket, 1u); s_stored = -1; s_halo = -1; }
     __syncthreads();
     const int job = s_job;
-    if (job >= n_pics * rows_per_pic) return;
-    const lf_pic_dev P = pics[job / rows_per_pic];
-    const int sb_row = job % rows_per_pic;
+    if (job >= n_pics * rows_per_pic) break;
+    const lf_pic_dev P = pics[job % n_pics];
+    const int sb_row = job / n_pics;
     const int sb_cols = (P.mi_cols + 7) >> 3, sb_rows = (P.mi_rows + 7) >> 3;
-    if (sb_row >= sb_rows) return;
+    if (sb_row >= sb_rows) continue;
     const int W = P.planes.width, H = P.planes.height;
     const int mi_row = sb_row * 8;
     const int wave = tid >> 6, lane = tid & 63;
@@ -491,6 +498,7 @@ __global__ __launch_bounds__(256) void svt_lf_kernel(const lf_pic_dev *__restric
         }
     }
 #undef LF_MARK
+    } /* next ticket */
 }
 } // namespace
 
@@ -529,7 +537,11 @@ static int32_t lf_launch(svt_hip_ctx *ctx, int n_pics, const svt_yuv_planes *d_r
     static const bool want_prof = getenv("SVT_HIP_LF_PROFILE") != nullptr;
     if (want_prof) { unsigned long long z[8] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lf_prof), z, sizeof z)); }
     hipLaunchKernelGGL(svt_lf_desc_kernel, dim3(n_pics * max_rows * max_cols), dim3(128), 0, ctx->stream, (const lf_pic_dev *)d, max_rows, max_cols);
-    hipLaunchKernelGGL(svt_lf_kernel, dim3(n_pics * max_rows), dim3(256), 0, ctx->stream, (const lf_pic_dev *)d, n_pics, *thr, cnt, max_rows, want_prof ? 1 : 0);
+    /* rows in flight per picture: a row takes ~60 SB steps and starts ~4 steps after the one above, so ~16 keep the
+     * wavefront of a 4K picture full; more would only wait */
+    static const int rows_in_flight = getenv("SVT_HIP_LF_ROWS") ? atoi(getenv("SVT_HIP_LF_ROWS")) : 16;
+    const int lf_wgs = n_pics * (max_rows < rows_in_flight ? max_rows : rows_in_flight);
+    hipLaunchKernelGGL(svt_lf_kernel, dim3(lf_wgs), dim3(256), 0, ctx->stream, (const lf_pic_dev *)d, n_pics, *thr, cnt, max_rows, want_prof ? 1 : 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     if (want_prof) {
