@@ -537,9 +537,10 @@ static int32_t lf_launch(svt_hip_ctx *ctx, int n_pics, const svt_yuv_planes *d_r
     static const bool want_prof = getenv("SVT_HIP_LF_PROFILE") != nullptr;
     if (want_prof) { unsigned long long z[8] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lf_prof), z, sizeof z)); }
     hipLaunchKernelGGL(svt_lf_desc_kernel, dim3(n_pics * max_rows * max_cols), dim3(128), 0, ctx->stream, (const lf_pic_dev *)d, max_rows, max_cols);
-    /* rows in flight per picture: a row takes ~60 SB steps and starts ~4 steps after the one above, so ~16 keep the
-     * wavefront of a 4K picture full; more would only wait */
-    static const int rows_in_flight = getenv("SVT_HIP_LF_ROWS") ? atoi(getenv("SVT_HIP_LF_ROWS")) : 16;
+    /* rows in flight per picture: a row takes sb_cols steps of ~6 us and starts ~23 us after the one above, so about
+     * sb_cols * 6 / 23 rows keep the wavefront full (16 for 4K, 8 for 1080p); more would only wait */
+    static const int rows_env = getenv("SVT_HIP_LF_ROWS") ? atoi(getenv("SVT_HIP_LF_ROWS")) : 0;
+    const int rows_in_flight = rows_env > 0 ? rows_env : (max_cols * 17 + 63) / 64 < 4 ? 4 : (max_cols * 17 + 63) / 64;
     const int lf_wgs = n_pics * (max_rows < rows_in_flight ? max_rows : rows_in_flight);
     hipLaunchKernelGGL(svt_lf_kernel, dim3(lf_wgs), dim3(256), 0, ctx->stream, (const lf_pic_dev *)d, n_pics, *thr, cnt, max_rows, want_prof ? 1 : 0);
     HIP_TRY(hipGetLastError());
