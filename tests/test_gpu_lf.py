@@ -40,3 +40,36 @@ def test_lf_y_only_and_repeatability(ctx):
     for _ in range(5):
         g = T.hip_lf_frame(ctx, case)
         assert all(np.array_equal(a, b) for a, b in zip(full, g))
+
+
+def test_lf_batch_of_different_pictures(ctx):
+    """svt_hip_lf_batch_device: three pictures of different sizes (1, 3 and 4 SB rows; partial SBs) in one launch -- the
+    persistent workgroups interleave their rows by ticket; every picture must come out as if filtered alone"""
+    import torch
+    lib = B.load()
+    cases = [T.make_lf_case(21, 328, 200), T.make_lf_case(22, 136, 64), T.make_lf_case(23, 256, 192)]
+    n = len(cases)
+    keep, descs = [], (B.YuvPlanes * n)()
+
+    def dev(a):
+        t = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()
+        keep.append(t)
+        return t
+
+    planes, lfms = [], []
+    for k, c in enumerate(cases):
+        y, u, v = dev(c["y"]), dev(c["u"]), dev(c["v"])
+        planes.append((y, u, v))
+        lfms.append(dev(c["lfm"]))
+        d = descs[k]
+        d.y, d.u, d.v = y.data_ptr(), u.data_ptr(), v.data_ptr()
+        d.y_stride, d.uv_stride, d.width, d.height = c["y"].shape[1], c["u"].shape[1], c["y"].shape[1], c["y"].shape[0]
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in lfms])
+    arr = lambda vals: (C.c_int32 * n)(*vals)
+    B.check(lib.svt_hip_lf_batch_device(ctx, n, descs, ptrs, arr([c["lfm"].shape[1] for c in cases]), C.byref(cases[0]["thr"]),
+                                        arr([c["mi_rows"] for c in cases]), arr([c["mi_cols"] for c in cases]), 0))
+    B.check(lib.svt_hip_ctx_synchronize(ctx))
+    for c, (y, u, v) in zip(cases, planes):
+        oy, ou, ov = T.oracle_lf_frame(c)
+        assert np.array_equal(y.cpu().numpy().reshape(oy.shape), oy)
+        assert np.array_equal(u.cpu().numpy().reshape(ou.shape), ou) and np.array_equal(v.cpu().numpy().reshape(ov.shape), ov)
