@@ -313,6 +313,21 @@ SVT_DEV void me_pu_geom(int pu, int *x, int *y, int *w) {
 /* unaligned 32-bit fetch from a byte address (LDS or global): two aligned loads + v_alignbyte.  Branch-free on
  * purpose: a conditional second load serialises the two memory round trips and keeps the compiler from batching the
  * loads of unrolled callers.  An aligned address re-reads its own dword, so nothing beyond the 4 bytes is touched. */
+/* Pointers into picture planes and result arrays are known to be global memory: saying so turns the generic
+ * (flat_load: 64-bit address per lane, aperture check, counted against the LDS counter too) accesses into global_load /
+ * global_store, which also accept a scalar base plus a 32-bit lane offset. */
+#ifdef SVT_HOST_EMU
+#define SVT_GLOBAL
+#else
+#define SVT_GLOBAL __attribute__((address_space(1)))
+#endif
+#define SVT_AS_GLOBAL(T, p) ((T SVT_GLOBAL *)(uintptr_t)(p))
+SVT_DEV uint32_t me_ld32u_g(const uint8_t *p) { /* me_ld32u (below) for a global address */
+    const uint32_t                   sh = (uint32_t)((uintptr_t)p & 3);
+    const uint32_t SVT_GLOBAL const *q  = SVT_AS_GLOBAL(const uint32_t, p - sh);
+    const uint32_t                   lo = q[0], hi = q[sh ? 1 : 0];
+    return svt_alignbyte(hi, lo, sh);
+}
 SVT_DEV uint32_t me_ld32u(const uint8_t *p) {
     const uint32_t  sh = (uint32_t)((uintptr_t)p & 3);
     const uint32_t *q  = (const uint32_t *)(p - sh);
@@ -360,7 +375,7 @@ SVT_DEV me_gsrc me_gsrc_of(const uint8_t *p, int stride) {
 }
 /* the 4 bytes at byte offset off (a multiple of 4 plus whole rows) of the rectangle */
 SVT_DEV uint32_t me_gld(const me_gsrc g, uint32_t off) {
-    return svt_alignbyte(*(const uint32_t *)(g.hi + off), *(const uint32_t *)(g.lo + off), g.sh);
+    return svt_alignbyte(*SVT_AS_GLOBAL(const uint32_t, g.hi + off), *SVT_AS_GLOBAL(const uint32_t, g.lo + off), g.sh);
 }
 
 /* a plane descriptor read from LDS (or HBM) into scalar registers: every lane holds the same values, and with them in
@@ -417,7 +432,7 @@ SVT_DEV void ph_load_rect(int tid, uint8_t *dst, int dst_stride, const uint8_t *
         _Pragma("unroll") for (int u = 0; u < 8; u++) {
             o[u] = -1;
             if (t0 + u * SVT_NT < n) {
-                v[u] = g.ok ? me_gld(g, (uint32_t)(ME_MUL(r, src_stride) + 4 * i)) : me_ld32u(src + (ptrdiff_t)r * src_stride + 4 * i);
+                v[u] = g.ok ? me_gld(g, (uint32_t)(ME_MUL(r, src_stride) + 4 * i)) : me_ld32u_g(src + (ptrdiff_t)r * src_stride + 4 * i);
                 o[u] = r * dst_stride + 4 * i;
             }
             i += di; r += dr;
@@ -446,14 +461,14 @@ SVT_DEV void ph_init(const me_ctx_t *c, int tid) {
         int rows = (c->sb_h >> 2) >> 1, wq = c->sb_w >> 2;
         for (int t = tid; t < rows * 16; t += SVT_NT) {
             int r = t >> 4, x = t & 15;
-            st->sixteenth_sb[t] = x < wq ? *me_pix(&c->pic->cur.sixteenth, (c->sb_x >> 2) + x, (c->sb_y >> 2) + 2 * r) : 0;
+            st->sixteenth_sb[t] = x < wq ? *SVT_AS_GLOBAL(const uint8_t, me_pix(&c->pic->cur.sixteenth, (c->sb_x >> 2) + x, (c->sb_y >> 2) + 2 * r)) : 0;
         }
     }
     if (c->p->enable_hme_level_1_flag) {
         int rows = c->sb_h >> 1, wq = c->sb_w >> 1;
         for (int t = tid; t < rows * 32; t += SVT_NT) {
             int r = t >> 5, x = t & 31;
-            c->quarter_sb[t] = x < wq ? *me_pix(&c->pic->cur.quarter, (c->sb_x >> 1) + x, (c->sb_y >> 1) + r) : 0;
+            c->quarter_sb[t] = x < wq ? *SVT_AS_GLOBAL(const uint8_t, me_pix(&c->pic->cur.quarter, (c->sb_x >> 1) + x, (c->sb_y >> 1) + r)) : 0;
         }
     }
 }
@@ -481,7 +496,7 @@ SVT_DEV void ph_center_sads(const me_ctx_t *c, int tid, const svt_plane *ref, in
             s[h] = *(const uint32_t *)(c->src + (2 * r) * ME_SB + 4 * i);
             _Pragma("unroll") for (int k = 0; k < 5; k++)
                 if (k < ncand) v[h][k] = g[k].ok ? me_gld(g[k], (uint32_t)(ME_MUL(2 * r, rstride) + 4 * i))
-                                                 : me_ld32u(me_pix(ref, c->sb_x + dx[k] + 4 * i, c->sb_y + dy[k] + 2 * r));
+                                                 : me_ld32u_g(me_pix(ref, c->sb_x + dx[k] + 4 * i, c->sb_y + dy[k] + 2 * r));
                 else v[h][k] = s[h];
         } else {
             _Pragma("unroll") for (int k = 0; k < 5; k++) v[h][k] = s[h];
@@ -1251,7 +1266,7 @@ SVT_DEV void ph_hme_load_multi(const me_ctx_t *c, int tid, const svt_plane *ref_
                 const int t = T - wn[e].tl, nd = wn[e].nd;
                 if (e != cur) { cur = e; inv = me_magic_of(nd); }
                 const int row = me_div_magic(t, inv), i = t - row * nd;
-                v[u]   = me_ld32u(me_pix(ref, wn[e].gx + 4 * i, wn[e].gy + row));
+                v[u]   = me_ld32u_g(me_pix(ref, wn[e].gx + 4 * i, wn[e].gy + row));
                 dst[u] = wn[e].off + row * wn[e].wstride + 4 * i;
             }
         }
@@ -1820,7 +1835,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
     uint32_t *ow = (uint32_t *)c->planes;
     ME_PHASE(ph_output(c, tid, 0, ow));
     {
-        uint32_t *g = (uint32_t *)(c->pic->results + (size_t)c->sb_index * 85);
+        uint32_t SVT_GLOBAL *g = SVT_AS_GLOBAL(uint32_t, c->pic->results + (size_t)c->sb_index * 85);
 #ifdef SVT_HOST_EMU
         for (int t = 0; t < 850; t++) g[t] = ow[t];
 #else
@@ -1829,7 +1844,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         if (c->pic->rcme && tid == 0) {
             uint32_t acc = 0;
             for (int i = 0; i < 16; i++) acc += ow[(5 + i) * 10 + 2];
-            c->pic->rcme[c->sb_index] = acc;
+            *SVT_AS_GLOBAL(uint32_t, &c->pic->rcme[c->sb_index]) = acc;
         }
     }
     ME_MARK(13);
