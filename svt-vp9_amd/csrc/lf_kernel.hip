@@ -176,7 +176,12 @@ __device__ __forceinline__ uint32_t vert_entry(int c, int fwd, unsigned m16, uns
 /* horizontal edges of one 8-row band, column block cb: replays the greedy left-to-right pairing of
  * filter_selectively_horiz (vp9_loopfilter.c:481-568) to find this block's filter width and thresholds.
  * [quirk] the second block of a 16-wide pair uses the first block's thresholds (vp9_loopfilter.c:492-494). */
-__device__ __forceinline__ uint32_t horiz_entry(int cb, unsigned m16, unsigned m8, unsigned m4, unsigned mi4, const uint8_t *lfl, int lstep) {
+/* pointers taken from the picture descriptors are global memory: global_load / global_store instead of flat accesses */
+#define LF_GLOBAL __attribute__((address_space(1)))
+#define LF_AS_GLOBAL(T, p) ((T LF_GLOBAL *)(uintptr_t)(p))
+#define LF_LDS __attribute__((address_space(3)))
+
+__device__ __forceinline__ uint32_t horiz_entry(int cb, unsigned m16, unsigned m8, unsigned m4, unsigned mi4, const uint8_t LF_GLOBAL *lfl, int lstep) {
     int  kind = 0, lvl = 0, ilvl = 0;
     bool inner = false;
     int  p = 0;
@@ -255,7 +260,7 @@ __device__ __forceinline__ void lf_line(uint8_t *s, int st, int nblk, const uint
 template <int UNITS, typename UT>
 __device__ __forceinline__ void tile_io_t(bool load, uint8_t *g, int gstride, uint8_t *l, int lstride, int x0, int y0, int tx0, int ty0,
                                           int nx, int ny, int seam_lo_end, int seam_hi_begin, int lane, int nlanes,
-                                          const volatile int *wait_flag, int wait_val) {
+                                          const volatile int LF_LDS *wait_flag, int wait_val) {
     constexpr int UB = (int)sizeof(UT);      /* unit = 8 bytes, or 4 when the plane rows are only 4-byte aligned */
     const int nu = nx / UB, total = nu * ny;
     for (int t0 = lane; t0 < total; t0 += UNITS * nlanes) {
@@ -266,7 +271,7 @@ __device__ __forceinline__ void tile_io_t(bool load, uint8_t *g, int gstride, ui
             lo[u] = -1;
             if (t < total) {
                 const int  r = t / nu, ty = ty0 + r, tx = tx0 + UB * (t - r * nu);
-                UT        *gp = (UT *)(g + (ptrdiff_t)(y0 + ty) * gstride + x0 + tx);
+                UT LF_GLOBAL *gp = LF_AS_GLOBAL(UT, g + (ptrdiff_t)(y0 + ty) * gstride + x0 + tx);
                 const bool seam = ty < seam_lo_end || ty >= seam_hi_begin;
                 lo[u] = ty * lstride + tx;
                 if (load) v[u] = seam ? __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *gp;
@@ -294,7 +299,7 @@ __device__ __forceinline__ void tile_io_t(bool load, uint8_t *g, int gstride, ui
 template <int UNITS>
 __device__ __forceinline__ void tile_io(bool wide, bool load, uint8_t *g, int gstride, uint8_t *l, int lstride, int x0, int y0, int tx0,
                                         int ty0, int nx, int ny, int seam_lo_end, int seam_hi_begin, int lane, int nlanes,
-                                        const volatile int *wait_flag = nullptr, int wait_val = 0) {
+                                        const volatile int LF_LDS *wait_flag = nullptr, int wait_val = 0) {
     if (wide) tile_io_t<UNITS, unsigned long long>(load, g, gstride, l, lstride, x0, y0, tx0, ty0, nx, ny, seam_lo_end, seam_hi_begin, lane, nlanes, wait_flag, wait_val);
     else tile_io_t<2 * UNITS, unsigned int>(load, g, gstride, l, lstride, x0, y0, tx0, ty0, nx, ny, seam_lo_end, seam_hi_begin, lane, nlanes, wait_flag, wait_val);
 }
@@ -320,11 +325,11 @@ __global__ __launch_bounds__(128) void svt_lf_desc_kernel(const lf_pic_dev *__re
     const int sb_cols = (P.mi_cols + 7) >> 3, sb_rows = (P.mi_rows + 7) >> 3;
     if (sb_row >= sb_rows || sc >= sb_cols) return;
     const int tid = threadIdx.x, mi_row = sb_row * 8;
-    uint32_t *d = const_cast<uint32_t *>(P.desc) + ((size_t)sb_row * sb_cols + sc) * LF_DESC_WORDS;
+    uint32_t LF_GLOBAL *d = LF_AS_GLOBAL(uint32_t, const_cast<uint32_t *>(P.desc) + ((size_t)sb_row * sb_cols + sc) * LF_DESC_WORDS);
     /* the masks are adjusted on a register copy; the per-8x8 levels are read straight from HBM (indexing them in the
      * copy would push the whole struct to scratch memory) */
-    const svt_lf_mask *gm = &P.lfm[sb_row * P.lfm_stride + sc];
-    const uint8_t     *lfl = gm->lfl_y;
+    const svt_lf_mask LF_GLOBAL *gm = LF_AS_GLOBAL(const svt_lf_mask, &P.lfm[sb_row * P.lfm_stride + sc]);
+    const uint8_t LF_GLOBAL     *lfl = gm->lfl_y;
     svt_lf_mask        m;
     _Pragma("unroll") for (int i = 0; i < 4; i++) { m.left_y[i] = gm->left_y[i]; m.above_y[i] = gm->above_y[i]; m.left_uv[i] = gm->left_uv[i]; m.above_uv[i] = gm->above_uv[i]; }
     m.int_4x4_y = gm->int_4x4_y; m.int_4x4_uv = gm->int_4x4_uv;
@@ -368,8 +373,8 @@ __global__ __launch_bounds__(256) void svt_lf_kernel(const lf_pic_dev *__restric
     __shared__ uint32_t              s_desc[2][LF_DESC_WORDS]; /* edge descriptors: luma vertical [band][block] 64, luma horizontal 64,
                                                                   chroma vertical 16, chroma horizontal 16 */
     __shared__ int                   s_job;
-    __shared__ volatile int          s_stored;              /* last SB whose tile wave 2 has read back out of LDS */
-    __shared__ volatile int          s_halo;                /* last SB whose top halo rows (the SB row above's bottom rows) are in LDS */
+    __shared__ int                   s_stored_;             /* last SB whose tile wave 2 has read back out of LDS */
+    __shared__ int                   s_halo_;               /* last SB whose top halo rows (the SB row above's bottom rows) are in LDS */
     const int tid = threadIdx.x;
     if (tid < 64) s_thr[tid] = (uint32_t)thr.mblim[tid] | ((uint32_t)thr.lim[tid] << 8) | ((uint32_t)thr.hev_thr[tid] << 16);
     /* Persistent workgroups: each takes SB rows by ticket until none is left.  Tickets run over the rows of all pictures
@@ -379,6 +384,9 @@ __global__ __launch_bounds__(256) void svt_lf_kernel(const lf_pic_dev *__restric
      * predecessor while it occupies LDS and registers other kernels could use. */
     for (;;) {
     __syncthreads(); /* the previous row of this workgroup is complete (its last write-back included) */
+    /* the two flags are polled: keep them explicit LDS references so the polls are ds_reads, not flat loads */
+    volatile int LF_LDS &s_stored = *(volatile int LF_LDS *)&s_stored_;
+    volatile int LF_LDS &s_halo   = *(volatile int LF_LDS *)&s_halo_;
     if (tid == 0) { s_job = (int)atomicAdd(ticket, 1u); s_stored = -1; s_halo = -1; }
     __syncthreads();
     const int job = s_job;
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(256) void svt_lf_kernel(const lf_pic_dev *__restric
         if (sb_row > 0) { /* wait for (sb_row-1, sc+1): its tiles up to sc+1 have been written back */
             const uint32_t need = (uint32_t)(sc + 2 < sb_cols ? sc + 2 : sb_cols);
             if (lane == 0)
-                while (__hip_atomic_load(&P.progress[sb_row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(1);
+                while (__hip_atomic_load(LF_AS_GLOBAL(uint32_t, &P.progress[sb_row - 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(1);
             LF_MARK(0, 128);
             tile_io<2>(wide_y, true, P.planes.y, P.planes.y_stride, ytile[buf], YS, g.x0 - 8, g.y0 - 8, 8, 0, g.vw, 8, 8, 8 + g.vh - 8, lane, 64);
             if (!P.y_only) {
@@ -431,7 +439,7 @@ __global__ __launch_bounds__(256) void svt_lf_kernel(const lf_pic_dev *__restric
         LF_MARK(1, 128);
         /* edge descriptors of this SB (built by svt_lf_desc_kernel): luma vertical 64, luma horizontal 64, chroma 16 + 16 */
         {
-            const uint32_t *d = P.desc + ((size_t)sb_row * sb_cols + sc) * LF_DESC_WORDS;
+            const uint32_t LF_GLOBAL *d = LF_AS_GLOBAL(const uint32_t, P.desc + ((size_t)sb_row * sb_cols + sc) * LF_DESC_WORDS);
             s_desc[buf][lane] = d[lane];
             s_desc[buf][64 + lane] = d[64 + lane];
             if (lane < 32) s_desc[buf][128 + lane] = d[128 + lane];
@@ -493,7 +501,7 @@ __global__ __launch_bounds__(256) void svt_lf_kernel(const lf_pic_dev *__restric
             LF_MARK(6, 192);
             /* publish: every store of this wave has completed (seam rows were written through) -> progress counter */
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(&P.progress[sb_row], (uint32_t)(sc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(LF_AS_GLOBAL(uint32_t, &P.progress[sb_row]), (uint32_t)(sc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             LF_MARK(7, 192);
         }
     }

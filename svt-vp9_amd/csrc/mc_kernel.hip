@@ -57,6 +57,11 @@ __device__ __forceinline__ uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, ui
     return __builtin_amdgcn_perm(c | (d << 8), a | (b << 8), 0x05040100u);
 }
 
+/* picture planes, mode info and prediction live in device memory: say so, and the loads/stores are global_* with no
+ * aperture check instead of flat_* */
+#define MC_GLOBAL __attribute__((address_space(1)))
+#define MC_AS_GLOBAL(T, p) ((T MC_GLOBAL *)(uintptr_t)(p))
+
 /* 4 x NR tile at plane position (x, y) displaced by (s_col, s_row) sixteenths, VP9 regular filter */
 template <int NR>
 __device__ __forceinline__ void mc_tile(const uint8_t *plane, int stride, int x, int y, int s_row, int s_col, int sx, int sy, uint32_t out[NR]) {
@@ -72,7 +77,7 @@ __device__ __forceinline__ void mc_tile(const uint8_t *plane, int stride, int x,
     const bool any_sx = __builtin_amdgcn_ballot_w64(sx != 0) != 0, any_sy = __builtin_amdgcn_ballot_w64(sy != 0) != 0;
     _Pragma("unroll") for (int r = 0; r < NM; r++) {
         if (!any_sy && (r < 3 || r >= 3 + NR)) { mid[r] = 0; continue; }
-        const u32x4a4 d = *(const u32x4a4 *)(p0 + (ptrdiff_t)r * stride);
+        const u32x4a4 d = *MC_AS_GLOBAL(const u32x4a4, p0 + (ptrdiff_t)r * stride);
         /* bytes 0..11 of the row window (sample x - 3 first) */
         const uint32_t e0 = alignbyte(d.y, d.x, sh), e1 = alignbyte(d.z, d.y, sh), e2 = alignbyte(d.w, d.z, sh);
         if (!any_sx) { mid[r] = alignbyte(e1, e0, 3); continue; }
@@ -113,7 +118,7 @@ __device__ __forceinline__ void mc_tile(const uint8_t *plane, int stride, int x,
 
 template <int NR>
 __device__ __forceinline__ void mc_unit(const mc_pic_dev &P, int plane, int mi_row, int mi_col, int x, int y) {
-    const uint32_t *mp = (const uint32_t *)(P.mi + (size_t)mi_row * P.mi_stride + mi_col);
+    const uint32_t MC_GLOBAL *mp = MC_AS_GLOBAL(const uint32_t, P.mi + (size_t)mi_row * P.mi_stride + mi_col);
     const uint32_t  m0 = mp[0], m1 = mp[1], m2 = mp[2];
     const int       rl0 = (int8_t)(m2 & 0xff), rl1 = (int8_t)((m2 >> 8) & 0xff), bw8 = (int)((m2 >> 16) & 0xff), bh8 = (int)(m2 >> 24);
     if (rl0 < 0 || bw8 < 1 || bh8 < 1) return;
@@ -144,7 +149,7 @@ __device__ __forceinline__ void mc_unit(const mc_pic_dev &P, int plane, int mi_r
     }
     uint8_t  *dp = plane == 0 ? P.pred.y : plane == 1 ? P.pred.u : P.pred.v;
     const int ds = plane ? P.pred.uv_stride : P.pred.y_stride;
-    _Pragma("unroll") for (int r = 0; r < NR; r++) *(uint32_t *)(dp + (size_t)(y + r) * ds + x) = acc[r];
+    _Pragma("unroll") for (int r = 0; r < NR; r++) *MC_AS_GLOBAL(uint32_t, dp + (size_t)(y + r) * ds + x) = acc[r];
 }
 
 __global__ __launch_bounds__(128) void svt_mc_kernel(const mc_pic_dev *__restrict__ pics, int max_rows, int xblocks, int total, int chunk) {

@@ -11,6 +11,10 @@
 #include <hip/hip_runtime.h>
 #include "svt_ctx.h"
 
+/* pictures are device memory: global_* loads/stores, no aperture check */
+#define PA_GLOBAL __attribute__((address_space(1)))
+#define PA_AS_GLOBAL(T, p) ((T PA_GLOBAL *)(uintptr_t)(p))
+
 namespace {
 struct pa_job {
     const uint8_t *src; /* luma sample (0,0) */
@@ -34,12 +38,12 @@ __global__ __launch_bounds__(256) void svt_pa_plane_kernel(const pa_job *__restr
         if (py >= th) break;
         int sy = py - J.pad_y;
         sy = sy < 0 ? 0 : sy > J.dh - 1 ? J.dh - 1 : sy;
-        const uint8_t *srow = J.src + (size_t)(sy * J.step) * J.sstride;
-        uint8_t       *drow = J.dst + (size_t)py * J.dstride + 4 * q;
+        const uint8_t PA_GLOBAL *srow = PA_AS_GLOBAL(const uint8_t, J.src + (size_t)(sy * J.step) * J.sstride);
+        uint8_t PA_GLOBAL       *drow = PA_AS_GLOBAL(uint8_t, J.dst + (size_t)py * J.dstride + 4 * q);
         const int      px0 = 4 * q - J.pad_x;
         uint32_t       w;
         if (J.step == 1 && px0 >= 0 && px0 + 3 < J.dw && ((((uintptr_t)srow + px0) & 3) == 0)) {
-            w = *(const uint32_t *)(srow + px0); /* interior of the full-resolution plane: aligned dword copy */
+            w = *(const uint32_t PA_GLOBAL *)(srow + px0); /* interior of the full-resolution plane: aligned dword copy */
         } else {
             w = 0;
             _Pragma("unroll") for (int b = 0; b < 4; b++) {
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(256) void svt_pa_plane_kernel(const pa_job *__restr
                 w |= (uint32_t)srow[sx * J.step] << (8 * b);
             }
         }
-        if (4 * q + 3 < tw && (((uintptr_t)drow) & 3) == 0) *(uint32_t *)drow = w;
+        if (4 * q + 3 < tw && (((uintptr_t)drow) & 3) == 0) *(uint32_t PA_GLOBAL *)drow = w;
         else
             for (int b = 0; b < 4 && 4 * q + b < tw; b++) drow[b] = (uint8_t)(w >> (8 * b));
     }
@@ -62,10 +66,10 @@ __global__ __launch_bounds__(256) void svt_pa_meanvar_kernel(svt_plane pl, int n
     __shared__ uint64_t s_m[4][85], s_q[4][85]; /* mean << 8 and mean of squares << 16, per wave */
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, sb = blockIdx.x * 4 + w;
     if (sb >= n_sb) return;
-    const uint8_t *p = pl.buf + (size_t)(pl.origin_y + (sb / nx) * 64 + (lane >> 3) * 8) * pl.stride + pl.origin_x + (sb % nx) * 64 + (lane & 7) * 8;
+    const uint8_t PA_GLOBAL *p = PA_AS_GLOBAL(const uint8_t, pl.buf) + (size_t)(pl.origin_y + (sb / nx) * 64 + (lane >> 3) * 8) * pl.stride + pl.origin_x + (sb % nx) * 64 + (lane & 7) * 8;
     uint32_t sum = 0, sq = 0;
     _Pragma("unroll") for (int r = 0; r < 8; r += 2) { /* rows 0, 2, 4, 6 */
-        const uint8_t *row = p + (size_t)r * pl.stride;
+        const uint8_t PA_GLOBAL *row = p + (size_t)r * pl.stride;
         _Pragma("unroll") for (int x = 0; x < 8; x++) { const uint32_t v = row[x]; sum += v; sq += v * v; }
     }
     uint64_t *m = s_m[w], *q = s_q[w];
