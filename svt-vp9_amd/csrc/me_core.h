@@ -674,16 +674,23 @@ SVT_DEV uint32_t me_tap4_half(uint32_t a, uint32_t b, uint32_t d, uint32_t e) {
     v = (v >> 5) & 0x07ff07ffu;
     return svt_pk_clamp_sub32(v); /* per lane: min(max(v, 32), 287) - 32 */
 #else
-    /* the same per-lane arithmetic on the packed 16-bit ALU: two adds, two multiply-adds, a shift, the clamp */
-    const svt_u16x2 A = __builtin_bit_cast(svt_u16x2, a), B = __builtin_bit_cast(svt_u16x2, b), D = __builtin_bit_cast(svt_u16x2, d),
-                    E = __builtin_bit_cast(svt_u16x2, e);
-    const svt_u16x2 k18 = {18, 18}, kb = {1040, 1040}, km2 = {0xfffe, 0xfffe}, k5 = {5, 5};
-    svt_u16x2       v = (B + D) * k18 + kb;
-    v = (A + E) * km2 + v; /* - 2 (a + e), modulo 2^16: the true value is in [20, 10220] */
+    /* on the packed 16-bit ALU, signed: two adds, two multiply-adds, an arithmetic shift; v_sat_pk_u8_i16 is the clip and
+     * leaves the two samples in bytes 0 and 1 */
+    typedef short   s16x2 __attribute__((ext_vector_type(2)));
+    const s16x2     A = __builtin_bit_cast(s16x2, a), B = __builtin_bit_cast(s16x2, b), D = __builtin_bit_cast(s16x2, d), E = __builtin_bit_cast(s16x2, e);
+    const s16x2     k18 = {18, 18}, k16 = {16, 16}, km2 = {-2, -2}, k5 = {5, 5};
+    s16x2           v = (B + D) * k18 + k16;
+    v = (A + E) * km2 + v; /* in [-1004, 9196] */
     v = v >> k5;
-    return svt_pk_clamp_sub32(__builtin_bit_cast(uint32_t, v));
+    uint32_t r;
+    __asm__("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(__builtin_bit_cast(uint32_t, v)));
+    return r;
 #endif
 }
+#ifndef SVT_HOST_EMU
+/* even samples in bytes 0,1 of ev, odd ones in bytes 0,1 of od -> the 4 samples in order */
+SVT_DEV uint32_t me_tap4_join(uint32_t ev, uint32_t od) { return __builtin_amdgcn_perm(od, ev, 0x05010400u); }
+#endif
 SVT_DEV uint32_t me_tap4_x4(uint32_t a, uint32_t b, uint32_t d, uint32_t e) {
 #ifdef SVT_HOST_EMU
     const uint32_t M = 0x00ff00ffu;
@@ -695,7 +702,7 @@ SVT_DEV uint32_t me_tap4_x4(uint32_t a, uint32_t b, uint32_t d, uint32_t e) {
     const uint32_t SE = 0x0c020c00u, SO = 0x0c030c01u;
     const uint32_t ev = me_tap4_half(__builtin_amdgcn_perm(0, a, SE), __builtin_amdgcn_perm(0, b, SE), __builtin_amdgcn_perm(0, d, SE), __builtin_amdgcn_perm(0, e, SE));
     const uint32_t od = me_tap4_half(__builtin_amdgcn_perm(0, a, SO), __builtin_amdgcn_perm(0, b, SO), __builtin_amdgcn_perm(0, d, SO), __builtin_amdgcn_perm(0, e, SO));
-    return ev | (od << 8);
+    return me_tap4_join(ev, od);
 #endif
 }
 
@@ -715,13 +722,26 @@ SVT_DEV void ph_interp_bh(const me_ctx_t *c, int tid, int W, int H) {
         const uint8_t  *rr = c->region + ME_MUL(ME_RGN_GY - ME_PL_G + py, rs) + 4 * j;
         const uint32_t *r0 = (const uint32_t *)rr;
         uint32_t        lo = r0[0], hi = r0[1];
+        const uint32_t *ra = (const uint32_t *)(rr - rs), *rb = (const uint32_t *)(rr + rs), *rc = (const uint32_t *)(rr + 2 * rs);
+#ifdef SVT_HOST_EMU
         /* bytes b0..b7 = lo,hi; output k uses b[k+1..k+4] */
         uint32_t t1 = svt_alignbyte(hi, lo, 1), t2 = svt_alignbyte(hi, lo, 2), t3 = svt_alignbyte(hi, lo, 3);
         *(uint32_t *)(B + ME_MUL(py, ps) + 4 * j) = me_tap4_x4(t1, t2, t3, hi);
         /* vertical: samples at region byte offset 4j+2 of rows y-1, y, y+1, y+2 */
-        const uint32_t *ra = (const uint32_t *)(rr - rs), *rb = (const uint32_t *)(rr + rs), *rc = (const uint32_t *)(rr + 2 * rs);
         uint32_t va = svt_alignbyte(ra[1], ra[0], 2), vc = svt_alignbyte(rb[1], rb[0], 2), vd = svt_alignbyte(rc[1], rc[0], 2);
         *(uint32_t *)(Hh + ME_MUL(py, ps) + 4 * j) = me_tap4_x4(va, t2, vc, vd);
+#else
+        /* the same, with every 16-bit-lane operand picked straight out of the dword pair by one v_perm_b32: P(k) = bytes
+         * (k, k+2) of b0..b7 zero-extended.  Horizontal taps of the even outputs are P1 P2 P3 P4, of the odd ones
+         * P2 P3 P4 P5; the vertical filter works on bytes 2..5 of each row = P2 (even) and P3 (odd). */
+#define ME_P(h, l, k) __builtin_amdgcn_perm(h, l, 0x0c000c00u | (uint32_t)(k) | ((uint32_t)((k) + 2) << 16))
+        const uint32_t p1 = ME_P(hi, lo, 1), p2 = ME_P(hi, lo, 2), p3 = ME_P(hi, lo, 3), p4 = ME_P(hi, lo, 4), p5 = ME_P(hi, lo, 5);
+        *(uint32_t *)(B + ME_MUL(py, ps) + 4 * j) = me_tap4_join(me_tap4_half(p1, p2, p3, p4), me_tap4_half(p2, p3, p4, p5));
+        const uint32_t a0 = ra[0], a1 = ra[1], b0 = rb[0], b1 = rb[1], c0 = rc[0], c1 = rc[1];
+        *(uint32_t *)(Hh + ME_MUL(py, ps) + 4 * j) = me_tap4_join(me_tap4_half(ME_P(a1, a0, 2), p2, ME_P(b1, b0, 2), ME_P(c1, c0, 2)),
+                                                                  me_tap4_half(ME_P(a1, a0, 3), p3, ME_P(b1, b0, 3), ME_P(c1, c0, 3)));
+#undef ME_P
+#endif
         j += dj; py += dpy;
         if (j >= pwd) { j -= pwd; py++; }
     }
