@@ -145,7 +145,7 @@ __device__ __forceinline__ void mc_unit(const mc_pic_dev &P, int plane, int mi_r
         uint32_t       o[NR];
         mc_tile<NR>(pl, plane ? R.uv_stride : R.y_stride, x, y, s_row, s_col, sx, sy, o);
         _Pragma("unroll") for (int r = 0; r < NR; r++)
-            acc[r] = k ? (acc[r] | o[r]) - (((acc[r] ^ o[r]) >> 1) & 0x7f7f7f7fu) : o[r]; /* ROUND_POWER_OF_TWO(dst + p, 1) per byte */
+            acc[r] = k ? __builtin_amdgcn_lerp(acc[r], o[r], 0x01010101u) : o[r]; /* ROUND_POWER_OF_TWO(dst + p, 1) per byte */
     }
     uint8_t  *dp = plane == 0 ? P.pred.y : plane == 1 ? P.pred.u : P.pred.v;
     const int ds = plane ? P.pred.uv_stride : P.pred.y_stride;

@@ -62,6 +62,8 @@ static inline uint32_t svt_sad4(uint32_t a, uint32_t b, uint32_t acc) {
     }
     return acc;
 }
+/* per-byte (a + b + 1) >> 1 without carries between bytes */
+static inline uint32_t svt_avg4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }
 static inline uint32_t svt_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
     return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3)));
 }
@@ -96,6 +98,8 @@ SVT_DEV uint32_t svt_ssd4(uint32_t a, uint32_t b, uint32_t acc) {
     return acc - 2u * __builtin_amdgcn_udot4(a, b, 0u, false);
 }
 SVT_DEV uint32_t svt_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+/* per-byte (a + b + 1) >> 1: v_lerp_u8 with the rounding bit set in every byte of the third operand */
+SVT_DEV uint32_t svt_avg4(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }
 /* per 16-bit lane: min(max(v, 32), 287) - 32 (v_pk_max_u16 / v_pk_min_u16 / v_pk_sub_u16) */
 typedef unsigned short svt_u16x2 __attribute__((ext_vector_type(2)));
 SVT_DEV uint32_t svt_pk_clamp_sub32(uint32_t v) {
@@ -791,7 +795,7 @@ SVT_DEV uint32_t me_block_sad_rows(const uint8_t *src, int ss, const uint8_t *a,
                 uint32_t hb = pb[i + 1];
                 uint32_t vb = svt_alignbyte(hb, lb, shb);
                 lb = hb;
-                va = (va | vb) - (((va ^ vb) >> 1) & 0x7f7f7f7fu); /* per-byte (a + b + 1) >> 1 */
+                va = svt_avg4(va, vb); /* per-byte (a + b + 1) >> 1 */
             }
             sad = svt_sad4(va, s[i], sad);
             if (ssd_out) ssd = svt_ssd4(va, s[i], ssd);
@@ -1118,7 +1122,7 @@ SVT_DEV uint32_t me_pred_fetch(const uint8_t *a, const uint8_t *b, int offa, int
     uint32_t va = me_ld32u(a + offa);
     if (b) {
         uint32_t vb = me_ld32u(b + offb);
-        va = (va | vb) - (((va ^ vb) >> 1) & 0x7f7f7f7fu); /* (a + b + 1) >> 1 per byte */
+        va = svt_avg4(va, vb); /* (a + b + 1) >> 1 per byte */
     }
     return va;
 }
@@ -1170,7 +1174,7 @@ SVT_DEV void ph_bipred(const me_ctx_t *c, int tid, int sox, int soy, const uint3
                 int      d = l + (k << sh), r = (d >> (4 - L)) << sub, i = d & ((16 >> L) - 1);
                 uint32_t s  = *(const uint32_t *)(c->src + (py + r) * ME_SB + px + 4 * i);
                 uint32_t va = ME_PR(4 * L + k), vb = me_pred_fetch(a, b, ME_MUL(r, sa) + 4 * i, ME_MUL(r, sb) + 4 * i);
-                uint32_t av = (va | vb) - (((va ^ vb) >> 1) & 0x7f7f7f7fu);
+                uint32_t av = svt_avg4(va, vb);
                 dsum = svt_sad4(av, s, dsum);
             }
         }
