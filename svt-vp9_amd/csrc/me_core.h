@@ -682,10 +682,13 @@ SVT_DEV uint32_t me_tap4_half(uint32_t a, uint32_t b, uint32_t d, uint32_t e) {
      * leaves the two samples in bytes 0 and 1 */
     typedef short   s16x2 __attribute__((ext_vector_type(2)));
     const s16x2     A = __builtin_bit_cast(s16x2, a), B = __builtin_bit_cast(s16x2, b), D = __builtin_bit_cast(s16x2, d), E = __builtin_bit_cast(s16x2, e);
-    const s16x2     k18 = {18, 18}, k16 = {16, 16}, km2 = {-2, -2}, k5 = {5, 5};
-    s16x2           v = (B + D) * k18 + k16;
-    v = (A + E) * km2 + v; /* in [-1004, 9196] */
-    v = v >> k5;
+    const s16x2     k5 = {5, 5};
+    /* 18 (b + d) + 16, then - 2 (a + e) on top: two v_pk_mad_i16 (the compiler splits them into mul / shift / sub / add);
+     * the value stays in [-1004, 9196] */
+    uint32_t        m;
+    __asm__("v_pk_mad_i16 %0, %1, 18, 16 op_sel_hi:[1,0,0]" : "=v"(m) : "v"(__builtin_bit_cast(uint32_t, B + D)));
+    __asm__("v_pk_mad_i16 %0, %1, -2, %2 op_sel_hi:[1,0,1]" : "=v"(m) : "v"(__builtin_bit_cast(uint32_t, A + E)), "v"(m));
+    s16x2           v = __builtin_bit_cast(s16x2, m) >> k5;
     uint32_t r;
     __asm__("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(__builtin_bit_cast(uint32_t, v)));
     return r;
