@@ -328,7 +328,7 @@ SVT_DEV void me_pu_geom(int pu, int *x, int *y, int *w) {
 #define SVT_AS_GLOBAL(T, p) ((T SVT_GLOBAL *)(uintptr_t)(p))
 SVT_DEV uint32_t me_ld32u_g(const uint8_t *p) { /* me_ld32u (below) for a global address */
     const uint32_t                   sh = (uint32_t)((uintptr_t)p & 3);
-    const uint32_t SVT_GLOBAL const *q  = SVT_AS_GLOBAL(const uint32_t, p - sh);
+    const uint32_t SVT_GLOBAL *q  = SVT_AS_GLOBAL(const uint32_t, p - sh);
     const uint32_t                   lo = q[0], hi = q[sh ? 1 : 0];
     return svt_alignbyte(hi, lo, sh);
 }
