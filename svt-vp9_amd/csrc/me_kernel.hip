@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC != 0 ?
     svt_me_params pp = p;
     if constexpr (SPEC != 0) me_spec_apply<SPEC>(&pp); /* constants equal to the caller's values (me_spec_match) */
     c.p   = &pp;
+    if constexpr (SPEC != 0) me_lds_layout_geom(&pp, &L); /* the same values as the host's, as compile-time constants */
     c.L   = L;
     c.lds = svt_lds;
     c.st     = (me_state_t *)(svt_lds + L.off_state);
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC != 0 ?
     c.region = svt_lds + L.off_region;
     c.planes = svt_lds + L.off_planes;
     c.quarter_sb  = svt_lds + L.off_quarter;
-    c.ssdc        = p.fractional_search_method == SVT_SSD_SEARCH ? (uint32_t *)(svt_lds + L.off_ssd) : nullptr;
+    c.ssdc        = pp.fractional_search_method == SVT_SSD_SEARCH ? (uint32_t *)(svt_lds + L.off_ssd) : nullptr;
     c.best_ssd    = c.ssdc ? c.ssdc + 85 * 9 : nullptr;
     c.cand        = (uint32_t *)(svt_lds + L.off_cand);
     c.pred0       = (uint32_t *)(svt_lds + L.off_pred0);

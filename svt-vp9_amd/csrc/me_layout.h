@@ -3,11 +3,17 @@
 #define SVT_ME_LAYOUT_H
 #include "me_core.h"
 
-static inline int me_round_up(int v, int a) { return (v + a - 1) / a * a; }
+#if defined(__HIPCC__)
+#define ME_LAYOUT_FN __host__ __device__ static inline
+#else
+#define ME_LAYOUT_FN static inline
+#endif
+ME_LAYOUT_FN int me_round_up(int v, int a) { return (v + a - 1) / a * a; }
 
-/* Sizes follow the largest search area the parameters allow (clipping at picture borders only
- * shrinks it).  Returns 0, or -1 when the configuration does not fit in 160 KiB of LDS. */
-static inline int me_lds_layout_compute(const svt_me_params *p, me_lds_layout *L) {
+/* The geometry: sizes follow the largest search area the parameters allow (clipping at picture borders only shrinks it).
+ * Also callable in the kernel: a specialised instance evaluates it on its compile-time parameters, so strides and offsets
+ * are immediates instead of scalar registers (the kernel is short of those). */
+ME_LAYOUT_FN void me_lds_layout_geom(const svt_me_params *p, me_lds_layout *L) {
     int saw = p->search_area_width < 127 ? p->search_area_width : 127;
     int sah = p->search_area_height < 127 ? p->search_area_height : 127;
     if (saw < 1) saw = 1;
@@ -40,6 +46,11 @@ static inline int me_lds_layout_compute(const svt_me_params *p, me_lds_layout *L
     if (p->num_ref_lists == 2) off += 16 * 256 * 4;
 #endif
     L->total_bytes = off;
+}
+
+/* Geometry + the HME level-0 area multipliers.  Returns 0, or -1 when the configuration does not fit in 160 KiB of LDS. */
+static inline int me_lds_layout_compute(const svt_me_params *p, me_lds_layout *L) {
+    me_lds_layout_geom(p, L);
     {   /* HME level-0 search area multipliers, Codec/EbDefinitions.h:989-1005, indexed [hierarchical_levels][temporal_layer] */
         static const int32_t mult_tab[6][6] = {{100, 0, 0, 0, 0, 0},       {100, 100, 0, 0, 0, 0},
                                                {100, 100, 100, 0, 0, 0},   {200, 140, 100, 70, 0, 0},
@@ -53,6 +64,6 @@ static inline int me_lds_layout_compute(const svt_me_params *p, me_lds_layout *L
         L->hme_tw0 = (int16_t)((p->hme_level0_total_search_area_width * mult) / 100);
         L->hme_th0 = (int16_t)((p->hme_level0_total_search_area_height * mult) / 100);
     }
-    return off <= 160 * 1024 ? 0 : -1;
+    return L->total_bytes <= 160 * 1024 ? 0 : -1;
 }
 #endif
