@@ -38,7 +38,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC != 0 ?
     svt_me_params pp = p;
     if constexpr (SPEC != 0) me_spec_apply<SPEC>(&pp); /* constants equal to the caller's values (me_spec_match) */
     c.p   = &pp;
-    if constexpr (SPEC != 0) me_lds_layout_geom(&pp, &L); /* the same values as the host's, as compile-time constants */
+    if constexpr (SPEC != 0) { /* the same values as the host's, as compile-time constants */
+        me_lds_layout G = L;
+        me_lds_layout_geom(&pp, &G);
+        L.region_stride = G.region_stride; L.plane_stride = G.plane_stride; L.plane_bytes = G.plane_bytes; L.region_rows = G.region_rows;
+        L.cand_dwords = G.cand_dwords; L.scratch_bytes = G.scratch_bytes;
+    }
     c.L   = L;
     c.lds = svt_lds;
     c.st     = (me_state_t *)(svt_lds + L.off_state);
