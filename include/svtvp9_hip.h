@@ -487,6 +487,19 @@ int32_t svt_hip_coeff_rate_batch(svt_hip_ctx *ctx, const int16_t *qcoeff, size_t
                                  int32_t n_blocks, const svt_rate_tables *tables, const int16_t *scan, size_t scan_count,
                                  int32_t *bits);
 
+/* ------------------------------------------------------------------------------------------------ */
+/* IVF container (host only): what the reference's sample application wraps the encoder's packets in   */
+/* ------------------------------------------------------------------------------------------------ */
+#define SVT_IVF_STREAM_HEADER_BYTES 32
+/* replaces write_ivf_stream_header (App/EbAppProcessCmd.c:515-540); frame_rate_q16 is used when numerator or
+ * denominator is 0, exactly as there */
+int32_t svt_ivf_stream_header(uint8_t out[SVT_IVF_STREAM_HEADER_BYTES], uint32_t width, uint32_t height, uint32_t frame_rate_q16,
+                              uint32_t rate_numerator, uint32_t rate_denominator);
+/* replaces the stream-writing branch of process_output_stream_buffer (App/EbAppProcessCmd.c:617-650): one encoder packet
+ * -> one IVF frame, or five when the packet is flagged EB_BUFFERFLAG_SHOW_EXT (the coded frame, then the four trailing
+ * one-byte show-existing-frame headers with pts - 2, - 1, + 0, + 1).  Returns bytes written or a negative error. */
+int64_t svt_ivf_packetize(const uint8_t *packet, uint32_t len, uint64_t pts, int32_t show_ext, uint8_t *out, size_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

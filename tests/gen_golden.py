@@ -13,6 +13,9 @@ import svt_testlib as T  # noqa: E402
 
 G = T.GOLDEN_DIR
 QUANT_GOLDEN_DELTAS = ((0, 0, 0), (-3, 4, -5))
+# (width, height, frame_rate_q16, numerator, denominator, [(byte_count, pts), ...]) -> the reference application's IVF headers
+IVF_GOLDEN_CASES = ((3840, 2160, 60 << 16, 0, 0, ((1000, 5), (7, (1 << 32) + 5))), (640, 360, 30 << 16, 30000, 1001, ((0, 0), (4294967295, (1 << 63) + 12345))),
+                    (8192, 4320, (24 << 16) + 4660, 0, 1, ((1, 1),)), (64, 64, 0, 25, 1, ()))
 RATE_GOLDEN_CASES = ((1, 256, 128, False), (2, 128, 64, False), (11, 128, 64, True))
 MC_GOLDEN_CASES = ((1, 192, 128, 1), (2, 128, 72, 1), (3, 64, 64, 0), (4, 200, 136, 1))
 
@@ -91,6 +94,11 @@ def main():
         out = subprocess.check_output([os.path.join(T.REF_DIR, "ref_quant_tables")] + [str(d) for d in deltas]).decode()
         qt["|".join(map(str, deltas))] = np.array([[int(x) for x in line.split()] for line in out.strip().splitlines()], np.int32)
     np.savez_compressed(os.path.join(G, "quant_reference.npz"), **qt)
+    # ---- IVF container headers: the reference application's write_ivf_stream_header / write_ivf_frame_header ----
+    ivf = {}
+    for k, (w, h, fr, num, den, frames) in enumerate(IVF_GOLDEN_CASES):
+        ivf[str(k)] = np.frombuffer(T.ref_ivf_headers(w, h, fr, num, den, frames), np.uint8)
+    np.savez_compressed(os.path.join(G, "ivf_reference.npz"), **ivf)
     for f in sorted(os.listdir(G)):
         print(f, os.path.getsize(os.path.join(G, f)))
 

@@ -1009,3 +1009,17 @@ def ref_me_side(cur, prev, input_resolution, cur_mean, cur_var, ref_mean, ref_va
         subprocess.check_call([exe, req, rsp])
         raw = np.frombuffer(open(rsp, "rb").read(), np.uint8)
     return raw[:n].copy(), raw[n:2 * n].copy(), raw[2 * n:3 * n].copy()
+
+
+def ref_ivf_headers(width, height, frame_rate_q16, numerator, denominator, frames):
+    """bytes written by the REFERENCE application's write_ivf_stream_header followed by one write_ivf_frame_header per
+    (byte_count, pts) (oracle/_ref/ref_ivf_headers = App/EbAppProcessCmd.c compiled as it lies)"""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "h.bin")
+        args = [os.path.join(REF_DIR, "ref_ivf_headers"), out, str(width), str(height), str(frame_rate_q16), str(numerator), str(denominator)]
+        for n, pts in frames:
+            args += [str(n), str(pts)]
+        subprocess.check_call(args)
+        return open(out, "rb").read()
