@@ -13,7 +13,7 @@ B = T.B
 def test_library_exports_every_declared_symbol():
     lib = B.load()
     header = open(f"{T.ROOT}/include/svtvp9_hip.h").read()
-    declared = set(re.findall(r"\b(svt_hip_[a-z0-9_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(svt_(?:hip|ivf)_[a-z0-9_]+)\s*\(", header))
     assert declared == set(B.EXPORTS), declared ^ set(B.EXPORTS)
     for s in declared:
         assert hasattr(lib, s), s
