@@ -290,29 +290,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 4
 }
 
 
-/* 4x4 blocks: one block per lane.  With four lanes per block the 4-point transforms are a sliver of the instruction stream
- * (loads, LDS transposes, shuffles for eob and distortion, the descriptor decode repeated in every lane dominate: ~125 VALU
- * lane-operations per sample); a lane that owns the whole block keeps its 16 samples in registers from the residual to the
- * reconstruction, needs no LDS, no barrier and no cross-lane step.  Same arithmetic as svt_tq_kernel<4>: for 4x4 the
- * fwd_txfm.c and vp9_dct.c forms of DCT_DCT coincide (the int16 casts are no-ops at this size), so one path serves all four
- * transform types.  Memory instructions per block are unchanged (a lane issues the four row loads its four lanes issued). */
-__global__ __launch_bounds__(256) void svt_tq4_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ pred,
-                                                      uint8_t *__restrict__ recon, const svt_tq_block *__restrict__ blocks,
-                                                      int n_blocks, const svt_quant_tables *__restrict__ qtabs,
-                                                      const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,
-                                                      int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out,
-                                                      uint64_t *__restrict__ dist_out) {
+/* 4x4 (and, unused, 8x8) blocks: one block per lane.  With N lanes per block the small transforms are a sliver of the instruction
+ * stream (descriptor decode and table loads repeated in every lane, LDS transposes, shuffles for eob and distortion: ~125
+ * VALU lane-operations per sample, as many as a 32x32 block); a lane that owns the whole block keeps its samples in
+ * registers from the residual to the reconstruction, needs no LDS, no barrier and no cross-lane step.  Same arithmetic as
+ * svt_tq_kernel<N>.  4x4: the fwd_txfm.c and vp9_dct.c forms of the DCT coincide (the int16 casts are no-ops at this size);
+ * 8x8: they differ in the cast inside tx_fdct8 (vp9_dct.c:67-68), selected by the block's transform type.  The inverse
+ * always runs all rows (the reference's reduced variants are shortcuts with identical results).  Memory instructions per
+ * block are unchanged (a lane issues the N row loads its N lanes issued). */
+template <int N>
+__global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ pred,
+                                                          uint8_t *__restrict__ recon, const svt_tq_block *__restrict__ blocks,
+                                                          int n_blocks, const svt_quant_tables *__restrict__ qtabs,
+                                                          const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,
+                                                          int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out,
+                                                          uint64_t *__restrict__ dist_out) {
+    static_assert(N == 4 || N == 8, "block-per-lane form: 4x4 and 8x8 only");
+    constexpr int ND = N / 4; /* dwords per row of samples */
     const int blk = blockIdx.x * 256 + threadIdx.x;
     if (blk >= n_blocks) return;
     const svt_tq_block k = blocks[blk];
     const bool col_adst = k.tx_type == SVT_ADST_DCT || k.tx_type == SVT_ADST_ADST;
     const bool row_adst = k.tx_type == SVT_DCT_ADST || k.tx_type == SVT_ADST_ADST;
-    uint32_t   srow[4], prow[4];
-    _Pragma("unroll") for (int r = 0; r < 4; r++) {
-        srow[r] = *(const uint32_t *)(src + k.src_off + (size_t)r * k.src_stride);
-        prow[r] = *(const uint32_t *)(pred + k.pred_off + (size_t)r * k.pred_stride);
+    const bool dct_dct  = k.tx_type == SVT_DCT_DCT;
+    uint32_t   prow[N][ND];
+    int32_t    m[N][N]; /* after the column pass: m[kk][cc] = vertical frequency kk of column cc */
+    {
+        uint32_t srow[N][ND];
+        _Pragma("unroll") for (int r = 0; r < N; r++) {
+            const uint8_t *sp = src + k.src_off + (size_t)r * k.src_stride, *pp = pred + k.pred_off + (size_t)r * k.pred_stride;
+            if constexpr (N == 4) { srow[r][0] = *(const uint32_t *)sp; prow[r][0] = *(const uint32_t *)pp; }
+            else {
+                row_load<N>(sp, ((uintptr_t)sp & 7) == 0, srow[r]);
+                row_load<N>(pp, ((uintptr_t)pp & 7) == 0, prow[r]);
+            }
+        }
+        _Pragma("unroll") for (int cc = 0; cc < N; cc++) {
+            int32_t v[N], o[N];
+            _Pragma("unroll") for (int r = 0; r < N; r++)
+                v[r] = ((int)((srow[r][cc >> 2] >> (8 * (cc & 3))) & 0xff) - (int)((prow[r][cc >> 2] >> (8 * (cc & 3))) & 0xff)) * (N == 4 ? 16 : 4);
+            if constexpr (N == 4) {
+                if (cc == 0 && v[0]) ++v[0];
+                if (col_adst) tx_fadst4(v, o); else tx_fdct4(v, o);
+            } else {
+                if (col_adst) tx_adst8(v, o);
+                else if (dct_dct) tx_fdct8(v, o, 0);
+                else tx_fdct8(v, o, 1);
+            }
+            _Pragma("unroll") for (int kk = 0; kk < N; kk++) m[kk][cc] = (int16_t)o[kk];
+        }
     }
-    /* quantiser tables and the inverse scan of the block (lanes of one transform type read the same addresses) */
+    /* quantiser tables of the block (lanes of one table read the same addresses) */
     svt_quant_tables q;
     {
         const uint32_t *qp = (const uint32_t *)(qtabs + k.qtab);
@@ -322,31 +350,28 @@ __global__ __launch_bounds__(256) void svt_tq4_kernel(const uint8_t *__restrict_
         q.quant[0] = (int16_t)qw5[2]; q.quant[1] = (int16_t)(qw5[2] >> 16); q.quant_shift[0] = (int16_t)qw5[3]; q.quant_shift[1] = (int16_t)(qw5[3] >> 16);
         q.dequant[0] = (int16_t)qw5[4]; q.dequant[1] = (int16_t)(qw5[4] >> 16);
     }
-    uint32_t isw[8];
-    {
-        const uint32_t *ip = (const uint32_t *)(iscan_all + k.iscan_off);
-        _Pragma("unroll") for (int j = 0; j < 8; j++) isw[j] = ip[j];
-    }
-    /* ---- column pass: m[kk][cc] = vertical frequency kk of column cc ---- */
-    int32_t m[4][4];
-    _Pragma("unroll") for (int cc = 0; cc < 4; cc++) {
-        int32_t v[4], o[4];
-        _Pragma("unroll") for (int r = 0; r < 4; r++)
-            v[r] = ((int)((srow[r] >> (8 * cc)) & 0xff) - (int)((prow[r] >> (8 * cc)) & 0xff)) * 16;
-        if (cc == 0 && v[0]) ++v[0];
-        if (col_adst) tx_fadst4(v, o); else tx_fdct4(v, o);
-        _Pragma("unroll") for (int kk = 0; kk < 4; kk++) m[kk][cc] = (int16_t)o[kk];
-    }
-    /* ---- row pass, quantisation, distortion, eob ---- */
-    int32_t  dq[4][4];
-    uint32_t qw[8], dqw[8], rdist = 0, pdist = 0;
+    /* ---- row pass, quantisation, distortion, eob; each row of coefficients leaves as one 8/16-byte vector ---- */
+    int32_t  dq[N][N];
+    uint32_t rdist = 0, pdist = 0;
     int      eob = 0;
-    _Pragma("unroll") for (int i = 0; i < 4; i++) {
-        int32_t o[4];
-        if (row_adst) tx_fadst4(m[i], o);
-        else { tx_fdct4(m[i], o); _Pragma("unroll") for (int kk = 0; kk < 4; kk++) o[kk] = (int16_t)o[kk]; }
-        _Pragma("unroll") for (int kk = 0; kk < 4; kk++) {
-            const int cv = (int16_t)((o[kk] + 1) >> 2), ac = (i | kk) != 0, sign = cv >> 31, a = (cv ^ sign) - sign;
+    const uint32_t *ip = (const uint32_t *)(iscan_all + k.iscan_off);
+    _Pragma("unroll") for (int i = 0; i < N; i++) {
+        int32_t  o[N];
+        uint32_t isw[N / 2], qw[N / 2], dqw[N / 2];
+        _Pragma("unroll") for (int j = 0; j < N / 2; j++) isw[j] = ip[i * (N / 2) + j];
+        if constexpr (N == 4) {
+            if (row_adst) tx_fadst4(m[i], o);
+            else { tx_fdct4(m[i], o); _Pragma("unroll") for (int kk = 0; kk < N; kk++) o[kk] = (int16_t)o[kk]; }
+        } else {
+            if (row_adst) tx_adst8(m[i], o);
+            else {
+                if (dct_dct) tx_fdct8(m[i], o, 0); else tx_fdct8(m[i], o, 1);
+                _Pragma("unroll") for (int kk = 0; kk < N; kk++) o[kk] = (int16_t)o[kk];
+            }
+        }
+        _Pragma("unroll") for (int kk = 0; kk < N; kk++) {
+            const int cv = N == 4 ? (int16_t)((o[kk] + 1) >> 2) : (int16_t)((o[kk] + (o[kk] < 0)) >> 1);
+            const int ac = (i | kk) != 0, sign = cv >> 31, a = (cv ^ sign) - sign;
             int       level = 0, qv = 0, dv = 0;
             if (a >= q.zbin[ac]) {
                 const int tmp = clamp16(a + q.round[ac]);
@@ -358,49 +383,57 @@ __global__ __launch_bounds__(256) void svt_tq4_kernel(const uint8_t *__restrict_
             const int dd = (int16_t)(cv - dv);
             rdist += (uint32_t)(dd * dd);
             pdist += (uint32_t)(cv * cv);
-            const int rc = 4 * i + kk;
-            if (rc & 1) { qw[rc >> 1] |= (uint32_t)(uint16_t)qv << 16; dqw[rc >> 1] |= (uint32_t)(uint16_t)dv << 16; }
-            else { qw[rc >> 1] = (uint16_t)qv; dqw[rc >> 1] = (uint16_t)dv; }
-            if (level) { const int pos = (int)((isw[rc >> 1] >> (16 * (rc & 1))) & 0xffff) + 1; eob = pos > eob ? pos : eob; }
+            if (kk & 1) { qw[kk >> 1] |= (uint32_t)(uint16_t)qv << 16; dqw[kk >> 1] |= (uint32_t)(uint16_t)dv << 16; }
+            else { qw[kk >> 1] = (uint16_t)qv; dqw[kk >> 1] = (uint16_t)dv; }
+            if (level) { const int pos = (int)((isw[kk >> 1] >> (16 * (kk & 1))) & 0xffff) + 1; eob = pos > eob ? pos : eob; }
         }
-    }
-    {
-        uint4 *qo = (uint4 *)(qcoeff + k.coeff_off), *dqo = (uint4 *)(dqcoeff + k.coeff_off);
-        qo[0] = make_uint4(qw[0], qw[1], qw[2], qw[3]); qo[1] = make_uint4(qw[4], qw[5], qw[6], qw[7]);
-        dqo[0] = make_uint4(dqw[0], dqw[1], dqw[2], dqw[3]); dqo[1] = make_uint4(dqw[4], dqw[5], dqw[6], dqw[7]);
+        int16_t *qo = qcoeff + k.coeff_off + i * N, *dqo = dqcoeff + k.coeff_off + i * N;
+        if constexpr (N == 4) { *(uint2 *)qo = make_uint2(qw[0], qw[1]); *(uint2 *)dqo = make_uint2(dqw[0], dqw[1]); }
+        else { *(uint4 *)qo = make_uint4(qw[0], qw[1], qw[2], qw[3]); *(uint4 *)dqo = make_uint4(dqw[0], dqw[1], dqw[2], dqw[3]); }
     }
     eob_out[blk] = (uint16_t)eob;
     if (dist_out) { dist_out[2 * blk] = rdist; dist_out[2 * blk + 1] = pdist; }
     if (!k.do_recon) return;
-    /* ---- reconstruction: rows first, then columns (vp9_idct.c:111-125, inv_txfm.c:130-189) ---- */
-    int32_t res[4][4];
-    const bool dc_only = k.tx_type == SVT_DCT_DCT && eob <= 1;
+    /* ---- reconstruction: rows first, then columns (vp9_idct.c:111-189, inv_txfm.c); a column's eight results go straight
+     * into the packed output rows ---- */
+    constexpr int SH = txcfg<N>::shift;
+    uint32_t      rw[N][ND];
+    _Pragma("unroll") for (int r = 0; r < N; r++) { _Pragma("unroll") for (int j = 0; j < ND; j++) rw[r][j] = 0; }
+    const bool dc_only = dct_dct && (N == 4 ? eob <= 1 : eob == 1);
     if (eob != 0 && !dc_only) {
-        int32_t t[4][4];
-        _Pragma("unroll") for (int i = 0; i < 4; i++) {
-            int32_t o[4];
-            if (row_adst) tx_iadst4(dq[i], o); else tx_idct4(dq[i], o);
-            _Pragma("unroll") for (int kk = 0; kk < 4; kk++) t[i][kk] = (int16_t)o[kk];
+        int32_t t[N][N];
+        _Pragma("unroll") for (int i = 0; i < N; i++) {
+            int32_t o[N];
+            if constexpr (N == 4) { if (row_adst) tx_iadst4(dq[i], o); else tx_idct4(dq[i], o); }
+            else { if (row_adst) tx_adst8(dq[i], o); else tx_idct8(dq[i], o); }
+            _Pragma("unroll") for (int kk = 0; kk < N; kk++) t[i][kk] = (int16_t)o[kk];
         }
-        _Pragma("unroll") for (int cc = 0; cc < 4; cc++) {
-            int32_t v[4], o[4];
-            _Pragma("unroll") for (int r = 0; r < 4; r++) v[r] = t[r][cc];
-            if (col_adst) tx_iadst4(v, o); else tx_idct4(v, o);
-            _Pragma("unroll") for (int r = 0; r < 4; r++) res[r][cc] = ((int16_t)o[r] + 8) >> 4;
+        _Pragma("unroll") for (int cc = 0; cc < N; cc++) {
+            int32_t v[N], o[N];
+            _Pragma("unroll") for (int r = 0; r < N; r++) v[r] = t[r][cc];
+            if constexpr (N == 4) { if (col_adst) tx_iadst4(v, o); else tx_idct4(v, o); }
+            else { if (col_adst) tx_adst8(v, o); else tx_idct8(v, o); }
+            _Pragma("unroll") for (int r = 0; r < N; r++) {
+                const int res = ((int16_t)o[r] + (1 << (SH - 1))) >> SH;
+                rw[r][cc >> 2] |= (uint32_t)clip_add((int)((prow[r][cc >> 2] >> (8 * (cc & 3))) & 0xff), res) << (8 * (cc & 3));
+            }
         }
     } else {
         int32_t a1 = 0;
-        if (eob != 0) { /* eb_vp9_idct4x4_1_add_c, inv_txfm.c:174 */
+        if (eob != 0) { /* eb_vp9_idct4x4_1_add_c / idct8x8_1_add_c, inv_txfm.c:174, 368 */
             int32_t d = tx_rsw((int16_t)dq[0][0] * TX_C16);
             d = tx_rsw(d * TX_C16);
-            a1 = (d + 8) >> 4;
+            a1 = (d + (1 << (SH - 1))) >> SH;
         }
-        _Pragma("unroll") for (int r = 0; r < 4; r++) { _Pragma("unroll") for (int cc = 0; cc < 4; cc++) res[r][cc] = a1; }
+        _Pragma("unroll") for (int r = 0; r < N; r++) {
+            _Pragma("unroll") for (int cc = 0; cc < N; cc++)
+                rw[r][cc >> 2] |= (uint32_t)clip_add((int)((prow[r][cc >> 2] >> (8 * (cc & 3))) & 0xff), a1) << (8 * (cc & 3));
+        }
     }
-    _Pragma("unroll") for (int r = 0; r < 4; r++) {
-        uint32_t w = 0;
-        _Pragma("unroll") for (int b = 0; b < 4; b++) w |= (uint32_t)clip_add((int)((prow[r] >> (8 * b)) & 0xff), res[r][b]) << (8 * b);
-        *(uint32_t *)(recon + k.recon_off + (size_t)r * k.recon_stride) = w;
+    _Pragma("unroll") for (int r = 0; r < N; r++) {
+        uint8_t *d = recon + k.recon_off + (size_t)r * k.recon_stride;
+        if constexpr (N == 4) *(uint32_t *)d = rw[r][0];
+        else row_store<N>(d, ((uintptr_t)d & 7) == 0, rw[r]);
     }
 }
 
@@ -408,8 +441,11 @@ template <int N>
 int launch_tq(svt_hip_ctx *ctx, const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks, int n,
               const svt_quant_tables *q, const int16_t *iscan, int16_t *qc, int16_t *dqc, uint16_t *eob, uint64_t *dist) {
     if (n <= 0) return 0;
+    /* block per lane for 4x4 only: the 8x8 instance is bit-exact too but needs 201 VGPRs (64 samples + the transposed
+     * intermediate live in one lane; 87 spills when held to 128) -- two waves per SIMD, and each displaces two ME waves:
+     * the overlapped step went from 3.27 to 3.77 ms with it, so 8x8 stays on the N-lanes-per-block kernel */
     if constexpr (N == 4) {
-        hipLaunchKernelGGL(svt_tq4_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, src, pred, recon, blocks, n, q, iscan, qc, dqc, eob, dist);
+        hipLaunchKernelGGL(svt_tq_lane_kernel<N>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, src, pred, recon, blocks, n, q, iscan, qc, dqc, eob, dist);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     constexpr int NT = N == 32 ? 128 : 256, BPW = NT / N;

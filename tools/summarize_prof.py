@@ -13,7 +13,7 @@ prof = os.path.join(root, "profiles")
 
 
 def short(name):
-    if re.search(r"(?<![A-Za-z_0-9])svt_tq4_kernel(?![A-Za-z_0-9])", name):
+    if re.search(r"(?<![A-Za-z_0-9])svt_tq_lane_kernel(?![A-Za-z_0-9])", name):
         return "svt_tq_kernel"  # the 4x4 instance of the TQ stage
     for k in ("svt_me_sb_kernel", "svt_tq_kernel", "svt_lf_kernel", "svt_lf_desc_kernel", "svt_pa_plane_kernel", "svt_pa_meanvar_kernel", "svt_me_zz_sad_kernel", "svt_mc_kernel", "svt_rate_kernel"):
         if re.search(r"(?<![A-Za-z_0-9])" + k + r"(?![A-Za-z_0-9])", name):
