@@ -166,14 +166,14 @@ SVT_DEV void svt_group_add_u32(uint32_t *p, uint32_t v, int group) {
             (uint32_t)__builtin_amdgcn_readlane((int)v, 47) + (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
     if ((threadIdx.x & (group - 1)) == (unsigned)(group - 1) && v) atomicAdd(p, v);
 }
-/* as svt_group_add_u32, but the group size (1, 4 or 16 consecutive lanes, aligned) may differ from lane to lane inside a
+/* as svt_group_add_u32, but the group size (1, 2, 4, 8 or 16 consecutive lanes, aligned) may differ from lane to lane inside a
  * wave: every lane runs the four row-shift steps and picks the partial sum that covers its own group */
 SVT_DEV void svt_group_add_var(uint32_t *p, uint32_t v, int group) {
     const uint32_t s1 = SVT_DPP_ADD(v, 0x111);
     const uint32_t s2 = SVT_DPP_ADD(s1, 0x112); /* 4 lanes */
     const uint32_t s3 = SVT_DPP_ADD(s2, 0x114);
     const uint32_t s4 = SVT_DPP_ADD(s3, 0x118); /* 16 lanes */
-    const uint32_t t = group == 1 ? v : group == 4 ? s2 : s4;
+    const uint32_t t = group == 1 ? v : group == 2 ? s1 : group == 4 ? s2 : group == 8 ? s3 : s4;
     if ((threadIdx.x & (group - 1)) == (unsigned)(group - 1) && t) atomicAdd(p, t);
 }
 #endif
@@ -922,11 +922,17 @@ SVT_DEV void ph_subpel_prep(const me_ctx_t *c, int tid, int en32, int en16, int 
  * candidate is one lane's job (8 or 4 rows of 16 or 8 samples) -- at the BASELINE settings that is exactly 256 tasks of
  * equal size per half-pel pass.  The dense PU index k runs 64x64, 32x32, 16x16, 8x8 (me_active_pu), so the task ranges of
  * the three lane counts are contiguous.  t -> (k, candidate index, sub-lane, lanes per candidate); returns 0 past the end. */
+/* lanes per candidate block: 16 for 64x64, 4 for 32x32, 1 below.  With the 21 PUs and 8 candidates of the M8 / M9 presets
+ * that is 384 tasks = one and a half passes of the workgroup; 8 / 2 / 1 (exactly one pass of tasks twice as long) was
+ * measured slower (ME 2.30 instead of 2.24 ms per mini-GOP): the longer serial row loops expose more LDS latency than the
+ * half-empty second pass costs */
+#define ME_HP_NL64 16
+#define ME_HP_NL32 4
 SVT_DEV int me_subpel_task(int t, int ncand, int n64, int n32, int nrest, int *k, int *ci, int *sl, int *nl) {
-    const int T64 = n64 * ncand * 16, T32 = n32 * ncand * 4;
+    const int T64 = n64 * ncand * ME_HP_NL64, T32 = n32 * ncand * ME_HP_NL32;
     int       q, base;
-    if (t < T64) { *nl = 16; *sl = t & 15; q = t >> 4; base = 0; }
-    else if (t < T64 + T32) { const int u = t - T64; *nl = 4; *sl = u & 3; q = u >> 2; base = n64; }
+    if (t < T64) { *nl = ME_HP_NL64; *sl = t & (ME_HP_NL64 - 1); q = t / ME_HP_NL64; base = 0; }
+    else if (t < T64 + T32) { const int u = t - T64; *nl = ME_HP_NL32; *sl = u & (ME_HP_NL32 - 1); q = u / ME_HP_NL32; base = n64; }
     else { q = t - T64 - T32; *nl = 1; *sl = 0; base = n64 + n32; if (q >= nrest * ncand) return 0; }
     const int kk = ncand == 8 ? q >> 3 : ncand == 3 ? q / 3 : q / 9;
     *k = base + kk; *ci = q - kk * ncand;
@@ -942,7 +948,7 @@ SVT_DEV void ph_halfpel(const me_ctx_t *c, int tid, int list, int sox, int soy, 
     const int ncand   = ssd ? 9 : 8;
     int       n64, n32, n16;
     const int nact = me_active_count(c, en32, en16, en8, &n64, &n32, &n16);
-    const int total = ncand * (n64 * 16 + n32 * 4 + (nact - n64 - n32));
+    const int total = ncand * (n64 * ME_HP_NL64 + n32 * ME_HP_NL32 + (nact - n64 - n32));
     for (int t = tid; t < total; t += SVT_NT) {
         int k, cand, sl, nl;
         if (!me_subpel_task(t, ncand, n64, n32, nact - n64 - n32, &k, &cand, &sl, &nl)) break;
@@ -956,7 +962,7 @@ SVT_DEV void ph_halfpel(const me_ctx_t *c, int tid, int list, int sox, int soy, 
         const uint8_t *cp = me_plane_at(c, hpl, xs + hdx, ys + hdy);
         const uint8_t *sp = c->src + py * ME_SB + px;
         const int      rows = sub_sad ? (w >> 1) : w, step = sub_sad ? 2 : 1;
-        const int      per = nl == 16 ? rows >> 4 : nl == 4 ? rows >> 2 : rows, r0 = sl * per;
+        const int      per = nl == ME_HP_NL64 ? rows / ME_HP_NL64 : nl == ME_HP_NL32 ? rows / ME_HP_NL32 : rows, r0 = sl * per;
         uint32_t e = 0;
         const int cs = me_plane_stride(c, hpl) * step;
         uint32_t d = me_block_sad_rows(sp, ME_SB * step, cp, 0, cs, cs, w, r0, r0 + per, ssd ? &e : 0);
