@@ -24,7 +24,7 @@ def _build(td):
     return exe
 
 
-def _write_clip(td):
+def _write_clip(td, W=W, H=H, N=N):
     frames = T.gen_clip(W, H, N, 31)
     path = os.path.join(td, "in.yuv")
     with open(path, "wb") as f:
@@ -47,13 +47,13 @@ def test_app_builds_and_fails_loudly_without_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("bipred", [False, True])
-def test_app_records_equal_the_oracle(bipred):
+@pytest.mark.parametrize("W,H,N,mode,bipred", [(320, 192, 4, 9, False), (320, 192, 4, 9, True), (1920, 1080, 3, 8, True)])
+def test_app_records_equal_the_oracle(W, H, N, mode, bipred):
     with tempfile.TemporaryDirectory() as td:
         exe = _build(td)
-        frames, path = _write_clip(td)
+        frames, path = _write_clip(td, W, H, N)
         out, ivf = os.path.join(td, "me.bin"), os.path.join(td, "me.ivf")
-        r = subprocess.run([exe, "-i", path, "-w", str(W), "-h", str(H), "-enc-mode", "9", "-o", out, "-ivf", ivf, "-fps", "30"] + (["-b"] if bipred else []),
+        r = subprocess.run([exe, "-i", path, "-w", str(W), "-h", str(H), "-enc-mode", str(mode), "-o", out, "-ivf", ivf, "-fps", "30"] + (["-b"] if bipred else []),
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         nsb = T.n_sb(W, H)
@@ -61,7 +61,7 @@ def test_app_records_equal_the_oracle(bipred):
         pics = [T.PaPic(f) for f in frames]
         for k in range(1, N):
             two = bipred and k + 1 < N
-            prm = B.me_params_preset(W, H, 9, 1, 2 if two else 1, 1 if two else 0, 4)
+            prm = B.me_params_preset(W, H, mode, 1, 2 if two else 1, 1 if two else 0, 4)
             want, _ = T.oracle_me_picture(pics[k], pics[k - 1], pics[k + 1] if two else None, prm)
             assert got[k - 1].tobytes() == want.tobytes(), k
         # the IVF stream: the reference application's header, then one frame per picture holding the same records
