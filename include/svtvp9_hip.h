@@ -132,12 +132,34 @@ typedef struct svt_me_pu_result {
 /* Geometry helper: number of SBs of a picture (ceil(w/64)*ceil(h/64)). */
 int32_t svt_hip_sb_count(int32_t pic_width, int32_t pic_height);
 
-/* Fill `p` exactly as eb_vp9_signal_derivation_me_kernel_{oq,sq} + eb_vp9_set_me_hme_params_{oq,sq}
- * (Codec/EbMotionEstimationProcess.c:55-324, 541-720) and picture_decision's picture-level signals
- * (Codec/EbPictureDecisionProcess.c:682-703, 856-870, Codec/EbResourceCoordinationProcess.c:343-457)
- * do for the BASELINE configurations: tune 1 (OQ) enc_mode 8/9 at <=576p / 1080p / 2160p and
- * tune 0 (SQ) enc_mode 3 at 2160p.  Returns SVT_HIP_ERR_UNSUPPORTED for other combinations (callers
- * then fill svt_me_params themselves -- every field is a plain copy of a reference field). */
+/* INPUT_SIZE_576p_RANGE_OR_LOWER / 1080i / 1080p / 4K_RANGE = 0..3 of a picture size, by luma sample count
+ * (eb_vp9_derive_input_resolution, Codec/EbSequenceControlSet.c:489-499).  It is also the index of the non-moving
+ * threshold shift that svt_hip_me_zz_sad_device takes. */
+int32_t svt_hip_input_resolution(int32_t pic_width, int32_t pic_height);
+
+/* What the reference's parameter derivation reads from the sequence / picture control sets. */
+typedef struct svt_me_picture_config {
+    int32_t pic_width, pic_height;   /* luma_width / luma_height */
+    int32_t enc_mode;                /* 0..12 */
+    int32_t tune;                    /* 0 SQ, 1 OQ, 2 VMAF (Codec/EbDefinitions.h:658-660) */
+    int32_t frame_rate;              /* static_config.frame_rate >> 16 (frames per second) */
+    int32_t num_ref_lists;           /* 1 = P picture, 2 = B picture */
+    int32_t temporal_layer_index;
+    int32_t hierarchical_levels;
+    int32_t is_used_as_reference;    /* is_used_as_reference_flag */
+    int32_t same_ref_poc;            /* both lists hold the same picture */
+    int32_t rate_control_mode;
+} svt_me_picture_config;
+
+/* Fill `p` exactly as the reference derives the ME signals of a picture with use_default_me_hme = 1, for every tune,
+ * enc_mode and picture size it accepts: eb_vp9_signal_derivation_pre_analysis_* (HME enables,
+ * Codec/EbResourceCoordinationProcess.c:291-460), eb_vp9_signal_derivation_multi_processes_* (use_subpel_flag, cu8x8_mode,
+ * Codec/EbPictureDecisionProcess.c:682-925), eb_vp9_set_me_hme_params_* + eb_vp9_signal_derivation_me_kernel_*
+ * (Codec/EbMotionEstimationProcess.c:55-324, 541-720). */
+int32_t svt_hip_me_params_derive(svt_me_params *p, const svt_me_picture_config *cfg);
+
+/* Shorthand for the reference's default random-access structure at 60 frames/s: every temporal layer but the deepest is
+ * used as reference (is_used_as_reference = temporal_layer_index < hierarchical_levels). */
 int32_t svt_hip_me_params_preset(svt_me_params *p, int32_t pic_width, int32_t pic_height, int32_t enc_mode,
                                  int32_t tune, int32_t num_ref_lists, int32_t temporal_layer_index,
                                  int32_t hierarchical_levels);

@@ -117,7 +117,7 @@ class McPicture(C.Structure):
 
 # every symbol include/svtvp9_hip.h declares
 EXPORTS = [
-    "svt_hip_sb_count", "svt_hip_me_params_preset", "svt_hip_ctx_create", "svt_hip_ctx_create_on_stream", "svt_hip_ctx_create_cu_mask", "svt_hip_ctx_stream",
+    "svt_hip_sb_count", "svt_hip_input_resolution", "svt_hip_me_params_derive", "svt_hip_me_params_preset", "svt_hip_ctx_create", "svt_hip_ctx_create_on_stream", "svt_hip_ctx_create_cu_mask", "svt_hip_ctx_stream",
     "svt_hip_ctx_destroy", "svt_hip_ctx_synchronize", "svt_hip_last_error", "svt_hip_last_kernel_ms",
     "svt_hip_me_picture_device", "svt_hip_me_batch_device", "svt_hip_me_picture", "svt_hip_sad_loop_batch_device",
     "svt_hip_me_zz_sad_device", "svt_hip_me_similar_collocated", "svt_hip_pa_prepare_batch_device", "svt_hip_pa_mean_variance_device",
@@ -150,6 +150,18 @@ def load():
 def check(rc):
     if rc != 0:
         raise RuntimeError(f"svt_hip call failed rc={rc}: {load().svt_hip_last_error().decode()}")
+
+
+class MePictureConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("pic_width", "pic_height", "enc_mode", "tune", "frame_rate", "num_ref_lists",
+                                         "temporal_layer_index", "hierarchical_levels", "is_used_as_reference", "same_ref_poc",
+                                         "rate_control_mode")]
+
+
+def me_params_derive(**kw):
+    p, c = MeParams(), MePictureConfig(**kw)
+    check(load().svt_hip_me_params_derive(C.byref(p), C.byref(c)))
+    return p
 
 
 def me_params_preset(width, height, enc_mode, tune, num_ref_lists, temporal_layer, hierarchical_levels):

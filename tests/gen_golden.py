@@ -20,9 +20,11 @@ RATE_GOLDEN_CASES = ((1, 256, 128, False), (2, 128, 64, False), (11, 128, 64, Tr
 MC_GOLDEN_CASES = ((1, 192, 128, 1), (2, 128, 72, 1), (3, 64, 64, 0), (4, 200, 136, 1))
 
 
-def main():
-    assert T.ref_kernels() is not None and T.have_ref("ref_me_sb") and T.have_ref("ref_lf_frame"), "build oracle/_ref first"
+def gen_scan():
     np.savez_compressed(os.path.join(G, "vp9_scan_tables.npz"), **T.ref_scan_tables())
+
+
+def gen_me():
     # ---- ME: reference motion_estimate_sb results ----
     me = {}
     for name in MC.PRESETS:
@@ -32,6 +34,9 @@ def main():
             res, rc = T.ref_me_picture(pics[1], pics[0], pics[2] if nl == 2 else None, MC.preset(name, nl, tl))
             me[f"{name}|{nl}|{tl}|{clip}"] = res
     np.savez_compressed(os.path.join(G, "me_reference.npz"), **me)
+
+
+def gen_tq():
     # ---- TQ: reference kernels on the seeded block list of make_tq_case ----
     tq = {}
     for seed in (1, 2):
@@ -54,12 +59,18 @@ def main():
             recon[y:y + n, x:x + n] = T.ref_inv_add(dq, pred, ts, tt, eob) if eob else pred
         tq[f"q{seed}"], tq[f"dq{seed}"], tq[f"eob{seed}"], tq[f"recon{seed}"] = q_all, dq_all, eobs, recon
     np.savez_compressed(os.path.join(G, "tq_reference.npz"), **tq)
+
+
+def gen_lf():
     # ---- LF: reference eb_vp9_loop_filter_frame ----
     lf = {}
     for (w, h, seed, sharp) in ((200, 136, 2, 0), (328, 200, 3, 4), (72, 72, 5, 0)):
         y, u, v = T.ref_lf_frame(T.make_lf_case(seed, w, h, sharp))
         lf[f"y|{w}|{h}|{seed}|{sharp}"], lf[f"u|{w}|{h}|{seed}|{sharp}"], lf[f"v|{w}|{h}|{seed}|{sharp}"] = y, u, v
     np.savez_compressed(os.path.join(G, "lf_reference.npz"), **lf)
+
+
+def gen_lf_masks():
     # ---- LF masks: reference eb_vp9_setup_mask on random mode-info grids (same cases as tests/test_lf_masks.py) ----
     lm = {}
     for (seed, mi_rows, mi_cols) in ((1, 8, 8), (2, 27, 41), (3, 17, 9), (4, 5, 3), (5, 34, 60)):
@@ -68,6 +79,9 @@ def main():
         for n in r.dtype.names:
             lm[f"lfm_{seed}_{n}"] = np.ascontiguousarray(r[n])
     np.savez_compressed(os.path.join(G, "lf_masks_reference.npz"), **lm)
+
+
+def gen_mc():
     # ---- inter prediction: the reference's inter_prediction() on seeded mode-info grids (tests/test_mc.py) ----
     assert T.have_ref("ref_mc_frame")
     mc = {}
@@ -76,6 +90,9 @@ def main():
         y, u, v = T.ref_mc_frame(case)
         mc[f"y|{seed}|{w}|{h}|{sub}"], mc[f"u|{seed}|{w}|{h}|{sub}"], mc[f"v|{seed}|{w}|{h}|{sub}"] = y, u, v
     np.savez_compressed(os.path.join(G, "mc_reference.npz"), **mc)
+
+
+def gen_rate():
     # ---- coefficient rate estimation: the reference's tables (token costs of the default coefficient probabilities, value
     # / cat6 cost tables, scan orders with neighbours) and its coeff_rate_estimate() on the blocks of tests/test_rate.py ----
     assert T.have_ref("ref_rate_blocks")
@@ -87,6 +104,9 @@ def main():
         case = T.make_rate_case(seed, width=w, height=h, scan=scan, extreme=ext)
         rate[f"bits|{seed}|{w}|{h}|{int(ext)}"] = T.ref_rate_run(case)[0]
     np.savez_compressed(os.path.join(G, "rate_reference.npz"), **rate)
+
+
+def gen_quant():
     # ---- quantiser tables: the reference's eb_vp9_init_quantizer for all 256 q indices, two delta settings ----
     import subprocess
     qt = {}
@@ -94,11 +114,34 @@ def main():
         out = subprocess.check_output([os.path.join(T.REF_DIR, "ref_quant_tables")] + [str(d) for d in deltas]).decode()
         qt["|".join(map(str, deltas))] = np.array([[int(x) for x in line.split()] for line in out.strip().splitlines()], np.int32)
     np.savez_compressed(os.path.join(G, "quant_reference.npz"), **qt)
+
+
+def gen_ivf():
     # ---- IVF container headers: the reference application's write_ivf_stream_header / write_ivf_frame_header ----
     ivf = {}
     for k, (w, h, fr, num, den, frames) in enumerate(IVF_GOLDEN_CASES):
         ivf[str(k)] = np.frombuffer(T.ref_ivf_headers(w, h, fr, num, den, frames), np.uint8)
     np.savez_compressed(os.path.join(G, "ivf_reference.npz"), **ivf)
+
+
+def gen_lf_params():
+    # ---- LF parameters: the reference's eb_vp9_loop_filter_init (sharpness 0..7) and eb_vp9_pick_filter_level (all q) ----
+    np.savez_compressed(os.path.join(G, "lf_params_reference.npz"), **T.ref_lf_params())
+
+
+def gen_me_presets():
+    # ---- ME presets: the reference's eb_vp9_signal_derivation_me_kernel_{oq,sq} for every picture class / mode / tune ----
+    np.savez_compressed(os.path.join(G, "me_presets_reference.npz"), **T.ref_me_presets())
+
+
+SECTIONS = ("scan", "me", "tq", "lf", "lf_masks", "mc", "rate", "quant", "ivf", "lf_params", "me_presets")
+
+
+def main():
+    """python tests/gen_golden.py [section ...]  (no argument: every section)"""
+    assert T.ref_kernels() is not None and T.have_ref("ref_me_sb") and T.have_ref("ref_lf_frame"), "build oracle/_ref first"
+    for n in sys.argv[1:] or SECTIONS:
+        globals()["gen_" + n]()
     for f in sorted(os.listdir(G)):
         print(f, os.path.getsize(os.path.join(G, f)))
 

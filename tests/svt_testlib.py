@@ -555,7 +555,7 @@ def make_lf_case(seed, width, height, sharpness=0):
     lfm = gen_lf_masks(rng, sb_rows, sb_cols)
     thr = B.LfThresh()
     oracle().svt_oracle_lf_thresh_init(C.byref(thr), sharpness)
-    return dict(y=y, u=u, v=v, lfm=lfm, thr=thr, mi_rows=mi_rows, mi_cols=mi_cols)
+    return dict(y=y, u=u, v=v, lfm=lfm, thr=thr, mi_rows=mi_rows, mi_cols=mi_cols, sharpness=sharpness)
 
 
 def _yuv_desc(y, u, v):
@@ -589,7 +589,7 @@ def ref_lf_frame(case, y_only=False):
         req, rsp = os.path.join(td, "req.bin"), os.path.join(td, "rsp.bin")
         with open(req, "wb") as f:
             f.write(struct.pack("<10i", 0x464C5653, y.shape[1], y.shape[0], y.shape[1], u.shape[1], case["mi_rows"],
-                                case["mi_cols"], lfm.shape[1], lfm.size, int(y_only)))
+                                case["mi_cols"], lfm.shape[1], lfm.size, int(y_only) | case["sharpness"] << 8))
             f.write(bytes(case["thr"]))
             f.write(lfm.tobytes())
             f.write(y.tobytes()); f.write(u.tobytes()); f.write(v.tobytes())
@@ -599,6 +599,73 @@ def ref_lf_frame(case, y_only=False):
     return (np.frombuffer(raw, np.uint8, ys).reshape(y.shape)[:H0, :W0].copy(),
             np.frombuffer(raw, np.uint8, us, ys).reshape(u.shape)[:H0 // 2, :W0 // 2].copy(),
             np.frombuffer(raw, np.uint8, us, ys + us).reshape(v.shape)[:H0 // 2, :W0 // 2].copy())
+
+
+# (W, H): every resolution class incl. the boundaries of eb_vp9_derive_input_resolution and the aspect-ratio split of the
+# 1080i range; the sizes ADVICE r1 names (2048x1080, 1440x1080, 1600x900, 960x540, 1024x576) are among them
+ME_PRESET_SIZES = ((640, 360), (720, 576), (960, 540), (1024, 576), (1000, 750), (1280, 720), (1600, 900), (1440, 1080), (2048, 512),
+                   (4096, 256), (1536, 512), (1920, 1080), (2048, 1080), (1672, 1046), (2560, 1080), (2560, 1440), (3840, 2160), (4096, 2176),
+                   (8192, 4320), (64, 64))
+ME_PRESET_FIELDS = ("input_resolution", "enable_hme_flag", "enable_hme_level_0_flag", "enable_hme_level_1_flag", "enable_hme_level_2_flag",
+                    "use_subpel", "cu8x8_mode", "cu16x16_mode", "single_hme_quadrant", "fractional_search_method", "fractional_search64x64",
+                    "fractional_search_model", "search_area_width", "search_area_height", "number_hme_search_region_in_width",
+                    "number_hme_search_region_in_height", "hme_level0_total_search_area_width", "hme_level0_total_search_area_height")
+ME_PRESET_ARRAYS = ("hme_level0_search_area_in_width_array", "hme_level0_search_area_in_height_array", "hme_level1_search_area_in_width_array",
+                    "hme_level1_search_area_in_height_array", "hme_level2_search_area_in_width_array", "hme_level2_search_area_in_height_array")
+
+
+def me_preset_requests():
+    """(W, H, enc_mode, tune, temporal_layer, is_used_as_reference, frame_rate) rows: every size class x tune x mode x layer."""
+    rows = []
+    for (w, h) in ME_PRESET_SIZES:
+        for tune in range(3):
+            for mode in range(13):
+                for (tl, used) in ((0, 1), (1, 1), (3, 1), (4, 0)):
+                    for fps in (60, 30):
+                        rows.append((w, h, mode, tune, tl, used, fps))
+    return np.array(rows, np.int32)
+
+
+def ref_me_presets():
+    """The reference's own derivation (oracle/_ref/ref_me_presets) for me_preset_requests(): dict(req, out int32 [n][30])."""
+    req = me_preset_requests()
+    text = "".join(" ".join(map(str, r)) + "\n" for r in req.tolist())
+    out = subprocess.check_output([os.path.join(REF_DIR, "ref_me_presets")], input=text.encode()).decode()
+    out = np.array([[int(x) for x in ln.split()] for ln in out.strip().splitlines()], np.int32)
+    assert out.shape == (len(req), 30)
+    return dict(req=req, out=out)
+
+
+def product_me_preset_row(w, h, mode, tune, tl, used, fps):
+    """svt_hip_me_params_derive + svt_hip_input_resolution in the column order of ref_me_presets() (use_subpel is the one
+    column svt_me_params does not carry directly: it is fractional_search_model != 2)."""
+    p = B.me_params_derive(pic_width=w, pic_height=h, enc_mode=mode, tune=tune, frame_rate=fps, num_ref_lists=2,
+                           temporal_layer_index=tl, hierarchical_levels=4, is_used_as_reference=used)
+    row = []
+    for n in ME_PRESET_FIELDS:
+        if n == "input_resolution":
+            row.append(B.load().svt_hip_input_resolution(w, h))
+        elif n == "use_subpel":
+            row.append(int(p.fractional_search_model != 2))
+        else:
+            row.append(int(getattr(p, n)))
+    for n in ME_PRESET_ARRAYS:
+        row += [int(x) for x in getattr(p, n)]
+    return row
+
+
+def ref_lf_params():
+    """The reference's own eb_vp9_loop_filter_init tables for sharpness 0..7 and eb_vp9_pick_filter_level's choice for
+    every base_qindex (inter / key frame): dict(thr uint8 [8][3][64] = mblim, lim, hev_thr; pick int32 [2][256][3] =
+    ac_quant(qindex), filter_level, sharpness_level)."""
+    exe = os.path.join(REF_DIR, "ref_lf_frame")
+    with tempfile.TemporaryDirectory() as td:
+        req, rsp = os.path.join(td, "req.bin"), os.path.join(td, "rsp.bin")
+        open(req, "wb").write(struct.pack("<5i", 0x504C5653, 0, 0, 0, 0))
+        subprocess.check_call([exe, req, rsp])
+        raw = open(rsp, "rb").read()
+    return dict(thr=np.frombuffer(raw, np.uint8, 8 * 192).reshape(8, 3, 64).copy(),
+                pick=np.frombuffer(raw, np.int32, 2 * 256 * 3, 8 * 192).reshape(2, 256, 3).copy())
 
 
 def hip_lf_frame(ctx, case, y_only=False):

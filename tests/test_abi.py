@@ -35,32 +35,6 @@ def test_struct_sizes_match_header():
     assert sizes == [32, 40, 32, 160, 12, 16, 56472, C.sizeof(B.McPicture)], sizes
 
 
-def test_me_presets_follow_reference_tables():
-    p = B.me_params_preset(3840, 2160, 8, 1, 2, 1, 4)
-    assert (p.search_area_width, p.search_area_height) == (8, 7) and p.single_hme_quadrant == 1
-    assert p.enable_hme_level_1_flag == 0 and p.hme_level0_total_search_area_width == 64 and p.fractional_search_model == 1
-    p = B.me_params_preset(1920, 1080, 8, 1, 2, 1, 4)
-    assert (p.search_area_width, p.search_area_height) == (16, 9) and p.single_hme_quadrant == 0 and p.enable_hme_level_2_flag == 1
-    p = B.me_params_preset(640, 360, 9, 1, 1, 0, 4)
-    assert (p.search_area_width, p.search_area_height, p.hme_level0_total_search_area_width) == (16, 7, 32)
-    p = B.me_params_preset(3840, 2160, 3, 0, 2, 1, 3)
-    assert p.fractional_search_method == 2 and p.search_area_width == 64 and p.cu8x8_mode == 0
-    q = B.MeParams()
-    assert B.load().svt_hip_me_params_preset(C.byref(q), 1280, 720, 5, 1, 1, 0, 4) == -4  # unsupported combination
-
-
-def test_lf_host_params_match_oracle():
-    lib, ora = B.load(), T.oracle()
-    for sharp in range(8):
-        a, b = B.LfThresh(), B.LfThresh()
-        lib.svt_hip_lf_thresh_init(C.byref(a), sharp)
-        ora.svt_oracle_lf_thresh_init(C.byref(b), sharp)
-        assert bytes(a) == bytes(b)
-    for q in (4, 100, 400, 1000, 1828):
-        for key in (0, 1):
-            assert lib.svt_hip_lf_level_from_q(q, key) == ora.svt_oracle_lf_level_from_q(q, key)
-
-
 def test_compute_entry_points_fail_loudly_without_gpu():
     """No CPU fallback: without a usable device the context cannot even be created."""
     import torch

@@ -1,0 +1,55 @@
+"""Host-side ME parameter derivation (svt_hip_me_params_derive / _preset, svt_hip_input_resolution) against the REFERENCE's
+own eb_vp9_derive_input_resolution + eb_vp9_signal_derivation_{pre_analysis,multi_processes,me_kernel}_{sq,oq,vmaf}: every
+resolution class (incl. the class boundaries and odd aspect ratios), tune 0-2, enc_mode 0-12, four temporal layers, 60 and 30
+frames/s.  The committed fixture holds the reference's output (tests/gen_golden.py me_presets); with oracle/_ref present the
+reference is also run live."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import svt_testlib as T
+
+B = T.B
+GOLD = os.path.join(T.GOLDEN_DIR, "me_presets_reference.npz")
+
+
+def _check(req, out):
+    assert len(req) == len(out) and len(req) > 3000
+    for r, want in zip(req.tolist(), out.tolist()):
+        got = T.product_me_preset_row(*r)
+        assert got == want, (r, got, want)
+
+
+def test_me_presets_vs_golden():
+    g = np.load(GOLD)
+    assert np.array_equal(g["req"], T.me_preset_requests())
+    _check(g["req"], g["out"])
+
+
+@pytest.mark.skipif(not T.have_ref("ref_me_presets"), reason="oracle/_ref/ref_me_presets not built (reference absent)")
+def test_me_presets_vs_reference_live():
+    r = T.ref_me_presets()
+    _check(r["req"], r["out"])
+
+
+def test_me_preset_shorthand_is_the_default_structure():
+    """svt_hip_me_params_preset = derive() with is_used_as_reference = (layer < levels) at 60 frames/s; BASELINE rows."""
+    for (w, h, mode, tune, nl, tl, hl) in ((3840, 2160, 8, 1, 2, 1, 4), (1920, 1080, 8, 1, 2, 4, 4), (640, 360, 9, 1, 1, 0, 4),
+                                           (3840, 2160, 3, 0, 2, 3, 3), (2048, 1080, 8, 1, 2, 2, 4), (960, 540, 5, 2, 2, 4, 4)):
+        a = B.me_params_preset(w, h, mode, tune, nl, tl, hl)
+        b = B.me_params_derive(pic_width=w, pic_height=h, enc_mode=mode, tune=tune, frame_rate=60, num_ref_lists=nl,
+                               temporal_layer_index=tl, hierarchical_levels=hl, is_used_as_reference=int(tl < hl))
+        assert bytes(a) == bytes(b)
+    p = B.me_params_preset(3840, 2160, 8, 1, 2, 1, 4)
+    assert (p.search_area_width, p.search_area_height, p.single_hme_quadrant, p.enable_hme_level_1_flag) == (8, 7, 1, 0)
+
+
+def test_me_preset_rejects_bad_arguments():
+    q = B.MeParams()
+    lib = B.load()
+    assert lib.svt_hip_me_params_preset(C.byref(q), 1280, 720, 13, 1, 1, 0, 4) == -1
+    assert lib.svt_hip_me_params_preset(C.byref(q), 1280, 720, 5, 3, 1, 0, 4) == -1
+    assert lib.svt_hip_me_params_preset(C.byref(q), 1280, 720, 5, 1, 3, 0, 4) == -1
+    assert lib.svt_hip_me_params_preset(None, 1280, 720, 5, 1, 1, 0, 4) == -1
