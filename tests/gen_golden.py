@@ -124,6 +124,11 @@ def gen_ivf():
     np.savez_compressed(os.path.join(G, "ivf_reference.npz"), **ivf)
 
 
+def gen_sad_loop():
+    # ---- stand-alone exhaustive SAD search: the reference's eb_vp9_sad_loop_kernel on the jobs of make_sad_loop_case ----
+    np.savez_compressed(os.path.join(G, "sad_loop_reference.npz"), **{str(seed): T.ref_sad_loop_case(T.make_sad_loop_case(seed)) for seed in (1, 2)})
+
+
 def gen_lf_params():
     # ---- LF parameters: the reference's eb_vp9_loop_filter_init (sharpness 0..7) and eb_vp9_pick_filter_level (all q) ----
     np.savez_compressed(os.path.join(G, "lf_params_reference.npz"), **T.ref_lf_params())
@@ -134,7 +139,7 @@ def gen_me_presets():
     np.savez_compressed(os.path.join(G, "me_presets_reference.npz"), **T.ref_me_presets())
 
 
-SECTIONS = ("scan", "me", "tq", "lf", "lf_masks", "mc", "rate", "quant", "ivf", "lf_params", "me_presets")
+SECTIONS = ("scan", "me", "tq", "lf", "lf_masks", "mc", "rate", "quant", "ivf", "lf_params", "me_presets", "sad_loop")
 
 
 def main():

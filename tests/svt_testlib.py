@@ -118,6 +118,28 @@ def oracle_me_picture(cur, ref0, ref1, params, sb_begin=0, sb_end=-1):
     return res, rcme
 
 
+def oracle_me_picture_mt(cur, ref0, ref1, params, threads=None):
+    """svt_oracle_me_picture over the whole picture, SB ranges spread over host threads (ctypes drops the GIL; an SB's result
+    depends on nothing outside the SB, and the oracle keeps its working state per call)."""
+    from concurrent.futures import ThreadPoolExecutor
+    threads = threads or min(os.cpu_count() or 1, 64)
+    w, h = cur.luma.shape[1], cur.luma.shape[0]
+    nsb = n_sb(w, h)
+    res = np.zeros((nsb, 85), dtype=B.ME_RESULT_DTYPE)
+    rcme = np.zeros(nsb, dtype=np.uint32)
+    dc, d0 = cur.desc(), ref0.desc()
+    d1 = ref1.desc() if ref1 is not None else None
+    step = max(1, (nsb + 4 * threads - 1) // (4 * threads))
+
+    def run(b):
+        rc = oracle().svt_oracle_me_picture(C.byref(dc), C.byref(d0), C.byref(d1) if d1 is not None else None, C.byref(params),
+                                            res.ctypes.data_as(C.c_void_p), rcme.ctypes.data_as(C.c_void_p), b, min(nsb, b + step))
+        assert rc == 0
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(run, range(0, nsb, step)))
+    return res, rcme
+
+
 def ref_me_picture(cur, ref0, ref1, params, sb_begin=0, sb_end=-1):
     """Run the REFERENCE's motion_estimate_sb through oracle/_ref/ref_me_sb (build container only)."""
     exe = os.path.join(REF_DIR, "ref_me_sb")
@@ -599,6 +621,71 @@ def ref_lf_frame(case, y_only=False):
     return (np.frombuffer(raw, np.uint8, ys).reshape(y.shape)[:H0, :W0].copy(),
             np.frombuffer(raw, np.uint8, us, ys).reshape(u.shape)[:H0 // 2, :W0 // 2].copy(),
             np.frombuffer(raw, np.uint8, us, ys + us).reshape(v.shape)[:H0 // 2, :W0 // 2].copy())
+
+
+# ---- stand-alone exhaustive SAD search (row M1) ----------------------------------------------------------------------
+def make_sad_loop_case(seed, n_jobs=48):
+    """Jobs shaped like the reference's three HME uses of eb_vp9_sad_loop_kernel (16x8 / 32x16 / 64x32 blocks whose rows are
+    every other row of the plane: ref_stride = 2 x ref_stride_raw) over windows 1..224 wide, half of them on low-entropy
+    data so that many positions tie (the first minimum in raster order must win)."""
+    rng = np.random.default_rng(seed)
+    src = np.zeros((64, 4096), np.uint8)
+    ref = np.zeros((320, 1024), np.uint8)
+    ref[:, :512] = rng.integers(0, 256, (320, 512))
+    ref[:, 512:] = rng.integers(0, 3, (320, 512))
+    jobs = np.zeros(n_jobs, dtype=B.SAD_LOOP_JOB_DTYPE)
+    for j in range(n_jobs):
+        bw, bh = ((16, 8), (32, 16), (64, 32))[j % 3]
+        low = (j // 3) % 2
+        sw = int(rng.integers(1, 225 if bw == 16 else 40)); sh = int(rng.integers(1, 113 if bw == 16 else 20))
+        if j == 0: sw, sh = 224, 112
+        if j == 1: sw, sh = 1, 1
+        x0 = int(rng.integers(0, 512 - sw - bw)) + 512 * low
+        y0 = int(rng.integers(0, 320 - sh - 2 * bh))
+        blk = rng.integers(0, 3 if low else 256, (bh, bw))
+        if j % 5 == 0:   # plant the block so that an exact match exists
+            yy, xx = y0 + int(rng.integers(0, sh)), x0 + int(rng.integers(0, sw))
+            blk = ref[yy:yy + 2 * bh:2, xx:xx + bw]
+        src[:bh, 64 * j:64 * j + bw] = blk
+        jobs[j] = (64 * j, y0 * 1024 + x0, 4096, 2048, 1024, bw, bh, sw, sh)
+    return dict(src=src, ref=ref, jobs=jobs)
+
+
+def _sad_loop_run(fn, case, is_ref):
+    out = np.zeros((len(case["jobs"]), 3), np.int64)
+    sp, rp = case["src"].ctypes.data, case["ref"].ctypes.data
+    u8p = C.POINTER(C.c_uint8)
+    for i, j in enumerate(case["jobs"]):
+        best, x, y = C.c_uint64(0), C.c_int16(-1), C.c_int16(-1)
+        sw, sh = int(j["search_w"]), int(j["search_h"])
+        fn(C.cast(sp + int(j["src_off"]), u8p), int(j["src_stride"]), C.cast(rp + int(j["ref_off"]), u8p), int(j["ref_stride"]),
+           int(j["height"]), int(j["width"]), C.byref(best), C.byref(x), C.byref(y), int(j["ref_stride_raw"]),
+           C.c_int16(sw) if is_ref else sw, C.c_int16(sh) if is_ref else sh)
+        out[i] = (best.value, x.value, y.value)
+    return out
+
+
+def oracle_sad_loop_case(case):
+    return _sad_loop_run(oracle().oracle_sad_loop, case, False)
+
+
+def ref_sad_loop_case(case):
+    return _sad_loop_run(ref_kernels().eb_vp9_sad_loop_kernel, case, True)
+
+
+def hip_sad_loop_case(ctx, case):
+    import torch
+    dev = torch.device("cuda", 0)
+    ts, tr = torch.from_numpy(case["src"]).to(dev), torch.from_numpy(case["ref"]).to(dev)
+    tj = torch.from_numpy(case["jobs"].view(np.uint8)).to(dev)
+    n = len(case["jobs"])
+    to = torch.zeros(n * 8, dtype=torch.uint8, device=dev)
+    lib = B.load()
+    B.check(lib.svt_hip_sad_loop_batch_device(ctx, C.c_void_p(ts.data_ptr()), C.c_void_p(tr.data_ptr()), C.c_void_p(tj.data_ptr()), n,
+                                              C.c_void_p(to.data_ptr())))
+    B.check(lib.svt_hip_ctx_synchronize(ctx))
+    r = to.cpu().numpy().view(B.SAD_LOOP_RESULT_DTYPE)
+    return np.stack([r["best_sad"].astype(np.int64), r["x"].astype(np.int64), r["y"].astype(np.int64)], axis=1)
 
 
 # (W, H): every resolution class incl. the boundaries of eb_vp9_derive_input_resolution and the aspect-ratio split of the

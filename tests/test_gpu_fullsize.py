@@ -44,6 +44,18 @@ def test_me_full_picture_vs_oracle(ctx, clips, size, nl, tl):
     assert len(np.unique(g["x_mv_l0"])) > 8  # real motion was found
 
 
+def test_me_c5_full_4k_picture_vs_oracle(ctx):
+    """BASELINE config C5 at its own size: 3840x2160, enc-mode 3 tune 0 -- 64x64 full-pel search, 4 HME regions x 3 levels, SSD
+    fractional search on all 85 PUs -- one whole B picture (generic kernel instance) against the oracle (host threads)."""
+    pics = [T.PaPic(f) for f in T.gen_clip_subpel(3840, 2160, 3, 23)]
+    p = MC.preset_c5(2, 1)
+    assert (p.search_area_width, p.search_area_height, p.fractional_search_method, p.cu8x8_mode) == (64, 64, 2, 0)
+    o, _ = T.oracle_me_picture_mt(pics[1], pics[0], pics[2], p)
+    g, _ = hip_me_picture(ctx, pics[1], pics[0], pics[2], p)
+    assert not T.me_results_equal(o, g, 2)
+    assert len(np.unique(g["x_mv_l0"])) > 8
+
+
 def test_me_specialised_and_generic_instances_agree_at_4k():
     """the kernel instance specialised for the 2160p M8 parameters and the generic instance (SVT_HIP_ME_GENERIC=1) are
     the same algorithm: equal checksums of all results of a 4K B picture (run in two fresh processes: the choice is
