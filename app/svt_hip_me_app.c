@@ -90,6 +90,7 @@ int main(int argc, char **argv) {
     if (fv) {
         uint8_t h[SVT_IVF_STREAM_HEADER_BYTES];
         svt_ivf_stream_header(h, (uint32_t)W, (uint32_t)H, (uint32_t)fps << 16, 0, 0);
+        memcpy(h + 8, "SVME", 4); /* the payload is ME records, not a VP9 bitstream: not the reference's "VP90" fourcc */
         fwrite(h, 1, sizeof h, fv);
     }
     /* a window of three pictures: previous, current, next */

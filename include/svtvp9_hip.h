@@ -500,7 +500,12 @@ typedef struct svt_rate_block {
     uint8_t  pad_[2];
 } svt_rate_block;        /* 16 bytes */
 
-/* d_bits[b] = coeff_rate_estimate(...) of block b.  Device pointers; blocks in any order. */
+/* d_bits[b] = coeff_rate_estimate(...) of block b.  Device pointers; blocks in any order.
+ * d_scan must be 4-byte aligned and hold at least SVT_RATE_SCAN_MIN_ENTRIES int16 entries (the size of the four 4x4 and
+ * four 8x8 tables): every workgroup stages that prefix in LDS before it looks at a block (with the canonical layout --
+ * the 4x4 tables of tx_type 0..3 first, then the 8x8 ones -- those blocks read their scan from LDS; any other layout
+ * is still correct, the entries are then read in place).  The host-pointer form pads a shorter array itself. */
+#define SVT_RATE_SCAN_MIN_ENTRIES 976
 int32_t svt_hip_coeff_rate_batch_device(svt_hip_ctx *ctx, const int16_t *d_qcoeff, const svt_rate_block *d_blocks,
                                         int32_t n_blocks, const svt_rate_tables *d_tables, const int16_t *d_scan,
                                         int32_t *d_bits);

@@ -39,9 +39,13 @@ static int32_t ctx_create(svt_hip_ctx **out, int32_t device, void *stream, int o
         c->stream = (hipStream_t)stream;
     }
     c->owns_stream = owns;
-    if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) { free(c); return svt_set_error(SVT_HIP_ERR_DEVICE, "ctx: events"); }
-    for (int i = 0; i < SVT_CTX_RING; i++)
-        if (hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming) != hipSuccess) { free(c); return svt_set_error(SVT_HIP_ERR_DEVICE, "ctx: events"); }
+    /* on failure release whatever exists: events are created null-checked, destroy tolerates the missing ones */
+    bool ok = hipEventCreate(&c->ev_start) == hipSuccess && hipEventCreate(&c->ev_stop) == hipSuccess;
+    for (int i = 0; ok && i < SVT_CTX_RING; i++) ok = hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        svt_hip_ctx_destroy(c);
+        return svt_set_error(SVT_HIP_ERR_DEVICE, "ctx: events");
+    }
     *out = c;
     return SVT_HIP_OK;
 }
@@ -57,16 +61,16 @@ extern "C" void *svt_hip_ctx_stream(svt_hip_ctx *c) { return c ? (void *)c->stre
 extern "C" void svt_hip_ctx_destroy(svt_hip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream || !c->owns_stream) (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < SVT_CTX_SLOTS; i++) if (c->slot[i]) (void)hipFree(c->slot[i]);
     for (int i = 0; i < SVT_CTX_RING; i++) {
         if (c->ring_dev[i]) (void)hipFree(c->ring_dev[i]);
         if (c->ring_host[i]) (void)hipHostFree(c->ring_host[i]);
-        (void)hipEventDestroy(c->ring_ev[i]);
+        if (c->ring_ev[i]) (void)hipEventDestroy(c->ring_ev[i]);
     }
-    (void)hipEventDestroy(c->ev_start);
-    (void)hipEventDestroy(c->ev_stop);
-    if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     free(c);
 }
 extern "C" int32_t svt_hip_ctx_synchronize(svt_hip_ctx *c) {

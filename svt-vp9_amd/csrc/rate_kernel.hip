@@ -68,6 +68,8 @@ __device__ __forceinline__ int rate_positions(const int16_t *q, const int16_t *s
 
 constexpr int RATE_SLICE = 6 * 2 * 6 * 12;           /* dwords of one token_costs[tx_size][plane_type][is_inter] slice */
 constexpr int RATE_SCAN4 = 16 + 2 * 17, RATE_SCAN8 = 64 + 2 * 65; /* int16 entries of a 4x4 / 8x8 {scan, neighbors} table */
+constexpr size_t RATE_SCAN_PREFETCH = 4 * RATE_SCAN4 + 4 * RATE_SCAN8; /* = SVT_RATE_SCAN_MIN_ENTRIES (976) */
+static_assert(RATE_SCAN_PREFETCH == SVT_RATE_SCAN_MIN_ENTRIES, "header constant");
 
 /* Persistent workgroups: a workgroup first copies what the small blocks need -- the eight cost slices of 4x4 / 8x8 blocks
  * (27 KB), their eight scan orders (2 KB, when the caller's scan array has the canonical layout of
@@ -148,12 +150,15 @@ extern "C" int32_t svt_hip_coeff_rate_batch(svt_hip_ctx *ctx, const int16_t *qco
     int16_t          *dq = (int16_t *)svt_ctx_slot(ctx, 34, sizeof(int16_t) * coeff_count);
     svt_rate_block   *db = (svt_rate_block *)svt_ctx_slot(ctx, 35, sizeof(svt_rate_block) * (size_t)n_blocks);
     svt_rate_tables  *dt = (svt_rate_tables *)svt_ctx_slot(ctx, 36, sizeof(svt_rate_tables));
-    int16_t          *ds = (int16_t *)svt_ctx_slot(ctx, 37, sizeof(int16_t) * scan_count);
+    /* the kernel's prologue copies the first RATE_SCAN_PREFETCH entries whatever the blocks use (see the header) */
+    const size_t      scan_alloc = scan_count > RATE_SCAN_PREFETCH ? scan_count : RATE_SCAN_PREFETCH;
+    int16_t          *ds = (int16_t *)svt_ctx_slot(ctx, 37, sizeof(int16_t) * scan_alloc);
     int32_t          *dbits = (int32_t *)svt_ctx_slot(ctx, 38, sizeof(int32_t) * (size_t)n_blocks);
     if (!dq || !db || !dt || !ds || !dbits) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "rate: device buffers");
     HIP_TRY(hipMemcpyAsync(dq, qcoeff, sizeof(int16_t) * coeff_count, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(db, blocks, sizeof(svt_rate_block) * (size_t)n_blocks, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(dt, tables, sizeof(svt_rate_tables), hipMemcpyHostToDevice, ctx->stream));
+    if (scan_alloc > scan_count) HIP_TRY(hipMemsetAsync(ds + scan_count, 0, sizeof(int16_t) * (scan_alloc - scan_count), ctx->stream));
     HIP_TRY(hipMemcpyAsync(ds, scan, sizeof(int16_t) * scan_count, hipMemcpyHostToDevice, ctx->stream));
     int32_t rc = svt_hip_coeff_rate_batch_device(ctx, dq, db, n_blocks, dt, ds, dbits);
     if (rc) return rc;

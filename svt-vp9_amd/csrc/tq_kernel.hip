@@ -438,20 +438,20 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
 }
 
 template <int N>
-int launch_tq(svt_hip_ctx *ctx, const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks, int n,
+hipError_t launch_tq(svt_hip_ctx *ctx, const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks, int n,
               const svt_quant_tables *q, const int16_t *iscan, int16_t *qc, int16_t *dqc, uint16_t *eob, uint64_t *dist) {
-    if (n <= 0) return 0;
+    if (n <= 0) return hipSuccess;
     /* block per lane for 4x4 only: the 8x8 instance is bit-exact too but needs 201 VGPRs (64 samples + the transposed
      * intermediate live in one lane; 87 spills when held to 128) -- two waves per SIMD, and each displaces two ME waves:
      * the overlapped step went from 3.27 to 3.77 ms with it, so 8x8 stays on the N-lanes-per-block kernel */
     if constexpr (N == 4) {
         hipLaunchKernelGGL(svt_tq_lane_kernel<N>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, src, pred, recon, blocks, n, q, iscan, qc, dqc, eob, dist);
-        return hipGetLastError() == hipSuccess ? 0 : -1;
+        return hipGetLastError();
     }
     constexpr int NT = N == 32 ? 128 : 256, BPW = NT / N;
     hipLaunchKernelGGL(svt_tq_kernel<N>, dim3((n + BPW - 1) / BPW), dim3(NT), 0, ctx->stream, src, pred, recon, blocks, n, q, iscan,
                        qc, dqc, eob, dist);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return hipGetLastError();
 }
 } // namespace
 
@@ -477,16 +477,17 @@ extern "C" int32_t svt_hip_tq_batch_dist_device(svt_hip_ctx *ctx, const uint8_t 
     if (((uintptr_t)d_qcoeff | (uintptr_t)d_dqcoeff) & 15) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq: coefficient arrays must be 16-byte aligned");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
-    int off = 0, rc = 0;
-    rc |= launch_tq<4>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[0], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr);
+    int        off = 0;
+    hipError_t rc;
+    rc = launch_tq<4>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[0], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr);
     off += size_count[0];
-    rc |= launch_tq<8>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[1], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr);
+    if (rc == hipSuccess) rc = launch_tq<8>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[1], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr);
     off += size_count[1];
-    rc |= launch_tq<16>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[2], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr);
+    if (rc == hipSuccess) rc = launch_tq<16>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[2], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr);
     off += size_count[2];
-    rc |= launch_tq<32>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[3], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr);
-    if (rc) return svt_set_hip_error(hipGetLastError(), __FILE__, __LINE__);
-    HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    if (rc == hipSuccess) rc = launch_tq<32>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[3], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr);
+    (void)hipEventRecord(ctx->ev_stop, ctx->stream); /* also on a failed launch: ev_start is already in the stream */
+    if (rc != hipSuccess) return svt_set_hip_error(rc, __FILE__, __LINE__);
     ctx->timed = 1;
     return SVT_HIP_OK;
 }

@@ -66,7 +66,7 @@ def test_app_records_equal_the_oracle(W, H, N, mode, bipred):
             assert got[k - 1].tobytes() == want.tobytes(), k
         # the IVF stream: the reference application's header, then one frame per picture holding the same records
         raw = open(ivf, "rb").read()
-        assert raw[:4] == b"DKIF" and struct.unpack("<HHIHHII", raw[4:24]) == (0, 32, 0x30395056, W, H, 30000, 1000)
+        assert raw[:4] == b"DKIF" and struct.unpack("<HHIHHII", raw[4:24]) == (0, 32, struct.unpack("<I", b"SVME")[0], W, H, 30000, 1000)   # own fourcc: records, not VP9
         rb, pos = nsb * 85 * B.ME_RESULT_DTYPE.itemsize, 32
         for k in range(1, N):
             size, pts = struct.unpack("<IQ", raw[pos:pos + 12])
