@@ -608,7 +608,7 @@ def cpu_baseline(T, B, frames, src_all, mi_list, tq_blocks_all, pic_of_block, qt
     orc = build_native_oracle()
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
     ncpu = os.cpu_count() or 1
-    sample = [8, 4, 12, 2]            # mini-GOP positions (temporal layers 1, 2, 2, 3)
+    sample = [8, 4, 2, 1, 3, 12, 5, 7]   # mini-GOP positions: temporal layers 1, 2, 3, 4, 4, 2, 4, 4 (half of a mini-GOP is layer 4)
     mi_rows, mi_cols = Hd // 8, Wd // 8
     nsb = T.n_sb(Wd, Hd)
     yuv_rows = Hd + Hd // 2
@@ -641,7 +641,7 @@ def cpu_baseline(T, B, frames, src_all, mi_list, tq_blocks_all, pic_of_block, qt
             # motion estimation: SB ranges of the sampled pictures
             jobs = []
             res = {i: np.zeros((nsb, 85), dtype=B.ME_RESULT_DTYPE) for i in sample}
-            step = max(1, nsb // (4 * nthreads) if nthreads > 1 else nsb)
+            step = max(4, -(-len(sample) * nsb // (3 * nthreads)))   # ~3 jobs per thread: the oracle allocates its planes per call
             for i in sample:
                 p = B.me_params_preset(Wd, Hd, 8, 1, 2, LAYER[i - 1], 4)
                 a, b = refs_of(i)
@@ -684,33 +684,33 @@ def cpu_baseline(T, B, frames, src_all, mi_list, tq_blocks_all, pic_of_block, qt
             blk["src_off"] -= np.uint32(pic_bytes)       # host source buffer below starts at picture 1
             src_h = src_all[1:]
             sel = np.nonzero(np.isin(pic_of_block, [i - 1 for i in sample]))[0]
-            chunks = np.array_split(sel, max(1, 8 * nthreads))
+            chunks = [ix for ix in np.array_split(sel, max(1, 3 * nthreads)) if len(ix)]
+            blk_of = [np.ascontiguousarray(blk[ix]) for ix in chunks]     # sliced outside the timed part
+            rb_of = [np.ascontiguousarray(rb[ix]) for ix in chunks]
 
-            def tq_chunk(ix):
-                if not len(ix):
-                    return
-                b = np.ascontiguousarray(blk[ix])
+            def tq_chunk(k):
+                ix, b = chunks[k], blk_of[k]
                 e = np.zeros(len(ix), np.uint16)
                 rc = orc.svt_oracle_tq_batch(vp(src_h), vp(pred_h), vp(rec_h), vp(b), len(ix), vp(qtabs), vp(iscan), vp(q_h), vp(dq_h), vp(e))
                 assert rc == 0
                 eob_o[ix] = e
             t0 = time.perf_counter()
-            list(ex.map(tq_chunk, chunks))
+            list(ex.map(tq_chunk, range(len(chunks))))
             t["tq"] = time.perf_counter() - t0
             # coefficient rate: block ranges
             bits = np.zeros(len(rb), np.int32)
 
-            def rate_chunk(ix):
-                if not len(ix):
-                    return
-                r = np.ascontiguousarray(rb[ix])
+            rtab_c = np.ascontiguousarray(rtab).reshape(1)
+
+            def rate_chunk(k):
+                ix, r = chunks[k], rb_of[k]
                 r["eob"] = eob_o[ix]
                 o = np.zeros(len(ix), np.int32)
-                rc = orc.svt_oracle_coeff_rate_batch(vp(q_h), vp(r), len(ix), vp(np.ascontiguousarray(rtab).reshape(1)), vp(rscan), vp(o))
+                rc = orc.svt_oracle_coeff_rate_batch(vp(q_h), vp(r), len(ix), vp(rtab_c), vp(rscan), vp(o))
                 assert rc == 0
                 bits[ix] = o
             t0 = time.perf_counter()
-            list(ex.map(rate_chunk, chunks))
+            list(ex.map(rate_chunk, range(len(chunks))))
             t["rate"] = time.perf_counter() - t0
             # deblocking: one picture per task (SB raster order inside a picture is serial in the reference's C path too)
 
