@@ -8,7 +8,7 @@ wrote:
 
     picture analysis (padded + 1/16 planes from the source luma)  ->  motion estimation (16 B pictures, 2 lists)
     inter prediction from the mode-info grids  ->  residual / transform / quantisation / reconstruction + distortion
-        ->  coefficient rate of the quantised blocks  ->  in-loop deblocking of the reconstruction
+        + coefficient rate of the quantised blocks (one fused pass)  ->  in-loop deblocking of the reconstruction
 
 The mode-info grids (partition, prediction direction and motion vectors of every block) are mode decision's output
 -- host logic outside this path -- and are built ONCE before the timed loop from a first ME pass over the same
@@ -40,7 +40,7 @@ MINIGOP = 16
 Q_INDEX = 160   # -q 40: quantizer_to_qindex[40]
 # temporal layer of picture i (1..16) inside a 16-picture mini-GOP (5 layers, hierarchical_levels = 4)
 LAYER = [4, 3, 4, 2, 4, 3, 4, 1, 4, 3, 4, 2, 4, 3, 4, 0]
-STAGES = ("pa", "me", "mc", "tq", "rate", "lf")
+STAGES = ("pa", "me", "mc", "tq", "rate", "lf")   # "rate" is a launch of its own only with SVT_BENCH_SEPARATE_RATE=1 (A/B aid)
 
 
 def algorithmic_bytes_me(width, height, n_lists, l1_on):
@@ -378,6 +378,8 @@ def main():
         B.check(lib.svt_hip_inter_pred_batch_device(ctx_enc, MINIGOP, mc_pics))
 
     # ---- stage "tq": residual -> transform -> quantisation -> reconstruction (+ coefficient-domain distortion) ----
+    rate_ctx = np.random.default_rng(8).integers(0, 3, len(tq_blocks_all)).astype(np.uint8)   # entropy context of every block (an input)
+    tq_blocks_all["pad"][:, 0] = rate_ctx | (tq_blocks_all["qtab"] << 2) | (1 << 3)            # SVT_TQ_RATE_INFO(ctx, plane_type, is_inter = 1)
     d_blocks, d_qt, d_iscan = to_dev(tq_blocks_all.view(np.uint8)), to_dev(qtabs.view(np.uint8)), to_dev(iscan)
     d_q, d_dq = dev_zeros(n_coeff_all, torch.int16), dev_zeros(n_coeff_all, torch.int16)
     d_eob = dev_zeros(len(tq_blocks_all), torch.int16)
@@ -385,7 +387,9 @@ def main():
     d_rec = [dev_zeros((MINIGOP, yuv_rows, plane_w), torch.uint8) for _ in range(2)]   # double-buffered: LF(k) || TQ(k+1)
     # the block list is the same for both reconstruction buffers (offsets are relative to the buffer)
 
-    def run_tq(buf):
+    separate_rate = os.environ.get("SVT_BENCH_SEPARATE_RATE", "0") == "1"
+
+    def run_tq_plain(buf):
         B.check(lib.svt_hip_tq_batch_dist_device(ctx_enc, C.c_void_p(d_src.data_ptr()), C.c_void_p(d_pred.data_ptr()), C.c_void_p(d_rec[buf].data_ptr()),
                                                  C.c_void_p(d_blocks.data_ptr()), cnt_c, C.c_void_p(d_qt.data_ptr()), C.c_void_p(d_iscan.data_ptr()),
                                                  C.c_void_p(d_q.data_ptr()), C.c_void_p(d_dq.data_ptr()), C.c_void_p(d_eob.data_ptr()),
@@ -394,10 +398,16 @@ def main():
     # first transform pass (setup): eobs -> skip flags of the loop-filter mode info and the rate stage's records
     with torch.cuda.stream(streams[1]):
         run_mc()
-        run_tq(0)
+        run_tq_plain(0)
     B.check(lib.svt_hip_ctx_synchronize(ctx_enc))
     torch.cuda.synchronize()
     eob_h = d_eob.cpu().numpy().view(np.uint16)
+    # what the synthesised mode decision produced (reported with the result: the transform / rate stages' work depends on it)
+    with torch.no_grad():
+        resid = (d_src[1:, :Hd].to(torch.int16) - d_pred[:, :Hd].to(torch.int16)).abs().to(torch.float32).mean().item()
+    workload_stats = {"mean_abs_luma_residual": round(resid, 2),
+                      "mean_eob_by_tx_size": [round(float(eob_h[tq_blocks_all["tx_size"] == ts].mean()), 1) for ts in range(4)],
+                      "blocks_by_tx_size": counts}
 
     # ---- stage "rate": bits of every transform block from the quantised coefficients the transform stage wrote ----
     rtab, rscan = T.rate_tables()
@@ -406,9 +416,18 @@ def main():
     rb["coeff_off"], rb["tx_size"], rb["eob"] = tq_blocks_all["coeff_off"], tq_blocks_all["tx_size"], eob_h
     rb["scan_off"] = np.array([roffs[(ts, 0)] for ts in range(4)], np.uint32)[tq_blocks_all["tx_size"]]
     rb["plane_type"], rb["is_inter"] = tq_blocks_all["qtab"], 1
-    rb["ctx"] = np.random.default_rng(8).integers(0, 3, len(rb))
+    rb["ctx"] = rate_ctx
     d_rb, d_rt, d_rs = to_dev(rb.view(np.uint8)), to_dev(np.ascontiguousarray(rtab).reshape(1).view(np.uint8)), to_dev(rscan)
     d_bits = dev_zeros(len(rb), torch.int32)
+
+    def run_tq_rd(buf):   # distortion + rate behind the quantiser: perform_dist_rate_calc in one pass
+        B.check(lib.svt_hip_tq_rd_batch_device(ctx_enc, C.c_void_p(d_src.data_ptr()), C.c_void_p(d_pred.data_ptr()), C.c_void_p(d_rec[buf].data_ptr()),
+                                               C.c_void_p(d_blocks.data_ptr()), cnt_c, C.c_void_p(d_qt.data_ptr()), C.c_void_p(d_iscan.data_ptr()),
+                                               C.c_void_p(d_q.data_ptr()), C.c_void_p(d_dq.data_ptr()), C.c_void_p(d_eob.data_ptr()),
+                                               C.c_void_p(d_dist.data_ptr()), C.c_void_p(d_rt.data_ptr()), C.c_void_p(d_rs.data_ptr()),
+                                               C.c_void_p(d_bits.data_ptr())))
+
+    run_tq = run_tq_plain if separate_rate else run_tq_rd
 
     def run_rate():
         B.check(lib.svt_hip_coeff_rate_batch_device(ctx_enc, C.c_void_p(d_q.data_ptr()), C.c_void_p(d_rb.data_ptr()), len(rb), C.c_void_p(d_rt.data_ptr()),
@@ -485,7 +504,8 @@ def main():
         staged("tq", streams[1], lambda: run_tq(buf), record)
         e_tq = torch.cuda.Event()
         e_tq.record(streams[1])
-        staged("rate", streams[1], run_rate, record)
+        if separate_rate:
+            staged("rate", streams[1], run_rate, record)
         streams[2].wait_event(e_tq)
         staged("lf", streams[2], lambda: run_lf(buf), record)
         lf_done[buf] = torch.cuda.Event()
@@ -532,8 +552,11 @@ def main():
         "rate": int(np.sum(np.minimum(nn, ((eob_h.astype(np.int64) * 2 + 63) // 64 + 1) * 32)) * 2 + 20 * len(rb)),
         "lf": MINIGOP * (3 * L + 160 * nsb),         # recon read + write (3L) + masks
     }
-    kernel_of = {"pa": "svt_pa_plane_kernel", "me": "svt_me_sb_kernel", "mc": "svt_mc_kernel", "tq": "svt_tq_kernel<4|8|16|32>",
+    kernel_of = {"pa": "svt_pa_plane_kernel", "me": "svt_me_sb_kernel", "mc": "svt_mc_kernel",
+                 "tq": "svt_tq_kernel<4|8|16|32>" + ("" if separate_rate else " (+ fused coefficient rate)"),
                  "rate": "svt_rate_kernel", "lf": "svt_lf_kernel"}
+    if not separate_rate:
+        stages.discard("rate")
     if rank != 0:
         return
     me_ms = max(stage_ms["me"], 1e-9)
@@ -576,6 +599,7 @@ def main():
                               "coefficient_rate", "deblocking"],
                    "stages_run": [s for s in STAGES if s in stages],
                    "pictures_per_step": MINIGOP, "transform_blocks_per_step": int(len(tq_blocks_all)), "q_index": Q_INDEX,
+                   "workload_stats": workload_stats,
                    "parallelism": f"gop-shard x{world}"},
         "roofline": {"bound": "hbm", "kernel": "svt_me_sb_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
                      "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,

@@ -305,8 +305,11 @@ typedef struct svt_tq_block {
     uint8_t  qtab;       /* index into the quant-table array */
     uint8_t  do_recon;   /* run inverse transform + add into recon */
     uint8_t  partial32;  /* 32x32 only: use eb_vpx_partial_fdct32x32 (low 16x16 kept, rest zero) */
-    uint8_t  pad_[1];
+    uint8_t  pad_[1];    /* svt_hip_tq_rd_batch_device only: SVT_TQ_RATE_INFO(ctx, plane_type, is_inter), the block's rate inputs */
 } svt_tq_block;          /* 32 bytes */
+/* rate inputs of a block for the fused distortion + rate entry: ctx = combine_entropy_contexts(left, above) 0..2
+ * (Codec/EbEncDecProcess.c:734), plane_type = get_plane_type (0 luma, 1 chroma), is_inter = is_inter_block(mi) */
+#define SVT_TQ_RATE_INFO(ctx, plane_type, is_inter) ((uint8_t)(((ctx) & 3) | (((plane_type) & 1) << 2) | (((is_inter) & 1) << 3)))
 
 /* Scan tables: the caller passes the reference's own iscan tables (scan_order->iscan of
  * eb_vp9_scan_orders[tx_size][tx_type] / eb_vp9_default_scan_orders[TX_32X32], VPX/vp9_scan.c) concatenated
@@ -338,6 +341,25 @@ int32_t svt_hip_tq_batch_dist_device(svt_hip_ctx *ctx, const uint8_t *d_src, con
                                      const svt_tq_block *d_blocks, const int32_t size_count[4],
                                      const svt_quant_tables *d_qtabs, const int16_t *d_iscan, int16_t *d_qcoeff,
                                      int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist);
+
+/* Forward declaration (defined with the coefficient rate section below). */
+struct svt_rate_tables;
+
+/* perform_dist_rate_calc in one pass (Codec/EbEncDecProcess.c:700-745): svt_hip_tq_batch_dist_device plus, per block,
+ * d_bits[b] = coeff_rate_estimate(...) (Codec/EbRateDistortionCost.c:55-172, use_fast_coef_costing = 0) of the coefficients the
+ * quantiser has just produced -- computed from registers / LDS behind the quantiser, no second pass over d_qcoeff.  The
+ * block's rate inputs travel in svt_tq_block.pad_[0] (SVT_TQ_RATE_INFO).  d_tables / d_scan as for
+ * svt_hip_coeff_rate_batch_device, with d_scan in the CANONICAL layout: for tx_size 0..3, for tx_type 0..3 the table
+ * {scan[n], neighbors[2 (n + 1)]} of eb_vp9_scan_orders[tx_size][tx_type] (for 32x32 the four slots all hold the
+ * default order); a block's table is found from its tx_size / tx_type.  4x4 blocks are walked with the three VP9 4x4 scan
+ * orders compiled into the kernel (svt_hip_rate_scan4x4_table returns them; d_scan must hold the same, normative, ones). */
+int32_t svt_hip_tq_rd_batch_device(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *d_recon,
+                                   const svt_tq_block *d_blocks, const int32_t size_count[4],
+                                   const svt_quant_tables *d_qtabs, const int16_t *d_iscan, int16_t *d_qcoeff,
+                                   int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist,
+                                   const struct svt_rate_tables *d_tables, const int16_t *d_scan, int32_t *d_bits);
+/* host: the 4x4 scan order (16 entries) and neighbour pairs (32 entries) the fused rate pass uses for tx_type 0..3 */
+int32_t svt_hip_rate_scan4x4_table(int32_t tx_type, int16_t out[48]);
 
 int32_t svt_hip_tq_batch(svt_hip_ctx *ctx, const uint8_t *src, const uint8_t *pred, uint8_t *recon,
                          size_t plane_bytes, const svt_tq_block *blocks, int32_t n_blocks,

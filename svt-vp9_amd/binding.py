@@ -121,7 +121,7 @@ EXPORTS = [
     "svt_hip_ctx_destroy", "svt_hip_ctx_synchronize", "svt_hip_last_error", "svt_hip_last_kernel_ms",
     "svt_hip_me_picture_device", "svt_hip_me_batch_device", "svt_hip_me_picture", "svt_hip_sad_loop_batch_device",
     "svt_hip_me_zz_sad_device", "svt_hip_me_similar_collocated", "svt_hip_pa_prepare_batch_device", "svt_hip_pa_mean_variance_device",
-    "svt_hip_quant_tables_init", "svt_hip_tq_batch_device", "svt_hip_tq_batch_dist_device", "svt_hip_tq_batch", "svt_hip_lf_thresh_init", "svt_hip_lf_level_from_q",
+    "svt_hip_quant_tables_init", "svt_hip_tq_batch_device", "svt_hip_tq_batch_dist_device", "svt_hip_tq_rd_batch_device", "svt_hip_rate_scan4x4_table", "svt_hip_tq_batch", "svt_hip_lf_thresh_init", "svt_hip_lf_level_from_q",
     "svt_hip_lf_frame_device", "svt_hip_lf_batch_device", "svt_hip_lf_frame", "svt_hip_lf_build_masks",
     "svt_hip_inter_pred_batch_device", "svt_hip_inter_pred_frame", "svt_hip_coeff_rate_batch_device", "svt_hip_coeff_rate_batch",
     "svt_ivf_stream_header", "svt_ivf_packetize",

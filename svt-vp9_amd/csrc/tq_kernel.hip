@@ -19,8 +19,31 @@
 #include <hip/hip_runtime.h>
 #include "svt_ctx.h"
 #include "txfm1d.h"
+#include "rate_core.h"
 
 namespace {
+
+/* Coefficient rate fused behind the quantiser (svt_hip_tq_rd_batch_device): what coeff_rate_estimate
+ * (Codec/EbRateDistortionCost.c:55-172) returns for the block just quantised, from the coefficients while they are still
+ * in registers / LDS -- perform_dist_rate_calc's (Codec/EbEncDecProcess.c:700-745) distortion + rate pair in one pass. */
+struct tq_rate_args {
+    const svt_rate_tables *T;   /* cost tables (device) */
+    const int16_t         *scan; /* {scan, neighbors} tables, canonical layout [tx_size][tx_type] (device) */
+    int32_t               *bits; /* out, per block */
+};
+
+/* Workgroups are persistent and XCD-aware: workgroup w runs on XCD w & 7 (round-robin dispatch), and the groups of blocks it
+ * walks are a contiguous eighth of the batch -- neighbouring blocks (which share 64-byte lines of the planes: a 4x4 block's
+ * row is 4 bytes) are then fetched into ONE XCD's L2 instead of two. */
+struct tq_walk { int per_xcd, first, step, base; };
+__device__ __forceinline__ tq_walk tq_walk_of(int ngroups) {
+    tq_walk w;
+    w.per_xcd = (ngroups + 7) >> 3;
+    w.base    = (int)(blockIdx.x & 7) * w.per_xcd;
+    w.first   = (int)(blockIdx.x >> 3);
+    w.step    = (int)(gridDim.x >> 3);
+    return w;
+}
 
 template <int N> struct txcfg;
 template <> struct txcfg<4> { static constexpr int size = SVT_TX_4X4, shift = 4; };
@@ -89,20 +112,38 @@ __device__ __forceinline__ int clamp16(int v) { return v < -32768 ? -32768 : v >
 __device__ __forceinline__ uint8_t clip_add(int d, int t) { int v = d + t; return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
 
 /* 32x32: 33 KB of LDS per workgroup allow four workgroups per CU; the register budget is held to the matching 128 */
-template <int N>
+template <int N, bool RATE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 4 : 1))) void svt_tq_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ pred,
                                                      uint8_t *__restrict__ recon, const svt_tq_block *__restrict__ blocks,
                                                      int n_blocks, const svt_quant_tables *__restrict__ qtabs,
                                                      const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,
                                                      int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out,
-                                                     uint64_t *__restrict__ dist_out) {
+                                                     uint64_t *__restrict__ dist_out, tq_rate_args ra) {
     constexpr int BPW = (N == 32 ? 128 : 256) / N; /* blocks per workgroup (32x32: 4 blocks = 17 KB of LDS, small enough to
                                                       share a CU with four ME workgroups) */
+    constexpr int NT  = N == 32 ? 128 : 256;
     constexpr int LS  = N + 1;            /* padded LDS row stride in dwords */
     __shared__ int32_t tile[BPW][N * LS];
+    /* RATE: the four token-cost slices [plane_type][is_inter] of this transform size, copied once per (persistent) workgroup */
+    __shared__ uint32_t s_tc[RATE ? 4 * RATE_SLICE : 1];
+    /* ... and the {scan, neighbours} tables of this size (all four transform types; one for 32x32): the walk's three table
+     * reads per position then cost an LDS access instead of a dependent global round trip */
+    constexpr int SCAN_T = 3 * N * N + 2, SCAN_N = (N == 32 ? 1 : 4) * SCAN_T;
+    __shared__ int16_t s_scan[RATE ? SCAN_N : 2];
+    if constexpr (RATE) {
+        const uint32_t *g = &ra.T->token_costs[txcfg<N>::size][0][0][0][0][0][0];
+        for (int j = threadIdx.x; j < 4 * RATE_SLICE; j += NT) s_tc[j] = g[j];
+        const uint32_t *gs = (const uint32_t *)(ra.scan + rate_scan_offset(txcfg<N>::size, 0)); /* 4-byte aligned, even count */
+        for (int j = threadIdx.x; j < SCAN_N / 2; j += NT) ((uint32_t *)s_scan)[j] = gs[j];
+        __syncthreads();
+    }
     const int lb  = threadIdx.x / N;      /* block slot inside the workgroup */
     const int i   = threadIdx.x % N;      /* column (pass 1) / row (pass 2) owned by this lane */
-    const int blk = blockIdx.x * BPW + lb;
+    const tq_walk wk = tq_walk_of((n_blocks + BPW - 1) / BPW);
+  for (int gj = wk.first; gj < wk.per_xcd; gj += wk.step) {
+    const int grp = wk.base + gj;
+    if (grp * BPW >= n_blocks) break;     /* uniform: depends on the workgroup only */
+    const int blk = grp * BPW + lb;
     const bool active = blk < n_blocks;
     svt_tq_block k;
     if (active) k = blocks[blk];
@@ -221,12 +262,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 4
             const int j = (kk % VC) >> 1;
             if (kk & 1) { qw[j] |= (uint32_t)(uint16_t)qv << 16; dqw[j] |= (uint32_t)(uint16_t)dv << 16; }
             else { qw[j] = (uint16_t)qv; dqw[j] = (uint16_t)dv; }
-            if ((kk % VC) == VC - 1 && active) {
+            if ((kk % VC) == VC - 1) {
                 if constexpr (N == 4) {
-                    *(uint2 *)qo = make_uint2(qw[0], qw[1]); *(uint2 *)dqo = make_uint2(dqw[0], dqw[1]);
+                    if (active) { *(uint2 *)qo = make_uint2(qw[0], qw[1]); *(uint2 *)dqo = make_uint2(dqw[0], dqw[1]); }
                 } else {
-                    ((uint4 *)qo)[kk / VC]  = make_uint4(qw[0], qw[1], qw[2], qw[3]);
-                    ((uint4 *)dqo)[kk / VC] = make_uint4(dqw[0], dqw[1], dqw[2], dqw[3]);
+                    if (active) {
+                        ((uint4 *)qo)[kk / VC]  = make_uint4(qw[0], qw[1], qw[2], qw[3]);
+                        ((uint4 *)dqo)[kk / VC] = make_uint4(dqw[0], dqw[1], dqw[2], dqw[3]);
+                    }
+                    /* RATE: the block's quantised coefficients also go to the (now dead) transpose tile, raster order, for
+                     * the scan walk below; the tile of a block is private to its N lanes, which sit in one wave */
+                    if constexpr (RATE) ((uint4 *)t)[(i * N + kk - (VC - 1)) / 8] = make_uint4(qw[0], qw[1], qw[2], qw[3]);
                 }
             }
         }
@@ -238,9 +284,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 4
         _Pragma("unroll") for (int off = 1; off < N; off <<= 1) { rdist += __shfl_xor(rdist, off); pdist += __shfl_xor(pdist, off); }
         if (active && i == 0) { dist_out[2 * blk] = rdist; dist_out[2 * blk + 1] = pdist; }
     }
-    if (!k.do_recon) return; /* uniform per block; blocks of one workgroup may differ but no barrier follows for them */
-    /* NOTE: the barrier below is reached by every lane whose block reconstructs; to keep it workgroup-uniform the
-       host launches reconstructing and non-reconstructing blocks in separate grids (see launcher). */
+    if constexpr (RATE) {
+        /* coeff_rate_estimate of the block: lane i takes the scan positions i, i + N, .. <= eob (rate_core.h) */
+        const int      rinfo = k.pad_[0], ptype = (rinfo >> 2) & 1, inter = (rinfo >> 3) & 1, ctx0 = rinfo & 3;
+        const int16_t *sc = s_scan + tx_type * SCAN_T; /* tx_type is 0 for 32x32 */
+        int bits = rate_positions<N>((const int16_t *)t, sc, sc + N * N, s_tc + (ptype * 2 + inter) * RATE_SLICE, ra.T, i, eob, N * N,
+                                     txcfg<N>::size, ctx0);
+        _Pragma("unroll") for (int off = 1; off < N; off <<= 1) bits += __shfl_xor(bits, off);
+        if (active && i == 0) ra.bits[blk] = bits;
+    }
+    if (k.do_recon) { /* uniform within a size group (launcher contract): the barriers below stay workgroup-uniform */
     /* ---- reconstruction: recon = pred + inverse transform (rows first, then columns) ---- */
     int32_t res[N];
     _Pragma("unroll") for (int r = 0; r < N; r++) res[r] = 0;
@@ -287,8 +340,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 4
         }
         row_store<N>(d, ((uintptr_t)d & (N >= 16 ? 15 : N - 1)) == 0, rw);
     }
+    } /* do_recon */
+    __syncthreads(); /* the tile is rewritten by the next group */
+  }
 }
 
+
+/* ---- coefficient rate of a 4x4 block inside the lane that owns it ----
+ * The three 4x4 scan orders of VP9 (VPX/vp9_scan.c: default_scan_4x4 for DCT_DCT and ADST_ADST, row_scan_4x4 for ADST_DCT,
+ * col_scan_4x4 for DCT_ADST) with their neighbour pairs are compile-time tables here, so that the unrolled walk over the
+ * scan positions addresses the lane's 16 token / energy registers with constant indices: no LDS staging of the coefficients,
+ * no cross-lane step.  svt_hip_rate_scan4x4_table exposes them; tests/test_rate.py checks them against the reference's tables
+ * (the scan array the caller passes must hold the same ones -- they are normative).  */
+struct scan4_tab { uint8_t scan[16], nb[32]; };
+constexpr scan4_tab SCAN4[3] = {
+    {{0, 4, 1, 5, 8, 2, 12, 9, 3, 6, 13, 10, 7, 14, 11, 15},
+     {0, 0, 0, 0, 0, 0, 1, 4, 4, 4, 1, 1, 8, 8, 5, 8, 2, 2, 2, 5, 9, 12, 6, 9, 3, 6, 10, 13, 7, 10, 11, 14}},
+    {{0, 1, 4, 2, 5, 3, 6, 8, 9, 7, 12, 10, 13, 11, 14, 15},
+     {0, 0, 0, 0, 0, 0, 1, 1, 4, 4, 2, 2, 5, 5, 4, 4, 8, 8, 6, 6, 8, 8, 9, 9, 12, 12, 10, 10, 13, 13, 14, 14}},
+    {{0, 4, 8, 1, 12, 5, 9, 2, 13, 6, 10, 3, 7, 14, 11, 15},
+     {0, 0, 0, 0, 4, 4, 0, 0, 8, 8, 1, 1, 5, 5, 1, 1, 9, 9, 2, 2, 6, 6, 2, 2, 3, 3, 10, 10, 7, 7, 11, 11}}};
+constexpr uint8_t BAND4[16] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 5};
+__host__ __device__ constexpr int scan4_kind(int tx_type) { return tx_type == SVT_ADST_DCT ? 1 : tx_type == SVT_DCT_ADST ? 2 : 0; }
+
+/* tok[r] / en[r]: token and energy class of raster coefficient r; tc: the block's cost slice in LDS.  Position c contributes
+ * tc[band][previous token == ZERO][ctx][token] while c < eob and the EOB token at c == eob (< 16); the position-independent
+ * value costs are added by the caller.  The loop is unrolled; it leaves as soon as no lane of the wave has c <= eob. */
+template <int K>
+__device__ __forceinline__ int rate_walk4(const int (&tok)[16], const int (&en)[16], const uint32_t *tc, int eob, int ctx0) {
+    int sum = (int)tc[ctx0 * 12 + (eob == 0 ? 11 : tok[0])];
+    _Pragma("unroll") for (int c = 1; c < 16; c++) {
+        if (!__any(c <= eob)) break;
+        const int  pt = (1 + en[SCAN4[K].nb[2 * c]] + en[SCAN4[K].nb[2 * c + 1]]) >> 1;
+        const bool in = c < eob;
+        const int  pz = in && tok[SCAN4[K].scan[c - 1]] == 0, tk = in ? tok[SCAN4[K].scan[c]] : 11;
+        const int  v  = (int)tc[((BAND4[c] * 2 + pz) * 6 + pt) * 12 + tk];
+        sum += c <= eob ? v : 0;
+    }
+    return sum;
+}
 
 /* 4x4 (and, unused, 8x8) blocks: one block per lane.  With N lanes per block the small transforms are a sliver of the instruction
  * stream (descriptor decode and table loads repeated in every lane, LDS transposes, shuffles for eob and distortion: ~125
@@ -298,17 +388,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 4
  * 8x8: they differ in the cast inside tx_fdct8 (vp9_dct.c:67-68), selected by the block's transform type.  The inverse
  * always runs all rows (the reference's reduced variants are shortcuts with identical results).  Memory instructions per
  * block are unchanged (a lane issues the N row loads its N lanes issued). */
-template <int N>
+template <int N, bool RATE>
 __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ pred,
                                                           uint8_t *__restrict__ recon, const svt_tq_block *__restrict__ blocks,
                                                           int n_blocks, const svt_quant_tables *__restrict__ qtabs,
                                                           const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,
                                                           int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out,
-                                                          uint64_t *__restrict__ dist_out) {
+                                                          uint64_t *__restrict__ dist_out, tq_rate_args ra) {
     static_assert(N == 4 || N == 8, "block-per-lane form: 4x4 and 8x8 only");
+    static_assert(!RATE || N == 4, "in-lane rate: 4x4 only");
     constexpr int ND = N / 4; /* dwords per row of samples */
-    const int blk = blockIdx.x * 256 + threadIdx.x;
-    if (blk >= n_blocks) return;
+    /* RATE: the four 4x4 token-cost slices [plane_type][is_inter] and the value-cost table, copied once per workgroup */
+    __shared__ uint32_t s_tc[RATE ? 4 * RATE_SLICE : 1];
+    __shared__ int32_t  s_vc[RATE ? 136 : 1];
+    if constexpr (RATE) {
+        const uint32_t *g = &ra.T->token_costs[0][0][0][0][0][0][0];
+        for (int j = threadIdx.x; j < 4 * RATE_SLICE; j += 256) s_tc[j] = g[j];
+        if (threadIdx.x < 133) s_vc[threadIdx.x] = ra.T->value_cost[threadIdx.x];
+        __syncthreads();
+    }
+    const tq_walk wk = tq_walk_of((n_blocks + 255) / 256);
+  for (int gj = wk.first; gj < wk.per_xcd; gj += wk.step) {
+    const int blk = (wk.base + gj) * 256 + (int)threadIdx.x;
+    if (blk >= n_blocks) continue; /* no barrier inside the loop */
     const svt_tq_block k = blocks[blk];
     const bool col_adst = k.tx_type == SVT_ADST_DCT || k.tx_type == SVT_ADST_ADST;
     const bool row_adst = k.tx_type == SVT_DCT_ADST || k.tx_type == SVT_ADST_ADST;
@@ -354,6 +456,7 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
     int32_t  dq[N][N];
     uint32_t rdist = 0, pdist = 0;
     int      eob = 0;
+    int      tok[RATE ? 16 : 1], en[RATE ? 16 : 1], vsum = 0, nnz = 0; /* RATE: per raster coefficient */
     const uint32_t *ip = (const uint32_t *)(iscan_all + k.iscan_off);
     _Pragma("unroll") for (int i = 0; i < N; i++) {
         int32_t  o[N];
@@ -386,6 +489,23 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
             if (kk & 1) { qw[kk >> 1] |= (uint32_t)(uint16_t)qv << 16; dqw[kk >> 1] |= (uint32_t)(uint16_t)dv << 16; }
             else { qw[kk >> 1] = (uint16_t)qv; dqw[kk >> 1] = (uint16_t)dv; }
             if (level) { const int pos = (int)((isw[kk >> 1] >> (16 * (kk & 1))) & 0xffff) + 1; eob = pos > eob ? pos : eob; }
+            if constexpr (RATE) {
+                /* token, energy class and value cost of this coefficient; skipped when it is zero in every lane of the wave */
+                tok[i * N + kk] = 0; en[i * N + kk] = 0;
+                if (__any(level != 0)) {
+                    const int al = qv < 0 ? -qv : qv; /* |level| as the reference sees it (the int16 qcoeff) */
+                    tok[i * N + kk] = token_of(qv);
+                    en[i * N + kk]  = energy_of_value(qv);
+                    nnz += qv != 0;
+                    int vc = s_vc[66 + (al < 67 ? qv : 0)];
+                    if (__any(al >= 67)) { /* CAT6: vp9_get_token_cost, VPX/vp9_tokenize.h:118-127 */
+                        const int extra = al >= 67 ? al - 67 : 0;
+                        const int c6 = ra.T->cat6_low_cost[extra & 0xff] + ra.T->cat6_high_cost[extra >> 8];
+                        vc = al >= 67 ? c6 : vc;
+                    }
+                    vsum += qv != 0 ? vc : 0;
+                }
+            }
         }
         int16_t *qo = qcoeff + k.coeff_off + i * N, *dqo = dqcoeff + k.coeff_off + i * N;
         if constexpr (N == 4) { *(uint2 *)qo = make_uint2(qw[0], qw[1]); *(uint2 *)dqo = make_uint2(dqw[0], dqw[1]); }
@@ -393,7 +513,18 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
     }
     eob_out[blk] = (uint16_t)eob;
     if (dist_out) { dist_out[2 * blk] = rdist; dist_out[2 * blk + 1] = pdist; }
-    if (!k.do_recon) return;
+    if constexpr (RATE) {
+        const int       rinfo = k.pad_[0], ptype = (rinfo >> 2) & 1, inter = (rinfo >> 3) & 1, ctx0 = rinfo & 3;
+        const uint32_t *tc = s_tc + (ptype * 2 + inter) * RATE_SLICE;
+        const int       kind = scan4_kind(k.tx_type);
+        int             bits = 0;
+        if (kind == 0) bits = rate_walk4<0>(tok, en, tc, eob, ctx0);
+        if (kind == 1) bits = rate_walk4<1>(tok, en, tc, eob, ctx0);
+        if (kind == 2) bits = rate_walk4<2>(tok, en, tc, eob, ctx0);
+        /* value costs: every position before eob pays the cost of its value; the zeros among them pay value_cost[0 + 66] */
+        ra.bits[blk] = bits + vsum + (eob - nnz) * s_vc[66];
+    }
+    if (!k.do_recon) continue;
     /* ---- reconstruction: rows first, then columns (vp9_idct.c:111-189, inv_txfm.c); a column's eight results go straight
      * into the packed output rows ---- */
     constexpr int SH = txcfg<N>::shift;
@@ -435,23 +566,56 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
         if constexpr (N == 4) *(uint32_t *)d = rw[r][0];
         else row_store<N>(d, ((uintptr_t)d & 7) == 0, rw[r]);
     }
+  }
 }
 
-template <int N>
+/* persistent grid: a multiple of 8 workgroups (one walk per XCD, tq_walk_of), at most `per_cu` per compute unit */
+int tq_grid(svt_hip_ctx *ctx, int ngroups, int per_cu) {
+    hipDeviceProp_t pr;
+    const int cus = (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    const int per_xcd = (ngroups + 7) / 8, cap = (cus * per_cu + 7) / 8;
+    return 8 * (per_xcd < cap ? per_xcd : cap);
+}
+
+template <int N, bool RATE>
 hipError_t launch_tq(svt_hip_ctx *ctx, const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks, int n,
-              const svt_quant_tables *q, const int16_t *iscan, int16_t *qc, int16_t *dqc, uint16_t *eob, uint64_t *dist) {
+                     const svt_quant_tables *q, const int16_t *iscan, int16_t *qc, int16_t *dqc, uint16_t *eob, uint64_t *dist, tq_rate_args ra) {
     if (n <= 0) return hipSuccess;
     /* block per lane for 4x4 only: the 8x8 instance is bit-exact too but needs 201 VGPRs (64 samples + the transposed
      * intermediate live in one lane; 87 spills when held to 128) -- two waves per SIMD, and each displaces two ME waves:
      * the overlapped step went from 3.27 to 3.77 ms with it, so 8x8 stays on the N-lanes-per-block kernel */
     if constexpr (N == 4) {
-        hipLaunchKernelGGL(svt_tq_lane_kernel<N>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, src, pred, recon, blocks, n, q, iscan, qc, dqc, eob, dist);
+        hipLaunchKernelGGL((svt_tq_lane_kernel<N, RATE>), dim3(tq_grid(ctx, (n + 255) / 256, 8)), dim3(256), 0, ctx->stream, src, pred, recon, blocks, n, q,
+                           iscan, qc, dqc, eob, dist, ra);
+        return hipGetLastError();
+    } else {
+        constexpr int NT = N == 32 ? 128 : 256, BPW = NT / N;
+        hipLaunchKernelGGL((svt_tq_kernel<N, RATE>), dim3(tq_grid(ctx, (n + BPW - 1) / BPW, 8)), dim3(NT), 0, ctx->stream, src, pred, recon, blocks, n, q,
+                           iscan, qc, dqc, eob, dist, ra);
         return hipGetLastError();
     }
-    constexpr int NT = N == 32 ? 128 : 256, BPW = NT / N;
-    hipLaunchKernelGGL(svt_tq_kernel<N>, dim3((n + BPW - 1) / BPW), dim3(NT), 0, ctx->stream, src, pred, recon, blocks, n, q, iscan,
-                       qc, dqc, eob, dist);
-    return hipGetLastError();
+}
+
+template <bool RATE>
+int32_t tq_launch_all(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *d_recon, const svt_tq_block *d_blocks,
+                      const int32_t size_count[4], const svt_quant_tables *d_qtabs, const int16_t *d_iscan, int16_t *d_qcoeff,
+                      int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist, tq_rate_args ra) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    int        off = 0;
+    hipError_t rc = hipSuccess;
+    auto at = [&](int o) { tq_rate_args r = ra; if (r.bits) r.bits += o; return r; };
+    rc = launch_tq<4, RATE>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[0], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off));
+    off += size_count[0];
+    if (rc == hipSuccess) rc = launch_tq<8, RATE>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[1], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off));
+    off += size_count[1];
+    if (rc == hipSuccess) rc = launch_tq<16, RATE>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[2], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off));
+    off += size_count[2];
+    if (rc == hipSuccess) rc = launch_tq<32, RATE>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[3], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off));
+    (void)hipEventRecord(ctx->ev_stop, ctx->stream); /* also on a failed launch: ev_start is already in the stream */
+    if (rc != hipSuccess) return svt_set_hip_error(rc, __FILE__, __LINE__);
+    ctx->timed = 1;
+    return SVT_HIP_OK;
 }
 } // namespace
 
@@ -475,20 +639,32 @@ extern "C" int32_t svt_hip_tq_batch_dist_device(svt_hip_ctx *ctx, const uint8_t 
     if (!ctx || !d_src || !d_pred || !d_blocks || !size_count || !d_qtabs || !d_iscan || !d_qcoeff || !d_dqcoeff || !d_eob)
         return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq: null argument");
     if (((uintptr_t)d_qcoeff | (uintptr_t)d_dqcoeff) & 15) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq: coefficient arrays must be 16-byte aligned");
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
-    int        off = 0;
-    hipError_t rc;
-    rc = launch_tq<4>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[0], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr);
-    off += size_count[0];
-    if (rc == hipSuccess) rc = launch_tq<8>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[1], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr);
-    off += size_count[1];
-    if (rc == hipSuccess) rc = launch_tq<16>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[2], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr);
-    off += size_count[2];
-    if (rc == hipSuccess) rc = launch_tq<32>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[3], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr);
-    (void)hipEventRecord(ctx->ev_stop, ctx->stream); /* also on a failed launch: ev_start is already in the stream */
-    if (rc != hipSuccess) return svt_set_hip_error(rc, __FILE__, __LINE__);
-    ctx->timed = 1;
+    tq_rate_args none = {nullptr, nullptr, nullptr};
+    return tq_launch_all<false>(ctx, d_src, d_pred, d_recon, d_blocks, size_count, d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob, d_dist, none);
+}
+
+/* as svt_hip_tq_batch_dist_device, plus d_bits[b] = coeff_rate_estimate of block b computed behind the quantiser (no second
+ * pass over the coefficients): the rate inputs of a block travel in svt_tq_block.pad_[0] (SVT_TQ_RATE_INFO) */
+extern "C" int32_t svt_hip_tq_rd_batch_device(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *d_recon,
+                                              const svt_tq_block *d_blocks, const int32_t size_count[4],
+                                              const svt_quant_tables *d_qtabs, const int16_t *d_iscan, int16_t *d_qcoeff,
+                                              int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist,
+                                              const svt_rate_tables *d_tables, const int16_t *d_scan, int32_t *d_bits) {
+    if (!ctx || !d_src || !d_pred || !d_blocks || !size_count || !d_qtabs || !d_iscan || !d_qcoeff || !d_dqcoeff || !d_eob || !d_tables ||
+        !d_scan || !d_bits)
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq_rd: null argument");
+    if (((uintptr_t)d_qcoeff | (uintptr_t)d_dqcoeff) & 15) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq_rd: coefficient arrays must be 16-byte aligned");
+    if ((uintptr_t)d_scan & 3) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq_rd: scan array must be 4-byte aligned");
+    tq_rate_args ra = {d_tables, d_scan, d_bits};
+    return tq_launch_all<true>(ctx, d_src, d_pred, d_recon, d_blocks, size_count, d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob, d_dist, ra);
+}
+
+/* the compiled-in 4x4 scan orders of the in-lane rate pass: out[0..15] = scan, out[16..47] = the neighbour pairs of positions 0..15 */
+extern "C" int32_t svt_hip_rate_scan4x4_table(int32_t tx_type, int16_t out[48]) {
+    if (tx_type < 0 || tx_type > 3 || !out) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "scan4x4: bad argument");
+    const scan4_tab &t = SCAN4[scan4_kind(tx_type)];
+    for (int i = 0; i < 16; i++) out[i] = t.scan[i];
+    for (int i = 0; i < 32; i++) out[16 + i] = t.nb[i];
     return SVT_HIP_OK;
 }
 

@@ -887,6 +887,52 @@ def hip_tq_batch_dist_device(ctx, case):
             dist.cpu().numpy().view(np.uint64).reshape(-1, 2))
 
 
+def add_rate_info(case, seed, inter_share=0.5):
+    """rate inputs for the fused distortion + rate entry: plane type, inter flag and entropy context per block in pad[0]
+    (SVT_TQ_RATE_INFO).  Returns the equivalent svt_rate_block records (eob left 0: it is the transform stage's output)."""
+    rng = np.random.default_rng(seed)
+    nb = len(case["blocks"])
+    pt, inter, ctx = rng.integers(0, 2, nb), (rng.random(nb) < inter_share).astype(np.int64), rng.integers(0, 3, nb)
+    case["blocks"]["pad"][:, 0] = (ctx | (pt << 2) | (inter << 3)).astype(np.uint8)
+    offs, _ = rate_scan_offsets()
+    rb = np.zeros(nb, dtype=B.RATE_BLOCK_DTYPE)
+    rb["coeff_off"], rb["tx_size"], rb["plane_type"], rb["is_inter"], rb["ctx"] = case["blocks"]["coeff_off"], case["blocks"]["tx_size"], pt, inter, ctx
+    rb["scan_off"] = [offs[(int(b["tx_size"]), int(b["tx_type"]) if b["tx_size"] < 3 else 0)] for b in case["blocks"]]
+    return rb
+
+
+def oracle_tq_rd_batch(case, rb):
+    """the oracle's two stages chained: transform / quantisation (+ distortion), then coeff_rate_estimate on its output"""
+    recon, q, dq, eob, dist = oracle_tq_batch_dist(case)
+    rb = rb.copy()
+    rb["eob"] = eob
+    return recon, q, dq, eob, dist, oracle_rate_batch(dict(qcoeff=q, blocks=rb))
+
+
+def hip_tq_rd_batch_device(ctx, case):
+    """svt_hip_tq_rd_batch_device on device buffers allocated with torch (GPU tests only)."""
+    import torch
+    lib = B.load()
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
+    src, pred, blocks, qt, isc = up(case["src"]), up(case["pred"]), up(case["blocks"]), up(case["qtabs"]), up(case["iscan"])
+    rtab, rscan = rate_tables()
+    tab, scan = up(np.ascontiguousarray(rtab).reshape(1)), up(rscan)
+    recon = torch.zeros(case["src"].size, dtype=torch.uint8, device=dev)
+    q = torch.zeros(case["n_coeff"], dtype=torch.int16, device=dev)
+    dq = torch.zeros(case["n_coeff"], dtype=torch.int16, device=dev)
+    eob = torch.zeros(len(case["blocks"]), dtype=torch.int16, device=dev)
+    dist = torch.zeros(2 * len(case["blocks"]), dtype=torch.int64, device=dev)
+    bits = torch.zeros(len(case["blocks"]), dtype=torch.int32, device=dev)
+    cnt = (C.c_int32 * 4)(*[int(v) for v in case["counts"]])
+    p = lambda t: C.c_void_p(t.data_ptr())
+    B.check(lib.svt_hip_tq_rd_batch_device(ctx, p(src), p(pred), p(recon), p(blocks), cnt, p(qt), p(isc), p(q), p(dq), p(eob), p(dist),
+                                           p(tab), p(scan), p(bits)))
+    B.check(lib.svt_hip_ctx_synchronize(ctx))
+    return (recon.cpu().numpy().reshape(case["src"].shape), q.cpu().numpy(), dq.cpu().numpy(), eob.cpu().numpy().view(np.uint16),
+            dist.cpu().numpy().view(np.uint64).reshape(-1, 2), bits.cpu().numpy())
+
+
 # ---------------------------------------------------------------------------------------------------
 # M12 side outputs
 # ---------------------------------------------------------------------------------------------------

@@ -69,3 +69,34 @@ def test_tq_distortion_pairs_vs_oracle(ctx, seed, extreme):
     for n, a, b in zip(("recon", "qcoeff", "dqcoeff", "eob", "dist"), o, g):
         assert np.array_equal(a, b), (n, int(np.sum(a != b)))
     assert (o[4][:, 0] != o[4][:, 1]).any() and o[4].max() > 0
+
+
+@pytest.mark.parametrize("seed,extreme,inter_share", [(1, False, 0.5), (2, False, 1.0), (4, False, 0.0), (11, True, 0.5), (12, True, 0.3)])
+def test_tq_rd_fused_rate_vs_oracle(ctx, seed, extreme, inter_share):
+    """svt_hip_tq_rd_batch_device: distortion + coefficient rate computed behind the quantiser (4x4 blocks walked inside their
+    lane with the compiled-in scan orders, bigger blocks from the LDS copy of their coefficients) == the oracle's transform
+    stage followed by its coeff_rate_estimate; all four sizes, all transform types (intra blocks keep ADST mixes: row / column
+    scans), empty blocks (eob 0), full blocks, CAT6 levels (extreme residuals at tiny steps)."""
+    case = T.make_tq_case(seed, extreme=extreme, qsteps=((4, 4), (1336, 1828), (40, 48)) if extreme else ((40, 48), (8, 9), (200, 260)))
+    rb = T.add_rate_info(case, seed + 100, inter_share)
+    o = T.oracle_tq_rd_batch(case, rb)
+    g = T.hip_tq_rd_batch_device(ctx, case)
+    for n, a, b in zip(("recon", "qcoeff", "dqcoeff", "eob", "dist", "bits"), o, g):
+        assert np.array_equal(a, b), (n, int(np.sum(a != b)), np.argwhere(a != b)[:6].ravel().tolist())
+    eob = o[3]
+    n2 = 16 << (2 * case["blocks"]["tx_size"].astype(np.int64))
+    assert len(set(o[5].tolist())) > 32
+    if not extreme:
+        assert (eob == 0).any()
+    else:
+        assert (eob == n2).any() and np.abs(o[1]).max() >= 67     # full blocks and CAT6 tokens occur
+
+
+def test_tq_rd_many_blocks_persistent_grid(ctx):
+    """more groups of blocks than resident workgroups: the persistent, XCD-striped walk covers every block exactly once"""
+    case = T.make_tq_case(21, width=1024, height=512)
+    rb = T.add_rate_info(case, 5)
+    o = T.oracle_tq_rd_batch(case, rb)
+    g = T.hip_tq_rd_batch_device(ctx, case)
+    for n, a, b in zip(("recon", "qcoeff", "dqcoeff", "eob", "dist", "bits"), o, g):
+        assert np.array_equal(a, b), (n, int(np.sum(a != b)))

@@ -49,3 +49,17 @@ def test_full_block_has_no_eob_token_and_empty_block_is_one_token():
     bits = T.oracle_rate_batch(dict(qcoeff=q, blocks=blocks))
     assert bits[2] == tab["token_costs"][0, 0, 0, 0, 0, 2, 11] and bits[5] == tab["token_costs"][1, 1, 1, 0, 0, 2, 11]
     assert bits[0] != bits[1] and bits[3] != bits[4]
+
+
+def test_compiled_in_4x4_scan_orders_are_the_reference_tables():
+    """the fused distortion + rate entry walks 4x4 blocks with scan orders compiled into the kernel: they must be the
+    reference's eb_vp9_scan_orders[TX_4X4][tx_type] (scan + neighbours), as the committed fixture has them"""
+    import ctypes as C
+    _, scan = T.rate_tables()
+    offs, _ = T.rate_scan_offsets()
+    for tt in range(4):
+        out = np.zeros(48, np.int16)
+        assert T.B.load().svt_hip_rate_scan4x4_table(tt, out.ctypes.data_as(C.c_void_p)) == 0
+        o = offs[(0, tt)]
+        assert np.array_equal(out[:16], scan[o:o + 16]) and np.array_equal(out[16:], scan[o + 16:o + 48]), tt
+    assert T.B.load().svt_hip_rate_scan4x4_table(4, None) != 0
