@@ -68,11 +68,29 @@ extern "C" void svt_hip_ctx_destroy(svt_hip_ctx *c) {
         if (c->ring_host[i]) (void)hipHostFree(c->ring_host[i]);
         if (c->ring_ev[i]) (void)hipEventDestroy(c->ring_ev[i]);
     }
+    if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
+    for (int i = 0; i < 3; i++) {
+        if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
+        if (c->aux_join[i]) (void)hipEventDestroy(c->aux_join[i]);
+    }
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     free(c);
 }
+int svt_ctx_aux_init(svt_hip_ctx *c) {
+    if (c->aux_ready) return 0;
+    int prio = 0;
+    (void)hipStreamGetPriority(c->stream, &prio);
+    if (hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming) != hipSuccess) return -1;
+    for (int i = 0; i < 3; i++) {
+        if (hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, prio) != hipSuccess) return -1;
+        if (hipEventCreateWithFlags(&c->aux_join[i], hipEventDisableTiming) != hipSuccess) return -1;
+    }
+    c->aux_ready = 1;
+    return 0;
+}
+
 extern "C" int32_t svt_hip_ctx_synchronize(svt_hip_ctx *c) {
     if (!c) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "ctx: null");
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -23,6 +23,11 @@ struct svt_hip_ctx {
     hipEvent_t  ring_ev[SVT_CTX_RING];
     int         ring_used[SVT_CTX_RING];
     int         ring_pos;
+    /* helper streams for entry points whose kernels are independent of each other (the four transform sizes of a TQ batch):
+       forked from / joined into `stream` with events, so the call still behaves as one operation on the context's stream */
+    hipStream_t aux[3];
+    hipEvent_t  aux_fork, aux_join[3];
+    int         aux_ready;
     void       *slot[SVT_CTX_SLOTS]; /* grow-only device buffers of the host-pointer convenience entry points */
     size_t      slot_bytes[SVT_CTX_SLOTS];
 };
@@ -34,6 +39,8 @@ int     svt_ctx_stage(svt_hip_ctx *ctx, size_t bytes, void **host, void **dev);
 /* call after the last operation that reads the slot has been enqueued on ctx->stream */
 void    svt_ctx_stage_commit(svt_hip_ctx *ctx);
 void   *svt_ctx_slot(svt_hip_ctx *ctx, int slot, size_t bytes);
+/* creates the helper streams on first use (same priority as the context's stream); returns 0 on success */
+int     svt_ctx_aux_init(svt_hip_ctx *ctx);
 
 #define HIP_TRY(expr)                                                        \
     do {                                                                     \

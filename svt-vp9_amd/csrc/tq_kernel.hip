@@ -20,6 +20,7 @@
 #include "svt_ctx.h"
 #include "txfm1d.h"
 #include "rate_core.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -44,6 +45,11 @@ __device__ __forceinline__ tq_walk tq_walk_of(int ngroups) {
     w.step    = (int)(gridDim.x >> 3);
     return w;
 }
+
+/* threads per workgroup.  The fused-rate instances keep their LDS (transpose tiles + cost slices + scan tables) under
+ * 32 000 bytes = the LDS one motion-estimation workgroup releases when it retires (25 granules of 1280 bytes): on a CU that
+ * the ME kernel has filled, a transform workgroup can then move into the first hole instead of waiting for two. */
+template <int N, bool RATE> constexpr int tq_threads() { return N == 32 ? (RATE ? 64 : 128) : N == 16 ? (RATE ? 128 : 256) : 256; }
 
 template <int N> struct txcfg;
 template <> struct txcfg<4> { static constexpr int size = SVT_TX_4X4, shift = 4; };
@@ -119,9 +125,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 4
                                                      const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,
                                                      int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out,
                                                      uint64_t *__restrict__ dist_out, tq_rate_args ra) {
-    constexpr int BPW = (N == 32 ? 128 : 256) / N; /* blocks per workgroup (32x32: 4 blocks = 17 KB of LDS, small enough to
-                                                      share a CU with four ME workgroups) */
-    constexpr int NT  = N == 32 ? 128 : 256;
+    constexpr int NT  = tq_threads<N, RATE>();
+    constexpr int BPW = NT / N;           /* blocks per workgroup */
     constexpr int LS  = N + 1;            /* padded LDS row stride in dwords */
     __shared__ int32_t tile[BPW][N * LS];
     /* RATE: the four token-cost slices [plane_type][is_inter] of this transform size, copied once per (persistent) workgroup */
@@ -578,19 +583,19 @@ int tq_grid(svt_hip_ctx *ctx, int ngroups, int per_cu) {
 }
 
 template <int N, bool RATE>
-hipError_t launch_tq(svt_hip_ctx *ctx, const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks, int n,
+hipError_t launch_tq(svt_hip_ctx *ctx, hipStream_t st, const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks, int n,
                      const svt_quant_tables *q, const int16_t *iscan, int16_t *qc, int16_t *dqc, uint16_t *eob, uint64_t *dist, tq_rate_args ra) {
     if (n <= 0) return hipSuccess;
     /* block per lane for 4x4 only: the 8x8 instance is bit-exact too but needs 201 VGPRs (64 samples + the transposed
      * intermediate live in one lane; 87 spills when held to 128) -- two waves per SIMD, and each displaces two ME waves:
      * the overlapped step went from 3.27 to 3.77 ms with it, so 8x8 stays on the N-lanes-per-block kernel */
     if constexpr (N == 4) {
-        hipLaunchKernelGGL((svt_tq_lane_kernel<N, RATE>), dim3(tq_grid(ctx, (n + 255) / 256, 8)), dim3(256), 0, ctx->stream, src, pred, recon, blocks, n, q,
+        hipLaunchKernelGGL((svt_tq_lane_kernel<N, RATE>), dim3(tq_grid(ctx, (n + 255) / 256, 8)), dim3(256), 0, st, src, pred, recon, blocks, n, q,
                            iscan, qc, dqc, eob, dist, ra);
         return hipGetLastError();
     } else {
-        constexpr int NT = N == 32 ? 128 : 256, BPW = NT / N;
-        hipLaunchKernelGGL((svt_tq_kernel<N, RATE>), dim3(tq_grid(ctx, (n + BPW - 1) / BPW, 8)), dim3(NT), 0, ctx->stream, src, pred, recon, blocks, n, q,
+        constexpr int NT = tq_threads<N, RATE>(), BPW = NT / N;
+        hipLaunchKernelGGL((svt_tq_kernel<N, RATE>), dim3(tq_grid(ctx, (n + BPW - 1) / BPW, 8)), dim3(NT), 0, st, src, pred, recon, blocks, n, q,
                            iscan, qc, dqc, eob, dist, ra);
         return hipGetLastError();
     }
@@ -602,16 +607,32 @@ int32_t tq_launch_all(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_p
                       int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist, tq_rate_args ra) {
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    /* The four size groups are independent of each other; SVT_HIP_TQ_FORK=1 launches each on a stream of its own (forked from
+     * and joined into the context's stream).  Measured: slower -- 1.59 instead of 1.39 ms per mini-GOP for the four launches
+     * alone, no change inside the pipeline: kernels that share compute units take longer in sum than one after the other (every
+     * pairing of the stages shows it), so the default keeps them in sequence. */
+    static const bool want_fork = getenv("SVT_HIP_TQ_FORK") != nullptr;
+    const bool        fork = want_fork && svt_ctx_aux_init(ctx) == 0;
+    if (fork) {
+        HIP_TRY(hipEventRecord(ctx->aux_fork, ctx->stream));
+        for (int i = 0; i < 3; i++) HIP_TRY(hipStreamWaitEvent(ctx->aux[i], ctx->aux_fork, 0));
+    }
     int        off = 0;
     hipError_t rc = hipSuccess;
     auto at = [&](int o) { tq_rate_args r = ra; if (r.bits) r.bits += o; return r; };
-    rc = launch_tq<4, RATE>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[0], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off));
+    auto on = [&](int i) { return fork && i > 0 ? ctx->aux[i - 1] : ctx->stream; };
+    rc = launch_tq<4, RATE>(ctx, on(0), d_src, d_pred, d_recon, d_blocks + off, size_count[0], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off));
     off += size_count[0];
-    if (rc == hipSuccess) rc = launch_tq<8, RATE>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[1], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off));
+    if (rc == hipSuccess) rc = launch_tq<8, RATE>(ctx, on(1), d_src, d_pred, d_recon, d_blocks + off, size_count[1], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off));
     off += size_count[1];
-    if (rc == hipSuccess) rc = launch_tq<16, RATE>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[2], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off));
+    if (rc == hipSuccess) rc = launch_tq<16, RATE>(ctx, on(2), d_src, d_pred, d_recon, d_blocks + off, size_count[2], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off));
     off += size_count[2];
-    if (rc == hipSuccess) rc = launch_tq<32, RATE>(ctx, d_src, d_pred, d_recon, d_blocks + off, size_count[3], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off));
+    if (rc == hipSuccess) rc = launch_tq<32, RATE>(ctx, on(3), d_src, d_pred, d_recon, d_blocks + off, size_count[3], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off));
+    if (fork)
+        for (int i = 0; i < 3; i++) {
+            (void)hipEventRecord(ctx->aux_join[i], ctx->aux[i]);
+            (void)hipStreamWaitEvent(ctx->stream, ctx->aux_join[i], 0);
+        }
     (void)hipEventRecord(ctx->ev_stop, ctx->stream); /* also on a failed launch: ev_start is already in the stream */
     if (rc != hipSuccess) return svt_set_hip_error(rc, __FILE__, __LINE__);
     ctx->timed = 1;
