@@ -245,6 +245,39 @@ void svt_hip_me_similar_collocated(const uint8_t *cur_mean, const uint16_t *cur_
                                    const uint16_t *ref_var, int32_t n_sb, int32_t is_i_slice,
                                    int32_t is_used_as_reference, uint8_t *similar, uint8_t *similar_all_layers);
 
+/* The rest of the ME kernel process's per-SB bookkeeping (scope row M12), on the device so that neither the 6.9 MB result
+ * array nor the picture-analysis statistics have to come back to the host for it:
+ *   stationary_edge_over_update_over_time_sb_part1 / _part2 (Codec/EbMotionEstimationProcess.c:785-869): the logo /
+ *       stationary-edge flags of every SB from the 64x64 list-0 MV and distortion of its best ME candidate (d_results[sb][0])
+ *       and the variance of its four 32x32 blocks (d_var[sb * 85 + 1..4], svt_hip_pa_mean_variance_device's layout);
+ *       which SBs can hold a logo is eb_vp9_sb_params_init's potential_logo_sb rule (Codec/EbSequenceControlSet.c:332-413);
+ *   the rate-control SAD-interval indices and histograms (:1103-1237): inter index from rcme_distortion[sb] (the ME entry
+ *       points' d_rcme_distortion), intra index from the 64x64 variance, one count per complete SB in each histogram.
+ * part2 only runs when run_part2 != 0 (= !end_of_sequence_flag && look_ahead_distance != 0); without it check2 /
+ * low_dist_logo are written as 0.  The histograms and the full-SB count are ADDED to (the reference zeroes them per picture). */
+typedef struct svt_me_sb_stats_params {
+    int32_t pic_width, pic_height;
+    int32_t input_resolution;      /* svt_hip_input_resolution() */
+    int32_t temporal_layer_index;
+    int32_t slice_type;            /* 0 B_SLICE, 1 P_SLICE, 2 I_SLICE (Codec/EbDefinitions.h EB_SLICE) */
+    int32_t run_part2;
+    int32_t rate_control_mode;     /* 0: no indices / histograms (static_config.rate_control_mode) */
+} svt_me_sb_stats_params;
+typedef struct svt_me_sb_stats {
+    uint8_t  check1_for_logo_stationary_edge_over_time_flag;
+    uint8_t  pm_check1_for_logo_stationary_edge_over_time_flag;
+    uint8_t  check2_for_logo_stationary_edge_over_time_flag;
+    uint8_t  low_dist_logo;
+    uint16_t inter_sad_interval_index;
+    uint16_t intra_sad_interval_index;
+} svt_me_sb_stats;                 /* 8 bytes */
+#define SVT_SAD_INTERVALS 128      /* NUMBER_OF_SAD_INTERVALS, Codec/EbRateControlTables.h:19 */
+/* d_results may be NULL for an I picture, d_rcme_distortion when rate_control_mode == 0 or for an I picture.
+ * d_hist: [0..127] me_distortion_histogram, [128..255] ois_distortion_histogram; d_full_sb_count: one uint32. */
+int32_t svt_hip_me_sb_stats_device(svt_hip_ctx *ctx, const svt_me_sb_stats_params *params, const svt_me_pu_result *d_results,
+                                   const uint16_t *d_var, const uint32_t *d_rcme_distortion, svt_me_sb_stats *d_stats,
+                                   uint32_t *d_hist, uint32_t *d_full_sb_count);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* Picture-analysis pre-ME stage ("next" row f-1 of the scope table)                                  */
 /* ------------------------------------------------------------------------------------------------ */

@@ -41,6 +41,8 @@ int32_t svt_oracle_tq_batch_dist(const uint8_t *src, const uint8_t *pred, uint8_
 int32_t svt_oracle_me_zz_sad(const svt_plane *cur16, const svt_plane *prev, int32_t input_resolution, uint32_t *zz, uint8_t *nmi);
 void    svt_oracle_me_similar_collocated(const uint8_t *cur_mean, const uint16_t *cur_var, const uint8_t *ref_mean, const uint16_t *ref_var,
                                          int32_t n_sb, int32_t is_i_slice, int32_t is_used_as_reference, uint8_t *similar, uint8_t *similar_all);
+int32_t svt_oracle_me_sb_stats(const svt_me_sb_stats_params *p, const svt_me_pu_result *results, const uint16_t *var,
+                               const uint32_t *rcme, svt_me_sb_stats *out, uint32_t *hist, uint32_t *full_sb_count);
 /* picture-analysis pre-ME stage: decimate_input_picture + padding (Codec/EbPictureAnalysisProcess.c:5010-5088) */
 int32_t svt_oracle_pa_prepare(const uint8_t *luma, int32_t luma_stride, const svt_pa_picture *out, int32_t make_quarter);
 /* compute_block_mean_compute_variance (Codec/EbPictureAnalysisProcess.c:2115-3356) */

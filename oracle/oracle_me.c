@@ -956,3 +956,71 @@ void svt_oracle_me_similar_collocated(const uint8_t *cur_mean, const uint16_t *c
         }
     }
 }
+
+
+/* M12, rest: stationary_edge_over_update_over_time_sb_part1 / _part2 (Codec/EbMotionEstimationProcess.c:785-869) with
+ * eb_vp9_sb_params_init's potential_logo_sb / is_complete_sb (Codec/EbSequenceControlSet.c:281-413), and the rate-control
+ * SAD-interval indices / histograms of eb_vp9_motion_estimation_kernel (:1103-1237; VP9_RC branch: the intra index comes
+ * from the 64x64 variance).  part1 / part2 are pinned against the reference built from source (oracle/_ref/ref_me_side);
+ * the histogram code is inline in the reference's thread function and cannot be called in isolation: restated by reading. */
+static int potential_logo_sb(int ox, int oy, int W, int H, int input_resolution) {
+    const int k = input_resolution <= 0 ? 1 : input_resolution < 3 ? 2 : 4; /* 480p: 3 x 2 SBs, 720p/1080p: 7 x 4, 4K: 14 x 8 */
+    const int wx = (k == 1 ? 3 : 7 * (k >> 1)) * 64, wy = 2 * k * 64;
+    int p = 0;
+    if (ox >= W - wx && oy < wy) p = 1;
+    if (ox < wx && oy < wy) p = 1;
+    if (oy >= H - wy) p = 1;
+    return p;
+}
+static uint16_t sad_interval(uint32_t v) { /* :1126-1137 / :1168-1178: v already >> (12 - SAD_PRECISION_INTERVAL) or variance >> 4 */
+    uint32_t i = (uint16_t)((uint16_t)v >> 2);
+    if (i > 63) i = 63 + ((i - 63) >> 3);
+    if (i >= 127) i = 127;
+    return (uint16_t)i;
+}
+int32_t svt_oracle_me_sb_stats(const svt_me_sb_stats_params *p, const svt_me_pu_result *results, const uint16_t *var,
+                               const uint32_t *rcme, svt_me_sb_stats *out, uint32_t *hist, uint32_t *full_sb_count) {
+    const int W = p->pic_width, H = p->pic_height, nx = (W + 63) / 64, ny = (H + 63) / 64;
+    for (int sb = 0; sb < nx * ny; sb++) {
+        const int ox = (sb % nx) * 64, oy = (sb / nx) * 64;
+        const int complete = ox + 64 <= W && oy + 64 <= H;
+        const int logo = potential_logo_sb(ox, oy, W, H, p->input_resolution) && complete;
+        svt_me_sb_stats *o = &out[sb];
+        o->check1_for_logo_stationary_edge_over_time_flag = 0; o->pm_check1_for_logo_stationary_edge_over_time_flag = 0;
+        o->check2_for_logo_stationary_edge_over_time_flag = 0; o->low_dist_logo = 0;
+        o->inter_sad_interval_index = 0; o->intra_sad_interval_index = 0;
+        if (logo) { /* part 1 */
+            int32_t mvx = 0, mvy = 0;
+            if (p->temporal_layer_index > 0 && results) { mvx = results[sb * 85].x_mv_l0; mvy = results[sb * 85].y_mv_l0; }
+            const int low_motion = p->temporal_layer_index == 0 ? 1 : (abs(mvx) < 16 && abs(mvy) < 16);
+            const uint64_t v0 = var[sb * 85 + 1], v1 = var[sb * 85 + 2], v2 = var[sb * 85 + 3], v3 = var[sb * 85 + 4];
+            const uint64_t avg = (v0 + v1 + v2 + v3) >> 2;
+            /* the reference adds four int32 products, shifts the int32 sum and only then widens it to uint64 (:806-811).  The
+             * variance of 8-bit samples is at most 16256, so the sum stays below 2^31; for larger (impossible) inputs the
+             * reference's expression overflows int32 = undefined behaviour in C, nothing to be exact against */
+            const int32_t d0 = (int32_t)(v0 - avg), d1 = (int32_t)(v1 - avg), d2 = (int32_t)(v2 - avg), d3 = (int32_t)(v3 - avg);
+            const int32_t s4 = (int32_t)((uint32_t)d0 * (uint32_t)d0 + (uint32_t)d1 * (uint32_t)d1 + (uint32_t)d2 * (uint32_t)d2 + (uint32_t)d3 * (uint32_t)d3);
+            const uint64_t vov = (uint64_t)(int64_t)(s4 >> 2);
+            o->check1_for_logo_stationary_edge_over_time_flag    = !(vov <= 50000 || !low_motion);
+            o->pm_check1_for_logo_stationary_edge_over_time_flag = vov > 1000;
+        }
+        if (p->run_part2) { /* part 2; [quirk] check2 is set to 1 at the end whatever was decided (:868) */
+            if (logo) {
+                const uint32_t low_sad_th = p->input_resolution < 2 ? 5 : 2;
+                const uint32_t me_dist = (p->slice_type == 0 && results) ? results[sb * 85].distortion_direction[0].distortion : 0;
+                o->low_dist_logo = p->slice_type == 0 && me_dist < 64 * 64 * low_sad_th;
+            }
+            o->check2_for_logo_stationary_edge_over_time_flag = 1;
+        }
+        if (p->rate_control_mode && complete) {
+            if (p->slice_type != 2) {
+                o->inter_sad_interval_index = sad_interval(rcme[sb] >> 8);
+                hist[o->inter_sad_interval_index]++;
+            }
+            o->intra_sad_interval_index = sad_interval(var[sb * 85] >> 4);
+            hist[128 + o->intra_sad_interval_index]++;
+            ++*full_sb_count;
+        }
+    }
+    return 0;
+}

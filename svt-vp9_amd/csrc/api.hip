@@ -31,6 +31,10 @@ static int32_t ctx_create(svt_hip_ctx **out, int32_t device, void *stream, int o
     svt_hip_ctx *c = (svt_hip_ctx *)calloc(1, sizeof *c);
     if (!c) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "ctx: malloc");
     c->device = device;
+    {
+        hipDeviceProp_t pr;
+        c->cu_count = (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
     if (owns && cu_mask) {
         if (hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask_words, cu_mask) != hipSuccess) { free(c); return svt_set_error(SVT_HIP_ERR_DEVICE, "ctx: CU-masked stream"); }
     } else if (owns) {

@@ -293,3 +293,92 @@ extern "C" int32_t svt_hip_sad_loop_batch_device(svt_hip_ctx *ctx, const uint8_t
     ctx->timed = 1;
     return SVT_HIP_OK;
 }
+
+
+/* The rest of the ME kernel process's per-SB bookkeeping (row M12): stationary_edge_over_update_over_time_sb_part1 / _part2
+ * (Codec/EbMotionEstimationProcess.c:785-869) and the rate-control SAD-interval indices / histograms (:1103-1237), one thread
+ * per SB straight from the ME results, the picture-analysis variances and the rcme distortions in HBM.  The histograms are
+ * first gathered per workgroup in LDS (128 + 128 bins), then added to the picture's. */
+__device__ __forceinline__ uint32_t me_sad_interval(uint32_t v) { /* :1126-1137 */
+    uint32_t i = (v & 0xffffu) >> 2;
+    if (i > 63) i = 63 + ((i - 63) >> 3);
+    return i >= 127 ? 127 : i;
+}
+__global__ __launch_bounds__(256) void svt_me_sb_stats_kernel(svt_me_sb_stats_params p, int nx, int n_sb, const svt_me_pu_result *__restrict__ results,
+                                                              const uint16_t *__restrict__ var, const uint32_t *__restrict__ rcme,
+                                                              svt_me_sb_stats *__restrict__ out, uint32_t *__restrict__ hist, uint32_t *__restrict__ full_count) {
+    __shared__ uint32_t s_hist[2 * SVT_SAD_INTERVALS + 1];
+    for (int i = threadIdx.x; i < 2 * SVT_SAD_INTERVALS + 1; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    const int sb = blockIdx.x * 256 + threadIdx.x;
+    if (sb < n_sb) {
+        const int W = p.pic_width, H = p.pic_height, ox = (sb % nx) * ME_SB, oy = (sb / nx) * ME_SB;
+        const int complete = ox + ME_SB <= W && oy + ME_SB <= H;
+        /* potential_logo_sb (Codec/EbSequenceControlSet.c:332-413): the top corners and the bottom band, 3 x 2 / 7 x 4 / 14 x 8 SBs */
+        const int k = p.input_resolution <= 0 ? 1 : p.input_resolution < 3 ? 2 : 4;
+        const int wx = (k == 1 ? 3 : 7 * (k >> 1)) * ME_SB, wy = 2 * k * ME_SB;
+        const int logo = complete && ((oy < wy && (ox >= W - wx || ox < wx)) || oy >= H - wy);
+        uint32_t  check1 = 0, pm1 = 0, check2 = 0, low = 0, inter_idx = 0, intra_idx = 0;
+        if (logo) {
+            int mvx = 0, mvy = 0;
+            if (p.temporal_layer_index > 0 && results) { mvx = results[(size_t)sb * 85].x_mv_l0; mvy = results[(size_t)sb * 85].y_mv_l0; }
+            const bool     low_motion = p.temporal_layer_index == 0 || ((mvx < 0 ? -mvx : mvx) < 16 && (mvy < 0 ? -mvy : mvy) < 16);
+            const uint16_t *v = var + (size_t)sb * 85;
+            const int64_t  v0 = v[1], v1 = v[2], v2 = v[3], v3 = v[4], avg = (v0 + v1 + v2 + v3) >> 2;
+            const int32_t  d0 = (int32_t)(v0 - avg), d1 = (int32_t)(v1 - avg), d2 = (int32_t)(v2 - avg), d3 = (int32_t)(v3 - avg);
+            /* int32 products that wrap, an arithmetic shift of the int32 sum, then the widening (:806-811) */
+            const int32_t  s4 = (int32_t)((uint32_t)d0 * (uint32_t)d0 + (uint32_t)d1 * (uint32_t)d1 + (uint32_t)d2 * (uint32_t)d2 + (uint32_t)d3 * (uint32_t)d3);
+            const uint64_t vov = (uint64_t)(int64_t)(s4 >> 2);
+            check1 = !(vov <= 50000 || !low_motion);
+            pm1    = vov > 1000;
+        }
+        if (p.run_part2) {
+            if (logo) {
+                const uint32_t th = p.input_resolution < 2 ? 5u : 2u;
+                const uint32_t dist = (p.slice_type == 0 && results) ? results[(size_t)sb * 85].distortion_direction[0].distortion : 0u;
+                low = p.slice_type == 0 && dist < 64u * 64u * th;
+            }
+            check2 = 1; /* [quirk] :868 */
+        }
+        if (p.rate_control_mode && complete) {
+            if (p.slice_type != 2) {
+                inter_idx = me_sad_interval(rcme[sb] >> 8);
+                atomicAdd(&s_hist[inter_idx], 1u);
+            }
+            intra_idx = me_sad_interval((uint32_t)var[(size_t)sb * 85] >> 4);
+            atomicAdd(&s_hist[SVT_SAD_INTERVALS + intra_idx], 1u);
+            atomicAdd(&s_hist[2 * SVT_SAD_INTERVALS], 1u);
+        }
+        svt_me_sb_stats o;
+        o.check1_for_logo_stationary_edge_over_time_flag = (uint8_t)check1; o.pm_check1_for_logo_stationary_edge_over_time_flag = (uint8_t)pm1;
+        o.check2_for_logo_stationary_edge_over_time_flag = (uint8_t)check2; o.low_dist_logo = (uint8_t)low;
+        o.inter_sad_interval_index = (uint16_t)inter_idx; o.intra_sad_interval_index = (uint16_t)intra_idx;
+        out[sb] = o;
+    }
+    __syncthreads();
+    if (p.rate_control_mode) {
+        for (int i = threadIdx.x; i < 2 * SVT_SAD_INTERVALS; i += 256) if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
+        if (threadIdx.x == 0 && s_hist[2 * SVT_SAD_INTERVALS]) atomicAdd(full_count, s_hist[2 * SVT_SAD_INTERVALS]);
+    }
+}
+
+extern "C" int32_t svt_hip_me_sb_stats_device(svt_hip_ctx *ctx, const svt_me_sb_stats_params *params, const svt_me_pu_result *d_results,
+                                              const uint16_t *d_var, const uint32_t *d_rcme, svt_me_sb_stats *d_stats, uint32_t *d_hist,
+                                              uint32_t *d_full_sb_count) {
+    if (!ctx || !params || !d_var || !d_stats) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "sb_stats: null argument");
+    if (params->pic_width < 8 || params->pic_height < 8 || params->input_resolution < 0 || params->input_resolution > 3 ||
+        params->slice_type < 0 || params->slice_type > 2)
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "sb_stats: parameter out of range");
+    if (params->slice_type != 2 && !d_results) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "sb_stats: results missing for an inter picture");
+    if (params->rate_control_mode && (!d_hist || !d_full_sb_count || (params->slice_type != 2 && !d_rcme)))
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "sb_stats: histogram / rcme buffers missing");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int nx = (params->pic_width + ME_SB - 1) / ME_SB, ny = (params->pic_height + ME_SB - 1) / ME_SB, n_sb = nx * ny;
+    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    hipLaunchKernelGGL(svt_me_sb_stats_kernel, dim3((n_sb + 255) / 256), dim3(256), 0, ctx->stream, *params, nx, n_sb, d_results, d_var, d_rcme, d_stats,
+                       d_hist, d_full_sb_count);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->timed = 1;
+    return SVT_HIP_OK;
+}

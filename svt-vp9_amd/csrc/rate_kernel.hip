@@ -81,8 +81,7 @@ extern "C" int32_t svt_hip_coeff_rate_batch_device(svt_hip_ctx *ctx, const int16
         return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "rate: scan / block / coefficient arrays must be 4 / 16 / 16-byte aligned");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
-    int dev_cus = 256;
-    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess && pr.multiProcessorCount > 0) dev_cus = pr.multiProcessorCount; }
+    const int dev_cus = ctx->cu_count;
     const int want = (n_blocks + 15) / 16, cap = dev_cus * 5; /* 31 KB of LDS per workgroup: five per CU */
     hipLaunchKernelGGL(svt_rate_kernel, dim3(want < cap ? want : cap), dim3(256), 0, ctx->stream, d_qcoeff, d_blocks, n_blocks, d_tables, d_scan, d_bits);
     HIP_TRY(hipGetLastError());

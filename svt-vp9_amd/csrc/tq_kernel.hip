@@ -576,8 +576,7 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
 
 /* persistent grid: a multiple of 8 workgroups (one walk per XCD, tq_walk_of), at most `per_cu` per compute unit */
 int tq_grid(svt_hip_ctx *ctx, int ngroups, int per_cu) {
-    hipDeviceProp_t pr;
-    const int cus = (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    const int cus = ctx->cu_count;
     const int per_xcd = (ngroups + 7) / 8, cap = (cus * per_cu + 7) / 8;
     return 8 * (per_xcd < cap ? per_xcd : cap);
 }

@@ -129,6 +129,11 @@ def gen_sad_loop():
     np.savez_compressed(os.path.join(G, "sad_loop_reference.npz"), **{str(seed): T.ref_sad_loop_case(T.make_sad_loop_case(seed)) for seed in (1, 2)})
 
 
+def gen_sb_stats():
+    # ---- stationary-edge flags: the reference's part1 / part2 + eb_vp9_sb_params_init on the cases of tests/test_me_side.py ----
+    np.savez_compressed(os.path.join(G, "sb_stats_reference.npz"), **{str(c[0]): T.ref_me_stationary_edge(T.make_sb_stats_case(*c)) for c in T.SB_STATS_CASES})
+
+
 def gen_lf_params():
     # ---- LF parameters: the reference's eb_vp9_loop_filter_init (sharpness 0..7) and eb_vp9_pick_filter_level (all q) ----
     np.savez_compressed(os.path.join(G, "lf_params_reference.npz"), **T.ref_lf_params())
@@ -139,7 +144,7 @@ def gen_me_presets():
     np.savez_compressed(os.path.join(G, "me_presets_reference.npz"), **T.ref_me_presets())
 
 
-SECTIONS = ("scan", "me", "tq", "lf", "lf_masks", "mc", "rate", "quant", "ivf", "lf_params", "me_presets", "sad_loop")
+SECTIONS = ("scan", "me", "tq", "lf", "lf_masks", "mc", "rate", "quant", "ivf", "lf_params", "me_presets", "sad_loop", "sb_stats")
 
 
 def main():

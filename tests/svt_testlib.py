@@ -1190,6 +1190,68 @@ def hip_rate_batch(ctx, case):
     return bits
 
 
+# ---- M12, rest: stationary-edge flags and rate-control SAD-interval histograms -------------------------------------
+def make_sb_stats_case(seed, width, height, input_resolution, temporal_layer, slice_type, run_part2, rate_control_mode=1):
+    rng = np.random.default_rng(seed)
+    n = n_sb(width, height)
+    res = np.zeros((n, 85), dtype=B.ME_RESULT_DTYPE)
+    res["x_mv_l0"][:, 0], res["y_mv_l0"][:, 0] = rng.integers(-40, 41, n), rng.integers(-40, 41, n)
+    res["dist0"][:, 0] = rng.integers(0, 4, n) * 6000 + rng.integers(0, 9000, n)       # around 64 * 64 * {2, 5}
+    var = rng.integers(0, 3000, (n, 85)).astype(np.uint16)
+    # wide spreads up to the largest variance 8-bit samples can have (127.5^2 = 16256): beyond that the reference's int32
+    # products of differences overflow, which is undefined behaviour in its C (the compiled result depends on the compiler)
+    var[::3, 1:5] = rng.integers(0, 16257, (len(var[::3]), 4))
+    var[::7, 1:5] = np.array([0, 0, 0, 16256], np.uint16)
+    var[1::7, 1:5] = rng.integers(1000, 1040, (len(var[1::7]), 4))                     # near-equal: both checks off
+    var[:, 0] = rng.integers(0, 65536, n)
+    rcme = rng.integers(0, 1 << 20, n).astype(np.uint32)
+    p = B.MeSbStatsParams(width, height, input_resolution, temporal_layer, slice_type, run_part2, rate_control_mode)
+    return dict(p=p, res=res, var=var, rcme=rcme, n=n)
+
+
+def oracle_me_sb_stats(case):
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    out = np.zeros(case["n"], dtype=B.ME_SB_STATS_DTYPE)
+    hist, full = np.zeros(256, np.uint32), np.zeros(1, np.uint32)
+    rc = oracle().svt_oracle_me_sb_stats(C.byref(case["p"]), vp(case["res"]), vp(case["var"]), vp(case["rcme"]), vp(out), vp(hist), vp(full))
+    assert rc == 0
+    return out, hist, int(full[0])
+
+
+def hip_me_sb_stats(ctx, case):
+    import torch
+    dev = torch.device("cuda", 0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
+    res, var, rcme = up(case["res"]), up(case["var"]), up(case["rcme"])
+    out = torch.zeros(case["n"] * 8, dtype=torch.uint8, device=dev)
+    hist, full = torch.zeros(256, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    lib = B.load()
+    B.check(lib.svt_hip_me_sb_stats_device(ctx, C.byref(case["p"]), p(res), p(var), p(rcme), p(out), p(hist), p(full)))
+    B.check(lib.svt_hip_ctx_synchronize(ctx))
+    return out.cpu().numpy().view(B.ME_SB_STATS_DTYPE), hist.cpu().numpy().view(np.uint32), int(full.cpu().numpy()[0])
+
+
+def ref_me_stationary_edge(case):
+    """the reference's own stationary_edge_over_update_over_time_sb_part1 / _part2 and eb_vp9_sb_params_init
+    (oracle/_ref/ref_me_side, request 'SVMT'): uint8 [n_sb][6] = check1, pm_check1, check2, low_dist_logo, potential_logo_sb, complete"""
+    exe = os.path.join(REF_DIR, "ref_me_side")
+    p = case["p"]
+    with tempfile.TemporaryDirectory() as td:
+        req, rsp = os.path.join(td, "req.bin"), os.path.join(td, "rsp.bin")
+        with open(req, "wb") as f:
+            f.write(struct.pack("<7i", 0x544D5653, p.pic_width, p.pic_height, p.input_resolution, p.temporal_layer_index, p.slice_type, p.run_part2))
+            for i in range(case["n"]):
+                r = case["res"][i, 0]
+                f.write(struct.pack("<hhI4H", int(r["x_mv_l0"]), int(r["y_mv_l0"]), int(r["dist0"]), *[int(v) for v in case["var"][i, 1:5]]))
+        subprocess.check_call([exe, req, rsp])
+        return np.frombuffer(open(rsp, "rb").read(), np.uint8).reshape(case["n"], 6).copy()
+
+
+SB_STATS_CASES = ((1, 640, 360, 0, 0, 2, 1), (2, 1280, 720, 1, 1, 0, 1), (3, 1920, 1080, 2, 3, 0, 1), (4, 3840, 2160, 3, 2, 0, 1), (5, 3840, 2160, 3, 0, 1, 0),
+                  (6, 328, 200, 0, 4, 0, 1), (7, 1920, 1088, 2, 0, 2, 0), (8, 832, 480, 0, 1, 1, 1))
+
+
 def ref_me_side(cur, prev, input_resolution, cur_mean, cur_var, ref_mean, ref_var, is_i_slice, is_used_as_reference):
     """the reference's compute_zz_sad + eb_vp9_derive_similar_collocated_flag (oracle/_ref/ref_me_side).
     Returns (non_moving_index, similar, similar_all_layers)."""

@@ -106,3 +106,51 @@ def test_oracle_and_host_vs_reference_me_side(res, w, h):
             T.oracle().svt_oracle_me_similar_collocated(vp(cm), vp(cv), vp(rm), vp(rv), n, i_slice, is_ref, vp(a), vp(b))
             assert np.array_equal(a, r_sim) and np.array_equal(b, r_all)
     assert len(set(nmi.tolist())) >= 2
+
+
+# ---- M12, rest: stationary-edge flags and rate-control SAD-interval indices / histograms ----
+def _flags(out):
+    return np.stack([out["check1"], out["pm_check1"], out["check2"], out["low_dist_logo"]], axis=1)
+
+
+@pytest.mark.parametrize("c", T.SB_STATS_CASES)
+def test_sb_stats_oracle_vs_reference_golden(c):
+    case = T.make_sb_stats_case(*c)
+    out, hist, full = T.oracle_me_sb_stats(case)
+    g = np.load(f"{T.GOLDEN_DIR}/sb_stats_reference.npz")[str(c[0])]
+    assert np.array_equal(_flags(out), g[:, :4]), c
+    nx = (c[1] + 63) // 64
+    complete = np.array([(sb % nx) * 64 + 64 <= c[1] and (sb // nx) * 64 + 64 <= c[2] for sb in range(case["n"])])
+    assert np.array_equal(complete, g[:, 5].astype(bool))
+    assert g[:, 4].any() and not g[:, 4].all() or case["n"] < 40           # some SBs can hold a logo, not all
+    # histograms: one count per complete SB, the indices they were counted under
+    assert full == complete.sum() and hist[128:].sum() == full
+    assert hist[:128].sum() == (full if c[5] != 2 else 0)
+    assert np.array_equal(np.bincount(out["intra_idx"][complete], minlength=128), hist[128:])
+    assert out["inter_idx"].max() <= 127 and (out["inter_idx"][~complete] == 0).all()
+
+
+@pytest.mark.skipif(not T.have_ref("ref_me_side"), reason="oracle/_ref/ref_me_side not built (reference absent)")
+@pytest.mark.parametrize("c", [(11, 3840, 2160, 3, 1, 0, 1), (12, 1280, 720, 1, 0, 2, 1), (13, 720, 576, 0, 2, 0, 0)])
+def test_sb_stats_oracle_vs_reference_live(c):
+    case = T.make_sb_stats_case(*c)
+    out, _, _ = T.oracle_me_sb_stats(case)
+    r = T.ref_me_stationary_edge(case)
+    assert np.array_equal(_flags(out), r[:, :4])
+    assert len(set(map(tuple, r[:, :4].tolist()))) >= 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", T.SB_STATS_CASES)
+def test_gpu_sb_stats_vs_oracle_and_golden(c):
+    lib = B.load()
+    ctx = C.c_void_p()
+    B.check(lib.svt_hip_ctx_create(C.byref(ctx), 0))
+    try:
+        case = T.make_sb_stats_case(*c)
+        o, oh, of = T.oracle_me_sb_stats(case)
+        g, gh, gf = T.hip_me_sb_stats(ctx, case)
+        assert np.array_equal(o, g) and np.array_equal(oh, gh) and of == gf
+        assert np.array_equal(_flags(g), np.load(f"{T.GOLDEN_DIR}/sb_stats_reference.npz")[str(c[0])][:, :4])
+    finally:
+        lib.svt_hip_ctx_destroy(ctx)
