@@ -183,6 +183,16 @@ const char *svt_hip_last_error(void);
  * hipEvents recorded on the context's stream (ms).  Valid after svt_hip_ctx_synchronize(). */
 float   svt_hip_last_kernel_ms(svt_hip_ctx *ctx);
 
+/* Device memory for C hosts (the *_device entry points take HBM pointers): plain allocations on the context's device, and
+ * copies ordered on the context's stream.  svt_hip_mem_upload_2d returns after the host rows have been consumed (the caller
+ * may reuse them), svt_hip_mem_download after the data has arrived. */
+int32_t svt_hip_mem_alloc(svt_hip_ctx *ctx, size_t bytes, void **d_ptr);
+void    svt_hip_mem_free(svt_hip_ctx *ctx, void *d_ptr);
+int32_t svt_hip_mem_upload_2d(svt_hip_ctx *ctx, void *d_dst, size_t dst_stride, const void *src, size_t src_stride, size_t width_bytes,
+                              size_t rows);
+int32_t svt_hip_mem_download(svt_hip_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+int32_t svt_hip_mem_set(svt_hip_ctx *ctx, void *d_dst, int32_t value, size_t bytes);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* ME entry points                                                                                    */
 /* ------------------------------------------------------------------------------------------------ */

@@ -141,3 +141,39 @@ void *svt_ctx_slot(svt_hip_ctx *c, int s, size_t bytes) {
     }
     return c->slot[s];
 }
+
+/* ---- device memory for C hosts ---- */
+extern "C" int32_t svt_hip_mem_alloc(svt_hip_ctx *ctx, size_t bytes, void **d_ptr) {
+    if (!ctx || !d_ptr || !bytes) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "mem_alloc: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (hipMalloc(d_ptr, bytes) != hipSuccess) { *d_ptr = nullptr; return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "mem_alloc: out of device memory"); }
+    return SVT_HIP_OK;
+}
+extern "C" void svt_hip_mem_free(svt_hip_ctx *ctx, void *d_ptr) {
+    if (!ctx || !d_ptr) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_ptr);
+}
+extern "C" int32_t svt_hip_mem_upload_2d(svt_hip_ctx *ctx, void *d_dst, size_t dst_stride, const void *src, size_t src_stride,
+                                         size_t width_bytes, size_t rows) {
+    if (!ctx || !d_dst || !src || !width_bytes || !rows || dst_stride < width_bytes || src_stride < width_bytes)
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "mem_upload: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpy2DAsync(d_dst, dst_stride, src, src_stride, width_bytes, rows, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); /* the host rows may be pageable and are the caller's to reuse on return */
+    return SVT_HIP_OK;
+}
+extern "C" int32_t svt_hip_mem_download(svt_hip_ctx *ctx, void *dst, const void *d_src, size_t bytes) {
+    if (!ctx || !dst || !d_src || !bytes) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "mem_download: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SVT_HIP_OK;
+}
+extern "C" int32_t svt_hip_mem_set(svt_hip_ctx *ctx, void *d_dst, int32_t value, size_t bytes) {
+    if (!ctx || !d_dst || !bytes) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "mem_set: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+    return SVT_HIP_OK;
+}

@@ -134,6 +134,11 @@ def gen_sb_stats():
     np.savez_compressed(os.path.join(G, "sb_stats_reference.npz"), **{str(c[0]): T.ref_me_stationary_edge(T.make_sb_stats_case(*c)) for c in T.SB_STATS_CASES})
 
 
+def gen_api():
+    # ---- public encoder API: struct layouts, library defaults, level tables, parameter-check verdicts of the reference ----
+    np.savez_compressed(os.path.join(G, "api_reference.npz"), **T.ref_api())
+
+
 def gen_lf_params():
     # ---- LF parameters: the reference's eb_vp9_loop_filter_init (sharpness 0..7) and eb_vp9_pick_filter_level (all q) ----
     np.savez_compressed(os.path.join(G, "lf_params_reference.npz"), **T.ref_lf_params())
@@ -144,7 +149,7 @@ def gen_me_presets():
     np.savez_compressed(os.path.join(G, "me_presets_reference.npz"), **T.ref_me_presets())
 
 
-SECTIONS = ("scan", "me", "tq", "lf", "lf_masks", "mc", "rate", "quant", "ivf", "lf_params", "me_presets", "sad_loop", "sb_stats")
+SECTIONS = ("scan", "me", "tq", "lf", "lf_masks", "mc", "rate", "quant", "ivf", "lf_params", "me_presets", "sad_loop", "sb_stats", "api")
 
 
 def main():

@@ -623,6 +623,37 @@ def ref_lf_frame(case, y_only=False):
             np.frombuffer(raw, np.uint8, us, ys + us).reshape(v.shape)[:H0 // 2, :W0 // 2].copy())
 
 
+# ---- public encoder ABI (row b-1) ----------------------------------------------------------------------------------
+API_VERIFY_CASES = (
+    "", "enc_mode=8 tune=1", "source_width=3840 source_height=2160 enc_mode=8 tune=1", "source_width=3840 source_height=2160 enc_mode=11 tune=1",
+    "source_width=3840 source_height=2160 enc_mode=12 tune=0", "source_width=3840 source_height=2160 enc_mode=13 tune=0", "enc_mode=10", "enc_mode=11",
+    "source_width=640 source_height=360 enc_mode=9", "source_width=640 source_height=360 enc_mode=10", "source_width=60", "source_height=56",
+    "source_width=1002", "source_width=1004", "source_height=1082", "source_width=8200", "source_height=4328", "source_width=8192 source_height=4320",
+    "pred_structure=1", "pred_structure=0 base_layer_switch_mode=1", "base_layer_switch_mode=2", "qp=63", "qp=64", "intra_period=-2", "intra_period=-3",
+    "intra_period=255", "intra_period=256", "loop_filter=2", "use_default_me_hme=2", "enable_hme_flag=2", "search_area_width=0", "search_area_width=256",
+    "search_area_width=257", "search_area_height=0", "search_area_height=257", "level=10", "level=40", "level=41", "level=13", "level=62", "level=51 frame_rate=7864320",
+    "source_width=3840 source_height=2160 level=50", "source_width=3840 source_height=2160 level=51 frame_rate=3932160", "frame_rate=0", "frame_rate=15728640", "frame_rate=15728641",
+    "rate_control_mode=2", "rate_control_mode=3", "rate_control_mode=1 tune=1", "rate_control_mode=1 tune=0", "rate_control_mode=1 tune=0 max_qp_allowed=64",
+    "rate_control_mode=0 max_qp_allowed=64", "rate_control_mode=2 min_qp_allowed=63", "rate_control_mode=2 min_qp_allowed=40 max_qp_allowed=30", "tune=2", "tune=3",
+    "encoder_bit_depth=10", "profile=1", "speed_control_flag=2", "asm_type=2", "asm_type=0", "target_socket=1", "target_socket=2", "target_socket=-2",
+)
+
+
+def ref_api():
+    """what oracle/_ref/ref_api reports about the reference's public API: layout lines, default configuration bytes, level
+    tables, verify_settings' verdict for API_VERIFY_CASES"""
+    exe = os.path.join(REF_DIR, "ref_api")
+    run = lambda mode, inp=None: subprocess.run([exe, mode], input=inp, capture_output=True, check=True)
+    layout = [ln for ln in run("layout").stdout.decode().splitlines() if ln.split()[0].split(".")[0] in
+              ("EbComponentType", "EbSvtEncInput", "EbBufferHeaderType", "EbSvtVp9EncConfiguration", "enum")]
+    grab = lambda r, tag: [ln for ln in r.stderr.decode().splitlines() if ln.startswith(tag)]
+    defaults = np.array(grab(run("defaults"), "DEFAULTS")[0].split()[1:], np.int64).astype(np.uint8)
+    levels = np.array(grab(run("levels"), "LEVELS")[0].split()[1:], np.uint64)
+    verify = np.array([int(ln.split()[1]) for ln in grab(run("verify", "\n".join(API_VERIFY_CASES).encode() + b"\n"), "VERIFY")], np.int64)
+    assert len(verify) == len(API_VERIFY_CASES)
+    return dict(layout=np.array(layout), defaults=defaults, levels=levels, verify=verify)
+
+
 # ---- stand-alone exhaustive SAD search (row M1) ----------------------------------------------------------------------
 def make_sad_loop_case(seed, n_jobs=48):
     """Jobs shaped like the reference's three HME uses of eb_vp9_sad_loop_kernel (16x8 / 32x16 / 64x32 blocks whose rows are

@@ -1,0 +1,203 @@
+"""Scope row b-1: libSvtVp9Enc.so exports the reference's public encoder ABI.  CPU: struct layouts, enum values, library
+defaults and the parameter checks against what the reference itself reports (committed fixture from oracle/_ref/ref_api =
+Source/API/EbSvtVp9Enc.h + Codec/EbEncHandle.c compiled in the build container; live when present), the exported symbols, a
+C caller written against the documented call sequence (compiled against this repository's header and, when the reference is
+present, against the reference's own header -- same source, same library).  GPU: the caller runs a clip through the library;
+the ME results behind the ABI equal the oracle's for the mini-GOP structure the library reports."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import svt_testlib as T
+
+B = T.B
+SHIM = os.path.join(T.ROOT, "svt-vp9_amd", "libSvtVp9Enc.so")
+HDR = os.path.join(T.ROOT, "include")
+GOLD = os.path.join(T.GOLDEN_DIR, "api_reference.npz")
+REF_API_DIR = "/root/reference/Source/API"
+
+CFG_FIELDS = [("enc_mode", C.c_uint8), ("tune", C.c_uint8), ("intra_period", C.c_int32), ("pred_structure", C.c_uint8), ("base_layer_switch_mode", C.c_uint32),
+              ("source_width", C.c_uint32), ("source_height", C.c_uint32), ("frame_rate", C.c_uint32), ("frame_rate_numerator", C.c_uint32),
+              ("frame_rate_denominator", C.c_uint32), ("encoder_bit_depth", C.c_uint32), ("partition_depth", C.c_uint32), ("qp", C.c_uint32),
+              ("use_qp_file", C.c_uint8), ("enable_qp_scaling_flag", C.c_uint32), ("loop_filter", C.c_uint8), ("use_default_me_hme", C.c_uint8),
+              ("enable_hme_flag", C.c_uint8), ("search_area_width", C.c_uint32), ("search_area_height", C.c_uint32), ("rate_control_mode", C.c_uint32),
+              ("target_bit_rate", C.c_uint32), ("max_qp_allowed", C.c_uint32), ("min_qp_allowed", C.c_uint32), ("profile", C.c_uint32), ("level", C.c_uint32),
+              ("asm_type", C.c_uint32), ("channel_id", C.c_uint32), ("active_channel_count", C.c_uint32), ("speed_control_flag", C.c_uint32),
+              ("injector_frame_rate", C.c_int32), ("logical_processors", C.c_uint32), ("target_socket", C.c_int32), ("recon_file", C.c_uint32),
+              ("input_picture_stride", C.c_uint32), ("vbv_max_rate", C.c_uint32), ("vbv_buf_size", C.c_uint32), ("frames_to_be_encoded", C.c_uint64)]
+
+
+class Cfg(C.Structure):
+    _fields_ = CFG_FIELDS
+
+
+class PicInfo(C.Structure):
+    _fields_ = [("picture_number", C.c_uint64), ("is_intra", C.c_int32), ("temporal_layer_index", C.c_int32), ("hierarchical_levels", C.c_int32),
+                ("num_ref_lists", C.c_int32), ("ref_picture_number", C.c_int64 * 2), ("n_sb", C.c_uint32)]
+
+
+def shim():
+    lib = C.CDLL(SHIM)
+    for n in ("eb_vp9_svt_init_handle", "eb_vp9_svt_enc_set_parameter", "eb_vp9_init_encoder", "eb_vp9_deinit_handle", "eb_vp9_deinit_encoder"):
+        getattr(lib, n).restype = C.c_int32
+    return lib
+
+
+def _layout_of_our_header():
+    """the same report oracle/ref_api_driver.c prints, from include/svt_vp9_enc_api.h"""
+    fields = {"EbComponentType": ["n_size", "p_component_private", "p_application_private"],
+              "EbSvtEncInput": ["luma", "cb", "cr", "luma_ext", "cb_ext", "cr_ext", "y_stride", "cr_stride", "cb_stride"],
+              "EbBufferHeaderType": ["size", "p_buffer", "n_filled_len", "n_alloc_len", "p_app_private", "wrapper_ptr", "n_tick_count", "dts", "pts", "qp",
+                                     "pic_type", "flags"],
+              "EbSvtVp9EncConfiguration": [f for f, _ in CFG_FIELDS]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "svt_vp9_enc_api.h"', 'int main(void){']
+    for t, fs in fields.items():
+        src.append(f'printf("{t} %zu\\n", sizeof({t}));')
+        src += [f'printf("{t}.{f} %zu %zu\\n", offsetof({t}, {f}), sizeof((({t}*)0)->{f}));' for f in fs]
+    for e in ("EB_ErrorNone", "EB_ErrorInsufficientResources", "EB_ErrorUndefined", "EB_ErrorInvalidComponent", "EB_ErrorBadParameter", "EB_NoErrorEmptyQueue",
+              "EB_ErrorMax", "EB_BUFFERFLAG_EOS", "EB_BUFFERFLAG_SHOW_EXT"):
+        src.append(f'printf("enum.{e} %lld 4\\n", (long long){e});')
+    src.append("return 0;}")
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "l.c"), "w").write("\n".join(src))
+        subprocess.check_call(["gcc", "-I", HDR, os.path.join(td, "l.c"), "-o", os.path.join(td, "l")])
+        return subprocess.check_output([os.path.join(td, "l")]).decode().splitlines()
+
+
+def _check_against(ref):
+    assert _layout_of_our_header() == [str(x) for x in ref["layout"]]
+    assert C.sizeof(Cfg) == len(ref["defaults"])
+    lib = shim()
+    # defaults: init_handle overwrites exactly the bytes the reference's eb_vp9_svt_enc_init_parameter overwrites
+    cfg = Cfg()
+    C.memset(C.byref(cfg), 0xAA, C.sizeof(cfg))
+    h = C.c_void_p()
+    assert lib.eb_vp9_svt_init_handle(C.byref(h), None, C.byref(cfg)) == 0 and h.value
+    assert np.array_equal(np.frombuffer(bytes(cfg), np.uint8), ref["defaults"])
+    # parameter checks: the reference's verdict for every case
+    for case, want in zip(T.API_VERIFY_CASES, ref["verify"].tolist()):
+        c = Cfg()
+        hh = C.c_void_p()
+        assert lib.eb_vp9_svt_init_handle(C.byref(hh), None, C.byref(c)) == 0
+        c.source_width, c.source_height = 1920, 1080
+        for tok in case.split():
+            k, v = tok.split("=")
+            setattr(c, k, int(v))
+        got = lib.eb_vp9_svt_enc_set_parameter(hh, C.byref(c))
+        assert got == want, (case, got, want)
+        assert lib.eb_vp9_deinit_handle(hh) == 0
+    assert lib.eb_vp9_deinit_handle(h) == 0
+    assert len(ref["levels"]) == 26
+
+
+def test_abi_layout_defaults_and_checks_vs_reference_golden():
+    _check_against(dict(np.load(GOLD)))
+    assert (np.load(GOLD)["verify"] == 0).sum() >= 20 and (np.load(GOLD)["verify"] != 0).sum() >= 20
+
+
+@pytest.mark.skipif(not T.have_ref("ref_api"), reason="oracle/_ref/ref_api not built (reference absent)")
+def test_abi_vs_reference_live():
+    _check_against(T.ref_api())
+
+
+def test_exported_symbols_are_the_reference_surface():
+    out = subprocess.check_output(["nm", "-D", "--defined-only", SHIM]).decode()
+    syms = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    want = {"eb_vp9_svt_init_handle", "eb_vp9_svt_enc_set_parameter", "eb_vp9_init_encoder", "eb_vp9_svt_enc_stream_header", "eb_vp9_svt_enc_eos_nal",
+            "eb_vp9_svt_enc_send_picture", "eb_vp9_svt_get_packet", "eb_vp9_svt_release_out_buffer", "eb_vp9_svt_get_recon", "eb_vp9_deinit_encoder",
+            "eb_vp9_deinit_handle"}
+    assert want <= syms and syms - want == {"svt_vp9_shim_get_me_results"}
+    assert "libSvtVp9Enc.so.1" in subprocess.check_output(["readelf", "-d", SHIM]).decode()
+
+
+def _build_app(td, header_dir, header_name):
+    exe = os.path.join(td, "enc_app_" + header_name.split(".")[0])
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Werror", f'-DSVT_API_HEADER="{header_name}"', "-I", header_dir, "-I", os.path.join(T.ROOT, "oracle", "_ref", "gen"),
+                           os.path.join(T.ROOT, "tests", "c", "enc_app.c"), "-L", os.path.dirname(SHIM), "-lSvtVp9Enc", f"-Wl,-rpath,{os.path.dirname(SHIM)}", "-o", exe])
+    return exe
+
+
+def _clip(td, w, h, n):
+    frames = T.gen_clip_subpel(w, h, n, 41)
+    path = os.path.join(td, "in.yuv")
+    with open(path, "wb") as f:
+        for y in frames:
+            f.write(y.tobytes()); f.write((y[::2, ::2] // 2 + 32).astype(np.uint8).tobytes()); f.write(np.full((h // 2, w // 2), 128, np.uint8).tobytes())
+    return path, frames
+
+
+def test_c_caller_compiles_links_and_fails_loudly_without_gpu():
+    import torch
+    with tempfile.TemporaryDirectory() as td:
+        exes = [_build_app(td, HDR, "svt_vp9_enc_api.h")]
+        if os.path.isdir(REF_API_DIR) and os.path.exists(os.path.join(T.ROOT, "oracle", "_ref", "gen", "EbApiVersion.h")):
+            exes.append(_build_app(td, REF_API_DIR, "EbSvtVp9Enc.h"))   # the reference's own header: same source, same library
+        if torch.cuda.is_available():
+            pytest.skip("GPU present: covered by the gpu test")
+        path, _ = _clip(td, 128, 64, 2)
+        for exe in exes:
+            r = subprocess.run([exe, path, "128", "64", "2", "9", "1"], capture_output=True, text=True)
+            assert r.returncode == 3 and "no device" in r.stdout, (r.returncode, r.stdout, r.stderr)   # no CPU fallback behind the ABI
+
+
+@pytest.mark.gpu
+def test_c_caller_runs_a_clip_and_me_results_equal_oracle():
+    W, H, N = 256, 192, 36          # picture 0 intra, two mini-GOPs of 16 (tune 1 -> 4 hierarchical levels), 3 pictures left over
+    with tempfile.TemporaryDirectory() as td:
+        path, frames = _clip(td, W, H, N)
+        exe = _build_app(td, HDR, "svt_vp9_enc_api.h")
+        r = subprocess.run([exe, path, str(W), str(H), str(N), "9", "1"], capture_output=True, text=True)
+        assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+        assert r.stdout.strip().endswith(f"packets {N} eos 1 bytes 0")      # one zero-byte packet per picture, EOS on the last
+        # the same calls through ctypes, then the extension: what ran behind the ABI
+        lib = shim()
+        lib.svt_vp9_shim_get_me_results.restype = C.c_int32
+        cfg, h = Cfg(), C.c_void_p()
+        assert lib.eb_vp9_svt_init_handle(C.byref(h), None, C.byref(cfg)) == 0
+        cfg.source_width, cfg.source_height, cfg.enc_mode, cfg.tune, cfg.frame_rate, cfg.intra_period = W, H, 9, 1, 60 << 16, -1
+        assert lib.eb_vp9_svt_enc_set_parameter(h, C.byref(cfg)) == 0 and lib.eb_vp9_init_encoder(h) == 0
+
+        class In(C.Structure):
+            _fields_ = [(n, C.c_void_p) for n in ("luma", "cb", "cr", "luma_ext", "cb_ext", "cr_ext")] + [(n, C.c_uint32) for n in ("y_stride", "cr_stride", "cb_stride")]
+
+        class Hdr(C.Structure):
+            _fields_ = [("size", C.c_uint32), ("p_buffer", C.c_void_p), ("n_filled_len", C.c_uint32), ("n_alloc_len", C.c_uint32), ("p_app_private", C.c_void_p),
+                        ("wrapper_ptr", C.c_void_p), ("n_tick_count", C.c_uint32), ("dts", C.c_int64), ("pts", C.c_int64), ("qp", C.c_uint32), ("pic_type", C.c_uint32),
+                        ("flags", C.c_uint32)]
+        nsb = T.n_sb(W, H)
+        checked = 0
+        pics = [T.PaPic(f) for f in frames]
+        for n in range(N):
+            y = np.ascontiguousarray(frames[n]); u = np.ascontiguousarray(y[::2, ::2]); v = u.copy()
+            i = In(y.ctypes.data, u.ctypes.data, v.ctypes.data, None, None, None, W, W // 2, W // 2)
+            b = Hdr(size=C.sizeof(Hdr), p_buffer=C.addressof(i), pts=n, flags=1 if n == N - 1 else 0)
+            assert lib.eb_vp9_svt_enc_send_picture(h, C.byref(b)) == 0
+            if n in (16, 32, N - 1):      # a mini-GOP has just been processed (or the stream flushed): check what is still buffered
+                lo = {16: 1, 32: 17, N - 1: 33}[n]
+                for k in range(lo, n + 1):
+                    info, res = PicInfo(), np.zeros((nsb, 85), dtype=B.ME_RESULT_DTYPE)
+                    assert lib.svt_vp9_shim_get_me_results(h, C.c_uint64(k), C.byref(info), res.ctypes.data_as(C.c_void_p), C.c_uint64(res.nbytes)) == 0
+                    assert not info.is_intra and info.n_sb == nsb
+                    r0, r1 = info.ref_picture_number[0], info.ref_picture_number[1]
+                    if k <= 32:     # inside a full mini-GOP: the reference's hierarchy
+                        kk = k - lo + 1
+                        layer = 0 if kk == 16 else 4 - ((kk & -kk).bit_length() - 1)
+                        span = 16 >> layer
+                        assert (info.temporal_layer_index, info.num_ref_lists, r0, r1) == ((layer, 2, lo - 1, lo - 1) if kk == 16 else (layer, 2, k - span, k + span))
+                    else:           # the short tail: a chain of P pictures
+                        assert (info.temporal_layer_index, info.num_ref_lists, r0, r1) == (0, 1, k - 1, -1)
+                    if k % 5 == 1 or k >= 33:
+                        p = B.me_params_derive(pic_width=W, pic_height=H, enc_mode=9, tune=1, frame_rate=60, num_ref_lists=info.num_ref_lists,
+                                               temporal_layer_index=info.temporal_layer_index, hierarchical_levels=info.hierarchical_levels,
+                                               is_used_as_reference=int(info.temporal_layer_index < info.hierarchical_levels), same_ref_poc=int(info.num_ref_lists == 2 and r0 == r1))
+                        o, _ = T.oracle_me_picture(pics[k], pics[r0], pics[r1] if info.num_ref_lists == 2 else None, p)
+                        assert not T.me_results_equal(o, res, info.num_ref_lists), k
+                        checked += 1
+        info = PicInfo()
+        assert lib.svt_vp9_shim_get_me_results(h, C.c_uint64(0), C.byref(info), None, C.c_uint64(0)) != 0   # picture 0 has left the buffer
+        assert checked >= 8
+        assert lib.eb_vp9_deinit_encoder(h) == 0 and lib.eb_vp9_deinit_handle(h) == 0
