@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--height", type=int, default=H4K)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--handoff", action="store_true", help="N > 1 only: split-GOP mode -- every step each rank also hands its padded base-layer reconstruction to "
+                    "the next rank (RCCL send / recv over xGMI), the one exchange step of the path; closed GOPs (the default) need none")
     ap.add_argument("--stages", default=",".join(STAGES), help="profiling aid: run only these stages (the contract run uses all six)")
     args = ap.parse_args()
 
@@ -479,6 +481,21 @@ def main():
     def run_lf(buf):
         B.check(lib.svt_hip_lf_batch_device(ctx_lf, MINIGOP, lf_desc[buf], lfm_ptrs, lfs, C.byref(thr), mrs, mcs, 0))
 
+    # split-GOP hand-off (optional, N > 1): the padded base-layer reconstruction (luma + chroma with 80 / 40 samples of padding)
+    handoff = args.handoff and world > 1
+    if handoff:
+        ho_bytes = (Wd + 2 * pad) * (Hd + 2 * pad) + 2 * (Wd // 2 + pad) * (Hd // 2 + pad)
+        ho_send, ho_recv = dev_zeros(ho_bytes, torch.uint8), dev_zeros(ho_bytes, torch.uint8)
+        ho_stream = torch.cuda.Stream(device=local_rank)
+
+    def run_handoff():
+        # ordered after this step's deblocking (the picture handed over is its output), overlapped with the next step's work
+        ho_stream.wait_stream(streams[2])
+        with torch.cuda.stream(ho_stream):
+            ops = [dist.P2POp(dist.isend, ho_send, (rank + 1) % world), dist.P2POp(dist.irecv, ho_recv, (rank - 1) % world)]
+            for w_ in dist.batch_isend_irecv(ops):
+                w_.wait()
+
     stages = set(args.stages.split(","))
     ev = []            # (stage name, start event, stop event) of every stage of every timed step
     lf_done = [None, None]   # event after the deblocking that last read reconstruction buffer b
@@ -516,6 +533,8 @@ def main():
         staged("lf", streams[2], lambda: run_lf(buf), record)
         lf_done[buf] = torch.cuda.Event()
         lf_done[buf].record(streams[2])
+        if handoff:
+            run_handoff()
 
     def sync():
         for c_ in ctxs:
@@ -608,7 +627,7 @@ def main():
                    "stages_run": [s for s in STAGES if s in stages],
                    "pictures_per_step": MINIGOP, "transform_blocks_per_step": int(len(tq_blocks_all)), "q_index": Q_INDEX,
                    "workload_stats": workload_stats,
-                   "parallelism": f"gop-shard x{world}"},
+                   "parallelism": f"gop-shard x{world}" + (" + split-GOP reference hand-off (RCCL send/recv)" if handoff else "")},
         "roofline": {"bound": "hbm", "kernel": "svt_me_sb_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
                      "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                      "launches_per_step": len(me_launches), "avg_launch_ms": round(per_launch_ms, 4),

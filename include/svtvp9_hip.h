@@ -580,6 +580,33 @@ int32_t svt_hip_coeff_rate_batch(svt_hip_ctx *ctx, const int16_t *qcoeff, size_t
                                  int32_t *bits);
 
 /* ------------------------------------------------------------------------------------------------ */
+/* Multi-GPU: GOP sharding and the inter-segment reference hand-off (scope row e)                      */
+/* ------------------------------------------------------------------------------------------------ */
+/* Closed GOPs are independent units of the reference (every intra refresh is a key frame, Codec/EbPictureDecisionProcess.c:952,
+ * 1596-1603): GOP g is encoded by device g % n_devices and the data path needs no exchange.  svt_hip_gop_assign writes the
+ * GOPs of device `index` (ascending) into gops[] (capacity max) and returns how many there are; svt_hip_gop_owner is g % n. */
+int32_t svt_hip_gop_owner(int64_t gop, int32_t n_devices);
+int32_t svt_hip_gop_assign(int64_t n_gops, int32_t n_devices, int32_t index, int64_t *gops, int32_t max);
+/* Split-GOP (low-latency) mode: consecutive mini-GOPs of ONE GOP go to consecutive devices; mini-GOP m is encoded by device
+ * m % n_devices and needs the reconstructed, deblocked, padded base-layer picture of mini-GOP m - 1 from device (m - 1) %
+ * n_devices first -- the one exchange step of the path (a point-to-point copy over one xGMI link, ~13.9 MB at 4K).
+ * Returns the device that produces the reference mini-GOP m needs, or -1 for m = 0 (it starts from the key frame). */
+int32_t svt_hip_minigop_reference_source(int64_t minigop, int32_t n_devices);
+
+/* A set of contexts, one per device of a node, for a host that drives several GPUs from one process (one host thread per
+ * device is the intended use: a context is not shared between threads).  Devices are HIP ordinals. */
+typedef struct svt_hip_device_set svt_hip_device_set;
+int32_t      svt_hip_device_set_create(svt_hip_device_set **set, const int32_t *device_ordinals, int32_t n_devices);
+int32_t      svt_hip_device_set_size(const svt_hip_device_set *set);
+svt_hip_ctx *svt_hip_device_set_ctx(svt_hip_device_set *set, int32_t index);
+void         svt_hip_device_set_destroy(svt_hip_device_set *set);
+/* The hand-off itself: `bytes` of device memory (a padded picture buffer) from d_src on src's device to d_dst on dst's
+ * device, ordered after everything enqueued on src's stream and before everything enqueued later on dst's stream; src's
+ * stream also waits for the copy, so the producer may overwrite d_src afterwards.  Peer access is enabled on first use;
+ * the copy travels device to device (xGMI) when the devices are peers.  src == dst degenerates to a device-local copy. */
+int32_t svt_hip_ref_handoff_device(svt_hip_ctx *src, const void *d_src, svt_hip_ctx *dst, void *d_dst, size_t bytes);
+
+/* ------------------------------------------------------------------------------------------------ */
 /* IVF container (host only): what the reference's sample application wraps the encoder's packets in   */
 /* ------------------------------------------------------------------------------------------------ */
 #define SVT_IVF_STREAM_HEADER_BYTES 32

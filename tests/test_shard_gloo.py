@@ -85,3 +85,73 @@ def test_gop_shard_world2_gloo(tmp_path):
 
 if __name__ == "__main__" and len(sys.argv) == 6 and sys.argv[1] == "--worker":
     _worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
+
+
+# ---- split-GOP mode: the inter-segment reference hand-off (the one exchange step of the path) ----
+N_MINIGOPS = 7
+
+
+def _encode_minigop(ref, m):
+    """stand-in for "encode mini-GOP m from its reference": the next reference depends on every byte of the previous one"""
+    import torch
+    return (ref.to(torch.int32) * 3 + m + torch.arange(ref.numel(), dtype=torch.int32).reshape(ref.shape) % 7).to(torch.uint8)
+
+
+def _handoff_worker(rank, world, port, out_path):
+    import json
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S = _load_shard()
+    ref = torch.zeros((40, 56), dtype=torch.uint8)        # a (small) padded reference picture buffer
+    if S.minigop_owner(0, world) == rank:
+        ref = torch.full((40, 56), 9, dtype=torch.uint8)  # the key frame's reconstruction
+    log = []
+    for m in range(N_MINIGOPS):
+        got = S.handoff_reference(dist, ref, m, world, rank)       # no-op for everyone but producer and consumer
+        if S.minigop_owner(m, world) == rank:
+            log.append((m, bool(got)))
+            ref = _encode_minigop(ref, m)
+    last = S.minigop_owner(N_MINIGOPS - 1, world)
+    out = [None] * world
+    dist.all_gather_object(out, (log, int(ref.to(torch.int64).sum()) if rank == last else None))
+    if rank == 0:
+        with open(out_path, "w") as f:
+            json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reference_handoff_chain_gloo_world2(tmp_path):
+    import json
+    import torch
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "handoff.json")
+    mp.spawn(_handoff_worker, args=(2, port, out), nprocs=2, join=True)
+    got = json.load(open(out))
+    # serial run of the same chain
+    ref = torch.full((40, 56), 9, dtype=torch.uint8)
+    for m in range(N_MINIGOPS):
+        ref = _encode_minigop(ref, m)
+    want = int(ref.to(torch.int64).sum())
+    logs = {m: rcv for r in range(2) for (m, rcv) in got[r][0]}
+    assert sorted(logs) == list(range(N_MINIGOPS))                     # every mini-GOP encoded exactly once
+    assert logs[0] is False and all(logs[m] for m in range(1, N_MINIGOPS))   # all but the first waited for their reference
+    assert [r for r in range(2) if got[r][1] is not None] == [(N_MINIGOPS - 1) % 2] and got[(N_MINIGOPS - 1) % 2][1] == want
+
+
+def test_c_side_assignment_functions():
+    import ctypes as C
+    sys.path.insert(0, HERE)
+    import svt_testlib as T
+    lib = T.B.load()
+    buf = (C.c_int64 * 8)()
+    assert lib.svt_hip_gop_assign(C.c_int64(10), 4, 1, buf, 8) == 3 and list(buf[:3]) == [1, 5, 9]
+    assert lib.svt_hip_gop_assign(C.c_int64(10), 4, 4, buf, 8) < 0 and lib.svt_hip_gop_assign(C.c_int64(2), 8, 5, buf, 8) == 0
+    assert [lib.svt_hip_gop_owner(C.c_int64(g), 8) for g in (0, 7, 8, 19)] == [0, 7, 0, 3]
+    assert [lib.svt_hip_minigop_reference_source(C.c_int64(m), 8) for m in (0, 1, 8, 9)] == [-1, 0, 7, 0]
