@@ -713,58 +713,68 @@ SVT_DEV uint32_t me_tap4_x4(uint32_t a, uint32_t b, uint32_t d, uint32_t e) {
 #endif
 }
 
-/* half-pel planes B (x+1/2,y) and H (x,y+1/2) from the region; natural coordinates, guard ME_PL_G
- * (interpolate_search_region_avc, Codec/EbMotionEstimation.c:992-1070; C_DEFAULT/EbAvcStyleMcp_C.c:25-73).
- * One task = one dword (4 samples) of both planes: plane column px is region column px + 2 (ME_RGN_GX - ME_PL_G),
- * so the 7 region bytes a B dword needs sit in two aligned region dwords. */
-/* task = one dword of one plane row; the (row, dword) pair of a thread advances by 256 tasks per step without a
- * division (one division per thread up front), so every lane has work whatever the row length is */
-SVT_DEV void ph_interp_bh(const me_ctx_t *c, int tid, int W, int H) {
-    int       rs = c->L.region_stride, ps = c->L.plane_stride, pwd = (W + 2 * ME_PL_G + 3) >> 2, ph = H + 2 * ME_PL_G;
-    uint8_t  *B = c->planes, *Hh = c->planes + c->L.plane_bytes;
-    const int dpy = SVT_NT / pwd, dj = SVT_NT - dpy * pwd;
-    int       py = tid / pwd, j = tid - py * pwd;
-    while (py < ph) {
-        /* region row of this plane row: y = py - ME_PL_G -> region row ME_RGN_GY + y */
-        const uint8_t  *rr = c->region + ME_MUL(ME_RGN_GY - ME_PL_G + py, rs) + 4 * j;
-        const uint32_t *r0 = (const uint32_t *)rr;
-        uint32_t        lo = r0[0], hi = r0[1];
-        const uint32_t *ra = (const uint32_t *)(rr - rs), *rb = (const uint32_t *)(rr + rs), *rc = (const uint32_t *)(rr + 2 * rs);
+/* Half-pel planes (interpolate_search_region_avc, Codec/EbMotionEstimation.c:992-1070; C_DEFAULT/EbAvcStyleMcp_C.c:25-73), natural
+ * coordinates with a guard of ME_PL_G samples: B (x + 1/2, y) = 4-tap filter along the region row, H (x, y + 1/2) = the same filter
+ * down the region's columns, J (x + 1/2, y + 1/2) = the vertical filter over B, defined for y in [-1, H - 1].  Plane column px is
+ * region column px + 2 (ME_RGN_GX - ME_PL_G), so the 7 region bytes a B dword needs sit in two aligned region dwords. */
+/* ---- the three half-pel planes in ONE pass over column strips ----
+ * A thread owns one dword column of the planes and a run of rows, and walks DOWN the region: region row R (two aligned dwords)
+ * yields, in 16-bit lanes, the horizontal half-pel samples B(R - 1) and the samples the vertical filter needs from that row;
+ * a window of the last four rows then gives H(R - 3) (vertical filter of the region) and J(R - 3) (vertical filter of B)
+ * without re-reading anything: 2 LDS reads and 3 writes per output dword triple (a phase per plane pair needed 12 and 3, and
+ * permuted every operand again for H and J). */
+SVT_DEV uint32_t me_pair16(uint32_t hi, uint32_t lo, int k) { /* bytes k and k + 2 of the 8-byte pair, zero-extended into the two 16-bit lanes */
 #ifdef SVT_HOST_EMU
-        /* bytes b0..b7 = lo,hi; output k uses b[k+1..k+4] */
-        uint32_t t1 = svt_alignbyte(hi, lo, 1), t2 = svt_alignbyte(hi, lo, 2), t3 = svt_alignbyte(hi, lo, 3);
-        *(uint32_t *)(B + ME_MUL(py, ps) + 4 * j) = me_tap4_x4(t1, t2, t3, hi);
-        /* vertical: samples at region byte offset 4j+2 of rows y-1, y, y+1, y+2 */
-        uint32_t va = svt_alignbyte(ra[1], ra[0], 2), vc = svt_alignbyte(rb[1], rb[0], 2), vd = svt_alignbyte(rc[1], rc[0], 2);
-        *(uint32_t *)(Hh + ME_MUL(py, ps) + 4 * j) = me_tap4_x4(va, t2, vc, vd);
+    const uint64_t v = ((uint64_t)hi << 32) | lo;
+    return (uint32_t)((v >> (8 * k)) & 0xff) | ((uint32_t)((v >> (8 * (k + 2))) & 0xff) << 16);
 #else
-        /* the same, with every 16-bit-lane operand picked straight out of the dword pair by one v_perm_b32: P(k) = bytes
-         * (k, k+2) of b0..b7 zero-extended.  Horizontal taps of the even outputs are P1 P2 P3 P4, of the odd ones
-         * P2 P3 P4 P5; the vertical filter works on bytes 2..5 of each row = P2 (even) and P3 (odd). */
-#define ME_P(h, l, k) __builtin_amdgcn_perm(h, l, 0x0c000c00u | (uint32_t)(k) | ((uint32_t)((k) + 2) << 16))
-        const uint32_t p1 = ME_P(hi, lo, 1), p2 = ME_P(hi, lo, 2), p3 = ME_P(hi, lo, 3), p4 = ME_P(hi, lo, 4), p5 = ME_P(hi, lo, 5);
-        *(uint32_t *)(B + ME_MUL(py, ps) + 4 * j) = me_tap4_join(me_tap4_half(p1, p2, p3, p4), me_tap4_half(p2, p3, p4, p5));
-        const uint32_t a0 = ra[0], a1 = ra[1], b0 = rb[0], b1 = rb[1], c0 = rc[0], c1 = rc[1];
-        *(uint32_t *)(Hh + ME_MUL(py, ps) + 4 * j) = me_tap4_join(me_tap4_half(ME_P(a1, a0, 2), p2, ME_P(b1, b0, 2), ME_P(c1, c0, 2)),
-                                                                  me_tap4_half(ME_P(a1, a0, 3), p3, ME_P(b1, b0, 3), ME_P(c1, c0, 3)));
-#undef ME_P
+    return __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)k | ((uint32_t)(k + 2) << 16));
 #endif
-        j += dj; py += dpy;
-        if (j >= pwd) { j -= pwd; py++; }
-    }
 }
-/* J (x+1/2, y+1/2) = vertical filter over B; defined for y in [-1, H-1] (H + 1 rows) */
-SVT_DEV void ph_interp_j(const me_ctx_t *c, int tid, int W, int H) {
-    int       ps = c->L.plane_stride, pwd = (W + 2 * ME_PL_G + 3) >> 2;
-    uint8_t  *B = c->planes, *J = c->planes + 2 * c->L.plane_bytes;
-    const int dyy = SVT_NT / pwd, dj = SVT_NT - dyy * pwd, st = ps >> 2;
-    int       yy = tid / pwd, j = tid - yy * pwd;
-    while (yy < H + 1) {
-        const int       py = yy + ME_PL_G - 1; /* y = yy - 1 */
-        const uint32_t *b  = (const uint32_t *)(B + ME_MUL(py, ps) + 4 * j);
-        *(uint32_t *)(J + ME_MUL(py, ps) + 4 * j) = me_tap4_x4(b[-st], b[0], b[st], b[2 * st]);
-        j += dj; yy += dyy;
-        if (j >= pwd) { j -= pwd; yy++; }
+SVT_DEV uint32_t me_half_lanes(uint32_t r) { /* result of me_tap4_half -> its two samples in the two 16-bit lanes */
+#ifdef SVT_HOST_EMU
+    return r;
+#else
+    return __builtin_amdgcn_perm(0, r, 0x0c010c00u);
+#endif
+}
+SVT_DEV uint32_t me_half_join(uint32_t ev, uint32_t od) { /* even / odd results of me_tap4_half -> the four samples in order */
+#ifdef SVT_HOST_EMU
+    return (ev & 0xffu) | ((od & 0xffu) << 8) | (((ev >> 16) & 0xffu) << 16) | (((od >> 16) & 0xffu) << 24);
+#else
+    return me_tap4_join(ev, od);
+#endif
+}
+SVT_DEV void ph_interp_strips(const me_ctx_t *c, int tid, int W, int H) {
+    const int rs = c->L.region_stride, ps = c->L.plane_stride, pwd = (W + 2 * ME_PL_G + 3) >> 2, ph = H + 2 * ME_PL_G;
+    uint8_t  *B = c->planes, *Hh = c->planes + c->L.plane_bytes, *J = c->planes + 2 * c->L.plane_bytes;
+    const int nseg = SVT_NT / pwd, per = (ph + nseg - 1) / nseg;
+    const int seg = tid / pwd, j = tid - seg * pwd;
+    const int r0 = seg * per, r1 = r0 + per < ph ? r0 + per : ph;
+    if (seg >= nseg || r0 >= r1) return;
+    /* Plane row py (natural row py - ME_PL_G) takes: B(py) from region row py + 1 (horizontal filter along it); H(py) and J(py)
+     * from region rows py .. py + 3 -- H filters the rows themselves vertically, J the B rows derived from them (B(py - 1) ..
+     * B(py + 2)).  So the walk visits region rows r0 .. r1 + 2; row R completes the window of H(R - 3) / J(R - 3). */
+    uint32_t ve[4], vo[4], be[4], bo[4]; /* per window row: its samples for the vertical filter (even / odd), and the B row it yields */
+    _Pragma("unroll") for (int k = 0; k < 4; k++) { ve[k] = vo[k] = be[k] = bo[k] = 0; }
+    const uint8_t *col = c->region + 4 * j;
+    for (int R = r0; R < r1 + 3; R++) {
+        const uint32_t *rw = (const uint32_t *)(col + ME_MUL(R, rs));
+        const uint32_t  lo = rw[0], hi = rw[1];
+        /* P(k) = bytes (k, k + 2) of the row's 8 bytes in 16-bit lanes: horizontal taps of the even outputs are P1..P4, of the odd
+         * ones P2..P5; the vertical filter works on bytes 2..5 = P2 (even) and P3 (odd) */
+        const uint32_t  p1 = me_pair16(hi, lo, 1), p2 = me_pair16(hi, lo, 2), p3 = me_pair16(hi, lo, 3), p4 = me_pair16(hi, lo, 4), p5 = me_pair16(hi, lo, 5);
+        const uint32_t  he = me_tap4_half(p1, p2, p3, p4), ho = me_tap4_half(p2, p3, p4, p5);
+        const int       q = R - 1; /* the B row this region row yields */
+        if (q >= r0 && q < r1) *(uint32_t *)(B + ME_MUL(q, ps) + 4 * j) = me_half_join(he, ho);
+        _Pragma("unroll") for (int k = 0; k < 3; k++) { ve[k] = ve[k + 1]; vo[k] = vo[k + 1]; be[k] = be[k + 1]; bo[k] = bo[k + 1]; }
+        ve[3] = p2; vo[3] = p3; be[3] = me_half_lanes(he); bo[3] = me_half_lanes(ho);
+        const int py = R - 3;
+        if (py >= r0) {
+            *(uint32_t *)(Hh + ME_MUL(py, ps) + 4 * j) = me_half_join(me_tap4_half(ve[0], ve[1], ve[2], ve[3]), me_tap4_half(vo[0], vo[1], vo[2], vo[3]));
+            if (py >= 1 && py < H + 2) /* J exists for plane rows 1 .. H + 1 (natural rows -1 .. H - 1) */
+                *(uint32_t *)(J + ME_MUL(py, ps) + 4 * j) = me_half_join(me_tap4_half(be[0], be[1], be[2], be[3]), me_tap4_half(bo[0], bo[1], bo[2], bo[3]));
+        }
     }
 }
 
@@ -1837,8 +1847,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         const int need_planes = en32 || en16 || en8 || enq || (nlist == 2);
         ME_MARK(8);
         if (need_planes) {
-            ME_PHASE(ph_interp_bh(c, tid, W, H));
-            ME_PHASE(ph_interp_j(c, tid, W, H));
+            ME_PHASE(ph_interp_strips(c, tid, W, H));
         }
         ME_MARK(9);
         if (en32 || en16 || en8 || enq) {
