@@ -31,6 +31,7 @@
 #define SVT_ME_CORE_H
 
 #include <stdint.h>
+#include <string.h>
 #include "../../include/svtvp9_hip.h"
 
 #ifdef SVT_HOST_EMU
@@ -326,12 +327,15 @@ SVT_DEV void me_pu_geom(int pu, int *x, int *y, int *w) {
 #define SVT_GLOBAL __attribute__((address_space(1)))
 #endif
 #define SVT_AS_GLOBAL(T, p) ((T SVT_GLOBAL *)(uintptr_t)(p))
-SVT_DEV uint32_t me_ld32u_g(const uint8_t *p) { /* me_ld32u (below) for a global address */
-    const uint32_t                   sh = (uint32_t)((uintptr_t)p & 3);
-    const uint32_t SVT_GLOBAL *q  = SVT_AS_GLOBAL(const uint32_t, p - sh);
-    const uint32_t                   lo = q[0], hi = q[sh ? 1 : 0];
-    return svt_alignbyte(hi, lo, sh);
-}
+/* 32 bits from a global byte address of any alignment: ONE load.  Global (and scratch) accesses need no alignment on this
+ * target (the compiler emits a single global_load_dword for an align-1 dword; the texture unit splits the rare access that
+ * straddles a line) -- only LDS penalises misalignment, which is why me_ld32u below still assembles its dword from two. */
+#ifdef SVT_HOST_EMU
+SVT_DEV uint32_t me_ld32u_g(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+#else
+typedef uint32_t __attribute__((aligned(1))) me_u32_unaligned;
+SVT_DEV uint32_t me_ld32u_g(const uint8_t *p) { return *SVT_AS_GLOBAL(const me_u32_unaligned, p); }
+#endif
 SVT_DEV uint32_t me_ld32u(const uint8_t *p) {
     const uint32_t  sh = (uint32_t)((uintptr_t)p & 3);
     const uint32_t *q  = (const uint32_t *)(p - sh);
@@ -359,28 +363,20 @@ SVT_DEV int16_t me_clip_center(int origin, int16_t c, int pad, int pic_dim) {
     return c;
 }
 
-/* A rectangle of global memory whose rows all start at the same byte alignment (row stride a multiple of 4): one
- * uniform dword-aligned base (scalar registers -> the loads use the scalar-base addressing form and a 32-bit lane
- * offset, no 64-bit address arithmetic per lane) and one uniform byte shift.  ok = 0: the stride breaks the
- * assumption, callers fall back to me_ld32u on per-lane pointers. */
-typedef struct me_gsrc { const uint8_t *lo, *hi; uint32_t sh; int ok; } me_gsrc;
-SVT_DEV me_gsrc me_gsrc_of(const uint8_t *p, int stride) {
+/* A rectangle of global memory addressed as one uniform base (scalar registers -> the loads use the scalar-base addressing
+ * form with a 32-bit lane offset, no 64-bit address arithmetic per lane) plus byte offsets. */
+typedef struct me_gsrc { const uint8_t *base; } me_gsrc;
+SVT_DEV me_gsrc me_gsrc_of(const uint8_t *p) {
     me_gsrc   g;
     uintptr_t a = (uintptr_t)p;
-    uint32_t  sh = (uint32_t)(a & 3);
-    a -= sh;
 #ifndef SVT_HOST_EMU
     a  = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
-    sh = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh);
 #endif
-    g.lo = (const uint8_t *)a; g.hi = g.lo + (sh ? 4 : 0); /* an aligned rectangle re-reads its own dword: nothing beyond it is touched */
-    g.sh = sh; g.ok = (stride & 3) == 0;
+    g.base = (const uint8_t *)a;
     return g;
 }
-/* the 4 bytes at byte offset off (a multiple of 4 plus whole rows) of the rectangle */
-SVT_DEV uint32_t me_gld(const me_gsrc g, uint32_t off) {
-    return svt_alignbyte(*SVT_AS_GLOBAL(const uint32_t, g.hi + off), *SVT_AS_GLOBAL(const uint32_t, g.lo + off), g.sh);
-}
+/* the 4 bytes at byte offset off of the rectangle */
+SVT_DEV uint32_t me_gld(const me_gsrc g, uint32_t off) { return me_ld32u_g(g.base + off); }
 
 /* a plane descriptor read from LDS (or HBM) into scalar registers: every lane holds the same values, and with them in
  * SGPRs the address arithmetic built on them (clipping, me_pix, row offsets) runs on the scalar unit */
@@ -429,14 +425,14 @@ SVT_DEV void ph_load_rect(int tid, uint8_t *dst, int dst_stride, const uint8_t *
     const int nd = (w_bytes + 3) >> 2, n = nd * rows;
     const int dr = SVT_NT / nd, di = SVT_NT - dr * nd;
     int       r = tid / nd, i = tid - r * nd;
-    const me_gsrc g = me_gsrc_of(src, src_stride);
+    const me_gsrc g = me_gsrc_of(src);
     for (int t0 = tid; t0 < n; t0 += 8 * SVT_NT) {
         uint32_t v[8];
         int      o[8];
         _Pragma("unroll") for (int u = 0; u < 8; u++) {
             o[u] = -1;
             if (t0 + u * SVT_NT < n) {
-                v[u] = g.ok ? me_gld(g, (uint32_t)(ME_MUL(r, src_stride) + 4 * i)) : me_ld32u_g(src + (ptrdiff_t)r * src_stride + 4 * i);
+                v[u] = me_gld(g, (uint32_t)(ME_MUL(r, src_stride) + 4 * i));
                 o[u] = r * dst_stride + 4 * i;
             }
             i += di; r += dr;
@@ -487,7 +483,7 @@ SVT_DEV void ph_center_sads(const me_ctx_t *c, int tid, const svt_plane *ref, in
     uint32_t v[2][5], s[2];
     me_gsrc  g[5];
     _Pragma("unroll") for (int k = 0; k < 5; k++)
-        g[k] = me_gsrc_of(me_pix(ref, c->sb_x + dx[k < ncand ? k : 0], c->sb_y + dy[k < ncand ? k : 0]), ref->stride);
+        g[k] = me_gsrc_of(me_pix(ref, c->sb_x + dx[k < ncand ? k : 0], c->sb_y + dy[k < ncand ? k : 0]));
     const int rstride = ref->stride;
     /* every thread takes part in the wave reductions below; all (independent) global loads of both pieces are issued
      * before the first use: one memory round trip for the phase */
@@ -499,8 +495,7 @@ SVT_DEV void ph_center_sads(const me_ctx_t *c, int tid, const svt_plane *ref, in
             const int r = t / wd, i = t - r * wd;
             s[h] = *(const uint32_t *)(c->src + (2 * r) * ME_SB + 4 * i);
             _Pragma("unroll") for (int k = 0; k < 5; k++)
-                if (k < ncand) v[h][k] = g[k].ok ? me_gld(g[k], (uint32_t)(ME_MUL(2 * r, rstride) + 4 * i))
-                                                 : me_ld32u_g(me_pix(ref, c->sb_x + dx[k] + 4 * i, c->sb_y + dy[k] + 2 * r));
+                if (k < ncand) v[h][k] = me_gld(g[k], (uint32_t)(ME_MUL(2 * r, rstride) + 4 * i));
                 else v[h][k] = s[h];
         } else {
             _Pragma("unroll") for (int k = 0; k < 5; k++) v[h][k] = s[h];
