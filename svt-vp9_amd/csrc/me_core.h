@@ -336,6 +336,18 @@ SVT_DEV uint32_t me_ld32u_g(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); re
 typedef uint32_t __attribute__((aligned(1))) me_u32_unaligned;
 SVT_DEV uint32_t me_ld32u_g(const uint8_t *p) { return *SVT_AS_GLOBAL(const me_u32_unaligned, p); }
 #endif
+/* 8 / 16 bytes from a global byte address of any alignment: one global_load_dwordx2 / x4 */
+typedef struct me_u32x2 { uint32_t x, y; } me_u32x2;
+typedef struct me_u32x4 { uint32_t x, y, z, w; } me_u32x4;
+#ifdef SVT_HOST_EMU
+SVT_DEV me_u32x2 me_ld64u_g(const uint8_t *p) { me_u32x2 v; memcpy(&v, p, 8); return v; }
+SVT_DEV me_u32x4 me_ld128u_g(const uint8_t *p) { me_u32x4 v; memcpy(&v, p, 16); return v; }
+#else
+typedef uint32_t me_v2u __attribute__((ext_vector_type(2), aligned(1)));
+typedef uint32_t me_v4u __attribute__((ext_vector_type(4), aligned(1)));
+SVT_DEV me_u32x2 me_ld64u_g(const uint8_t *p) { const me_v2u t = *SVT_AS_GLOBAL(const me_v2u, p); me_u32x2 v = {t.x, t.y}; return v; }
+SVT_DEV me_u32x4 me_ld128u_g(const uint8_t *p) { const me_v4u t = *SVT_AS_GLOBAL(const me_v4u, p); me_u32x4 v = {t.x, t.y, t.z, t.w}; return v; }
+#endif
 SVT_DEV uint32_t me_ld32u(const uint8_t *p) {
     const uint32_t  sh = (uint32_t)((uintptr_t)p & 3);
     const uint32_t *q  = (const uint32_t *)(p - sh);
@@ -420,26 +432,43 @@ typedef struct me_ctx_t {
 
 /* copy a w_bytes x rows rectangle from global memory (any alignment) into LDS (dst 4-byte aligned rows) */
 SVT_DEV void ph_load_rect(int tid, uint8_t *dst, int dst_stride, const uint8_t *src, int src_stride, int w_bytes, int rows) {
-    /* task = one dword; a thread's (row, dword) pair advances by SVT_NT tasks per step without a division, and the
-     * global loads of 8 steps are all issued before the first LDS store (one memory round trip per 8 steps) */
-    const int nd = (w_bytes + 3) >> 2, n = nd * rows;
-    const int dr = SVT_NT / nd, di = SVT_NT - dr * nd;
-    int       r = tid / nd, i = tid - r * nd;
+    /* task = 16 bytes of a row: one global load (four times fewer memory instructions than dwords -- the texture unit's
+     * instruction rate, not bandwidth, is what these small rectangles cost), four LDS dword stores; the last unit of a row
+     * is shortened to whole dwords so that nothing beyond the rectangle's last dword is read or written.  A thread's
+     * (row, unit) pair advances by SVT_NT tasks per step without a division; the loads of two steps are issued before the
+     * first LDS store. */
+    const int nd = (w_bytes + 3) >> 2, nu = (nd + 3) >> 2, n = nu * rows;
+    const int dr = SVT_NT / nu, di = SVT_NT - dr * nu;
+    int       r = tid / nu, i = tid - r * nu;
     const me_gsrc g = me_gsrc_of(src);
-    for (int t0 = tid; t0 < n; t0 += 8 * SVT_NT) {
-        uint32_t v[8];
-        int      o[8];
-        _Pragma("unroll") for (int u = 0; u < 8; u++) {
-            o[u] = -1;
+    for (int t0 = tid; t0 < n; t0 += 2 * SVT_NT) {
+        me_u32x4 v[2];
+        int      o[2], k[2];
+        _Pragma("unroll") for (int u = 0; u < 2; u++) {
+            o[u] = -1; k[u] = 0;
             if (t0 + u * SVT_NT < n) {
-                v[u] = me_gld(g, (uint32_t)(ME_MUL(r, src_stride) + 4 * i));
-                o[u] = r * dst_stride + 4 * i;
+                const uint32_t goff = (uint32_t)(ME_MUL(r, src_stride) + 16 * i);
+                k[u] = nd - 4 * i < 4 ? nd - 4 * i : 4; /* dwords of this unit */
+                if (k[u] == 4) v[u] = me_ld128u_g(g.base + goff);
+                else {
+                    v[u].x = me_gld(g, goff);
+                    v[u].y = k[u] > 1 ? me_gld(g, goff + 4) : 0;
+                    v[u].z = k[u] > 2 ? me_gld(g, goff + 8) : 0;
+                    v[u].w = 0;
+                }
+                o[u] = r * dst_stride + 16 * i;
             }
             i += di; r += dr;
-            if (i >= nd) { i -= nd; r++; }
+            if (i >= nu) { i -= nu; r++; }
         }
-        _Pragma("unroll") for (int u = 0; u < 8; u++)
-            if (o[u] >= 0) *(uint32_t *)(dst + o[u]) = v[u];
+        _Pragma("unroll") for (int u = 0; u < 2; u++)
+            if (o[u] >= 0) {
+                uint32_t *d = (uint32_t *)(dst + o[u]);
+                d[0] = v[u].x;
+                if (k[u] > 1) d[1] = v[u].y;
+                if (k[u] > 2) d[2] = v[u].z;
+                if (k[u] > 3) d[3] = v[u].w;
+            }
     }
 }
 
@@ -477,33 +506,27 @@ SVT_DEV void ph_init(const me_ctx_t *c, int tid) {
  * global memory (test_search_area_bounds / check_zero_zero_center).  Each thread: one (row, 8-byte) piece.
  * Results accumulate in st->red[k]; caller doubles them. */
 SVT_DEV void ph_center_sads(const me_ctx_t *c, int tid, const svt_plane *ref, int ncand, const int16_t *dx, const int16_t *dy) {
-    int rows = c->sb_h >> 1, wd = c->sb_w >> 2; /* dwords per row */
-    int n = rows * wd;                           /* <= 512: two pieces per thread */
-    uint32_t acc[5] = {0, 0, 0, 0, 0};
-    uint32_t v[2][5], s[2];
-    me_gsrc  g[5];
-    _Pragma("unroll") for (int k = 0; k < 5; k++)
-        g[k] = me_gsrc_of(me_pix(ref, c->sb_x + dx[k < ncand ? k : 0], c->sb_y + dy[k < ncand ? k : 0]));
-    const int rstride = ref->stride;
-    /* every thread takes part in the wave reductions below; all (independent) global loads of both pieces are issued
-     * before the first use: one memory round trip for the phase */
-    _Pragma("unroll") for (int h = 0; h < 2; h++) {
-        const int t = tid + h * SVT_NT;
-        s[h] = 0;
-        _Pragma("unroll") for (int k = 0; k < 5; k++) v[h][k] = 0;
-        if (t < n) {
-            const int r = t / wd, i = t - r * wd;
-            s[h] = *(const uint32_t *)(c->src + (2 * r) * ME_SB + 4 * i);
-            _Pragma("unroll") for (int k = 0; k < 5; k++)
-                if (k < ncand) v[h][k] = me_gld(g[k], (uint32_t)(ME_MUL(2 * r, rstride) + 4 * i));
-                else v[h][k] = s[h];
-        } else {
-            _Pragma("unroll") for (int k = 0; k < 5; k++) v[h][k] = s[h];
+    const int rows = c->sb_h >> 1, wq = c->sb_w >> 3; /* 8-byte pieces per row (SB widths are multiples of 8) */
+    const int n = rows * wq;                          /* <= 256: one piece per thread */
+    uint32_t  acc[5] = {0, 0, 0, 0, 0};
+    me_u32x2  v[5], s = {0, 0};
+    /* every thread takes part in the wave reductions below; the (independent) global loads of all candidates are issued before
+     * the first use: one memory round trip for the phase, one 8-byte load per candidate and thread */
+    _Pragma("unroll") for (int k = 0; k < 5; k++) v[k] = s;
+    if (tid < n) {
+        const int r = tid / wq, i = tid - r * wq;
+        const uint32_t *sp = (const uint32_t *)(c->src + (2 * r) * ME_SB + 8 * i);
+        s.x = sp[0]; s.y = sp[1];
+        const int rstride = ref->stride;
+        _Pragma("unroll") for (int k = 0; k < 5; k++) {
+            if (k < ncand) {
+                const me_gsrc g = me_gsrc_of(me_pix(ref, c->sb_x + dx[k], c->sb_y + dy[k]));
+                v[k] = me_ld64u_g(g.base + (uint32_t)(ME_MUL(2 * r, rstride) + 8 * i));
+            } else v[k] = s;
         }
     }
-    _Pragma("unroll") for (int h = 0; h < 2; h++)
-        _Pragma("unroll") for (int k = 0; k < 5; k++)
-            if (k < ncand) acc[k] = svt_sad4(v[h][k], s[h], acc[k]);
+    _Pragma("unroll") for (int k = 0; k < 5; k++)
+        if (k < ncand) acc[k] = svt_sad4(v[k].y, s.y, svt_sad4(v[k].x, s.x, 0));
     _Pragma("unroll") for (int k = 0; k < 5; k++)
         if (k < ncand) svt_wave_add_u32(&c->st->red[k], acc[k], 1);
 }
