@@ -1308,30 +1308,46 @@ __device__ int g_me_stop_after = -1;
 SVT_DEV uint32_t me_magic_of(int d) { return (uint32_t)(0xffffffffu / (uint32_t)d) + 1u; }
 SVT_DEV int me_div_magic(int t, uint32_t inv) { return inv ? (int)(((uint64_t)(uint32_t)t * inv) >> 32) : t; }
 
-/* copy the windows [e0, e1) of a batch: flattened (window,row,dword) tasks, four global loads in flight per thread
- * before the LDS stores; ntask = total load tasks of the batch */
+/* copy the windows [e0, e1) of a batch: flattened (window, row, 16-byte unit) tasks -- one global load per unit (the last unit
+ * of a row is shortened to whole dwords), two units in flight per thread before the LDS stores; ntask = total load tasks */
+#define ME_HME_UNITS(nd) (((nd) + 3) >> 2)
 SVT_DEV void ph_hme_load_multi(const me_ctx_t *c, int tid, const svt_plane *ref_lds, const me_hme_win *wn, int e0, int e1, int ntask) {
     const svt_plane  ref_u = me_plane_uni(ref_lds);
     const svt_plane *ref = &ref_u;
     int      cur = -1;
     uint32_t inv = 0;
-    for (int t0 = tid; t0 < ntask; t0 += 4 * SVT_NT) {
-        uint32_t v[4];
-        int      dst[4];
-        _Pragma("unroll") for (int u = 0; u < 4; u++) {
+    for (int t0 = tid; t0 < ntask; t0 += 2 * SVT_NT) {
+        me_u32x4 v[2];
+        int      dst[2], k[2];
+        _Pragma("unroll") for (int u = 0; u < 2; u++) {
             int T = t0 + u * SVT_NT;
-            dst[u] = -1;
+            dst[u] = -1; k[u] = 0;
             if (T < ntask) {
                 int e = e0;
                 while (e + 1 < e1 && T >= wn[e + 1].tl) e++;
-                const int t = T - wn[e].tl, nd = wn[e].nd;
-                if (e != cur) { cur = e; inv = me_magic_of(nd); }
-                const int row = me_div_magic(t, inv), i = t - row * nd;
-                v[u]   = me_ld32u_g(me_pix(ref, wn[e].gx + 4 * i, wn[e].gy + row));
-                dst[u] = wn[e].off + row * wn[e].wstride + 4 * i;
+                const int t = T - wn[e].tl, nd = wn[e].nd, nu = ME_HME_UNITS(nd);
+                if (e != cur) { cur = e; inv = me_magic_of(nu); }
+                const int row = me_div_magic(t, inv), i = t - row * nu;
+                const uint8_t *gp = me_pix(ref, wn[e].gx + 16 * i, wn[e].gy + row);
+                k[u] = nd - 4 * i < 4 ? nd - 4 * i : 4;
+                if (k[u] == 4) v[u] = me_ld128u_g(gp);
+                else {
+                    v[u].x = me_ld32u_g(gp);
+                    v[u].y = k[u] > 1 ? me_ld32u_g(gp + 4) : 0;
+                    v[u].z = k[u] > 2 ? me_ld32u_g(gp + 8) : 0;
+                    v[u].w = 0;
+                }
+                dst[u] = wn[e].off + row * wn[e].wstride + 16 * i;
             }
         }
-        _Pragma("unroll") for (int u = 0; u < 4; u++) if (dst[u] >= 0) *(uint32_t *)(c->planes + dst[u]) = v[u];
+        _Pragma("unroll") for (int u = 0; u < 2; u++)
+            if (dst[u] >= 0) {
+                uint32_t *d = (uint32_t *)(c->planes + dst[u]);
+                d[0] = v[u].x;
+                if (k[u] > 1) d[1] = v[u].y;
+                if (k[u] > 2) d[2] = v[u].z;
+                if (k[u] > 3) d[3] = v[u].w;
+            }
     }
 }
 
@@ -1553,7 +1569,7 @@ SVT_DEV void me_hme_plan_level(const me_ctx_t *c, int list, int lvl, int16_t xsc
             me_hme_win *wn = &st->hme_win[ne++];
             wn->off = bytes; wn->wstride = ws; wn->nd = (wbytes + 3) >> 2; wn->rows = nr + span; wn->sw = w; wn->sh = nr;
             wn->gx = g.ox + ox; wn->gy = g.oy + oy + y; wn->slot = k; wn->y0 = y; wn->tl = tl; wn->ts = ts;
-            tl += wn->nd * wn->rows; ts += ng * nr;
+            tl += ME_HME_UNITS(wn->nd) * wn->rows; ts += ng * nr;
             bytes += ws * (nr + span); y += nr;
         }
     }
@@ -1716,7 +1732,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                     for (int b = 0; b < nbatch; b++) {
                         const int         e0 = ME_UNI(st->hme_bstart[b]), e1 = ME_UNI(st->hme_bstart[b + 1]);
                         const me_hme_win *wl = &st->hme_win[e1 - 1];
-                        const int         ntl = ME_UNI(wl->tl + wl->nd * wl->rows);
+                        const int         ntl = ME_UNI(wl->tl + ME_HME_UNITS(wl->nd) * wl->rows);
                         const int         nts = ME_UNI(wl->ts + ((g.bw & 3) == 0 ? (wl->sw + 3) >> 2 : wl->sw) * wl->sh);
                         int               slot_mask = 0;
                         for (int e = e0; e < e1; e++) slot_mask |= 1 << st->hme_win[e].slot;
