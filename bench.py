@@ -293,26 +293,27 @@ def main():
         k_ = load.index(min(load))
         me_slot[li] = k_
         load[k_] += me_launches[li][0]
-    me_ev = []   # (start, stop) HIP events bracketing the launches each ME stream got in a timed step, recorded on that stream
-    # (events around every single launch would be the literal reading of "per-launch duration", but an event record between
-    # two launches of a stream costs the overlap between the ME streams: ME alone 4.46 instead of 2.26 ms per step, measured)
-    first_of = {k_: min(li for li in range(len(me_launches)) if me_slot[li] == k_) for k_ in set(me_slot)}
-    last_of = {k_: max(li for li in range(len(me_launches)) if me_slot[li] == k_) for k_ in set(me_slot)}
+    # per-launch durations of the dominant kernel: a (start, stop) HIP event pair around EVERY timed ME launch, recorded on the
+    # stream the launch goes to.  The events come from a pool created before the timed region: creating an event costs the host
+    # tens of microseconds, and ten creations per step in the launch path cost the overlap of the two ME streams (ME alone 4.46
+    # instead of 2.26 ms per step, measured); recording an existing event costs nothing measurable.
+    me_ev = []
+    me_pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * len(me_launches) * (args.steps + 1))]
+    for e_ in me_pool:
+        e_.record(me_streams[0])   # an event object is created on its first record
 
     def run_me(record=False):
         for st_ in me_streams[1:]:
             st_.wait_stream(me_streams[0])
-        open_ev = {}
         for li, (n, cur, r0, r1, p, res) in enumerate(me_launches):
             k_ = me_slot[li]
-            if record and first_of[k_] == li:
-                open_ev[k_] = torch.cuda.Event(enable_timing=True)
-                open_ev[k_].record(me_streams[k_])
+            if record:
+                e0, e1 = me_pool.pop(), me_pool.pop()
+                e0.record(me_streams[k_])
             B.check(lib.svt_hip_me_batch_device(me_ctxs[k_], n, cur, r0, r1, C.byref(p), res, None))
-            if record and last_of[k_] == li:
-                e1 = torch.cuda.Event(enable_timing=True)
+            if record:
                 e1.record(me_streams[k_])
-                me_ev.append((open_ev[k_], e1))
+                me_ev.append((e0, e1))
         for st_ in me_streams[1:]:
             me_streams[0].wait_stream(st_)
 
@@ -561,8 +562,8 @@ def main():
     stage_ms = {s: 0.0 for s in STAGES}
     for name, e0, e1 in ev:
         stage_ms[name] += e0.elapsed_time(e1) / args.steps
-    me_launch_ms = sum(e0.elapsed_time(e1) for e0, e1 in me_ev)   # sum over the ME streams of the time each spent in its launches
-    n_me_launch = max(1, len(me_launches) * args.steps)
+    me_launch_ms = sum(e0.elapsed_time(e1) for e0, e1 in me_ev)   # sum of the individual launch durations (the two ME streams overlap)
+    n_me_launch = max(1, len(me_ev))
     L = Wd * Hd
     inter = np.concatenate([(m["ref_list"][..., 0] >= 0).ravel() for m in mi_list])
     comp = np.concatenate([(m["ref_list"][..., 1] >= 0).ravel() for m in mi_list])
@@ -634,8 +635,7 @@ def main():
                      "algorithmic_bytes_per_launch": int(stage_bytes["me"] / len(me_launches)),
                      "stream_span": {"kernel_ms_per_step": round(me_ms, 3), "GB_per_s": round(stage_bytes["me"] / (me_ms * 1e-3) / 1e9, 2),
                                      "frac": round(stage_bytes["me"] / (me_ms * 1e-3) / 8e12, 5),
-                                     "note": f"{n_me_streams} ME streams run launches concurrently: each launch's own duration is stretched; "
-                                             "avg_launch_ms = (time the ME streams spent inside their launches, events on those streams) / launches"},
+                                     "note": f"{n_me_streams} ME streams run launches concurrently: each launch's own duration is stretched"},
                      "valu": valu},
         "kernels": {kernel_of[s]: {"ms_per_step": round(stage_ms[s], 3), "algorithmic_bytes_per_step": stage_bytes[s],
                                    "GB_per_s": round(stage_bytes[s] / (max(stage_ms[s], 1e-9) * 1e-3) / 1e9, 2),
