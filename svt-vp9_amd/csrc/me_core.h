@@ -764,35 +764,40 @@ SVT_DEV uint32_t me_half_join(uint32_t ev, uint32_t od) { /* even / odd results 
 #endif
 }
 SVT_DEV void ph_interp_strips(const me_ctx_t *c, int tid, int W, int H) {
-    const int rs = c->L.region_stride, ps = c->L.plane_stride, pwd = (W + 2 * ME_PL_G + 3) >> 2, ph = H + 2 * ME_PL_G;
-    uint8_t  *B = c->planes, *Hh = c->planes + c->L.plane_bytes, *J = c->planes + 2 * c->L.plane_bytes;
+    const int rs = c->L.region_stride, ps = c->L.plane_stride, pb = c->L.plane_bytes, pwd = (W + 2 * ME_PL_G + 3) >> 2, ph = H + 2 * ME_PL_G;
     const int nseg = SVT_NT / pwd, per = (ph + nseg - 1) / nseg;
     const int seg = tid / pwd, j = tid - seg * pwd;
-    const int r0 = seg * per, r1 = r0 + per < ph ? r0 + per : ph;
-    if (seg >= nseg || r0 >= r1) return;
+    const int r0 = ME_MUL(seg, per), cnt = r0 + per < ph ? per : ph - r0; /* this strip: plane rows r0 .. r0 + cnt - 1 */
+    if (seg >= nseg || cnt <= 0) return;
     /* Plane row py (natural row py - ME_PL_G) takes: B(py) from region row py + 1 (horizontal filter along it); H(py) and J(py)
      * from region rows py .. py + 3 -- H filters the rows themselves vertically, J the B rows derived from them (B(py - 1) ..
-     * B(py + 2)).  So the walk visits region rows r0 .. r1 + 2; row R completes the window of H(R - 3) / J(R - 3). */
+     * B(py + 2)).  Step i of the walk reads region row r0 + i (i = 0 .. cnt + 2), stores B(r0 + i - 1) and completes the window
+     * of H / J(r0 + i - 3).  The window is a ring of four slots indexed by i & 3; the walk is unrolled by four so that every slot
+     * is a named register (no moves) and the row offsets are immediates where the strides are. */
     uint32_t ve[4], vo[4], be[4], bo[4]; /* per window row: its samples for the vertical filter (even / odd), and the B row it yields */
     _Pragma("unroll") for (int k = 0; k < 4; k++) { ve[k] = vo[k] = be[k] = bo[k] = 0; }
-    const uint8_t *col = c->region + 4 * j;
-    for (int R = r0; R < r1 + 3; R++) {
-        const uint32_t *rw = (const uint32_t *)(col + ME_MUL(R, rs));
-        const uint32_t  lo = rw[0], hi = rw[1];
-        /* P(k) = bytes (k, k + 2) of the row's 8 bytes in 16-bit lanes: horizontal taps of the even outputs are P1..P4, of the odd
-         * ones P2..P5; the vertical filter works on bytes 2..5 = P2 (even) and P3 (odd) */
-        const uint32_t  p1 = me_pair16(hi, lo, 1), p2 = me_pair16(hi, lo, 2), p3 = me_pair16(hi, lo, 3), p4 = me_pair16(hi, lo, 4), p5 = me_pair16(hi, lo, 5);
-        const uint32_t  he = me_tap4_half(p1, p2, p3, p4), ho = me_tap4_half(p2, p3, p4, p5);
-        const int       q = R - 1; /* the B row this region row yields */
-        if (q >= r0 && q < r1) *(uint32_t *)(B + ME_MUL(q, ps) + 4 * j) = me_half_join(he, ho);
-        _Pragma("unroll") for (int k = 0; k < 3; k++) { ve[k] = ve[k + 1]; vo[k] = vo[k + 1]; be[k] = be[k + 1]; bo[k] = bo[k + 1]; }
-        ve[3] = p2; vo[3] = p3; be[3] = me_half_lanes(he); bo[3] = me_half_lanes(ho);
-        const int py = R - 3;
-        if (py >= r0) {
-            *(uint32_t *)(Hh + ME_MUL(py, ps) + 4 * j) = me_half_join(me_tap4_half(ve[0], ve[1], ve[2], ve[3]), me_tap4_half(vo[0], vo[1], vo[2], vo[3]));
-            if (py >= 1 && py < H + 2) /* J exists for plane rows 1 .. H + 1 (natural rows -1 .. H - 1) */
-                *(uint32_t *)(J + ME_MUL(py, ps) + 4 * j) = me_half_join(me_tap4_half(be[0], be[1], be[2], be[3]), me_tap4_half(bo[0], bo[1], bo[2], bo[3]));
+    const uint8_t *rp = c->region + 4 * j + ME_MUL(r0, rs);      /* region row r0 + i0 */
+    uint8_t       *wp = c->planes + 4 * j + ME_MUL(r0 - 3, ps);  /* plane row r0 + i0 - 3 of B (H, J: + pb, + 2 pb) */
+    const int      jlo = 4 - r0, jhi = H + 5 - r0;               /* J exists for plane rows 1 .. H + 1: i in [jlo, jhi) */
+    for (int i0 = 0; i0 < per + 3; i0 += 4) {                    /* same trip count in every lane; the stores carry the lane's bounds */
+        _Pragma("unroll") for (int u = 0; u < 4; u++) {
+            const int       i = i0 + u;
+            const uint32_t *rw = (const uint32_t *)(rp + u * rs);
+            const uint32_t  lo = rw[0], hi = rw[1];
+            /* P(k) = bytes (k, k + 2) of the row's 8 bytes in 16-bit lanes: horizontal taps of the even outputs are P1..P4, of the
+             * odd ones P2..P5; the vertical filter works on bytes 2..5 = P2 (even) and P3 (odd) */
+            const uint32_t  p1 = me_pair16(hi, lo, 1), p2 = me_pair16(hi, lo, 2), p3 = me_pair16(hi, lo, 3), p4 = me_pair16(hi, lo, 4), p5 = me_pair16(hi, lo, 5);
+            const uint32_t  he = me_tap4_half(p1, p2, p3, p4), ho = me_tap4_half(p2, p3, p4, p5);
+            if (i >= 1 && i <= cnt) *(uint32_t *)(wp + (u + 2) * ps) = me_half_join(he, ho);
+            ve[u] = p2; vo[u] = p3; be[u] = me_half_lanes(he); bo[u] = me_half_lanes(ho);
+            if (i >= 3 && i < cnt + 3) {
+                const int o = (u + 1) & 3, a = (u + 2) & 3, b = (u + 3) & 3; /* oldest .. newest = o, a, b, u */
+                *(uint32_t *)(wp + u * ps + pb) = me_half_join(me_tap4_half(ve[o], ve[a], ve[b], ve[u]), me_tap4_half(vo[o], vo[a], vo[b], vo[u]));
+                if (i >= jlo && i < jhi)
+                    *(uint32_t *)(wp + u * ps + 2 * pb) = me_half_join(me_tap4_half(be[o], be[a], be[b], be[u]), me_tap4_half(bo[o], bo[a], bo[b], bo[u]));
+            }
         }
+        rp += 4 * rs; wp += 4 * ps;
     }
 }
 

@@ -7,7 +7,7 @@
 #include "../../include/svtvp9_hip.h"
 
 #define SVT_CTX_SLOTS 40
-#define SVT_CTX_RING 16
+#define SVT_CTX_RING 64
 
 struct svt_hip_ctx {
     int         device;
