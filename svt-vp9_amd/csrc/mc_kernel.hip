@@ -75,9 +75,14 @@ __device__ __forceinline__ void mc_tile(const uint8_t *plane, int stride, int x,
      * vertical phase in the wave the 7 extra rows are neither fetched nor filtered, without a horizontal phase the taps
      * are skipped.  Branches on ballots: every lane of the wave takes the same side. */
     const bool any_sx = __builtin_amdgcn_ballot_w64(sx != 0) != 0, any_sy = __builtin_amdgcn_ballot_w64(sy != 0) != 0;
+    /* all row loads first (up to 15 x 16 bytes in flight per lane): the kernel is bound by the latency of these loads, not by
+     * their bandwidth or by the filter arithmetic */
+    u32x4a4 rows[NM];
+    _Pragma("unroll") for (int r = 0; r < NM; r++)
+        if (any_sy || (r >= 3 && r < 3 + NR)) rows[r] = *MC_AS_GLOBAL(const u32x4a4, p0 + (ptrdiff_t)r * stride);
     _Pragma("unroll") for (int r = 0; r < NM; r++) {
         if (!any_sy && (r < 3 || r >= 3 + NR)) { mid[r] = 0; continue; }
-        const u32x4a4 d = *MC_AS_GLOBAL(const u32x4a4, p0 + (ptrdiff_t)r * stride);
+        const u32x4a4 d = rows[r];
         /* bytes 0..11 of the row window (sample x - 3 first) */
         const uint32_t e0 = alignbyte(d.y, d.x, sh), e1 = alignbyte(d.z, d.y, sh), e2 = alignbyte(d.w, d.z, sh);
         if (!any_sx) { mid[r] = alignbyte(e1, e0, 3); continue; }

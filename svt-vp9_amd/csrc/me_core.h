@@ -635,6 +635,96 @@ SVT_DEV void ph_fullpel_sad8(const me_ctx_t *c, int tid, uint32_t *U, int sw, in
     }
 }
 
+/* full-pel, search areas whose width is a multiple of 8 (no tail path) with at most 4096 positions: SADs, the nested sums and
+ * the per-PU arg-min in ONE phase without the table.  Lane = 8x8 block in z-order, so a DPP quad is a 16x16 PU, a DPP row of
+ * 16 lanes a 32x32 PU and the wave the 64x64 PU; the four waves take the groups of 4 positions round-robin.  A lane keeps one
+ * running minimum per level as a 32-bit key -- (sad << 16) | position for 8x8 / 16x16 (sums < 2^16), (sad << 12) | position
+ * for 32x32 / 64x64 -- and the waves meet in the same 64-bit LDS minimum as ph_fullpel_argmin: unsigned min = the
+ * reference's first minimum in raster order. */
+SVT_DEV void ph_fullpel_fused(const me_ctx_t *c, int tid, int sw, int sh) {
+    const int rs = c->L.region_stride;
+#ifdef SVT_HOST_EMU
+    if (tid != 0) return;
+    for (int y = 0; y < sh; y++)
+        for (int x = 0; x < sw; x++) {
+            uint32_t s8[64], s16[16], s32[4] = {0, 0, 0, 0}, s64 = 0;
+            for (int z = 0; z < 64; z++) {
+                const int bx = ((z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4)) * 8, by = (((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4)) * 8;
+                uint32_t  a = 0;
+                for (int r = 0; r < 8; r += 2)
+                    for (int i = 0; i < 8; i++) {
+                        const int d = (int)c->src[(by + r) * ME_SB + bx + i] - (int)c->region[(ME_RGN_GY + y + by + r) * rs + ME_RGN_GX + x + bx + i];
+                        a += (uint32_t)(d < 0 ? -d : d);
+                    }
+                s8[z] = a;
+            }
+            for (int i = 0; i < 16; i++) s16[i] = (uint16_t)(s8[4 * i] + s8[4 * i + 1] + s8[4 * i + 2] + s8[4 * i + 3]);
+            for (int i = 0; i < 16; i++) { s32[i >> 2] += s16[i]; s64 += s16[i]; }
+            const uint32_t pos = (uint32_t)(y * sw + x);
+            svt_lds_min_u64(&c->st->key[0], ((uint64_t)(2u * s64) << 32) | pos);
+            for (int i = 0; i < 4; i++) svt_lds_min_u64(&c->st->key[1 + i], ((uint64_t)(2u * s32[i]) << 32) | pos);
+            for (int i = 0; i < 16; i++) svt_lds_min_u64(&c->st->key[5 + i], ((uint64_t)(2u * s16[i]) << 32) | pos);
+            for (int i = 0; i < 64; i++) svt_lds_min_u64(&c->st->key[21 + i], ((uint64_t)(2u * s8[i]) << 32) | pos);
+        }
+#else
+    const int z = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bx = ((z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4)) * 8, by = (((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4)) * 8;
+    uint32_t  s0[4], s1[4]; /* rows 0, 2, 4, 6 of the source block */
+    _Pragma("unroll") for (int r = 0; r < 4; r++) {
+        const uint32_t *s = (const uint32_t *)(c->src + (by + 2 * r) * ME_SB + bx);
+        s0[r] = s[0]; s1[r] = s[1];
+    }
+    const uint8_t *rbase = c->region + ME_MUL(ME_RGN_GY + by, rs) + ME_RGN_GX + bx;
+    const int      ng = sw >> 2;
+    uint32_t       b8 = 0xffffffffu, b16 = 0xffffffffu, b32 = 0xffffffffu, b64 = 0xffffffffu;
+#define FP_MIN3(b, x, y) do { const uint32_t m_ = (x) < (y) ? (x) : (y); (b) = (b) < m_ ? (b) : m_; } while (0)
+#define FP_DPP(v, ctrl, rows) ((v) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rows), 0xf, false))
+    int y = 0, g = w; /* group q = y * ng + g, q = w, w + 4, ... (wave-uniform) */
+    while (g >= ng) { g -= ng; y++; }
+    while (y < sh) {
+        const uint8_t *rp = rbase + (y * rs + 4 * g); /* wave-uniform offset: scalar arithmetic */
+        uint64_t       acc = 0;
+        _Pragma("unroll") for (int r = 0; r < 4; r++) {
+            const uint32_t *q = (const uint32_t *)(rp + 2 * r * rs);
+            const uint32_t  d0 = q[0], d1 = q[1], d2 = q[2];
+            acc = svt_qsad(((uint64_t)d1 << 32) | d0, s0[r], acc);
+            acc = svt_qsad(((uint64_t)d2 << 32) | d1, s1[r], acc);
+        }
+        const uint32_t pos = (uint32_t)(y * sw + 4 * g);
+        uint32_t       lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32); /* positions pos, pos + 1 | pos + 2, pos + 3 as 16-bit sums */
+        FP_MIN3(b8, (lo << 16) | pos, (lo & 0xffff0000u) | (pos + 1));
+        FP_MIN3(b8, (hi << 16) | (pos + 2), (hi & 0xffff0000u) | (pos + 3));
+        /* 16x16: the quad's four blocks (sums stay below 2^16: no carry between the halves) */
+        lo = FP_DPP(lo, 0xB1, 0xf); hi = FP_DPP(hi, 0xB1, 0xf); /* quad_perm:[1,0,3,2] */
+        lo = FP_DPP(lo, 0x4E, 0xf); hi = FP_DPP(hi, 0x4E, 0xf); /* quad_perm:[2,3,0,1] */
+        FP_MIN3(b16, (lo << 16) | pos, (lo & 0xffff0000u) | (pos + 1));
+        FP_MIN3(b16, (hi << 16) | (pos + 2), (hi & 0xffff0000u) | (pos + 3));
+        /* 32x32: two quads still fit 16 bits, the four of the row need 32 */
+        lo = FP_DPP(lo, 0x124, 0xf); hi = FP_DPP(hi, 0x124, 0xf); /* row_ror:4 */
+        uint32_t a0 = lo & 0xffffu, a1 = lo >> 16, a2 = hi & 0xffffu, a3 = hi >> 16;
+        a0 = FP_DPP(a0, 0x128, 0xf); a1 = FP_DPP(a1, 0x128, 0xf); a2 = FP_DPP(a2, 0x128, 0xf); a3 = FP_DPP(a3, 0x128, 0xf); /* row_ror:8 */
+        FP_MIN3(b32, (a0 << 12) | pos, (a1 << 12) | (pos + 1));
+        FP_MIN3(b32, (a2 << 12) | (pos + 2), (a3 << 12) | (pos + 3));
+        /* 64x64: row 1 += row 0, row 3 += row 2 (row_bcast:15), then row 3 += row 1 (row_bcast:31): complete in lanes 48..63 */
+        a0 = FP_DPP(a0, 0x142, 0xa); a1 = FP_DPP(a1, 0x142, 0xa); a2 = FP_DPP(a2, 0x142, 0xa); a3 = FP_DPP(a3, 0x142, 0xa);
+        a0 = FP_DPP(a0, 0x143, 0xc); a1 = FP_DPP(a1, 0x143, 0xc); a2 = FP_DPP(a2, 0x143, 0xc); a3 = FP_DPP(a3, 0x143, 0xc);
+        FP_MIN3(b64, (a0 << 12) | pos, (a1 << 12) | (pos + 1));
+        FP_MIN3(b64, (a2 << 12) | (pos + 2), (a3 << 12) | (pos + 3));
+        g += 4;
+        while (g >= ng) { g -= ng; y++; }
+    }
+#undef FP_MIN3
+#undef FP_DPP
+    uint64_t *key = c->st->key;
+    if (b8 != 0xffffffffu) { /* this wave took at least one group */
+        svt_lds_min_u64(&key[21 + z], ((uint64_t)((b8 >> 16) << 1) << 32) | (b8 & 0xffffu));
+        if ((z & 3) == 0) svt_lds_min_u64(&key[5 + (z >> 2)], ((uint64_t)((b16 >> 16) << 1) << 32) | (b16 & 0xffffu));
+        if ((z & 15) == 0) svt_lds_min_u64(&key[1 + (z >> 4)], ((uint64_t)((b32 >> 12) << 1) << 32) | (b32 & 0xfffu));
+        if (z == 63) svt_lds_min_u64(&key[0], ((uint64_t)((b64 >> 12) << 1) << 32) | (b64 & 0xfffu));
+    }
+#endif
+}
+
 /* full-pel: 16x16 sums of every position of the chunk.  In the 8-point path (x < w8) the reference keeps this sum
  * in uint16 (C_DEFAULT/EbComputeSAD_C.c:201,276), in the tail path in 32 bits. */
 SVT_DEV void ph_fullpel_sum16(const me_ctx_t *c, int tid, uint32_t *U, int sw, int ny, int w8) {
@@ -1823,6 +1913,11 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
             if (rows_chunk < 1) rows_chunk = 1;
             if (rows_chunk > sah) rows_chunk = sah;
             uint32_t *U = (uint32_t *)c->planes;
+            if ((saw & 7) == 0 && saw * sah <= 4096) {
+                ME_PHASE(ph_fullpel_fused(c, tid, saw, sah));
+                ME_MARK(5);
+                ME_MARK(6);
+            } else
             for (int y0 = 0; y0 < sah; y0 += rows_chunk) {
                 int ny = y0 + rows_chunk <= sah ? rows_chunk : sah - y0;
                 ME_PHASE(ph_fullpel_sad8(c, tid, U, saw, y0, ny, w8));
