@@ -25,6 +25,21 @@ struct pa_job {
 
 constexpr int PA_ROWS = 4; /* destination rows per workgroup */
 
+typedef uint32_t pa_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t pa_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+
+/* 4 destination bytes whose sources lie inside the picture: `s` = address of the first source byte, consecutive destination
+ * bytes are `step` source bytes apart.  Global loads need no alignment on gfx950: one load per destination dword. */
+__device__ __forceinline__ uint32_t pa_dword_inside(const uint8_t PA_GLOBAL *s, int step) {
+    if (step == 1) return *(const uint32_t PA_GLOBAL *)s;
+    if (step == 2) {
+        const pa_u32x2 d = *(const pa_u32x2 PA_GLOBAL *)s;
+        return __builtin_amdgcn_perm(d.y, d.x, 0x06040200u);
+    }
+    const pa_u32x4 d = *(const pa_u32x4 PA_GLOBAL *)s; /* step 4: bytes 0, 4, 8, 12 */
+    return __builtin_amdgcn_perm(d.y, d.x, 0x0c0c0400u) | __builtin_amdgcn_perm(d.w, d.z, 0x04000c0cu);
+}
+
 __global__ __launch_bounds__(256) void svt_pa_plane_kernel(const pa_job *__restrict__ jobs, int n_jobs) {
     /* find the job of this workgroup row (a handful of jobs: linear scan) */
     int j = 0;
@@ -32,29 +47,38 @@ __global__ __launch_bounds__(256) void svt_pa_plane_kernel(const pa_job *__restr
     const pa_job J = jobs[j];
     const int tw = J.dw + 2 * J.pad_x, th = J.dh + 2 * J.pad_y; /* padded size */
     const int py0 = ((int)blockIdx.x - J.row0) * PA_ROWS;
-    const int nq = (tw + 3) >> 2; /* dwords per destination row */
-    for (int t = threadIdx.x; t < nq * PA_ROWS; t += 256) {
-        const int r = t / nq, q = t - r * nq, py = py0 + r;
+    const int nu = (tw + 15) >> 4; /* 16-byte units per destination row: a thread produces one */
+    for (int t = threadIdx.x; t < nu * PA_ROWS; t += 256) {
+        const int r = t / nu, u = t - r * nu, py = py0 + r;
         if (py >= th) break;
         int sy = py - J.pad_y;
         sy = sy < 0 ? 0 : sy > J.dh - 1 ? J.dh - 1 : sy;
         const uint8_t PA_GLOBAL *srow = PA_AS_GLOBAL(const uint8_t, J.src + (size_t)(sy * J.step) * J.sstride);
-        uint8_t PA_GLOBAL       *drow = PA_AS_GLOBAL(uint8_t, J.dst + (size_t)py * J.dstride + 4 * q);
-        const int      px0 = 4 * q - J.pad_x;
-        uint32_t       w;
-        if (J.step == 1 && px0 >= 0 && px0 + 3 < J.dw && ((((uintptr_t)srow + px0) & 3) == 0)) {
-            w = *(const uint32_t PA_GLOBAL *)(srow + px0); /* interior of the full-resolution plane: aligned dword copy */
-        } else {
-            w = 0;
-            _Pragma("unroll") for (int b = 0; b < 4; b++) {
-                int sx = px0 + b;
-                sx = sx < 0 ? 0 : sx > J.dw - 1 ? J.dw - 1 : sx;
-                w |= (uint32_t)srow[sx * J.step] << (8 * b);
+        uint8_t PA_GLOBAL       *drow = PA_AS_GLOBAL(uint8_t, J.dst + (size_t)py * J.dstride + 16 * u);
+        const int      px0 = 16 * u - J.pad_x;
+        uint32_t       w[4];
+        if (px0 >= 0 && px0 + 15 < J.dw) { /* interior */
+            if (J.step == 1) {
+                const pa_u32x4 d = *(const pa_u32x4 PA_GLOBAL *)(srow + px0);
+                w[0] = d.x; w[1] = d.y; w[2] = d.z; w[3] = d.w;
+            } else {
+                _Pragma("unroll") for (int k = 0; k < 4; k++) w[k] = pa_dword_inside(srow + (px0 + 4 * k) * J.step, J.step);
+            }
+        } else { /* the replicated borders */
+            _Pragma("unroll") for (int k = 0; k < 4; k++) {
+                w[k] = 0;
+                _Pragma("unroll") for (int b = 0; b < 4; b++) {
+                    int sx = px0 + 4 * k + b;
+                    sx = sx < 0 ? 0 : sx > J.dw - 1 ? J.dw - 1 : sx;
+                    w[k] |= (uint32_t)srow[sx * J.step] << (8 * b);
+                }
             }
         }
-        if (4 * q + 3 < tw && (((uintptr_t)drow) & 3) == 0) *(uint32_t PA_GLOBAL *)drow = w;
-        else
-            for (int b = 0; b < 4 && 4 * q + b < tw; b++) drow[b] = (uint8_t)(w >> (8 * b));
+        if (16 * u + 15 < tw) {
+            pa_u32x4 o; o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+            *(pa_u32x4 PA_GLOBAL *)drow = o;
+        } else
+            for (int b = 0; b < 16 && 16 * u + b < tw; b++) drow[b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
     }
 }
 } // namespace
