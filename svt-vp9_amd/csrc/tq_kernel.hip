@@ -577,6 +577,8 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
 /* persistent grid: a multiple of 8 workgroups (one walk per XCD, tq_walk_of), at most `per_cu` per compute unit */
 int tq_grid(svt_hip_ctx *ctx, int ngroups, int per_cu) {
     const int cus = ctx->cu_count;
+    static const int per_cu_env = getenv("SVT_HIP_TQ_PER_CU") ? atoi(getenv("SVT_HIP_TQ_PER_CU")) : 0;
+    if (per_cu_env > 0) per_cu = per_cu_env;
     const int per_xcd = (ngroups + 7) / 8, cap = (cus * per_cu + 7) / 8;
     return 8 * (per_xcd < cap ? per_xcd : cap);
 }
