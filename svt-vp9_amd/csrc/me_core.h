@@ -263,14 +263,17 @@ typedef struct me_lds_layout {
 /* ---- HME work list: (region, band of search rows) windows staged in the scratch and searched batch by batch ---- */
 #define ME_HME_MAX_WIN 16
 typedef struct me_hme_win {
-    int32_t off;      /* byte offset of the window inside the scratch */
-    int32_t wstride;  /* window row stride (bytes, odd number of dwords) */
-    int32_t nd, rows; /* window dwords per row, rows */
-    int32_t sw, sh;   /* search positions */
-    int32_t gx, gy;   /* reference-picture coordinates of window column 0 / row 0 */
-    int32_t slot;     /* region (key) this window belongs to */
-    int32_t y0;       /* first search row of this window inside its region (row band offset) */
-    int32_t tl, ts;   /* first load task / first search task of this window inside its batch */
+    int16_t  gx, gy;         /* reference-picture coordinates of window column 0 / row 0 */
+    uint16_t off;            /* byte offset of the window inside the scratch */
+    uint16_t wstride;        /* window row stride (bytes, odd number of dwords) */
+    uint16_t tl, ts;         /* first load task / first search task of this window inside its batch */
+    uint16_t sw, sh;         /* search positions */
+    uint16_t y0;             /* first search row of this window inside its region (row band offset) */
+    uint16_t rows;           /* window rows */
+    uint8_t  nd;             /* window dwords per row */
+    uint8_t  slot;           /* region (key) this window belongs to */
+    uint16_t pad_;
+    uint32_t inv_nu, inv_ng; /* me_magic_of(16-byte units per window row) / (search tasks per search row): the planning thread divides once */
 } me_hme_win;
 
 /* per-SB state in LDS */
@@ -1409,8 +1412,6 @@ SVT_DEV int me_div_magic(int t, uint32_t inv) { return inv ? (int)(((uint64_t)(u
 SVT_DEV void ph_hme_load_multi(const me_ctx_t *c, int tid, const svt_plane *ref_lds, const me_hme_win *wn, int e0, int e1, int ntask) {
     const svt_plane  ref_u = me_plane_uni(ref_lds);
     const svt_plane *ref = &ref_u;
-    int      cur = -1;
-    uint32_t inv = 0;
     for (int t0 = tid; t0 < ntask; t0 += 2 * SVT_NT) {
         me_u32x4 v[2];
         int      dst[2], k[2];
@@ -1421,8 +1422,7 @@ SVT_DEV void ph_hme_load_multi(const me_ctx_t *c, int tid, const svt_plane *ref_
                 int e = e0;
                 while (e + 1 < e1 && T >= wn[e + 1].tl) e++;
                 const int t = T - wn[e].tl, nd = wn[e].nd, nu = ME_HME_UNITS(nd);
-                if (e != cur) { cur = e; inv = me_magic_of(nu); }
-                const int row = me_div_magic(t, inv), i = t - row * nu;
+                const int row = me_div_magic(t, wn[e].inv_nu), i = t - row * nu;
                 const uint8_t *gp = me_pix(ref, wn[e].gx + 16 * i, wn[e].gy + row);
                 k[u] = nd - 4 * i < 4 ? nd - 4 * i : 4;
                 if (k[u] == 4) v[u] = me_ld128u_g(gp);
@@ -1503,6 +1503,39 @@ SVT_DEV void me_qsad_block(const uint8_t *blk, int bstride, int nd, int bh, cons
     }
 }
 
+/* 32-bit form of the HME key for the 1/16-resolution level: (sad << 16) | (y << 8) | x -- the SAD of a 16 x 8 block is below
+ * 2^15 and the search positions of a region stay below 256 either way; ordered exactly like the 64-bit key it stands for */
+SVT_DEV uint64_t me_hme_key64(uint32_t k) { return ((uint64_t)(k >> 16) << 32) | (((k >> 8) & 0xffu) << 16) | (k & 0xffu); }
+#ifdef SVT_HOST_EMU
+static inline void svt_wave_min_key32(uint64_t *p, uint32_t k) { if (k != 0xffffffffu && me_hme_key64(k) < *p) *p = me_hme_key64(k); }
+#else
+/* min over the wave (all lanes must call; ~0 = nothing), then ONE 64-bit LDS atomic by lane 0 */
+SVT_DEV void svt_wave_min_key32(uint64_t *p, uint32_t k) {
+#define SVT_DPP_MIN32(ctrl) do { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp((int)k, (int)k, (ctrl), 0xf, 0xf, false); k = o_ < k ? o_ : k; } while (0)
+    SVT_DPP_MIN32(0x111); SVT_DPP_MIN32(0x112); SVT_DPP_MIN32(0x114); SVT_DPP_MIN32(0x118);
+#undef SVT_DPP_MIN32
+    uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)k, 15);
+    _Pragma("unroll") for (int l = 31; l < 64; l += 16) { const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)k, l); m = w < m ? w : m; }
+    if ((threadIdx.x & 63) == 0 && m != 0xffffffffu)
+        __hip_atomic_fetch_min((unsigned long long *)p, (unsigned long long)me_hme_key64(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#endif
+
+/* the 1/16-resolution level with a whole SB (16 x 8 block, rows of 4 dwords; window rows two apart): straight-line task --
+ * each QSAD operand pair is read as such (the overlapping pairs cost LDS reads, not register moves), one packed add joins the
+ * even / odd row accumulators (8 rows x 16 samples x 255 < 2^16) */
+SVT_DEV void me_qsad_16x8(const uint8_t *blk, const uint8_t *win, int wstride, uint32_t *lo_out, uint32_t *hi_out) {
+    uint64_t acc0 = 0, acc1 = 0;
+    _Pragma("unroll") for (int j = 0; j < 8; j++) {
+        const uint32_t *w = (const uint32_t *)(win + 2 * j * wstride), *b = (const uint32_t *)(blk + 16 * j);
+        uint64_t        a = (j & 1) ? acc1 : acc0;
+        _Pragma("unroll") for (int i = 0; i < 4; i++) a = svt_qsad(((uint64_t)w[i + 1] << 32) | w[i], b[i], a);
+        if (j & 1) acc1 = a; else acc0 = a;
+    }
+    *lo_out = (uint32_t)acc0 + (uint32_t)acc1;                 /* positions 0, 1 as 16-bit sums: no carry between the halves */
+    *hi_out = (uint32_t)(acc0 >> 32) + (uint32_t)(acc1 >> 32); /* positions 2, 3 */
+}
+
 /* exhaustive search of the windows [e0, e1) of a batch in one phase; keys[slot] = min over
  * (sad << 32 | y << 16 | x inside the region): ordered like the raster index, no division to take it apart */
 SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk, int bstride, int bw, int bh, const me_hme_win *wn,
@@ -1517,11 +1550,34 @@ SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk,
 #else
 #define FP(i) ((void)0)
 #endif
+    if (bw == 16 && bh == 8 && bstride == 16 && c->L.hme_tw0 <= 256 && c->L.hme_th0 <= 256 && c->L.hme_w0[0] <= 256 && c->L.hme_w0[1] <= 256 &&
+        c->L.hme_h0[0] <= 256 && c->L.hme_h0[1] <= 256) { /* positions inside a region fit 8 bits each */
+        uint32_t b32[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        for (int T = tid; T < ntask; T += SVT_NT) {
+            int e = e0;
+            while (e + 1 < e1 && T >= wn[e + 1].ts) e++;
+            const int t = T - wn[e].ts, sw = wn[e].sw, slot = wn[e].slot;
+            const int ng = (sw + 3) >> 2, y = me_div_magic(t, wn[e].inv_ng), g = t - ME_MUL(y, ng);
+            uint32_t  lo, hi;
+            me_qsad_16x8(blk, c->planes + wn[e].off + ME_MUL(y, wn[e].wstride) + 4 * g, wn[e].wstride, &lo, &hi);
+            const uint32_t pos = ((uint32_t)(wn[e].y0 + y) << 8) | (uint32_t)(4 * g);
+            uint32_t       k0 = (lo << 16) | pos, k1 = (lo & 0xffff0000u) | (pos + 1), k2 = (hi << 16) | (pos + 2), k3 = (hi & 0xffff0000u) | (pos + 3);
+            if (4 * g + 3 >= sw) { /* last group of a width that is not a multiple of 4 */
+                if (4 * g + 1 >= sw) k1 = 0xffffffffu;
+                if (4 * g + 2 >= sw) k2 = 0xffffffffu;
+                k3 = 0xffffffffu;
+            }
+            k0 = k0 < k1 ? k0 : k1; k2 = k2 < k3 ? k2 : k3; k0 = k0 < k2 ? k0 : k2;
+            _Pragma("unroll") for (int q = 0; q < 4; q++) if (q == slot && k0 < b32[q]) b32[q] = k0;
+        }
+        _Pragma("unroll") for (int q = 0; q < 4; q++) if ((slot_mask >> q) & 1) svt_wave_min_key32(&keys[q], b32[q]);
+        return;
+    }
     for (int T = tid; T < ntask; T += SVT_NT) {
         int e = e0;
         while (e + 1 < e1 && T >= wn[e + 1].ts) e++;
         const int      t = T - wn[e].ts, ws = wn[e].wstride, sw = wn[e].sw, slot = wn[e].slot, y0 = wn[e].y0;
-        if (e != cur) { cur = e; inv = me_magic_of(qs ? (sw + 3) >> 2 : sw); }
+        if (e != cur) { cur = e; inv = wn[e].inv_ng; }
         const uint8_t *win = c->planes + wn[e].off;
         uint64_t       kb = ~0ull;
         FP(16);
@@ -1664,6 +1720,7 @@ SVT_DEV void me_hme_plan_level(const me_ctx_t *c, int list, int lvl, int16_t xsc
             me_hme_win *wn = &st->hme_win[ne++];
             wn->off = bytes; wn->wstride = ws; wn->nd = (wbytes + 3) >> 2; wn->rows = nr + span; wn->sw = w; wn->sh = nr;
             wn->gx = g.ox + ox; wn->gy = g.oy + oy + y; wn->slot = k; wn->y0 = y; wn->tl = tl; wn->ts = ts;
+            wn->inv_nu = me_magic_of(ME_HME_UNITS(wn->nd)); wn->inv_ng = me_magic_of(ng);
             tl += ME_HME_UNITS(wn->nd) * wn->rows; ts += ng * nr;
             bytes += ws * (nr + span); y += nr;
         }
