@@ -1233,6 +1233,136 @@ SVT_DEV void ph_quarterpel_decide(const me_ctx_t *c, int tid, int list, int en32
     }
 }
 
+#ifndef SVT_HOST_EMU
+/* ---- half- and quarter-pel refinement of the 32x32 and 16x16 PUs in ONE phase (SUB_SAD search, the M5+ presets) ----
+ * The task lists above spend nine tenths of their instructions on finding out what a task is.  Here a lane owns 16 samples of
+ * one (subsampled) row of one PU for the whole refinement: waves 0-1 the four 32x32 PUs (32 lanes each: 16 rows x 2 halves),
+ * waves 2-3 the sixteen 16x16 PUs (8 lanes each: one row per lane).  The lane keeps its 4 source dwords and runs through the 8
+ * half-pel candidates (planes and offsets are compile-time per candidate), the lanes of a PU are summed with DPP row shifts
+ * (inclusive prefix: the PU's last lane holds the totals), that lane takes the reference's decisions (pu_half_pel_refinement
+ * :1076-1559: strict '<' in test order = minimum of (distortion, test index); direction by the tie order L,R,T,B,TL,TR,BL,BR)
+ * and publishes them through LDS -- LDS operations of one wave execute in order, so the PU's other lanes (same wave) read them
+ * back without a barrier -- and the three quarter-pel candidates around that direction follow the same way
+ * (pu_quarter_pel_refinement_on_the_fly :2471-2715).  No candidate table, no atomics, no barrier inside. */
+SVT_DEV uint32_t me_sad16(const uint8_t *p, const uint32_t s[4]) { /* 16 samples at any byte alignment in LDS against 4 source dwords */
+    const uint32_t  sh = (uint32_t)((uintptr_t)p & 3);
+    const uint32_t *q  = (const uint32_t *)(p - sh);
+    const uint32_t  l0 = q[0], l1 = q[1], l2 = q[2], l3 = q[3], l4 = q[4];
+    uint32_t        d = svt_sad4(svt_alignbyte(l1, l0, sh), s[0], 0);
+    d = svt_sad4(svt_alignbyte(l2, l1, sh), s[1], d);
+    d = svt_sad4(svt_alignbyte(l3, l2, sh), s[2], d);
+    return svt_sad4(svt_alignbyte(l4, l3, sh), s[3], d);
+}
+SVT_DEV uint32_t me_sad16_avg(const uint8_t *pa, const uint8_t *pb, const uint32_t s[4]) { /* the same against the rounded average of two planes */
+    const uint32_t  sa = (uint32_t)((uintptr_t)pa & 3), sb = (uint32_t)((uintptr_t)pb & 3);
+    const uint32_t *qa = (const uint32_t *)(pa - sa), *qb = (const uint32_t *)(pb - sb);
+    const uint32_t  a0 = qa[0], a1 = qa[1], a2 = qa[2], a3 = qa[3], a4 = qa[4], b0 = qb[0], b1 = qb[1], b2 = qb[2], b3 = qb[3], b4 = qb[4];
+    uint32_t        d = svt_sad4(svt_avg4(svt_alignbyte(a1, a0, sa), svt_alignbyte(b1, b0, sb)), s[0], 0);
+    d = svt_sad4(svt_avg4(svt_alignbyte(a2, a1, sa), svt_alignbyte(b2, b1, sb)), s[1], d);
+    d = svt_sad4(svt_avg4(svt_alignbyte(a3, a2, sa), svt_alignbyte(b3, b2, sb)), s[2], d);
+    return svt_sad4(svt_avg4(svt_alignbyte(a4, a3, sa), svt_alignbyte(b4, b3, sb)), s[3], d);
+}
+/* inclusive sums over the lanes of a PU (8 lanes, or 32 = two DPP rows): exact in the PU's last lane */
+SVT_DEV uint32_t me_pu_lanes_sum(uint32_t v, int big) {
+    v = SVT_DPP_ADD(v, 0x111); v = SVT_DPP_ADD(v, 0x112); v = SVT_DPP_ADD(v, 0x114);
+    if (big) {
+        v = SVT_DPP_ADD(v, 0x118);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); /* row_bcast:15 into rows 1 and 3 */
+    }
+    return v;
+}
+SVT_DEV void ph_subpel_fast(const me_ctx_t *c, int tid, int list, int sox, int soy, int en32, int en16) {
+    me_state_t *st = c->st;
+    const int   w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, big = w < 2;
+    if (big ? !en32 : !en16) return; /* wave-uniform */
+    int pu, r, xo, px, py, last;
+    if (big) { pu = 1 + 2 * w + (l >> 5); r = (l & 31) >> 1; xo = (l & 1) * 16; px = ((pu - 1) & 1) * 32; py = ((pu - 1) >> 1) * 32; last = (l & 31) == 31; }
+    else { pu = 5 + 8 * (w - 2) + (l >> 3); r = l & 7; xo = 0; px = ((pu - 5) & 3) * 16; py = ((pu - 5) >> 2) * 16; last = (l & 7) == 7; }
+    const int n = me_pu_nidx(pu), ps = c->L.plane_stride, pb = c->L.plane_bytes;
+    uint32_t  s[4];
+    {
+        const uint32_t *sp = (const uint32_t *)(c->src + (py + 2 * r) * ME_SB + px + xo);
+        s[0] = sp[0]; s[1] = sp[1]; s[2] = sp[2]; s[3] = sp[3];
+    }
+    uint32_t mv = st->best_mv[list][n], best = st->best_sad[list][n];
+    int      xm = me_mvx(mv), ym = me_mvy(mv);
+    /* ---- half-pel: 8 candidates ---- */
+    {
+        const int      xs = (int16_t)((xm >> 2) - (int16_t)sox) + px + xo, ys = (int16_t)((ym >> 2) - (int16_t)soy) + py + 2 * r;
+        const uint8_t *base = c->planes + ME_MUL(ys + ME_PL_G, ps) + xs + ME_PL_G; /* plane B at (xs, ys); H, J one / two planes further */
+        uint32_t       d[8];
+        _Pragma("unroll") for (int i = 0; i < 8; i++) {
+            int hpl, hdx, hdy;
+            me_hcand_get(i, &hpl, &hdx, &hdy);
+            d[i] = me_sad16(base + (hpl - 1) * pb + hdy * ps + hdx, s);
+        }
+        /* a lane's sums stay below 2^12 and a group of 8 lanes below 2^15: two candidates per dword for the first three steps */
+        uint32_t p4[4];
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {
+            uint32_t v = d[i] | (d[i + 4] << 16);
+            v = SVT_DPP_ADD(v, 0x111); v = SVT_DPP_ADD(v, 0x112); v = SVT_DPP_ADD(v, 0x114);
+            p4[i] = v;
+        }
+        _Pragma("unroll") for (int i = 0; i < 4; i++) { d[i] = p4[i] & 0xffffu; d[i + 4] = p4[i] >> 16; }
+        if (big) {
+            _Pragma("unroll") for (int i = 0; i < 8; i++) {
+                uint32_t v = SVT_DPP_ADD(d[i], 0x118);
+                d[i] = v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+            }
+        }
+        /* decisions (meaningful in the PU's last lane): distortions are doubled (rows 0, 2, 4, ...) */
+        uint32_t km = 0xffffffffu, kr = 0xffffffffu;
+        _Pragma("unroll") for (int i = 0; i < 8; i++) {
+            const uint32_t dd = d[i] << 4; /* (2 d) << 3 */
+            const uint32_t k1 = dd | (uint32_t)i, k2 = dd | (uint32_t)(i == 6 ? 7 : i == 7 ? 6 : i);
+            km = k1 < km ? k1 : km; kr = k2 < kr ? k2 : kr;
+        }
+        if ((km >> 3) < best) {
+            int sx, sy;
+            me_dmv_get((int)(km & 7u), &sx, &sy);
+            best = km >> 3; mv = me_pack_mv(xm + 2 * sx, ym + 2 * sy);
+        }
+        const uint32_t dir = (0x46205137u >> (4 * (kr & 7u))) & 7u; /* tie rank L,R,T,B,TL,TR,BL,BR -> direction code */
+        if (last) { st->best_sad[list][n] = best; st->best_mv[list][n] = mv; st->dir[n] = (uint8_t)dir; }
+    }
+    __asm__ volatile("" ::: "memory"); /* the reads below must stay behind the stores above (other lanes' data) */
+    /* ---- quarter-pel: the three positions around the half-pel direction ---- */
+    {
+        mv = st->best_mv[list][n]; best = st->best_sad[list][n];
+        const int dir = st->dir[n];
+        xm = me_mvx(mv); ym = me_mvy(mv);
+        const int method = (ym & 2) + ((xm & 2) >> 1);
+        const int xs = (int16_t)(((xm + 2) >> 2) - (int16_t)sox) + px + xo, ys = (int16_t)(((ym + 2) >> 2) - (int16_t)soy) + py + 2 * r;
+        uint32_t  q[3], pos[3];
+        _Pragma("unroll") for (int j = 0; j < 3; j++) {
+            const int dirx = ((method != 0 ? dir ^ 4 : dir) + j - 1) & 7;
+            pos[j] = (0x07361524u >> (4 * dirx)) & 7u; /* direction code -> L,R,T,B,TL,TR,BR,BL index */
+            const uint32_t e = me_qtab_get(method, (int)pos[j]);
+            const uint8_t *a = me_plane_at(c, (int)(e & 3), xs - (int)((e >> 2) & 1), ys - (int)((e >> 3) & 1));
+            const uint8_t *b = me_plane_at(c, (int)((e >> 4) & 3), xs - (int)((e >> 6) & 1), ys - (int)((e >> 7) & 1));
+            q[j] = me_sad16_avg(a, b, s);
+        }
+        uint32_t v01 = q[0] | (q[1] << 16), v2 = q[2];
+        v01 = SVT_DPP_ADD(v01, 0x111); v01 = SVT_DPP_ADD(v01, 0x112); v01 = SVT_DPP_ADD(v01, 0x114);
+        v2 = SVT_DPP_ADD(v2, 0x111); v2 = SVT_DPP_ADD(v2, 0x112); v2 = SVT_DPP_ADD(v2, 0x114);
+        q[0] = v01 & 0xffffu; q[1] = v01 >> 16; q[2] = v2;
+        if (big) {
+            _Pragma("unroll") for (int j = 0; j < 3; j++) {
+                uint32_t v = SVT_DPP_ADD(q[j], 0x118);
+                q[j] = v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+            }
+        }
+        uint32_t km = 0xffffffffu;
+        _Pragma("unroll") for (int j = 0; j < 3; j++) { const uint32_t k = (q[j] << 4) | pos[j]; km = k < km ? k : km; }
+        if (last && (km >> 3) < best) {
+            int sx, sy;
+            me_dmv_get((int)(km & 7u), &sx, &sy);
+            st->best_sad[list][n] = km >> 3; st->best_mv[list][n] = me_pack_mv(xm + sx, ym + sy);
+        }
+    }
+}
+#endif
+
 /* Build the prediction block of the current list for every PU that takes part in bi-prediction
  * (select_buffer :3310 / quarter_pel_compensation :3358): task = (pu, row).  Output pred[pu_off + r*w + x].
  * Layout of pred blocks: pu 0 at 0 (64x64), 32x32 at 4096 + i*1024, 16x16 at 8192 + i*256, 8x8 at 12288 + i*64. */
@@ -2041,6 +2171,15 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
             ME_PHASE(ph_interp_strips(c, tid, W, H));
         }
         ME_MARK(9);
+#ifndef SVT_HOST_EMU
+        /* SUB_SAD refinement of the 32x32 / 16x16 PUs only (the M5+ presets): one phase, see ph_subpel_fast */
+        if (enq && p->fractional_search_method == SVT_SUB_SAD_SEARCH && !p->fractional_search64x64 && p->cu16x16_mode == 0 &&
+            !(en8 && p->cu8x8_mode != 1)) {
+            if (en32 || en16) ME_PHASE(ph_subpel_fast(c, tid, list, sox, soy, en32, en16));
+            ME_MARK(10);
+            ME_MARK(11);
+        } else
+#endif
         if (en32 || en16 || en8 || enq) {
             ME_PHASE(for (int t = tid; t < 85 * 9; t += SVT_NT) { if (t < c->L.cand_dwords) c->cand[t] = 0; if (c->ssdc) c->ssdc[t] = 0; }
                      ph_subpel_prep(c, tid, en32, en16, en8));
