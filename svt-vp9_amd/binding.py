@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsvtvp9_hip.so")
+# SVT_HIP_LIB: experiment aid (tools/build_variant.sh), never set by the tests or the bench contract run
+LIB_PATH = os.environ.get("SVT_HIP_LIB") or os.path.join(HERE, "libsvtvp9_hip.so")
 
 SVT_ME_PU_COUNT = 85
 

@@ -429,6 +429,25 @@ typedef struct me_ctx_t {
     unsigned long long  *prof;   /* optional per-phase cycle accumulators (profiling builds), else NULL */
 } me_ctx_t;
 
+/* t / d for a small wave-uniform divisor d (phase geometry: units per row, lanes per strip, search width ...).  An integer
+ * division costs ~25 vector instructions per wave here; the reciprocals of 1..256 sit in constant memory instead (one scalar
+ * load) and the quotient is one v_mul_hi: exact while t * d < 2^32 (inv = floor((2^32 - 1) / d) + 1; d = 1 -> inv = 0 -> t). */
+#ifdef SVT_HOST_EMU
+static inline int me_udiv(int t, int d) { return t / d; }
+#else
+struct me_magic_table {
+    uint32_t v[257];
+    constexpr me_magic_table() : v() { for (uint32_t d = 1; d <= 256; d++) v[d] = (uint32_t)(0xffffffffu / d) + 1u; }
+};
+__constant__ const me_magic_table me_magics = me_magic_table();
+SVT_DEV int me_udiv(int t, int d) {
+    const int du = __builtin_amdgcn_readfirstlane(d);
+    if (du > 256) return t / du;
+    const uint32_t inv = me_magics.v[du];
+    return inv ? (int)__umulhi((uint32_t)t, inv) : t;
+}
+#endif
+
 /* ------------------------------------------------------------------------------------------------ */
 /* phases (each: grid-stride loop over tasks; tid in [0,256))                                         */
 /* ------------------------------------------------------------------------------------------------ */
@@ -441,8 +460,8 @@ SVT_DEV void ph_load_rect(int tid, uint8_t *dst, int dst_stride, const uint8_t *
      * (row, unit) pair advances by SVT_NT tasks per step without a division; the loads of two steps are issued before the
      * first LDS store. */
     const int nd = (w_bytes + 3) >> 2, nu = (nd + 3) >> 2, n = nu * rows;
-    const int dr = SVT_NT / nu, di = SVT_NT - dr * nu;
-    int       r = tid / nu, i = tid - r * nu;
+    const int dr = me_udiv(SVT_NT, nu), di = SVT_NT - dr * nu;
+    int       r = me_udiv(tid, nu), i = tid - r * nu;
     const me_gsrc g = me_gsrc_of(src);
     for (int t0 = tid; t0 < n; t0 += 2 * SVT_NT) {
         me_u32x4 v[2];
@@ -517,7 +536,7 @@ SVT_DEV void ph_center_sads(const me_ctx_t *c, int tid, const svt_plane *ref, in
      * the first use: one memory round trip for the phase, one 8-byte load per candidate and thread */
     _Pragma("unroll") for (int k = 0; k < 5; k++) v[k] = s;
     if (tid < n) {
-        const int r = tid / wq, i = tid - r * wq;
+        const int r = me_udiv(tid, wq), i = tid - r * wq;
         const uint32_t *sp = (const uint32_t *)(c->src + (2 * r) * ME_SB + 8 * i);
         s.x = sp[0]; s.y = sp[1];
         const int rstride = ref->stride;
@@ -542,7 +561,7 @@ SVT_DEV void ph_region_center_sad(const me_ctx_t *c, int tid, int col, int row) 
     _Pragma("unroll") for (int h = 0; h < 2; h++) {
         const int t = tid + h * SVT_NT;
         if (t < n) {
-            const int r = t / wd, i = t - r * wd;
+            const int r = me_udiv(t, wd), i = t - r * wd;
             acc = svt_sad4(me_ld32u(c->region + ME_MUL(row + 2 * r, rs) + col + 4 * i), *(const uint32_t *)(c->src + (2 * r) * ME_SB + 4 * i), acc);
         }
     }
@@ -858,8 +877,8 @@ SVT_DEV uint32_t me_half_join(uint32_t ev, uint32_t od) { /* even / odd results 
 }
 SVT_DEV void ph_interp_strips(const me_ctx_t *c, int tid, int W, int H) {
     const int rs = c->L.region_stride, ps = c->L.plane_stride, pb = c->L.plane_bytes, pwd = (W + 2 * ME_PL_G + 3) >> 2, ph = H + 2 * ME_PL_G;
-    const int nseg = SVT_NT / pwd, per = (ph + nseg - 1) / nseg;
-    const int seg = tid / pwd, j = tid - seg * pwd;
+    const int nseg = me_udiv(SVT_NT, pwd), per = me_udiv(ph + nseg - 1, nseg);
+    const int seg = me_udiv(tid, pwd), j = tid - seg * pwd;
     const int r0 = ME_MUL(seg, per), cnt = r0 + per < ph ? per : ph - r0; /* this strip: plane rows r0 .. r0 + cnt - 1 */
     if (seg >= nseg || cnt <= 0) return;
     /* Plane row py (natural row py - ME_PL_G) takes: B(py) from region row py + 1 (horizontal filter along it); H(py) and J(py)
@@ -2095,16 +2114,16 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         ME_MARK(4);
         /* ---- full-pel search, in chunks of search rows ---- */
         {
-            int max_pos   = c->L.scratch_bytes / (4 * ME_PU_STRIDE);
-            int rows_chunk = max_pos / saw;
-            if (rows_chunk < 1) rows_chunk = 1;
-            if (rows_chunk > sah) rows_chunk = sah;
             uint32_t *U = (uint32_t *)c->planes;
             if ((saw & 7) == 0 && saw * sah <= 4096) {
                 ME_PHASE(ph_fullpel_fused(c, tid, saw, sah));
                 ME_MARK(5);
                 ME_MARK(6);
-            } else
+            } else {
+            int max_pos   = c->L.scratch_bytes / (4 * ME_PU_STRIDE);
+            int rows_chunk = max_pos / saw;
+            if (rows_chunk < 1) rows_chunk = 1;
+            if (rows_chunk > sah) rows_chunk = sah;
             for (int y0 = 0; y0 < sah; y0 += rows_chunk) {
                 int ny = y0 + rows_chunk <= sah ? rows_chunk : sah - y0;
                 ME_PHASE(ph_fullpel_sad8(c, tid, U, saw, y0, ny, w8));
@@ -2114,6 +2133,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                 ME_PHASE(ph_fullpel_argmin(c, tid, U, saw, y0, ny));
                 ME_MARK(6);
             }
+            }
             /* keys -> best sad / mv (curr_mv = (y << 18) | (uint16)(x << 2), :108-110) */
             ME_PHASE(if (tid >= 128 && tid < 137) st->supel[tid - 128] = 0;
                      for (int t = tid; t < 85; t += SVT_NT) {
@@ -2121,7 +2141,8 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                 uint32_t idx = (uint32_t)k;
                 st->best_sad[list][t] = (uint32_t)(k >> 32);
                 if ((uint32_t)(k >> 32) != (uint32_t)ME_MAX_SAD_VALUE) {
-                    int xi = (int)(idx % (uint32_t)saw) + sox, yi = (int)(idx / (uint32_t)saw) + soy;
+                    const int yq = me_udiv((int)idx, saw);
+                    int       xi = (int)idx - yq * saw + sox, yi = yq + soy;
                     st->best_mv[list][t] = (((uint32_t)(uint16_t)yi) << 18) | (uint16_t)((uint16_t)xi << 2);
                 }
             });
