@@ -1968,7 +1968,8 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
 
     for (int list = 0; list < nlist; list++) {
         /* the reference's plane descriptors are read many times (address arithmetic, clipping): keep them in LDS */
-        ME_PHASE(if (tid < (int)(3 * sizeof(svt_plane) / 4)) ((uint32_t *)st->refd)[tid] = ((const uint32_t *)&c->pic->ref[list])[tid]);
+        ME_PHASE(if (tid < (int)(3 * sizeof(svt_plane) / 4)) ((uint32_t *)st->refd)[tid] = ((const uint32_t *)&c->pic->ref[list])[tid];
+                 if (tid >= 64 && tid < 72) st->red[tid - 64] = 0);
         const svt_plane  rf_u = me_plane_uni(&st->refd[0]); /* full-resolution reference plane of this list */
         const svt_plane *rf = &rf_u;
         const int        ox = (int16_t)c->sb_x, oy = (int16_t)c->sb_y;
@@ -1993,8 +1994,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                     dx[4] = me_clip_center(ox, dirx, pad, W); dy[4] = me_clip_center(oy, diry, pad, H);
                     nc = 5;
                 }
-                ME_PHASE(if (tid < 8) st->red[tid] = 0);
-                ME_PHASE(ph_center_sads(c, tid, rf, nc, dx, dy));
+                ME_PHASE(ph_center_sads(c, tid, rf, nc, dx, dy)); /* red[] was zeroed with the plane descriptors above */
                 zero_c = (uint64_t)(uint32_t)ME_UNI(st->red[0]) << 1; have_zero = 1;
                 uint64_t b_c = (uint64_t)(uint32_t)ME_UNI(st->red[1]) << 1,
                          c_c = (uint64_t)(uint32_t)ME_UNI(st->red[2]) << 1, d_c = (uint64_t)(uint32_t)ME_UNI(st->red[3]) << 1;
@@ -2012,7 +2012,9 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                 else if (best == c_c) { xsc = 0; ysc = (int16_t)(0 - th); }
                 else if (best == dir_c) { xsc = list ? dirx : 0; ysc = list ? diry : 0; }
                 else { xsc = 0; ysc = (int16_t)th; }
-                ME_PHASE((void)0); /* everyone has read red[] */
+                /* red[] is zeroed again when the search region is staged: a barrier must lie between; the HME phases bring theirs */
+                if (!(p->enable_hme_flag && c->sb_h == ME_SB && (p->enable_hme_level_0_flag || p->enable_hme_level_1_flag || p->enable_hme_level_2_flag)))
+                    ME_PHASE((void)0);
             }
             ME_MARK(1);
             /* ---- HME ---- */
@@ -2074,7 +2076,8 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
     ME_PHASE(ph_load_rect(tid, c->region, c->L.region_stride, me_pix(rf, c->sb_x + sox - ME_RGN_GX, c->sb_y + soy - ME_RGN_GY), \
                           rf->stride, W + ME_RGN_GX + 4 + tail_extra, H + 2 * ME_RGN_GY + 1);                        \
              for (int t = tid; t < 85; t += SVT_NT) st->key[t] = ((uint64_t)ME_MAX_SAD_VALUE << 32);                  \
-             if (tid < 8) st->red[tid] = 0)
+             if (tid < 8) st->red[tid] = 0;                                                                          \
+             if (tid >= 128 && tid < 137) st->supel[tid - 128] = 0)
         if (xsc != 0 || ysc != 0) {
             /* ---- check_zero_zero_center (:4420-4500): the centre found above against (0, 0).  The SAD at (0, 0) is the
              * one test_search_area_bounds already computed for this list (same function, same block); the SAD at the
@@ -2101,7 +2104,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
             }
             uint64_t m = z < h ? z : h;
             if (m == z) { xsc = 0; ysc = 0; loaded = 0; }
-            ME_PHASE((void)0);
+            if (!loaded) ME_PHASE((void)0); /* everyone has read red[] before the staging below zeroes it */
         }
         ME_MARK(3);
         if (!loaded) {
@@ -2134,16 +2137,31 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                 ME_MARK(6);
             }
             }
-            /* keys -> best sad / mv (curr_mv = (y << 18) | (uint16)(x << 2), :108-110) */
-            ME_PHASE(if (tid >= 128 && tid < 137) st->supel[tid - 128] = 0;
-                     for (int t = tid; t < 85; t += SVT_NT) {
-                uint64_t k = st->key[t];
-                uint32_t idx = (uint32_t)k;
-                st->best_sad[list][t] = (uint32_t)(k >> 32);
-                if ((uint32_t)(k >> 32) != (uint32_t)ME_MAX_SAD_VALUE) {
-                    const int yq = me_udiv((int)idx, saw);
-                    int       xi = (int)idx - yq * saw + sox, yi = yq + soy;
-                    st->best_mv[list][t] = (((uint32_t)(uint16_t)yi) << 18) | (uint16_t)((uint16_t)xi << 2);
+            /* keys -> best sad / mv (curr_mv = (y << 18) | (uint16)(x << 2), :108-110) and, where the sub-pel search is gated
+             * (su_pel_enable :3839-4258: average MV magnitude / SAD per size class), the nine sums of that decision from the
+             * values the lanes have just produced: one PU per lane, wave reductions (st->supel was zeroed with the keys) */
+            ME_PHASE(if (tid < 128) {
+                const int t = tid;
+                uint32_t  mv = 0, sd = 0;
+                if (t < 85) {
+                    const uint64_t k = st->key[t];
+                    const uint32_t idx = (uint32_t)k;
+                    sd = (uint32_t)(k >> 32);
+                    st->best_sad[list][t] = sd;
+                    if (sd != (uint32_t)ME_MAX_SAD_VALUE) {
+                        const int yq = me_udiv((int)idx, saw);
+                        int       xi = (int)idx - yq * saw + sox, yi = yq + soy;
+                        mv = (((uint32_t)(uint16_t)yi) << 18) | (uint16_t)((uint16_t)xi << 2);
+                        st->best_mv[list][t] = mv;
+                    } else mv = st->best_mv[list][t];
+                }
+                if (p->fractional_search_model == 1) {
+                    const int cls = t >= 85 ? -1 : t >= 21 ? 2 : t >= 5 ? 1 : t >= 1 ? 0 : -1;
+                    _Pragma("unroll") for (int k = 0; k < 3; k++) {
+                        svt_wave_add_u32(&st->supel[3 * k + 0], cls == k ? (uint32_t)(int32_t)me_mvx(mv) : 0u, 1);
+                        svt_wave_add_u32(&st->supel[3 * k + 1], cls == k ? (uint32_t)(int32_t)me_mvy(mv) : 0u, 1);
+                        svt_wave_add_u32(&st->supel[3 * k + 2], cls == k ? sd : 0u, 1);
+                    }
                 }
             });
         }
@@ -2153,18 +2171,6 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         int en32 = 0, en16 = 0, en8 = 0, enq = 0;
         if (p->fractional_search_model == 0) { en32 = en16 = en8 = enq = 1; }
         else if (p->fractional_search_model == 1) {
-            /* su_pel_enable (:3839-4258): average MV magnitude / SAD per size class; the nine sums come from one
-             * element per lane and wave reductions (st->supel was zeroed with the keys) */
-            ME_PHASE(if (tid < 128) {
-                const int      i = tid;
-                const int      cls = i >= 85 ? -1 : i >= 21 ? 2 : i >= 5 ? 1 : i >= 1 ? 0 : -1;
-                const uint32_t mv = i < 85 ? st->best_mv[list][i] : 0, sd = i < 85 ? st->best_sad[list][i] : 0;
-                _Pragma("unroll") for (int k = 0; k < 3; k++) {
-                    svt_wave_add_u32(&st->supel[3 * k + 0], cls == k ? (uint32_t)(int32_t)me_mvx(mv) : 0u, 1);
-                    svt_wave_add_u32(&st->supel[3 * k + 1], cls == k ? (uint32_t)(int32_t)me_mvy(mv) : 0u, 1);
-                    svt_wave_add_u32(&st->supel[3 * k + 2], cls == k ? sd : 0u, 1);
-                }
-            });
             int      sx = ME_UNI(st->supel[0]), sy = ME_UNI(st->supel[1]);
             uint32_t ss = (uint32_t)ME_UNI(st->supel[2]);
             uint32_t ax = (uint32_t)(sx >> 2), ay = (uint32_t)(sy >> 2);
