@@ -263,32 +263,42 @@ def main():
             setattr(d, name, pl)
         return d
 
-    pa_pics = [pa_alloc() for _ in range(MINIGOP + 1)]
+    # two sets of analysed planes: picture analysis runs one mini-GOP ahead of motion estimation on its own stream (as the
+    # reference's picture-analysis threads run ahead of its ME threads), writing set (k + 1) & 1 while ME reads set k & 1
+    pa_sets = [[pa_alloc() for _ in range(MINIGOP + 1)] for _ in range(2)]
+    pa_stream = torch.cuda.Stream(device=local_rank, priority=prio[0])
+    ctx_pa = C.c_void_p()
+    B.check(lib.svt_hip_ctx_create_on_stream(C.byref(ctx_pa), local_rank, C.c_void_p(pa_stream.cuda_stream)))
+    ctxs.append(ctx_pa)
 
-    def pa_call(ctx_, idx):
+    def pa_call(ctx_, idx, s=0):
         n = len(idx)
         lum = (C.c_void_p * n)(*[d_src.data_ptr() + i * pic_bytes for i in idx])
         strides = (C.c_int32 * n)(*[plane_w] * n)
-        out = (B.PaPicture * n)(*[pa_pics[i] for i in idx])
+        out = (B.PaPicture * n)(*[pa_sets[s][i] for i in idx])
         B.check(lib.svt_hip_pa_prepare_batch_device(ctx_, n, lum, strides, out, 1 if l1_on else 0))
 
-    pa_call(ctx_me, [0])   # the previous mini-GOP's base picture: analysed when that mini-GOP was
+    for s_ in range(2):
+        pa_call(ctx_me, [0], s_)   # the previous mini-GOP's base picture: analysed when that mini-GOP was
     B.check(lib.svt_hip_ctx_synchronize(ctx_me))
     pa_idx = list(range(1, MINIGOP + 1))
 
     # ---- stage "me": one batched launch per temporal layer (parameters differ per layer) ----
     results = [dev_zeros((nsb, 85 * 10), torch.int32) for _ in range(MINIGOP + 1)]
-    me_launches = []
-    for layer in range(5):
-        idx = [i for i in range(1, MINIGOP + 1) if LAYER[i - 1] == layer]
-        p = B.me_params_preset(Wd, Hd, 8, 1, 2, layer, 4)
-        p.same_ref_poc = 1 if layer == 0 else 0
-        n = len(idx)
-        cur = (B.PaPicture * n)(*[pa_pics[i] for i in idx])
-        r0 = (B.PaPicture * n)(*[pa_pics[refs_of(i)[0]] for i in idx])
-        r1 = (B.PaPicture * n)(*[pa_pics[refs_of(i)[1]] for i in idx])
-        res = (C.c_void_p * n)(*[results[i].data_ptr() for i in idx])
-        me_launches.append((n, cur, r0, r1, p, res))
+    me_launch_sets = []
+    for pa_pics in pa_sets:
+        me_launches = []
+        for layer in range(5):
+            idx = [i for i in range(1, MINIGOP + 1) if LAYER[i - 1] == layer]
+            p = B.me_params_preset(Wd, Hd, 8, 1, 2, layer, 4)
+            p.same_ref_poc = 1 if layer == 0 else 0
+            n = len(idx)
+            cur = (B.PaPicture * n)(*[pa_pics[i] for i in idx])
+            r0 = (B.PaPicture * n)(*[pa_pics[refs_of(i)[0]] for i in idx])
+            r1 = (B.PaPicture * n)(*[pa_pics[refs_of(i)[1]] for i in idx])
+            res = (C.c_void_p * n)(*[results[i].data_ptr() for i in idx])
+            me_launches.append((n, cur, r0, r1, p, res))
+        me_launch_sets.append(me_launches)
     # launches -> ME streams: largest first onto the least loaded stream
     me_slot, load = [0] * len(me_launches), [0] * len(me_ctxs)
     for li in sorted(range(len(me_launches)), key=lambda j: -me_launches[j][0]):
@@ -304,10 +314,10 @@ def main():
     for e_ in me_pool:
         e_.record(me_streams[0])   # an event object is created on its first record
 
-    def run_me(record=False):
+    def run_me(record=False, s=0):
         for st_ in me_streams[1:]:
             st_.wait_stream(me_streams[0])
-        for li, (n, cur, r0, r1, p, res) in enumerate(me_launches):
+        for li, (n, cur, r0, r1, p, res) in enumerate(me_launch_sets[s]):
             k_ = me_slot[li]
             if record:
                 e0, e1 = me_pool.pop(), me_pool.pop()
@@ -502,6 +512,7 @@ def main():
     stages = set(args.stages.split(","))
     ev = []            # (stage name, start event, stop event) of every stage of every timed step
     lf_done = [None, None]   # event after the deblocking that last read reconstruction buffer b
+    pa_done, me_done = [None, None], [None, None]   # analysed-plane set s: written / last read
 
     def staged(name, stream, fn, record):
         if name not in stages:
@@ -520,8 +531,19 @@ def main():
         buf = step_no[0] & 1
         step_no[0] += 1
         # ME side (one mini-GOP ahead of the EncDec side, as the reference's ME threads are): PA writes the planes ME reads
-        staged("pa", streams[0], lambda: pa_call(ctx_me, pa_idx), record)
-        staged("me", streams[0], lambda: run_me(record), record)
+        # and picture analysis of the NEXT mini-GOP runs beside it on its own stream
+        if pa_done[buf] is not None:
+            streams[0].wait_event(pa_done[buf])
+        staged("me", streams[0], lambda: run_me(record, buf), record)
+        if "me" in stages:
+            me_done[buf] = torch.cuda.Event()
+            me_done[buf].record(streams[0])
+        if "pa" in stages:
+            if me_done[1 - buf] is not None:
+                pa_stream.wait_event(me_done[1 - buf])   # ME of the previous step read the set written now
+            staged("pa", pa_stream, lambda: pa_call(ctx_pa, pa_idx, 1 - buf), record)
+            pa_done[1 - buf] = torch.cuda.Event()
+            pa_done[1 - buf].record(pa_stream)
         # EncDec side: prediction -> transform (reads the prediction, writes coefficients + reconstruction) -> rate (reads the
         # coefficients); the reconstruction buffer is free again once the deblocking that used it two steps ago is done
         if lf_done[buf] is not None:
