@@ -1553,6 +1553,12 @@ __device__ int g_me_stop_after = -1;
 /* t / d through inv = floor((2^32 - 1) / d) + 1 (exact while t * d < 2^32; d = 1 gives inv = 0 -> t).  Every thread derives
  * inv itself when it enters a window: the (slow) division runs in parallel instead of on the planning thread */
 SVT_DEV uint32_t me_magic_of(int d) { return (uint32_t)(0xffffffffu / (uint32_t)d) + 1u; }
+/* the same from the reciprocal table when d is small (no division) */
+#ifdef SVT_HOST_EMU
+static inline uint32_t me_magic_small(int d) { return me_magic_of(d); }
+#else
+SVT_DEV uint32_t me_magic_small(int d) { return d <= 256 ? me_magics.v[d] : me_magic_of(d); }
+#endif
 SVT_DEV int me_div_magic(int t, uint32_t inv) { return inv ? (int)(((uint64_t)(uint32_t)t * inv) >> 32) : t; }
 
 /* copy the windows [e0, e1) of a batch: flattened (window, row, 16-byte unit) tasks -- one global load per unit (the last unit
@@ -1800,6 +1806,45 @@ SVT_DEV void me_hme_plan_level(const me_ctx_t *c, int list, int lvl, int16_t xsc
     const int single = lvl == 0 && p->single_hme_quadrant && !p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag;
     const int span   = 2 * (g.bh - 1);
     int       ne = 0, nb = 0, bytes = 0, tl = 0, ts = 0;
+#ifndef SVT_HOST_EMU
+    if (single) {
+        /* one region, one level (the 4K presets M8+): only slot 0 of level 0 is ever read back (me_hme_finish_level / me_hme_select
+         * skip the other slots) -- the same steps as the general code below for k = 0, without the loops around them */
+        st->hme_x[0][0] = (int16_t)(xsc >> 2); st->hme_y[0][0] = (int16_t)(ysc >> 2);
+        st->hme_rh = 0;
+        st->hme_bstart[0] = 0;
+        { uint32_t *kw_ = (uint32_t *)&st->hme_keys[0]; kw_[0] = ~0u; kw_[1] = ~0u; }
+        int16_t w = c->L.hme_tw0, h = c->L.hme_th0;
+        int16_t ox = (int16_t)(-(int16_t)(w >> 1) + (int16_t)(xsc >> 2)), oy = (int16_t)(-(int16_t)(h >> 1) + (int16_t)(ysc >> 2));
+        me_clip_area(g.ox, &ox, &w, g.pad_w, g.ref->width);
+        me_clip_area(g.oy, &oy, &h, g.pad_h, g.ref->height);
+        if ((w & 15) != 0) w = (int16_t)((w >> 4) << 4);
+        st->hme_cox[0] = ox; st->hme_coy[0] = oy;
+        const int ok = w > 0 && h > 0;
+        st->hme_cw[0] = ok ? w : 0; st->hme_ch[0] = ok ? h : 0;
+        if (ok) {
+            const int wbytes = w + g.bw + 3;
+            int       ws     = ((wbytes + 3) & ~3) + 4;
+            if (((ws >> 2) & 1) == 0) ws += 4;
+            const int ng = (g.bw & 3) == 0 ? (w + 3) >> 2 : w;
+            for (int y = 0; y < h && ne < ME_HME_MAX_WIN;) {
+                int nr = h - y;
+                if (ws * (nr + span) > c->L.scratch_bytes - bytes) nr = (c->L.scratch_bytes - bytes) / ws - span;
+                if (nr < 1 && bytes > 0) { st->hme_bstart[++nb] = ne; bytes = 0; tl = 0; ts = 0; continue; }
+                if (nr < 1) break;
+                me_hme_win *wn = &st->hme_win[ne++];
+                wn->off = bytes; wn->wstride = ws; wn->nd = (wbytes + 3) >> 2; wn->rows = nr + span; wn->sw = w; wn->sh = nr;
+                wn->gx = g.ox + ox; wn->gy = g.oy + oy + y; wn->slot = 0; wn->y0 = y; wn->tl = tl; wn->ts = ts;
+                wn->inv_nu = me_magic_small(ME_HME_UNITS(wn->nd)); wn->inv_ng = me_magic_small(ng);
+                tl += ME_HME_UNITS(wn->nd) * wn->rows; ts += ng * nr;
+                bytes += ws * (nr + span); y += nr;
+            }
+        }
+        if (ne > st->hme_bstart[nb]) st->hme_bstart[++nb] = ne;
+        st->hme_nbatch = nb;
+        return;
+    }
+#endif
     if (first && st->hme_rh < NH) { /* [quirk] centres are only initialised while the reference's row counter is below NH */
         for (int k = 0; k < 4; k++)
             if ((k & 1) < NW && (k >> 1) < NH && (k >> 1) >= st->hme_rh) {
@@ -1869,7 +1914,7 @@ SVT_DEV void me_hme_plan_level(const me_ctx_t *c, int list, int lvl, int16_t xsc
             me_hme_win *wn = &st->hme_win[ne++];
             wn->off = bytes; wn->wstride = ws; wn->nd = (wbytes + 3) >> 2; wn->rows = nr + span; wn->sw = w; wn->sh = nr;
             wn->gx = g.ox + ox; wn->gy = g.oy + oy + y; wn->slot = k; wn->y0 = y; wn->tl = tl; wn->ts = ts;
-            wn->inv_nu = me_magic_of(ME_HME_UNITS(wn->nd)); wn->inv_ng = me_magic_of(ng);
+            wn->inv_nu = me_magic_small(ME_HME_UNITS(wn->nd)); wn->inv_ng = me_magic_small(ng);
             tl += ME_HME_UNITS(wn->nd) * wn->rows; ts += ng * nr;
             bytes += ws * (nr + span); y += nr;
         }
