@@ -1263,6 +1263,7 @@ SVT_DEV void ph_quarterpel_decide(const me_ctx_t *c, int tid, int list, int en32
  * and publishes them through LDS -- LDS operations of one wave execute in order, so the PU's other lanes (same wave) read them
  * back without a barrier -- and the three quarter-pel candidates around that direction follow the same way
  * (pu_quarter_pel_refinement_on_the_fly :2471-2715).  No candidate table, no atomics, no barrier inside. */
+SVT_DEV void me_pred_ptrs(const me_ctx_t *c, int list, int sox, int soy, int pu, int px, int py, const uint8_t **a, const uint8_t **b, int *sa, int *sb);
 SVT_DEV uint32_t me_sad16(const uint8_t *p, const uint32_t s[4]) { /* 16 samples at any byte alignment in LDS against 4 source dwords */
     const uint32_t  sh = (uint32_t)((uintptr_t)p & 3);
     const uint32_t *q  = (const uint32_t *)(p - sh);
@@ -1290,10 +1291,11 @@ SVT_DEV uint32_t me_pu_lanes_sum(uint32_t v, int big) {
     }
     return v;
 }
-SVT_DEV void ph_subpel_fast(const me_ctx_t *c, int tid, int list, int sox, int soy, int en32, int en16) {
+SVT_DEV void ph_subpel_fast(const me_ctx_t *c, int tid, int list, int sox, int soy, int en32, int en16, int bipred, uint32_t *pr) {
     me_state_t *st = c->st;
     const int   w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, big = w < 2;
-    if (big ? !en32 : !en16) return; /* wave-uniform */
+    const int   refine = big ? en32 : en16; /* wave-uniform */
+    if (!refine && !bipred) return;
     int pu, r, xo, px, py, last;
     if (big) { pu = 1 + 2 * w + (l >> 5); r = (l & 31) >> 1; xo = (l & 1) * 16; px = ((pu - 1) & 1) * 32; py = ((pu - 1) >> 1) * 32; last = (l & 31) == 31; }
     else { pu = 5 + 8 * (w - 2) + (l >> 3); r = l & 7; xo = 0; px = ((pu - 5) & 3) * 16; py = ((pu - 5) >> 2) * 16; last = (l & 7) == 7; }
@@ -1306,7 +1308,7 @@ SVT_DEV void ph_subpel_fast(const me_ctx_t *c, int tid, int list, int sox, int s
     uint32_t mv = st->best_mv[list][n], best = st->best_sad[list][n];
     int      xm = me_mvx(mv), ym = me_mvy(mv);
     /* ---- half-pel: 8 candidates ---- */
-    {
+    if (refine) {
         const int      xs = (int16_t)((xm >> 2) - (int16_t)sox) + px + xo, ys = (int16_t)((ym >> 2) - (int16_t)soy) + py + 2 * r;
         const uint8_t *base = c->planes + ME_MUL(ys + ME_PL_G, ps) + xs + ME_PL_G; /* plane B at (xs, ys); H, J one / two planes further */
         uint32_t       d[8];
@@ -1346,7 +1348,7 @@ SVT_DEV void ph_subpel_fast(const me_ctx_t *c, int tid, int list, int sox, int s
     }
     __asm__ volatile("" ::: "memory"); /* the reads below must stay behind the stores above (other lanes' data) */
     /* ---- quarter-pel: the three positions around the half-pel direction ---- */
-    {
+    if (refine) {
         mv = st->best_mv[list][n]; best = st->best_sad[list][n];
         const int dir = st->dir[n];
         xm = me_mvx(mv); ym = me_mvy(mv);
@@ -1377,6 +1379,38 @@ SVT_DEV void ph_subpel_fast(const me_ctx_t *c, int tid, int list, int sox, int s
             int sx, sy;
             me_dmv_get((int)(km & 7u), &sx, &sy);
             st->best_sad[list][n] = km >> 3; st->best_mv[list][n] = me_pack_mv(xm + sx, ym + sy);
+        }
+    }
+    /* ---- the lane's 16 samples of the PU's prediction at its final motion vector (select_buffer :3310 / quarter_pel_compensation
+     * :3358): kept in registers after list 0; after list 1 averaged with them and compared with the source -- the PU's
+     * bi-prediction distortion (bi_pred_averging :3466-3560), summed over the PU's lanes, written by its last lane ---- */
+    if (bipred) {
+        __asm__ volatile("" ::: "memory");
+        const uint8_t *a, *b;
+        int            sa, sb;
+        me_pred_ptrs(c, list, sox, soy, pu, px + xo, py + 2 * r, &a, &b, &sa, &sb);
+        uint32_t v[4];
+        {
+            const uint32_t  sh = (uint32_t)((uintptr_t)a & 3);
+            const uint32_t *q  = (const uint32_t *)(a - sh);
+            const uint32_t  l0 = q[0], l1 = q[1], l2 = q[2], l3 = q[3], l4 = q[4];
+            v[0] = svt_alignbyte(l1, l0, sh); v[1] = svt_alignbyte(l2, l1, sh); v[2] = svt_alignbyte(l3, l2, sh); v[3] = svt_alignbyte(l4, l3, sh);
+        }
+        if (b) {
+            const uint32_t  sh = (uint32_t)((uintptr_t)b & 3);
+            const uint32_t *q  = (const uint32_t *)(b - sh);
+            const uint32_t  l0 = q[0], l1 = q[1], l2 = q[2], l3 = q[3], l4 = q[4];
+            v[0] = svt_avg4(v[0], svt_alignbyte(l1, l0, sh)); v[1] = svt_avg4(v[1], svt_alignbyte(l2, l1, sh));
+            v[2] = svt_avg4(v[2], svt_alignbyte(l3, l2, sh)); v[3] = svt_avg4(v[3], svt_alignbyte(l4, l3, sh));
+        }
+        if (list == 0) { pr[4] = v[0]; pr[5] = v[1]; pr[6] = v[2]; pr[7] = v[3]; }
+        else {
+            uint32_t d = svt_sad4(svt_avg4(pr[4], v[0]), s[0], 0);
+            d = svt_sad4(svt_avg4(pr[5], v[1]), s[1], d);
+            d = svt_sad4(svt_avg4(pr[6], v[2]), s[2], d);
+            d = svt_sad4(svt_avg4(pr[7], v[3]), s[3], d);
+            d = me_pu_lanes_sum(d, big);
+            if (last) c->cand[pu] = d;
         }
     }
 }
@@ -1422,8 +1456,8 @@ SVT_DEV int me_bipred_levels(const me_ctx_t *c) { return c->p->cu16x16_mode != 0
 #else
 #define ME_PR(j) pr[(j)]
 #endif
-SVT_DEV void ph_store_pred0(const me_ctx_t *c, int tid, int sox, int soy, uint32_t *pr) {
-    const int sub = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH, K = sub ? 2 : 4, levels = me_bipred_levels(c);
+SVT_DEV void ph_store_pred0(const me_ctx_t *c, int tid, int sox, int soy, uint32_t *pr, int lmax) {
+    const int sub = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH, K = sub ? 2 : 4, levels = me_bipred_levels(c) < lmax ? me_bipred_levels(c) : lmax;
     _Pragma("unroll") for (int L = 0; L < 4; L++) {
         if (L >= levels) break;
         const int sh = 8 - 2 * L, l = tid & ((1 << sh) - 1), pu = (int)((0x15050100u >> (8 * L)) & 0xff) + (tid >> sh);
@@ -1442,8 +1476,8 @@ SVT_DEV void ph_store_pred0(const me_ctx_t *c, int tid, int sox, int soy, uint32
     }
 }
 /* bi-pred distortion: avg-SAD of (list0 pred, list1 pred) vs source (bi_pred_averging :3466-3560) */
-SVT_DEV void ph_bipred(const me_ctx_t *c, int tid, int sox, int soy, const uint32_t *pr) {
-    const int sub = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH, K = sub ? 2 : 4, levels = me_bipred_levels(c);
+SVT_DEV void ph_bipred(const me_ctx_t *c, int tid, int sox, int soy, const uint32_t *pr, int lmax) {
+    const int sub = c->p->fractional_search_method == SVT_SUB_SAD_SEARCH, K = sub ? 2 : 4, levels = me_bipred_levels(c) < lmax ? me_bipred_levels(c) : lmax;
     _Pragma("unroll") for (int L = 0; L < 4; L++) {
         if (L >= levels) break;
         const int sh = 8 - 2 * L, l = tid & ((1 << sh) - 1), pu = (int)((0x15050100u >> (8 * L)) & 0xff) + (tid >> sh);
@@ -2245,9 +2279,13 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         ME_MARK(9);
 #ifndef SVT_HOST_EMU
         /* SUB_SAD refinement of the 32x32 / 16x16 PUs only (the M5+ presets): one phase, see ph_subpel_fast */
+        /* with cu8x8_mode == 1 that holds for both lists whatever the gating says: the 32x32 / 16x16 levels of the bi-prediction
+         * ride on the same lanes (fast_bi), the 64x64 level stays with ph_store_pred0 / ph_bipred */
+        const int fast_bi = nlist == 2 && p->fractional_search_model != 2 && p->fractional_search_method == SVT_SUB_SAD_SEARCH &&
+                            !p->fractional_search64x64 && p->cu16x16_mode == 0 && p->cu8x8_mode == 1;
         if (enq && p->fractional_search_method == SVT_SUB_SAD_SEARCH && !p->fractional_search64x64 && p->cu16x16_mode == 0 &&
             !(en8 && p->cu8x8_mode != 1)) {
-            if (en32 || en16) ME_PHASE(ph_subpel_fast(c, tid, list, sox, soy, en32, en16));
+            if (en32 || en16 || fast_bi) ME_PHASE(ph_subpel_fast(c, tid, list, sox, soy, en32, en16, fast_bi, ME_PRED0_REGS));
             ME_MARK(10);
             ME_MARK(11);
         } else
@@ -2266,10 +2304,15 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
             ME_MARK(11);
         }
         if (nlist == 2) {
-            if (list == 0) ME_PHASE(ph_store_pred0(c, tid, sox, soy, ME_PRED0_REGS));
+#ifdef SVT_HOST_EMU
+            const int lmax = 4, czero = 85;
+#else
+            const int lmax = fast_bi ? 1 : 4, czero = fast_bi ? 1 : 85; /* fast_bi: levels 1, 2 are done, cand[1..20] hold their sums */
+#endif
+            if (list == 0) ME_PHASE(ph_store_pred0(c, tid, sox, soy, ME_PRED0_REGS, lmax));
             else {
-                ME_PHASE(for (int t = tid; t < 85; t += SVT_NT) c->cand[t] = 0);
-                ME_PHASE(ph_bipred(c, tid, sox, soy, ME_PRED0_REGS));
+                ME_PHASE(for (int t = tid; t < czero; t += SVT_NT) c->cand[t] = 0);
+                ME_PHASE(ph_bipred(c, tid, sox, soy, ME_PRED0_REGS, lmax));
             }
             ME_MARK(12);
         }
