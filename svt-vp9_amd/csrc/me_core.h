@@ -1264,6 +1264,7 @@ SVT_DEV void ph_quarterpel_decide(const me_ctx_t *c, int tid, int list, int en32
  * back without a barrier -- and the three quarter-pel candidates around that direction follow the same way
  * (pu_quarter_pel_refinement_on_the_fly :2471-2715).  No candidate table, no atomics, no barrier inside. */
 SVT_DEV void me_pred_ptrs(const me_ctx_t *c, int list, int sox, int soy, int pu, int px, int py, const uint8_t **a, const uint8_t **b, int *sa, int *sb);
+SVT_DEV uint32_t me_pred_fetch(const uint8_t *a, const uint8_t *b, int offa, int offb);
 SVT_DEV uint32_t me_sad16(const uint8_t *p, const uint32_t s[4]) { /* 16 samples at any byte alignment in LDS against 4 source dwords */
     const uint32_t  sh = (uint32_t)((uintptr_t)p & 3);
     const uint32_t *q  = (const uint32_t *)(p - sh);
@@ -1412,6 +1413,19 @@ SVT_DEV void ph_subpel_fast(const me_ctx_t *c, int tid, int list, int sox, int s
             d = me_pu_lanes_sum(d, big);
             if (last) c->cand[pu] = d;
         }
+        /* the 64x64 PU (never refined on this path: its vector is the full-pel one): every lane takes dword tid & 15 of the
+         * subsampled rows 2 (tid >> 4) and 2 (tid >> 4) + 32; wave sums into cand[0], which the position-decode phase zeroed */
+        const uint8_t *a0, *b0;
+        int            sa0, sb0;
+        me_pred_ptrs(c, list, sox, soy, 0, 0, 0, &a0, &b0, &sa0, &sb0);
+        uint32_t d0 = 0;
+        _Pragma("unroll") for (int k = 0; k < 2; k++) {
+            const int      rr = 2 * (tid >> 4) + 32 * k, ii = tid & 15;
+            const uint32_t vb = me_pred_fetch(a0, b0, ME_MUL(rr, sa0) + 4 * ii, ME_MUL(rr, sb0) + 4 * ii);
+            if (list == 0) pr[k] = vb;
+            else d0 = svt_sad4(svt_avg4(pr[k], vb), *(const uint32_t *)(c->src + rr * ME_SB + 4 * ii), d0);
+        }
+        if (list != 0) svt_wave_add_u32(&c->cand[0], d0, 1);
     }
 }
 #endif
@@ -2225,6 +2239,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                 if (t < 85) {
                     const uint64_t k = st->key[t];
                     const uint32_t idx = (uint32_t)k;
+                    if (t == 0 && list == 1) c->cand[0] = 0; /* (after the read: the table may share the keys' bytes) bi-prediction sum of the 64x64 PU */
                     sd = (uint32_t)(k >> 32);
                     st->best_sad[list][t] = sd;
                     if (sd != (uint32_t)ME_MAX_SAD_VALUE) {
@@ -2307,9 +2322,10 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
 #ifdef SVT_HOST_EMU
             const int lmax = 4, czero = 85;
 #else
-            const int lmax = fast_bi ? 1 : 4, czero = fast_bi ? 1 : 85; /* fast_bi: levels 1, 2 are done, cand[1..20] hold their sums */
+            const int lmax = fast_bi ? 0 : 4, czero = 85; /* fast_bi: every level is done, cand[0..20] hold the sums */
 #endif
-            if (list == 0) ME_PHASE(ph_store_pred0(c, tid, sox, soy, ME_PRED0_REGS, lmax));
+            if (lmax == 0) { /* nothing left */ }
+            else if (list == 0) ME_PHASE(ph_store_pred0(c, tid, sox, soy, ME_PRED0_REGS, lmax));
             else {
                 ME_PHASE(for (int t = tid; t < czero; t += SVT_NT) c->cand[t] = 0);
                 ME_PHASE(ph_bipred(c, tid, sox, soy, ME_PRED0_REGS, lmax));
