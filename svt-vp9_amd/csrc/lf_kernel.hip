@@ -257,12 +257,22 @@ __device__ __forceinline__ void lf_line(uint8_t *s, int st, int nblk, const uint
  * workgroup of the next SB row inside the same launch, so they move with agent-scope (sc1, write-through / L2-bypass)
  * 8-byte accesses -- no release/acquire fence is needed for them (cdna_hip_programming.md, guideline 16).  Up to UNITS
  * loads per lane are in flight before the first store.  Plane rows must be 8-byte (wide) or 4-byte aligned. */
+/* t / nu for the tile copies (units per tile row: at most 18): reciprocals from constant memory, one v_mul_hi per unit instead
+ * of an integer division (~25 instructions) -- the copy waves spent most of their instructions dividing */
+struct lf_magic_table {
+    uint32_t v[33];
+    constexpr lf_magic_table() : v() { for (uint32_t d = 1; d <= 32; d++) v[d] = (uint32_t)(0xffffffffu / d) + 1u; }
+};
+__constant__ const lf_magic_table lf_magics = lf_magic_table();
+__device__ __forceinline__ int lf_udiv(int t, int d, uint32_t inv) { return d > 32 ? t / d : inv ? (int)__umulhi((uint32_t)t, inv) : t; }
+
 template <int UNITS, typename UT>
 __device__ __forceinline__ void tile_io_t(bool load, uint8_t *g, int gstride, uint8_t *l, int lstride, int x0, int y0, int tx0, int ty0,
                                           int nx, int ny, int seam_lo_end, int seam_hi_begin, int lane, int nlanes,
                                           const volatile int LF_LDS *wait_flag, int wait_val) {
     constexpr int UB = (int)sizeof(UT);      /* unit = 8 bytes, or 4 when the plane rows are only 4-byte aligned */
     const int nu = nx / UB, total = nu * ny;
+    const uint32_t inv = lf_magics.v[nu <= 32 ? nu : 0];
     for (int t0 = lane; t0 < total; t0 += UNITS * nlanes) {
         UT  v[UNITS];
         int lo[UNITS];
@@ -270,7 +280,7 @@ __device__ __forceinline__ void tile_io_t(bool load, uint8_t *g, int gstride, ui
             const int t = t0 + u * nlanes;
             lo[u] = -1;
             if (t < total) {
-                const int  r = t / nu, ty = ty0 + r, tx = tx0 + UB * (t - r * nu);
+                const int  r = lf_udiv(t, nu, inv), ty = ty0 + r, tx = tx0 + UB * (t - r * nu);
                 UT LF_GLOBAL *gp = LF_AS_GLOBAL(UT, g + (ptrdiff_t)(y0 + ty) * gstride + x0 + tx);
                 const bool seam = ty < seam_lo_end || ty >= seam_hi_begin;
                 lo[u] = ty * lstride + tx;
@@ -365,7 +375,7 @@ __global__ __launch_bounds__(128) void svt_lf_desc_kernel(const lf_pic_dev *__re
  *           descriptors (svt_lf_desc_kernel) into the other buffer;
  *   wave 3  writes the finished columns of the tile filtered in the previous step back and publishes the row's progress.
  * One workgroup barrier per SB; wave 2 lets its loads fly while wave 3 is still reading the buffer they will land in.  Tile rows 0-7 (top halo) and the SB's last 8 rows are seam rows (sc1 accesses). */
-__global__ __launch_bounds__(256) void svt_lf_kernel(const lf_pic_dev *__restrict__ pics, int n_pics, svt_lf_thresh thr,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void svt_lf_kernel(const lf_pic_dev *__restrict__ pics, int n_pics, svt_lf_thresh thr,
                                                      uint32_t *__restrict__ ticket, int rows_per_pic, int prof) {
     __shared__ __align__(16) uint8_t ytile[2][YROWS * YS];
     __shared__ __align__(16) uint8_t ctile[2][2][CROWS * CS];
