@@ -43,6 +43,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC != 0 ?
         me_lds_layout_geom(&pp, &G);
         L.region_stride = G.region_stride; L.plane_stride = G.plane_stride; L.plane_bytes = G.plane_bytes; L.region_rows = G.region_rows;
         L.cand_dwords = G.cand_dwords; L.scratch_bytes = G.scratch_bytes;
+        L.off_state = G.off_state; L.off_src = G.off_src; L.off_region = G.off_region; L.off_planes = G.off_planes;
+        L.off_quarter = G.off_quarter; L.off_ssd = G.off_ssd; L.off_cand = G.off_cand; L.off_pred0 = G.off_pred0;
     }
     c.L   = L;
     c.lds = svt_lds;
