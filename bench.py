@@ -283,16 +283,26 @@ def main():
     B.check(lib.svt_hip_ctx_synchronize(ctx_me))
     pa_idx = list(range(1, MINIGOP + 1))
 
-    # ---- stage "me": one batched launch per temporal layer (parameters differ per layer) ----
+    # ---- stage "me": one batched launch per temporal layer ----
     results = [dev_zeros((nsb, 85 * 10), torch.int32) for _ in range(MINIGOP + 1)]
+    # One launch per temporal layer, spread over the ME streams.  SVT_BENCH_ME_ONE_LAUNCH=1: the whole mini-GOP in one launch
+    # (the per-picture parameters -- list count, temporal layer, same_ref_poc -- travel with the picture descriptors either
+    # way: svt_hip_me_batch_layers_device).  Measured: ME alone 1.485 ms in one launch against 1.505 in five, but the whole
+    # step 3.21 against 3.16 ms -- five launches on two streams interleave better with the EncDec-side kernels.
+    per_layer = not os.environ.get("SVT_BENCH_ME_ONE_LAUNCH")
     me_launch_sets = []
     for pa_pics in pa_sets:
         me_launches = []
-        for layer in range(5):
-            idx = [i for i in range(1, MINIGOP + 1) if LAYER[i - 1] == layer]
-            p = B.me_params_preset(Wd, Hd, 8, 1, 2, layer, 4)
-            p.same_ref_poc = 1 if layer == 0 else 0
+        if per_layer:
+            groups = [[i for i in range(1, MINIGOP + 1) if LAYER[i - 1] == layer] for layer in range(5)]
+        else:   # the whole mini-GOP in one launch, biggest search areas (lowest layers) first
+            groups = [sorted(range(1, MINIGOP + 1), key=lambda i: LAYER[i - 1])]
+        for idx in groups:
             n = len(idx)
+            p = (B.MeParams * n)()
+            for k_, i in enumerate(idx):
+                p[k_] = B.me_params_preset(Wd, Hd, 8, 1, 2, LAYER[i - 1], 4)
+                p[k_].same_ref_poc = 1 if LAYER[i - 1] == 0 else 0
             cur = (B.PaPicture * n)(*[pa_pics[i] for i in idx])
             r0 = (B.PaPicture * n)(*[pa_pics[refs_of(i)[0]] for i in idx])
             r1 = (B.PaPicture * n)(*[pa_pics[refs_of(i)[1]] for i in idx])
@@ -322,7 +332,7 @@ def main():
             if record:
                 e0, e1 = me_pool.pop(), me_pool.pop()
                 e0.record(me_streams[k_])
-            B.check(lib.svt_hip_me_batch_device(me_ctxs[k_], n, cur, r0, r1, C.byref(p), res, None))
+            B.check(lib.svt_hip_me_batch_layers_device(me_ctxs[k_], n, cur, r0, r1, p, res, None))
             if record:
                 e1.record(me_streams[k_])
                 me_ev.append((e0, e1))

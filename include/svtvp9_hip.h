@@ -211,6 +211,14 @@ int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_p
                                 const svt_pa_picture *ref0, const svt_pa_picture *ref1,
                                 const svt_me_params *params, svt_me_pu_result *const *d_results,
                                 uint32_t *const *d_rcme_distortion);
+/* The same with one parameter set PER PICTURE (params[i] for picture i): the pictures of a mini-GOP differ in
+ * num_ref_lists, temporal_layer_index, hierarchical_levels and same_ref_poc only (everything else follows from the
+ * configuration: Codec/EbMotionEstimationProcess.c:541-720), so one launch serves all its temporal layers -- no launch
+ * tails between the layers.  Returns SVT_HIP_ERR_BAD_PARAMETER when the sets differ in any other field. */
+int32_t svt_hip_me_batch_layers_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture *cur,
+                                       const svt_pa_picture *ref0, const svt_pa_picture *ref1,
+                                       const svt_me_params *params, svt_me_pu_result *const *d_results,
+                                       uint32_t *const *d_rcme_distortion);
 
 /* Host-pointer convenience form (what the reference's ME thread would call): uploads the planes,
  * runs svt_hip_me_picture_device, downloads results[n_sb][85], synchronous. */

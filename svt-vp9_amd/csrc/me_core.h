@@ -233,6 +233,10 @@ typedef struct me_pic_dev {
     svt_pa_picture    cur, ref[2];
     svt_me_pu_result *results;
     uint32_t         *rcme;
+    /* the parameters that change from picture to picture inside a configuration (me_spec.h) and what the host derives from
+     * them (HME level-0 areas scaled by the temporal layer's multiplier): one launch serves pictures of several layers */
+    uint8_t           num_ref_lists, temporal_layer_index, hierarchical_levels, same_ref_poc;
+    int16_t           hme_w0[2], hme_h0[2], hme_tw0, hme_th0;
 } me_pic_dev;
 
 /* LDS layout (byte offsets), computed on the host from the parameters (me_lds_layout) */

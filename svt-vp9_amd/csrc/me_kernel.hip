@@ -29,13 +29,19 @@ extern __shared__ __align__(16) uint8_t svt_lds[];
 template <int SPEC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC != 0 ? ME_WAVES_PER_EU_SPEC : ME_WAVES_PER_EU))) void svt_me_sb_kernel(const me_pic_dev *__restrict__ pics, svt_me_params p, me_lds_layout L,
                                                         int n_sb, int nx, int pic_w, int pic_h, int total, int chunk, unsigned long long *prof) {
-    const int b = blockIdx.x;
-    const int l = (b & 7) * chunk + (b >> 3);
-    if (l >= total) return;
-    const int pic = l / n_sb, sb = l - pic * n_sb;
+    /* block b runs on XCD b & 7: XCD k takes the k-th eighth of the SBs of EVERY picture (chunk SBs each; pictures of different
+     * temporal layers cost differently, an XCD per picture range would leave the XCDs unbalanced), in picture order */
+    const int b = blockIdx.x, j = b >> 3;
+    const int pic = j / chunk, sb = (b & 7) * chunk + (j - pic * chunk);
+    if (sb >= n_sb || pic * n_sb >= total) return;
     me_ctx_t  c;
     c.pic = &pics[pic];
     svt_me_params pp = p;
+    /* per-picture parameters travel with the picture (a launch may mix temporal layers) */
+    pp.num_ref_lists = c.pic->num_ref_lists; pp.temporal_layer_index = c.pic->temporal_layer_index;
+    pp.hierarchical_levels = c.pic->hierarchical_levels; pp.same_ref_poc = c.pic->same_ref_poc;
+    L.hme_w0[0] = c.pic->hme_w0[0]; L.hme_w0[1] = c.pic->hme_w0[1]; L.hme_h0[0] = c.pic->hme_h0[0]; L.hme_h0[1] = c.pic->hme_h0[1];
+    L.hme_tw0 = c.pic->hme_tw0; L.hme_th0 = c.pic->hme_th0;
     if constexpr (SPEC != 0) me_spec_apply<SPEC>(&pp); /* constants equal to the caller's values (me_spec_match) */
     c.p   = &pp;
     if constexpr (SPEC != 0) { /* the same values as the host's, as compile-time constants */
@@ -120,16 +126,29 @@ __global__ __launch_bounds__(256) void svt_sad_loop_kernel(const uint8_t *__rest
 /* ------------------------------------------------------------------------------------------------ */
 /* launchers                                                                                          */
 /* ------------------------------------------------------------------------------------------------ */
-extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture *cur,
-                                           const svt_pa_picture *ref0, const svt_pa_picture *ref1,
-                                           const svt_me_params *params, svt_me_pu_result *const *d_results,
-                                           uint32_t *const *d_rcme) {
-    if (!ctx || !cur || !ref0 || !params || !d_results || n_pics < 1) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: null argument");
-    if (params->num_ref_lists < 1 || params->num_ref_lists > 2) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: num_ref_lists");
-    if (params->num_ref_lists == 2 && !ref1) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: ref1 missing for B picture");
-    if (params->hierarchical_levels > 5 || params->temporal_layer_index > 5 || params->number_hme_search_region_in_width > 2 ||
-        params->number_hme_search_region_in_height > 2)
-        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: parameter out of range");
+/* the fields that may differ between the pictures of one launch (me_spec.h: everything else is constant inside a configuration) */
+static bool me_params_same_config(const svt_me_params *a, const svt_me_params *b) {
+    svt_me_params x = *a, y = *b;
+    x.num_ref_lists = y.num_ref_lists = 0; x.temporal_layer_index = y.temporal_layer_index = 0;
+    x.hierarchical_levels = y.hierarchical_levels = 0; x.same_ref_poc = y.same_ref_poc = 0;
+    return memcmp(&x, &y, sizeof x) == 0;
+}
+
+/* params_stride = 0: one parameter set for every picture; 1: params[i] belongs to picture i */
+static int32_t me_launch(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture *cur, const svt_pa_picture *ref0, const svt_pa_picture *ref1,
+                         const svt_me_params *params_all, int params_stride, svt_me_pu_result *const *d_results, uint32_t *const *d_rcme) {
+    if (!ctx || !cur || !ref0 || !params_all || !d_results || n_pics < 1) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: null argument");
+    const svt_me_params *params = params_all;
+    for (int i = 0; i < (params_stride ? n_pics : 1); i++) {
+        const svt_me_params *q = &params_all[i];
+        if (q->num_ref_lists < 1 || q->num_ref_lists > 2) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: num_ref_lists");
+        if (q->num_ref_lists == 2 && !ref1) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: ref1 missing for B picture");
+        if (q->hierarchical_levels > 5 || q->temporal_layer_index > 5 || q->number_hme_search_region_in_width > 2 ||
+            q->number_hme_search_region_in_height > 2)
+            return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: parameter out of range");
+        if (i && !me_params_same_config(params, q))
+            return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: the pictures of one launch may differ in num_ref_lists, temporal_layer_index, hierarchical_levels and same_ref_poc only");
+    }
     me_lds_layout L;
     if (me_lds_layout_compute(params, &L)) return svt_set_error(SVT_HIP_ERR_UNSUPPORTED, "me: search area does not fit in LDS");
     const int W = cur[0].full.width, H = cur[0].full.height;
@@ -147,9 +166,16 @@ extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, con
         if (ref1) h[i].ref[1] = ref1[i];
         h[i].results = d_results[i];
         h[i].rcme    = d_rcme ? d_rcme[i] : nullptr;
+        const svt_me_params *q = &params_all[params_stride ? i : 0];
+        me_lds_layout        Li;
+        if (me_lds_layout_compute(q, &Li)) return svt_set_error(SVT_HIP_ERR_UNSUPPORTED, "me: search area does not fit in LDS");
+        h[i].num_ref_lists = q->num_ref_lists; h[i].temporal_layer_index = q->temporal_layer_index;
+        h[i].hierarchical_levels = q->hierarchical_levels; h[i].same_ref_poc = q->same_ref_poc;
+        h[i].hme_w0[0] = Li.hme_w0[0]; h[i].hme_w0[1] = Li.hme_w0[1]; h[i].hme_h0[0] = Li.hme_h0[0]; h[i].hme_h0[1] = Li.hme_h0[1];
+        h[i].hme_tw0 = Li.hme_tw0; h[i].hme_th0 = Li.hme_th0;
     }
     HIP_TRY(hipMemcpyAsync(d, h, sizeof(me_pic_dev) * (size_t)n_pics, hipMemcpyHostToDevice, ctx->stream));
-    const int total = n_sb * n_pics, chunk = (total + 7) / 8;
+    const int total = n_sb * n_pics, chunk = (n_sb + 7) / 8; /* SBs of one picture per XCD */
     /* SVT_HIP_ME_PROFILE=1: per-phase shader-cycle breakdown (thread 0 of every workgroup), printed to stderr */
     static const bool want_prof = getenv("SVT_HIP_ME_PROFILE") != nullptr;
     unsigned long long *d_prof = nullptr;
@@ -167,7 +193,7 @@ extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, con
 #define ME_LAUNCH(S) \
     if (L.total_bytes > 64 * 1024) \
         HIP_TRY(hipFuncSetAttribute((const void *)svt_me_sb_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total_bytes)); \
-    hipLaunchKernelGGL(svt_me_sb_kernel<S>, dim3(chunk * 8), dim3(256), L.total_bytes, ctx->stream, d, *params, L, n_sb, nx, W, H, total, chunk, d_prof)
+    hipLaunchKernelGGL(svt_me_sb_kernel<S>, dim3(chunk * 8 * n_pics), dim3(256), L.total_bytes, ctx->stream, d, *params, L, n_sb, nx, W, H, total, chunk, d_prof)
     case 1: ME_LAUNCH(1); break;
     case 2: ME_LAUNCH(2); break;
     case 3: ME_LAUNCH(3); break;
@@ -195,6 +221,19 @@ extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, con
     svt_ctx_stage_commit(ctx);
     ctx->timed = 1;
     return SVT_HIP_OK;
+}
+
+extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture *cur,
+                                           const svt_pa_picture *ref0, const svt_pa_picture *ref1,
+                                           const svt_me_params *params, svt_me_pu_result *const *d_results,
+                                           uint32_t *const *d_rcme) {
+    return me_launch(ctx, n_pics, cur, ref0, ref1, params, 0, d_results, d_rcme);
+}
+extern "C" int32_t svt_hip_me_batch_layers_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture *cur,
+                                                  const svt_pa_picture *ref0, const svt_pa_picture *ref1,
+                                                  const svt_me_params *params, svt_me_pu_result *const *d_results,
+                                                  uint32_t *const *d_rcme) {
+    return me_launch(ctx, n_pics, cur, ref0, ref1, params, 1, d_results, d_rcme);
 }
 
 extern "C" int32_t svt_hip_me_picture_device(svt_hip_ctx *ctx, const svt_pa_picture *cur, const svt_pa_picture *ref0,

@@ -80,3 +80,51 @@ def test_me_random_content(ctx):
     _check(ctx, pics, MC.preset("c3_2160p_m8", 2, 1), 2)
     flat = [T.PaPic(np.full((192, 256), v, dtype=np.uint8)) for v in (10, 10, 12)]
     _check(ctx, flat, MC.preset("c2_1080p_m8", 2, 1), 2)  # all-tie case: first minimum in raster order
+
+
+def test_me_batch_layers_one_launch(ctx):
+    """svt_hip_me_batch_layers_device: pictures of different temporal layers / list counts in ONE launch (per-picture
+    parameters travel with the picture descriptors) -- every picture equals the oracle run with its own parameters; parameter
+    sets that differ in a configuration field are refused."""
+    import torch
+    lib = B.load()
+    dev = torch.device("cuda", 0)
+    w, h = 384, 256
+    frames = T.gen_clip_subpel(w, h, 4, 31)
+    pics = [T.PaPic(f) for f in frames]
+    keep = []
+
+    def dev_desc(pa):
+        d = B.PaPicture()
+        for name, (a, pad) in zip(("full", "quarter", "sixteenth"), pa.planes()):
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            keep.append(t)
+            pl = B.Plane()
+            pl.buf, pl.stride, pl.origin_x, pl.origin_y = t.data_ptr(), t.shape[1], pad, pad
+            pl.width, pl.height = t.shape[1] - 2 * pad, t.shape[0] - 2 * pad
+            setattr(d, name, pl)
+        return d
+
+    d = [dev_desc(p_) for p_ in pics]
+    nsb = T.n_sb(w, h)
+    cases = [(1, 0, 3, (2, 0, 1)), (2, 0, 3, (2, 2, 0)), (1, 0, 2, (1, 3, 0)), (2, 1, 3, (2, 4, 0))]  # cur, ref0, ref1, (nl, tl, same_poc)
+    n = len(cases)
+    params = (B.MeParams * n)()
+    for i, (_, _, _, (nl, tl, sp)) in enumerate(cases):
+        p = MC.preset("c3_2160p_m8", nl, tl)
+        p.same_ref_poc = sp
+        params[i] = p
+    cur = (B.PaPicture * n)(*[d[c_] for c_, _, _, _ in cases])
+    r0 = (B.PaPicture * n)(*[d[a] for _, a, _, _ in cases])
+    r1 = (B.PaPicture * n)(*[d[b] for _, _, b, _ in cases])
+    res = [torch.zeros((nsb, 85 * 10), dtype=torch.int32, device=dev) for _ in range(n)]
+    rp = (C.c_void_p * n)(*[t.data_ptr() for t in res])
+    B.check(lib.svt_hip_me_batch_layers_device(ctx, n, cur, r0, r1, params, rp, None))
+    B.check(lib.svt_hip_ctx_synchronize(ctx))
+    for i, (c_, a, b, (nl, tl, sp)) in enumerate(cases):
+        g = res[i].cpu().numpy().view(B.ME_RESULT_DTYPE).reshape(nsb, 85)
+        o, _ = T.oracle_me_picture(pics[c_], pics[a], pics[b] if nl == 2 else None, params[i])
+        assert not T.me_results_equal(o, g, nl), (i, nl, tl)
+    bad = (B.MeParams * n)(*[params[i] for i in range(n)])
+    bad[2].search_area_width = 16
+    assert lib.svt_hip_me_batch_layers_device(ctx, n, cur, r0, r1, bad, rp, None) == -1  # SVT_HIP_ERR_BAD_PARAMETER
