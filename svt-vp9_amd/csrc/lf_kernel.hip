@@ -40,6 +40,7 @@ constexpr int CS = 44, CROWS = 40;   /* chroma tile stride / rows (8 halo + 32) 
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int sclamp(int t) { return t < -128 ? -128 : t > 127 ? 127 : t; }
+__device__ __forceinline__ int uclamp(int t) { return t < 0 ? 0 : t > 255 ? 255 : t; }
 
 /* One sample position across an edge (VPX/loopfilter.c filter_mask :31, flat_mask4/5 :44-63, hev_mask :65, filter4 :72,
  * filter8 :147, filter16 :209), on registers: p[0] = p0 (nearest the edge) ... p[7] = p7, q[0] = q0 ... q[7] = q7; kind 4
@@ -68,13 +69,14 @@ __device__ __forceinline__ void filter_regs(int (&p)[8], int (&q)[8], int kind, 
     /* filter4: signed 8-bit arithmetic; with mask = 0 every step yields 0 and the samples come out unchanged */
     const int m = mask ? -1 : 0;
     const int hev = max(d10, e10) > hev_thr ? -1 : 0;
-    const int ps1 = (int8_t)(p1 ^ 0x80), ps0 = (int8_t)(p0 ^ 0x80), qs0 = (int8_t)(q0 ^ 0x80), qs1 = (int8_t)(q1 ^ 0x80);
-    int f = sclamp(ps1 - qs1) & hev;
-    f = sclamp(f + 3 * (qs0 - ps0)) & m;
+    /* the reference works on samples biased by -128 (x ^ 0x80 as int8): the bias cancels in the two differences, and
+     * signed_char_clamp(xs +- f) ^ 0x80 == clamp(x +- f, 0, 255) -- no conversions needed */
+    int f = sclamp(p1 - q1) & hev;
+    f = sclamp(f + 3 * (q0 - p0)) & m;
     const int f1 = sclamp(f + 4) >> 3, f2_ = sclamp(f + 3) >> 3;
-    int       o_q0 = (uint8_t)(sclamp(qs0 - f1) ^ 0x80), o_p0 = (uint8_t)(sclamp(ps0 + f2_) ^ 0x80);
+    int       o_q0 = uclamp(q0 - f1), o_p0 = uclamp(p0 + f2_);
     f = ((f1 + 1) >> 1) & ~hev;
-    int o_q1 = (uint8_t)(sclamp(qs1 - f) ^ 0x80), o_p1 = (uint8_t)(sclamp(ps1 + f) ^ 0x80);
+    int o_q1 = uclamp(q1 - f), o_p1 = uclamp(p1 + f);
     int o_p2 = p2, o_q2 = q2;
     if (__builtin_amdgcn_ballot_w64(use_flat && !use16)) { /* filter8 for the lanes that take it */
         int s = 3 * p3 + 2 * p2 + p1 + p0 + q0 + 4, r;
