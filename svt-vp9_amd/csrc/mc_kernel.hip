@@ -50,6 +50,14 @@ __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
 /* ROUND_POWER_OF_TWO(sum, 7) then clip_pixel; `acc` already holds the +64 and the bias correction */
 __device__ __forceinline__ uint32_t finish(int acc) { return (uint32_t)clampi(acc >> 7, 0, 255); }
+/* first dot product of a chain: acc = dot4(a, b) + bias with the bias as a scalar operand.  Written as the VOP3 instruction: the
+ * compiler otherwise picks the accumulate-in-place form (v_dot4c) and copies the bias into a fresh register for every chain --
+ * one instruction in seven of this kernel */
+__device__ __forceinline__ int dot4_bias(uint32_t a, uint32_t b, int bias) {
+    int r;
+    __asm__("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(bias));
+    return r;
+}
 /* four clipped samples into a dword.  The halves are joined with an explicit v_perm_b32: written as shifts and ors, this
  * hipcc folds the clamps of samples 2 and 3 into the packing and produces wrong bytes (seen on gfx950, ROCm 7.2; the ME
  * kernel's interpolation hit the same fold) */
@@ -88,10 +96,10 @@ __device__ __forceinline__ void mc_tile(const uint8_t *plane, int stride, int x,
         if (!any_sx) { mid[r] = alignbyte(e1, e0, 3); continue; }
         const uint32_t b0 = e0 ^ 0x80808080u, b1 = e1 ^ 0x80808080u, b2 = e2 ^ 0x80808080u;
         const int      bias = 128 * 128 + 64;
-        int            a0 = __builtin_amdgcn_sdot4((int)b1, (int)th, __builtin_amdgcn_sdot4((int)b0, (int)tl, bias, false), false);
-        int            a1 = __builtin_amdgcn_sdot4((int)alignbyte(b2, b1, 1), (int)th, __builtin_amdgcn_sdot4((int)alignbyte(b1, b0, 1), (int)tl, bias, false), false);
-        int            a2 = __builtin_amdgcn_sdot4((int)alignbyte(b2, b1, 2), (int)th, __builtin_amdgcn_sdot4((int)alignbyte(b1, b0, 2), (int)tl, bias, false), false);
-        int            a3 = __builtin_amdgcn_sdot4((int)alignbyte(b2, b1, 3), (int)th, __builtin_amdgcn_sdot4((int)alignbyte(b1, b0, 3), (int)tl, bias, false), false);
+        int            a0 = __builtin_amdgcn_sdot4((int)b1, (int)th, dot4_bias(b0, tl, bias), false);
+        int            a1 = __builtin_amdgcn_sdot4((int)alignbyte(b2, b1, 1), (int)th, dot4_bias(alignbyte(b1, b0, 1), tl, bias), false);
+        int            a2 = __builtin_amdgcn_sdot4((int)alignbyte(b2, b1, 2), (int)th, dot4_bias(alignbyte(b1, b0, 2), tl, bias), false);
+        int            a3 = __builtin_amdgcn_sdot4((int)alignbyte(b2, b1, 3), (int)th, dot4_bias(alignbyte(b1, b0, 3), tl, bias), false);
         const uint32_t f = pack4(finish(a0), finish(a1), finish(a2), finish(a3));
         mid[r] = sx ? f : alignbyte(e1, e0, 3); /* phase 0: the samples themselves (bytes 3..6) */
     }
@@ -115,7 +123,7 @@ __device__ __forceinline__ void mc_tile(const uint8_t *plane, int stride, int x,
         const int g0 = yy >> 2, sft = yy & 3;
         _Pragma("unroll") for (int j = 0; j < 4; j++) {
             const uint32_t lo = sft ? alignbyte(col[j][g0 + 1], col[j][g0], sft) : col[j][g0], hi = sft ? alignbyte(col[j][g0 + 2], col[j][g0 + 1], sft) : col[j][g0 + 1];
-            o[j] = finish(__builtin_amdgcn_sdot4((int)hi, (int)vh, __builtin_amdgcn_sdot4((int)lo, (int)vl, 128 * 128 + 64, false), false));
+            o[j] = finish(__builtin_amdgcn_sdot4((int)hi, (int)vh, dot4_bias(lo, vl, 128 * 128 + 64), false));
         }
         out[yy] = sy ? pack4(o[0], o[1], o[2], o[3]) : mid[yy + 3];
     }
