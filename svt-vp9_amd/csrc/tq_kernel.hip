@@ -46,6 +46,29 @@ __device__ __forceinline__ tq_walk tq_walk_of(int ngroups) {
     return w;
 }
 
+/* all-reduce over the N (8, 16 or 32) lanes of a block with DPP instead of ds_bpermute shuffles (~90 cycles each and two address
+ * instructions; the eob all-reduce sits on the critical path in front of the rate walk): after quad_perm [1,0,3,2] and [2,3,0,1]
+ * the four lanes of a quad agree, row_half_mirror (i <-> 7 - i) then brings the other quad, row_mirror (i <-> 15 - i) the other
+ * eight, and for 32 lanes one ds_swizzle (lane ^ 16) the other row. */
+#define TQ_DPP(v, ctrl) __builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xf, 0xf, false)
+template <int N> __device__ __forceinline__ int tq_lanes_max(int v) {
+    int o;
+    o = TQ_DPP(v, 0xB1); v = o > v ? o : v;
+    o = TQ_DPP(v, 0x4E); v = o > v ? o : v;
+    if constexpr (N >= 8) { o = TQ_DPP(v, 0x141); v = o > v ? o : v; }
+    if constexpr (N >= 16) { o = TQ_DPP(v, 0x140); v = o > v ? o : v; }
+    if constexpr (N >= 32) { o = __builtin_amdgcn_ds_swizzle(v, 0x401F); v = o > v ? o : v; }
+    return v;
+}
+template <int N> __device__ __forceinline__ uint32_t tq_lanes_sum(uint32_t v) {
+    v += (uint32_t)TQ_DPP(v, 0xB1);
+    v += (uint32_t)TQ_DPP(v, 0x4E);
+    if constexpr (N >= 8) v += (uint32_t)TQ_DPP(v, 0x141);
+    if constexpr (N >= 16) v += (uint32_t)TQ_DPP(v, 0x140);
+    if constexpr (N >= 32) v += (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);
+    return v;
+}
+
 /* threads per workgroup.  The fused-rate instances keep their LDS (transpose tiles + cost slices + scan tables) under
  * 32 000 bytes = the LDS one motion-estimation workgroup releases when it retires (25 granules of 1280 bytes): on a CU that
  * the ME kernel has filled, a transform workgroup can then move into the first hole instead of waiting for two. */
@@ -283,10 +306,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 4
         }
         if (level && active) { const int pos = (int)((isw[kk >> 1] >> (16 * (kk & 1))) & 0xffff) + 1; eob = pos > eob ? pos : eob; }
     }
-    _Pragma("unroll") for (int off = 1; off < N; off <<= 1) { const int other = __shfl_xor(eob, off); eob = other > eob ? other : eob; }
+    eob = tq_lanes_max<N>(eob);
     if (active && i == 0) eob_out[blk] = (uint16_t)eob;
     if (dist_out) { /* T3: coefficient-domain distortion of the block, summed over its N lanes */
-        _Pragma("unroll") for (int off = 1; off < N; off <<= 1) { rdist += __shfl_xor(rdist, off); pdist += __shfl_xor(pdist, off); }
+        rdist = tq_lanes_sum<N>(rdist); pdist = tq_lanes_sum<N>(pdist);
         if (active && i == 0) { dist_out[2 * blk] = rdist; dist_out[2 * blk + 1] = pdist; }
     }
     if constexpr (RATE) {
@@ -295,7 +318,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 4
         const int16_t *sc = s_scan + tx_type * SCAN_T; /* tx_type is 0 for 32x32 */
         int bits = rate_positions<N>((const int16_t *)t, sc, sc + N * N, s_tc + (ptype * 2 + inter) * RATE_SLICE, ra.T, i, eob, N * N,
                                      txcfg<N>::size, ctx0);
-        _Pragma("unroll") for (int off = 1; off < N; off <<= 1) bits += __shfl_xor(bits, off);
+        bits = (int)tq_lanes_sum<N>((uint32_t)bits);
         if (active && i == 0) ra.bits[blk] = bits;
     }
     if (k.do_recon) { /* uniform within a size group (launcher contract): the barriers below stay workgroup-uniform */
