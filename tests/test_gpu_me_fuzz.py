@@ -1,0 +1,16 @@
+"""Randomised ME parity sweep (tools/me_fuzz.py): random sizes incl. partial SBs, five content kinds (smooth / sub-pel motion,
+noise, flat, blocky = tie-heavy), every preset, both list counts, all temporal layers -- HIP == oracle, bit-exact."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed", [101, 202])
+def test_me_random_sweep(seed):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "me_fuzz.py"), "80", str(seed)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
