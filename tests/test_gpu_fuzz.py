@@ -14,3 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_me_random_sweep(seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "me_fuzz.py"), "80", str(seed)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_lf_random_sweep():
+    """tools/lf_fuzz.py: random sizes, masks, levels, sharpness 0..7, noisy and smooth (flat-filter) content"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lf_fuzz.py"), "60", "5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
