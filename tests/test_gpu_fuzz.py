@@ -20,3 +20,10 @@ def test_lf_random_sweep():
     """tools/lf_fuzz.py: random sizes, masks, levels, sharpness 0..7, noisy and smooth (flat-filter) content"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lf_fuzz.py"), "60", "5"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_tq_rd_random_sweep():
+    """tools/tq_fuzz.py: random plane sizes, quantiser steps from tiny (CAT6, full blocks) to huge (empty blocks), extreme
+    residuals, inter / intra mixes -- recon, qcoeff, dqcoeff, eob, distortion pair and bits all equal the oracle's"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "tq_fuzz.py"), "40", "9"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
