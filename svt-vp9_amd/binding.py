@@ -148,6 +148,13 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        # In a process that also uses PyTorch, torch must load ITS HIP runtime first: the product library is linked against
+        # the system's libamdhip64, and whichever copy is loaded second finds no device ("no ROCm-capable device" on either
+        # side).  Plain C hosts are not affected.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.svt_hip_last_error.restype = C.c_char_p
         _lib.svt_hip_ctx_stream.restype = C.c_void_p
