@@ -3,8 +3,8 @@
 # 1. build the library with -DME_FINE_PROF (the kernel then returns after phase SVT_HIP_ME_STOP):
 #      (cd svt-vp9_amd && touch csrc/me_kernel.hip && make HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -DME_FINE_PROF")
 # 2. run this script on the GPU box (gpurun -- 'bash tools/me_phase_profile.sh'), 3. rebuild the product library (touch + make).
-cd /tmp; export TMPDIR=/tmp
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
+cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d /tmp/ph -o p -- python $ROOT/tools/me_phase_counts.py > /dev/null 2>&1
 python3 - <<'PY'
 import csv, glob, collections
