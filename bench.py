@@ -582,9 +582,14 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    # host cost of a step = time to enqueue it while nothing holds the enqueue thread back: over the first steps only -- once the
+    # 64-slot descriptor rings of the contexts are full (~20 steps ahead of the GPU) the thread waits for the GPU and the
+    # figure would read as the GPU's step time
+    n_free = min(args.steps, 16)
+    for i_ in range(args.steps):
         step(record=True)
-    t_enqueued = time.perf_counter() - t0   # host time to enqueue all steps (the GPU runs behind it)
+        if i_ + 1 == n_free:
+            t_enqueued = time.perf_counter() - t0
     sync()
     if world > 1:
         dist.barrier()
@@ -648,7 +653,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3),
+        "host_enqueue_ms_per_step": round(t_enqueued / n_free * 1e3, 3),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
