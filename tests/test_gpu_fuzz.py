@@ -27,3 +27,9 @@ def test_tq_rd_random_sweep():
     residuals, inter / intra mixes -- recon, qcoeff, dqcoeff, eob, distortion pair and bits all equal the oracle's"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "tq_fuzz.py"), "40", "9"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_mc_random_sweep():
+    """tools/mc_fuzz.py: random sizes, motion-vector ranges up to far outside the picture, both use_subpel modes"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mc_fuzz.py"), "60", "4"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

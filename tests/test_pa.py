@@ -51,7 +51,8 @@ def test_oracle_vs_reference_leaf_functions():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h,quarter", [(328, 200, 1), (640, 360, 1), (3840, 2160, 0)])
+@pytest.mark.parametrize("w,h,quarter", [(328, 200, 1), (640, 360, 1), (3840, 2160, 0), (8, 8, 1), (24, 16, 1), (72, 64, 1), (136, 72, 0),
+                                         (1000, 568, 1), (1096, 600, 0)])
 def test_gpu_pa_vs_oracle(w, h, quarter):
     import torch
     lib = B.load()
