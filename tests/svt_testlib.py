@@ -298,7 +298,11 @@ def iscan_array():
 
 def quant_table(q_dc, q_ac):
     """[DC, AC] quantiser rows as eb_vp9_init_quantizer derives them from the step sizes
-    (VPX/vp9_quantize.c:182-265: invert_quant, zbin = ROUND_POWER_OF_TWO(qzbin_factor * q, 7), round = 48*q>>7)."""
+    (VPX/vp9_quantize.c:182-265: invert_quant, zbin = ROUND_POWER_OF_TWO(qzbin_factor * q, 7), round = 48*q>>7).
+    Test-input generator only: any table is a valid quantiser input, and the zero-bin factor used here (64 below step 148) is NOT
+    the reference's (84, get_qzbin_factor :192-204) -- the golden fixtures were produced from these inputs, so it stays.  The
+    tables of a real q index come from svt_hip_quant_tables_init, which is pinned against eb_vp9_init_quantizer for all 256
+    indices (tests/test_tq_params.py) and is what bench.py uses."""
     rec = np.zeros((), dtype=B.QUANT_DTYPE)
     for i, q in enumerate((q_dc, q_ac)):
         t = 1 << 16
