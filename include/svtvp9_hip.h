@@ -541,6 +541,19 @@ int32_t svt_hip_inter_pred_frame(svt_hip_ctx *ctx, const svt_mc_mode_info *mi, i
                                  uint8_t *pred_u, uint8_t *pred_v);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Deblocked reconstruction -> reference picture: the step that closes the loop of the path.
+ *
+ * Replaces pad_ref_and_set_flags (Codec/EbEncDecProcess.c:4822-4851, called after the loop filter at :5696 for every picture
+ * with is_used_as_reference_flag) -> eb_vp9_generate_padding (Codec/EbMcp.c:17-58) on Y with (pad_x, pad_y) and on Cb / Cr
+ * with (pad_x >> 1, pad_y >> 1): the picture's edge samples are replicated into the border of its buffer, in place (in the
+ * reference a reference picture's reconstruction buffer IS the reference picture, allocated with 64 + 16 samples of border,
+ * Codec/EbEncHandle.c:968-971).  pics[i] gives the sample (0,0) pointers and strides of picture i (device memory; the
+ * border of pad_y rows / pad_x columns around each plane must belong to the buffer: stride >= width + 2 pad_x).  The
+ * padded planes are what svt_mc_picture.ref[] expects and what svt_hip_ref_handoff_device ships.  Host array of
+ * descriptors; asynchronous on the context's stream. */
+int32_t svt_hip_ref_pad_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_yuv_planes *pics, int32_t pad_x, int32_t pad_y);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Coefficient rate estimation -- SURVEY 8(f) row 4 (with T3, svt_hip_tq_batch_dist_device, this completes what
  * perform_dist_rate_calc computes per transform block, Codec/EbEncDecProcess.c:700-745).
  *

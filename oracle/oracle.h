@@ -45,6 +45,8 @@ int32_t svt_oracle_me_sb_stats(const svt_me_sb_stats_params *p, const svt_me_pu_
                                const uint32_t *rcme, svt_me_sb_stats *out, uint32_t *hist, uint32_t *full_sb_count);
 /* picture-analysis pre-ME stage: decimate_input_picture + padding (Codec/EbPictureAnalysisProcess.c:5010-5088) */
 int32_t svt_oracle_pa_prepare(const uint8_t *luma, int32_t luma_stride, const svt_pa_picture *out, int32_t make_quarter);
+/* pad_ref_and_set_flags (Codec/EbEncDecProcess.c:4822-4851): eb_vp9_generate_padding on Y, Cb, Cr of a reconstructed picture, in place */
+int32_t svt_oracle_ref_pad(const svt_yuv_planes *pic, int32_t pad_x, int32_t pad_y);
 /* compute_block_mean_compute_variance (Codec/EbPictureAnalysisProcess.c:2115-3356) */
 void    svt_oracle_pa_mean8x8(const uint8_t *p, int32_t stride, uint64_t *mean, uint64_t *mean_sq);
 int32_t svt_oracle_pa_mean_variance(const svt_plane *full, uint8_t *mean_out, uint16_t *var_out);

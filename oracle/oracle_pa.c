@@ -6,6 +6,7 @@
  *   eb_vp9_generate_padding       Source/Lib/Codec/EbMcp.c:17-58 (horizontal replication of every row, then the padded
  *                                 first / last row copied upwards / downwards)
  */
+#include <stddef.h>
 #include <string.h>
 #include "oracle.h"
 
@@ -42,6 +43,14 @@ int32_t svt_oracle_pa_prepare(const uint8_t *luma, int32_t luma_stride, const sv
     return 0;
 }
 
+/* pad_ref_and_set_flags (Source/Lib/Codec/EbEncDecProcess.c:4822-4851): the deblocked reconstruction of a reference picture is
+ * padded in place, Y with (origin_x, origin_y), Cb and Cr with half of it (width >> 1, height >> 1, origin >> 1) */
+int32_t svt_oracle_ref_pad(const svt_yuv_planes *pic, int32_t pad_x, int32_t pad_y) {
+    generate_padding(pic->y - pad_x - (ptrdiff_t)pad_y * pic->y_stride, pic->y_stride, pic->width, pic->height, pad_x, pad_y);
+    generate_padding(pic->u - (pad_x >> 1) - (ptrdiff_t)(pad_y >> 1) * pic->uv_stride, pic->uv_stride, pic->width >> 1, pic->height >> 1, pad_x >> 1, pad_y >> 1);
+    generate_padding(pic->v - (pad_x >> 1) - (ptrdiff_t)(pad_y >> 1) * pic->uv_stride, pic->uv_stride, pic->width >> 1, pic->height >> 1, pad_x >> 1, pad_y >> 1);
+    return 0;
+}
 
 /* compute_block_mean_compute_variance (Codec/EbPictureAnalysisProcess.c:2115-3356), the path taken without AVX2:
  * eb_vp9_compute_sub_mean8x8_sse2_intrin / eb_vp9_compute_subd_mean_of_squared_values8x8_sse2_intrin

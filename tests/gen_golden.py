@@ -149,7 +149,17 @@ def gen_me_presets():
     np.savez_compressed(os.path.join(G, "me_presets_reference.npz"), **T.ref_me_presets())
 
 
-SECTIONS = ("scan", "me", "tq", "lf", "lf_masks", "mc", "rate", "quant", "ivf", "lf_params", "me_presets", "sad_loop", "sb_stats", "api")
+def gen_refpad():
+    # ---- recon -> reference padding: the reference's pad_ref_and_set_flags on seeded buffers (tests/test_refpad.py) ----
+    assert T.have_ref("ref_refpad")
+    out = {}
+    for args in T.REFPAD_GOLDEN_CASES:
+        for k, b in enumerate(T.ref_ref_pad(T.make_refpad_case(*args))):
+            out[f"{args[0]}|{k}"] = b
+    np.savez_compressed(os.path.join(G, "refpad_reference.npz"), **out)
+
+
+SECTIONS = ("scan", "me", "tq", "lf", "lf_masks", "mc", "rate", "quant", "ivf", "lf_params", "me_presets", "sad_loop", "sb_stats", "api", "refpad")
 
 
 def main():

@@ -1320,3 +1320,70 @@ def ref_ivf_headers(width, height, frame_rate_q16, numerator, denominator, frame
             args += [str(n), str(pts)]
         subprocess.check_call(args)
         return open(out, "rb").read()
+
+
+# ---------------------------------------------------------------------------------------------------
+# deblocked reconstruction -> padded reference picture (pad_ref_and_set_flags, Codec/EbEncDecProcess.c:4822-4851)
+# ---------------------------------------------------------------------------------------------------
+REFPAD_GOLDEN_CASES = ((1, 72, 40, 80, 80, 0), (2, 200, 136, 80, 80, 8), (3, 64, 64, 16, 32, 0), (4, 136, 72, 70, 10, 3))
+
+
+def make_refpad_case(seed, width, height, pad_x=80, pad_y=80, slack=0):
+    """three padded buffers whose borders hold junk (what a recycled reference buffer holds before the padding)"""
+    rng = np.random.default_rng(seed)
+    bufs = []
+    for sh in (0, 1, 1):
+        w, h, px, py = width >> sh, height >> sh, pad_x >> sh, pad_y >> sh
+        bufs.append(rng.integers(0, 256, (h + 2 * py, w + 2 * px + slack), dtype=np.uint8))
+    return dict(bufs=bufs, width=width, height=height, pad_x=pad_x, pad_y=pad_y, slack=slack)
+
+
+def _refpad_desc(case, ptrs):
+    d = B.YuvPlanes()
+    px, py = case["pad_x"], case["pad_y"]
+    sy, sc = case["bufs"][0].shape[1], case["bufs"][1].shape[1]
+    d.y = ptrs[0] + py * sy + px
+    d.u, d.v = (p + (py >> 1) * sc + (px >> 1) for p in ptrs[1:])
+    d.y_stride, d.uv_stride, d.width, d.height = sy, sc, case["width"], case["height"]
+    return d
+
+
+def refpad_valid(case, bufs):
+    """the part of each buffer the padding defines: every row, the first width + 2 pad bytes (not the slack behind them)"""
+    return [b[:, :b.shape[1] - case["slack"]] for b in bufs]
+
+
+def oracle_ref_pad(case):
+    out = [b.copy() for b in case["bufs"]]
+    d = _refpad_desc(case, [o.ctypes.data for o in out])
+    assert oracle().svt_oracle_ref_pad(C.byref(d), case["pad_x"], case["pad_y"]) == 0
+    return out
+
+
+def ref_ref_pad(case):
+    """the reference's own pad_ref_and_set_flags (oracle/_ref/ref_refpad)"""
+    with tempfile.TemporaryDirectory() as td:
+        rq, rs = os.path.join(td, "rq"), os.path.join(td, "rs")
+        with open(rq, "wb") as f:
+            f.write(struct.pack("<7i", 0x50525653, case["width"], case["height"], case["pad_x"], case["pad_y"], case["bufs"][0].shape[1], case["bufs"][1].shape[1]))
+            for b in case["bufs"]:
+                f.write(np.ascontiguousarray(b).tobytes())
+        subprocess.check_call([os.path.join(REF_DIR, "ref_refpad"), rq, rs])
+        raw = np.fromfile(rs, np.uint8)
+    out, pos = [], 0
+    for b in case["bufs"]:
+        out.append(raw[pos:pos + b.size].reshape(b.shape).copy())
+        pos += b.size
+    return out
+
+
+def hip_ref_pad_batch(ctx, cases):
+    """several pictures (of different sizes) through one svt_hip_ref_pad_batch_device call; pad_x / pad_y of the first case"""
+    import torch
+    lib = B.load()
+    dev = [[torch.from_numpy(np.ascontiguousarray(b)).cuda() for b in c["bufs"]] for c in cases]
+    descs = (B.YuvPlanes * len(cases))(*[_refpad_desc(c, [t.data_ptr() for t in ts]) for c, ts in zip(cases, dev)])
+    torch.cuda.synchronize()
+    B.check(lib.svt_hip_ref_pad_batch_device(ctx, len(cases), descs, cases[0]["pad_x"], cases[0]["pad_y"]))
+    B.check(lib.svt_hip_ctx_synchronize(ctx))
+    return [[t.cpu().numpy() for t in ts] for ts in dev]
