@@ -268,7 +268,7 @@ typedef struct me_lds_layout {
 #define ME_HME_MAX_WIN 16
 typedef struct me_hme_win {
     int16_t  gx, gy;         /* reference-picture coordinates of window column 0 / row 0 */
-    uint16_t off;            /* byte offset of the window inside the scratch */
+    uint32_t off;            /* byte offset of the window inside the scratch (the scratch can exceed 64 KB: search areas up to 127 x 127) */
     uint16_t wstride;        /* window row stride (bytes, odd number of dwords) */
     uint16_t tl, ts;         /* first load task / first search task of this window inside its batch */
     uint16_t sw, sh;         /* search positions */
@@ -276,7 +276,6 @@ typedef struct me_hme_win {
     uint16_t rows;           /* window rows */
     uint8_t  nd;             /* window dwords per row */
     uint8_t  slot;           /* region (key) this window belongs to */
-    uint16_t pad_;
     uint32_t inv_nu, inv_ng; /* me_magic_of(16-byte units per window row) / (search tasks per search row): the planning thread divides once */
 } me_hme_win;
 
@@ -2215,7 +2214,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         /* ---- full-pel search, in chunks of search rows ---- */
         {
             uint32_t *U = (uint32_t *)c->planes;
-            if ((saw & 7) == 0 && saw * sah <= 4096) {
+            if (saw >= 8 && (saw & 7) == 0 && saw * sah <= 4096) {
                 ME_PHASE(ph_fullpel_fused(c, tid, saw, sah));
                 ME_MARK(5);
                 ME_MARK(6);

@@ -146,6 +146,9 @@ static int32_t me_launch(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture 
         if (q->hierarchical_levels > 5 || q->temporal_layer_index > 5 || q->number_hme_search_region_in_width > 2 ||
             q->number_hme_search_region_in_height > 2)
             return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: parameter out of range");
+        /* a search area of 0 x n has no position: the reference never produces one (verify_settings wants 1..256,
+           Codec/EbEncHandle.c:2352-2360) and the search phases assume at least one */
+        if (q->search_area_width < 1 || q->search_area_height < 1) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: empty full-pel search area");
         if (i && !me_params_same_config(params, q))
             return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: the pictures of one launch may differ in num_ref_lists, temporal_layer_index, hierarchical_levels and same_ref_poc only");
     }

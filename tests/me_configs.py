@@ -51,3 +51,18 @@ def variant_l0_only_4quadrants(num_lists, temporal_layer):
     p.enable_hme_level_1_flag = 0
     p.enable_hme_level_2_flag = 0
     return p
+
+
+def variant_wide_search(num_lists, temporal_layer):
+    """1080p preset (four HME regions, three levels) with a 120 x 110 full-pel search area and C5-sized level-0 HME areas
+    (64 x 40 per region, x 3.5 at layer 0): the LDS scratch is 100 KB and, on pictures at least ~1000 samples wide, the
+    windows of one HME batch lie beyond byte offset 65535 (a 16-bit window offset wrapped here once)."""
+    p = preset("c2_1080p_m8", num_lists, temporal_layer)
+    p.search_area_width = 120
+    p.search_area_height = 110
+    for i in range(2):
+        p.hme_level0_search_area_in_width_array[i] = 64
+        p.hme_level0_search_area_in_height_array[i] = 40
+    p.hme_level0_total_search_area_width = 128
+    p.hme_level0_total_search_area_height = 80
+    return p

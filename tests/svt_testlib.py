@@ -69,6 +69,20 @@ class PaPic:
         return [(self.full, 68), (self.quarter, 32), (self.sixteenth, 16)]
 
 
+def gen_shifted_pair(width, height, dx, dy, seed, noise=2):
+    """(reference, current) with current[y][x] = reference[y - dy][x - dx] (+ noise): one global displacement of any size,
+    e.g. far inside an outer HME region"""
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, ((height + abs(dy)) // 4 + 2, (width + abs(dx)) // 4 + 2), dtype=np.uint8)
+    big = np.repeat(np.repeat(base, 4, axis=0), 4, axis=1)
+    oy, ox = max(dy, 0), max(dx, 0)
+    out = []
+    for (y0, x0) in ((oy, ox), (oy - dy, ox - dx)):
+        f = big[y0:y0 + height, x0:x0 + width].astype(np.int16) + rng.integers(-noise, noise + 1, (height, width), dtype=np.int16)
+        out.append(np.clip(f, 0, 255).astype(np.uint8))
+    return out
+
+
 def n_sb(width, height):
     return ((width + 63) // 64) * ((height + 63) // 64)
 
@@ -446,6 +460,27 @@ def make_tq_case(seed, width=256, height=128, do_recon=True, qsteps=((40, 48), (
         pos += n * n
     counts = np.array([sum(1 for b in blocks if b[0] == s) for s in range(4)], dtype=np.int32)
     return dict(src=src, pred=pred, blocks=arr, counts=counts, qtabs=qtabs, iscan=iscan, n_coeff=pos)
+
+
+def make_tq_md_case(seed, width, height, n_cand):
+    """The (block x candidate) form of mode decision's full loop: every transform block of the partition is coded n_cand
+    times, each time against another prediction (same src_off, n_cand different pred_off -- the candidates' predictions are
+    planes stacked below each other), nothing reconstructs (do_recon = 0)."""
+    case = make_tq_case(seed, width=width, height=height, do_recon=False)
+    rng = np.random.default_rng(seed + 77)
+    src = case["src"]
+    preds = [case["pred"]]
+    for k in range(1, n_cand):
+        preds.append(np.clip(np.roll(src, (k, -k), (0, 1)).astype(np.int16) + rng.integers(-6 * k, 6 * k + 1, src.shape), 0, 255).astype(np.uint8))
+    base = case["blocks"]
+    blocks = np.repeat(base, n_cand)                       # candidates of a block are neighbours in the list (grouping by size stays)
+    cand = np.tile(np.arange(n_cand, dtype=np.uint32), len(base))
+    blocks["pred_off"] += cand * np.uint32(src.size)
+    blocks["recon_off"] = 0
+    nn = 16 << (2 * blocks["tx_size"].astype(np.int64))
+    blocks["coeff_off"] = np.concatenate([[0], np.cumsum(nn)[:-1]]).astype(np.uint32)
+    return dict(src=src, pred=np.ascontiguousarray(np.concatenate(preds, axis=0)), blocks=blocks, counts=case["counts"] * n_cand, qtabs=case["qtabs"],
+                iscan=case["iscan"], n_coeff=int(nn.sum()), n_cand=n_cand)
 
 
 def oracle_tq_batch(case):
@@ -944,8 +979,9 @@ def oracle_tq_rd_batch(case, rb):
     return recon, q, dq, eob, dist, oracle_rate_batch(dict(qcoeff=q, blocks=rb))
 
 
-def hip_tq_rd_batch_device(ctx, case):
-    """svt_hip_tq_rd_batch_device on device buffers allocated with torch (GPU tests only)."""
+def hip_tq_rd_batch_device(ctx, case, null_recon=False):
+    """svt_hip_tq_rd_batch_device on device buffers allocated with torch (GPU tests only).  null_recon: d_recon = NULL (the mode
+    decision form: no block reconstructs)."""
     import torch
     lib = B.load()
     dev = torch.device("cuda", 0)
@@ -961,8 +997,8 @@ def hip_tq_rd_batch_device(ctx, case):
     bits = torch.zeros(len(case["blocks"]), dtype=torch.int32, device=dev)
     cnt = (C.c_int32 * 4)(*[int(v) for v in case["counts"]])
     p = lambda t: C.c_void_p(t.data_ptr())
-    B.check(lib.svt_hip_tq_rd_batch_device(ctx, p(src), p(pred), p(recon), p(blocks), cnt, p(qt), p(isc), p(q), p(dq), p(eob), p(dist),
-                                           p(tab), p(scan), p(bits)))
+    B.check(lib.svt_hip_tq_rd_batch_device(ctx, p(src), p(pred), None if null_recon else p(recon), p(blocks), cnt, p(qt), p(isc), p(q), p(dq),
+                                           p(eob), p(dist), p(tab), p(scan), p(bits)))
     B.check(lib.svt_hip_ctx_synchronize(ctx))
     return (recon.cpu().numpy().reshape(case["src"].shape), q.cpu().numpy(), dq.cpu().numpy(), eob.cpu().numpy().view(np.uint16),
             dist.cpu().numpy().view(np.uint64).reshape(-1, 2), bits.cpu().numpy())

@@ -47,6 +47,17 @@ def test_kernel_emulation_c5_ssd_search(nl, tl):
     _cmp(T.oracle_me_picture, T.emu_me_picture, pics, MC.preset_c5(nl, tl), nl)
 
 
+def test_kernel_emulation_wide_search_area():
+    """scratch > 64 KB and HME windows beyond byte offset 65535 (SBs in the middle of a 1920 x 1088 picture: the whole 448 x 280 level-0 area lies inside the 1/16 plane)"""
+    # the displacement (-400, -240) puts the best level-0 match into region 0, in rows a wrapped window offset would overwrite
+    pics = [T.PaPic(f) for f in T.gen_shifted_pair(1920, 1088, 400, 240, 5)]
+    p = MC.variant_wide_search(1, 0)
+    o, _ = T.oracle_me_picture(pics[1], pics[0], None, p, 254, 258)
+    e, _ = T.emu_me_picture(pics[1], pics[0], None, p, 254, 258)
+    assert not T.me_results_equal(o[254:258], e[254:258], 1)
+    assert (abs(o[254:258, 0]["x_mv_l0"] + 1600) <= 8).all() and (abs(o[254:258, 0]["y_mv_l0"] + 960) <= 8).all()
+
+
 needs_ref = pytest.mark.skipif(not T.have_ref("ref_me_sb"), reason="oracle/_ref/ref_me_sb not built (reference absent)")
 
 

@@ -73,6 +73,26 @@ def test_me_c5_ssd_search_vs_oracle(ctx, nl, tl):
     _check(ctx, pics, MC.preset_c5(nl, tl), nl)
 
 
+def test_me_wide_search_area_and_empty_area(ctx):
+    """A 120 x 110 search area with all HME levels: the LDS scratch exceeds 64 KB (window offsets beyond 65535).  An empty
+    search area is refused instead of spinning in the fused full-pel phase."""
+    pics = [T.PaPic(f) for f in T.gen_clip_subpel(264, 200, 3, 5)]
+    _check(ctx, pics, MC.variant_wide_search(2, 2), 2)
+    big = [T.PaPic(f) for f in T.gen_shifted_pair(1920, 1088, 400, 240, 5)]   # HME windows of one batch beyond byte offset 65535
+    p = MC.variant_wide_search(1, 0)
+    g, _ = hip_me_picture(ctx, big[1], big[0], None, p)
+    for b in (0, 240, 500):   # corner, middle, last rows
+        o, _ = T.oracle_me_picture(big[1], big[0], None, p, b, b + 10)
+        assert not T.me_results_equal(o[b:b + 10], g[b:b + 10], 1), b
+    lib = B.load()
+    for wh in ((0, 7), (8, 0)):
+        p = MC.preset("c3_2160p_m8", 1, 0)
+        p.search_area_width, p.search_area_height = wh
+        res = np.zeros((T.n_sb(264, 200), 85), dtype=B.ME_RESULT_DTYPE)
+        dc, d0 = pics[1].desc(), pics[0].desc()
+        assert lib.svt_hip_me_picture(ctx, C.byref(dc), C.byref(d0), None, C.byref(p), res.ctypes.data_as(C.c_void_p), None) == -1
+
+
 def test_me_random_content(ctx):
     """Uniform random pictures: worst case for ties/early outs (there are none in the SAD paths)."""
     rng = np.random.default_rng(3)

@@ -100,3 +100,24 @@ def test_tq_rd_many_blocks_persistent_grid(ctx):
     g = T.hip_tq_rd_batch_device(ctx, case)
     for n, a, b in zip(("recon", "qcoeff", "dqcoeff", "eob", "dist", "bits"), o, g):
         assert np.array_equal(a, b), (n, int(np.sum(a != b)))
+
+
+def test_tq_rd_mode_decision_candidate_form(ctx):
+    """The MD call sites of the transform path -- perform_coding_loop in the full loop for Y / Cb / Cr
+    (Codec/EbEncDecProcess.c:853, 911, 960) and in the chroma-mode search (:1820, 1873), followed by perform_dist_rate_calc
+    (:700-745) -- as ONE svt_hip_tq_rd_batch_device call over (block x candidate): K candidates per transform block share the
+    block's src_off and differ in pred_off, do_recon = 0 everywhere and d_recon = NULL (mode decision reconstructs nothing; the
+    winner's reconstruction is the encode pass).  1080p block counts (1920 x 1056 = 33 rows of 32 x 32 areas, K = 3 -> 126 171
+    blocks), against the oracle's transform stage + coeff_rate_estimate."""
+    K = 3
+    case = T.make_tq_md_case(31, 1920, 1056, K)
+    assert (case["blocks"]["do_recon"] == 0).all() and len(case["blocks"]) > 100000
+    b = case["blocks"]
+    assert (b["src_off"][0::K] == b["src_off"][1::K]).all() and (b["pred_off"][0::K] != b["pred_off"][1::K]).all()
+    rb = T.add_rate_info(case, 9, inter_share=0.7)
+    o = T.oracle_tq_rd_batch(case, rb)
+    g = T.hip_tq_rd_batch_device(ctx, case, null_recon=True)
+    for n, x, y in list(zip(("recon", "qcoeff", "dqcoeff", "eob", "dist", "bits"), o, g))[1:]:
+        assert np.array_equal(x, y), (n, int(np.sum(x != y)))
+    # the candidates of a block really differ (different predictions -> different coefficients / costs)
+    assert (o[5][0::K] != o[5][1::K]).mean() > 0.5 and (o[4][0::K, 0] != o[4][2::K, 0]).mean() > 0.5
