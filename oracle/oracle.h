@@ -11,6 +11,7 @@ uint64_t oracle_spatial_full_distortion(const uint8_t *src, int ss, const uint8_
 uint32_t oracle_sad_nxm(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int h, int w);
 uint32_t oracle_avg_sad(const uint8_t *src, int src_stride, const uint8_t *r1, int s1, const uint8_t *r2, int s2,
                         int h, int w);
+uint32_t oracle_avg_ssd(const uint8_t *src, int src_stride, const uint8_t *r1, int s1, const uint8_t *r2, int s2, int h, int w);
 void oracle_sad_loop(const uint8_t *src, int src_stride, const uint8_t *ref, int ref_stride, int height, int width,
                      uint64_t *best_sad, int16_t *xc, int16_t *yc, int ref_stride_raw, int search_w, int search_h);
 /* motion_estimate_sb over SBs [sb_begin, sb_end) of a picture (sb_end < 0 = all).

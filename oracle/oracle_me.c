@@ -56,6 +56,19 @@ uint32_t oracle_sad_nxm(const uint8_t *src, int src_stride, const uint8_t *ref, 
 }
 
 /* C_DEFAULT/EbComputeSAD_C.c:14-31 eb_vp9_combined_averaging_sad */
+/* eb_vp9_combined_averaging_ssd (Codec/EbMotionEstimation.c:1708-1725): SSD between the source block and the rounded average
+ * of two prediction blocks, accumulated in 32 bits -- the quarter-pel metric of the SSD fractional search */
+uint32_t oracle_avg_ssd(const uint8_t *src, int src_stride, const uint8_t *r1, int s1, const uint8_t *r2, int s2, int h, int w) {
+    uint32_t ssd = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int avg = (r1[y * s1 + x] + r2[y * s2 + x] + 1) >> 1;
+            const int d   = (int)src[y * src_stride + x] - avg;
+            ssd += (uint32_t)(d * d);
+        }
+    return ssd;
+}
+
 uint32_t oracle_avg_sad(const uint8_t *src, int src_stride, const uint8_t *r1, int s1, const uint8_t *r2, int s2,
                         int h, int w) {
     uint32_t sad = 0;
@@ -506,15 +519,8 @@ static void pu_quarter_pel(me_sb_t *s, int list, const uint8_t *tl, int rs, int 
         pl_t a = plane_at(s, list, tl, rs, e[0], xs + e[1], ys + e[2]);
         pl_t b = plane_at(s, list, tl, rs, e[3], xs + e[4], ys + e[5]);
         uint64_t dist;
-        if (m == SVT_SSD_SEARCH) { /* eb_vp9_combined_averaging_ssd :1708-1725 */
-            uint32_t ssd = 0;
-            for (int y = 0; y < h; y++)
-                for (int x = 0; x < w; x++) {
-                    int avg = (a.p[y * a.stride + x] + b.p[y * b.stride + x] + 1) >> 1;
-                    int d   = (int)src[y * ss + x] - avg;
-                    ssd += (uint32_t)(d * d);
-                }
-            dist = ssd;
+        if (m == SVT_SSD_SEARCH) {
+            dist = oracle_avg_ssd(src, ss, a.p, a.stride, b.p, b.stride, h, w);
             if (dist < *best_ssd) {
                 *best_sad = oracle_avg_sad(src, ss, a.p, a.stride, b.p, b.stride, h, w);
                 *best_mv  = pack_mv(xm + dmv[i][0], ym + dmv[i][1]);

@@ -18,6 +18,12 @@
  *   9 planes (cur.full, cur.quarter, cur.sixteenth, ref0.*, ref1.*), each:
  *   int32 stride, origin_x, origin_y, width, height, nbytes, then nbytes of samples (nbytes may be 0).
  * response: int32 n_sb, then n_sb*85 svt_me_pu_result, then n_sb uint32 rcme distortion.
+ *
+ * Second request kind (the one leaf of the SSD fractional search that has external linkage and runs without the yasm-only
+ * Log2f: eb_vp9_combined_averaging_ssd, Codec/EbMotionEstimation.c:1708-1725, the quarter-pel metric of SSD_SEARCH):
+ *   int32 magic 'SVAS', int32 n, then n jobs {int32 width, height, src_stride, ref1_stride, ref2_stride; src[height *
+ *   src_stride]; ref1[height * ref1_stride]; ref2[height * ref2_stride]}
+ * response: n uint32
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -60,7 +66,31 @@ int main(int argc, char **argv) {
     if (!f) return 2;
     int32_t       magic, sb_begin, sb_end;
     svt_me_params p;
-    if (rd(f, &magic, 4) || magic != 0x454D5653) return 3;
+    if (rd(f, &magic, 4)) return 3;
+    if (magic == 0x53415653) { /* 'SVAS' */
+        int32_t n;
+        if (rd(f, &n, 4) || n < 0) return 3;
+        uint32_t *out = (uint32_t *)calloc((size_t)n + 1, sizeof *out);
+        for (int i = 0; i < n; i++) {
+            int32_t g[5];
+            if (rd(f, g, sizeof g)) return 3;
+            uint8_t *b[3];
+            for (int k = 0; k < 3; k++) {
+                const size_t nb = (size_t)g[1] * g[2 + k];
+                b[k] = (uint8_t *)malloc(nb + 64);
+                if (rd(f, b[k], nb)) return 3;
+            }
+            out[i] = eb_vp9_combined_averaging_ssd(b[0], (uint32_t)g[2], b[1], (uint32_t)g[3], b[2], (uint32_t)g[4], (uint32_t)g[1], (uint32_t)g[0]);
+            for (int k = 0; k < 3; k++) free(b[k]);
+        }
+        fclose(f);
+        FILE *o = fopen(argv[2], "wb");
+        if (!o) return 2;
+        fwrite(out, sizeof *out, (size_t)n, o);
+        fclose(o);
+        return 0;
+    }
+    if (magic != 0x454D5653) return 3;
     if (rd(f, &p, sizeof p) || rd(f, &sb_begin, 4) || rd(f, &sb_end, 4)) return 3;
     EbPictureBufferDesc *pl[9];
     for (int i = 0; i < 9; i++) pl[i] = read_plane(f);

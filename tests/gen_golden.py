@@ -159,7 +159,12 @@ def gen_refpad():
     np.savez_compressed(os.path.join(G, "refpad_reference.npz"), **out)
 
 
-SECTIONS = ("scan", "me", "tq", "lf", "lf_masks", "mc", "rate", "quant", "ivf", "lf_params", "me_presets", "sad_loop", "sb_stats", "api", "refpad")
+def gen_avg_ssd():
+    # ---- eb_vp9_combined_averaging_ssd: the one leaf of the SSD fractional search that runs here (no Log2f) ----
+    np.savez_compressed(os.path.join(G, "avg_ssd_reference.npz"), **{str(seed): T.ref_avg_ssd_jobs(T.make_avg_ssd_jobs(seed)) for seed in (1, 2)})
+
+
+SECTIONS = ("scan", "me", "tq", "lf", "lf_masks", "mc", "rate", "quant", "ivf", "lf_params", "me_presets", "sad_loop", "sb_stats", "api", "refpad", "avg_ssd")
 
 
 def main():

@@ -1423,3 +1423,44 @@ def hip_ref_pad_batch(ctx, cases):
     B.check(lib.svt_hip_ref_pad_batch_device(ctx, len(cases), descs, cases[0]["pad_x"], cases[0]["pad_y"]))
     B.check(lib.svt_hip_ctx_synchronize(ctx))
     return [[t.cpu().numpy() for t in ts] for ts in dev]
+
+
+# ---------------------------------------------------------------------------------------------------
+# eb_vp9_combined_averaging_ssd (Codec/EbMotionEstimation.c:1708-1725): the quarter-pel metric of the SSD fractional search
+# ---------------------------------------------------------------------------------------------------
+def make_avg_ssd_jobs(seed, n=40):
+    """(src, ref1, ref2) blocks of the PU sizes, strides >= width; includes the extremes (0 / 255 planes: the largest sums)"""
+    rng = np.random.default_rng(seed)
+    jobs = []
+    for i in range(n):
+        w = int(rng.choice([8, 16, 32, 64]))
+        h = w if i % 5 else w // 2
+        strides = [w + int(rng.integers(0, 3)) * 8 for _ in range(3)]
+        if i % 7 == 0:
+            vals = [(0, 255, 255), (255, 0, 0), (255, 0, 1)][(i // 7) % 3]
+            blocks = [np.full((h, st), v, np.uint8) for st, v in zip(strides, vals)]
+        else:
+            blocks = [rng.integers(0, 256, (h, st), dtype=np.uint8) for st in strides]
+        jobs.append((w, h, blocks))
+    return jobs
+
+
+def oracle_avg_ssd_jobs(jobs):
+    o = oracle()
+    o.oracle_avg_ssd.restype = C.c_uint32
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    return np.array([o.oracle_avg_ssd(vp(b[0]), b[0].shape[1], vp(b[1]), b[1].shape[1], vp(b[2]), b[2].shape[1], h, w) for w, h, b in jobs], np.uint32)
+
+
+def ref_avg_ssd_jobs(jobs):
+    """the reference's own eb_vp9_combined_averaging_ssd (request 'SVAS' of oracle/_ref/ref_me_sb)"""
+    with tempfile.TemporaryDirectory() as td:
+        rq, rs = os.path.join(td, "rq"), os.path.join(td, "rs")
+        with open(rq, "wb") as f:
+            f.write(struct.pack("<2i", 0x53415653, len(jobs)))
+            for w, h, b in jobs:
+                f.write(struct.pack("<5i", w, h, b[0].shape[1], b[1].shape[1], b[2].shape[1]))
+                for a in b:
+                    f.write(np.ascontiguousarray(a).tobytes())
+        subprocess.check_call([os.path.join(REF_DIR, "ref_me_sb"), rq, rs])
+        return np.fromfile(rs, np.uint32)

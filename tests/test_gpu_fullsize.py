@@ -1,4 +1,4 @@
-"""GPU parity at BASELINE.json's full picture sizes (3840x2160 and 1920x1080): every stage of the path through the C ABI
+"""GPU parity at BASELINE.json's full picture sizes (3840x2160, 1920x1080 and C1's 640x360): every stage of the path through the C ABI
 against the oracle on whole pictures, plus size-independent properties (specialised vs generic ME instance, block order
 independence of the TQ batch, row-band independence of inter prediction)."""
 import ctypes as C
@@ -15,7 +15,7 @@ from test_gpu_me import hip_me_picture
 
 B = T.B
 pytestmark = pytest.mark.gpu
-SIZES = {"2160p": (3840, 2160, "c3_2160p_m8"), "1080p": (1920, 1080, "c2_1080p_m8")}
+SIZES = {"2160p": (3840, 2160, "c3_2160p_m8"), "1080p": (1920, 1080, "c2_1080p_m8"), "360p": (640, 360, "c1_360p_m9")}
 
 
 @pytest.fixture(scope="module")
@@ -32,9 +32,11 @@ def clips():
     return {k: [T.PaPic(f) for f in T.gen_clip_subpel(w, h, 3, 5)] for k, (w, h, _) in SIZES.items()}
 
 
-@pytest.mark.parametrize("size,nl,tl", [("2160p", 2, 4), ("2160p", 2, 0), ("1080p", 2, 2), ("1080p", 1, 0)])
+@pytest.mark.parametrize("size,nl,tl", [("2160p", 2, 4), ("2160p", 2, 0), ("1080p", 2, 2), ("1080p", 1, 0), ("360p", 2, 3), ("360p", 1, 0),
+                                        ("360p", 2, 1)])
 def test_me_full_picture_vs_oracle(ctx, clips, size, nl, tl):
-    """all 2040 (510) superblocks, incl. the partial bottom row of 2160 = 33.75 x 64"""
+    """all 2040 (510, 60) superblocks, incl. the partial bottom row of 2160 = 33.75 x 64 (360 = 5.625 x 64); 360p = BASELINE
+    config C1 at its own size with its own preset (enc-mode 9, tune 1)"""
     pics = clips[size]
     p = MC.preset(SIZES[size][2], nl, tl)
     ref1 = pics[2] if nl == 2 else None
@@ -103,7 +105,7 @@ def test_tq_full_plane_vs_oracle_and_order_independence(ctx, size):
         pos += cnt
 
 
-@pytest.mark.parametrize("size", ["2160p", "1080p"])
+@pytest.mark.parametrize("size", ["2160p", "1080p", "360p"])
 def test_lf_full_picture_vs_oracle(ctx, size):
     w, h, _ = SIZES[size]
     case = T.make_lf_case(3, w, h)
@@ -111,7 +113,7 @@ def test_lf_full_picture_vs_oracle(ctx, size):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("size", ["2160p", "1080p"])
+@pytest.mark.parametrize("size", ["2160p", "1080p", "360p"])
 def test_mc_full_picture_vs_oracle_and_band_independence(ctx, size):
     w, h, _ = SIZES[size]
     case = T.make_mc_case(3, width=w, height=h, mv_range=64)

@@ -80,7 +80,7 @@ def test_sad_loop_oracle_matches_reference_golden(seed):
     assert len(o) == 48 and (o[:, 0] == 0).sum() >= 5      # the planted exact matches are found
 
 
-@pytest.mark.skipif(T.ref_kernels() is None, reason="oracle/_ref not built (reference sources absent)")
+@pytest.mark.skipif(not T.have_ref("libsvtref_kernels.so"), reason="oracle/_ref not built (reference sources absent)")
 def test_sad_loop_oracle_matches_reference_live():
     case = T.make_sad_loop_case(7)
     assert np.array_equal(T.oracle_sad_loop_case(case), T.ref_sad_loop_case(case))

@@ -8,7 +8,7 @@ import pytest
 import me_configs as MC
 import svt_testlib as T
 
-live = pytest.mark.skipif(T.ref_kernels() is None, reason="oracle/_ref not built (reference sources absent)")
+live = pytest.mark.skipif(not T.have_ref("libsvtref_kernels.so"), reason="oracle/_ref not built (reference sources absent)")
 
 
 def _golden(name):
@@ -44,6 +44,21 @@ def test_lf_oracle_matches_reference_golden():
         w, h, seed, sharp = (int(v) for v in k.split("|"))
         y, u, v = T.oracle_lf_frame(T.make_lf_case(seed, w, h, sharp))
         assert np.array_equal(y, g["y|" + k]) and np.array_equal(u, g["u|" + k]) and np.array_equal(v, g["v|" + k])
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_avg_ssd_oracle_matches_reference_golden(seed):
+    """eb_vp9_combined_averaging_ssd (Codec/EbMotionEstimation.c:1708-1725), the quarter-pel metric of the SSD fractional
+    search: the only leaf of that search with external linkage that does not go through the yasm-only Log2f"""
+    g = _golden("avg_ssd_reference.npz")[str(seed)]
+    o = T.oracle_avg_ssd_jobs(T.make_avg_ssd_jobs(seed))
+    assert np.array_equal(o, g) and g.max() > 64 * 32 * 255 * 255 // 2
+
+
+@pytest.mark.skipif(not T.have_ref("ref_me_sb"), reason="oracle/_ref/ref_me_sb not built (reference absent)")
+def test_avg_ssd_oracle_matches_reference_live():
+    jobs = T.make_avg_ssd_jobs(9, n=64)
+    assert np.array_equal(T.oracle_avg_ssd_jobs(jobs), T.ref_avg_ssd_jobs(jobs))
 
 
 def test_scan_tables_are_permutations():
