@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- hot-path throughput of the MI355X implementation of SVT-VP9's block-level DSP path.
+"""bench.py -- hot-path throughput of the MI355X implementation of SVT-VP9's block-level DSP path, dependency-true.
 
-One "step" = one pass of the whole path over one mini-GOP (16 pictures of the 5-temporal-layer random-access structure
-the reference uses at hierarchical_levels = 4) of synthetic 3840x2160 8-bit 4:2:0 input at the enc-mode 8 / tune 1 (OQ)
-settings, q index 160 (-q 40).  Inside the timed region, per mini-GOP, every stage works on what the stage before it
-wrote:
+One "step" = one 16-picture mini-GOP (5 temporal layers, hierarchical_levels = 4, B pictures with 2 reference lists) of EACH of
+G concurrent closed GOPs (closed GOPs are independent streams of work) of synthetic 3840x2160 8-bit 4:2:0 input at the
+enc-mode 8 / tune 1 (OQ) settings, q index 160 (-q 40), through the whole data path in the order the data dependencies of the
+encoder impose:
 
-    picture analysis (padded + 1/16 planes from the source luma)  ->  motion estimation (16 B pictures, 2 lists)
-    inter prediction from the mode-info grids  ->  residual / transform / quantisation / reconstruction + distortion
-        + coefficient rate of the quantised blocks (one fused pass)  ->  in-loop deblocking of the reconstruction
+    ME side (source pictures only, one mini-GOP ahead, own streams):
+        picture analysis (padded + 1/16 planes from the source luma)  ->  motion estimation (16 B pictures per GOP)
+    EncDec side, per GOP FIVE DEPENDENT WAVES -- temporal layer 0 (picture 16), 1 (8), 2 (4, 12), 3 (2, 6, 10, 14), 4 (odd) --
+    each wave:
+        inter prediction FROM THE DEBLOCKED, PADDED RECONSTRUCTION of its lower-layer reference pictures (svt_mc_kernel)
+        ->  residual / transform / quantisation / reconstruction + distortion + coefficient rate (one fused pass) into the
+            picture's reference buffer  ->  in-loop deblocking in place  ->  border padding in place (svt_refpad_kernel):
+            the picture is now the reference of the next wave (and picture 16 the base of the next mini-GOP)
 
-The mode-info grids (partition, prediction direction and motion vectors of every block) are mode decision's output
--- host logic outside this path -- and are built ONCE before the timed loop from a first ME pass over the same
-pictures (so the prediction the transform stage codes is the motion-compensated one), as are the loop-filter masks
-(svt_hip_lf_build_masks on the same grids, skip flags from a first transform pass).  ME runs one mini-GOP ahead of the
-EncDec-side stages, as the reference's ME threads do.  Inputs are resident in HBM before the timed region.
-value = pictures / second (whole job, all ranks).
+A wave of layer l of a mini-GOP cannot start before the wave of layer l - 1 has been padded: the reconstruction buffers ARE the
+reference pictures (as in the reference, Codec/EbEncDecProcess.c:4822-4851, 5676-5696) and every stage runs on the stream of
+its GOP group in program order.  GOPs are split into groups that run on separate streams, so the deblocking tail of one group
+overlaps the transform work of another.  `value` uses G GOPs in flight (config.gops_in_flight; enough to fill the GPU);
+`single_gop_value` is the same path with G = 1 (one stream of mini-GOPs, nothing to overlap the dependent waves with).
+
+The mode-info grids (partition, prediction direction and motion vectors of every block) are mode decision's output -- host
+logic outside this path -- and are built ONCE before the timed loop from a first ME pass over the same pictures, as are the
+loop-filter masks (svt_hip_lf_build_masks on the same grids, skip flags from a first pass of the dependent chain).  Deblocking
+runs on every picture (the reference does so when it writes reconstructed output, `-o`; without it, it skips the pictures that are
+not used as references).  Inputs are resident in HBM before the timed region.  value = pictures / second (whole job, all ranks).
 
 Contract: python bench.py --gpus N --steps K --warmup W ; for N>1 launched by torch.distributed.run, one rank per GPU;
 GOP segments are independent (closed GOPs) so ranks share nothing and the only collectives are the
@@ -38,9 +48,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 W4K, H4K = 3840, 2160
 MINIGOP = 16
 Q_INDEX = 160   # -q 40: quantizer_to_qindex[40]
+PAD = 80        # border of a reference picture: 64 + 16 (Codec/EbEncHandle.c:968-971); chroma half of it
 # temporal layer of picture i (1..16) inside a 16-picture mini-GOP (5 layers, hierarchical_levels = 4)
 LAYER = [4, 3, 4, 2, 4, 3, 4, 1, 4, 3, 4, 2, 4, 3, 4, 0]
-STAGES = ("pa", "me", "mc", "tq", "rate", "lf")   # "rate" is a launch of its own only with SVT_BENCH_SEPARATE_RATE=1 (A/B aid)
+STAGES = ("pa", "me", "mc", "tq", "rate", "lf", "pad")   # "rate" is a launch of its own only with SVT_BENCH_SEPARATE_RATE=1 (A/B aid)
 
 
 def algorithmic_bytes_me(width, height, n_lists, l1_on):
@@ -143,6 +154,8 @@ def build_lf_mode_info(B, k_cell, nz4, mi_rows, mi_cols, level):
     return lmi
 
 
+
+
 # -----------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (kind "port"), built -O3 -march=native on this host, threaded over independent units
 # -----------------------------------------------------------------------------------------------------------------------
@@ -164,17 +177,132 @@ def build_native_oracle():
     return C.CDLL(out)
 
 
+
+
+def reference_me_rate(T, B, orc, frames, Wd, Hd, l1_on, ncpu):
+    """The REFERENCE's own motion_estimate_sb (oracle/_ref/ref_me_sb = Codec/EbMotionEstimation.c compiled from /root/reference in
+    the build container, C path, gcc -O2; it travels to the GPU box as a prebuilt file) timed beside the port on the same
+    picture: one 4K B picture of temporal layer 2 of the mini-GOP, SB ranges over up to 64 processes / threads; the seconds
+    are the SB loops' own (clock_gettime inside the harness: no request I/O).  Returns None when the prebuilt reference is
+    absent."""
+    from concurrent.futures import ThreadPoolExecutor
+    import struct
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_me_sb")
+    if not os.path.exists(exe):
+        return None
+    i = 4
+    a, b = refs_of(i)
+    pics = [T.PaPic(frames[j]) for j in (i, a, b)]
+    p = B.me_params_preset(Wd, Hd, 8, 1, 2, LAYER[i - 1], 4)
+    nsb = T.n_sb(Wd, Hd)
+    workers = max(1, min(ncpu, 64))
+    per = max(1, min(16, nsb // workers))       # bounded sample: at most 16 SBs per worker
+    ranges = [(k * per, min(nsb, (k + 1) * per)) for k in range(workers) if k * per < nsb]
+    with tempfile.TemporaryDirectory() as td:
+        reqs = []
+        for k, (s0, s1) in enumerate(ranges):
+            rq = os.path.join(td, f"rq{k}")
+            with open(rq, "wb") as f:
+                f.write(struct.pack("<i", 0x454D5653))
+                f.write(bytes(p))
+                f.write(struct.pack("<ii", s0, s1))
+                for pic in pics:
+                    for arr, pd in pic.planes():
+                        hh, ww = arr.shape
+                        f.write(struct.pack("<6i", ww, pd, pd, ww - 2 * pd, hh - 2 * pd, arr.size))
+                        f.write(arr.tobytes())
+            reqs.append((rq, os.path.join(td, f"rs{k}")))
+
+        def run_ref(k):
+            subprocess.check_call([exe, reqs[k][0], reqs[k][1]])
+            raw = open(reqs[k][1], "rb").read()
+            return struct.unpack_from("<d", raw, len(raw) - 8)[0], np.frombuffer(raw, dtype=B.ME_RESULT_DTYPE, count=nsb * 85, offset=4).reshape(nsb, 85)
+        with ThreadPoolExecutor(len(ranges)) as ex:
+            ref_out = list(ex.map(run_ref, range(len(ranges))))
+        one = run_ref(0)    # alone on the machine: the single-thread figure
+    res = np.zeros((nsb, 85), dtype=B.ME_RESULT_DTYPE)
+    dc, d0, d1 = (pc.desc() for pc in pics)
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+
+    def run_port(k):
+        t0 = time.perf_counter()
+        rc = orc.svt_oracle_me_picture(C.byref(dc), C.byref(d0), C.byref(d1), C.byref(p), vp(res), None, ranges[k][0], ranges[k][1])
+        assert rc == 0
+        return time.perf_counter() - t0
+    with ThreadPoolExecutor(len(ranges)) as ex:
+        port_t = list(ex.map(run_port, range(len(ranges))))
+    port_one = run_port(0)
+    n_done = sum(s1 - s0 for s0, s1 in ranges)
+    same = all(not T.me_results_equal(ref_out[k][1][s0:s1], res[s0:s1], 2) for k, (s0, s1) in enumerate(ranges))
+    n0 = ranges[0][1] - ranges[0][0]
+    return {"kind": "reference", "what": "motion_estimate_sb (Codec/EbMotionEstimation.c:4524) of the reference built from its own sources, C path (-asm 0), gcc -O2",
+            "sample": f"{n_done} of the {nsb} superblocks of one {Wd}x{Hd} B picture (temporal layer 2), {len(ranges)} processes x {per} SBs",
+            "workers": len(ranges),
+            "sb_per_s": round(n_done / max(t_ for t_, _ in ref_out), 1), "frames_per_s_me_only": round(n_done / max(t_ for t_, _ in ref_out) / nsb, 3),
+            "sb_per_s_1_thread": round(n0 / one[0], 1),
+            "port_sb_per_s": round(n_done / max(port_t), 1), "port_sb_per_s_1_thread": round(n0 / port_one, 1),
+            "port_over_reference_1_thread": round((n0 / port_one) / (n0 / one[0]), 3),
+            "results_identical": bool(same)}
+
+
+class Geometry:
+    """Layouts in HBM.  Source / prediction pictures: Y rows followed by U | V rows (half width each) at the luma stride.
+    Reconstruction = reference pictures: three padded planes one after the other (Y with PAD samples of border, U and V with
+    PAD / 2), as the reference allocates its reference pictures (Codec/EbEncHandle.c:968-971)."""
+
+    def __init__(self, w, h):
+        self.w, self.h = w, h
+        self.plane_w, self.yuv_rows = w, h + h // 2
+        self.pic_bytes = self.yuv_rows * self.plane_w
+        self.pw, self.ph = w + 2 * PAD, h + 2 * PAD
+        self.cpw, self.cph = w // 2 + PAD, h // 2 + PAD
+        self.u_base = self.pw * self.ph
+        self.v_base = self.u_base + self.cpw * self.cph
+        self.rec_bytes = (self.v_base + self.cpw * self.cph + 63) // 64 * 64
+        self.y0 = PAD * self.pw + PAD                               # offsets of sample (0,0) of each plane inside a reference picture
+        self.u0 = self.u_base + (PAD // 2) * self.cpw + PAD // 2
+        self.v0 = self.v_base + (PAD // 2) * self.cpw + PAD // 2
+        self.coeffs = w * h * 3 // 2                                # transform coefficients of a picture
+
+    def recon_offsets(self, tight_off):
+        """offset of a transform block inside a padded reference picture (and its row stride) from its offset in the tight layout"""
+        r, c = tight_off // self.plane_w, tight_off % self.plane_w
+        luma = r < self.h
+        isv = c >= self.w // 2
+        cr, cc = r - self.h, np.where(isv, c - self.w // 2, c)
+        off = np.where(luma, self.y0 + r * self.pw + c, np.where(isv, self.v0, self.u0) + cr * self.cpw + cc)
+        return off.astype(np.int64), np.where(luma, self.pw, self.cpw).astype(np.uint16)
+
+
+def pics_of_layer(layer):
+    return [i for i in range(1, MINIGOP + 1) if LAYER[i - 1] == layer]
+
+
+def slot_of(i, parity):
+    """reference-picture slot (0..16) of picture i of the current mini-GOP (i = 0: the previous mini-GOP's base picture).  The two
+    base pictures alternate between slots 0 and 16 from one mini-GOP to the next, so the new base is written where the base
+    before the previous one was -- no copy between mini-GOPs."""
+    if i == 0:
+        return 16 if parity else 0
+    if i == MINIGOP:
+        return 0 if parity else 16
+    return i
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--height", type=int, default=H4K)
+    ap.add_argument("--gops", type=int, default=int(os.environ.get("SVT_BENCH_GOPS", "4")), help="closed GOPs in flight per GPU (value); single_gop_value always uses 1")
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("SVT_BENCH_GROUPS", "2")), help="GOP groups = EncDec streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--handoff", action="store_true", help="N > 1 only: split-GOP mode -- every step each rank also hands its padded base-layer reconstruction to "
-                    "the next rank (RCCL send / recv over xGMI), the one exchange step of the path; closed GOPs (the default) need none")
-    ap.add_argument("--stages", default=",".join(STAGES), help="profiling aid: run only these stages (the contract run uses all six)")
+    ap.add_argument("--no-single", action="store_true", help="skip the G = 1 run (single_gop_value)")
+    ap.add_argument("--handoff", action="store_true", help="N > 1 only: split-GOP mode -- every step each rank also hands the padded base-layer reconstruction of its "
+                    "first GOP to the next rank (RCCL send / recv over xGMI), the one exchange step of the path; closed GOPs (the default) need none")
+    ap.add_argument("--stages", default=",".join(STAGES), help="profiling aid: run only these stages (the contract run uses all)")
     args = ap.parse_args()
 
     import torch
@@ -193,7 +321,7 @@ def main():
         dist.init_process_group("nccl")
 
     import importlib.util
-    import me_configs as MC
+    import me_configs as MC  # noqa: F401
     import svt_testlib as T
     _sp = importlib.util.spec_from_file_location("gop_shard", os.path.join(ROOT, "svt-vp9_amd", "gop_shard.py"))
     GS = importlib.util.module_from_spec(_sp)
@@ -201,28 +329,39 @@ def main():
     B = T.B
     lib = B.load()
     dev = torch.device("cuda", local_rank)
+    G = max(1, args.gops)
+    n_groups = max(1, min(args.groups, G))
+    t_setup0 = time.perf_counter()
 
-    # streams: 0 = PA + ME (+ a second ME stream: ME of different pictures is independent, the tail of one launch is filled
-    # by the other), 1 = EncDec side (inter prediction -> transform -> rate), 2 = deblocking.  ME is the long pole of the
-    # step and fills every CU by itself (5 workgroups use all of a CU's LDS and 480 of the 512 registers per SIMD): the EncDec
-    # stream gets the higher priority, so that when an ME workgroup retires a waiting transform workgroup moves in first
-    # (measured: -1,0,0 = 3.70 ms/step, 0,0,0 = 3.64, 0,-1,0 = 3.61).
-    prio = [int(x) for x in os.environ.get("SVT_BENCH_PRIO", "0,-1,0").split(",")]
+    # streams: 0 = ME (+ a second ME stream: ME of different pictures is independent, the tail of one launch is filled by the
+    # other), one per GOP group for the EncDec side (prediction -> transform -> deblocking -> padding, in program order = in
+    # dependency order), one for picture analysis.  ME fills every CU by itself (5 workgroups use all of a CU's LDS and 480 of
+    # the 512 registers per SIMD): the EncDec streams get the higher priority, so that when an ME workgroup retires a waiting
+    # transform workgroup moves in first.
+    prio = [int(x) for x in os.environ.get("SVT_BENCH_PRIO", "0,-1").split(",")]
     n_me_streams = max(1, int(os.environ.get("SVT_BENCH_ME_STREAMS", "2")))
-    streams = [torch.cuda.Stream(device=local_rank, priority=prio[min(i, 2)]) for i in range(3)]
-    streams += [torch.cuda.Stream(device=local_rank, priority=prio[0]) for _ in range(n_me_streams - 1)]
     ctxs = []
-    for st_ in streams:
+
+    def new_ctx(priority):
+        st_ = torch.cuda.Stream(device=local_rank, priority=priority)
         c_ = C.c_void_p()
         B.check(lib.svt_hip_ctx_create_on_stream(C.byref(c_), local_rank, C.c_void_p(st_.cuda_stream)))
         ctxs.append(c_)
-    ctx_me, ctx_enc, ctx_lf = ctxs[:3]
-    me_ctxs, me_streams = [ctx_me] + ctxs[3:], [streams[0]] + streams[3:]
+        return st_, c_
+
+    me_pairs = [new_ctx(prio[0]) for _ in range(n_me_streams)]
+    me_streams, me_ctxs = [p_[0] for p_ in me_pairs], [p_[1] for p_ in me_pairs]
+    grp_pairs = [new_ctx(prio[1]) for _ in range(n_groups)]
+    pa_stream, ctx_pa = new_ctx(prio[0])
+    single_stream, ctx_single = new_ctx(prio[1])
 
     Wd, Hd = args.width, args.height
+    geo = Geometry(Wd, Hd)
     nsbx = (Wd + 63) // 64
     nsb = T.n_sb(Wd, Hd)
     mi_rows, mi_cols = Hd // 8, Wd // 8
+    sb_rows, sb_cols = (mi_rows + 7) // 8, (mi_cols + 7) // 8
+    plane_w, yuv_rows, pic_bytes = geo.plane_w, geo.yuv_rows, geo.pic_bytes
     keep = []  # keeps device tensors alive
 
     def to_dev(a):
@@ -235,20 +374,23 @@ def main():
         keep.append(t)
         return t
 
-    # ---- synthetic mini-GOP (+ the previous base-layer picture), resident in HBM: Y rows followed by U | V rows (half
-    # width each, same stride) in one buffer per picture ----
-    frames = T.gen_clip(Wd, Hd, MINIGOP + 1, seed=GS.gop_seed(11, rank))  # rank r encodes its own GOP segment(s)
-    plane_w, yuv_rows = Wd, Hd + Hd // 2
-    pic_bytes = yuv_rows * plane_w
-    src_all = np.zeros((MINIGOP + 1, yuv_rows, plane_w), np.uint8)   # index 0 = previous base picture
-    for i, y in enumerate(frames):
-        src_all[i, :Hd] = y
-        src_all[i, Hd:, :Wd // 2] = y[::2, ::2] // 2 + 32
-        src_all[i, Hd:, Wd // 2:] = 255 - y[::2, ::2] // 2 - y[1::2, 1::2] // 4
-    d_src = to_dev(src_all)
+    # ---- synthetic input, resident in HBM: G GOP segments of 17 pictures (index 0 = the previous mini-GOP's base picture) ----
+    d_src = dev_zeros((G, MINIGOP + 1, yuv_rows, plane_w), torch.uint8)
+    frames_all, src0 = [], None
+    for g in range(G):
+        frames = T.gen_clip(Wd, Hd, MINIGOP + 1, seed=GS.gop_seed(11, rank * G + g))   # rank r encodes its own GOP segments
+        src_all = np.zeros((MINIGOP + 1, yuv_rows, plane_w), np.uint8)
+        for i, y in enumerate(frames):
+            src_all[i, :Hd] = y
+            src_all[i, Hd:, :Wd // 2] = y[::2, ::2] // 2 + 32
+            src_all[i, Hd:, Wd // 2:] = 255 - y[::2, ::2] // 2 - y[1::2, 1::2] // 4
+        d_src[g].copy_(torch.from_numpy(src_all))
+        frames_all.append(frames if g == 0 else None)   # the CPU baseline works on GOP 0
+        if g == 0:
+            src0 = src_all
+    src_ptr = lambda g, i: d_src.data_ptr() + (g * (MINIGOP + 1) + i) * pic_bytes
 
-    # ---- stage "pa": the three ME planes of every picture from its luma (device buffers laid out as the reference's
-    # EbPaReferenceObject planes: padding 68 / 32 / 16) ----
+    # ---- stage "pa": the three ME planes of every picture from its luma (EbPaReferenceObject planes: padding 68 / 32 / 16) ----
     p_probe = B.me_params_preset(Wd, Hd, 8, 1, 2, 1, 4)
     l1_on = bool(p_probe.enable_hme_level_1_flag)
     pads = (68, 32, 16)
@@ -265,113 +407,118 @@ def main():
 
     # two sets of analysed planes: picture analysis runs one mini-GOP ahead of motion estimation on its own stream (as the
     # reference's picture-analysis threads run ahead of its ME threads), writing set (k + 1) & 1 while ME reads set k & 1
-    pa_sets = [[pa_alloc() for _ in range(MINIGOP + 1)] for _ in range(2)]
-    pa_stream = torch.cuda.Stream(device=local_rank, priority=prio[0])
-    ctx_pa = C.c_void_p()
-    B.check(lib.svt_hip_ctx_create_on_stream(C.byref(ctx_pa), local_rank, C.c_void_p(pa_stream.cuda_stream)))
-    ctxs.append(ctx_pa)
+    pa_sets = [[[pa_alloc() for _ in range(MINIGOP + 1)] for _ in range(G)] for _ in range(2)]
 
-    def pa_call(ctx_, idx, s=0):
-        n = len(idx)
-        lum = (C.c_void_p * n)(*[d_src.data_ptr() + i * pic_bytes for i in idx])
+    def pa_call(ctx_, gops, idx, s=0):
+        items = [(g, i) for g in gops for i in idx]
+        n = len(items)
+        lum = (C.c_void_p * n)(*[src_ptr(g, i) for g, i in items])
         strides = (C.c_int32 * n)(*[plane_w] * n)
-        out = (B.PaPicture * n)(*[pa_sets[s][i] for i in idx])
+        out = (B.PaPicture * n)(*[pa_sets[s][g][i] for g, i in items])
         B.check(lib.svt_hip_pa_prepare_batch_device(ctx_, n, lum, strides, out, 1 if l1_on else 0))
 
+    all_gops = list(range(G))
     for s_ in range(2):
-        pa_call(ctx_me, [0], s_)   # the previous mini-GOP's base picture: analysed when that mini-GOP was
-    B.check(lib.svt_hip_ctx_synchronize(ctx_me))
+        pa_call(me_ctxs[0], all_gops, [0], s_)   # the previous mini-GOP's base picture: analysed when that mini-GOP was
+    B.check(lib.svt_hip_ctx_synchronize(me_ctxs[0]))
     pa_idx = list(range(1, MINIGOP + 1))
 
-    # ---- stage "me": one batched launch per temporal layer ----
-    results = [dev_zeros((nsb, 85 * 10), torch.int32) for _ in range(MINIGOP + 1)]
-    # One launch per temporal layer, spread over the ME streams.  SVT_BENCH_ME_ONE_LAUNCH=1: the whole mini-GOP in one launch
-    # (the per-picture parameters -- list count, temporal layer, same_ref_poc -- travel with the picture descriptors either
-    # way: svt_hip_me_batch_layers_device).  Measured: ME alone 1.485 ms in one launch against 1.505 in five, but the whole
-    # step 3.21 against 3.16 ms -- five launches on two streams interleave better with the EncDec-side kernels.
+    # ---- stage "me": one batched launch per temporal layer over the GOPs of the pipeline ----
+    results = [[dev_zeros((nsb, 85 * 10), torch.int32) for _ in range(MINIGOP + 1)] for _ in range(G)]
     per_layer = not os.environ.get("SVT_BENCH_ME_ONE_LAUNCH")
-    me_launch_sets = []
-    for pa_pics in pa_sets:
-        me_launches = []
-        if per_layer:
-            groups = [[i for i in range(1, MINIGOP + 1) if LAYER[i - 1] == layer] for layer in range(5)]
-        else:   # the whole mini-GOP in one launch, biggest search areas (lowest layers) first
-            groups = [sorted(range(1, MINIGOP + 1), key=lambda i: LAYER[i - 1])]
-        for idx in groups:
-            n = len(idx)
-            p = (B.MeParams * n)()
-            for k_, i in enumerate(idx):
-                p[k_] = B.me_params_preset(Wd, Hd, 8, 1, 2, LAYER[i - 1], 4)
-                p[k_].same_ref_poc = 1 if LAYER[i - 1] == 0 else 0
-            cur = (B.PaPicture * n)(*[pa_pics[i] for i in idx])
-            r0 = (B.PaPicture * n)(*[pa_pics[refs_of(i)[0]] for i in idx])
-            r1 = (B.PaPicture * n)(*[pa_pics[refs_of(i)[1]] for i in idx])
-            res = (C.c_void_p * n)(*[results[i].data_ptr() for i in idx])
-            me_launches.append((n, cur, r0, r1, p, res))
-        me_launch_sets.append(me_launches)
-    # launches -> ME streams: largest first onto the least loaded stream
-    me_slot, load = [0] * len(me_launches), [0] * len(me_ctxs)
-    for li in sorted(range(len(me_launches)), key=lambda j: -me_launches[j][0]):
-        k_ = load.index(min(load))
-        me_slot[li] = k_
-        load[k_] += me_launches[li][0]
-    # per-launch durations of the dominant kernel: a (start, stop) HIP event pair around EVERY timed ME launch, recorded on the
-    # stream the launch goes to.  The events come from a pool created before the timed region: creating an event costs the host
-    # tens of microseconds, and ten creations per step in the launch path cost the overlap of the two ME streams (ME alone 4.46
-    # instead of 2.26 ms per step, measured); recording an existing event costs nothing measurable.
-    me_ev = []
-    me_pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * len(me_launches) * (args.steps + 1))]
-    for e_ in me_pool:
-        e_.record(me_streams[0])   # an event object is created on its first record
 
-    def run_me(record=False, s=0):
+    def build_me_launches(gops):
+        sets = []
+        for s in range(2):
+            launches = []
+            if per_layer:
+                groups = [pics_of_layer(layer) for layer in range(5)]
+            else:   # the whole step in one launch, biggest search areas (lowest layers) first
+                groups = [sorted(range(1, MINIGOP + 1), key=lambda i: LAYER[i - 1])]
+            for idx in groups:
+                items = [(g, i) for g in gops for i in idx]
+                n = len(items)
+                p = (B.MeParams * n)()
+                for k_, (g, i) in enumerate(items):
+                    p[k_] = B.me_params_preset(Wd, Hd, 8, 1, 2, LAYER[i - 1], 4)
+                    p[k_].same_ref_poc = 1 if LAYER[i - 1] == 0 else 0
+                cur = (B.PaPicture * n)(*[pa_sets[s][g][i] for g, i in items])
+                r0 = (B.PaPicture * n)(*[pa_sets[s][g][refs_of(i)[0]] for g, i in items])
+                r1 = (B.PaPicture * n)(*[pa_sets[s][g][refs_of(i)[1]] for g, i in items])
+                res = (C.c_void_p * n)(*[results[g][i].data_ptr() for g, i in items])
+                launches.append((n, cur, r0, r1, p, res))
+            sets.append(launches)
+        # launches -> ME streams: largest first onto the least loaded stream
+        slot, load = [0] * len(sets[0]), [0] * len(me_ctxs)
+        for li in sorted(range(len(sets[0])), key=lambda j: -sets[0][j][0]):
+            k_ = load.index(min(load))
+            slot[li] = k_
+            load[k_] += sets[0][li][0]
+        return sets, slot
+
+    # event pools are created before the timed region: creating an event costs the host tens of microseconds and, inside the
+    # launch path, the overlap between streams (measured in round 2); recording an existing event costs nothing measurable
+    class EventPool:
+        def __init__(self, n):
+            self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+            for e_ in self.ev:
+                e_.record(me_streams[0])   # an event object is created on its first record
+
+        def pair(self):
+            return self.ev.pop(), self.ev.pop()
+
+    def run_me(P, s, pool=None):
         for st_ in me_streams[1:]:
             st_.wait_stream(me_streams[0])
-        for li, (n, cur, r0, r1, p, res) in enumerate(me_launch_sets[s]):
-            k_ = me_slot[li]
-            if record:
-                e0, e1 = me_pool.pop(), me_pool.pop()
+        for li, (n, cur, r0, r1, p, res) in enumerate(P["me_sets"][s]):
+            k_ = P["me_slot"][li]
+            if pool is not None:
+                e0, e1 = pool.pair()
                 e0.record(me_streams[k_])
             B.check(lib.svt_hip_me_batch_layers_device(me_ctxs[k_], n, cur, r0, r1, p, res, None))
-            if record:
+            if pool is not None:
                 e1.record(me_streams[k_])
-                me_ev.append((e0, e1))
+                P["me_ev"].append((e0, e1))
         for st_ in me_streams[1:]:
             me_streams[0].wait_stream(st_)
 
-    # ---- first pass (setup, untimed): PA + ME, results to the host = the input of the synthesised mode decision ----
-    pa_call(ctx_me, pa_idx)
-    with torch.cuda.stream(streams[0]):
-        run_me()
+    # ---- first pass (setup, untimed): PA + ME of every GOP, results to the host = the input of the synthesised mode decision ----
+    P_all = {"gops": all_gops}
+    P_all["me_sets"], P_all["me_slot"] = build_me_launches(all_gops)
+    P_all["me_ev"] = []
+    pa_call(me_ctxs[0], all_gops, pa_idx)
+    with torch.cuda.stream(me_streams[0]):
+        run_me(P_all, 0)
     for c_ in ctxs:
         B.check(lib.svt_hip_ctx_synchronize(c_))
     torch.cuda.synchronize()
-    rng = np.random.default_rng(5 + rank)
+
     area_rows, area_cols = (Hd + 31) // 32, (Wd + 31) // 32
     iscan, ioffs = T.iscan_array()
     iscan_off_dct = [ioffs[(ts, 0)] for ts in range(4)]
-    mi_list, kcell_list, blocks_by_ts = [], [], [[] for _ in range(4)]
-    for i in range(1, MINIGOP + 1):
-        res = results[i].cpu().numpy().view(B.ME_RESULT_DTYPE).reshape(nsb, 85)
-        kinds = rng.integers(0, 4, (area_rows, area_cols))
-        if Hd % 32:   # blocks must not reach below the picture
-            kinds[-1] = np.minimum(kinds[-1], 2 if Hd % 32 == 16 else 1)
-        mi, k_cell = build_mode_info(B, res, kinds, mi_rows, mi_cols, nsbx)
-        mi_list.append(mi)
-        kcell_list.append(k_cell)
-        for ts, a in enumerate(build_tq_blocks(B, kinds, Wd, Hd, plane_w, iscan_off_dct)):
-            for f in ("src_off", "pred_off", "recon_off"):
-                a[f] += np.uint32((i - 1) * pic_bytes)
-            a["src_off"] += np.uint32(pic_bytes)        # d_src also holds picture 0
-            blocks_by_ts[ts].append(a)
-    # the whole mini-GOP is one batch, grouped by transform size across pictures -> 4 launches, each fills the GPU
-    tq_blocks_all = np.concatenate([a for ts in range(4) for a in blocks_by_ts[ts]])
-    counts = [sum(len(a) for a in blocks_by_ts[ts]) for ts in range(4)]
-    pic_of_block = np.concatenate([np.full(len(a), k, np.int32) for ts in range(4) for k, a in enumerate(blocks_by_ts[ts])])
-    nn = (16 << (2 * tq_blocks_all["tx_size"].astype(np.int64)))
-    tq_blocks_all["coeff_off"] = np.concatenate([[0], np.cumsum(nn)[:-1]]).astype(np.uint32)
-    n_coeff_all = int(nn.sum())
-    cnt_c = (C.c_int32 * 4)(*counts)
+    rtab, rscan = T.rate_tables()
+    d_mi = [[None] * (MINIGOP + 1) for _ in range(G)]
+    blk_tight = [[None] * (MINIGOP + 1) for _ in range(G)]     # per picture: the four per-size block arrays, offsets relative to the picture
+    kcell = [[None] * (MINIGOP + 1) for _ in range(G)]
+    mi_host0 = []
+    inter_units = comp_units = mi_units = 0
+    for g in range(G):
+        rng = np.random.default_rng(5 + rank * G + g)
+        for i in range(1, MINIGOP + 1):
+            res = results[g][i].cpu().numpy().view(B.ME_RESULT_DTYPE).reshape(nsb, 85)
+            kinds = rng.integers(0, 4, (area_rows, area_cols))
+            if Hd % 32:   # blocks must not reach below the picture
+                kinds[-1] = np.minimum(kinds[-1], 2 if Hd % 32 == 16 else 1)
+            mi, k_cell = build_mode_info(B, res, kinds, mi_rows, mi_cols, nsbx)
+            d_mi[g][i] = to_dev(mi.view(np.uint8))
+            kcell[g][i] = k_cell
+            blk_tight[g][i] = build_tq_blocks(B, kinds, Wd, Hd, plane_w, iscan_off_dct)
+            inter, comp = mi["ref_list"][..., 0] >= 0, mi["ref_list"][..., 1] >= 0
+            inter_units += int(inter.sum())
+            comp_units += int((inter & comp).sum())
+            mi_units += inter.size
+            if g == 0:
+                mi_host0.append(mi)
 
     # quantiser tables of q index 160, luma and chroma (no chroma deltas): the steps are the reference's eb_vp9_dc_quant /
     # eb_vp9_ac_quant values (committed fixture), the tables svt_hip_quant_tables_init's
@@ -380,247 +527,320 @@ def main():
     for j, base in enumerate((2, 14)):
         B.check(lib.svt_hip_quant_tables_init(Q_INDEX, int(qrow[1]), int(qrow[base]), int(qrow[base + 1]), qtabs[j:j + 1].ctypes.data_as(C.c_void_p)))
     ac_q = int(qrow[3])
+    d_qt, d_iscan = to_dev(qtabs.view(np.uint8)), to_dev(iscan)
+    d_rt, d_rs = to_dev(np.ascontiguousarray(rtab).reshape(1).view(np.uint8)), to_dev(rscan)
 
-    # ---- stage "mc": inter prediction of the 16 pictures from their mode-info grids; the references are the padded
-    # pictures of the reference lists (80 / 40 samples of padding, Codec/EbEncHandle.c:968-971) ----
-    pad = 80
-    ref_pics = []
-    for i in range(MINIGOP + 1):
-        y = src_all[i, :Hd]
-        u, v = src_all[i, Hd:, :Wd // 2], src_all[i, Hd:, Wd // 2:]
-        ty, tu, tv = (to_dev(np.pad(pl, pd, mode="edge")) for pl, pd in ((y, pad), (u, pad // 2), (v, pad // 2)))
-        ref_pics.append((ty.data_ptr() + pad * ty.shape[1] + pad, tu.data_ptr() + (pad // 2) * tu.shape[1] + pad // 2,
-                         tv.data_ptr() + (pad // 2) * tv.shape[1] + pad // 2, ty.shape[1], tu.shape[1]))
-    d_mi = [to_dev(m.view(np.uint8)) for m in mi_list]
-    d_pred = dev_zeros((MINIGOP, yuv_rows, plane_w), torch.uint8)
-    mc_pics = (B.McPicture * MINIGOP)()
-    for k in range(MINIGOP):
-        mp = mc_pics[k]
-        mp.d_mi, mp.mi_stride, mp.mi_rows, mp.mi_cols, mp.use_subpel = d_mi[k].data_ptr(), mi_cols, mi_rows, mi_cols, 1
-        for l in range(2):
-            r = mp.ref[l]
-            r.y, r.u, r.v, r.y_stride, r.uv_stride = ref_pics[refs_of(k + 1)[l]]
-            r.width, r.height = Wd, Hd
-        base = d_pred.data_ptr() + k * pic_bytes
-        mp.pred.y, mp.pred.u, mp.pred.v = base, base + Hd * plane_w, base + Hd * plane_w + Wd // 2
-        mp.pred.y_stride, mp.pred.uv_stride, mp.pred.width, mp.pred.height = plane_w, plane_w, Wd, Hd
+    # ---- EncDec-side arenas: prediction pictures, reference pictures (= reconstruction buffers), coefficients ----
+    d_pred = dev_zeros((G, MINIGOP, yuv_rows, plane_w), torch.uint8)
+    d_rec = dev_zeros((G, MINIGOP + 1, geo.rec_bytes), torch.uint8)
+    d_q, d_dq = dev_zeros(G * MINIGOP * geo.coeffs, torch.int16), dev_zeros(G * MINIGOP * geo.coeffs, torch.int16)
+    assert max(d_src.numel(), d_rec.numel(), d_q.numel()) < 2 ** 32, "svt_tq_block offsets are 32 bits: fewer GOPs in flight"
+    rec_ptr = lambda g, slot: d_rec.data_ptr() + (g * (MINIGOP + 1) + slot) * geo.rec_bytes
+    pred_ptr = lambda g, i: d_pred.data_ptr() + (g * MINIGOP + i - 1) * pic_bytes
+    def yuv_desc(d, g, slot):
+        base = rec_ptr(g, slot)
+        d.y, d.u, d.v = base + geo.y0, base + geo.u0, base + geo.v0
+        d.y_stride, d.uv_stride, d.width, d.height = geo.pw, geo.cpw, Wd, Hd
 
-    def run_mc():
-        B.check(lib.svt_hip_inter_pred_batch_device(ctx_enc, MINIGOP, mc_pics))
-
-    # ---- stage "tq": residual -> transform -> quantisation -> reconstruction (+ coefficient-domain distortion) ----
-    rate_ctx = np.random.default_rng(8).integers(0, 3, len(tq_blocks_all)).astype(np.uint8)   # entropy context of every block (an input)
-    tq_blocks_all["pad"][:, 0] = rate_ctx | (tq_blocks_all["qtab"] << 2) | (1 << 3)            # SVT_TQ_RATE_INFO(ctx, plane_type, is_inter = 1)
-    d_blocks, d_qt, d_iscan = to_dev(tq_blocks_all.view(np.uint8)), to_dev(qtabs.view(np.uint8)), to_dev(iscan)
-    d_q, d_dq = dev_zeros(n_coeff_all, torch.int16), dev_zeros(n_coeff_all, torch.int16)
-    d_eob = dev_zeros(len(tq_blocks_all), torch.int16)
-    d_dist = dev_zeros(2 * len(tq_blocks_all), torch.int64)
-    d_rec = [dev_zeros((MINIGOP, yuv_rows, plane_w), torch.uint8) for _ in range(2)]   # double-buffered: LF(k) || TQ(k+1)
-    # the block list is the same for both reconstruction buffers (offsets are relative to the buffer)
-
-    separate_rate = os.environ.get("SVT_BENCH_SEPARATE_RATE", "0") == "1"
-
-    def run_tq_plain(buf):
-        B.check(lib.svt_hip_tq_batch_dist_device(ctx_enc, C.c_void_p(d_src.data_ptr()), C.c_void_p(d_pred.data_ptr()), C.c_void_p(d_rec[buf].data_ptr()),
-                                                 C.c_void_p(d_blocks.data_ptr()), cnt_c, C.c_void_p(d_qt.data_ptr()), C.c_void_p(d_iscan.data_ptr()),
-                                                 C.c_void_p(d_q.data_ptr()), C.c_void_p(d_dq.data_ptr()), C.c_void_p(d_eob.data_ptr()),
-                                                 C.c_void_p(d_dist.data_ptr())))
-
-    # first transform pass (setup): eobs -> skip flags of the loop-filter mode info and the rate stage's records
-    with torch.cuda.stream(streams[1]):
-        run_mc()
-        run_tq_plain(0)
-    B.check(lib.svt_hip_ctx_synchronize(ctx_enc))
+    # the base picture of the mini-GOP before the first one: its source, padded (from then on every reference is a reconstruction)
+    for g in range(G):
+        s0 = d_src[g, 0]
+        y, u, v = s0[:Hd], s0[Hd:, :Wd // 2], s0[Hd:, Wd // 2:]
+        r = d_rec[g, 0]
+        r[:geo.u_base].view(geo.ph, geo.pw)[PAD:PAD + Hd, PAD:PAD + Wd] = y
+        r[geo.u_base:geo.v_base].view(geo.cph, geo.cpw)[PAD // 2:PAD // 2 + Hd // 2, PAD // 2:PAD // 2 + Wd // 2] = u
+        r[geo.v_base:geo.v_base + geo.cph * geo.cpw].view(geo.cph, geo.cpw)[PAD // 2:PAD // 2 + Hd // 2, PAD // 2:PAD // 2 + Wd // 2] = v
+    dsc0 = (B.YuvPlanes * G)()
+    for g in range(G):
+        yuv_desc(dsc0[g], g, 0)
     torch.cuda.synchronize()
-    eob_h = d_eob.cpu().numpy().view(np.uint16)
-    # what the synthesised mode decision produced (reported with the result: the transform / rate stages' work depends on it)
-    with torch.no_grad():
-        resid = (d_src[1:, :Hd].to(torch.int16) - d_pred[:, :Hd].to(torch.int16)).abs().to(torch.float32).mean().item()
-    workload_stats = {"mean_abs_luma_residual": round(resid, 2),
-                      "mean_eob_by_tx_size": [round(float(eob_h[tq_blocks_all["tx_size"] == ts].mean()), 1) for ts in range(4)],
-                      "blocks_by_tx_size": counts}
+    B.check(lib.svt_hip_ref_pad_batch_device(me_ctxs[0], G, dsc0, PAD, PAD))
+    B.check(lib.svt_hip_ctx_synchronize(me_ctxs[0]))
 
-    # ---- stage "rate": bits of every transform block from the quantised coefficients the transform stage wrote ----
-    rtab, rscan = T.rate_tables()
-    roffs, _ = T.rate_scan_offsets()
-    rb = np.zeros(len(tq_blocks_all), dtype=B.RATE_BLOCK_DTYPE)
-    rb["coeff_off"], rb["tx_size"], rb["eob"] = tq_blocks_all["coeff_off"], tq_blocks_all["tx_size"], eob_h
-    rb["scan_off"] = np.array([roffs[(ts, 0)] for ts in range(4)], np.uint32)[tq_blocks_all["tx_size"]]
-    rb["plane_type"], rb["is_inter"] = tq_blocks_all["qtab"], 1
-    rb["ctx"] = rate_ctx
-    d_rb, d_rt, d_rs = to_dev(rb.view(np.uint8)), to_dev(np.ascontiguousarray(rtab).reshape(1).view(np.uint8)), to_dev(rscan)
-    d_bits = dev_zeros(len(rb), torch.int32)
 
-    def run_tq_rd(buf):   # distortion + rate behind the quantiser: perform_dist_rate_calc in one pass
-        B.check(lib.svt_hip_tq_rd_batch_device(ctx_enc, C.c_void_p(d_src.data_ptr()), C.c_void_p(d_pred.data_ptr()), C.c_void_p(d_rec[buf].data_ptr()),
-                                               C.c_void_p(d_blocks.data_ptr()), cnt_c, C.c_void_p(d_qt.data_ptr()), C.c_void_p(d_iscan.data_ptr()),
-                                               C.c_void_p(d_q.data_ptr()), C.c_void_p(d_dq.data_ptr()), C.c_void_p(d_eob.data_ptr()),
-                                               C.c_void_p(d_dist.data_ptr()), C.c_void_p(d_rt.data_ptr()), C.c_void_p(d_rs.data_ptr()),
-                                               C.c_void_p(d_bits.data_ptr())))
-
-    run_tq = run_tq_plain if separate_rate else run_tq_rd
-
-    def run_rate():
-        B.check(lib.svt_hip_coeff_rate_batch_device(ctx_enc, C.c_void_p(d_q.data_ptr()), C.c_void_p(d_rb.data_ptr()), len(rb), C.c_void_p(d_rt.data_ptr()),
-                                                    C.c_void_p(d_rs.data_ptr()), C.c_void_p(d_bits.data_ptr())))
-
-    # ---- stage "lf": in-loop deblocking of the 16 reconstructed pictures, one batched launch; per-picture masks from the
-    # pictures' own mode info (svt_hip_lf_build_masks), filter level from the q index ----
     level = lib.svt_hip_lf_level_from_q(ac_q, 0)
     thr = B.LfThresh()
     lib.svt_hip_lf_thresh_init(C.byref(thr), 0)
-    sb_rows, sb_cols = (mi_rows + 7) // 8, (mi_cols + 7) // 8
-    d_lfm = []
-    luma = (tq_blocks_all["qtab"] == 0)
-    for k in range(MINIGOP):
-        sel = luma & (pic_of_block == k)
-        off = tq_blocks_all["recon_off"][sel].astype(np.int64) - k * pic_bytes
-        r4, c4 = (off // plane_w) >> 2, (off % plane_w) >> 2
-        n4 = (1 << tq_blocks_all["tx_size"][sel].astype(np.int64))
-        nz4 = np.zeros(((Hd + 31) // 32 * 8, (Wd + 31) // 32 * 8), bool)
-        nzb = eob_h[sel] != 0
-        for s in range(4):   # a block of 2^s x 2^s 4x4 units
-            m = nzb & (n4 == (1 << s))
-            for dy in range(1 << s):
-                for dx in range(1 << s):
-                    nz4[r4[m] + dy, c4[m] + dx] = True
-        lmi = build_lf_mode_info(B, kcell_list[k], nz4, mi_rows, mi_cols, level)
-        lfm = np.zeros((sb_rows, sb_cols), dtype=B.LF_MASK_DTYPE)
-        B.check(lib.svt_hip_lf_build_masks(lmi.ctypes.data_as(C.c_void_p), mi_cols, mi_rows, mi_cols, lfm.ctypes.data_as(C.c_void_p), sb_cols))
-        d_lfm.append(to_dev(lfm.view(np.uint8)))
-    lfm_ptrs = (C.c_void_p * MINIGOP)(*[t.data_ptr() for t in d_lfm])
-    i32 = lambda v: (C.c_int32 * MINIGOP)(*[v] * MINIGOP)
-    lfs, mrs, mcs = i32(sb_cols), i32(mi_rows), i32(mi_cols)
-    lf_desc = []
-    for buf in range(2):
-        dsc = (B.YuvPlanes * MINIGOP)()
-        for k in range(MINIGOP):
-            base = d_rec[buf].data_ptr() + k * pic_bytes
-            d = dsc[k]
-            d.y, d.u, d.v = base, base + Hd * plane_w, base + Hd * plane_w + Wd // 2
-            d.y_stride, d.uv_stride, d.width, d.height = plane_w, plane_w, Wd, Hd
-        lf_desc.append(dsc)
+    d_lfm = [[dev_zeros(sb_rows * sb_cols * B.LF_MASK_DTYPE.itemsize, torch.uint8) if i else None for i in range(MINIGOP + 1)] for _ in range(G)]
+    separate_rate = os.environ.get("SVT_BENCH_SEPARATE_RATE", "0") == "1"
+    rate_ctx_rng = np.random.default_rng(8)
 
-    def run_lf(buf):
-        B.check(lib.svt_hip_lf_batch_device(ctx_lf, MINIGOP, lf_desc[buf], lfm_ptrs, lfs, C.byref(thr), mrs, mcs, 0))
+    def build_wave(gops, layer):
+        """descriptors of one wave = the pictures of one temporal layer of the current mini-GOP of each GOP of a group, for both
+        parities of the base-picture slots"""
+        items = [(g, i) for g in gops for i in pics_of_layer(layer)]
+        n = len(items)
+        wv = {"n": n, "items": items, "mc": [], "yuv": [], "blocks": []}
+        for par in range(2):
+            mc = (B.McPicture * n)()
+            yv = (B.YuvPlanes * n)()
+            for k, (g, i) in enumerate(items):
+                mp = mc[k]
+                mp.d_mi, mp.mi_stride, mp.mi_rows, mp.mi_cols, mp.use_subpel = d_mi[g][i].data_ptr(), mi_cols, mi_rows, mi_cols, 1
+                for l in range(2):
+                    yuv_desc(mp.ref[l], g, slot_of(refs_of(i)[l], par))
+                pb = pred_ptr(g, i)
+                mp.pred.y, mp.pred.u, mp.pred.v = pb, pb + Hd * plane_w, pb + Hd * plane_w + Wd // 2
+                mp.pred.y_stride, mp.pred.uv_stride, mp.pred.width, mp.pred.height = plane_w, plane_w, Wd, Hd
+                yuv_desc(yv[k], g, slot_of(i, par))
+            wv["mc"].append(mc)
+            wv["yuv"].append(yv)
+        # transform blocks of the wave, grouped by transform size across its pictures
+        per_ts, pic_of = [[] for _ in range(4)], [[] for _ in range(4)]
+        for k, (g, i) in enumerate(items):
+            arrs = blk_tight[g][i]
+            nn_pic = np.concatenate([np.full(len(a), 16 << (2 * ts), np.int64) for ts, a in enumerate(arrs)])
+            coff = np.concatenate([[0], np.cumsum(nn_pic)[:-1]]) + (g * MINIGOP + i - 1) * geo.coeffs
+            pos = 0
+            for ts, a in enumerate(arrs):
+                b = a.copy()
+                b["coeff_off"] = coff[pos:pos + len(a)].astype(np.uint32)
+                pos += len(a)
+                per_ts[ts].append(b)
+                pic_of[ts].append(np.full(len(a), k, np.int32))
+        blocks = np.concatenate([b for ts in range(4) for b in per_ts[ts]])
+        wv["pic_of_block"] = np.concatenate([p_ for ts in range(4) for p_ in pic_of[ts]])
+        wv["counts"] = [sum(len(b) for b in per_ts[ts]) for ts in range(4)]
+        wv["cnt_c"] = (C.c_int32 * 4)(*wv["counts"])
+        tight = blocks["src_off"].astype(np.int64)      # offsets relative to the picture, tight layout
+        gi = np.array(items, np.int64)[wv["pic_of_block"]]
+        roff, rstride = geo.recon_offsets(tight)
+        blocks["src_off"] = (tight + (gi[:, 0] * (MINIGOP + 1) + gi[:, 1]) * pic_bytes).astype(np.uint32)
+        blocks["pred_off"] = (tight + (gi[:, 0] * MINIGOP + gi[:, 1] - 1) * pic_bytes).astype(np.uint32)
+        blocks["recon_stride"] = rstride
+        rate_ctx = rate_ctx_rng.integers(0, 3, len(blocks)).astype(np.uint8)    # entropy context of every block (an input)
+        blocks["pad"][:, 0] = rate_ctx | (blocks["qtab"] << 2) | (1 << 3)         # SVT_TQ_RATE_INFO(ctx, plane_type, is_inter = 1)
+        for par in range(2):
+            slots = np.array([slot_of(i, par) for _, i in items], np.int64)[wv["pic_of_block"]]
+            bp = blocks.copy()
+            bp["recon_off"] = (roff + (gi[:, 0] * (MINIGOP + 1) + slots) * geo.rec_bytes).astype(np.uint32)
+            if par == 1 and layer != 0:
+                wv["blocks"].append(wv["blocks"][0])    # only the base picture changes its slot
+            else:
+                wv["blocks"].append(to_dev(bp.view(np.uint8)))
+        wv["blocks_host"] = blocks
+        nb = len(blocks)
+        wv["eob"], wv["dist"], wv["bits"] = dev_zeros(nb, torch.int16), dev_zeros(2 * nb, torch.int64), dev_zeros(nb, torch.int32)
+        wv["lfm"] = (C.c_void_p * n)(*[d_lfm[g][i].data_ptr() for g, i in items])
+        i32 = lambda v: (C.c_int32 * n)(*[v] * n)
+        wv["lfs"], wv["mrs"], wv["mcs"] = i32(sb_cols), i32(mi_rows), i32(mi_cols)
+        if separate_rate:
+            roffs, _ = T.rate_scan_offsets()
+            rb = np.zeros(nb, dtype=B.RATE_BLOCK_DTYPE)
+            rb["coeff_off"], rb["tx_size"], rb["plane_type"], rb["is_inter"], rb["ctx"] = blocks["coeff_off"], blocks["tx_size"], blocks["qtab"], 1, rate_ctx
+            rb["scan_off"] = np.array([roffs[(ts, 0)] for ts in range(4)], np.uint32)[blocks["tx_size"]]
+            wv["rb_host"] = rb
+        return wv
 
-    # split-GOP hand-off (optional, N > 1): the padded base-layer reconstruction (luma + chroma with 80 / 40 samples of padding)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+
+    def run_mc(ctx_, wv, par):
+        B.check(lib.svt_hip_inter_pred_batch_device(ctx_, wv["n"], wv["mc"][par]))
+
+    def run_tq(ctx_, wv, par, plain=False):
+        if plain or separate_rate:
+            B.check(lib.svt_hip_tq_batch_dist_device(ctx_, vp(d_src), vp(d_pred), vp(d_rec), vp(wv["blocks"][par]), wv["cnt_c"], vp(d_qt), vp(d_iscan), vp(d_q),
+                                                     vp(d_dq), vp(wv["eob"]), vp(wv["dist"])))
+        else:   # distortion + rate behind the quantiser: perform_dist_rate_calc in one pass
+            B.check(lib.svt_hip_tq_rd_batch_device(ctx_, vp(d_src), vp(d_pred), vp(d_rec), vp(wv["blocks"][par]), wv["cnt_c"], vp(d_qt), vp(d_iscan), vp(d_q),
+                                                   vp(d_dq), vp(wv["eob"]), vp(wv["dist"]), vp(d_rt), vp(d_rs), vp(wv["bits"])))
+
+    def run_rate(ctx_, wv):
+        B.check(lib.svt_hip_coeff_rate_batch_device(ctx_, vp(d_q), vp(wv["d_rb"]), len(wv["rb_host"]), vp(d_rt), vp(d_rs), vp(wv["bits"])))
+
+    def run_lf(ctx_, wv, par):
+        B.check(lib.svt_hip_lf_batch_device(ctx_, wv["n"], wv["yuv"][par], wv["lfm"], wv["lfs"], C.byref(thr), wv["mrs"], wv["mcs"], 0))
+
+    def run_pad(ctx_, wv, par):
+        B.check(lib.svt_hip_ref_pad_batch_device(ctx_, wv["n"], wv["yuv"][par], PAD, PAD))
+
+    def build_pipeline(gops, pairs):
+        """a pipeline = a set of GOPs in flight, split into groups with one EncDec stream each"""
+        ng = len(pairs)
+        groups = [gops[k::ng] for k in range(ng)]
+        P = {"gops": gops, "groups": [], "me_ev": []}
+        P["me_sets"], P["me_slot"] = build_me_launches(gops)
+        for grp, (st_, ctx_) in zip(groups, pairs):
+            P["groups"].append({"gops": grp, "stream": st_, "ctx": ctx_, "waves": [build_wave(grp, layer) for layer in range(5)]})
+        return P
+
+    P_main = build_pipeline(all_gops, grp_pairs)
+
+    # ---- setup pass of the dependent chain (untimed, parity 0): per wave prediction -> transform -> [eobs -> loop-filter masks of
+    # the wave's pictures: skip flags are mode decision's output] -> deblocking -> padding ----
+    eob_stats, resid_acc = [[] for _ in range(4)], []
+    for layer in range(5):
+        for grp in P_main["groups"]:
+            wv, ctx_ = grp["waves"][layer], grp["ctx"]
+            with torch.cuda.stream(grp["stream"]):
+                run_mc(ctx_, wv, 0)
+                run_tq(ctx_, wv, 0, plain=True)
+            B.check(lib.svt_hip_ctx_synchronize(ctx_))
+            eob_h = wv["eob"].cpu().numpy().view(np.uint16)
+            blocks = wv["blocks_host"]
+            if separate_rate:
+                wv["rb_host"]["eob"] = eob_h
+                wv["d_rb"] = to_dev(wv["rb_host"].view(np.uint8))
+            for ts in range(4):
+                eob_stats[ts].append(eob_h[blocks["tx_size"] == ts].astype(np.int64))
+            luma = blocks["qtab"] == 0
+            for k, (g, i) in enumerate(wv["items"]):
+                sel = luma & (wv["pic_of_block"] == k)
+                off = blocks["src_off"][sel].astype(np.int64) - (g * (MINIGOP + 1) + i) * pic_bytes
+                r4, c4 = (off // plane_w) >> 2, (off % plane_w) >> 2
+                n4 = (1 << blocks["tx_size"][sel].astype(np.int64))
+                nz4 = np.zeros(((Hd + 31) // 32 * 8, (Wd + 31) // 32 * 8), bool)
+                nzb = eob_h[sel] != 0
+                for s in range(4):   # a block of 2^s x 2^s 4x4 units
+                    m = nzb & (n4 == (1 << s))
+                    for dy in range(1 << s):
+                        for dx in range(1 << s):
+                            nz4[r4[m] + dy, c4[m] + dx] = True
+                lmi = build_lf_mode_info(B, kcell[g][i], nz4, mi_rows, mi_cols, level)
+                lfm = np.zeros((sb_rows, sb_cols), dtype=B.LF_MASK_DTYPE)
+                B.check(lib.svt_hip_lf_build_masks(lmi.ctypes.data_as(C.c_void_p), mi_cols, mi_rows, mi_cols, lfm.ctypes.data_as(C.c_void_p), sb_cols))
+                d_lfm[g][i].copy_(torch.from_numpy(lfm.view(np.uint8).reshape(-1)))
+                if g == 0:
+                    with torch.no_grad():
+                        resid_acc.append((d_src[0, i, :Hd].to(torch.int16) - d_pred[0, i - 1, :Hd].to(torch.int16)).abs().to(torch.float32).mean().item())
+            torch.cuda.synchronize()
+            with torch.cuda.stream(grp["stream"]):
+                run_lf(ctx_, wv, 0)
+                run_pad(ctx_, wv, 0)
+            B.check(lib.svt_hip_ctx_synchronize(ctx_))
+    n_blocks_step = sum(len(w_["blocks_host"]) for grp in P_main["groups"] for w_ in grp["waves"])
+    counts_step = [sum(w_["counts"][ts] for grp in P_main["groups"] for w_ in grp["waves"]) for ts in range(4)]
+    workload_stats = {"mean_abs_luma_residual_gop0": round(float(np.mean(resid_acc)), 2),
+                      "mean_eob_by_tx_size": [round(float(np.concatenate(eob_stats[ts]).mean()), 1) for ts in range(4)],
+                      "blocks_by_tx_size": counts_step}
+    parity = [1]    # the setup pass ran at parity 0: the new base pictures are in slot 16
+    P_single = None if args.no_single else build_pipeline([0], [(single_stream, ctx_single)])
+    setup_s = time.perf_counter() - t_setup0
+
+    # split-GOP hand-off (optional, N > 1): the padded base-layer reconstruction of this rank's first GOP, as the deblocking +
+    # padding of this step left it (a whole reference picture: luma + chroma with 80 / 40 samples of border)
     handoff = args.handoff and world > 1
     if handoff:
-        ho_bytes = (Wd + 2 * pad) * (Hd + 2 * pad) + 2 * (Wd // 2 + pad) * (Hd // 2 + pad)
-        ho_send, ho_recv = dev_zeros(ho_bytes, torch.uint8), dev_zeros(ho_bytes, torch.uint8)
+        ho_recv = dev_zeros(geo.rec_bytes, torch.uint8)
         ho_stream = torch.cuda.Stream(device=local_rank)
 
-    def run_handoff():
-        # ordered after this step's deblocking (the picture handed over is its output), overlapped with the next step's work
-        ho_stream.wait_stream(streams[2])
+    def run_handoff(P, par):
+        grp0 = P["groups"][0]
+        ho_stream.wait_stream(grp0["stream"])   # ordered after this step's deblocking + padding of the base picture
         with torch.cuda.stream(ho_stream):
-            ops = [dist.P2POp(dist.isend, ho_send, (rank + 1) % world), dist.P2POp(dist.irecv, ho_recv, (rank - 1) % world)]
+            ops = [dist.P2POp(dist.isend, d_rec[grp0["gops"][0], slot_of(MINIGOP, par)], (rank + 1) % world), dist.P2POp(dist.irecv, ho_recv, (rank - 1) % world)]
             for w_ in dist.batch_isend_irecv(ops):
                 w_.wait()
 
     stages = set(args.stages.split(","))
-    ev = []            # (stage name, start event, stop event) of every stage of every timed step
-    lf_done = [None, None]   # event after the deblocking that last read reconstruction buffer b
-    pa_done, me_done = [None, None], [None, None]   # analysed-plane set s: written / last read
 
-    def staged(name, stream, fn, record):
+    def make_state():
+        return {"pa_done": [None, None], "me_done": [None, None], "step": 0, "ev": []}
+
+    def staged(S, name, stream, fn, pool):
         if name not in stages:
             return
-        if not record:
+        if pool is None:
             return fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = pool.pair()
         e0.record(stream)
         fn()
         e1.record(stream)
-        ev.append((name, e0, e1))
+        S["ev"].append((name, e0, e1))
 
-    step_no = [0]
-
-    def step(record=False):
-        buf = step_no[0] & 1
-        step_no[0] += 1
-        # ME side (one mini-GOP ahead of the EncDec side, as the reference's ME threads are): PA writes the planes ME reads
-        # and picture analysis of the NEXT mini-GOP runs beside it on its own stream
-        if pa_done[buf] is not None:
-            streams[0].wait_event(pa_done[buf])
-        staged("me", streams[0], lambda: run_me(record, buf), record)
+    def step(P, S, pool=None):
+        buf = S["step"] & 1
+        S["step"] += 1
+        par = parity[0]
+        parity[0] ^= 1
+        # ME side (one mini-GOP ahead of the EncDec side, as the reference's ME threads are): PA writes the planes ME reads and
+        # picture analysis of the NEXT mini-GOP runs beside it on its own stream
+        if S["pa_done"][buf] is not None:
+            me_streams[0].wait_event(S["pa_done"][buf])
+        staged(S, "me", me_streams[0], lambda: run_me(P, buf, pool), pool)
         if "me" in stages:
-            me_done[buf] = torch.cuda.Event()
-            me_done[buf].record(streams[0])
+            S["me_done"][buf] = torch.cuda.Event()
+            S["me_done"][buf].record(me_streams[0])
         if "pa" in stages:
-            if me_done[1 - buf] is not None:
-                pa_stream.wait_event(me_done[1 - buf])   # ME of the previous step read the set written now
-            staged("pa", pa_stream, lambda: pa_call(ctx_pa, pa_idx, 1 - buf), record)
-            pa_done[1 - buf] = torch.cuda.Event()
-            pa_done[1 - buf].record(pa_stream)
-        # EncDec side: prediction -> transform (reads the prediction, writes coefficients + reconstruction) -> rate (reads the
-        # coefficients); the reconstruction buffer is free again once the deblocking that used it two steps ago is done
-        if lf_done[buf] is not None:
-            streams[1].wait_event(lf_done[buf])
-        staged("mc", streams[1], run_mc, record)
-        staged("tq", streams[1], lambda: run_tq(buf), record)
-        e_tq = torch.cuda.Event()
-        e_tq.record(streams[1])
-        if separate_rate:
-            staged("rate", streams[1], run_rate, record)
-        streams[2].wait_event(e_tq)
-        staged("lf", streams[2], lambda: run_lf(buf), record)
-        lf_done[buf] = torch.cuda.Event()
-        lf_done[buf].record(streams[2])
+            if S["me_done"][1 - buf] is not None:
+                pa_stream.wait_event(S["me_done"][1 - buf])   # ME of the previous step read the set written now
+            staged(S, "pa", pa_stream, lambda: pa_call(ctx_pa, P["gops"], pa_idx, 1 - buf), pool)
+            S["pa_done"][1 - buf] = torch.cuda.Event()
+            S["pa_done"][1 - buf].record(pa_stream)
+        # EncDec side: the five dependent waves of every group, each stage on the group's stream in program order
+        for layer in range(5):
+            for grp in P["groups"]:
+                wv, ctx_, st_ = grp["waves"][layer], grp["ctx"], grp["stream"]
+                staged(S, "mc", st_, lambda: run_mc(ctx_, wv, par), pool)
+                staged(S, "tq", st_, lambda: run_tq(ctx_, wv, par), pool)
+                if separate_rate:
+                    staged(S, "rate", st_, lambda: run_rate(ctx_, wv), pool)
+                staged(S, "lf", st_, lambda: run_lf(ctx_, wv, par), pool)
+                staged(S, "pad", st_, lambda: run_pad(ctx_, wv, par), pool)
         if handoff:
-            run_handoff()
+            run_handoff(P, par)
 
     def sync():
         for c_ in ctxs:
             B.check(lib.svt_hip_ctx_synchronize(c_))
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    # host cost of a step = time to enqueue it while nothing holds the enqueue thread back: over the first steps only -- once the
-    # 64-slot descriptor rings of the contexts are full (~20 steps ahead of the GPU) the thread waits for the GPU and the
-    # figure would read as the GPU's step time
-    n_free = min(args.steps, 16)
-    for i_ in range(args.steps):
-        step(record=True)
-        if i_ + 1 == n_free:
-            t_enqueued = time.perf_counter() - t0
-    sync()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    dt = GS.reduce_elapsed(dt, dist if world > 1 else None, dev)
+    def timed_run(P, steps, warmup, barrier):
+        S = make_state()
+        n_ev = 2 * steps * (len(P["me_sets"][0]) + 2 + 5 * len(P["groups"]) * (5 if separate_rate else 4)) + 8
+        pool = EventPool(n_ev)
+        P["me_ev"] = []
+        for _ in range(warmup):
+            step(P, S)
+        sync()
+        if barrier and world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        # host cost of a step = time to enqueue it while nothing holds the enqueue thread back: over the first steps only -- once
+        # the 64-slot descriptor rings of the contexts are full the thread waits for the GPU
+        n_free = min(steps, 8)
+        t_enq = 0.0
+        for i_ in range(steps):
+            step(P, S, pool)
+            if i_ + 1 == n_free:
+                t_enq = time.perf_counter() - t0
+        sync()
+        if barrier and world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        stage_ms = {s: 0.0 for s in STAGES}
+        for name, e0, e1 in S["ev"]:
+            stage_ms[name] += e0.elapsed_time(e1) / steps
+        me_launch_ms = sum(e0.elapsed_time(e1) for e0, e1 in P["me_ev"])
+        return dt, t_enq / n_free, stage_ms, me_launch_ms, len(P["me_ev"])
 
-    # ---- per-stage time: HIP events on each stage's own stream, bracketing that stage's launches of every timed step (so
-    # it includes whatever slowdown the overlap with the other stages causes, like a rocprofv3 trace) ----
-    stage_ms = {s: 0.0 for s in STAGES}
-    for name, e0, e1 in ev:
-        stage_ms[name] += e0.elapsed_time(e1) / args.steps
-    me_launch_ms = sum(e0.elapsed_time(e1) for e0, e1 in me_ev)   # sum of the individual launch durations (the two ME streams overlap)
-    n_me_launch = max(1, len(me_ev))
+    dt, enq_s, stage_ms, me_launch_ms, n_me_launch = timed_run(P_main, args.steps, args.warmup, True)
+    dt = GS.reduce_elapsed(dt, dist if world > 1 else None, dev)
+    single = None
+    if P_single is not None:
+        k1 = max(4, args.steps)
+        dt1, enq1, stage1, _, _ = timed_run(P_single, k1, max(2, args.warmup), False)
+        single = {"frames_per_s": MINIGOP * k1 / dt1, "ms_per_minigop": dt1 / k1 * 1e3, "steps": k1, "stage_ms": stage1, "enq": enq1}
+
     L = Wd * Hd
-    inter = np.concatenate([(m["ref_list"][..., 0] >= 0).ravel() for m in mi_list])
-    comp = np.concatenate([(m["ref_list"][..., 1] >= 0).ravel() for m in mi_list])
+    pics_step = G * MINIGOP
+    n_launch_step = len(P_main["me_sets"][0])
     stage_bytes = {
         # source luma read + padded / decimated planes written (SURVEY 8(f)-1)
-        "pa": MINIGOP * int(L + (Wd + 2 * pads[0]) * (Hd + 2 * pads[0]) + (Wd // 4 + 2 * pads[2]) * (Hd // 4 + 2 * pads[2]) +
-                            (((Wd // 2 + 2 * pads[1]) * (Hd // 2 + 2 * pads[1])) if l1_on else 0)),
-        "me": MINIGOP * algorithmic_bytes_me(Wd, Hd, 2, l1_on),
+        "pa": pics_step * int(L + (Wd + 2 * pads[0]) * (Hd + 2 * pads[0]) + (Wd // 4 + 2 * pads[2]) * (Hd // 4 + 2 * pads[2]) +
+                              (((Wd // 2 + 2 * pads[1]) * (Hd // 2 + 2 * pads[1])) if l1_on else 0)),
+        "me": pics_step * algorithmic_bytes_me(Wd, Hd, 2, l1_on),
         # per 8x8 unit: 96 bytes (64 luma + 2 x 16 chroma) read per reference and written once, + the 12-byte mode-info record
-        "mc": int(96 * (inter.sum() + (inter & comp).sum()) + 96 * inter.sum() + 12 * inter.size),
-        "tq": MINIGOP * int(7.5 * L),                # src 1.5L + pred 1.5L + qcoeff 3L + recon 1.5L (the kernel also writes dqcoeff, +3L)
-        # per block: the coefficients up to eob (whole 64-byte lines), 16-byte descriptor, 4-byte result
-        "rate": int(np.sum(np.minimum(nn, ((eob_h.astype(np.int64) * 2 + 63) // 64 + 1) * 32)) * 2 + 20 * len(rb)),
-        "lf": MINIGOP * (3 * L + 160 * nsb),         # recon read + write (3L) + masks
+        "mc": int(96 * (inter_units + comp_units) + 96 * inter_units + 12 * mi_units),
+        "tq": pics_step * int(7.5 * L),                # SURVEY 8(d): src 1.5L + pred 1.5L + qcoeff 3L + recon 1.5L (the kernel also writes dqcoeff, +3L)
+        "rate": 0,
+        "lf": pics_step * (3 * L + 160 * nsb),         # recon read + write (3L) + masks
+        # the border of the three planes written, the edge samples read
+        "pad": pics_step * int((geo.pw * geo.ph - L) + 2 * (geo.cpw * geo.cph - L // 4) + 2 * (Hd + Wd)),
     }
     kernel_of = {"pa": "svt_pa_plane_kernel", "me": "svt_me_sb_kernel", "mc": "svt_mc_kernel",
                  "tq": "svt_tq_kernel<4|8|16|32>" + ("" if separate_rate else " (+ fused coefficient rate)"),
-                 "rate": "svt_rate_kernel", "lf": "svt_lf_kernel"}
+                 "rate": "svt_rate_kernel", "lf": "svt_lf_kernel", "pad": "svt_refpad_kernel"}
     if not separate_rate:
         stages.discard("rate")
     if rank != 0:
@@ -628,50 +848,63 @@ def main():
     me_ms = max(stage_ms["me"], 1e-9)
     # roofline of the dominant kernel, per launch: algorithmic bytes of a launch / its own duration, averaged over the
     # launches = (bytes of all launches) / (sum of their durations); the stream-span figure is given beside it
-    per_launch_ms = me_launch_ms / n_me_launch
-    achieved = stage_bytes["me"] * args.steps / max(me_launch_ms * 1e-3, 1e-12) / 1e9 if me_ev else 0.0
-    traffic, valu = None, None
+    per_launch_ms = me_launch_ms / max(1, n_me_launch)
+    achieved = stage_bytes["me"] * args.steps / max(me_launch_ms * 1e-3, 1e-12) / 1e9 if n_me_launch else 0.0
+    traffic, valu, traffic_source = None, None, None
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj) and (Wd, Hd) == (W4K, H4K):
         rec = json.load(open(tj)).get("svt_me_sb_kernel", {})
-        if rec.get("bytes_per_step"):
-            traffic = int(rec["bytes_per_step"] / len(me_launches))   # per launch, like `achieved`
+        if rec.get("bytes_per_step"):   # the profiling run's step is one mini-GOP of one GOP
+            traffic = int(rec["bytes_per_step"] * G / n_launch_step)      # per launch, like `achieved`
+            traffic_source = "profiles/traffic.json (rocprofv3 --pmc passes of tools/profile_round.sh, committed; not measured in this run)"
         vi = rec.get("valu_wave_insts_per_step")
         if vi and "me" in stages:
             # the kernel's real roof: 64-lane VALU instructions issued (rocprofv3 SQ_INSTS_VALU, profiles/) per second against
             # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (MI355X_MICROARCH.md)
-            ach = vi * 64 / (me_ms * 1e-3) / 1e12
-            valu = {"achieved": round(ach, 2), "peak": 39.3, "unit": "T lane-ops/s", "frac": round(ach / 39.3, 4), "wave_insts_per_step": vi}
-    fps = GS.aggregate_rate(MINIGOP, args.steps, world, dt)
+            ach = vi * G * 64 / (me_ms * 1e-3) / 1e12
+            valu = {"achieved": round(ach, 2), "peak": 39.3, "unit": "T lane-ops/s", "frac": round(ach / 39.3, 4), "wave_insts_per_minigop": vi,
+                    "source": "profiles/traffic.json"}
+    fps = GS.aggregate_rate(pics_step, args.steps, world, dt)
     out = {
-        "metric": "encoded frames/sec (block-level DSP hot path: picture analysis + ME + inter prediction + DCT/quant/recon + "
-                  "coefficient rate + deblock), 4Kp60 yuv420p enc-mode 8",
+        "metric": "encoded frames/sec (block-level DSP hot path: picture analysis + ME + inter prediction from reconstructed references + "
+                  "DCT/quant/recon + coefficient rate + deblock + reference padding), 4Kp60 yuv420p enc-mode 8",
         "value": round(fps, 2),
         "unit": "frames/s",
         "mpixels_per_s": round(fps * Wd * Hd / 1e6, 1),
+        "single_gop_value": round(single["frames_per_s"], 2) if single else None,
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "host_enqueue_ms_per_step": round(t_enqueued / n_free * 1e3, 3),
+        "ms_per_minigop": round(dt / args.steps / G * 1e3, 3),
+        "host_enqueue_ms_per_step": round(enq_s * 1e3, 3),
+        "setup_s": round(setup_s, 1),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": f"{Wd}x{Hd} 8-bit yuv420p, -enc-mode 8 -tune 1 -q 40, 1xMI355X per rank; step = one 16-picture "
-                               "mini-GOP (5 temporal layers, B pictures, 2 reference lists) through the hot path, every stage "
-                               "consuming the previous stage's output",
+        "config": {"workload": f"{Wd}x{Hd} 8-bit yuv420p, -enc-mode 8 -tune 1 -q 40, 1xMI355X per rank; step = one 16-picture mini-GOP (5 temporal "
+                               f"layers, B pictures, 2 reference lists) of each of {G} closed GOPs in flight; ME side on source pictures one "
+                               "mini-GOP ahead; EncDec side as five dependent temporal-layer waves per GOP, each wave: inter prediction from the "
+                               "deblocked + padded reconstruction of its lower-layer references -> transform / quant / recon (+ distortion + "
+                               "rate) -> deblocking -> reference padding, in place in the reference buffers",
+                   "gops_in_flight": G, "gop_groups": n_groups,
                    "stages": ["picture_analysis", "motion_estimation", "inter_prediction", "transform_quant_recon_distortion",
-                              "coefficient_rate", "deblocking"],
+                              "coefficient_rate", "deblocking", "reference_padding"],
                    "stages_run": [s for s in STAGES if s in stages],
-                   "pictures_per_step": MINIGOP, "transform_blocks_per_step": int(len(tq_blocks_all)), "q_index": Q_INDEX,
+                   "pictures_per_step": pics_step, "transform_blocks_per_step": int(n_blocks_step), "q_index": Q_INDEX,
+                   "deblocked_pictures": "all (as with reconstructed output enabled; the reference skips non-reference pictures otherwise)",
                    "workload_stats": workload_stats,
-                   "parallelism": f"gop-shard x{world}" + (" + split-GOP reference hand-off (RCCL send/recv)" if handoff else "")},
+                   "parallelism": f"gop-shard x{world}" + (" + split-GOP reference hand-off (RCCL send/recv of the padded base-layer reconstruction)" if handoff else "")},
+        "single_gop": None if not single else {
+            "frames_per_s": round(single["frames_per_s"], 2), "ms_per_minigop": round(single["ms_per_minigop"], 3), "gops_in_flight": 1, "steps": single["steps"],
+            "stage_ms_per_minigop": {s: round(single["stage_ms"][s], 3) for s in STAGES if s in stages},
+            "note": "one GOP: the five waves of a mini-GOP run one after the other on one stream (only ME / picture analysis of the next mini-GOP overlap them)"},
         "roofline": {"bound": "hbm", "kernel": "svt_me_sb_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
-                     "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-                     "launches_per_step": len(me_launches), "avg_launch_ms": round(per_launch_ms, 4),
-                     "algorithmic_bytes_per_launch": int(stage_bytes["me"] / len(me_launches)),
+                     "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_source,
+                     "launches_per_step": n_launch_step, "avg_launch_ms": round(per_launch_ms, 4),
+                     "algorithmic_bytes_per_launch": int(stage_bytes["me"] / n_launch_step),
                      "stream_span": {"kernel_ms_per_step": round(me_ms, 3), "GB_per_s": round(stage_bytes["me"] / (me_ms * 1e-3) / 1e9, 2),
                                      "frac": round(stage_bytes["me"] / (me_ms * 1e-3) / 8e12, 5),
                                      "note": f"{n_me_streams} ME streams run launches concurrently: each launch's own duration is stretched"},
@@ -680,11 +913,32 @@ def main():
                                    "GB_per_s": round(stage_bytes[s] / (max(stage_ms[s], 1e-9) * 1e-3) / 1e9, 2),
                                    "frac_of_8TBps": round(stage_bytes[s] / (max(stage_ms[s], 1e-9) * 1e-3) / 8e12, 5)}
                     for s in STAGES if s in stages},
+        "pcie_note": f"inputs are resident in HBM when the clock starts; a 4K 4:2:0 picture is {pic_bytes / 1e6:.1f} MB, so {round(fps)} frames/s "
+                     f"would need {fps * pic_bytes / 1e9:.0f} GB/s of host-to-device traffic if every picture crossed PCIe (gen5 x16 sustains ~50): the "
+                     "PCIe-inclusive rate of the public-API path is `api_path` (tests/c/enc_app.c, DESIGN.md section 2)",
     }
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(T, B, frames, src_all, mi_list, tq_blocks_all, pic_of_block, qtabs, iscan, rb, rtab, rscan,
-                                           [np.frombuffer(t.cpu().numpy(), dtype=B.LF_MASK_DTYPE).reshape(sb_rows, sb_cols) for t in d_lfm],
-                                           thr, Wd, Hd, plane_w, l1_on, n_coeff_all)
+        # the CPU leg works on GOP 0 in the tight layout of round 2 (one mini-GOP, blocks grouped by size across its pictures)
+        by_ts = [[] for _ in range(4)]
+        for i in range(1, MINIGOP + 1):
+            for ts, a in enumerate(blk_tight[0][i]):
+                b = a.copy()
+                for f in ("src_off", "pred_off", "recon_off"):
+                    b[f] += np.uint32((i - 1) * pic_bytes)
+                b["src_off"] += np.uint32(pic_bytes)
+                by_ts[ts].append(b)
+        blocks0 = np.concatenate([a for ts in range(4) for a in by_ts[ts]])
+        pic_of0 = np.concatenate([np.full(len(a), k, np.int32) for ts in range(4) for k, a in enumerate(by_ts[ts])])
+        nn0 = (16 << (2 * blocks0["tx_size"].astype(np.int64)))
+        blocks0["coeff_off"] = np.concatenate([[0], np.cumsum(nn0)[:-1]]).astype(np.uint32)
+        roffs, _ = T.rate_scan_offsets()
+        rb0 = np.zeros(len(blocks0), dtype=B.RATE_BLOCK_DTYPE)
+        rb0["coeff_off"], rb0["tx_size"], rb0["plane_type"], rb0["is_inter"] = blocks0["coeff_off"], blocks0["tx_size"], blocks0["qtab"], 1
+        rb0["scan_off"] = np.array([roffs[(ts, 0)] for ts in range(4)], np.uint32)[blocks0["tx_size"]]
+        rb0["ctx"] = np.random.default_rng(8).integers(0, 3, len(blocks0)).astype(np.uint8)
+        lfms0 = [np.frombuffer(d_lfm[0][i].cpu().numpy(), dtype=B.LF_MASK_DTYPE).reshape(sb_rows, sb_cols) for i in range(1, MINIGOP + 1)]
+        out["cpu_baseline"] = cpu_baseline(T, B, frames_all[0], src0, mi_host0, blocks0, pic_of0, qtabs, iscan, rb0, rtab, rscan, lfms0, thr, Wd, Hd, plane_w,
+                                           l1_on, int(nn0.sum()))
     print(json.dumps(out))
     for c_ in ctxs:
         lib.svt_hip_ctx_destroy(c_)
@@ -816,6 +1070,27 @@ def cpu_baseline(T, B, frames, src_all, mi_list, tq_blocks_all, pic_of_block, qt
             t0 = time.perf_counter()
             list(ex.map(lf_one, sample))
             t["lf"] = time.perf_counter() - t0
+            # reference padding of the deblocked pictures (in the reference the reconstruction buffer is the padded reference
+            # picture; here the port's planes are copied into padded buffers first, untimed)
+            padded = {}
+            for i in sample:
+                base = rec_h[i - 1]
+                trio = []
+                for pl, pd in ((base[:Hd], pad), (base[Hd:, :Wd // 2], pad // 2), (base[Hd:, Wd // 2:], pad // 2)):
+                    a = np.zeros((pl.shape[0] + 2 * pd, pl.shape[1] + 2 * pd), np.uint8)
+                    a[pd:pd + pl.shape[0], pd:pd + pl.shape[1]] = pl
+                    trio.append(a)
+                padded[i] = trio
+
+            def pad_one(i):
+                y, u, v = padded[i]
+                yd = B.YuvPlanes()
+                yd.y, yd.u, yd.v = y.ctypes.data + pad * y.shape[1] + pad, u.ctypes.data + (pad // 2) * u.shape[1] + pad // 2, v.ctypes.data + (pad // 2) * v.shape[1] + pad // 2
+                yd.y_stride, yd.uv_stride, yd.width, yd.height = y.shape[1], u.shape[1], Wd, Hd
+                assert orc.svt_oracle_ref_pad(C.byref(yd), pad, pad) == 0
+            t0 = time.perf_counter()
+            list(ex.map(pad_one, sample))
+            t["pad"] = time.perf_counter() - t0
         return t
 
     t_all = run(ncpu)
@@ -823,10 +1098,11 @@ def cpu_baseline(T, B, frames, src_all, mi_list, tq_blocks_all, pic_of_block, qt
     fps = lambda t: len(sample) / sum(t.values())
     return {"value": round(fps(t_all), 3), "unit": "frames/s", "cores": ncpu, "kind": "port", "cpu_model": cpu_model(),
             "value_8_cores": round(fps(t_8), 3),
+            "reference_me": reference_me_rate(T, B, orc, frames, Wd, Hd, l1_on, ncpu),
             "stage_seconds_all_cores": {k: round(v, 3) for k, v in t_all.items()},
             "stage_seconds_8_cores": {k: round(v, 3) for k, v in t_8.items()},
             "sample": f"oracle (C restatement of the reference's C path, gcc -O3 -march=native on this host = auto-vectorised \"AVX2-class\" "
-                      f"proxy) on {len(sample)} whole {Wd}x{Hd} pictures of the same mini-GOP (positions {sample}) through all six stages, "
+                      f"proxy) on {len(sample)} whole {Wd}x{Hd} pictures of the same mini-GOP (positions {sample}) through all seven stages, "
                       f"threads over independent units (ME: SB ranges, transform / rate: block ranges, prediction / deblocking / analysis: pictures); "
                       f"wall-clock with {ncpu} threads (value) and with 8 (value_8_cores)"}
 

@@ -902,8 +902,21 @@ int32_t svt_oracle_me_picture(const svt_pa_picture *cur, const svt_pa_picture *r
                               int32_t sb_begin, int32_t sb_end) {
     if (!cur || !ref0 || !params || !results) return -1;
     if (params->num_ref_lists == 2 && !ref1) return -1;
-    me_sb_t *s = (me_sb_t *)calloc(1, sizeof *s);
-    if (!s || sb_alloc(s)) return -2;
+    /* working state (the counterpart of the reference's MeContext, which lives as long as its ME thread): one per calling
+     * thread, allocated on the thread's first call and kept -- a timed caller does not pay six allocations per SB range */
+    static _Thread_local me_sb_t *tls_state;
+    me_sb_t *s = tls_state;
+    if (!s) {
+        s = (me_sb_t *)calloc(1, sizeof *s);
+        if (!s || sb_alloc(s)) { if (s) { sb_free(s); free(s); } return -2; }
+        tls_state = s;
+    } else { /* everything but the half-pel planes starts from zero, as in a fresh context */
+        uint8_t *keep[6] = {s->hb[0], s->hb[1], s->hh[0], s->hh[1], s->hj[0], s->hj[1]};
+        const int hs = s->hp_stride, hr = s->hp_rows;
+        memset(s, 0, sizeof *s);
+        s->hb[0] = keep[0]; s->hb[1] = keep[1]; s->hh[0] = keep[2]; s->hh[1] = keep[3]; s->hj[0] = keep[4]; s->hj[1] = keep[5];
+        s->hp_stride = hs; s->hp_rows = hr;
+    }
     int W = cur->full.width, H = cur->full.height;
     int nx = (W + SB - 1) / SB, ny = (H + SB - 1) / SB;
     if (sb_end < 0 || sb_end > nx * ny) sb_end = nx * ny;
@@ -916,8 +929,6 @@ int32_t svt_oracle_me_picture(const svt_pa_picture *cur, const svt_pa_picture *r
         s->src_stride = cur->full.stride;
         me_sb(s, results + (size_t)sb * 85, rcme_distortion ? &rcme_distortion[sb] : NULL);
     }
-    sb_free(s);
-    free(s);
     return 0;
 }
 

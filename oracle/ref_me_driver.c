@@ -17,7 +17,9 @@
  *   int32 magic 'SVME', svt_me_params (raw), int32 sb_begin, int32 sb_end,
  *   9 planes (cur.full, cur.quarter, cur.sixteenth, ref0.*, ref1.*), each:
  *   int32 stride, origin_x, origin_y, width, height, nbytes, then nbytes of samples (nbytes may be 0).
- * response: int32 n_sb, then n_sb*85 svt_me_pu_result, then n_sb uint32 rcme distortion.
+ * response: int32 n_sb, then n_sb*85 svt_me_pu_result, then n_sb uint32 rcme distortion, then one double: the seconds the SB
+ *           loop took (clock_gettime around the motion_estimate_sb calls only: the figure bench.py's cpu_baseline reports for
+ *           the reference's own C path, free of this harness's file I/O).
  *
  * Second request kind (the one leaf of the SSD fractional search that has external linkage and runs without the yasm-only
  * Log2f: eb_vp9_combined_averaging_ssd, Codec/EbMotionEstimation.c:1708-1725, the quarter-pel metric of SSD_SEARCH):
@@ -29,6 +31,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
+#include <time.h>
 
 #include "EbDefinitions.h"
 #include "EbPictureControlSet.h"
@@ -182,6 +185,8 @@ int main(int argc, char **argv) {
 
     /* the SB loop of eb_vp9_motion_estimation_kernel (Codec/EbMotionEstimationProcess.c:964-1044) */
     EbPictureBufferDesc *in = pl[0], *q = pl[1], *s16 = pl[2];
+    struct timespec t_begin, t_end;
+    clock_gettime(CLOCK_MONOTONIC, &t_begin);
     for (int sb = sb_begin; sb < sb_end; sb++) {
         uint32_t ox = (uint32_t)(sb % nx) * 64, oy = (uint32_t)(sb / nx) * 64;
         uint32_t sw = (W - ox) < 64 ? W - ox : 64, sh = (H - oy) < 64 ? H - oy : 64;
@@ -206,6 +211,8 @@ int main(int argc, char **argv) {
         }
         motion_estimate_sb(pcs, (uint32_t)sb, ox, oy, mc, in);
     }
+    clock_gettime(CLOCK_MONOTONIC, &t_end);
+    const double loop_seconds = (double)(t_end.tv_sec - t_begin.tv_sec) + 1e-9 * (double)(t_end.tv_nsec - t_begin.tv_nsec);
 
     FILE *o = fopen(argv[2], "wb");
     if (!o) return 2;
@@ -225,6 +232,7 @@ int main(int argc, char **argv) {
             fwrite(&r, sizeof r, 1, o);
         }
     fwrite(pcs->rcme_distortion, sizeof(uint32_t), (size_t)n_sb, o);
+    fwrite(&loop_seconds, sizeof loop_seconds, 1, o);
     fclose(o);
     return 0;
 }
