@@ -278,15 +278,7 @@ def pics_of_layer(layer):
     return [i for i in range(1, MINIGOP + 1) if LAYER[i - 1] == layer]
 
 
-def slot_of(i, parity):
-    """reference-picture slot (0..16) of picture i of the current mini-GOP (i = 0: the previous mini-GOP's base picture).  The two
-    base pictures alternate between slots 0 and 16 from one mini-GOP to the next, so the new base is written where the base
-    before the previous one was -- no copy between mini-GOPs."""
-    if i == 0:
-        return 16 if parity else 0
-    if i == MINIGOP:
-        return 0 if parity else 16
-    return i
+RING = 6   # mini-GOPs whose reference pictures are alive at a time (the diagonal schedule reaches back five mini-GOPs)
 
 
 def main():
@@ -298,6 +290,9 @@ def main():
     ap.add_argument("--height", type=int, default=H4K)
     ap.add_argument("--gops", type=int, default=int(os.environ.get("SVT_BENCH_GOPS", "4")), help="closed GOPs in flight per GPU (value); single_gop_value always uses 1")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("SVT_BENCH_GROUPS", "2")), help="GOP groups = EncDec streams")
+    ap.add_argument("--schedule", choices=("diagonal", "waves"), default=os.environ.get("SVT_BENCH_SCHEDULE", "diagonal"),
+                    help="EncDec-side schedule of `value`: diagonal = per step, temporal layer l of the mini-GOP l steps back (one batch of mutually "
+                         "independent pictures per GOP group); waves = the five layers of the newest mini-GOP one after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the G = 1 run (single_gop_value)")
     ap.add_argument("--handoff", action="store_true", help="N > 1 only: split-GOP mode -- every step each rank also hands the padded base-layer reconstruction of its "
@@ -531,32 +526,44 @@ def main():
     d_rt, d_rs = to_dev(np.ascontiguousarray(rtab).reshape(1).view(np.uint8)), to_dev(rscan)
 
     # ---- EncDec-side arenas: prediction pictures, reference pictures (= reconstruction buffers), coefficients ----
+    # Reference pictures live in a ring of RING mini-GOPs per GOP: picture i (1..16) of mini-GOP m is rec[m % RING][g][i - 1]; its
+    # "picture 0" -- the base picture of the mini-GOP before -- is rec[(m - 1) % RING][g][15].  Nothing is ever copied: a picture is
+    # reconstructed, deblocked and padded in the buffer later pictures predict from.
     d_pred = dev_zeros((G, MINIGOP, yuv_rows, plane_w), torch.uint8)
-    d_rec = dev_zeros((G, MINIGOP + 1, geo.rec_bytes), torch.uint8)
+    d_rec = dev_zeros((RING, G, MINIGOP, geo.rec_bytes), torch.uint8)
     d_q, d_dq = dev_zeros(G * MINIGOP * geo.coeffs, torch.int16), dev_zeros(G * MINIGOP * geo.coeffs, torch.int16)
-    assert max(d_src.numel(), d_rec.numel(), d_q.numel()) < 2 ** 32, "svt_tq_block offsets are 32 bits: fewer GOPs in flight"
-    rec_ptr = lambda g, slot: d_rec.data_ptr() + (g * (MINIGOP + 1) + slot) * geo.rec_bytes
+    slot_bytes = G * MINIGOP * geo.rec_bytes
+    assert max(d_src.numel(), slot_bytes, d_q.numel()) < 2 ** 32, "svt_tq_block offsets are 32 bits: fewer GOPs in flight"
+    rec_ptr = lambda slot, g, i: d_rec.data_ptr() + ((slot % RING) * G * MINIGOP + g * MINIGOP + i - 1) * geo.rec_bytes
     pred_ptr = lambda g, i: d_pred.data_ptr() + (g * MINIGOP + i - 1) * pic_bytes
-    def yuv_desc(d, g, slot):
-        base = rec_ptr(g, slot)
+
+    def yuv_desc(d, slot, g, i):
+        base = rec_ptr(slot, g, i)
         d.y, d.u, d.v = base + geo.y0, base + geo.u0, base + geo.v0
         d.y_stride, d.uv_stride, d.width, d.height = geo.pw, geo.cpw, Wd, Hd
 
-    # the base picture of the mini-GOP before the first one: its source, padded (from then on every reference is a reconstruction)
+    def ref_desc(d, slot, g, j):
+        """reference picture j (0..16) of the mini-GOP in ring slot `slot`"""
+        if j == 0:
+            yuv_desc(d, slot - 1, g, MINIGOP)
+        else:
+            yuv_desc(d, slot, g, j)
+
+    # the base picture of the mini-GOP before the first one (ring slot -1): its source, padded -- from then on every reference is
+    # a reconstruction
     for g in range(G):
         s0 = d_src[g, 0]
         y, u, v = s0[:Hd], s0[Hd:, :Wd // 2], s0[Hd:, Wd // 2:]
-        r = d_rec[g, 0]
+        r = d_rec[RING - 1, g, MINIGOP - 1]
         r[:geo.u_base].view(geo.ph, geo.pw)[PAD:PAD + Hd, PAD:PAD + Wd] = y
         r[geo.u_base:geo.v_base].view(geo.cph, geo.cpw)[PAD // 2:PAD // 2 + Hd // 2, PAD // 2:PAD // 2 + Wd // 2] = u
         r[geo.v_base:geo.v_base + geo.cph * geo.cpw].view(geo.cph, geo.cpw)[PAD // 2:PAD // 2 + Hd // 2, PAD // 2:PAD // 2 + Wd // 2] = v
     dsc0 = (B.YuvPlanes * G)()
     for g in range(G):
-        yuv_desc(dsc0[g], g, 0)
+        yuv_desc(dsc0[g], -1, g, MINIGOP)
     torch.cuda.synchronize()
     B.check(lib.svt_hip_ref_pad_batch_device(me_ctxs[0], G, dsc0, PAD, PAD))
     B.check(lib.svt_hip_ctx_synchronize(me_ctxs[0]))
-
 
     level = lib.svt_hip_lf_level_from_q(ac_q, 0)
     thr = B.LfThresh()
@@ -565,27 +572,11 @@ def main():
     separate_rate = os.environ.get("SVT_BENCH_SEPARATE_RATE", "0") == "1"
     rate_ctx_rng = np.random.default_rng(8)
 
-    def build_wave(gops, layer):
-        """descriptors of one wave = the pictures of one temporal layer of the current mini-GOP of each GOP of a group, for both
-        parities of the base-picture slots"""
+    def build_layer_blocks(gops, layer):
+        """transform blocks of the pictures of one temporal layer of the GOPs of a group, grouped by transform size; reconstruction
+        offsets are relative to the ring slot the launch is given"""
         items = [(g, i) for g in gops for i in pics_of_layer(layer)]
-        n = len(items)
-        wv = {"n": n, "items": items, "mc": [], "yuv": [], "blocks": []}
-        for par in range(2):
-            mc = (B.McPicture * n)()
-            yv = (B.YuvPlanes * n)()
-            for k, (g, i) in enumerate(items):
-                mp = mc[k]
-                mp.d_mi, mp.mi_stride, mp.mi_rows, mp.mi_cols, mp.use_subpel = d_mi[g][i].data_ptr(), mi_cols, mi_rows, mi_cols, 1
-                for l in range(2):
-                    yuv_desc(mp.ref[l], g, slot_of(refs_of(i)[l], par))
-                pb = pred_ptr(g, i)
-                mp.pred.y, mp.pred.u, mp.pred.v = pb, pb + Hd * plane_w, pb + Hd * plane_w + Wd // 2
-                mp.pred.y_stride, mp.pred.uv_stride, mp.pred.width, mp.pred.height = plane_w, plane_w, Wd, Hd
-                yuv_desc(yv[k], g, slot_of(i, par))
-            wv["mc"].append(mc)
-            wv["yuv"].append(yv)
-        # transform blocks of the wave, grouped by transform size across its pictures
+        lb = {"items": items}
         per_ts, pic_of = [[] for _ in range(4)], [[] for _ in range(4)]
         for k, (g, i) in enumerate(items):
             arrs = blk_tight[g][i]
@@ -599,93 +590,113 @@ def main():
                 per_ts[ts].append(b)
                 pic_of[ts].append(np.full(len(a), k, np.int32))
         blocks = np.concatenate([b for ts in range(4) for b in per_ts[ts]])
-        wv["pic_of_block"] = np.concatenate([p_ for ts in range(4) for p_ in pic_of[ts]])
-        wv["counts"] = [sum(len(b) for b in per_ts[ts]) for ts in range(4)]
-        wv["cnt_c"] = (C.c_int32 * 4)(*wv["counts"])
+        lb["pic_of_block"] = np.concatenate([p_ for ts in range(4) for p_ in pic_of[ts]])
+        lb["counts"] = [sum(len(b) for b in per_ts[ts]) for ts in range(4)]
+        lb["cnt_c"] = (C.c_int32 * 4)(*lb["counts"])
         tight = blocks["src_off"].astype(np.int64)      # offsets relative to the picture, tight layout
-        gi = np.array(items, np.int64)[wv["pic_of_block"]]
+        gi = np.array(items, np.int64)[lb["pic_of_block"]]
         roff, rstride = geo.recon_offsets(tight)
         blocks["src_off"] = (tight + (gi[:, 0] * (MINIGOP + 1) + gi[:, 1]) * pic_bytes).astype(np.uint32)
         blocks["pred_off"] = (tight + (gi[:, 0] * MINIGOP + gi[:, 1] - 1) * pic_bytes).astype(np.uint32)
+        blocks["recon_off"] = (roff + (gi[:, 0] * MINIGOP + gi[:, 1] - 1) * geo.rec_bytes).astype(np.uint32)
         blocks["recon_stride"] = rstride
         rate_ctx = rate_ctx_rng.integers(0, 3, len(blocks)).astype(np.uint8)    # entropy context of every block (an input)
         blocks["pad"][:, 0] = rate_ctx | (blocks["qtab"] << 2) | (1 << 3)         # SVT_TQ_RATE_INFO(ctx, plane_type, is_inter = 1)
-        for par in range(2):
-            slots = np.array([slot_of(i, par) for _, i in items], np.int64)[wv["pic_of_block"]]
-            bp = blocks.copy()
-            bp["recon_off"] = (roff + (gi[:, 0] * (MINIGOP + 1) + slots) * geo.rec_bytes).astype(np.uint32)
-            if par == 1 and layer != 0:
-                wv["blocks"].append(wv["blocks"][0])    # only the base picture changes its slot
-            else:
-                wv["blocks"].append(to_dev(bp.view(np.uint8)))
-        wv["blocks_host"] = blocks
+        lb["blocks_host"], lb["blocks"] = blocks, to_dev(blocks.view(np.uint8))
         nb = len(blocks)
-        wv["eob"], wv["dist"], wv["bits"] = dev_zeros(nb, torch.int16), dev_zeros(2 * nb, torch.int64), dev_zeros(nb, torch.int32)
-        wv["lfm"] = (C.c_void_p * n)(*[d_lfm[g][i].data_ptr() for g, i in items])
-        i32 = lambda v: (C.c_int32 * n)(*[v] * n)
-        wv["lfs"], wv["mrs"], wv["mcs"] = i32(sb_cols), i32(mi_rows), i32(mi_cols)
+        lb["eob"], lb["dist"], lb["bits"] = dev_zeros(nb, torch.int16), dev_zeros(2 * nb, torch.int64), dev_zeros(nb, torch.int32)
         if separate_rate:
             roffs, _ = T.rate_scan_offsets()
             rb = np.zeros(nb, dtype=B.RATE_BLOCK_DTYPE)
             rb["coeff_off"], rb["tx_size"], rb["plane_type"], rb["is_inter"], rb["ctx"] = blocks["coeff_off"], blocks["tx_size"], blocks["qtab"], 1, rate_ctx
             rb["scan_off"] = np.array([roffs[(ts, 0)] for ts in range(4)], np.uint32)[blocks["tx_size"]]
-            wv["rb_host"] = rb
-        return wv
+            lb["rb_host"] = rb
+        return lb
+
+    def build_batch(items):
+        """descriptors of one batch of mutually independent pictures: items = (g, i, back) -- picture i of GOP g of the mini-GOP
+        `back` mini-GOPs before the newest one of the step; one descriptor set per ring phase"""
+        n = len(items)
+        bt = {"n": n, "items": items, "mc": [], "yuv": []}
+        for ph in range(RING):
+            mc = (B.McPicture * n)()
+            yv = (B.YuvPlanes * n)()
+            for k, (g, i, back) in enumerate(items):
+                slot = ph - back
+                mp = mc[k]
+                mp.d_mi, mp.mi_stride, mp.mi_rows, mp.mi_cols, mp.use_subpel = d_mi[g][i].data_ptr(), mi_cols, mi_rows, mi_cols, 1
+                for l in range(2):
+                    ref_desc(mp.ref[l], slot, g, refs_of(i)[l])
+                pb = pred_ptr(g, i)
+                mp.pred.y, mp.pred.u, mp.pred.v = pb, pb + Hd * plane_w, pb + Hd * plane_w + Wd // 2
+                mp.pred.y_stride, mp.pred.uv_stride, mp.pred.width, mp.pred.height = plane_w, plane_w, Wd, Hd
+                yuv_desc(yv[k], slot, g, i)
+            bt["mc"].append(mc)
+            bt["yuv"].append(yv)
+        bt["lfm"] = (C.c_void_p * n)(*[d_lfm[g][i].data_ptr() for g, i, _ in items])
+        i32 = lambda v: (C.c_int32 * n)(*[v] * n)
+        bt["lfs"], bt["mrs"], bt["mcs"] = i32(sb_cols), i32(mi_rows), i32(mi_cols)
+        return bt
 
     vp = lambda t: C.c_void_p(t.data_ptr())
+    slot_base = lambda slot: C.c_void_p(d_rec.data_ptr() + (slot % RING) * slot_bytes)
 
-    def run_mc(ctx_, wv, par):
-        B.check(lib.svt_hip_inter_pred_batch_device(ctx_, wv["n"], wv["mc"][par]))
+    def run_mc(ctx_, bt, ph):
+        B.check(lib.svt_hip_inter_pred_batch_device(ctx_, bt["n"], bt["mc"][ph]))
 
-    def run_tq(ctx_, wv, par, plain=False):
+    def run_tq(ctx_, lb, slot, plain=False):
         if plain or separate_rate:
-            B.check(lib.svt_hip_tq_batch_dist_device(ctx_, vp(d_src), vp(d_pred), vp(d_rec), vp(wv["blocks"][par]), wv["cnt_c"], vp(d_qt), vp(d_iscan), vp(d_q),
-                                                     vp(d_dq), vp(wv["eob"]), vp(wv["dist"])))
+            B.check(lib.svt_hip_tq_batch_dist_device(ctx_, vp(d_src), vp(d_pred), slot_base(slot), vp(lb["blocks"]), lb["cnt_c"], vp(d_qt), vp(d_iscan), vp(d_q),
+                                                     vp(d_dq), vp(lb["eob"]), vp(lb["dist"])))
         else:   # distortion + rate behind the quantiser: perform_dist_rate_calc in one pass
-            B.check(lib.svt_hip_tq_rd_batch_device(ctx_, vp(d_src), vp(d_pred), vp(d_rec), vp(wv["blocks"][par]), wv["cnt_c"], vp(d_qt), vp(d_iscan), vp(d_q),
-                                                   vp(d_dq), vp(wv["eob"]), vp(wv["dist"]), vp(d_rt), vp(d_rs), vp(wv["bits"])))
+            B.check(lib.svt_hip_tq_rd_batch_device(ctx_, vp(d_src), vp(d_pred), slot_base(slot), vp(lb["blocks"]), lb["cnt_c"], vp(d_qt), vp(d_iscan), vp(d_q),
+                                                   vp(d_dq), vp(lb["eob"]), vp(lb["dist"]), vp(d_rt), vp(d_rs), vp(lb["bits"])))
 
-    def run_rate(ctx_, wv):
-        B.check(lib.svt_hip_coeff_rate_batch_device(ctx_, vp(d_q), vp(wv["d_rb"]), len(wv["rb_host"]), vp(d_rt), vp(d_rs), vp(wv["bits"])))
+    def run_rate(ctx_, lb):
+        B.check(lib.svt_hip_coeff_rate_batch_device(ctx_, vp(d_q), vp(lb["d_rb"]), len(lb["rb_host"]), vp(d_rt), vp(d_rs), vp(lb["bits"])))
 
-    def run_lf(ctx_, wv, par):
-        B.check(lib.svt_hip_lf_batch_device(ctx_, wv["n"], wv["yuv"][par], wv["lfm"], wv["lfs"], C.byref(thr), wv["mrs"], wv["mcs"], 0))
+    def run_lf(ctx_, bt, ph):
+        B.check(lib.svt_hip_lf_batch_device(ctx_, bt["n"], bt["yuv"][ph], bt["lfm"], bt["lfs"], C.byref(thr), bt["mrs"], bt["mcs"], 0))
 
-    def run_pad(ctx_, wv, par):
-        B.check(lib.svt_hip_ref_pad_batch_device(ctx_, wv["n"], wv["yuv"][par], PAD, PAD))
+    def run_pad(ctx_, bt, ph):
+        B.check(lib.svt_hip_ref_pad_batch_device(ctx_, bt["n"], bt["yuv"][ph], PAD, PAD))
 
     def build_pipeline(gops, pairs):
-        """a pipeline = a set of GOPs in flight, split into groups with one EncDec stream each"""
+        """a pipeline = a set of GOPs in flight, split into groups with one EncDec stream each.  Per group: the transform block lists
+        per temporal layer, the five wave batches (all pictures of one layer of the newest mini-GOP) and the diagonal batch (layer
+        l of the mini-GOP l steps back: every picture of it depends only on pictures of earlier steps)"""
         ng = len(pairs)
         groups = [gops[k::ng] for k in range(ng)]
         P = {"gops": gops, "groups": [], "me_ev": []}
         P["me_sets"], P["me_slot"] = build_me_launches(gops)
         for grp, (st_, ctx_) in zip(groups, pairs):
-            P["groups"].append({"gops": grp, "stream": st_, "ctx": ctx_, "waves": [build_wave(grp, layer) for layer in range(5)]})
+            P["groups"].append({"gops": grp, "stream": st_, "ctx": ctx_, "layers": [build_layer_blocks(grp, layer) for layer in range(5)],
+                                "waves": [build_batch([(g, i, 0) for g in grp for i in pics_of_layer(layer)]) for layer in range(5)],
+                                "diag": build_batch([(g, i, LAYER[i - 1]) for g in grp for i in range(1, MINIGOP + 1)])})
         return P
 
     P_main = build_pipeline(all_gops, grp_pairs)
 
-    # ---- setup pass of the dependent chain (untimed, parity 0): per wave prediction -> transform -> [eobs -> loop-filter masks of
-    # the wave's pictures: skip flags are mode decision's output] -> deblocking -> padding ----
+    # ---- setup pass of the dependent chain (untimed, mini-GOP 0 = ring phase 0, wave schedule): per wave prediction -> transform
+    # -> [eobs -> loop-filter masks of the wave's pictures: skip flags are mode decision's output] -> deblocking -> padding ----
     eob_stats, resid_acc = [[] for _ in range(4)], []
     for layer in range(5):
         for grp in P_main["groups"]:
-            wv, ctx_ = grp["waves"][layer], grp["ctx"]
+            bt, lb, ctx_ = grp["waves"][layer], grp["layers"][layer], grp["ctx"]
             with torch.cuda.stream(grp["stream"]):
-                run_mc(ctx_, wv, 0)
-                run_tq(ctx_, wv, 0, plain=True)
+                run_mc(ctx_, bt, 0)
+                run_tq(ctx_, lb, 0, plain=True)
             B.check(lib.svt_hip_ctx_synchronize(ctx_))
-            eob_h = wv["eob"].cpu().numpy().view(np.uint16)
-            blocks = wv["blocks_host"]
+            eob_h = lb["eob"].cpu().numpy().view(np.uint16)
+            blocks = lb["blocks_host"]
             if separate_rate:
-                wv["rb_host"]["eob"] = eob_h
-                wv["d_rb"] = to_dev(wv["rb_host"].view(np.uint8))
+                lb["rb_host"]["eob"] = eob_h
+                lb["d_rb"] = to_dev(lb["rb_host"].view(np.uint8))
             for ts in range(4):
                 eob_stats[ts].append(eob_h[blocks["tx_size"] == ts].astype(np.int64))
             luma = blocks["qtab"] == 0
-            for k, (g, i) in enumerate(wv["items"]):
-                sel = luma & (wv["pic_of_block"] == k)
+            for k, (g, i) in enumerate(lb["items"]):
+                sel = luma & (lb["pic_of_block"] == k)
                 off = blocks["src_off"][sel].astype(np.int64) - (g * (MINIGOP + 1) + i) * pic_bytes
                 r4, c4 = (off // plane_w) >> 2, (off % plane_w) >> 2
                 n4 = (1 << blocks["tx_size"][sel].astype(np.int64))
@@ -705,16 +716,16 @@ def main():
                         resid_acc.append((d_src[0, i, :Hd].to(torch.int16) - d_pred[0, i - 1, :Hd].to(torch.int16)).abs().to(torch.float32).mean().item())
             torch.cuda.synchronize()
             with torch.cuda.stream(grp["stream"]):
-                run_lf(ctx_, wv, 0)
-                run_pad(ctx_, wv, 0)
+                run_lf(ctx_, bt, 0)
+                run_pad(ctx_, bt, 0)
             B.check(lib.svt_hip_ctx_synchronize(ctx_))
-    n_blocks_step = sum(len(w_["blocks_host"]) for grp in P_main["groups"] for w_ in grp["waves"])
-    counts_step = [sum(w_["counts"][ts] for grp in P_main["groups"] for w_ in grp["waves"]) for ts in range(4)]
+    n_blocks_step = sum(len(lb["blocks_host"]) for grp in P_main["groups"] for lb in grp["layers"])
+    counts_step = [sum(lb["counts"][ts] for grp in P_main["groups"] for lb in grp["layers"]) for ts in range(4)]
     workload_stats = {"mean_abs_luma_residual_gop0": round(float(np.mean(resid_acc)), 2),
                       "mean_eob_by_tx_size": [round(float(np.concatenate(eob_stats[ts]).mean()), 1) for ts in range(4)],
                       "blocks_by_tx_size": counts_step}
-    parity = [1]    # the setup pass ran at parity 0: the new base pictures are in slot 16
-    P_single = None if args.no_single else build_pipeline([0], [(single_stream, ctx_single)])
+    step_no = [1]   # the setup pass was step 0 (mini-GOP 0 complete in ring slot 0)
+    P_single = None if (args.no_single or separate_rate) else build_pipeline([0], [(single_stream, ctx_single)])
     setup_s = time.perf_counter() - t_setup0
 
     # split-GOP hand-off (optional, N > 1): the padded base-layer reconstruction of this rank's first GOP, as the deblocking +
@@ -724,11 +735,11 @@ def main():
         ho_recv = dev_zeros(geo.rec_bytes, torch.uint8)
         ho_stream = torch.cuda.Stream(device=local_rank)
 
-    def run_handoff(P, par):
+    def run_handoff(P, ph):
         grp0 = P["groups"][0]
         ho_stream.wait_stream(grp0["stream"])   # ordered after this step's deblocking + padding of the base picture
         with torch.cuda.stream(ho_stream):
-            ops = [dist.P2POp(dist.isend, d_rec[grp0["gops"][0], slot_of(MINIGOP, par)], (rank + 1) % world), dist.P2POp(dist.irecv, ho_recv, (rank - 1) % world)]
+            ops = [dist.P2POp(dist.isend, d_rec[ph % RING, grp0["gops"][0], MINIGOP - 1], (rank + 1) % world), dist.P2POp(dist.irecv, ho_recv, (rank - 1) % world)]
             for w_ in dist.batch_isend_irecv(ops):
                 w_.wait()
 
@@ -748,11 +759,11 @@ def main():
         e1.record(stream)
         S["ev"].append((name, e0, e1))
 
-    def step(P, S, pool=None):
+    def step(P, S, schedule, pool=None):
         buf = S["step"] & 1
         S["step"] += 1
-        par = parity[0]
-        parity[0] ^= 1
+        ph = step_no[0] % RING          # ring slot of the newest mini-GOP of this step
+        step_no[0] += 1
         # ME side (one mini-GOP ahead of the EncDec side, as the reference's ME threads are): PA writes the planes ME reads and
         # picture analysis of the NEXT mini-GOP runs beside it on its own stream
         if S["pa_done"][buf] is not None:
@@ -767,31 +778,47 @@ def main():
             staged(S, "pa", pa_stream, lambda: pa_call(ctx_pa, P["gops"], pa_idx, 1 - buf), pool)
             S["pa_done"][1 - buf] = torch.cuda.Event()
             S["pa_done"][1 - buf].record(pa_stream)
-        # EncDec side: the five dependent waves of every group, each stage on the group's stream in program order
-        for layer in range(5):
+        # EncDec side, every stage on the group's stream in program order = dependency order
+        if schedule == "waves":      # the five dependent temporal-layer waves of the newest mini-GOP
+            for layer in range(5):
+                for grp in P["groups"]:
+                    bt, lb, ctx_, st_ = grp["waves"][layer], grp["layers"][layer], grp["ctx"], grp["stream"]
+                    staged(S, "mc", st_, lambda: run_mc(ctx_, bt, ph), pool)
+                    staged(S, "tq", st_, lambda: run_tq(ctx_, lb, ph), pool)
+                    if separate_rate:
+                        staged(S, "rate", st_, lambda: run_rate(ctx_, lb), pool)
+                    staged(S, "lf", st_, lambda: run_lf(ctx_, bt, ph), pool)
+                    staged(S, "pad", st_, lambda: run_pad(ctx_, bt, ph), pool)
+        else:                        # diagonal: layer l of the mini-GOP l steps back -- one batch of independent pictures
             for grp in P["groups"]:
-                wv, ctx_, st_ = grp["waves"][layer], grp["ctx"], grp["stream"]
-                staged(S, "mc", st_, lambda: run_mc(ctx_, wv, par), pool)
-                staged(S, "tq", st_, lambda: run_tq(ctx_, wv, par), pool)
+                bt, ctx_, st_ = grp["diag"], grp["ctx"], grp["stream"]
+                staged(S, "mc", st_, lambda: run_mc(ctx_, bt, ph), pool)
+
+                def tq_all():
+                    for layer in range(5):
+                        run_tq(ctx_, grp["layers"][layer], ph - layer)
+                staged(S, "tq", st_, tq_all, pool)
                 if separate_rate:
-                    staged(S, "rate", st_, lambda: run_rate(ctx_, wv), pool)
-                staged(S, "lf", st_, lambda: run_lf(ctx_, wv, par), pool)
-                staged(S, "pad", st_, lambda: run_pad(ctx_, wv, par), pool)
+                    staged(S, "rate", st_, lambda: [run_rate(ctx_, lb) for lb in grp["layers"]], pool)
+                staged(S, "lf", st_, lambda: run_lf(ctx_, bt, ph), pool)
+                staged(S, "pad", st_, lambda: run_pad(ctx_, bt, ph), pool)
         if handoff:
-            run_handoff(P, par)
+            run_handoff(P, ph)
 
     def sync():
         for c_ in ctxs:
             B.check(lib.svt_hip_ctx_synchronize(c_))
         torch.cuda.synchronize()
 
-    def timed_run(P, steps, warmup, barrier):
+    def timed_run(P, schedule, steps, warmup, barrier):
         S = make_state()
+        if schedule == "diagonal":
+            warmup = max(warmup, 5)   # the pipeline of five mini-GOPs has to fill
         n_ev = 2 * steps * (len(P["me_sets"][0]) + 2 + 5 * len(P["groups"]) * (5 if separate_rate else 4)) + 8
         pool = EventPool(n_ev)
         P["me_ev"] = []
         for _ in range(warmup):
-            step(P, S)
+            step(P, S, schedule)
         sync()
         if barrier and world > 1:
             dist.barrier()
@@ -801,7 +828,7 @@ def main():
         n_free = min(steps, 8)
         t_enq = 0.0
         for i_ in range(steps):
-            step(P, S, pool)
+            step(P, S, schedule, pool)
             if i_ + 1 == n_free:
                 t_enq = time.perf_counter() - t0
         sync()
@@ -814,13 +841,14 @@ def main():
         me_launch_ms = sum(e0.elapsed_time(e1) for e0, e1 in P["me_ev"])
         return dt, t_enq / n_free, stage_ms, me_launch_ms, len(P["me_ev"])
 
-    dt, enq_s, stage_ms, me_launch_ms, n_me_launch = timed_run(P_main, args.steps, args.warmup, True)
+    dt, enq_s, stage_ms, me_launch_ms, n_me_launch = timed_run(P_main, args.schedule, args.steps, args.warmup, True)
     dt = GS.reduce_elapsed(dt, dist if world > 1 else None, dev)
-    single = None
+    single = {}
     if P_single is not None:
         k1 = max(4, args.steps)
-        dt1, enq1, stage1, _, _ = timed_run(P_single, k1, max(2, args.warmup), False)
-        single = {"frames_per_s": MINIGOP * k1 / dt1, "ms_per_minigop": dt1 / k1 * 1e3, "steps": k1, "stage_ms": stage1, "enq": enq1}
+        for sched in ("diagonal", "waves"):
+            dt1, enq1, stage1, _, _ = timed_run(P_single, sched, k1, max(2, args.warmup), False)
+            single[sched] = {"frames_per_s": MINIGOP * k1 / dt1, "ms_per_minigop": dt1 / k1 * 1e3, "steps": k1, "stage_ms": stage1, "enq": enq1}
 
     L = Wd * Hd
     pics_step = G * MINIGOP
@@ -871,7 +899,8 @@ def main():
         "value": round(fps, 2),
         "unit": "frames/s",
         "mpixels_per_s": round(fps * Wd * Hd / 1e6, 1),
-        "single_gop_value": round(single["frames_per_s"], 2) if single else None,
+        "single_stream_value": round(single["diagonal"]["frames_per_s"], 2) if single else None,
+        "single_gop_value": round(single["waves"]["frames_per_s"], 2) if single else None,
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -886,10 +915,12 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{Wd}x{Hd} 8-bit yuv420p, -enc-mode 8 -tune 1 -q 40, 1xMI355X per rank; step = one 16-picture mini-GOP (5 temporal "
                                f"layers, B pictures, 2 reference lists) of each of {G} closed GOPs in flight; ME side on source pictures one "
-                               "mini-GOP ahead; EncDec side as five dependent temporal-layer waves per GOP, each wave: inter prediction from the "
-                               "deblocked + padded reconstruction of its lower-layer references -> transform / quant / recon (+ distortion + "
-                               "rate) -> deblocking -> reference padding, in place in the reference buffers",
-                   "gops_in_flight": G, "gop_groups": n_groups,
+                               "mini-GOP ahead; EncDec side in dependency order (" +
+                               ("per step temporal layer l of the mini-GOP l steps back: every picture is predicted from reconstructions finished in "
+                                "earlier steps" if args.schedule == "diagonal" else "five dependent temporal-layer waves per mini-GOP") +
+                               "): inter prediction from the deblocked + padded reconstruction of the lower-layer references -> transform / quant / "
+                               "recon (+ distortion + rate) -> deblocking -> reference padding, in place in the reference buffers",
+                   "gops_in_flight": G, "gop_groups": n_groups, "schedule": args.schedule,
                    "stages": ["picture_analysis", "motion_estimation", "inter_prediction", "transform_quant_recon_distortion",
                               "coefficient_rate", "deblocking", "reference_padding"],
                    "stages_run": [s for s in STAGES if s in stages],
@@ -897,10 +928,19 @@ def main():
                    "deblocked_pictures": "all (as with reconstructed output enabled; the reference skips non-reference pictures otherwise)",
                    "workload_stats": workload_stats,
                    "parallelism": f"gop-shard x{world}" + (" + split-GOP reference hand-off (RCCL send/recv of the padded base-layer reconstruction)" if handoff else "")},
+        "single_stream": None if not single else {
+            "frames_per_s": round(single["diagonal"]["frames_per_s"], 2), "ms_per_minigop": round(single["diagonal"]["ms_per_minigop"], 3), "gops_in_flight": 1,
+            "schedule": "diagonal", "steps": single["diagonal"]["steps"],
+            "stage_ms_per_minigop": {s: round(single["diagonal"]["stage_ms"][s], 3) for s in STAGES if s in stages},
+            "note": "ONE stream of mini-GOPs: per step temporal layer l of the mini-GOP l steps back (16 mutually independent pictures of five consecutive "
+                    "mini-GOPs, each predicted from reconstructions finished in earlier steps) -- the picture-level pipelining the reference's EncDec "
+                    "processes do; needs five mini-GOPs of look-ahead"},
         "single_gop": None if not single else {
-            "frames_per_s": round(single["frames_per_s"], 2), "ms_per_minigop": round(single["ms_per_minigop"], 3), "gops_in_flight": 1, "steps": single["steps"],
-            "stage_ms_per_minigop": {s: round(single["stage_ms"][s], 3) for s in STAGES if s in stages},
-            "note": "one GOP: the five waves of a mini-GOP run one after the other on one stream (only ME / picture analysis of the next mini-GOP overlap them)"},
+            "frames_per_s": round(single["waves"]["frames_per_s"], 2), "ms_per_minigop": round(single["waves"]["ms_per_minigop"], 3), "gops_in_flight": 1,
+            "schedule": "waves", "steps": single["waves"]["steps"],
+            "stage_ms_per_minigop": {s: round(single["waves"]["stage_ms"][s], 3) for s in STAGES if s in stages},
+            "note": "one mini-GOP at a time: its five temporal-layer waves run one after the other on one stream (only ME / picture analysis of the next "
+                    "mini-GOP overlap them) -- the lowest-latency schedule, bounded by the per-picture latency of the deblocking wavefront"},
         "roofline": {"bound": "hbm", "kernel": "svt_me_sb_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
                      "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_source,
                      "launches_per_step": n_launch_step, "avg_launch_ms": round(per_launch_ms, 4),
