@@ -179,6 +179,31 @@ def build_native_oracle():
 
 
 
+def api_path_rate(frames, Wd, Hd, n_send=130):
+    """SURVEY 8(d)'s metric through the PUBLIC API (libSvtVp9Enc.so, the reference's eb_vp9_svt_* entry points): wall-clock from the
+    first send_picture to the EOS packet, host buffers handed over (PCIe inside the clock), measured by the plain-C caller
+    app/svt_enc_api_bench.c in its own process.  Behind the API the library runs picture analysis + one batched ME launch per
+    mini-GOP + the per-SB ME statistics; no other stage is reachable from it, and only the luma plane
+    crosses PCIe.  n_send = 130: two closed GOPs of 65 pictures at 60 frames/s."""
+    exe = os.path.join(ROOT, "app", "svt_enc_api_bench")
+    if not os.path.exists(exe):
+        return None
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "luma.bin")
+        with open(path, "wb") as f:
+            for y in frames:
+                f.write(np.ascontiguousarray(y).tobytes())
+        r = subprocess.run([exe, path, str(Wd), str(Hd), str(len(frames)), str(n_send), "8", "1"], capture_output=True, text=True)
+    if r.returncode != 0:
+        return {"error": f"svt_enc_api_bench rc={r.returncode}: {(r.stdout + r.stderr).strip()[-200:]}"}
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    return {"value": d["frames_per_s"], "unit": "frames/s", "frames": d["frames"], "seconds": d["seconds"], "me_launches": d["me_launches"],
+            "mpixels_per_s": round(d["frames_per_s"] * Wd * Hd / 1e6, 1),
+            "what": f"{Wd}x{Hd} -enc-mode 8 -tune 1, {d['frames']} pictures through eb_vp9_svt_enc_send_picture / eb_vp9_svt_get_packet (app/svt_enc_api_bench.c): "
+                    "first send_picture -> EOS packet, host buffers in, PCIe included; stages behind the API: picture analysis + motion estimation (one "
+                    "batched launch per mini-GOP) + per-SB ME statistics; zero-byte packets (no entropy coding)"}
+
+
 def reference_me_rate(T, B, orc, frames, Wd, Hd, l1_on, ncpu):
     """The REFERENCE's own motion_estimate_sb (oracle/_ref/ref_me_sb = Codec/EbMotionEstimation.c compiled from /root/reference in
     the build container, C path, gcc -O2; it travels to the GPU box as a prebuilt file) timed beside the port on the same
@@ -196,7 +221,7 @@ def reference_me_rate(T, B, orc, frames, Wd, Hd, l1_on, ncpu):
     p = B.me_params_preset(Wd, Hd, 8, 1, 2, LAYER[i - 1], 4)
     nsb = T.n_sb(Wd, Hd)
     workers = max(1, min(ncpu, 64))
-    per = max(1, min(16, nsb // workers))       # bounded sample: at most 16 SBs per worker
+    per = max(1, min(32, nsb // workers))       # bounded sample: at most 32 SBs per worker
     ranges = [(k * per, min(nsb, (k + 1) * per)) for k in range(workers) if k * per < nsb]
     with tempfile.TemporaryDirectory() as td:
         reqs = []
@@ -979,9 +1004,15 @@ def main():
         lfms0 = [np.frombuffer(d_lfm[0][i].cpu().numpy(), dtype=B.LF_MASK_DTYPE).reshape(sb_rows, sb_cols) for i in range(1, MINIGOP + 1)]
         out["cpu_baseline"] = cpu_baseline(T, B, frames_all[0], src0, mi_host0, blocks0, pic_of0, qtabs, iscan, rb0, rtab, rscan, lfms0, thr, Wd, Hd, plane_w,
                                            l1_on, int(nn0.sum()))
-    print(json.dumps(out))
     for c_ in ctxs:
         lib.svt_hip_ctx_destroy(c_)
+    ctxs.clear()
+    if (Wd, Hd) == (W4K, H4K) or os.environ.get("SVT_BENCH_API_PATH"):
+        torch.cuda.synchronize()
+        api = api_path_rate(frames_all[0], Wd, Hd)
+        if api is not None:
+            out["api_path"] = api
+    print(json.dumps(out))
 
 
 def cpu_baseline(T, B, frames, src_all, mi_list, tq_blocks_all, pic_of_block, qtabs, iscan, rb, rtab, rscan, lfms, thr, Wd, Hd,

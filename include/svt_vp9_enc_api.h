@@ -114,10 +114,18 @@ typedef struct svt_vp9_shim_picture_info {
     int64_t  ref_picture_number[2]; /* display-order numbers of the list 0 / list 1 reference pictures (-1: none) */
     uint32_t n_sb;
 } svt_vp9_shim_picture_info;
-/* copies the ME results of a picture that has been processed (and not yet overwritten by a later mini-GOP: the library keeps
- * the last mini-GOP + 1 pictures) into out (n_sb * 85 records of 40 bytes, svt_me_pu_result of svtvp9_hip.h) */
+/* copies the ME results of a picture whose mini-GOP has been processed (and not yet overwritten: the library keeps the last two
+ * mini-GOPs + 2 pictures) into out (n_sb * 85 records of 40 bytes, svt_me_pu_result of svtvp9_hip.h); waits for the GPU work of
+ * that picture.  EB_NoErrorEmptyQueue while the picture still waits in an incomplete mini-GOP (or is no longer kept). */
 EbErrorType svt_vp9_shim_get_me_results(EbComponentType *svt_enc_component, uint64_t picture_number, svt_vp9_shim_picture_info *info,
                                         void *out, uint64_t out_bytes);
+/* the per-SB side outputs of the same picture: stats = n_sb records of svt_me_sb_stats (8 bytes), histograms = 257 uint32 (ME
+ * distortion histogram, OIS histogram, number of complete SBs), mean / variance = n_sb * 85 picture-analysis values; any pointer
+ * may be NULL */
+EbErrorType svt_vp9_shim_get_sb_stats(EbComponentType *svt_enc_component, uint64_t picture_number, void *stats, uint64_t stats_bytes,
+                                      uint32_t *histograms, uint8_t *mean, uint16_t *variance);
+/* how many batched ME launches the library has issued, how many pictures it has accepted */
+EbErrorType svt_vp9_shim_get_counters(EbComponentType *svt_enc_component, uint64_t *me_launches, uint64_t *pictures_sent);
 
 #ifdef __cplusplus
 }

@@ -191,6 +191,19 @@ void    svt_hip_mem_free(svt_hip_ctx *ctx, void *d_ptr);
 int32_t svt_hip_mem_upload_2d(svt_hip_ctx *ctx, void *d_dst, size_t dst_stride, const void *src, size_t src_stride, size_t width_bytes,
                               size_t rows);
 int32_t svt_hip_mem_download(svt_hip_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+/* Asynchronous form of svt_hip_mem_upload_2d for a host that must not wait for the device: the rows are copied into a pinned
+ * staging buffer owned by the context before the call returns (= the copy eb_vp9_svt_enc_send_picture makes of the caller's
+ * picture, Codec/EbEncHandle.c:2743-2796: the caller may reuse its buffer at once), the host-to-device copy is enqueued on the
+ * context's stream.  The call blocks only when all staging buffers (4) still hold copies the device has not consumed. */
+int32_t svt_hip_mem_upload_2d_async(svt_hip_ctx *ctx, void *d_dst, size_t dst_stride, const void *src, size_t src_stride, size_t width_bytes,
+                                    size_t rows);
+/* Completion markers: svt_hip_ctx_marker_record notes "everything enqueued on the context's stream so far" and returns a marker;
+ * svt_hip_ctx_marker_query returns 1 when that work has completed, 0 while it is pending (never blocks), negative on error;
+ * svt_hip_ctx_marker_wait blocks until it has.  This is what lets eb_vp9_svt_get_packet poll without blocking and block only when
+ * the application says it has sent its last picture (Codec/EbEncHandle.c:2880-2915). */
+int32_t svt_hip_ctx_marker_record(svt_hip_ctx *ctx, uint64_t *marker);
+int32_t svt_hip_ctx_marker_query(svt_hip_ctx *ctx, uint64_t marker);
+int32_t svt_hip_ctx_marker_wait(svt_hip_ctx *ctx, uint64_t marker);
 int32_t svt_hip_mem_set(svt_hip_ctx *ctx, void *d_dst, int32_t value, size_t bytes);
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -613,6 +626,20 @@ int32_t svt_hip_gop_assign(int64_t n_gops, int32_t n_devices, int32_t index, int
  * n_devices first -- the one exchange step of the path (a point-to-point copy over one xGMI link, ~13.9 MB at 4K).
  * Returns the device that produces the reference mini-GOP m needs, or -1 for m = 0 (it starts from the key frame). */
 int32_t svt_hip_minigop_reference_source(int64_t minigop, int32_t n_devices);
+
+/* How the reference cuts a group of n_pictures consecutive non-intra pictures that is shorter than a mini-GOP (end of stream, or an
+ * intra refresh arrived) into the units it assigns prediction structures to: eb_vp9_generate_picture_window_split +
+ * eb_vp9_handle_incomplete_picture_window_map as the picture-decision kernel drives them (Codec/EbPictureDecisionProcess.c:387-476,
+ * 1662-1680; mini-GOP table Codec/EbUtility.c:167-185).  A full group (n_pictures == 1 << hierarchical_levels) is one part.  A
+ * part whose length equals the period of its own levels (8 pictures at 3 levels) keeps the random-access hierarchy; any other
+ * part -- and every part of a group cut by an intra refresh -- is coded with the low-delay P structure (:1711-1727).
+ * Returns the number of parts (<= 4) or a negative error. */
+typedef struct svt_minigop_part {
+    int32_t start, length;          /* pictures [start, start + length) of the group */
+    int32_t hierarchical_levels;    /* of the part (mini_gop_hierarchical_levels) */
+    int32_t random_access;          /* 1: hierarchical B pictures; 0: low-delay P */
+} svt_minigop_part;
+int32_t svt_hip_minigop_split(int32_t n_pictures, int32_t hierarchical_levels, int32_t cut_by_intra, svt_minigop_part parts[4]);
 
 /* A set of contexts, one per device of a node, for a host that drives several GPUs from one process (one host thread per
  * device is the intended use: a context is not shared between threads).  Devices are HIP ordinals. */

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "svt_ctx.h"
 
 static thread_local char g_err[512] = "";
@@ -72,6 +73,13 @@ extern "C" void svt_hip_ctx_destroy(svt_hip_ctx *c) {
         if (c->ring_host[i]) (void)hipHostFree(c->ring_host[i]);
         if (c->ring_ev[i]) (void)hipEventDestroy(c->ring_ev[i]);
     }
+    for (int i = 0; i < SVT_CTX_UPLOAD_RING; i++) {
+        if (c->up_host[i]) (void)hipHostFree(c->up_host[i]);
+        if (c->up_ev[i]) (void)hipEventDestroy(c->up_ev[i]);
+    }
+    for (int i = 0; i < SVT_CTX_MARKERS; i++) if (c->mk_ev[i]) (void)hipEventDestroy(c->mk_ev[i]);
+    if (c->ho_produced) (void)hipEventDestroy(c->ho_produced);
+    if (c->ho_consumed) (void)hipEventDestroy(c->ho_consumed);
     if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
     for (int i = 0; i < 3; i++) {
         if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
@@ -86,10 +94,11 @@ int svt_ctx_aux_init(svt_hip_ctx *c) {
     if (c->aux_ready) return 0;
     int prio = 0;
     (void)hipStreamGetPriority(c->stream, &prio);
-    if (hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming) != hipSuccess) return -1;
+    /* idempotent per resource: a call that failed half-way leaves its handles in place and the next call creates only what is missing */
+    if (!c->aux_fork && hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming) != hipSuccess) { c->aux_fork = nullptr; return -1; }
     for (int i = 0; i < 3; i++) {
-        if (hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, prio) != hipSuccess) return -1;
-        if (hipEventCreateWithFlags(&c->aux_join[i], hipEventDisableTiming) != hipSuccess) return -1;
+        if (!c->aux[i] && hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, prio) != hipSuccess) { c->aux[i] = nullptr; return -1; }
+        if (!c->aux_join[i] && hipEventCreateWithFlags(&c->aux_join[i], hipEventDisableTiming) != hipSuccess) { c->aux_join[i] = nullptr; return -1; }
     }
     c->aux_ready = 1;
     return 0;
@@ -164,6 +173,62 @@ extern "C" int32_t svt_hip_mem_upload_2d(svt_hip_ctx *ctx, void *d_dst, size_t d
     HIP_TRY(hipStreamSynchronize(ctx->stream)); /* the host rows may be pageable and are the caller's to reuse on return */
     return SVT_HIP_OK;
 }
+/* The rows are copied into a pinned staging buffer of the context before the call returns (the copy the reference makes of an
+ * input picture inside eb_vp9_svt_enc_send_picture, Codec/EbEncHandle.c:2743-2796): the caller may reuse them at once, the
+ * host-to-device copy runs asynchronously in stream order. */
+extern "C" int32_t svt_hip_mem_upload_2d_async(svt_hip_ctx *ctx, void *d_dst, size_t dst_stride, const void *src, size_t src_stride,
+                                               size_t width_bytes, size_t rows) {
+    if (!ctx || !d_dst || !src || !width_bytes || !rows || dst_stride < width_bytes || src_stride < width_bytes)
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "mem_upload_async: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int    k = ctx->up_pos;
+    const size_t bytes = width_bytes * rows;
+    if (ctx->up_used[k]) { HIP_TRY(hipEventSynchronize(ctx->up_ev[k])); ctx->up_used[k] = 0; }
+    if (!ctx->up_ev[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->up_ev[k], hipEventDisableTiming));
+    if (bytes > ctx->up_bytes[k]) {
+        if (ctx->up_host[k]) (void)hipHostFree(ctx->up_host[k]);
+        ctx->up_host[k] = nullptr; ctx->up_bytes[k] = 0;
+        if (hipHostMalloc(&ctx->up_host[k], bytes, hipHostMallocDefault) != hipSuccess) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "mem_upload_async: pinned staging buffer");
+        ctx->up_bytes[k] = bytes;
+    }
+    uint8_t *st = (uint8_t *)ctx->up_host[k];
+    if (src_stride == width_bytes) memcpy(st, src, bytes);
+    else for (size_t r = 0; r < rows; r++) memcpy(st + r * width_bytes, (const uint8_t *)src + r * src_stride, width_bytes);
+    HIP_TRY(hipMemcpy2DAsync(d_dst, dst_stride, st, width_bytes, width_bytes, rows, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->up_ev[k], ctx->stream));
+    ctx->up_used[k] = 1;
+    ctx->up_pos = (k + 1) % SVT_CTX_UPLOAD_RING;
+    return SVT_HIP_OK;
+}
+
+/* ---- completion markers: "everything enqueued on the context's stream so far" as a value a host can poll or wait for ---- */
+extern "C" int32_t svt_hip_ctx_marker_record(svt_hip_ctx *ctx, uint64_t *marker) {
+    if (!ctx || !marker) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "marker: null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint64_t m = ctx->mk_next;
+    hipEvent_t    &e = ctx->mk_ev[m % SVT_CTX_MARKERS];
+    if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    else HIP_TRY(hipEventSynchronize(e)); /* its previous use (marker m - SVT_CTX_MARKERS) is complete from here on */
+    HIP_TRY(hipEventRecord(e, ctx->stream));
+    ctx->mk_next = m + 1;
+    *marker = m;
+    return SVT_HIP_OK;
+}
+extern "C" int32_t svt_hip_ctx_marker_query(svt_hip_ctx *ctx, uint64_t marker) {
+    if (!ctx || marker >= ctx->mk_next) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "marker: unknown");
+    if (ctx->mk_next - marker > SVT_CTX_MARKERS) return 1; /* its event has been waited for and recorded again since */
+    const hipError_t e = hipEventQuery(ctx->mk_ev[marker % SVT_CTX_MARKERS]);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    return svt_set_hip_error(e, __FILE__, __LINE__);
+}
+extern "C" int32_t svt_hip_ctx_marker_wait(svt_hip_ctx *ctx, uint64_t marker) {
+    if (!ctx || marker >= ctx->mk_next) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "marker: unknown");
+    if (ctx->mk_next - marker > SVT_CTX_MARKERS) return SVT_HIP_OK;
+    HIP_TRY(hipEventSynchronize(ctx->mk_ev[marker % SVT_CTX_MARKERS]));
+    return SVT_HIP_OK;
+}
+
 extern "C" int32_t svt_hip_mem_download(svt_hip_ctx *ctx, void *dst, const void *d_src, size_t bytes) {
     if (!ctx || !dst || !d_src || !bytes) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "mem_download: bad argument");
     HIP_TRY(hipSetDevice(ctx->device));

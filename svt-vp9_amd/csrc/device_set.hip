@@ -48,17 +48,21 @@ extern "C" int32_t svt_hip_ref_handoff_device(svt_hip_ctx *src, const void *d_sr
             (void)hipGetLastError();
         }
     }
-    /* producer's stream -> event -> consumer's stream: the copy runs on the consumer's stream after the producer's work */
-    if (svt_ctx_aux_init(src) || svt_ctx_aux_init(dst)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "handoff: events");
+    /* producer's stream -> event -> consumer's stream: the copy runs on the consumer's stream after the producer's work.  The two
+     * events are the contexts' own hand-off events (not shared with any other entry point).  The call touches BOTH contexts: the
+     * caller serialises it against other calls on either of them (one thread per device: do the hand-off while the consumer's
+     * thread is not enqueuing, e.g. at the mini-GOP boundary it synchronises on anyway). */
     HIP_TRY(hipSetDevice(src->device));
-    HIP_TRY(hipEventRecord(src->aux_fork, src->stream));
+    if (!src->ho_produced) HIP_TRY(hipEventCreateWithFlags(&src->ho_produced, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(src->ho_produced, src->stream));
     HIP_TRY(hipSetDevice(dst->device));
-    HIP_TRY(hipStreamWaitEvent(dst->stream, src->aux_fork, 0));
+    if (!dst->ho_consumed) HIP_TRY(hipEventCreateWithFlags(&dst->ho_consumed, hipEventDisableTiming));
+    HIP_TRY(hipStreamWaitEvent(dst->stream, src->ho_produced, 0));
     if (src->device == dst->device) HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, dst->stream));
     else HIP_TRY(hipMemcpyPeerAsync(d_dst, dst->device, d_src, src->device, bytes, dst->stream));
     /* the producer may reuse its buffer only once the copy has read it */
-    HIP_TRY(hipEventRecord(dst->aux_fork, dst->stream));
+    HIP_TRY(hipEventRecord(dst->ho_consumed, dst->stream));
     HIP_TRY(hipSetDevice(src->device));
-    HIP_TRY(hipStreamWaitEvent(src->stream, dst->aux_fork, 0));
+    HIP_TRY(hipStreamWaitEvent(src->stream, dst->ho_consumed, 0));
     return SVT_HIP_OK;
 }

@@ -8,6 +8,8 @@
 
 #define SVT_CTX_SLOTS 40
 #define SVT_CTX_RING 64
+#define SVT_CTX_UPLOAD_RING 4   /* pinned staging buffers of svt_hip_mem_upload_2d_async */
+#define SVT_CTX_MARKERS 1024    /* completion markers in flight (svt_hip_ctx_marker_*) */
 
 struct svt_hip_ctx {
     int         device;
@@ -29,6 +31,19 @@ struct svt_hip_ctx {
     hipStream_t aux[3];
     hipEvent_t  aux_fork, aux_join[3];
     int         aux_ready;
+    /* asynchronous uploads: the caller's rows are copied into a pinned buffer of this ring before the call returns, the device
+       copy is ordered on the stream; a buffer is reused once the event behind its copy has completed */
+    void       *up_host[SVT_CTX_UPLOAD_RING];
+    size_t      up_bytes[SVT_CTX_UPLOAD_RING];
+    hipEvent_t  up_ev[SVT_CTX_UPLOAD_RING];
+    int         up_used[SVT_CTX_UPLOAD_RING];
+    int         up_pos;
+    /* completion markers: marker m is event m % SVT_CTX_MARKERS; before an event is recorded again its previous use is waited
+       for, so a marker older than SVT_CTX_MARKERS records is complete by construction */
+    hipEvent_t  mk_ev[SVT_CTX_MARKERS];
+    uint64_t    mk_next;
+    /* dedicated events of svt_hip_ref_handoff_device (producer side / consumer side) */
+    hipEvent_t  ho_produced, ho_consumed;
     void       *slot[SVT_CTX_SLOTS]; /* grow-only device buffers of the host-pointer convenience entry points */
     size_t      slot_bytes[SVT_CTX_SLOTS];
 };

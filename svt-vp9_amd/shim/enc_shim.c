@@ -12,8 +12,12 @@
  *                                library's until eb_vp9_svt_release_out_buffer (:1752-1757)
  *   eb_vp9_svt_get_recon         EB_ErrorMax when recon_file == 0 (:2856-2861)
  *   stream_header / eos_nal      no-ops returning EB_ErrorNone (:2953-2971)
- * What the library does with the pictures: picture analysis + motion estimation of the reference's random-access
- * mini-GOPs on the GPU (see svt_vp9_enc_api.h); every picture is answered by a zero-byte packet.
+ * What the library does with the pictures: picture analysis (padded / decimated planes, block mean / variance) as each picture
+ * arrives, motion estimation of a whole mini-GOP in ONE batched launch (svt_hip_me_batch_layers_device) plus the per-SB ME
+ * statistics (svt_hip_me_sb_stats_device) when its last picture has arrived -- all enqueued asynchronously: send_picture returns
+ * after the host copy of the picture (pinned staging), get_packet polls completion markers and blocks only when the caller says
+ * it has sent its last picture (pic_send_done), as in the reference (:2880-2915).  Every picture is answered by a zero-byte
+ * packet: entropy coding is outside the hot path.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -27,19 +31,23 @@
 typedef struct shim_packet {
     EbBufferHeaderType  hdr;
     struct shim_packet *next;
+    uint64_t            marker;     /* the GPU work behind this packet (svt_hip_ctx_marker_*) */
 } shim_packet;
 
-typedef struct shim_slot { /* one buffered picture: its three ME planes and its ME results, all on the device */
+typedef struct shim_slot { /* one buffered picture: its three ME planes, its block statistics and its ME outputs, all on the device */
     int64_t        number;  /* display order, -1 = empty */
     int64_t        pts;
     svt_pa_picture pa;
     void          *d_luma;  /* the source luma, tightly packed (stride = width) */
-    void          *d_results;
+    void          *d_results, *d_mean, *d_var, *d_rcme, *d_stats, *d_hist;
+    int            processed;   /* its ME (or, for an intra picture, its analysis) has been enqueued */
+    int            has_marker;
+    uint64_t       marker;      /* completion of everything enqueued for this picture so far */
     svt_vp9_shim_picture_info info;
 } shim_slot;
 
 typedef struct shim_state {
-    EbSvtVp9EncConfiguration cfg;
+    EbSvtVp9EncConfiguration cfg;   /* the library's copy, with frame_rate / intra_period resolved (copy_api_from_app) */
     int         configured, initialised, eos;
     int         levels, minigop;       /* hierarchical levels, 1 << levels */
     int         intra_period;          /* resolved */
@@ -52,6 +60,7 @@ typedef struct shim_state {
     int64_t     last_base;             /* display number of the latest base-layer / intra picture (-1: none yet) */
     shim_packet *q_head, *q_tail;
     int         eos_reported;
+    uint64_t    me_launches;           /* batched ME launches so far (svt_vp9_shim_get_counters) */
 } shim_state;
 
 /* VP9 level limits (max luma picture size, max luma sample rate), indexed like the reference's tables (:109-134) */
@@ -139,19 +148,22 @@ EbErrorType eb_vp9_svt_init_handle(EbComponentType **p_handle, void *p_app_data,
 EbErrorType eb_vp9_svt_enc_set_parameter(EbComponentType *h, EbSvtVp9EncConfiguration *p) {
     shim_state *s = state_of(h);
     if (!s || !p) return EB_ErrorBadParameter;
-    if (verify(p) != EB_ErrorNone) return EB_ErrorBadParameter;
-    s->cfg = *p;
-    /* set_param_based_on_input (:2166-2192) */
-    s->levels  = (s->cfg.tune != 0 && s->cfg.rate_control_mode == 0) ? 4 : 3;
-    s->minigop = 1 << s->levels;
-    if (s->cfg.frame_rate_numerator != 0 && s->cfg.frame_rate_denominator != 0)
-        s->cfg.frame_rate = ((s->cfg.frame_rate_numerator << 8) / s->cfg.frame_rate_denominator) << 8;
-    s->intra_period = s->cfg.intra_period;
-    if (s->intra_period == -2) { /* compute_default_intra_period (:2014-2024) */
-        const int fps = s->cfg.frame_rate < 1000 ? (int)s->cfg.frame_rate : (int)(s->cfg.frame_rate >> 16);
-        const int lo = fps / s->minigop * s->minigop, hi = (fps + s->minigop) / s->minigop * s->minigop;
-        s->intra_period = abs(fps - hi) > abs(fps - lo) ? lo : hi;
+    /* copy_api_from_app (:2052-2192) builds the library's copy FIRST -- hierarchical levels, frame rate from numerator /
+     * denominator, the automatic intra period -- and verify_settings (:2203) judges that copy */
+    EbSvtVp9EncConfiguration c = *p;
+    const int levels = (c.tune != 0 && c.rate_control_mode == 0) ? 4 : 3, minigop = 1 << levels;
+    if (c.frame_rate_numerator != 0 && c.frame_rate_denominator != 0)
+        c.frame_rate = ((c.frame_rate_numerator << 8) / c.frame_rate_denominator) << 8;
+    if (c.intra_period == -2) { /* compute_default_intra_period (:2014-2024) */
+        const int fps = c.frame_rate < 1000 ? (int)c.frame_rate : (int)(c.frame_rate >> 16);
+        const int lo = fps / minigop * minigop, hi = (fps + minigop) / minigop * minigop;
+        c.intra_period = abs(fps - hi) > abs(fps - lo) ? lo : hi;
     }
+    if (verify(&c) != EB_ErrorNone) return EB_ErrorBadParameter;
+    s->cfg = c;
+    s->levels = levels;
+    s->minigop = minigop;
+    s->intra_period = c.intra_period;
     s->configured = 1;
     return EB_ErrorNone;
 }
@@ -163,8 +175,8 @@ static void free_slots(shim_state *s) {
         svt_hip_mem_free(s->ctx, (void *)t->pa.full.buf);
         svt_hip_mem_free(s->ctx, (void *)t->pa.quarter.buf);
         svt_hip_mem_free(s->ctx, (void *)t->pa.sixteenth.buf);
-        svt_hip_mem_free(s->ctx, t->d_luma);
-        svt_hip_mem_free(s->ctx, t->d_results);
+        void *v[7] = {t->d_luma, t->d_results, t->d_mean, t->d_var, t->d_rcme, t->d_stats, t->d_hist};
+        for (int k = 0; k < 7; k++) svt_hip_mem_free(s->ctx, v[k]);
     }
     free(s->slot);
     s->slot = NULL;
@@ -174,31 +186,46 @@ EbErrorType eb_vp9_init_encoder(EbComponentType *h) {
     shim_state *s = state_of(h);
     if (!s || !s->configured) return EB_ErrorBadParameter;
     if (s->initialised) return EB_ErrorNone;
-    if (svt_hip_ctx_create(&s->ctx, s->cfg.target_socket > 0 ? s->cfg.target_socket : 0) != SVT_HIP_OK) {
+    /* target_socket names a CPU socket in the reference (-1 = both); here the GPU ordinal comes from SVT_HIP_DEVICE (default 0) */
+    const char *dv = getenv("SVT_HIP_DEVICE");
+    if (svt_hip_ctx_create(&s->ctx, dv ? atoi(dv) : 0) != SVT_HIP_OK) {
         fprintf(stderr, "SvtVp9Enc (GPU hot path): %s\n", svt_hip_last_error());
         s->ctx = NULL;
         return EB_ErrorInsufficientResources;
     }
     const int W = (int)s->cfg.source_width, H = (int)s->cfg.source_height;
     const int pad[3] = {68, 32, 16}; /* PA reference paddings, Codec/EbEncHandle.c:1003-1026 */
-    s->n_slots = s->minigop + 1;
+    /* the mini-GOP being collected, the one whose ME is in flight, and the base picture before it */
+    s->n_slots = 2 * s->minigop + 2;
     s->slot = (shim_slot *)calloc((size_t)s->n_slots, sizeof(shim_slot));
-    if (!s->slot) return EB_ErrorInsufficientResources;
+    if (!s->slot) { svt_hip_ctx_destroy(s->ctx); s->ctx = NULL; return EB_ErrorInsufficientResources; }
     const uint32_t n_sb = (uint32_t)svt_hip_sb_count(W, H);
-    for (int i = 0; i < s->n_slots; i++) {
+    int ok = 1;
+    for (int i = 0; ok && i < s->n_slots; i++) {
         shim_slot *t = &s->slot[i];
         t->number = -1;
         svt_plane *pl[3] = {&t->pa.full, &t->pa.quarter, &t->pa.sixteenth};
-        for (int k = 0; k < 3; k++) {
+        for (int k = 0; ok && k < 3; k++) {
             const int w = W >> k, hh = H >> k;
             void *d = NULL;
-            if (svt_hip_mem_alloc(s->ctx, (size_t)(w + 2 * pad[k]) * (size_t)(hh + 2 * pad[k]), &d) != SVT_HIP_OK) { free_slots(s); return EB_ErrorInsufficientResources; }
+            ok = svt_hip_mem_alloc(s->ctx, (size_t)(w + 2 * pad[k]) * (size_t)(hh + 2 * pad[k]), &d) == SVT_HIP_OK;
             pl[k]->buf = (const uint8_t *)d; pl[k]->stride = w + 2 * pad[k]; pl[k]->origin_x = pl[k]->origin_y = pad[k];
             pl[k]->width = w; pl[k]->height = hh;
         }
-        if (svt_hip_mem_alloc(s->ctx, (size_t)W * H, &t->d_luma) != SVT_HIP_OK ||
-            svt_hip_mem_alloc(s->ctx, (size_t)n_sb * 85 * sizeof(svt_me_pu_result), &t->d_results) != SVT_HIP_OK) { free_slots(s); return EB_ErrorInsufficientResources; }
+        ok = ok && svt_hip_mem_alloc(s->ctx, (size_t)W * H, &t->d_luma) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(s->ctx, (size_t)n_sb * 85 * sizeof(svt_me_pu_result), &t->d_results) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(s->ctx, (size_t)n_sb * 85, &t->d_mean) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(s->ctx, (size_t)n_sb * 85 * sizeof(uint16_t), &t->d_var) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(s->ctx, (size_t)n_sb * sizeof(uint32_t), &t->d_rcme) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(s->ctx, (size_t)n_sb * sizeof(svt_me_sb_stats), &t->d_stats) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(s->ctx, (2 * SVT_SAD_INTERVALS + 1) * sizeof(uint32_t), &t->d_hist) == SVT_HIP_OK;
         t->info.n_sb = n_sb;
+    }
+    if (!ok) { /* nothing half-initialised is left behind: the handle is back in its configured state */
+        free_slots(s);
+        svt_hip_ctx_destroy(s->ctx);
+        s->ctx = NULL;
+        return EB_ErrorInsufficientResources;
     }
     s->initialised = 1;
     return EB_ErrorNone;
@@ -210,7 +237,7 @@ EbErrorType eb_vp9_svt_enc_eos_nal(EbComponentType *h, EbBufferHeaderType **o) {
 /* ------------------------------------------------------------------------------------------------ */
 static shim_slot *slot_of(shim_state *s, int64_t number) { return &s->slot[number % s->n_slots]; }
 
-static int push_packet(shim_state *s, int64_t pts, uint32_t flags, uint32_t pic_type) {
+static int push_packet(shim_state *s, int64_t pts, uint32_t flags, uint32_t pic_type, uint64_t marker) {
     shim_packet *p = (shim_packet *)calloc(1, sizeof *p);
     if (!p) return -1;
     p->hdr.size = sizeof(EbBufferHeaderType);
@@ -218,70 +245,149 @@ static int push_packet(shim_state *s, int64_t pts, uint32_t flags, uint32_t pic_
     p->hdr.flags = flags;
     p->hdr.pic_type = pic_type;
     p->hdr.wrapper_ptr = p; /* the round trip of the reference's wrapper_ptr (:2923) */
+    p->marker = marker;
     if (s->q_tail) s->q_tail->next = p; else s->q_head = p;
     s->q_tail = p;
     return 0;
 }
 
-/* motion estimation of one picture against its references, parameters as the reference derives them for this picture */
-static EbErrorType me_picture(shim_state *s, int64_t number, int64_t ref0, int64_t ref1, int layer, int levels, int n_lists) {
-    shim_slot *t = slot_of(s, number);
+/* one picture of a group whose motion estimation is about to be launched */
+typedef struct shim_job {
+    int64_t       number, ref0, ref1;
+    int           layer, levels, n_lists, used_as_ref;
+    svt_me_params p;
+} shim_job;
+
+/* the parameters motion_estimate_sb reads for this picture, as the reference derives them */
+static EbErrorType job_params(shim_state *s, shim_job *j) {
     svt_me_picture_config pc;
     memset(&pc, 0, sizeof pc);
     pc.pic_width = (int32_t)s->cfg.source_width; pc.pic_height = (int32_t)s->cfg.source_height;
     pc.enc_mode = s->cfg.enc_mode; pc.tune = s->cfg.tune;
-    pc.frame_rate = (int32_t)(s->cfg.frame_rate > 1000 ? s->cfg.frame_rate >> 16 : s->cfg.frame_rate);
-    pc.num_ref_lists = n_lists; pc.temporal_layer_index = layer; pc.hierarchical_levels = levels;
-    pc.is_used_as_reference = layer < levels;
-    pc.same_ref_poc = n_lists == 2 && ref0 == ref1;
+    /* static_config.frame_rate >> 16, the value the reference's 4K HME widening tests (Codec/EbMotionEstimationProcess.c:55-324) */
+    pc.frame_rate = (int32_t)(s->cfg.frame_rate >> 16);
+    pc.num_ref_lists = j->n_lists; pc.temporal_layer_index = j->layer; pc.hierarchical_levels = j->levels;
+    pc.is_used_as_reference = j->used_as_ref;
+    pc.same_ref_poc = j->n_lists == 2 && j->ref0 == j->ref1;
     pc.rate_control_mode = (int32_t)s->cfg.rate_control_mode;
-    svt_me_params p;
-    if (svt_hip_me_params_derive(&p, &pc) != SVT_HIP_OK) return EB_ErrorBadParameter;
-    if (!s->cfg.use_default_me_hme) { /* eb_vp9_set_me_hme_params_from_confi (Codec/EbMotionEstimationProcess.c:316-324) */
-        p.search_area_width  = (uint8_t)s->cfg.search_area_width;
-        p.search_area_height = (uint8_t)s->cfg.search_area_height;
-        p.enable_hme_flag    = s->cfg.enable_hme_flag;
+    if (svt_hip_me_params_derive(&j->p, &pc) != SVT_HIP_OK) return EB_ErrorBadParameter;
+    if (!s->cfg.use_default_me_hme) { /* eb_vp9_set_me_hme_params_from_config (Codec/EbMotionEstimationProcess.c:316-324) */
+        /* verify_settings accepts 1..256 and the reference keeps the value in a uint8_t (256 wraps to 0 there: a configuration
+           it cannot run); here the search area is clamped to what the kernel's record holds */
+        const uint32_t w = s->cfg.search_area_width, hh = s->cfg.search_area_height;
+        j->p.search_area_width  = (uint8_t)(w > 255 ? 255 : w < 1 ? 1 : w);
+        j->p.search_area_height = (uint8_t)(hh > 255 ? 255 : hh < 1 ? 1 : hh);
+        j->p.enable_hme_flag    = s->cfg.enable_hme_flag;
     }
-    const svt_pa_picture *r1 = n_lists == 2 ? &slot_of(s, ref1)->pa : NULL;
-    if (svt_hip_me_picture_device(s->ctx, &t->pa, &slot_of(s, ref0)->pa, r1, &p, (svt_me_pu_result *)t->d_results, NULL) != SVT_HIP_OK) {
-        fprintf(stderr, "SvtVp9Enc (GPU hot path): %s\n", svt_hip_last_error());
-        return EB_ErrorMax;
-    }
-    t->info.is_intra = 0; t->info.temporal_layer_index = layer; t->info.hierarchical_levels = levels; t->info.num_ref_lists = n_lists;
-    t->info.ref_picture_number[0] = ref0; t->info.ref_picture_number[1] = n_lists == 2 ? ref1 : -1;
     return EB_ErrorNone;
 }
 
-/* a complete mini-GOP [first, first + n): base picture first (decode order), then the hierarchy by bisection */
-static EbErrorType me_hierarchy(shim_state *s, int64_t lo, int64_t hi, int layer) { /* pictures strictly between lo and hi */
-    if (hi - lo < 2) return EB_ErrorNone;
-    const int64_t mid = (lo + hi) / 2;
-    EbErrorType e = me_picture(s, mid, lo, hi, layer, s->levels, 2);
-    if (e != EB_ErrorNone) return e;
-    if (push_packet(s, slot_of(s, mid)->pts, 0, 0 /* EB_B_PICTURE */)) return EB_ErrorInsufficientResources;
-    if ((e = me_hierarchy(s, lo, mid, layer + 1)) != EB_ErrorNone) return e;
-    return me_hierarchy(s, mid, hi, layer + 1);
+/* do two parameter sets belong to one launch (svt_hip_me_batch_layers_device)?  They may differ in the four per-picture fields */
+static int same_launch(const svt_me_params *a, const svt_me_params *b) {
+    svt_me_params x = *a, y = *b;
+    x.num_ref_lists = y.num_ref_lists = 0; x.temporal_layer_index = y.temporal_layer_index = 0;
+    x.hierarchical_levels = y.hierarchical_levels = 0; x.same_ref_poc = y.same_ref_poc = 0;
+    return memcmp(&x, &y, sizeof x) == 0;
 }
 
-static EbErrorType flush_pending(shim_state *s) {
-    EbErrorType e = EB_ErrorNone;
-    if (!s->pending) return e;
+/* the hierarchy between two already-listed pictures lo < hi by bisection, decode order */
+static void add_hierarchy(shim_job *jobs, int *n, int64_t lo, int64_t hi, int layer, int levels) {
+    if (hi - lo < 2) return;
+    const int64_t mid = (lo + hi) / 2;
+    shim_job *j = &jobs[(*n)++];
+    memset(j, 0, sizeof *j);
+    j->number = mid; j->ref0 = lo; j->ref1 = hi; j->layer = layer; j->levels = levels; j->n_lists = 2; j->used_as_ref = layer < levels;
+    add_hierarchy(jobs, n, lo, mid, layer + 1, levels);
+    add_hierarchy(jobs, n, mid, hi, layer + 1, levels);
+}
+
+/* Motion estimation of the collected group: its pictures are cut into parts as the reference cuts them
+ * (svt_hip_minigop_split), all of them go to the GPU in as few launches as their parameter sets allow (one for a regular
+ * mini-GOP), followed by the per-SB statistics of every picture.  Nothing here waits for the device. */
+static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_stream) {
+    if (!s->pending) return EB_ErrorNone;
+    shim_job jobs[SHIM_MAX_MINIGOP];
+    int      n = 0;
     const int64_t first = s->pending_first;
-    if (s->pending == s->minigop && s->last_base >= 0) {
-        const int64_t base = first + s->minigop - 1;
-        if ((e = me_picture(s, base, s->last_base, s->last_base, 0, s->levels, 2)) != EB_ErrorNone) return e;
-        if (push_packet(s, slot_of(s, base)->pts, 0, 0)) return EB_ErrorInsufficientResources;
-        if ((e = me_hierarchy(s, s->last_base, base, 1)) != EB_ErrorNone) return e;
-        s->last_base = base;
-    } else { /* a short group (end of stream, or cut by an intra refresh): a chain of P pictures, each from its predecessor */
-        for (int k = 0; k < s->pending; k++) {
-            if ((e = me_picture(s, first + k, first + k - 1, -1, 0, 0, 1)) != EB_ErrorNone) return e;
-            if (push_packet(s, slot_of(s, first + k)->pts, 0, 1 /* EB_P_PICTURE */)) return EB_ErrorInsufficientResources;
+    svt_minigop_part parts[4];
+    const int np = svt_hip_minigop_split(s->pending, s->levels, cut_by_intra, parts);
+    if (np < 1) return EB_ErrorBadParameter;
+    int64_t prev = s->last_base;
+    for (int k = 0; k < np; k++) {
+        const int64_t p0 = first + parts[k].start, base = p0 + parts[k].length - 1;
+        if (parts[k].random_access && prev >= 0) { /* base picture first (decode order), then the B hierarchy */
+            shim_job *j = &jobs[n++];
+            memset(j, 0, sizeof *j);
+            j->number = base; j->ref0 = j->ref1 = prev; j->layer = 0; j->levels = parts[k].hierarchical_levels; j->n_lists = 2; j->used_as_ref = 1;
+            add_hierarchy(jobs, &n, prev, base, 1, parts[k].hierarchical_levels);
+        } else { /* low-delay P: the reference's structure tables (Codec/EbPredictionStructure.c) are picture decision, not
+                    reproduced -- every picture is predicted from its predecessor and serves as the next one's reference */
+            for (int64_t q = p0; q <= base; q++) {
+                shim_job *j = &jobs[n++];
+                memset(j, 0, sizeof *j);
+                j->number = q; j->ref0 = q - 1; j->ref1 = -1; j->layer = 0; j->levels = parts[k].hierarchical_levels; j->n_lists = 1; j->used_as_ref = 1;
+            }
         }
-        s->last_base = first + s->pending - 1;
+        prev = base;
     }
+    for (int i = 0; i < n; i++) {
+        const EbErrorType e = job_params(s, &jobs[i]);
+        if (e != EB_ErrorNone) return e;
+    }
+    /* launches: classes of pictures whose parameter sets may share one */
+    int done[SHIM_MAX_MINIGOP] = {0};
+    for (int i = 0; i < n; i++) {
+        if (done[i]) continue;
+        svt_pa_picture    cur[SHIM_MAX_MINIGOP], r0[SHIM_MAX_MINIGOP], r1[SHIM_MAX_MINIGOP];
+        svt_me_params     pp[SHIM_MAX_MINIGOP];
+        svt_me_pu_result *res[SHIM_MAX_MINIGOP];
+        uint32_t         *rc[SHIM_MAX_MINIGOP];
+        int               m = 0;
+        for (int k = i; k < n; k++) {
+            if (done[k] || !same_launch(&jobs[i].p, &jobs[k].p)) continue;
+            shim_slot *t = slot_of(s, jobs[k].number);
+            cur[m] = t->pa; r0[m] = slot_of(s, jobs[k].ref0)->pa; r1[m] = slot_of(s, jobs[k].n_lists == 2 ? jobs[k].ref1 : jobs[k].ref0)->pa;
+            pp[m] = jobs[k].p; res[m] = (svt_me_pu_result *)t->d_results; rc[m] = (uint32_t *)t->d_rcme;
+            done[k] = 1;
+            m++;
+        }
+        if (svt_hip_me_batch_layers_device(s->ctx, m, cur, r0, r1, pp, res, s->cfg.rate_control_mode ? rc : NULL) != SVT_HIP_OK) {
+            fprintf(stderr, "SvtVp9Enc (GPU hot path): %s\n", svt_hip_last_error());
+            return EB_ErrorMax;
+        }
+        s->me_launches++;
+    }
+    /* the tail of the ME kernel process per picture (Codec/EbMotionEstimationProcess.c:1047-1237): stationary-edge flags and the
+       rate-control histograms from the ME results and the picture-analysis variances, all device resident */
+    const int res_class = svt_hip_input_resolution((int32_t)s->cfg.source_width, (int32_t)s->cfg.source_height);
+    for (int i = 0; i < n; i++) {
+        shim_slot *t = slot_of(s, jobs[i].number);
+        svt_me_sb_stats_params sp;
+        memset(&sp, 0, sizeof sp);
+        sp.pic_width = (int32_t)s->cfg.source_width; sp.pic_height = (int32_t)s->cfg.source_height; sp.input_resolution = res_class;
+        sp.temporal_layer_index = jobs[i].layer; sp.slice_type = jobs[i].n_lists == 2 ? 0 : 1;
+        sp.run_part2 = !end_of_stream; sp.rate_control_mode = (int32_t)s->cfg.rate_control_mode;
+        if (svt_hip_mem_set(s->ctx, t->d_hist, 0, (2 * SVT_SAD_INTERVALS + 1) * sizeof(uint32_t)) != SVT_HIP_OK ||
+            svt_hip_me_sb_stats_device(s->ctx, &sp, (const svt_me_pu_result *)t->d_results, (const uint16_t *)t->d_var,
+                                       s->cfg.rate_control_mode ? (const uint32_t *)t->d_rcme : NULL, (svt_me_sb_stats *)t->d_stats, (uint32_t *)t->d_hist,
+                                       (uint32_t *)t->d_hist + 2 * SVT_SAD_INTERVALS) != SVT_HIP_OK) {
+            fprintf(stderr, "SvtVp9Enc (GPU hot path): %s\n", svt_hip_last_error());
+            return EB_ErrorMax;
+        }
+    }
+    uint64_t marker = 0;
+    if (svt_hip_ctx_marker_record(s->ctx, &marker) != SVT_HIP_OK) return EB_ErrorMax;
+    for (int i = 0; i < n; i++) { /* packets in decode order */
+        shim_slot *t = slot_of(s, jobs[i].number);
+        t->info.is_intra = 0; t->info.temporal_layer_index = jobs[i].layer; t->info.hierarchical_levels = jobs[i].levels;
+        t->info.num_ref_lists = jobs[i].n_lists;
+        t->info.ref_picture_number[0] = jobs[i].ref0; t->info.ref_picture_number[1] = jobs[i].n_lists == 2 ? jobs[i].ref1 : -1;
+        t->processed = 1; t->has_marker = 1; t->marker = marker;
+        if (push_packet(s, t->pts, 0, jobs[i].n_lists == 2 ? 0 /* EB_B_PICTURE */ : 1 /* EB_P_PICTURE */, marker)) return EB_ErrorInsufficientResources;
+    }
+    s->last_base = first + s->pending - 1;
     s->pending = 0;
-    return e;
+    return EB_ErrorNone;
 }
 
 EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *b) {
@@ -293,45 +399,67 @@ EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *
     if (b && b->p_buffer) {
         const EbSvtEncInput *in = (const EbSvtEncInput *)b->p_buffer;
         if (!in->luma || in->y_stride < s->cfg.source_width) return EB_ErrorBadParameter;
-        const int64_t n = s->next_number++;
+        const int64_t n = s->next_number;
         shim_slot    *t = slot_of(s, n);
         const int     W = (int)s->cfg.source_width, H = (int)s->cfg.source_height;
-        t->number = n; t->pts = b->pts; t->info.picture_number = (uint64_t)n;
-        /* the copy the reference makes in copy_frame_buffer (:2743-2796): the caller's planes are free again on return */
-        if (svt_hip_mem_upload_2d(s->ctx, t->d_luma, (size_t)W, in->luma, in->y_stride, (size_t)W, (size_t)H) != SVT_HIP_OK) return EB_ErrorMax;
+        /* the slot's previous picture (2 mini-GOPs + 2 ago) must have left the GPU: the one place send_picture can block, as the
+           reference blocks when its picture pool is exhausted */
+        if (t->has_marker && svt_hip_ctx_marker_wait(s->ctx, t->marker) != SVT_HIP_OK) return EB_ErrorMax;
+        /* the copy the reference makes in copy_frame_buffer (:2743-2796), into pinned staging: the caller's planes are free again
+           on return; the transfer and the analysis below run asynchronously */
+        if (svt_hip_mem_upload_2d_async(s->ctx, t->d_luma, (size_t)W, in->luma, in->y_stride, (size_t)W, (size_t)H) != SVT_HIP_OK) return EB_ErrorMax;
         const uint8_t *lum = (const uint8_t *)t->d_luma;
         const int32_t  stride = W;
-        if (svt_hip_pa_prepare_batch_device(s->ctx, 1, &lum, &stride, &t->pa, 1) != SVT_HIP_OK) return EB_ErrorMax;
+        if (svt_hip_pa_prepare_batch_device(s->ctx, 1, &lum, &stride, &t->pa, 1) != SVT_HIP_OK ||
+            svt_hip_pa_mean_variance_device(s->ctx, &t->pa.full, (uint8_t *)t->d_mean, (uint16_t *)t->d_var) != SVT_HIP_OK) return EB_ErrorMax;
+        /* the picture is accepted from here on */
+        s->next_number = n + 1;
+        t->number = n; t->pts = b->pts; t->info.picture_number = (uint64_t)n; t->processed = 0; t->has_marker = 0;
         const int intra = n == 0 || (s->intra_period >= 0 && n % (s->intra_period + 1) == 0);
         if (intra) {
-            if ((e = flush_pending(s)) != EB_ErrorNone) return e;
+            if ((e = flush_pending(s, 1, 0)) != EB_ErrorNone) return e;
             t->info.is_intra = 1; t->info.num_ref_lists = 0; t->info.temporal_layer_index = 0; t->info.hierarchical_levels = s->levels;
             t->info.ref_picture_number[0] = t->info.ref_picture_number[1] = -1;
-            if (push_packet(s, t->pts, 0, 2 /* EB_I_PICTURE */)) return EB_ErrorInsufficientResources;
+            if (svt_hip_ctx_marker_record(s->ctx, &t->marker) != SVT_HIP_OK) return EB_ErrorMax;
+            t->has_marker = 1; t->processed = 1;
+            if (push_packet(s, t->pts, 0, 2 /* EB_I_PICTURE */, t->marker)) return EB_ErrorInsufficientResources;
             s->last_base = n;
         } else {
             if (!s->pending) s->pending_first = n;
-            if (++s->pending == s->minigop) e = flush_pending(s);
+            if (++s->pending == s->minigop) e = flush_pending(s, 0, 0);
         }
     }
     if (end && e == EB_ErrorNone) {
-        e = flush_pending(s);
+        e = flush_pending(s, 0, 1);
         s->eos = 1;
         if (e == EB_ErrorNone) {
             if (s->q_tail) s->q_tail->hdr.flags |= EB_BUFFERFLAG_EOS; /* the last picture's packet closes the stream */
-            else if (push_packet(s, b ? b->pts : 0, EB_BUFFERFLAG_EOS, 0)) e = EB_ErrorInsufficientResources;
+            else {
+                uint64_t m = 0;
+                if (svt_hip_ctx_marker_record(s->ctx, &m) != SVT_HIP_OK) return EB_ErrorMax;
+                if (push_packet(s, b ? b->pts : 0, EB_BUFFERFLAG_EOS, 0, m)) e = EB_ErrorInsufficientResources;
+            }
         }
     }
-    if (e == EB_ErrorNone && svt_hip_ctx_synchronize(s->ctx) != SVT_HIP_OK) e = EB_ErrorMax;
     return e;
 }
 
+/* Non-blocking while pictures are still being sent (EB_NoErrorEmptyQueue when the next packet's GPU work has not finished);
+ * with pic_send_done the call waits for it, as eb_vp9_svt_get_packet does (:2880-2915: eb_vp9_get_full_object vs the
+ * non-blocking variant). */
 EbErrorType eb_vp9_svt_get_packet(EbComponentType *h, EbBufferHeaderType **p_buffer, uint8_t pic_send_done) {
     shim_state *s = state_of(h);
-    (void)pic_send_done; /* everything sent has been processed when send_picture returned: nothing to block on */
     if (!s || !p_buffer) return EB_ErrorBadParameter;
     shim_packet *p = s->q_head;
     if (!p) return EB_NoErrorEmptyQueue;
+    if (s->ctx) {
+        if (pic_send_done) { if (svt_hip_ctx_marker_wait(s->ctx, p->marker) != SVT_HIP_OK) return EB_ErrorMax; }
+        else {
+            const int32_t q = svt_hip_ctx_marker_query(s->ctx, p->marker);
+            if (q < 0) return EB_ErrorMax;
+            if (q == 0) return EB_NoErrorEmptyQueue;
+        }
+    }
     s->q_head = p->next;
     if (!s->q_head) s->q_tail = NULL;
     p->next = NULL;
@@ -385,12 +513,40 @@ EbErrorType svt_vp9_shim_get_me_results(EbComponentType *h, uint64_t picture_num
     shim_state *s = state_of(h);
     if (!s || !s->initialised) return EB_ErrorBadParameter;
     shim_slot *t = slot_of(s, (int64_t)picture_number);
-    if (t->number != (int64_t)picture_number) return EB_NoErrorEmptyQueue;
+    /* a picture that waits in an incomplete mini-GOP has no results yet; neither has one the ring has already given away */
+    if (t->number != (int64_t)picture_number || !t->processed) return EB_NoErrorEmptyQueue;
+    if (svt_hip_ctx_marker_wait(s->ctx, t->marker) != SVT_HIP_OK) return EB_ErrorMax;
     if (info) *info = t->info;
     if (out && !t->info.is_intra) {
         const uint64_t need = (uint64_t)t->info.n_sb * 85 * sizeof(svt_me_pu_result);
         if (out_bytes < need) return EB_ErrorBadParameter;
         if (svt_hip_mem_download(s->ctx, out, t->d_results, (size_t)need) != SVT_HIP_OK) return EB_ErrorMax;
     }
+    return EB_ErrorNone;
+}
+
+EbErrorType svt_vp9_shim_get_sb_stats(EbComponentType *h, uint64_t picture_number, void *stats, uint64_t stats_bytes, uint32_t *histograms,
+                                      uint8_t *mean, uint16_t *variance) {
+    shim_state *s = state_of(h);
+    if (!s || !s->initialised) return EB_ErrorBadParameter;
+    shim_slot *t = slot_of(s, (int64_t)picture_number);
+    if (t->number != (int64_t)picture_number || !t->processed) return EB_NoErrorEmptyQueue;
+    if (svt_hip_ctx_marker_wait(s->ctx, t->marker) != SVT_HIP_OK) return EB_ErrorMax;
+    const size_t n_sb = t->info.n_sb;
+    if (stats && !t->info.is_intra) {
+        if (stats_bytes < n_sb * sizeof(svt_me_sb_stats)) return EB_ErrorBadParameter;
+        if (svt_hip_mem_download(s->ctx, stats, t->d_stats, n_sb * sizeof(svt_me_sb_stats)) != SVT_HIP_OK) return EB_ErrorMax;
+    }
+    if (histograms && !t->info.is_intra && svt_hip_mem_download(s->ctx, histograms, t->d_hist, (2 * SVT_SAD_INTERVALS + 1) * sizeof(uint32_t)) != SVT_HIP_OK) return EB_ErrorMax;
+    if (mean && svt_hip_mem_download(s->ctx, mean, t->d_mean, n_sb * 85) != SVT_HIP_OK) return EB_ErrorMax;
+    if (variance && svt_hip_mem_download(s->ctx, variance, t->d_var, n_sb * 85 * sizeof(uint16_t)) != SVT_HIP_OK) return EB_ErrorMax;
+    return EB_ErrorNone;
+}
+
+EbErrorType svt_vp9_shim_get_counters(EbComponentType *h, uint64_t *me_launches, uint64_t *pictures_sent) {
+    shim_state *s = state_of(h);
+    if (!s) return EB_ErrorBadParameter;
+    if (me_launches) *me_launches = s->me_launches;
+    if (pictures_sent) *pictures_sent = (uint64_t)s->next_number;
     return EB_ErrorNone;
 }

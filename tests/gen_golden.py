@@ -164,7 +164,12 @@ def gen_avg_ssd():
     np.savez_compressed(os.path.join(G, "avg_ssd_reference.npz"), **{str(seed): T.ref_avg_ssd_jobs(T.make_avg_ssd_jobs(seed)) for seed in (1, 2)})
 
 
-SECTIONS = ("scan", "me", "tq", "lf", "lf_masks", "mc", "rate", "quant", "ivf", "lf_params", "me_presets", "sad_loop", "sb_stats", "api", "refpad", "avg_ssd")
+def gen_pd_split():
+    # ---- mini-GOP window split: the reference's picture-decision functions for pre-assignment buffers of 2..16 pictures ----
+    np.savez_compressed(os.path.join(G, "pd_split_reference.npz"), split=T.ref_minigop_split())
+
+
+SECTIONS = ("scan", "me", "tq", "lf", "lf_masks", "mc", "rate", "quant", "ivf", "lf_params", "me_presets", "sad_loop", "sb_stats", "api", "refpad", "avg_ssd", "pd_split")
 
 
 def main():

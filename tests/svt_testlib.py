@@ -1464,3 +1464,28 @@ def ref_avg_ssd_jobs(jobs):
                     f.write(np.ascontiguousarray(a).tobytes())
         subprocess.check_call([os.path.join(REF_DIR, "ref_me_sb"), rq, rs])
         return np.fromfile(rs, np.uint32)
+
+
+# ---------------------------------------------------------------------------------------------------
+# mini-GOP window split of the picture-decision kernel (Codec/EbPictureDecisionProcess.c:367-476, 1662-1680)
+# ---------------------------------------------------------------------------------------------------
+class MinigopPart(C.Structure):
+    _fields_ = [("start", C.c_int32), ("length", C.c_int32), ("hierarchical_levels", C.c_int32), ("random_access", C.c_int32)]
+
+
+def ref_minigop_split():
+    """the reference's own split of pre-assignment buffers of 2..16 pictures: rows (n, start, length, levels), padded with -1"""
+    out = subprocess.check_output([os.path.join(REF_DIR, "ref_pd_split")]).decode()
+    rows = np.full((15, 1 + 3 * 4), -1, np.int32)
+    for k, line in enumerate(out.strip().splitlines()):
+        v = [int(x) for x in line.split()]
+        rows[k, 0] = v[0]
+        rows[k, 1:1 + 3 * v[1]] = v[2:]
+    return rows
+
+
+def product_minigop_split(n, levels=4, cut_by_intra=0):
+    parts = (MinigopPart * 4)()
+    k = B.load().svt_hip_minigop_split(n, levels, cut_by_intra, parts)
+    assert k >= 1
+    return [(p.start, p.length, p.hierarchical_levels, p.random_access) for p in parts[:k]]

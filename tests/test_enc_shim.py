@@ -110,7 +110,7 @@ def test_exported_symbols_are_the_reference_surface():
     want = {"eb_vp9_svt_init_handle", "eb_vp9_svt_enc_set_parameter", "eb_vp9_init_encoder", "eb_vp9_svt_enc_stream_header", "eb_vp9_svt_enc_eos_nal",
             "eb_vp9_svt_enc_send_picture", "eb_vp9_svt_get_packet", "eb_vp9_svt_release_out_buffer", "eb_vp9_svt_get_recon", "eb_vp9_deinit_encoder",
             "eb_vp9_deinit_handle"}
-    assert want <= syms and syms - want == {"svt_vp9_shim_get_me_results"}
+    assert want <= syms and syms - want == {"svt_vp9_shim_get_me_results", "svt_vp9_shim_get_sb_stats", "svt_vp9_shim_get_counters"}
     assert "libSvtVp9Enc.so.1" in subprocess.check_output(["readelf", "-d", SHIM]).decode()
 
 
@@ -200,4 +200,94 @@ def test_c_caller_runs_a_clip_and_me_results_equal_oracle():
         info = PicInfo()
         assert lib.svt_vp9_shim_get_me_results(h, C.c_uint64(0), C.byref(info), None, C.c_uint64(0)) != 0   # picture 0 has left the buffer
         assert checked >= 8
+        launches, sent = C.c_uint64(), C.c_uint64()
+        assert lib.svt_vp9_shim_get_counters(h, C.byref(launches), C.byref(sent)) == 0
+        assert sent.value == N and launches.value == 3       # ONE batched ME launch per mini-GOP (two full ones + the tail)
         assert lib.eb_vp9_deinit_encoder(h) == 0 and lib.eb_vp9_deinit_handle(h) == 0
+
+
+def _send(lib, h, frames, n, last, W, H, In, Hdr):
+    y = np.ascontiguousarray(frames[n]); u = np.ascontiguousarray(y[::2, ::2]); v = u.copy()
+    i = In(y.ctypes.data, u.ctypes.data, v.ctypes.data, None, None, None, W, W // 2, W // 2)
+    b = Hdr(size=C.sizeof(Hdr), p_buffer=C.addressof(i), pts=n, flags=1 if last else 0)
+    rc = lib.eb_vp9_svt_enc_send_picture(h, C.byref(b))
+    y[:] = 0xEE          # the library has copied the picture (pinned staging): the caller's buffer is its own again
+    return rc
+
+
+@pytest.mark.gpu
+def test_short_group_split_batched_launches_stats_and_polling():
+    """28 pictures: intra, one full mini-GOP, then 11 pictures cut short by the end of the stream -> the reference's split: an
+    8-picture random-access hierarchy with 3 levels + 3 low-delay pictures (svt_hip_minigop_split); everything the library
+    enqueued per group went out in one batched ME launch; the per-SB statistics behind the ABI equal the oracle's on the same ME
+    results / picture-analysis variances; get_packet never blocks before pic_send_done and delivers everything after it."""
+    W, H, N = 256, 192, 28
+    frames = T.gen_clip_subpel(W, H, N, 43)
+    pics = [T.PaPic(f) for f in frames]
+    lib = shim()
+    for f_ in ("svt_vp9_shim_get_me_results", "svt_vp9_shim_get_sb_stats", "svt_vp9_shim_get_counters", "eb_vp9_svt_get_packet", "eb_vp9_svt_enc_send_picture"):
+        getattr(lib, f_).restype = C.c_int32
+    cfg, h = Cfg(), C.c_void_p()
+    assert lib.eb_vp9_svt_init_handle(C.byref(h), None, C.byref(cfg)) == 0
+    cfg.source_width, cfg.source_height, cfg.enc_mode, cfg.tune, cfg.intra_period, cfg.rate_control_mode = W, H, 9, 1, -1, 0
+    cfg.frame_rate, cfg.frame_rate_numerator, cfg.frame_rate_denominator = 0, 60000, 1000     # frame rate from numerator / denominator only
+    assert lib.eb_vp9_svt_enc_set_parameter(h, C.byref(cfg)) == 0 and lib.eb_vp9_init_encoder(h) == 0
+
+    class In(C.Structure):
+        _fields_ = [(n, C.c_void_p) for n in ("luma", "cb", "cr", "luma_ext", "cb_ext", "cr_ext")] + [(n, C.c_uint32) for n in ("y_stride", "cr_stride", "cb_stride")]
+
+    class Hdr(C.Structure):
+        _fields_ = [("size", C.c_uint32), ("p_buffer", C.c_void_p), ("n_filled_len", C.c_uint32), ("n_alloc_len", C.c_uint32), ("p_app_private", C.c_void_p),
+                    ("wrapper_ptr", C.c_void_p), ("n_tick_count", C.c_uint32), ("dts", C.c_int64), ("pts", C.c_int64), ("qp", C.c_uint32), ("pic_type", C.c_uint32),
+                    ("flags", C.c_uint32)]
+    lib.eb_vp9_svt_release_out_buffer.restype = None
+    got = []
+
+    def drain(done):
+        while True:
+            pp = C.POINTER(Hdr)()
+            rc = lib.eb_vp9_svt_get_packet(h, C.byref(pp), C.c_uint8(done))
+            if rc != 0:
+                assert (rc & 0xffffffff) == 0x80002033, hex(rc)       # EB_NoErrorEmptyQueue
+                return
+            got.append((int(pp.contents.pts), int(pp.contents.pic_type), int(pp.contents.flags)))
+            lib.eb_vp9_svt_release_out_buffer(C.byref(pp))
+    nsb = T.n_sb(W, H)
+    for n in range(N):
+        assert _send(lib, h, [f.copy() for f in frames], n, n == N - 1, W, H, In, Hdr) == 0
+        drain(0)                                   # polling while pictures are still being sent: may be empty, never blocks
+        if n in (5, 20):                           # a picture that waits in an incomplete mini-GOP has no results yet
+            assert lib.svt_vp9_shim_get_me_results(h, C.c_uint64(n), None, None, C.c_uint64(0)) != 0
+    drain(1)
+    assert len(got) == N and got[-1][2] & 1 and all(g[2] == 0 for g in got[:-1])
+    assert sorted(g[0] for g in got) == list(range(N))
+    # structure of the tail 17..27: part 0 = pictures 17..24 (base 24 from 16, 3 levels), part 1 = 25..27 (P chain)
+    want = {24: (0, 2, 16, 16), 20: (1, 2, 16, 24), 18: (2, 2, 16, 20), 22: (2, 2, 20, 24), 17: (3, 2, 16, 18), 19: (3, 2, 18, 20), 21: (3, 2, 20, 22),
+            23: (3, 2, 22, 24), 25: (0, 1, 24, -1), 26: (0, 1, 25, -1), 27: (0, 1, 26, -1)}
+    for k, (layer, nl, r0, r1) in want.items():
+        info, res = PicInfo(), np.zeros((nsb, 85), dtype=B.ME_RESULT_DTYPE)
+        assert lib.svt_vp9_shim_get_me_results(h, C.c_uint64(k), C.byref(info), res.ctypes.data_as(C.c_void_p), C.c_uint64(res.nbytes)) == 0
+        assert (info.temporal_layer_index, info.num_ref_lists, info.ref_picture_number[0], info.ref_picture_number[1], info.hierarchical_levels) == (layer, nl, r0, r1, 3), k
+        p = B.me_params_derive(pic_width=W, pic_height=H, enc_mode=9, tune=1, frame_rate=60, num_ref_lists=nl, temporal_layer_index=layer, hierarchical_levels=3,
+                               is_used_as_reference=int(nl == 1 or layer < 3), same_ref_poc=int(nl == 2 and r0 == r1))
+        o, _ = T.oracle_me_picture(pics[k], pics[r0], pics[r1] if nl == 2 else None, p)
+        assert not T.me_results_equal(o, res, nl), k
+        if k in (24, 19, 26):      # the per-SB statistics and the picture-analysis block statistics of the same picture
+            stats, hist = np.zeros(nsb, dtype=B.ME_SB_STATS_DTYPE), np.zeros(257, np.uint32)
+            mean, var = np.zeros((nsb, 85), np.uint8), np.zeros((nsb, 85), np.uint16)
+            vp = lambda a: a.ctypes.data_as(C.c_void_p)
+            assert lib.svt_vp9_shim_get_sb_stats(h, C.c_uint64(k), vp(stats), C.c_uint64(stats.nbytes), vp(hist), vp(mean), vp(var)) == 0
+            om, ov = np.zeros((nsb, 85), np.uint8), np.zeros((nsb, 85), np.uint16)
+            d = pics[k].desc()
+            assert T.oracle().svt_oracle_pa_mean_variance(C.byref(d.full), vp(om), vp(ov)) == 0
+            assert np.array_equal(om, mean) and np.array_equal(ov, var)
+            case = dict(p=B.MeSbStatsParams(W, H, lib_res(W, H), layer, 0 if nl == 2 else 1, 0, 0), res=res, var=var, rcme=np.zeros(nsb, np.uint32), n=nsb)
+            so, ho, fo = T.oracle_me_sb_stats(case)
+            assert np.array_equal(so, stats) and np.array_equal(ho, hist[:256]) and fo == int(hist[256])
+    launches = C.c_uint64()
+    assert lib.svt_vp9_shim_get_counters(h, C.byref(launches), None) == 0 and launches.value == 2     # the full mini-GOP, the whole tail
+    assert lib.eb_vp9_deinit_encoder(h) == 0 and lib.eb_vp9_deinit_handle(h) == 0
+
+
+def lib_res(w, h):
+    return B.load().svt_hip_input_resolution(w, h)
