@@ -34,7 +34,7 @@ struct lf_pic_dev {
 
 __device__ unsigned long long g_lf_prof[8]; /* SVT_HIP_LF_PROFILE: cycles per stage, thread 0 of every workgroup */
 
-constexpr int LF_DESC_WORDS = 160;
+constexpr int LF_DESC_WORDS = 320; /* two words per block: leading edge, inner edge (lf_entry2) */
 constexpr int YS = 76, YROWS = 72;   /* luma tile stride / rows (8 halo + 64) */
 constexpr int CS = 44, CROWS = 40;   /* chroma tile stride / rows (8 halo + 32) */
 
@@ -53,18 +53,21 @@ __device__ __forceinline__ int uclamp(int t) { return t < 0 ? 0 : t > 255 ? 255 
 __device__ __forceinline__ int lf_ad(int a, int b) { return (int)__builtin_amdgcn_sad_u8((unsigned)a, (unsigned)b, 0u); } /* |a - b|, 0..255 */
 __device__ __forceinline__ int lf_max3(int a, int b, int c) { return max(max(a, b), c); }
 
+template <int MAXK>   /* the widest filter a caller can ask for: an inner edge only ever takes the 4-wide one */
 __device__ __forceinline__ void filter_regs(int (&p)[8], int (&q)[8], int kind, uint32_t th) {
     const int mblim = (int)(th & 0xff), lim = (int)((th >> 8) & 0xff), hev_thr = (int)((th >> 16) & 0xff);
     const int p3 = p[3], p2 = p[2], p1 = p[1], p0 = p[0], q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     const int d10 = lf_ad(p1, p0), e10 = lf_ad(q1, q0);
     const bool mask = kind != 0 && max(lf_max3(lf_ad(p3, p2), lf_ad(p2, p1), d10), lf_max3(e10, lf_ad(q2, q1), lf_ad(q3, q2))) <= lim &&
                       lf_ad(p0, q0) * 2 + (lf_ad(p1, q1) >> 1) <= mblim;
-    const bool flat = kind >= 8 && lf_max3(max(d10, e10), max(lf_ad(p2, p0), lf_ad(q2, q0)), max(lf_ad(p3, p0), lf_ad(q3, q0))) <= 1;
-    const bool use_flat = flat && mask;
-    bool       use16 = false;
-    if (__builtin_amdgcn_ballot_w64(kind == 16)) {
-        const int f2 = max(lf_max3(lf_ad(p[4], p0), lf_ad(p[5], p0), lf_ad(p[6], p0)), lf_max3(lf_ad(p[7], p0), lf_ad(q[4], q0), lf_ad(q[5], q0)));
-        use16 = kind == 16 && use_flat && max(f2, max(lf_ad(q[6], q0), lf_ad(q[7], q0))) <= 1;
+    bool use_flat = false, use16 = false;
+    if (MAXK >= 8 && __builtin_amdgcn_ballot_w64(kind >= 8)) {
+        const bool flat = kind >= 8 && lf_max3(max(d10, e10), max(lf_ad(p2, p0), lf_ad(q2, q0)), max(lf_ad(p3, p0), lf_ad(q3, q0))) <= 1;
+        use_flat = flat && mask;
+        if (__builtin_amdgcn_ballot_w64(kind == 16)) {
+            const int f2 = max(lf_max3(lf_ad(p[4], p0), lf_ad(p[5], p0), lf_ad(p[6], p0)), lf_max3(lf_ad(p[7], p0), lf_ad(q[4], q0), lf_ad(q[5], q0)));
+            use16 = kind == 16 && use_flat && max(f2, max(lf_ad(q[6], q0), lf_ad(q[7], q0))) <= 1;
+        }
     }
     /* filter4: signed 8-bit arithmetic; with mask = 0 every step yields 0 and the samples come out unchanged */
     const int m = mask ? -1 : 0;
@@ -78,7 +81,7 @@ __device__ __forceinline__ void filter_regs(int (&p)[8], int (&q)[8], int kind, 
     f = ((f1 + 1) >> 1) & ~hev;
     int o_q1 = uclamp(q1 - f), o_p1 = uclamp(p1 + f);
     int o_p2 = p2, o_q2 = q2;
-    if (__builtin_amdgcn_ballot_w64(use_flat && !use16)) { /* filter8 for the lanes that take it */
+    if (MAXK >= 8 && __builtin_amdgcn_ballot_w64(use_flat && !use16)) { /* filter8 for the lanes that take it */
         int s = 3 * p3 + 2 * p2 + p1 + p0 + q0 + 4, r;
         r = s >> 3; o_p2 = (use_flat && !use16) ? r : o_p2;
         s += p1 + q1 - p3 - p2; r = s >> 3; o_p1 = (use_flat && !use16) ? r : o_p1;
@@ -87,7 +90,7 @@ __device__ __forceinline__ void filter_regs(int (&p)[8], int (&q)[8], int kind, 
         s += q1 + q3 - p2 - q0; r = s >> 3; o_q1 = (use_flat && !use16) ? r : o_q1;
         s += q2 + q3 - p1 - q1; r = s >> 3; o_q2 = (use_flat && !use16) ? r : o_q2;
     }
-    if (__builtin_amdgcn_ballot_w64(use16)) { /* filter16 for the lanes that take it */
+    if (MAXK >= 16 && __builtin_amdgcn_ballot_w64(use16)) { /* filter16 for the lanes that take it */
         const int p7 = p[7], p6 = p[6], p5 = p[5], p4 = p[4], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];
         int       s = 7 * p7 + 2 * p6 + p5 + p4 + p3 + p2 + p1 + p0 + q0 + 8, r;
         r = s >> 4; p[6] = use16 ? r : p6;
@@ -108,23 +111,32 @@ __device__ __forceinline__ void filter_regs(int (&p)[8], int (&q)[8], int kind, 
     p[2] = o_p2; p[1] = o_p1; p[0] = o_p0; q[0] = o_q0; q[1] = o_q1; q[2] = o_q2;
 }
 
-/* Edge descriptor of one 8x8 block along the filtering direction: which filters run on its leading edge and on
- * its inner 4-sample edge, with the levels they use (built once per SB from the masks). */
+/* Edge descriptor of one 8x8 block along the filtering direction: which filters run on its leading edge and on its inner
+ * 4-sample edge, with the levels they use (built once per SB from the masks by svt_lf_desc_kernel).  The descriptor kernel turns
+ * an entry into the two words the filter waves read: word 0 = thresholds of the leading edge (mblim | lim << 8 | hev_thr << 16) with
+ * its width flags in the top byte, word 1 = thresholds of the inner edge with LF_KI in the top byte -- the filter loop then has no
+ * dependent table look-up between reading a block's descriptor and filtering it. */
 enum { LF_K16 = 1, LF_K8 = 2, LF_K4 = 4, LF_KI = 8 };
 __device__ __forceinline__ uint32_t lf_entry(int flags, int lvl16, int lvl84, int lvli) {
     return (uint32_t)flags | ((uint32_t)lvl16 << 8) | ((uint32_t)lvl84 << 14) | ((uint32_t)lvli << 20);
 }
-
-/* all filters of one block: leading edge between p and q, then the inner edge inside q (q[3..0] | q[4..7]) */
-__device__ __forceinline__ void lf_block_edges(int (&p)[8], int (&q)[8], uint32_t e, const uint32_t *thr) {
-    /* a position carries at most one width (eb_vp9_build_mask puts an edge into exactly one of the 16/8/4 masks) */
-    const int kind = (e & LF_K16) ? 16 : (e & LF_K8) ? 8 : (e & LF_K4) ? 4 : 0;
-    if (__builtin_amdgcn_ballot_w64(kind != 0)) filter_regs(p, q, kind, thr[((e & LF_K16) ? e >> 8 : e >> 14) & 63]);
+__device__ __forceinline__ void lf_entry2(uint32_t e, const uint32_t *thr, uint32_t &w0, uint32_t &w1) {
+    w0 = thr[((e & LF_K16) ? e >> 8 : e >> 14) & 63] | ((e & (LF_K16 | LF_K8 | LF_K4)) << 24);
+    w1 = thr[(e >> 20) & 63] | ((e & LF_KI) << 24);
 }
-__device__ __forceinline__ void lf_inner_edge(int (&q)[8], uint32_t e, const uint32_t *thr) {
-    if (__builtin_amdgcn_ballot_w64((e & LF_KI) != 0)) {
+
+/* the filter of a block's leading edge between p and q ... */
+__device__ __forceinline__ void lf_block_edges(int (&p)[8], int (&q)[8], uint32_t w0) {
+    /* a position carries at most one width (eb_vp9_build_mask puts an edge into exactly one of the 16/8/4 masks) */
+    const uint32_t fl = w0 >> 24;
+    const int      kind = (fl & LF_K16) ? 16 : (fl & LF_K8) ? 8 : (fl & LF_K4) ? 4 : 0;
+    if (__builtin_amdgcn_ballot_w64(kind != 0)) filter_regs<16>(p, q, kind, w0);
+}
+/* ... and of the inner edge inside q (q[3..0] | q[4..7]): only ever the 4-wide filter */
+__device__ __forceinline__ void lf_inner_edge(int (&q)[8], uint32_t w1) {
+    if (__builtin_amdgcn_ballot_w64((w1 >> 24) != 0)) {
         int ip[8] = {q[3], q[2], q[1], q[0], 0, 0, 0, 0}, iq[8] = {q[4], q[5], q[6], q[7], 0, 0, 0, 0};
-        filter_regs(ip, iq, (e & LF_KI) ? 4 : 0, thr[(e >> 20) & 63]);
+        filter_regs<4>(ip, iq, (w1 >> 24) ? 4 : 0, w1);
         q[3] = ip[0]; q[2] = ip[1]; q[4] = iq[0]; q[5] = iq[1];
     }
 }
@@ -235,19 +247,44 @@ __device__ __forceinline__ void col_store8(uint8_t *s, int st, const int (&v)[8]
     _Pragma("unroll") for (int i = 0; i < 8; i++) s[i * st] = (uint8_t)v[reversed ? 7 - i : i];
 }
 
+/* raw fetch of a block's 8 samples (two dwords along a row, 8 bytes down a column) and its unpacking: split so that the fetch
+ * of block c + 1 can be issued before block c is filtered (LDS round trips are ~100 cycles and this wave has nothing else to
+ * hide them with) */
+struct lf_raw { uint32_t w[8]; };
+template <bool ROW> __device__ __forceinline__ void lf_fetch(const uint8_t *s, int st, lf_raw &r) {
+    if (ROW) { const uint32_t *w = (const uint32_t *)s; r.w[0] = w[0]; r.w[1] = w[1]; }
+    else { _Pragma("unroll") for (int i = 0; i < 8; i++) r.w[i] = s[i * st]; }
+}
+template <bool ROW> __device__ __forceinline__ void lf_unpack(const lf_raw &r, int (&v)[8]) {
+    if (ROW) {
+        const uint32_t a = r.w[0], b = r.w[1];
+        v[0] = (int)(a & 0xff); v[1] = (int)((a >> 8) & 0xff); v[2] = (int)((a >> 16) & 0xff); v[3] = (int)(a >> 24);
+        v[4] = (int)(b & 0xff); v[5] = (int)((b >> 8) & 0xff); v[6] = (int)((b >> 16) & 0xff); v[7] = (int)(b >> 24);
+    } else { _Pragma("unroll") for (int i = 0; i < 8; i++) v[i] = (int)r.w[i]; }
+}
+
 /* One line of samples (a tile row for the vertical edges, a tile column for the horizontal ones) through its nblk
  * blocks: p slides along in registers, every sample is read and written once.  s = first sample of block 0 (the 8
- * samples before it are the neighbour's), tab[c * tstep] = descriptor of this line's block c. */
+ * samples before it are the neighbour's), tab[2 * c * tstep], tab[2 * c * tstep + 1] = descriptor words of this line's block c.
+ * Samples and descriptor of block c + 1 are fetched while block c is filtered: nothing block c's filters write lies in block
+ * c + 1 (the widest filter changes q0..q6 of its own block). */
 template <bool ROW>
-__device__ __forceinline__ void lf_line(uint8_t *s, int st, int nblk, const uint32_t *tab, int tstep, const uint32_t *thr) {
-    int p[8], q[8];
+__device__ __forceinline__ void lf_line(uint8_t *s, int st, int nblk, const uint32_t *tab, int tstep) {
+    int    p[8], q[8];
+    lf_raw nxt;
     if (ROW) row_load8(s - 8, p, true); else col_load8(s - 8 * st, st, p, true);
+    uint32_t w0 = tab[0], w1 = tab[1];
+    lf_fetch<ROW>(s, st, nxt);
     for (int c = 0; c < nblk; c++) {
-        const uint32_t e = tab[c * tstep];
-        if (ROW) row_load8(s + 8 * c, q, false); else col_load8(s + 8 * c * st, st, q, false);
-        lf_block_edges(p, q, e, thr);
+        lf_unpack<ROW>(nxt, q);
+        const uint32_t e0 = w0, e1 = w1;
+        if (c + 1 < nblk) { /* wave-uniform */
+            w0 = tab[2 * (c + 1) * tstep]; w1 = tab[2 * (c + 1) * tstep + 1];
+            lf_fetch<ROW>(ROW ? s + 8 * (c + 1) : s + 8 * (c + 1) * st, st, nxt);
+        }
+        lf_block_edges(p, q, e0);
         if (ROW) row_store8(s + 8 * c - 8, p, true); else col_store8(s + (8 * c - 8) * st, st, p, true);
-        lf_inner_edge(q, e, thr);
+        lf_inner_edge(q, e1);
         _Pragma("unroll") for (int i = 0; i < 8; i++) p[i] = q[7 - i];
     }
     if (ROW) row_store8(s + 8 * nblk - 8, p, true); else col_store8(s + (8 * nblk - 8) * st, st, p, true);
@@ -330,7 +367,10 @@ __device__ __forceinline__ lf_geom lf_geometry(int sb_row, int sc, int W, int H)
 }
 
 /* Edge descriptors of every SB of every picture: no dependencies, one 128-thread workgroup per SB */
-__global__ __launch_bounds__(128) void svt_lf_desc_kernel(const lf_pic_dev *__restrict__ pics, int rows_per_pic, int max_cols) {
+__global__ __launch_bounds__(128) void svt_lf_desc_kernel(const lf_pic_dev *__restrict__ pics, int rows_per_pic, int max_cols, svt_lf_thresh thr) {
+    __shared__ uint32_t s_thr[64]; /* mblim | lim << 8 | hev_thr << 16 per filter level */
+    if (threadIdx.x < 64) s_thr[threadIdx.x] = (uint32_t)thr.mblim[threadIdx.x] | ((uint32_t)thr.lim[threadIdx.x] << 8) | ((uint32_t)thr.hev_thr[threadIdx.x] << 16);
+    __syncthreads();
     const int pic = blockIdx.x / (rows_per_pic * max_cols), rem = blockIdx.x - pic * rows_per_pic * max_cols;
     const int sb_row = rem / max_cols, sc = rem - sb_row * max_cols;
     const lf_pic_dev P = pics[pic];
@@ -348,24 +388,31 @@ __global__ __launch_bounds__(128) void svt_lf_desc_kernel(const lf_pic_dev *__re
     adjust_mask(m, mi_row, sc * 8, P.mi_rows, P.mi_cols);
     if (tid < 64) {
         const int rr = tid >> 3, c = tid & 7, pair = rr >> 1, half = rr & 1;
-        d[tid] = vert_entry(c, 8, (unsigned)(m.left_y[2] >> (16 * pair)) & 0xffff, (unsigned)(m.left_y[1] >> (16 * pair)) & 0xffff,
+        uint32_t w0, w1;
+        lf_entry2(vert_entry(c, 8, (unsigned)(m.left_y[2] >> (16 * pair)) & 0xffff, (unsigned)(m.left_y[1] >> (16 * pair)) & 0xffff,
                             (unsigned)(m.left_y[0] >> (16 * pair)) & 0xffff, (unsigned)(m.int_4x4_y >> (16 * pair)) & 0xffff, half,
-                            lfl[(2 * pair) * 8 + c], lfl[(2 * pair + 1) * 8 + c]);
+                            lfl[(2 * pair) * 8 + c], lfl[(2 * pair + 1) * 8 + c]), s_thr, w0, w1);
+        d[2 * tid] = w0; d[2 * tid + 1] = w1;
         const int r = rr;
         unsigned  a16 = 0, a8 = 0, a4 = 0;
         if (mi_row + r != 0) { a16 = (unsigned)(m.above_y[2] >> (8 * r)) & 0xff; a8 = (unsigned)(m.above_y[1] >> (8 * r)) & 0xff; a4 = (unsigned)(m.above_y[0] >> (8 * r)) & 0xff; }
-        d[64 + tid] = horiz_entry(c, a16, a8, a4, (unsigned)(m.int_4x4_y >> (8 * r)) & 0xff, &lfl[r * 8], 1);
+        lf_entry2(horiz_entry(c, a16, a8, a4, (unsigned)(m.int_4x4_y >> (8 * r)) & 0xff, &lfl[r * 8], 1), s_thr, w0, w1);
+        d[128 + 2 * tid] = w0; d[129 + 2 * tid] = w1;
     } else if (tid < 80) {
         const int t = tid - 64, rr = t >> 2, c = t & 3, pair = rr >> 1, half = rr & 1;
-        d[128 + t] = vert_entry(c, 4, (unsigned)(m.left_uv[2] >> (8 * pair)) & 0xff, (unsigned)(m.left_uv[1] >> (8 * pair)) & 0xff,
+        uint32_t w0, w1;
+        lf_entry2(vert_entry(c, 4, (unsigned)(m.left_uv[2] >> (8 * pair)) & 0xff, (unsigned)(m.left_uv[1] >> (8 * pair)) & 0xff,
                                 (unsigned)(m.left_uv[0] >> (8 * pair)) & 0xff, (unsigned)(m.int_4x4_uv >> (8 * pair)) & 0xff, half,
-                                lfl[(4 * pair) * 8 + 2 * c], lfl[(4 * pair + 2) * 8 + 2 * c]);
+                                lfl[(4 * pair) * 8 + 2 * c], lfl[(4 * pair + 2) * 8 + 2 * c]), s_thr, w0, w1);
+        d[256 + 2 * t] = w0; d[257 + 2 * t] = w1;
     } else if (tid < 96) {
         const int t = tid - 80, ru = t >> 2, c = t & 3, r = 2 * ru;
         unsigned  a16 = 0, a8 = 0, a4 = 0;
         if (mi_row + r != 0) { a16 = (unsigned)(m.above_uv[2] >> (4 * ru)) & 0xf; a8 = (unsigned)(m.above_uv[1] >> (4 * ru)) & 0xf; a4 = (unsigned)(m.above_uv[0] >> (4 * ru)) & 0xf; }
         const unsigned mi4 = (mi_row + r == P.mi_rows - 1) ? 0u : ((unsigned)(m.int_4x4_uv >> (4 * ru)) & 0xf);
-        d[144 + t] = horiz_entry(c, a16, a8, a4, mi4, &lfl[r * 8], 2);
+        uint32_t w0, w1;
+        lf_entry2(horiz_entry(c, a16, a8, a4, mi4, &lfl[r * 8], 2), s_thr, w0, w1);
+        d[288 + 2 * t] = w0; d[289 + 2 * t] = w1;
     }
 }
 
@@ -377,18 +424,16 @@ __global__ __launch_bounds__(128) void svt_lf_desc_kernel(const lf_pic_dev *__re
  *           descriptors (svt_lf_desc_kernel) into the other buffer;
  *   wave 3  writes the finished columns of the tile filtered in the previous step back and publishes the row's progress.
  * One workgroup barrier per SB; wave 2 lets its loads fly while wave 3 is still reading the buffer they will land in.  Tile rows 0-7 (top halo) and the SB's last 8 rows are seam rows (sc1 accesses). */
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void svt_lf_kernel(const lf_pic_dev *__restrict__ pics, int n_pics, svt_lf_thresh thr,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void svt_lf_kernel(const lf_pic_dev *__restrict__ pics, int n_pics,
                                                      uint32_t *__restrict__ ticket, int rows_per_pic, int prof) {
     __shared__ __align__(16) uint8_t ytile[2][YROWS * YS];
     __shared__ __align__(16) uint8_t ctile[2][2][CROWS * CS];
-    __shared__ uint32_t              s_thr[64];             /* mblim | lim << 8 | hev_thr << 16 per filter level */
-    __shared__ uint32_t              s_desc[2][LF_DESC_WORDS]; /* edge descriptors: luma vertical [band][block] 64, luma horizontal 64,
-                                                                  chroma vertical 16, chroma horizontal 16 */
+    __shared__ uint32_t              s_desc[2][LF_DESC_WORDS]; /* edge descriptors, two words each: luma vertical [band][block] 64, luma
+                                                                  horizontal 64, chroma vertical 16, chroma horizontal 16 */
     __shared__ int                   s_job;
     __shared__ int                   s_stored_;             /* last SB whose tile wave 2 has read back out of LDS */
     __shared__ int                   s_halo_;               /* last SB whose top halo rows (the SB row above's bottom rows) are in LDS */
     const int tid = threadIdx.x;
-    if (tid < 64) s_thr[tid] = (uint32_t)thr.mblim[tid] | ((uint32_t)thr.lim[tid] << 8) | ((uint32_t)thr.hev_thr[tid] << 16);
     /* Persistent workgroups: each takes SB rows by ticket until none is left.  Tickets run over the rows of all pictures
      * interleaved (row 0 of every picture, then row 1, ...): the row a workgroup depends on, (pic, sb_row - 1), always
      * holds an earlier ticket and is therefore being worked on -- no residency assumption, no deadlock -- and only as
@@ -452,9 +497,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         /* edge descriptors of this SB (built by svt_lf_desc_kernel): luma vertical 64, luma horizontal 64, chroma 16 + 16 */
         {
             const uint32_t LF_GLOBAL *d = LF_AS_GLOBAL(const uint32_t, P.desc + ((size_t)sb_row * sb_cols + sc) * LF_DESC_WORDS);
-            s_desc[buf][lane] = d[lane];
-            s_desc[buf][64 + lane] = d[64 + lane];
-            if (lane < 32) s_desc[buf][128 + lane] = d[128 + lane];
+            _Pragma("unroll") for (int k = 0; k < LF_DESC_WORDS / 64; k++) s_desc[buf][k * 64 + lane] = d[k * 64 + lane];
         }
         LF_MARK(2, 128);
     };
@@ -471,10 +514,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         } else if (wave == 0) {
             /* vertical edges: lane = sample row; horizontal edges: lane = sample column (LDS accesses of one wave are
              * ordered, no barrier between the two passes) */
-            if (lane < g.vh) lf_line<true>(ytile[buf] + (8 + lane) * YS + 8, 1, 8, &s_desc[buf][(lane >> 3) * 8], 1, s_thr);
+            if (lane < g.vh) lf_line<true>(ytile[buf] + (8 + lane) * YS + 8, 1, 8, &s_desc[buf][2 * (lane >> 3) * 8], 1);
             LF_MARK(3, 0);
             while (s_halo < sc) __builtin_amdgcn_s_sleep(1); /* the rows above the SB have arrived */
-            if (lane < g.vw) lf_line<false>(ytile[buf] + 8 * YS + 8 + lane, YS, nrows, &s_desc[buf][64 + (lane >> 3)], 8, s_thr);
+            if (lane < g.vw) lf_line<false>(ytile[buf] + 8 * YS + 8 + lane, YS, nrows, &s_desc[buf][128 + 2 * (lane >> 3)], 8);
             LF_MARK(4, 0);
             if (!last) {
                 while (s_stored < sc - 1) __builtin_amdgcn_s_sleep(1); /* the other buffer has been written back */
@@ -486,9 +529,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             }
         } else if (wave == 1 && !P.y_only) {
             const int pl = lane >> 5, l5 = lane & 31;
-            if (l5 < g.cvh) lf_line<true>(ctile[buf][pl] + (8 + l5) * CS + 8, 1, 4, &s_desc[buf][128 + (l5 >> 3) * 4], 1, s_thr);
+            if (l5 < g.cvh) lf_line<true>(ctile[buf][pl] + (8 + l5) * CS + 8, 1, 4, &s_desc[buf][256 + 2 * (l5 >> 3) * 4], 1);
             while (s_halo < sc) __builtin_amdgcn_s_sleep(1);
-            if (l5 < g.cvw) lf_line<false>(ctile[buf][pl] + 8 * CS + 8 + l5, CS, (nrows + 1) >> 1, &s_desc[buf][144 + (l5 >> 3)], 4, s_thr);
+            if (l5 < g.cvw) lf_line<false>(ctile[buf][pl] + 8 * CS + 8 + l5, CS, (nrows + 1) >> 1, &s_desc[buf][288 + 2 * (l5 >> 3)], 4);
             if (!last) {
                 while (s_stored < sc - 1) __builtin_amdgcn_s_sleep(1);
                 for (int r = l5; r < CROWS; r += 32) {
@@ -556,13 +599,17 @@ static int32_t lf_launch(svt_hip_ctx *ctx, int n_pics, const svt_yuv_planes *d_r
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
     static const bool want_prof = getenv("SVT_HIP_LF_PROFILE") != nullptr;
     if (want_prof) { unsigned long long z[8] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lf_prof), z, sizeof z)); }
-    hipLaunchKernelGGL(svt_lf_desc_kernel, dim3(n_pics * max_rows * max_cols), dim3(128), 0, ctx->stream, (const lf_pic_dev *)d, max_rows, max_cols);
+    hipLaunchKernelGGL(svt_lf_desc_kernel, dim3(n_pics * max_rows * max_cols), dim3(128), 0, ctx->stream, (const lf_pic_dev *)d, max_rows, max_cols, *thr);
     /* rows in flight per picture: a row takes sb_cols steps of ~6 us and starts ~23 us after the one above, so about
      * sb_cols * 6 / 23 rows keep the wavefront full (16 for 4K, 8 for 1080p); more would only wait */
     static const int rows_env = getenv("SVT_HIP_LF_ROWS") ? atoi(getenv("SVT_HIP_LF_ROWS")) : 0;
-    const int rows_in_flight = rows_env > 0 ? rows_env : (max_cols * 17 + 63) / 64 < 4 ? 4 : (max_cols * 17 + 63) / 64;
+    /* few pictures in the launch: their latency is what the caller waits for (a temporal-layer wave of one GOP) and the GPU has
+     * room -- every SB row gets its own workgroup (1.09 instead of 1.39 ms for one 4K picture); many pictures: only as many rows
+     * as the wavefront keeps busy, so that the launch does not hold CU slots other stages could use */
+    const int heuristic = (max_cols * 17 + 63) / 64 < 4 ? 4 : (max_cols * 17 + 63) / 64;
+    const int rows_in_flight = rows_env > 0 ? rows_env : n_pics <= 4 ? max_rows : heuristic;
     const int lf_wgs = n_pics * (max_rows < rows_in_flight ? max_rows : rows_in_flight);
-    hipLaunchKernelGGL(svt_lf_kernel, dim3(lf_wgs), dim3(256), 0, ctx->stream, (const lf_pic_dev *)d, n_pics, *thr, cnt, max_rows, want_prof ? 1 : 0);
+    hipLaunchKernelGGL(svt_lf_kernel, dim3(lf_wgs), dim3(256), 0, ctx->stream, (const lf_pic_dev *)d, n_pics, cnt, max_rows, want_prof ? 1 : 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     if (want_prof) {
