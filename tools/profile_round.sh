@@ -2,15 +2,18 @@
 # tools/profile_round.sh TAG -- the rocprofv3 passes behind profiles/ (run on the GPU box, e.g. through gpurun).
 # Pass 1: kernel trace + stats of the default bench command.  Passes 2-5: PMC counters, each in its own run with
 # --kernel-trace only (never combined with other trace domains).  Everything lands under gpurun_out/prof_TAG*.
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG} -o $TAG --output-format csv -- $BENCH --steps 3 --warmup 1 > $OUT/prof_${TAG}_bench.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_${TAG}_fetch -o f --output-format csv -- $BENCH --steps 1 --warmup 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_${TAG}_write -o w --output-format csv -- $BENCH --steps 1 --warmup 0 > /dev/null 2>&1
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-single"
+# the counter passes profile ONE GOP in flight (diagonal schedule): a step is then one 16-picture mini-GOP and a stage's launches of
+# the last step are the last PER_STEP dispatches of its kernel (tools/summarize_prof.py)
+ONE="--gops 1 --groups 1 --schedule diagonal"
+rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG} -o $TAG --output-format csv -- $BENCH --steps 3 --warmup 5 > $OUT/prof_${TAG}_bench.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_${TAG}_fetch -o f --output-format csv -- $BENCH $ONE --steps 1 --warmup 5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_${TAG}_write -o w --output-format csv -- $BENCH $ONE --steps 1 --warmup 5 > /dev/null 2>&1
 # instruction counts of every stage (one step, all stages), and the ME kernel's issue / LDS counters with ME alone on the GPU
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d $OUT/prof_${TAG}_insts -o i --output-format csv -- $BENCH --steps 1 --warmup 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $OUT/prof_${TAG}_sq -o s --output-format csv -- $BENCH --steps 1 --warmup 0 --stages me > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d $OUT/prof_${TAG}_insts -o i --output-format csv -- $BENCH $ONE --steps 1 --warmup 5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $OUT/prof_${TAG}_sq -o s --output-format csv -- $BENCH $ONE --steps 1 --warmup 5 --stages me > /dev/null 2>&1
 tail -1 $OUT/prof_${TAG}_bench.log

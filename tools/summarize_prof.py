@@ -8,11 +8,14 @@ bench.py's untimed first pass launches the same kernels once more (the transform
 stage's figure is the sum over its LAST launches_per_step dispatches."""
 import csv, glob, json, os, re, shutil, sys, collections
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out")
 prof = os.path.join(root, "profiles")
-PER_STEP = {"svt_me_sb_kernel": 5, "svt_tq_kernel": 4, "svt_lf_kernel": 1, "svt_lf_desc_kernel": 1, "svt_pa_plane_kernel": 1, "svt_mc_kernel": 1}
+# launches of one step with ONE GOP in flight, diagonal schedule: ME per temporal layer, the transform stage per temporal layer (= ring
+# slot) and transform size, everything else once over the 16 pictures
+PER_STEP = {"svt_me_sb_kernel": 5, "svt_tq_kernel": 20, "svt_lf_kernel": 1, "svt_lf_desc_kernel": 1, "svt_pa_plane_kernel": 1, "svt_mc_kernel": 1,
+            "svt_refpad_kernel": 1}
 
 
 def short(name):
@@ -20,7 +23,7 @@ def short(name):
         return None     # the set-up pass of bench.py (no rate): not part of a step
     if re.search(r"(?<![A-Za-z_0-9])svt_tq_lane_kernel(?![A-Za-z_0-9])", name):
         return "svt_tq_kernel"  # the 4x4 instance of the TQ stage
-    for k in ("svt_me_sb_kernel", "svt_tq_kernel", "svt_lf_kernel", "svt_lf_desc_kernel", "svt_pa_plane_kernel", "svt_mc_kernel", "svt_rate_kernel"):
+    for k in ("svt_me_sb_kernel", "svt_tq_kernel", "svt_lf_kernel", "svt_lf_desc_kernel", "svt_pa_plane_kernel", "svt_mc_kernel", "svt_rate_kernel", "svt_refpad_kernel"):
         if re.search(r"(?<![A-Za-z_0-9])" + k + r"(?![A-Za-z_0-9])", name):
             return k
     return None
@@ -42,7 +45,7 @@ def pmc(sub, prefix):
 
 
 fetch, write, insts, sq = pmc("fetch", "f"), pmc("write", "w"), pmc("insts", "i"), pmc("sq", "s")
-traffic = {"_comment": "per 16-picture step, from rocprofv3 PMC passes on MI355X (tools/profile_round.sh, tools/summarize_prof.py): "
+traffic = {"_comment": "per 16-picture mini-GOP (one step with one GOP in flight, diagonal schedule), from rocprofv3 PMC passes on MI355X (tools/profile_round.sh, tools/summarize_prof.py): "
                        "bytes = 1024 * (2 x FETCH_SIZE + WRITE_SIZE); instruction counts = SQ_INSTS_* summed over the stage's launches of one step"}
 print("| kernel | launches/step | FETCH_SIZE raw (KiB) | WRITE_SIZE (KiB) | traffic (MB) | VALU / SALU / LDS wave-instructions | waves |")
 print("|---|---|---|---|---|---|---|")
