@@ -69,10 +69,12 @@ template <int N> __device__ __forceinline__ uint32_t tq_lanes_sum(uint32_t v) {
     return v;
 }
 
-/* threads per workgroup.  The fused-rate instances keep their LDS (transpose tiles + cost slices + scan tables) under
- * 32 000 bytes = the LDS one motion-estimation workgroup releases when it retires (25 granules of 1280 bytes): on a CU that
- * the ME kernel has filled, a transform workgroup can then move into the first hole instead of waiting for two. */
-template <int N, bool RATE> constexpr int tq_threads() { return N == 32 ? (RATE ? 64 : 128) : N == 16 ? (RATE ? 128 : 256) : 256; }
+/* threads per workgroup: 256 for every instance.  Round 2 sized the fused-rate instances of the big transforms (64 / 128
+ * threads) so that their LDS stayed under what ONE motion-estimation workgroup releases; with the cost slices (13.8 KB) and scan
+ * tables (6 KB) per workgroup that left 5 (32x32) / 10 (16x16) waves per CU -- the stage was latency-bound by its own occupancy.
+ * In the dependency-true step the transform stage's time on the GPU adds to the step 1:1, so the tables are shared by four
+ * waves instead: 12 / 16 waves per CU, the stage alone 1.57 -> 1.32 ms per mini-GOP, the step 3.27 -> 3.17 ms. */
+template <int N, bool RATE> constexpr int tq_threads() { return 256; }
 
 template <int N> struct txcfg;
 template <> struct txcfg<4> { static constexpr int size = SVT_TX_4X4, shift = 4; };
@@ -140,9 +142,9 @@ template <int N> __device__ __forceinline__ void row_store(uint8_t *p, bool vec,
 __device__ __forceinline__ int clamp16(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
 __device__ __forceinline__ uint8_t clip_add(int d, int t) { int v = d + t; return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
 
-/* 32x32: 33 KB of LDS per workgroup allow four workgroups per CU; the register budget is held to the matching 128 */
+/* 32x32: 54 KB of LDS per 256-thread workgroup (eight blocks + the rate tables) allow three workgroups = 12 waves per CU */
 template <int N, bool RATE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 4 : 1))) void svt_tq_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ pred,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 3 : 1))) void svt_tq_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ pred,
                                                      uint8_t *__restrict__ recon, const svt_tq_block *__restrict__ blocks,
                                                      int n_blocks, const svt_quant_tables *__restrict__ qtabs,
                                                      const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,
