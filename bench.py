@@ -638,6 +638,23 @@ def main():
             lb["rb_host"] = rb
         return lb
 
+    def build_diag_blocks(layers):
+        """the transform blocks of the five temporal layers of a group in ONE batch, grouped by transform size across the layers; a
+        block names its layer's reconstruction buffer (= ring slot) in pad_[0] bits 4-6 (svt_hip_tq_rd_batch_multi_device)"""
+        per_ts = [[] for _ in range(4)]
+        for layer, lb in enumerate(layers):
+            b = lb["blocks_host"].copy()
+            b["pad"][:, 0] |= np.uint8(layer << 4)
+            pos = 0
+            for ts in range(4):
+                per_ts[ts].append(b[pos:pos + lb["counts"][ts]])
+                pos += lb["counts"][ts]
+        blocks = np.concatenate([a for ts in range(4) for a in per_ts[ts]])
+        counts = [sum(len(a) for a in per_ts[ts]) for ts in range(4)]
+        nb = len(blocks)
+        return {"blocks": to_dev(blocks.view(np.uint8)), "counts": counts, "cnt_c": (C.c_int32 * 4)(*counts), "n": nb,
+                "eob": dev_zeros(nb, torch.int16), "dist": dev_zeros(2 * nb, torch.int64), "bits": dev_zeros(nb, torch.int32)}
+
     def build_batch(items):
         """descriptors of one batch of mutually independent pictures: items = (g, i, back) -- picture i of GOP g of the mini-GOP
         `back` mini-GOPs before the newest one of the step; one descriptor set per ring phase"""
@@ -677,6 +694,16 @@ def main():
             B.check(lib.svt_hip_tq_rd_batch_device(ctx_, vp(d_src), vp(d_pred), slot_base(slot), vp(lb["blocks"]), lb["cnt_c"], vp(d_qt), vp(d_iscan), vp(d_q),
                                                    vp(d_dq), vp(lb["eob"]), vp(lb["dist"]), vp(d_rt), vp(d_rs), vp(lb["bits"])))
 
+    multi_tq = os.environ.get("SVT_BENCH_TQ_PER_LAYER", "0") != "1" and not separate_rate
+
+    def run_tq_diag(ctx_, grp, ph):
+        """the transform stage of a diagonal batch: one launch per transform size over all five layers, each layer reconstructing
+        into the reference buffers of its own ring slot"""
+        db = grp["diag_blocks"]
+        rset = (C.c_void_p * 5)(*[d_rec.data_ptr() + ((ph - layer) % RING) * slot_bytes for layer in range(5)])
+        B.check(lib.svt_hip_tq_rd_batch_multi_device(ctx_, vp(d_src), vp(d_pred), rset, 5, vp(db["blocks"]), db["cnt_c"], vp(d_qt), vp(d_iscan), vp(d_q), vp(d_dq),
+                                                     vp(db["eob"]), vp(db["dist"]), vp(d_rt), vp(d_rs), vp(db["bits"])))
+
     def run_rate(ctx_, lb):
         B.check(lib.svt_hip_coeff_rate_batch_device(ctx_, vp(d_q), vp(lb["d_rb"]), len(lb["rb_host"]), vp(d_rt), vp(d_rs), vp(lb["bits"])))
 
@@ -695,7 +722,8 @@ def main():
         P = {"gops": gops, "groups": [], "me_ev": []}
         P["me_sets"], P["me_slot"] = build_me_launches(gops)
         for grp, (st_, ctx_) in zip(groups, pairs):
-            P["groups"].append({"gops": grp, "stream": st_, "ctx": ctx_, "layers": [build_layer_blocks(grp, layer) for layer in range(5)],
+            layers = [build_layer_blocks(grp, layer) for layer in range(5)]
+            P["groups"].append({"gops": grp, "stream": st_, "ctx": ctx_, "layers": layers, "diag_blocks": build_diag_blocks(layers),
                                 "waves": [build_batch([(g, i, 0) for g in grp for i in pics_of_layer(layer)]) for layer in range(5)],
                                 "diag": build_batch([(g, i, LAYER[i - 1]) for g in grp for i in range(1, MINIGOP + 1)])})
         return P
@@ -820,6 +848,8 @@ def main():
                 staged(S, "mc", st_, lambda: run_mc(ctx_, bt, ph), pool)
 
                 def tq_all():
+                    if multi_tq:
+                        return run_tq_diag(ctx_, grp, ph)
                     for layer in range(5):
                         run_tq(ctx_, grp["layers"][layer], ph - layer)
                 staged(S, "tq", st_, tq_all, pool)

@@ -132,7 +132,7 @@ EXPORTS = [
     "svt_hip_ctx_marker_record", "svt_hip_ctx_marker_query", "svt_hip_ctx_marker_wait", "svt_hip_minigop_split",
     "svt_hip_me_picture_device", "svt_hip_me_batch_device", "svt_hip_me_batch_layers_device", "svt_hip_me_picture", "svt_hip_sad_loop_batch_device",
     "svt_hip_me_zz_sad_device", "svt_hip_me_similar_collocated", "svt_hip_me_sb_stats_device", "svt_hip_pa_prepare_batch_device", "svt_hip_pa_mean_variance_device",
-    "svt_hip_quant_tables_init", "svt_hip_tq_batch_device", "svt_hip_tq_batch_dist_device", "svt_hip_tq_rd_batch_device", "svt_hip_rate_scan4x4_table", "svt_hip_tq_batch", "svt_hip_lf_thresh_init", "svt_hip_lf_level_from_q",
+    "svt_hip_quant_tables_init", "svt_hip_tq_batch_device", "svt_hip_tq_batch_dist_device", "svt_hip_tq_rd_batch_device", "svt_hip_tq_rd_batch_multi_device", "svt_hip_rate_scan4x4_table", "svt_hip_tq_batch", "svt_hip_lf_thresh_init", "svt_hip_lf_level_from_q",
     "svt_hip_lf_frame_device", "svt_hip_lf_batch_device", "svt_hip_lf_frame", "svt_hip_lf_build_masks",
     "svt_hip_inter_pred_batch_device", "svt_hip_inter_pred_frame", "svt_hip_ref_pad_batch_device", "svt_hip_coeff_rate_batch_device", "svt_hip_coeff_rate_batch",
     "svt_hip_gop_owner", "svt_hip_gop_assign", "svt_hip_minigop_reference_source", "svt_hip_device_set_create", "svt_hip_device_set_size",

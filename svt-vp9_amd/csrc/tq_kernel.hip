@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 3
                                                      int n_blocks, const svt_quant_tables *__restrict__ qtabs,
                                                      const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,
                                                      int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out,
-                                                     uint64_t *__restrict__ dist_out, tq_rate_args ra) {
+                                                     uint64_t *__restrict__ dist_out, tq_rate_args ra, const uint8_t *const *__restrict__ recon_set) {
     constexpr int NT  = tq_threads<N, RATE>();
     constexpr int BPW = NT / N;           /* blocks per workgroup */
     constexpr int LS  = N + 1;            /* padded LDS row stride in dwords */
@@ -360,7 +360,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 3
     /* residual column i -> LDS -> row i; reconstruction = clip(pred row + residual row), stored as dwords */
     _Pragma("unroll") for (int r = 0; r < N; r++) t[r * LS + i] = res[r];
     if (active) {
-        uint8_t *d = recon + k.recon_off + (size_t)i * k.recon_stride;
+        /* a batch may reconstruct into several buffers (reference pictures of different mini-GOPs): pad_[0] bits 4-6 name the one */
+        uint8_t *d = (recon_set ? (uint8_t *)recon_set[(k.pad_[0] >> 4) & 7] : recon) + k.recon_off + (size_t)i * k.recon_stride;
         uint32_t rw[N / 4];
         _Pragma("unroll") for (int q = 0; q < N / 4; q++) {
             uint32_t w = 0;
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
                                                           int n_blocks, const svt_quant_tables *__restrict__ qtabs,
                                                           const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,
                                                           int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out,
-                                                          uint64_t *__restrict__ dist_out, tq_rate_args ra) {
+                                                          uint64_t *__restrict__ dist_out, tq_rate_args ra, const uint8_t *const *__restrict__ recon_set) {
     static_assert(N == 4 || N == 8, "block-per-lane form: 4x4 and 8x8 only");
     static_assert(!RATE || N == 4, "in-lane rate: 4x4 only");
     constexpr int ND = N / 4; /* dwords per row of samples */
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
         }
     }
     _Pragma("unroll") for (int r = 0; r < N; r++) {
-        uint8_t *d = recon + k.recon_off + (size_t)r * k.recon_stride;
+        uint8_t *d = (recon_set ? (uint8_t *)recon_set[(k.pad_[0] >> 4) & 7] : recon) + k.recon_off + (size_t)r * k.recon_stride;
         if constexpr (N == 4) *(uint32_t *)d = rw[r][0];
         else row_store<N>(d, ((uintptr_t)d & 7) == 0, rw[r]);
     }
@@ -610,19 +611,20 @@ int tq_grid(svt_hip_ctx *ctx, int ngroups, int per_cu) {
 
 template <int N, bool RATE>
 hipError_t launch_tq(svt_hip_ctx *ctx, hipStream_t st, const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks, int n,
-                     const svt_quant_tables *q, const int16_t *iscan, int16_t *qc, int16_t *dqc, uint16_t *eob, uint64_t *dist, tq_rate_args ra) {
+                     const svt_quant_tables *q, const int16_t *iscan, int16_t *qc, int16_t *dqc, uint16_t *eob, uint64_t *dist, tq_rate_args ra,
+                     const uint8_t *const *recon_set) {
     if (n <= 0) return hipSuccess;
     /* block per lane for 4x4 only: the 8x8 instance is bit-exact too but needs 201 VGPRs (64 samples + the transposed
      * intermediate live in one lane; 87 spills when held to 128) -- two waves per SIMD, and each displaces two ME waves:
      * the overlapped step went from 3.27 to 3.77 ms with it, so 8x8 stays on the N-lanes-per-block kernel */
     if constexpr (N == 4) {
         hipLaunchKernelGGL((svt_tq_lane_kernel<N, RATE>), dim3(tq_grid(ctx, (n + 255) / 256, 8)), dim3(256), 0, st, src, pred, recon, blocks, n, q,
-                           iscan, qc, dqc, eob, dist, ra);
+                           iscan, qc, dqc, eob, dist, ra, recon_set);
         return hipGetLastError();
     } else {
         constexpr int NT = tq_threads<N, RATE>(), BPW = NT / N;
         hipLaunchKernelGGL((svt_tq_kernel<N, RATE>), dim3(tq_grid(ctx, (n + BPW - 1) / BPW, 8)), dim3(NT), 0, st, src, pred, recon, blocks, n, q,
-                           iscan, qc, dqc, eob, dist, ra);
+                           iscan, qc, dqc, eob, dist, ra, recon_set);
         return hipGetLastError();
     }
 }
@@ -630,8 +632,17 @@ hipError_t launch_tq(svt_hip_ctx *ctx, hipStream_t st, const uint8_t *src, const
 template <bool RATE>
 int32_t tq_launch_all(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *d_recon, const svt_tq_block *d_blocks,
                       const int32_t size_count[4], const svt_quant_tables *d_qtabs, const int16_t *d_iscan, int16_t *d_qcoeff,
-                      int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist, tq_rate_args ra) {
+                      int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist, tq_rate_args ra, uint8_t *const *recon_set = nullptr, int n_set = 0) {
     HIP_TRY(hipSetDevice(ctx->device));
+    /* several reconstruction buffers: their base pointers go to the device through the descriptor ring */
+    const uint8_t *const *d_set = nullptr;
+    if (recon_set) {
+        void *h = nullptr, *d = nullptr;
+        if (svt_ctx_stage(ctx, 8 * sizeof(void *), &h, &d)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "tq: descriptor buffers");
+        for (int i = 0; i < 8; i++) ((uint8_t **)h)[i] = recon_set[i < n_set ? i : 0];
+        HIP_TRY(hipMemcpyAsync(d, h, 8 * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+        d_set = (const uint8_t *const *)d;
+    }
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
     /* The four size groups are independent of each other; SVT_HIP_TQ_FORK=1 launches each on a stream of its own (forked from
      * and joined into the context's stream).  Measured: slower -- 1.59 instead of 1.39 ms per mini-GOP for the four launches
@@ -647,19 +658,20 @@ int32_t tq_launch_all(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_p
     hipError_t rc = hipSuccess;
     auto at = [&](int o) { tq_rate_args r = ra; if (r.bits) r.bits += o; return r; };
     auto on = [&](int i) { return fork && i > 0 ? ctx->aux[i - 1] : ctx->stream; };
-    rc = launch_tq<4, RATE>(ctx, on(0), d_src, d_pred, d_recon, d_blocks + off, size_count[0], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off));
+    rc = launch_tq<4, RATE>(ctx, on(0), d_src, d_pred, d_recon, d_blocks + off, size_count[0], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off), d_set);
     off += size_count[0];
-    if (rc == hipSuccess) rc = launch_tq<8, RATE>(ctx, on(1), d_src, d_pred, d_recon, d_blocks + off, size_count[1], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off));
+    if (rc == hipSuccess) rc = launch_tq<8, RATE>(ctx, on(1), d_src, d_pred, d_recon, d_blocks + off, size_count[1], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off), d_set);
     off += size_count[1];
-    if (rc == hipSuccess) rc = launch_tq<16, RATE>(ctx, on(2), d_src, d_pred, d_recon, d_blocks + off, size_count[2], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off));
+    if (rc == hipSuccess) rc = launch_tq<16, RATE>(ctx, on(2), d_src, d_pred, d_recon, d_blocks + off, size_count[2], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off), d_set);
     off += size_count[2];
-    if (rc == hipSuccess) rc = launch_tq<32, RATE>(ctx, on(3), d_src, d_pred, d_recon, d_blocks + off, size_count[3], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off));
+    if (rc == hipSuccess) rc = launch_tq<32, RATE>(ctx, on(3), d_src, d_pred, d_recon, d_blocks + off, size_count[3], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob + off, d_dist ? d_dist + 2 * off : nullptr, at(off), d_set);
     if (fork)
         for (int i = 0; i < 3; i++) {
             (void)hipEventRecord(ctx->aux_join[i], ctx->aux[i]);
             (void)hipStreamWaitEvent(ctx->stream, ctx->aux_join[i], 0);
         }
     (void)hipEventRecord(ctx->ev_stop, ctx->stream); /* also on a failed launch: ev_start is already in the stream */
+    if (recon_set) svt_ctx_stage_commit(ctx);
     if (rc != hipSuccess) return svt_set_hip_error(rc, __FILE__, __LINE__);
     ctx->timed = 1;
     return SVT_HIP_OK;
@@ -704,6 +716,26 @@ extern "C" int32_t svt_hip_tq_rd_batch_device(svt_hip_ctx *ctx, const uint8_t *d
     if ((uintptr_t)d_scan & 3) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq_rd: scan array must be 4-byte aligned");
     tq_rate_args ra = {d_tables, d_scan, d_bits};
     return tq_launch_all<true>(ctx, d_src, d_pred, d_recon, d_blocks, size_count, d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob, d_dist, ra);
+}
+
+/* svt_hip_tq_rd_batch_device for a batch whose blocks reconstruct into up to 8 different buffers: block b writes into
+ * recon_set[(pad_[0] >> 4) & 7] + recon_off.  One launch per transform size then serves pictures whose reference buffers lie further
+ * apart than a 32-bit offset reaches, or in separate allocations -- e.g. the pictures of five consecutive mini-GOPs that one step of
+ * a picture-level pipeline codes (bench.py's diagonal schedule). */
+extern "C" int32_t svt_hip_tq_rd_batch_multi_device(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *const *recon_set, int32_t n_set,
+                                                    const svt_tq_block *d_blocks, const int32_t size_count[4], const svt_quant_tables *d_qtabs,
+                                                    const int16_t *d_iscan, int16_t *d_qcoeff, int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist,
+                                                    const svt_rate_tables *d_tables, const int16_t *d_scan, int32_t *d_bits) {
+    if (!ctx || !d_src || !d_pred || !recon_set || n_set < 1 || n_set > 8 || !d_blocks || !size_count || !d_qtabs || !d_iscan || !d_qcoeff || !d_dqcoeff || !d_eob)
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq_multi: bad argument");
+    if (((uintptr_t)d_qcoeff | (uintptr_t)d_dqcoeff) & 15) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq_multi: coefficient arrays must be 16-byte aligned");
+    if (d_bits) {
+        if (!d_tables || !d_scan || ((uintptr_t)d_scan & 3)) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "tq_multi: rate tables / scan array");
+        tq_rate_args ra = {d_tables, d_scan, d_bits};
+        return tq_launch_all<true>(ctx, d_src, d_pred, nullptr, d_blocks, size_count, d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob, d_dist, ra, recon_set, n_set);
+    }
+    tq_rate_args none = {nullptr, nullptr, nullptr};
+    return tq_launch_all<false>(ctx, d_src, d_pred, nullptr, d_blocks, size_count, d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob, d_dist, none, recon_set, n_set);
 }
 
 /* the compiled-in 4x4 scan orders of the in-lane rate pass: out[0..15] = scan, out[16..47] = the neighbour pairs of positions 0..15 */

@@ -121,3 +121,43 @@ def test_tq_rd_mode_decision_candidate_form(ctx):
         assert np.array_equal(x, y), (n, int(np.sum(x != y)))
     # the candidates of a block really differ (different predictions -> different coefficients / costs)
     assert (o[5][0::K] != o[5][1::K]).mean() > 0.5 and (o[4][0::K, 0] != o[4][2::K, 0]).mean() > 0.5
+
+
+def test_tq_rd_multi_reconstruction_buffers(ctx):
+    """svt_hip_tq_rd_batch_multi_device: the blocks of one batch reconstruct into three separate buffers (pad_[0] bits 4-6 name the
+    buffer) -- every output equals the oracle's, and each buffer holds exactly the reconstruction of its own blocks (elsewhere it
+    keeps its fill)."""
+    import torch
+    lib = B.load()
+    dev = torch.device("cuda", 0)
+    case = T.make_tq_case(5, width=256, height=128)
+    rb = T.add_rate_info(case, 3, 0.6)
+    o = T.oracle_tq_rd_batch(case, rb)
+    nb = len(case["blocks"])
+    which = (np.arange(nb) * 7 // 3) % 3
+    blocks = case["blocks"].copy()
+    blocks["pad"][:, 0] |= (which << 4).astype(np.uint8)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
+    src, pred, dblk, qt, isc = up(case["src"]), up(case["pred"]), up(blocks), up(case["qtabs"]), up(case["iscan"])
+    rtab, rscan = T.rate_tables()
+    tab, scan = up(np.ascontiguousarray(rtab).reshape(1)), up(rscan)
+    recs = [torch.full((case["src"].size,), 0x5A, dtype=torch.uint8, device=dev) for _ in range(3)]
+    q, dq = torch.zeros(case["n_coeff"], dtype=torch.int16, device=dev), torch.zeros(case["n_coeff"], dtype=torch.int16, device=dev)
+    eob, dist, bits = torch.zeros(nb, dtype=torch.int16, device=dev), torch.zeros(2 * nb, dtype=torch.int64, device=dev), torch.zeros(nb, dtype=torch.int32, device=dev)
+    cnt = (C.c_int32 * 4)(*[int(v) for v in case["counts"]])
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rset = (C.c_void_p * 3)(*[t.data_ptr() for t in recs])
+    B.check(lib.svt_hip_tq_rd_batch_multi_device(ctx, p(src), p(pred), rset, 3, p(dblk), cnt, p(qt), p(isc), p(q), p(dq), p(eob), p(dist), p(tab), p(scan), p(bits)))
+    B.check(lib.svt_hip_ctx_synchronize(ctx))
+    assert np.array_equal(q.cpu().numpy(), o[1]) and np.array_equal(dq.cpu().numpy(), o[2]) and np.array_equal(eob.cpu().numpy().view(np.uint16), o[3])
+    assert np.array_equal(dist.cpu().numpy().view(np.uint64).reshape(-1, 2), o[4]) and np.array_equal(bits.cpu().numpy(), o[5])
+    W = case["src"].shape[1]
+    own = np.full(case["src"].shape, -1, np.int32)
+    for b, k in zip(case["blocks"], which):
+        n = T.TX_N[int(b["tx_size"])]
+        y, x = divmod(int(b["recon_off"]), W)
+        own[y:y + n, x:x + n] = k
+    for k in range(3):
+        got = recs[k].cpu().numpy().reshape(case["src"].shape)
+        assert np.array_equal(got[own == k], o[0][own == k]) and (got[own != k] == 0x5A).all(), k
+    assert lib.svt_hip_tq_rd_batch_multi_device(ctx, p(src), p(pred), rset, 9, p(dblk), cnt, p(qt), p(isc), p(q), p(dq), p(eob), p(dist), p(tab), p(scan), p(bits)) == -1
