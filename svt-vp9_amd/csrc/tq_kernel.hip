@@ -618,12 +618,12 @@ hipError_t launch_tq(svt_hip_ctx *ctx, hipStream_t st, const uint8_t *src, const
      * intermediate live in one lane; 87 spills when held to 128) -- two waves per SIMD, and each displaces two ME waves:
      * the overlapped step went from 3.27 to 3.77 ms with it, so 8x8 stays on the N-lanes-per-block kernel */
     if constexpr (N == 4) {
-        hipLaunchKernelGGL((svt_tq_lane_kernel<N, RATE>), dim3(tq_grid(ctx, (n + 255) / 256, 8)), dim3(256), 0, st, src, pred, recon, blocks, n, q,
+        hipLaunchKernelGGL((svt_tq_lane_kernel<N, RATE>), dim3(tq_grid(ctx, (n + 255) / 256, 6)), dim3(256), 0, st, src, pred, recon, blocks, n, q,
                            iscan, qc, dqc, eob, dist, ra, recon_set);
         return hipGetLastError();
     } else {
         constexpr int NT = tq_threads<N, RATE>(), BPW = NT / N;
-        hipLaunchKernelGGL((svt_tq_kernel<N, RATE>), dim3(tq_grid(ctx, (n + BPW - 1) / BPW, 8)), dim3(NT), 0, st, src, pred, recon, blocks, n, q,
+        hipLaunchKernelGGL((svt_tq_kernel<N, RATE>), dim3(tq_grid(ctx, (n + BPW - 1) / BPW, 6)), dim3(NT), 0, st, src, pred, recon, blocks, n, q,
                            iscan, qc, dqc, eob, dist, ra, recon_set);
         return hipGetLastError();
     }
