@@ -373,7 +373,7 @@ def main():
     me_streams, me_ctxs = [p_[0] for p_ in me_pairs], [p_[1] for p_ in me_pairs]
     grp_pairs = [new_ctx(prio[1]) for _ in range(n_groups)]
     pa_stream, ctx_pa = new_ctx(prio[0])
-    single_stream, ctx_single = new_ctx(prio[1])
+    single_pairs = [new_ctx(prio[1]) for _ in range(max(1, int(os.environ.get("SVT_BENCH_SINGLE_STREAMS", "2"))))]
 
     Wd, Hd = args.width, args.height
     geo = Geometry(Wd, Hd)
@@ -597,11 +597,12 @@ def main():
     separate_rate = os.environ.get("SVT_BENCH_SEPARATE_RATE", "0") == "1"
     rate_ctx_rng = np.random.default_rng(8)
 
-    def build_layer_blocks(gops, layer):
-        """transform blocks of the pictures of one temporal layer of the GOPs of a group, grouped by transform size; reconstruction
-        offsets are relative to the ring slot the launch is given"""
-        items = [(g, i) for g in gops for i in pics_of_layer(layer)]
-        lb = {"items": items}
+    def build_layer_blocks(items):
+        """transform blocks of the pictures (g, i) of one temporal layer of a group, grouped by transform size; reconstruction offsets
+        are relative to the ring slot the launch is given"""
+        lb = {"items": items, "counts": [0, 0, 0, 0], "blocks_host": np.zeros(0, dtype=B.TQ_BLOCK_DTYPE), "pic_of_block": np.zeros(0, np.int32)}
+        if not items:
+            return lb
         per_ts, pic_of = [[] for _ in range(4)], [[] for _ in range(4)]
         for k, (g, i) in enumerate(items):
             arrs = blk_tight[g][i]
@@ -644,7 +645,8 @@ def main():
         per_ts = [[] for _ in range(4)]
         for layer, lb in enumerate(layers):
             b = lb["blocks_host"].copy()
-            b["pad"][:, 0] |= np.uint8(layer << 4)
+            if len(b):
+                b["pad"][:, 0] |= np.uint8(layer << 4)
             pos = 0
             for ts in range(4):
                 per_ts[ts].append(b[pos:pos + lb["counts"][ts]])
@@ -660,6 +662,8 @@ def main():
         `back` mini-GOPs before the newest one of the step; one descriptor set per ring phase"""
         n = len(items)
         bt = {"n": n, "items": items, "mc": [], "yuv": []}
+        if not n:
+            return bt
         for ph in range(RING):
             mc = (B.McPicture * n)()
             yv = (B.YuvPlanes * n)()
@@ -684,9 +688,12 @@ def main():
     slot_base = lambda slot: C.c_void_p(d_rec.data_ptr() + (slot % RING) * slot_bytes)
 
     def run_mc(ctx_, bt, ph):
-        B.check(lib.svt_hip_inter_pred_batch_device(ctx_, bt["n"], bt["mc"][ph]))
+        if bt["n"]:
+            B.check(lib.svt_hip_inter_pred_batch_device(ctx_, bt["n"], bt["mc"][ph]))
 
     def run_tq(ctx_, lb, slot, plain=False):
+        if not lb["items"]:
+            return
         if plain or separate_rate:
             B.check(lib.svt_hip_tq_batch_dist_device(ctx_, vp(d_src), vp(d_pred), slot_base(slot), vp(lb["blocks"]), lb["cnt_c"], vp(d_qt), vp(d_iscan), vp(d_q),
                                                      vp(d_dq), vp(lb["eob"]), vp(lb["dist"])))
@@ -708,24 +715,39 @@ def main():
         B.check(lib.svt_hip_coeff_rate_batch_device(ctx_, vp(d_q), vp(lb["d_rb"]), len(lb["rb_host"]), vp(d_rt), vp(d_rs), vp(lb["bits"])))
 
     def run_lf(ctx_, bt, ph):
-        B.check(lib.svt_hip_lf_batch_device(ctx_, bt["n"], bt["yuv"][ph], bt["lfm"], bt["lfs"], C.byref(thr), bt["mrs"], bt["mcs"], 0))
+        if bt["n"]:
+            B.check(lib.svt_hip_lf_batch_device(ctx_, bt["n"], bt["yuv"][ph], bt["lfm"], bt["lfs"], C.byref(thr), bt["mrs"], bt["mcs"], 0))
 
     def run_pad(ctx_, bt, ph):
-        B.check(lib.svt_hip_ref_pad_batch_device(ctx_, bt["n"], bt["yuv"][ph], PAD, PAD))
+        if bt["n"]:
+            B.check(lib.svt_hip_ref_pad_batch_device(ctx_, bt["n"], bt["yuv"][ph], PAD, PAD))
 
-    def build_pipeline(gops, pairs):
-        """a pipeline = a set of GOPs in flight, split into groups with one EncDec stream each.  Per group: the transform block lists
-        per temporal layer, the five wave batches (all pictures of one layer of the newest mini-GOP) and the diagonal batch (layer
-        l of the mini-GOP l steps back: every picture of it depends only on pictures of earlier steps)"""
+    def build_pipeline(gops, pairs, split="gop"):
+        """a pipeline = a set of GOPs in flight whose pictures are split into groups with one EncDec stream each: whole GOPs per
+        group ("gop"), or -- any partition of a batch of mutually independent pictures is valid -- the pictures of every GOP dealt
+        round-robin ("picture": what one stream of mini-GOPs uses to overlap the deblocking of one half of a batch with the transform
+        stage of the other).  Per group: the transform block lists per temporal layer, the five wave batches (the group's pictures
+        of one layer of the newest mini-GOP) and the diagonal batch (layer l of the mini-GOP l steps back)"""
         ng = len(pairs)
-        groups = [gops[k::ng] for k in range(ng)]
+        if split == "gop":
+            members = [[(g, i) for g in gops[k::ng] for i in range(1, MINIGOP + 1)] for k in range(ng)]
+        else:
+            members = [[(g, i) for g in gops for i in range(1, MINIGOP + 1) if i % ng == k] for k in range(ng)]
         P = {"gops": gops, "groups": [], "me_ev": []}
+        # with the pictures of a GOP spread over several streams, a batch's references may have been finished on another stream:
+        # every group then waits for the events all groups recorded behind their previous batch (events from a pool made here)
+        P["cross_sync"] = split == "picture" and ng > 1
+        P["sync_pool"] = [torch.cuda.Event() for _ in range(64 * ng)] if P["cross_sync"] else []
+        for e_ in P["sync_pool"]:
+            e_.record(me_streams[0])
+        P["sync_pos"], P["sync_last"] = 0, []
         P["me_sets"], P["me_slot"] = build_me_launches(gops)
-        for grp, (st_, ctx_) in zip(groups, pairs):
-            layers = [build_layer_blocks(grp, layer) for layer in range(5)]
-            P["groups"].append({"gops": grp, "stream": st_, "ctx": ctx_, "layers": layers, "diag_blocks": build_diag_blocks(layers),
-                                "waves": [build_batch([(g, i, 0) for g in grp for i in pics_of_layer(layer)]) for layer in range(5)],
-                                "diag": build_batch([(g, i, LAYER[i - 1]) for g in grp for i in range(1, MINIGOP + 1)])})
+        for pics_, (st_, ctx_) in zip(members, pairs):
+            by_layer = [[(g, i) for g, i in pics_ if LAYER[i - 1] == layer] for layer in range(5)]
+            layers = [build_layer_blocks(by_layer[layer]) for layer in range(5)]
+            P["groups"].append({"pics": pics_, "stream": st_, "ctx": ctx_, "layers": layers, "diag_blocks": build_diag_blocks(layers),
+                                "waves": [build_batch([(g, i, 0) for g, i in by_layer[layer]]) for layer in range(5)],
+                                "diag": build_batch([(g, i, LAYER[i - 1]) for g, i in pics_])})
         return P
 
     P_main = build_pipeline(all_gops, grp_pairs)
@@ -736,6 +758,8 @@ def main():
     for layer in range(5):
         for grp in P_main["groups"]:
             bt, lb, ctx_ = grp["waves"][layer], grp["layers"][layer], grp["ctx"]
+            if not bt["n"]:
+                continue
             with torch.cuda.stream(grp["stream"]):
                 run_mc(ctx_, bt, 0)
                 run_tq(ctx_, lb, 0, plain=True)
@@ -778,7 +802,7 @@ def main():
                       "mean_eob_by_tx_size": [round(float(np.concatenate(eob_stats[ts]).mean()), 1) for ts in range(4)],
                       "blocks_by_tx_size": counts_step}
     step_no = [1]   # the setup pass was step 0 (mini-GOP 0 complete in ring slot 0)
-    P_single = None if (args.no_single or separate_rate) else build_pipeline([0], [(single_stream, ctx_single)])
+    P_single = None if (args.no_single or separate_rate) else build_pipeline([0], single_pairs, split="picture")
     setup_s = time.perf_counter() - t_setup0
 
     # split-GOP hand-off (optional, N > 1): the padded base-layer reconstruction of this rank's first GOP, as the deblocking +
@@ -789,10 +813,10 @@ def main():
         ho_stream = torch.cuda.Stream(device=local_rank)
 
     def run_handoff(P, ph):
-        grp0 = P["groups"][0]
-        ho_stream.wait_stream(grp0["stream"])   # ordered after this step's deblocking + padding of the base picture
+        for grp0 in P["groups"]:
+            ho_stream.wait_stream(grp0["stream"])   # ordered after this step's deblocking + padding of the base picture
         with torch.cuda.stream(ho_stream):
-            ops = [dist.P2POp(dist.isend, d_rec[ph % RING, grp0["gops"][0], MINIGOP - 1], (rank + 1) % world), dist.P2POp(dist.irecv, ho_recv, (rank - 1) % world)]
+            ops = [dist.P2POp(dist.isend, d_rec[ph % RING, P["gops"][0], MINIGOP - 1], (rank + 1) % world), dist.P2POp(dist.irecv, ho_recv, (rank - 1) % world)]
             for w_ in dist.batch_isend_irecv(ops):
                 w_.wait()
 
@@ -832,17 +856,40 @@ def main():
             S["pa_done"][1 - buf] = torch.cuda.Event()
             S["pa_done"][1 - buf].record(pa_stream)
         # EncDec side, every stage on the group's stream in program order = dependency order
+        def barrier_groups():
+            """cross-stream dependency of a picture-split pipeline: the next batch of every group starts after the previous batch of all"""
+            if not P["cross_sync"]:
+                return
+            for grp in P["groups"]:
+                for e_ in P["sync_last"]:
+                    grp["stream"].wait_event(e_)
+
+        def mark_groups():
+            if not P["cross_sync"]:
+                return
+            P["sync_last"] = []
+            for grp in P["groups"]:
+                e_ = P["sync_pool"][P["sync_pos"] % len(P["sync_pool"])]
+                P["sync_pos"] += 1
+                e_.record(grp["stream"])
+                P["sync_last"].append(e_)
+
         if schedule == "waves":      # the five dependent temporal-layer waves of the newest mini-GOP
             for layer in range(5):
+                barrier_groups()
                 for grp in P["groups"]:
                     bt, lb, ctx_, st_ = grp["waves"][layer], grp["layers"][layer], grp["ctx"], grp["stream"]
+                    if not bt["n"]:
+                        continue
                     staged(S, "mc", st_, lambda: run_mc(ctx_, bt, ph), pool)
                     staged(S, "tq", st_, lambda: run_tq(ctx_, lb, ph), pool)
                     if separate_rate:
                         staged(S, "rate", st_, lambda: run_rate(ctx_, lb), pool)
                     staged(S, "lf", st_, lambda: run_lf(ctx_, bt, ph), pool)
                     staged(S, "pad", st_, lambda: run_pad(ctx_, bt, ph), pool)
+                mark_groups()
         else:                        # diagonal: layer l of the mini-GOP l steps back -- one batch of independent pictures
+            barrier_groups()
             for grp in P["groups"]:
                 bt, ctx_, st_ = grp["diag"], grp["ctx"], grp["stream"]
                 staged(S, "mc", st_, lambda: run_mc(ctx_, bt, ph), pool)
@@ -857,6 +904,7 @@ def main():
                     staged(S, "rate", st_, lambda: [run_rate(ctx_, lb) for lb in grp["layers"]], pool)
                 staged(S, "lf", st_, lambda: run_lf(ctx_, bt, ph), pool)
                 staged(S, "pad", st_, lambda: run_pad(ctx_, bt, ph), pool)
+            mark_groups()
         if handoff:
             run_handoff(P, ph)
 
@@ -1010,7 +1058,7 @@ def main():
                     for s in STAGES if s in stages},
         "pcie_note": f"inputs are resident in HBM when the clock starts; a 4K 4:2:0 picture is {pic_bytes / 1e6:.1f} MB, so {round(fps)} frames/s "
                      f"would need {fps * pic_bytes / 1e9:.0f} GB/s of host-to-device traffic if every picture crossed PCIe (gen5 x16 sustains ~50): the "
-                     "PCIe-inclusive rate of the public-API path is `api_path` (tests/c/enc_app.c, DESIGN.md section 2)",
+                     "PCIe-inclusive rate of the public-API path is `api_path` (app/svt_enc_api_bench.c, DESIGN.md section 2)",
     }
     if not args.no_cpu_baseline:
         # the CPU leg works on GOP 0 in the tight layout of round 2 (one mini-GOP, blocks grouped by size across its pictures)
