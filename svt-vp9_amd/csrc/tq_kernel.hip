@@ -158,7 +158,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 3
     __shared__ uint32_t s_tc[RATE ? 4 * RATE_SLICE : 1];
     /* ... and the {scan, neighbours} tables of this size (all four transform types; one for 32x32): the walk's three table
      * reads per position then cost an LDS access instead of a dependent global round trip */
-    constexpr int SCAN_T = 3 * N * N + 2, SCAN_N = (N == 32 ? 1 : 4) * SCAN_T;
+    /* (the two entries that close a table -- the neighbours of position n -- are never read: a walk ends at position eob <= n - 1 or,
+     * for a full block, without an EOB token; leaving them out of the single 32x32 table keeps that instance at 53 760 bytes = 42 LDS
+     * granules, three workgroups per CU instead of two) */
+    constexpr int SCAN_T = 3 * N * N + 2, SCAN_N = N == 32 ? 3 * N * N : 4 * SCAN_T;
     __shared__ int16_t s_scan[RATE ? SCAN_N : 2];
     if constexpr (RATE) {
         const uint32_t *g = &ra.T->token_costs[txcfg<N>::size][0][0][0][0][0][0];

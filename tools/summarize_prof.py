@@ -12,9 +12,9 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out")
 prof = os.path.join(root, "profiles")
-# launches of one step with ONE GOP in flight, diagonal schedule: ME per temporal layer, the transform stage per temporal layer (= ring
-# slot) and transform size, everything else once over the 16 pictures
-PER_STEP = {"svt_me_sb_kernel": 5, "svt_tq_kernel": 20, "svt_lf_kernel": 1, "svt_lf_desc_kernel": 1, "svt_pa_plane_kernel": 1, "svt_mc_kernel": 1,
+# launches of one step with ONE GOP in flight, diagonal schedule: ME per temporal layer, the transform stage per transform size (one
+# launch serves the five ring slots: svt_hip_tq_rd_batch_multi_device), everything else once over the 16 pictures
+PER_STEP = {"svt_me_sb_kernel": 5, "svt_tq_kernel": 4, "svt_lf_kernel": 1, "svt_lf_desc_kernel": 1, "svt_pa_plane_kernel": 1, "svt_mc_kernel": 1,
             "svt_refpad_kernel": 1}
 
 
