@@ -424,6 +424,7 @@ __global__ __launch_bounds__(128) void svt_lf_desc_kernel(const lf_pic_dev *__re
  *           descriptors (svt_lf_desc_kernel) into the other buffer;
  *   wave 3  writes the finished columns of the tile filtered in the previous step back and publishes the row's progress.
  * One workgroup barrier per SB; wave 2 lets its loads fly while wave 3 is still reading the buffer they will land in.  Tile rows 0-7 (top halo) and the SB's last 8 rows are seam rows (sc1 accesses). */
+template <bool early> /* latency mode (launches of few pictures): seam rows are handed to the SB row below early, see step (c) */
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void svt_lf_kernel(const lf_pic_dev *__restrict__ pics, int n_pics,
                                                      uint32_t *__restrict__ ticket, int rows_per_pic, int prof) {
     __shared__ __align__(16) uint8_t ytile[2][YROWS * YS];
@@ -433,6 +434,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     __shared__ int                   s_job;
     __shared__ int                   s_stored_;             /* last SB whose tile wave 2 has read back out of LDS */
     __shared__ int                   s_halo_;               /* last SB whose top halo rows (the SB row above's bottom rows) are in LDS */
+    __shared__ int                   s_vdone_[2];           /* last SB whose vertical-edge pass the luma / the chroma wave has finished */
     const int tid = threadIdx.x;
     /* Persistent workgroups: each takes SB rows by ticket until none is left.  Tickets run over the rows of all pictures
      * interleaved (row 0 of every picture, then row 1, ...): the row a workgroup depends on, (pic, sb_row - 1), always
@@ -444,7 +446,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     /* the two flags are polled: keep them explicit LDS references so the polls are ds_reads, not flat loads */
     volatile int LF_LDS &s_stored = *(volatile int LF_LDS *)&s_stored_;
     volatile int LF_LDS &s_halo   = *(volatile int LF_LDS *)&s_halo_;
-    if (tid == 0) { s_job = (int)atomicAdd(ticket, 1u); s_stored = -1; s_halo = -1; }
+    volatile int LF_LDS *s_vdone  = (volatile int LF_LDS *)s_vdone_;
+    if (tid == 0) { s_job = (int)atomicAdd(ticket, 1u); s_stored = -1; s_halo = -1; s_vdone[0] = -1; s_vdone[1] = -1; }
     __syncthreads();
     const int job = s_job;
     if (job >= n_pics * rows_per_pic) break;
@@ -470,8 +473,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     auto stage_halo = [&](int sc) {
         const int     buf = sc & 1;
         const lf_geom g = lf_geometry(sb_row, sc, W, H);
-        if (sb_row > 0) { /* wait for (sb_row-1, sc+1): its tiles up to sc+1 have been written back */
-            const uint32_t need = (uint32_t)(sc + 2 < sb_cols ? sc + 2 : sb_cols);
+        if (sb_row > 0) { /* wait for the SB row above to have handed over everything above this SB: its tile sc (columns up to 56)
+                             and, early, the bottom rows of its last 8 columns, which (sb_row-1, sc+1)'s vertical pass finishes */
+            const uint32_t need = early ? (uint32_t)(sc + 1) : (uint32_t)(sc + 2 < sb_cols ? sc + 2 : sb_cols);
             if (lane == 0)
                 while (__hip_atomic_load(LF_AS_GLOBAL(uint32_t, &P.progress[sb_row - 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(1);
             LF_MARK(0, 128);
@@ -515,6 +519,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             /* vertical edges: lane = sample row; horizontal edges: lane = sample column (LDS accesses of one wave are
              * ordered, no barrier between the two passes) */
             if (lane < g.vh) lf_line<true>(ytile[buf] + (8 + lane) * YS + 8, 1, 8, &s_desc[buf][2 * (lane >> 3) * 8], 1);
+            if (early && lane == 0) s_vdone[0] = sc; /* LDS accesses of one wave are ordered: the flag lands behind the pass's stores */
             LF_MARK(3, 0);
             while (s_halo < sc) __builtin_amdgcn_s_sleep(1); /* the rows above the SB have arrived */
             if (lane < g.vw) lf_line<false>(ytile[buf] + 8 * YS + 8 + lane, YS, nrows, &s_desc[buf][128 + 2 * (lane >> 3)], 8);
@@ -530,6 +535,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         } else if (wave == 1 && !P.y_only) {
             const int pl = lane >> 5, l5 = lane & 31;
             if (l5 < g.cvh) lf_line<true>(ctile[buf][pl] + (8 + l5) * CS + 8, 1, 4, &s_desc[buf][256 + 2 * (l5 >> 3) * 4], 1);
+            if (early && lane == 0) s_vdone[1] = sc;
             while (s_halo < sc) __builtin_amdgcn_s_sleep(1);
             if (l5 < g.cvw) lf_line<false>(ctile[buf][pl] + 8 * CS + 8 + l5, CS, (nrows + 1) >> 1, &s_desc[buf][288 + 2 * (l5 >> 3)], 4);
             if (!last) {
@@ -544,17 +550,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         __syncthreads();
         LF_MARK(5, 0);
         if (wave == 3) {
-            /* write back what is final: tile columns 8-hx .. 8+56 (.. 8+vw for the last SB), rows 8-hy .. 8+vh */
-            const int nxs = (last ? g.vw : 56) + g.hx, nxc = (last ? g.cvw : 24) + g.hx;
-            tile_io<11>(wide_y, false, P.planes.y, P.planes.y_stride, ytile[buf], YS, g.x0 - 8, g.y0 - 8, 8 - g.hx, 8 - g.hy, nxs, g.vh + g.hy, 8, 8 + g.vh - 8, lane, 64);
+            /* Write back what is final.  (a) the SB's own columns 8 .. 8+56 (.. 8+vw for the last SB), rows 8-hy .. 8+vh; (b) the 8
+             * left-halo columns (the previous SB's last columns, which this SB's vertical pass finished) -- without their bottom 8
+             * rows when an SB row below waits for them: those went out early, in the previous iteration's step (c), and the row
+             * below may already have filtered and rewritten them. */
+            const bool below = early && sb_row + 1 < sb_rows;
+            if (!early) { /* throughput mode: one rectangle per plane (tile columns 8-hx .. 8+56, rows 8-hy .. 8+vh), nothing handed over early */
+                const int nxs = (last ? g.vw : 56) + g.hx, nxc = (last ? g.cvw : 24) + g.hx;
+                tile_io<11>(wide_y, false, P.planes.y, P.planes.y_stride, ytile[buf], YS, g.x0 - 8, g.y0 - 8, 8 - g.hx, 8 - g.hy, nxs, g.vh + g.hy, 8, 8 + g.vh - 8, lane, 64);
+                if (!P.y_only) {
+                    tile_io<3>(wide_c, false, P.planes.u, P.planes.uv_stride, ctile[buf][0], CS, g.cx0 - 8, g.cy0 - 8, 8 - g.hx, 8 - g.hy, nxc, g.cvh + g.hy, 8, 8 + g.cvh - 8, lane, 64);
+                    tile_io<3>(wide_c, false, P.planes.v, P.planes.uv_stride, ctile[buf][1], CS, g.cx0 - 8, g.cy0 - 8, 8 - g.hx, 8 - g.hy, nxc, g.cvh + g.hy, 8, 8 + g.cvh - 8, lane, 64);
+                }
+            } else {
+            const int  nown = last ? g.vw : 56, nownc = last ? g.cvw : 24, cut = below ? 8 : 0;
+            tile_io<11>(wide_y, false, P.planes.y, P.planes.y_stride, ytile[buf], YS, g.x0 - 8, g.y0 - 8, 8, 8 - g.hy, nown, g.vh + g.hy, 8, 8 + g.vh - 8, lane, 64);
+            if (g.hx) tile_io<2>(wide_y, false, P.planes.y, P.planes.y_stride, ytile[buf], YS, g.x0 - 8, g.y0 - 8, 0, 8 - g.hy, 8, g.vh + g.hy - cut, 8, 8 + g.vh - 8, lane, 64);
             if (!P.y_only) {
-                tile_io<3>(wide_c, false, P.planes.u, P.planes.uv_stride, ctile[buf][0], CS, g.cx0 - 8, g.cy0 - 8, 8 - g.hx, 8 - g.hy, nxc, g.cvh + g.hy, 8, 8 + g.cvh - 8, lane, 64);
-                tile_io<3>(wide_c, false, P.planes.v, P.planes.uv_stride, ctile[buf][1], CS, g.cx0 - 8, g.cy0 - 8, 8 - g.hx, 8 - g.hy, nxc, g.cvh + g.hy, 8, 8 + g.cvh - 8, lane, 64);
+                _Pragma("unroll") for (int pl = 0; pl < 2; pl++) {
+                    uint8_t *cp = pl ? P.planes.v : P.planes.u;
+                    tile_io<3>(wide_c, false, cp, P.planes.uv_stride, ctile[buf][pl], CS, g.cx0 - 8, g.cy0 - 8, 8, 8 - g.hy, nownc, g.cvh + g.hy, 8, 8 + g.cvh - 8, lane, 64);
+                    if (g.hx) tile_io<1>(wide_c, false, cp, P.planes.uv_stride, ctile[buf][pl], CS, g.cx0 - 8, g.cy0 - 8, 0, 8 - g.hy, 8, g.cvh + g.hy - cut, 8, 8 + g.cvh - 8, lane, 64);
+                }
+            }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the tile has left LDS: the buffer may be refilled */
             if (lane == 0) s_stored = sc;
             LF_MARK(6, 192);
-            /* publish: every store of this wave has completed (seam rows were written through) -> progress counter */
+            /* (c) early hand-over to the SB row below: the bottom 8 rows of this SB's LAST 8 columns are final as soon as the NEXT SB's
+             * vertical pass (running right now in the other buffer, whose left-halo columns they are) has filtered its left edge --
+             * its horizontal pass never touches the halo columns.  Handing them over now instead of with the next tile's
+             * write-back lets row r + 1 follow 1.2 instead of 2 SB steps behind row r: 1.09 -> 0.91 ms for one 4K picture.  It costs
+             * extra (write-through) stores, which a launch of many pictures -- throughput, not latency -- does not get back (16
+             * pictures: 1.47 -> 1.51 ms), so the launcher turns it on for launches of few pictures only (`early`). */
+            if (!last && below) {
+                while (s_vdone[0] < sc + 1) __builtin_amdgcn_s_sleep(1);
+                const lf_geom gn = lf_geometry(sb_row, sc + 1, W, H);
+                tile_io<1>(wide_y, false, P.planes.y, P.planes.y_stride, ytile[buf ^ 1], YS, gn.x0 - 8, gn.y0 - 8, 0, 8 + gn.vh - 8, 8, 8, 1 << 20, 0, lane, 64);
+                if (!P.y_only) {
+                    while (s_vdone[1] < sc + 1) __builtin_amdgcn_s_sleep(1);
+                    tile_io<1>(wide_c, false, P.planes.u, P.planes.uv_stride, ctile[buf ^ 1][0], CS, gn.cx0 - 8, gn.cy0 - 8, 0, 8 + gn.cvh - 8, 8, 8, 1 << 20, 0, lane, 64);
+                    tile_io<1>(wide_c, false, P.planes.v, P.planes.uv_stride, ctile[buf ^ 1][1], CS, gn.cx0 - 8, gn.cy0 - 8, 0, 8 + gn.cvh - 8, 8, 8, 1 << 20, 0, lane, 64);
+                }
+            }
+            /* publish: every store of this wave has completed (seam rows were written through) -> progress counter.  sc + 1 = "everything
+             * above SB sc of the row below is in memory" */
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(LF_AS_GLOBAL(uint32_t, &P.progress[sb_row]), (uint32_t)(sc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             LF_MARK(7, 192);
@@ -609,7 +649,10 @@ static int32_t lf_launch(svt_hip_ctx *ctx, int n_pics, const svt_yuv_planes *d_r
     const int heuristic = (max_cols * 17 + 63) / 64 < 4 ? 4 : (max_cols * 17 + 63) / 64;
     const int rows_in_flight = rows_env > 0 ? rows_env : n_pics <= 4 ? max_rows : heuristic;
     const int lf_wgs = n_pics * (max_rows < rows_in_flight ? max_rows : rows_in_flight);
-    hipLaunchKernelGGL(svt_lf_kernel, dim3(lf_wgs), dim3(256), 0, ctx->stream, (const lf_pic_dev *)d, n_pics, cnt, max_rows, want_prof ? 1 : 0);
+    static const int early_env = getenv("SVT_HIP_LF_EARLY") ? atoi(getenv("SVT_HIP_LF_EARLY")) : -1;
+    const int early = early_env >= 0 ? early_env : n_pics <= 4;
+    if (early) hipLaunchKernelGGL(svt_lf_kernel<true>, dim3(lf_wgs), dim3(256), 0, ctx->stream, (const lf_pic_dev *)d, n_pics, cnt, max_rows, want_prof ? 1 : 0);
+    else hipLaunchKernelGGL(svt_lf_kernel<false>, dim3(lf_wgs), dim3(256), 0, ctx->stream, (const lf_pic_dev *)d, n_pics, cnt, max_rows, want_prof ? 1 : 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     if (want_prof) {
