@@ -42,12 +42,15 @@ def test_lf_y_only_and_repeatability(ctx):
         assert all(np.array_equal(a, b) for a, b in zip(full, g))
 
 
-def test_lf_batch_of_different_pictures(ctx):
-    """svt_hip_lf_batch_device: three pictures of different sizes (1, 3 and 4 SB rows; partial SBs) in one launch -- the
-    persistent workgroups interleave their rows by ticket; every picture must come out as if filtered alone"""
+@pytest.mark.parametrize("sizes", [((328, 200), (136, 64), (256, 192)),
+                                   ((328, 200), (136, 64), (256, 192), (640, 360), (72, 72), (200, 136), (648, 264))])
+def test_lf_batch_of_different_pictures(ctx, sizes):
+    """svt_hip_lf_batch_device: pictures of different sizes (1 .. 6 SB rows; partial SBs) in one launch -- the persistent
+    workgroups interleave their rows by ticket; every picture must come out as if filtered alone.  Three pictures run on the latency
+    instance of the kernel (every SB row resident, seam rows handed to the row below early), seven on the throughput instance."""
     import torch
     lib = B.load()
-    cases = [T.make_lf_case(21, 328, 200), T.make_lf_case(22, 136, 64), T.make_lf_case(23, 256, 192)]
+    cases = [T.make_lf_case(21 + k, w, h) for k, (w, h) in enumerate(sizes)]
     n = len(cases)
     keep, descs = [], (B.YuvPlanes * n)()
 
