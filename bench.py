@@ -802,7 +802,7 @@ def main():
                       "mean_eob_by_tx_size": [round(float(np.concatenate(eob_stats[ts]).mean()), 1) for ts in range(4)],
                       "blocks_by_tx_size": counts_step}
     step_no = [1]   # the setup pass was step 0 (mini-GOP 0 complete in ring slot 0)
-    P_single = None if (args.no_single or separate_rate) else build_pipeline([0], single_pairs, split="picture")
+    P_single = None if (args.no_single or separate_rate or rank != 0) else build_pipeline([0], single_pairs, split="picture")
     setup_s = time.perf_counter() - t_setup0
 
     # split-GOP hand-off (optional, N > 1): the padded base-layer reconstruction of this rank's first GOP, as the deblocking +
@@ -946,6 +946,10 @@ def main():
 
     dt, enq_s, stage_ms, me_launch_ms, n_me_launch = timed_run(P_main, args.schedule, args.steps, args.warmup, True)
     dt = GS.reduce_elapsed(dt, dist if world > 1 else None, dev)
+    if world > 1:   # nothing below needs the other ranks: they leave in step, rank 0 reports
+        sync()
+        dist.barrier()
+        dist.destroy_process_group()
     single = {}
     if P_single is not None:
         k1 = max(4, args.steps)
@@ -1060,7 +1064,7 @@ def main():
                      f"would need {fps * pic_bytes / 1e9:.0f} GB/s of host-to-device traffic if every picture crossed PCIe (gen5 x16 sustains ~50): the "
                      "PCIe-inclusive rate of the public-API path is `api_path` (app/svt_enc_api_bench.c, DESIGN.md section 2)",
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # the CPU leg runs at N = 1 only (rank 0's host cores are not shared with other ranks)
         # the CPU leg works on GOP 0 in the tight layout of round 2 (one mini-GOP, blocks grouped by size across its pictures)
         by_ts = [[] for _ in range(4)]
         for i in range(1, MINIGOP + 1):
@@ -1085,7 +1089,7 @@ def main():
     for c_ in ctxs:
         lib.svt_hip_ctx_destroy(c_)
     ctxs.clear()
-    if (Wd, Hd) == (W4K, H4K) or os.environ.get("SVT_BENCH_API_PATH"):
+    if world == 1 and ((Wd, Hd) == (W4K, H4K) or os.environ.get("SVT_BENCH_API_PATH")):
         torch.cuda.synchronize()
         api = api_path_rate(frames_all[0], Wd, Hd)
         if api is not None:
