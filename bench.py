@@ -1060,7 +1060,7 @@ def main():
                                    "GB_per_s": round(stage_bytes[s] / (max(stage_ms[s], 1e-9) * 1e-3) / 1e9, 2),
                                    "frac_of_8TBps": round(stage_bytes[s] / (max(stage_ms[s], 1e-9) * 1e-3) / 8e12, 5)}
                     for s in STAGES if s in stages},
-        "pcie_note": f"inputs are resident in HBM when the clock starts; a 4K 4:2:0 picture is {pic_bytes / 1e6:.1f} MB, so {round(fps)} frames/s "
+        "pcie_note": f"inputs are resident in HBM when the clock starts; a {Wd}x{Hd} 4:2:0 picture is {pic_bytes / 1e6:.1f} MB, so {round(fps)} frames/s "
                      f"would need {fps * pic_bytes / 1e9:.0f} GB/s of host-to-device traffic if every picture crossed PCIe (gen5 x16 sustains ~50): the "
                      "PCIe-inclusive rate of the public-API path is `api_path` (app/svt_enc_api_bench.c, DESIGN.md section 2)",
     }
