@@ -9,6 +9,8 @@
 #include <string.h>
 #include "svt_ctx.h"
 
+extern "C" void svt_copy_rows_mt(uint8_t *dst, size_t dst_stride, const uint8_t *src, size_t src_stride, size_t width, size_t rows);
+
 static thread_local char g_err[512] = "";
 
 int32_t svt_set_error(int32_t code, const char *msg) {
@@ -192,9 +194,10 @@ extern "C" int32_t svt_hip_mem_upload_2d_async(svt_hip_ctx *ctx, void *d_dst, si
         ctx->up_bytes[k] = bytes;
     }
     uint8_t *st = (uint8_t *)ctx->up_host[k];
-    if (src_stride == width_bytes) memcpy(st, src, bytes);
-    else for (size_t r = 0; r < rows; r++) memcpy(st + r * width_bytes, (const uint8_t *)src + r * src_stride, width_bytes);
-    HIP_TRY(hipMemcpy2DAsync(d_dst, dst_stride, st, width_bytes, width_bytes, rows, hipMemcpyHostToDevice, ctx->stream));
+    svt_copy_rows_mt(st, width_bytes, (const uint8_t *)src, src_stride, width_bytes, rows); /* host/copy_pool.c: a few threads */
+    /* the staging buffer is tight: a contiguous destination takes one linear copy (the DMA engines' fast path) */
+    if (dst_stride == width_bytes) HIP_TRY(hipMemcpyAsync(d_dst, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+    else HIP_TRY(hipMemcpy2DAsync(d_dst, dst_stride, st, width_bytes, width_bytes, rows, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->up_ev[k], ctx->stream));
     ctx->up_used[k] = 1;
     ctx->up_pos = (k + 1) % SVT_CTX_UPLOAD_RING;

@@ -1,0 +1,91 @@
+/*
+ * copy_pool.c -- the host copy of an input picture into pinned staging (svt_hip_mem_upload_2d_async = the copy
+ * eb_vp9_svt_enc_send_picture makes of the caller's picture, Source/Lib/Codec/EbEncHandle.c:2743-2796), spread over a few
+ * threads: one thread moves ~10-25 GB/s, a 4K luma plane is 8.3 MB, and that copy -- not the PCIe transfer behind it, not the GPU --
+ * is what bounds the public API's picture rate.  The reference's own input path is multi-threaded as well (resource coordination
+ * and picture analysis run in their own threads).  A process-wide fork-join pool, created on first use; SVT_HIP_COPY_THREADS
+ * (default 4, 1 = copy in the calling thread).  Plain C, pthreads.
+ */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define POOL_MAX 16
+
+static struct {
+    pthread_mutex_t lock;      /* protects the job fields and the counters */
+    pthread_cond_t  go, done;
+    pthread_mutex_t busy;      /* one fork-join at a time (callers of different contexts may arrive together) */
+    pthread_t       th[POOL_MAX];
+    int             n;         /* workers besides the caller */
+    unsigned long   gen;       /* job generation */
+    int             pending;
+    uint8_t        *dst;
+    const uint8_t  *src;
+    size_t          dst_stride, src_stride, width, rows;
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, {0}, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static pthread_once_t g_once = PTHREAD_ONCE_INIT;
+
+static void copy_slice(int part, int parts) {
+    const size_t r0 = g_pool.rows * (size_t)part / (size_t)parts, r1 = g_pool.rows * (size_t)(part + 1) / (size_t)parts;
+    if (g_pool.src_stride == g_pool.width && g_pool.dst_stride == g_pool.width)
+        memcpy(g_pool.dst + r0 * g_pool.width, g_pool.src + r0 * g_pool.width, (r1 - r0) * g_pool.width);
+    else
+        for (size_t r = r0; r < r1; r++) memcpy(g_pool.dst + r * g_pool.dst_stride, g_pool.src + r * g_pool.src_stride, g_pool.width);
+}
+
+static void *worker(void *arg) {
+    const int     id = (int)(intptr_t)arg;
+    unsigned long seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&g_pool.lock);
+        while (g_pool.gen == seen) pthread_cond_wait(&g_pool.go, &g_pool.lock);
+        seen = g_pool.gen;
+        pthread_mutex_unlock(&g_pool.lock);
+        copy_slice(id + 1, g_pool.n + 1);
+        pthread_mutex_lock(&g_pool.lock);
+        if (--g_pool.pending == 0) pthread_cond_signal(&g_pool.done);
+        pthread_mutex_unlock(&g_pool.lock);
+    }
+    return NULL;
+}
+
+static void pool_init(void) {
+    const char *e = getenv("SVT_HIP_COPY_THREADS");
+    int         n = e ? atoi(e) : 4;
+    if (n < 1) n = 1;
+    if (n > POOL_MAX + 1) n = POOL_MAX + 1;
+    int made = 0;
+    for (int i = 0; i < n - 1; i++) {
+        pthread_attr_t a;
+        pthread_attr_init(&a);
+        pthread_attr_setdetachstate(&a, PTHREAD_CREATE_DETACHED);
+        if (pthread_create(&g_pool.th[made], &a, worker, (void *)(intptr_t)made) == 0) made++;
+        pthread_attr_destroy(&a);
+        if (made != i + 1) break; /* no more threads to be had: the pool stays as big as it got */
+    }
+    g_pool.n = made;
+}
+
+/* copies `rows` rows of `width` bytes; returns when all of them have arrived */
+void svt_copy_rows_mt(uint8_t *dst, size_t dst_stride, const uint8_t *src, size_t src_stride, size_t width, size_t rows) {
+    pthread_once(&g_once, pool_init);
+    if (g_pool.n == 0 || width * rows < (1u << 20)) { /* small pictures: the hand-over costs more than it saves */
+        if (src_stride == width && dst_stride == width) memcpy(dst, src, width * rows);
+        else for (size_t r = 0; r < rows; r++) memcpy(dst + r * dst_stride, src + r * src_stride, width);
+        return;
+    }
+    pthread_mutex_lock(&g_pool.busy);
+    pthread_mutex_lock(&g_pool.lock);
+    g_pool.dst = dst; g_pool.src = src; g_pool.dst_stride = dst_stride; g_pool.src_stride = src_stride; g_pool.width = width; g_pool.rows = rows;
+    g_pool.pending = g_pool.n;
+    g_pool.gen++;
+    pthread_cond_broadcast(&g_pool.go);
+    pthread_mutex_unlock(&g_pool.lock);
+    copy_slice(0, g_pool.n + 1);
+    pthread_mutex_lock(&g_pool.lock);
+    while (g_pool.pending) pthread_cond_wait(&g_pool.done, &g_pool.lock);
+    pthread_mutex_unlock(&g_pool.lock);
+    pthread_mutex_unlock(&g_pool.busy);
+}
