@@ -623,6 +623,137 @@ int32_t svt_hip_coeff_rate_batch(svt_hip_ctx *ctx, const int16_t *qcoeff, size_t
                                  int32_t n_blocks, const svt_rate_tables *tables, const int16_t *scan, size_t scan_count,
                                  int32_t *bits);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Picture-level EncDec: everything the encode pass does with mode decision's output, whole pictures at a time, device resident.
+ *
+ * Replaces, per batch of mutually independent pictures (e.g. the pictures of one temporal layer of a mini-GOP), the data path of
+ * eb_vp9_enc_dec_kernel behind mode decision (Codec/EbEncDecProcess.c:5306): encode_pass_sb (:3627-4241) = inter prediction
+ * (:3787-3802) -> perform_coding_loop per transform block (:3830, 3890, 3940) -> skip flags (:4069-4098) -> and, once per picture,
+ * eb_vp9_build_mask_frame + eb_vp9_loop_filter_frame (:5651-5686) -> pad_ref_and_set_flags (:5694-5697).  The input is the mode-info
+ * grid (what mode decision leaves in picture_control_set_ptr->mode_info_array), not block lists: the transform-block descriptors,
+ * the skip flags and the LOOP_FILTER_MASKs are derived ON THE DEVICE (svt_tq_count / _emit, svt_tq_skip, svt_lf_mask kernels --
+ * the same rules as svt_hip_tq_blocks_from_grid and svt_hip_lf_build_masks, one text: csrc/encdec_core.h), so no per-picture
+ * descriptor data crosses PCIe and nothing waits for the host between the stages.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* Where the planes of one picture of a batch live relative to the batch's base pointers, and where its outputs go.  Offsets are
+ * bytes from the batch's source / prediction base pointer (one 32-bit offset space each) and from the picture's own
+ * reconstruction buffer; plane order Y, Cb, Cr. */
+typedef struct svt_tq_pic_geom {
+    uint32_t src_off[3], pred_off[3], recon_off[3];
+    uint16_t src_stride[2], pred_stride[2], recon_stride[2]; /* luma, chroma */
+    uint32_t coeff_base;    /* element offset of the picture's coefficient area (n_sb * SVT_SB_COEFFS elements) in the batch's arrays */
+    int32_t  width, height; /* luma samples (multiples of 8) */
+    uint8_t  recon_set;     /* which reconstruction buffer of the batch (0..7) */
+    uint8_t  do_recon;
+    uint8_t  pad_[2];
+} svt_tq_pic_geom;
+/* Coefficient layout of the driver: per SB 64*64 luma + 2 x 32*32 chroma coefficients (Y at +0, Cb at +4096, Cr at +5120), every
+ * block's N*N coefficients contiguous (raster inside the block) as in the reference's per-SB quantized_coeff_buffer
+ * (Codec/EbEncDecProcess.c:4100-4108), but addressed by POSITION: inside a plane area the 4x4 units are in z-order, so the block at
+ * sample (x, y) of its plane starts at zorder((x % S) / 4, (y % S) / 4) * 16 with S = 64 (luma) / 32 (chroma). */
+#define SVT_SB_COEFFS 6144
+
+/* host: the transform blocks of n_pics pictures (one geometry) from their mode-info grids, grouped by transform size and inside a
+ * size ordered picture, SB (raster), 8x8 unit of the SB (raster), and per unit luma, Cb, Cr -- exactly the lists the driver builds
+ * on the device.  The luma transform type of a block travels in svt_lf_mode_info.pad_[0] (0 = DCT_DCT).  pos[i] = picture-in-batch
+ * << 28 | plane << 26 | (y / 4) << 13 | (x / 4) of block i, x / y in samples of its plane.  Returns the number of blocks or a negative error. */
+int32_t svt_hip_tq_blocks_from_grid(int32_t n_pics, const svt_lf_mode_info *const *lf_mi, int32_t mi_stride, const svt_tq_pic_geom *geom,
+                                    svt_tq_block *blocks, uint32_t *pos, int32_t capacity, int32_t size_count[4]);
+
+/* host: the normative VP9 tables the transform stage needs (generated from the reference's own objects, tools/gen_vp9_tables.py):
+ * the inverse scan orders eb_vp9_scan_orders[tx_size][tx_type].iscan (VPX/vp9_scan.c) concatenated, offsets16[tx_size * 4 +
+ * tx_type] = element offset of a table; the quantiser steps eb_vp9_dc_quant / eb_vp9_ac_quant(q_index, 0, 8 bit)
+ * (VPX/vp9_quant_common.c); eb_vp9_quantizer_to_qindex (VPX/vp9_quantize.c:329). */
+const int16_t *svt_hip_vp9_iscan_tables(const uint32_t **offsets16, int32_t *entries);
+int32_t svt_hip_vp9_qindex_from_qp(int32_t qp);
+int32_t svt_hip_vp9_dc_step(int32_t q_index);
+int32_t svt_hip_vp9_ac_step(int32_t q_index);
+/* out[0] luma, out[1] chroma tables of a q index with zero deltas (the sequence-level eb_vp9_init_quantizer) */
+int32_t svt_hip_quant_tables_for_qindex(int32_t q_index, svt_quant_tables out[2]);
+
+/* Which stages the reference runs behind mode decision for a picture: the flags eb_vp9_signal_derivation_enc_dec_kernel_{sq,oq,
+ * vmaf} derive (limit_intra, Codec/EbEncDecProcess.c:4989-4997 / 5127-5136 / 5257-5263; allow_enc_dec_mismatch, :4954-4959 /
+ * 5084-5089 / 5201) and what encode_pass_sb (:3653-3657) and the picture's last SB (:5633-5697) do with them. */
+typedef struct svt_encdec_flags_config {
+    int32_t enc_mode, tune;
+    int32_t temporal_layer_index;
+    int32_t is_used_as_reference;
+    int32_t recon_file;            /* static_config.recon_file */
+    int32_t loop_filter;           /* static_config.loop_filter */
+} svt_encdec_flags_config;
+typedef struct svt_encdec_flags {
+    int32_t limit_intra, allow_enc_dec_mismatch;
+    int32_t do_recon;              /* inter SBs are reconstructed (inverse transform + add) */
+    int32_t apply_loop_filter;     /* lf_application_enable_flag */
+    int32_t pad_reference;         /* pad_ref_and_set_flags runs */
+} svt_encdec_flags;
+int32_t svt_hip_encdec_flags_derive(const svt_encdec_flags_config *cfg, svt_encdec_flags *flags);
+
+/* One picture of a batch.  Every pointer is a device pointer.  The grids are [mi_rows][mi_stride] records per 8x8 unit. */
+typedef struct svt_encdec_picture {
+    const svt_mc_mode_info *d_mc_mi;   /* inter part of the mode info (prediction) */
+    svt_lf_mode_info       *d_lf_mi;   /* sb_type, tx_size, is_inter, filter_level (+ luma tx_type in pad_[0]); `skip` is WRITTEN */
+    svt_yuv_planes          src;       /* source picture, sample (0,0) pointers */
+    svt_yuv_planes          ref[2];    /* padded reference pictures (as svt_mc_picture.ref) */
+    svt_yuv_planes          pred;      /* prediction picture (written by the inter prediction, read by the transform stage) */
+    svt_yuv_planes          recon;     /* the picture's reconstruction = reference buffer (sample (0,0) pointers into padded planes) */
+    int16_t                *d_qcoeff, *d_dqcoeff; /* n_sb * SVT_SB_COEFFS each, 16-byte aligned, position-addressed (above) */
+    uint16_t               *d_eob_map; /* eob of every transform block at its 4x4 unit: [Y: (H/4) x (W/4)] [Cb: (H/8) x (W/8)] [Cr] */
+    svt_lf_mask            *d_lfm;     /* [sb_rows][sb_cols] masks (written; read by the loop filter) */
+    uint8_t                *d_nz;      /* scratch, mi_rows * mi_stride bytes */
+    int32_t                 use_subpel; /* svt_mc_picture.use_subpel */
+} svt_encdec_picture;
+
+/* workspace of a batch: descriptor lists, per-list eob, counters (device memory owned by the object); sized for max_pics pictures
+ * of width x height.  Calls that share a workspace must be issued on the same context (stream order protects it). */
+typedef struct svt_encdec_work svt_encdec_work;
+int32_t svt_hip_encdec_work_create(svt_hip_ctx *ctx, int32_t max_pics, int32_t width, int32_t height, svt_encdec_work **work);
+void    svt_hip_encdec_work_destroy(svt_hip_ctx *ctx, svt_encdec_work *work);
+
+/* n_pics (<= 8, <= the workspace's max_pics) pictures of one geometry and one set of flags (the pictures of a temporal layer):
+ * inter prediction -> transform blocks from the grids -> residual / transform / quantisation (/ reconstruction when
+ * flags->do_recon) with the tables of q_index -> skip flags + eob map -> (flags->apply_loop_filter: masks + deblocking with
+ * filter_level's thresholds) -> (flags->pad_reference: border of pad_x / pad_y samples).  Source and prediction planes of the
+ * batch must each lie within 4 GB of the lowest of them (32-bit block offsets).  Asynchronous on the context's stream.
+ * A malformed grid (block crossing the picture edge, transform larger than its block ...) is reported by
+ * svt_hip_encdec_work_status after the work has completed; its blocks are left out. */
+int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work *work, int32_t n_pics, const svt_encdec_picture *pics, int32_t width,
+                                    int32_t height, int32_t mi_stride, int32_t q_index, const svt_encdec_flags *flags,
+                                    const svt_lf_thresh *thr, int32_t pad_x, int32_t pad_y);
+/* synchronises the context; 0 = every grid the workspace has seen was well-formed, else SVT_HIP_ERR_BAD_PARAMETER (and the flag is
+ * cleared).  counts[8] (optional) = offset and number of blocks per transform size of the most recent batch. */
+int32_t svt_hip_encdec_work_status(svt_hip_ctx *ctx, svt_encdec_work *work, int32_t counts[8]);
+/* most recent batch: copies the descriptor list, the position codes and the per-list eob to the host (capacity in blocks);
+ * returns the number of blocks.  For tests and for hosts that walk the coefficients in list order. */
+int32_t svt_hip_encdec_work_download(svt_hip_ctx *ctx, svt_encdec_work *work, svt_tq_block *blocks, uint32_t *pos, uint16_t *eob, int32_t capacity);
+
+/* Stand-in for mode decision (NOT the reference's: mode decision is host control logic outside this path).  Turns the ME results
+ * of n_pics pictures into well-formed mode-info grids so that the stages behind mode decision can run without a host-supplied
+ * decision: bottom-up merge over the PU tree (16x16 -> 32x32 -> 64x64: a parent replaces its four children when
+ * distortion(parent) <= sum distortion(children) + 3 lambda), blocks split at the picture edge down to 8x8, every block inter with
+ * the direction / vectors of its own PU's best ME candidate and the transform of its own size (32x32 for 64x64).  d_results[i],
+ * d_mc_mi[i], d_lf_mi[i] device arrays of picture i.  svt_hip_md_default_picture is the host form (same text). */
+int32_t svt_hip_md_default_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_me_pu_result *const *d_results, int32_t width, int32_t height,
+                                        uint32_t lambda, int32_t filter_level, svt_mc_mode_info *const *d_mc_mi, svt_lf_mode_info *const *d_lf_mi,
+                                        int32_t mi_stride);
+int32_t svt_hip_md_default_picture(const svt_me_pu_result *results, int32_t pic_width, int32_t pic_height, uint32_t lambda, int32_t filter_level,
+                                   svt_mc_mode_info *mc_mi, svt_lf_mode_info *lf_mi, int32_t mi_stride);
+
+/* device form of svt_hip_lf_build_masks (same text): masks of n_pics pictures from device-resident grids */
+int32_t svt_hip_lf_build_masks_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_lf_mode_info *const *d_lf_mi, int32_t mi_stride, int32_t mi_rows,
+                                      int32_t mi_cols, svt_lf_mask *const *d_lfm);
+
+/* Makes everything enqueued LATER on `ctx` wait for marker `marker` of `other` (both on the same device or not): the
+ * stream-to-stream dependency a pipeline of contexts needs (ME one mini-GOP ahead of EncDec) without a host wait. */
+int32_t svt_hip_ctx_wait_marker(svt_hip_ctx *ctx, svt_hip_ctx *other, uint64_t marker);
+/* asynchronous device-to-host copy into PINNED host memory (svt_hip_host_alloc), ordered on the context's stream; completion is
+ * observed through a marker recorded after it */
+int32_t svt_hip_host_alloc(svt_hip_ctx *ctx, size_t bytes, void **ptr);
+void    svt_hip_host_free(svt_hip_ctx *ctx, void *ptr);
+int32_t svt_hip_mem_download_2d_async(svt_hip_ctx *ctx, void *pinned_dst, size_t dst_stride, const void *d_src, size_t src_stride, size_t width_bytes,
+                                      size_t rows);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* Multi-GPU: GOP sharding and the inter-segment reference hand-off (scope row e)                      */
 /* ------------------------------------------------------------------------------------------------ */
@@ -637,12 +768,15 @@ int32_t svt_hip_gop_assign(int64_t n_gops, int32_t n_devices, int32_t index, int
  * Returns the device that produces the reference mini-GOP m needs, or -1 for m = 0 (it starts from the key frame). */
 int32_t svt_hip_minigop_reference_source(int64_t minigop, int32_t n_devices);
 
-/* How the reference cuts a group of n_pictures consecutive non-intra pictures that is shorter than a mini-GOP (end of stream, or an
- * intra refresh arrived) into the units it assigns prediction structures to: eb_vp9_generate_picture_window_split +
+/* How the reference cuts the pictures waiting in its pre-assignment buffer when they are released short of a full mini-GOP (end of
+ * stream, or an intra refresh arrived) into the units it assigns prediction structures to: eb_vp9_generate_picture_window_split +
  * eb_vp9_handle_incomplete_picture_window_map as the picture-decision kernel drives them (Codec/EbPictureDecisionProcess.c:387-476,
- * 1662-1680; mini-GOP table Codec/EbUtility.c:167-185).  A full group (n_pictures == 1 << hierarchical_levels) is one part.  A
- * part whose length equals the period of its own levels (8 pictures at 3 levels) keeps the random-access hierarchy; any other
- * part -- and every part of a group cut by an intra refresh -- is coded with the low-delay P structure (:1711-1727).
+ * 1662-1680; mini-GOP table Codec/EbUtility.c:167-185).  A full group (n_pictures == 1 << hierarchical_levels) is one part.
+ * cut_by_intra != 0: the group was released by an intra refresh and n_pictures INCLUDES that intra picture as its last element, as
+ * the reference's pre_assignment_buffer_count does (:1641-1646).  A part whose length equals the period of its own levels (8
+ * pictures at 3 levels) keeps the random-access hierarchy; any other part is coded with the low-delay P structure (:1711-1727), and
+ * so is the LAST part of a group cut by an intra refresh -- the one that ends with the intra picture (mini_gop_idr_count is set for
+ * the last part only, :419-424, 463-472): earlier whole-period parts of such a group stay random access.
  * Returns the number of parts (<= 4) or a negative error. */
 typedef struct svt_minigop_part {
     int32_t start, length;          /* pictures [start, start + length) of the group */

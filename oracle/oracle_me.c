@@ -916,6 +916,8 @@ int32_t svt_oracle_me_picture(const svt_pa_picture *cur, const svt_pa_picture *r
         memset(s, 0, sizeof *s);
         s->hb[0] = keep[0]; s->hb[1] = keep[1]; s->hh[0] = keep[2]; s->hh[1] = keep[3]; s->hj[0] = keep[4]; s->hj[1] = keep[5];
         s->hp_stride = hs; s->hp_rows = hr;
+        /* ... and so do the planes themselves: the checker's output must not depend on what an earlier call left in them */
+        for (int k = 0; k < 6; k++) memset(keep[k], 0, (size_t)hs * (size_t)hr);
     }
     int W = cur->full.width, H = cur->full.height;
     int nx = (W + SB - 1) / SB, ny = (H + SB - 1) / SB;

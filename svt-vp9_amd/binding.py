@@ -124,6 +124,28 @@ class MeSbStatsParams(C.Structure):
 ME_SB_STATS_DTYPE = np.dtype([("check1", "u1"), ("pm_check1", "u1"), ("check2", "u1"), ("low_dist_logo", "u1"), ("inter_idx", "<u2"), ("intra_idx", "<u2")])
 assert ME_SB_STATS_DTYPE.itemsize == 8
 
+class TqPicGeom(C.Structure):
+    _fields_ = [("src_off", C.c_uint32 * 3), ("pred_off", C.c_uint32 * 3), ("recon_off", C.c_uint32 * 3), ("src_stride", C.c_uint16 * 2),
+                ("pred_stride", C.c_uint16 * 2), ("recon_stride", C.c_uint16 * 2), ("coeff_base", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32),
+                ("recon_set", C.c_uint8), ("do_recon", C.c_uint8), ("pad", C.c_uint8 * 2)]
+
+
+class EncdecFlagsConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("enc_mode", "tune", "temporal_layer_index", "is_used_as_reference", "recon_file", "loop_filter")]
+
+
+class EncdecFlags(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("limit_intra", "allow_enc_dec_mismatch", "do_recon", "apply_loop_filter", "pad_reference")]
+
+
+class EncdecPicture(C.Structure):
+    _fields_ = [("d_mc_mi", C.c_void_p), ("d_lf_mi", C.c_void_p), ("src", YuvPlanes), ("ref", YuvPlanes * 2), ("pred", YuvPlanes), ("recon", YuvPlanes),
+                ("d_qcoeff", C.c_void_p), ("d_dqcoeff", C.c_void_p), ("d_eob_map", C.c_void_p), ("d_lfm", C.c_void_p), ("d_nz", C.c_void_p),
+                ("use_subpel", C.c_int32)]
+
+
+SB_COEFFS = 6144
+
 # every symbol include/svtvp9_hip.h declares
 EXPORTS = [
     "svt_hip_sb_count", "svt_hip_input_resolution", "svt_hip_me_params_derive", "svt_hip_me_params_preset", "svt_hip_ctx_create", "svt_hip_ctx_create_on_stream", "svt_hip_ctx_create_cu_mask", "svt_hip_ctx_stream",
@@ -138,6 +160,11 @@ EXPORTS = [
     "svt_hip_gop_owner", "svt_hip_gop_assign", "svt_hip_minigop_reference_source", "svt_hip_device_set_create", "svt_hip_device_set_size",
     "svt_hip_device_set_ctx", "svt_hip_device_set_destroy", "svt_hip_ref_handoff_device",
     "svt_ivf_stream_header", "svt_ivf_packetize",
+    "svt_hip_tq_blocks_from_grid", "svt_hip_vp9_iscan_tables", "svt_hip_vp9_qindex_from_qp", "svt_hip_vp9_dc_step", "svt_hip_vp9_ac_step",
+    "svt_hip_quant_tables_for_qindex", "svt_hip_encdec_flags_derive", "svt_hip_encdec_work_create", "svt_hip_encdec_work_destroy",
+    "svt_hip_encdec_batch_device", "svt_hip_encdec_work_status", "svt_hip_encdec_work_download", "svt_hip_md_default_batch_device",
+    "svt_hip_md_default_picture", "svt_hip_lf_build_masks_device", "svt_hip_ctx_wait_marker", "svt_hip_host_alloc", "svt_hip_host_free",
+    "svt_hip_mem_download_2d_async",
 ]
 
 _lib = None
@@ -163,6 +190,10 @@ def load():
         _lib.svt_hip_last_kernel_ms.restype = C.c_float
         _lib.svt_hip_last_kernel_ms.argtypes = [C.c_void_p]
         _lib.svt_hip_lf_thresh_init.restype = None
+        _lib.svt_hip_vp9_iscan_tables.restype = C.POINTER(C.c_int16)
+        _lib.svt_hip_vp9_iscan_tables.argtypes = [C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int32)]
+        _lib.svt_hip_encdec_work_destroy.restype = None
+        _lib.svt_hip_host_free.restype = None
         _lib.svt_hip_lf_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     return _lib
 

@@ -245,3 +245,32 @@ extern "C" int32_t svt_hip_mem_set(svt_hip_ctx *ctx, void *d_dst, int32_t value,
     HIP_TRY(hipMemsetAsync(d_dst, value, bytes, ctx->stream));
     return SVT_HIP_OK;
 }
+
+/* ---- stream-to-stream ordering between contexts, pinned host memory, asynchronous downloads ---- */
+extern "C" int32_t svt_hip_ctx_wait_marker(svt_hip_ctx *ctx, svt_hip_ctx *other, uint64_t marker) {
+    if (!ctx || !other || marker >= other->mk_next) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "wait_marker: unknown");
+    if (other->mk_next - marker > SVT_CTX_MARKERS) return SVT_HIP_OK; /* long complete */
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, other->mk_ev[marker % SVT_CTX_MARKERS], 0));
+    return SVT_HIP_OK;
+}
+extern "C" int32_t svt_hip_host_alloc(svt_hip_ctx *ctx, size_t bytes, void **ptr) {
+    if (!ctx || !ptr || !bytes) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "host_alloc: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (hipHostMalloc(ptr, bytes, hipHostMallocDefault) != hipSuccess) { *ptr = nullptr; return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "host_alloc: pinned memory"); }
+    return SVT_HIP_OK;
+}
+extern "C" void svt_hip_host_free(svt_hip_ctx *ctx, void *ptr) {
+    if (!ctx || !ptr) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipHostFree(ptr);
+}
+extern "C" int32_t svt_hip_mem_download_2d_async(svt_hip_ctx *ctx, void *dst, size_t dst_stride, const void *d_src, size_t src_stride, size_t width_bytes,
+                                                 size_t rows) {
+    if (!ctx || !dst || !d_src || !width_bytes || !rows || dst_stride < width_bytes || src_stride < width_bytes)
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "mem_download_2d: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (dst_stride == width_bytes && src_stride == width_bytes) HIP_TRY(hipMemcpyAsync(dst, d_src, width_bytes * rows, hipMemcpyDeviceToHost, ctx->stream));
+    else HIP_TRY(hipMemcpy2DAsync(dst, dst_stride, d_src, src_stride, width_bytes, rows, hipMemcpyDeviceToHost, ctx->stream));
+    return SVT_HIP_OK;
+}

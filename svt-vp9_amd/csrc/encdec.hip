@@ -1,0 +1,445 @@
+/*
+ * encdec.hip -- picture-level EncDec driver (gfx950): everything the encode pass does with mode decision's output, for a batch of
+ * mutually independent pictures, device resident from the mode-info grid to the padded reference picture.
+ *
+ * Replaces the data path of eb_vp9_enc_dec_kernel behind mode decision (Source/Lib/Codec/EbEncDecProcess.c:5306):
+ *   encode_pass_sb (:3627-4241): inter prediction (:3787-3802)  -> svt_mc_kernel
+ *                                perform_coding_loop per block   -> svt_tq_kernel<N> over lists built here from the grid
+ *                                skip flags (:4069-4098)         -> svt_tq_skip_kernel + svt_skip_update_kernel
+ *   last SB of the picture (:5625-5697): eb_vp9_build_mask_frame -> svt_lf_mask_kernel (device form of svt_hip_lf_build_masks)
+ *                                eb_vp9_loop_filter_frame        -> svt_lf_kernel
+ *                                pad_ref_and_set_flags           -> svt_refpad_kernel
+ * The reference walks SBs and blocks one at a time on the host; here the host only enqueues: the block lists, skip flags and
+ * filter masks are derived on the device from the grid (rules: encdec_core.h, shared with the host forms the CPU tests pin), so a
+ * picture costs no per-block descriptor traffic over PCIe and no host wait between the stages.
+ *
+ * List building is three small kernels: count (one wave per SB, one lane per 8x8 unit; per-SB totals per transform size), an
+ * exclusive scan over [size][picture][SB] (one workgroup), emit (same mapping; a lane's place inside its SB comes from a wave
+ * prefix sum).  The order is deterministic: size, picture, SB raster, unit raster, luma / Cb / Cr -- SB-ordered inside a size, so
+ * the blocks a wave of the transform kernel takes lie next to each other in the planes.  These kernels move a few MB per picture
+ * and are bound by launch latency, not by bandwidth; they exist to keep the chain on the device.
+ */
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include "svt_ctx.h"
+#include "encdec_core.h"
+
+#define ED_MAX_PICS 8
+
+struct svt_encdec_work {
+    int           max_pics, width, height, n_sb, sb_cols, mi_rows, mi_cols;
+    size_t        cap_per_pic;   /* transform blocks of a picture at most: all 4x4 */
+    svt_tq_block *d_blocks;
+    uint32_t     *d_pos;
+    uint16_t     *d_eob;
+    int32_t      *d_counts;      /* [4][max_pics][n_sb], turned into offsets by the scan */
+    int32_t      *d_off_cnt;     /* [8]: first block / number of blocks per size */
+    int32_t      *d_status;      /* != 0: a malformed grid was seen */
+    svt_quant_tables *d_qtabs;   /* [2] luma, chroma of the batch's q index */
+    int16_t      *d_iscan;
+    int           last_pics;
+};
+
+namespace {
+
+struct ed_pic_dev {
+    const svt_me_pu_result *res;    /* stand-in decision only */
+    svt_mc_mode_info       *mc_mi;
+    svt_lf_mode_info       *lf_mi;
+    uint8_t                *nz;
+    uint16_t               *eob_map;
+    svt_lf_mask            *lfm;
+    svt_tq_pic_geom         g;
+};
+struct ed_batch_dev {
+    ed_pic_dev pic[ED_MAX_PICS];
+    uint32_t   iscan_off[16];
+    int32_t    n_pics, n_sb, sb_cols, mi_rows, mi_cols, mi_stride, width, height;
+    uint32_t   lambda;
+    int32_t    filter_level;
+};
+
+__device__ __forceinline__ int wave_sum(int v) {
+    _Pragma("unroll") for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_excl_prefix(int v, int lane) {
+    int incl = v;
+    _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    return incl - v;
+}
+
+/* one wave per (picture, SB), one lane per 8x8 unit: per-SB number of transform blocks of each size; also clears the unit's
+ * "has coefficients" scratch byte for the skip pass */
+__global__ __launch_bounds__(64) void svt_tq_count_kernel(const ed_batch_dev *__restrict__ B, int32_t *__restrict__ counts, int32_t *__restrict__ status) {
+    const int sb = (int)blockIdx.x % B->n_sb, pic = (int)blockIdx.x / B->n_sb, lane = (int)threadIdx.x;
+    const ed_pic_dev &P = B->pic[pic];
+    const int ur = (sb / B->sb_cols) * 8 + (lane >> 3), uc = (sb % B->sb_cols) * 8 + (lane & 7);
+    int cnt[4] = {0, 0, 0, 0};
+    if (ur < B->mi_rows && uc < B->mi_cols) P.nz[ur * B->mi_stride + uc] = 0;
+    const int o = svt_tq_unit_is_origin(P.lf_mi, B->mi_stride, B->mi_rows, B->mi_cols, ur, uc);
+    if (o < 0) atomicOr(status, 1);
+    if (o == 1) svt_tq_unit_counts(P.lf_mi, B->mi_stride, ur, uc, cnt);
+    _Pragma("unroll") for (int s = 0; s < 4; s++) {
+        const int v = wave_sum(cnt[s]);
+        if (lane == 0) counts[(s * B->n_pics + pic) * B->n_sb + sb] = v;
+    }
+}
+
+/* exclusive scan of a[0..M) in place by one workgroup; off_cnt[s] = a[s * group] after the scan (first block of size s),
+ * off_cnt[4 + s] = number of blocks of size s */
+__global__ __launch_bounds__(1024) void svt_scan_kernel(int32_t *__restrict__ a, int M, int group, int32_t *__restrict__ off_cnt) {
+    __shared__ int32_t part[1024];
+    const int t = (int)threadIdx.x, per = (M + 1023) / 1024, b = t * per, e = b + per < M ? b + per : M;
+    int s = 0;
+    for (int i = b; i < e; i++) s += a[i];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int i = b; i < e; i++) { const int v = a[i]; a[i] = run; run += v; }
+    __syncthreads();
+    if (t < 4) {
+        const int first = a[t * group], next = t < 3 ? a[(t + 1) * group] : part[1023];
+        off_cnt[t] = first;
+        off_cnt[4 + t] = next - first;
+    }
+}
+
+/* same mapping as the count kernel: every block-origin lane writes its descriptors at offsets[size][picture][SB] + (blocks of that
+ * size of the lanes before it) */
+__global__ __launch_bounds__(64) void svt_tq_emit_kernel(const ed_batch_dev *__restrict__ B, const int32_t *__restrict__ offsets, svt_tq_block *__restrict__ blocks,
+                                                         uint32_t *__restrict__ pos) {
+    const int sb = (int)blockIdx.x % B->n_sb, pic = (int)blockIdx.x / B->n_sb, lane = (int)threadIdx.x;
+    const ed_pic_dev &P = B->pic[pic];
+    const int ur = (sb / B->sb_cols) * 8 + (lane >> 3), uc = (sb % B->sb_cols) * 8 + (lane & 7);
+    int cnt[4] = {0, 0, 0, 0};
+    const int o = svt_tq_unit_is_origin(P.lf_mi, B->mi_stride, B->mi_rows, B->mi_cols, ur, uc);
+    if (o == 1) svt_tq_unit_counts(P.lf_mi, B->mi_stride, ur, uc, cnt);
+    uint32_t base[4];
+    _Pragma("unroll") for (int s = 0; s < 4; s++) base[s] = (uint32_t)(offsets[(s * B->n_pics + pic) * B->n_sb + sb] + wave_excl_prefix(cnt[s], lane));
+    if (o == 1) svt_tq_unit_emit(P.lf_mi, B->mi_stride, ur, uc, &P.g, B->iscan_off, base, blocks, pos);
+}
+
+/* after the transform stage: the eob of every block goes to its place in the picture's eob map, and a block with coefficients marks
+ * the prediction block it belongs to (the skip flag of the reference is "no coefficient in any transform block of the block",
+ * Codec/EbEncDecProcess.c:4069-4098; the four 4x4 quadrants of a sub-8x8 unit share one flag the same way) */
+__global__ __launch_bounds__(256) void svt_tq_skip_kernel(const ed_batch_dev *__restrict__ B, const int32_t *__restrict__ off_cnt, const uint32_t *__restrict__ pos,
+                                                          const uint16_t *__restrict__ eob) {
+    const int total = off_cnt[3] + off_cnt[7];
+    const int w4 = B->width >> 2, h4 = B->height >> 2;
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < total; i += (int)(gridDim.x * blockDim.x)) {
+        const uint32_t p = pos[i];
+        const int      pic = (int)(p >> 28) & 7, plane = (int)(p >> 26) & 3, y4 = (int)(p >> 13) & 0x1fff, x4 = (int)p & 0x1fff;
+        const ed_pic_dev &P = B->pic[pic];
+        const int      e = eob[i];
+        const int      pw4 = plane ? w4 >> 1 : w4;
+        const int      off = plane == 0 ? 0 : w4 * h4 + (plane == 2 ? (w4 >> 1) * (h4 >> 1) : 0);
+        P.eob_map[off + y4 * pw4 + x4] = (uint16_t)e;
+        if (e) {
+            const int uy = plane ? y4 : y4 >> 1, ux = plane ? x4 : x4 >> 1;
+            const svt_lf_mode_info b = P.lf_mi[uy * B->mi_stride + ux];
+            const int w8 = svt_blk_w8(b.sb_type), h8 = svt_blk_h8(b.sb_type);
+            P.nz[(uy - uy % h8) * B->mi_stride + (ux - ux % w8)] = 1;
+        }
+    }
+}
+/* every unit takes the skip flag of its block */
+__global__ __launch_bounds__(256) void svt_skip_update_kernel(const ed_batch_dev *__restrict__ B) {
+    const int units = B->mi_rows * B->mi_cols;
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= units * B->n_pics) return;
+    const int pic = i / units, u = i % units, ur = u / B->mi_cols, uc = u % B->mi_cols;
+    const ed_pic_dev &P = B->pic[pic];
+    svt_lf_mode_info *b = &P.lf_mi[ur * B->mi_stride + uc];
+    if (b->sb_type > 12) return;
+    const int w8 = svt_blk_w8(b->sb_type), h8 = svt_blk_h8(b->sb_type);
+    b->skip = P.nz[(ur - ur % h8) * B->mi_stride + (uc - uc % w8)] ? 0 : 1;
+}
+
+/* one thread per (picture, SB): its LOOP_FILTER_MASK (the rule of svt_hip_lf_build_masks, same text) */
+__global__ __launch_bounds__(64) void svt_lf_mask_kernel(const ed_batch_dev *__restrict__ B, int32_t *__restrict__ status) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= B->n_sb * B->n_pics) return;
+    const int pic = i / B->n_sb, sb = i % B->n_sb;
+    const ed_pic_dev &P = B->pic[pic];
+    if (svt_lf_mask_build_sb(P.lf_mi, B->mi_stride, B->mi_rows, B->mi_cols, sb / B->sb_cols, sb % B->sb_cols, &P.lfm[sb]) && status) atomicOr(status, 1);
+}
+
+/* stand-in decision: one wave per (picture, SB), one lane per unit */
+__global__ __launch_bounds__(64) void svt_md_default_kernel(const ed_batch_dev *__restrict__ B) {
+    const int sb = (int)blockIdx.x % B->n_sb, pic = (int)blockIdx.x / B->n_sb, lane = (int)threadIdx.x;
+    const ed_pic_dev &P = B->pic[pic];
+    const int r = lane >> 3, c = lane & 7, sr = sb / B->sb_cols, sc = sb % B->sb_cols, ur = sr * 8 + r, uc = sc * 8 + c;
+    if (ur >= B->mi_rows || uc >= B->mi_cols) return;
+    svt_md_default_unit(P.res + (size_t)sb * SVT_ME_PU_COUNT, r, c, sr, sc, B->mi_rows, B->mi_cols, B->lambda, B->filter_level, &P.mc_mi[ur * B->mi_stride + uc],
+                        &P.lf_mi[ur * B->mi_stride + uc]);
+}
+
+/* the batch's parameter block goes to the device through the context's descriptor ring; the slot is committed at once: every
+ * consumer is enqueued on the same stream behind the copy, and a later re-use of the slot is a copy on that stream too */
+int stage_batch(svt_hip_ctx *ctx, const ed_batch_dev &hb, const ed_batch_dev **d_out) {
+    void *h = nullptr, *d = nullptr;
+    if (svt_ctx_stage(ctx, sizeof hb, &h, &d)) return -1;
+    memcpy(h, &hb, sizeof hb);
+    if (hipMemcpyAsync(d, h, sizeof hb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return -1;
+    svt_ctx_stage_commit(ctx);
+    *d_out = (const ed_batch_dev *)d;
+    return 0;
+}
+
+void fill_dims(ed_batch_dev &hb, int n_pics, int width, int height, int mi_stride) {
+    hb.n_pics = n_pics; hb.width = width; hb.height = height;
+    hb.sb_cols = (width + 63) >> 6;
+    hb.n_sb = hb.sb_cols * ((height + 63) >> 6);
+    hb.mi_rows = height >> 3; hb.mi_cols = width >> 3; hb.mi_stride = mi_stride;
+}
+
+} // namespace
+
+extern "C" int32_t svt_hip_encdec_work_create(svt_hip_ctx *ctx, int32_t max_pics, int32_t width, int32_t height, svt_encdec_work **out) {
+    if (!ctx || !out || max_pics < 1 || max_pics > ED_MAX_PICS || width < 8 || height < 8 || (width & 7) || (height & 7))
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec_work: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    svt_encdec_work *w = (svt_encdec_work *)calloc(1, sizeof *w);
+    if (!w) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "encdec_work: malloc");
+    w->max_pics = max_pics; w->width = width; w->height = height;
+    w->sb_cols = (width + 63) >> 6; w->n_sb = w->sb_cols * ((height + 63) >> 6);
+    w->mi_rows = height >> 3; w->mi_cols = width >> 3;
+    w->cap_per_pic = (size_t)width * height * 3 / 32;
+    const size_t cap = w->cap_per_pic * (size_t)max_pics;
+    uint32_t const *offs = nullptr;
+    int32_t         entries = 0;
+    const int16_t  *isc = svt_hip_vp9_iscan_tables(&offs, &entries);
+    bool ok = hipMalloc((void **)&w->d_blocks, cap * sizeof(svt_tq_block)) == hipSuccess && hipMalloc((void **)&w->d_pos, cap * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void **)&w->d_eob, cap * sizeof(uint16_t)) == hipSuccess &&
+              hipMalloc((void **)&w->d_counts, ((size_t)4 * max_pics * w->n_sb + 16) * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void **)&w->d_qtabs, 2 * sizeof(svt_quant_tables)) == hipSuccess && hipMalloc((void **)&w->d_iscan, (size_t)entries * sizeof(int16_t)) == hipSuccess;
+    if (ok) {
+        w->d_off_cnt = w->d_counts + (size_t)4 * max_pics * w->n_sb;
+        w->d_status = w->d_off_cnt + 8;
+        ok = hipMemsetAsync(w->d_off_cnt, 0, 16 * sizeof(int32_t), ctx->stream) == hipSuccess &&
+             hipMemcpyAsync(w->d_iscan, isc, (size_t)entries * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
+    if (!ok) {
+        svt_hip_encdec_work_destroy(ctx, w);
+        return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "encdec_work: device memory");
+    }
+    *out = w;
+    return SVT_HIP_OK;
+}
+
+extern "C" void svt_hip_encdec_work_destroy(svt_hip_ctx *ctx, svt_encdec_work *w) {
+    if (!w) return;
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    void *v[6] = {w->d_blocks, w->d_pos, w->d_eob, w->d_counts, w->d_qtabs, w->d_iscan};
+    for (int i = 0; i < 6; i++) if (v[i]) (void)hipFree(v[i]);
+    free(w);
+}
+
+extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work *w, int32_t n_pics, const svt_encdec_picture *pics, int32_t width,
+                                               int32_t height, int32_t mi_stride, int32_t q_index, const svt_encdec_flags *flags, const svt_lf_thresh *thr,
+                                               int32_t pad_x, int32_t pad_y) {
+    if (!ctx || !w || !pics || !flags || n_pics < 1 || n_pics > w->max_pics || width != w->width || height != w->height || mi_stride < (width >> 3))
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: bad argument");
+    if (flags->apply_loop_filter && !thr) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: loop filter without thresholds");
+    HIP_TRY(hipSetDevice(ctx->device));
+    /* one 32-bit offset space for the source planes and one for the prediction planes of the batch */
+    uintptr_t src_lo = UINTPTR_MAX, src_hi = 0, pred_lo = UINTPTR_MAX, pred_hi = 0;
+    for (int i = 0; i < n_pics; i++) {
+        const svt_encdec_picture &p = pics[i];
+        if (!p.d_mc_mi || !p.d_lf_mi || !p.src.y || !p.src.u || !p.src.v || !p.pred.y || !p.pred.u || !p.pred.v || !p.recon.y || !p.recon.u || !p.recon.v ||
+            !p.d_qcoeff || !p.d_dqcoeff || !p.d_eob_map || !p.d_nz || (flags->apply_loop_filter && !p.d_lfm))
+            return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: null picture field");
+        if (((uintptr_t)p.d_qcoeff | (uintptr_t)p.d_dqcoeff) & 15) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: coefficient arrays must be 16-byte aligned");
+        const uint8_t *s3[3] = {p.src.y, p.src.u, p.src.v}, *p3[3] = {p.pred.y, p.pred.u, p.pred.v};
+        for (int k = 0; k < 3; k++) {
+            src_lo = (uintptr_t)s3[k] < src_lo ? (uintptr_t)s3[k] : src_lo; src_hi = (uintptr_t)s3[k] > src_hi ? (uintptr_t)s3[k] : src_hi;
+            pred_lo = (uintptr_t)p3[k] < pred_lo ? (uintptr_t)p3[k] : pred_lo; pred_hi = (uintptr_t)p3[k] > pred_hi ? (uintptr_t)p3[k] : pred_hi;
+        }
+    }
+    const uint64_t plane_span = (uint64_t)width * height * 2; /* generous: stride x rows of the largest plane */
+    if ((uint64_t)(src_hi - src_lo) + plane_span >= (1ull << 32) || (uint64_t)(pred_hi - pred_lo) + plane_span >= (1ull << 32))
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: the batch's source / prediction planes must lie within 4 GB");
+    /* coefficient arrays: one base for the batch as well (element offsets are 32 bit) */
+    uintptr_t q_lo = UINTPTR_MAX, dq_lo = UINTPTR_MAX;
+    for (int i = 0; i < n_pics; i++) {
+        q_lo = (uintptr_t)pics[i].d_qcoeff < q_lo ? (uintptr_t)pics[i].d_qcoeff : q_lo;
+        dq_lo = (uintptr_t)pics[i].d_dqcoeff < dq_lo ? (uintptr_t)pics[i].d_dqcoeff : dq_lo;
+    }
+    ed_batch_dev hb;
+    memset(&hb, 0, sizeof hb);
+    fill_dims(hb, n_pics, width, height, mi_stride);
+    {
+        const uint32_t *offs = nullptr;
+        (void)svt_hip_vp9_iscan_tables(&offs, nullptr);
+        for (int i = 0; i < 16; i++) hb.iscan_off[i] = offs[i];
+    }
+    uint8_t       *recon_set[ED_MAX_PICS];
+    svt_mc_picture mcp[ED_MAX_PICS];
+    svt_yuv_planes rec[ED_MAX_PICS];
+    const svt_lf_mask *lfm[ED_MAX_PICS];
+    int32_t        lfm_stride[ED_MAX_PICS], mi_rows_a[ED_MAX_PICS], mi_cols_a[ED_MAX_PICS];
+    for (int i = 0; i < n_pics; i++) {
+        const svt_encdec_picture &p = pics[i];
+        ed_pic_dev &P = hb.pic[i];
+        P.mc_mi = (svt_mc_mode_info *)p.d_mc_mi; P.lf_mi = p.d_lf_mi; P.nz = p.d_nz; P.eob_map = p.d_eob_map; P.lfm = p.d_lfm;
+        const uintptr_t q_off = ((uintptr_t)p.d_qcoeff - q_lo) / sizeof(int16_t), dq_off = ((uintptr_t)p.d_dqcoeff - dq_lo) / sizeof(int16_t);
+        if (q_off != dq_off || q_off + (uint64_t)hb.n_sb * SVT_SB_COEFFS >= (1ull << 32))
+            return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: qcoeff / dqcoeff of the batch must be laid out alike, within 2^32 elements");
+        uint8_t *rb = p.recon.y < p.recon.u ? p.recon.y : p.recon.u;
+        rb = rb < p.recon.v ? rb : p.recon.v;
+        recon_set[i] = rb;
+        svt_tq_pic_geom &g = P.g;
+        const uint8_t *s3[3] = {p.src.y, p.src.u, p.src.v}, *p3[3] = {p.pred.y, p.pred.u, p.pred.v}, *r3[3] = {p.recon.y, p.recon.u, p.recon.v};
+        for (int k = 0; k < 3; k++) {
+            g.src_off[k] = (uint32_t)((uintptr_t)s3[k] - src_lo); g.pred_off[k] = (uint32_t)((uintptr_t)p3[k] - pred_lo);
+            const uint64_t ro = (uint64_t)((uintptr_t)r3[k] - (uintptr_t)rb);
+            if (ro + plane_span >= (1ull << 32)) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: reconstruction planes too far apart");
+            g.recon_off[k] = (uint32_t)ro;
+        }
+        if (p.src.y_stride > 65535 || p.pred.y_stride > 65535 || p.recon.y_stride > 65535) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: stride");
+        g.src_stride[0] = (uint16_t)p.src.y_stride; g.src_stride[1] = (uint16_t)p.src.uv_stride;
+        g.pred_stride[0] = (uint16_t)p.pred.y_stride; g.pred_stride[1] = (uint16_t)p.pred.uv_stride;
+        g.recon_stride[0] = (uint16_t)p.recon.y_stride; g.recon_stride[1] = (uint16_t)p.recon.uv_stride;
+        g.coeff_base = (uint32_t)q_off; g.width = width; g.height = height; g.recon_set = (uint8_t)i; g.do_recon = flags->do_recon ? 1 : 0;
+        mcp[i].d_mi = p.d_mc_mi; mcp[i].mi_stride = mi_stride; mcp[i].mi_rows = hb.mi_rows; mcp[i].mi_cols = hb.mi_cols;
+        mcp[i].ref[0] = p.ref[0]; mcp[i].ref[1] = p.ref[1]; mcp[i].pred = p.pred; mcp[i].use_subpel = p.use_subpel;
+        rec[i] = p.recon; rec[i].width = width; rec[i].height = height;
+        lfm[i] = p.d_lfm; lfm_stride[i] = hb.sb_cols; mi_rows_a[i] = hb.mi_rows; mi_cols_a[i] = hb.mi_cols;
+    }
+    const ed_batch_dev *dB = nullptr;
+    if (stage_batch(ctx, hb, &dB)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "encdec: descriptor buffers");
+    /* quantiser tables of the q index */
+    {
+        svt_quant_tables qt[2];
+        if (svt_hip_quant_tables_for_qindex(q_index, qt) != SVT_HIP_OK) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: q index");
+        void *h = nullptr, *d = nullptr;
+        if (svt_ctx_stage(ctx, sizeof qt, &h, &d)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "encdec: descriptor buffers");
+        memcpy(h, qt, sizeof qt);
+        HIP_TRY(hipMemcpyAsync(w->d_qtabs, h, sizeof qt, hipMemcpyHostToDevice, ctx->stream));
+        svt_ctx_stage_commit(ctx);
+    }
+    /* 1. inter prediction of the whole batch */
+    int32_t rc = svt_hip_inter_pred_batch_device(ctx, n_pics, mcp);
+    if (rc) return rc;
+    /* 2. transform blocks from the grids */
+    const int nwg = n_pics * hb.n_sb, M = 4 * n_pics * hb.n_sb;
+    hipLaunchKernelGGL(svt_tq_count_kernel, dim3(nwg), dim3(64), 0, ctx->stream, dB, w->d_counts, w->d_status);
+    hipLaunchKernelGGL(svt_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, w->d_counts, M, n_pics * hb.n_sb, w->d_off_cnt);
+    hipLaunchKernelGGL(svt_tq_emit_kernel, dim3(nwg), dim3(64), 0, ctx->stream, dB, (const int32_t *)w->d_counts, w->d_blocks, w->d_pos);
+    HIP_TRY(hipGetLastError());
+    /* 3. residual -> transform -> quantisation (-> inverse -> reconstruction) */
+    int32_t cap[4];
+    for (int s = 0; s < 4; s++) cap[s] = (int32_t)((size_t)n_pics * width * height * 3 / 2 / (size_t)(16 << (2 * s)));
+    rc = svt_tq_launch_device_lists(ctx, (const uint8_t *)src_lo, (const uint8_t *)pred_lo, recon_set, n_pics, w->d_blocks, cap, w->d_off_cnt, w->d_qtabs, w->d_iscan,
+                                    (int16_t *)q_lo, (int16_t *)dq_lo, w->d_eob, nullptr);
+    if (rc) return rc;
+    /* 4. eob map + skip flags */
+    {
+        const int total_cap = (int)(w->cap_per_pic * (size_t)n_pics);
+        int       g = (total_cap + 255) / 256;
+        if (g > ctx->cu_count * 8) g = ctx->cu_count * 8;
+        hipLaunchKernelGGL(svt_tq_skip_kernel, dim3(g), dim3(256), 0, ctx->stream, dB, (const int32_t *)w->d_off_cnt, (const uint32_t *)w->d_pos, (const uint16_t *)w->d_eob);
+        hipLaunchKernelGGL(svt_skip_update_kernel, dim3((n_pics * hb.mi_rows * hb.mi_cols + 255) / 256), dim3(256), 0, ctx->stream, dB);
+        HIP_TRY(hipGetLastError());
+    }
+    /* 5. deblocking */
+    if (flags->apply_loop_filter) {
+        hipLaunchKernelGGL(svt_lf_mask_kernel, dim3((nwg + 63) / 64), dim3(64), 0, ctx->stream, dB, w->d_status);
+        HIP_TRY(hipGetLastError());
+        rc = svt_hip_lf_batch_device(ctx, n_pics, rec, lfm, lfm_stride, thr, mi_rows_a, mi_cols_a, 0);
+        if (rc) return rc;
+    }
+    /* 6. the reconstruction becomes a reference picture */
+    if (flags->pad_reference) {
+        rc = svt_hip_ref_pad_batch_device(ctx, n_pics, rec, pad_x, pad_y);
+        if (rc) return rc;
+    }
+    w->last_pics = n_pics;
+    return SVT_HIP_OK;
+}
+
+extern "C" int32_t svt_hip_encdec_work_status(svt_hip_ctx *ctx, svt_encdec_work *w, int32_t counts[8]) {
+    if (!ctx || !w) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec_status: null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int32_t h[9];
+    HIP_TRY(hipMemcpyAsync(h, w->d_off_cnt, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (counts) memcpy(counts, h, 8 * sizeof(int32_t));
+    if (h[8]) {
+        HIP_TRY(hipMemsetAsync(w->d_status, 0, sizeof(int32_t), ctx->stream));
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: malformed mode-info grid (block outside the picture, misaligned, or transform larger than its block)");
+    }
+    return SVT_HIP_OK;
+}
+
+extern "C" int32_t svt_hip_encdec_work_download(svt_hip_ctx *ctx, svt_encdec_work *w, svt_tq_block *blocks, uint32_t *pos, uint16_t *eob, int32_t capacity) {
+    int32_t c[8];
+    const int32_t rc = svt_hip_encdec_work_status(ctx, w, c);
+    if (rc) return rc;
+    const int32_t total = c[3] + c[7];
+    if (total > capacity) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "encdec_download: capacity");
+    if (total > 0) {
+        if (blocks) HIP_TRY(hipMemcpyAsync(blocks, w->d_blocks, (size_t)total * sizeof(svt_tq_block), hipMemcpyDeviceToHost, ctx->stream));
+        if (pos) HIP_TRY(hipMemcpyAsync(pos, w->d_pos, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (eob) HIP_TRY(hipMemcpyAsync(eob, w->d_eob, (size_t)total * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return total;
+}
+
+extern "C" int32_t svt_hip_md_default_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_me_pu_result *const *d_results, int32_t width, int32_t height,
+                                                   uint32_t lambda, int32_t filter_level, svt_mc_mode_info *const *d_mc_mi, svt_lf_mode_info *const *d_lf_mi,
+                                                   int32_t mi_stride) {
+    if (!ctx || n_pics < 1 || !d_results || !d_mc_mi || !d_lf_mi || width < 8 || height < 8 || (width & 7) || (height & 7) || mi_stride < (width >> 3))
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "md_default: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (int first = 0; first < n_pics; first += ED_MAX_PICS) {
+        const int n = n_pics - first < ED_MAX_PICS ? n_pics - first : ED_MAX_PICS;
+        ed_batch_dev hb;
+        memset(&hb, 0, sizeof hb);
+        fill_dims(hb, n, width, height, mi_stride);
+        hb.lambda = lambda; hb.filter_level = filter_level;
+        for (int i = 0; i < n; i++) {
+            if (!d_results[first + i] || !d_mc_mi[first + i] || !d_lf_mi[first + i]) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "md_default: null picture");
+            hb.pic[i].res = d_results[first + i]; hb.pic[i].mc_mi = d_mc_mi[first + i]; hb.pic[i].lf_mi = d_lf_mi[first + i];
+        }
+        const ed_batch_dev *dB = nullptr;
+        if (stage_batch(ctx, hb, &dB)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "md_default: descriptor buffers");
+        hipLaunchKernelGGL(svt_md_default_kernel, dim3(n * hb.n_sb), dim3(64), 0, ctx->stream, dB);
+        HIP_TRY(hipGetLastError());
+    }
+    return SVT_HIP_OK;
+}
+
+extern "C" int32_t svt_hip_lf_build_masks_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_lf_mode_info *const *d_lf_mi, int32_t mi_stride, int32_t mi_rows,
+                                                 int32_t mi_cols, svt_lf_mask *const *d_lfm) {
+    if (!ctx || n_pics < 1 || !d_lf_mi || !d_lfm || mi_rows < 1 || mi_cols < 1 || mi_stride < mi_cols) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "lf_masks: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (int first = 0; first < n_pics; first += ED_MAX_PICS) {
+        const int n = n_pics - first < ED_MAX_PICS ? n_pics - first : ED_MAX_PICS;
+        ed_batch_dev hb;
+        memset(&hb, 0, sizeof hb);
+        fill_dims(hb, n, mi_cols * 8, mi_rows * 8, mi_stride);
+        for (int i = 0; i < n; i++) {
+            if (!d_lf_mi[first + i] || !d_lfm[first + i]) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "lf_masks: null picture");
+            hb.pic[i].lf_mi = (svt_lf_mode_info *)d_lf_mi[first + i]; hb.pic[i].lfm = d_lfm[first + i];
+        }
+        const ed_batch_dev *dB = nullptr;
+        if (stage_batch(ctx, hb, &dB)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "lf_masks: descriptor buffers");
+        hipLaunchKernelGGL(svt_lf_mask_kernel, dim3((n * hb.n_sb + 63) / 64), dim3(64), 0, ctx->stream, dB, (int32_t *)nullptr);
+        HIP_TRY(hipGetLastError());
+    }
+    return SVT_HIP_OK;
+}

@@ -58,6 +58,11 @@ void   *svt_ctx_slot(svt_hip_ctx *ctx, int slot, size_t bytes);
 /* creates the helper streams on first use (same priority as the context's stream); returns 0 on success */
 int     svt_ctx_aux_init(svt_hip_ctx *ctx);
 
+/* transform stage over device-built block lists (tq_kernel.hip; used by encdec.hip) */
+int32_t svt_tq_launch_device_lists(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *const *recon_set, int n_set,
+                                   const svt_tq_block *d_blocks, const int32_t cap[4], const int32_t *d_off_cnt, const svt_quant_tables *d_qtabs,
+                                   const int16_t *d_iscan, int16_t *d_qcoeff, int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist);
+
 #define HIP_TRY(expr)                                                        \
     do {                                                                     \
         hipError_t e_ = (expr);                                              \

@@ -33,6 +33,10 @@ struct tq_rate_args {
     int32_t               *bits; /* out, per block */
 };
 
+/* Block lists built on the device (csrc/encdec.hip): the launch is sized for the list's capacity on the host, the actual offset and
+ * number of blocks of this transform size are read from device memory: p[s] = first block of size s, p[4 + s] = how many. */
+struct tq_dev_count { const int32_t *p; int s; };
+
 /* Workgroups are persistent and XCD-aware: workgroup w runs on XCD w & 7 (round-robin dispatch), and the groups of blocks it
  * walks are a contiguous eighth of the batch -- neighbouring blocks (which share 64-byte lines of the planes: a 4x4 block's
  * row is 4 bytes) are then fetched into ONE XCD's L2 instead of two. */
@@ -149,7 +153,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 3
                                                      int n_blocks, const svt_quant_tables *__restrict__ qtabs,
                                                      const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,
                                                      int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out,
-                                                     uint64_t *__restrict__ dist_out, tq_rate_args ra, const uint8_t *const *__restrict__ recon_set) {
+                                                     uint64_t *__restrict__ dist_out, tq_rate_args ra, const uint8_t *const *__restrict__ recon_set, tq_dev_count dc) {
+    if (dc.p) { /* device-built list: where this size's blocks start and how many there are */
+        const int o = dc.p[dc.s];
+        n_blocks = dc.p[4 + dc.s];
+        blocks += o; eob_out += o;
+        if (dist_out) dist_out += 2 * o;
+        if constexpr (RATE) ra.bits += o;
+    }
     constexpr int NT  = tq_threads<N, RATE>();
     constexpr int BPW = NT / N;           /* blocks per workgroup */
     constexpr int LS  = N + 1;            /* padded LDS row stride in dwords */
@@ -428,7 +439,14 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
                                                           int n_blocks, const svt_quant_tables *__restrict__ qtabs,
                                                           const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,
                                                           int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out,
-                                                          uint64_t *__restrict__ dist_out, tq_rate_args ra, const uint8_t *const *__restrict__ recon_set) {
+                                                          uint64_t *__restrict__ dist_out, tq_rate_args ra, const uint8_t *const *__restrict__ recon_set, tq_dev_count dc) {
+    if (dc.p) {
+        const int o = dc.p[dc.s];
+        n_blocks = dc.p[4 + dc.s];
+        blocks += o; eob_out += o;
+        if (dist_out) dist_out += 2 * o;
+        if constexpr (RATE) ra.bits += o;
+    }
     static_assert(N == 4 || N == 8, "block-per-lane form: 4x4 and 8x8 only");
     static_assert(!RATE || N == 4, "in-lane rate: 4x4 only");
     constexpr int ND = N / 4; /* dwords per row of samples */
@@ -615,19 +633,19 @@ int tq_grid(svt_hip_ctx *ctx, int ngroups, int per_cu) {
 template <int N, bool RATE>
 hipError_t launch_tq(svt_hip_ctx *ctx, hipStream_t st, const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks, int n,
                      const svt_quant_tables *q, const int16_t *iscan, int16_t *qc, int16_t *dqc, uint16_t *eob, uint64_t *dist, tq_rate_args ra,
-                     const uint8_t *const *recon_set) {
+                     const uint8_t *const *recon_set, tq_dev_count dc = {nullptr, 0}) {
     if (n <= 0) return hipSuccess;
     /* block per lane for 4x4 only: the 8x8 instance is bit-exact too but needs 201 VGPRs (64 samples + the transposed
      * intermediate live in one lane; 87 spills when held to 128) -- two waves per SIMD, and each displaces two ME waves:
      * the overlapped step went from 3.27 to 3.77 ms with it, so 8x8 stays on the N-lanes-per-block kernel */
     if constexpr (N == 4) {
         hipLaunchKernelGGL((svt_tq_lane_kernel<N, RATE>), dim3(tq_grid(ctx, (n + 255) / 256, 6)), dim3(256), 0, st, src, pred, recon, blocks, n, q,
-                           iscan, qc, dqc, eob, dist, ra, recon_set);
+                           iscan, qc, dqc, eob, dist, ra, recon_set, dc);
         return hipGetLastError();
     } else {
         constexpr int NT = tq_threads<N, RATE>(), BPW = NT / N;
         hipLaunchKernelGGL((svt_tq_kernel<N, RATE>), dim3(tq_grid(ctx, (n + BPW - 1) / BPW, 6)), dim3(NT), 0, st, src, pred, recon, blocks, n, q,
-                           iscan, qc, dqc, eob, dist, ra, recon_set);
+                           iscan, qc, dqc, eob, dist, ra, recon_set, dc);
         return hipGetLastError();
     }
 }
@@ -680,6 +698,28 @@ int32_t tq_launch_all(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_p
     return SVT_HIP_OK;
 }
 } // namespace
+
+/* Transform stage over block lists that were built ON THE DEVICE (csrc/encdec.hip): d_off_cnt[s] / d_off_cnt[4 + s] = first block and
+ * number of blocks of size s inside d_blocks / d_eob; cap[s] = an upper bound known to the host, which only sizes the persistent
+ * grids.  No rate, optional distortion.  Internal to the library (declared in svt_ctx.h). */
+int32_t svt_tq_launch_device_lists(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *const *recon_set, int n_set,
+                                   const svt_tq_block *d_blocks, const int32_t cap[4], const int32_t *d_off_cnt, const svt_quant_tables *d_qtabs,
+                                   const int16_t *d_iscan, int16_t *d_qcoeff, int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    void *h = nullptr, *d = nullptr;
+    if (svt_ctx_stage(ctx, 8 * sizeof(void *), &h, &d)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "tq: descriptor buffers");
+    for (int i = 0; i < 8; i++) ((uint8_t **)h)[i] = recon_set[i < n_set ? i : 0];
+    HIP_TRY(hipMemcpyAsync(d, h, 8 * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    const uint8_t *const *d_set = (const uint8_t *const *)d;
+    const tq_rate_args none = {nullptr, nullptr, nullptr};
+    hipError_t rc = launch_tq<4, false>(ctx, ctx->stream, d_src, d_pred, nullptr, d_blocks, cap[0], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob, d_dist, none, d_set, tq_dev_count{d_off_cnt, 0});
+    if (rc == hipSuccess) rc = launch_tq<8, false>(ctx, ctx->stream, d_src, d_pred, nullptr, d_blocks, cap[1], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob, d_dist, none, d_set, tq_dev_count{d_off_cnt, 1});
+    if (rc == hipSuccess) rc = launch_tq<16, false>(ctx, ctx->stream, d_src, d_pred, nullptr, d_blocks, cap[2], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob, d_dist, none, d_set, tq_dev_count{d_off_cnt, 2});
+    if (rc == hipSuccess) rc = launch_tq<32, false>(ctx, ctx->stream, d_src, d_pred, nullptr, d_blocks, cap[3], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob, d_dist, none, d_set, tq_dev_count{d_off_cnt, 3});
+    svt_ctx_stage_commit(ctx);
+    if (rc != hipSuccess) return svt_set_hip_error(rc, __FILE__, __LINE__);
+    return SVT_HIP_OK;
+}
 
 /* Blocks must be grouped by transform size: size_count[s] blocks of SVT_TX_<s>, in the order 4x4, 8x8, 16x16,
  * 32x32, and within a size all blocks must share the same do_recon flag (the encode pass reconstructs every

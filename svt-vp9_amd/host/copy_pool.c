@@ -5,6 +5,10 @@
  * is what bounds the public API's picture rate.  The reference's own input path is multi-threaded as well (resource coordination
  * and picture analysis run in their own threads).  A process-wide fork-join pool, created on first use; SVT_HIP_COPY_THREADS
  * (default 4, 1 = copy in the calling thread).  Plain C, pthreads.
+ * Lifetime: the workers are joinable and are stopped and joined when the library is unloaded (destructor below), so a dlclose
+ * leaves no thread running on unmapped code; a fork() child starts without workers (they do not exist there) and copies in the
+ * calling thread.  One fork-join at a time: callers of different contexts take turns (a copy saturates the memory controllers
+ * of its socket anyway).
  */
 #include <pthread.h>
 #include <stdint.h>
@@ -20,11 +24,12 @@ static struct {
     pthread_t       th[POOL_MAX];
     int             n;         /* workers besides the caller */
     unsigned long   gen;       /* job generation */
+    int             stop;      /* set by the destructor: workers leave */
     int             pending;
     uint8_t        *dst;
     const uint8_t  *src;
     size_t          dst_stride, src_stride, width, rows;
-} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, {0}, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, {0}, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;
 
 static void copy_slice(int part, int parts) {
@@ -40,7 +45,8 @@ static void *worker(void *arg) {
     unsigned long seen = 0;
     for (;;) {
         pthread_mutex_lock(&g_pool.lock);
-        while (g_pool.gen == seen) pthread_cond_wait(&g_pool.go, &g_pool.lock);
+        while (g_pool.gen == seen && !g_pool.stop) pthread_cond_wait(&g_pool.go, &g_pool.lock);
+        if (g_pool.stop) { pthread_mutex_unlock(&g_pool.lock); break; }
         seen = g_pool.gen;
         pthread_mutex_unlock(&g_pool.lock);
         copy_slice(id + 1, g_pool.n + 1);
@@ -51,6 +57,29 @@ static void *worker(void *arg) {
     return NULL;
 }
 
+/* in a fork() child the workers do not exist: forget them (the locks are re-initialised: no other thread survived the fork) */
+static void pool_atfork_child(void) {
+    g_pool.n = 0;
+    g_pool.pending = 0;
+    pthread_mutex_init(&g_pool.lock, NULL);
+    pthread_mutex_init(&g_pool.busy, NULL);
+    pthread_cond_init(&g_pool.go, NULL);
+    pthread_cond_init(&g_pool.done, NULL);
+}
+
+/* library unload / process exit: stop and join the workers */
+__attribute__((destructor)) static void pool_shutdown(void) {
+    pthread_mutex_lock(&g_pool.busy);
+    pthread_mutex_lock(&g_pool.lock);
+    const int n = g_pool.n;
+    g_pool.stop = 1;
+    g_pool.n = 0;
+    pthread_cond_broadcast(&g_pool.go);
+    pthread_mutex_unlock(&g_pool.lock);
+    for (int i = 0; i < n; i++) pthread_join(g_pool.th[i], NULL);
+    pthread_mutex_unlock(&g_pool.busy);
+}
+
 static void pool_init(void) {
     const char *e = getenv("SVT_HIP_COPY_THREADS");
     int         n = e ? atoi(e) : 4;
@@ -58,14 +87,11 @@ static void pool_init(void) {
     if (n > POOL_MAX + 1) n = POOL_MAX + 1;
     int made = 0;
     for (int i = 0; i < n - 1; i++) {
-        pthread_attr_t a;
-        pthread_attr_init(&a);
-        pthread_attr_setdetachstate(&a, PTHREAD_CREATE_DETACHED);
-        if (pthread_create(&g_pool.th[made], &a, worker, (void *)(intptr_t)made) == 0) made++;
-        pthread_attr_destroy(&a);
+        if (pthread_create(&g_pool.th[made], NULL, worker, (void *)(intptr_t)made) == 0) made++;
         if (made != i + 1) break; /* no more threads to be had: the pool stays as big as it got */
     }
     g_pool.n = made;
+    pthread_atfork(NULL, NULL, pool_atfork_child);
 }
 
 /* copies `rows` rows of `width` bytes; returns when all of them have arrived */

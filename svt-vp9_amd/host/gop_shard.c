@@ -50,6 +50,9 @@ int32_t svt_hip_minigop_split(int32_t n, int32_t levels, int32_t cut_by_intra, s
             parts[np].start = parts[np - 1].start + parts[np - 1].length; parts[np].length = n - parts[np].start; parts[np].hierarchical_levels = 3; np++;
         }
     }
-    for (int i = 0; i < np; i++) parts[i].random_access = !cut_by_intra && parts[i].length == (1 << parts[i].hierarchical_levels);
+    /* a part keeps the random-access hierarchy when it is a whole period of its own levels (:1711-1714: mini_gop_length <
+       pred_struct_period switches to low-delay P); mini_gop_idr_count is non-zero for the LAST part only (:419-424, 463-472), the one
+       that ends with the intra picture, and forces low-delay P there whatever its length */
+    for (int i = 0; i < np; i++) parts[i].random_access = parts[i].length == (1 << parts[i].hierarchical_levels) && !(cut_by_intra && i == np - 1);
     return np;
 }

@@ -19,7 +19,11 @@ def _check(rows):
         assert [g[:3] for g in got] == want, (n, got, want)
         for (start, length, lv, ra) in got:
             assert ra == int(length == (1 << lv))
-        assert all(g[3] == 0 for g in T.product_minigop_split(n, 4, 1))      # cut by an intra refresh: low-delay P everywhere
+        # released by an intra refresh (the intra picture is the group's last element): only the LAST part -- the one that ends
+        # with the intra picture, mini_gop_idr_count > 0 -- is forced to low-delay P; earlier whole periods stay random access
+        cut = T.product_minigop_split(n, 4, 1)
+        assert [g[:3] for g in cut] == want and cut[-1][3] == 0
+        assert all(g[3] == int(g[1] == (1 << g[2])) for g in cut[:-1])
 
 
 def test_split_matches_reference_golden():
