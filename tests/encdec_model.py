@@ -1,0 +1,158 @@
+"""The oracle's view of the picture-level EncDec chain (test infrastructure): inter prediction -> transform / quantisation /
+reconstruction over the blocks of the mode-info grid -> skip flags -> loop-filter masks -> deblocking -> reference padding,
+each stage the oracle's (oracle/*.c), composed on the host exactly as svt_hip_encdec_batch_device composes the kernels.
+Used by tests/test_gpu_encdec.py and tests/test_enc_shim.py to check the device chain and the encoder shim's reconstruction."""
+import ctypes as C
+
+import numpy as np
+
+import svt_testlib as T
+
+B = T.B
+PAD = 80
+_W4 = [1, 1, 2, 2, 2, 4, 4, 4, 8, 8, 8, 16, 16]
+_H4 = [1, 2, 1, 2, 4, 2, 4, 8, 4, 8, 16, 8, 16]
+
+
+class RefPic:
+    """a padded reference / reconstruction picture: three planes in one buffer (Y with `pad` samples of border, Cb and Cr with
+    pad / 2), the layout the reference gives its reference pictures (Codec/EbEncHandle.c:968-971)"""
+
+    def __init__(self, W, H, pad=PAD, fill=None):
+        self.W, self.H, self.pad = W, H, pad
+        self.pw, self.ph, self.cpw, self.cph = W + 2 * pad, H + 2 * pad, W // 2 + pad, H // 2 + pad
+        self.u_base = self.pw * self.ph
+        self.v_base = self.u_base + self.cpw * self.cph
+        self.nbytes = (self.v_base + self.cpw * self.cph + 63) // 64 * 64
+        self.buf = np.zeros(self.nbytes, np.uint8) if fill is None else np.full(self.nbytes, fill, np.uint8)
+
+    def planes(self, buf=None):
+        b = self.buf if buf is None else buf
+        return (b[:self.u_base].reshape(self.ph, self.pw), b[self.u_base:self.v_base].reshape(self.cph, self.cpw),
+                b[self.v_base:self.v_base + self.cpw * self.cph].reshape(self.cph, self.cpw))
+
+    def offsets(self):
+        """byte offsets of sample (0, 0) of Y, Cb, Cr"""
+        p = self.pad
+        return (p * self.pw + p, self.u_base + (p // 2) * self.cpw + p // 2, self.v_base + (p // 2) * self.cpw + p // 2)
+
+    def interior(self, buf=None):
+        y, u, v = self.planes(buf)
+        p = self.pad
+        return y[p:p + self.H, p:p + self.W], u[p // 2:p // 2 + self.H // 2, p // 2:p // 2 + self.W // 2], v[p // 2:p // 2 + self.H // 2, p // 2:p // 2 + self.W // 2]
+
+    def set_padded(self, y, u, v):
+        py, pu, pv = self.planes()
+        p = self.pad
+        py[:] = np.pad(y, p, mode="edge")
+        pu[:] = np.pad(u, p // 2, mode="edge")
+        pv[:] = np.pad(v, p // 2, mode="edge")
+        return self
+
+    def desc(self, base):
+        d = B.YuvPlanes()
+        o = self.offsets()
+        d.y, d.u, d.v = base + o[0], base + o[1], base + o[2]
+        d.y_stride, d.uv_stride, d.width, d.height = self.pw, self.cpw, self.W, self.H
+        return d
+
+
+def uv_tx(bs, tx):
+    m = min(max(_W4[bs] // 2, 1), max(_H4[bs] // 2, 1))
+    return min(tx, 3 if m >= 8 else 2 if m >= 4 else 1 if m >= 2 else 0)
+
+
+def host_block_list(lf_mis, geoms, mi_stride):
+    """the product's HOST list builder (tests/test_encdec_host.py checks it against an independent enumeration)"""
+    n = len(lf_mis)
+    W, H = geoms[0].width, geoms[0].height
+    cap = n * W * H * 3 // 32
+    arr = (C.c_void_p * n)(*[m.ctypes.data for m in lf_mis])
+    gs = (B.TqPicGeom * n)(*geoms)
+    blocks = np.zeros(cap, dtype=B.TQ_BLOCK_DTYPE)
+    pos = np.zeros(cap, np.uint32)
+    cnt = (C.c_int32 * 4)()
+    rc = B.load().svt_hip_tq_blocks_from_grid(n, arr, mi_stride, gs, blocks.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p), cap, cnt)
+    assert rc >= 0, rc
+    return blocks[:rc].copy(), pos[:rc].copy(), list(cnt)
+
+
+def qtabs_of(q_index):
+    out = (B.QuantTables * 2)()
+    assert B.load().svt_hip_quant_tables_for_qindex(q_index, out) == 0
+    return np.frombuffer(bytes(out), dtype=B.QUANT_DTYPE).copy()
+
+
+def eob_map_offsets(W, H):
+    w4, h4 = W // 4, H // 4
+    return 0, w4 * h4, w4 * h4 + (w4 // 2) * (h4 // 2), w4 * h4 + 2 * (w4 // 2) * (h4 // 2)
+
+
+def oracle_encdec_picture(src, refs, mc_mi, lf_mi, q_index, flags, thr, use_subpel=1, pad=PAD, recon_init=None):
+    """src = (y, u, v) tight planes; refs = two RefPic; mc_mi / lf_mi [mi_rows][mi_cols] records.  Returns a dict with the padded
+    reconstruction buffer (RefPic layout), qcoeff / dqcoeff in the driver's position-addressed layout, the eob map, the updated lf
+    grid (skip flags) and the masks."""
+    H, W = src[0].shape
+    mi_rows, mi_cols = H // 8, W // 8
+    mc_mi, lf_mi = np.ascontiguousarray(mc_mi), np.ascontiguousarray(lf_mi).copy()
+    # 1. inter prediction
+    mcase = dict(mi=mc_mi, mi_rows=mi_rows, mi_cols=mi_cols, refs=[r.planes() for r in refs], pad=pad, use_subpel=use_subpel, width=W, height=H)
+    pred = T.oracle_mc_frame(mcase)
+    # 2. the blocks: source and prediction as tight planes one after the other, the reconstruction padded
+    rec = RefPic(W, H, pad) if recon_init is None else recon_init
+    g = B.TqPicGeom()
+    g.width, g.height = W, H
+    so = (0, W * H, W * H + (W // 2) * (H // 2))
+    ro = rec.offsets()
+    for k in range(3):
+        g.src_off[k] = g.pred_off[k] = so[k]
+        g.recon_off[k] = ro[k]
+    g.src_stride[0] = g.pred_stride[0] = W
+    g.src_stride[1] = g.pred_stride[1] = W // 2
+    g.recon_stride[0], g.recon_stride[1] = rec.pw, rec.cpw
+    g.coeff_base, g.recon_set, g.do_recon = 0, 0, int(flags.do_recon)
+    blocks, pos, cnt = host_block_list([lf_mi], [g], lf_mi.shape[1])
+    blocks["pad"] &= 0x0F                                       # the oracle has one reconstruction buffer
+    srcb = np.concatenate([p.ravel() for p in src])
+    predb = np.concatenate([p.ravel() for p in pred])
+    n_coeff = T.n_sb(W, H) * B.SB_COEFFS
+    q, dq = np.zeros(n_coeff, np.int16), np.zeros(n_coeff, np.int16)
+    eob = np.zeros(len(blocks), np.uint16)
+    iscan, _ = T.iscan_array()
+    # (the product's iscan offsets index ITS table, which has one 32x32 entry: rebase onto the test table's offsets)
+    _, offs = T.iscan_array()
+    blocks["iscan_off"] = [offs[(int(t), int(tt))] for t, tt in zip(blocks["tx_size"], blocks["tx_type"])]
+    qt = qtabs_of(q_index)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = T.oracle().svt_oracle_tq_batch(vp(srcb), vp(predb), vp(rec.buf), vp(blocks), len(blocks), vp(qt), vp(iscan), vp(q), vp(dq), vp(eob))
+    assert rc == 0
+    # 3. eob map, skip flags
+    e0, e1, e2, e3 = eob_map_offsets(W, H)
+    emap = np.zeros(e3, np.uint16)
+    nz = np.zeros((mi_rows, mi_cols), bool)
+    plane = (pos >> 26) & 3
+    y4, x4 = (pos >> 13) & 0x1FFF, pos & 0x1FFF
+    pw4 = np.where(plane == 0, W // 4, W // 8)
+    emap[np.array([e0, e1, e2])[plane] + y4 * pw4 + x4] = eob
+    uy, ux = np.where(plane == 0, y4 >> 1, y4), np.where(plane == 0, x4 >> 1, x4)
+    w8 = np.maximum(np.array(_W4)[lf_mi["sb_type"]] // 2, 1)
+    h8 = np.maximum(np.array(_H4)[lf_mi["sb_type"]] // 2, 1)
+    hit = eob > 0
+    oy, ox = uy - uy % h8[uy, ux], ux - ux % w8[uy, ux]
+    nz[oy[hit], ox[hit]] = True
+    r, c = np.meshgrid(np.arange(mi_rows), np.arange(mi_cols), indexing="ij")
+    lf_mi["skip"][:, :mi_cols] = ~nz[r - r % h8[:, :mi_cols], c - c % w8[:, :mi_cols]]
+    out = dict(rec=rec, qcoeff=q, dqcoeff=dq, eob_map=emap, lf_mi=lf_mi, blocks=blocks, pos=pos, eob=eob, counts=cnt, pred=pred, lfm=None)
+    # 4. deblocking
+    if flags.apply_loop_filter:
+        lfm = T.oracle_lf_build_masks(lf_mi, mi_rows, mi_cols)
+        out["lfm"] = lfm
+        d = rec.desc(rec.buf.ctypes.data)
+        lfm_c = np.ascontiguousarray(lfm)
+        rc = T.oracle().svt_oracle_lf_frame(C.byref(d), lfm_c.ctypes.data_as(C.c_void_p), lfm_c.shape[1], C.byref(thr), mi_rows, mi_cols, 0)
+        assert rc == 0
+    # 5. the border
+    if flags.pad_reference:
+        d = rec.desc(rec.buf.ctypes.data)
+        assert T.oracle().svt_oracle_ref_pad(C.byref(d), pad, pad) == 0
+    return out
