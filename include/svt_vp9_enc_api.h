@@ -10,10 +10,15 @@
  *
  * What the library does behind the ABI is the hot path of this repository, not an encoder: pictures are copied to the GPU
  * (the caller may reuse its buffers as soon as eb_vp9_svt_enc_send_picture returns, Codec/EbEncHandle.c:2743-2796), grouped
- * into the reference's mini-GOPs and run through picture analysis and motion estimation; entropy coding is out of scope,
- * so every picture is reported by a packet of ZERO bytes (n_filled_len = 0, p_buffer = NULL) carrying its pts and, on
- * the last one, EB_BUFFERFLAG_EOS -- no bitstream is produced and none is pretended.  eb_vp9_svt_get_recon returns
- * EB_ErrorMax when recon_file is 0 (as the reference) and EB_NoErrorEmptyQueue otherwise.
+ * into the reference's mini-GOPs and run through picture analysis, motion estimation and -- behind a mode decision that is
+ * either the host's (svt_vp9_shim_set_mode_decision) or a built-in stand-in -- inter prediction, transform / quantisation /
+ * reconstruction, in-loop deblocking and reference padding, every picture predicting from the reconstructed reference pictures
+ * before it (the closed loop of Codec/EbEncDecProcess.c).  Entropy coding is out of scope, so every picture is reported by a
+ * packet of ZERO bytes (n_filled_len = 0, p_buffer = NULL) carrying its pts and, on the last one, EB_BUFFERFLAG_EOS -- no
+ * bitstream is produced and none is pretended.  eb_vp9_svt_get_recon delivers the reconstructed pictures as the reference
+ * does (Codec/EbEncHandle.c:2837-2865, recon_output Codec/EbEncDecProcess.c:4693-4820): with recon_file != 0, one picture per
+ * call in coding order, pts = picture number, W x H luma then the two chroma planes, EB_BUFFERFLAG_EOS on the last;
+ * EB_NoErrorEmptyQueue while none is ready; EB_ErrorMax when recon_file is 0.
  */
 #ifndef SVT_VP9_ENC_API_H
 #define SVT_VP9_ENC_API_H
@@ -113,10 +118,18 @@ typedef struct svt_vp9_shim_picture_info {
     int32_t  temporal_layer_index, hierarchical_levels, num_ref_lists;
     int64_t  ref_picture_number[2]; /* display-order numbers of the list 0 / list 1 reference pictures (-1: none) */
     uint32_t n_sb;
+    /* the stages behind mode decision (svt_encdec_flags of svtvp9_hip.h, as the reference derives them for this picture) */
+    int32_t  is_used_as_reference, do_recon, apply_loop_filter, pad_reference;
+    int32_t  q_index, filter_level;
+    int32_t  decision_source;      /* 0 built-in stand-in, 1 the host's callback, 2 intra picture (see intra_recon_is_source) */
+    int32_t  intra_recon_is_source; /* 1: an intra picture's reconstruction is its source picture (intra prediction is not on the
+                                      GPU path: SURVEY 8 lists it outside the hot path), padded as a reference picture */
+    int32_t  device_ordinal;       /* the GPU that coded the picture's GOP */
 } svt_vp9_shim_picture_info;
 /* copies the ME results of a picture whose mini-GOP has been processed (and not yet overwritten: the library keeps the last two
- * mini-GOPs + 2 pictures) into out (n_sb * 85 records of 40 bytes, svt_me_pu_result of svtvp9_hip.h); waits for the GPU work of
- * that picture.  EB_NoErrorEmptyQueue while the picture still waits in an incomplete mini-GOP (or is no longer kept). */
+ * mini-GOPs + 2 pictures of a GOP's device) into out (n_sb * 85 records of 40 bytes, svt_me_pu_result of svtvp9_hip.h); waits for
+ * the GPU work of that picture.  EB_NoErrorEmptyQueue while the picture still waits in an incomplete mini-GOP (or is no longer
+ * kept). */
 EbErrorType svt_vp9_shim_get_me_results(EbComponentType *svt_enc_component, uint64_t picture_number, svt_vp9_shim_picture_info *info,
                                         void *out, uint64_t out_bytes);
 /* the per-SB side outputs of the same picture: stats = n_sb records of svt_me_sb_stats (8 bytes), histograms = 257 uint32 (ME
@@ -126,6 +139,28 @@ EbErrorType svt_vp9_shim_get_sb_stats(EbComponentType *svt_enc_component, uint64
                                       uint32_t *histograms, uint8_t *mean, uint16_t *variance);
 /* how many batched ME launches the library has issued, how many pictures it has accepted */
 EbErrorType svt_vp9_shim_get_counters(EbComponentType *svt_enc_component, uint64_t *me_launches, uint64_t *pictures_sent);
+
+/* Mode decision is the host's (control logic outside the hot path).  A host that has one registers it here, before
+ * eb_vp9_init_encoder: the library calls it once per inter picture, in coding order, on the thread that calls
+ * eb_vp9_svt_enc_send_picture, after the picture's motion estimation has completed (the call waits for it: a host decision
+ * serialises the GPU pipeline at this point, which is what a host-side decision costs), with the picture's ME results
+ * (n_sb * 85 records of svt_me_pu_result).  It fills the two mode-info grids of svtvp9_hip.h -- mc_mode_info: (height / 8) rows of
+ * mi_stride records of svt_mc_mode_info (12 bytes); lf_mode_info: the same grid of svt_lf_mode_info (8 bytes; `skip` is the
+ * library's to write) -- and returns 0; a non-zero return makes the library use its stand-in for that picture.  Without a
+ * callback the stand-in decides every picture (svt_hip_md_default_batch_device: a deterministic partition from the ME results,
+ * NOT the reference's mode decision). */
+typedef int32_t (*svt_vp9_shim_md_callback)(void *user, const svt_vp9_shim_picture_info *info, const void *me_results, void *mc_mode_info,
+                                            void *lf_mode_info, int32_t mi_stride);
+EbErrorType svt_vp9_shim_set_mode_decision(EbComponentType *svt_enc_component, svt_vp9_shim_md_callback callback, void *user);
+/* what the stages behind mode decision left for a coded picture (kept as long as its ME results): the two grids (lf grid with the
+ * skip flags the transform stage produced), the quantised coefficients (n_sb * 6144 int16, position-addressed: SVT_SB_COEFFS
+ * layout of svtvp9_hip.h), the eob of every transform block at its 4x4 unit (Y (H/4 x W/4), Cb, Cr; uint16).  Any pointer may be
+ * NULL.  EB_NoErrorEmptyQueue while the picture has not been coded (or is no longer kept). */
+EbErrorType svt_vp9_shim_get_coded_picture(EbComponentType *svt_enc_component, uint64_t picture_number, svt_vp9_shim_picture_info *info,
+                                           void *mc_mode_info, void *lf_mode_info, int16_t *qcoeff, uint16_t *eob_map);
+/* the padded reference picture of a coded picture as later pictures predict from it: three planes, Y (W + 160) x (H + 160), then
+ * Cb and Cr ((W / 2 + 80) x (H / 2 + 80)); bytes must be at least their sum */
+EbErrorType svt_vp9_shim_get_reference_picture(EbComponentType *svt_enc_component, uint64_t picture_number, uint8_t *out, uint64_t bytes);
 
 #ifdef __cplusplus
 }

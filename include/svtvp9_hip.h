@@ -753,6 +753,9 @@ int32_t svt_hip_host_alloc(svt_hip_ctx *ctx, size_t bytes, void **ptr);
 void    svt_hip_host_free(svt_hip_ctx *ctx, void *ptr);
 int32_t svt_hip_mem_download_2d_async(svt_hip_ctx *ctx, void *pinned_dst, size_t dst_stride, const void *d_src, size_t src_stride, size_t width_bytes,
                                       size_t rows);
+/* device-to-device rectangle copy on the context's stream */
+int32_t svt_hip_mem_copy_2d_device(svt_hip_ctx *ctx, void *d_dst, size_t dst_stride, const void *d_src, size_t src_stride, size_t width_bytes,
+                                   size_t rows);
 
 /* ------------------------------------------------------------------------------------------------ */
 /* Multi-GPU: GOP sharding and the inter-segment reference hand-off (scope row e)                      */

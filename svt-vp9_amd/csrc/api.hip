@@ -274,3 +274,11 @@ extern "C" int32_t svt_hip_mem_download_2d_async(svt_hip_ctx *ctx, void *dst, si
     else HIP_TRY(hipMemcpy2DAsync(dst, dst_stride, d_src, src_stride, width_bytes, rows, hipMemcpyDeviceToHost, ctx->stream));
     return SVT_HIP_OK;
 }
+extern "C" int32_t svt_hip_mem_copy_2d_device(svt_hip_ctx *ctx, void *d_dst, size_t dst_stride, const void *d_src, size_t src_stride, size_t width_bytes,
+                                              size_t rows) {
+    if (!ctx || !d_dst || !d_src || !width_bytes || !rows || dst_stride < width_bytes || src_stride < width_bytes)
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "mem_copy_2d: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpy2DAsync(d_dst, dst_stride, d_src, src_stride, width_bytes, rows, hipMemcpyDeviceToDevice, ctx->stream));
+    return SVT_HIP_OK;
+}

@@ -345,7 +345,8 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
     rc = svt_tq_launch_device_lists(ctx, (const uint8_t *)src_lo, (const uint8_t *)pred_lo, recon_set, n_pics, w->d_blocks, cap, w->d_off_cnt, w->d_qtabs, w->d_iscan,
                                     (int16_t *)q_lo, (int16_t *)dq_lo, w->d_eob, nullptr);
     if (rc) return rc;
-    /* 4. eob map + skip flags */
+    /* 4. eob map + skip flags (entries of the map that are not the origin of a transform block of THIS picture read 0) */
+    for (int i = 0; i < n_pics; i++) HIP_TRY(hipMemsetAsync(pics[i].d_eob_map, 0, (size_t)(width / 4) * (height / 4) * 3 / 2 * sizeof(uint16_t), ctx->stream));
     {
         const int total_cap = (int)(w->cap_per_pic * (size_t)n_pics);
         int       g = (total_cap + 255) / 256;

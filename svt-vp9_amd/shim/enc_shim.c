@@ -10,14 +10,26 @@
  *   eb_vp9_svt_enc_send_picture  the picture is COPIED before the call returns (:2743-2796); NULL p_buffer / EOS flag ends the stream
  *   eb_vp9_svt_get_packet        non-blocking poll -> EB_NoErrorEmptyQueue when nothing is ready (:2880-2915); packets are the
  *                                library's until eb_vp9_svt_release_out_buffer (:1752-1757)
- *   eb_vp9_svt_get_recon         EB_ErrorMax when recon_file == 0 (:2856-2861)
+ *   eb_vp9_svt_get_recon         with recon_file: one reconstructed picture per call in coding order, pts = picture number, EOS on
+ *                                the last (:2837-2865 <- recon_output, Codec/EbEncDecProcess.c:4693-4820); EB_ErrorMax without
  *   stream_header / eos_nal      no-ops returning EB_ErrorNone (:2953-2971)
- * What the library does with the pictures: picture analysis (padded / decimated planes, block mean / variance) as each picture
- * arrives, motion estimation of a whole mini-GOP in ONE batched launch (svt_hip_me_batch_layers_device) plus the per-SB ME
- * statistics (svt_hip_me_sb_stats_device) when its last picture has arrived -- all enqueued asynchronously: send_picture returns
- * after the host copy of the picture (pinned staging), get_packet polls completion markers and blocks only when the caller says
- * it has sent its last picture (pic_send_done), as in the reference (:2880-2915).  Every picture is answered by a zero-byte
- * packet: entropy coding is outside the hot path.
+ *
+ * What the library does with the pictures (all of it enqueued asynchronously; send_picture returns after the host copy of the
+ * picture into pinned staging):
+ *   as each picture arrives      three planes to the device, picture analysis (padded / decimated luma planes, block mean / variance)
+ *   when a mini-GOP is complete  (or cut short by an intra refresh / the end of the stream: cut as the reference cuts it,
+ *                                svt_hip_minigop_split) ONE batched motion-estimation launch for all its pictures + the per-SB ME
+ *                                statistics, then the stages behind mode decision in dependency order -- one batch per temporal
+ *                                layer: mode decision (the host's callback, or the built-in stand-in) -> inter prediction from the
+ *                                reconstructed, padded reference pictures -> transform / quantisation / reconstruction -> skip flags
+ *                                -> deblocking -> reference padding (svt_hip_encdec_batch_device), with the per-picture stage flags
+ *                                the reference derives (svt_hip_encdec_flags_derive)
+ *   GOPs                         closed GOPs are independent (Codec/EbPictureDecisionProcess.c:952): with SVT_HIP_DEVICES=0,1,.. GOP g
+ *                                is coded on device g mod N, each with its own context and picture ring
+ * Every picture is answered by a zero-byte packet: entropy coding is outside the hot path.
+ * Not reproduced (picture decision / rate control, control plane): the low-delay-P structure tables of the parts of a short group
+ * (those pictures are a P chain), per-layer QP scaling (every picture uses quantizer_to_qindex[qp]), intra prediction (an intra
+ * picture's reconstruction is its source picture, flagged in svt_vp9_shim_picture_info).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -27,40 +39,78 @@
 #include "../../include/svtvp9_hip.h"
 
 #define SHIM_MAX_MINIGOP 16
+#define SHIM_MAX_DEV 8
+#define SHIM_REF_PAD 80 /* border of a reference picture: 64 + 16 (Codec/EbEncHandle.c:968-971) */
+#define SHIM_WAVE_MAX 8 /* pictures per EncDec batch (the deepest temporal layer of a 16-picture mini-GOP) */
 
 typedef struct shim_packet {
     EbBufferHeaderType  hdr;
     struct shim_packet *next;
+    int                 dev;
     uint64_t            marker;     /* the GPU work behind this packet (svt_hip_ctx_marker_*) */
 } shim_packet;
 
-typedef struct shim_slot { /* one buffered picture: its three ME planes, its block statistics and its ME outputs, all on the device */
+typedef struct shim_recon { /* one reconstructed picture on its way to eb_vp9_svt_get_recon: pinned host memory, filled asynchronously */
+    struct shim_recon *next;
+    uint8_t           *host;
+    int                dev;
+    uint64_t           marker;
+    int64_t            pts;
+    uint32_t           flags;
+} shim_recon;
+
+typedef struct shim_slot { /* one buffered picture, everything device resident */
     int64_t        number;  /* display order, -1 = empty */
     int64_t        pts;
     svt_pa_picture pa;
-    void          *d_luma;  /* the source luma, tightly packed (stride = width) */
+    uint8_t       *d_src;   /* Y (W x H) then Cb then Cr, tight: inside the device's source slab */
+    uint8_t       *d_pred;  /* prediction picture, same layout: inside the prediction slab */
+    uint8_t       *d_rec;   /* reconstruction = reference picture, three padded planes */
     void          *d_results, *d_mean, *d_var, *d_rcme, *d_stats, *d_hist;
+    void          *d_mc_mi, *d_lf_mi, *d_eob_map, *d_lfm, *d_nz;
+    int16_t       *d_qcoeff, *d_dqcoeff;
     int            processed;   /* its ME (or, for an intra picture, its analysis) has been enqueued */
+    int            coded;       /* the stages behind mode decision have been enqueued */
     int            has_marker;
     uint64_t       marker;      /* completion of everything enqueued for this picture so far */
     svt_vp9_shim_picture_info info;
 } shim_slot;
 
+typedef struct shim_dev {
+    svt_hip_ctx     *ctx;
+    int              ordinal;
+    int              n_slots;
+    shim_slot       *slot;
+    int64_t          accepted;       /* pictures this device has taken: ring position */
+    void            *d_src_slab, *d_pred_slab, *d_q_slab, *d_dq_slab;
+    svt_encdec_work *work;
+    shim_recon      *free_recon;     /* pinned buffers ready for re-use */
+} shim_dev;
+
 typedef struct shim_state {
     EbSvtVp9EncConfiguration cfg;   /* the library's copy, with frame_rate / intra_period resolved (copy_api_from_app) */
-    int         configured, initialised, eos;
+    int         configured, initialised, eos, failed;
     int         levels, minigop;       /* hierarchical levels, 1 << levels */
     int         intra_period;          /* resolved */
-    svt_hip_ctx *ctx;
-    int         n_slots;
-    shim_slot   *slot;
+    int         n_dev, cur_dev;
+    shim_dev    dev[SHIM_MAX_DEV];
+    int64_t     gop;                   /* index of the GOP being sent */
     int64_t     next_number;           /* display number of the next picture sent */
     int64_t     pending_first;         /* first picture of the mini-GOP being collected */
     int         pending;               /* pictures collected */
-    int64_t     last_base;             /* display number of the latest base-layer / intra picture (-1: none yet) */
+    int64_t     last_base;             /* display number of the latest base-layer / intra picture of the current GOP (-1: none yet) */
     shim_packet *q_head, *q_tail;
-    int         eos_reported;
+    shim_recon  *r_head, *r_tail;
     uint64_t    me_launches;           /* batched ME launches so far (svt_vp9_shim_get_counters) */
+    /* geometry and per-stream constants of the stages behind mode decision */
+    int         W, H, mi_rows, mi_cols, n_sb;
+    size_t      pic_bytes, rec_bytes, coeffs;
+    int         q_index, filter_level;
+    uint32_t    md_lambda;
+    svt_lf_thresh thr;
+    svt_vp9_shim_md_callback md_cb;
+    void       *md_user;
+    void       *h_results, *h_mc, *h_lf;   /* host staging of the callback */
 } shim_state;
 
 /* VP9 level limits (max luma picture size, max luma sample rate), indexed like the reference's tables (:109-134) */
@@ -129,6 +179,14 @@ static EbErrorType verify(const EbSvtVp9EncConfiguration *in) {
 
 static shim_state *state_of(EbComponentType *h) { return h ? (shim_state *)h->p_component_private : NULL; }
 
+static EbErrorType gpu_fail(shim_state *s) { /* a failed device call ends the stream: every later call reports it (the reference posts
+                                                a pipeline error and answers EB_ErrorMax from then on, :437-452, 2914-2917) */
+    fprintf(stderr, "SvtVp9Enc (GPU hot path): %s\n", svt_hip_last_error());
+    s->failed = 1;
+    return EB_ErrorMax;
+}
+#define GPU_TRY(call) do { if ((call) != SVT_HIP_OK) return gpu_fail(s); } while (0)
+
 /* ------------------------------------------------------------------------------------------------ */
 EbErrorType eb_vp9_svt_init_handle(EbComponentType **p_handle, void *p_app_data, EbSvtVp9EncConfiguration *config_ptr) {
     if (!p_handle) return EB_ErrorBadParameter;
@@ -168,73 +226,135 @@ EbErrorType eb_vp9_svt_enc_set_parameter(EbComponentType *h, EbSvtVp9EncConfigur
     return EB_ErrorNone;
 }
 
-static void free_slots(shim_state *s) {
-    if (!s->slot) return;
-    for (int i = 0; i < s->n_slots; i++) {
-        shim_slot *t = &s->slot[i];
-        svt_hip_mem_free(s->ctx, (void *)t->pa.full.buf);
-        svt_hip_mem_free(s->ctx, (void *)t->pa.quarter.buf);
-        svt_hip_mem_free(s->ctx, (void *)t->pa.sixteenth.buf);
-        void *v[7] = {t->d_luma, t->d_results, t->d_mean, t->d_var, t->d_rcme, t->d_stats, t->d_hist};
-        for (int k = 0; k < 7; k++) svt_hip_mem_free(s->ctx, v[k]);
+static void free_dev(shim_state *s, shim_dev *d) {
+    if (!d->ctx) return;
+    if (d->slot) {
+        for (int i = 0; i < d->n_slots; i++) {
+            shim_slot *t = &d->slot[i];
+            svt_hip_mem_free(d->ctx, (void *)t->pa.full.buf);
+            svt_hip_mem_free(d->ctx, (void *)t->pa.quarter.buf);
+            svt_hip_mem_free(d->ctx, (void *)t->pa.sixteenth.buf);
+            void *v[12] = {t->d_rec, t->d_results, t->d_mean, t->d_var, t->d_rcme, t->d_stats, t->d_hist, t->d_mc_mi, t->d_lf_mi, t->d_eob_map, t->d_lfm, t->d_nz};
+            for (int k = 0; k < 12; k++) svt_hip_mem_free(d->ctx, v[k]);
+        }
+        free(d->slot);
+        d->slot = NULL;
     }
-    free(s->slot);
-    s->slot = NULL;
+    void *v[4] = {d->d_src_slab, d->d_pred_slab, d->d_q_slab, d->d_dq_slab};
+    for (int k = 0; k < 4; k++) svt_hip_mem_free(d->ctx, v[k]);
+    d->d_src_slab = d->d_pred_slab = d->d_q_slab = d->d_dq_slab = NULL;
+    while (d->free_recon) { shim_recon *r = d->free_recon; d->free_recon = r->next; svt_hip_host_free(d->ctx, r->host); free(r); }
+    if (d->work) svt_hip_encdec_work_destroy(d->ctx, d->work);
+    d->work = NULL;
+    svt_hip_ctx_destroy(d->ctx);
+    d->ctx = NULL;
+    (void)s;
+}
+
+static int alloc_dev(shim_state *s, shim_dev *d) {
+    const int W = s->W, H = s->H;
+    const int pad[3] = {68, 32, 16}; /* PA reference paddings, Codec/EbEncHandle.c:1003-1026 */
+    /* the mini-GOP being collected, the one whose work is in flight, and the base picture before it */
+    d->n_slots = 2 * s->minigop + 2;
+    d->slot = (shim_slot *)calloc((size_t)d->n_slots, sizeof(shim_slot));
+    if (!d->slot) return 0;
+    const size_t n = (size_t)d->n_slots, units = (size_t)s->mi_rows * s->mi_cols;
+    int ok = svt_hip_mem_alloc(d->ctx, n * s->pic_bytes, &d->d_src_slab) == SVT_HIP_OK && svt_hip_mem_alloc(d->ctx, n * s->pic_bytes, &d->d_pred_slab) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(d->ctx, n * s->coeffs * sizeof(int16_t), &d->d_q_slab) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(d->ctx, n * s->coeffs * sizeof(int16_t), &d->d_dq_slab) == SVT_HIP_OK &&
+             svt_hip_encdec_work_create(d->ctx, SHIM_WAVE_MAX, W, H, &d->work) == SVT_HIP_OK;
+    for (int i = 0; ok && i < d->n_slots; i++) {
+        shim_slot *t = &d->slot[i];
+        t->number = -1;
+        svt_plane *pl[3] = {&t->pa.full, &t->pa.quarter, &t->pa.sixteenth};
+        for (int k = 0; ok && k < 3; k++) {
+            const int w = W >> k, hh = H >> k;
+            void *p = NULL;
+            ok = svt_hip_mem_alloc(d->ctx, (size_t)(w + 2 * pad[k]) * (size_t)(hh + 2 * pad[k]), &p) == SVT_HIP_OK;
+            pl[k]->buf = (const uint8_t *)p; pl[k]->stride = w + 2 * pad[k]; pl[k]->origin_x = pl[k]->origin_y = pad[k];
+            pl[k]->width = w; pl[k]->height = hh;
+        }
+        t->d_src = (uint8_t *)d->d_src_slab + (size_t)i * s->pic_bytes;
+        t->d_pred = (uint8_t *)d->d_pred_slab + (size_t)i * s->pic_bytes;
+        t->d_qcoeff = (int16_t *)d->d_q_slab + (size_t)i * s->coeffs;
+        t->d_dqcoeff = (int16_t *)d->d_dq_slab + (size_t)i * s->coeffs;
+        void *rec = NULL;
+        ok = ok && svt_hip_mem_alloc(d->ctx, s->rec_bytes, &rec) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(d->ctx, (size_t)s->n_sb * 85 * sizeof(svt_me_pu_result), &t->d_results) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(d->ctx, (size_t)s->n_sb * 85, &t->d_mean) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(d->ctx, (size_t)s->n_sb * 85 * sizeof(uint16_t), &t->d_var) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(d->ctx, (size_t)s->n_sb * sizeof(uint32_t), &t->d_rcme) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(d->ctx, (size_t)s->n_sb * sizeof(svt_me_sb_stats), &t->d_stats) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(d->ctx, (2 * SVT_SAD_INTERVALS + 1) * sizeof(uint32_t), &t->d_hist) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(d->ctx, units * sizeof(svt_mc_mode_info), &t->d_mc_mi) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(d->ctx, units * sizeof(svt_lf_mode_info), &t->d_lf_mi) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(d->ctx, (size_t)(W / 4) * (H / 4) * 3 / 2 * sizeof(uint16_t), &t->d_eob_map) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(d->ctx, (size_t)s->n_sb * sizeof(svt_lf_mask), &t->d_lfm) == SVT_HIP_OK &&
+             svt_hip_mem_alloc(d->ctx, units, &t->d_nz) == SVT_HIP_OK;
+        t->d_rec = (uint8_t *)rec;
+        t->info.n_sb = (uint32_t)s->n_sb;
+    }
+    if (ok) { /* take the context's pinned staging buffers now (init is outside the clock of SURVEY 8(d)'s metric, the first pictures are
+                 not): one throw-away upload per buffer of the ring */
+        uint8_t *z = (uint8_t *)calloc((size_t)W, (size_t)H);
+        if (z) {
+            for (int i = 0; i < 4; i++) (void)svt_hip_mem_upload_2d_async(d->ctx, d->slot[0].d_src, (size_t)W, z, (size_t)W, (size_t)W, (size_t)H);
+            (void)svt_hip_ctx_synchronize(d->ctx);
+            free(z);
+        }
+    }
+    return ok;
 }
 
 EbErrorType eb_vp9_init_encoder(EbComponentType *h) {
     shim_state *s = state_of(h);
     if (!s || !s->configured) return EB_ErrorBadParameter;
     if (s->initialised) return EB_ErrorNone;
-    /* target_socket names a CPU socket in the reference (-1 = both); here the GPU ordinal comes from SVT_HIP_DEVICE (default 0) */
-    const char *dv = getenv("SVT_HIP_DEVICE");
-    if (svt_hip_ctx_create(&s->ctx, dv ? atoi(dv) : 0) != SVT_HIP_OK) {
-        fprintf(stderr, "SvtVp9Enc (GPU hot path): %s\n", svt_hip_last_error());
-        s->ctx = NULL;
-        return EB_ErrorInsufficientResources;
-    }
-    const int W = (int)s->cfg.source_width, H = (int)s->cfg.source_height;
-    const int pad[3] = {68, 32, 16}; /* PA reference paddings, Codec/EbEncHandle.c:1003-1026 */
-    /* the mini-GOP being collected, the one whose ME is in flight, and the base picture before it */
-    s->n_slots = 2 * s->minigop + 2;
-    s->slot = (shim_slot *)calloc((size_t)s->n_slots, sizeof(shim_slot));
-    if (!s->slot) { svt_hip_ctx_destroy(s->ctx); s->ctx = NULL; return EB_ErrorInsufficientResources; }
-    const uint32_t n_sb = (uint32_t)svt_hip_sb_count(W, H);
-    int ok = 1;
-    for (int i = 0; ok && i < s->n_slots; i++) {
-        shim_slot *t = &s->slot[i];
-        t->number = -1;
-        svt_plane *pl[3] = {&t->pa.full, &t->pa.quarter, &t->pa.sixteenth};
-        for (int k = 0; ok && k < 3; k++) {
-            const int w = W >> k, hh = H >> k;
-            void *d = NULL;
-            ok = svt_hip_mem_alloc(s->ctx, (size_t)(w + 2 * pad[k]) * (size_t)(hh + 2 * pad[k]), &d) == SVT_HIP_OK;
-            pl[k]->buf = (const uint8_t *)d; pl[k]->stride = w + 2 * pad[k]; pl[k]->origin_x = pl[k]->origin_y = pad[k];
-            pl[k]->width = w; pl[k]->height = hh;
+    /* target_socket names a CPU socket in the reference (-1 = both); here the GPUs come from SVT_HIP_DEVICES (a comma-separated list
+       of ordinals: closed GOPs are dealt round-robin to them) or SVT_HIP_DEVICE (one ordinal, default 0) */
+    int         ord[SHIM_MAX_DEV], n = 0;
+    const char *list = getenv("SVT_HIP_DEVICES"), *one = getenv("SVT_HIP_DEVICE");
+    if (list && *list) {
+        for (const char *p = list; *p && n < SHIM_MAX_DEV;) {
+            ord[n++] = atoi(p);
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
         }
-        ok = ok && svt_hip_mem_alloc(s->ctx, (size_t)W * H, &t->d_luma) == SVT_HIP_OK &&
-             svt_hip_mem_alloc(s->ctx, (size_t)n_sb * 85 * sizeof(svt_me_pu_result), &t->d_results) == SVT_HIP_OK &&
-             svt_hip_mem_alloc(s->ctx, (size_t)n_sb * 85, &t->d_mean) == SVT_HIP_OK &&
-             svt_hip_mem_alloc(s->ctx, (size_t)n_sb * 85 * sizeof(uint16_t), &t->d_var) == SVT_HIP_OK &&
-             svt_hip_mem_alloc(s->ctx, (size_t)n_sb * sizeof(uint32_t), &t->d_rcme) == SVT_HIP_OK &&
-             svt_hip_mem_alloc(s->ctx, (size_t)n_sb * sizeof(svt_me_sb_stats), &t->d_stats) == SVT_HIP_OK &&
-             svt_hip_mem_alloc(s->ctx, (2 * SVT_SAD_INTERVALS + 1) * sizeof(uint32_t), &t->d_hist) == SVT_HIP_OK;
-        t->info.n_sb = n_sb;
     }
-    if (!ok) { /* nothing half-initialised is left behind: the handle is back in its configured state */
-        free_slots(s);
-        svt_hip_ctx_destroy(s->ctx);
-        s->ctx = NULL;
-        return EB_ErrorInsufficientResources;
+    if (n == 0) { ord[0] = one ? atoi(one) : 0; n = 1; }
+    s->W = (int)s->cfg.source_width; s->H = (int)s->cfg.source_height;
+    s->mi_rows = s->H >> 3; s->mi_cols = s->W >> 3;
+    s->n_sb = svt_hip_sb_count(s->W, s->H);
+    s->pic_bytes = (size_t)s->W * s->H * 3 / 2;
+    {
+        const size_t pw = (size_t)s->W + 2 * SHIM_REF_PAD, ph = (size_t)s->H + 2 * SHIM_REF_PAD, cpw = (size_t)s->W / 2 + SHIM_REF_PAD, cph = (size_t)s->H / 2 + SHIM_REF_PAD;
+        s->rec_bytes = (pw * ph + 2 * cpw * cph + 63) / 64 * 64;
     }
-    {   /* take the context's pinned staging buffers now (init is outside the clock of SURVEY 8(d)'s metric, the first pictures are
-           not): one throw-away upload per buffer of the ring */
-        uint8_t *z = (uint8_t *)calloc((size_t)W, (size_t)H);
-        if (z) {
-            for (int i = 0; i < 4; i++) (void)svt_hip_mem_upload_2d_async(s->ctx, s->slot[0].d_luma, (size_t)W, z, (size_t)W, (size_t)W, (size_t)H);
-            (void)svt_hip_ctx_synchronize(s->ctx);
-            free(z);
+    s->coeffs = (size_t)s->n_sb * SVT_SB_COEFFS;
+    /* fixed QP: quantizer_to_qindex[qp] for every picture (the per-layer QP scaling is rate control's, Codec/EbRateControlProcess.c:4581-4735) */
+    s->q_index = svt_hip_vp9_qindex_from_qp((int32_t)s->cfg.qp);
+    s->filter_level = s->cfg.loop_filter ? svt_hip_lf_level_from_q(svt_hip_vp9_ac_step(s->q_index), 0) : 0;
+    s->md_lambda = 4u * (uint32_t)svt_hip_vp9_ac_step(s->q_index);
+    svt_hip_lf_thresh_init(&s->thr, 0);
+    for (int i = 0; i < n; i++) {
+        shim_dev *d = &s->dev[i];
+        memset(d, 0, sizeof *d);
+        d->ordinal = ord[i];
+        int ok = svt_hip_ctx_create(&d->ctx, ord[i]) == SVT_HIP_OK;
+        if (!ok) { fprintf(stderr, "SvtVp9Enc (GPU hot path): %s\n", svt_hip_last_error()); d->ctx = NULL; }
+        ok = ok && alloc_dev(s, d);
+        if (!ok) { /* nothing half-initialised is left behind: the handle is back in its configured state */
+            for (int k = 0; k <= i; k++) free_dev(s, &s->dev[k]);
+            return EB_ErrorInsufficientResources;
         }
+    }
+    s->n_dev = n;
+    s->cur_dev = 0;
+    if (s->md_cb) {
+        s->h_results = malloc((size_t)s->n_sb * 85 * sizeof(svt_me_pu_result));
+        s->h_mc = malloc((size_t)s->mi_rows * s->mi_cols * sizeof(svt_mc_mode_info));
+        s->h_lf = malloc((size_t)s->mi_rows * s->mi_cols * sizeof(svt_lf_mode_info));
+        if (!s->h_results || !s->h_mc || !s->h_lf) { (void)eb_vp9_deinit_encoder(h); return EB_ErrorInsufficientResources; }
     }
     s->initialised = 1;
     return EB_ErrorNone;
@@ -244,9 +364,19 @@ EbErrorType eb_vp9_svt_enc_stream_header(EbComponentType *h, EbBufferHeaderType 
 EbErrorType eb_vp9_svt_enc_eos_nal(EbComponentType *h, EbBufferHeaderType **o) { (void)h; (void)o; return EB_ErrorNone; }
 
 /* ------------------------------------------------------------------------------------------------ */
-static shim_slot *slot_of(shim_state *s, int64_t number) { return &s->slot[number % s->n_slots]; }
+static shim_slot *find_slot(shim_dev *d, int64_t number) {
+    for (int i = 0; i < d->n_slots; i++) if (d->slot[i].number == number) return &d->slot[i];
+    return NULL;
+}
+static shim_slot *find_any(shim_state *s, int64_t number, shim_dev **dev) {
+    for (int k = 0; k < s->n_dev; k++) {
+        shim_slot *t = find_slot(&s->dev[k], number);
+        if (t) { if (dev) *dev = &s->dev[k]; return t; }
+    }
+    return NULL;
+}
 
-static int push_packet(shim_state *s, int64_t pts, uint32_t flags, uint32_t pic_type, uint64_t marker) {
+static int push_packet(shim_state *s, int64_t pts, uint32_t flags, uint32_t pic_type, int dev, uint64_t marker) {
     shim_packet *p = (shim_packet *)calloc(1, sizeof *p);
     if (!p) return -1;
     p->hdr.size = sizeof(EbBufferHeaderType);
@@ -254,16 +384,61 @@ static int push_packet(shim_state *s, int64_t pts, uint32_t flags, uint32_t pic_
     p->hdr.flags = flags;
     p->hdr.pic_type = pic_type;
     p->hdr.wrapper_ptr = p; /* the round trip of the reference's wrapper_ptr (:2923) */
+    p->dev = dev;
     p->marker = marker;
     if (s->q_tail) s->q_tail->next = p; else s->q_head = p;
     s->q_tail = p;
     return 0;
 }
 
+/* planes of a slot's tight source / prediction picture and of its padded reference picture */
+static svt_yuv_planes tight_planes(const shim_state *s, uint8_t *base) {
+    svt_yuv_planes p;
+    p.y = base; p.u = base + (size_t)s->W * s->H; p.v = p.u + (size_t)(s->W / 2) * (s->H / 2);
+    p.y_stride = s->W; p.uv_stride = s->W / 2; p.width = s->W; p.height = s->H;
+    return p;
+}
+static svt_yuv_planes rec_planes(const shim_state *s, uint8_t *base) {
+    const size_t pw = (size_t)s->W + 2 * SHIM_REF_PAD, ph = (size_t)s->H + 2 * SHIM_REF_PAD, cpw = (size_t)s->W / 2 + SHIM_REF_PAD, cph = (size_t)s->H / 2 + SHIM_REF_PAD;
+    svt_yuv_planes p;
+    p.y = base + SHIM_REF_PAD * pw + SHIM_REF_PAD;
+    p.u = base + pw * ph + (SHIM_REF_PAD / 2) * cpw + SHIM_REF_PAD / 2;
+    p.v = base + pw * ph + cpw * cph + (SHIM_REF_PAD / 2) * cpw + SHIM_REF_PAD / 2;
+    p.y_stride = (int32_t)pw; p.uv_stride = (int32_t)cpw; p.width = s->W; p.height = s->H;
+    return p;
+}
+
+/* the reconstruction of a picture on its way to eb_vp9_svt_get_recon: W x H luma, then Cb, then Cr (recon_output,
+ * Codec/EbEncDecProcess.c:4693-4820), copied to pinned host memory behind the picture's last stage */
+static EbErrorType queue_recon(shim_state *s, shim_dev *d, shim_slot *t) {
+    shim_recon *r = d->free_recon;
+    if (r) d->free_recon = r->next;
+    else {
+        r = (shim_recon *)calloc(1, sizeof *r);
+        if (!r) return EB_ErrorInsufficientResources;
+        void *hp = NULL;
+        if (svt_hip_host_alloc(d->ctx, s->pic_bytes, &hp) != SVT_HIP_OK) { free(r); return gpu_fail(s); }
+        r->host = (uint8_t *)hp;
+    }
+    const svt_yuv_planes p = rec_planes(s, t->d_rec);
+    const size_t W = (size_t)s->W, H = (size_t)s->H;
+    if (svt_hip_mem_download_2d_async(d->ctx, r->host, W, p.y, (size_t)p.y_stride, W, H) != SVT_HIP_OK ||
+        svt_hip_mem_download_2d_async(d->ctx, r->host + W * H, W / 2, p.u, (size_t)p.uv_stride, W / 2, H / 2) != SVT_HIP_OK ||
+        svt_hip_mem_download_2d_async(d->ctx, r->host + W * H + W * H / 4, W / 2, p.v, (size_t)p.uv_stride, W / 2, H / 2) != SVT_HIP_OK ||
+        svt_hip_ctx_marker_record(d->ctx, &r->marker) != SVT_HIP_OK) {
+        r->next = d->free_recon; d->free_recon = r;
+        return gpu_fail(s);
+    }
+    r->dev = (int)(d - s->dev); r->pts = t->number; r->flags = 0; r->next = NULL;
+    if (s->r_tail) s->r_tail->next = r; else s->r_head = r;
+    s->r_tail = r;
+    return EB_ErrorNone;
+}
+
 /* one picture of a group whose motion estimation is about to be launched */
 typedef struct shim_job {
     int64_t       number, ref0, ref1;
-    int           layer, levels, n_lists, used_as_ref;
+    int           layer, levels, n_lists, used_as_ref, wave;
     svt_me_params p;
 } shim_job;
 
@@ -291,50 +466,143 @@ static EbErrorType job_params(shim_state *s, shim_job *j) {
     return EB_ErrorNone;
 }
 
-/* do two parameter sets belong to one launch (svt_hip_me_batch_layers_device)?  They may differ in the four per-picture fields */
+/* do two parameter sets belong to one launch (svt_hip_me_batch_layers_device)?  They may differ in the four per-picture fields
+ * (num_ref_lists, temporal_layer_index, hierarchical_levels, same_ref_poc); compared field by field -- the records carry padding */
 static int same_launch(const svt_me_params *a, const svt_me_params *b) {
-    svt_me_params x = *a, y = *b;
-    x.num_ref_lists = y.num_ref_lists = 0; x.temporal_layer_index = y.temporal_layer_index = 0;
-    x.hierarchical_levels = y.hierarchical_levels = 0; x.same_ref_poc = y.same_ref_poc = 0;
-    return memcmp(&x, &y, sizeof x) == 0;
+#define EQ(f) (a->f == b->f)
+#define EQ2(f) (a->f[0] == b->f[0] && a->f[1] == b->f[1])
+    return EQ(enable_hme_flag) && EQ(enable_hme_level_0_flag) && EQ(enable_hme_level_1_flag) && EQ(enable_hme_level_2_flag) && EQ(cu8x8_mode) &&
+           EQ(cu16x16_mode) && EQ(rate_control_mode) && EQ(fractional_search_method) && EQ(fractional_search_model) && EQ(fractional_search64x64) &&
+           EQ(single_hme_quadrant) && EQ(search_area_width) && EQ(search_area_height) && EQ(number_hme_search_region_in_width) &&
+           EQ(number_hme_search_region_in_height) && EQ(hme_level0_total_search_area_width) && EQ(hme_level0_total_search_area_height) &&
+           EQ2(hme_level0_search_area_in_width_array) && EQ2(hme_level0_search_area_in_height_array) && EQ2(hme_level1_search_area_in_width_array) &&
+           EQ2(hme_level1_search_area_in_height_array) && EQ2(hme_level2_search_area_in_width_array) && EQ2(hme_level2_search_area_in_height_array);
+#undef EQ
+#undef EQ2
 }
 
 /* the hierarchy between two already-listed pictures lo < hi by bisection, decode order */
-static void add_hierarchy(shim_job *jobs, int *n, int64_t lo, int64_t hi, int layer, int levels) {
+static void add_hierarchy(shim_job *jobs, int *n, int64_t lo, int64_t hi, int layer, int levels, int wave0) {
     if (hi - lo < 2) return;
     const int64_t mid = (lo + hi) / 2;
     shim_job *j = &jobs[(*n)++];
     memset(j, 0, sizeof *j);
     j->number = mid; j->ref0 = lo; j->ref1 = hi; j->layer = layer; j->levels = levels; j->n_lists = 2; j->used_as_ref = layer < levels;
-    add_hierarchy(jobs, n, lo, mid, layer + 1, levels);
-    add_hierarchy(jobs, n, mid, hi, layer + 1, levels);
+    j->wave = wave0 + layer;
+    add_hierarchy(jobs, n, lo, mid, layer + 1, levels, wave0);
+    add_hierarchy(jobs, n, mid, hi, layer + 1, levels, wave0);
 }
 
-/* Motion estimation of the collected group: its pictures are cut into parts as the reference cuts them
- * (svt_hip_minigop_split), all of them go to the GPU in as few launches as their parameter sets allow (one for a regular
- * mini-GOP), followed by the per-SB statistics of every picture.  Nothing here waits for the device. */
+/* pred_struct use_subpel_flag of the picture, as the encode pass reads it for its inter prediction (Codec/EbEncDecProcess.c:5507):
+ * the ME parameter derivation encodes it as "fractional search off" */
+static int job_use_subpel(const shim_job *j) { return j->p.fractional_search_model != 2; }
+
+/* The stages behind mode decision for one batch of mutually independent pictures (a temporal layer of a part of the group, or one
+ * picture of a P chain): decision -> svt_hip_encdec_batch_device -> reconstruction output. */
+static EbErrorType encode_wave(shim_state *s, shim_dev *d, const shim_job *const *wj, int n) {
+    svt_encdec_picture pics[SHIM_WAVE_MAX];
+    shim_slot         *ts[SHIM_WAVE_MAX];
+    svt_encdec_flags   fl;
+    {
+        svt_encdec_flags_config fc;
+        fc.enc_mode = s->cfg.enc_mode; fc.tune = s->cfg.tune; fc.temporal_layer_index = wj[0]->layer; fc.is_used_as_reference = wj[0]->used_as_ref;
+        fc.recon_file = (int32_t)s->cfg.recon_file; fc.loop_filter = s->cfg.loop_filter;
+        if (svt_hip_encdec_flags_derive(&fc, &fl) != SVT_HIP_OK) return EB_ErrorBadParameter;
+    }
+    int n_stand_in = 0;
+    const svt_me_pu_result *res[SHIM_WAVE_MAX];
+    svt_mc_mode_info       *mcs[SHIM_WAVE_MAX];
+    svt_lf_mode_info       *lfs[SHIM_WAVE_MAX];
+    for (int i = 0; i < n; i++) {
+        shim_slot *t = ts[i] = find_slot(d, wj[i]->number);
+        shim_slot *r0 = find_slot(d, wj[i]->ref0), *r1 = wj[i]->n_lists == 2 ? find_slot(d, wj[i]->ref1) : r0;
+        if (!t || !r0 || !r1) return EB_ErrorBadParameter;
+        int decided = 0;
+        t->info.decision_source = 0;
+        if (s->md_cb) { /* the host decides: it needs the ME results, so the pipeline drains here */
+            GPU_TRY(svt_hip_mem_download(d->ctx, s->h_results, t->d_results, (size_t)s->n_sb * 85 * sizeof(svt_me_pu_result)));
+            memset(s->h_mc, 0, (size_t)s->mi_rows * s->mi_cols * sizeof(svt_mc_mode_info));
+            memset(s->h_lf, 0, (size_t)s->mi_rows * s->mi_cols * sizeof(svt_lf_mode_info));
+            if (s->md_cb(s->md_user, &t->info, s->h_results, s->h_mc, s->h_lf, s->mi_cols) == 0) {
+                GPU_TRY(svt_hip_mem_upload_2d(d->ctx, t->d_mc_mi, (size_t)s->mi_cols * sizeof(svt_mc_mode_info), s->h_mc, (size_t)s->mi_cols * sizeof(svt_mc_mode_info),
+                                              (size_t)s->mi_cols * sizeof(svt_mc_mode_info), (size_t)s->mi_rows));
+                GPU_TRY(svt_hip_mem_upload_2d(d->ctx, t->d_lf_mi, (size_t)s->mi_cols * sizeof(svt_lf_mode_info), s->h_lf, (size_t)s->mi_cols * sizeof(svt_lf_mode_info),
+                                              (size_t)s->mi_cols * sizeof(svt_lf_mode_info), (size_t)s->mi_rows));
+                decided = 1;
+                t->info.decision_source = 1;
+            }
+        }
+        if (!decided) { res[n_stand_in] = (const svt_me_pu_result *)t->d_results; mcs[n_stand_in] = (svt_mc_mode_info *)t->d_mc_mi; lfs[n_stand_in] = (svt_lf_mode_info *)t->d_lf_mi; n_stand_in++; }
+        svt_encdec_picture *p = &pics[i];
+        memset(p, 0, sizeof *p);
+        p->d_mc_mi = (const svt_mc_mode_info *)t->d_mc_mi; p->d_lf_mi = (svt_lf_mode_info *)t->d_lf_mi;
+        p->src = tight_planes(s, t->d_src); p->pred = tight_planes(s, t->d_pred); p->recon = rec_planes(s, t->d_rec);
+        p->ref[0] = rec_planes(s, r0->d_rec); p->ref[1] = rec_planes(s, r1->d_rec);
+        p->d_qcoeff = t->d_qcoeff; p->d_dqcoeff = t->d_dqcoeff; p->d_eob_map = (uint16_t *)t->d_eob_map; p->d_lfm = (svt_lf_mask *)t->d_lfm; p->d_nz = (uint8_t *)t->d_nz;
+        p->use_subpel = job_use_subpel(wj[i]);
+        t->info.is_used_as_reference = wj[i]->used_as_ref; t->info.do_recon = fl.do_recon; t->info.apply_loop_filter = fl.apply_loop_filter;
+        t->info.pad_reference = fl.pad_reference; t->info.q_index = s->q_index; t->info.filter_level = s->filter_level; t->info.intra_recon_is_source = 0;
+    }
+    if (n_stand_in)
+        GPU_TRY(svt_hip_md_default_batch_device(d->ctx, n_stand_in, res, s->W, s->H, s->md_lambda, s->filter_level, mcs, lfs, s->mi_cols));
+    GPU_TRY(svt_hip_encdec_batch_device(d->ctx, d->work, n, pics, s->W, s->H, s->mi_cols, s->q_index, &fl, &s->thr, SHIM_REF_PAD, SHIM_REF_PAD));
+    for (int i = 0; i < n; i++) {
+        ts[i]->coded = 1;
+        if (s->cfg.recon_file) { const EbErrorType e = queue_recon(s, d, ts[i]); if (e != EB_ErrorNone) return e; }
+    }
+    return EB_ErrorNone;
+}
+
+/* an intra picture: intra prediction is not on the GPU path (outside the hot path), so its reference picture is its source
+ * picture, padded -- flagged in the picture's info; everything that predicts from it runs the real chain */
+static EbErrorType encode_intra(shim_state *s, shim_dev *d, shim_slot *t) {
+    const svt_yuv_planes src = tight_planes(s, t->d_src), rec = rec_planes(s, t->d_rec);
+    const size_t W = (size_t)s->W, H = (size_t)s->H;
+    GPU_TRY(svt_hip_mem_copy_2d_device(d->ctx, rec.y, (size_t)rec.y_stride, src.y, W, W, H));
+    GPU_TRY(svt_hip_mem_copy_2d_device(d->ctx, rec.u, (size_t)rec.uv_stride, src.u, W / 2, W / 2, H / 2));
+    GPU_TRY(svt_hip_mem_copy_2d_device(d->ctx, rec.v, (size_t)rec.uv_stride, src.v, W / 2, W / 2, H / 2));
+    GPU_TRY(svt_hip_ref_pad_batch_device(d->ctx, 1, &rec, SHIM_REF_PAD, SHIM_REF_PAD));
+    t->info.is_used_as_reference = 1; t->info.do_recon = 1; t->info.apply_loop_filter = 0; t->info.pad_reference = 1;
+    t->info.q_index = s->q_index; t->info.filter_level = s->filter_level; t->info.decision_source = 2; t->info.intra_recon_is_source = 1;
+    t->coded = 1;
+    if (s->cfg.recon_file) return queue_recon(s, d, t);
+    return EB_ErrorNone;
+}
+
+/* The collected group on the current GOP's device: its pictures are cut into parts as the reference cuts them
+ * (svt_hip_minigop_split), all of them go to the GPU's motion estimation in as few launches as their parameter sets allow (one for
+ * a regular mini-GOP), followed by the per-SB statistics of every picture and by the stages behind mode decision, one batch per
+ * temporal layer.  cut_by_intra: the group was released by an intra refresh -- the reference's pre-assignment buffer then holds
+ * the intra picture as its last element (Codec/EbPictureDecisionProcess.c:1641-1646) and the split is made over pending + 1.
+ * Nothing here waits for the device (unless the host decides the modes). */
 static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_stream) {
     if (!s->pending) return EB_ErrorNone;
+    shim_dev *d = &s->dev[s->cur_dev];
     shim_job jobs[SHIM_MAX_MINIGOP];
-    int      n = 0;
+    int      n = 0, n_waves = 0;
     const int64_t first = s->pending_first;
     svt_minigop_part parts[4];
-    const int np = svt_hip_minigop_split(s->pending, s->levels, cut_by_intra, parts);
+    const int np = svt_hip_minigop_split(s->pending + (cut_by_intra ? 1 : 0), s->levels, cut_by_intra, parts);
     if (np < 1) return EB_ErrorBadParameter;
+    if (cut_by_intra) parts[np - 1].length -= 1; /* the intra picture itself is handled by the caller */
     int64_t prev = s->last_base;
     for (int k = 0; k < np; k++) {
+        if (parts[k].length < 1) continue;
         const int64_t p0 = first + parts[k].start, base = p0 + parts[k].length - 1;
         if (parts[k].random_access && prev >= 0) { /* base picture first (decode order), then the B hierarchy */
             shim_job *j = &jobs[n++];
             memset(j, 0, sizeof *j);
             j->number = base; j->ref0 = j->ref1 = prev; j->layer = 0; j->levels = parts[k].hierarchical_levels; j->n_lists = 2; j->used_as_ref = 1;
-            add_hierarchy(jobs, &n, prev, base, 1, parts[k].hierarchical_levels);
+            j->wave = n_waves;
+            add_hierarchy(jobs, &n, prev, base, 1, parts[k].hierarchical_levels, n_waves);
+            n_waves += parts[k].hierarchical_levels + 1;
         } else { /* low-delay P: the reference's structure tables (Codec/EbPredictionStructure.c) are picture decision, not
                     reproduced -- every picture is predicted from its predecessor and serves as the next one's reference */
             for (int64_t q = p0; q <= base; q++) {
                 shim_job *j = &jobs[n++];
                 memset(j, 0, sizeof *j);
                 j->number = q; j->ref0 = q - 1; j->ref1 = -1; j->layer = 0; j->levels = parts[k].hierarchical_levels; j->n_lists = 1; j->used_as_ref = 1;
+                j->wave = n_waves++;
             }
         }
         prev = base;
@@ -354,45 +622,56 @@ static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_str
         int               m = 0;
         for (int k = i; k < n; k++) {
             if (done[k] || !same_launch(&jobs[i].p, &jobs[k].p)) continue;
-            shim_slot *t = slot_of(s, jobs[k].number);
-            cur[m] = t->pa; r0[m] = slot_of(s, jobs[k].ref0)->pa; r1[m] = slot_of(s, jobs[k].n_lists == 2 ? jobs[k].ref1 : jobs[k].ref0)->pa;
+            shim_slot *t = find_slot(d, jobs[k].number), *a = find_slot(d, jobs[k].ref0), *b = find_slot(d, jobs[k].n_lists == 2 ? jobs[k].ref1 : jobs[k].ref0);
+            if (!t || !a || !b) return EB_ErrorBadParameter;
+            cur[m] = t->pa; r0[m] = a->pa; r1[m] = b->pa;
             pp[m] = jobs[k].p; res[m] = (svt_me_pu_result *)t->d_results; rc[m] = (uint32_t *)t->d_rcme;
             done[k] = 1;
             m++;
         }
-        if (svt_hip_me_batch_layers_device(s->ctx, m, cur, r0, r1, pp, res, s->cfg.rate_control_mode ? rc : NULL) != SVT_HIP_OK) {
-            fprintf(stderr, "SvtVp9Enc (GPU hot path): %s\n", svt_hip_last_error());
-            return EB_ErrorMax;
-        }
+        GPU_TRY(svt_hip_me_batch_layers_device(d->ctx, m, cur, r0, r1, pp, res, s->cfg.rate_control_mode ? rc : NULL));
         s->me_launches++;
     }
     /* the tail of the ME kernel process per picture (Codec/EbMotionEstimationProcess.c:1047-1237): stationary-edge flags and the
        rate-control histograms from the ME results and the picture-analysis variances, all device resident */
     const int res_class = svt_hip_input_resolution((int32_t)s->cfg.source_width, (int32_t)s->cfg.source_height);
     for (int i = 0; i < n; i++) {
-        shim_slot *t = slot_of(s, jobs[i].number);
+        shim_slot *t = find_slot(d, jobs[i].number);
         svt_me_sb_stats_params sp;
         memset(&sp, 0, sizeof sp);
         sp.pic_width = (int32_t)s->cfg.source_width; sp.pic_height = (int32_t)s->cfg.source_height; sp.input_resolution = res_class;
         sp.temporal_layer_index = jobs[i].layer; sp.slice_type = jobs[i].n_lists == 2 ? 0 : 1;
         sp.run_part2 = !end_of_stream; sp.rate_control_mode = (int32_t)s->cfg.rate_control_mode;
-        if (svt_hip_mem_set(s->ctx, t->d_hist, 0, (2 * SVT_SAD_INTERVALS + 1) * sizeof(uint32_t)) != SVT_HIP_OK ||
-            svt_hip_me_sb_stats_device(s->ctx, &sp, (const svt_me_pu_result *)t->d_results, (const uint16_t *)t->d_var,
-                                       s->cfg.rate_control_mode ? (const uint32_t *)t->d_rcme : NULL, (svt_me_sb_stats *)t->d_stats, (uint32_t *)t->d_hist,
-                                       (uint32_t *)t->d_hist + 2 * SVT_SAD_INTERVALS) != SVT_HIP_OK) {
-            fprintf(stderr, "SvtVp9Enc (GPU hot path): %s\n", svt_hip_last_error());
-            return EB_ErrorMax;
-        }
-    }
-    uint64_t marker = 0;
-    if (svt_hip_ctx_marker_record(s->ctx, &marker) != SVT_HIP_OK) return EB_ErrorMax;
-    for (int i = 0; i < n; i++) { /* packets in decode order */
-        shim_slot *t = slot_of(s, jobs[i].number);
+        GPU_TRY(svt_hip_mem_set(d->ctx, t->d_hist, 0, (2 * SVT_SAD_INTERVALS + 1) * sizeof(uint32_t)));
+        GPU_TRY(svt_hip_me_sb_stats_device(d->ctx, &sp, (const svt_me_pu_result *)t->d_results, (const uint16_t *)t->d_var,
+                                           s->cfg.rate_control_mode ? (const uint32_t *)t->d_rcme : NULL, (svt_me_sb_stats *)t->d_stats, (uint32_t *)t->d_hist,
+                                           (uint32_t *)t->d_hist + 2 * SVT_SAD_INTERVALS));
         t->info.is_intra = 0; t->info.temporal_layer_index = jobs[i].layer; t->info.hierarchical_levels = jobs[i].levels;
         t->info.num_ref_lists = jobs[i].n_lists;
         t->info.ref_picture_number[0] = jobs[i].ref0; t->info.ref_picture_number[1] = jobs[i].n_lists == 2 ? jobs[i].ref1 : -1;
-        t->processed = 1; t->has_marker = 1; t->marker = marker;
-        if (push_packet(s, t->pts, 0, jobs[i].n_lists == 2 ? 0 /* EB_B_PICTURE */ : 1 /* EB_P_PICTURE */, marker)) return EB_ErrorInsufficientResources;
+        t->info.device_ordinal = d->ordinal;
+    }
+    uint64_t me_marker = 0;
+    GPU_TRY(svt_hip_ctx_marker_record(d->ctx, &me_marker));
+    for (int i = 0; i < n; i++) { shim_slot *t = find_slot(d, jobs[i].number); t->processed = 1; t->has_marker = 1; t->marker = me_marker; }
+    /* the stages behind mode decision, wave by wave (a wave = the pictures of one temporal layer of one part: their references
+       belong to earlier waves) */
+    uint64_t wave_marker[SHIM_MAX_MINIGOP + 8];
+    for (int w = 0; w < n_waves; w++) {
+        const shim_job *wj[SHIM_MAX_MINIGOP];
+        int             m = 0;
+        for (int i = 0; i < n; i++) if (jobs[i].wave == w) wj[m++] = &jobs[i];
+        for (int b = 0; b < m; b += SHIM_WAVE_MAX) {
+            const EbErrorType e = encode_wave(s, d, wj + b, m - b < SHIM_WAVE_MAX ? m - b : SHIM_WAVE_MAX);
+            if (e != EB_ErrorNone) return e;
+        }
+        wave_marker[w] = 0;
+        GPU_TRY(svt_hip_ctx_marker_record(d->ctx, &wave_marker[w]));
+    }
+    for (int i = 0; i < n; i++) { /* packets in decode order */
+        shim_slot *t = find_slot(d, jobs[i].number);
+        t->marker = wave_marker[jobs[i].wave];
+        if (push_packet(s, t->pts, 0, jobs[i].n_lists == 2 ? 0 /* EB_B_PICTURE */ : 1 /* EB_P_PICTURE */, s->cur_dev, t->marker)) return EB_ErrorInsufficientResources;
     }
     s->last_base = first + s->pending - 1;
     s->pending = 0;
@@ -402,36 +681,52 @@ static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_str
 EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *b) {
     shim_state *s = state_of(h);
     if (!s || !s->initialised) return EB_ErrorBadParameter;
+    if (s->failed) return EB_ErrorMax;
     if (s->eos) return EB_ErrorBadParameter;
     const int end = !b || !b->p_buffer || (b->flags & EB_BUFFERFLAG_EOS);
     EbErrorType e = EB_ErrorNone;
     if (b && b->p_buffer) {
         const EbSvtEncInput *in = (const EbSvtEncInput *)b->p_buffer;
         if (!in->luma || in->y_stride < s->cfg.source_width) return EB_ErrorBadParameter;
+        if ((in->cb && in->cb_stride < s->cfg.source_width / 2) || (in->cr && in->cr_stride < s->cfg.source_width / 2)) return EB_ErrorBadParameter;
         const int64_t n = s->next_number;
-        shim_slot    *t = slot_of(s, n);
-        const int     W = (int)s->cfg.source_width, H = (int)s->cfg.source_height;
-        /* the slot's previous picture (2 mini-GOPs + 2 ago) must have left the GPU: the one place send_picture can block, as the
-           reference blocks when its picture pool is exhausted */
-        if (t->has_marker && svt_hip_ctx_marker_wait(s->ctx, t->marker) != SVT_HIP_OK) return EB_ErrorMax;
+        const int     W = s->W, H = s->H;
+        const int     intra = n == 0 || (s->intra_period >= 0 && n % (s->intra_period + 1) == 0);
+        if (intra) { /* an intra refresh closes the GOP: what is waiting is coded on its own device, cut as the reference cuts it */
+            if ((e = flush_pending(s, 1, 0)) != EB_ErrorNone) return e;
+            if (n) { s->gop++; s->cur_dev = svt_hip_gop_owner(s->gop, s->n_dev); }
+            s->last_base = -1;
+        }
+        shim_dev  *d = &s->dev[s->cur_dev];
+        shim_slot *t = &d->slot[d->accepted % d->n_slots];
+        /* the slot's previous picture (2 mini-GOPs + 2 ago on this device) must have left the GPU: the one place send_picture can
+           block, as the reference blocks when its picture pool is exhausted */
+        if (t->has_marker) GPU_TRY(svt_hip_ctx_marker_wait(d->ctx, t->marker));
         /* the copy the reference makes in copy_frame_buffer (:2743-2796), into pinned staging: the caller's planes are free again
            on return; the transfer and the analysis below run asynchronously */
-        if (svt_hip_mem_upload_2d_async(s->ctx, t->d_luma, (size_t)W, in->luma, in->y_stride, (size_t)W, (size_t)H) != SVT_HIP_OK) return EB_ErrorMax;
-        const uint8_t *lum = (const uint8_t *)t->d_luma;
+        const svt_yuv_planes sp = tight_planes(s, t->d_src);
+        GPU_TRY(svt_hip_mem_upload_2d_async(d->ctx, sp.y, (size_t)W, in->luma, in->y_stride, (size_t)W, (size_t)H));
+        if (in->cb) GPU_TRY(svt_hip_mem_upload_2d_async(d->ctx, sp.u, (size_t)W / 2, in->cb, in->cb_stride, (size_t)W / 2, (size_t)H / 2));
+        else GPU_TRY(svt_hip_mem_set(d->ctx, sp.u, 128, (size_t)(W / 2) * (H / 2)));
+        if (in->cr) GPU_TRY(svt_hip_mem_upload_2d_async(d->ctx, sp.v, (size_t)W / 2, in->cr, in->cr_stride, (size_t)W / 2, (size_t)H / 2));
+        else GPU_TRY(svt_hip_mem_set(d->ctx, sp.v, 128, (size_t)(W / 2) * (H / 2)));
+        const uint8_t *lum = sp.y;
         const int32_t  stride = W;
-        if (svt_hip_pa_prepare_batch_device(s->ctx, 1, &lum, &stride, &t->pa, 1) != SVT_HIP_OK ||
-            svt_hip_pa_mean_variance_device(s->ctx, &t->pa.full, (uint8_t *)t->d_mean, (uint16_t *)t->d_var) != SVT_HIP_OK) return EB_ErrorMax;
+        GPU_TRY(svt_hip_pa_prepare_batch_device(d->ctx, 1, &lum, &stride, &t->pa, 1));
+        GPU_TRY(svt_hip_pa_mean_variance_device(d->ctx, &t->pa.full, (uint8_t *)t->d_mean, (uint16_t *)t->d_var));
         /* the picture is accepted from here on */
         s->next_number = n + 1;
-        t->number = n; t->pts = b->pts; t->info.picture_number = (uint64_t)n; t->processed = 0; t->has_marker = 0;
-        const int intra = n == 0 || (s->intra_period >= 0 && n % (s->intra_period + 1) == 0);
+        d->accepted++;
+        t->number = n; t->pts = b->pts; t->processed = 0; t->coded = 0; t->has_marker = 0;
+        memset(&t->info, 0, sizeof t->info);
+        t->info.picture_number = (uint64_t)n; t->info.n_sb = (uint32_t)s->n_sb; t->info.device_ordinal = d->ordinal;
         if (intra) {
-            if ((e = flush_pending(s, 1, 0)) != EB_ErrorNone) return e;
             t->info.is_intra = 1; t->info.num_ref_lists = 0; t->info.temporal_layer_index = 0; t->info.hierarchical_levels = s->levels;
             t->info.ref_picture_number[0] = t->info.ref_picture_number[1] = -1;
-            if (svt_hip_ctx_marker_record(s->ctx, &t->marker) != SVT_HIP_OK) return EB_ErrorMax;
+            if ((e = encode_intra(s, d, t)) != EB_ErrorNone) return e;
+            GPU_TRY(svt_hip_ctx_marker_record(d->ctx, &t->marker));
             t->has_marker = 1; t->processed = 1;
-            if (push_packet(s, t->pts, 0, 2 /* EB_I_PICTURE */, t->marker)) return EB_ErrorInsufficientResources;
+            if (push_packet(s, t->pts, 0, 2 /* EB_I_PICTURE */, s->cur_dev, t->marker)) return EB_ErrorInsufficientResources;
             s->last_base = n;
         } else {
             if (!s->pending) s->pending_first = n;
@@ -445,9 +740,10 @@ EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *
             if (s->q_tail) s->q_tail->hdr.flags |= EB_BUFFERFLAG_EOS; /* the last picture's packet closes the stream */
             else {
                 uint64_t m = 0;
-                if (svt_hip_ctx_marker_record(s->ctx, &m) != SVT_HIP_OK) return EB_ErrorMax;
-                if (push_packet(s, b ? b->pts : 0, EB_BUFFERFLAG_EOS, 0, m)) e = EB_ErrorInsufficientResources;
+                GPU_TRY(svt_hip_ctx_marker_record(s->dev[s->cur_dev].ctx, &m));
+                if (push_packet(s, b ? b->pts : 0, EB_BUFFERFLAG_EOS, 0, s->cur_dev, m)) e = EB_ErrorInsufficientResources;
             }
+            if (s->r_tail) s->r_tail->flags |= EB_BUFFERFLAG_EOS; /* ... and the last reconstruction the recon stream (recon_output :4711-4713) */
         }
     }
     return e;
@@ -459,13 +755,15 @@ EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *
 EbErrorType eb_vp9_svt_get_packet(EbComponentType *h, EbBufferHeaderType **p_buffer, uint8_t pic_send_done) {
     shim_state *s = state_of(h);
     if (!s || !p_buffer) return EB_ErrorBadParameter;
+    if (s->failed) return EB_ErrorMax;
     shim_packet *p = s->q_head;
     if (!p) return EB_NoErrorEmptyQueue;
-    if (s->ctx) {
-        if (pic_send_done) { if (svt_hip_ctx_marker_wait(s->ctx, p->marker) != SVT_HIP_OK) return EB_ErrorMax; }
+    svt_hip_ctx *ctx = s->dev[p->dev].ctx;
+    if (ctx) {
+        if (pic_send_done) { GPU_TRY(svt_hip_ctx_marker_wait(ctx, p->marker)); }
         else {
-            const int32_t q = svt_hip_ctx_marker_query(s->ctx, p->marker);
-            if (q < 0) return EB_ErrorMax;
+            const int32_t q = svt_hip_ctx_marker_query(ctx, p->marker);
+            if (q < 0) return gpu_fail(s);
             if (q == 0) return EB_NoErrorEmptyQueue;
         }
     }
@@ -483,11 +781,34 @@ void eb_vp9_svt_release_out_buffer(EbBufferHeaderType **p_buffer) {
     }
 }
 
+/* eb_vp9_svt_get_recon (:2837-2865): non-blocking; the next reconstructed picture, copied into the caller's p_buffer (the caller
+ * allocates W * H * 3 / 2 bytes, App/EbAppContext.c allocate_output_recon_buffers), with the header fields copy_output_recon_buffer
+ * copies (:2815-2830) */
 EbErrorType eb_vp9_svt_get_recon(EbComponentType *h, EbBufferHeaderType *p_buffer) {
     shim_state *s = state_of(h);
-    (void)p_buffer;
     if (!s) return EB_ErrorBadParameter;
-    return s->cfg.recon_file ? EB_NoErrorEmptyQueue : EB_ErrorMax;
+    if (!s->cfg.recon_file) return EB_ErrorMax; /* recon is not enabled */
+    if (s->failed) return EB_ErrorMax;
+    shim_recon *r = s->r_head;
+    if (!r || !p_buffer) return EB_NoErrorEmptyQueue;
+    shim_dev *d = &s->dev[r->dev];
+    const int32_t q = svt_hip_ctx_marker_query(d->ctx, r->marker);
+    if (q < 0) return gpu_fail(s);
+    if (q == 0) return EB_NoErrorEmptyQueue;
+    if (p_buffer->p_buffer) {
+        if (p_buffer->n_alloc_len && p_buffer->n_alloc_len < s->pic_bytes) return EB_ErrorBadParameter;
+        memcpy(p_buffer->p_buffer, r->host, s->pic_bytes);
+    }
+    p_buffer->size = sizeof(EbBufferHeaderType);
+    p_buffer->n_filled_len = (uint32_t)s->pic_bytes;
+    p_buffer->pts = r->pts; p_buffer->dts = 0;
+    p_buffer->flags = r->flags;
+    p_buffer->pic_type = 0;
+    s->r_head = r->next;
+    if (!s->r_head) s->r_tail = NULL;
+    r->next = d->free_recon;
+    d->free_recon = r;
+    return EB_ErrorNone;
 }
 
 EbErrorType eb_vp9_deinit_encoder(EbComponentType *h) {
@@ -495,11 +816,17 @@ EbErrorType eb_vp9_deinit_encoder(EbComponentType *h) {
     if (!s) return EB_ErrorNone; /* the reference accepts a NULL component here (:1846) */
     while (s->q_head) { shim_packet *p = s->q_head; s->q_head = p->next; free(p); }
     s->q_tail = NULL;
-    if (s->ctx) {
-        free_slots(s);
-        svt_hip_ctx_destroy(s->ctx);
-        s->ctx = NULL;
+    while (s->r_head) { /* undelivered reconstructions go back to their device's pool, which is freed with the device */
+        shim_recon *r = s->r_head;
+        s->r_head = r->next;
+        r->next = s->dev[r->dev].free_recon;
+        s->dev[r->dev].free_recon = r;
     }
+    s->r_tail = NULL;
+    for (int k = 0; k < s->n_dev; k++) free_dev(s, &s->dev[k]);
+    s->n_dev = 0;
+    free(s->h_results); free(s->h_mc); free(s->h_lf);
+    s->h_results = s->h_mc = s->h_lf = NULL;
     s->initialised = 0;
     return EB_ErrorNone;
 }
@@ -517,19 +844,38 @@ EbErrorType eb_vp9_deinit_handle(EbComponentType *h) {
     return e;
 }
 
+/* part of the reference library's exported surface (EB_API, Codec/EbEncHandle.c:3086-3110): its sample application links it for its
+ * own string handling (App/EbAppConfig.c) */
+size_t eb_vp9_strnlen_ss(const char *str, size_t max_len) {
+    if (!str || max_len == 0 || max_len > (4ul << 10)) return 0;
+    size_t n = 0;
+    while (n < max_len && str[n]) n++;
+    return n;
+}
+
+/* ---- extensions ---- */
+EbErrorType svt_vp9_shim_set_mode_decision(EbComponentType *h, svt_vp9_shim_md_callback cb, void *user) {
+    shim_state *s = state_of(h);
+    if (!s || s->initialised) return EB_ErrorBadParameter; /* before eb_vp9_init_encoder */
+    s->md_cb = cb;
+    s->md_user = user;
+    return EB_ErrorNone;
+}
+
 EbErrorType svt_vp9_shim_get_me_results(EbComponentType *h, uint64_t picture_number, svt_vp9_shim_picture_info *info, void *out,
                                         uint64_t out_bytes) {
     shim_state *s = state_of(h);
     if (!s || !s->initialised) return EB_ErrorBadParameter;
-    shim_slot *t = slot_of(s, (int64_t)picture_number);
+    shim_dev  *d = NULL;
+    shim_slot *t = find_any(s, (int64_t)picture_number, &d);
     /* a picture that waits in an incomplete mini-GOP has no results yet; neither has one the ring has already given away */
-    if (t->number != (int64_t)picture_number || !t->processed) return EB_NoErrorEmptyQueue;
-    if (svt_hip_ctx_marker_wait(s->ctx, t->marker) != SVT_HIP_OK) return EB_ErrorMax;
+    if (!t || !t->processed) return EB_NoErrorEmptyQueue;
+    GPU_TRY(svt_hip_ctx_marker_wait(d->ctx, t->marker));
     if (info) *info = t->info;
     if (out && !t->info.is_intra) {
         const uint64_t need = (uint64_t)t->info.n_sb * 85 * sizeof(svt_me_pu_result);
         if (out_bytes < need) return EB_ErrorBadParameter;
-        if (svt_hip_mem_download(s->ctx, out, t->d_results, (size_t)need) != SVT_HIP_OK) return EB_ErrorMax;
+        GPU_TRY(svt_hip_mem_download(d->ctx, out, t->d_results, (size_t)need));
     }
     return EB_ErrorNone;
 }
@@ -538,17 +884,50 @@ EbErrorType svt_vp9_shim_get_sb_stats(EbComponentType *h, uint64_t picture_numbe
                                       uint8_t *mean, uint16_t *variance) {
     shim_state *s = state_of(h);
     if (!s || !s->initialised) return EB_ErrorBadParameter;
-    shim_slot *t = slot_of(s, (int64_t)picture_number);
-    if (t->number != (int64_t)picture_number || !t->processed) return EB_NoErrorEmptyQueue;
-    if (svt_hip_ctx_marker_wait(s->ctx, t->marker) != SVT_HIP_OK) return EB_ErrorMax;
+    shim_dev  *d = NULL;
+    shim_slot *t = find_any(s, (int64_t)picture_number, &d);
+    if (!t || !t->processed) return EB_NoErrorEmptyQueue;
+    GPU_TRY(svt_hip_ctx_marker_wait(d->ctx, t->marker));
     const size_t n_sb = t->info.n_sb;
     if (stats && !t->info.is_intra) {
         if (stats_bytes < n_sb * sizeof(svt_me_sb_stats)) return EB_ErrorBadParameter;
-        if (svt_hip_mem_download(s->ctx, stats, t->d_stats, n_sb * sizeof(svt_me_sb_stats)) != SVT_HIP_OK) return EB_ErrorMax;
+        GPU_TRY(svt_hip_mem_download(d->ctx, stats, t->d_stats, n_sb * sizeof(svt_me_sb_stats)));
     }
-    if (histograms && !t->info.is_intra && svt_hip_mem_download(s->ctx, histograms, t->d_hist, (2 * SVT_SAD_INTERVALS + 1) * sizeof(uint32_t)) != SVT_HIP_OK) return EB_ErrorMax;
-    if (mean && svt_hip_mem_download(s->ctx, mean, t->d_mean, n_sb * 85) != SVT_HIP_OK) return EB_ErrorMax;
-    if (variance && svt_hip_mem_download(s->ctx, variance, t->d_var, n_sb * 85 * sizeof(uint16_t)) != SVT_HIP_OK) return EB_ErrorMax;
+    if (histograms && !t->info.is_intra) GPU_TRY(svt_hip_mem_download(d->ctx, histograms, t->d_hist, (2 * SVT_SAD_INTERVALS + 1) * sizeof(uint32_t)));
+    if (mean) GPU_TRY(svt_hip_mem_download(d->ctx, mean, t->d_mean, n_sb * 85));
+    if (variance) GPU_TRY(svt_hip_mem_download(d->ctx, variance, t->d_var, n_sb * 85 * sizeof(uint16_t)));
+    return EB_ErrorNone;
+}
+
+EbErrorType svt_vp9_shim_get_coded_picture(EbComponentType *h, uint64_t picture_number, svt_vp9_shim_picture_info *info, void *mc_mode_info,
+                                           void *lf_mode_info, int16_t *qcoeff, uint16_t *eob_map) {
+    shim_state *s = state_of(h);
+    if (!s || !s->initialised) return EB_ErrorBadParameter;
+    shim_dev  *d = NULL;
+    shim_slot *t = find_any(s, (int64_t)picture_number, &d);
+    if (!t || !t->coded) return EB_NoErrorEmptyQueue;
+    GPU_TRY(svt_hip_ctx_marker_wait(d->ctx, t->marker));
+    if (info) *info = t->info;
+    if (t->info.is_intra) return EB_ErrorNone;
+    const size_t units = (size_t)s->mi_rows * s->mi_cols;
+    if (mc_mode_info) GPU_TRY(svt_hip_mem_download(d->ctx, mc_mode_info, t->d_mc_mi, units * sizeof(svt_mc_mode_info)));
+    if (lf_mode_info) GPU_TRY(svt_hip_mem_download(d->ctx, lf_mode_info, t->d_lf_mi, units * sizeof(svt_lf_mode_info)));
+    if (qcoeff) GPU_TRY(svt_hip_mem_download(d->ctx, qcoeff, t->d_qcoeff, s->coeffs * sizeof(int16_t)));
+    if (eob_map) GPU_TRY(svt_hip_mem_download(d->ctx, eob_map, t->d_eob_map, (size_t)(s->W / 4) * (s->H / 4) * 3 / 2 * sizeof(uint16_t)));
+    return EB_ErrorNone;
+}
+
+EbErrorType svt_vp9_shim_get_reference_picture(EbComponentType *h, uint64_t picture_number, uint8_t *out, uint64_t bytes) {
+    shim_state *s = state_of(h);
+    if (!s || !s->initialised || !out) return EB_ErrorBadParameter;
+    shim_dev  *d = NULL;
+    shim_slot *t = find_any(s, (int64_t)picture_number, &d);
+    if (!t || !t->coded) return EB_NoErrorEmptyQueue;
+    const size_t pw = (size_t)s->W + 2 * SHIM_REF_PAD, ph = (size_t)s->H + 2 * SHIM_REF_PAD, cpw = (size_t)s->W / 2 + SHIM_REF_PAD, cph = (size_t)s->H / 2 + SHIM_REF_PAD;
+    const size_t need = pw * ph + 2 * cpw * cph;
+    if (bytes < need) return EB_ErrorBadParameter;
+    GPU_TRY(svt_hip_ctx_marker_wait(d->ctx, t->marker));
+    GPU_TRY(svt_hip_mem_download(d->ctx, out, t->d_rec, need));
     return EB_ErrorNone;
 }
 

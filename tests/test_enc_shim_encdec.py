@@ -1,0 +1,298 @@
+"""The stages behind mode decision through the PUBLIC API (libSvtVp9Enc.so): a clip goes in through eb_vp9_svt_enc_send_picture,
+eb_vp9_svt_get_recon hands out the reconstructed pictures with the reference's semantics (coding order, pts = picture number, EOS on
+the last; Codec/EbEncHandle.c:2837-2865), and every byte equals the oracle chain run on the host in the same dependency order:
+each picture predicted from the RECONSTRUCTED, deblocked (where the reference deblocks), padded pictures before it.  Both decision
+sources: the built-in stand-in and a host callback (svt_vp9_shim_set_mode_decision)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import encdec_model as M
+import svt_testlib as T
+from test_enc_shim import Cfg, PicInfo, shim
+
+B = T.B
+pytestmark = pytest.mark.gpu
+
+
+class In(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("luma", "cb", "cr", "luma_ext", "cb_ext", "cr_ext")] + [(n, C.c_uint32) for n in ("y_stride", "cr_stride", "cb_stride")]
+
+
+class Hdr(C.Structure):
+    _fields_ = [("size", C.c_uint32), ("p_buffer", C.c_void_p), ("n_filled_len", C.c_uint32), ("n_alloc_len", C.c_uint32), ("p_app_private", C.c_void_p),
+                ("wrapper_ptr", C.c_void_p), ("n_tick_count", C.c_uint32), ("dts", C.c_int64), ("pts", C.c_int64), ("qp", C.c_uint32), ("pic_type", C.c_uint32),
+                ("flags", C.c_uint32)]
+
+
+MD_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(PicInfo), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32)
+EMPTY = 0x80002033
+
+
+def chroma(y, n):
+    return (y[::2, ::2] // 2 + 32 + (n % 5)).astype(np.uint8), (200 - y[1::2, ::2] // 3).astype(np.uint8)
+
+
+def host_decision(me, W, H, number, level):
+    """a host-side 'mode decision' for the callback test: a seeded partition per 32x32 area among {8x8 blocks / 4x4 transforms, 8x8 /
+    8x8, 16x16 / 16x16, 32x32 / 32x32}, every block with the best ME candidate of its own PU (the rule bench.py uses)"""
+    mi_rows, mi_cols, nsbx = H // 8, W // 8, (W + 63) // 64
+    kinds = np.random.default_rng(1000 + number).integers(0, 4, ((H + 31) // 32, (W + 31) // 32))
+    r, c = np.meshgrid(np.arange(mi_rows), np.arange(mi_cols), indexing="ij")
+    k = kinds[r >> 2, c >> 2]
+    q32, q16, q8 = (((r >> 2) & 1) * 2 + ((c >> 2) & 1)), (((r >> 1) & 1) * 2 + ((c >> 1) & 1)), ((r & 1) * 2 + (c & 1))
+    pu = np.where(k == 3, 1 + q32, np.where(k == 2, 5 + 4 * q32 + q16, 21 + 16 * q32 + 4 * q16 + q8))
+    rec = me[(r >> 3) * nsbx + (c >> 3), pu]
+    d = rec["dir0"].astype(np.int64)
+    mc = np.zeros((mi_rows, mi_cols), dtype=B.MC_MODE_INFO_DTYPE)
+    bw = np.where(k == 3, 4, np.where(k == 2, 2, 1)).astype(np.uint8)
+    mc["bw8"], mc["bh8"] = bw, bw
+    mc["ref_list"][..., 0] = np.where(d == 1, 1, 0)
+    mc["ref_list"][..., 1] = np.where(d == 2, 1, -1)
+    mc["mv_row"][..., 0] = 2 * np.where(d == 1, rec["y_mv_l1"], rec["y_mv_l0"])
+    mc["mv_col"][..., 0] = 2 * np.where(d == 1, rec["x_mv_l1"], rec["x_mv_l0"])
+    mc["mv_row"][..., 1] = np.where(d == 2, 2 * rec["y_mv_l1"].astype(np.int32), 0)
+    mc["mv_col"][..., 1] = np.where(d == 2, 2 * rec["x_mv_l1"].astype(np.int32), 0)
+    lf = np.zeros((mi_rows, mi_cols), dtype=B.LF_MODE_INFO_DTYPE)
+    lf["sb_type"] = np.where(k == 3, 9, np.where(k == 2, 6, 3))
+    lf["tx_size"], lf["is_inter"], lf["filter_level"] = k, 1, level
+    return mc, lf
+
+
+def stand_in(me, W, H, lam, level):
+    mc = np.zeros((H // 8, W // 8), dtype=B.MC_MODE_INFO_DTYPE)
+    lf = np.zeros((H // 8, W // 8), dtype=B.LF_MODE_INFO_DTYPE)
+    assert B.load().svt_hip_md_default_picture(me.ctypes.data_as(C.c_void_p), W, H, lam, level, mc.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p), W // 8) == 0
+    return mc, lf
+
+
+def run_clip(W, H, N, enc_mode, tune, qp, recon_file, intra_period, use_callback, seed=41):
+    """returns (frames, delivered reconstructions {pts: bytes}, order of delivery, per-picture info, padded reference pictures of some pictures)"""
+    lib = shim()
+    for f_ in ("svt_vp9_shim_get_me_results", "svt_vp9_shim_get_coded_picture", "svt_vp9_shim_get_reference_picture", "svt_vp9_shim_set_mode_decision", "eb_vp9_svt_get_packet",
+               "eb_vp9_svt_enc_send_picture", "eb_vp9_svt_get_recon"):
+        getattr(lib, f_).restype = C.c_int32
+    lib.eb_vp9_svt_release_out_buffer.restype = None
+    frames = T.gen_clip_subpel(W, H, N, seed)
+    cfg, h = Cfg(), C.c_void_p()
+    assert lib.eb_vp9_svt_init_handle(C.byref(h), None, C.byref(cfg)) == 0
+    cfg.source_width, cfg.source_height, cfg.enc_mode, cfg.tune, cfg.frame_rate, cfg.intra_period, cfg.qp, cfg.recon_file = W, H, enc_mode, tune, 60 << 16, intra_period, qp, recon_file
+    assert lib.eb_vp9_svt_enc_set_parameter(h, C.byref(cfg)) == 0
+    level = B.load().svt_hip_lf_level_from_q(B.load().svt_hip_vp9_ac_step(B.load().svt_hip_vp9_qindex_from_qp(qp)), 0)
+    nsb = T.n_sb(W, H)
+    seen = []
+
+    def cb(user, info, me_p, mc_p, lf_p, mi_stride):
+        i = info.contents
+        seen.append(int(i.picture_number))
+        if i.picture_number % 7 == 3:
+            return 1                                            # "no decision": the library's stand-in takes this picture
+        me = np.ctypeslib.as_array(C.cast(me_p, C.POINTER(C.c_uint8)), (nsb * 85 * 40,)).view(B.ME_RESULT_DTYPE).reshape(nsb, 85)
+        mc, lf = host_decision(me, W, H, int(i.picture_number), level)
+        C.memmove(mc_p, mc.ctypes.data, mc.nbytes)
+        C.memmove(lf_p, lf.ctypes.data, lf.nbytes)
+        return 0
+    keep = MD_CB(cb)
+    if use_callback:
+        assert lib.svt_vp9_shim_set_mode_decision(h, keep, None) == 0
+    assert lib.eb_vp9_init_encoder(h) == 0
+    recon, order, flags_seen, packets = {}, [], [], []
+    rbuf = np.zeros(W * H * 3 // 2, np.uint8)
+
+    def poll_recon():
+        while True:
+            b = Hdr(size=C.sizeof(Hdr), p_buffer=rbuf.ctypes.data, n_alloc_len=rbuf.size)
+            rc = lib.eb_vp9_svt_get_recon(h, C.byref(b)) & 0xffffffff
+            if rc == EMPTY:
+                return
+            assert rc == 0, hex(rc)
+            assert b.n_filled_len == rbuf.size
+            recon[int(b.pts)] = rbuf.copy()
+            order.append(int(b.pts))
+            flags_seen.append(int(b.flags))
+
+    def poll_packets(done):
+        while True:
+            pp = C.POINTER(Hdr)()
+            rc = lib.eb_vp9_svt_get_packet(h, C.byref(pp), C.c_uint8(done)) & 0xffffffff
+            if rc == EMPTY:
+                return
+            assert rc == 0
+            packets.append((int(pp.contents.pts), int(pp.contents.flags)))
+            lib.eb_vp9_svt_release_out_buffer(C.byref(pp))
+    infos, refpics = {}, {}
+    for n in range(N):
+        y = np.ascontiguousarray(frames[n])
+        u, v = (np.ascontiguousarray(p) for p in chroma(y, n))
+        i = In(y.ctypes.data, u.ctypes.data, v.ctypes.data, None, None, None, W, W // 2, W // 2)
+        b = Hdr(size=C.sizeof(Hdr), p_buffer=C.addressof(i), pts=n, flags=1 if n == N - 1 else 0)
+        assert lib.eb_vp9_svt_enc_send_picture(h, C.byref(b)) == 0
+        poll_packets(0)
+        if recon_file:
+            poll_recon()
+    poll_packets(1)
+    if recon_file:
+        for _ in range(2000):
+            poll_recon()
+            if len(recon) == N:
+                break
+    else:
+        b = Hdr(size=C.sizeof(Hdr), p_buffer=rbuf.ctypes.data, n_alloc_len=rbuf.size)
+        assert lib.eb_vp9_svt_get_recon(h, C.byref(b)) == 0x7FFFFFFF        # recon is not enabled: EB_ErrorMax, as the reference
+    rp = M.RefPic(W, H)
+    for k in range(max(0, N - 20), N):
+        info = PicInfo()
+        mc = np.zeros((H // 8, W // 8), dtype=B.MC_MODE_INFO_DTYPE)
+        lf = np.zeros((H // 8, W // 8), dtype=B.LF_MODE_INFO_DTYPE)
+        q = np.zeros(nsb * B.SB_COEFFS, np.int16)
+        em = np.zeros(M.eob_map_offsets(W, H)[3], np.uint16)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert lib.svt_vp9_shim_get_coded_picture(h, C.c_uint64(k), C.byref(info), vp(mc), vp(lf), vp(q), vp(em)) == 0
+        infos[k] = dict(info=info, mc=mc, lf=lf, q=q, em=em)
+        out = np.zeros(rp.u_base + 2 * rp.cpw * rp.cph, np.uint8)
+        assert lib.svt_vp9_shim_get_reference_picture(h, C.c_uint64(k), vp(out), C.c_uint64(out.size)) == 0
+        refpics[k] = out
+    assert lib.eb_vp9_deinit_encoder(h) == 0 and lib.eb_vp9_deinit_handle(h) == 0
+    return frames, recon, order, flags_seen, packets, infos, refpics, seen
+
+
+def structure(N, minigop, intra_period):
+    """coding structure the library documents: (number, layer, levels, n_lists, ref0, ref1, used_as_ref) in dependency order"""
+    out = []
+    levels = {16: 4, 8: 3}[minigop]
+
+    def hierarchy(lo, hi, layer, lv):
+        if hi - lo < 2:
+            return
+        mid = (lo + hi) // 2
+        out.append((mid, layer, lv, 2, lo, hi, int(layer < lv)))
+        hierarchy(lo, mid, layer + 1, lv)
+        hierarchy(mid, hi, layer + 1, lv)
+
+    def group(first, count, prev, cut_by_intra):
+        parts = T.product_minigop_split(count + (1 if cut_by_intra else 0), levels, 1 if cut_by_intra else 0)
+        for idx, (start, length, lv, ra) in enumerate(parts):
+            if cut_by_intra and idx == len(parts) - 1:
+                length -= 1
+            if length < 1:
+                continue
+            p0, base = first + start, first + start + length - 1
+            if ra and prev >= 0:
+                out.append((base, 0, lv, 2, prev, prev, 1))
+                hierarchy(prev, base, 1, lv)
+            else:
+                for q in range(p0, base + 1):
+                    out.append((q, 0, lv, 1, q - 1, -1, 1))
+            prev = base
+        return prev
+    n, prev, pend_first, pend = 0, -1, 0, 0
+    while n < N:
+        intra = n == 0 or (intra_period >= 0 and n % (intra_period + 1) == 0)
+        if intra:
+            if pend:
+                group(pend_first, pend, prev, True)
+                pend = 0
+            out.append((n, 0, levels, 0, -1, -1, 1))
+            prev = n
+        else:
+            if not pend:
+                pend_first = n
+            pend += 1
+            if pend == minigop:
+                prev = group(pend_first, pend, prev, False)
+                pend = 0
+        n += 1
+    if pend:
+        group(pend_first, pend, prev, False)
+    return out
+
+
+def oracle_clip(frames, W, H, N, enc_mode, tune, qp, recon_file, intra_period, use_callback):
+    lib = B.load()
+    q_index = lib.svt_hip_vp9_qindex_from_qp(qp)
+    ac = lib.svt_hip_vp9_ac_step(q_index)
+    level = lib.svt_hip_lf_level_from_q(ac, 0)
+    thr = B.LfThresh()
+    lib.svt_hip_lf_thresh_init(C.byref(thr), 0)
+    pics = [T.PaPic(f) for f in frames]
+    minigop = 16 if tune != 0 else 8
+    recs, outs = {}, {}
+    for (k, layer, lv, nl, r0, r1, used) in structure(N, minigop, intra_period):
+        src = (frames[k],) + chroma(frames[k], k)
+        if nl == 0:
+            recs[k] = M.RefPic(W, H).set_padded(*src)
+            outs[k] = dict(intra=True)
+            continue
+        p = B.me_params_derive(pic_width=W, pic_height=H, enc_mode=enc_mode, tune=tune, frame_rate=60, num_ref_lists=nl, temporal_layer_index=layer,
+                               hierarchical_levels=lv, is_used_as_reference=used, same_ref_poc=int(nl == 2 and r0 == r1))
+        me, _ = T.oracle_me_picture_mt(pics[k], pics[r0], pics[r1] if nl == 2 else None, p)
+        if use_callback and k % 7 != 3:
+            mc, lf = host_decision(me, W, H, k, level)
+        else:
+            mc, lf = stand_in(me, W, H, 4 * ac, level)
+        c, fl = B.EncdecFlagsConfig(enc_mode=enc_mode, tune=tune, temporal_layer_index=layer, is_used_as_reference=used, recon_file=recon_file, loop_filter=1), B.EncdecFlags()
+        assert lib.svt_hip_encdec_flags_derive(C.byref(c), C.byref(fl)) == 0
+        o = M.oracle_encdec_picture(src, [recs[r0], recs[r1 if nl == 2 else r0]], mc, lf, q_index, fl, thr, use_subpel=int(p.fractional_search_model != 2))
+        recs[k] = o["rec"]
+        outs[k] = dict(intra=False, o=o, mc=mc, flags=fl, layer=layer, refs=(r0, r1), nl=nl)
+    return recs, outs
+
+
+@pytest.mark.parametrize("use_callback,N,intra_period", [(False, 36, -1), (True, 36, -1), (False, 34, 19)])
+def test_get_recon_equals_the_oracle_chain(use_callback, N, intra_period):
+    W, H, enc_mode, tune, qp = 256, 192, 8, 1, 40
+    frames, recon, order, flags_seen, packets, infos, refpics, seen = run_clip(W, H, N, enc_mode, tune, qp, 1, intra_period, use_callback)
+    recs, outs = oracle_clip(frames, W, H, N, enc_mode, tune, qp, 1, intra_period, use_callback)
+    assert sorted(order) == list(range(N)) and len(packets) == N and packets[-1][1] & 1          # every picture once; EOS packet last
+    assert flags_seen[-1] == 1 and all(f == 0 for f in flags_seen[:-1])                            # EOS on the last reconstruction delivered
+    # coding order, as recon_output posts them: the reference posts a picture when its EncDec finishes, so any order in which every
+    # picture follows its reference pictures is the reference's
+    at = {k: i for i, k in enumerate(order)}
+    for (k, layer, lv, nl, r0, r1, used) in structure(N, 16, intra_period):
+        for r in ((r0, r1) if nl == 2 else (r0,) if nl == 1 else ()):
+            assert at[r] < at[k], (k, r)
+    for k in range(N):
+        y, u, v = recs[k].interior()
+        want = np.concatenate([y.ravel(), u.ravel(), v.ravel()])
+        assert np.array_equal(recon[k], want), (k, int(np.sum(recon[k] != want)), outs[k].get("layer"))
+    for k, got in refpics.items():                                                                   # the padded reference pictures later pictures read
+        if infos[k]["info"].pad_reference:
+            assert np.array_equal(got, recs[k].buf[:got.size]), k
+    n_cb = 0
+    for k, d in infos.items():
+        i = d["info"]
+        if outs[k]["intra"]:
+            assert i.is_intra and i.intra_recon_is_source and i.decision_source == 2
+            continue
+        o = outs[k]["o"]
+        assert (i.do_recon, i.apply_loop_filter, i.pad_reference) == (outs[k]["flags"].do_recon, outs[k]["flags"].apply_loop_filter, outs[k]["flags"].pad_reference)
+        assert i.decision_source == (1 if use_callback and k % 7 != 3 else 0)
+        n_cb += i.decision_source == 1
+        assert d["mc"].tobytes() == outs[k]["mc"].tobytes() and d["lf"].tobytes() == o["lf_mi"].tobytes(), k      # incl. the skip flags
+        assert np.array_equal(d["q"], o["qcoeff"]) and np.array_equal(d["em"], o["eob_map"]), k
+    if use_callback:
+        assert n_cb >= 10 and sorted(seen) == sorted(k for k in range(N) if not outs[k]["intra"])
+    # the loop is closed: a picture predicted from reconstructions differs from one predicted from sources
+    deblocked = [k for k in range(N) if not outs[k]["intra"] and outs[k]["flags"].apply_loop_filter]
+    assert deblocked and len(deblocked) == N - sum(1 for k in range(N) if outs[k]["intra"])         # recon output on: every picture is deblocked
+
+
+def test_without_recon_output_only_reference_pictures_are_reconstructed():
+    """recon_file = 0 at enc-mode 8: base-layer pictures deblocked, layers 1-3 reconstructed without deblocking (the reference allows
+    the encoder / decoder mismatch there), the deepest layer not reconstructed at all -- and eb_vp9_svt_get_recon answers EB_ErrorMax"""
+    W, H, N, enc_mode, tune, qp = 256, 192, 34, 8, 1, 40
+    frames, recon, order, flags_seen, packets, infos, refpics, _ = run_clip(W, H, N, enc_mode, tune, qp, 0, -1, False, seed=47)
+    recs, outs = oracle_clip(frames, W, H, N, enc_mode, tune, qp, 0, -1, False)
+    assert not recon and len(packets) == N
+    kinds = set()
+    for k, d in infos.items():
+        if outs[k]["intra"]:
+            continue
+        i, fl = d["info"], outs[k]["flags"]
+        kinds.add((i.do_recon, i.apply_loop_filter, i.pad_reference))
+        assert (i.do_recon, i.apply_loop_filter, i.pad_reference) == (fl.do_recon, fl.apply_loop_filter, fl.pad_reference)
+        assert np.array_equal(d["q"], outs[k]["o"]["qcoeff"]), k
+        if i.pad_reference:
+            assert np.array_equal(refpics[k], recs[k].buf[:refpics[k].size]), k
+    assert kinds == {(1, 1, 1), (1, 0, 1), (0, 0, 0)}
