@@ -758,6 +758,9 @@ EbErrorType eb_vp9_svt_get_packet(EbComponentType *h, EbBufferHeaderType **p_buf
     if (s->failed) return EB_ErrorMax;
     shim_packet *p = s->q_head;
     if (!p) return EB_NoErrorEmptyQueue;
+    /* the newest packet stays in the queue until the library knows whether it is the last one (it then carries EB_BUFFERFLAG_EOS): the
+       end-of-stream buffer arrives in a send_picture call of its own (App/EbAppProcessCmd.c:483-494) */
+    if (p == s->q_tail && !s->eos) return EB_NoErrorEmptyQueue;
     svt_hip_ctx *ctx = s->dev[p->dev].ctx;
     if (ctx) {
         if (pic_send_done) { GPU_TRY(svt_hip_ctx_marker_wait(ctx, p->marker)); }
@@ -791,6 +794,7 @@ EbErrorType eb_vp9_svt_get_recon(EbComponentType *h, EbBufferHeaderType *p_buffe
     if (s->failed) return EB_ErrorMax;
     shim_recon *r = s->r_head;
     if (!r || !p_buffer) return EB_NoErrorEmptyQueue;
+    if (r == s->r_tail && !s->eos) return EB_NoErrorEmptyQueue; /* as for packets: the last reconstruction carries EB_BUFFERFLAG_EOS */
     shim_dev *d = &s->dev[r->dev];
     const int32_t q = svt_hip_ctx_marker_query(d->ctx, r->marker);
     if (q < 0) return gpu_fail(s);
