@@ -5,10 +5,13 @@
  * (App/EbAppProcessCmd.c:437-683): send a picture, poll get_packet without blocking, after the last picture drain with
  * pic_send_done = 1.
  *
- *   svt_enc_api_bench luma.bin W H frames_in_file frames_to_send enc_mode tune
- *       luma.bin holds frames_in_file luma planes of W x H (the library reads luma only: picture analysis and motion
- *       estimation are what runs behind the API); they are sent round-robin.
- *   prints one line: {"frames": N, "seconds": T, "frames_per_s": F, "packets": P, "me_launches": L}
+ *   svt_enc_api_bench clip.yuv W H frames_in_file frames_to_send enc_mode tune [recon]
+ *       clip.yuv holds frames_in_file 4:2:0 pictures of W x H (Y, Cb, Cr); they are sent round-robin.  All three planes cross
+ *       PCIe: behind the API run picture analysis, motion estimation, the stand-in decision, inter prediction, transform /
+ *       quantisation / reconstruction, deblocking and reference padding (which of the last three a picture gets is the
+ *       reference's rule: svt_hip_encdec_flags_derive).  recon = 1: recon_file is set and every reconstructed picture is fetched
+ *       with eb_vp9_svt_get_recon (12.4 MB per 4K picture back over PCIe), as the reference's application does with -o.
+ *   prints one line: {"frames": N, "seconds": T, "frames_per_s": F, "packets": P, "me_launches": L, "recon": R, "recon_pictures": K}
  *   exit 3 = no GPU (init_encoder refused: the library has no CPU path)
  */
 #define _POSIX_C_SOURCE 200809L
@@ -25,15 +28,14 @@ static double now_s(void) {
 }
 
 int main(int argc, char **argv) {
-    if (argc < 8) { fprintf(stderr, "usage: %s luma.bin W H frames_in_file frames_to_send enc_mode tune\n", argv[0]); return 2; }
-    const int W = atoi(argv[2]), H = atoi(argv[3]), K = atoi(argv[4]), N = atoi(argv[5]);
+    if (argc < 8) { fprintf(stderr, "usage: %s clip.yuv W H frames_in_file frames_to_send enc_mode tune [recon]\n", argv[0]); return 2; }
+    const int W = atoi(argv[2]), H = atoi(argv[3]), K = atoi(argv[4]), N = atoi(argv[5]), want_recon = argc > 8 ? atoi(argv[8]) : 0;
     if (W < 64 || H < 64 || K < 1 || N < 1) return 2;
-    const size_t ysz = (size_t)W * H;
-    uint8_t     *clip = (uint8_t *)malloc(ysz * (size_t)K), *chroma = (uint8_t *)malloc(ysz / 4);
+    const size_t ysz = (size_t)W * H, psz = ysz + ysz / 2;
+    uint8_t     *clip = (uint8_t *)malloc(psz * (size_t)K), *rbuf = (uint8_t *)malloc(psz);
     FILE        *f = fopen(argv[1], "rb");
-    if (!clip || !chroma || !f || fread(clip, 1, ysz * (size_t)K, f) != ysz * (size_t)K) { fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
+    if (!clip || !rbuf || !f || fread(clip, 1, psz * (size_t)K, f) != psz * (size_t)K) { fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
     fclose(f);
-    memset(chroma, 128, ysz / 4);
 
     EbComponentType         *h = NULL;
     EbSvtVp9EncConfiguration cfg;
@@ -41,18 +43,18 @@ int main(int argc, char **argv) {
     if (eb_vp9_svt_init_handle(&h, NULL, &cfg) != EB_ErrorNone || !h) return 4;
     cfg.source_width = (uint32_t)W; cfg.source_height = (uint32_t)H;
     cfg.enc_mode = (uint8_t)atoi(argv[6]); cfg.tune = (uint8_t)atoi(argv[7]);
-    cfg.frame_rate = 60 << 16; cfg.qp = 40; cfg.intra_period = -2; cfg.frames_to_be_encoded = (uint64_t)N;
+    cfg.frame_rate = 60 << 16; cfg.qp = 40; cfg.intra_period = -2; cfg.frames_to_be_encoded = (uint64_t)N; cfg.recon_file = (uint32_t)want_recon;
     if (eb_vp9_svt_enc_set_parameter(h, &cfg) != EB_ErrorNone) return 6;
     const EbErrorType ie = eb_vp9_init_encoder(h);
     if (ie == EB_ErrorInsufficientResources) { printf("no device\n"); eb_vp9_deinit_handle(h); return 3; }
     if (ie != EB_ErrorNone) return 7;
 
-    int          packets = 0, eos = 0;
+    int          packets = 0, eos = 0, recons = 0, recon_eos = 0;
     const double t0 = now_s();
     for (int n = 0; n < N; n++) {
         EbSvtEncInput in;
         memset(&in, 0, sizeof in);
-        in.luma = clip + ysz * (size_t)(n % K); in.cb = chroma; in.cr = chroma;
+        in.luma = clip + psz * (size_t)(n % K); in.cb = in.luma + ysz; in.cr = in.cb + ysz / 4;
         in.y_stride = (uint32_t)W; in.cb_stride = in.cr_stride = (uint32_t)W / 2;
         EbBufferHeaderType b;
         memset(&b, 0, sizeof b);
@@ -68,16 +70,26 @@ int main(int argc, char **argv) {
             eos |= (p->flags & EB_BUFFERFLAG_EOS) != 0;
             eb_vp9_svt_release_out_buffer(&p);
         }
+        while (want_recon && !recon_eos) { /* what is ready of the reconstructed pictures; after the last picture: all of them */
+            EbBufferHeaderType r;
+            memset(&r, 0, sizeof r);
+            r.size = sizeof r; r.p_buffer = rbuf; r.n_alloc_len = (uint32_t)psz;
+            const EbErrorType e = eb_vp9_svt_get_recon(h, &r);
+            if (e == EB_NoErrorEmptyQueue) { if (n == N - 1) continue; break; }
+            if (e != EB_ErrorNone) return 14;
+            recons++;
+            recon_eos = (r.flags & EB_BUFFERFLAG_EOS) != 0;
+        }
     }
     const double t1 = now_s();
     uint64_t     launches = 0, sent = 0;
     (void)svt_vp9_shim_get_counters(h, &launches, &sent);
-    if (!eos || packets != N) { fprintf(stderr, "packets %d of %d, eos %d\n", packets, N, eos); return 13; }
-    printf("{\"frames\": %d, \"seconds\": %.6f, \"frames_per_s\": %.2f, \"packets\": %d, \"me_launches\": %llu}\n", N, t1 - t0, N / (t1 - t0), packets,
-           (unsigned long long)launches);
+    if (!eos || packets != N || (want_recon && recons != N)) { fprintf(stderr, "packets %d of %d, eos %d, reconstructions %d\n", packets, N, eos, recons); return 13; }
+    printf("{\"frames\": %d, \"seconds\": %.6f, \"frames_per_s\": %.2f, \"packets\": %d, \"me_launches\": %llu, \"recon\": %d, \"recon_pictures\": %d}\n", N,
+           t1 - t0, N / (t1 - t0), packets, (unsigned long long)launches, want_recon, recons);
     eb_vp9_deinit_encoder(h);
     eb_vp9_deinit_handle(h);
     free(clip);
-    free(chroma);
+    free(rbuf);
     return 0;
 }

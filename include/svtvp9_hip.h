@@ -644,9 +644,10 @@ typedef struct svt_tq_pic_geom {
     uint16_t src_stride[2], pred_stride[2], recon_stride[2]; /* luma, chroma */
     uint32_t coeff_base;    /* element offset of the picture's coefficient area (n_sb * SVT_SB_COEFFS elements) in the batch's arrays */
     int32_t  width, height; /* luma samples (multiples of 8) */
-    uint8_t  recon_set;     /* which reconstruction buffer of the batch (0..7) */
+    uint8_t  recon_set;     /* which reconstruction base pointer of the batch (0..7): recon_off is relative to it */
     uint8_t  do_recon;
-    uint8_t  pad_[2];
+    uint8_t  pic;           /* index of the picture in its batch (0..63): goes into the position code */
+    uint8_t  pad_[1];
 } svt_tq_pic_geom;
 /* Coefficient layout of the driver: per SB 64*64 luma + 2 x 32*32 chroma coefficients (Y at +0, Cb at +4096, Cr at +5120), every
  * block's N*N coefficients contiguous (raster inside the block) as in the reference's per-SB quantized_coeff_buffer
@@ -657,7 +658,7 @@ typedef struct svt_tq_pic_geom {
 /* host: the transform blocks of n_pics pictures (one geometry) from their mode-info grids, grouped by transform size and inside a
  * size ordered picture, SB (raster), 8x8 unit of the SB (raster), and per unit luma, Cb, Cr -- exactly the lists the driver builds
  * on the device.  The luma transform type of a block travels in svt_lf_mode_info.pad_[0] (0 = DCT_DCT).  pos[i] = picture-in-batch
- * << 28 | plane << 26 | (y / 4) << 13 | (x / 4) of block i, x / y in samples of its plane.  Returns the number of blocks or a negative error. */
+ * << 24 | plane << 22 | (y / 4) << 11 | (x / 4) of block i, x / y in samples of its plane.  Returns the number of blocks or a negative error. */
 int32_t svt_hip_tq_blocks_from_grid(int32_t n_pics, const svt_lf_mode_info *const *lf_mi, int32_t mi_stride, const svt_tq_pic_geom *geom,
                                     svt_tq_block *blocks, uint32_t *pos, int32_t capacity, int32_t size_count[4]);
 
@@ -703,6 +704,8 @@ typedef struct svt_encdec_picture {
     svt_lf_mask            *d_lfm;     /* [sb_rows][sb_cols] masks (written; read by the loop filter) */
     uint8_t                *d_nz;      /* scratch, mi_rows * mi_stride bytes */
     int32_t                 use_subpel; /* svt_mc_picture.use_subpel */
+    int32_t                 no_pad;    /* 1: this picture is not padded although the batch's flags say pad_reference (a picture that is not
+                                          used as a reference riding in a batch of reference pictures) */
 } svt_encdec_picture;
 
 /* workspace of a batch: descriptor lists, per-list eob, counters (device memory owned by the object); sized for max_pics pictures
@@ -711,7 +714,9 @@ typedef struct svt_encdec_work svt_encdec_work;
 int32_t svt_hip_encdec_work_create(svt_hip_ctx *ctx, int32_t max_pics, int32_t width, int32_t height, svt_encdec_work **work);
 void    svt_hip_encdec_work_destroy(svt_hip_ctx *ctx, svt_encdec_work *work);
 
-/* n_pics (<= 8, <= the workspace's max_pics) pictures of one geometry and one set of flags (the pictures of a temporal layer):
+/* n_pics (<= 32, <= the workspace's max_pics) pictures of one geometry and one set of flags (the pictures of a temporal layer, or
+ * of several layers of different mini-GOPs that share their flags; the reconstruction buffers of a batch must fall into at most 8
+ * regions of 4 GB -- e.g. be carved out of a few slabs):
  * inter prediction -> transform blocks from the grids -> residual / transform / quantisation (/ reconstruction when
  * flags->do_recon) with the tables of q_index -> skip flags + eob map -> (flags->apply_loop_filter: masks + deblocking with
  * filter_level's thresholds) -> (flags->pad_reference: border of pad_x / pad_y samples).  Source and prediction planes of the
@@ -721,6 +726,18 @@ void    svt_hip_encdec_work_destroy(svt_hip_ctx *ctx, svt_encdec_work *work);
 int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work *work, int32_t n_pics, const svt_encdec_picture *pics, int32_t width,
                                     int32_t height, int32_t mi_stride, int32_t q_index, const svt_encdec_flags *flags,
                                     const svt_lf_thresh *thr, int32_t pad_x, int32_t pad_y);
+/* Profiling aid: `hook` is called on the enqueueing thread at every stage boundary of svt_hip_encdec_batch_device (before the
+ * stage named is enqueued; SVT_ENCDEC_STAGE_END after the last), so that a host can record events of its own on the context's stream
+ * and attribute the chain's time to its stages.  NULL removes it. */
+#define SVT_ENCDEC_STAGE_MC 0
+#define SVT_ENCDEC_STAGE_LISTS 1
+#define SVT_ENCDEC_STAGE_TQ 2
+#define SVT_ENCDEC_STAGE_SKIP 3
+#define SVT_ENCDEC_STAGE_LF 4
+#define SVT_ENCDEC_STAGE_PAD 5
+#define SVT_ENCDEC_STAGE_END 6
+typedef void (*svt_encdec_stage_hook)(void *user, int32_t stage);
+void svt_hip_encdec_work_set_stage_hook(svt_encdec_work *work, svt_encdec_stage_hook hook, void *user);
 /* synchronises the context; 0 = every grid the workspace has seen was well-formed, else SVT_HIP_ERR_BAD_PARAMETER (and the flag is
  * cleared).  counts[8] (optional) = offset and number of blocks per transform size of the most recent batch. */
 int32_t svt_hip_encdec_work_status(svt_hip_ctx *ctx, svt_encdec_work *work, int32_t counts[8]);

@@ -127,7 +127,7 @@ assert ME_SB_STATS_DTYPE.itemsize == 8
 class TqPicGeom(C.Structure):
     _fields_ = [("src_off", C.c_uint32 * 3), ("pred_off", C.c_uint32 * 3), ("recon_off", C.c_uint32 * 3), ("src_stride", C.c_uint16 * 2),
                 ("pred_stride", C.c_uint16 * 2), ("recon_stride", C.c_uint16 * 2), ("coeff_base", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32),
-                ("recon_set", C.c_uint8), ("do_recon", C.c_uint8), ("pad", C.c_uint8 * 2)]
+                ("recon_set", C.c_uint8), ("do_recon", C.c_uint8), ("pic", C.c_uint8), ("pad", C.c_uint8 * 1)]
 
 
 class EncdecFlagsConfig(C.Structure):
@@ -141,7 +141,7 @@ class EncdecFlags(C.Structure):
 class EncdecPicture(C.Structure):
     _fields_ = [("d_mc_mi", C.c_void_p), ("d_lf_mi", C.c_void_p), ("src", YuvPlanes), ("ref", YuvPlanes * 2), ("pred", YuvPlanes), ("recon", YuvPlanes),
                 ("d_qcoeff", C.c_void_p), ("d_dqcoeff", C.c_void_p), ("d_eob_map", C.c_void_p), ("d_lfm", C.c_void_p), ("d_nz", C.c_void_p),
-                ("use_subpel", C.c_int32)]
+                ("use_subpel", C.c_int32), ("no_pad", C.c_int32)]
 
 
 SB_COEFFS = 6144
@@ -164,7 +164,7 @@ EXPORTS = [
     "svt_hip_quant_tables_for_qindex", "svt_hip_encdec_flags_derive", "svt_hip_encdec_work_create", "svt_hip_encdec_work_destroy",
     "svt_hip_encdec_batch_device", "svt_hip_encdec_work_status", "svt_hip_encdec_work_download", "svt_hip_md_default_batch_device",
     "svt_hip_md_default_picture", "svt_hip_lf_build_masks_device", "svt_hip_ctx_wait_marker", "svt_hip_host_alloc", "svt_hip_host_free",
-    "svt_hip_mem_download_2d_async", "svt_hip_mem_copy_2d_device",
+    "svt_hip_mem_download_2d_async", "svt_hip_mem_copy_2d_device", "svt_hip_encdec_work_set_stage_hook",
 ]
 
 _lib = None
@@ -194,6 +194,7 @@ def load():
         _lib.svt_hip_vp9_iscan_tables.argtypes = [C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int32)]
         _lib.svt_hip_encdec_work_destroy.restype = None
         _lib.svt_hip_host_free.restype = None
+        _lib.svt_hip_encdec_work_set_stage_hook.restype = None
         _lib.svt_hip_lf_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     return _lib
 

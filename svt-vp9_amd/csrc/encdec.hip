@@ -25,7 +25,8 @@
 #include "svt_ctx.h"
 #include "encdec_core.h"
 
-#define ED_MAX_PICS 8
+#define ED_MAX_PICS 32
+#define ED_MAX_SETS 8 /* reconstruction base pointers a transform launch can address (svt_tq_block.pad_[0] bits 4-6) */
 
 struct svt_encdec_work {
     int           max_pics, width, height, n_sb, sb_cols, mi_rows, mi_cols;
@@ -39,6 +40,8 @@ struct svt_encdec_work {
     svt_quant_tables *d_qtabs;   /* [2] luma, chroma of the batch's q index */
     int16_t      *d_iscan;
     int           last_pics;
+    svt_encdec_stage_hook hook;  /* profiling aid: called on the enqueueing thread at every stage boundary */
+    void         *hook_user;
 };
 
 namespace {
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void svt_tq_skip_kernel(const ed_batch_dev *__
     const int w4 = B->width >> 2, h4 = B->height >> 2;
     for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < total; i += (int)(gridDim.x * blockDim.x)) {
         const uint32_t p = pos[i];
-        const int      pic = (int)(p >> 28) & 7, plane = (int)(p >> 26) & 3, y4 = (int)(p >> 13) & 0x1fff, x4 = (int)p & 0x1fff;
+        const int      pic = (int)(p >> 24) & 63, plane = (int)(p >> 22) & 3, y4 = (int)(p >> 11) & 0x7ff, x4 = (int)p & 0x7ff;
         const ed_pic_dev &P = B->pic[pic];
         const int      e = eob[i];
         const int      pw4 = plane ? w4 >> 1 : w4;
@@ -285,9 +288,11 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
         (void)svt_hip_vp9_iscan_tables(&offs, nullptr);
         for (int i = 0; i < 16; i++) hb.iscan_off[i] = offs[i];
     }
-    uint8_t       *recon_set[ED_MAX_PICS];
+    uint8_t       *recon_set[ED_MAX_SETS];
+    int            n_sets = 0;
     svt_mc_picture mcp[ED_MAX_PICS];
-    svt_yuv_planes rec[ED_MAX_PICS];
+    svt_yuv_planes rec[ED_MAX_PICS], rec_pad[ED_MAX_PICS];
+    int            n_rec_pad = 0;
     const svt_lf_mask *lfm[ED_MAX_PICS];
     int32_t        lfm_stride[ED_MAX_PICS], mi_rows_a[ED_MAX_PICS], mi_cols_a[ED_MAX_PICS];
     for (int i = 0; i < n_pics; i++) {
@@ -297,25 +302,35 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
         const uintptr_t q_off = ((uintptr_t)p.d_qcoeff - q_lo) / sizeof(int16_t), dq_off = ((uintptr_t)p.d_dqcoeff - dq_lo) / sizeof(int16_t);
         if (q_off != dq_off || q_off + (uint64_t)hb.n_sb * SVT_SB_COEFFS >= (1ull << 32))
             return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: qcoeff / dqcoeff of the batch must be laid out alike, within 2^32 elements");
-        uint8_t *rb = p.recon.y < p.recon.u ? p.recon.y : p.recon.u;
-        rb = rb < p.recon.v ? rb : p.recon.v;
-        recon_set[i] = rb;
+        /* the picture's reconstruction planes: 32-bit offsets from one of at most ED_MAX_SETS base pointers (a base serves every
+           picture whose planes lie within 4 GB above it: buffers carved out of one slab share one) */
+        const uint8_t *r3[3] = {p.recon.y, p.recon.u, p.recon.v};
+        uintptr_t r_lo = UINTPTR_MAX, r_hi = 0;
+        for (int k = 0; k < 3; k++) { r_lo = (uintptr_t)r3[k] < r_lo ? (uintptr_t)r3[k] : r_lo; r_hi = (uintptr_t)r3[k] > r_hi ? (uintptr_t)r3[k] : r_hi; }
+        int set = -1;
+        for (int k = 0; k < n_sets && set < 0; k++)
+            if (r_lo >= (uintptr_t)recon_set[k] && (uint64_t)(r_hi - (uintptr_t)recon_set[k]) + plane_span < (1ull << 32)) set = k;
+        if (set < 0) {
+            if (n_sets == ED_MAX_SETS || (uint64_t)(r_hi - r_lo) + plane_span >= (1ull << 32))
+                return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: the batch's reconstruction buffers span more than 8 regions of 4 GB");
+            set = n_sets;
+            recon_set[n_sets++] = (uint8_t *)r_lo;
+        }
         svt_tq_pic_geom &g = P.g;
-        const uint8_t *s3[3] = {p.src.y, p.src.u, p.src.v}, *p3[3] = {p.pred.y, p.pred.u, p.pred.v}, *r3[3] = {p.recon.y, p.recon.u, p.recon.v};
+        const uint8_t *s3[3] = {p.src.y, p.src.u, p.src.v}, *p3[3] = {p.pred.y, p.pred.u, p.pred.v};
         for (int k = 0; k < 3; k++) {
             g.src_off[k] = (uint32_t)((uintptr_t)s3[k] - src_lo); g.pred_off[k] = (uint32_t)((uintptr_t)p3[k] - pred_lo);
-            const uint64_t ro = (uint64_t)((uintptr_t)r3[k] - (uintptr_t)rb);
-            if (ro + plane_span >= (1ull << 32)) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: reconstruction planes too far apart");
-            g.recon_off[k] = (uint32_t)ro;
+            g.recon_off[k] = (uint32_t)((uintptr_t)r3[k] - (uintptr_t)recon_set[set]);
         }
         if (p.src.y_stride > 65535 || p.pred.y_stride > 65535 || p.recon.y_stride > 65535) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: stride");
         g.src_stride[0] = (uint16_t)p.src.y_stride; g.src_stride[1] = (uint16_t)p.src.uv_stride;
         g.pred_stride[0] = (uint16_t)p.pred.y_stride; g.pred_stride[1] = (uint16_t)p.pred.uv_stride;
         g.recon_stride[0] = (uint16_t)p.recon.y_stride; g.recon_stride[1] = (uint16_t)p.recon.uv_stride;
-        g.coeff_base = (uint32_t)q_off; g.width = width; g.height = height; g.recon_set = (uint8_t)i; g.do_recon = flags->do_recon ? 1 : 0;
+        g.coeff_base = (uint32_t)q_off; g.width = width; g.height = height; g.recon_set = (uint8_t)set; g.pic = (uint8_t)i; g.do_recon = flags->do_recon ? 1 : 0;
         mcp[i].d_mi = p.d_mc_mi; mcp[i].mi_stride = mi_stride; mcp[i].mi_rows = hb.mi_rows; mcp[i].mi_cols = hb.mi_cols;
         mcp[i].ref[0] = p.ref[0]; mcp[i].ref[1] = p.ref[1]; mcp[i].pred = p.pred; mcp[i].use_subpel = p.use_subpel;
         rec[i] = p.recon; rec[i].width = width; rec[i].height = height;
+        if (!p.no_pad) rec_pad[n_rec_pad++] = rec[i];
         lfm[i] = p.d_lfm; lfm_stride[i] = hb.sb_cols; mi_rows_a[i] = hb.mi_rows; mi_cols_a[i] = hb.mi_cols;
     }
     const ed_batch_dev *dB = nullptr;
@@ -330,22 +345,27 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
         HIP_TRY(hipMemcpyAsync(w->d_qtabs, h, sizeof qt, hipMemcpyHostToDevice, ctx->stream));
         svt_ctx_stage_commit(ctx);
     }
+#define ED_STAGE(k) do { if (w->hook) w->hook(w->hook_user, (k)); } while (0)
     /* 1. inter prediction of the whole batch */
+    ED_STAGE(SVT_ENCDEC_STAGE_MC);
     int32_t rc = svt_hip_inter_pred_batch_device(ctx, n_pics, mcp);
     if (rc) return rc;
     /* 2. transform blocks from the grids */
+    ED_STAGE(SVT_ENCDEC_STAGE_LISTS);
     const int nwg = n_pics * hb.n_sb, M = 4 * n_pics * hb.n_sb;
     hipLaunchKernelGGL(svt_tq_count_kernel, dim3(nwg), dim3(64), 0, ctx->stream, dB, w->d_counts, w->d_status);
     hipLaunchKernelGGL(svt_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, w->d_counts, M, n_pics * hb.n_sb, w->d_off_cnt);
     hipLaunchKernelGGL(svt_tq_emit_kernel, dim3(nwg), dim3(64), 0, ctx->stream, dB, (const int32_t *)w->d_counts, w->d_blocks, w->d_pos);
     HIP_TRY(hipGetLastError());
     /* 3. residual -> transform -> quantisation (-> inverse -> reconstruction) */
+    ED_STAGE(SVT_ENCDEC_STAGE_TQ);
     int32_t cap[4];
     for (int s = 0; s < 4; s++) cap[s] = (int32_t)((size_t)n_pics * width * height * 3 / 2 / (size_t)(16 << (2 * s)));
-    rc = svt_tq_launch_device_lists(ctx, (const uint8_t *)src_lo, (const uint8_t *)pred_lo, recon_set, n_pics, w->d_blocks, cap, w->d_off_cnt, w->d_qtabs, w->d_iscan,
+    rc = svt_tq_launch_device_lists(ctx, (const uint8_t *)src_lo, (const uint8_t *)pred_lo, recon_set, n_sets, w->d_blocks, cap, w->d_off_cnt, w->d_qtabs, w->d_iscan,
                                     (int16_t *)q_lo, (int16_t *)dq_lo, w->d_eob, nullptr);
     if (rc) return rc;
     /* 4. eob map + skip flags (entries of the map that are not the origin of a transform block of THIS picture read 0) */
+    ED_STAGE(SVT_ENCDEC_STAGE_SKIP);
     for (int i = 0; i < n_pics; i++) HIP_TRY(hipMemsetAsync(pics[i].d_eob_map, 0, (size_t)(width / 4) * (height / 4) * 3 / 2 * sizeof(uint16_t), ctx->stream));
     {
         const int total_cap = (int)(w->cap_per_pic * (size_t)n_pics);
@@ -356,6 +376,7 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
         HIP_TRY(hipGetLastError());
     }
     /* 5. deblocking */
+    ED_STAGE(SVT_ENCDEC_STAGE_LF);
     if (flags->apply_loop_filter) {
         hipLaunchKernelGGL(svt_lf_mask_kernel, dim3((nwg + 63) / 64), dim3(64), 0, ctx->stream, dB, w->d_status);
         HIP_TRY(hipGetLastError());
@@ -363,12 +384,20 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
         if (rc) return rc;
     }
     /* 6. the reconstruction becomes a reference picture */
-    if (flags->pad_reference) {
-        rc = svt_hip_ref_pad_batch_device(ctx, n_pics, rec, pad_x, pad_y);
+    ED_STAGE(SVT_ENCDEC_STAGE_PAD);
+    if (flags->pad_reference && n_rec_pad) {
+        rc = svt_hip_ref_pad_batch_device(ctx, n_rec_pad, rec_pad, pad_x, pad_y);
         if (rc) return rc;
     }
+    ED_STAGE(SVT_ENCDEC_STAGE_END);
     w->last_pics = n_pics;
     return SVT_HIP_OK;
+}
+
+extern "C" void svt_hip_encdec_work_set_stage_hook(svt_encdec_work *w, svt_encdec_stage_hook hook, void *user) {
+    if (!w) return;
+    w->hook = hook;
+    w->hook_user = user;
 }
 
 extern "C" int32_t svt_hip_encdec_work_status(svt_hip_ctx *ctx, svt_encdec_work *w, int32_t counts[8]) {

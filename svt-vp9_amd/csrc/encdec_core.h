@@ -125,10 +125,10 @@ SVT_HD uint32_t svt_coeff_offset(int plane, int x, int y, int sb_cols) {
     const int sb = (y / sbw) * sb_cols + (x / sbw);
     return (uint32_t)sb * SVT_SB_COEFFS + (plane == 0 ? 0u : plane == 1 ? 4096u : 5120u) + svt_zorder4((x % sbw) >> 2, (y % sbw) >> 2) * 16u;
 }
-/* position code kept beside each descriptor: picture-in-batch << 28 | plane << 26 | (y >> 2) << 13 | (x >> 2), x / y in samples of
- * that plane (pictures are at most 8192 x 4320) */
+/* position code kept beside each descriptor: picture-in-batch << 24 | plane << 22 | (y >> 2) << 11 | (x >> 2), x / y in samples of
+ * that plane (pictures are at most 8192 x 4320: 11 bits each; up to 64 pictures per batch) */
 SVT_HD uint32_t svt_tq_pos(int pic, int plane, int x, int y) {
-    return (uint32_t)pic << 28 | (uint32_t)plane << 26 | (uint32_t)(y >> 2) << 13 | (uint32_t)(x >> 2);
+    return (uint32_t)pic << 24 | (uint32_t)plane << 22 | (uint32_t)(y >> 2) << 11 | (uint32_t)(x >> 2);
 }
 
 /* Is unit (ur, uc) the first unit of a well-formed prediction block that lies inside the picture?  1 yes, 0 no (covered by a
@@ -181,7 +181,7 @@ SVT_HD void svt_tq_unit_emit(const svt_lf_mode_info *mi, int mi_stride, int ur, 
                 k->src_stride = g->src_stride[c]; k->pred_stride = g->pred_stride[c]; k->recon_stride = g->recon_stride[c];
                 k->tx_size = (uint8_t)ts; k->tx_type = (uint8_t)tt; k->qtab = (uint8_t)c; k->do_recon = g->do_recon; k->partial32 = 0;
                 k->pad_[0] = (uint8_t)(SVT_TQ_RATE_INFO(0, c, b->is_inter) | SVT_TQ_RECON_SET(g->recon_set));
-                pos[i] = svt_tq_pos(g->recon_set, plane, x, y);
+                pos[i] = svt_tq_pos(g->pic, plane, x, y);
             }
     }
 }

@@ -3,6 +3,7 @@ reconstruction over the blocks of the mode-info grid -> skip flags -> loop-filte
 each stage the oracle's (oracle/*.c), composed on the host exactly as svt_hip_encdec_batch_device composes the kernels.
 Used by tests/test_gpu_encdec.py and tests/test_enc_shim.py to check the device chain and the encoder shim's reconstruction."""
 import ctypes as C
+import time
 
 import numpy as np
 
@@ -88,16 +89,25 @@ def eob_map_offsets(W, H):
     return 0, w4 * h4, w4 * h4 + (w4 // 2) * (h4 // 2), w4 * h4 + 2 * (w4 // 2) * (h4 // 2)
 
 
-def oracle_encdec_picture(src, refs, mc_mi, lf_mi, q_index, flags, thr, use_subpel=1, pad=PAD, recon_init=None):
+def oracle_encdec_picture(src, refs, mc_mi, lf_mi, q_index, flags, thr, use_subpel=1, pad=PAD, recon_init=None, timings=None):
     """src = (y, u, v) tight planes; refs = two RefPic; mc_mi / lf_mi [mi_rows][mi_cols] records.  Returns a dict with the padded
     reconstruction buffer (RefPic layout), qcoeff / dqcoeff in the driver's position-addressed layout, the eob map, the updated lf
     grid (skip flags) and the masks."""
     H, W = src[0].shape
     mi_rows, mi_cols = H // 8, W // 8
     mc_mi, lf_mi = np.ascontiguousarray(mc_mi), np.ascontiguousarray(lf_mi).copy()
+    tm = timings if timings is not None else {}
+    t0 = time.perf_counter()
+
+    def lap(name):
+        nonlocal t0
+        t1 = time.perf_counter()
+        tm[name] = tm.get(name, 0.0) + (t1 - t0)
+        t0 = t1
     # 1. inter prediction
     mcase = dict(mi=mc_mi, mi_rows=mi_rows, mi_cols=mi_cols, refs=[r.planes() for r in refs], pad=pad, use_subpel=use_subpel, width=W, height=H)
     pred = T.oracle_mc_frame(mcase)
+    lap("mc")
     # 2. the blocks: source and prediction as tight planes one after the other, the reconstruction padded
     rec = RefPic(W, H, pad) if recon_init is None else recon_init
     g = B.TqPicGeom()
@@ -110,7 +120,7 @@ def oracle_encdec_picture(src, refs, mc_mi, lf_mi, q_index, flags, thr, use_subp
     g.src_stride[0] = g.pred_stride[0] = W
     g.src_stride[1] = g.pred_stride[1] = W // 2
     g.recon_stride[0], g.recon_stride[1] = rec.pw, rec.cpw
-    g.coeff_base, g.recon_set, g.do_recon = 0, 0, int(flags.do_recon)
+    g.coeff_base, g.recon_set, g.pic, g.do_recon = 0, 0, 0, int(flags.do_recon)
     blocks, pos, cnt = host_block_list([lf_mi], [g], lf_mi.shape[1])
     blocks["pad"] &= 0x0F                                       # the oracle has one reconstruction buffer
     srcb = np.concatenate([p.ravel() for p in src])
@@ -124,14 +134,16 @@ def oracle_encdec_picture(src, refs, mc_mi, lf_mi, q_index, flags, thr, use_subp
     blocks["iscan_off"] = [offs[(int(t), int(tt))] for t, tt in zip(blocks["tx_size"], blocks["tx_type"])]
     qt = qtabs_of(q_index)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    lap("lists")
     rc = T.oracle().svt_oracle_tq_batch(vp(srcb), vp(predb), vp(rec.buf), vp(blocks), len(blocks), vp(qt), vp(iscan), vp(q), vp(dq), vp(eob))
     assert rc == 0
+    lap("tq")
     # 3. eob map, skip flags
     e0, e1, e2, e3 = eob_map_offsets(W, H)
     emap = np.zeros(e3, np.uint16)
     nz = np.zeros((mi_rows, mi_cols), bool)
-    plane = (pos >> 26) & 3
-    y4, x4 = (pos >> 13) & 0x1FFF, pos & 0x1FFF
+    plane = (pos >> 22) & 3
+    y4, x4 = (pos >> 11) & 0x7FF, pos & 0x7FF
     pw4 = np.where(plane == 0, W // 4, W // 8)
     emap[np.array([e0, e1, e2])[plane] + y4 * pw4 + x4] = eob
     uy, ux = np.where(plane == 0, y4 >> 1, y4), np.where(plane == 0, x4 >> 1, x4)
@@ -142,6 +154,7 @@ def oracle_encdec_picture(src, refs, mc_mi, lf_mi, q_index, flags, thr, use_subp
     nz[oy[hit], ox[hit]] = True
     r, c = np.meshgrid(np.arange(mi_rows), np.arange(mi_cols), indexing="ij")
     lf_mi["skip"][:, :mi_cols] = ~nz[r - r % h8[:, :mi_cols], c - c % w8[:, :mi_cols]]
+    lap("skip")
     out = dict(rec=rec, qcoeff=q, dqcoeff=dq, eob_map=emap, lf_mi=lf_mi, blocks=blocks, pos=pos, eob=eob, counts=cnt, pred=pred, lfm=None)
     # 4. deblocking
     if flags.apply_loop_filter:
@@ -151,8 +164,10 @@ def oracle_encdec_picture(src, refs, mc_mi, lf_mi, q_index, flags, thr, use_subp
         lfm_c = np.ascontiguousarray(lfm)
         rc = T.oracle().svt_oracle_lf_frame(C.byref(d), lfm_c.ctypes.data_as(C.c_void_p), lfm_c.shape[1], C.byref(thr), mi_rows, mi_cols, 0)
         assert rc == 0
+    lap("lf")
     # 5. the border
     if flags.pad_reference:
         d = rec.desc(rec.buf.ctypes.data)
         assert T.oracle().svt_oracle_ref_pad(C.byref(d), pad, pad) == 0
+    lap("pad")
     return out

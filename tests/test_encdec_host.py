@@ -66,7 +66,7 @@ def make_geom(W, H, pic=0, pad=80):
     g.recon_off[2] = g.recon_off[1] + cpw * (H // 2 + pad)
     g.recon_stride[0], g.recon_stride[1] = pw, cpw
     g.coeff_base = pic * (((W + 63) // 64) * ((H + 63) // 64) * B.SB_COEFFS)
-    g.recon_set, g.do_recon = pic, 1
+    g.recon_set, g.pic, g.do_recon = pic % 8, pic, 1
     return g
 
 
@@ -109,7 +109,7 @@ def test_tq_blocks_from_grid(seed, W, H):
         assert (k["src_stride"], k["pred_stride"], k["recon_stride"]) == (g.src_stride[c], g.pred_stride[c], g.recon_stride[c])
         tt = int(mis[p]["pad"][ur, uc, 0]) & 3 if (plane == 0 and ts < 3) else 0
         assert k["tx_type"] == tt
-        assert int(pos[i]) == (p << 28 | plane << 26 | (y >> 2) << 13 | (x >> 2))
+        assert int(pos[i]) == (p << 24 | plane << 22 | (y >> 2) << 11 | (x >> 2))
         assert (int(k["pad"][0]) >> 4) & 7 == p and (int(k["pad"][0]) >> 3) & 1 == int(mis[p]["is_inter"][ur, uc]) and (int(k["pad"][0]) >> 2) & 1 == c
         sbw = 32 if plane else 64
         sb = (y // sbw) * ((W + 63) // 64) + x // sbw

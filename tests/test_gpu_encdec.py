@@ -134,6 +134,7 @@ def run_device(ctx, W, H, srcs, refs, grids, q_index, flags, thr, rec_inits):
     (200, 136, 3, 208, dict(enc_mode=8, tune=1, temporal_layer_index=2, is_used_as_reference=1, recon_file=0, loop_filter=1)),   # no deblocking (mismatch allowed)
     (136, 72, 2, 100, dict(enc_mode=8, tune=1, temporal_layer_index=4, is_used_as_reference=0, recon_file=0, loop_filter=1)),    # no reconstruction at all
     (200, 136, 2, 236, dict(enc_mode=8, tune=1, temporal_layer_index=4, is_used_as_reference=0, recon_file=1, loop_filter=1)),   # recon output: filtered, not padded
+    (136, 72, 11, 180, dict(enc_mode=8, tune=1, temporal_layer_index=0, is_used_as_reference=1, recon_file=0, loop_filter=1)),   # more pictures than reconstruction bases
 ])
 def test_encdec_batch_vs_oracle_chain(ctx, W, H, n_pics, q_index, cfg):
     lib = B.load()
@@ -149,18 +150,25 @@ def test_encdec_batch_vs_oracle_chain(ctx, W, H, n_pics, q_index, cfg):
         r.buf[:] = rng.integers(0, 256, r.buf.size, dtype=np.uint8)      # a recycled buffer holds junk
     dp, blocks, pos, eob, cnt = run_device(ctx, W, H, srcs, refs, grids, q_index, flags, thr, rec_inits)
     # the lists the device built == the host lists of the same grids (batch order: size, picture, SB, unit)
-    geoms = []
+    geoms, set_base = [], []
     for i in range(n_pics):
         g = B.TqPicGeom()
         g.width, g.height = W, H
         for k, o in enumerate((0, W * H, W * H + (W // 2) * (H // 2))):
             g.src_off[k] = g.pred_off[k] = i * (W * H * 3 // 2) + o
-        for k, o in enumerate(rec_inits[i].offsets()):
-            g.recon_off[k] = o - rec_inits[i].offsets()[0]       # the driver's base of a reconstruction buffer: its lowest plane pointer
+        # the driver's reconstruction bases: a buffer joins the first base it lies within 4 GB above, else it opens a new one
+        ptrs = [dp[i].rec_t.data_ptr() + o for o in rec_inits[i].offsets()]
+        span = W * H * 2
+        k_set = next((k for k, b in enumerate(set_base) if min(ptrs) >= b and max(ptrs) - b + span < 2 ** 32), None)
+        if k_set is None:
+            k_set = len(set_base)
+            set_base.append(min(ptrs))
+        for k, ptr in enumerate(ptrs):
+            g.recon_off[k] = ptr - set_base[k_set]
         g.src_stride[0] = g.pred_stride[0] = W
         g.src_stride[1] = g.pred_stride[1] = W // 2
         g.recon_stride[0], g.recon_stride[1] = rec_inits[i].pw, rec_inits[i].cpw
-        g.coeff_base, g.recon_set, g.do_recon = i * T.n_sb(W, H) * B.SB_COEFFS, i, int(flags.do_recon)
+        g.coeff_base, g.recon_set, g.pic, g.do_recon = i * T.n_sb(W, H) * B.SB_COEFFS, k_set, i, int(flags.do_recon)
         geoms.append(g)
     hb, hp, hc = M.host_block_list([g_[1] for g_ in grids], geoms, W // 8)
     assert [cnt[4 + s] for s in range(4)] == hc and cnt[:4] == [0, hc[0], hc[0] + hc[1], hc[0] + hc[1] + hc[2]]
@@ -221,7 +229,7 @@ def test_lf_masks_device_equals_host(ctx):
     B.check(lib.svt_hip_ctx_synchronize(ctx))
     for g, m in zip(grids, m_t):
         want = T.product_lf_build_masks(g, mi_rows, mi_cols)
-        assert m.cpu().numpy().tobytes() == np.ascontiguousarray(want).tobytes()
+        assert masks_equal(m.cpu().numpy().view(B.LF_MASK_DTYPE).reshape(want.shape), want)
 
 
 def test_malformed_grid_is_reported(ctx):
