@@ -25,7 +25,10 @@
  *                                -> deblocking -> reference padding (svt_hip_encdec_batch_device), with the per-picture stage flags
  *                                the reference derives (svt_hip_encdec_flags_derive)
  *   GOPs                         closed GOPs are independent (Codec/EbPictureDecisionProcess.c:952): with SVT_HIP_DEVICES=0,1,.. GOP g
- *                                is coded on device g mod N, each with its own context and picture ring
+ *                                is coded on device g mod N, each with its own context and picture ring; with
+ *                                SVT_HIP_SPLIT_GOP=1 (latency mode) consecutive MINI-GOPs go to consecutive devices instead and the
+ *                                padded base-layer reconstruction (+ its analysed planes) is handed to the next device, device to
+ *                                device (svt_hip_ref_handoff_device): the one exchange step of the path
  * Every picture is answered by a zero-byte packet: entropy coding is outside the hot path.
  * Not reproduced (picture decision / rate control, control plane): the low-delay-P structure tables of the parts of a short group
  * (those pictures are a P chain), per-layer QP scaling (every picture uses quantizer_to_qindex[qp]), intra prediction (an intra
@@ -72,6 +75,8 @@ typedef struct shim_slot { /* one buffered picture, everything device resident *
     int            processed;   /* its ME (or, for an intra picture, its analysis) has been enqueued */
     int            coded;       /* the stages behind mode decision have been enqueued */
     int            has_marker;
+    int            is_copy;     /* split-GOP mode: the base picture of the previous mini-GOP, handed over from the device that coded it
+                                   (analysed planes + reference picture only) */
     uint64_t       marker;      /* completion of everything enqueued for this picture so far */
     svt_vp9_shim_picture_info info;
 } shim_slot;
@@ -92,7 +97,7 @@ typedef struct shim_state {
     int         configured, initialised, eos, failed;
     int         levels, minigop;       /* hierarchical levels, 1 << levels */
     int         intra_period;          /* resolved */
-    int         n_dev, cur_dev;
+    int         n_dev, cur_dev, split_gop;
     shim_dev    dev[SHIM_MAX_DEV];
     int64_t     gop;                   /* index of the GOP being sent */
     int64_t     next_number;           /* display number of the next picture sent */
@@ -350,6 +355,7 @@ EbErrorType eb_vp9_init_encoder(EbComponentType *h) {
     }
     s->n_dev = n;
     s->cur_dev = 0;
+    { const char *sg = getenv("SVT_HIP_SPLIT_GOP"); s->split_gop = n > 1 && sg && atoi(sg) != 0; }
     if (s->md_cb) {
         s->h_results = malloc((size_t)s->n_sb * 85 * sizeof(svt_me_pu_result));
         s->h_mc = malloc((size_t)s->mi_rows * s->mi_cols * sizeof(svt_mc_mode_info));
@@ -368,12 +374,32 @@ static shim_slot *find_slot(shim_dev *d, int64_t number) {
     for (int i = 0; i < d->n_slots; i++) if (d->slot[i].number == number) return &d->slot[i];
     return NULL;
 }
-static shim_slot *find_any(shim_state *s, int64_t number, shim_dev **dev) {
-    for (int k = 0; k < s->n_dev; k++) {
-        shim_slot *t = find_slot(&s->dev[k], number);
-        if (t) { if (dev) *dev = &s->dev[k]; return t; }
-    }
+static shim_slot *find_any(shim_state *s, int64_t number, shim_dev **dev) { /* the picture where it was coded, not a handed-over copy */
+    for (int k = 0; k < s->n_dev; k++)
+        for (int i = 0; i < s->dev[k].n_slots; i++) {
+            shim_slot *t = &s->dev[k].slot[i];
+            if (t->number == number && !t->is_copy) { if (dev) *dev = &s->dev[k]; return t; }
+        }
     return NULL;
+}
+
+/* split-GOP mode: the next mini-GOP is coded on device `to`; it predicts from the base picture the current device has just
+ * finished -- its analysed planes (motion estimation) and its padded reconstruction (inter prediction) travel device to device,
+ * ordered behind the producer's work and in front of the consumer's (svt_hip_ref_handoff_device) */
+static EbErrorType handoff_base(shim_state *s, shim_dev *from, shim_dev *to, int64_t number) {
+    shim_slot *a = find_slot(from, number);
+    if (!a) return EB_ErrorBadParameter;
+    shim_slot *b = &to->slot[to->accepted % to->n_slots];
+    if (b->has_marker) GPU_TRY(svt_hip_ctx_marker_wait(to->ctx, b->marker));
+    const svt_plane *pa[3] = {&a->pa.full, &a->pa.quarter, &a->pa.sixteenth}, *pb[3] = {&b->pa.full, &b->pa.quarter, &b->pa.sixteenth};
+    for (int k = 0; k < 3; k++)
+        GPU_TRY(svt_hip_ref_handoff_device(from->ctx, pa[k]->buf, to->ctx, (void *)pb[k]->buf, (size_t)pa[k]->stride * (size_t)(pa[k]->height + 2 * pa[k]->origin_y)));
+    GPU_TRY(svt_hip_ref_handoff_device(from->ctx, a->d_rec, to->ctx, b->d_rec, s->rec_bytes));
+    to->accepted++;
+    b->number = number; b->pts = a->pts; b->info = a->info; b->processed = 1; b->coded = 1; b->is_copy = 1;
+    GPU_TRY(svt_hip_ctx_marker_record(to->ctx, &b->marker));
+    b->has_marker = 1;
+    return EB_ErrorNone;
 }
 
 static int push_packet(shim_state *s, int64_t pts, uint32_t flags, uint32_t pic_type, int dev, uint64_t marker) {
@@ -675,6 +701,12 @@ static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_str
     }
     s->last_base = first + s->pending - 1;
     s->pending = 0;
+    if (s->split_gop && !cut_by_intra && !end_of_stream) { /* the next mini-GOP of this GOP goes to the next device */
+        const int next = (s->cur_dev + 1) % s->n_dev;
+        const EbErrorType e = handoff_base(s, d, &s->dev[next], s->last_base);
+        if (e != EB_ErrorNone) return e;
+        s->cur_dev = next;
+    }
     return EB_ErrorNone;
 }
 
@@ -694,7 +726,7 @@ EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *
         const int     intra = n == 0 || (s->intra_period >= 0 && n % (s->intra_period + 1) == 0);
         if (intra) { /* an intra refresh closes the GOP: what is waiting is coded on its own device, cut as the reference cuts it */
             if ((e = flush_pending(s, 1, 0)) != EB_ErrorNone) return e;
-            if (n) { s->gop++; s->cur_dev = svt_hip_gop_owner(s->gop, s->n_dev); }
+            if (n) { s->gop++; if (!s->split_gop) s->cur_dev = svt_hip_gop_owner(s->gop, s->n_dev); }
             s->last_base = -1;
         }
         shim_dev  *d = &s->dev[s->cur_dev];
@@ -717,7 +749,7 @@ EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *
         /* the picture is accepted from here on */
         s->next_number = n + 1;
         d->accepted++;
-        t->number = n; t->pts = b->pts; t->processed = 0; t->coded = 0; t->has_marker = 0;
+        t->number = n; t->pts = b->pts; t->processed = 0; t->coded = 0; t->has_marker = 0; t->is_copy = 0;
         memset(&t->info, 0, sizeof t->info);
         t->info.picture_number = (uint64_t)n; t->info.n_sb = (uint32_t)s->n_sb; t->info.device_ordinal = d->ordinal;
         if (intra) {

@@ -4,6 +4,7 @@ the last; Codec/EbEncHandle.c:2837-2865), and every byte equals the oracle chain
 each picture predicted from the RECONSTRUCTED, deblocked (where the reference deblocks), padded pictures before it.  Both decision
 sources: the built-in stand-in and a host callback (svt_vp9_shim_set_mode_decision)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -67,7 +68,7 @@ def stand_in(me, W, H, lam, level):
     return mc, lf
 
 
-def run_clip(W, H, N, enc_mode, tune, qp, recon_file, intra_period, use_callback, seed=41):
+def run_clip(W, H, N, enc_mode, tune, qp, recon_file, intra_period, use_callback, seed=41, env=None):
     """returns (frames, delivered reconstructions {pts: bytes}, order of delivery, per-picture info, padded reference pictures of some pictures)"""
     lib = shim()
     for f_ in ("svt_vp9_shim_get_me_results", "svt_vp9_shim_get_coded_picture", "svt_vp9_shim_get_reference_picture", "svt_vp9_shim_set_mode_decision", "eb_vp9_svt_get_packet",
@@ -96,7 +97,16 @@ def run_clip(W, H, N, enc_mode, tune, qp, recon_file, intra_period, use_callback
     keep = MD_CB(cb)
     if use_callback:
         assert lib.svt_vp9_shim_set_mode_decision(h, keep, None) == 0
-    assert lib.eb_vp9_init_encoder(h) == 0
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        assert lib.eb_vp9_init_encoder(h) == 0
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     recon, order, flags_seen, packets = {}, [], [], []
     rbuf = np.zeros(W * H * 3 // 2, np.uint8)
 
@@ -276,6 +286,24 @@ def test_get_recon_equals_the_oracle_chain(use_callback, N, intra_period):
     # the loop is closed: a picture predicted from reconstructions differs from one predicted from sources
     deblocked = [k for k in range(N) if not outs[k]["intra"] and outs[k]["flags"].apply_loop_filter]
     assert deblocked and len(deblocked) == N - sum(1 for k in range(N) if outs[k]["intra"])         # recon output on: every picture is deblocked
+
+
+@pytest.mark.parametrize("env,N,intra_period", [
+    ({"SVT_HIP_DEVICES": "0,0"}, 34, 19),                                  # two closed GOPs on two contexts (GOP g -> device g mod N)
+    ({"SVT_HIP_DEVICES": "0,0", "SVT_HIP_SPLIT_GOP": "1"}, 36, -1),        # one GOP, consecutive mini-GOPs on alternating contexts + hand-off
+    ({"SVT_HIP_DEVICES": "0,0,0", "SVT_HIP_SPLIT_GOP": "1"}, 34, 19),
+])
+def test_several_contexts_give_the_same_reconstruction(env, N, intra_period):
+    """the multi-device paths of the library on one GPU: every "device" is a context of its own on ordinal 0 (own stream, own picture
+    ring, own workspace); GOP sharding needs no exchange, split-GOP mode hands the padded base-layer reconstruction and its analysed
+    planes from context to context (svt_hip_ref_handoff_device).  The reconstruction must not depend on how the work was dealt."""
+    W, H, enc_mode, tune, qp = 256, 192, 8, 1, 40
+    frames, recon, order, flags_seen, packets, infos, refpics, _ = run_clip(W, H, N, enc_mode, tune, qp, 1, intra_period, False, env=env)
+    recs, outs = oracle_clip(frames, W, H, N, enc_mode, tune, qp, 1, intra_period, False)
+    assert sorted(order) == list(range(N)) and len(packets) == N and packets[-1][1] & 1 and flags_seen[-1] == 1
+    for k in range(N):
+        y, u, v = recs[k].interior()
+        assert np.array_equal(recon[k], np.concatenate([y.ravel(), u.ravel(), v.ravel()])), k
 
 
 def test_without_recon_output_only_reference_pictures_are_reconstructed():

@@ -91,10 +91,46 @@ if __name__ == "__main__" and len(sys.argv) == 6 and sys.argv[1] == "--worker":
 N_MINIGOPS = 7
 
 
+HW, HH = 136, 72      # picture of the hand-off chain: 3 x 2 superblocks, the last row 8 samples high
+
+
 def _encode_minigop(ref, m):
-    """stand-in for "encode mini-GOP m from its reference": the next reference depends on every byte of the previous one"""
+    """"encode the base picture of mini-GOP m from its reference": the REAL chain of the path on the host (the oracle's inter
+    prediction from the padded reference -> transform / quantisation / reconstruction -> skip flags -> masks -> deblocking ->
+    padding, tests/encdec_model.py) -- what comes out is the padded reference picture the next mini-GOP needs, every byte of it a
+    function of the previous one.  ref / result: the whole padded buffer (three planes) as a uint8 tensor."""
+    import ctypes as C
+    import numpy as np
     import torch
-    return (ref.to(torch.int32) * 3 + m + torch.arange(ref.numel(), dtype=torch.int32).reshape(ref.shape) % 7).to(torch.uint8)
+    sys.path.insert(0, HERE)
+    import encdec_model as M
+    import svt_testlib as T
+    B = T.B
+    lib = B.load()
+    src_y = T.gen_clip(HW, HH, 1, 300 + m)[0]
+    src = (src_y, (src_y[::2, ::2] // 2 + 32).astype(np.uint8), np.full((HH // 2, HW // 2), 128, np.uint8))
+    rp = M.RefPic(HW, HH)
+    rp.buf[:] = ref.numpy()[:rp.buf.size]
+    me = np.zeros((T.n_sb(HW, HH), 85), dtype=B.ME_RESULT_DTYPE)         # zero motion: predict from the co-located reference samples
+    me["dist0"] = (np.arange(85) * 37 + m) % 500
+    mc = np.zeros((HH // 8, HW // 8), dtype=B.MC_MODE_INFO_DTYPE)
+    lf = np.zeros((HH // 8, HW // 8), dtype=B.LF_MODE_INFO_DTYPE)
+    assert lib.svt_hip_md_default_picture(me.ctypes.data_as(C.c_void_p), HW, HH, 100, 20, mc.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p), HW // 8) == 0
+    fl = B.EncdecFlags(limit_intra=0, allow_enc_dec_mismatch=0, do_recon=1, apply_loop_filter=1, pad_reference=1)
+    thr = B.LfThresh()
+    lib.svt_hip_lf_thresh_init(C.byref(thr), 0)
+    o = M.oracle_encdec_picture(src, [rp, rp], mc, lf, 160, fl, thr)
+    return torch.from_numpy(o["rec"].buf.copy())
+
+
+def _first_reference():
+    import numpy as np
+    import torch
+    sys.path.insert(0, HERE)
+    import encdec_model as M
+    import svt_testlib as T
+    y = T.gen_clip(HW, HH, 1, 299)[0]
+    return torch.from_numpy(M.RefPic(HW, HH).set_padded(y, (y[::2, ::2] // 2 + 32).astype(np.uint8), np.full((HH // 2, HW // 2), 128, np.uint8)).buf.copy())
 
 
 def _handoff_worker(rank, world, port, out_path):
@@ -105,9 +141,9 @@ def _handoff_worker(rank, world, port, out_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     S = _load_shard()
-    ref = torch.zeros((40, 56), dtype=torch.uint8)        # a (small) padded reference picture buffer
+    ref = torch.zeros_like(_first_reference())            # a padded reference picture buffer (three planes)
     if S.minigop_owner(0, world) == rank:
-        ref = torch.full((40, 56), 9, dtype=torch.uint8)  # the key frame's reconstruction
+        ref = _first_reference()                          # the key frame's reconstruction
     log = []
     for m in range(N_MINIGOPS):
         got = S.handoff_reference(dist, ref, m, world, rank)       # no-op for everyone but producer and consumer
@@ -135,7 +171,7 @@ def test_reference_handoff_chain_gloo_world2(tmp_path):
     mp.spawn(_handoff_worker, args=(2, port, out), nprocs=2, join=True)
     got = json.load(open(out))
     # serial run of the same chain
-    ref = torch.full((40, 56), 9, dtype=torch.uint8)
+    ref = _first_reference()
     for m in range(N_MINIGOPS):
         ref = _encode_minigop(ref, m)
     want = int(ref.to(torch.int64).sum())
