@@ -145,6 +145,31 @@ def cpu_model():
     return "unknown"
 
 
+def effective_cpus():
+    """host cores this process may actually use: the hardware thread count, capped by the container's CPU-time quota (cgroup v2
+    cpu.max / v1 cfs quota) -- on the GPU boxes of this pool 256 hardware threads are visible but the quota is 16 CPUs' worth of time,
+    so more than 16 busy processes only take turns"""
+    n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    return max(1, min(n, int(quota))) if quota else n, n, quota
+
+
 def build_native_oracle():
     """oracle/*.c compiled for this host (auto-vectorised SAD / transform loops: the "AVX2-class" CPU proxy of SURVEY 8(d))"""
     out = os.path.join(tempfile.gettempdir(), f"liboracle_native_{os.getuid()}.so")
@@ -1052,7 +1077,7 @@ def cpu_baseline(T, B, frames, src_all, mc_mi, lf_mi, lfm, Wd, Hd, enc_mode, tun
     lets every core work.  Wall-clock of the slowest process.  Timed with min(host cores, memory-bound cap) processes and with 8
     (SURVEY 8(d)).  Reported, never the target."""
     import multiprocessing as mp
-    ncpu = os.cpu_count() or 1
+    ncpu, hw_threads, quota = effective_cpus()
     lib_path = build_native_oracle()
     orc = C.CDLL(lib_path)
     try:
@@ -1079,7 +1104,7 @@ def cpu_baseline(T, B, frames, src_all, mc_mi, lf_mi, lfm, Wd, Hd, enc_mode, tun
         n_all = max(1, min(ncpu, mem_cap, 256))
         fps_all, wall_all, stage_all = run(n_all)
         fps_8, wall_8, stage_8 = run(min(8, n_all)) if n_all > 8 else (fps_all, wall_all, stage_all)
-    return {"value": round(fps_all, 3), "unit": "frames/s", "cores": n_all, "host_cores": ncpu, "kind": "port", "cpu_model": cpu_model(),
+    return {"value": round(fps_all, 3), "unit": "frames/s", "cores": n_all, "hardware_threads": hw_threads, "cpu_quota_cores": quota, "kind": "port", "cpu_model": cpu_model(),
             "value_8_cores": round(fps_8, 3), "scaling_vs_8_cores": round(fps_all / max(fps_8, 1e-9), 2),
             "seconds_all_cores": round(wall_all, 2), "seconds_8_cores": round(wall_8, 2),
             "reference_me": reference_me_rate(T, B, orc, frames, Wd, Hd, enc_mode, tune, l1_on, ncpu),
@@ -1088,7 +1113,9 @@ def cpu_baseline(T, B, frames, src_all, mc_mi, lf_mi, lfm, Wd, Hd, enc_mode, tun
             "sample": f"C-path proxy: oracle (C restatement of the reference's C path, gcc -O3 -march=native on this host = auto-vectorised \"AVX2-class\" "
                       f"proxy; the reference's AVX2 / yasm build cannot be made here) on {n_all} whole {Wd}x{Hd} pictures of the same mini-GOP through the "
                       f"stages of the step (picture analysis, ME, inter prediction, transform / quant / recon, skip flags, masks + deblocking, padding), one "
-                      f"single-threaded process per picture, {n_all} processes at once (value) and 8 (value_8_cores); wall-clock of the slowest process"}
+                      f"single-threaded process per picture, {n_all} processes at once (value) and 8 (value_8_cores); wall-clock of the slowest process.  "
+                      f"cores = what this container may use: {hw_threads} hardware threads are visible, the cgroup CPU quota is "
+                      f"{quota if quota else 'unlimited'} CPUs' worth of time (more busy processes than that only take turns)"}
 
 
 def _cpu_warm(_k):

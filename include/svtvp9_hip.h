@@ -164,6 +164,13 @@ int32_t svt_hip_me_params_preset(svt_me_params *p, int32_t pic_width, int32_t pi
                                  int32_t tune, int32_t num_ref_lists, int32_t temporal_layer_index,
                                  int32_t hierarchical_levels);
 
+/* diagnostic: which compiled instance of the ME kernel serves a parameter set -- 0 the generic one, > 0 an instance whose search
+ * parameters are compile-time constants (one per BASELINE configuration; identical results by construction) */
+int32_t svt_hip_me_kernel_instance(const svt_me_params *p);
+/* 1 when two parameter sets may share one launch of svt_hip_me_batch_layers_device: equal in every field but num_ref_lists,
+ * temporal_layer_index, hierarchical_levels and same_ref_poc (compared field by field: the record has padding) */
+int32_t svt_hip_me_params_same_launch(const svt_me_params *a, const svt_me_params *b);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* context                                                                                            */
 /* ------------------------------------------------------------------------------------------------ */

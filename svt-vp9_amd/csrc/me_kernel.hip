@@ -27,7 +27,7 @@ extern __shared__ __align__(16) uint8_t svt_lds[];
  * (neighbouring SBs, which share most of their reference window) are placed on the same XCD so that the
  * window re-reads hit that XCD's L2 (block b runs on XCD b % 8). */
 template <int SPEC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC != 0 ? ME_WAVES_PER_EU_SPEC : ME_WAVES_PER_EU))) void svt_me_sb_kernel(const me_pic_dev *__restrict__ pics, svt_me_params p, me_lds_layout L,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC == 0 ? ME_WAVES_PER_EU : me_spec_waves_per_eu(SPEC) == 5 ? ME_WAVES_PER_EU_SPEC : me_spec_waves_per_eu(SPEC)))) void svt_me_sb_kernel(const me_pic_dev *__restrict__ pics, svt_me_params p, me_lds_layout L,
                                                         int n_sb, int nx, int pic_w, int pic_h, int total, int chunk, unsigned long long *prof) {
     /* block b runs on XCD b & 7: XCD k takes the k-th eighth of the SBs of EVERY picture (chunk SBs each; pictures of different
      * temporal layers cost differently, an XCD per picture range would leave the XCDs unbalanced), in picture order */
@@ -127,12 +127,7 @@ __global__ __launch_bounds__(256) void svt_sad_loop_kernel(const uint8_t *__rest
 /* launchers                                                                                          */
 /* ------------------------------------------------------------------------------------------------ */
 /* the fields that may differ between the pictures of one launch (me_spec.h: everything else is constant inside a configuration) */
-static bool me_params_same_config(const svt_me_params *a, const svt_me_params *b) {
-    svt_me_params x = *a, y = *b;
-    x.num_ref_lists = y.num_ref_lists = 0; x.temporal_layer_index = y.temporal_layer_index = 0;
-    x.hierarchical_levels = y.hierarchical_levels = 0; x.same_ref_poc = y.same_ref_poc = 0;
-    return memcmp(&x, &y, sizeof x) == 0;
-}
+static bool me_params_same_config(const svt_me_params *a, const svt_me_params *b) { return svt_hip_me_params_same_launch(a, b) != 0; }
 
 /* params_stride = 0: one parameter set for every picture; 1: params[i] belongs to picture i */
 static int32_t me_launch(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture *cur, const svt_pa_picture *ref0, const svt_pa_picture *ref1,
@@ -200,6 +195,8 @@ static int32_t me_launch(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture 
     case 1: ME_LAUNCH(1); break;
     case 2: ME_LAUNCH(2); break;
     case 3: ME_LAUNCH(3); break;
+    case 4: ME_LAUNCH(4); break;
+    case 5: ME_LAUNCH(5); break;
     default: ME_LAUNCH(0); break;
 #undef ME_LAUNCH
     }
@@ -225,6 +222,9 @@ static int32_t me_launch(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture 
     ctx->timed = 1;
     return SVT_HIP_OK;
 }
+
+/* which compiled instance serves a parameter set: 0 = the generic one, 1..ME_SPEC_COUNT = a specialised one (me_spec.h) */
+extern "C" int32_t svt_hip_me_kernel_instance(const svt_me_params *p) { return p ? me_spec_match(p) : -1; }
 
 extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture *cur,
                                            const svt_pa_picture *ref0, const svt_pa_picture *ref1,

@@ -123,3 +123,19 @@ int32_t svt_hip_me_params_preset(svt_me_params *p, int32_t pic_width, int32_t pi
     c.frame_rate = 60;
     return svt_hip_me_params_derive(p, &c);
 }
+
+/* may two parameter sets share one launch (svt_hip_me_batch_layers_device)?  They may differ in the four per-picture fields; compared
+ * field by field -- the records carry padding bytes that nothing initialises */
+int32_t svt_hip_me_params_same_launch(const svt_me_params *a, const svt_me_params *b) {
+    if (!a || !b) return 0;
+#define EQ(f) (a->f == b->f)
+#define EQ2(f) (a->f[0] == b->f[0] && a->f[1] == b->f[1])
+    return EQ(enable_hme_flag) && EQ(enable_hme_level_0_flag) && EQ(enable_hme_level_1_flag) && EQ(enable_hme_level_2_flag) && EQ(cu8x8_mode) &&
+           EQ(cu16x16_mode) && EQ(rate_control_mode) && EQ(fractional_search_method) && EQ(fractional_search_model) && EQ(fractional_search64x64) &&
+           EQ(single_hme_quadrant) && EQ(search_area_width) && EQ(search_area_height) && EQ(number_hme_search_region_in_width) &&
+           EQ(number_hme_search_region_in_height) && EQ(hme_level0_total_search_area_width) && EQ(hme_level0_total_search_area_height) &&
+           EQ2(hme_level0_search_area_in_width_array) && EQ2(hme_level0_search_area_in_height_array) && EQ2(hme_level1_search_area_in_width_array) &&
+           EQ2(hme_level1_search_area_in_height_array) && EQ2(hme_level2_search_area_in_width_array) && EQ2(hme_level2_search_area_in_height_array);
+#undef EQ
+#undef EQ2
+}

@@ -88,4 +88,5 @@ def test_cpu_baseline_leg_runs_one_process_per_picture():
         lf[i] = bench.build_lf_mode_info(B, k_cell, mi_rows, mi_cols, 20)
     out = bench.cpu_baseline(T, B, frames, src_all, mc, lf, None, W, H, 8, 1, True)
     assert out["kind"] == "port" and out["value"] > 0 and out["value_8_cores"] > 0 and 1 <= out["cores"] <= (os.cpu_count() or 1)
+    assert out["cores"] == bench.effective_cpus()[0] or out["cores"] < bench.effective_cpus()[0]
     assert set(out["stage_seconds_per_picture_1_core"]) == {"pa", "me", "mc", "lists", "tq", "skip", "lf", "pad"} and out["cpu_model"]

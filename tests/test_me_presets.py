@@ -53,3 +53,22 @@ def test_me_preset_rejects_bad_arguments():
     assert lib.svt_hip_me_params_preset(C.byref(q), 1280, 720, 5, 3, 1, 0, 4) == -1
     assert lib.svt_hip_me_params_preset(C.byref(q), 1280, 720, 5, 1, 3, 0, 4) == -1
     assert lib.svt_hip_me_params_preset(None, 1280, 720, 5, 1, 1, 0, 4) == -1
+
+
+def test_every_baseline_configuration_has_a_specialised_kernel_instance():
+    """the constants compiled into svt_me_sb_kernel<SPEC> (csrc/me_spec.h) equal what the parameter derivation yields for the BASELINE
+    configurations: the launcher finds an instance for each of them, every layer; any other parameter set gets the generic instance"""
+    import ctypes as C
+    lib = B.load()
+    want = {("c1", 640, 360, 9, 1, 4): {3}, ("c2", 1920, 1080, 8, 1, 4): {2}, ("c3", 3840, 2160, 8, 1, 4): {1}, ("c5", 3840, 2160, 3, 0, 3): {4, 5}}
+    for (name, w, h, mode, tune, levels), inst in want.items():
+        got = set()
+        for layer in range(levels + 1):
+            for nl in (1, 2):
+                p = B.me_params_preset(w, h, mode, tune, nl, layer, levels)
+                got.add(lib.svt_hip_me_kernel_instance(C.byref(p)))
+        assert got == inst, (name, got)
+    p = B.me_params_preset(1280, 720, 6, 1, 2, 1, 4)
+    assert lib.svt_hip_me_kernel_instance(C.byref(p)) == 0
+    a, b = B.me_params_preset(3840, 2160, 3, 0, 2, 1, 3), B.me_params_preset(3840, 2160, 3, 0, 2, 3, 3)
+    assert lib.svt_hip_me_params_same_launch(C.byref(a), C.byref(a)) == 1 and lib.svt_hip_me_params_same_launch(C.byref(a), C.byref(b)) == 0   # cu8x8_mode differs
