@@ -35,6 +35,7 @@ struct svt_encdec_work {
     uint32_t     *d_pos;
     uint16_t     *d_eob;
     int32_t      *d_counts;      /* [4][max_pics][n_sb], turned into offsets by the scan */
+    int32_t      *d_totals, *d_bases; /* [4][max_pics]: blocks of a (size, picture) / its first block */
     int32_t      *d_off_cnt;     /* [8]: first block / number of blocks per size */
     int32_t      *d_status;      /* != 0: a malformed grid was seen */
     svt_quant_tables *d_qtabs;   /* [2] luma, chroma of the batch's q index */
@@ -93,35 +94,42 @@ __global__ __launch_bounds__(64) void svt_tq_count_kernel(const ed_batch_dev *__
     }
 }
 
-/* exclusive scan of a[0..M) in place by one workgroup; off_cnt[s] = a[s * group] after the scan (first block of size s),
- * off_cnt[4 + s] = number of blocks of size s */
-__global__ __launch_bounds__(1024) void svt_scan_kernel(int32_t *__restrict__ a, int M, int group, int32_t *__restrict__ off_cnt) {
-    __shared__ int32_t part[1024];
-    const int t = (int)threadIdx.x, per = (M + 1023) / 1024, b = t * per, e = b + per < M ? b + per : M;
+/* Offsets of the lists, two small kernels instead of one long serial one.  Level 1: one workgroup per (size, picture) turns the
+ * picture's per-SB counts into exclusive prefixes in place and leaves the picture's total in totals[size * n_pics + picture].  Level 2:
+ * one wave turns the totals into the first block of every (size, picture) (bases[], in list order: size, then picture) and into
+ * off_cnt[s] / off_cnt[4 + s] = first block / number of blocks of size s.  The emit kernel adds bases[] to the per-SB prefixes. */
+__global__ __launch_bounds__(256) void svt_scan_sb_kernel(int32_t *__restrict__ a, int n_sb, int32_t *__restrict__ totals) {
+    __shared__ int32_t part[256];
+    int32_t *p = a + (size_t)blockIdx.x * n_sb;
+    const int t = (int)threadIdx.x, per = (n_sb + 255) / 256, b = t * per, e = b + per < n_sb ? b + per : n_sb;
     int s = 0;
-    for (int i = b; i < e; i++) s += a[i];
+    for (int i = b; i < e; i++) s += p[i];
     part[t] = s;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
+    for (int d = 1; d < 256; d <<= 1) {
         const int v = t >= d ? part[t - d] : 0;
         __syncthreads();
         part[t] += v;
         __syncthreads();
     }
     int run = part[t] - s;
-    for (int i = b; i < e; i++) { const int v = a[i]; a[i] = run; run += v; }
-    __syncthreads();
-    if (t < 4) {
-        const int first = a[t * group], next = t < 3 ? a[(t + 1) * group] : part[1023];
-        off_cnt[t] = first;
-        off_cnt[4 + t] = next - first;
+    for (int i = b; i < e; i++) { const int v = p[i]; p[i] = run; run += v; }
+    if (t == 255) totals[blockIdx.x] = part[255];
+}
+__global__ __launch_bounds__(64) void svt_scan_pic_kernel(const int32_t *__restrict__ totals, int n_pics, int32_t *__restrict__ bases, int32_t *__restrict__ off_cnt) {
+    if (threadIdx.x != 0) return; /* 4 x n_pics (<= 128) values: not worth more than one lane */
+    int run = 0;
+    for (int s = 0; s < 4; s++) {
+        off_cnt[s] = run;
+        for (int p = 0; p < n_pics; p++) { bases[s * n_pics + p] = run; run += totals[s * n_pics + p]; }
+        off_cnt[4 + s] = run - off_cnt[s];
     }
 }
 
 /* same mapping as the count kernel: every block-origin lane writes its descriptors at offsets[size][picture][SB] + (blocks of that
  * size of the lanes before it) */
-__global__ __launch_bounds__(64) void svt_tq_emit_kernel(const ed_batch_dev *__restrict__ B, const int32_t *__restrict__ offsets, svt_tq_block *__restrict__ blocks,
-                                                         uint32_t *__restrict__ pos) {
+__global__ __launch_bounds__(64) void svt_tq_emit_kernel(const ed_batch_dev *__restrict__ B, const int32_t *__restrict__ offsets, const int32_t *__restrict__ bases,
+                                                         svt_tq_block *__restrict__ blocks, uint32_t *__restrict__ pos) {
     const int sb = (int)blockIdx.x % B->n_sb, pic = (int)blockIdx.x / B->n_sb, lane = (int)threadIdx.x;
     const ed_pic_dev &P = B->pic[pic];
     const int ur = (sb / B->sb_cols) * 8 + (lane >> 3), uc = (sb % B->sb_cols) * 8 + (lane & 7);
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(64) void svt_tq_emit_kernel(const ed_batch_dev *__r
     const int o = svt_tq_unit_is_origin(P.lf_mi, B->mi_stride, B->mi_rows, B->mi_cols, ur, uc);
     if (o == 1) svt_tq_unit_counts(P.lf_mi, B->mi_stride, ur, uc, cnt);
     uint32_t base[4];
-    _Pragma("unroll") for (int s = 0; s < 4; s++) base[s] = (uint32_t)(offsets[(s * B->n_pics + pic) * B->n_sb + sb] + wave_excl_prefix(cnt[s], lane));
+    _Pragma("unroll") for (int s = 0; s < 4; s++) base[s] = (uint32_t)(bases[s * B->n_pics + pic] + offsets[(s * B->n_pics + pic) * B->n_sb + sb] + wave_excl_prefix(cnt[s], lane));
     if (o == 1) svt_tq_unit_emit(P.lf_mi, B->mi_stride, ur, uc, &P.g, B->iscan_off, base, blocks, pos);
 }
 
@@ -169,13 +177,36 @@ __global__ __launch_bounds__(256) void svt_skip_update_kernel(const ed_batch_dev
     b->skip = P.nz[(ur - ur % h8) * B->mi_stride + (uc - uc % w8)] ? 0 : 1;
 }
 
-/* one thread per (picture, SB): its LOOP_FILTER_MASK (the rule of svt_hip_lf_build_masks, same text) */
+/* one wave per (picture, SB), one lane per 8x8 unit: the unit's contribution (svt_lf_mask_unit, the text svt_hip_lf_build_masks runs
+ * on the host) and a wave-wide OR; lane u writes lfl_y[u], lanes 0..18 the mask words */
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+    _Pragma("unroll") for (int d = 32; d >= 1; d >>= 1) v |= (uint32_t)__shfl_xor((int)v, d, 64);
+    return v;
+}
 __global__ __launch_bounds__(64) void svt_lf_mask_kernel(const ed_batch_dev *__restrict__ B, int32_t *__restrict__ status) {
-    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i >= B->n_sb * B->n_pics) return;
-    const int pic = i / B->n_sb, sb = i % B->n_sb;
+    const int sb = (int)blockIdx.x % B->n_sb, pic = (int)blockIdx.x / B->n_sb, lane = (int)threadIdx.x;
     const ed_pic_dev &P = B->pic[pic];
-    if (svt_lf_mask_build_sb(P.lf_mi, B->mi_stride, B->mi_rows, B->mi_cols, sb / B->sb_cols, sb % B->sb_cols, &P.lfm[sb]) && status) atomicOr(status, 1);
+    svt_lf_unit_masks u;
+    svt_lf_mask_unit(P.lf_mi, B->mi_stride, B->mi_rows, B->mi_cols, sb / B->sb_cols, sb % B->sb_cols, lane >> 3, lane & 7, &u);
+    if (u.bad && status) atomicOr(status, 1);
+    svt_lf_mask *m = &P.lfm[sb];
+    uint64_t     w64[9];
+    _Pragma("unroll") for (int i = 0; i < 4; i++) { w64[i] = u.left_y[i]; w64[4 + i] = u.above_y[i]; }
+    w64[8] = u.int_4x4_y;
+    _Pragma("unroll") for (int i = 0; i < 9; i++) {
+        const uint64_t v = (uint64_t)wave_or((uint32_t)w64[i]) | (uint64_t)wave_or((uint32_t)(w64[i] >> 32)) << 32;
+        if (lane == i) ((uint64_t *)m)[i] = v;   /* left_y[4], above_y[4], int_4x4_y: the first nine quadwords of the mask */
+    }
+    /* the nine 16-bit chroma words, two per dword: left_uv[0..3], above_uv[0..3], int_4x4_uv */
+    const uint32_t c0 = wave_or((uint32_t)u.left_uv[0] | (uint32_t)u.left_uv[1] << 16), c1 = wave_or((uint32_t)u.left_uv[2] | (uint32_t)u.left_uv[3] << 16);
+    const uint32_t c2 = wave_or((uint32_t)u.above_uv[0] | (uint32_t)u.above_uv[1] << 16), c3 = wave_or((uint32_t)u.above_uv[2] | (uint32_t)u.above_uv[3] << 16);
+    const uint32_t c4 = wave_or((uint32_t)u.int_4x4_uv);
+    if (lane == 0) {
+        m->left_uv[0] = (uint16_t)c0; m->left_uv[1] = (uint16_t)(c0 >> 16); m->left_uv[2] = (uint16_t)c1; m->left_uv[3] = (uint16_t)(c1 >> 16);
+        m->above_uv[0] = (uint16_t)c2; m->above_uv[1] = (uint16_t)(c2 >> 16); m->above_uv[2] = (uint16_t)c3; m->above_uv[3] = (uint16_t)(c3 >> 16);
+        m->int_4x4_uv = (uint16_t)c4;
+    }
+    m->lfl_y[lane] = u.level;
 }
 
 /* stand-in decision: one wave per (picture, SB), one lane per unit */
@@ -225,11 +256,13 @@ extern "C" int32_t svt_hip_encdec_work_create(svt_hip_ctx *ctx, int32_t max_pics
     const int16_t  *isc = svt_hip_vp9_iscan_tables(&offs, &entries);
     bool ok = hipMalloc((void **)&w->d_blocks, cap * sizeof(svt_tq_block)) == hipSuccess && hipMalloc((void **)&w->d_pos, cap * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&w->d_eob, cap * sizeof(uint16_t)) == hipSuccess &&
-              hipMalloc((void **)&w->d_counts, ((size_t)4 * max_pics * w->n_sb + 16) * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void **)&w->d_counts, ((size_t)4 * max_pics * w->n_sb + 16 + 8 * ED_MAX_PICS) * sizeof(int32_t)) == hipSuccess &&
               hipMalloc((void **)&w->d_qtabs, 2 * sizeof(svt_quant_tables)) == hipSuccess && hipMalloc((void **)&w->d_iscan, (size_t)entries * sizeof(int16_t)) == hipSuccess;
     if (ok) {
         w->d_off_cnt = w->d_counts + (size_t)4 * max_pics * w->n_sb;
         w->d_status = w->d_off_cnt + 8;
+        w->d_totals = w->d_off_cnt + 16;
+        w->d_bases = w->d_totals + 4 * ED_MAX_PICS;
         ok = hipMemsetAsync(w->d_off_cnt, 0, 16 * sizeof(int32_t), ctx->stream) == hipSuccess &&
              hipMemcpyAsync(w->d_iscan, isc, (size_t)entries * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
              hipStreamSynchronize(ctx->stream) == hipSuccess;
@@ -352,10 +385,11 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
     if (rc) return rc;
     /* 2. transform blocks from the grids */
     ED_STAGE(SVT_ENCDEC_STAGE_LISTS);
-    const int nwg = n_pics * hb.n_sb, M = 4 * n_pics * hb.n_sb;
+    const int nwg = n_pics * hb.n_sb;
     hipLaunchKernelGGL(svt_tq_count_kernel, dim3(nwg), dim3(64), 0, ctx->stream, dB, w->d_counts, w->d_status);
-    hipLaunchKernelGGL(svt_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, w->d_counts, M, n_pics * hb.n_sb, w->d_off_cnt);
-    hipLaunchKernelGGL(svt_tq_emit_kernel, dim3(nwg), dim3(64), 0, ctx->stream, dB, (const int32_t *)w->d_counts, w->d_blocks, w->d_pos);
+    hipLaunchKernelGGL(svt_scan_sb_kernel, dim3(4 * n_pics), dim3(256), 0, ctx->stream, w->d_counts, hb.n_sb, w->d_totals);
+    hipLaunchKernelGGL(svt_scan_pic_kernel, dim3(1), dim3(64), 0, ctx->stream, (const int32_t *)w->d_totals, n_pics, w->d_bases, w->d_off_cnt);
+    hipLaunchKernelGGL(svt_tq_emit_kernel, dim3(nwg), dim3(64), 0, ctx->stream, dB, (const int32_t *)w->d_counts, (const int32_t *)w->d_bases, w->d_blocks, w->d_pos);
     HIP_TRY(hipGetLastError());
     /* 3. residual -> transform -> quantisation (-> inverse -> reconstruction) */
     ED_STAGE(SVT_ENCDEC_STAGE_TQ);
@@ -378,7 +412,7 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
     /* 5. deblocking */
     ED_STAGE(SVT_ENCDEC_STAGE_LF);
     if (flags->apply_loop_filter) {
-        hipLaunchKernelGGL(svt_lf_mask_kernel, dim3((nwg + 63) / 64), dim3(64), 0, ctx->stream, dB, w->d_status);
+        hipLaunchKernelGGL(svt_lf_mask_kernel, dim3(nwg), dim3(64), 0, ctx->stream, dB, w->d_status);
         HIP_TRY(hipGetLastError());
         rc = svt_hip_lf_batch_device(ctx, n_pics, rec, lfm, lfm_stride, thr, mi_rows_a, mi_cols_a, 0);
         if (rc) return rc;
@@ -468,7 +502,7 @@ extern "C" int32_t svt_hip_lf_build_masks_device(svt_hip_ctx *ctx, int32_t n_pic
         }
         const ed_batch_dev *dB = nullptr;
         if (stage_batch(ctx, hb, &dB)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "lf_masks: descriptor buffers");
-        hipLaunchKernelGGL(svt_lf_mask_kernel, dim3((n * hb.n_sb + 63) / 64), dim3(64), 0, ctx->stream, dB, (int32_t *)nullptr);
+        hipLaunchKernelGGL(svt_lf_mask_kernel, dim3(n * hb.n_sb), dim3(64), 0, ctx->stream, dB, (int32_t *)nullptr);
         HIP_TRY(hipGetLastError());
     }
     return SVT_HIP_OK;

@@ -66,43 +66,80 @@ SVT_HD uint64_t svt_tx_edge_mask(int tx_size, int vertical_edges, int cols, int 
     return m;
 }
 
-/* Every 8x8 unit that is the first unit of its prediction block contributes the block's edges at shift = row * 8 + col of its
- * SB.  Returns 0, or -1 when a record is malformed (sb_type > 12 or tx_size > 3). */
+/* What ONE 8x8 unit adds to the LOOP_FILTER_MASK of its SB: the unit that is the first of its prediction block contributes the block's
+ * edges at shift = row * 8 + col (the reference's per-block eb_vp9_build_mask); every unit carries the filter level of the block that
+ * covers it.  The host form ORs the 64 contributions of an SB one after the other, the device form one per lane with a wave-wide OR --
+ * the contribution itself is this one text. */
+typedef struct svt_lf_unit_masks {
+    uint64_t left_y[4], above_y[4], int_4x4_y;
+    uint16_t left_uv[4], above_uv[4], int_4x4_uv;
+    uint8_t  level;  /* lfl_y of this unit */
+    uint8_t  bad;    /* malformed record */
+} svt_lf_unit_masks;
+
+SVT_HD void svt_lf_mask_unit(const svt_lf_mode_info *mi, int mi_stride, int mi_rows, int mi_cols, int sb_r, int sb_c, int r, int c, svt_lf_unit_masks *m) {
+    for (int i = 0; i < 4; i++) { m->left_y[i] = m->above_y[i] = 0; m->left_uv[i] = m->above_uv[i] = 0; }
+    m->int_4x4_y = 0; m->int_4x4_uv = 0; m->level = 0; m->bad = 0;
+    if (sb_r * 8 + r >= mi_rows || sb_c * 8 + c >= mi_cols) {
+        /* a unit beyond the picture edge has no record, but a block that starts inside the picture may reach over it: the reference
+           writes that block's level over its whole w x h span (eb_vp9_build_mask, VPX/vp9_loopfilter.c:1611-1616) */
+        for (int kh = 8; kh >= 1; kh >>= 1)
+            for (int kw = 8; kw >= 1; kw >>= 1) {
+                const int oy = r - r % kh, ox = c - c % kw;
+                if (sb_r * 8 + oy >= mi_rows || sb_c * 8 + ox >= mi_cols) continue;
+                const svt_lf_mode_info *o = &mi[(sb_r * 8 + oy) * mi_stride + sb_c * 8 + ox];
+                if (o->sb_type > 12) continue;
+                if (svt_blk_h8(o->sb_type) == kh && svt_blk_w8(o->sb_type) == kw) { m->level = o->filter_level; return; }
+            }
+        return;
+    }
+    const svt_lf_mode_info *b = &mi[(sb_r * 8 + r) * mi_stride + sb_c * 8 + c];
+    if (b->sb_type > 12 || b->tx_size > 3) { m->bad = 1; return; }
+    const int w8 = svt_blk_w8(b->sb_type), h8 = svt_blk_h8(b->sb_type);
+    {   /* the level of the covering block: its first unit's record (every unit of a block carries the block's values; a block that
+           starts outside this SB does not exist -- blocks are aligned to their size) */
+        const svt_lf_mode_info *o = &mi[(sb_r * 8 + r - r % h8) * mi_stride + sb_c * 8 + c - c % w8];
+        m->level = o->filter_level;
+    }
+    if ((r % h8) != 0 || (c % w8) != 0) return; /* not the first unit of its block */
+    if (!b->filter_level) return;               /* level 0: the block is not filtered */
+    const int shift_y = r * 8 + c, shift_uv = (r >> 1) * 4 + (c >> 1);
+    const int with_uv = !(r & 1) && !(c & 1);   /* first 8x8 of a 16x16 area carries the chroma edges */
+    const int txy = b->tx_size, txuv = svt_uv_tx_size(b->sb_type, txy);
+    const int wuv = (w8 + 1) >> 1, huv = (h8 + 1) >> 1;
+    /* prediction block edges */
+    m->above_y[txy] |= svt_rect_mask(w8, 1, 8) << shift_y;
+    m->left_y[txy] |= svt_rect_mask(1, h8, 8) << shift_y;
+    if (with_uv) {
+        m->above_uv[txuv] |= (uint16_t)(svt_rect_mask(wuv, 1, 4) << shift_uv);
+        m->left_uv[txuv] |= (uint16_t)(svt_rect_mask(1, huv, 4) << shift_uv);
+    }
+    if (b->skip && b->is_inter) return; /* no residual, inter: only the block's own border */
+    /* transform edges inside the block, and the inner 4x4 edges */
+    m->above_y[txy] |= (svt_rect_mask(w8, h8, 8) & svt_tx_edge_mask(txy, 0, 8, 8)) << shift_y;
+    m->left_y[txy] |= (svt_rect_mask(w8, h8, 8) & svt_tx_edge_mask(txy, 1, 8, 8)) << shift_y;
+    if (txy == 0) m->int_4x4_y |= svt_rect_mask(w8, h8, 8) << shift_y;
+    if (with_uv) {
+        m->above_uv[txuv] |= (uint16_t)((svt_rect_mask(wuv, huv, 4) & svt_tx_edge_mask(txuv, 0, 4, 4)) << shift_uv);
+        m->left_uv[txuv] |= (uint16_t)((svt_rect_mask(wuv, huv, 4) & svt_tx_edge_mask(txuv, 1, 4, 4)) << shift_uv);
+        if (txuv == 0) m->int_4x4_uv |= (uint16_t)(svt_rect_mask(wuv, huv, 4) << shift_uv);
+    }
+}
+
+/* host form: one SB.  Returns 0, or -1 when a record is malformed (sb_type > 12 or tx_size > 3). */
 SVT_HD int svt_lf_mask_build_sb(const svt_lf_mode_info *mi, int mi_stride, int mi_rows, int mi_cols, int sb_r, int sb_c, svt_lf_mask *m) {
     {
         uint64_t *z = (uint64_t *)m; /* 160 bytes */
         for (int i = 0; i < (int)(sizeof(svt_lf_mask) / 8); i++) z[i] = 0;
     }
-    for (int r = 0; r < 8 && sb_r * 8 + r < mi_rows; r++)
-        for (int c = 0; c < 8 && sb_c * 8 + c < mi_cols; c++) {
-            const svt_lf_mode_info *b = &mi[(sb_r * 8 + r) * mi_stride + sb_c * 8 + c];
-            if (b->sb_type > 12 || b->tx_size > 3) return -1;
-            const int w8 = svt_blk_w8(b->sb_type), h8 = svt_blk_h8(b->sb_type);
-            if ((r % h8) != 0 || (c % w8) != 0) continue; /* not the first unit of its block */
-            if (!b->filter_level) continue;               /* level 0: the block is not filtered */
-            const int shift_y = r * 8 + c, shift_uv = (r >> 1) * 4 + (c >> 1);
-            const int with_uv = !(r & 1) && !(c & 1);     /* first 8x8 of a 16x16 area carries the chroma edges */
-            const int txy = b->tx_size, txuv = svt_uv_tx_size(b->sb_type, txy);
-            const int wuv = (w8 + 1) >> 1, huv = (h8 + 1) >> 1;
-            for (int i = 0; i < h8 && r + i < 8; i++)
-                for (int j = 0; j < w8 && c + j < 8; j++) m->lfl_y[shift_y + i * 8 + j] = b->filter_level;
-            /* prediction block edges */
-            m->above_y[txy] |= svt_rect_mask(w8, 1, 8) << shift_y;
-            m->left_y[txy] |= svt_rect_mask(1, h8, 8) << shift_y;
-            if (with_uv) {
-                m->above_uv[txuv] |= (uint16_t)(svt_rect_mask(wuv, 1, 4) << shift_uv);
-                m->left_uv[txuv] |= (uint16_t)(svt_rect_mask(1, huv, 4) << shift_uv);
-            }
-            if (b->skip && b->is_inter) continue; /* no residual, inter: only the block's own border */
-            /* transform edges inside the block, and the inner 4x4 edges */
-            m->above_y[txy] |= (svt_rect_mask(w8, h8, 8) & svt_tx_edge_mask(txy, 0, 8, 8)) << shift_y;
-            m->left_y[txy] |= (svt_rect_mask(w8, h8, 8) & svt_tx_edge_mask(txy, 1, 8, 8)) << shift_y;
-            if (txy == 0) m->int_4x4_y |= svt_rect_mask(w8, h8, 8) << shift_y;
-            if (with_uv) {
-                m->above_uv[txuv] |= (uint16_t)((svt_rect_mask(wuv, huv, 4) & svt_tx_edge_mask(txuv, 0, 4, 4)) << shift_uv);
-                m->left_uv[txuv] |= (uint16_t)((svt_rect_mask(wuv, huv, 4) & svt_tx_edge_mask(txuv, 1, 4, 4)) << shift_uv);
-                if (txuv == 0) m->int_4x4_uv |= (uint16_t)(svt_rect_mask(wuv, huv, 4) << shift_uv);
-            }
+    for (int r = 0; r < 8; r++)
+        for (int c = 0; c < 8; c++) {
+            svt_lf_unit_masks u;
+            svt_lf_mask_unit(mi, mi_stride, mi_rows, mi_cols, sb_r, sb_c, r, c, &u);
+            if (u.bad) return -1;
+            for (int i = 0; i < 4; i++) { m->left_y[i] |= u.left_y[i]; m->above_y[i] |= u.above_y[i]; m->left_uv[i] |= u.left_uv[i]; m->above_uv[i] |= u.above_uv[i]; }
+            m->int_4x4_y |= u.int_4x4_y; m->int_4x4_uv |= u.int_4x4_uv;
+            m->lfl_y[r * 8 + c] = u.level;
         }
     return 0;
 }
