@@ -189,24 +189,24 @@ __global__ __launch_bounds__(64) void svt_lf_mask_kernel(const ed_batch_dev *__r
     svt_lf_unit_masks u;
     svt_lf_mask_unit(P.lf_mi, B->mi_stride, B->mi_rows, B->mi_cols, sb / B->sb_cols, sb % B->sb_cols, lane >> 3, lane & 7, &u);
     if (u.bad && status) atomicOr(status, 1);
-    svt_lf_mask *m = &P.lfm[sb];
-    uint64_t     w64[9];
+    /* the 160-byte mask is assembled in LDS and leaves as 40 consecutive dwords (one coalesced store instead of a dozen partial ones) */
+    __shared__ uint32_t sm[40];
+    uint64_t            w64[9];
     _Pragma("unroll") for (int i = 0; i < 4; i++) { w64[i] = u.left_y[i]; w64[4 + i] = u.above_y[i]; }
     w64[8] = u.int_4x4_y;
-    _Pragma("unroll") for (int i = 0; i < 9; i++) {
-        const uint64_t v = (uint64_t)wave_or((uint32_t)w64[i]) | (uint64_t)wave_or((uint32_t)(w64[i] >> 32)) << 32;
-        if (lane == i) ((uint64_t *)m)[i] = v;   /* left_y[4], above_y[4], int_4x4_y: the first nine quadwords of the mask */
+    _Pragma("unroll") for (int i = 0; i < 9; i++) {   /* left_y[4], above_y[4], int_4x4_y: the first nine quadwords of the mask */
+        const uint32_t lo = wave_or((uint32_t)w64[i]), hi = wave_or((uint32_t)(w64[i] >> 32));
+        if (lane == i) { sm[2 * i] = lo; sm[2 * i + 1] = hi; }
     }
-    /* the nine 16-bit chroma words, two per dword: left_uv[0..3], above_uv[0..3], int_4x4_uv */
+    /* the nine 16-bit chroma words, two per dword: left_uv[0..3], above_uv[0..3], int_4x4_uv (bytes 72..89) */
     const uint32_t c0 = wave_or((uint32_t)u.left_uv[0] | (uint32_t)u.left_uv[1] << 16), c1 = wave_or((uint32_t)u.left_uv[2] | (uint32_t)u.left_uv[3] << 16);
     const uint32_t c2 = wave_or((uint32_t)u.above_uv[0] | (uint32_t)u.above_uv[1] << 16), c3 = wave_or((uint32_t)u.above_uv[2] | (uint32_t)u.above_uv[3] << 16);
     const uint32_t c4 = wave_or((uint32_t)u.int_4x4_uv);
-    if (lane == 0) {
-        m->left_uv[0] = (uint16_t)c0; m->left_uv[1] = (uint16_t)(c0 >> 16); m->left_uv[2] = (uint16_t)c1; m->left_uv[3] = (uint16_t)(c1 >> 16);
-        m->above_uv[0] = (uint16_t)c2; m->above_uv[1] = (uint16_t)(c2 >> 16); m->above_uv[2] = (uint16_t)c3; m->above_uv[3] = (uint16_t)(c3 >> 16);
-        m->int_4x4_uv = (uint16_t)c4;
-    }
-    m->lfl_y[lane] = u.level;
+    if (lane == 9) { sm[18] = c0; sm[19] = c1; sm[20] = c2; sm[21] = c3; sm[22] = c4; sm[38] = 0; sm[39] = 0; } /* (dword 22's upper half and dwords 38-39 are rewritten below) */
+    __syncthreads();
+    ((uint8_t *)sm)[90 + lane] = u.level;   /* lfl_y[64]: bytes 90..153 */
+    __syncthreads();
+    if (lane < 40) ((uint32_t *)&P.lfm[sb])[lane] = sm[lane];
 }
 
 /* stand-in decision: one wave per (picture, SB), one lane per unit */

@@ -48,22 +48,26 @@ SVT_HD int svt_uv_tx_size(int sb_type, int tx_size_y) {
 /* ------------------------------------------------------------------------------------------------------------------------ */
 /* LOOP_FILTER_MASK of one SB                                                                                                 */
 /* ------------------------------------------------------------------------------------------------------------------------ */
-/* rectangle of ones, w x h units at the origin of a grid with `cols` units per row */
+/* rectangle of ones, w x h units at the origin of a grid with `cols` (8 or 4) units per row: the row pattern replicated into the
+ * first h rows by one multiplication */
 SVT_HD uint64_t svt_rect_mask(int w, int h, int cols) {
     const uint64_t row = ((uint64_t)1 << w) - 1;
-    uint64_t       m = 0;
-    for (int i = 0; i < h; i++) m |= row << (i * cols);
-    return m;
+    const uint64_t rep = cols == 8 ? 0x0101010101010101ull : 0x1111ull;
+    const int      bits = h * cols;
+    return (row * rep) & (bits >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << bits) - 1));
 }
-/* units of a cols x rows area whose left (vertical_edges) / above side is a transform edge: every unit for 4x4 / 8x8, every 2nd
- * column (row) for 16x16, every 4th for 32x32 */
+/* units of an 8 x 8 (luma) or 4 x 4 (chroma) area whose left (vertical_edges) / above side is a transform edge: every unit for
+ * 4x4 / 8x8 transforms, every 2nd column (row) for 16x16, every 4th for 32x32 */
 SVT_HD uint64_t svt_tx_edge_mask(int tx_size, int vertical_edges, int cols, int rows) {
-    const int step = tx_size <= 1 ? 1 : tx_size == 2 ? 2 : 4;
-    uint64_t  m = 0;
-    for (int r = 0; r < rows; r++)
-        for (int c = 0; c < cols; c++)
-            if ((vertical_edges ? c : r) % step == 0) m |= (uint64_t)1 << (r * cols + c);
-    return m;
+    (void)rows;
+    if (cols == 8) {
+        if (tx_size <= 1) return ~(uint64_t)0;
+        if (tx_size == 2) return vertical_edges ? 0x5555555555555555ull : 0x00FF00FF00FF00FFull;
+        return vertical_edges ? 0x1111111111111111ull : 0x000000FF000000FFull;
+    }
+    if (tx_size <= 1) return 0xFFFFull;
+    if (tx_size == 2) return vertical_edges ? 0x5555ull : 0x0F0Full;
+    return vertical_edges ? 0x1111ull : 0x000Full;
 }
 
 /* What ONE 8x8 unit adds to the LOOP_FILTER_MASK of its SB: the unit that is the first of its prediction block contributes the block's

@@ -147,7 +147,7 @@ __device__ __forceinline__ int clamp16(int v) { return v < -32768 ? -32768 : v >
 __device__ __forceinline__ uint8_t clip_add(int d, int t) { int v = d + t; return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
 
 /* 32x32: 54 KB of LDS per 256-thread workgroup (eight blocks + the rate tables) allow three workgroups = 12 waves per CU */
-template <int N, bool RATE>
+template <int N, bool RATE, bool DIST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 3 : 1))) void svt_tq_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ pred,
                                                      uint8_t *__restrict__ recon, const svt_tq_block *__restrict__ blocks,
                                                      int n_blocks, const svt_quant_tables *__restrict__ qtabs,
@@ -299,9 +299,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 3
         dq[kk] = dv;
         /* full_distortion_kernel32bit (C_DEFAULT/EbPictureOperators_C.c:288-311): the difference goes through an int16_t
            parameter, the sums wrap in uint32_t */
-        const int dd = (int16_t)(cv - dv);
-        rdist += (uint32_t)(dd * dd);
-        pdist += (uint32_t)(cv * cv);
+        if constexpr (DIST) {
+            const int dd = (int16_t)(cv - dv);
+            rdist += (uint32_t)(dd * dd);
+            pdist += (uint32_t)(cv * cv);
+        }
         {   /* the row leaves in vectors of VC coefficients as soon as they are complete (few live registers) */
             const int j = (kk % VC) >> 1;
             if (kk & 1) { qw[j] |= (uint32_t)(uint16_t)qv << 16; dqw[j] |= (uint32_t)(uint16_t)dv << 16; }
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 3
     }
     eob = tq_lanes_max<N>(eob);
     if (active && i == 0) eob_out[blk] = (uint16_t)eob;
-    if (dist_out) { /* T3: coefficient-domain distortion of the block, summed over its N lanes */
+    if constexpr (DIST) if (dist_out) { /* T3: coefficient-domain distortion of the block, summed over its N lanes */
         rdist = tq_lanes_sum<N>(rdist); pdist = tq_lanes_sum<N>(pdist);
         if (active && i == 0) { dist_out[2 * blk] = rdist; dist_out[2 * blk + 1] = pdist; }
     }
@@ -433,7 +435,7 @@ __device__ __forceinline__ int rate_walk4(const int (&tok)[16], const int (&en)[
  * 8x8: they differ in the cast inside tx_fdct8 (vp9_dct.c:67-68), selected by the block's transform type.  The inverse
  * always runs all rows (the reference's reduced variants are shortcuts with identical results).  Memory instructions per
  * block are unchanged (a lane issues the N row loads its N lanes issued). */
-template <int N, bool RATE>
+template <int N, bool RATE, bool DIST>
 __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ pred,
                                                           uint8_t *__restrict__ recon, const svt_tq_block *__restrict__ blocks,
                                                           int n_blocks, const svt_quant_tables *__restrict__ qtabs,
@@ -535,9 +537,11 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
                 dv = (int16_t)(qv * q.dequant[ac]);
             }
             dq[i][kk] = dv;
-            const int dd = (int16_t)(cv - dv);
-            rdist += (uint32_t)(dd * dd);
-            pdist += (uint32_t)(cv * cv);
+            if constexpr (DIST) {
+                const int dd = (int16_t)(cv - dv);
+                rdist += (uint32_t)(dd * dd);
+                pdist += (uint32_t)(cv * cv);
+            }
             if (kk & 1) { qw[kk >> 1] |= (uint32_t)(uint16_t)qv << 16; dqw[kk >> 1] |= (uint32_t)(uint16_t)dv << 16; }
             else { qw[kk >> 1] = (uint16_t)qv; dqw[kk >> 1] = (uint16_t)dv; }
             if (level) { const int pos = (int)((isw[kk >> 1] >> (16 * (kk & 1))) & 0xffff) + 1; eob = pos > eob ? pos : eob; }
@@ -564,7 +568,7 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
         else { *(uint4 *)qo = make_uint4(qw[0], qw[1], qw[2], qw[3]); *(uint4 *)dqo = make_uint4(dqw[0], dqw[1], dqw[2], dqw[3]); }
     }
     eob_out[blk] = (uint16_t)eob;
-    if (dist_out) { dist_out[2 * blk] = rdist; dist_out[2 * blk + 1] = pdist; }
+    if constexpr (DIST) if (dist_out) { dist_out[2 * blk] = rdist; dist_out[2 * blk + 1] = pdist; }
     if constexpr (RATE) {
         const int       rinfo = k.pad_[0], ptype = (rinfo >> 2) & 1, inter = (rinfo >> 3) & 1, ctx0 = rinfo & 3;
         const uint32_t *tc = s_tc + (ptype * 2 + inter) * RATE_SLICE;
@@ -630,7 +634,7 @@ int tq_grid(svt_hip_ctx *ctx, int ngroups, int per_cu) {
     return 8 * (per_xcd < cap ? per_xcd : cap);
 }
 
-template <int N, bool RATE>
+template <int N, bool RATE, bool DIST = true>
 hipError_t launch_tq(svt_hip_ctx *ctx, hipStream_t st, const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks, int n,
                      const svt_quant_tables *q, const int16_t *iscan, int16_t *qc, int16_t *dqc, uint16_t *eob, uint64_t *dist, tq_rate_args ra,
                      const uint8_t *const *recon_set, tq_dev_count dc = {nullptr, 0}) {
@@ -639,12 +643,12 @@ hipError_t launch_tq(svt_hip_ctx *ctx, hipStream_t st, const uint8_t *src, const
      * intermediate live in one lane; 87 spills when held to 128) -- two waves per SIMD, and each displaces two ME waves:
      * the overlapped step went from 3.27 to 3.77 ms with it, so 8x8 stays on the N-lanes-per-block kernel */
     if constexpr (N == 4) {
-        hipLaunchKernelGGL((svt_tq_lane_kernel<N, RATE>), dim3(tq_grid(ctx, (n + 255) / 256, 6)), dim3(256), 0, st, src, pred, recon, blocks, n, q,
+        hipLaunchKernelGGL((svt_tq_lane_kernel<N, RATE, DIST>), dim3(tq_grid(ctx, (n + 255) / 256, 6)), dim3(256), 0, st, src, pred, recon, blocks, n, q,
                            iscan, qc, dqc, eob, dist, ra, recon_set, dc);
         return hipGetLastError();
     } else {
         constexpr int NT = tq_threads<N, RATE>(), BPW = NT / N;
-        hipLaunchKernelGGL((svt_tq_kernel<N, RATE>), dim3(tq_grid(ctx, (n + BPW - 1) / BPW, 6)), dim3(NT), 0, st, src, pred, recon, blocks, n, q,
+        hipLaunchKernelGGL((svt_tq_kernel<N, RATE, DIST>), dim3(tq_grid(ctx, (n + BPW - 1) / BPW, 6)), dim3(NT), 0, st, src, pred, recon, blocks, n, q,
                            iscan, qc, dqc, eob, dist, ra, recon_set, dc);
         return hipGetLastError();
     }
@@ -712,10 +716,20 @@ int32_t svt_tq_launch_device_lists(svt_hip_ctx *ctx, const uint8_t *d_src, const
     HIP_TRY(hipMemcpyAsync(d, h, 8 * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
     const uint8_t *const *d_set = (const uint8_t *const *)d;
     const tq_rate_args none = {nullptr, nullptr, nullptr};
-    hipError_t rc = launch_tq<4, false>(ctx, ctx->stream, d_src, d_pred, nullptr, d_blocks, cap[0], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob, d_dist, none, d_set, tq_dev_count{d_off_cnt, 0});
-    if (rc == hipSuccess) rc = launch_tq<8, false>(ctx, ctx->stream, d_src, d_pred, nullptr, d_blocks, cap[1], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob, d_dist, none, d_set, tq_dev_count{d_off_cnt, 1});
-    if (rc == hipSuccess) rc = launch_tq<16, false>(ctx, ctx->stream, d_src, d_pred, nullptr, d_blocks, cap[2], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob, d_dist, none, d_set, tq_dev_count{d_off_cnt, 2});
-    if (rc == hipSuccess) rc = launch_tq<32, false>(ctx, ctx->stream, d_src, d_pred, nullptr, d_blocks, cap[3], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob, d_dist, none, d_set, tq_dev_count{d_off_cnt, 3});
+    hipError_t rc = hipSuccess;
+#define TQ_DEV(N, S, D) launch_tq<N, false, D>(ctx, ctx->stream, d_src, d_pred, nullptr, d_blocks, cap[S], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob, d_dist, none, d_set, tq_dev_count{d_off_cnt, S})
+    if (d_dist) { /* with the coefficient-domain distortion pair */
+        rc = TQ_DEV(4, 0, true);
+        if (rc == hipSuccess) rc = TQ_DEV(8, 1, true);
+        if (rc == hipSuccess) rc = TQ_DEV(16, 2, true);
+        if (rc == hipSuccess) rc = TQ_DEV(32, 3, true);
+    } else {      /* the encode pass: no distortion sums (instances without that arithmetic) */
+        rc = TQ_DEV(4, 0, false);
+        if (rc == hipSuccess) rc = TQ_DEV(8, 1, false);
+        if (rc == hipSuccess) rc = TQ_DEV(16, 2, false);
+        if (rc == hipSuccess) rc = TQ_DEV(32, 3, false);
+    }
+#undef TQ_DEV
     svt_ctx_stage_commit(ctx);
     if (rc != hipSuccess) return svt_set_hip_error(rc, __FILE__, __LINE__);
     return SVT_HIP_OK;

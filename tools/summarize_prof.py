@@ -5,25 +5,28 @@ profiles/<round>_kernel_stats.csv, profiles/traffic.json and a markdown table on
 HBM traffic follows MI355X_MICROARCH.md's HBM section: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts
 64 B per 128-B request and is doubled, WRITE_SIZE is taken as reported.  The PMC passes run bench.py with one timed step;
 bench.py's untimed first pass launches the same kernels once more (the transform stage without the fused rate pass), so a
-stage's figure is the sum over its LAST launches_per_step dispatches."""
+stage's figure is the sum over its LAST launches_per_step dispatches.  Round 4: the EncDec side of a step is ONE call of the
+picture-level driver (svt_hip_encdec_batch_device) over the 16 pictures of the diagonal batch: every kernel of the chain launches once
+(the transform stage once per transform size), motion estimation once per temporal layer."""
 import csv, glob, json, os, re, shutil, sys, collections
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out")
 prof = os.path.join(root, "profiles")
 # launches of one step with ONE GOP in flight, diagonal schedule: ME per temporal layer, the transform stage per transform size (one
 # launch serves the five ring slots: svt_hip_tq_rd_batch_multi_device), everything else once over the 16 pictures
 PER_STEP = {"svt_me_sb_kernel": 5, "svt_tq_kernel": 4, "svt_lf_kernel": 1, "svt_lf_desc_kernel": 1, "svt_pa_plane_kernel": 1, "svt_mc_kernel": 1,
-            "svt_refpad_kernel": 1}
+            "svt_refpad_kernel": 1, "svt_tq_count_kernel": 1, "svt_scan_sb_kernel": 1, "svt_scan_pic_kernel": 1, "svt_tq_emit_kernel": 1, "svt_tq_skip_kernel": 1,
+            "svt_skip_update_kernel": 1, "svt_lf_mask_kernel": 1}
+KERNELS = ("svt_me_sb_kernel", "svt_tq_kernel", "svt_lf_kernel", "svt_lf_desc_kernel", "svt_lf_mask_kernel", "svt_pa_plane_kernel", "svt_mc_kernel", "svt_rate_kernel",
+           "svt_refpad_kernel", "svt_tq_count_kernel", "svt_scan_sb_kernel", "svt_scan_pic_kernel", "svt_tq_emit_kernel", "svt_tq_skip_kernel", "svt_skip_update_kernel")
 
 
 def short(name):
-    if "svt_tq_" in name and "false>" in name:
-        return None     # the set-up pass of bench.py (no rate): not part of a step
     if re.search(r"(?<![A-Za-z_0-9])svt_tq_lane_kernel(?![A-Za-z_0-9])", name):
         return "svt_tq_kernel"  # the 4x4 instance of the TQ stage
-    for k in ("svt_me_sb_kernel", "svt_tq_kernel", "svt_lf_kernel", "svt_lf_desc_kernel", "svt_pa_plane_kernel", "svt_mc_kernel", "svt_rate_kernel", "svt_refpad_kernel"):
+    for k in KERNELS:
         if re.search(r"(?<![A-Za-z_0-9])" + k + r"(?![A-Za-z_0-9])", name):
             return k
     return None
