@@ -169,7 +169,13 @@ def gen_pd_split():
     np.savez_compressed(os.path.join(G, "pd_split_reference.npz"), split=T.ref_minigop_split())
 
 
-SECTIONS = ("scan", "me", "tq", "lf", "lf_masks", "mc", "rate", "quant", "ivf", "lf_params", "me_presets", "sad_loop", "sb_stats", "api", "refpad", "avg_ssd", "pd_split")
+def gen_encdec_flags():
+    # ---- the EncDec kernel's stage flags for every (tune, enc-mode, temporal layer, reference / not) from the reference's own derivation ----
+    assert T.have_ref("ref_refpad")
+    np.savez_compressed(os.path.join(G, "encdec_flags_reference.npz"), flags=T.ref_encdec_flags())
+
+
+SECTIONS = ("scan", "me", "tq", "lf", "lf_masks", "mc", "rate", "quant", "ivf", "lf_params", "me_presets", "sad_loop", "sb_stats", "api", "refpad", "avg_ssd", "pd_split", "encdec_flags")
 
 
 def main():

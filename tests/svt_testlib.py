@@ -1413,6 +1413,17 @@ def ref_ref_pad(case):
     return out
 
 
+def ref_encdec_flags():
+    """the reference's own eb_vp9_signal_derivation_enc_dec_kernel_{sq,oq,vmaf} (oracle/_ref/ref_refpad, request 'SVFL'):
+    [tune 0..2][enc_mode 0..12][temporal layer 0..4][is_used_as_reference 0..1][limit_intra, allow_enc_dec_mismatch]"""
+    with tempfile.TemporaryDirectory() as td:
+        rq, rs = os.path.join(td, "rq"), os.path.join(td, "rs")
+        with open(rq, "wb") as f:
+            f.write(struct.pack("<i", 0x4C465653))
+        subprocess.check_call([os.path.join(REF_DIR, "ref_refpad"), rq, rs])
+        return np.fromfile(rs, np.uint8).reshape(3, 13, 5, 2, 2)
+
+
 def hip_ref_pad_batch(ctx, cases):
     """several pictures (of different sizes) through one svt_hip_ref_pad_batch_device call; pad_x / pad_y of the first case"""
     import torch

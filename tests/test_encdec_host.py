@@ -233,3 +233,28 @@ def test_quant_tables_for_qindex_match_init():
         assert lib.svt_hip_quant_tables_init(q, dc, dc, ac, C.byref(one)) == 0
         assert bytes(out[0]) == bytes(one) == bytes(out[1])
     assert lib.svt_hip_vp9_qindex_from_qp(40) == 160 and lib.svt_hip_vp9_qindex_from_qp(63) == 255 and lib.svt_hip_vp9_qindex_from_qp(64) < 0
+
+
+def _flags_vs(ref):
+    lib = B.load()
+    for tune in range(3):
+        for mode in range(13):
+            for layer in range(5):
+                for used in range(2):
+                    c = B.EncdecFlagsConfig(enc_mode=mode, tune=tune, temporal_layer_index=layer, is_used_as_reference=used, recon_file=0, loop_filter=1)
+                    o = B.EncdecFlags()
+                    assert lib.svt_hip_encdec_flags_derive(C.byref(c), C.byref(o)) == 0
+                    assert (o.limit_intra, o.allow_enc_dec_mismatch) == tuple(int(v) for v in ref[tune, mode, layer, used]), (tune, mode, layer, used)
+
+
+def test_encdec_flags_vs_reference_golden():
+    """limit_intra / allow_enc_dec_mismatch for every (tune, enc-mode, layer, reference or not) equal what the reference's own
+    eb_vp9_signal_derivation_enc_dec_kernel_{sq,oq,vmaf} derive (fixture from oracle/_ref/ref_refpad, request 'SVFL')"""
+    ref = np.load(os.path.join(T.GOLDEN_DIR, "encdec_flags_reference.npz"))["flags"]
+    assert ref.shape == (3, 13, 5, 2, 2) and ref[..., 0].any() and ref[..., 1].any()
+    _flags_vs(ref)
+
+
+@pytest.mark.skipif(not T.have_ref("ref_refpad"), reason="oracle/_ref/ref_refpad not built (reference absent)")
+def test_encdec_flags_vs_reference_live():
+    _flags_vs(T.ref_encdec_flags())
