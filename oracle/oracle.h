@@ -58,4 +58,12 @@ int32_t svt_oracle_inter_pred_frame(const svt_mc_mode_info *mi, int32_t mi_strid
 /* coefficient rate estimation (Codec/EbRateDistortionCost.c:55-172) */
 int32_t svt_oracle_coeff_rate_batch(const int16_t *qcoeff, const svt_rate_block *blocks, int32_t n_blocks, const svt_rate_tables *t,
                                     const int16_t *scan_all, int32_t *bits);
+/* intra path of the encode pass (oracle_intra.c): predictors (VPX/intrapred.c), reference samples (Codec/EbEncDecProcess.c:1128-1310),
+ * one intra picture block by block (encode_pass_sb, :3680-4160) */
+void    svt_oracle_intra_predict(int32_t mode, int32_t bs, int32_t have_left, int32_t have_top, const uint8_t *above, const uint8_t *left,
+                                 uint8_t *dst, int32_t stride);
+void    svt_oracle_intra_ref_samples(const uint8_t *plane, int32_t stride, int32_t x0, int32_t y0, int32_t bs, uint8_t *above_row, uint8_t *left_col);
+int32_t svt_oracle_intra_picture(const uint8_t *src, uint8_t *pred, uint8_t *recon_buf, const uint32_t recon_off[3], const int32_t recon_stride[2],
+                                 const svt_lf_mode_info *mi, int32_t mi_stride, int32_t width, int32_t height, const svt_quant_tables qt[2],
+                                 const int16_t *iscan, const uint32_t iscan_off[16], int16_t *qcoeff, int16_t *dqcoeff, uint16_t *eob_map);
 #endif

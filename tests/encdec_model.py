@@ -171,3 +171,98 @@ def oracle_encdec_picture(src, refs, mc_mi, lf_mi, q_index, flags, thr, use_subp
         assert T.oracle().svt_oracle_ref_pad(C.byref(d), pad, pad) == 0
     lap("pad")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# intra pictures
+# ---------------------------------------------------------------------------------------------------
+INTRA_TX_TYPE = (0, 1, 2, 0, 3, 1, 2, 2, 1, 3)   # eb_vp9_intra_mode_to_tx_type_lookup (VPX/vp9_reconintra.c:20-31)
+
+
+def gen_intra_grid(seed, W, H, sizes=(8, 16, 32), modes=tuple(range(10)), filter_level=20, mi_stride=None):
+    """a random intra partition of a W x H picture: per 32x32 area one 32x32 block, four 16x16 areas, each of which is one 16x16
+    block or four 8x8 blocks (areas that cross the picture edge always split); random luma / chroma modes per block"""
+    rng = np.random.default_rng(seed)
+    mi_rows, mi_cols = H // 8, W // 8
+    mi = np.zeros((mi_rows, mi_stride or mi_cols), dtype=B.LF_MODE_INFO_DTYPE)
+    mi["sb_type"] = 255
+
+    def put(r, c, n8):
+        rec = mi[r:r + n8, c:c + n8]
+        rec["sb_type"], rec["tx_size"] = {1: 3, 2: 6, 4: 9}[n8], {1: 1, 2: 2, 4: 3}[n8]
+        rec["is_inter"], rec["skip"], rec["filter_level"] = 0, 0, filter_level
+        pad = rec["pad"]
+        pad[..., 0], pad[..., 1], pad[..., 2] = 0, rng.choice(modes), rng.choice(modes)
+
+    def split(r, c, n8):
+        fits = r + n8 <= mi_rows and c + n8 <= mi_cols
+        allowed = (8 * n8) in sizes
+        smaller = any(s < 8 * n8 for s in sizes)
+        if fits and allowed and (n8 == 1 or not smaller or rng.random() < 0.45):
+            put(r, c, n8)
+            return
+        assert n8 > 1, "an 8x8 block must be allowed at the picture edge"
+        h = n8 // 2
+        for dr in (0, h):
+            for dc in (0, h):
+                if r + dr < mi_rows and c + dc < mi_cols:
+                    split(r + dr, c + dc, h)
+    for r in range(0, mi_rows, 4):
+        for c in range(0, mi_cols, 4):
+            split(r, c, 4)
+    return mi
+
+
+def oracle_intra_picture(src, lf_mi, q_index, rec=None, pad=PAD):
+    """the oracle's intra encode pass (oracle/oracle_intra.c) into a RefPic (or `rec`): prediction, coefficients, eob map, reconstruction
+    before deblocking"""
+    H, W = src[0].shape
+    rec = RefPic(W, H, pad) if rec is None else rec
+    srcb = np.concatenate([p.ravel() for p in src])
+    predb = np.zeros_like(srcb)
+    n_coeff = T.n_sb(W, H) * B.SB_COEFFS
+    q, dq = np.zeros(n_coeff, np.int16), np.zeros(n_coeff, np.int16)
+    emap = np.zeros(eob_map_offsets(W, H)[3], np.uint16)
+    iscan, offs = T.iscan_array()
+    ioff = (C.c_uint32 * 16)(*[offs[(ts, tt)] for ts in range(4) for tt in range(4)])
+    ro = (C.c_uint32 * 3)(*rec.offsets())
+    rs = (C.c_int32 * 2)(rec.pw, rec.cpw)
+    qt = qtabs_of(q_index)
+    mi = np.ascontiguousarray(lf_mi)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = T.oracle().svt_oracle_intra_picture(vp(srcb), vp(predb), vp(rec.buf), ro, rs, vp(mi), mi.shape[1], W, H, vp(qt), vp(iscan), ioff, vp(q), vp(dq), vp(emap))
+    assert rc == 0, rc
+    ny, nc = W * H, W * H // 4
+    pred = [predb[:ny].reshape(H, W), predb[ny:ny + nc].reshape(H // 2, W // 2), predb[ny + nc:].reshape(H // 2, W // 2)]
+    return dict(rec=rec, pred=pred, qcoeff=q, dqcoeff=dq, eob_map=emap)
+
+
+def ref_intra_picture(src, lf_mi, q_index):
+    """the same picture through the reference's own functions (oracle/_ref/ref_intra); tight planes"""
+    import os, struct, subprocess, tempfile
+    H, W = src[0].shape
+    mi = np.ascontiguousarray(lf_mi)
+    with tempfile.TemporaryDirectory() as td:
+        req, rsp = os.path.join(td, "req.bin"), os.path.join(td, "rsp.bin")
+        with open(req, "wb") as f:
+            f.write(struct.pack("<5i", 0x4E495653, W, H, mi.shape[1], q_index))
+            for p in src:
+                f.write(np.ascontiguousarray(p).tobytes())
+            f.write(mi.tobytes())
+        subprocess.check_call([os.path.join(T.REF_DIR, "ref_intra"), req, rsp])
+        raw = open(rsp, "rb").read()
+    ny, nc, o = W * H, W * H // 4, 0
+    out = {}
+    for name in ("pred", "rec"):
+        planes = []
+        for n, shp in ((ny, (H, W)), (nc, (H // 2, W // 2)), (nc, (H // 2, W // 2))):
+            planes.append(np.frombuffer(raw, np.uint8, n, o).reshape(shp).copy())
+            o += n
+        out[name] = planes
+    n_coeff = T.n_sb(W, H) * B.SB_COEFFS
+    out["qcoeff"] = np.frombuffer(raw, np.int16, n_coeff, o).copy(); o += 2 * n_coeff
+    out["dqcoeff"] = np.frombuffer(raw, np.int16, n_coeff, o).copy(); o += 2 * n_coeff
+    ne = eob_map_offsets(W, H)[3]
+    out["eob_map"] = np.frombuffer(raw, np.uint16, ne, o).copy()
+    assert o + 2 * ne == len(raw)
+    return out

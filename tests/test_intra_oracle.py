@@ -1,0 +1,75 @@
+"""The intra path of the oracle (oracle/oracle_intra.c) pinned against the reference's own code:
+  * every predictor of VPX/intrapred.c, called directly (oracle/_ref/libsvtref_kernels.so), on random edges -- including the 4x4 forms
+    that read the above-right samples;
+  * whole intra pictures through oracle/_ref/ref_intra: generate_intra_reference_samples + intra_prediction + perform_coding_loop +
+    the neighbour-array writer, block by block in the reference's coding order.
+CPU only; skipped where the reference build is absent (the GPU box has the prebuilt files)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import svt_testlib as T
+import encdec_model as M
+
+NAMES = {1: "v", 2: "h", 3: "d45", 4: "d135", 5: "d117", 6: "d153", 7: "d207", 8: "d63", 9: "tm"}
+DC = {(0, 0): "dc_128", (0, 1): "dc_top", (1, 0): "dc_left", (1, 1): "dc"}
+
+
+def _oracle_pred(mode, bs, have_left, have_top, above, left):
+    dst = np.zeros((bs, bs), np.uint8)
+    T.oracle().svt_oracle_intra_predict(mode, bs, have_left, have_top, C.c_void_p(above.ctypes.data + 1), left.ctypes.data_as(C.c_void_p),
+                                        dst.ctypes.data_as(C.c_void_p), bs)
+    return dst
+
+
+@pytest.mark.skipif(not T.have_ref("libsvtref_kernels.so"), reason="reference kernels not built")
+@pytest.mark.parametrize("bs", [4, 8, 16, 32])
+def test_predictors_match_reference(bs):
+    ref = T.ref_kernels()
+    rng = np.random.default_rng(100 + bs)
+    for trial in range(40):
+        above = rng.integers(0, 256, 2 * bs + 1 + 8, dtype=np.uint8)   # [0] = corner
+        left = rng.integers(0, 256, bs, dtype=np.uint8)
+        if trial % 5 == 0:
+            above[:] = rng.choice([0, 255, 127]); left[:] = rng.choice([0, 255, 129])
+        for mode, nm in NAMES.items():
+            fn = getattr(ref, f"eb_vp9_{nm}_predictor_{bs}x{bs}_c")
+            want = np.zeros((bs, bs), np.uint8)
+            fn(want.ctypes.data_as(C.c_void_p), C.c_ssize_t(bs), C.c_void_p(above.ctypes.data + 1), left.ctypes.data_as(C.c_void_p))
+            got = _oracle_pred(mode, bs, 1, 1, above, left)
+            assert np.array_equal(got, want), (nm, bs, trial)
+        for (hl, ht), nm in DC.items():
+            fn = getattr(ref, f"eb_vp9_{nm}_predictor_{bs}x{bs}_c")
+            want = np.zeros((bs, bs), np.uint8)
+            fn(want.ctypes.data_as(C.c_void_p), C.c_ssize_t(bs), C.c_void_p(above.ctypes.data + 1), left.ctypes.data_as(C.c_void_p))
+            assert np.array_equal(_oracle_pred(0, bs, hl, ht, above, left), want), (nm, bs, trial)
+
+
+def _check_picture(W, H, seed, q_index, sizes=(8, 16, 32), modes=tuple(range(10))):
+    src = T.gen_yuv(W, H, seed)
+    mi = M.gen_intra_grid(seed, W, H, sizes=sizes, modes=modes)
+    want = M.ref_intra_picture(src, mi, q_index)
+    got = M.oracle_intra_picture(src, mi, q_index)
+    for k in range(3):
+        assert np.array_equal(got["pred"][k], want["pred"][k]), ("pred", k)
+        assert np.array_equal(got["rec"].interior()[k], want["rec"][k]), ("rec", k)
+    assert np.array_equal(got["qcoeff"], want["qcoeff"])
+    assert np.array_equal(got["dqcoeff"], want["dqcoeff"])
+    assert np.array_equal(got["eob_map"], want["eob_map"])
+    return got
+
+
+@pytest.mark.skipif(not T.have_ref("ref_intra"), reason="reference harness not built")
+@pytest.mark.parametrize("W,H,seed,q", [(128, 64, 1, 60), (136, 72, 2, 120), (192, 128, 3, 20), (64, 200, 4, 200), (320, 192, 5, 255)])
+def test_picture_matches_reference(W, H, seed, q):
+    got = _check_picture(W, H, seed, q)
+    assert got["eob_map"].any()
+
+
+@pytest.mark.skipif(not T.have_ref("ref_intra"), reason="reference harness not built")
+@pytest.mark.parametrize("size", [8, 16, 32])
+@pytest.mark.parametrize("mode", range(10))
+def test_single_mode_pictures(size, mode):
+    """one block size and one mode over a whole picture: every predictor at every picture-edge position (no left, no top, corner)"""
+    _check_picture(128, 96, 40 + mode, 90, sizes=(8, size) if size > 8 else (8,), modes=(mode,))
