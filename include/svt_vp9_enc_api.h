@@ -121,9 +121,9 @@ typedef struct svt_vp9_shim_picture_info {
     /* the stages behind mode decision (svt_encdec_flags of svtvp9_hip.h, as the reference derives them for this picture) */
     int32_t  is_used_as_reference, do_recon, apply_loop_filter, pad_reference;
     int32_t  q_index, filter_level;
-    int32_t  decision_source;      /* 0 built-in stand-in, 1 the host's callback, 2 intra picture (see intra_recon_is_source) */
-    int32_t  intra_recon_is_source; /* 1: an intra picture's reconstruction is its source picture (intra prediction is not on the
-                                      GPU path: SURVEY 8 lists it outside the hot path), padded as a reference picture */
+    int32_t  decision_source;      /* 0 built-in stand-in, 1 the host's callback */
+    int32_t  intra_recon_is_source; /* always 0 since round 4: intra pictures go through the intra encode pass on the GPU
+                                      (svt_hip_encdec_intra_device); the field keeps the struct layout of round 3 */
     int32_t  device_ordinal;       /* the GPU that coded the picture's GOP */
 } svt_vp9_shim_picture_info;
 /* copies the ME results of a picture whose mini-GOP has been processed (and not yet overwritten: the library keeps the last two
@@ -141,14 +141,17 @@ EbErrorType svt_vp9_shim_get_sb_stats(EbComponentType *svt_enc_component, uint64
 EbErrorType svt_vp9_shim_get_counters(EbComponentType *svt_enc_component, uint64_t *me_launches, uint64_t *pictures_sent);
 
 /* Mode decision is the host's (control logic outside the hot path).  A host that has one registers it here, before
- * eb_vp9_init_encoder: the library calls it once per inter picture, in coding order, on the thread that calls
+ * eb_vp9_init_encoder: the library calls it once per picture, in coding order, on the thread that calls
  * eb_vp9_svt_enc_send_picture, after the picture's motion estimation has completed (the call waits for it: a host decision
  * serialises the GPU pipeline at this point, which is what a host-side decision costs), with the picture's ME results
  * (n_sb * 85 records of svt_me_pu_result).  It fills the two mode-info grids of svtvp9_hip.h -- mc_mode_info: (height / 8) rows of
  * mi_stride records of svt_mc_mode_info (12 bytes); lf_mode_info: the same grid of svt_lf_mode_info (8 bytes; `skip` is the
  * library's to write) -- and returns 0; a non-zero return makes the library use its stand-in for that picture.  Without a
  * callback the stand-in decides every picture (svt_hip_md_default_batch_device: a deterministic partition from the ME results,
- * NOT the reference's mode decision). */
+ * NOT the reference's mode decision).  For an intra picture (info->is_intra) me_results is NULL and only lf_mode_info is read: intra
+ * blocks of 8x8 / 16x16 / 32x32 (sb_type 3 / 6 / 9, tx_size 1 / 2 / 3, is_inter 0) with pad_[1] = luma mode and pad_[2] = chroma mode
+ * (0 DC, 1 V, 2 H, 3 D45, 4 D135, 5 D117, 6 D153, 7 D207, 8 D63, 9 TM), svt_hip_encdec_intra_device of svtvp9_hip.h; the stand-in
+ * for an intra picture is 16x16 blocks with DC prediction. */
 typedef int32_t (*svt_vp9_shim_md_callback)(void *user, const svt_vp9_shim_picture_info *info, const void *me_results, void *mc_mode_info,
                                             void *lf_mode_info, int32_t mi_stride);
 EbErrorType svt_vp9_shim_set_mode_decision(EbComponentType *svt_enc_component, svt_vp9_shim_md_callback callback, void *user);

@@ -733,6 +733,22 @@ void    svt_hip_encdec_work_destroy(svt_hip_ctx *ctx, svt_encdec_work *work);
 int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work *work, int32_t n_pics, const svt_encdec_picture *pics, int32_t width,
                                     int32_t height, int32_t mi_stride, int32_t q_index, const svt_encdec_flags *flags,
                                     const svt_lf_thresh *thr, int32_t pad_x, int32_t pad_y);
+/* The encode pass of an INTRA picture (key frames, intra-refresh pictures): reference samples + the ten VP9 intra predictors +
+ * transform / quantisation / reconstruction of every block in coding-dependency order (encode_pass_sb with intra blocks,
+ * Codec/EbEncDecProcess.c:3680-4160: generate_intra_reference_samples :1128, intra_prediction Codec/EbIntraPrediction.c:16 ->
+ * VPX/vp9_reconintra.c:249-408 / VPX/intrapred.c, perform_coding_loop :365), then the tail of svt_hip_encdec_batch_device: skip flags,
+ * loop-filter masks, deblocking, border.  The grid (pic->d_lf_mi) describes intra blocks of 8x8, 16x16 or 32x32 (sb_type 3 / 6 / 9)
+ * with the transform of their own size, is_inter = 0, pad_[1] = luma mode, pad_[2] = chroma mode (PREDICTION_MODE: 0 DC, 1 V, 2 H,
+ * 3 D45, 4 D135, 5 D117, 6 D153, 7 D207, 8 D63, 9 TM); the luma transform type follows the mode
+ * (eb_vp9_intra_mode_to_tx_type_lookup).  4x4 blocks and the 64x64 block are outside this entry (reported as malformed through
+ * svt_hip_encdec_work_status).  pic->ref / d_mc_mi are ignored; pic->pred may be all NULL (the prediction is then not stored).
+ * flags->do_recon must be set.  Planes and strides 4-byte aligned.  Asynchronous on the context's stream. */
+int32_t svt_hip_encdec_intra_device(svt_hip_ctx *ctx, svt_encdec_work *work, const svt_encdec_picture *pic, int32_t width, int32_t height,
+                                    int32_t mi_stride, int32_t q_index, const svt_encdec_flags *flags, const svt_lf_thresh *thr, int32_t pad_x,
+                                    int32_t pad_y);
+/* Stand-in decision for an intra picture (NOT the reference's): 16x16 blocks with DC prediction, 8x8 where a 16x16 block would
+ * cross the picture edge. */
+int32_t svt_hip_md_intra_default_device(svt_hip_ctx *ctx, int32_t width, int32_t height, int32_t filter_level, svt_lf_mode_info *d_lf_mi, int32_t mi_stride);
 /* Profiling aid: `hook` is called on the enqueueing thread at every stage boundary of svt_hip_encdec_batch_device (before the
  * stage named is enqueued; SVT_ENCDEC_STAGE_END after the last), so that a host can record events of its own on the context's stream
  * and attribute the chain's time to its stages.  NULL removes it. */

@@ -38,6 +38,7 @@ struct svt_encdec_work {
     int32_t      *d_totals, *d_bases; /* [4][max_pics]: blocks of a (size, picture) / its first block */
     int32_t      *d_off_cnt;     /* [8]: first block / number of blocks per size */
     int32_t      *d_status;      /* != 0: a malformed grid was seen */
+    int32_t      *d_intra_sync;  /* ticket, status and per-(plane, SB) flags of the intra kernel */
     svt_quant_tables *d_qtabs;   /* [2] luma, chroma of the batch's q index */
     int16_t      *d_iscan;
     int           last_pics;
@@ -256,13 +257,14 @@ extern "C" int32_t svt_hip_encdec_work_create(svt_hip_ctx *ctx, int32_t max_pics
     const int16_t  *isc = svt_hip_vp9_iscan_tables(&offs, &entries);
     bool ok = hipMalloc((void **)&w->d_blocks, cap * sizeof(svt_tq_block)) == hipSuccess && hipMalloc((void **)&w->d_pos, cap * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&w->d_eob, cap * sizeof(uint16_t)) == hipSuccess &&
-              hipMalloc((void **)&w->d_counts, ((size_t)4 * max_pics * w->n_sb + 16 + 8 * ED_MAX_PICS) * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void **)&w->d_counts, ((size_t)4 * max_pics * w->n_sb + 16 + 8 * ED_MAX_PICS + 4 + 3 * (size_t)w->n_sb) * sizeof(int32_t)) == hipSuccess &&
               hipMalloc((void **)&w->d_qtabs, 2 * sizeof(svt_quant_tables)) == hipSuccess && hipMalloc((void **)&w->d_iscan, (size_t)entries * sizeof(int16_t)) == hipSuccess;
     if (ok) {
         w->d_off_cnt = w->d_counts + (size_t)4 * max_pics * w->n_sb;
         w->d_status = w->d_off_cnt + 8;
         w->d_totals = w->d_off_cnt + 16;
         w->d_bases = w->d_totals + 4 * ED_MAX_PICS;
+        w->d_intra_sync = w->d_bases + 4 * ED_MAX_PICS;
         ok = hipMemsetAsync(w->d_off_cnt, 0, 16 * sizeof(int32_t), ctx->stream) == hipSuccess &&
              hipMemcpyAsync(w->d_iscan, isc, (size_t)entries * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
              hipStreamSynchronize(ctx->stream) == hipSuccess;
@@ -426,6 +428,77 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
     ED_STAGE(SVT_ENCDEC_STAGE_END);
     w->last_pics = n_pics;
     return SVT_HIP_OK;
+}
+
+/* An intra picture: prediction + transform + reconstruction by the wavefront kernel (intra_kernel.hip), then the same tail as a batch of
+ * inter pictures -- skip flags, loop-filter masks, deblocking, border. */
+extern "C" int32_t svt_hip_encdec_intra_device(svt_hip_ctx *ctx, svt_encdec_work *w, const svt_encdec_picture *pic, int32_t width, int32_t height, int32_t mi_stride,
+                                               int32_t q_index, const svt_encdec_flags *flags, const svt_lf_thresh *thr, int32_t pad_x, int32_t pad_y) {
+    if (!ctx || !w || !pic || !flags || width != w->width || height != w->height || mi_stride < (width >> 3))
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec_intra: bad argument");
+    if (!flags->do_recon) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec_intra: intra prediction needs the reconstruction (do_recon)");
+    if (flags->apply_loop_filter && !thr) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec_intra: loop filter without thresholds");
+    const svt_encdec_picture &p = *pic;
+    if (!p.d_lf_mi || !p.src.y || !p.src.u || !p.src.v || !p.recon.y || !p.recon.u || !p.recon.v || !p.d_qcoeff || !p.d_dqcoeff || !p.d_eob_map || !p.d_nz ||
+        (flags->apply_loop_filter && !p.d_lfm))
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec_intra: null picture field");
+    if (((uintptr_t)p.d_qcoeff | (uintptr_t)p.d_dqcoeff) & 15) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec_intra: coefficient arrays must be 16-byte aligned");
+    if (p.recon.y_stride > 65535 || ((p.src.y_stride | p.src.uv_stride | p.recon.y_stride | p.recon.uv_stride) & 3) ||
+        (((uintptr_t)p.src.y | (uintptr_t)p.src.u | (uintptr_t)p.src.v | (uintptr_t)p.recon.y | (uintptr_t)p.recon.u | (uintptr_t)p.recon.v) & 3) ||
+        (p.pred.y && (((uintptr_t)p.pred.y | (uintptr_t)p.pred.u | (uintptr_t)p.pred.v | (uintptr_t)p.pred.y_stride | (uintptr_t)p.pred.uv_stride) & 3)))
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec_intra: planes and strides must be 4-byte aligned");
+    if (p.pred.y && (!p.pred.u || !p.pred.v)) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec_intra: prediction planes");
+    HIP_TRY(hipSetDevice(ctx->device));
+    ed_batch_dev hb;
+    memset(&hb, 0, sizeof hb);
+    fill_dims(hb, 1, width, height, mi_stride);
+    const uint32_t *offs = nullptr;
+    (void)svt_hip_vp9_iscan_tables(&offs, nullptr);
+    hb.pic[0].lf_mi = p.d_lf_mi; hb.pic[0].nz = p.d_nz; hb.pic[0].eob_map = p.d_eob_map; hb.pic[0].lfm = p.d_lfm;
+    const ed_batch_dev *dB = nullptr;
+    if (stage_batch(ctx, hb, &dB)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "encdec_intra: descriptor buffers");
+    {
+        svt_quant_tables qt[2];
+        if (svt_hip_quant_tables_for_qindex(q_index, qt) != SVT_HIP_OK) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec_intra: q index");
+        void *h = nullptr, *d = nullptr;
+        if (svt_ctx_stage(ctx, sizeof qt, &h, &d)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "encdec_intra: descriptor buffers");
+        memcpy(h, qt, sizeof qt);
+        HIP_TRY(hipMemcpyAsync(w->d_qtabs, h, sizeof qt, hipMemcpyHostToDevice, ctx->stream));
+        svt_ctx_stage_commit(ctx);
+    }
+    ED_STAGE(SVT_ENCDEC_STAGE_TQ);
+    HIP_TRY(hipMemsetAsync(p.d_eob_map, 0, (size_t)(width / 4) * (height / 4) * 3 / 2 * sizeof(uint16_t), ctx->stream));
+    HIP_TRY(hipMemsetAsync(p.d_nz, 0, (size_t)mi_stride * hb.mi_rows, ctx->stream));
+    int32_t rc = svt_intra_launch(ctx, pic, width, height, mi_stride, w->d_qtabs, w->d_iscan, offs, w->d_intra_sync, w->d_status);
+    if (rc) return rc;
+    ED_STAGE(SVT_ENCDEC_STAGE_SKIP);
+    hipLaunchKernelGGL(svt_skip_update_kernel, dim3((hb.mi_rows * hb.mi_cols + 255) / 256), dim3(256), 0, ctx->stream, dB);
+    HIP_TRY(hipGetLastError());
+    ED_STAGE(SVT_ENCDEC_STAGE_LF);
+    svt_yuv_planes rec = p.recon;
+    rec.width = width; rec.height = height;
+    if (flags->apply_loop_filter) {
+        hipLaunchKernelGGL(svt_lf_mask_kernel, dim3(hb.n_sb), dim3(64), 0, ctx->stream, dB, w->d_status);
+        HIP_TRY(hipGetLastError());
+        const svt_lf_mask *lfm = p.d_lfm;
+        const int32_t      lfm_stride = hb.sb_cols, mr = hb.mi_rows, mc = hb.mi_cols;
+        rc = svt_hip_lf_batch_device(ctx, 1, &rec, &lfm, &lfm_stride, thr, &mr, &mc, 0);
+        if (rc) return rc;
+    }
+    ED_STAGE(SVT_ENCDEC_STAGE_PAD);
+    if (flags->pad_reference && !p.no_pad) {
+        rc = svt_hip_ref_pad_batch_device(ctx, 1, &rec, pad_x, pad_y);
+        if (rc) return rc;
+    }
+    ED_STAGE(SVT_ENCDEC_STAGE_END);
+    return SVT_HIP_OK;
+}
+
+extern "C" int32_t svt_hip_md_intra_default_device(svt_hip_ctx *ctx, int32_t width, int32_t height, int32_t filter_level, svt_lf_mode_info *d_lf_mi, int32_t mi_stride) {
+    if (!ctx || !d_lf_mi || width < 8 || height < 8 || (width & 7) || (height & 7) || mi_stride < (width >> 3))
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "md_intra_default: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return svt_md_intra_default_launch(ctx, d_lf_mi, mi_stride, height >> 3, width >> 3, filter_level);
 }
 
 extern "C" void svt_hip_encdec_work_set_stage_hook(svt_encdec_work *w, svt_encdec_stage_hook hook, void *user) {

@@ -1,0 +1,268 @@
+/*
+ * intra_kernel.hip -- the encode pass of an INTRA picture (gfx950): reference samples, the ten VP9 predictors, transform /
+ * quantisation / reconstruction of every block, in the dependency order intra prediction imposes.
+ *
+ * Replaces, for a picture whose blocks are all intra (key frames and intra-refresh pictures), the per-block body of encode_pass_sb
+ * (Source/Lib/Codec/EbEncDecProcess.c:3680-4160):
+ *   generate_intra_reference_samples (:1128-1310; the neighbour arrays of Codec/EbNeighborArrays.c:107-240 hold the block's
+ *   unfiltered reconstruction, so the reference samples are read straight from the reconstruction plane here)
+ *   -> intra_prediction (Codec/EbIntraPrediction.c:16) -> eb_vp9_predict_intra_block / build_intra_predictors
+ *      (VPX/vp9_reconintra.c:249-408) -> the predictors of VPX/intrapred.c:22-416
+ *   -> perform_coding_loop (:365-587) with the transform type of the luma mode (eb_vp9_intra_mode_to_tx_type_lookup,
+ *      vp9_reconintra.c:20-31; chroma and 32x32: DCT_DCT) -> tq_block_body (tq_core.h, the body the batch kernels use).
+ * Scope: blocks of 8x8, 16x16 and 32x32 with the transform of their own size, inside the picture (what the reference codes in
+ * an intra picture whose dimensions are multiples of 8, without its 4x4 blocks: they never use the above-right neighbour --
+ * have_right = 0, EbEncDecProcess.c:1146 -- and never cross the picture edge).
+ *
+ * Parallelism: a block needs the reconstruction of its left, above and above-left neighbours, so blocks of one SB are coded one
+ * after the other (z-order) and SB (r, c) can start when (r, c - 1) and (r - 1, c) are done: an anti-diagonal wavefront over the
+ * SBs, times three independent planes.  One 64-lane workgroup codes one (SB, plane); workgroups take TICKETS (an atomic counter)
+ * that enumerate the (SB, plane) pairs diagonal by diagonal, so every workgroup only ever waits for tickets smaller than its own
+ * -- which are held by workgroups that already run: no deadlock whatever the dispatch order, no co-residency requirement.
+ * A block is N x N with N lanes active (lane i = row i of the prediction, then column / row i of the transform); the chain of
+ * dependent blocks, not the lane count, bounds the speed: a 2160p key frame is 93 diagonals of at most 34 SBs.  This kernel is
+ * latency-bound by design (one picture in a GOP); it shares the GPU with the batches of the inter pictures running beside it.
+ * Visibility between workgroups (other CUs, other XCDs' L2): release fence + flag store when an SB is done, flag load + acquire
+ * fence before the first reference-sample load; inside a workgroup the block's stores are drained (workgroup fence) before the
+ * next block reads them.
+ */
+#include <hip/hip_runtime.h>
+#include "tq_core.h"
+#include "encdec_core.h"
+
+namespace {
+
+struct intra_pic_dev {
+    const uint8_t *src[3];
+    uint8_t       *pred[3];  /* may be null: the prediction is then not stored */
+    uint8_t       *rec[3];
+    int32_t        src_stride[2], pred_stride[2], rec_stride[2];
+    const svt_lf_mode_info *mi;
+    int32_t        mi_stride, mi_rows, mi_cols, sb_cols, sb_rows, width, height;
+    const svt_quant_tables *qtabs;
+    const int16_t *iscan;
+    uint32_t       iscan_off[16];
+    int16_t       *qcoeff, *dqcoeff;
+    uint16_t      *eob_map;
+    uint8_t       *nz;
+    int32_t       *sync;    /* [0] ticket counter, [2 + plane * n_sb + sb] done flags; zeroed before the launch */
+    int32_t       *status;  /* |= 1: a malformed grid was seen */
+};
+
+/* eb_vp9_intra_mode_to_tx_type_lookup (VPX/vp9_reconintra.c:20-31): DC, V, H, D45, D135, D117, D153, D207, D63, TM */
+__device__ __forceinline__ int intra_tx_type(int mode) { return (int)((0x3122130210ull >> (4 * mode)) & 3); }
+
+#define AVG2(a, b) (((a) + (b) + 1) >> 1)
+#define AVG3(a, b, c) (((a) + 2 * (b) + (c) + 2) >> 2)
+
+/* Row r of the N x N prediction, packed.  e[k + 32] = B(k): B(0) the corner sample above[-1], B(k > 0) = above[k - 1] (2N samples:
+ * the second N replicate above[N - 1], or are the true above-right samples), B(-k) = left[k - 1].  Closed forms of the procedures of
+ * VPX/intrapred.c (d207 :22, d63 :43, d45 :59, d117 :75, d135 :99, d153 :120, v / h / tm :140-172, the four DC forms :174-236,
+ * the 4x4 forms of d45 / d63 :349-416 which read the above-right samples). */
+template <int N> __device__ __forceinline__ void intra_pred_row(const uint8_t *e, int mode, int r, int have_left, int have_top, uint32_t (&prow)[N / 4]) {
+    auto B = [&](int k) -> int { return (int)e[k + 32]; };
+    int dc = 128;
+    if (mode == 0 && (have_left || have_top)) {
+        int sum = 0, cnt = 0;
+        if (have_top) { _Pragma("unroll") for (int j = 0; j < N; j++) sum += B(j + 1); cnt += N; }
+        if (have_left) { _Pragma("unroll") for (int j = 0; j < N; j++) sum += B(-(j + 1)); cnt += N; }
+        dc = (sum + (cnt >> 1)) / cnt;
+    }
+    _Pragma("unroll") for (int q = 0; q < N / 4; q++) prow[q] = 0;
+    /* the mode is uniform over the wave: one branch, then N samples without control flow */
+    auto fill = [&](auto f) {
+        _Pragma("unroll") for (int c = 0; c < N; c++) prow[c >> 2] |= (uint32_t)(f(c) & 0xff) << (8 * (c & 3));
+    };
+    switch (mode) {
+    case 0: fill([&](int) { return dc; }); break;
+    case 1: fill([&](int c) { return B(c + 1); }); break;
+    case 2: fill([&](int) { return B(-(r + 1)); }); break;
+    case 3: /* D45 */
+        fill([&](int c) {
+            if (N == 4) return (r + c == 6) ? B(8) : AVG3(B(r + c + 1), B(r + c + 2), B(r + c + 3));
+            return (r + c < N - 1) ? AVG3(B(r + c + 1), B(r + c + 2), B(r + c + 3)) : B(N);
+        });
+        break;
+    case 4: fill([&](int c) { const int p = c - r; return AVG3(B(p - 1), B(p), B(p + 1)); }); break; /* D135 */
+    case 5: /* D117 */
+        fill([&](int c) {
+            const int h = r >> 1;
+            if (c >= h) { const int cc = c - h; return (r & 1) ? AVG3(B(cc - 1), B(cc), B(cc + 1)) : AVG2(B(cc), B(cc + 1)); }
+            const int rr = r - 2 * c;
+            return AVG3(B(-(rr - 2)), B(-(rr - 1)), B(-rr));
+        });
+        break;
+    case 6: /* D153 */
+        fill([&](int c) {
+            const int h = c >> 1;
+            if (r >= h) { const int rr = r - h; return (c & 1) ? AVG3(B(-rr + 1), B(-rr), B(-rr - 1)) : AVG2(B(-rr), B(-rr - 1)); }
+            const int cc = c - 2 * r;
+            return AVG3(B(cc - 2), B(cc - 1), B(cc));
+        });
+        break;
+    case 7: /* D207: left[] clamped at N - 1 */
+        fill([&](int c) {
+            const int idx = r + (c >> 1);
+            const int l0 = B(-(min(idx, N - 1) + 1)), l1 = B(-(min(idx + 1, N - 1) + 1)), l2 = B(-(min(idx + 2, N - 1) + 1));
+            return (c & 1) ? AVG3(l0, l1, l2) : AVG2(l0, l1);
+        });
+        break;
+    case 8: /* D63 */
+        fill([&](int c) {
+            const int h = r >> 1;
+            if (N > 4 && r >= 2 && c >= N - 1 - h) return B(N);
+            return (r & 1) ? AVG3(B(c + h + 1), B(c + h + 2), B(c + h + 3)) : AVG2(B(c + h + 1), B(c + h + 2));
+        });
+        break;
+    default: /* TM */
+        fill([&](int c) { const int v = B(-(r + 1)) + B(c + 1) - B(0); return v < 0 ? 0 : v > 255 ? 255 : v; });
+        break;
+    }
+}
+
+/* one N x N transform block of plane `plane` at sample (x0, y0) of that plane; the whole workgroup (one wave) calls it */
+template <int N>
+__device__ __forceinline__ int intra_block(const intra_pic_dev &P, int plane, int x0, int y0, int mode, int sb, int32_t *tile, uint8_t *edge) {
+    const int lane = (int)threadIdx.x, c = plane ? 1 : 0;
+    const int rs = P.rec_stride[c];
+    uint8_t  *rp = P.rec[plane];
+    const int have_left = x0 > 0, have_top = y0 > 0;
+    /* reference samples -> LDS (generate_intra_reference_samples, the paths of a block >= 8x8 inside the picture) */
+    {
+        const int j = lane & 31;
+        if (lane < 32) { /* left column */
+            if (j < N) edge[32 - (j + 1)] = have_left ? rp[(size_t)(y0 + j) * rs + x0 - 1] : (uint8_t)129;
+        } else {         /* above row, replicated to the right */
+            if (j < N) {
+                const uint8_t a = have_top ? rp[(size_t)(y0 - 1) * rs + x0 + j] : (uint8_t)127;
+                edge[32 + 1 + j] = a;
+                if (j == N - 1) { _Pragma("unroll") for (int q = 0; q < N; q++) edge[32 + 1 + N + q] = a; }
+            }
+        }
+        if (lane == 0) edge[32] = have_top ? (have_left ? rp[(size_t)(y0 - 1) * rs + x0 - 1] : (uint8_t)129) : (uint8_t)127;
+    }
+    __syncthreads();
+    const bool active = lane < N;
+    const int  i = lane % N;
+    uint32_t   srow[N / 4], prow[N / 4];
+    intra_pred_row<N>(edge, mode, i, have_left, have_top, prow);
+    constexpr uintptr_t AM = N >= 16 ? 15 : N - 1;
+    {
+        const uint8_t *sp = P.src[plane] + (size_t)(y0 + i) * P.src_stride[c] + x0;
+        _Pragma("unroll") for (int q = 0; q < N / 4; q++) srow[q] = 0u;
+        if (active) row_load<N>(sp, ((uintptr_t)sp & AM) == 0, srow);
+        if (active && P.pred[plane]) {
+            uint8_t *pp = P.pred[plane] + (size_t)(y0 + i) * P.pred_stride[c] + x0;
+            row_store<N>(pp, ((uintptr_t)pp & AM) == 0, prow);
+        }
+    }
+    svt_tq_block k;
+    k.src_off = k.pred_off = 0;
+    k.recon_off = (uint32_t)y0 * (uint32_t)rs + (uint32_t)x0;
+    k.coeff_off = (uint32_t)sb * SVT_SB_COEFFS + (plane == 0 ? 0u : plane == 1 ? 4096u : 5120u) + svt_zorder4((x0 & (plane ? 31 : 63)) >> 2, (y0 & (plane ? 31 : 63)) >> 2) * 16u;
+    k.tx_size = (uint8_t)txcfg<N>::size;
+    k.tx_type = (uint8_t)((plane == 0 && N < 32) ? intra_tx_type(mode) : 0);
+    k.iscan_off = P.iscan_off[k.tx_size * 4 + k.tx_type];
+    k.src_stride = k.pred_stride = 0; k.recon_stride = (uint16_t)rs;
+    k.qtab = (uint8_t)c; k.do_recon = 1; k.partial32 = 0; k.pad_[0] = 0;
+    const int pw4 = (plane ? P.width >> 1 : P.width) >> 2, w4 = P.width >> 2, h4 = P.height >> 2;
+    const int eo = plane == 0 ? 0 : w4 * h4 + (plane == 2 ? (w4 >> 1) * (h4 >> 1) : 0);
+    int32_t *t = tile + (lane / N) * (N * (N + 1)); /* the idle slots of the wave run along on tiles of their own */
+    const int eob = tq_block_body<N, false, false>(k, active, i, t, srow, prow, P.qtabs, P.iscan, P.qcoeff, P.dqcoeff,
+                                                   P.eob_map + eo + (y0 >> 2) * pw4 + (x0 >> 2), nullptr, nullptr, nullptr, nullptr, nullptr, rp);
+    /* the block's reconstruction is read by the next block of this wave: drain the stores */
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(eob);
+}
+
+__global__ __launch_bounds__(64) void svt_intra_kernel(const intra_pic_dev P) {
+    __shared__ int32_t tile[2 * 32 * 33];
+    __shared__ uint8_t edge[128];
+    __shared__ int32_t s_ticket;
+    const int lane = (int)threadIdx.x, n_sb = P.sb_cols * P.sb_rows;
+    if (lane == 0) s_ticket = atomicAdd(&P.sync[0], 1);
+    __syncthreads();
+    const int ticket = s_ticket, plane = ticket % 3;
+    /* the n-th SB in anti-diagonal order (diagonal d = row + col, rows ascending inside a diagonal) */
+    int n = ticket / 3, sr = 0, sc = 0;
+    for (int d = 0; d < P.sb_rows + P.sb_cols - 1; d++) {
+        const int r_lo = d - (P.sb_cols - 1) > 0 ? d - (P.sb_cols - 1) : 0, r_hi = d < P.sb_rows - 1 ? d : P.sb_rows - 1, cnt = r_hi - r_lo + 1;
+        if (n < cnt) { sr = r_lo + n; sc = d - sr; break; }
+        n -= cnt;
+    }
+    const int sb = sr * P.sb_cols + sc;
+    int32_t  *done = P.sync + 2 + plane * n_sb;
+    if (lane == 0) {
+        if (sc > 0) while (__hip_atomic_load(&done[sb - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+        if (sr > 0) while (__hip_atomic_load(&done[sb - P.sb_cols], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int z = 0; z < 64; z++) {
+        const int r = ((z >> 1) & 1) | ((z >> 3) & 1) << 1 | ((z >> 5) & 1) << 2, c = (z & 1) | ((z >> 2) & 1) << 1 | ((z >> 4) & 1) << 2;
+        const int ur = sr * 8 + r, uc = sc * 8 + c;
+        if (ur >= P.mi_rows || uc >= P.mi_cols) continue;
+        const svt_lf_mode_info b = P.mi[ur * P.mi_stride + uc];
+        const int w8 = b.sb_type == 3 ? 1 : b.sb_type == 6 ? 2 : b.sb_type == 9 ? 4 : 0;
+        if (w8 == 0 || b.is_inter) { if (lane == 0) atomicOr(P.status, 1); continue; }
+        if ((ur % w8) || (uc % w8)) continue;
+        const int mode = plane ? b.pad_[2] : b.pad_[1];
+        if (ur + w8 > P.mi_rows || uc + w8 > P.mi_cols || b.tx_size != (w8 == 1 ? 1 : w8 == 2 ? 2 : 3) || mode > 9) { if (lane == 0) atomicOr(P.status, 1); continue; }
+        const int x0 = plane ? uc * 4 : uc * 8, y0 = plane ? ur * 4 : ur * 8, nn = plane ? w8 * 4 : w8 * 8;
+        int eob;
+        if (nn == 32) eob = intra_block<32>(P, plane, x0, y0, mode, sb, tile, edge);
+        else if (nn == 16) eob = intra_block<16>(P, plane, x0, y0, mode, sb, tile, edge);
+        else if (nn == 8) eob = intra_block<8>(P, plane, x0, y0, mode, sb, tile, edge);
+        else eob = intra_block<4>(P, plane, x0, y0, mode, sb, tile, edge);
+        if (eob && lane == 0) P.nz[ur * P.mi_stride + uc] = 1; /* the three planes of a block may all store the same 1 */
+    }
+    /* publish the SB: its reconstruction reaches memory before the flag does */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(&done[sb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/* stand-in decision for an intra picture (no claim of coding efficiency; the public API's callback replaces it): 16x16 blocks with
+ * DC prediction, 8x8 where a 16x16 block would cross the picture edge */
+__global__ __launch_bounds__(256) void svt_md_intra_default_kernel(svt_lf_mode_info *mi, int mi_stride, int mi_rows, int mi_cols, int filter_level) {
+    const int u = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (u >= mi_rows * mi_cols) return;
+    const int r = u / mi_cols, c = u % mi_cols;
+    const int fit16 = (r & ~1) + 2 <= mi_rows && (c & ~1) + 2 <= mi_cols;
+    svt_lf_mode_info m;
+    m.sb_type = fit16 ? 6 : 3; m.tx_size = fit16 ? 2 : 1; m.skip = 0; m.is_inter = 0; m.filter_level = (uint8_t)filter_level;
+    m.pad_[0] = m.pad_[1] = m.pad_[2] = 0;
+    mi[r * mi_stride + c] = m;
+}
+
+} // namespace
+
+/* internal launchers (declared in svt_ctx.h; the entry points are in encdec.hip) */
+int32_t svt_intra_launch(svt_hip_ctx *ctx, const svt_encdec_picture *p, int32_t width, int32_t height, int32_t mi_stride, const svt_quant_tables *d_qtabs,
+                         const int16_t *d_iscan, const uint32_t iscan_off[16], int32_t *d_sync, int32_t *d_status) {
+    intra_pic_dev P;
+    memset(&P, 0, sizeof P);
+    P.src[0] = p->src.y; P.src[1] = p->src.u; P.src[2] = p->src.v;
+    P.pred[0] = p->pred.y; P.pred[1] = p->pred.u; P.pred[2] = p->pred.v;
+    P.rec[0] = p->recon.y; P.rec[1] = p->recon.u; P.rec[2] = p->recon.v;
+    P.src_stride[0] = p->src.y_stride; P.src_stride[1] = p->src.uv_stride;
+    P.pred_stride[0] = p->pred.y_stride; P.pred_stride[1] = p->pred.uv_stride;
+    P.rec_stride[0] = p->recon.y_stride; P.rec_stride[1] = p->recon.uv_stride;
+    P.mi = p->d_lf_mi; P.mi_stride = mi_stride; P.mi_rows = height >> 3; P.mi_cols = width >> 3;
+    P.sb_cols = (width + 63) >> 6; P.sb_rows = (height + 63) >> 6; P.width = width; P.height = height;
+    P.qtabs = d_qtabs; P.iscan = d_iscan;
+    for (int i = 0; i < 16; i++) P.iscan_off[i] = iscan_off[i];
+    P.qcoeff = p->d_qcoeff; P.dqcoeff = p->d_dqcoeff; P.eob_map = p->d_eob_map; P.nz = p->d_nz; P.sync = d_sync; P.status = d_status;
+    const int n_sb = P.sb_cols * P.sb_rows;
+    HIP_TRY(hipMemsetAsync(d_sync, 0, (size_t)(2 + 3 * n_sb) * sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(svt_intra_kernel, dim3(3 * n_sb), dim3(64), 0, ctx->stream, P);
+    HIP_TRY(hipGetLastError());
+    return SVT_HIP_OK;
+}
+
+int32_t svt_md_intra_default_launch(svt_hip_ctx *ctx, svt_lf_mode_info *d_lf_mi, int32_t mi_stride, int32_t mi_rows, int32_t mi_cols, int32_t filter_level) {
+    hipLaunchKernelGGL(svt_md_intra_default_kernel, dim3((mi_rows * mi_cols + 255) / 256), dim3(256), 0, ctx->stream, d_lf_mi, mi_stride, mi_rows, mi_cols, filter_level);
+    HIP_TRY(hipGetLastError());
+    return SVT_HIP_OK;
+}

@@ -567,17 +567,39 @@ static EbErrorType encode_wave(shim_state *s, shim_dev *d, const shim_job *const
     return EB_ErrorNone;
 }
 
-/* an intra picture: intra prediction is not on the GPU path (outside the hot path), so its reference picture is its source
- * picture, padded -- flagged in the picture's info; everything that predicts from it runs the real chain */
+/* an intra picture (key frame / intra refresh): the intra encode pass on the GPU (svt_hip_encdec_intra_device: reference samples,
+ * predictors, transform / quantisation / reconstruction in coding-dependency order, then deblocking and border).  The host's callback
+ * decides its blocks and modes when it wants to (info->is_intra = 1, no ME results); otherwise the stand-in (16x16, DC). */
 static EbErrorType encode_intra(shim_state *s, shim_dev *d, shim_slot *t) {
-    const svt_yuv_planes src = tight_planes(s, t->d_src), rec = rec_planes(s, t->d_rec);
-    const size_t W = (size_t)s->W, H = (size_t)s->H;
-    GPU_TRY(svt_hip_mem_copy_2d_device(d->ctx, rec.y, (size_t)rec.y_stride, src.y, W, W, H));
-    GPU_TRY(svt_hip_mem_copy_2d_device(d->ctx, rec.u, (size_t)rec.uv_stride, src.u, W / 2, W / 2, H / 2));
-    GPU_TRY(svt_hip_mem_copy_2d_device(d->ctx, rec.v, (size_t)rec.uv_stride, src.v, W / 2, W / 2, H / 2));
-    GPU_TRY(svt_hip_ref_pad_batch_device(d->ctx, 1, &rec, SHIM_REF_PAD, SHIM_REF_PAD));
-    t->info.is_used_as_reference = 1; t->info.do_recon = 1; t->info.apply_loop_filter = 0; t->info.pad_reference = 1;
-    t->info.q_index = s->q_index; t->info.filter_level = s->filter_level; t->info.decision_source = 2; t->info.intra_recon_is_source = 1;
+    svt_encdec_flags fl;
+    {
+        svt_encdec_flags_config fc;
+        fc.enc_mode = s->cfg.enc_mode; fc.tune = s->cfg.tune; fc.temporal_layer_index = 0; fc.is_used_as_reference = 1;
+        fc.recon_file = (int32_t)s->cfg.recon_file; fc.loop_filter = s->cfg.loop_filter;
+        if (svt_hip_encdec_flags_derive(&fc, &fl) != SVT_HIP_OK) return EB_ErrorBadParameter;
+    }
+    const int level = s->cfg.loop_filter ? svt_hip_lf_level_from_q(svt_hip_vp9_ac_step(s->q_index), 1) : 0; /* key-frame rule of eb_vp9_pick_filter_level */
+    t->info.is_used_as_reference = 1; t->info.do_recon = fl.do_recon; t->info.apply_loop_filter = fl.apply_loop_filter; t->info.pad_reference = fl.pad_reference;
+    t->info.q_index = s->q_index; t->info.filter_level = level; t->info.decision_source = 0; t->info.intra_recon_is_source = 0;
+    int decided = 0;
+    if (s->md_cb) {
+        memset(s->h_mc, 0, (size_t)s->mi_rows * s->mi_cols * sizeof(svt_mc_mode_info));
+        memset(s->h_lf, 0, (size_t)s->mi_rows * s->mi_cols * sizeof(svt_lf_mode_info));
+        if (s->md_cb(s->md_user, &t->info, NULL, s->h_mc, s->h_lf, s->mi_cols) == 0) {
+            GPU_TRY(svt_hip_mem_upload_2d(d->ctx, t->d_lf_mi, (size_t)s->mi_cols * sizeof(svt_lf_mode_info), s->h_lf, (size_t)s->mi_cols * sizeof(svt_lf_mode_info),
+                                          (size_t)s->mi_cols * sizeof(svt_lf_mode_info), (size_t)s->mi_rows));
+            decided = 1;
+            t->info.decision_source = 1;
+        }
+    }
+    if (!decided) GPU_TRY(svt_hip_md_intra_default_device(d->ctx, s->W, s->H, level, (svt_lf_mode_info *)t->d_lf_mi, s->mi_cols));
+    GPU_TRY(svt_hip_mem_set(d->ctx, t->d_mc_mi, 0, (size_t)s->mi_rows * s->mi_cols * sizeof(svt_mc_mode_info))); /* no motion in an intra picture */
+    svt_encdec_picture p;
+    memset(&p, 0, sizeof p);
+    p.d_lf_mi = (svt_lf_mode_info *)t->d_lf_mi;
+    p.src = tight_planes(s, t->d_src); p.pred = tight_planes(s, t->d_pred); p.recon = rec_planes(s, t->d_rec);
+    p.d_qcoeff = t->d_qcoeff; p.d_dqcoeff = t->d_dqcoeff; p.d_eob_map = (uint16_t *)t->d_eob_map; p.d_lfm = (svt_lf_mask *)t->d_lfm; p.d_nz = (uint8_t *)t->d_nz;
+    GPU_TRY(svt_hip_encdec_intra_device(d->ctx, d->work, &p, s->W, s->H, s->mi_cols, s->q_index, &fl, &s->thr, SHIM_REF_PAD, SHIM_REF_PAD));
     t->coded = 1;
     if (s->cfg.recon_file) return queue_recon(s, d, t);
     return EB_ErrorNone;
@@ -932,7 +954,6 @@ EbErrorType svt_vp9_shim_get_coded_picture(EbComponentType *h, uint64_t picture_
     if (!t || !t->coded) return EB_NoErrorEmptyQueue;
     GPU_TRY(svt_hip_ctx_marker_wait(d->ctx, t->marker));
     if (info) *info = t->info;
-    if (t->info.is_intra) return EB_ErrorNone;
     const size_t units = (size_t)s->mi_rows * s->mi_cols;
     if (mc_mode_info) GPU_TRY(svt_hip_mem_download(d->ctx, mc_mode_info, t->d_mc_mi, units * sizeof(svt_mc_mode_info)));
     if (lf_mode_info) GPU_TRY(svt_hip_mem_download(d->ctx, lf_mode_info, t->d_lf_mi, units * sizeof(svt_lf_mode_info)));

@@ -266,3 +266,32 @@ def ref_intra_picture(src, lf_mi, q_index):
     out["eob_map"] = np.frombuffer(raw, np.uint16, ne, o).copy()
     assert o + 2 * ne == len(raw)
     return out
+
+
+def oracle_intra_chain(src, lf_mi, q_index, flags, thr, pad=PAD, recon_init=None):
+    """an intra picture through the whole encode pass: oracle_intra_picture, then skip flags, masks, deblocking and border as
+    oracle_encdec_picture does for an inter picture"""
+    H, W = src[0].shape
+    mi_rows, mi_cols = H // 8, W // 8
+    lf_mi = np.ascontiguousarray(lf_mi).copy()
+    out = oracle_intra_picture(src, lf_mi, q_index, rec=recon_init, pad=pad)
+    rec, emap = out["rec"], out["eob_map"]
+    e0, e1, e2, e3 = eob_map_offsets(W, H)
+    ey = emap[e0:e1].reshape(H // 4, W // 4)
+    eu, ev = emap[e1:e2].reshape(H // 8, W // 8), emap[e2:e3].reshape(H // 8, W // 8)
+    # a block's transform blocks start at its first unit (one per plane): eob of luma at (2 ur, 2 uc), chroma at (ur, uc)
+    any_nz = (ey[::2, ::2] != 0) | (eu != 0) | (ev != 0)
+    w8 = np.maximum(np.array(_W4)[lf_mi["sb_type"][:, :mi_cols]] // 2, 1)
+    r, c = np.meshgrid(np.arange(mi_rows), np.arange(mi_cols), indexing="ij")
+    lf_mi["skip"][:, :mi_cols] = ~any_nz[r - r % w8, c - c % w8]
+    out["lf_mi"], out["lfm"] = lf_mi, None
+    if flags.apply_loop_filter:
+        lfm = T.oracle_lf_build_masks(lf_mi, mi_rows, mi_cols)
+        out["lfm"] = lfm
+        d = rec.desc(rec.buf.ctypes.data)
+        lfm_c = np.ascontiguousarray(lfm)
+        assert T.oracle().svt_oracle_lf_frame(C.byref(d), lfm_c.ctypes.data_as(C.c_void_p), lfm_c.shape[1], C.byref(thr), mi_rows, mi_cols, 0) == 0
+    if flags.pad_reference:
+        d = rec.desc(rec.buf.ctypes.data)
+        assert T.oracle().svt_oracle_ref_pad(C.byref(d), pad, pad) == 0
+    return out

@@ -61,6 +61,20 @@ def host_decision(me, W, H, number, level):
     return mc, lf
 
 
+def intra_stand_in(W, H, level):
+    """the library's stand-in for an intra picture: 16x16 blocks with DC prediction, 8x8 where a 16x16 block would cross the edge"""
+    mi_rows, mi_cols = H // 8, W // 8
+    r, c = np.meshgrid(np.arange(mi_rows), np.arange(mi_cols), indexing="ij")
+    fit = ((r & ~1) + 2 <= mi_rows) & ((c & ~1) + 2 <= mi_cols)
+    lf = np.zeros((mi_rows, mi_cols), dtype=B.LF_MODE_INFO_DTYPE)
+    lf["sb_type"], lf["tx_size"], lf["filter_level"] = np.where(fit, 6, 3), np.where(fit, 2, 1), level
+    return lf
+
+
+def intra_host_decision(W, H, number, level):
+    return M.gen_intra_grid(2000 + number, W, H, filter_level=level)
+
+
 def stand_in(me, W, H, lam, level):
     mc = np.zeros((H // 8, W // 8), dtype=B.MC_MODE_INFO_DTYPE)
     lf = np.zeros((H // 8, W // 8), dtype=B.LF_MODE_INFO_DTYPE)
@@ -81,6 +95,7 @@ def run_clip(W, H, N, enc_mode, tune, qp, recon_file, intra_period, use_callback
     cfg.source_width, cfg.source_height, cfg.enc_mode, cfg.tune, cfg.frame_rate, cfg.intra_period, cfg.qp, cfg.recon_file = W, H, enc_mode, tune, 60 << 16, intra_period, qp, recon_file
     assert lib.eb_vp9_svt_enc_set_parameter(h, C.byref(cfg)) == 0
     level = B.load().svt_hip_lf_level_from_q(B.load().svt_hip_vp9_ac_step(B.load().svt_hip_vp9_qindex_from_qp(qp)), 0)
+    level_key = B.load().svt_hip_lf_level_from_q(B.load().svt_hip_vp9_ac_step(B.load().svt_hip_vp9_qindex_from_qp(qp)), 1)
     nsb = T.n_sb(W, H)
     seen = []
 
@@ -89,6 +104,11 @@ def run_clip(W, H, N, enc_mode, tune, qp, recon_file, intra_period, use_callback
         seen.append(int(i.picture_number))
         if i.picture_number % 7 == 3:
             return 1                                            # "no decision": the library's stand-in takes this picture
+        if i.is_intra:                                          # an intra picture: blocks and modes, no ME results
+            assert not me_p
+            lf = intra_host_decision(W, H, int(i.picture_number), level_key)
+            C.memmove(lf_p, lf.ctypes.data, lf.nbytes)
+            return 0
         me = np.ctypeslib.as_array(C.cast(me_p, C.POINTER(C.c_uint8)), (nsb * 85 * 40,)).view(B.ME_RESULT_DTYPE).reshape(nsb, 85)
         mc, lf = host_decision(me, W, H, int(i.picture_number), level)
         C.memmove(mc_p, mc.ctypes.data, mc.nbytes)
@@ -222,7 +242,7 @@ def oracle_clip(frames, W, H, N, enc_mode, tune, qp, recon_file, intra_period, u
     lib = B.load()
     q_index = lib.svt_hip_vp9_qindex_from_qp(qp)
     ac = lib.svt_hip_vp9_ac_step(q_index)
-    level = lib.svt_hip_lf_level_from_q(ac, 0)
+    level, level_key = lib.svt_hip_lf_level_from_q(ac, 0), lib.svt_hip_lf_level_from_q(ac, 1)
     thr = B.LfThresh()
     lib.svt_hip_lf_thresh_init(C.byref(thr), 0)
     pics = [T.PaPic(f) for f in frames]
@@ -231,8 +251,12 @@ def oracle_clip(frames, W, H, N, enc_mode, tune, qp, recon_file, intra_period, u
     for (k, layer, lv, nl, r0, r1, used) in structure(N, minigop, intra_period):
         src = (frames[k],) + chroma(frames[k], k)
         if nl == 0:
-            recs[k] = M.RefPic(W, H).set_padded(*src)
-            outs[k] = dict(intra=True)
+            lf = intra_host_decision(W, H, k, level_key) if use_callback and k % 7 != 3 else intra_stand_in(W, H, level_key)
+            c, fl = B.EncdecFlagsConfig(enc_mode=enc_mode, tune=tune, temporal_layer_index=0, is_used_as_reference=1, recon_file=recon_file, loop_filter=1), B.EncdecFlags()
+            assert lib.svt_hip_encdec_flags_derive(C.byref(c), C.byref(fl)) == 0
+            o = M.oracle_intra_chain(src, lf, q_index, fl, thr)
+            recs[k] = o["rec"]
+            outs[k] = dict(intra=True, o=o, flags=fl, layer=0)
             continue
         p = B.me_params_derive(pic_width=W, pic_height=H, enc_mode=enc_mode, tune=tune, frame_rate=60, num_ref_lists=nl, temporal_layer_index=layer,
                                hierarchical_levels=lv, is_used_as_reference=used, same_ref_poc=int(nl == 2 and r0 == r1))
@@ -249,7 +273,7 @@ def oracle_clip(frames, W, H, N, enc_mode, tune, qp, recon_file, intra_period, u
     return recs, outs
 
 
-@pytest.mark.parametrize("use_callback,N,intra_period", [(False, 36, -1), (True, 36, -1), (False, 34, 19)])
+@pytest.mark.parametrize("use_callback,N,intra_period", [(False, 36, -1), (True, 36, -1), (False, 34, 19), (True, 34, 19)])
 def test_get_recon_equals_the_oracle_chain(use_callback, N, intra_period):
     W, H, enc_mode, tune, qp = 256, 192, 8, 1, 40
     frames, recon, order, flags_seen, packets, infos, refpics, seen = run_clip(W, H, N, enc_mode, tune, qp, 1, intra_period, use_callback)
@@ -272,20 +296,23 @@ def test_get_recon_equals_the_oracle_chain(use_callback, N, intra_period):
     n_cb = 0
     for k, d in infos.items():
         i = d["info"]
-        if outs[k]["intra"]:
-            assert i.is_intra and i.intra_recon_is_source and i.decision_source == 2
-            continue
         o = outs[k]["o"]
+        if outs[k]["intra"]:
+            assert i.is_intra and not i.intra_recon_is_source and i.decision_source == (1 if use_callback and k % 7 != 3 else 0)
+            assert (i.do_recon, i.apply_loop_filter, i.pad_reference) == (1, 1, 1)
+            assert d["lf"].tobytes() == o["lf_mi"].tobytes() and np.array_equal(d["q"], o["qcoeff"]) and np.array_equal(d["em"], o["eob_map"]), k
+            assert not d["mc"].view(np.uint8).any()
+            continue
         assert (i.do_recon, i.apply_loop_filter, i.pad_reference) == (outs[k]["flags"].do_recon, outs[k]["flags"].apply_loop_filter, outs[k]["flags"].pad_reference)
         assert i.decision_source == (1 if use_callback and k % 7 != 3 else 0)
         n_cb += i.decision_source == 1
         assert d["mc"].tobytes() == outs[k]["mc"].tobytes() and d["lf"].tobytes() == o["lf_mi"].tobytes(), k      # incl. the skip flags
         assert np.array_equal(d["q"], o["qcoeff"]) and np.array_equal(d["em"], o["eob_map"]), k
     if use_callback:
-        assert n_cb >= 10 and sorted(seen) == sorted(k for k in range(N) if not outs[k]["intra"])
+        assert n_cb >= 10 and sorted(seen) == list(range(N))                                        # once per picture, intra pictures included
     # the loop is closed: a picture predicted from reconstructions differs from one predicted from sources
-    deblocked = [k for k in range(N) if not outs[k]["intra"] and outs[k]["flags"].apply_loop_filter]
-    assert deblocked and len(deblocked) == N - sum(1 for k in range(N) if outs[k]["intra"])         # recon output on: every picture is deblocked
+    deblocked = [k for k in range(N) if outs[k]["flags"].apply_loop_filter]
+    assert len(deblocked) == N                                                                       # recon output on: every picture is deblocked
 
 
 @pytest.mark.parametrize("env,N,intra_period", [
