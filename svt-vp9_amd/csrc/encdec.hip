@@ -38,7 +38,7 @@ struct svt_encdec_work {
     int32_t      *d_totals, *d_bases; /* [4][max_pics]: blocks of a (size, picture) / its first block */
     int32_t      *d_off_cnt;     /* [8]: first block / number of blocks per size */
     int32_t      *d_status;      /* != 0: a malformed grid was seen */
-    int32_t      *d_intra_sync;  /* ticket, status and per-(plane, SB) flags of the intra kernel */
+    int32_t      *d_intra_sync;  /* ticket and per-(plane, 32x32 area) flags of the intra kernel: 2 + 3 * (at most 4 per SB) dwords */
     svt_quant_tables *d_qtabs;   /* [2] luma, chroma of the batch's q index */
     int16_t      *d_iscan;
     int           last_pics;
@@ -257,7 +257,7 @@ extern "C" int32_t svt_hip_encdec_work_create(svt_hip_ctx *ctx, int32_t max_pics
     const int16_t  *isc = svt_hip_vp9_iscan_tables(&offs, &entries);
     bool ok = hipMalloc((void **)&w->d_blocks, cap * sizeof(svt_tq_block)) == hipSuccess && hipMalloc((void **)&w->d_pos, cap * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&w->d_eob, cap * sizeof(uint16_t)) == hipSuccess &&
-              hipMalloc((void **)&w->d_counts, ((size_t)4 * max_pics * w->n_sb + 16 + 8 * ED_MAX_PICS + 4 + 3 * (size_t)w->n_sb) * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void **)&w->d_counts, ((size_t)4 * max_pics * w->n_sb + 16 + 8 * ED_MAX_PICS + 4 + 12 * (size_t)w->n_sb) * sizeof(int32_t)) == hipSuccess &&
               hipMalloc((void **)&w->d_qtabs, 2 * sizeof(svt_quant_tables)) == hipSuccess && hipMalloc((void **)&w->d_iscan, (size_t)entries * sizeof(int16_t)) == hipSuccess;
     if (ok) {
         w->d_off_cnt = w->d_counts + (size_t)4 * max_pics * w->n_sb;

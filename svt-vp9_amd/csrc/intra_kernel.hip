@@ -14,14 +14,16 @@
  * an intra picture whose dimensions are multiples of 8, without its 4x4 blocks: they never use the above-right neighbour --
  * have_right = 0, EbEncDecProcess.c:1146 -- and never cross the picture edge).
  *
- * Parallelism: a block needs the reconstruction of its left, above and above-left neighbours, so blocks of one SB are coded one
- * after the other (z-order) and SB (r, c) can start when (r, c - 1) and (r - 1, c) are done: an anti-diagonal wavefront over the
- * SBs, times three independent planes.  One 64-lane workgroup codes one (SB, plane); workgroups take TICKETS (an atomic counter)
- * that enumerate the (SB, plane) pairs diagonal by diagonal, so every workgroup only ever waits for tickets smaller than its own
- * -- which are held by workgroups that already run: no deadlock whatever the dispatch order, no co-residency requirement.
- * A block is N x N with N lanes active (lane i = row i of the prediction, then column / row i of the transform); the chain of
- * dependent blocks, not the lane count, bounds the speed: a 2160p key frame is 93 diagonals of at most 34 SBs.  This kernel is
- * latency-bound by design (one picture in a GOP); it shares the GPU with the batches of the inter pictures running beside it.
+ * Parallelism: a block needs the reconstruction of its left, above and above-left neighbours -- and nothing else: without the
+ * above-right neighbour the reference's z-order is only ONE of the orders that give its result.  The picture is cut into 32x32 luma
+ * areas (the largest block here); the blocks of an area are coded one after the other (z-order) and area (r, c) can start when
+ * (r, c - 1) and (r - 1, c) are done: an anti-diagonal wavefront over the areas, times three independent planes.  One 64-lane
+ * workgroup codes one (area, plane); workgroups take TICKETS (an atomic counter) that enumerate the (area, plane) pairs diagonal by
+ * diagonal, so every workgroup only ever waits for tickets smaller than its own -- which are held by workgroups that already run:
+ * no deadlock whatever the dispatch order, no co-residency requirement.  A block is N x N with N lanes active (lane i = row i of the
+ * prediction, then column / row i of the transform); the chain of dependent blocks, not the lane count, bounds the speed: a 2160p key
+ * frame is 187 diagonals of at most 68 areas.  This kernel is latency-bound by design (one picture in a GOP); it shares the GPU with
+ * the batches of the inter pictures running beside it.
  * Visibility between workgroups (other CUs, other XCDs' L2): release fence + flag store when an SB is done, flag load + acquire
  * fence before the first reference-sample load; inside a workgroup the block's stores are drained (workgroup fence) before the
  * next block reads them.
@@ -45,7 +47,7 @@ struct intra_pic_dev {
     int16_t       *qcoeff, *dqcoeff;
     uint16_t      *eob_map;
     uint8_t       *nz;
-    int32_t       *sync;    /* [0] ticket counter, [2 + plane * n_sb + sb] done flags; zeroed before the launch */
+    int32_t       *sync;    /* [0] ticket counter, [2 + plane * n_area + area] done flags (32x32 luma areas); zeroed before the launch */
     int32_t       *status;  /* |= 1: a malformed grid was seen */
 };
 
@@ -127,6 +129,15 @@ __device__ __forceinline__ int intra_block(const intra_pic_dev &P, int plane, in
     const int rs = P.rec_stride[c];
     uint8_t  *rp = P.rec[plane];
     const int have_left = x0 > 0, have_top = y0 > 0;
+    const bool active = lane < N;
+    const int  i = lane % N;
+    uint32_t   srow[N / 4], prow[N / 4];
+    constexpr uintptr_t AM = N >= 16 ? 15 : N - 1;
+    {   /* the source row does not depend on the neighbours: its load is issued first and completes under the reference-sample loads */
+        const uint8_t *sp = P.src[plane] + (size_t)(y0 + i) * P.src_stride[c] + x0;
+        _Pragma("unroll") for (int q = 0; q < N / 4; q++) srow[q] = 0u;
+        if (active) row_load<N>(sp, ((uintptr_t)sp & AM) == 0, srow);
+    }
     /* reference samples -> LDS (generate_intra_reference_samples, the paths of a block >= 8x8 inside the picture) */
     {
         const int j = lane & 31;
@@ -142,15 +153,8 @@ __device__ __forceinline__ int intra_block(const intra_pic_dev &P, int plane, in
         if (lane == 0) edge[32] = have_top ? (have_left ? rp[(size_t)(y0 - 1) * rs + x0 - 1] : (uint8_t)129) : (uint8_t)127;
     }
     __syncthreads();
-    const bool active = lane < N;
-    const int  i = lane % N;
-    uint32_t   srow[N / 4], prow[N / 4];
     intra_pred_row<N>(edge, mode, i, have_left, have_top, prow);
-    constexpr uintptr_t AM = N >= 16 ? 15 : N - 1;
     {
-        const uint8_t *sp = P.src[plane] + (size_t)(y0 + i) * P.src_stride[c] + x0;
-        _Pragma("unroll") for (int q = 0; q < N / 4; q++) srow[q] = 0u;
-        if (active) row_load<N>(sp, ((uintptr_t)sp & AM) == 0, srow);
         if (active && P.pred[plane]) {
             uint8_t *pp = P.pred[plane] + (size_t)(y0 + i) * P.pred_stride[c] + x0;
             row_store<N>(pp, ((uintptr_t)pp & AM) == 0, prow);
@@ -180,28 +184,32 @@ __global__ __launch_bounds__(64) void svt_intra_kernel(const intra_pic_dev P) {
     __shared__ int32_t tile[2 * 32 * 33];
     __shared__ uint8_t edge[128];
     __shared__ int32_t s_ticket;
-    const int lane = (int)threadIdx.x, n_sb = P.sb_cols * P.sb_rows;
+    /* the unit of scheduling is a 32x32 luma AREA (the largest block of this entry): four to a SB.  Intra prediction of blocks >= 8x8
+     * never reads the above-right neighbour, so any order in which a block follows its left, above and above-left neighbours gives the
+     * reference's result -- areas go in anti-diagonal order, the blocks of an area in z-order */
+    const int lane = (int)threadIdx.x, a_cols = (P.width + 31) >> 5, a_rows = (P.height + 31) >> 5, n_area = a_cols * a_rows;
     if (lane == 0) s_ticket = atomicAdd(&P.sync[0], 1);
     __syncthreads();
     const int ticket = s_ticket, plane = ticket % 3;
-    /* the n-th SB in anti-diagonal order (diagonal d = row + col, rows ascending inside a diagonal) */
-    int n = ticket / 3, sr = 0, sc = 0;
-    for (int d = 0; d < P.sb_rows + P.sb_cols - 1; d++) {
-        const int r_lo = d - (P.sb_cols - 1) > 0 ? d - (P.sb_cols - 1) : 0, r_hi = d < P.sb_rows - 1 ? d : P.sb_rows - 1, cnt = r_hi - r_lo + 1;
-        if (n < cnt) { sr = r_lo + n; sc = d - sr; break; }
+    /* the n-th area in anti-diagonal order (diagonal d = row + col, rows ascending inside a diagonal) */
+    int n = ticket / 3, ar = 0, ac = 0;
+    for (int d = 0; d < a_rows + a_cols - 1; d++) {
+        const int r_lo = d - (a_cols - 1) > 0 ? d - (a_cols - 1) : 0, r_hi = d < a_rows - 1 ? d : a_rows - 1, cnt = r_hi - r_lo + 1;
+        if (n < cnt) { ar = r_lo + n; ac = d - ar; break; }
         n -= cnt;
     }
-    const int sb = sr * P.sb_cols + sc;
-    int32_t  *done = P.sync + 2 + plane * n_sb;
+    const int area = ar * a_cols + ac;
+    int32_t  *done = P.sync + 2 + plane * n_area;
     if (lane == 0) {
-        if (sc > 0) while (__hip_atomic_load(&done[sb - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
-        if (sr > 0) while (__hip_atomic_load(&done[sb - P.sb_cols], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+        if (ac > 0) while (__hip_atomic_load(&done[area - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
+        if (ar > 0) while (__hip_atomic_load(&done[area - a_cols], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    for (int z = 0; z < 64; z++) {
-        const int r = ((z >> 1) & 1) | ((z >> 3) & 1) << 1 | ((z >> 5) & 1) << 2, c = (z & 1) | ((z >> 2) & 1) << 1 | ((z >> 4) & 1) << 2;
-        const int ur = sr * 8 + r, uc = sc * 8 + c;
+    const int sb = (ar >> 1) * P.sb_cols + (ac >> 1);
+    for (int z = 0; z < 16; z++) {
+        const int r = ((z >> 1) & 1) | ((z >> 3) & 1) << 1, c = (z & 1) | ((z >> 2) & 1) << 1;
+        const int ur = ar * 4 + r, uc = ac * 4 + c;
         if (ur >= P.mi_rows || uc >= P.mi_cols) continue;
         const svt_lf_mode_info b = P.mi[ur * P.mi_stride + uc];
         const int w8 = b.sb_type == 3 ? 1 : b.sb_type == 6 ? 2 : b.sb_type == 9 ? 4 : 0;
@@ -217,10 +225,10 @@ __global__ __launch_bounds__(64) void svt_intra_kernel(const intra_pic_dev P) {
         else eob = intra_block<4>(P, plane, x0, y0, mode, sb, tile, edge);
         if (eob && lane == 0) P.nz[ur * P.mi_stride + uc] = 1; /* the three planes of a block may all store the same 1 */
     }
-    /* publish the SB: its reconstruction reaches memory before the flag does */
+    /* publish the area: its reconstruction reaches memory before the flag does */
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    if (lane == 0) __hip_atomic_store(&done[sb], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(&done[area], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 /* stand-in decision for an intra picture (no claim of coding efficiency; the public API's callback replaces it): 16x16 blocks with
@@ -254,9 +262,9 @@ int32_t svt_intra_launch(svt_hip_ctx *ctx, const svt_encdec_picture *p, int32_t 
     P.qtabs = d_qtabs; P.iscan = d_iscan;
     for (int i = 0; i < 16; i++) P.iscan_off[i] = iscan_off[i];
     P.qcoeff = p->d_qcoeff; P.dqcoeff = p->d_dqcoeff; P.eob_map = p->d_eob_map; P.nz = p->d_nz; P.sync = d_sync; P.status = d_status;
-    const int n_sb = P.sb_cols * P.sb_rows;
-    HIP_TRY(hipMemsetAsync(d_sync, 0, (size_t)(2 + 3 * n_sb) * sizeof(int32_t), ctx->stream));
-    hipLaunchKernelGGL(svt_intra_kernel, dim3(3 * n_sb), dim3(64), 0, ctx->stream, P);
+    const int n_area = ((width + 31) >> 5) * ((height + 31) >> 5);
+    HIP_TRY(hipMemsetAsync(d_sync, 0, (size_t)(2 + 3 * n_area) * sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(svt_intra_kernel, dim3(3 * n_area), dim3(64), 0, ctx->stream, P);
     HIP_TRY(hipGetLastError());
     return SVT_HIP_OK;
 }
