@@ -75,6 +75,10 @@ typedef struct shim_slot { /* one buffered picture, everything device resident *
     int            processed;   /* its ME (or, for an intra picture, its analysis) has been enqueued */
     int            coded;       /* the stages behind mode decision have been enqueued */
     int            has_marker;
+    uint64_t       release;      /* marker of the main context after which nothing enqueued so far reads this slot's buffers */
+    int            has_release;
+    uint64_t       out_marker;   /* ctx_out: the device-to-host copy of this slot's reconstruction */
+    int            has_out;
     int            is_copy;     /* split-GOP mode: the base picture of the previous mini-GOP, handed over from the device that coded it
                                    (analysed planes + reference picture only) */
     uint64_t       marker;      /* completion of everything enqueued for this picture so far */
@@ -83,6 +87,13 @@ typedef struct shim_slot { /* one buffered picture, everything device resident *
 
 typedef struct shim_dev {
     svt_hip_ctx     *ctx;
+    /* input side: uploads and picture analysis run on a context (stream) of their own, so that the pictures of mini-GOP k + 1 cross
+       PCIe while the stages of mini-GOP k compute; the two sides meet through markers (svt_hip_ctx_wait_marker, no host wait).
+       SVT_HIP_SINGLE_STREAM=1 makes it the main context again (everything in one stream, as in round 3). */
+    svt_hip_ctx     *ctx_in;
+    uint64_t         in_marker;      /* ctx_in: the latest picture's upload + analysis */
+    int              has_in;
+    svt_hip_ctx     *ctx_out;        /* output side: the reconstructions' device-to-host copies (recon_file), behind the main stream's markers */
     int              ordinal;
     int              n_slots;
     shim_slot       *slot;
@@ -251,6 +262,9 @@ static void free_dev(shim_state *s, shim_dev *d) {
     while (d->free_recon) { shim_recon *r = d->free_recon; d->free_recon = r->next; svt_hip_host_free(d->ctx, r->host); free(r); }
     if (d->work) svt_hip_encdec_work_destroy(d->ctx, d->work);
     d->work = NULL;
+    if (d->ctx_in && d->ctx_in != d->ctx) svt_hip_ctx_destroy(d->ctx_in);
+    if (d->ctx_out && d->ctx_out != d->ctx) svt_hip_ctx_destroy(d->ctx_out);
+    d->ctx_in = d->ctx_out = NULL;
     svt_hip_ctx_destroy(d->ctx);
     d->ctx = NULL;
     (void)s;
@@ -303,8 +317,8 @@ static int alloc_dev(shim_state *s, shim_dev *d) {
                  not): one throw-away upload per buffer of the ring */
         uint8_t *z = (uint8_t *)calloc((size_t)W, (size_t)H);
         if (z) {
-            for (int i = 0; i < 4; i++) (void)svt_hip_mem_upload_2d_async(d->ctx, d->slot[0].d_src, (size_t)W, z, (size_t)W, (size_t)W, (size_t)H);
-            (void)svt_hip_ctx_synchronize(d->ctx);
+            for (int i = 0; i < 4; i++) (void)svt_hip_mem_upload_2d_async(d->ctx_in, d->slot[0].d_src, (size_t)W, z, (size_t)W, (size_t)W, (size_t)H);
+            (void)svt_hip_ctx_synchronize(d->ctx_in);
             free(z);
         }
     }
@@ -347,6 +361,12 @@ EbErrorType eb_vp9_init_encoder(EbComponentType *h) {
         d->ordinal = ord[i];
         int ok = svt_hip_ctx_create(&d->ctx, ord[i]) == SVT_HIP_OK;
         if (!ok) { fprintf(stderr, "SvtVp9Enc (GPU hot path): %s\n", svt_hip_last_error()); d->ctx = NULL; }
+        if (ok) {
+            const char *one = getenv("SVT_HIP_SINGLE_STREAM");
+            if (one && atoi(one) != 0) d->ctx_in = d->ctx_out = d->ctx;
+            else if (svt_hip_ctx_create(&d->ctx_in, ord[i]) != SVT_HIP_OK) { d->ctx_in = NULL; ok = 0; }
+            else if (svt_hip_ctx_create(&d->ctx_out, ord[i]) != SVT_HIP_OK) { d->ctx_out = NULL; ok = 0; }
+        }
         ok = ok && alloc_dev(s, d);
         if (!ok) { /* nothing half-initialised is left behind: the handle is back in its configured state */
             for (int k = 0; k <= i; k++) free_dev(s, &s->dev[k]);
@@ -383,6 +403,12 @@ static shim_slot *find_any(shim_state *s, int64_t number, shim_dev **dev) { /* t
     return NULL;
 }
 
+/* everything enqueued on the main context from here on sees the pictures uploaded and analysed so far */
+static EbErrorType sync_inputs(shim_state *s, shim_dev *d) {
+    if (d->has_in && d->ctx_in != d->ctx) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx, d->ctx_in, d->in_marker));
+    return EB_ErrorNone;
+}
+
 /* split-GOP mode: the next mini-GOP is coded on device `to`; it predicts from the base picture the current device has just
  * finished -- its analysed planes (motion estimation) and its padded reconstruction (inter prediction) travel device to device,
  * ordered behind the producer's work and in front of the consumer's (svt_hip_ref_handoff_device) */
@@ -391,6 +417,8 @@ static EbErrorType handoff_base(shim_state *s, shim_dev *from, shim_dev *to, int
     if (!a) return EB_ErrorBadParameter;
     shim_slot *b = &to->slot[to->accepted % to->n_slots];
     if (b->has_marker) GPU_TRY(svt_hip_ctx_marker_wait(to->ctx, b->marker));
+    if (b->has_out && to->ctx_out != to->ctx) GPU_TRY(svt_hip_ctx_wait_marker(to->ctx, to->ctx_out, b->out_marker)); /* its old reconstruction may still be on its way out */
+    b->has_out = 0;
     const svt_plane *pa[3] = {&a->pa.full, &a->pa.quarter, &a->pa.sixteenth}, *pb[3] = {&b->pa.full, &b->pa.quarter, &b->pa.sixteenth};
     for (int k = 0; k < 3; k++)
         GPU_TRY(svt_hip_ref_handoff_device(from->ctx, pa[k]->buf, to->ctx, (void *)pb[k]->buf, (size_t)pa[k]->stride * (size_t)(pa[k]->height + 2 * pa[k]->origin_y)));
@@ -399,6 +427,7 @@ static EbErrorType handoff_base(shim_state *s, shim_dev *from, shim_dev *to, int
     b->number = number; b->pts = a->pts; b->info = a->info; b->processed = 1; b->coded = 1; b->is_copy = 1;
     GPU_TRY(svt_hip_ctx_marker_record(to->ctx, &b->marker));
     b->has_marker = 1;
+    b->release = b->marker; b->has_release = 1;
     return EB_ErrorNone;
 }
 
@@ -448,13 +477,17 @@ static EbErrorType queue_recon(shim_state *s, shim_dev *d, shim_slot *t) {
     }
     const svt_yuv_planes p = rec_planes(s, t->d_rec);
     const size_t W = (size_t)s->W, H = (size_t)s->H;
-    if (svt_hip_mem_download_2d_async(d->ctx, r->host, W, p.y, (size_t)p.y_stride, W, H) != SVT_HIP_OK ||
-        svt_hip_mem_download_2d_async(d->ctx, r->host + W * H, W / 2, p.u, (size_t)p.uv_stride, W / 2, H / 2) != SVT_HIP_OK ||
-        svt_hip_mem_download_2d_async(d->ctx, r->host + W * H + W * H / 4, W / 2, p.v, (size_t)p.uv_stride, W / 2, H / 2) != SVT_HIP_OK ||
-        svt_hip_ctx_marker_record(d->ctx, &r->marker) != SVT_HIP_OK) {
+    /* the copy runs on the output stream, behind the main stream's work enqueued so far (the picture's deblocking / padding) */
+    uint64_t after = 0;
+    if ((d->ctx_out != d->ctx && (svt_hip_ctx_marker_record(d->ctx, &after) != SVT_HIP_OK || svt_hip_ctx_wait_marker(d->ctx_out, d->ctx, after) != SVT_HIP_OK)) ||
+        svt_hip_mem_download_2d_async(d->ctx_out, r->host, W, p.y, (size_t)p.y_stride, W, H) != SVT_HIP_OK ||
+        svt_hip_mem_download_2d_async(d->ctx_out, r->host + W * H, W / 2, p.u, (size_t)p.uv_stride, W / 2, H / 2) != SVT_HIP_OK ||
+        svt_hip_mem_download_2d_async(d->ctx_out, r->host + W * H + W * H / 4, W / 2, p.v, (size_t)p.uv_stride, W / 2, H / 2) != SVT_HIP_OK ||
+        svt_hip_ctx_marker_record(d->ctx_out, &r->marker) != SVT_HIP_OK) {
         r->next = d->free_recon; d->free_recon = r;
         return gpu_fail(s);
     }
+    t->out_marker = r->marker; t->has_out = 1;
     r->dev = (int)(d - s->dev); r->pts = t->number; r->flags = 0; r->next = NULL;
     if (s->r_tail) s->r_tail->next = r; else s->r_head = r;
     s->r_tail = r;
@@ -572,6 +605,7 @@ static EbErrorType encode_wave(shim_state *s, shim_dev *d, const shim_job *const
  * decides its blocks and modes when it wants to (info->is_intra = 1, no ME results); otherwise the stand-in (16x16, DC). */
 static EbErrorType encode_intra(shim_state *s, shim_dev *d, shim_slot *t) {
     svt_encdec_flags fl;
+    { const EbErrorType e = sync_inputs(s, d); if (e != EB_ErrorNone) return e; }
     {
         svt_encdec_flags_config fc;
         fc.enc_mode = s->cfg.enc_mode; fc.tune = s->cfg.tune; fc.temporal_layer_index = 0; fc.is_used_as_reference = 1;
@@ -614,6 +648,7 @@ static EbErrorType encode_intra(shim_state *s, shim_dev *d, shim_slot *t) {
 static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_stream) {
     if (!s->pending) return EB_ErrorNone;
     shim_dev *d = &s->dev[s->cur_dev];
+    { const EbErrorType e = sync_inputs(s, d); if (e != EB_ErrorNone) return e; }
     shim_job jobs[SHIM_MAX_MINIGOP];
     int      n = 0, n_waves = 0;
     const int64_t first = s->pending_first;
@@ -717,6 +752,17 @@ static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_str
         if (e != EB_ErrorNone) return e;
         s->cur_dev = next;
     }
+    /* from this point of the main stream on nothing enqueued so far reads the group's pictures or the pictures it predicted from: the
+       input side may overwrite their slots behind it */
+    uint64_t end_marker = 0;
+    GPU_TRY(svt_hip_ctx_marker_record(d->ctx, &end_marker));
+    for (int i = 0; i < n; i++) {
+        const int64_t who[3] = {jobs[i].number, jobs[i].ref0, jobs[i].n_lists == 2 ? jobs[i].ref1 : -1};
+        for (int k = 0; k < 3; k++) {
+            shim_slot *t = who[k] >= 0 ? find_slot(d, who[k]) : NULL;
+            if (t) { t->release = end_marker; t->has_release = 1; }
+        }
+    }
     return EB_ErrorNone;
 }
 
@@ -741,25 +787,30 @@ EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *
         }
         shim_dev  *d = &s->dev[s->cur_dev];
         shim_slot *t = &d->slot[d->accepted % d->n_slots];
-        /* the slot's previous picture (2 mini-GOPs + 2 ago on this device) must have left the GPU: the one place send_picture can
-           block, as the reference blocks when its picture pool is exhausted */
-        if (t->has_marker) GPU_TRY(svt_hip_ctx_marker_wait(d->ctx, t->marker));
+        /* the slot's previous picture (2 mini-GOPs + 2 ago on this device) must have left the GPU before its buffers are overwritten:
+           the input stream waits for the main stream's marker behind its last reader (a device-side wait; the host blocks only in
+           the staging ring of the upload below, as the reference blocks when its picture pool is exhausted) */
+        if (t->has_release) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_in, d->ctx, t->release));
+        else if (t->has_marker) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_in, d->ctx, t->marker));
+        if (t->has_out && d->ctx_out != d->ctx_in) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_in, d->ctx_out, t->out_marker));
         /* the copy the reference makes in copy_frame_buffer (:2743-2796), into pinned staging: the caller's planes are free again
            on return; the transfer and the analysis below run asynchronously */
         const svt_yuv_planes sp = tight_planes(s, t->d_src);
-        GPU_TRY(svt_hip_mem_upload_2d_async(d->ctx, sp.y, (size_t)W, in->luma, in->y_stride, (size_t)W, (size_t)H));
-        if (in->cb) GPU_TRY(svt_hip_mem_upload_2d_async(d->ctx, sp.u, (size_t)W / 2, in->cb, in->cb_stride, (size_t)W / 2, (size_t)H / 2));
-        else GPU_TRY(svt_hip_mem_set(d->ctx, sp.u, 128, (size_t)(W / 2) * (H / 2)));
-        if (in->cr) GPU_TRY(svt_hip_mem_upload_2d_async(d->ctx, sp.v, (size_t)W / 2, in->cr, in->cr_stride, (size_t)W / 2, (size_t)H / 2));
-        else GPU_TRY(svt_hip_mem_set(d->ctx, sp.v, 128, (size_t)(W / 2) * (H / 2)));
+        GPU_TRY(svt_hip_mem_upload_2d_async(d->ctx_in, sp.y, (size_t)W, in->luma, in->y_stride, (size_t)W, (size_t)H));
+        if (in->cb) GPU_TRY(svt_hip_mem_upload_2d_async(d->ctx_in, sp.u, (size_t)W / 2, in->cb, in->cb_stride, (size_t)W / 2, (size_t)H / 2));
+        else GPU_TRY(svt_hip_mem_set(d->ctx_in, sp.u, 128, (size_t)(W / 2) * (H / 2)));
+        if (in->cr) GPU_TRY(svt_hip_mem_upload_2d_async(d->ctx_in, sp.v, (size_t)W / 2, in->cr, in->cr_stride, (size_t)W / 2, (size_t)H / 2));
+        else GPU_TRY(svt_hip_mem_set(d->ctx_in, sp.v, 128, (size_t)(W / 2) * (H / 2)));
         const uint8_t *lum = sp.y;
         const int32_t  stride = W;
-        GPU_TRY(svt_hip_pa_prepare_batch_device(d->ctx, 1, &lum, &stride, &t->pa, 1));
-        GPU_TRY(svt_hip_pa_mean_variance_device(d->ctx, &t->pa.full, (uint8_t *)t->d_mean, (uint16_t *)t->d_var));
+        GPU_TRY(svt_hip_pa_prepare_batch_device(d->ctx_in, 1, &lum, &stride, &t->pa, 1));
+        GPU_TRY(svt_hip_pa_mean_variance_device(d->ctx_in, &t->pa.full, (uint8_t *)t->d_mean, (uint16_t *)t->d_var));
+        GPU_TRY(svt_hip_ctx_marker_record(d->ctx_in, &d->in_marker));
+        d->has_in = 1;
         /* the picture is accepted from here on */
         s->next_number = n + 1;
         d->accepted++;
-        t->number = n; t->pts = b->pts; t->processed = 0; t->coded = 0; t->has_marker = 0; t->is_copy = 0;
+        t->number = n; t->pts = b->pts; t->processed = 0; t->coded = 0; t->has_marker = 0; t->has_release = 0; t->has_out = 0; t->is_copy = 0;
         memset(&t->info, 0, sizeof t->info);
         t->info.picture_number = (uint64_t)n; t->info.n_sb = (uint32_t)s->n_sb; t->info.device_ordinal = d->ordinal;
         if (intra) {
@@ -768,6 +819,7 @@ EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *
             if ((e = encode_intra(s, d, t)) != EB_ErrorNone) return e;
             GPU_TRY(svt_hip_ctx_marker_record(d->ctx, &t->marker));
             t->has_marker = 1; t->processed = 1;
+            t->release = t->marker; t->has_release = 1;
             if (push_packet(s, t->pts, 0, 2 /* EB_I_PICTURE */, s->cur_dev, t->marker)) return EB_ErrorInsufficientResources;
             s->last_base = n;
         } else {
@@ -838,7 +890,7 @@ EbErrorType eb_vp9_svt_get_recon(EbComponentType *h, EbBufferHeaderType *p_buffe
     if (!r || !p_buffer) return EB_NoErrorEmptyQueue;
     if (r == s->r_tail && !s->eos) return EB_NoErrorEmptyQueue; /* as for packets: the last reconstruction carries EB_BUFFERFLAG_EOS */
     shim_dev *d = &s->dev[r->dev];
-    const int32_t q = svt_hip_ctx_marker_query(d->ctx, r->marker);
+    const int32_t q = svt_hip_ctx_marker_query(d->ctx_out, r->marker);
     if (q < 0) return gpu_fail(s);
     if (q == 0) return EB_NoErrorEmptyQueue;
     if (p_buffer->p_buffer) {
