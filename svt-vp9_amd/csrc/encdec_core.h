@@ -111,22 +111,32 @@ SVT_HD void svt_lf_mask_unit(const svt_lf_mode_info *mi, int mi_stride, int mi_r
     const int with_uv = !(r & 1) && !(c & 1);   /* first 8x8 of a 16x16 area carries the chroma edges */
     const int txy = b->tx_size, txuv = svt_uv_tx_size(b->sb_type, txy);
     const int wuv = (w8 + 1) >> 1, huv = (h8 + 1) >> 1;
+    /* the block's words are gathered in scalars and go to the entry of their transform size with CONSTANT indices at the end: an
+       array indexed by a run-time value lives in private memory on the device (the first version of the mask kernel wrote 290 MB of
+       scratch per mini-GOP that way) */
+    uint64_t ay, ly;
+    uint32_t auv = 0, luv = 0;
     /* prediction block edges */
-    m->above_y[txy] |= svt_rect_mask(w8, 1, 8) << shift_y;
-    m->left_y[txy] |= svt_rect_mask(1, h8, 8) << shift_y;
+    ay = svt_rect_mask(w8, 1, 8) << shift_y;
+    ly = svt_rect_mask(1, h8, 8) << shift_y;
     if (with_uv) {
-        m->above_uv[txuv] |= (uint16_t)(svt_rect_mask(wuv, 1, 4) << shift_uv);
-        m->left_uv[txuv] |= (uint16_t)(svt_rect_mask(1, huv, 4) << shift_uv);
+        auv = (uint32_t)(svt_rect_mask(wuv, 1, 4) << shift_uv);
+        luv = (uint32_t)(svt_rect_mask(1, huv, 4) << shift_uv);
     }
-    if (b->skip && b->is_inter) return; /* no residual, inter: only the block's own border */
-    /* transform edges inside the block, and the inner 4x4 edges */
-    m->above_y[txy] |= (svt_rect_mask(w8, h8, 8) & svt_tx_edge_mask(txy, 0, 8, 8)) << shift_y;
-    m->left_y[txy] |= (svt_rect_mask(w8, h8, 8) & svt_tx_edge_mask(txy, 1, 8, 8)) << shift_y;
-    if (txy == 0) m->int_4x4_y |= svt_rect_mask(w8, h8, 8) << shift_y;
-    if (with_uv) {
-        m->above_uv[txuv] |= (uint16_t)((svt_rect_mask(wuv, huv, 4) & svt_tx_edge_mask(txuv, 0, 4, 4)) << shift_uv);
-        m->left_uv[txuv] |= (uint16_t)((svt_rect_mask(wuv, huv, 4) & svt_tx_edge_mask(txuv, 1, 4, 4)) << shift_uv);
-        if (txuv == 0) m->int_4x4_uv |= (uint16_t)(svt_rect_mask(wuv, huv, 4) << shift_uv);
+    if (!(b->skip && b->is_inter)) { /* (no residual, inter: only the block's own border) */
+        /* transform edges inside the block, and the inner 4x4 edges */
+        ay |= (svt_rect_mask(w8, h8, 8) & svt_tx_edge_mask(txy, 0, 8, 8)) << shift_y;
+        ly |= (svt_rect_mask(w8, h8, 8) & svt_tx_edge_mask(txy, 1, 8, 8)) << shift_y;
+        if (txy == 0) m->int_4x4_y |= svt_rect_mask(w8, h8, 8) << shift_y;
+        if (with_uv) {
+            auv |= (uint32_t)((svt_rect_mask(wuv, huv, 4) & svt_tx_edge_mask(txuv, 0, 4, 4)) << shift_uv);
+            luv |= (uint32_t)((svt_rect_mask(wuv, huv, 4) & svt_tx_edge_mask(txuv, 1, 4, 4)) << shift_uv);
+            if (txuv == 0) m->int_4x4_uv |= (uint16_t)(svt_rect_mask(wuv, huv, 4) << shift_uv);
+        }
+    }
+    for (int i = 0; i < 4; i++) {
+        m->above_y[i] = i == txy ? ay : 0; m->left_y[i] = i == txy ? ly : 0;
+        m->above_uv[i] = (uint16_t)(i == txuv ? auv : 0); m->left_uv[i] = (uint16_t)(i == txuv ? luv : 0);
     }
 }
 

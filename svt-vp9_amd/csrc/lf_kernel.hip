@@ -425,7 +425,7 @@ __global__ __launch_bounds__(128) void svt_lf_desc_kernel(const lf_pic_dev *__re
  *   wave 3  writes the finished columns of the tile filtered in the previous step back and publishes the row's progress.
  * One workgroup barrier per SB; wave 2 lets its loads fly while wave 3 is still reading the buffer they will land in.  Tile rows 0-7 (top halo) and the SB's last 8 rows are seam rows (sc1 accesses). */
 template <bool early> /* latency mode (launches of few pictures): seam rows are handed to the SB row below early, see step (c) */
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void svt_lf_kernel(const lf_pic_dev *__restrict__ pics, int n_pics,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void svt_lf_kernel(const lf_pic_dev *__restrict__ pics, int n_pics,
                                                      uint32_t *__restrict__ ticket, int rows_per_pic, int prof) {
     __shared__ __align__(16) uint8_t ytile[2][YROWS * YS];
     __shared__ __align__(16) uint8_t ctile[2][2][CROWS * CS];

@@ -27,6 +27,8 @@ with tempfile.TemporaryDirectory() as td:
     for recon in (0, 1):
         for single in ("1", "0", "1", "0"):
             env = dict(os.environ, SVT_HIP_SINGLE_STREAM=single)
+            if len(sys.argv) > 2:
+                env["SVT_HIP_COPY_THREADS"] = sys.argv[2]
             r = subprocess.run([exe, path, str(W), str(H), str(n_frames), str(n_send), "8", "1", str(recon)], capture_output=True, text=True, env=env)
             d = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stdout + r.stderr)[-300:]}
             print("recon", recon, "single_stream", single, d.get("frames_per_s"), d.get("seconds"), d.get("error", ""), flush=True)
