@@ -713,6 +713,10 @@ typedef struct svt_encdec_picture {
     int32_t                 use_subpel; /* svt_mc_picture.use_subpel */
     int32_t                 no_pad;    /* 1: this picture is not padded although the batch's flags say pad_reference (a picture that is not
                                           used as a reference riding in a batch of reference pictures) */
+    int32_t                 has_intra; /* 1: the grid holds intra blocks (is_inter = 0; sizes / modes as for svt_hip_encdec_intra_device): they are
+                                          coded by the intra pass behind the batch's transform stage, from their neighbours' reconstruction
+                                          (needs the flags' do_recon).  0: every block is inter; an intra block would be left uncoded */
+    int32_t                 pad_;
 } svt_encdec_picture;
 
 /* workspace of a batch: descriptor lists, per-list eob, counters (device memory owned by the object); sized for max_pics pictures

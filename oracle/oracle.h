@@ -65,5 +65,5 @@ void    svt_oracle_intra_predict(int32_t mode, int32_t bs, int32_t have_left, in
 void    svt_oracle_intra_ref_samples(const uint8_t *plane, int32_t stride, int32_t x0, int32_t y0, int32_t bs, uint8_t *above_row, uint8_t *left_col);
 int32_t svt_oracle_intra_picture(const uint8_t *src, uint8_t *pred, uint8_t *recon_buf, const uint32_t recon_off[3], const int32_t recon_stride[2],
                                  const svt_lf_mode_info *mi, int32_t mi_stride, int32_t width, int32_t height, const svt_quant_tables qt[2],
-                                 const int16_t *iscan, const uint32_t iscan_off[16], int16_t *qcoeff, int16_t *dqcoeff, uint16_t *eob_map);
+                                 const int16_t *iscan, const uint32_t iscan_off[16], int16_t *qcoeff, int16_t *dqcoeff, uint16_t *eob_map, int32_t mixed);
 #endif

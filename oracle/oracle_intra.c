@@ -202,10 +202,13 @@ static uint32_t zorder4(int x4, int y4) {
  * lives in recon_buf at recon_off[plane] with recon_stride[plane != 0].  mi: one record per 8x8 unit (sb_type 3 / 6 / 9, tx_size =
  * the block's own size, is_inter 0, pad_[1] = luma mode, pad_[2] = chroma mode).  qcoeff / dqcoeff: the product's position-addressed
  * layout (6144 per SB: luma 4096, Cb 1024, Cr 1024, 4x4 units in z-order); eob_map: one entry per 4x4 unit, Y then U then V planes,
- * written at the block's first unit.  iscan_off[tx_size * 4 + tx_type].  Returns 0, or -1 for a grid outside this restatement. */
+ * written at the block's first unit.  iscan_off[tx_size * 4 + tx_type].  mixed: the picture is an inter picture whose inter blocks have
+ * been reconstructed into recon_buf already (any block shape); only its intra blocks are coded, in the same order -- every intra block
+ * then sees what the reference's neighbour arrays hold: the unfiltered reconstruction of the blocks coded before it, inter or intra
+ * (encode_pass_sb writes them after every block, EbEncDecProcess.c:4110-4160).  Returns 0, or -1 for a grid outside this restatement. */
 int32_t svt_oracle_intra_picture(const uint8_t *src, uint8_t *pred, uint8_t *recon_buf, const uint32_t recon_off[3], const int32_t recon_stride[2],
                                  const svt_lf_mode_info *mi, int32_t mi_stride, int32_t width, int32_t height, const svt_quant_tables qt[2],
-                                 const int16_t *iscan, const uint32_t iscan_off[16], int16_t *qcoeff, int16_t *dqcoeff, uint16_t *eob_map) {
+                                 const int16_t *iscan, const uint32_t iscan_off[16], int16_t *qcoeff, int16_t *dqcoeff, uint16_t *eob_map, int32_t mixed) {
     const int mi_rows = height >> 3, mi_cols = width >> 3, sb_cols = (width + 63) >> 6, sb_rows = (height + 63) >> 6;
     const size_t po[3] = {0, (size_t)width * height, (size_t)width * height + (size_t)(width / 2) * (height / 2)};
     const size_t eo[3] = {0, (size_t)(width / 4) * (height / 4), (size_t)(width / 4) * (height / 4) + (size_t)(width / 8) * (height / 8)};
@@ -217,6 +220,7 @@ int32_t svt_oracle_intra_picture(const uint8_t *src, uint8_t *pred, uint8_t *rec
                 const int ur = sr * 8 + r, uc = sc * 8 + c;
                 if (ur >= mi_rows || uc >= mi_cols) continue;
                 const svt_lf_mode_info *b = &mi[ur * mi_stride + uc];
+                if (b->is_inter && mixed) continue; /* an inter picture with intra blocks: the inter blocks are reconstructed already */
                 if (b->is_inter || (b->sb_type != 3 && b->sb_type != 6 && b->sb_type != 9)) return -1;
                 const int w8 = 1 << ((b->sb_type - 3) / 3);
                 if ((ur % w8) || (uc % w8)) continue;

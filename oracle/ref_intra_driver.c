@@ -15,8 +15,11 @@
  * filled field by field with the sizes eb_vp9_neighbor_array_unit_ctor derives from the arguments of Codec/EbPictureControlSet.c:168-200
  * (the constructor itself allocates through the encoder handle's memory map, which does not exist here).
  *
- * request : int32 magic 'SVIN', width, height, mi_stride, q_index; Y (W*H), U, V (W/2*H/2) tight source planes;
- *           mi_rows*mi_stride svt_lf_mode_info (sb_type 3 / 6 / 9, pad_[1] = luma mode, pad_[2] = chroma mode)
+ * request : int32 magic 'SVIN', width, height, mi_stride, q_index | mixed << 16; Y (W*H), U, V (W/2*H/2) tight source planes;
+ *           mi_rows*mi_stride svt_lf_mode_info (sb_type 3 / 6 / 9, pad_[1] = luma mode, pad_[2] = chroma mode);
+ *           mixed: + Y, U, V tight planes holding the reconstruction of the picture's INTER blocks (square, 8x8 .. 64x64): an inter
+ *           block is not coded here, its reconstruction goes to the neighbour arrays when its turn comes, as encode_pass_sb does after
+ *           every block -- what the intra blocks of an inter picture then predict from is the reference's own bookkeeping
  * response: pred Y, U, V; recon Y, U, V (tight); qcoeff, dqcoeff (n_sb * 6144 int16 each, the product's position layout);
  *           eob map (uint16 per 4x4 unit: Y, U, V)
  */
@@ -74,7 +77,7 @@ int main(int argc, char **argv) {
     if (!f) return 2;
     int32_t h[5];
     if (rd(f, h, sizeof h) || h[0] != 0x4E495653) return 3; /* 'SVIN' */
-    const int W = h[1], H = h[2], mi_stride = h[3], q_index = h[4];
+    const int W = h[1], H = h[2], mi_stride = h[3], q_index = h[4] & 0xffff, mixed = (h[4] >> 16) & 1;
     const int mi_rows = H / 8, mi_cols = W / 8, sb_cols = (W + 63) / 64, sb_rows = (H + 63) / 64, n_sb = sb_cols * sb_rows;
     const size_t ny = (size_t)W * H, nc = ny / 4;
     uint8_t *src[3] = {malloc(ny), malloc(nc), malloc(nc)}, *pred[3] = {calloc(ny, 1), calloc(nc, 1), calloc(nc, 1)}, *rec[3] = {calloc(ny, 1), calloc(nc, 1), calloc(nc, 1)};
@@ -82,6 +85,7 @@ int main(int argc, char **argv) {
     const size_t      n = (size_t)mi_rows * mi_stride;
     svt_lf_mode_info *cells = (svt_lf_mode_info *)malloc(n * sizeof *cells);
     if (rd(f, cells, n * sizeof *cells)) return 3;
+    if (mixed && (rd(f, rec[0], ny) || rd(f, rec[1], nc) || rd(f, rec[2], nc))) return 3;
     fclose(f);
 
     setup_rtcd_internal(0);
@@ -123,9 +127,18 @@ int main(int argc, char **argv) {
                 if (x >= W || y >= H) continue;
                 const svt_lf_mode_info *b = &cells[(size_t)(y >> 3) * mi_stride + (x >> 3)];
                 const int sq = 8 * eb_vp9_num_8x8_blocks_wide_lookup[b->sb_type];
-                if (b->sb_type > BLOCK_32X32 || eb_vp9_num_8x8_blocks_high_lookup[b->sb_type] * 8 != sq) return 5;
+                if (b->sb_type > BLOCK_64X64 || eb_vp9_num_8x8_blocks_high_lookup[b->sb_type] * 8 != sq) return 5;
                 if ((x % sq) || (y % sq)) continue; /* not the block's first unit */
                 if (x + sq > W || y + sq > H) return 5;
+                if (mixed && b->is_inter) { /* coded elsewhere: only the bookkeeping of :4110-4160 */
+                    for (int p = 0; p < 3; p++) {
+                        const int ss = p ? 1 : 0, ps = p ? W / 2 : W, bs = sq >> ss;
+                        eb_vp9_neighbor_array_unit_sample_write(na[p], rec[p], (uint32_t)ps, (uint32_t)(x >> ss), (uint32_t)(y >> ss), (uint32_t)(x >> ss),
+                                                                (uint32_t)(y >> ss), (uint32_t)bs, (uint32_t)bs, NEIGHBOR_ARRAY_UNIT_FULL_MASK);
+                    }
+                    continue;
+                }
+                if (b->sb_type > BLOCK_32X32 || b->is_inter) return 5;
                 EpBlockStats stv;
                 memset(&stv, 0, sizeof stv);
                 stv.sq_size = sq; stv.sq_size_uv = MAX(sq >> 1, 4); stv.shape = PART_N;

@@ -141,7 +141,7 @@ class EncdecFlags(C.Structure):
 class EncdecPicture(C.Structure):
     _fields_ = [("d_mc_mi", C.c_void_p), ("d_lf_mi", C.c_void_p), ("src", YuvPlanes), ("ref", YuvPlanes * 2), ("pred", YuvPlanes), ("recon", YuvPlanes),
                 ("d_qcoeff", C.c_void_p), ("d_dqcoeff", C.c_void_p), ("d_eob_map", C.c_void_p), ("d_lfm", C.c_void_p), ("d_nz", C.c_void_p),
-                ("use_subpel", C.c_int32), ("no_pad", C.c_int32)]
+                ("use_subpel", C.c_int32), ("no_pad", C.c_int32), ("has_intra", C.c_int32), ("pad_", C.c_int32)]
 
 
 SB_COEFFS = 6144

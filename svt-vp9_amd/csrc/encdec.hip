@@ -403,6 +403,14 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
     /* 4. eob map + skip flags (entries of the map that are not the origin of a transform block of THIS picture read 0) */
     ED_STAGE(SVT_ENCDEC_STAGE_SKIP);
     for (int i = 0; i < n_pics; i++) HIP_TRY(hipMemsetAsync(pics[i].d_eob_map, 0, (size_t)(width / 4) * (height / 4) * 3 / 2 * sizeof(uint16_t), ctx->stream));
+    /* 3b. intra blocks of inter pictures: their inter neighbours are reconstructed now; the wavefront kernel codes them, one picture
+           after the other (it writes their eob-map entries and coefficient flags itself) */
+    for (int i = 0; i < n_pics; i++)
+        if (pics[i].has_intra) {
+            if (!flags->do_recon) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: intra blocks need the reconstruction (do_recon)");
+            rc = svt_intra_launch(ctx, &pics[i], width, height, mi_stride, w->d_qtabs, w->d_iscan, hb.iscan_off, w->d_intra_sync, w->d_status, 1);
+            if (rc) return rc;
+        }
     {
         const int total_cap = (int)(w->cap_per_pic * (size_t)n_pics);
         int       g = (total_cap + 255) / 256;
@@ -469,7 +477,7 @@ extern "C" int32_t svt_hip_encdec_intra_device(svt_hip_ctx *ctx, svt_encdec_work
     ED_STAGE(SVT_ENCDEC_STAGE_TQ);
     HIP_TRY(hipMemsetAsync(p.d_eob_map, 0, (size_t)(width / 4) * (height / 4) * 3 / 2 * sizeof(uint16_t), ctx->stream));
     HIP_TRY(hipMemsetAsync(p.d_nz, 0, (size_t)mi_stride * hb.mi_rows, ctx->stream));
-    int32_t rc = svt_intra_launch(ctx, pic, width, height, mi_stride, w->d_qtabs, w->d_iscan, offs, w->d_intra_sync, w->d_status);
+    int32_t rc = svt_intra_launch(ctx, pic, width, height, mi_stride, w->d_qtabs, w->d_iscan, offs, w->d_intra_sync, w->d_status, 0);
     if (rc) return rc;
     ED_STAGE(SVT_ENCDEC_STAGE_SKIP);
     hipLaunchKernelGGL(svt_skip_update_kernel, dim3((hb.mi_rows * hb.mi_cols + 255) / 256), dim3(256), 0, ctx->stream, dB);

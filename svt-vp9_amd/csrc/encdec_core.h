@@ -198,9 +198,12 @@ SVT_HD int svt_tq_unit_is_origin(const svt_lf_mode_info *mi, int mi_stride, int 
     return 1;
 }
 
-/* number of transform blocks per size that the block starting at unit (ur, uc) adds; cnt[4] is ADDED to */
+/* number of transform blocks per size that the block starting at unit (ur, uc) adds; cnt[4] is ADDED to.  The lists hold the blocks
+ * of INTER prediction blocks only: an intra block (is_inter == 0) predicts from its neighbours' reconstruction, so it cannot ride in a
+ * size-grouped batch -- the intra pass (intra_kernel.hip) codes it after the batch, when its inter neighbours are reconstructed. */
 SVT_HD void svt_tq_unit_counts(const svt_lf_mode_info *mi, int mi_stride, int ur, int uc, int cnt[4]) {
     const svt_lf_mode_info *b = &mi[ur * mi_stride + uc];
+    if (!b->is_inter) return;
     const int bw = svt_blk_w8(b->sb_type) * 8, bh = svt_blk_h8(b->sb_type) * 8;
     const int n = 4 << b->tx_size, txuv = svt_uv_tx_size(b->sb_type, b->tx_size), nuv = 4 << txuv;
     cnt[b->tx_size] += (bw / n) * (bh / n);
@@ -213,6 +216,7 @@ SVT_HD void svt_tq_unit_counts(const svt_lf_mode_info *mi, int mi_stride, int ur
 SVT_HD void svt_tq_unit_emit(const svt_lf_mode_info *mi, int mi_stride, int ur, int uc, const svt_tq_pic_geom *g, const uint32_t *iscan_off /* [4][4] */,
                              uint32_t base[4], svt_tq_block *blocks, uint32_t *pos) {
     const svt_lf_mode_info *b = &mi[ur * mi_stride + uc];
+    if (!b->is_inter) return;
     const int bw = svt_blk_w8(b->sb_type) * 8, bh = svt_blk_h8(b->sb_type) * 8;
     const int sb_cols = (g->width + 63) >> 6;
     for (int plane = 0; plane < 3; plane++) {

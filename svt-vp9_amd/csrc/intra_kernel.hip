@@ -49,6 +49,7 @@ struct intra_pic_dev {
     uint8_t       *nz;
     int32_t       *sync;    /* [0] ticket counter, [2 + plane * n_area + area] done flags (32x32 luma areas); zeroed before the launch */
     int32_t       *status;  /* |= 1: a malformed grid was seen */
+    int32_t        mixed;   /* 1: an inter picture with some intra blocks: inter blocks are skipped (the batch coded them) */
 };
 
 /* eb_vp9_intra_mode_to_tx_type_lookup (VPX/vp9_reconintra.c:20-31): DC, V, H, D45, D135, D117, D153, D207, D63, TM */
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(64) void svt_intra_kernel(const intra_pic_dev P) {
         if (ur >= P.mi_rows || uc >= P.mi_cols) continue;
         const svt_lf_mode_info b = P.mi[ur * P.mi_stride + uc];
         const int w8 = b.sb_type == 3 ? 1 : b.sb_type == 6 ? 2 : b.sb_type == 9 ? 4 : 0;
+        if (b.is_inter && P.mixed) continue;
         if (w8 == 0 || b.is_inter) { if (lane == 0) atomicOr(P.status, 1); continue; }
         if ((ur % w8) || (uc % w8)) continue;
         const int mode = plane ? b.pad_[2] : b.pad_[1];
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void svt_md_intra_default_kernel(svt_lf_mode_i
 
 /* internal launchers (declared in svt_ctx.h; the entry points are in encdec.hip) */
 int32_t svt_intra_launch(svt_hip_ctx *ctx, const svt_encdec_picture *p, int32_t width, int32_t height, int32_t mi_stride, const svt_quant_tables *d_qtabs,
-                         const int16_t *d_iscan, const uint32_t iscan_off[16], int32_t *d_sync, int32_t *d_status) {
+                         const int16_t *d_iscan, const uint32_t iscan_off[16], int32_t *d_sync, int32_t *d_status, int32_t mixed) {
     intra_pic_dev P;
     memset(&P, 0, sizeof P);
     P.src[0] = p->src.y; P.src[1] = p->src.u; P.src[2] = p->src.v;
@@ -261,7 +263,7 @@ int32_t svt_intra_launch(svt_hip_ctx *ctx, const svt_encdec_picture *p, int32_t 
     P.sb_cols = (width + 63) >> 6; P.sb_rows = (height + 63) >> 6; P.width = width; P.height = height;
     P.qtabs = d_qtabs; P.iscan = d_iscan;
     for (int i = 0; i < 16; i++) P.iscan_off[i] = iscan_off[i];
-    P.qcoeff = p->d_qcoeff; P.dqcoeff = p->d_dqcoeff; P.eob_map = p->d_eob_map; P.nz = p->d_nz; P.sync = d_sync; P.status = d_status;
+    P.qcoeff = p->d_qcoeff; P.dqcoeff = p->d_dqcoeff; P.eob_map = p->d_eob_map; P.nz = p->d_nz; P.sync = d_sync; P.status = d_status; P.mixed = mixed;
     const int n_area = ((width + 31) >> 5) * ((height + 31) >> 5);
     HIP_TRY(hipMemsetAsync(d_sync, 0, (size_t)(2 + 3 * n_area) * sizeof(int32_t), ctx->stream));
     hipLaunchKernelGGL(svt_intra_kernel, dim3(3 * n_area), dim3(64), 0, ctx->stream, P);

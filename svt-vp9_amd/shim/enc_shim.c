@@ -562,6 +562,7 @@ static EbErrorType encode_wave(shim_state *s, shim_dev *d, const shim_job *const
         if (svt_hip_encdec_flags_derive(&fc, &fl) != SVT_HIP_OK) return EB_ErrorBadParameter;
     }
     int n_stand_in = 0;
+    int has_intra[SHIM_WAVE_MAX] = {0};
     const svt_me_pu_result *res[SHIM_WAVE_MAX];
     svt_mc_mode_info       *mcs[SHIM_WAVE_MAX];
     svt_lf_mode_info       *lfs[SHIM_WAVE_MAX];
@@ -582,6 +583,9 @@ static EbErrorType encode_wave(shim_state *s, shim_dev *d, const shim_job *const
                                               (size_t)s->mi_cols * sizeof(svt_lf_mode_info), (size_t)s->mi_rows));
                 decided = 1;
                 t->info.decision_source = 1;
+                /* a host decision may hold intra blocks: they go through the intra pass behind the batch */
+                const svt_lf_mode_info *g = (const svt_lf_mode_info *)s->h_lf;
+                for (size_t u = 0; u < (size_t)s->mi_rows * s->mi_cols && !has_intra[i]; u++) has_intra[i] = !g[u].is_inter;
             }
         }
         if (!decided) { res[n_stand_in] = (const svt_me_pu_result *)t->d_results; mcs[n_stand_in] = (svt_mc_mode_info *)t->d_mc_mi; lfs[n_stand_in] = (svt_lf_mode_info *)t->d_lf_mi; n_stand_in++; }
@@ -592,6 +596,8 @@ static EbErrorType encode_wave(shim_state *s, shim_dev *d, const shim_job *const
         p->ref[0] = rec_planes(s, r0->d_rec); p->ref[1] = rec_planes(s, r1->d_rec);
         p->d_qcoeff = t->d_qcoeff; p->d_dqcoeff = t->d_dqcoeff; p->d_eob_map = (uint16_t *)t->d_eob_map; p->d_lfm = (svt_lf_mask *)t->d_lfm; p->d_nz = (uint8_t *)t->d_nz;
         p->use_subpel = job_use_subpel(wj[i]);
+        if (has_intra[i] && !fl.do_recon) return EB_ErrorBadParameter; /* a picture that is not reconstructed cannot hold intra blocks (the reference's limit_intra) */
+        p->has_intra = has_intra[i];
         t->info.is_used_as_reference = wj[i]->used_as_ref; t->info.do_recon = fl.do_recon; t->info.apply_loop_filter = fl.apply_loop_filter;
         t->info.pad_reference = fl.pad_reference; t->info.q_index = s->q_index; t->info.filter_level = s->filter_level; t->info.intra_recon_is_source = 0;
     }

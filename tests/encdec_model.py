@@ -142,6 +142,15 @@ def oracle_encdec_picture(src, refs, mc_mi, lf_mi, q_index, flags, thr, use_subp
     e0, e1, e2, e3 = eob_map_offsets(W, H)
     emap = np.zeros(e3, np.uint16)
     nz = np.zeros((mi_rows, mi_cols), bool)
+    intra_units = lf_mi["is_inter"][:, :mi_cols] == 0
+    if intra_units.any():
+        # intra blocks of an inter picture: coded behind the batch, from their neighbours' reconstruction (oracle/oracle_intra.c, mixed)
+        assert flags.do_recon
+        oi = oracle_intra_picture(src, lf_mi, q_index, rec=rec, pad=pad, mixed=1, pred_init=pred, q_init=q, dq_init=dq, emap_init=emap)
+        pred = oi["pred"]
+        ey = emap[e0:e1].reshape(H // 4, W // 4)
+        eu, ev = emap[e1:e2].reshape(H // 8, W // 8), emap[e2:e3].reshape(H // 8, W // 8)
+        nz |= intra_units & ((ey[::2, ::2] != 0) | (eu != 0) | (ev != 0))     # set at the block's first unit
     plane = (pos >> 22) & 3
     y4, x4 = (pos >> 11) & 0x7FF, pos & 0x7FF
     pw4 = np.where(plane == 0, W // 4, W // 8)
@@ -213,16 +222,17 @@ def gen_intra_grid(seed, W, H, sizes=(8, 16, 32), modes=tuple(range(10)), filter
     return mi
 
 
-def oracle_intra_picture(src, lf_mi, q_index, rec=None, pad=PAD):
+def oracle_intra_picture(src, lf_mi, q_index, rec=None, pad=PAD, mixed=0, pred_init=None, q_init=None, dq_init=None, emap_init=None):
     """the oracle's intra encode pass (oracle/oracle_intra.c) into a RefPic (or `rec`): prediction, coefficients, eob map, reconstruction
-    before deblocking"""
+    before deblocking.  mixed = 1: the intra blocks of an inter picture whose inter blocks are already in rec / pred_init / q_init ..."""
     H, W = src[0].shape
     rec = RefPic(W, H, pad) if rec is None else rec
     srcb = np.concatenate([p.ravel() for p in src])
-    predb = np.zeros_like(srcb)
+    predb = np.zeros_like(srcb) if pred_init is None else np.concatenate([p.ravel() for p in pred_init])
     n_coeff = T.n_sb(W, H) * B.SB_COEFFS
-    q, dq = np.zeros(n_coeff, np.int16), np.zeros(n_coeff, np.int16)
-    emap = np.zeros(eob_map_offsets(W, H)[3], np.uint16)
+    q = np.zeros(n_coeff, np.int16) if q_init is None else q_init
+    dq = np.zeros(n_coeff, np.int16) if dq_init is None else dq_init
+    emap = np.zeros(eob_map_offsets(W, H)[3], np.uint16) if emap_init is None else emap_init
     iscan, offs = T.iscan_array()
     ioff = (C.c_uint32 * 16)(*[offs[(ts, tt)] for ts in range(4) for tt in range(4)])
     ro = (C.c_uint32 * 3)(*rec.offsets())
@@ -230,7 +240,7 @@ def oracle_intra_picture(src, lf_mi, q_index, rec=None, pad=PAD):
     qt = qtabs_of(q_index)
     mi = np.ascontiguousarray(lf_mi)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
-    rc = T.oracle().svt_oracle_intra_picture(vp(srcb), vp(predb), vp(rec.buf), ro, rs, vp(mi), mi.shape[1], W, H, vp(qt), vp(iscan), ioff, vp(q), vp(dq), vp(emap))
+    rc = T.oracle().svt_oracle_intra_picture(vp(srcb), vp(predb), vp(rec.buf), ro, rs, vp(mi), mi.shape[1], W, H, vp(qt), vp(iscan), ioff, vp(q), vp(dq), vp(emap), mixed)
     assert rc == 0, rc
     ny, nc = W * H, W * H // 4
     pred = [predb[:ny].reshape(H, W), predb[ny:ny + nc].reshape(H // 2, W // 2), predb[ny + nc:].reshape(H // 2, W // 2)]
@@ -294,4 +304,65 @@ def oracle_intra_chain(src, lf_mi, q_index, flags, thr, pad=PAD, recon_init=None
     if flags.pad_reference:
         d = rec.desc(rec.buf.ctypes.data)
         assert T.oracle().svt_oracle_ref_pad(C.byref(d), pad, pad) == 0
+    return out
+
+
+def make_mixed(seed, lf_mi, mc_mi=None, share=0.3, level=None):
+    """turns a share of the square blocks (8x8 .. 32x32) of an inter grid into intra blocks with random modes: lf grid is_inter = 0,
+    tx_size = the block's own, pad[1] / pad[2] = luma / chroma mode; mc grid (when given) ref_list[0] = -1 (no inter prediction)"""
+    rng = np.random.default_rng(seed)
+    lf = np.ascontiguousarray(lf_mi).copy()
+    mc = None if mc_mi is None else np.ascontiguousarray(mc_mi).copy()
+    mi_rows, mi_cols = lf.shape[0], lf.shape[1] if mc is None else mc.shape[1]
+    n = 0
+    for r in range(mi_rows):
+        for c in range(mi_cols):
+            bs = int(lf["sb_type"][r, c])
+            if bs not in (3, 6, 9):
+                continue
+            w8 = {3: 1, 6: 2, 9: 4}[bs]
+            if r % w8 or c % w8 or rng.random() >= share:
+                continue
+            blk = lf[r:r + w8, c:c + w8]
+            blk["is_inter"], blk["tx_size"], blk["skip"] = 0, {3: 1, 6: 2, 9: 3}[bs], 0
+            blk["pad"][..., 0], blk["pad"][..., 1], blk["pad"][..., 2] = 0, rng.integers(0, 10), rng.integers(0, 10)
+            if level is not None:
+                blk["filter_level"] = level
+            if mc is not None:
+                m = mc[r:r + w8, c:c + w8]
+                m["ref_list"][..., 0], m["ref_list"][..., 1] = -1, -1
+                m["mv_row"], m["mv_col"] = 0, 0
+            n += 1
+    return lf, mc, n
+
+
+def ref_intra_picture_mixed(src, lf_mi, q_index, inter_rec):
+    """the intra blocks of an inter picture through the reference's functions: inter_rec = tight planes holding the reconstruction of
+    the inter blocks (oracle/_ref/ref_intra, mixed request)"""
+    import os, struct, subprocess, tempfile
+    H, W = src[0].shape
+    mi = np.ascontiguousarray(lf_mi)
+    with tempfile.TemporaryDirectory() as td:
+        req, rsp = os.path.join(td, "req.bin"), os.path.join(td, "rsp.bin")
+        with open(req, "wb") as f:
+            f.write(struct.pack("<5i", 0x4E495653, W, H, mi.shape[1], q_index | 1 << 16))
+            for p in src:
+                f.write(np.ascontiguousarray(p).tobytes())
+            f.write(mi.tobytes())
+            for p in inter_rec:
+                f.write(np.ascontiguousarray(p).tobytes())
+        subprocess.check_call([os.path.join(T.REF_DIR, "ref_intra"), req, rsp])
+        raw = open(rsp, "rb").read()
+    ny, nc, o = W * H, W * H // 4, 0
+    out = {}
+    for name in ("pred", "rec"):
+        planes = []
+        for n, shp in ((ny, (H, W)), (nc, (H // 2, W // 2)), (nc, (H // 2, W // 2))):
+            planes.append(np.frombuffer(raw, np.uint8, n, o).reshape(shp).copy())
+            o += n
+        out[name] = planes
+    n_coeff = T.n_sb(W, H) * B.SB_COEFFS
+    out["qcoeff"] = np.frombuffer(raw, np.int16, n_coeff, o).copy(); o += 2 * n_coeff
+    out["dqcoeff"] = np.frombuffer(raw, np.int16, n_coeff, o).copy(); o += 2 * n_coeff
+    out["eob_map"] = np.frombuffer(raw, np.uint16, eob_map_offsets(W, H)[3], o).copy()
     return out

@@ -58,6 +58,8 @@ def host_decision(me, W, H, number, level):
     lf = np.zeros((mi_rows, mi_cols), dtype=B.LF_MODE_INFO_DTYPE)
     lf["sb_type"] = np.where(k == 3, 9, np.where(k == 2, 6, 3))
     lf["tx_size"], lf["is_inter"], lf["filter_level"] = k, 1, level
+    if number % 5 == 2:                                        # some pictures carry intra blocks (random modes) among the inter ones
+        lf, mc, _ = M.make_mixed(3000 + number, lf, mc, share=0.2, level=level)
     return mc, lf
 
 

@@ -41,6 +41,8 @@ def model_blocks(mi, mi_rows, mi_cols, geom, pic=0):
                 w8, h8 = max(_W4[bs] // 2, 1), max(_H4[bs] // 2, 1)
                 if ur % h8 or uc % w8:
                     continue
+                if not mi["is_inter"][ur, uc]:
+                    continue                                   # intra blocks are not in the lists: the intra pass codes them
                 for plane in range(3):
                     ts = _uv_tx(bs, tx) if plane else tx
                     n = 4 << ts
@@ -119,8 +121,16 @@ def test_tq_blocks_from_grid(seed, W, H):
         yy = y if plane == 0 else H + y
         xx = x if plane < 2 else W // 2 + x
         covered[p][yy:yy + n, xx:xx + n] += 1
-    assert all((c == 1).all() for c in covered)               # every sample of both pictures exactly once
-    assert (coeff_used == 1).all()                              # the coefficient areas tile their SB slots exactly
+    # every sample of the inter blocks of both pictures exactly once, nothing of the intra blocks
+    for p in range(2):
+        inter = np.kron(mis[p]["is_inter"][:, :mi_cols].astype(bool), np.ones((8, 8), bool))
+        ci = np.kron(mis[p]["is_inter"][:, :mi_cols].astype(bool), np.ones((4, 4), bool))
+        want_cov = np.zeros((H * 3 // 2, W), np.int32)
+        want_cov[:H] = inter
+        want_cov[H:, :W // 2] = ci
+        want_cov[H:, W // 2:] = ci
+        assert np.array_equal(covered[p], want_cov)
+    assert (coeff_used <= 1).all() and coeff_used.sum() == sum(int(np.kron(m["is_inter"][:, :mi_cols].astype(bool), np.ones((8, 8), bool)).sum()) * 3 // 2 for m in mis)
 
 
 def test_tq_blocks_iscan_offsets_match_tables():
@@ -141,6 +151,7 @@ def test_malformed_grid_is_rejected():
     _, _, mi = T.gen_mode_info_grid(5, H // 8, W // 8, mi_stride=W // 8)
     mi["sb_type"][:] = 12                                       # 64x64 blocks; 64-high picture: fine
     mi["tx_size"][:] = 3
+    mi["is_inter"][:] = 1
     rc, *_ = host_blocks([mi], [make_geom(W, H)], W // 8, W * H * 3 // 32)
     assert rc == 2 * (4 + 2)
     bad = mi.copy()

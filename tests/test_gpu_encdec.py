@@ -60,8 +60,9 @@ class DevPicture:
         d.y_stride, d.uv_stride, d.width, d.height = W, W // 2, W, H
         return d
 
-    def struct(self, refs, use_subpel=1):
+    def struct(self, refs, use_subpel=1, has_intra=0):
         p = B.EncdecPicture()
+        p.has_intra = has_intra
         p.d_mc_mi, p.d_lf_mi = self.mc_t.data_ptr(), self.lf_t.data_ptr()
         p.src, p.pred = self.tight(self.src_t.data_ptr(), self.W), self.tight(self.pred_t.data_ptr(), self.W)
         p.recon = self.rec.desc(self.rec_t.data_ptr())
@@ -103,7 +104,7 @@ def md_host(me, W, H, lam, level):
     return mc, lf
 
 
-def run_device(ctx, W, H, srcs, refs, grids, q_index, flags, thr, rec_inits):
+def run_device(ctx, W, H, srcs, refs, grids, q_index, flags, thr, rec_inits, has_intra=0):
     lib = B.load()
     n = len(srcs)
     pic = W * H * 3 // 2
@@ -112,7 +113,7 @@ def run_device(ctx, W, H, srcs, refs, grids, q_index, flags, thr, rec_inits):
     slab_q, slab_dq = torch.zeros(n * nco, dtype=torch.int16, device="cuda"), torch.zeros(n * nco, dtype=torch.int16, device="cuda")
     refs_dev = [dev(r.buf) for r in refs]
     dp = [DevPicture(W, H, srcs[i], refs_dev, grids[i][0], grids[i][1], slab_src, slab_pred, slab_q, slab_dq, i, rec_inits[i]) for i in range(n)]
-    arr = (B.EncdecPicture * n)(*[d.struct(refs) for d in dp])
+    arr = (B.EncdecPicture * n)(*[d.struct(refs, has_intra=has_intra) for d in dp])
     work = C.c_void_p()
     B.check(lib.svt_hip_encdec_work_create(ctx, n, W, H, C.byref(work)))
     torch.cuda.synchronize()
@@ -244,3 +245,50 @@ def test_malformed_grid_is_reported(ctx):
     lib.svt_hip_lf_thresh_init(C.byref(thr), 0)
     with pytest.raises(RuntimeError):
         run_device(ctx, W, H, srcs, refs, [(mc, lf)], 160, flags, thr, [M.RefPic(W, H)])
+
+
+@pytest.mark.parametrize("W,H,n_pics,q_index,cfg", [
+    (256, 192, 2, 160, dict(enc_mode=8, tune=1, temporal_layer_index=0, is_used_as_reference=1, recon_file=0, loop_filter=1)),
+    (200, 136, 3, 120, dict(enc_mode=8, tune=1, temporal_layer_index=2, is_used_as_reference=1, recon_file=0, loop_filter=1)),   # reconstructed, not deblocked
+    (136, 72, 2, 200, dict(enc_mode=8, tune=1, temporal_layer_index=4, is_used_as_reference=0, recon_file=1, loop_filter=1)),
+])
+def test_intra_blocks_inside_inter_pictures(ctx, W, H, n_pics, q_index, cfg):
+    """inter pictures with a share of intra blocks (random modes): the batch codes the inter blocks, the intra pass behind it the intra
+    blocks from their neighbours' reconstruction; everything downstream (skip flags, masks, deblocking, border) sees both"""
+    lib = B.load()
+    srcs, refs, me = make_inputs(W, H, n_pics, seed=W + n_pics + 1)
+    level = lib.svt_hip_lf_level_from_q(lib.svt_hip_vp9_ac_step(q_index), 0)
+    grids, n_intra = [], 0
+    for i, m in enumerate(me):
+        mc, lf = md_host(m, W, H, 300, level)
+        lf2, mc2, n = M.make_mixed(50 + i, lf, mc, share=0.3, level=level)
+        grids.append((mc2, lf2))
+        n_intra += n
+    assert n_intra > 10
+    flags = flags_of(**cfg)
+    assert flags.do_recon
+    thr = B.LfThresh()
+    lib.svt_hip_lf_thresh_init(C.byref(thr), 0)
+    rng = np.random.default_rng(6)
+    rec_inits = [M.RefPic(W, H) for _ in range(n_pics)]
+    for r in rec_inits:
+        r.buf[:] = rng.integers(0, 256, r.buf.size, dtype=np.uint8)
+    dp, blocks, pos, eob, cnt = run_device(ctx, W, H, srcs, refs, grids, q_index, flags, thr, rec_inits, has_intra=1)
+    for i in range(n_pics):
+        rec0 = M.RefPic(W, H)
+        rec0.buf[:] = rec_inits[i].buf
+        o = M.oracle_encdec_picture(srcs[i], refs, grids[i][0], grids[i][1], q_index, flags, thr, recon_init=rec0)
+        d = dp[i]
+        inter_y = np.kron(grids[i][1]["is_inter"] == 1, np.ones((8, 8), bool))
+        pred_g = d.pred_t.cpu().numpy()
+        want_pred = np.concatenate([p.ravel() for p in o["pred"]])
+        assert np.array_equal(pred_g, want_pred), "prediction (inter blocks from MC, intra blocks from the intra pass)"
+        assert np.array_equal(d.q_t.cpu().numpy(), o["qcoeff"]) and np.array_equal(d.dq_t.cpu().numpy(), o["dqcoeff"]), "coefficients"
+        assert np.array_equal(d.emap_t.cpu().numpy().view(np.uint16), o["eob_map"]), "eob map"
+        lf_g = d.lf_t.cpu().numpy().view(B.LF_MODE_INFO_DTYPE).reshape(H // 8, W // 8)
+        assert np.array_equal(lf_g["skip"], o["lf_mi"]["skip"]), "skip flags"
+        if flags.apply_loop_filter:
+            assert masks_equal(d.lfm_t.cpu().numpy().view(B.LF_MASK_DTYPE).reshape(o["lfm"].shape), o["lfm"]), "masks"
+        rec_g = d.rec_t.cpu().numpy()
+        assert np.array_equal(rec_g, o["rec"].buf), ("reconstruction", int(np.sum(rec_g != o["rec"].buf)))
+        assert not inter_y.all()

@@ -73,3 +73,52 @@ def test_picture_matches_reference(W, H, seed, q):
 def test_single_mode_pictures(size, mode):
     """one block size and one mode over a whole picture: every predictor at every picture-edge position (no left, no top, corner)"""
     _check_picture(128, 96, 40 + mode, 90, sizes=(8, size) if size > 8 else (8,), modes=(mode,))
+
+
+def _square_inter_grid(seed, W, H):
+    """an inter grid of square blocks 8x8 .. 64x64 (what the reference harness walks in mixed mode)"""
+    rng = np.random.default_rng(seed)
+    mi_rows, mi_cols = H // 8, W // 8
+    mi = np.zeros((mi_rows, mi_cols), dtype=T.B.LF_MODE_INFO_DTYPE)
+
+    def put(r, c, n8):
+        b = mi[r:r + n8, c:c + n8]
+        b["sb_type"], b["tx_size"], b["is_inter"], b["filter_level"] = {1: 3, 2: 6, 4: 9, 8: 12}[n8], min({1: 1, 2: 2, 4: 3, 8: 3}[n8], 3), 1, 20
+
+    def split(r, c, n8):
+        if r + n8 <= mi_rows and c + n8 <= mi_cols and (n8 == 1 or rng.random() < 0.4):
+            return put(r, c, n8)
+        h = n8 // 2
+        for dr in (0, h):
+            for dc in (0, h):
+                if r + dr < mi_rows and c + dc < mi_cols:
+                    split(r + dr, c + dc, h)
+    for r in range(0, mi_rows, 8):
+        for c in range(0, mi_cols, 8):
+            split(r, c, 8)
+    return mi
+
+
+@pytest.mark.skipif(not T.have_ref("ref_intra"), reason="reference harness not built")
+@pytest.mark.parametrize("W,H,seed,q", [(192, 128, 11, 100), (136, 72, 12, 40), (320, 192, 13, 200)])
+def test_intra_blocks_of_inter_pictures_match_reference(W, H, seed, q):
+    """mixed pictures: the inter blocks' reconstruction is given, the intra blocks predict from it exactly as the reference's
+    neighbour-array bookkeeping makes them (blocks in its coding order, every block's reconstruction written when its turn comes)"""
+    src = T.gen_yuv(W, H, seed)
+    lf, _, n_intra = M.make_mixed(seed, _square_inter_grid(seed, W, H), share=0.35)
+    assert n_intra > 5
+    rng = np.random.default_rng(seed)
+    inter_rec = [np.clip(p.astype(np.int32) + rng.integers(-6, 7, p.shape), 0, 255).astype(np.uint8) for p in src]
+    want = M.ref_intra_picture_mixed(src, lf, q, inter_rec)
+    rec = M.RefPic(W, H)
+    for d, s_ in zip(rec.interior(), inter_rec):
+        d[:] = s_
+    got = M.oracle_intra_picture(src, lf, q, rec=rec, mixed=1)
+    iy = np.kron(lf["is_inter"] == 0, np.ones((8, 8), bool))
+    ic = np.kron(lf["is_inter"] == 0, np.ones((4, 4), bool))
+    for k, m in enumerate((iy, ic, ic)):
+        assert np.array_equal(got["pred"][k][m], want["pred"][k][m]), ("pred", k)
+        assert np.array_equal(got["rec"].interior()[k], want["rec"][k]), ("rec", k)
+        assert np.array_equal(got["rec"].interior()[k][~m], inter_rec[k][~m])                # inter blocks untouched
+    assert np.array_equal(got["qcoeff"], want["qcoeff"]) and np.array_equal(got["dqcoeff"], want["dqcoeff"])
+    assert np.array_equal(got["eob_map"], want["eob_map"]) and want["eob_map"].any()
