@@ -61,7 +61,7 @@ def run_intra(ctx, src, mi, q_index, flags, thr, rec_init, want_pred=True):
                 emap=emap_t.cpu().numpy().view(np.uint16), lfm=lfm_t.cpu().numpy(), lf=lf_t.cpu().numpy().view(B.LF_MODE_INFO_DTYPE).reshape(mi.shape))
 
 
-def check(ctx, W, H, seed, q_index, cfg, sizes=(8, 16, 32), modes=tuple(range(10)), mi_stride=None):
+def check(ctx, W, H, seed, q_index, cfg, sizes=(8, 16, 32), modes=tuple(range(10)), mi_stride=None, quality=True):
     lib = B.load()
     src = T.gen_yuv(W, H, seed)
     level = lib.svt_hip_lf_level_from_q(lib.svt_hip_vp9_ac_step(q_index), 1)
@@ -86,8 +86,9 @@ def check(ctx, W, H, seed, q_index, cfg, sizes=(8, 16, 32), modes=tuple(range(10
     if flags.apply_loop_filter:
         assert masks_equal(g["lfm"].view(B.LF_MASK_DTYPE).reshape(o["lfm"].shape), o["lfm"]), "masks"
     assert np.array_equal(g["rec"], o["rec"].buf), ("reconstruction", int(np.sum(g["rec"] != o["rec"].buf)))
-    for a, b in zip(o["rec"].interior(g["rec"]), src):
-        assert np.mean(np.abs(a.astype(np.int32) - b)) < 24
+    if quality:                                                          # (it IS a reconstruction of the source; not at the coarsest q indices)
+        for a, b in zip(o["rec"].interior(g["rec"]), src):
+            assert np.mean(np.abs(a.astype(np.int32) - b)) < 24, "reconstruction far from the source"
     return g, o
 
 
