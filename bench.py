@@ -344,7 +344,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        # SVT_BENCH_BACKEND=gloo: dry run of the multi-rank control flow on a box with fewer GPUs than ranks (several ranks then share a
+        # device, which RCCL refuses); the driver's runs use the default
+        dist.init_process_group(os.environ.get("SVT_BENCH_BACKEND", "nccl"))
 
     import importlib.util
     import svt_testlib as T
@@ -842,7 +844,7 @@ def main():
         return dt, t_enq / n_free, stage_ms, stage_ms_sum, me_launches
 
     dt, enq_s, stage_ms, stage_ms_sum, me_launch_list = timed_run(P_main, args.schedule, args.steps, args.warmup, True)
-    dt = GS.reduce_elapsed(dt, dist if world > 1 else None, dev)
+    dt = GS.reduce_elapsed(dt, dist if world > 1 else None, dev if os.environ.get("SVT_BENCH_BACKEND", "nccl") == "nccl" else None)
     if world > 1:   # nothing below needs the other ranks: they leave in step, rank 0 reports
         sync()
         dist.barrier()
