@@ -18,9 +18,9 @@
  * above-right neighbour the reference's z-order is only ONE of the orders that give its result.  The picture is cut into 32x32 luma
  * areas (the largest block here); the blocks of an area are coded one after the other (z-order) and area (r, c) can start when
  * (r, c - 1) and (r - 1, c) are done: an anti-diagonal wavefront over the areas, times three independent planes.  One 64-lane
- * workgroup codes one (area, plane); workgroups take TICKETS (an atomic counter) that enumerate the (area, plane) pairs diagonal by
- * diagonal, so every workgroup only ever waits for tickets smaller than its own -- which are held by workgroups that already run:
- * no deadlock whatever the dispatch order, no co-residency requirement.  A block is N x N with N lanes active (lane i = row i of the
+ * workgroup codes one (area, plane) at a time; the workgroups (one per CU, persistent) take TICKETS (an atomic counter) that enumerate
+ * the (area, plane) pairs diagonal by diagonal, so a workgroup only ever waits for tickets smaller than its own -- which are held by
+ * workgroups that already run or are done: no deadlock whatever the dispatch order, no co-residency requirement.  A block is N x N with N lanes active (lane i = row i of the
  * prediction, then column / row i of the transform); the chain of dependent blocks, not the lane count, bounds the speed: a 2160p key
  * frame is 187 diagonals of at most 68 areas.  This kernel is latency-bound by design (one picture in a GOP); it shares the GPU with
  * the batches of the inter pictures running beside it.
@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 #include "tq_core.h"
 #include "encdec_core.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -189,8 +190,13 @@ __global__ __launch_bounds__(64) void svt_intra_kernel(const intra_pic_dev P) {
      * never reads the above-right neighbour, so any order in which a block follows its left, above and above-left neighbours gives the
      * reference's result -- areas go in anti-diagonal order, the blocks of an area in z-order */
     const int lane = (int)threadIdx.x, a_cols = (P.width + 31) >> 5, a_rows = (P.height + 31) >> 5, n_area = a_cols * a_rows;
+  /* workgroups are persistent: each keeps drawing tickets until they run out -- a launch of one workgroup per pair would keep ~1000 of
+     them resident, nearly all polling flags of areas many diagonals away */
+  for (;;) {
+    __syncthreads(); /* (s_ticket of the previous round has been read by every lane) */
     if (lane == 0) s_ticket = atomicAdd(&P.sync[0], 1);
     __syncthreads();
+    if (s_ticket >= 3 * n_area) break;
     const int ticket = s_ticket, plane = ticket % 3;
     /* the n-th area in anti-diagonal order (diagonal d = row + col, rows ascending inside a diagonal) */
     int n = ticket / 3, ar = 0, ac = 0;
@@ -231,6 +237,7 @@ __global__ __launch_bounds__(64) void svt_intra_kernel(const intra_pic_dev P) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (lane == 0) __hip_atomic_store(&done[area], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 /* stand-in decision for an intra picture (no claim of coding efficiency; the public API's callback replaces it): 16x16 blocks with
@@ -266,7 +273,11 @@ int32_t svt_intra_launch(svt_hip_ctx *ctx, const svt_encdec_picture *p, int32_t 
     P.qcoeff = p->d_qcoeff; P.dqcoeff = p->d_dqcoeff; P.eob_map = p->d_eob_map; P.nz = p->d_nz; P.sync = d_sync; P.status = d_status; P.mixed = mixed;
     const int n_area = ((width + 31) >> 5) * ((height + 31) >> 5);
     HIP_TRY(hipMemsetAsync(d_sync, 0, (size_t)(2 + 3 * n_area) * sizeof(int32_t), ctx->stream));
-    hipLaunchKernelGGL(svt_intra_kernel, dim3(3 * n_area), dim3(64), 0, ctx->stream, P);
+    static int wg_per_cu = 0;
+    if (!wg_per_cu) { const char *e = getenv("SVT_HIP_INTRA_WG_PER_CU"); wg_per_cu = e && atoi(e) > 0 ? atoi(e) : 1; }
+    int grid = ctx->cu_count * wg_per_cu;
+    if (grid > 3 * n_area) grid = 3 * n_area;
+    hipLaunchKernelGGL(svt_intra_kernel, dim3(grid), dim3(64), 0, ctx->stream, P);
     HIP_TRY(hipGetLastError());
     return SVT_HIP_OK;
 }
