@@ -149,7 +149,8 @@ EbErrorType svt_vp9_shim_get_counters(EbComponentType *svt_enc_component, uint64
  * library's to write) -- and returns 0; a non-zero return makes the library use its stand-in for that picture.  Without a
  * callback the stand-in decides every picture (svt_hip_md_default_batch_device: a deterministic partition from the ME results,
  * NOT the reference's mode decision).  For an intra picture (info->is_intra) me_results is NULL and only lf_mode_info is read: intra
- * blocks of 8x8 / 16x16 / 32x32 (sb_type 3 / 6 / 9, tx_size 1 / 2 / 3, is_inter 0) with pad_[1] = luma mode and pad_[2] = chroma mode
+ * blocks of 8x8 / 16x16 / 32x32 (sb_type 3 / 6 / 9, tx_size 1 / 2 / 3, is_inter 0) with pad_[1] = luma mode and pad_[2] = chroma mode;
+ * units of four 4x4 blocks: sb_type 0, tx_size 0, their luma modes in the nibbles of pad_[1] (blocks 0, 1) and pad_[0] (blocks 2, 3)
  * (0 DC, 1 V, 2 H, 3 D45, 4 D135, 5 D117, 6 D153, 7 D207, 8 D63, 9 TM), svt_hip_encdec_intra_device of svtvp9_hip.h; the stand-in
  * for an intra picture is 16x16 blocks with DC prediction.  The grids of an INTER picture may hold intra blocks as well (is_inter 0 + modes in
  * lf_mode_info, ref_list[0] = -1 in mc_mode_info) as long as the picture is reconstructed (info->do_recon; the reference's limit_intra

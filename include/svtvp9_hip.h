@@ -744,8 +744,9 @@ int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work *work, int
  * loop-filter masks, deblocking, border.  The grid (pic->d_lf_mi) describes intra blocks of 8x8, 16x16 or 32x32 (sb_type 3 / 6 / 9)
  * with the transform of their own size, is_inter = 0, pad_[1] = luma mode, pad_[2] = chroma mode (PREDICTION_MODE: 0 DC, 1 V, 2 H,
  * 3 D45, 4 D135, 5 D117, 6 D153, 7 D207, 8 D63, 9 TM); the luma transform type follows the mode
- * (eb_vp9_intra_mode_to_tx_type_lookup).  4x4 blocks and the 64x64 block are outside this entry (reported as malformed through
- * svt_hip_encdec_work_status).  pic->ref / d_mc_mi are ignored; pic->pred may be all NULL (the prediction is then not stored).
+ * (eb_vp9_intra_mode_to_tx_type_lookup).  sb_type 0 = an 8x8 unit of four 4x4 luma blocks (+ one 4x4 chroma block per plane): tx_size 0,
+ * the luma modes of blocks 0..3 in the nibbles of pad_[1] (blocks 0, 1) and pad_[0] (blocks 2, 3), pad_[2] the chroma mode.  The 64x64
+ * block and rectangular blocks are outside this entry (reported as malformed through svt_hip_encdec_work_status).  pic->ref / d_mc_mi are ignored; pic->pred may be all NULL (the prediction is then not stored).
  * flags->do_recon must be set.  Planes and strides 4-byte aligned.  Asynchronous on the context's stream. */
 int32_t svt_hip_encdec_intra_device(svt_hip_ctx *ctx, svt_encdec_work *work, const svt_encdec_picture *pic, int32_t width, int32_t height,
                                     int32_t mi_stride, int32_t q_index, const svt_encdec_flags *flags, const svt_lf_thresh *thr, int32_t pad_x,

@@ -2,8 +2,8 @@
  * oracle_intra.c -- CPU restatement of the intra path of the encode pass.  TEST INFRASTRUCTURE ONLY: nothing in the product links,
  * imports or calls this file (tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg are its only users).
  *
- * Follows, for blocks of 8x8 .. 32x32 that lie inside the picture (what encode_pass_sb codes when the picture's width and height
- * are multiples of 8; 4x4 blocks and the 64x64 block are outside this restatement):
+ * Follows, for blocks of 4x4 .. 32x32 that lie inside the picture (what encode_pass_sb codes when the picture's width and height
+ * are multiples of 8; the 64x64 block is outside this restatement):
  *   reference samples   generate_intra_reference_samples     Source/Lib/Codec/EbEncDecProcess.c:1128-1310
  *                        (neighbour arrays written by eb_vp9_neighbor_array_unit_sample_write, Codec/EbNeighborArrays.c:107-240,
  *                         from the block's UNFILTERED reconstruction, EbEncDecProcess.c:4110-4160)
@@ -176,14 +176,23 @@ void svt_oracle_intra_predict(int32_t mode, int32_t bs, int32_t have_left, int32
 /* generate_intra_reference_samples for a transform block of bs x bs at (x0, y0) of a plane whose blocks never use the above-right
  * neighbour (blocks >= 8x8: have_right = 0, EbEncDecProcess.c:1146) and never cross the picture edge (the "faster" paths).
  * above_row[0] = the corner, above_row[1 .. 2 bs] = the row; left_col[0 .. bs - 1]. */
+void svt_oracle_intra_ref_samples2(const uint8_t *plane, int32_t stride, int32_t x0, int32_t y0, int32_t bs, int32_t have_right, uint8_t *above_row,
+                                   uint8_t *left_col);
 void svt_oracle_intra_ref_samples(const uint8_t *plane, int32_t stride, int32_t x0, int32_t y0, int32_t bs, uint8_t *above_row, uint8_t *left_col) {
+    svt_oracle_intra_ref_samples2(plane, stride, x0, y0, bs, 0, above_row, left_col);
+}
+/* have_right: a 4x4 luma block in the left half of its 8x8 unit (aoff = 0: have_right = (aoff + txw) < bw, :1146) reads the four true
+ * above-right samples (:1283-1288 and the const_above_row path :1279-1280, which is the same eight samples) */
+void svt_oracle_intra_ref_samples2(const uint8_t *plane, int32_t stride, int32_t x0, int32_t y0, int32_t bs, int32_t have_right, uint8_t *above_row,
+                                   uint8_t *left_col) {
     const int have_top = y0 > 0, have_left = x0 > 0;
     const uint8_t *p = plane + (size_t)y0 * stride + x0;
     if (have_left) for (int i = 0; i < bs; i++) left_col[i] = p[(ptrdiff_t)i * stride - 1];
     else memset(left_col, 129, (size_t)bs);
     if (have_top) {
         memcpy(above_row + 1, p - stride, (size_t)bs);
-        memset(above_row + 1 + bs, above_row[bs], (size_t)bs);
+        if (bs == 4 && have_right) memcpy(above_row + 1 + bs, p - stride + bs, (size_t)bs);
+        else memset(above_row + 1 + bs, above_row[bs], (size_t)bs);
         above_row[0] = have_left ? p[-stride - 1] : 129;
     } else {
         memset(above_row, 127, (size_t)(2 * bs + 1));
@@ -200,7 +209,8 @@ static uint32_t zorder4(int x4, int y4) {
 
 /* One intra picture through the encode pass.  src / pred: the three tight planes one after the other (Y, U, V); the reconstruction
  * lives in recon_buf at recon_off[plane] with recon_stride[plane != 0].  mi: one record per 8x8 unit (sb_type 3 / 6 / 9, tx_size =
- * the block's own size, is_inter 0, pad_[1] = luma mode, pad_[2] = chroma mode).  qcoeff / dqcoeff: the product's position-addressed
+ * the block's own size, is_inter 0, pad_[1] = luma mode, pad_[2] = chroma mode; sb_type 0 = four 4x4 luma blocks + one 4x4 chroma
+ * block per plane: tx_size 0, luma modes of blocks 0..3 in the nibbles of pad_[1] (0, 1) and pad_[0] (2, 3)).  qcoeff / dqcoeff: the product's position-addressed
  * layout (6144 per SB: luma 4096, Cb 1024, Cr 1024, 4x4 units in z-order); eob_map: one entry per 4x4 unit, Y then U then V planes,
  * written at the block's first unit.  iscan_off[tx_size * 4 + tx_type].  mixed: the picture is an inter picture whose inter blocks have
  * been reconstructed into recon_buf already (any block shape); only its intra blocks are coded, in the same order -- every intra block
@@ -221,24 +231,33 @@ int32_t svt_oracle_intra_picture(const uint8_t *src, uint8_t *pred, uint8_t *rec
                 if (ur >= mi_rows || uc >= mi_cols) continue;
                 const svt_lf_mode_info *b = &mi[ur * mi_stride + uc];
                 if (b->is_inter && mixed) continue; /* an inter picture with intra blocks: the inter blocks are reconstructed already */
-                if (b->is_inter || (b->sb_type != 3 && b->sb_type != 6 && b->sb_type != 9)) return -1;
-                const int w8 = 1 << ((b->sb_type - 3) / 3);
+                if (b->is_inter || (b->sb_type != 0 && b->sb_type != 3 && b->sb_type != 6 && b->sb_type != 9)) return -1;
+                const int w8 = b->sb_type == 0 ? 1 : 1 << ((b->sb_type - 3) / 3);
                 if ((ur % w8) || (uc % w8)) continue;
-                if (ur + w8 > mi_rows || uc + w8 > mi_cols || b->tx_size != (b->sb_type - 3) / 3 + 1 || b->pad_[1] > 9 || b->pad_[2] > 9) return -1;
-                for (int plane = 0; plane < 3; plane++) {
-                    const int bs = plane ? w8 * 4 : w8 * 8, x0 = plane ? uc * 4 : uc * 8, y0 = plane ? ur * 4 : ur * 8;
+                if (ur + w8 > mi_rows || uc + w8 > mi_cols || b->pad_[2] > 9) return -1;
+                if (b->sb_type == 0 ? b->tx_size != 0 : (b->tx_size != (b->sb_type - 3) / 3 + 1 || b->pad_[1] > 9)) return -1;
+                /* transform blocks of the prediction block in the reference's order: an 8x8 unit of 4x4 blocks is four blocks of its
+                   own (bmi_index 0..3, :3706), the chroma 4x4 rides with the last; any other block is luma, Cb, Cr */
+                const int sub = b->sb_type == 0;
+                const int modes4[4] = {b->pad_[1] & 15, b->pad_[1] >> 4, b->pad_[0] & 15, b->pad_[0] >> 4}; /* 4x4: luma modes of blocks 0..3 */
+                for (int step = 0; step < (sub ? 6 : 3); step++) {
+                    const int plane = sub ? (step < 4 ? 0 : step - 3) : step;
+                    const int bmi = sub && step < 4 ? step : 0;
+                    const int bs = sub ? 4 : (plane ? w8 * 4 : w8 * 8);
+                    const int x0 = (plane ? uc * 4 : uc * 8) + (sub && !plane ? 4 * (bmi & 1) : 0), y0 = (plane ? ur * 4 : ur * 8) + (sub && !plane ? 4 * (bmi >> 1) : 0);
                     const int pw = plane ? width / 2 : width, rs = recon_stride[plane ? 1 : 0];
-                    const int mode = plane ? b->pad_[2] : b->pad_[1];
+                    const int mode = plane ? b->pad_[2] : sub ? modes4[bmi] : b->pad_[1];
+                    if (mode > 9) return -1;
                     uint8_t  *rp = recon_buf + recon_off[plane];
                     uint8_t   above[65], left[32];
-                    svt_oracle_intra_ref_samples(rp, rs, x0, y0, bs, above, left);
+                    svt_oracle_intra_ref_samples2(rp, rs, x0, y0, bs, sub && !plane && !(bmi & 1), above, left);
                     svt_oracle_intra_predict(mode, bs, x0 > 0, y0 > 0, above + 1, left, pred + po[plane] + (size_t)y0 * pw + x0, pw);
                     svt_tq_block k;
                     memset(&k, 0, sizeof k);
                     k.src_off = k.pred_off = (uint32_t)(po[plane] + (size_t)y0 * pw + x0);
                     k.recon_off = recon_off[plane] + (uint32_t)y0 * (uint32_t)rs + (uint32_t)x0;
                     k.src_stride = k.pred_stride = (uint16_t)pw; k.recon_stride = (uint16_t)rs;
-                    k.tx_size = (uint8_t)(plane ? b->tx_size - 1 : b->tx_size);
+                    k.tx_size = (uint8_t)(sub ? 0 : plane ? b->tx_size - 1 : b->tx_size);
                     k.tx_type = (uint8_t)((plane == 0 && k.tx_size < 3) ? MODE_TX_TYPE[mode] : 0);
                     k.qtab = (uint8_t)(plane ? 1 : 0); k.do_recon = 1;
                     k.iscan_off = iscan_off[k.tx_size * 4 + k.tx_type];

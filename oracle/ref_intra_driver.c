@@ -16,7 +16,8 @@
  * (the constructor itself allocates through the encoder handle's memory map, which does not exist here).
  *
  * request : int32 magic 'SVIN', width, height, mi_stride, q_index | mixed << 16; Y (W*H), U, V (W/2*H/2) tight source planes;
- *           mi_rows*mi_stride svt_lf_mode_info (sb_type 3 / 6 / 9, pad_[1] = luma mode, pad_[2] = chroma mode);
+ *           mi_rows*mi_stride svt_lf_mode_info (sb_type 3 / 6 / 9, pad_[1] = luma mode, pad_[2] = chroma mode; sb_type 0: four 4x4
+ *           luma blocks, their modes in the nibbles of pad_[1] (blocks 0, 1) and pad_[0] (2, 3));
  *           mixed: + Y, U, V tight planes holding the reconstruction of the picture's INTER blocks (square, 8x8 .. 64x64): an inter
  *           block is not coded here, its reconstruction goes to the neighbour arrays when its turn comes, as encode_pass_sb does after
  *           every block -- what the intra blocks of an inter picture then predict from is the reference's own bookkeeping
@@ -139,35 +140,51 @@ int main(int argc, char **argv) {
                     continue;
                 }
                 if (b->sb_type > BLOCK_32X32 || b->is_inter) return 5;
+                /* an 8x8 unit of 4x4 blocks is four blocks of the reference's table (bsize BLOCK_4X4, origins 4 apart; bmi_index from the
+                   origin, :3706); the chroma 4x4 rides with the last one (has_uv = is_last_quadrant, Codec/EbUtility.c:395) */
+                const int sub = b->sb_type == BLOCK_4X4, nq = sub ? 4 : 1, bsq = sub ? 4 : sq;
+                for (int q4 = 0; q4 < nq; q4++) {
+                const int bx = x + (sub ? 4 * (q4 & 1) : 0), by = y + (sub ? 4 * (q4 >> 1) : 0);
                 EpBlockStats stv;
                 memset(&stv, 0, sizeof stv);
-                stv.sq_size = sq; stv.sq_size_uv = MAX(sq >> 1, 4); stv.shape = PART_N;
-                stv.origin_x = (uint8_t)(uc * 8); stv.origin_y = (uint8_t)(ur * 8);
-                stv.bwidth = stv.bheight = (uint8_t)sq; stv.bwidth_uv = stv.bheight_uv = (uint8_t)MAX(4, sq >> 1);
-                stv.bsize = (BLOCK_SIZE)b->sb_type; stv.bsize_uv = eb_vp9_ss_size_lookup[stv.bsize][1][1];
-                stv.tx_size = blocksize_to_txsize[stv.bsize]; stv.tx_size_uv = blocksize_to_txsize[stv.bsize_uv];
-                stv.has_uv = 1;
+                stv.sq_size = bsq; stv.sq_size_uv = MAX(bsq >> 1, 4); stv.shape = PART_N;
+                stv.origin_x = (uint8_t)(bx - sc * 64); stv.origin_y = (uint8_t)(by - sr * 64);
+                stv.bwidth = stv.bheight = (uint8_t)bsq; stv.bwidth_uv = stv.bheight_uv = (uint8_t)MAX(4, bsq >> 1);
+                stv.bsize = (BLOCK_SIZE)b->sb_type;
+                stv.bsize_uv = sub ? BLOCK_4X4 : eb_vp9_ss_size_lookup[stv.bsize][1][1]; /* (the table's own entry for 4x4 is get_plane_block_size = BLOCK_INVALID,
+                                                                                             whose transform size is read past blocksize_to_txsize[]: the 4x4 it means is set here) */
+                stv.tx_size = blocksize_to_txsize[stv.bsize]; stv.tx_size_uv = sub ? TX_4X4 : blocksize_to_txsize[stv.bsize_uv];
+                stv.has_uv = !sub || q4 == 3;
+                stv.is_last_quadrant = sub && q4 == 3;
                 const EpBlockStats *st = &stv;
-                const int idx = 0;
+                const int idx = 0, n_planes = st->has_uv ? 3 : 1;
                 memset(&mi, 0, sizeof mi);
-                mi.sb_type = st->bsize; mi.mode = (PREDICTION_MODE)b->pad_[1]; mi.uv_mode = (PREDICTION_MODE)b->pad_[2];
+                mi.sb_type = st->bsize; mi.uv_mode = (PREDICTION_MODE)b->pad_[2];
+                if (sub) {
+                    mi.bmi[0].as_mode = (PREDICTION_MODE)(b->pad_[1] & 15); mi.bmi[1].as_mode = (PREDICTION_MODE)(b->pad_[1] >> 4);
+                    mi.bmi[2].as_mode = (PREDICTION_MODE)(b->pad_[0] & 15); mi.bmi[3].as_mode = (PREDICTION_MODE)(b->pad_[0] >> 4);
+                    mi.mode = mi.bmi[3].as_mode;
+                } else mi.mode = (PREDICTION_MODE)b->pad_[1];
                 mi.tx_size = st->tx_size; mi.ref_frame[0] = INTRA_FRAME; mi.ref_frame[1] = NONE;
                 ctx->ep_block_stats_ptr = st; ctx->ep_block_index = (uint16_t)idx;
-                ctx->block_origin_x = (uint16_t)x; ctx->block_origin_y = (uint16_t)y;
-                ctx->mi_col = x >> 3; ctx->mi_row = y >> 3;
-                ctx->bmi_index = 0;
+                ctx->block_origin_x = (uint16_t)bx; ctx->block_origin_y = (uint16_t)by;
+                ctx->mi_col = bx >> 3; ctx->mi_row = by >> 3;
+                ctx->bmi_index = ((bx >> 2) & 1) + (((by >> 2) & 1) << 1); /* :3706 */
                 /* Codec/EbEncDecProcess.c:3708-3719 */
-                xd->mb_to_top_edge    = -(((y >> 3) * MI_SIZE) * 8);
-                xd->mb_to_bottom_edge = ((mi_rows - eb_vp9_num_8x8_blocks_high_lookup[st->bsize] - (y >> 3)) * MI_SIZE) * 8;
-                xd->mb_to_left_edge   = -(((x >> 3) * MI_SIZE) * 8);
-                xd->mb_to_right_edge  = ((mi_cols - eb_vp9_num_8x8_blocks_wide_lookup[st->bsize] - (x >> 3)) * MI_SIZE) * 8;
-                for (int p = 0; p < 3; p++) {
-                    const int ss = p ? 1 : 0, ps = p ? W / 2 : W;
+                xd->mb_to_top_edge    = -(((by >> 3) * MI_SIZE) * 8);
+                xd->mb_to_bottom_edge = ((mi_rows - eb_vp9_num_8x8_blocks_high_lookup[st->bsize] - (by >> 3)) * MI_SIZE) * 8;
+                xd->mb_to_left_edge   = -(((bx >> 3) * MI_SIZE) * 8);
+                xd->mb_to_right_edge  = ((mi_cols - eb_vp9_num_8x8_blocks_wide_lookup[st->bsize] - (bx >> 3)) * MI_SIZE) * 8;
+                /* plane positions: luma at the block's origin, chroma at ROUND_UV(origin) >> 1 (:3692-3701) */
+                int px_[3], py_[3];
+                px_[0] = bx; py_[0] = by; px_[1] = px_[2] = ROUND_UV(bx) >> 1; py_[1] = py_[2] = ROUND_UV(by) >> 1;
+                for (int p = 0; p < n_planes; p++) {
+                    const int ps = p ? W / 2 : W;
                     generate_intra_reference_samples(scs, ctx, p);
-                    intra_prediction(ctx, pred[p] + (size_t)(y >> ss) * ps + (x >> ss), (uint16_t)ps, p);
+                    intra_prediction(ctx, pred[p] + (size_t)py_[p] * ps + px_[p], (uint16_t)ps, p);
                 }
-                for (int p = 0; p < 3; p++) {
-                    const int ss = p ? 1 : 0, ps = p ? W / 2 : W, px = x >> ss, py = y >> ss, bs = p ? st->sq_size_uv : st->sq_size;
+                for (int p = 0; p < n_planes; p++) {
+                    const int ps = p ? W / 2 : W, px = px_[p], py = py_[p], bs = p ? st->sq_size_uv : st->sq_size;
                     const TX_SIZE tx = p ? st->tx_size_uv : st->tx_size;
                     const int sbw = p ? 32 : 64;
                     const size_t co = (size_t)(sr * sb_cols + sc) * 6144 + (p == 0 ? 0 : p == 1 ? 4096 : 5120) + zorder4((px % sbw) >> 2, (py % sbw) >> 2) * 16;
@@ -181,10 +198,11 @@ int main(int argc, char **argv) {
                     memcpy(dq + co, dqs, (size_t)bs * bs * 2);
                     emap[eo[p] + (size_t)(py >> 2) * (size_t)(ps >> 2) + (size_t)(px >> 2)] = eob;
                 }
-                for (int p = 0; p < 3; p++) { /* :4110-4160 */
-                    const int ss = p ? 1 : 0, ps = p ? W / 2 : W, bs = p ? st->bwidth_uv : st->bwidth;
-                    eb_vp9_neighbor_array_unit_sample_write(na[p], rec[p], (uint32_t)ps, (uint32_t)(x >> ss), (uint32_t)(y >> ss), (uint32_t)(x >> ss),
-                                                            (uint32_t)(y >> ss), (uint32_t)bs, (uint32_t)bs, NEIGHBOR_ARRAY_UNIT_FULL_MASK);
+                for (int p = 0; p < n_planes; p++) { /* :4110-4160 */
+                    const int ps = p ? W / 2 : W, bs = p ? st->bwidth_uv : st->bwidth;
+                    eb_vp9_neighbor_array_unit_sample_write(na[p], rec[p], (uint32_t)ps, (uint32_t)px_[p], (uint32_t)py_[p], (uint32_t)px_[p],
+                                                            (uint32_t)py_[p], (uint32_t)bs, (uint32_t)bs, NEIGHBOR_ARRAY_UNIT_FULL_MASK);
+                }
                 }
             }
     FILE *o = fopen(argv[2], "wb");

@@ -10,9 +10,11 @@
  *      (VPX/vp9_reconintra.c:249-408) -> the predictors of VPX/intrapred.c:22-416
  *   -> perform_coding_loop (:365-587) with the transform type of the luma mode (eb_vp9_intra_mode_to_tx_type_lookup,
  *      vp9_reconintra.c:20-31; chroma and 32x32: DCT_DCT) -> tq_block_body (tq_core.h, the body the batch kernels use).
- * Scope: blocks of 8x8, 16x16 and 32x32 with the transform of their own size, inside the picture (what the reference codes in
- * an intra picture whose dimensions are multiples of 8, without its 4x4 blocks: they never use the above-right neighbour --
- * have_right = 0, EbEncDecProcess.c:1146 -- and never cross the picture edge).
+ * Scope: blocks of 4x4 (four to an 8x8 unit, each with its own mode), 8x8, 16x16 and 32x32 with the transform of their own size, inside
+ * the picture -- what the reference codes in an intra picture whose dimensions are multiples of 8.  None of them reads the
+ * above-right NEIGHBOUR BLOCK (have_right = 0 for blocks >= 8x8, EbEncDecProcess.c:1146; a 4x4 block in the left half of its unit
+ * reads four above-right samples, which belong to the unit above or to the 4x4 block coded just before it) and none crosses the
+ * picture edge.
  *
  * Parallelism: a block needs the reconstruction of its left, above and above-left neighbours -- and nothing else: without the
  * above-right neighbour the reference's z-order is only ONE of the orders that give its result.  The picture is cut into 32x32 luma
@@ -126,7 +128,7 @@ template <int N> __device__ __forceinline__ void intra_pred_row(const uint8_t *e
 
 /* one N x N transform block of plane `plane` at sample (x0, y0) of that plane; the whole workgroup (one wave) calls it */
 template <int N>
-__device__ __forceinline__ int intra_block(const intra_pic_dev &P, int plane, int x0, int y0, int mode, int sb, int32_t *tile, uint8_t *edge) {
+__device__ __forceinline__ int intra_block(const intra_pic_dev &P, int plane, int x0, int y0, int mode, int sb, int32_t *tile, uint8_t *edge, int have_right = 0) {
     const int lane = (int)threadIdx.x, c = plane ? 1 : 0;
     const int rs = P.rec_stride[c];
     uint8_t  *rp = P.rec[plane];
@@ -149,7 +151,10 @@ __device__ __forceinline__ int intra_block(const intra_pic_dev &P, int plane, in
             if (j < N) {
                 const uint8_t a = have_top ? rp[(size_t)(y0 - 1) * rs + x0 + j] : (uint8_t)127;
                 edge[32 + 1 + j] = a;
-                if (j == N - 1) { _Pragma("unroll") for (int q = 0; q < N; q++) edge[32 + 1 + N + q] = a; }
+                /* the right half of the row: true above-right samples for a 4x4 luma block in the left half of its unit (have_right,
+                   EbEncDecProcess.c:1146, 1279-1288), copies of the last sample otherwise */
+                if (N == 4 && have_right) edge[32 + 1 + N + j] = have_top ? rp[(size_t)(y0 - 1) * rs + x0 + N + j] : (uint8_t)127;
+                else if (j == N - 1) { _Pragma("unroll") for (int q = 0; q < N; q++) edge[32 + 1 + N + q] = a; }
             }
         }
         if (lane == 0) edge[32] = have_top ? (have_left ? rp[(size_t)(y0 - 1) * rs + x0 - 1] : (uint8_t)129) : (uint8_t)127;
@@ -219,15 +224,28 @@ __global__ __launch_bounds__(64) void svt_intra_kernel(const intra_pic_dev P) {
         const int ur = ar * 4 + r, uc = ac * 4 + c;
         if (ur >= P.mi_rows || uc >= P.mi_cols) continue;
         const svt_lf_mode_info b = P.mi[ur * P.mi_stride + uc];
-        const int w8 = b.sb_type == 3 ? 1 : b.sb_type == 6 ? 2 : b.sb_type == 9 ? 4 : 0;
+        const int sub = b.sb_type == 0; /* an 8x8 unit of four 4x4 luma blocks + one 4x4 chroma block per plane */
+        const int w8 = b.sb_type == 3 || sub ? 1 : b.sb_type == 6 ? 2 : b.sb_type == 9 ? 4 : 0;
         if (b.is_inter && P.mixed) continue;
         if (w8 == 0 || b.is_inter) { if (lane == 0) atomicOr(P.status, 1); continue; }
         if ((ur % w8) || (uc % w8)) continue;
         const int mode = plane ? b.pad_[2] : b.pad_[1];
-        if (ur + w8 > P.mi_rows || uc + w8 > P.mi_cols || b.tx_size != (w8 == 1 ? 1 : w8 == 2 ? 2 : 3) || mode > 9) { if (lane == 0) atomicOr(P.status, 1); continue; }
+        if (ur + w8 > P.mi_rows || uc + w8 > P.mi_cols || b.tx_size != (sub ? 0 : w8 == 1 ? 1 : w8 == 2 ? 2 : 3) || (!sub && mode > 9) || b.pad_[2] > 9) {
+            if (lane == 0) atomicOr(P.status, 1);
+            continue;
+        }
         const int x0 = plane ? uc * 4 : uc * 8, y0 = plane ? ur * 4 : ur * 8, nn = plane ? w8 * 4 : w8 * 8;
         int eob;
-        if (nn == 32) eob = intra_block<32>(P, plane, x0, y0, mode, sb, tile, edge);
+        if (sub && plane == 0) { /* blocks 0..3 in the reference's order, each with its own mode (nibbles of pad_[1], pad_[0]) */
+            const int m4 = (int)b.pad_[1] | (int)b.pad_[0] << 8;
+            eob = 0;
+            for (int q4 = 0; q4 < 4; q4++) {
+                const int mq = (m4 >> (4 * q4)) & 15;
+                if (mq > 9) { if (lane == 0) atomicOr(P.status, 1); continue; }
+                eob |= intra_block<4>(P, 0, x0 + 4 * (q4 & 1), y0 + 4 * (q4 >> 1), mq, sb, tile, edge, !(q4 & 1));
+            }
+        }
+        else if (nn == 32) eob = intra_block<32>(P, plane, x0, y0, mode, sb, tile, edge);
         else if (nn == 16) eob = intra_block<16>(P, plane, x0, y0, mode, sb, tile, edge);
         else if (nn == 8) eob = intra_block<8>(P, plane, x0, y0, mode, sb, tile, edge);
         else eob = intra_block<4>(P, plane, x0, y0, mode, sb, tile, edge);

@@ -24,7 +24,7 @@ namespace {
 
 /* 32x32: 54 KB of LDS per 256-thread workgroup (eight blocks + the rate tables) allow three workgroups = 12 waves per CU */
 template <int N, bool RATE, bool DIST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? 3 : 1))) void svt_tq_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ pred,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? (RATE ? 3 : 4) : 1))) void svt_tq_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ pred,
                                                      uint8_t *__restrict__ recon, const svt_tq_block *__restrict__ blocks,
                                                      int n_blocks, const svt_quant_tables *__restrict__ qtabs,
                                                      const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,

@@ -150,7 +150,7 @@ def oracle_encdec_picture(src, refs, mc_mi, lf_mi, q_index, flags, thr, use_subp
         pred = oi["pred"]
         ey = emap[e0:e1].reshape(H // 4, W // 4)
         eu, ev = emap[e1:e2].reshape(H // 8, W // 8), emap[e2:e3].reshape(H // 8, W // 8)
-        nz |= intra_units & ((ey[::2, ::2] != 0) | (eu != 0) | (ev != 0))     # set at the block's first unit
+        nz |= intra_units & ((ey.reshape(H // 8, 2, W // 8, 2) != 0).any(axis=(1, 3)) | (eu != 0) | (ev != 0))     # set at the block's first unit
     plane = (pos >> 22) & 3
     y4, x4 = (pos >> 11) & 0x7FF, pos & 0x7FF
     pw4 = np.where(plane == 0, W // 4, W // 8)
@@ -202,10 +202,15 @@ def gen_intra_grid(seed, W, H, sizes=(8, 16, 32), modes=tuple(range(10)), filter
         rec["is_inter"], rec["skip"], rec["filter_level"] = 0, 0, filter_level
         pad = rec["pad"]
         pad[..., 0], pad[..., 1], pad[..., 2] = 0, rng.choice(modes), rng.choice(modes)
+        if n8 == 1 and 4 in sizes and (8 not in sizes or rng.random() < 0.4):
+            # an 8x8 unit of four 4x4 luma blocks (+ one 4x4 chroma block per plane): modes of blocks 0..3 in nibbles
+            m4 = [int(rng.choice(modes)) for _ in range(4)]
+            rec["sb_type"], rec["tx_size"] = 0, 0
+            pad[..., 1], pad[..., 0] = m4[0] | m4[1] << 4, m4[2] | m4[3] << 4
 
     def split(r, c, n8):
         fits = r + n8 <= mi_rows and c + n8 <= mi_cols
-        allowed = (8 * n8) in sizes
+        allowed = (8 * n8) in sizes or (n8 == 1 and 4 in sizes)
         smaller = any(s < 8 * n8 for s in sizes)
         if fits and allowed and (n8 == 1 or not smaller or rng.random() < 0.45):
             put(r, c, n8)
@@ -289,8 +294,8 @@ def oracle_intra_chain(src, lf_mi, q_index, flags, thr, pad=PAD, recon_init=None
     e0, e1, e2, e3 = eob_map_offsets(W, H)
     ey = emap[e0:e1].reshape(H // 4, W // 4)
     eu, ev = emap[e1:e2].reshape(H // 8, W // 8), emap[e2:e3].reshape(H // 8, W // 8)
-    # a block's transform blocks start at its first unit (one per plane): eob of luma at (2 ur, 2 uc), chroma at (ur, uc)
-    any_nz = (ey[::2, ::2] != 0) | (eu != 0) | (ev != 0)
+    # a block's transform blocks start at its first unit (one per plane; four luma ones in a unit of 4x4 blocks)
+    any_nz = (ey.reshape(H // 8, 2, W // 8, 2) != 0).any(axis=(1, 3)) | (eu != 0) | (ev != 0)   # (a unit of 4x4 blocks has four luma entries)
     w8 = np.maximum(np.array(_W4)[lf_mi["sb_type"][:, :mi_cols]] // 2, 1)
     r, c = np.meshgrid(np.arange(mi_rows), np.arange(mi_cols), indexing="ij")
     lf_mi["skip"][:, :mi_cols] = ~any_nz[r - r % w8, c - c % w8]
@@ -326,6 +331,10 @@ def make_mixed(seed, lf_mi, mc_mi=None, share=0.3, level=None):
             blk = lf[r:r + w8, c:c + w8]
             blk["is_inter"], blk["tx_size"], blk["skip"] = 0, {3: 1, 6: 2, 9: 3}[bs], 0
             blk["pad"][..., 0], blk["pad"][..., 1], blk["pad"][..., 2] = 0, rng.integers(0, 10), rng.integers(0, 10)
+            if w8 == 1 and rng.random() < 0.35:                      # a unit of four 4x4 luma blocks, a mode each
+                m4 = rng.integers(0, 10, 4)
+                blk["sb_type"], blk["tx_size"] = 0, 0
+                blk["pad"][..., 1], blk["pad"][..., 0] = int(m4[0]) | int(m4[1]) << 4, int(m4[2]) | int(m4[3]) << 4
             if level is not None:
                 blk["filter_level"] = level
             if mc is not None:

@@ -101,6 +101,17 @@ def test_intra_picture_vs_oracle_chain(ctx, W, H, seed, q):
     assert o["eob_map"].any()
 
 
+@pytest.mark.parametrize("W,H,seed,q,sizes", [(128, 64, 31, 60, (4,)), (136, 72, 32, 120, (4, 8)), (320, 192, 33, 40, (4, 8, 16, 32)), (704, 392, 34, 160, (4, 8, 16, 32))])
+def test_intra_pictures_with_4x4_blocks(ctx, W, H, seed, q, sizes):
+    g, o = check(ctx, W, H, seed, q, KEY, sizes=sizes)
+    assert (o["lf_mi"]["sb_type"] == 0).any()
+
+
+@pytest.mark.parametrize("mode", range(10))
+def test_intra_4x4_single_mode(ctx, mode):
+    check(ctx, 96, 72, 80 + mode, 100, KEY, sizes=(4,), modes=(mode,))
+
+
 @pytest.mark.parametrize("size", [8, 16, 32])
 @pytest.mark.parametrize("mode", range(10))
 def test_intra_single_mode(ctx, size, mode):

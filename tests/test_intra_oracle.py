@@ -68,6 +68,20 @@ def test_picture_matches_reference(W, H, seed, q):
 
 
 @pytest.mark.skipif(not T.have_ref("ref_intra"), reason="reference harness not built")
+@pytest.mark.parametrize("W,H,seed,q,sizes", [(128, 64, 21, 60, (4,)), (136, 72, 22, 120, (4, 8)), (192, 128, 23, 30, (4, 8, 16, 32)), (72, 200, 24, 220, (4, 16))])
+def test_pictures_with_4x4_blocks_match_reference(W, H, seed, q, sizes):
+    """8x8 units of four 4x4 luma blocks: each with its own mode and transform type, the left ones reading true above-right samples"""
+    got = _check_picture(W, H, seed, q, sizes=sizes)
+    assert got["eob_map"].any()
+
+
+@pytest.mark.skipif(not T.have_ref("ref_intra"), reason="reference harness not built")
+@pytest.mark.parametrize("mode", range(10))
+def test_4x4_single_mode(mode):
+    _check_picture(96, 72, 60 + mode, 90, sizes=(4,), modes=(mode,))
+
+
+@pytest.mark.skipif(not T.have_ref("ref_intra"), reason="reference harness not built")
 @pytest.mark.parametrize("size", [8, 16, 32])
 @pytest.mark.parametrize("mode", range(10))
 def test_single_mode_pictures(size, mode):

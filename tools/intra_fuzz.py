@@ -18,7 +18,7 @@ B.check(B.load().svt_hip_ctx_create(C.byref(ctx), 0))
 for k in range(n_cases):
     W, H = 8 * int(rng.integers(2, 60)), 8 * int(rng.integers(2, 40))
     q = int(rng.integers(1, 256))
-    sizes = [(8,), (8, 16), (8, 32), (8, 16, 32)][int(rng.integers(0, 4))]
+    sizes = [(8,), (8, 16), (8, 32), (8, 16, 32), (4,), (4, 8), (4, 8, 16, 32), (4, 16)][int(rng.integers(0, 8))]
     modes = tuple(sorted(set(int(m) for m in rng.integers(0, 10, int(rng.integers(1, 6))))))
     cfg = dict(enc_mode=int(rng.integers(0, 10)), tune=int(rng.integers(0, 3)), temporal_layer_index=0, is_used_as_reference=1, recon_file=int(rng.integers(0, 2)),
                loop_filter=int(rng.integers(0, 2)))
