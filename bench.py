@@ -25,7 +25,7 @@ Inputs are resident in HBM before the timed region.  value = pictures / second (
 
 Contract: python bench.py --gpus N --steps K --warmup W ; for N>1 launched by torch.distributed.run, one rank per GPU;
 GOP segments are independent (closed GOPs) so ranks share nothing and the only collectives are the
-timing barrier / max-reduce.  --preset c2 | c3 | c5 selects the BASELINE.json configuration (default c3, the one `metric` is quoted on).
+timing barrier / max-reduce.  --preset c1 | c2 | c3 | c5 selects the BASELINE.json configuration (default c3, the one `metric` is quoted on).
 """
 import argparse
 import ctypes as C
@@ -43,6 +43,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W4K, H4K = 3840, 2160
 PRESETS = {   # BASELINE.json configs: (width, height, enc_mode, tune)
+    "c1": (640, 360, 9, 1),    # the reference's own CPU-runnable case (its parameters; there is no CPU path here)
     "c2": (1920, 1080, 8, 1),
     "c3": (W4K, H4K, 8, 1),
     "c5": (W4K, H4K, 3, 0),
