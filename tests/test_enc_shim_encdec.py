@@ -84,14 +84,14 @@ def stand_in(me, W, H, lam, level):
     return mc, lf
 
 
-def run_clip(W, H, N, enc_mode, tune, qp, recon_file, intra_period, use_callback, seed=41, env=None):
+def run_clip(W, H, N, enc_mode, tune, qp, recon_file, intra_period, use_callback, seed=41, env=None, frames=None):
     """returns (frames, delivered reconstructions {pts: bytes}, order of delivery, per-picture info, padded reference pictures of some pictures)"""
     lib = shim()
     for f_ in ("svt_vp9_shim_get_me_results", "svt_vp9_shim_get_coded_picture", "svt_vp9_shim_get_reference_picture", "svt_vp9_shim_set_mode_decision", "eb_vp9_svt_get_packet",
                "eb_vp9_svt_enc_send_picture", "eb_vp9_svt_get_recon"):
         getattr(lib, f_).restype = C.c_int32
     lib.eb_vp9_svt_release_out_buffer.restype = None
-    frames = T.gen_clip_subpel(W, H, N, seed)
+    frames = T.gen_clip_subpel(W, H, N, seed) if frames is None else frames
     cfg, h = Cfg(), C.c_void_p()
     assert lib.eb_vp9_svt_init_handle(C.byref(h), None, C.byref(cfg)) == 0
     cfg.source_width, cfg.source_height, cfg.enc_mode, cfg.tune, cfg.frame_rate, cfg.intra_period, cfg.qp, cfg.recon_file = W, H, enc_mode, tune, 60 << 16, intra_period, qp, recon_file
@@ -353,3 +353,18 @@ def test_without_recon_output_only_reference_pictures_are_reconstructed():
         if i.pad_reference:
             assert np.array_equal(refpics[k], recs[k].buf[:refpics[k].size]), k
     assert kinds == {(1, 1, 1), (1, 0, 1), (0, 0, 0)}
+
+
+def test_long_clip_reuses_every_picture_slot_several_times():
+    """90 pictures with an intra refresh every 40: every slot of the 34-picture ring is overwritten two or three times while the input,
+    main and output streams run side by side -- a slot must not be overwritten before its last reader (the marker chain of the library)
+    nor read before its upload.  Every reconstruction still equals the oracle chain."""
+    W, H, N, enc_mode, tune, qp, intra_period = 136, 72, 90, 8, 1, 40, 39
+    base = T.gen_clip_subpel(W, H, 30, 53)
+    clip = [base[i % 30] if (i // 30) % 2 == 0 else base[29 - i % 30] for i in range(N)]          # 30 pictures forth and back
+    frames, recon, order, flags_seen, packets, infos, refpics, _ = run_clip(W, H, N, enc_mode, tune, qp, 1, intra_period, False, frames=clip)
+    recs, outs = oracle_clip(frames, W, H, N, enc_mode, tune, qp, 1, intra_period, False)
+    assert sorted(order) == list(range(N)) and len(packets) == N and packets[-1][1] & 1 and flags_seen[-1] == 1
+    for k in range(N):
+        y, u, v = recs[k].interior()
+        assert np.array_equal(recon[k], np.concatenate([y.ravel(), u.ravel(), v.ravel()])), k
