@@ -22,11 +22,11 @@
  * (r, c - 1) and (r - 1, c) are done: an anti-diagonal wavefront over the areas, times three independent planes.  One 64-lane
  * workgroup codes one (area, plane) at a time; the workgroups (one per CU, persistent) take TICKETS (an atomic counter) that enumerate
  * the (area, plane) pairs diagonal by diagonal, so a workgroup only ever waits for tickets smaller than its own -- which are held by
- * workgroups that already run or are done: no deadlock whatever the dispatch order, no co-residency requirement.  A block is N x N with N lanes active (lane i = row i of the
- * prediction, then column / row i of the transform); the chain of dependent blocks, not the lane count, bounds the speed: a 2160p key
- * frame is 187 diagonals of at most 68 areas.  This kernel is latency-bound by design (one picture in a GOP); it shares the GPU with
+ * workgroups that already run or are done: no deadlock whatever the dispatch order, no co-residency requirement.  A block is N x N
+ * with N lanes active (lane i = row i of the prediction, then column / row i of the transform); the chain of dependent blocks, not
+ * the lane count, bounds the speed: a 2160p key frame is 187 diagonals of at most 68 areas.  This kernel is latency-bound by design (one picture in a GOP); it shares the GPU with
  * the batches of the inter pictures running beside it.
- * Visibility between workgroups (other CUs, other XCDs' L2): release fence + flag store when an SB is done, flag load + acquire
+ * Visibility between workgroups (other CUs, other XCDs' L2): release fence + flag store when an area is done, flag load + acquire
  * fence before the first reference-sample load; inside a workgroup the block's stores are drained (workgroup fence) before the
  * next block reads them.
  */
@@ -142,7 +142,7 @@ __device__ __forceinline__ int intra_block(const intra_pic_dev &P, int plane, in
         _Pragma("unroll") for (int q = 0; q < N / 4; q++) srow[q] = 0u;
         if (active) row_load<N>(sp, ((uintptr_t)sp & AM) == 0, srow);
     }
-    /* reference samples -> LDS (generate_intra_reference_samples, the paths of a block >= 8x8 inside the picture) */
+    /* reference samples -> LDS (generate_intra_reference_samples, the paths of a block inside the picture) */
     {
         const int j = lane & 31;
         if (lane < 32) { /* left column */
