@@ -89,3 +89,30 @@ def test_hip_me_vs_reference_motion_estimate_sb(ctx, name, layer):
         assert not bad, (name, layer, s0, s1, bad)
         checked += s1 - s0
     assert checked >= min(nsb, 160)
+
+
+@pytest.mark.skipif(not T.have_ref("ref_intra"), reason="oracle/_ref/ref_intra not built")
+@pytest.mark.parametrize("W,H,seed,q,sizes", [(320, 192, 3, 100, (8, 16, 32)), (136, 200, 4, 40, (4, 8, 16, 32)), (704, 392, 5, 180, (4, 8, 16, 32))])
+def test_hip_intra_pass_vs_reference_functions(ctx, W, H, seed, q, sizes):
+    """the GPU's intra pass against the REFERENCE's own generate_intra_reference_samples + intra_prediction + perform_coding_loop +
+    neighbour-array writer (oracle/_ref/ref_intra, travels to the box prebuilt), with no oracle in between: prediction, coefficients,
+    eob of every block and the reconstruction before deblocking"""
+    import encdec_model as M
+    import test_gpu_intra as TI
+    from test_gpu_encdec import flags_of
+    lib = B.load()
+    src = T.gen_yuv(W, H, seed)
+    mi = M.gen_intra_grid(seed, W, H, sizes=sizes)
+    flags = flags_of(enc_mode=8, tune=1, temporal_layer_index=0, is_used_as_reference=1, recon_file=0, loop_filter=0)   # no deblocking: what the harness returns
+    assert not flags.apply_loop_filter
+    thr = B.LfThresh()
+    lib.svt_hip_lf_thresh_init(C.byref(thr), 0)
+    rec = M.RefPic(W, H)
+    g = TI.run_intra(ctx, src, mi, q, flags, thr, rec)
+    assert g["rc"] == 0
+    want = M.ref_intra_picture(src, mi, q)
+    assert np.array_equal(g["pred"], np.concatenate([p.ravel() for p in want["pred"]])), "prediction"
+    assert np.array_equal(g["q"], want["qcoeff"]) and np.array_equal(g["dq"], want["dqcoeff"]), "coefficients"
+    assert np.array_equal(g["emap"], want["eob_map"]) and want["eob_map"].any(), "eob"
+    for a, b in zip(rec.interior(g["rec"]), want["rec"]):
+        assert np.array_equal(a, b), "reconstruction"
