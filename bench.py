@@ -179,6 +179,25 @@ def build_native_oracle():
     return out
 
 
+def intra_pass_times():
+    """The encode pass of a key frame (svt_hip_encdec_intra_device: wavefront prediction + transform, then deblocking and border) is not
+    part of the step -- one picture per GOP, latency-bound, beside the inter batches.  tools/intra_time.py times it alone on one 2160p
+    picture (inputs resident, wall clock around call + synchronisation) for uniform block sizes and a random partition."""
+    exe = os.path.join(ROOT, "tools", "intra_time.py")
+    if not os.path.exists(exe):
+        return None
+    r = subprocess.run([sys.executable, exe], capture_output=True, text=True)
+    if r.returncode != 0:
+        return {"error": (r.stdout + r.stderr).strip()[-200:]}
+    ms = {}
+    for line in r.stdout.splitlines():
+        if line.rstrip().endswith(" ms"):
+            name, val = line.rsplit(None, 2)[0].strip(), float(line.rsplit(None, 2)[1])
+            ms[name] = val
+    return {"ms_per_2160p_picture": ms, "what": "svt_hip_encdec_intra_device on one 3840x2160 picture, q index 140, deblocking + border included; one 64-lane "
+                                              "workgroup per CU draws (32x32 area, plane) tickets in anti-diagonal order: 187 dependent area steps per picture"}
+
+
 def api_path_rate(frames, Wd, Hd, enc_mode, tune, n_send=130):
     """SURVEY 8(d)'s metric through the PUBLIC API (libSvtVp9Enc.so, the reference's eb_vp9_svt_* entry points): wall-clock from the
     first send_picture to the EOS packet, host buffers handed over (PCIe inside the clock: all three planes of every picture), measured
@@ -1018,6 +1037,9 @@ def main():
         api = api_path_rate(frames0, Wd, Hd, enc_mode, tune)
         if api is not None:
             out["api_path"] = api
+        ip = intra_pass_times()
+        if ip is not None:
+            out["intra_pass"] = ip
     print(json.dumps(out))
 
 
