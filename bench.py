@@ -235,7 +235,7 @@ def api_path_rate(frames, Wd, Hd, enc_mode, tune, n_send=130):
                     "(app/svt_enc_api_bench.c): first send_picture -> EOS packet, host buffers in (Y, Cb, Cr), PCIe included; every stage of the path behind the "
                     "API, one mini-GOP at a time (uploads + picture analysis on an input stream, reconstruction copies on an output stream, beside the main stream), the stage flags per picture as the reference derives them (recon_file = 0: deblocking on base-layer pictures "
                     "only, no reconstruction of the deepest layer; with_recon_output: recon_file = 1, all pictures reconstructed + deblocked and fetched with "
-                    "eb_vp9_svt_get_recon); zero-byte packets (no entropy coding); picture 0 is a key frame coded by the intra encode pass (svt_hip_encdec_intra_device, stand-in decision: 16x16 DC), ~6.5 ms of the run"}
+                    "eb_vp9_svt_get_recon); zero-byte packets (no entropy coding); picture 0 is a key frame coded by the intra encode pass (svt_hip_encdec_intra_device, stand-in decision: 16x16 DC), ~6.2 ms of the run"}
 
 
 def reference_me_rate(T, B, orc, frames, Wd, Hd, enc_mode, tune, l1_on, ncpu):
