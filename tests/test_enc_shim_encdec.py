@@ -173,7 +173,7 @@ def run_clip(W, H, N, enc_mode, tune, qp, recon_file, intra_period, use_callback
         b = Hdr(size=C.sizeof(Hdr), p_buffer=rbuf.ctypes.data, n_alloc_len=rbuf.size)
         assert lib.eb_vp9_svt_get_recon(h, C.byref(b)) == 0x7FFFFFFF        # recon is not enabled: EB_ErrorMax, as the reference
     rp = M.RefPic(W, H)
-    for k in range(max(0, N - 20), N):
+    for k in range(max(0, N - (16 if tune == 0 else 20)), N):      # (the library keeps 2 mini-GOPs + 2 pictures)
         info = PicInfo()
         mc = np.zeros((H // 8, W // 8), dtype=B.MC_MODE_INFO_DTYPE)
         lf = np.zeros((H // 8, W // 8), dtype=B.LF_MODE_INFO_DTYPE)
@@ -368,3 +368,18 @@ def test_long_clip_reuses_every_picture_slot_several_times():
     for k in range(N):
         y, u, v = recs[k].interior()
         assert np.array_equal(recon[k], np.concatenate([y.ravel(), u.ravel(), v.ravel()])), k
+
+
+def test_enc_mode_3_tune_0_through_the_api():
+    """BASELINE C5's parameters behind the public API: tune 0 (SQ) -> 3 hierarchical levels, 8-picture mini-GOPs; enc-mode 3 -> the 64x64
+    search area with the SSD sub-pel search on every PU (the C5 instances of the ME kernel), the SQ variant of the stage flags.  Every
+    reconstruction equals the oracle chain."""
+    W, H, N, enc_mode, tune, qp = 192, 136, 19, 3, 0, 36
+    frames, recon, order, flags_seen, packets, infos, refpics, _ = run_clip(W, H, N, enc_mode, tune, qp, 1, -1, False, seed=61)
+    recs, outs = oracle_clip(frames, W, H, N, enc_mode, tune, qp, 1, -1, False)
+    assert sorted(order) == list(range(N)) and len(packets) == N
+    for k in range(N):
+        y, u, v = recs[k].interior()
+        assert np.array_equal(recon[k], np.concatenate([y.ravel(), u.ravel(), v.ravel()])), (k, outs[k].get("layer"))
+    levels = {d["info"].hierarchical_levels for k, d in infos.items() if not outs[k]["intra"]}
+    assert levels <= {0, 1, 2, 3} and 3 in levels
