@@ -383,3 +383,16 @@ def test_enc_mode_3_tune_0_through_the_api():
         assert np.array_equal(recon[k], np.concatenate([y.ravel(), u.ravel(), v.ravel()])), (k, outs[k].get("layer"))
     levels = {d["info"].hierarchical_levels for k, d in infos.items() if not outs[k]["intra"]}
     assert levels <= {0, 1, 2, 3} and 3 in levels
+
+
+@pytest.mark.parametrize("enc_mode,tune", [(5, 2), (9, 1), (0, 1), (6, 0)])
+def test_other_presets_through_the_api(enc_mode, tune):
+    """more corners of the preset table behind the API (VMAF tune, the fastest and the slowest enc-modes, SQ at enc-mode 6): the ME
+    parameters, the mini-GOP structure and the stage flags the library derives must be the ones the oracle chain is run with"""
+    W, H, N, qp = 136, 72, 20, 44
+    frames, recon, order, flags_seen, packets, infos, refpics, _ = run_clip(W, H, N, enc_mode, tune, qp, 1, -1, False, seed=70 + enc_mode)
+    recs, outs = oracle_clip(frames, W, H, N, enc_mode, tune, qp, 1, -1, False)
+    assert sorted(order) == list(range(N)) and len(packets) == N
+    for k in range(N):
+        y, u, v = recs[k].interior()
+        assert np.array_equal(recon[k], np.concatenate([y.ravel(), u.ravel(), v.ravel()])), (k, outs[k].get("layer"))
