@@ -167,6 +167,9 @@ int32_t svt_hip_me_params_preset(svt_me_params *p, int32_t pic_width, int32_t pi
 /* diagnostic: which compiled instance of the ME kernel serves a parameter set -- 0 the generic one, > 0 an instance whose search
  * parameters are compile-time constants (one per BASELINE configuration; identical results by construction) */
 int32_t svt_hip_me_kernel_instance(const svt_me_params *p);
+/* diagnostic: the instance the last ME launch on ctx actually ran -- the index above, + 100 when the launch was served by the
+ * driver for single-region level-0 HME presets (csrc/me_fast.h: whole SB columns, level-0 areas up to 256 x 256) */
+int32_t svt_hip_me_last_instance(const svt_hip_ctx *ctx);
 /* 1 when two parameter sets may share one launch of svt_hip_me_batch_layers_device: equal in every field but num_ref_lists,
  * temporal_layer_index, hierarchical_levels and same_ref_poc (compared field by field: the record has padding) */
 int32_t svt_hip_me_params_same_launch(const svt_me_params *a, const svt_me_params *b);

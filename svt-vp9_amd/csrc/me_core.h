@@ -237,6 +237,7 @@ typedef struct me_pic_dev {
      * them (HME level-0 areas scaled by the temporal layer's multiplier): one launch serves pictures of several layers */
     uint8_t           num_ref_lists, temporal_layer_index, hierarchical_levels, same_ref_poc;
     int16_t           hme_w0[2], hme_h0[2], hme_tw0, hme_th0;
+    int16_t           hme_band; /* me_fast.h: search rows of the (widest) level-0 window that fit the LDS scratch at a time */
 } me_pic_dev;
 
 /* LDS layout (byte offsets), computed on the host from the parameters (me_lds_layout) */
@@ -1575,7 +1576,10 @@ SVT_DEV void ph_output(const me_ctx_t *c, int tid, svt_me_pu_result *out, uint32
 #else
 #define ME_STOP_AT(i) ((void)0)
 #endif
-#ifdef ME_FINE_PROF
+#if defined(ME_ASM_MARKS)
+/* static instruction counts (tools/me_static_counts.py): a comment in the assembly at every mark */
+#define ME_MARK(i) __asm__ volatile("; @MARK %0" ::"n"(i))
+#elif defined(ME_FINE_PROF)
 /* instruction-count profiling builds: the kernel stops (all threads) at mark g_me_stop_after of the first list, so
  * that per-dispatch SQ counters of successive launches give cumulative instruction counts per phase */
 __device__ int g_me_stop_after = -1;

@@ -4,6 +4,7 @@
  */
 #include <hip/hip_runtime.h>
 #include "me_core.h"
+#include "me_fast.h"
 #include "me_layout.h"
 #include "me_spec.h"
 #include "svt_ctx.h"
@@ -26,9 +27,9 @@ extern __shared__ __align__(16) uint8_t svt_lds[];
 /* One workgroup per (picture, SB).  blockIdx -> work item mapping is XCD-aware: consecutive work items
  * (neighbouring SBs, which share most of their reference window) are placed on the same XCD so that the
  * window re-reads hit that XCD's L2 (block b runs on XCD b % 8). */
-template <int SPEC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC == 0 ? ME_WAVES_PER_EU : me_spec_waves_per_eu(SPEC) == 5 ? ME_WAVES_PER_EU_SPEC : me_spec_waves_per_eu(SPEC)))) void svt_me_sb_kernel(const me_pic_dev *__restrict__ pics, svt_me_params p, me_lds_layout L,
-                                                        int n_sb, int nx, int pic_w, int pic_h, int total, int chunk, unsigned long long *prof) {
+template <int SPEC, bool FAST>
+__device__ __forceinline__ void me_kernel_body(const me_pic_dev *__restrict__ pics, svt_me_params p, me_lds_layout L, int n_sb, int nx, int pic_w, int pic_h,
+                                               int total, int chunk, unsigned long long *prof) {
     /* block b runs on XCD b & 7: XCD k takes the k-th eighth of the SBs of EVERY picture (chunk SBs each; pictures of different
      * temporal layers cost differently, an XCD per picture range would leave the XCDs unbalanced), in picture order */
     const int b = blockIdx.x, j = b >> 3;
@@ -67,7 +68,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC == 0 ?
     c.sb_x = (sb % nx) * ME_SB; c.sb_y = (sb / nx) * ME_SB;
     c.sb_w = (pic_w - c.sb_x) < ME_SB ? pic_w - c.sb_x : ME_SB;
     c.sb_h = (pic_h - c.sb_y) < ME_SB ? pic_h - c.sb_y : ME_SB;
-    me_sb_run(&c, threadIdx.x);
+    if constexpr (FAST) me_sb_run_fast<SPEC>(&c, threadIdx.x);
+    else me_sb_run(&c, threadIdx.x);
+}
+#define ME_KERNEL_ATTRS(SPEC) __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC == 0 ? ME_WAVES_PER_EU : me_spec_waves_per_eu(SPEC) == 5 ? ME_WAVES_PER_EU_SPEC : me_spec_waves_per_eu(SPEC))))
+template <int SPEC>
+ME_KERNEL_ATTRS(SPEC) void svt_me_sb_kernel(const me_pic_dev *__restrict__ pics, svt_me_params p, me_lds_layout L,
+                                                        int n_sb, int nx, int pic_w, int pic_h, int total, int chunk, unsigned long long *prof) {
+    me_kernel_body<SPEC, false>(pics, p, L, n_sb, nx, pic_w, pic_h, total, chunk, prof);
+}
+/* the same for the presets me_fast.h serves (me_spec_fast), pictures of whole SB columns and level-0 areas up to 256 x 256 */
+template <int SPEC>
+ME_KERNEL_ATTRS(SPEC) void svt_me_fast_kernel(const me_pic_dev *__restrict__ pics, svt_me_params p, me_lds_layout L,
+                                                          int n_sb, int nx, int pic_w, int pic_h, int total, int chunk, unsigned long long *prof) {
+    me_kernel_body<SPEC, true>(pics, p, L, n_sb, nx, pic_w, pic_h, total, chunk, prof);
 }
 
 /* Stand-alone exhaustive SAD search = eb_vp9_sad_loop_kernel (C_DEFAULT/EbComputeSAD_C.c:132-169), one
@@ -156,6 +170,7 @@ static int32_t me_launch(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture 
     /* picture descriptors -> device (pinned staging ring so that the copy is truly asynchronous) */
     me_pic_dev *h = nullptr, *d = nullptr;
     if (svt_ctx_stage(ctx, sizeof(me_pic_dev) * (size_t)n_pics, (void **)&h, (void **)&d)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "me: descriptor buffers");
+    bool fast_ok = (W & 63) == 0; /* me_fast.h: whole SB columns, level-0 areas whose positions fit 8 bits */
     for (int i = 0; i < n_pics; i++) {
         if (cur[i].full.width != W || cur[i].full.height != H) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me: batch pictures differ in size");
         memset(&h[i], 0, sizeof h[i]);
@@ -171,6 +186,14 @@ static int32_t me_launch(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture 
         h[i].hierarchical_levels = q->hierarchical_levels; h[i].same_ref_poc = q->same_ref_poc;
         h[i].hme_w0[0] = Li.hme_w0[0]; h[i].hme_w0[1] = Li.hme_w0[1]; h[i].hme_h0[0] = Li.hme_h0[0]; h[i].hme_h0[1] = Li.hme_h0[1];
         h[i].hme_tw0 = Li.hme_tw0; h[i].hme_th0 = Li.hme_th0;
+        {   /* me_fast.h: rows of the widest level-0 window (area + 16 x 8 block + alignment slack, odd dword stride) per scratch fill */
+            const int wbytes = Li.hme_tw0 + 16 + 3;
+            int       ws = ((wbytes + 3) & ~3) + 4;
+            if (((ws >> 2) & 1) == 0) ws += 4;
+            const int band = Li.scratch_bytes / ws - 14;
+            h[i].hme_band = (int16_t)(band > 256 ? 256 : band);
+            if (band < 1 || Li.hme_tw0 > 256 || Li.hme_th0 > 256) fast_ok = false;
+        }
     }
     HIP_TRY(hipMemcpyAsync(d, h, sizeof(me_pic_dev) * (size_t)n_pics, hipMemcpyHostToDevice, ctx->stream));
     const int total = n_sb * n_pics, chunk = (n_sb + 7) / 8; /* SBs of one picture per XCD */
@@ -187,7 +210,15 @@ static int32_t me_launch(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture 
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
     /* the instance specialised for the caller's parameter set when there is one (me_spec.h), else the generic one */
     static const bool no_spec = getenv("SVT_HIP_ME_GENERIC") != nullptr;
-    switch (no_spec ? 0 : me_spec_match(params)) {
+    static const bool no_fast = getenv("SVT_HIP_ME_NOFAST") != nullptr;
+    const int spec = no_spec ? 0 : me_spec_match(params);
+    ctx->me_instance = spec;
+    if (spec == 1 && fast_ok && !no_fast) { /* the instances of me_spec_fast() */
+        static_assert(me_spec_fast(1), "SPEC 1 is served by me_fast.h");
+        ctx->me_instance = 101;
+        hipLaunchKernelGGL(svt_me_fast_kernel<1>, dim3(chunk * 8 * n_pics), dim3(256), L.total_bytes, ctx->stream, d, *params, L, n_sb, nx, W, H, total, chunk, d_prof);
+    } else
+    switch (spec) {
 #define ME_LAUNCH(S) \
     if (L.total_bytes > 64 * 1024) \
         HIP_TRY(hipFuncSetAttribute((const void *)svt_me_sb_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total_bytes)); \
@@ -225,6 +256,8 @@ static int32_t me_launch(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture 
 
 /* which compiled instance serves a parameter set: 0 = the generic one, 1..ME_SPEC_COUNT = a specialised one (me_spec.h) */
 extern "C" int32_t svt_hip_me_kernel_instance(const svt_me_params *p) { return p ? me_spec_match(p) : -1; }
+/* the instance the last ME launch on this context actually ran: the me_spec.h index, + 100 when it was me_fast.h's driver */
+extern "C" int32_t svt_hip_me_last_instance(const svt_hip_ctx *ctx) { return ctx ? ctx->me_instance : -1; }
 
 extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture *cur,
                                            const svt_pa_picture *ref0, const svt_pa_picture *ref1,

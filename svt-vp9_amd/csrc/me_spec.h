@@ -30,6 +30,13 @@ static constexpr me_spec_vals ME_SPECS[ME_SPEC_COUNT] = {
  * instances need 58.5 KB of LDS -- two workgroups per CU whatever the registers -- so they may use 256 VGPRs (no spills) */
 constexpr int me_spec_waves_per_eu(int spec) { return spec >= 4 ? 2 : 5; }
 
+/* the instances me_fast.h's driver serves: one HME region at the 1/16 level only, SUB_SAD refinement of the 32x32 / 16x16 PUs */
+constexpr bool me_spec_fast(int spec) {
+    return spec >= 1 && spec <= ME_SPEC_COUNT && ME_SPECS[spec - 1].hme && ME_SPECS[spec - 1].l0 && !ME_SPECS[spec - 1].l1 && !ME_SPECS[spec - 1].l2 &&
+           ME_SPECS[spec - 1].single_quadrant && ME_SPECS[spec - 1].method == 0 && ME_SPECS[spec - 1].model == 1 && !ME_SPECS[spec - 1].f64 &&
+           ME_SPECS[spec - 1].cu16 == 0 && ME_SPECS[spec - 1].cu8 == 1;
+}
+
 /* overwrite the configuration-constant fields of *p with the constants of SPEC (1..ME_SPEC_COUNT) */
 template <int SPEC> __host__ __device__ inline void me_spec_apply(svt_me_params *p) {
     static_assert(SPEC >= 1 && SPEC <= ME_SPEC_COUNT, "no such specialisation");

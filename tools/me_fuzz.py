@@ -1,5 +1,6 @@
 """Randomised parity sweep of the ME kernel against the oracle (GPU): random picture sizes (incl. partial SBs), content kinds
-(smooth motion, noise, flat / tie-heavy, blocky), presets, list counts and temporal layers.  tools/me_fuzz.py [cases] [seed]"""
+(smooth motion, noise, flat / tie-heavy, blocky), presets, list counts and temporal layers.  tools/me_fuzz.py [cases] [seed] [fast]
+`fast`: the 2160p enc-mode-8 preset on pictures of whole SB columns only (csrc/me_fast.h's driver; the run checks that it served)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,6 +10,8 @@ B = T.B; lib = B.load()
 ctx = C.c_void_p(); B.check(lib.svt_hip_ctx_create(C.byref(ctx), 0))
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+fast = len(sys.argv) > 3 and sys.argv[3] == "fast"
+lib.svt_hip_me_last_instance.argtypes = [C.c_void_p]
 
 def content(kind, w, h):
     if kind == 0: return list(T.gen_clip(w, h, 3, int(rng.integers(1 << 20))))
@@ -33,12 +36,14 @@ for i in range(n_cases):
     w, h = 8 * int(rng.integers(16, 56)), 8 * int(rng.integers(12, 40))
     kind = int(rng.integers(0, 5)); name = names[int(rng.integers(len(names)))]
     nl = int(rng.integers(1, 3)); tl = int(rng.integers(0, 5))
+    if fast: w, name = 64 * int(rng.integers(2, 8)), "c3_2160p_m8"
     pics = [T.PaPic(f) for f in content(kind, w, h)]
     p = MC.preset(name, nl, tl)
     if nl == 2 and rng.integers(0, 4) == 0: p.same_ref_poc = 1
     r1 = pics[2] if nl == 2 else None
     o, _ = T.oracle_me_picture(pics[1], pics[0], r1, p)
     g = hip(pics[1], pics[0], r1, p)
+    if fast and not os.environ.get("SVT_HIP_ME_NOFAST"): assert lib.svt_hip_me_last_instance(ctx) == 101, lib.svt_hip_me_last_instance(ctx)
     m = T.me_results_equal(o, g, nl)
     if m:
         bad += 1
