@@ -36,8 +36,10 @@ constexpr bool me_fast_params_ok(uint8_t hme, uint8_t l0, uint8_t l1, uint8_t l2
 
 /* accumulators of the centre tests: slot s = 2 * list + (0: test_search_area_bounds, 1: check_zero_zero_center), two 64-bit
  * words each, zeroed once per SB; they live in the bytes of hme_sad (the general driver's per-level results: unused here) */
-#ifdef ME_ASM_MARKS /* static instruction counts (tools/me_static_counts.py): a comment in the assembly at every mark */
+#if defined(ME_ASM_MARKS) /* static instruction counts (tools/me_static_counts.py): a comment in the assembly at every mark */
 #define FME_MARK(i) __asm__ volatile("; @MARK %0" ::"n"(i))
+#elif defined(ME_FINE_PROF) /* dynamic counts and times per phase (tools/me_phase_profile.sh): the kernel ends at mark g_me_stop_after of list 0 */
+#define FME_MARK(i) do { if (g_me_stop_after == (i)) return; } while (0)
 #else
 #define FME_MARK(i) ((void)0)
 #endif
@@ -46,6 +48,20 @@ constexpr bool me_fast_params_ok(uint8_t hme, uint8_t l0, uint8_t l1, uint8_t l2
 #define FME_HKEY(st, l) ((uint32_t *)(st)->hme_keys + (l))
 /* su_pel_enable decision of the current list: bit 0 = 32x32, bit 1 = 16x16 */
 #define FME_GATE(st) (&(st)->supel[0])
+/* Source planes of the sub-pel candidates as byte offsets, built once per SB (fph_init) in the bytes of spu (the general
+ * driver's refined-PU list: unused here).  QTAB[method * 8 + position]: the two planes a quarter-pel candidate averages
+ * (set_quarter_pel_refinement_inputs_on_the_fly :2290-2465); BTAB[frac]: the plane(s) of a prediction at a quarter-pel vector
+ * (select_buffer :3310 / quarter_pel_compensation :3358; one plane: twice the same).  A source is 16 bits: bit 15 = the integer
+ * plane (search region), bits 0-14 = 128 + byte offset from the lane's position in that class of planes (B / H / J share a
+ * stride and lie plane_bytes apart). */
+#define FME_QTAB(st) ((uint32_t *)(st)->spu)
+#define FME_BTAB(st) ((uint32_t *)(st)->spu + 32)
+SVT_DEV uint32_t fme_src_code(const me_ctx_t *c, int plane, int dx, int dy) {
+    return plane == ME_PF ? (0x8000u | (uint32_t)(128 + ME_MUL(dy, c->L.region_stride) + dx))
+                          : (uint32_t)(128 + ME_MUL(plane - 1, c->L.plane_bytes) + ME_MUL(dy, c->L.plane_stride) + dx);
+}
+
+typedef uint64_t __attribute__((aligned(4))) fme_u64a4; /* a dword pair in LDS: ds_read2_b32 */
 
 /* inclusive sums over the wave: total in lane 63 (row_shr 1, 2, 4, 8, then row_bcast:15 into rows 1 / 3 and row_bcast:31 into
  * rows 2 / 3) */
@@ -69,6 +85,16 @@ SVT_DEV void fph_init(const me_ctx_t *c, int tid, int do_hme) {
     if (tid >= 96 && tid < 118) ((uint32_t *)st->dir)[tid - 96] = 0;
     if (tid >= 128 && tid < 144) ((uint32_t *)st->hme_sad)[tid - 128] = 0;
     if (tid >= 160 && tid < 162) FME_HKEY(st, tid - 160)[0] = 0xffffffffu;
+    if (tid >= 192 && tid < 224) {
+        const uint32_t e = me_qtab_get((tid - 192) >> 3, (tid - 192) & 7);
+        FME_QTAB(st)[tid - 192] = fme_src_code(c, (int)(e & 3), -(int)((e >> 2) & 1), -(int)((e >> 3) & 1)) |
+                                  (fme_src_code(c, (int)((e >> 4) & 3), -(int)((e >> 6) & 1), -(int)((e >> 7) & 1)) << 16);
+    }
+    if (tid >= 224 && tid < 240) {
+        int            has_b;
+        const uint32_t e = me_btab_get(tid - 224, &has_b), a = fme_src_code(c, (int)(e & 3), (int)((e >> 2) & 1), (int)((e >> 3) & 1));
+        FME_BTAB(st)[tid - 224] = a | ((has_b ? fme_src_code(c, (int)((e >> 4) & 3), (int)((e >> 6) & 1), (int)((e >> 7) & 1)) : a) << 16);
+    }
     const svt_plane *cf = &c->pic->cur.full;
     {
         const uint8_t *g = me_pix(cf, c->sb_x, c->sb_y);
@@ -174,10 +200,29 @@ template <int WS> SVT_DEV void fph_hme_search(const me_ctx_t *c, int tid, int ws
     const int      ws = WS ? WS : ws_rt, ng = sw >> 2, ntask = ME_MUL(ng, nr);
     const uint32_t inv = me_magics.v[ng]; /* ng in [4, 64] */
     uint32_t       b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu, b3 = 0xffffffffu;
+    const uint32_t *blk = (const uint32_t *)c->st->sixteenth_sb; /* the block: 8 rows of 4 dwords (same address in every lane: broadcast reads) */
     for (int T = tid; T < ntask; T += SVT_NT) {
         const int y = (int)__umulhi((uint32_t)T, inv), g = T - ME_MUL(y, ng);
-        uint32_t  lo, hi;
-        me_qsad_16x8(c->st->sixteenth_sb, c->planes + ME_MUL(y, ws) + 4 * g, ws, &lo, &hi);
+        /* byte offsets (inside the workgroup's LDS) of the task's first window dword and of the one after it, opaque to the compiler:
+         * every QSAD operand pair (w[i], w[i + 1]) is then read as such by one ds_read2_b32 at an immediate offset -- the pairs of even
+         * i from the first stream, of odd i from the second; nothing is assembled with register moves.  Window rows 12 and 14 lie
+         * beyond the 8-bit dword offsets of ds_read2 when the stride is large: a second pair of bases serves them. */
+        uint32_t o0 = (uint32_t)(c->planes - c->lds) + (uint32_t)(ME_MUL(y, ws) + 4 * g), o1 = o0 + 4, o2 = o0 + 12 * ws, o3 = o2 + 4;
+        __asm__("" : "+v"(o0));
+        __asm__("" : "+v"(o1));
+        __asm__("" : "+v"(o2));
+        __asm__("" : "+v"(o3));
+        uint64_t acc0 = 0, acc1 = 0;
+        _Pragma("unroll") for (int j = 0; j < 8; j++) {
+            const uint8_t *wa = c->lds + (j < 6 ? o0 + 2 * j * ws : o2 + 2 * (j - 6) * ws), *wb = c->lds + (j < 6 ? o1 + 2 * j * ws : o3 + 2 * (j - 6) * ws);
+            uint64_t       a = (j & 1) ? acc1 : acc0;
+            a = svt_qsad(*(const fme_u64a4 *)wa, blk[4 * j], a);
+            a = svt_qsad(*(const fme_u64a4 *)wb, blk[4 * j + 1], a);
+            a = svt_qsad(*(const fme_u64a4 *)(wa + 8), blk[4 * j + 2], a);
+            a = svt_qsad(*(const fme_u64a4 *)(wb + 8), blk[4 * j + 3], a);
+            if (j & 1) acc1 = a; else acc0 = a;
+        }
+        const uint32_t lo = (uint32_t)acc0 + (uint32_t)acc1, hi = (uint32_t)(acc0 >> 32) + (uint32_t)(acc1 >> 32); /* 8 rows x 16 x 255 < 2^16 */
         const uint32_t pos = ((uint32_t)(y0 + y) << 8) | (uint32_t)(4 * g);
         /* one running minimum per position of the group; the position's offset inside the group is added at the end */
         const uint32_t k0 = (lo << 16) | pos, k1 = (lo & 0xffff0000u) | pos, k2 = (hi << 16) | pos, k3 = (hi & 0xffff0000u) | pos;
@@ -194,6 +239,91 @@ template <int WS> SVT_DEV void fph_hme_search(const me_ctx_t *c, int tid, int ws
     FME_DPP_MIN(0x142, 0xa); FME_DPP_MIN(0x143, 0xc);
 #undef FME_DPP_MIN
     if ((tid & 63) == 63 && k != 0xffffffffu) atomicMin(key, k);
+}
+
+/* full-pel search, widths that are multiples of 8 and at most 4096 positions: the same fused phase as ph_fullpel_fused (lane = 8x8
+ * block in z-order: a DPP quad is a 16x16 PU, a DPP row a 32x32 PU, the wave the 64x64 PU; the four waves take the groups of 4
+ * positions round-robin), with the instruction stream of a group written out: both dwords of every QSAD operand are read as a
+ * pair (two ds_read2 per row instead of register moves), a key is one v_lshl_or / v_and_or and five keys meet in two v_min3,
+ * the 32x32 step adds 16-bit halves across the row without unpacking them first, and the 64x64 step is eight in-place DPP adds. */
+SVT_DEV uint32_t fme_min3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; }
+SVT_DEV void fph_fullpel_fused(const me_ctx_t *c, int tid, int sw, int sh) {
+    const int rs = c->L.region_stride;
+    const int z = tid & 63, w = ME_UNI(tid >> 6);
+    const int bx = ((z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4)) * 8, by = (((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4)) * 8;
+    uint32_t  s0[4], s1[4]; /* rows 0, 2, 4, 6 of the source block */
+    _Pragma("unroll") for (int r = 0; r < 4; r++) {
+        const uint32_t *s = (const uint32_t *)(c->src + (by + 2 * r) * ME_SB + bx);
+        s0[r] = s[0]; s1[r] = s[1];
+    }
+    /* byte offsets inside the workgroup's LDS of this lane's block at search position (0, 0) and of the dword after it.  Opaque:
+     * the address arithmetic of a group is then ONE add per operand stream with the rows as immediate offsets, and the second
+     * operand pair of a row is loaded as such, not assembled from the first with register moves. */
+    uint32_t ro0 = (uint32_t)(c->region - c->lds) + (uint32_t)(ME_MUL(ME_RGN_GY + by, rs) + ME_RGN_GX + bx), ro1 = ro0 + 4;
+    __asm__("" : "+v"(ro0));
+    __asm__("" : "+v"(ro1));
+    uint32_t mhi = 0xffff0000u;
+    __asm__("" : "+v"(mhi)); /* in a vector register: (x & mhi) | s is then ONE v_and_or_b32 (one scalar operand per instruction) */
+    const int ng = sw >> 2;
+    uint32_t  b8 = 0xffffffffu, b16 = 0xffffffffu, b32 = 0xffffffffu, b64 = 0xffffffffu;
+#define FP_DPP(v, ctrl) ((v) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xf, 0xf, false))
+#define FP_KEYS(b, lo, hi) do { \
+        b = fme_min3(b, ((lo) << 16) | pos, ((lo) & mhi) | (pos + 1)); \
+        b = fme_min3(b, ((hi) << 16) | (pos + 2), ((hi) & mhi) | (pos + 3)); } while (0)
+    /* group q = y * ng + g, q = w, w + 4, ... (wave-uniform; y by reciprocal multiplication on the scalar unit: the body stays one
+     * basic block) */
+    const uint32_t inv = me_magics.v[ng]; /* ng in [2, 31] */
+    const int      nq = ME_MUL(ng, sh);
+    for (int q = w; q < nq; q += 4) {
+        const int y = (int)(((uint64_t)(uint32_t)q * inv) >> 32), g = q - y * ng;
+        const int      off = ME_MUL(y, rs) + 4 * g; /* wave-uniform */
+        const uint8_t *rp = c->lds + (ro0 + (uint32_t)off), *rp1 = c->lds + (ro1 + (uint32_t)off);
+        uint64_t       acc = 0;
+        _Pragma("unroll") for (int r = 0; r < 4; r++) {
+            const uint64_t pa = *(const fme_u64a4 *)(rp + 2 * r * rs), pb = *(const fme_u64a4 *)(rp1 + 2 * r * rs);
+            acc = svt_qsad(pa, s0[r], acc);
+            acc = svt_qsad(pb, s1[r], acc);
+        }
+        const uint32_t pos = (uint32_t)(ME_MUL(y, sw) + 4 * g);
+        uint32_t       lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32); /* positions pos, pos + 1 | pos + 2, pos + 3 as 16-bit sums */
+        FP_KEYS(b8, lo, hi);
+        /* 16x16: the quad's four blocks (sums stay below 2^16: no carry between the halves) */
+        lo = FP_DPP(lo, 0xB1); hi = FP_DPP(hi, 0xB1); /* quad_perm:[1,0,3,2] */
+        lo = FP_DPP(lo, 0x4E); hi = FP_DPP(hi, 0x4E); /* quad_perm:[2,3,0,1] */
+        FP_KEYS(b16, lo, hi);
+        /* 32x32: two quads still fit 16 bits; the other half of the row is added half by half into 32-bit sums */
+        lo = FP_DPP(lo, 0x124); hi = FP_DPP(hi, 0x124); /* row_ror:4 */
+        const uint32_t lo8 = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0x128, 0xf, 0xf, false); /* row_ror:8 */
+        const uint32_t hi8 = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0x128, 0xf, 0xf, false);
+        uint32_t       a0 = (lo & 0xffffu) + (lo8 & 0xffffu), a1 = (lo >> 16) + (lo8 >> 16), a2 = (hi & 0xffffu) + (hi8 & 0xffffu), a3 = (hi >> 16) + (hi8 >> 16);
+        b32 = fme_min3(b32, (a0 << 12) | pos, (a1 << 12) | (pos + 1));
+        b32 = fme_min3(b32, (a2 << 12) | (pos + 2), (a3 << 12) | (pos + 3));
+        SVT_SCHED_FENCE(); /* the 32x32 keys above are done with a0..a3: the sums below run in place */
+        /* 64x64: row 1 += row 0, row 3 += row 2 (row_bcast:15), then rows 2, 3 += row 1 (row_bcast:31): complete in lanes 48..63.
+         * In place; the first DPP read comes two wait states behind the last write of its operand (s_nop: inline assembly is not
+         * covered by the compiler's hazard recogniser), the second round reads what was written four instructions earlier. */
+        __asm__("s_nop 1\n\t"
+                "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                "v_add_u32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                "v_add_u32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                "v_add_u32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                "v_add_u32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                "v_add_u32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                "v_add_u32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        b64 = fme_min3(b64, (a0 << 12) | pos, (a1 << 12) | (pos + 1));
+        b64 = fme_min3(b64, (a2 << 12) | (pos + 2), (a3 << 12) | (pos + 3));
+    }
+#undef FP_KEYS
+#undef FP_DPP
+    uint64_t *key = c->st->key;
+    if (b8 != 0xffffffffu) { /* this wave took at least one group */
+        svt_lds_min_u64(&key[21 + z], ((uint64_t)((b8 >> 16) << 1) << 32) | (b8 & 0xffffu));
+        if ((z & 3) == 0) svt_lds_min_u64(&key[5 + (z >> 2)], ((uint64_t)((b16 >> 16) << 1) << 32) | (b16 & 0xffffu));
+        if ((z & 15) == 0) svt_lds_min_u64(&key[1 + (z >> 4)], ((uint64_t)((b32 >> 12) << 1) << 32) | (b32 & 0xfffu));
+        if (z == 63) svt_lds_min_u64(&key[0], ((uint64_t)((b64 >> 12) << 1) << 32) | (b64 & 0xfffu));
+    }
 }
 
 /* keys -> best SAD / motion vector of every PU (curr_mv = (y << 18) | (uint16)(x << 2), :108-110) and the su_pel_enable
@@ -240,6 +370,186 @@ SVT_DEV void fph_decode_gate(const me_ctx_t *c, int tid, int list, int saw, int 
         const int      i32 = 2 * !(mag32 < t2) + !(sad32 < 32 * 32 * 6), i16 = 2 * !(mag16 < t2) + !(sad16 < 16 * 16 * 2);
         const uint32_t en32 = (t32n >> i32) & 1u, en16 = (0xAu >> i16) & 1u; /* t16_ = {0, 1, 0, 1} */
         if (l == 0) *FME_GATE(st) = en32 | (en16 << 1);
+    }
+}
+
+/* 16 samples at LDS byte offset a (any alignment) as four dwords */
+SVT_DEV void fme_fetch16(const uint8_t *lds, uint32_t a, uint32_t v[4]) {
+    const uint32_t  sh = a & 3u;
+    const uint32_t *q = (const uint32_t *)(lds + (a - sh));
+    const uint32_t  l0 = q[0], l1 = q[1], l2 = q[2], l3 = q[3], l4 = q[4];
+    v[0] = svt_alignbyte(l1, l0, sh); v[1] = svt_alignbyte(l2, l1, sh); v[2] = svt_alignbyte(l3, l2, sh); v[3] = svt_alignbyte(l4, l3, sh);
+}
+/* LDS byte offset of a 16-bit source (see FME_QTAB) for a lane whose position is bp in the B / H / J planes and bf in the region
+ * (both biased by -128) */
+SVT_DEV uint32_t fme_src_at(uint32_t code, uint32_t bp, uint32_t bf) { return ((code & 0x8000u) ? bf : bp) + (code & 0x7fffu); }
+
+/* ---- half- and quarter-pel refinement of the 32x32 and 16x16 PUs, both decisions and every level of the bi-prediction in ONE
+ * phase: the same lane roles and the same arithmetic as ph_subpel_fast (me_core.h) -- waves 0-1 the four 32x32 PUs (32 lanes each:
+ * 16 subsampled rows x 2 halves), waves 2-3 the sixteen 16x16 PUs (8 lanes each), a lane owns 16 samples of one row, DPP sums inside
+ * the PU, decisions in the PU's last lane, published through LDS -- with the addressing taken out of the instruction stream:
+ *   - the eight half-pel candidates lie at compile-time distances from the lane's position in plane B and fall into two alignment
+ *     classes (x and x - 1): two aligned bases + shifts, every fetch an immediate offset;
+ *   - the planes of a quarter-pel candidate / of a prediction come from the offset tables in LDS (FME_QTAB / FME_BTAB) instead of
+ *     being derived from the packed candidate tables in every lane (plane, stride, displacement: ~15 instructions per source);
+ *   - the 64x64 PU's vector is wave-uniform: its planes and strides are chosen on the scalar unit;
+ *   - candidate sums stay packed two per dword up to the last cross-row step of a 32x32 PU. */
+SVT_DEV void fph_subpel(const me_ctx_t *c, int tid, int list, int sox, int soy, int en32, int en16, int bipred, uint32_t *pr) {
+    me_state_t *st = c->st;
+    const int   w = ME_UNI(tid >> 6), l = tid & 63, big = w < 2;
+    const int   refine = big ? en32 : en16; /* wave-uniform */
+    if (!refine && !bipred) return;
+    const int rs = c->L.region_stride, ps = c->L.plane_stride, pb = c->L.plane_bytes;
+    int       pu, n, r, xo, px, py, last;
+    if (big) { pu = 1 + 2 * w + (l >> 5); n = pu; r = (l & 31) >> 1; xo = (l & 1) * 16; px = ((pu - 1) & 1) * 32; py = ((pu - 1) >> 1) * 32; last = (l & 31) == 31; }
+    else { pu = 5 + 8 * (w - 2) + (l >> 3); n = me_z4(pu - 5) + 5; r = l & 7; xo = 0; px = ((pu - 5) & 3) * 16; py = ((pu - 5) >> 2) * 16; last = (l & 7) == 7; }
+    uint32_t s[4];
+    {
+        const uint32_t *sp = (const uint32_t *)(c->src + (py + 2 * r) * ME_SB + px + xo);
+        s[0] = sp[0]; s[1] = sp[1]; s[2] = sp[2]; s[3] = sp[3];
+    }
+    /* the lane's sample position relative to the search area's origin, and the LDS byte offsets of sample (0, 0) of the region /
+     * of plane B (biased by -128 for the table offsets) */
+    const int      lx = px + xo - sox, ly = py + 2 * r - soy;
+    const uint32_t of = (uint32_t)(c->region - c->lds) + (uint32_t)(ME_RGN_GY * rs + ME_RGN_GX) - 128u,
+                   op = (uint32_t)(c->planes - c->lds) + (uint32_t)(ME_PL_G * ps + ME_PL_G) - 128u;
+    uint32_t mv = st->best_mv[list][n], best = st->best_sad[list][n];
+    int      xm = me_mvx(mv), ym = me_mvy(mv);
+    /* ---- half-pel: 8 candidates (pu_half_pel_refinement :1076-1559) ---- */
+    if (refine) {
+        const int xs = (int16_t)(xm >> 2) + lx, ys = (int16_t)(ym >> 2) + ly;
+        const uint32_t a0 = op + 128u + (uint32_t)(ME_MUL(ys, ps) + xs); /* plane B at (xs, ys) */
+        uint32_t       sh0 = a0 & 3u, q0 = a0 - sh0, sh1 = (a0 - 1u) & 3u, q1 = a0 - 1u - sh1;
+        __asm__("" : "+v"(q0));
+        __asm__("" : "+v"(q1));
+        uint32_t d[8];
+        _Pragma("unroll") for (int i = 0; i < 8; i++) {
+            int hpl, hdx, hdy;
+            me_hcand_get(i, &hpl, &hdx, &hdy);
+            const uint32_t *q = (const uint32_t *)(c->lds + (hdx ? q1 : q0) + (uint32_t)((hpl - 1) * pb + hdy * ps));
+            const uint32_t  sh = hdx ? sh1 : sh0, l0 = q[0], l1 = q[1], l2 = q[2], l3 = q[3], l4 = q[4];
+            uint32_t        t = svt_sad4(svt_alignbyte(l1, l0, sh), s[0], 0);
+            t = svt_sad4(svt_alignbyte(l2, l1, sh), s[1], t);
+            t = svt_sad4(svt_alignbyte(l3, l2, sh), s[2], t);
+            d[i] = svt_sad4(svt_alignbyte(l4, l3, sh), s[3], t);
+        }
+        /* a lane's sums stay below 2^12, 16 lanes' below 2^16: two candidates per dword up to the row; a 32x32 PU's second row is
+         * added half by half into 32-bit sums */
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {
+            uint32_t v = d[i] | (d[i + 4] << 16);
+            v = SVT_DPP_ADD(v, 0x111); v = SVT_DPP_ADD(v, 0x112); v = SVT_DPP_ADD(v, 0x114);
+            if (big) {
+                v = SVT_DPP_ADD(v, 0x118);
+                const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); /* row_bcast:15 into rows 1 and 3 */
+                d[i] = (v & 0xffffu) + (x & 0xffffu); d[i + 4] = (v >> 16) + (x >> 16);
+            } else { d[i] = v & 0xffffu; d[i + 4] = v >> 16; }
+        }
+        /* decisions (meaningful in the PU's last lane): strict '<' in test order = minimum of (2 d) << 3 | test index; direction by
+         * the tie order L,R,T,B,TL,TR,BL,BR (:1531-1556) */
+        uint32_t k[8];
+        _Pragma("unroll") for (int i = 0; i < 8; i++) k[i] = (d[i] << 4) | (uint32_t)i;
+        const uint32_t m5 = fme_min3(fme_min3(k[0], k[1], k[2]), k[3], k[4]);
+        const uint32_t km = fme_min3(m5 < k[5] ? m5 : k[5], k[6], k[7]);
+        const uint32_t kr = fme_min3(m5 < k[5] ? m5 : k[5], k[6] + 1, k[7] - 1); /* ranks of candidates 6 (BR) and 7 (BL) swapped */
+        if ((km >> 3) < best) {
+            int sx, sy;
+            me_dmv_get((int)(km & 7u), &sx, &sy);
+            best = km >> 3; mv = me_pack_mv(xm + 2 * sx, ym + 2 * sy);
+        }
+        const uint32_t dir = (0x46205137u >> (4 * (kr & 7u))) & 7u; /* tie rank L,R,T,B,TL,TR,BL,BR -> direction code */
+        if (last) { st->best_sad[list][n] = best; st->best_mv[list][n] = mv; st->dir[n] = (uint8_t)dir; }
+    }
+    __asm__ volatile("" ::: "memory"); /* the reads below must stay behind the stores above (other lanes' data) */
+    /* ---- quarter-pel: the three positions around the half-pel direction (pu_quarter_pel_refinement_on_the_fly :2471-2715) ---- */
+    if (refine) {
+        mv = st->best_mv[list][n]; best = st->best_sad[list][n];
+        const int dir = st->dir[n];
+        xm = me_mvx(mv); ym = me_mvy(mv);
+        const int      method = (ym & 2) + ((xm & 2) >> 1);
+        const int      xs = (int16_t)((xm + 2) >> 2) + lx, ys = (int16_t)((ym + 2) >> 2) + ly;
+        const uint32_t bp = op + (uint32_t)(ME_MUL(ys, ps) + xs), bf = of + (uint32_t)(ME_MUL(ys, rs) + xs);
+        const int      d0 = method != 0 ? dir ^ 4 : dir;
+        uint32_t       q[3], pos[3], e[3];
+        _Pragma("unroll") for (int j = 0; j < 3; j++) {
+            pos[j] = (0x07361524u >> (4 * ((d0 + j - 1) & 7))) & 7u; /* direction code -> L,R,T,B,TL,TR,BR,BL index */
+            e[j] = FME_QTAB(st)[method * 8 + (int)pos[j]];
+        }
+        _Pragma("unroll") for (int j = 0; j < 3; j++) {
+            uint32_t va[4], vb[4];
+            fme_fetch16(c->lds, fme_src_at(e[j] & 0xffffu, bp, bf), va);
+            fme_fetch16(c->lds, fme_src_at(e[j] >> 16, bp, bf), vb);
+            uint32_t t = svt_sad4(svt_avg4(va[0], vb[0]), s[0], 0);
+            t = svt_sad4(svt_avg4(va[1], vb[1]), s[1], t);
+            t = svt_sad4(svt_avg4(va[2], vb[2]), s[2], t);
+            q[j] = svt_sad4(svt_avg4(va[3], vb[3]), s[3], t);
+        }
+        uint32_t v01 = q[0] | (q[1] << 16), v2 = q[2];
+        v01 = SVT_DPP_ADD(v01, 0x111); v01 = SVT_DPP_ADD(v01, 0x112); v01 = SVT_DPP_ADD(v01, 0x114);
+        v2 = SVT_DPP_ADD(v2, 0x111); v2 = SVT_DPP_ADD(v2, 0x112); v2 = SVT_DPP_ADD(v2, 0x114);
+        if (big) {
+            v01 = SVT_DPP_ADD(v01, 0x118); v2 = SVT_DPP_ADD(v2, 0x118);
+            const uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v01, 0x142, 0xa, 0xf, false);
+            q[0] = (v01 & 0xffffu) + (x & 0xffffu); q[1] = (v01 >> 16) + (x >> 16);
+            q[2] = v2 + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v2, 0x142, 0xa, 0xf, false);
+        } else { q[0] = v01 & 0xffffu; q[1] = v01 >> 16; q[2] = v2; }
+        const uint32_t km = fme_min3((q[0] << 4) | pos[0], (q[1] << 4) | pos[1], (q[2] << 4) | pos[2]);
+        if (last && (km >> 3) < best) {
+            int sx, sy;
+            me_dmv_get((int)(km & 7u), &sx, &sy);
+            st->best_sad[list][n] = km >> 3; st->best_mv[list][n] = me_pack_mv(xm + sx, ym + sy);
+        }
+    }
+    /* ---- the lane's 16 samples of the PU's prediction at its final motion vector: kept in registers after list 0; after list 1
+     * averaged with them and compared with the source -- the PU's bi-prediction distortion (bi_pred_averging :3466-3560), summed
+     * over the PU's lanes, written by its last lane ---- */
+    if (bipred) {
+        __asm__ volatile("" ::: "memory");
+        {
+            const uint32_t fm = st->best_mv[list][n];
+            const int      mx = me_mvx(fm), my = me_mvy(fm);
+            const int      xi = (int16_t)(mx >> 2) + lx, yi = (int16_t)(my >> 2) + ly;
+            const uint32_t e = FME_BTAB(st)[(mx & 3) + ((my & 3) << 2)];
+            const uint32_t bp = op + (uint32_t)(ME_MUL(yi, ps) + xi), bf = of + (uint32_t)(ME_MUL(yi, rs) + xi);
+            uint32_t       va[4], vb[4];
+            fme_fetch16(c->lds, fme_src_at(e & 0xffffu, bp, bf), va);
+            fme_fetch16(c->lds, fme_src_at(e >> 16, bp, bf), vb);
+            _Pragma("unroll") for (int i = 0; i < 4; i++) va[i] = svt_avg4(va[i], vb[i]); /* one plane: avg(a, a) = a */
+            if (list == 0) { pr[4] = va[0]; pr[5] = va[1]; pr[6] = va[2]; pr[7] = va[3]; }
+            else {
+                uint32_t d = svt_sad4(svt_avg4(pr[4], va[0]), s[0], 0);
+                d = svt_sad4(svt_avg4(pr[5], va[1]), s[1], d);
+                d = svt_sad4(svt_avg4(pr[6], va[2]), s[2], d);
+                d = svt_sad4(svt_avg4(pr[7], va[3]), s[3], d);
+                d = me_pu_lanes_sum(d, big);
+                if (last) c->cand[pu] = d;
+            }
+        }
+        /* the 64x64 PU (never refined on this path: its vector is the full-pel one, the same in every lane -> planes, strides and
+         * alignment are scalars): every lane takes dword tid & 15 of the subsampled rows 2 (tid >> 4) and 2 (tid >> 4) + 32; wave
+         * sums into cand[0], which fph_decode_gate zeroed */
+        {
+            const uint32_t mv0 = (uint32_t)ME_UNI(st->best_mv[list][0]);
+            const int      mx = me_mvx(mv0), my = me_mvy(mv0);
+            const int      xi = (int16_t)(mx >> 2) - sox, yi = (int16_t)(my >> 2) - soy;
+            int            has_b;
+            const uint32_t e = me_btab_get((mx & 3) + ((my & 3) << 2), &has_b);
+            const int      pa = (int)(e & 3), pbn = (int)((e >> 4) & 3);
+            const uint8_t *a = me_plane_at(c, pa, xi + (int)((e >> 2) & 1), yi + (int)((e >> 3) & 1));
+            const uint8_t *b = me_plane_at(c, pbn, xi + (int)((e >> 6) & 1), yi + (int)((e >> 7) & 1));
+            const int      sa = me_plane_stride(c, pa), sb = me_plane_stride(c, pbn);
+            uint32_t       d0 = 0;
+            _Pragma("unroll") for (int k = 0; k < 2; k++) {
+                const int rr = 2 * (tid >> 4) + 32 * k, ii = tid & 15;
+                uint32_t  vb = me_ld32u(a + ME_MUL(rr, sa) + 4 * ii);
+                if (has_b) vb = svt_avg4(vb, me_ld32u(b + ME_MUL(rr, sb) + 4 * ii));
+                if (list == 0) pr[k] = vb;
+                else d0 = svt_sad4(svt_avg4(pr[k], vb), *(const uint32_t *)(c->src + rr * ME_SB + 4 * ii), d0);
+            }
+            if (list != 0) {
+                d0 = fme_wave_sum63(d0);
+                if (l == 63) atomicAdd(&c->cand[0], d0);
+            }
+        }
     }
 }
 
@@ -383,7 +693,7 @@ template <int SPEC> __device__ __forceinline__ void me_sb_run_fast(const me_ctx_
         {
             uint32_t *U = (uint32_t *)c->planes;
             if (saw >= 8 && (saw & 7) == 0 && saw * sah <= 4096) {
-                ME_PHASE(ph_fullpel_fused(c, tid, saw, sah));
+                ME_PHASE(fph_fullpel_fused(c, tid, saw, sah));
                 FME_MARK(5);
                 FME_MARK(6);
             } else { /* clipped at a picture border: the table form, in chunks of search rows (me_sb_run) */
@@ -409,7 +719,7 @@ template <int SPEC> __device__ __forceinline__ void me_sb_run_fast(const me_ctx_
         FME_MARK(9);
         /* SUB_SAD refinement of the 32x32 / 16x16 PUs, both decisions and every level of the bi-prediction: one phase */
         const int fast_bi = nlist == 2;
-        if (en32 || en16 || fast_bi) ME_PHASE(ph_subpel_fast(c, tid, list, sox, soy, en32, en16, fast_bi, pred0_regs));
+        if (en32 || en16 || fast_bi) ME_PHASE(fph_subpel(c, tid, list, sox, soy, en32, en16, fast_bi, pred0_regs));
         FME_MARK(10);
         FME_MARK(11);
         FME_MARK(12);

@@ -21,11 +21,14 @@ def desc(luma):
     return d
 d = [desc(f) for f in frames]
 res = torch.zeros((T.n_sb(W, H), 850), dtype=torch.int32, device=dev)
-p = MC.preset("c3_2160p_m8", 2, 4, 4)
-cur, r0, r1 = (B.PaPicture * 1)(d[1]), (B.PaPicture * 1)(d[0]), (B.PaPicture * 1)(d[2])
-rp = (C.c_void_p * 1)(res.data_ptr())
-for k in [0, 1, 19, 20, 21, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, -1]:
+p = MC.preset("c3_2160p_m8", 2, int(os.environ.get("ME_TL", "4")), 4)
+STOPS = [int(x) for x in os.environ.get("ME_STOPS", "0,1,19,20,21,2,3,4,5,6,7,8,9,10,11,12,-1").split(",")]
+NP = int(os.environ.get("ME_PICS", "1")); REP = int(os.environ.get("ME_REPS", "1"))
+cur, r0, r1 = (B.PaPicture * NP)(*([d[1]] * NP)), (B.PaPicture * NP)(*([d[0]] * NP)), (B.PaPicture * NP)(*([d[2]] * NP))
+rp = (C.c_void_p * NP)(*([res.data_ptr()] * NP))
+for k in STOPS:
     os.environ["SVT_HIP_ME_STOP"] = str(k)
-    B.check(lib.svt_hip_me_batch_device(ctx, 1, cur, r0, r1, C.byref(p), rp, None))
-    B.check(lib.svt_hip_ctx_synchronize(ctx))
+    for _ in range(REP):
+        B.check(lib.svt_hip_me_batch_device(ctx, NP, cur, r0, r1, C.byref(p), rp, None))
+        B.check(lib.svt_hip_ctx_synchronize(ctx))
 print("ok")
