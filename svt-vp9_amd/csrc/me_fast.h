@@ -34,8 +34,8 @@ constexpr bool me_fast_params_ok(uint8_t hme, uint8_t l0, uint8_t l1, uint8_t l2
     return hme && l0 && !l1 && !l2 && single && method == SVT_SUB_SAD_SEARCH && model == 1 && !f64 && cu16 == 0 && cu8 == 1;
 }
 
-/* accumulators of the centre tests: slot s = 2 * list + (0: test_search_area_bounds, 1: check_zero_zero_center), two 64-bit
- * words each, zeroed once per SB; they live in the bytes of hme_sad (the general driver's per-level results: unused here) */
+/* sums of the centre tests: slot s = 2 * list + (0: test_search_area_bounds, 1: check_zero_zero_center), five dwords each; they
+ * live in the bytes of hme_sad (the general driver's per-level results: unused here) */
 #if defined(ME_ASM_MARKS) /* static instruction counts (tools/me_static_counts.py): a comment in the assembly at every mark */
 #define FME_MARK(i) __asm__ volatile("; @MARK %0" ::"n"(i))
 #elif defined(ME_FINE_PROF) /* dynamic counts and times per phase (tools/me_phase_profile.sh): the kernel ends at mark g_me_stop_after of list 0 */
@@ -43,7 +43,7 @@ constexpr bool me_fast_params_ok(uint8_t hme, uint8_t l0, uint8_t l1, uint8_t l2
 #else
 #define FME_MARK(i) ((void)0)
 #endif
-#define FME_ACC(st, s) ((unsigned long long *)(st)->hme_sad + 2 * (s))
+#define FME_ACC(st, s) ((uint32_t *)(st)->hme_sad + 5 * (s))
 /* HME arg-min key (sad << 16 | y << 8 | x) of list l: in the bytes of hme_keys */
 #define FME_HKEY(st, l) ((uint32_t *)(st)->hme_keys + (l))
 /* su_pel_enable decision of the current list: bit 0 = 32x32, bit 1 = 16x16 */
@@ -83,7 +83,6 @@ SVT_DEV void fph_init(const me_ctx_t *c, int tid, int do_hme) {
     me_state_t *st = c->st;
     if (tid < 85) { st->best_mv[0][tid] = 0; st->best_mv[1][tid] = 0; st->best_sad[0][tid] = 0; st->best_sad[1][tid] = 0; }
     if (tid >= 96 && tid < 118) ((uint32_t *)st->dir)[tid - 96] = 0;
-    if (tid >= 128 && tid < 144) ((uint32_t *)st->hme_sad)[tid - 128] = 0;
     if (tid >= 160 && tid < 162) FME_HKEY(st, tid - 160)[0] = 0xffffffffu;
     if (tid >= 192 && tid < 224) {
         const uint32_t e = me_qtab_get((tid - 192) >> 3, (tid - 192) & 7);
@@ -112,56 +111,68 @@ SVT_DEV void fph_init(const me_ctx_t *c, int tid, int do_hme) {
 }
 
 /* Row-subsampled 64-wide SADs of the source SB against up to five displaced reference blocks in global memory
- * (test_search_area_bounds :4260 / check_zero_zero_center :3758): thread = one (row, 8 bytes) piece of every candidate;
- * base + off[k] = top-left sample of candidate k.  The sums of the workgroup are ADDED to slot[0] (candidates 0-2 at bits 0 /
- * 20 / 40) and slot[1] (candidates 3, 4 at bits 0 / 20). */
-SVT_DEV void fph_center(const me_ctx_t *c, int tid, const uint8_t *base, int rstride, int nc, const int32_t *off, unsigned long long *slot) {
-    const int r = tid >> 3, i = tid & 7;
+ * (test_search_area_bounds :4260 / check_zero_zero_center :3758), by WAVE 0 ALONE: 5 x 2048 samples are too little work to pay
+ * four waves' address set-up, reductions and a cross-wave meeting in LDS -- the kernel is bound by the sum of vector
+ * instructions over its waves, and the other three waves wait at the barrier for the same global round trip either way.
+ * Lane = half a row (32 bytes: two 16-byte loads per candidate); base + off[k] = top-left sample of candidate k.  The sums go to
+ * slot[0..4]. */
+SVT_DEV void fph_center(const me_ctx_t *c, int tid, const uint8_t *base, int rstride, int nc, const int32_t *off, uint32_t *slot) {
+    if (ME_UNI(tid >> 6) != 0) return;
+    const int r = tid >> 1, h = tid & 1;
     uint32_t  acc[5] = {0, 0, 0, 0, 0};
     if (2 * r < c->sb_h) {
-        const uint32_t voff = (uint32_t)(ME_MUL(2 * r, rstride) + 8 * i);
-        me_u32x2       v[5];
+        const uint32_t voff = (uint32_t)(ME_MUL(2 * r, rstride) + 32 * h);
+        me_u32x4       v[5][2];
         _Pragma("unroll") for (int k = 0; k < 5; k++)
-            if (k < nc) v[k] = me_ld64u_g(base + off[k] + voff);
-        const uint32_t *sp = (const uint32_t *)(c->src + (2 * r) * ME_SB + 8 * i);
-        const uint32_t  s0 = sp[0], s1 = sp[1];
+            if (k < nc) { v[k][0] = me_ld128u_g(base + off[k] + voff); v[k][1] = me_ld128u_g(base + off[k] + voff + 16); }
+        const uint32_t *sp = (const uint32_t *)(c->src + (2 * r) * ME_SB + 32 * h);
+        uint32_t        sv[8];
+        _Pragma("unroll") for (int i = 0; i < 8; i++) sv[i] = sp[i];
         _Pragma("unroll") for (int k = 0; k < 5; k++)
-            if (k < nc) acc[k] = svt_sad4(v[k].y, s1, svt_sad4(v[k].x, s0, 0));
+            if (k < nc) {
+                uint32_t t = svt_sad4(v[k][0].x, sv[0], 0);
+                t = svt_sad4(v[k][0].y, sv[1], t); t = svt_sad4(v[k][0].z, sv[2], t); t = svt_sad4(v[k][0].w, sv[3], t);
+                t = svt_sad4(v[k][1].x, sv[4], t); t = svt_sad4(v[k][1].y, sv[5], t); t = svt_sad4(v[k][1].z, sv[6], t);
+                acc[k] = svt_sad4(v[k][1].w, sv[7], t);
+            }
     }
-    const uint32_t p0 = fme_half_sums_pk(acc[0] | (acc[1] << 16)), p1 = fme_half_sums_pk(acc[2] | (acc[3] << 16)),
-                   p2 = nc > 4 ? fme_half_sums_pk(acc[4]) : 0u;
-    const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)p0, 31), b0 = (uint32_t)__builtin_amdgcn_readlane((int)p0, 63);
-    const uint32_t a1 = (uint32_t)__builtin_amdgcn_readlane((int)p1, 31), b1 = (uint32_t)__builtin_amdgcn_readlane((int)p1, 63);
-    const uint32_t a2 = nc > 4 ? (uint32_t)__builtin_amdgcn_readlane((int)p2, 31) : 0u, b2 = nc > 4 ? (uint32_t)__builtin_amdgcn_readlane((int)p2, 63) : 0u;
-    const unsigned long long x = (unsigned long long)((a0 & 0xffffu) + (b0 & 0xffffu)) | ((unsigned long long)((a0 >> 16) + (b0 >> 16)) << 20) |
-                                 ((unsigned long long)((a1 & 0xffffu) + (b1 & 0xffffu)) << 40);
-    const unsigned long long y = (unsigned long long)((a1 >> 16) + (b1 >> 16)) | ((unsigned long long)(a2 + b2) << 20);
-    if ((tid & 63) == 0) { atomicAdd(&slot[0], x); atomicAdd(&slot[1], y); }
+    /* a lane's sums stay below 2^13: two candidates per dword through the first three steps (8 lanes < 2^16), then singly */
+    uint32_t p[3] = {acc[0] | (acc[1] << 16), acc[2] | (acc[3] << 16), acc[4]};
+    _Pragma("unroll") for (int i = 0; i < 3; i++)
+        if (i < 2 || nc > 4) { p[i] = SVT_DPP_ADD(p[i], 0x111); p[i] = SVT_DPP_ADD(p[i], 0x112); p[i] = SVT_DPP_ADD(p[i], 0x114); }
+    uint32_t a[5] = {p[0] & 0xffffu, p[0] >> 16, p[1] & 0xffffu, p[1] >> 16, p[2]};
+    _Pragma("unroll") for (int k = 0; k < 5; k++)
+        if (k < nc) {
+            a[k] = SVT_DPP_ADD(a[k], 0x118);
+            a[k] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a[k], 0x142, 0xa, 0xf, false);
+            a[k] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a[k], 0x143, 0xc, 0xf, false);
+        }
+    if (tid == 63) { _Pragma("unroll") for (int k = 0; k < 5; k++) if (k < nc) slot[k] = a[k]; }
 }
-/* the five sums back as scalars (after the barrier that follows fph_center) */
-SVT_DEV void fme_center_sums(const unsigned long long *slot, uint32_t s[5]) {
-    const unsigned long long x = slot[0], y = slot[1];
-    const uint32_t xl = (uint32_t)ME_UNI((uint32_t)x), xh = (uint32_t)ME_UNI((uint32_t)(x >> 32)), yl = (uint32_t)ME_UNI((uint32_t)y),
-                   yh = (uint32_t)ME_UNI((uint32_t)(y >> 32));
-    s[0] = xl & 0xfffffu; s[1] = ((xl >> 20) | (xh << 12)) & 0xfffffu; s[2] = (xh >> 8) & 0xfffffu;
-    s[3] = yl & 0xfffffu; s[4] = ((yl >> 20) | (yh << 12)) & 0xfffffu;
+/* the sums back as scalars (after the barrier that follows fph_center) */
+SVT_DEV void fme_center_sums(const uint32_t *slot, int nc, uint32_t s[5]) {
+    _Pragma("unroll") for (int k = 0; k < 5; k++) s[k] = k < nc ? (uint32_t)ME_UNI(slot[k]) : 0u;
 }
 
 /* the same SAD for ONE displaced block that already sits in the LDS search region (region byte (col, row) = its top-left
- * sample): added to the low word of slot[0] */
-SVT_DEV void fph_region_center(const me_ctx_t *c, int tid, int col, int row, unsigned long long *slot) {
-    const int r = tid >> 3, i = tid & 7, rs = c->L.region_stride;
+ * sample), by wave 0: slot[0] */
+SVT_DEV void fph_region_center(const me_ctx_t *c, int tid, int col, int row, uint32_t *slot) {
+    if (ME_UNI(tid >> 6) != 0) return;
+    const int r = tid >> 1, h = tid & 1, rs = c->L.region_stride;
     uint32_t  acc = 0;
     if (2 * r < c->sb_h) {
-        const uint8_t  *p = c->region + ME_MUL(row + 2 * r, rs) + col + 8 * i;
-        const uint32_t  sh = (uint32_t)((uintptr_t)p & 3);
-        const uint32_t *q = (const uint32_t *)(p - sh);
-        const uint32_t  l0 = q[0], l1 = q[1], l2 = q[2];
-        const uint32_t *sp = (const uint32_t *)(c->src + (2 * r) * ME_SB + 8 * i);
-        acc = svt_sad4(svt_alignbyte(l2, l1, sh), sp[1], svt_sad4(svt_alignbyte(l1, l0, sh), sp[0], 0));
+        const uint32_t  a = (uint32_t)(c->region - c->lds) + (uint32_t)(ME_MUL(row + 2 * r, rs) + col + 32 * h), sh = a & 3u;
+        const uint32_t *q = (const uint32_t *)(c->lds + (a - sh));
+        const uint32_t *sp = (const uint32_t *)(c->src + (2 * r) * ME_SB + 32 * h);
+        uint32_t        lo = q[0];
+        _Pragma("unroll") for (int i = 0; i < 8; i++) {
+            const uint32_t hi = q[i + 1];
+            acc = svt_sad4(svt_alignbyte(hi, lo, sh), sp[i], acc);
+            lo = hi;
+        }
     }
     acc = fme_wave_sum63(acc);
-    if ((tid & 63) == 63) atomicAdd((uint32_t *)slot, acc);
+    if (tid == 63) slot[0] = acc;
 }
 
 /* copy a rectangle of nd dwords x rows from global memory (uniform base, any alignment) into LDS (rows at dst_stride, dword
@@ -592,7 +603,7 @@ template <int SPEC> __device__ __forceinline__ void me_sb_run_fast(const me_ctx_
                 }
                 ME_PHASE(fph_center(c, tid, me_pix(rf, c->sb_x, c->sb_y), rstride, nc, off, FME_ACC(st, 2 * list)));
                 uint32_t s[5];
-                fme_center_sums(FME_ACC(st, 2 * list), s);
+                fme_center_sums(FME_ACC(st, 2 * list), nc, s);
                 zero_c = s[0] << 1; have_zero = 1;
                 const uint32_t b_c = s[1] << 1, c_c = s[2] << 1, d_c = s[3] << 1;
                 const uint32_t a_c = zero_c; /* [quirk] A is evaluated at the zero-MV address (:4302-4327) */
@@ -670,13 +681,13 @@ template <int SPEC> __device__ __forceinline__ void me_sb_run_fast(const me_ctx_
             if (inside) {
                 FME_LOAD_REGION();
                 ME_PHASE(fph_region_center(c, tid, col, row, FME_ACC(st, 2 * list + 1)));
-                z = zero_c; hh = (uint32_t)ME_UNI(*(const uint32_t *)FME_ACC(st, 2 * list + 1)) << 1;
+                z = zero_c; hh = (uint32_t)ME_UNI(*FME_ACC(st, 2 * list + 1)) << 1;
                 loaded = 1;
             } else {
                 int32_t off[5] = {0, ME_MUL(ysc, rf->stride) + xsc, 0, 0, 0};
                 ME_PHASE(fph_center(c, tid, me_pix(rf, c->sb_x, c->sb_y), rf->stride, 2, off, FME_ACC(st, 2 * list + 1)));
                 uint32_t s[5];
-                fme_center_sums(FME_ACC(st, 2 * list + 1), s);
+                fme_center_sums(FME_ACC(st, 2 * list + 1), 2, s);
                 z = s[0] << 1; hh = s[1] << 1;
             }
             if (z <= hh) { xsc = 0; ysc = 0; loaded = 0; } /* min(z, h) == z */
