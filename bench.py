@@ -325,7 +325,9 @@ class Geometry:
         self.eob_entries = (w // 4) * (h // 4) * 3 // 2
 
 
-RING = 6   # mini-GOPs whose reference pictures are alive at a time (the diagonal schedule reaches back LEVELS mini-GOPs)
+RING = 8   # mini-GOPs whose reference pictures are alive at a time (the diagonal schedule reaches back LEVELS mini-GOPs); a multiple of the
+           # key-frame period in mini-GOPs, so that "first mini-GOP of a closed GOP" is a property of the ring slot
+INTRA_PERIOD = 64   # pictures per closed GOP behind its key frame (-intra-period 64 at 60 fps: one key frame per 64 inter pictures)
 
 
 def main():
@@ -348,6 +350,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip value_reference_flags, the ME-alone pass and the public-API leg (profiling aid)")
     ap.add_argument("--handoff", action="store_true", help="N > 1 only: split-GOP mode -- every step each rank also hands the padded base-layer reconstruction of its "
                     "first GOP to the next rank (RCCL send / recv over xGMI), the one exchange step of the path; closed GOPs (the default) need none")
+    ap.add_argument("--no-key-frames", action="store_true", help="profiling aid: inter pictures only (the round-4 step); `value_inter_only` is measured either way")
     ap.add_argument("--stages", default=",".join(STAGES), help="profiling aid: pa, me and / or the EncDec chain (any of mc..pad runs the whole chain)")
     args = ap.parse_args()
 
@@ -403,6 +406,7 @@ def main():
     me_streams, me_ctxs = [p_[0] for p_ in me_pairs], [p_[1] for p_ in me_pairs]
     grp_pairs = [new_ctx(prio[1]) for _ in range(n_groups)]
     pa_stream, ctx_pa = new_ctx(prio[0])
+    key_streams = [new_ctx(prio[1]) for _ in range(n_groups)]   # the key frames' encode pass: beside the inter batches of its GOP group
     single_pairs = [new_ctx(prio[1]) for _ in range(max(1, int(os.environ.get("SVT_BENCH_SINGLE_STREAMS", "2"))))]
 
     geo = Geometry(Wd, Hd)
@@ -588,9 +592,27 @@ def main():
         d.y, d.u, d.v = base + geo.y0, base + geo.u0, base + geo.v0
         d.y_stride, d.uv_stride, d.width, d.height = geo.pw, geo.cpw, Wd, Hd
 
+    # Key frames.  A closed GOP is a key frame + INTRA_PERIOD inter pictures = KEYP mini-GOPs; GOP stream g starts a new closed GOP in
+    # the ring slots with slot % KEYP == g % KEYP (staggered: with G = KEYP one key frame per step).  The first mini-GOP of a closed
+    # GOP predicts from the key frame's reconstruction (its "picture 0"), not from the base picture of the mini-GOP before.  Two key
+    # buffers per stream alternate: the deepest layer of that first mini-GOP still reads its key frame LEVELS steps later.
+    KEYP = max(1, INTRA_PERIOD // MINIGOP)
+    KEY_LEAD = int(os.environ.get("SVT_BENCH_KEY_LEAD", "1"))   # steps between a key frame's encode pass and the first batch that predicts from it
+    use_keys = [not args.no_key_frames]
+    d_key = dev_zeros((G, 2, geo.rec_bytes), torch.uint8)
+    key_first = lambda slot, g: use_keys[0] and (slot % RING) % KEYP == g % KEYP
+    key_buf = lambda slot: ((slot % RING) // KEYP) & 1
+
+    def key_desc(d, g, k):
+        base = d_key.data_ptr() + (g * 2 + k) * geo.rec_bytes
+        d.y, d.u, d.v = base + geo.y0, base + geo.u0, base + geo.v0
+        d.y_stride, d.uv_stride, d.width, d.height = geo.pw, geo.cpw, Wd, Hd
+
     def ref_desc(d, slot, g, j):
         """reference picture j (0..MINIGOP) of the mini-GOP in ring slot `slot`"""
-        if j == 0:
+        if j == 0 and key_first(slot, g):
+            key_desc(d, g, key_buf(slot))
+        elif j == 0:
             yuv_desc(d, slot - 1, g, MINIGOP)
         else:
             yuv_desc(d, slot, g, j)
@@ -656,7 +678,36 @@ def main():
 
     HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)
 
-    def build_pipeline(gops, pairs, split="gop", recon_file=1):
+    # ---- the encode pass of a key frame: stand-in decision (16x16 DC: the reference's intra mode decision is out of scope) once in
+    # set-up, svt_hip_encdec_intra_device (prediction + transform wavefront, deblocking, border) inside the step ----
+    level_key = lib.svt_hip_lf_level_from_q(ac_q, 1)
+    d_key_mi = dev_zeros((mi_rows * mi_cols, B.LF_MODE_INFO_DTYPE.itemsize), torch.uint8)
+    B.check(lib.svt_hip_md_intra_default_device(me_ctxs[0], Wd, Hd, level_key, C.c_void_p(d_key_mi.data_ptr()), mi_cols))
+    B.check(lib.svt_hip_ctx_synchronize(me_ctxs[0]))
+    fl_key_cfg = B.EncdecFlagsConfig(enc_mode=enc_mode, tune=tune, temporal_layer_index=0, is_used_as_reference=1, recon_file=1, loop_filter=1)
+    fl_key = B.EncdecFlags()
+    B.check(lib.svt_hip_encdec_flags_derive(C.byref(fl_key_cfg), C.byref(fl_key)))
+
+    def key_resources(ctx_):
+        """what one stream of key frames needs: a driver workspace and the per-picture outputs (coefficients, eob map, masks) -- nothing
+        downstream consumes them here, so one set per stream"""
+        work = C.c_void_p()
+        B.check(lib.svt_hip_encdec_work_create(ctx_, 1, Wd, Hd, C.byref(work)))
+        return {"work": work, "q": dev_zeros(geo.coeffs, torch.int16), "dq": dev_zeros(geo.coeffs, torch.int16), "emap": dev_zeros(geo.eob_entries, torch.int16),
+                "lfm": dev_zeros(nsb * B.LF_MASK_DTYPE.itemsize, torch.uint8), "nz": dev_zeros(mi_rows * mi_cols, torch.uint8)}
+
+    def key_picture(res, g, k):
+        p = B.EncdecPicture()
+        p.d_lf_mi = d_key_mi.data_ptr()
+        tight_desc(p.src, src_ptr(g, 0))
+        key_desc(p.recon, g, k)
+        p.d_qcoeff, p.d_dqcoeff, p.d_eob_map, p.d_lfm, p.d_nz = res["q"].data_ptr(), res["dq"].data_ptr(), res["emap"].data_ptr(), res["lfm"].data_ptr(), res["nz"].data_ptr()
+        return p
+
+    def run_key(ctx_, res, pic):
+        B.check(lib.svt_hip_encdec_intra_device(ctx_, res["work"], C.byref(pic), Wd, Hd, mi_cols, Q_INDEX, C.byref(fl_key), C.byref(thr), PAD, PAD))
+
+    def build_pipeline(gops, pairs, split="gop", recon_file=1, keys=True):
         """a pipeline = a set of GOPs in flight whose pictures are split into groups with one EncDec stream each: whole GOPs per
         group ("gop"), or -- any partition of a batch of mutually independent pictures is valid -- the pictures of every GOP dealt
         round-robin ("picture": what one stream of mini-GOPs uses to overlap the deblocking of one half of a batch with the transform
@@ -667,7 +718,9 @@ def main():
             members = [[(g, i) for g in gops[k::ng] for i in range(1, MINIGOP + 1)] for k in range(ng)]
         else:
             members = [[(g, i) for g in gops for i in range(1, MINIGOP + 1) if i % ng == k] for k in range(ng)]
-        P = {"gops": gops, "groups": []}
+        keys = keys and not args.no_key_frames
+        use_keys[0] = keys          # read by ref_desc while the descriptors below are built
+        P = {"gops": gops, "groups": [], "keys": keys, "n_keys": 0, "key_ready": {}, "key_owner": {}}
         # with the pictures of a GOP spread over several streams, a batch's references may have been finished on another stream:
         # every group then waits for the events all groups recorded behind their previous batch (events from a pool made here)
         P["cross_sync"] = split == "picture" and ng > 1
@@ -679,10 +732,25 @@ def main():
         for k_, (pics_, (st_, ctx_)) in enumerate(zip(members, pairs)):
             work = C.c_void_p()
             B.check(lib.svt_hip_encdec_work_create(ctx_, ED_BATCH, Wd, Hd, C.byref(work)))
-            grp = {"pics": pics_, "stream": st_, "ctx": ctx_, "work": work, "index": k_,
+            grp_gops = sorted({g for g, _ in pics_})
+            ist_, ictx_ = key_streams[k_ % len(key_streams)]
+            kres = key_resources(ictx_) if keys else None
+            grp = {"pics": pics_, "stream": st_, "ctx": ctx_, "work": work, "index": k_, "gops": grp_gops, "istream": ist_, "ictx": ictx_, "kres": kres,
+                   "kpics": {(g, k): key_picture(kres, g, k) for g in grp_gops for k in range(2)} if keys else {},
+                   "ev_ring": [torch.cuda.Event() for _ in range(8)], "ev_pos": 0, "step_done": None,
                    "waves": [build_batches([(g, i, 0) for g, i in pics_ if LAYER[i - 1] == layer], recon_file) for layer in range(n_layers)],
                    "diag": build_batches([(g, i, LAYER[i - 1]) for g, i in pics_], recon_file)}
+            for e_ in grp["ev_ring"]:
+                e_.record(st_)
+            for g in grp_gops:
+                P["key_owner"].setdefault(g, k_)
+            if keys:    # every key buffer holds a real reconstruction before the first step
+                with torch.cuda.stream(ist_):
+                    for (g, _k), kp in grp["kpics"].items():
+                        if P["key_owner"][g] == k_:
+                            run_key(ictx_, kres, kp)
             P["groups"].append(grp)
+        use_keys[0] = not args.no_key_frames
         return P
 
     def run_batches(grp, batches, ph):
@@ -719,6 +787,7 @@ def main():
     extras = not args.no_extras and rank == 0
     P_single = None if (args.no_single or rank != 0) else build_pipeline([0], single_pairs, split="picture")
     P_ref = build_pipeline(all_gops, grp_pairs, recon_file=0) if extras else None
+    P_inter = build_pipeline(all_gops, grp_pairs, keys=False) if (extras and P_main["keys"]) else None
     setup_s = time.perf_counter() - t_setup0
 
     # split-GOP hand-off (optional, N > 1): the padded base-layer reconstruction of this rank's first GOP, as the deblocking +
@@ -808,6 +877,36 @@ def main():
                 if s0 < len(ED_STAGE_NAMES):
                     S["ev"].append((ED_STAGE_NAMES[s0], 100 + grp["index"], e0, e1))
 
+        def grp_event(grp, stream):
+            e_ = grp["ev_ring"][grp["ev_pos"] % len(grp["ev_ring"])]
+            grp["ev_pos"] += 1
+            e_.record(stream)
+            return e_
+
+        if P["keys"]:
+            # a closed GOP whose first mini-GOP is the NEXT step's newest one: its key frame is coded now, on the group's key stream,
+            # beside this step's inter batches (the source is there: the ME side already runs a mini-GOP ahead) -- the picture-level
+            # overlap the reference's EncDec processes have at a closed-GOP boundary.  The buffer's previous readers are behind the
+            # group's last batch; the next step's batch waits for the key frame.
+            for grp in P["groups"]:     # (a picture-split pipeline shares its GOPs between the groups: the first group codes the key frames)
+                for g in grp["gops"]:
+                    if g in P["key_ready"] and P["key_ready"][g][1] <= S["step"]:
+                        grp["stream"].wait_event(P["key_ready"][g][0])
+            P["key_ready"] = {g: v for g, v in P["key_ready"].items() if v[1] > S["step"]}
+            for grp in P["groups"]:
+                todo = [g for g in grp["gops"] if ((ph + KEY_LEAD) % RING) % KEYP == g % KEYP and P["key_owner"][g] == grp["index"]]
+                if todo:
+                    for other in P["groups"]:
+                        if other["step_done"] is not None and set(todo) & set(other["gops"]):
+                            grp["istream"].wait_event(other["step_done"])
+                    with torch.cuda.stream(grp["istream"]):
+                        for g in todo:
+                            run_key(grp["ictx"], grp["kres"], grp["kpics"][(g, key_buf(ph + KEY_LEAD))])
+                            P["n_keys"] += 1
+                    e_ = grp_event(grp, grp["istream"])
+                    for g in todo:
+                        P["key_ready"][g] = (e_, S["step"] + KEY_LEAD)   # S["step"] already counts this step
+
         if schedule == "waves":      # the dependent temporal-layer waves of the newest mini-GOP
             for layer in range(n_layers):
                 barrier_groups()
@@ -821,6 +920,9 @@ def main():
                 with torch.cuda.stream(grp["stream"]):
                     hooked(grp, grp["diag"])
             mark_groups()
+        if P["keys"]:
+            for grp in P["groups"]:
+                grp["step_done"] = grp_event(grp, grp["stream"])
         if handoff:
             run_handoff(P, ph)
 
@@ -838,6 +940,7 @@ def main():
         for _ in range(warmup):
             step(P, S, schedule)
         sync()
+        P["n_keys"] = 0
         if barrier and world > 1:
             dist.barrier()
         t0 = time.perf_counter()
@@ -864,6 +967,7 @@ def main():
         return dt, t_enq / n_free, stage_ms, stage_ms_sum, me_launches
 
     dt, enq_s, stage_ms, stage_ms_sum, me_launch_list = timed_run(P_main, args.schedule, args.steps, args.warmup, True)
+    n_keys_main = P_main["n_keys"]
     dt = GS.reduce_elapsed(dt, dist if world > 1 else None, dev if os.environ.get("SVT_BENCH_BACKEND", "nccl") == "nccl" else None)
     if world > 1:   # nothing below needs the other ranks: they leave in step, rank 0 reports
         sync()
@@ -876,14 +980,30 @@ def main():
         k1 = max(4, args.steps)
         for sched in ("diagonal", "waves"):
             dt1, enq1, stage1, _, _ = timed_run(P_single, sched, k1, max(2, args.warmup), False)
-            single[sched] = {"frames_per_s": MINIGOP * k1 / dt1, "ms_per_minigop": dt1 / k1 * 1e3, "steps": k1, "stage_ms": stage1, "enq": enq1}
+            single[sched] = {"frames_per_s": (MINIGOP * k1 + P_single["n_keys"]) / dt1, "ms_per_minigop": dt1 / k1 * 1e3, "steps": k1, "stage_ms": stage1, "enq": enq1}
     ref_flags = None
     me_alone = None
+    inter_only = key_alone_ms = None
     if extras:
+        if P_inter is not None:
+            # the same step without the key frames (round 4's `value`), and a key frame's encode pass alone on the idle GPU: what part of
+            # it the schedule hides = 1 - (step with - step without) / (key frames per step x alone)
+            k0 = max(4, args.steps // 2)
+            dt0, _, _, _, _ = timed_run(P_inter, args.schedule, k0, args.warmup, False)
+            inter_only = {"frames_per_s": G * MINIGOP * k0 / dt0, "ms_per_step": dt0 / k0 * 1e3, "steps": k0}
+            grp0 = P_main["groups"][0]
+            ts_ = []
+            for _ in range(4):
+                sync()
+                t_ = time.perf_counter()
+                run_key(grp0["ictx"], grp0["kres"], grp0["kpics"][(grp0["gops"][0], 0)])
+                B.check(lib.svt_hip_ctx_synchronize(grp0["ictx"]))
+                ts_.append(time.perf_counter() - t_)
+            key_alone_ms = min(ts_) * 1e3
         k2 = max(4, args.steps // 2)
         dt2, _, stage2, _, _ = timed_run(P_ref, args.schedule, k2, args.warmup, False)
         fl = {layer: flags_for(layer, 0) for layer in range(n_layers)}
-        ref_flags = {"frames_per_s": G * MINIGOP * k2 / dt2, "ms_per_minigop": dt2 / k2 / G * 1e3, "steps": k2,
+        ref_flags = {"frames_per_s": (G * MINIGOP * k2 + P_ref["n_keys"]) / dt2, "ms_per_minigop": dt2 / k2 / G * 1e3, "steps": k2,
                      "flags_by_layer": {str(layer): {"do_recon": fl[layer].do_recon, "deblock": fl[layer].apply_loop_filter, "pad": fl[layer].pad_reference} for layer in fl}}
         # motion estimation alone: one stream, nothing beside it -- the clean per-launch duration of the dominant kernel
         saved, stages = stages, {"me"}
@@ -938,7 +1058,7 @@ def main():
             ach = vi * G * 64 / (me_clean_ms * 1e-3) / 1e12
             valu = {"achieved": round(ach, 2), "peak": 39.3, "unit": "T lane-ops/s", "frac": round(ach / 39.3, 4), "wave_insts_per_minigop": vi,
                     "source": "profiles/traffic.json"}
-    fps = GS.aggregate_rate(pics_step, args.steps, world, dt)
+    fps = GS.aggregate_rate(pics_step + n_keys_main / args.steps, args.steps, world, dt)   # every rank codes the same number of key frames
     stages_run = [s for s in STAGES if s in stages or (s in ED_STAGE_NAMES and run_encdec)]
     out = {
         "metric": "hot-path frames/sec (+ Mpixels/sec): block-level DSP path (picture analysis + ME + inter prediction from reconstructed references + "
@@ -946,6 +1066,16 @@ def main():
         "value": round(fps, 2),
         "unit": "frames/s",
         "mpixels_per_s": round(fps * Wd * Hd / 1e6, 1),
+        "value_inter_only": round(inter_only["frames_per_s"], 2) if inter_only else None,
+        "key_frames": None if not P_main["keys"] else {
+            "per_step": round(n_keys_main / args.steps, 3), "intra_period": INTRA_PERIOD,
+            "what": f"one key frame per closed GOP of {INTRA_PERIOD} inter pictures: its encode pass (svt_hip_encdec_intra_device: prediction + transform wavefront, "
+                    "deblocking, border; stand-in decision 16x16 DC) runs inside the timed step on the GOP group's key stream, one step ahead of the mini-GOP "
+                    "that predicts from it; `value` counts it as one frame, `value_inter_only` is the same step without key frames",
+            "alone_ms": round(key_alone_ms, 3) if key_alone_ms else None,
+            "ms_per_step_with": round(dt / args.steps * 1e3, 3), "ms_per_step_without": round(inter_only["ms_per_step"], 3) if inter_only else None,
+            "hidden_fraction": (round(1.0 - max(0.0, dt / args.steps * 1e3 - inter_only["ms_per_step"]) / max(1e-9, key_alone_ms * n_keys_main / args.steps), 3)
+                                if (inter_only and key_alone_ms and n_keys_main) else None)},
         "value_reference_flags": round(ref_flags["frames_per_s"], 2) if ref_flags else None,
         "single_stream_value": round(single["diagonal"]["frames_per_s"], 2) if single else None,
         "single_gop_value": round(single["waves"]["frames_per_s"], 2) if single else None,
@@ -1025,8 +1155,10 @@ def main():
         lfm0 = {i: np.frombuffer(d_lfm[0, i - 1].cpu().numpy(), dtype=B.LF_MASK_DTYPE).reshape(sb_rows, sb_cols).copy() for i in range(1, MINIGOP + 1)}
         lf0 = {i: d_lf[0][i].cpu().numpy().view(B.LF_MODE_INFO_DTYPE).reshape(mi_rows, mi_cols).copy() for i in range(1, MINIGOP + 1)}   # with the skip flags
         out["cpu_baseline"] = cpu_baseline(T, B, frames0, src0, mc_host0, lf0, lfm0, Wd, Hd, enc_mode, tune, l1_on)
-    for grp in P_main["groups"] + (P_single["groups"] if P_single else []) + (P_ref["groups"] if P_ref else []):
+    for grp in P_main["groups"] + (P_single["groups"] if P_single else []) + (P_ref["groups"] if P_ref else []) + (P_inter["groups"] if P_inter else []):
         lib.svt_hip_encdec_work_destroy(grp["ctx"], grp["work"])
+        if grp["kres"]:
+            lib.svt_hip_encdec_work_destroy(grp["ictx"], grp["kres"]["work"])
     for c_ in ctxs:
         lib.svt_hip_ctx_destroy(c_)
     ctxs.clear()

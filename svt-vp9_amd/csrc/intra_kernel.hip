@@ -126,6 +126,18 @@ template <int N> __device__ __forceinline__ void intra_pred_row(const uint8_t *e
     }
 }
 
+/* Visibility of a block's reconstruction to the workgroups that predict from it (other CUs, other XCDs): written through and read
+ * with agent-scope accesses (the deblocking kernel's seam-row scheme), NOT with a release / acquire fence pair per area: such a pair
+ * is buffer_wbl2 sc1 + buffer_inv sc1 -- write-back and invalidation of the XCD's whole L2 -- 18 000 times per 2160p key frame, paid by
+ * every kernel that runs beside this one (measured in the step: a key frame cost + 4 ms of step time with the fences, however few
+ * workgroups coded it).  -DINTRA_FENCES restores the fence form (3-12 % faster when the pass has the GPU to itself). */
+#ifdef INTRA_FENCES
+#define INTRA_WT false
+#define INTRA_LD(p) (*(p))
+#else
+#define INTRA_WT true
+#define INTRA_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
 /* one N x N transform block of plane `plane` at sample (x0, y0) of that plane; the whole workgroup (one wave) calls it */
 template <int N>
 __device__ __forceinline__ int intra_block(const intra_pic_dev &P, int plane, int x0, int y0, int mode, int sb, int32_t *tile, uint8_t *edge, int have_right = 0) {
@@ -146,18 +158,18 @@ __device__ __forceinline__ int intra_block(const intra_pic_dev &P, int plane, in
     {
         const int j = lane & 31;
         if (lane < 32) { /* left column */
-            if (j < N) edge[32 - (j + 1)] = have_left ? rp[(size_t)(y0 + j) * rs + x0 - 1] : (uint8_t)129;
+            if (j < N) edge[32 - (j + 1)] = have_left ? INTRA_LD(&rp[(size_t)(y0 + j) * rs + x0 - 1]) : (uint8_t)129;
         } else {         /* above row, replicated to the right */
             if (j < N) {
-                const uint8_t a = have_top ? rp[(size_t)(y0 - 1) * rs + x0 + j] : (uint8_t)127;
+                const uint8_t a = have_top ? INTRA_LD(&rp[(size_t)(y0 - 1) * rs + x0 + j]) : (uint8_t)127;
                 edge[32 + 1 + j] = a;
                 /* the right half of the row: true above-right samples for a 4x4 luma block in the left half of its unit (have_right,
                    EbEncDecProcess.c:1146, 1279-1288), copies of the last sample otherwise */
-                if (N == 4 && have_right) edge[32 + 1 + N + j] = have_top ? rp[(size_t)(y0 - 1) * rs + x0 + N + j] : (uint8_t)127;
+                if (N == 4 && have_right) edge[32 + 1 + N + j] = have_top ? INTRA_LD(&rp[(size_t)(y0 - 1) * rs + x0 + N + j]) : (uint8_t)127;
                 else if (j == N - 1) { _Pragma("unroll") for (int q = 0; q < N; q++) edge[32 + 1 + N + q] = a; }
             }
         }
-        if (lane == 0) edge[32] = have_top ? (have_left ? rp[(size_t)(y0 - 1) * rs + x0 - 1] : (uint8_t)129) : (uint8_t)127;
+        if (lane == 0) edge[32] = have_top ? (have_left ? INTRA_LD(&rp[(size_t)(y0 - 1) * rs + x0 - 1]) : (uint8_t)129) : (uint8_t)127;
     }
     __syncthreads();
     intra_pred_row<N>(edge, mode, i, have_left, have_top, prow);
@@ -179,7 +191,7 @@ __device__ __forceinline__ int intra_block(const intra_pic_dev &P, int plane, in
     const int pw4 = (plane ? P.width >> 1 : P.width) >> 2, w4 = P.width >> 2, h4 = P.height >> 2;
     const int eo = plane == 0 ? 0 : w4 * h4 + (plane == 2 ? (w4 >> 1) * (h4 >> 1) : 0);
     int32_t *t = tile + (lane / N) * (N * (N + 1)); /* the idle slots of the wave run along on tiles of their own */
-    const int eob = tq_block_body<N, false, false>(k, active, i, t, srow, prow, P.qtabs, P.iscan, P.qcoeff, P.dqcoeff,
+    const int eob = tq_block_body<N, false, false, INTRA_WT>(k, active, i, t, srow, prow, P.qtabs, P.iscan, P.qcoeff, P.dqcoeff,
                                                    P.eob_map + eo + (y0 >> 2) * pw4 + (x0 >> 2), nullptr, nullptr, nullptr, nullptr, nullptr, rp);
     /* the block's reconstruction is read by the next block of this wave: drain the stores */
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -187,7 +199,17 @@ __device__ __forceinline__ int intra_block(const intra_pic_dev &P, int plane, in
     return __builtin_amdgcn_readfirstlane(eob);
 }
 
-__global__ __launch_bounds__(64) void svt_intra_kernel(const intra_pic_dev P) {
+#ifndef INTRA_WAVES_PER_EU
+#define INTRA_WAVES_PER_EU 4
+#endif
+/* Register budget: left alone the compiler takes 308 VGPRs for this kernel -- one such wave per CU, resident for milliseconds, leaves
+ * its SIMD room for two motion-estimation waves instead of five, i.e. the CU two ME workgroups instead of five (measured in the step:
+ * + 4 ms per key frame, whatever the number of workgroups of this launch).  Held to 128 it spills the 32x32 path's transform rows
+ * to scratch, but displaces one ME wave, not three. */
+#ifdef INTRA_NUM_VGPR
+__attribute__((amdgpu_num_vgpr(INTRA_NUM_VGPR)))
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INTRA_WAVES_PER_EU, INTRA_WAVES_PER_EU))) void svt_intra_kernel(const intra_pic_dev P) {
     __shared__ int32_t tile[2 * 32 * 33];
     __shared__ uint8_t edge[128];
     __shared__ int32_t s_ticket;
@@ -195,6 +217,9 @@ __global__ __launch_bounds__(64) void svt_intra_kernel(const intra_pic_dev P) {
      * never reads the above-right neighbour, so any order in which a block follows its left, above and above-left neighbours gives the
      * reference's result -- areas go in anti-diagonal order, the blocks of an area in z-order */
     const int lane = (int)threadIdx.x, a_cols = (P.width + 31) >> 5, a_rows = (P.height + 31) >> 5, n_area = a_cols * a_rows;
+    /* one wave per CU on a chain of dependent blocks, beside kernels that fill the SIMDs: it issues rarely, so letting it go first costs
+     * the others next to nothing and keeps the chain at the speed it has alone */
+    __builtin_amdgcn_s_setprio(3);
   /* workgroups are persistent: each keeps drawing tickets until they run out -- a launch of one workgroup per pair would keep ~1000 of
      them resident, nearly all polling flags of areas many diagonals away */
   for (;;) {
@@ -217,7 +242,9 @@ __global__ __launch_bounds__(64) void svt_intra_kernel(const intra_pic_dev P) {
         if (ar > 0) while (__hip_atomic_load(&done[area - a_cols], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
     }
     __syncthreads();
+#ifdef INTRA_FENCES
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     const int sb = (ar >> 1) * P.sb_cols + (ac >> 1);
     for (int z = 0; z < 16; z++) {
         const int r = ((z >> 1) & 1) | ((z >> 3) & 1) << 1, c = (z & 1) | ((z >> 2) & 1) << 1;
@@ -252,9 +279,15 @@ __global__ __launch_bounds__(64) void svt_intra_kernel(const intra_pic_dev P) {
         if (eob && lane == 0) P.nz[ur * P.mi_stride + uc] = 1; /* the three planes of a block may all store the same 1 */
     }
     /* publish the area: its reconstruction reaches memory before the flag does */
+#ifdef INTRA_FENCES
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (lane == 0) __hip_atomic_store(&done[area], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* every (write-through) store of this wave has completed */
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(&done[area], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   }
 }
 
@@ -294,6 +327,9 @@ int32_t svt_intra_launch(svt_hip_ctx *ctx, const svt_encdec_picture *p, int32_t 
     static int wg_per_cu = 0;
     if (!wg_per_cu) { const char *e = getenv("SVT_HIP_INTRA_WG_PER_CU"); wg_per_cu = e && atoi(e) > 0 ? atoi(e) : 1; }
     int grid = ctx->cu_count * wg_per_cu;
+    static int wg_cap = -1; /* experiment knob: fewer persistent workgroups = fewer CUs on which the pass displaces a motion-estimation workgroup */
+    if (wg_cap < 0) { const char *e = getenv("SVT_HIP_INTRA_WGS"); wg_cap = e && atoi(e) > 0 ? atoi(e) : 0; }
+    if (wg_cap && grid > wg_cap) grid = wg_cap;
     if (grid > 3 * n_area) grid = 3 * n_area;
     hipLaunchKernelGGL(svt_intra_kernel, dim3(grid), dim3(64), 0, ctx->stream, P);
     HIP_TRY(hipGetLastError());

@@ -79,6 +79,9 @@ ME_KERNEL_ATTRS(SPEC) void svt_me_sb_kernel(const me_pic_dev *__restrict__ pics,
 }
 /* the same for the presets me_fast.h serves (me_spec_fast), pictures of whole SB columns and level-0 areas up to 256 x 256 */
 template <int SPEC>
+#ifdef ME_FAST_NUM_VGPR
+__attribute__((amdgpu_num_vgpr(ME_FAST_NUM_VGPR)))
+#endif
 ME_KERNEL_ATTRS(SPEC) void svt_me_fast_kernel(const me_pic_dev *__restrict__ pics, svt_me_params p, me_lds_layout L,
                                                           int n_sb, int nx, int pic_w, int pic_h, int total, int chunk, unsigned long long *prof) {
     me_kernel_body<SPEC, true>(pics, p, L, n_sb, nx, pic_w, pic_h, total, chunk, prof);

@@ -139,7 +139,10 @@ __device__ __forceinline__ uint8_t clip_add(int d, int t) { int v = d + t; retur
  * prediction, packed; eob_slot / dist_slot / bits_slot: where the block's results go (dist_slot may be null; bits_slot, rate_T, s_tc,
  * s_scan only with RATE); recon_base + k.recon_off = the block's reconstruction.  Contains workgroup barriers: every lane of the
  * workgroup has to call it, with k.do_recon uniform over the workgroup.  Returns the block's eob (every lane of the block). */
-template <int N, bool RATE, bool DIST>
+/* WT: the reconstruction is stored write-through (agent-scope dword stores), for a caller whose neighbour blocks are read by other
+ * workgroups of the SAME launch (intra_kernel.hip): they then see it without a release fence -- on this part an agent-scope release /
+ * acquire pair writes back / invalidates the whole L2 of the XCD, for every kernel running beside the caller */
+template <int N, bool RATE, bool DIST, bool WT = false>
 __device__ __forceinline__ int tq_block_body(const svt_tq_block &k, const bool active, const int i, int32_t *t, const uint32_t (&srow)[N / 4],
                                               const uint32_t (&prow)[N / 4], const svt_quant_tables *__restrict__ qtabs, const int16_t *__restrict__ iscan_all,
                                               int16_t *__restrict__ qcoeff, int16_t *__restrict__ dqcoeff, uint16_t *eob_slot, uint64_t *dist_slot, int32_t *bits_slot,
@@ -329,7 +332,9 @@ __device__ __forceinline__ int tq_block_body(const svt_tq_block &k, const bool a
                 w |= (uint32_t)clip_add((int)((prow[q] >> (8 * b)) & 0xff), t[i * LS + 4 * q + b]) << (8 * b);
             rw[q] = w;
         }
-        row_store<N>(d, ((uintptr_t)d & (N >= 16 ? 15 : N - 1)) == 0, rw);
+        if constexpr (WT) {
+            _Pragma("unroll") for (int q = 0; q < N / 4; q++) __hip_atomic_store((uint32_t *)d + q, rw[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else row_store<N>(d, ((uintptr_t)d & (N >= 16 ? 15 : N - 1)) == 0, rw);
     }
     } /* do_recon */
     return eob;
