@@ -597,7 +597,7 @@ def main():
     # GOP predicts from the key frame's reconstruction (its "picture 0"), not from the base picture of the mini-GOP before.  Two key
     # buffers per stream alternate: the deepest layer of that first mini-GOP still reads its key frame LEVELS steps later.
     KEYP = max(1, INTRA_PERIOD // MINIGOP)
-    KEY_LEAD = int(os.environ.get("SVT_BENCH_KEY_LEAD", "1"))   # steps between a key frame's encode pass and the first batch that predicts from it
+    KEY_LEAD = int(os.environ.get("SVT_BENCH_KEY_LEAD", "2"))   # steps between a key frame's encode pass and the first batch that predicts from it
     use_keys = [not args.no_key_frames]
     d_key = dev_zeros((G, 2, geo.rec_bytes), torch.uint8)
     key_first = lambda slot, g: use_keys[0] and (slot % RING) % KEYP == g % KEYP
