@@ -414,6 +414,9 @@ SVT_DEV svt_plane me_plane_uni(const svt_plane *p) {
     return u;
 }
 
+/* two groups per iteration in the fused full-pel phase: the configurations with a 64x64 search area (few waves per SIMD) */
+#define ME_FULLPEL_UNROLL2(c) ((c)->p->search_area_width * (c)->p->search_area_height >= 2048)
+
 /* everything a phase needs */
 typedef struct me_ctx_t {
     const me_pic_dev    *pic;
@@ -661,13 +664,112 @@ SVT_DEV void ph_fullpel_sad8(const me_ctx_t *c, int tid, uint32_t *U, int sw, in
     }
 }
 
+#ifndef SVT_HOST_EMU
+/* The device form of ph_fullpel_fused (below).  The instruction stream of a group of 4 positions is written out: both dwords of
+ * every QSAD operand are read as a pair (two ds_read2 per row instead of register moves; the lane's LDS offsets are opaque to the
+ * compiler so that a group costs ONE add per operand stream and the rows are immediate offsets), a key is one v_lshl_or /
+ * v_and_or and five keys meet in two v_min3, the 32x32 step adds 16-bit halves across the row without unpacking them first, and
+ * the 64x64 step is eight in-place DPP adds: 56 vector instructions per group (87 before).  NG = 2 evaluates two groups per
+ * iteration with independent accumulators: for the configurations whose LDS need leaves one or two waves per SIMD (64x64 search
+ * areas) the phase is bound by the latency of its dependent chains, not by issue. */
+typedef uint64_t __attribute__((aligned(4))) me_u64a4; /* a dword pair in LDS: ds_read2_b32 */
+SVT_DEV uint32_t me_min3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; }
+template <int NG> SVT_DEV void me_fullpel_fused_dev(const me_ctx_t *c, int tid, int sw, int sh) {
+    const int rs = c->L.region_stride;
+    const int z = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bx = ((z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4)) * 8, by = (((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4)) * 8;
+    uint32_t  s0[4], s1[4]; /* rows 0, 2, 4, 6 of the source block */
+    _Pragma("unroll") for (int r = 0; r < 4; r++) {
+        const uint32_t *s = (const uint32_t *)(c->src + (by + 2 * r) * ME_SB + bx);
+        s0[r] = s[0]; s1[r] = s[1];
+    }
+    uint32_t ro0 = (uint32_t)(c->region - c->lds) + (uint32_t)(ME_MUL(ME_RGN_GY + by, rs) + ME_RGN_GX + bx), ro1 = ro0 + 4;
+    __asm__("" : "+v"(ro0));
+    __asm__("" : "+v"(ro1));
+    uint32_t mhi = 0xffff0000u;
+    __asm__("" : "+v"(mhi)); /* in a vector register: (x & mhi) | s is then ONE v_and_or_b32 (one scalar operand per instruction) */
+    const int ng = sw >> 2;
+    uint32_t  b8 = 0xffffffffu, b16 = 0xffffffffu, b32 = 0xffffffffu, b64 = 0xffffffffu;
+#define FP_DPP(v, ctrl) ((v) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xf, 0xf, false))
+#define FP_KEYS(b, lo, hi, pos) do { \
+        b = me_min3(b, ((lo) << 16) | (pos), ((lo) & mhi) | ((pos) + 1)); \
+        b = me_min3(b, ((hi) << 16) | ((pos) + 2), ((hi) & mhi) | ((pos) + 3)); } while (0)
+    /* group q = y * ng + g (wave-uniform; y by reciprocal multiplication on the scalar unit: the body stays one basic block); the
+     * waves take the groups round-robin, NG consecutive rounds per iteration (a group past the end repeats the last one: the
+     * minima do not change) */
+    const uint32_t inv = me_magics.v[ng]; /* ng in [2, 31] */
+    const int      nq = ME_MUL(ng, sh);
+    for (int q0 = w; q0 < nq; q0 += 4 * NG) {
+        uint32_t pos[NG], lo[NG], hi[NG], a0[NG], a1[NG], a2[NG], a3[NG];
+        _Pragma("unroll") for (int u = 0; u < NG; u++) {
+            const int      q = q0 + 4 * u < nq ? q0 + 4 * u : q0;
+            const int      y = (int)(((uint64_t)(uint32_t)q * inv) >> 32), g = q - y * ng;
+            const int      off = ME_MUL(y, rs) + 4 * g; /* wave-uniform */
+            const uint8_t *rp = c->lds + (ro0 + (uint32_t)off), *rp1 = c->lds + (ro1 + (uint32_t)off);
+            uint64_t       acc = 0;
+            _Pragma("unroll") for (int r = 0; r < 4; r++) {
+                const uint64_t pa = *(const me_u64a4 *)(rp + 2 * r * rs), pb = *(const me_u64a4 *)(rp1 + 2 * r * rs);
+                acc = svt_qsad(pa, s0[r], acc);
+                acc = svt_qsad(pb, s1[r], acc);
+            }
+            pos[u] = (uint32_t)(ME_MUL(y, sw) + 4 * g);
+            lo[u] = (uint32_t)acc; hi[u] = (uint32_t)(acc >> 32); /* positions pos, pos + 1 | pos + 2, pos + 3 as 16-bit sums */
+        }
+        _Pragma("unroll") for (int u = 0; u < NG; u++) {
+            FP_KEYS(b8, lo[u], hi[u], pos[u]);
+            /* 16x16: the quad's four blocks (sums stay below 2^16: no carry between the halves) */
+            lo[u] = FP_DPP(lo[u], 0xB1); hi[u] = FP_DPP(hi[u], 0xB1); /* quad_perm:[1,0,3,2] */
+            lo[u] = FP_DPP(lo[u], 0x4E); hi[u] = FP_DPP(hi[u], 0x4E); /* quad_perm:[2,3,0,1] */
+            FP_KEYS(b16, lo[u], hi[u], pos[u]);
+            /* 32x32: two quads still fit 16 bits; the other half of the row is added half by half into 32-bit sums */
+            lo[u] = FP_DPP(lo[u], 0x124); hi[u] = FP_DPP(hi[u], 0x124); /* row_ror:4 */
+            const uint32_t lo8 = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo[u], 0x128, 0xf, 0xf, false); /* row_ror:8 */
+            const uint32_t hi8 = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi[u], 0x128, 0xf, 0xf, false);
+            a0[u] = (lo[u] & 0xffffu) + (lo8 & 0xffffu); a1[u] = (lo[u] >> 16) + (lo8 >> 16);
+            a2[u] = (hi[u] & 0xffffu) + (hi8 & 0xffffu); a3[u] = (hi[u] >> 16) + (hi8 >> 16);
+            b32 = me_min3(b32, (a0[u] << 12) | pos[u], (a1[u] << 12) | (pos[u] + 1));
+            b32 = me_min3(b32, (a2[u] << 12) | (pos[u] + 2), (a3[u] << 12) | (pos[u] + 3));
+        }
+        SVT_SCHED_FENCE(); /* the 32x32 keys above are done with a0..a3: the sums below run in place */
+        /* 64x64: row 1 += row 0, row 3 += row 2 (row_bcast:15), then rows 2, 3 += row 1 (row_bcast:31): complete in lanes 48..63.
+         * In place; the first DPP read comes two wait states behind the last write of its operand (s_nop: inline assembly is not
+         * covered by the compiler's hazard recogniser), the second round reads what was written four instructions earlier. */
+        _Pragma("unroll") for (int u = 0; u < NG; u++)
+            __asm__("s_nop 1\n\t"
+                    "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_u32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_u32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_u32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                    "v_add_u32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                    "v_add_u32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                    "v_add_u32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                    : "+v"(a0[u]), "+v"(a1[u]), "+v"(a2[u]), "+v"(a3[u]));
+        _Pragma("unroll") for (int u = 0; u < NG; u++) {
+            b64 = me_min3(b64, (a0[u] << 12) | pos[u], (a1[u] << 12) | (pos[u] + 1));
+            b64 = me_min3(b64, (a2[u] << 12) | (pos[u] + 2), (a3[u] << 12) | (pos[u] + 3));
+        }
+    }
+#undef FP_KEYS
+#undef FP_DPP
+    uint64_t *key = c->st->key;
+    if (b8 != 0xffffffffu) { /* this wave took at least one group */
+        svt_lds_min_u64(&key[21 + z], ((uint64_t)((b8 >> 16) << 1) << 32) | (b8 & 0xffffu));
+        if ((z & 3) == 0) svt_lds_min_u64(&key[5 + (z >> 2)], ((uint64_t)((b16 >> 16) << 1) << 32) | (b16 & 0xffffu));
+        if ((z & 15) == 0) svt_lds_min_u64(&key[1 + (z >> 4)], ((uint64_t)((b32 >> 12) << 1) << 32) | (b32 & 0xfffu));
+        if (z == 63) svt_lds_min_u64(&key[0], ((uint64_t)((b64 >> 12) << 1) << 32) | (b64 & 0xfffu));
+    }
+}
+#endif
+
 /* full-pel, search areas whose width is a multiple of 8 (no tail path) with at most 4096 positions: SADs, the nested sums and
  * the per-PU arg-min in ONE phase without the table.  Lane = 8x8 block in z-order, so a DPP quad is a 16x16 PU, a DPP row of
  * 16 lanes a 32x32 PU and the wave the 64x64 PU; the four waves take the groups of 4 positions round-robin.  A lane keeps one
  * running minimum per level as a 32-bit key -- (sad << 16) | position for 8x8 / 16x16 (sums < 2^16), (sad << 12) | position
  * for 32x32 / 64x64 -- and the waves meet in the same 64-bit LDS minimum as ph_fullpel_argmin: unsigned min = the
  * reference's first minimum in raster order. */
-SVT_DEV void ph_fullpel_fused(const me_ctx_t *c, int tid, int sw, int sh) {
+SVT_DEV void ph_fullpel_fused(const me_ctx_t *c, int tid, int sw, int sh, int unroll2) {
+    (void)unroll2;
     const int rs = c->L.region_stride;
 #ifdef SVT_HOST_EMU
     if (tid != 0) return;
@@ -693,61 +795,8 @@ SVT_DEV void ph_fullpel_fused(const me_ctx_t *c, int tid, int sw, int sh) {
             for (int i = 0; i < 64; i++) svt_lds_min_u64(&c->st->key[21 + i], ((uint64_t)(2u * s8[i]) << 32) | pos);
         }
 #else
-    const int z = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bx = ((z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4)) * 8, by = (((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4)) * 8;
-    uint32_t  s0[4], s1[4]; /* rows 0, 2, 4, 6 of the source block */
-    _Pragma("unroll") for (int r = 0; r < 4; r++) {
-        const uint32_t *s = (const uint32_t *)(c->src + (by + 2 * r) * ME_SB + bx);
-        s0[r] = s[0]; s1[r] = s[1];
-    }
-    const uint8_t *rbase = c->region + ME_MUL(ME_RGN_GY + by, rs) + ME_RGN_GX + bx;
-    const int      ng = sw >> 2;
-    uint32_t       b8 = 0xffffffffu, b16 = 0xffffffffu, b32 = 0xffffffffu, b64 = 0xffffffffu;
-#define FP_MIN3(b, x, y) do { const uint32_t m_ = (x) < (y) ? (x) : (y); (b) = (b) < m_ ? (b) : m_; } while (0)
-#define FP_DPP(v, ctrl, rows) ((v) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rows), 0xf, false))
-    int y = 0, g = w; /* group q = y * ng + g, q = w, w + 4, ... (wave-uniform) */
-    while (g >= ng) { g -= ng; y++; }
-    while (y < sh) {
-        const uint8_t *rp = rbase + (y * rs + 4 * g); /* wave-uniform offset: scalar arithmetic */
-        uint64_t       acc = 0;
-        _Pragma("unroll") for (int r = 0; r < 4; r++) {
-            const uint32_t *q = (const uint32_t *)(rp + 2 * r * rs);
-            const uint32_t  d0 = q[0], d1 = q[1], d2 = q[2];
-            acc = svt_qsad(((uint64_t)d1 << 32) | d0, s0[r], acc);
-            acc = svt_qsad(((uint64_t)d2 << 32) | d1, s1[r], acc);
-        }
-        const uint32_t pos = (uint32_t)(y * sw + 4 * g);
-        uint32_t       lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32); /* positions pos, pos + 1 | pos + 2, pos + 3 as 16-bit sums */
-        FP_MIN3(b8, (lo << 16) | pos, (lo & 0xffff0000u) | (pos + 1));
-        FP_MIN3(b8, (hi << 16) | (pos + 2), (hi & 0xffff0000u) | (pos + 3));
-        /* 16x16: the quad's four blocks (sums stay below 2^16: no carry between the halves) */
-        lo = FP_DPP(lo, 0xB1, 0xf); hi = FP_DPP(hi, 0xB1, 0xf); /* quad_perm:[1,0,3,2] */
-        lo = FP_DPP(lo, 0x4E, 0xf); hi = FP_DPP(hi, 0x4E, 0xf); /* quad_perm:[2,3,0,1] */
-        FP_MIN3(b16, (lo << 16) | pos, (lo & 0xffff0000u) | (pos + 1));
-        FP_MIN3(b16, (hi << 16) | (pos + 2), (hi & 0xffff0000u) | (pos + 3));
-        /* 32x32: two quads still fit 16 bits, the four of the row need 32 */
-        lo = FP_DPP(lo, 0x124, 0xf); hi = FP_DPP(hi, 0x124, 0xf); /* row_ror:4 */
-        uint32_t a0 = lo & 0xffffu, a1 = lo >> 16, a2 = hi & 0xffffu, a3 = hi >> 16;
-        a0 = FP_DPP(a0, 0x128, 0xf); a1 = FP_DPP(a1, 0x128, 0xf); a2 = FP_DPP(a2, 0x128, 0xf); a3 = FP_DPP(a3, 0x128, 0xf); /* row_ror:8 */
-        FP_MIN3(b32, (a0 << 12) | pos, (a1 << 12) | (pos + 1));
-        FP_MIN3(b32, (a2 << 12) | (pos + 2), (a3 << 12) | (pos + 3));
-        /* 64x64: row 1 += row 0, row 3 += row 2 (row_bcast:15), then row 3 += row 1 (row_bcast:31): complete in lanes 48..63 */
-        a0 = FP_DPP(a0, 0x142, 0xa); a1 = FP_DPP(a1, 0x142, 0xa); a2 = FP_DPP(a2, 0x142, 0xa); a3 = FP_DPP(a3, 0x142, 0xa);
-        a0 = FP_DPP(a0, 0x143, 0xc); a1 = FP_DPP(a1, 0x143, 0xc); a2 = FP_DPP(a2, 0x143, 0xc); a3 = FP_DPP(a3, 0x143, 0xc);
-        FP_MIN3(b64, (a0 << 12) | pos, (a1 << 12) | (pos + 1));
-        FP_MIN3(b64, (a2 << 12) | (pos + 2), (a3 << 12) | (pos + 3));
-        g += 4;
-        while (g >= ng) { g -= ng; y++; }
-    }
-#undef FP_MIN3
-#undef FP_DPP
-    uint64_t *key = c->st->key;
-    if (b8 != 0xffffffffu) { /* this wave took at least one group */
-        svt_lds_min_u64(&key[21 + z], ((uint64_t)((b8 >> 16) << 1) << 32) | (b8 & 0xffffu));
-        if ((z & 3) == 0) svt_lds_min_u64(&key[5 + (z >> 2)], ((uint64_t)((b16 >> 16) << 1) << 32) | (b16 & 0xffffu));
-        if ((z & 15) == 0) svt_lds_min_u64(&key[1 + (z >> 4)], ((uint64_t)((b32 >> 12) << 1) << 32) | (b32 & 0xfffu));
-        if (z == 63) svt_lds_min_u64(&key[0], ((uint64_t)((b64 >> 12) << 1) << 32) | (b64 & 0xfffu));
-    }
+    if (unroll2) me_fullpel_fused_dev<2>(c, tid, sw, sh);
+    else me_fullpel_fused_dev<1>(c, tid, sw, sh);
 #endif
 }
 
@@ -1612,7 +1661,9 @@ SVT_DEV uint32_t me_magic_of(int d) { return (uint32_t)(0xffffffffu / (uint32_t)
 #ifdef SVT_HOST_EMU
 static inline uint32_t me_magic_small(int d) { return me_magic_of(d); }
 #else
-SVT_DEV uint32_t me_magic_small(int d) { return d <= 256 ? me_magics.v[d] : me_magic_of(d); }
+/* (d is the same in every active lane -- the planning thread is alone: a scalar load through the constant cache instead of a vector
+ * load with its ~1 us round trip on the critical path of the workgroup) */
+SVT_DEV uint32_t me_magic_small(int d) { const int du = __builtin_amdgcn_readfirstlane(d); return du <= 256 ? me_magics.v[du] : me_magic_of(du); }
 #endif
 SVT_DEV int me_div_magic(int t, uint32_t inv) { return inv ? (int)(((uint64_t)(uint32_t)t * inv) >> 32) : t; }
 
@@ -1826,9 +1877,18 @@ SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk,
 typedef struct me_hme_geom {
     const svt_plane *ref;
     const uint8_t   *blk; /* LDS */
-    int              bstride, bw, bh, ox, oy, pad_w, pad_h;
+    int              bstride, bw, bh, ox, oy, pad_w, pad_h, ref_w, ref_h;
 } me_hme_geom;
 
+/* a value the planning thread (alone in its wave) reads from LDS: on the device it goes to a scalar register, so that the
+ * arithmetic built on it -- placement, clipping, window sizes: everything a level's plan computes -- runs on the scalar unit
+ * instead of as a chain of dependent vector instructions of one lane (the workgroup waits for this thread: with the one or two
+ * waves per SIMD the 64x64-area configurations leave, its latency is not hidden by anything) */
+#ifdef SVT_HOST_EMU
+#define ME_PLAN_RD(x) (x)
+#else
+#define ME_PLAN_RD(x) __builtin_amdgcn_readfirstlane((int)(x))
+#endif
 SVT_DEV int16_t me_hme_round_w(int16_t w) { return (int16_t)((w < 8) ? 8 : (w & 7) ? w + (w - ((w >> 3) << 3)) : w); }
 
 /* geometry of an HME level for one reference list (hme_level0/1/2 of Codec/EbMotionEstimation.c) */
@@ -1843,8 +1903,9 @@ SVT_DEV void me_hme_geom_of(const me_ctx_t *c, int list, int lvl, me_hme_geom *g
         g->ref = &c->st->refd[0]; g->blk = c->src; g->bstride = 2 * ME_SB; g->bw = c->sb_w; g->bh = c->sb_h >> 1;
         g->ox = (int16_t)c->sb_x; g->oy = (int16_t)c->sb_y;
     }
-    g->pad_w = lvl == 2 ? ME_SB - 1 : g->ref->origin_x - 1;
-    g->pad_h = lvl == 2 ? ME_SB - 1 : g->ref->origin_y - 1;
+    g->pad_w = lvl == 2 ? ME_SB - 1 : ME_PLAN_RD(g->ref->origin_x) - 1;
+    g->pad_h = lvl == 2 ? ME_SB - 1 : ME_PLAN_RD(g->ref->origin_y) - 1;
+    g->ref_w = ME_PLAN_RD(g->ref->width); g->ref_h = ME_PLAN_RD(g->ref->height);
 }
 
 /* Plan one HME level (run by ONE thread): place the search areas of the level's regions (slot = rh*2 + rw), clip them,
@@ -1871,8 +1932,8 @@ SVT_DEV void me_hme_plan_level(const me_ctx_t *c, int list, int lvl, int16_t xsc
         { uint32_t *kw_ = (uint32_t *)&st->hme_keys[0]; kw_[0] = ~0u; kw_[1] = ~0u; }
         int16_t w = c->L.hme_tw0, h = c->L.hme_th0;
         int16_t ox = (int16_t)(-(int16_t)(w >> 1) + (int16_t)(xsc >> 2)), oy = (int16_t)(-(int16_t)(h >> 1) + (int16_t)(ysc >> 2));
-        me_clip_area(g.ox, &ox, &w, g.pad_w, g.ref->width);
-        me_clip_area(g.oy, &oy, &h, g.pad_h, g.ref->height);
+        me_clip_area(g.ox, &ox, &w, g.pad_w, g.ref_w);
+        me_clip_area(g.oy, &oy, &h, g.pad_h, g.ref_h);
         if ((w & 15) != 0) w = (int16_t)((w >> 4) << 4);
         st->hme_cox[0] = ox; st->hme_coy[0] = oy;
         const int ok = w > 0 && h > 0;
@@ -1900,9 +1961,9 @@ SVT_DEV void me_hme_plan_level(const me_ctx_t *c, int list, int lvl, int16_t xsc
         return;
     }
 #endif
-    if (first && st->hme_rh < NH) { /* [quirk] centres are only initialised while the reference's row counter is below NH */
+    if (first && ME_PLAN_RD(st->hme_rh) < NH) { /* [quirk] centres are only initialised while the reference's row counter is below NH */
         for (int k = 0; k < 4; k++)
-            if ((k & 1) < NW && (k >> 1) < NH && (k >> 1) >= st->hme_rh) {
+            if ((k & 1) < NW && (k >> 1) < NH && (k >> 1) >= ME_PLAN_RD(st->hme_rh)) {
                 st->hme_x[0][k] = (int16_t)(xsc >> 2); st->hme_y[0][k] = (int16_t)(ysc >> 2);
                 st->hme_x[1][k] = (int16_t)(xsc >> 1); st->hme_y[1][k] = (int16_t)(ysc >> 1);
                 st->hme_x[2][k] = xsc; st->hme_y[2][k] = ysc;
@@ -1939,16 +2000,16 @@ SVT_DEV void me_hme_plan_level(const me_ctx_t *c, int list, int lvl, int16_t xsc
         } else if (lvl == 1) {
             w  = me_hme_round_w((int16_t)p->hme_level1_search_area_in_width_array[rw]);
             h  = (int16_t)p->hme_level1_search_area_in_height_array[rh];
-            ox = (int16_t)(-(w >> 1) + (int16_t)(st->hme_x[0][k] >> 1));
-            oy = (int16_t)(-(h >> 1) + (int16_t)(st->hme_y[0][k] >> 1));
+            ox = (int16_t)(-(w >> 1) + (int16_t)((int16_t)ME_PLAN_RD(st->hme_x[0][k]) >> 1));
+            oy = (int16_t)(-(h >> 1) + (int16_t)((int16_t)ME_PLAN_RD(st->hme_y[0][k]) >> 1));
         } else {
             w  = me_hme_round_w((int16_t)p->hme_level2_search_area_in_width_array[rw]);
             h  = (int16_t)p->hme_level2_search_area_in_height_array[rh];
-            ox = (int16_t)(-(w >> 1) + st->hme_x[1][k]);
-            oy = (int16_t)(-(h >> 1) + st->hme_y[1][k]);
+            ox = (int16_t)(-(w >> 1) + (int16_t)ME_PLAN_RD(st->hme_x[1][k]));
+            oy = (int16_t)(-(h >> 1) + (int16_t)ME_PLAN_RD(st->hme_y[1][k]));
         }
-        me_clip_area(g.ox, &ox, &w, g.pad_w, g.ref->width);
-        me_clip_area(g.oy, &oy, &h, g.pad_h, g.ref->height);
+        me_clip_area(g.ox, &ox, &w, g.pad_w, g.ref_w);
+        me_clip_area(g.oy, &oy, &h, g.pad_h, g.ref_h);
         if (single && (w & 15) != 0) w = (int16_t)((w >> 4) << 4);
         st->hme_cox[k] = ox; st->hme_coy[k] = oy; /* kept even when nothing is searched: the centre still moves by them */
         if (w <= 0 || h <= 0) continue;
@@ -1988,7 +2049,7 @@ SVT_DEV void me_hme_finish_level(const me_ctx_t *c, int lvl) {
     for (int k = 0; k < 4; k++) {
         if (single ? k != 0 : ((k & 1) >= NW || (k >> 1) >= NH)) continue;
         uint64_t sad = 0xffffff;
-        int16_t  x = st->hme_x[lvl][k], y = st->hme_y[lvl][k];
+        int16_t  x = (int16_t)ME_PLAN_RD(st->hme_x[lvl][k]), y = (int16_t)ME_PLAN_RD(st->hme_y[lvl][k]);
         if (st->hme_cw[k] > 0) {
             const uint64_t key = st->hme_keys[k];
             if (key != ~0ull) {
@@ -2219,7 +2280,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         {
             uint32_t *U = (uint32_t *)c->planes;
             if (saw >= 8 && (saw & 7) == 0 && saw * sah <= 4096) {
-                ME_PHASE(ph_fullpel_fused(c, tid, saw, sah));
+                ME_PHASE(ph_fullpel_fused(c, tid, saw, sah, ME_FULLPEL_UNROLL2(c)));
                 ME_MARK(5);
                 ME_MARK(6);
             } else {

@@ -61,8 +61,6 @@ SVT_DEV uint32_t fme_src_code(const me_ctx_t *c, int plane, int dx, int dy) {
                           : (uint32_t)(128 + ME_MUL(plane - 1, c->L.plane_bytes) + ME_MUL(dy, c->L.plane_stride) + dx);
 }
 
-typedef uint64_t __attribute__((aligned(4))) fme_u64a4; /* a dword pair in LDS: ds_read2_b32 */
-
 /* inclusive sums over the wave: total in lane 63 (row_shr 1, 2, 4, 8, then row_bcast:15 into rows 1 / 3 and row_bcast:31 into
  * rows 2 / 3) */
 SVT_DEV uint32_t fme_wave_sum63(uint32_t v) {
@@ -227,10 +225,10 @@ template <int WS> SVT_DEV void fph_hme_search(const me_ctx_t *c, int tid, int ws
         _Pragma("unroll") for (int j = 0; j < 8; j++) {
             const uint8_t *wa = c->lds + (j < 6 ? o0 + 2 * j * ws : o2 + 2 * (j - 6) * ws), *wb = c->lds + (j < 6 ? o1 + 2 * j * ws : o3 + 2 * (j - 6) * ws);
             uint64_t       a = (j & 1) ? acc1 : acc0;
-            a = svt_qsad(*(const fme_u64a4 *)wa, blk[4 * j], a);
-            a = svt_qsad(*(const fme_u64a4 *)wb, blk[4 * j + 1], a);
-            a = svt_qsad(*(const fme_u64a4 *)(wa + 8), blk[4 * j + 2], a);
-            a = svt_qsad(*(const fme_u64a4 *)(wb + 8), blk[4 * j + 3], a);
+            a = svt_qsad(*(const me_u64a4 *)wa, blk[4 * j], a);
+            a = svt_qsad(*(const me_u64a4 *)wb, blk[4 * j + 1], a);
+            a = svt_qsad(*(const me_u64a4 *)(wa + 8), blk[4 * j + 2], a);
+            a = svt_qsad(*(const me_u64a4 *)(wb + 8), blk[4 * j + 3], a);
             if (j & 1) acc1 = a; else acc0 = a;
         }
         const uint32_t lo = (uint32_t)acc0 + (uint32_t)acc1, hi = (uint32_t)(acc0 >> 32) + (uint32_t)(acc1 >> 32); /* 8 rows x 16 x 255 < 2^16 */
@@ -250,91 +248,6 @@ template <int WS> SVT_DEV void fph_hme_search(const me_ctx_t *c, int tid, int ws
     FME_DPP_MIN(0x142, 0xa); FME_DPP_MIN(0x143, 0xc);
 #undef FME_DPP_MIN
     if ((tid & 63) == 63 && k != 0xffffffffu) atomicMin(key, k);
-}
-
-/* full-pel search, widths that are multiples of 8 and at most 4096 positions: the same fused phase as ph_fullpel_fused (lane = 8x8
- * block in z-order: a DPP quad is a 16x16 PU, a DPP row a 32x32 PU, the wave the 64x64 PU; the four waves take the groups of 4
- * positions round-robin), with the instruction stream of a group written out: both dwords of every QSAD operand are read as a
- * pair (two ds_read2 per row instead of register moves), a key is one v_lshl_or / v_and_or and five keys meet in two v_min3,
- * the 32x32 step adds 16-bit halves across the row without unpacking them first, and the 64x64 step is eight in-place DPP adds. */
-SVT_DEV uint32_t fme_min3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; }
-SVT_DEV void fph_fullpel_fused(const me_ctx_t *c, int tid, int sw, int sh) {
-    const int rs = c->L.region_stride;
-    const int z = tid & 63, w = ME_UNI(tid >> 6);
-    const int bx = ((z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4)) * 8, by = (((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4)) * 8;
-    uint32_t  s0[4], s1[4]; /* rows 0, 2, 4, 6 of the source block */
-    _Pragma("unroll") for (int r = 0; r < 4; r++) {
-        const uint32_t *s = (const uint32_t *)(c->src + (by + 2 * r) * ME_SB + bx);
-        s0[r] = s[0]; s1[r] = s[1];
-    }
-    /* byte offsets inside the workgroup's LDS of this lane's block at search position (0, 0) and of the dword after it.  Opaque:
-     * the address arithmetic of a group is then ONE add per operand stream with the rows as immediate offsets, and the second
-     * operand pair of a row is loaded as such, not assembled from the first with register moves. */
-    uint32_t ro0 = (uint32_t)(c->region - c->lds) + (uint32_t)(ME_MUL(ME_RGN_GY + by, rs) + ME_RGN_GX + bx), ro1 = ro0 + 4;
-    __asm__("" : "+v"(ro0));
-    __asm__("" : "+v"(ro1));
-    uint32_t mhi = 0xffff0000u;
-    __asm__("" : "+v"(mhi)); /* in a vector register: (x & mhi) | s is then ONE v_and_or_b32 (one scalar operand per instruction) */
-    const int ng = sw >> 2;
-    uint32_t  b8 = 0xffffffffu, b16 = 0xffffffffu, b32 = 0xffffffffu, b64 = 0xffffffffu;
-#define FP_DPP(v, ctrl) ((v) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xf, 0xf, false))
-#define FP_KEYS(b, lo, hi) do { \
-        b = fme_min3(b, ((lo) << 16) | pos, ((lo) & mhi) | (pos + 1)); \
-        b = fme_min3(b, ((hi) << 16) | (pos + 2), ((hi) & mhi) | (pos + 3)); } while (0)
-    /* group q = y * ng + g, q = w, w + 4, ... (wave-uniform; y by reciprocal multiplication on the scalar unit: the body stays one
-     * basic block) */
-    const uint32_t inv = me_magics.v[ng]; /* ng in [2, 31] */
-    const int      nq = ME_MUL(ng, sh);
-    for (int q = w; q < nq; q += 4) {
-        const int y = (int)(((uint64_t)(uint32_t)q * inv) >> 32), g = q - y * ng;
-        const int      off = ME_MUL(y, rs) + 4 * g; /* wave-uniform */
-        const uint8_t *rp = c->lds + (ro0 + (uint32_t)off), *rp1 = c->lds + (ro1 + (uint32_t)off);
-        uint64_t       acc = 0;
-        _Pragma("unroll") for (int r = 0; r < 4; r++) {
-            const uint64_t pa = *(const fme_u64a4 *)(rp + 2 * r * rs), pb = *(const fme_u64a4 *)(rp1 + 2 * r * rs);
-            acc = svt_qsad(pa, s0[r], acc);
-            acc = svt_qsad(pb, s1[r], acc);
-        }
-        const uint32_t pos = (uint32_t)(ME_MUL(y, sw) + 4 * g);
-        uint32_t       lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32); /* positions pos, pos + 1 | pos + 2, pos + 3 as 16-bit sums */
-        FP_KEYS(b8, lo, hi);
-        /* 16x16: the quad's four blocks (sums stay below 2^16: no carry between the halves) */
-        lo = FP_DPP(lo, 0xB1); hi = FP_DPP(hi, 0xB1); /* quad_perm:[1,0,3,2] */
-        lo = FP_DPP(lo, 0x4E); hi = FP_DPP(hi, 0x4E); /* quad_perm:[2,3,0,1] */
-        FP_KEYS(b16, lo, hi);
-        /* 32x32: two quads still fit 16 bits; the other half of the row is added half by half into 32-bit sums */
-        lo = FP_DPP(lo, 0x124); hi = FP_DPP(hi, 0x124); /* row_ror:4 */
-        const uint32_t lo8 = (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0x128, 0xf, 0xf, false); /* row_ror:8 */
-        const uint32_t hi8 = (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0x128, 0xf, 0xf, false);
-        uint32_t       a0 = (lo & 0xffffu) + (lo8 & 0xffffu), a1 = (lo >> 16) + (lo8 >> 16), a2 = (hi & 0xffffu) + (hi8 & 0xffffu), a3 = (hi >> 16) + (hi8 >> 16);
-        b32 = fme_min3(b32, (a0 << 12) | pos, (a1 << 12) | (pos + 1));
-        b32 = fme_min3(b32, (a2 << 12) | (pos + 2), (a3 << 12) | (pos + 3));
-        SVT_SCHED_FENCE(); /* the 32x32 keys above are done with a0..a3: the sums below run in place */
-        /* 64x64: row 1 += row 0, row 3 += row 2 (row_bcast:15), then rows 2, 3 += row 1 (row_bcast:31): complete in lanes 48..63.
-         * In place; the first DPP read comes two wait states behind the last write of its operand (s_nop: inline assembly is not
-         * covered by the compiler's hazard recogniser), the second round reads what was written four instructions earlier. */
-        __asm__("s_nop 1\n\t"
-                "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                "v_add_u32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                "v_add_u32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                "v_add_u32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-                "v_add_u32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-                "v_add_u32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-                "v_add_u32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf"
-                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
-        b64 = fme_min3(b64, (a0 << 12) | pos, (a1 << 12) | (pos + 1));
-        b64 = fme_min3(b64, (a2 << 12) | (pos + 2), (a3 << 12) | (pos + 3));
-    }
-#undef FP_KEYS
-#undef FP_DPP
-    uint64_t *key = c->st->key;
-    if (b8 != 0xffffffffu) { /* this wave took at least one group */
-        svt_lds_min_u64(&key[21 + z], ((uint64_t)((b8 >> 16) << 1) << 32) | (b8 & 0xffffu));
-        if ((z & 3) == 0) svt_lds_min_u64(&key[5 + (z >> 2)], ((uint64_t)((b16 >> 16) << 1) << 32) | (b16 & 0xffffu));
-        if ((z & 15) == 0) svt_lds_min_u64(&key[1 + (z >> 4)], ((uint64_t)((b32 >> 12) << 1) << 32) | (b32 & 0xfffu));
-        if (z == 63) svt_lds_min_u64(&key[0], ((uint64_t)((b64 >> 12) << 1) << 32) | (b64 & 0xfffu));
-    }
 }
 
 /* keys -> best SAD / motion vector of every PU (curr_mv = (y << 18) | (uint16)(x << 2), :108-110) and the su_pel_enable
@@ -459,9 +372,9 @@ SVT_DEV void fph_subpel(const me_ctx_t *c, int tid, int list, int sox, int soy, 
          * the tie order L,R,T,B,TL,TR,BL,BR (:1531-1556) */
         uint32_t k[8];
         _Pragma("unroll") for (int i = 0; i < 8; i++) k[i] = (d[i] << 4) | (uint32_t)i;
-        const uint32_t m5 = fme_min3(fme_min3(k[0], k[1], k[2]), k[3], k[4]);
-        const uint32_t km = fme_min3(m5 < k[5] ? m5 : k[5], k[6], k[7]);
-        const uint32_t kr = fme_min3(m5 < k[5] ? m5 : k[5], k[6] + 1, k[7] - 1); /* ranks of candidates 6 (BR) and 7 (BL) swapped */
+        const uint32_t m5 = me_min3(me_min3(k[0], k[1], k[2]), k[3], k[4]);
+        const uint32_t km = me_min3(m5 < k[5] ? m5 : k[5], k[6], k[7]);
+        const uint32_t kr = me_min3(m5 < k[5] ? m5 : k[5], k[6] + 1, k[7] - 1); /* ranks of candidates 6 (BR) and 7 (BL) swapped */
         if ((km >> 3) < best) {
             int sx, sy;
             me_dmv_get((int)(km & 7u), &sx, &sy);
@@ -503,7 +416,7 @@ SVT_DEV void fph_subpel(const me_ctx_t *c, int tid, int list, int sox, int soy, 
             q[0] = (v01 & 0xffffu) + (x & 0xffffu); q[1] = (v01 >> 16) + (x >> 16);
             q[2] = v2 + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v2, 0x142, 0xa, 0xf, false);
         } else { q[0] = v01 & 0xffffu; q[1] = v01 >> 16; q[2] = v2; }
-        const uint32_t km = fme_min3((q[0] << 4) | pos[0], (q[1] << 4) | pos[1], (q[2] << 4) | pos[2]);
+        const uint32_t km = me_min3((q[0] << 4) | pos[0], (q[1] << 4) | pos[1], (q[2] << 4) | pos[2]);
         if (last && (km >> 3) < best) {
             int sx, sy;
             me_dmv_get((int)(km & 7u), &sx, &sy);
@@ -704,7 +617,7 @@ template <int SPEC> __device__ __forceinline__ void me_sb_run_fast(const me_ctx_
         {
             uint32_t *U = (uint32_t *)c->planes;
             if (saw >= 8 && (saw & 7) == 0 && saw * sah <= 4096) {
-                ME_PHASE(fph_fullpel_fused(c, tid, saw, sah));
+                ME_PHASE(ph_fullpel_fused(c, tid, saw, sah, 0));
                 FME_MARK(5);
                 FME_MARK(6);
             } else { /* clipped at a picture border: the table form, in chunks of search rows (me_sb_run) */

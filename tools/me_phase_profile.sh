@@ -10,7 +10,7 @@ case "$SVT_HIP_LIB" in ""|/*) ;; *) export SVT_HIP_LIB=$ROOT/$SVT_HIP_LIB;; esac
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/ph /tmp/pht
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d /tmp/ph -o p -- python $ROOT/tools/me_phase_counts.py > /dev/null 2>&1
-ME_PICS=4 ME_REPS=5 rocprofv3 --kernel-trace --output-format csv -d /tmp/pht -o p -- python $ROOT/tools/me_phase_counts.py > /dev/null 2>&1
+ME_PICS=${ME_PICS:-4} ME_REPS=5 rocprofv3 --kernel-trace --output-format csv -d /tmp/pht -o p -- python $ROOT/tools/me_phase_counts.py > /dev/null 2>&1
 python3 - <<'PY'
 import csv, glob, collections, os
 f = glob.glob("/tmp/ph/**/*counter_collection.csv", recursive=True)[0]
@@ -20,7 +20,7 @@ for r in csv.DictReader(open(f)):
     rows.setdefault(r["Dispatch_Id"], {})[r["Counter_Name"]] = float(r["Counter_Value"])
 t = glob.glob("/tmp/pht/**/*kernel_trace.csv", recursive=True)[0]
 durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000.0 for r in sorted(csv.DictReader(open(t)), key=lambda r: int(r["Start_Timestamp"])) if "svt_me_" in r["Kernel_Name"] and "zz" not in r["Kernel_Name"]]
-durs = [min(durs[5 * i:5 * i + 5]) for i in range(len(durs) // 5)]   # 4 pictures per launch, best of 5
+durs = [min(durs[5 * i:5 * i + 5]) for i in range(len(durs) // 5)]   # $ME_PICS pictures per launch (default 4), best of 5
 names = [int(x) for x in os.environ["ME_STOPS"].split(",")]
 prev = None; pd = 0.0
 for k, (d, v), us in zip(names, rows.items(), durs):
