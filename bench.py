@@ -579,7 +579,7 @@ def main():
     # picture is reconstructed, deblocked and padded in the buffer later pictures predict from.
     d_pred = dev_zeros((G, MINIGOP, pic_bytes), torch.uint8)
     d_rec = dev_zeros((RING, G, MINIGOP, geo.rec_bytes), torch.uint8)
-    d_q, d_dq = dev_zeros(G * MINIGOP * geo.coeffs, torch.int16), dev_zeros(G * MINIGOP * geo.coeffs, torch.int16)
+    d_q = dev_zeros(G * MINIGOP * geo.coeffs, torch.int16)
     d_emap = dev_zeros((G, MINIGOP, geo.eob_entries), torch.int16)
     d_lfm = dev_zeros((G, MINIGOP, nsb * B.LF_MASK_DTYPE.itemsize), torch.uint8)
     d_nz = dev_zeros((G, MINIGOP, mi_rows * mi_cols), torch.uint8)
@@ -669,7 +669,7 @@ def main():
                         for l in range(2):
                             ref_desc(p.ref[l], slot, g, refs_of(i)[l])
                         co = (g * MINIGOP + i - 1) * geo.coeffs * 2
-                        p.d_qcoeff, p.d_dqcoeff = d_q.data_ptr() + co, d_dq.data_ptr() + co
+                        p.d_qcoeff, p.d_dqcoeff = d_q.data_ptr() + co, None   # the encode pass does not need dqcoeff in memory (svt_encdec_picture)
                         p.d_eob_map, p.d_lfm, p.d_nz = d_emap[g, i - 1].data_ptr(), d_lfm[g, i - 1].data_ptr(), d_nz[g, i - 1].data_ptr()
                         p.use_subpel, p.no_pad = 1, chunk_nopad[k]
                     per_phase.append(arr)
@@ -693,7 +693,7 @@ def main():
         downstream consumes them here, so one set per stream"""
         work = C.c_void_p()
         B.check(lib.svt_hip_encdec_work_create(ctx_, 1, Wd, Hd, C.byref(work)))
-        return {"work": work, "q": dev_zeros(geo.coeffs, torch.int16), "dq": dev_zeros(geo.coeffs, torch.int16), "emap": dev_zeros(geo.eob_entries, torch.int16),
+        return {"work": work, "q": dev_zeros(geo.coeffs, torch.int16), "emap": dev_zeros(geo.eob_entries, torch.int16),
                 "lfm": dev_zeros(nsb * B.LF_MASK_DTYPE.itemsize, torch.uint8), "nz": dev_zeros(mi_rows * mi_cols, torch.uint8)}
 
     def key_picture(res, g, k):
@@ -701,7 +701,7 @@ def main():
         p.d_lf_mi = d_key_mi.data_ptr()
         tight_desc(p.src, src_ptr(g, 0))
         key_desc(p.recon, g, k)
-        p.d_qcoeff, p.d_dqcoeff, p.d_eob_map, p.d_lfm, p.d_nz = res["q"].data_ptr(), res["dq"].data_ptr(), res["emap"].data_ptr(), res["lfm"].data_ptr(), res["nz"].data_ptr()
+        p.d_qcoeff, p.d_dqcoeff, p.d_eob_map, p.d_lfm, p.d_nz = res["q"].data_ptr(), None, res["emap"].data_ptr(), res["lfm"].data_ptr(), res["nz"].data_ptr()
         return p
 
     def run_key(ctx_, res, pic):
@@ -1028,7 +1028,7 @@ def main():
         "mc": int(96 * (inter_units + comp_units) + 96 * inter_units + 12 * mi_units),
         # the 8-byte grid records read twice (count, emit), a 32-byte descriptor + 4-byte position code written per block
         "lists": int(2 * 8 * mi_units + 36 * n_blocks_step),
-        "tq": pics_step * int(7.5 * L),                # src 1.5L + pred 1.5L + qcoeff 3L + recon 1.5L (the kernel also writes dqcoeff, +3L)
+        "tq": pics_step * int(7.5 * L),                # src 1.5L + pred 1.5L + qcoeff 3L + recon 1.5L (dqcoeff stays in registers: d_dqcoeff = NULL)
         # position code + eob read, eob map written (cleared first), the grid's skip flags updated
         "skip": int(6 * n_blocks_step + 2 * 2 * geo.eob_entries * pics_step + 2 * 8 * mi_units),
         "lf": pics_step * (3 * L + 160 * nsb),         # recon read + write (3L) + masks

@@ -709,7 +709,10 @@ typedef struct svt_encdec_picture {
     svt_yuv_planes          ref[2];    /* padded reference pictures (as svt_mc_picture.ref) */
     svt_yuv_planes          pred;      /* prediction picture (written by the inter prediction, read by the transform stage) */
     svt_yuv_planes          recon;     /* the picture's reconstruction = reference buffer (sample (0,0) pointers into padded planes) */
-    int16_t                *d_qcoeff, *d_dqcoeff; /* n_sb * SVT_SB_COEFFS each, 16-byte aligned, position-addressed (above) */
+    int16_t                *d_qcoeff, *d_dqcoeff; /* n_sb * SVT_SB_COEFFS each, 16-byte aligned, position-addressed (above).  d_dqcoeff may be
+                                                      NULL (for every picture of a call or for none): the encode pass consumes the dequantised
+                                                      coefficients in the lane that produced them (inverse transform) and nothing downstream
+                                                      reads them -- they then never travel to memory (3 bytes per sample less traffic) */
     uint16_t               *d_eob_map; /* eob of every transform block at its 4x4 unit: [Y: (H/4) x (W/4)] [Cb: (H/8) x (W/8)] [Cr] */
     svt_lf_mask            *d_lfm;     /* [sb_rows][sb_cols] masks (written; read by the loop filter) */
     uint8_t                *d_nz;      /* scratch, mi_rows * mi_stride bytes */

@@ -297,8 +297,9 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
     for (int i = 0; i < n_pics; i++) {
         const svt_encdec_picture &p = pics[i];
         if (!p.d_mc_mi || !p.d_lf_mi || !p.src.y || !p.src.u || !p.src.v || !p.pred.y || !p.pred.u || !p.pred.v || !p.recon.y || !p.recon.u || !p.recon.v ||
-            !p.d_qcoeff || !p.d_dqcoeff || !p.d_eob_map || !p.d_nz || (flags->apply_loop_filter && !p.d_lfm))
+            !p.d_qcoeff || !p.d_eob_map || !p.d_nz || (flags->apply_loop_filter && !p.d_lfm))
             return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: null picture field");
+        if (!p.d_dqcoeff != !pics[0].d_dqcoeff) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: d_dqcoeff must be given for every picture of a batch or for none");
         if (((uintptr_t)p.d_qcoeff | (uintptr_t)p.d_dqcoeff) & 15) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: coefficient arrays must be 16-byte aligned");
         const uint8_t *s3[3] = {p.src.y, p.src.u, p.src.v}, *p3[3] = {p.pred.y, p.pred.u, p.pred.v};
         for (int k = 0; k < 3; k++) {
@@ -335,7 +336,7 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
         ed_pic_dev &P = hb.pic[i];
         P.mc_mi = (svt_mc_mode_info *)p.d_mc_mi; P.lf_mi = p.d_lf_mi; P.nz = p.d_nz; P.eob_map = p.d_eob_map; P.lfm = p.d_lfm;
         const uintptr_t q_off = ((uintptr_t)p.d_qcoeff - q_lo) / sizeof(int16_t), dq_off = ((uintptr_t)p.d_dqcoeff - dq_lo) / sizeof(int16_t);
-        if (q_off != dq_off || q_off + (uint64_t)hb.n_sb * SVT_SB_COEFFS >= (1ull << 32))
+        if ((p.d_dqcoeff && q_off != dq_off) || q_off + (uint64_t)hb.n_sb * SVT_SB_COEFFS >= (1ull << 32))
             return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: qcoeff / dqcoeff of the batch must be laid out alike, within 2^32 elements");
         /* the picture's reconstruction planes: 32-bit offsets from one of at most ED_MAX_SETS base pointers (a base serves every
            picture whose planes lie within 4 GB above it: buffers carved out of one slab share one) */
@@ -447,7 +448,7 @@ extern "C" int32_t svt_hip_encdec_intra_device(svt_hip_ctx *ctx, svt_encdec_work
     if (!flags->do_recon) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec_intra: intra prediction needs the reconstruction (do_recon)");
     if (flags->apply_loop_filter && !thr) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec_intra: loop filter without thresholds");
     const svt_encdec_picture &p = *pic;
-    if (!p.d_lf_mi || !p.src.y || !p.src.u || !p.src.v || !p.recon.y || !p.recon.u || !p.recon.v || !p.d_qcoeff || !p.d_dqcoeff || !p.d_eob_map || !p.d_nz ||
+    if (!p.d_lf_mi || !p.src.y || !p.src.u || !p.src.v || !p.recon.y || !p.recon.u || !p.recon.v || !p.d_qcoeff || !p.d_eob_map || !p.d_nz ||
         (flags->apply_loop_filter && !p.d_lfm))
         return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec_intra: null picture field");
     if (((uintptr_t)p.d_qcoeff | (uintptr_t)p.d_dqcoeff) & 15) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec_intra: coefficient arrays must be 16-byte aligned");

@@ -137,7 +137,8 @@ __device__ __forceinline__ uint8_t clip_add(int d, int t) { int v = d + t; retur
 /* One block.  k: its descriptor; active: false for the idle slots of a partly filled workgroup (they run along, store nothing);
  * i: the lane's column (first pass) / row (second pass); t: the block's N x (N + 1) dword LDS tile; srow / prow: row i of source and
  * prediction, packed; eob_slot / dist_slot / bits_slot: where the block's results go (dist_slot may be null; bits_slot, rate_T, s_tc,
- * s_scan only with RATE); recon_base + k.recon_off = the block's reconstruction.  Contains workgroup barriers: every lane of the
+ * s_scan only with RATE); recon_base + k.recon_off = the block's reconstruction; dqcoeff may be null (the dequantised coefficients then
+ * go from the quantiser to the inverse transform in registers and nowhere else).  Contains workgroup barriers: every lane of the
  * workgroup has to call it, with k.do_recon uniform over the workgroup.  Returns the block's eob (every lane of the block). */
 /* WT: the reconstruction is stored write-through (agent-scope dword stores), for a caller whose neighbour blocks are read by other
  * workgroups of the SAME launch (intra_kernel.hip): they then see it without a release fence -- on this part an agent-scope release /
@@ -257,11 +258,11 @@ __device__ __forceinline__ int tq_block_body(const svt_tq_block &k, const bool a
             else { qw[j] = (uint16_t)qv; dqw[j] = (uint16_t)dv; }
             if ((kk % VC) == VC - 1) {
                 if constexpr (N == 4) {
-                    if (active) { *(uint2 *)qo = make_uint2(qw[0], qw[1]); *(uint2 *)dqo = make_uint2(dqw[0], dqw[1]); }
+                    if (active) { *(uint2 *)qo = make_uint2(qw[0], qw[1]); if (dqcoeff) *(uint2 *)dqo = make_uint2(dqw[0], dqw[1]); }
                 } else {
                     if (active) {
                         ((uint4 *)qo)[kk / VC]  = make_uint4(qw[0], qw[1], qw[2], qw[3]);
-                        ((uint4 *)dqo)[kk / VC] = make_uint4(dqw[0], dqw[1], dqw[2], dqw[3]);
+                        if (dqcoeff) ((uint4 *)dqo)[kk / VC] = make_uint4(dqw[0], dqw[1], dqw[2], dqw[3]); /* (uniform: a kernel argument) */
                     }
                     /* RATE: the block's quantised coefficients also go to the (now dead) transpose tile, raster order, for
                      * the scan walk below; the tile of a block is private to its N lanes, which sit in one wave */

@@ -259,8 +259,8 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
             }
         }
         int16_t *qo = qcoeff + k.coeff_off + i * N, *dqo = dqcoeff + k.coeff_off + i * N;
-        if constexpr (N == 4) { *(uint2 *)qo = make_uint2(qw[0], qw[1]); *(uint2 *)dqo = make_uint2(dqw[0], dqw[1]); }
-        else { *(uint4 *)qo = make_uint4(qw[0], qw[1], qw[2], qw[3]); *(uint4 *)dqo = make_uint4(dqw[0], dqw[1], dqw[2], dqw[3]); }
+        if constexpr (N == 4) { *(uint2 *)qo = make_uint2(qw[0], qw[1]); if (dqcoeff) *(uint2 *)dqo = make_uint2(dqw[0], dqw[1]); }
+        else { *(uint4 *)qo = make_uint4(qw[0], qw[1], qw[2], qw[3]); if (dqcoeff) *(uint4 *)dqo = make_uint4(dqw[0], dqw[1], dqw[2], dqw[3]); }
     }
     eob_out[blk] = (uint16_t)eob;
     if constexpr (DIST) if (dist_out) { dist_out[2 * blk] = rdist; dist_out[2 * blk + 1] = pdist; }

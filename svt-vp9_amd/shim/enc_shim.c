@@ -285,7 +285,6 @@ static int alloc_dev(shim_state *s, shim_dev *d) {
     const size_t n = (size_t)d->n_slots, units = (size_t)s->mi_rows * s->mi_cols;
     int ok = svt_hip_mem_alloc(d->ctx, n * s->pic_bytes, &d->d_src_slab) == SVT_HIP_OK && svt_hip_mem_alloc(d->ctx, n * s->pic_bytes, &d->d_pred_slab) == SVT_HIP_OK &&
              svt_hip_mem_alloc(d->ctx, n * s->coeffs * sizeof(int16_t), &d->d_q_slab) == SVT_HIP_OK &&
-             svt_hip_mem_alloc(d->ctx, n * s->coeffs * sizeof(int16_t), &d->d_dq_slab) == SVT_HIP_OK &&
              svt_hip_encdec_work_create(d->ctx, SHIM_WAVE_MAX, W, H, &d->work) == SVT_HIP_OK;
     for (int i = 0; ok && i < d->n_slots; i++) {
         shim_slot *t = &d->slot[i];
@@ -301,7 +300,7 @@ static int alloc_dev(shim_state *s, shim_dev *d) {
         t->d_src = (uint8_t *)d->d_src_slab + (size_t)i * s->pic_bytes;
         t->d_pred = (uint8_t *)d->d_pred_slab + (size_t)i * s->pic_bytes;
         t->d_qcoeff = (int16_t *)d->d_q_slab + (size_t)i * s->coeffs;
-        t->d_dqcoeff = (int16_t *)d->d_dq_slab + (size_t)i * s->coeffs;
+        t->d_dqcoeff = NULL; /* the encode pass keeps the dequantised coefficients in registers (svt_encdec_picture.d_dqcoeff) */
         void *rec = NULL;
         ok = ok && svt_hip_mem_alloc(d->ctx, s->rec_bytes, &rec) == SVT_HIP_OK &&
              svt_hip_mem_alloc(d->ctx, (size_t)s->n_sb * 85 * sizeof(svt_me_pu_result), &t->d_results) == SVT_HIP_OK &&

@@ -104,7 +104,7 @@ def md_host(me, W, H, lam, level):
     return mc, lf
 
 
-def run_device(ctx, W, H, srcs, refs, grids, q_index, flags, thr, rec_inits, has_intra=0):
+def run_device(ctx, W, H, srcs, refs, grids, q_index, flags, thr, rec_inits, has_intra=0, no_dq=False):
     lib = B.load()
     n = len(srcs)
     pic = W * H * 3 // 2
@@ -114,6 +114,9 @@ def run_device(ctx, W, H, srcs, refs, grids, q_index, flags, thr, rec_inits, has
     refs_dev = [dev(r.buf) for r in refs]
     dp = [DevPicture(W, H, srcs[i], refs_dev, grids[i][0], grids[i][1], slab_src, slab_pred, slab_q, slab_dq, i, rec_inits[i]) for i in range(n)]
     arr = (B.EncdecPicture * n)(*[d.struct(refs, has_intra=has_intra) for d in dp])
+    if no_dq:   # svt_encdec_picture.d_dqcoeff = NULL: the dequantised coefficients never leave the lane
+        for k in range(n):
+            arr[k].d_dqcoeff = None
     work = C.c_void_p()
     B.check(lib.svt_hip_encdec_work_create(ctx, n, W, H, C.byref(work)))
     torch.cuda.synchronize()
@@ -198,6 +201,29 @@ def test_encdec_batch_vs_oracle_chain(ctx, W, H, n_pics, q_index, cfg):
             for a, b in zip(o["rec"].interior(rec_g), srcs[i]):
                 assert np.mean(np.abs(a.astype(np.int32) - b)) < 16       # it IS a reconstruction of the source
     assert len(kinds) >= 2                                                # the stand-in decision really partitions
+
+
+def test_encdec_batch_without_dqcoeff(ctx):
+    """d_dqcoeff = NULL (the encode pass of the bench and of the encoder library): same quantised coefficients, same reconstruction,
+    and the dqcoeff buffers are not written"""
+    lib = B.load()
+    W, H, n_pics, q_index = 200, 136, 3, 150
+    srcs, refs, me = make_inputs(W, H, n_pics, seed=77)
+    level = lib.svt_hip_lf_level_from_q(lib.svt_hip_vp9_ac_step(q_index), 0)
+    grids = [md_host(m, W, H, 300, level) for m in me]
+    flags = flags_of(enc_mode=8, tune=1, temporal_layer_index=0, is_used_as_reference=1, recon_file=0, loop_filter=1)
+    thr = B.LfThresh()
+    lib.svt_hip_lf_thresh_init(C.byref(thr), 0)
+    out = []
+    for no_dq in (False, True):
+        rec_inits = [M.RefPic(W, H) for _ in range(n_pics)]
+        grids_k = [(mc.copy(), lf.copy()) for mc, lf in grids]
+        dp, blocks, pos, eob, cnt = run_device(ctx, W, H, srcs, refs, grids_k, q_index, flags, thr, rec_inits, no_dq=no_dq)
+        out.append(([d.q_t.cpu().numpy() for d in dp], [d.dq_t.cpu().numpy() for d in dp], [d.rec_t.cpu().numpy() for d in dp], eob))
+    for i in range(n_pics):
+        assert np.array_equal(out[0][0][i], out[1][0][i]) and np.array_equal(out[0][2][i], out[1][2][i])
+        assert out[0][1][i].any() and not out[1][1][i].any()
+    assert np.array_equal(out[0][3], out[1][3])
 
 
 def test_md_default_device_equals_host(ctx):
