@@ -433,7 +433,8 @@ int32_t svt_hip_tq_rd_batch_device(svt_hip_ctx *ctx, const uint8_t *d_src, const
                                    int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist,
                                    const struct svt_rate_tables *d_tables, const int16_t *d_scan, int32_t *d_bits);
 /* The same for a batch whose blocks reconstruct into up to 8 different buffers: block b writes into recon_set[i] + recon_off with
- * i = bits 4-6 of pad_[0] (SVT_TQ_RECON_SET(i), OR-ed with the rate info).  recon_set is a HOST array of n_set device pointers.
+ * i = bits 4-6 of pad_[0] (SVT_TQ_RECON_SET(i), OR-ed with the rate info).  recon_set is a HOST array of n_set device pointers; a
+ * block whose i >= n_set is transformed and quantised like any other but its reconstruction is written nowhere.
  * In the reference every picture reconstructs into its own reference-picture buffer (Codec/EbEncDecProcess.c:5658-5674); a step of
  * a picture-level pipeline codes pictures of several mini-GOPs whose buffers need not lie within one 32-bit offset of each other:
  * this entry serves them with one launch per transform size.  d_bits == NULL: no rate (then d_tables / d_scan are ignored). */

@@ -323,7 +323,7 @@ __device__ __forceinline__ int tq_block_body(const svt_tq_block &k, const bool a
     }
     /* residual column i -> LDS -> row i; reconstruction = clip(pred row + residual row), stored as dwords */
     _Pragma("unroll") for (int r = 0; r < N; r++) t[r * LS + i] = res[r];
-    if (active) {
+    if (active && recon_base) { /* (null: the block named a reconstruction set the caller did not pass) */
         /* a batch may reconstruct into several buffers (reference pictures of different mini-GOPs): pad_[0] bits 4-6 name the one */
         uint8_t *d = recon_base + k.recon_off + (size_t)i * k.recon_stride;
         uint32_t rw[N / 4];

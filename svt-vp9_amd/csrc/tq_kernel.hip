@@ -312,8 +312,10 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
                 rw[r][cc >> 2] |= (uint32_t)clip_add((int)((prow[r][cc >> 2] >> (8 * (cc & 3))) & 0xff), a1) << (8 * (cc & 3));
         }
     }
+    uint8_t *const rbase = recon_set ? (uint8_t *)recon_set[(k.pad_[0] >> 4) & 7] : recon;
+    if (!rbase) continue; /* a set index beyond the caller's n_set: nowhere to reconstruct to (never buffer 0 by default) */
     _Pragma("unroll") for (int r = 0; r < N; r++) {
-        uint8_t *d = (recon_set ? (uint8_t *)recon_set[(k.pad_[0] >> 4) & 7] : recon) + k.recon_off + (size_t)r * k.recon_stride;
+        uint8_t *d = rbase + k.recon_off + (size_t)r * k.recon_stride;
         if constexpr (N == 4) *(uint32_t *)d = rw[r][0];
         else row_store<N>(d, ((uintptr_t)d & 7) == 0, rw[r]);
     }
@@ -359,7 +361,7 @@ int32_t tq_launch_all(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_p
     if (recon_set) {
         void *h = nullptr, *d = nullptr;
         if (svt_ctx_stage(ctx, 8 * sizeof(void *), &h, &d)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "tq: descriptor buffers");
-        for (int i = 0; i < 8; i++) ((uint8_t **)h)[i] = recon_set[i < n_set ? i : 0];
+        for (int i = 0; i < 8; i++) ((uint8_t **)h)[i] = i < n_set ? recon_set[i] : nullptr; /* a block that names a set >= n_set is not reconstructed anywhere */
         HIP_TRY(hipMemcpyAsync(d, h, 8 * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
         d_set = (const uint8_t *const *)d;
     }
@@ -407,7 +409,7 @@ int32_t svt_tq_launch_device_lists(svt_hip_ctx *ctx, const uint8_t *d_src, const
     HIP_TRY(hipSetDevice(ctx->device));
     void *h = nullptr, *d = nullptr;
     if (svt_ctx_stage(ctx, 8 * sizeof(void *), &h, &d)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "tq: descriptor buffers");
-    for (int i = 0; i < 8; i++) ((uint8_t **)h)[i] = recon_set[i < n_set ? i : 0];
+    for (int i = 0; i < 8; i++) ((uint8_t **)h)[i] = i < n_set ? recon_set[i] : nullptr; /* a block that names a set >= n_set is not reconstructed anywhere */
     HIP_TRY(hipMemcpyAsync(d, h, 8 * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
     const uint8_t *const *d_set = (const uint8_t *const *)d;
     const tq_rate_args none = {nullptr, nullptr, nullptr};

@@ -74,12 +74,20 @@ def _sample_ranges(nsb, nsbx, want=200, run=20):
 
 
 @pytest.mark.skipif(not T.have_ref("ref_me_sb"), reason="oracle/_ref/ref_me_sb not built")
-@pytest.mark.parametrize("name,layer", [("c1_360p_m9", 1), ("c2_1080p_m8", 2), ("c3_2160p_m8", 3), ("c3_2160p_m8", 0)])
+@pytest.mark.parametrize("name,layer", [("c1_360p_m9", 1), ("c2_1080p_m8", 2), ("c3_2160p_m8", 3), ("c3_2160p_m8", 0), ("c5_sad", 1), ("c5_sad", 3)])
 def test_hip_me_vs_reference_motion_estimate_sb(ctx, name, layer):
-    W, H = MC.PRESETS[name][:2]
+    """c5_sad: BASELINE C5's parameter set (2160p enc-mode 3 tune 0: four HME regions x three levels, 64x64 full-pel area, every PU
+    refined) with the SAD fractional search instead of the SSD one -- the reference's SSD loop calls the yasm-only Log2f and cannot be
+    built here, everything else C5 exercises runs in the reference's own motion_estimate_sb"""
+    if name == "c5_sad":
+        W, H = MC.PRESET_C5[1][:2]
+        p = MC.preset_c5(2, layer)
+        p.fractional_search_method = 0   # SVT_SUB_SAD_SEARCH
+    else:
+        W, H = MC.PRESETS[name][:2]
+        p = MC.preset(name, 2, layer)
     frames = T.gen_clip_subpel(W, H, 3, 60 + layer)
     pics = [T.PaPic(f) for f in frames]
-    p = MC.preset(name, 2, layer)
     g, _ = hip_me_picture(ctx, pics[1], pics[0], pics[2], p)
     nsb, nsbx = T.n_sb(W, H), (W + 63) // 64
     checked = 0

@@ -161,3 +161,17 @@ def test_tq_rd_multi_reconstruction_buffers(ctx):
         got = recs[k].cpu().numpy().reshape(case["src"].shape)
         assert np.array_equal(got[own == k], o[0][own == k]) and (got[own != k] == 0x5A).all(), k
     assert lib.svt_hip_tq_rd_batch_multi_device(ctx, p(src), p(pred), rset, 9, p(dblk), cnt, p(qt), p(isc), p(q), p(dq), p(eob), p(dist), p(tab), p(scan), p(bits)) == -1
+    # only two of the three buffers passed: the blocks that name set 2 keep their coefficients but are reconstructed NOWHERE (not into
+    # buffer 0 by default)
+    for t in recs:
+        t.fill_(0x5A)
+    q.zero_()
+    B.check(lib.svt_hip_tq_rd_batch_multi_device(ctx, p(src), p(pred), rset, 2, p(dblk), cnt, p(qt), p(isc), p(q), p(dq), p(eob), p(dist), p(tab), p(scan), p(bits)))
+    B.check(lib.svt_hip_ctx_synchronize(ctx))
+    assert np.array_equal(q.cpu().numpy(), o[1])
+    for k in range(3):
+        got = recs[k].cpu().numpy().reshape(case["src"].shape)
+        if k < 2:
+            assert np.array_equal(got[own == k], o[0][own == k]) and (got[own != k] == 0x5A).all(), k
+        else:
+            assert (got == 0x5A).all()
