@@ -679,6 +679,11 @@ int32_t svt_hip_tq_blocks_from_grid(int32_t n_pics, const svt_lf_mode_info *cons
  * (VPX/vp9_quant_common.c); eb_vp9_quantizer_to_qindex (VPX/vp9_quantize.c:329). */
 const int16_t *svt_hip_vp9_iscan_tables(const uint32_t **offsets16, int32_t *entries);
 int32_t svt_hip_vp9_qindex_from_qp(int32_t qp);
+/* The q index a picture is coded at in fixed-QP mode: the sequence QP scaled by the picture's temporal layer -- QP_SCALING_MODE_0 of
+ * eb_vp9_rate_control_kernel (Codec/EbRateControlProcess.c:4680-4722: eb_vp9_compute_qdelta with delta_rate_oq / _sq / _vmaf).  tune:
+ * 0 SQ, 1 OQ, 2 VMAF; hierarchical_levels 3 or 4.  is_key: the sequence q index itself (key frames take the reference's adaptive
+ * QP_SCALING_MODE_1, which is rate control proper and not part of this path). */
+int32_t svt_hip_vp9_layer_qindex(int32_t qp, int32_t tune, int32_t hierarchical_levels, int32_t temporal_layer_index, int32_t is_key);
 int32_t svt_hip_vp9_dc_step(int32_t q_index);
 int32_t svt_hip_vp9_ac_step(int32_t q_index);
 /* out[0] luma, out[1] chroma tables of a q index with zero deltas (the sequence-level eb_vp9_init_quantizer) */

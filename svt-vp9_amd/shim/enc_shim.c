@@ -45,6 +45,7 @@
 
 #include "../../include/svt_vp9_enc_api.h"
 #include "../../include/svtvp9_hip.h"
+#include "../csrc/encdec_core.h" /* svt_tq_unit_is_origin: the block rules the device-side driver applies to a mode-info grid */
 
 #define SHIM_MAX_MINIGOP 16
 #define SHIM_MAX_DEV 8
@@ -207,6 +208,34 @@ static EbErrorType gpu_fail(shim_state *s) { /* a failed device call ends the st
     return EB_ErrorMax;
 }
 #define GPU_TRY(call) do { if ((call) != SVT_HIP_OK) return gpu_fail(s); } while (0)
+/* an error that is not the device's, found after work of the group has been enqueued: the stream ends the same way (later calls
+ * answer EB_ErrorMax) instead of going on with a group that is half processed */
+static EbErrorType stream_fail(shim_state *s, const char *why) {
+    fprintf(stderr, "SvtVp9Enc (GPU hot path): %s\n", why);
+    s->failed = 1;
+    return EB_ErrorBadParameter;
+}
+
+/* A mode-decision callback's grid, checked on the host before it is uploaded (the pipeline is drained at that point anyway): the
+ * rules the device-side driver applies (svt_tq_unit_is_origin: sizes, transform not larger than the block, blocks aligned to their
+ * size and inside the picture) and the intra pass's (csrc/intra_kernel.hip: square blocks of 4x4 .. 32x32 with the transform of
+ * their own size, modes 0..9).  The device would only flag such a grid and SKIP the offending blocks -- their area would keep the
+ * slot's previous picture and be used as a reference.  Returns 1 when the grid is malformed. */
+static int grid_malformed(const shim_state *s, const svt_lf_mode_info *g, int intra_picture) {
+    for (int ur = 0; ur < s->mi_rows; ur++)
+        for (int uc = 0; uc < s->mi_cols; uc++) {
+            const int o = svt_tq_unit_is_origin(g, s->mi_cols, s->mi_rows, s->mi_cols, ur, uc);
+            if (o < 0) return 1;
+            if (!o) continue;
+            const svt_lf_mode_info *b = &g[ur * s->mi_cols + uc];
+            if (b->is_inter) { if (intra_picture) return 1; continue; }
+            const int sub = b->sb_type == 0, w8 = (b->sb_type == 3 || sub) ? 1 : b->sb_type == 6 ? 2 : b->sb_type == 9 ? 4 : 0;
+            if (!w8 || b->tx_size != (sub ? 0 : w8 == 1 ? 1 : w8 == 2 ? 2 : 3) || b->pad_[2] > 9) return 1;
+            if (sub) { const int m4 = (int)b->pad_[1] | (int)b->pad_[0] << 8; for (int q = 0; q < 4; q++) if (((m4 >> (4 * q)) & 15) > 9) return 1; }
+            else if (b->pad_[1] > 9) return 1;
+        }
+    return 0;
+}
 
 /* ------------------------------------------------------------------------------------------------ */
 EbErrorType eb_vp9_svt_init_handle(EbComponentType **p_handle, void *p_app_data, EbSvtVp9EncConfiguration *config_ptr) {
@@ -560,6 +589,11 @@ static EbErrorType encode_wave(shim_state *s, shim_dev *d, const shim_job *const
         fc.recon_file = (int32_t)s->cfg.recon_file; fc.loop_filter = s->cfg.loop_filter;
         if (svt_hip_encdec_flags_derive(&fc, &fl) != SVT_HIP_OK) return EB_ErrorBadParameter;
     }
+    /* fixed-QP mode: the wave's temporal layer scales the sequence QP (QP_SCALING_MODE_0 of the reference's rate-control kernel,
+       svt_hip_vp9_layer_qindex); the deblocking level and the stand-in decision's lambda follow the picture's q index */
+    const int      q_l = s->cfg.rate_control_mode == 0 ? svt_hip_vp9_layer_qindex((int32_t)s->cfg.qp, s->cfg.tune, wj[0]->levels, wj[0]->layer, 0) : s->q_index;
+    const int      level_l = s->cfg.loop_filter ? svt_hip_lf_level_from_q(svt_hip_vp9_ac_step(q_l), 0) : 0;
+    const uint32_t lambda_l = 4u * (uint32_t)svt_hip_vp9_ac_step(q_l);
     int n_stand_in = 0;
     int has_intra[SHIM_WAVE_MAX] = {0};
     const svt_me_pu_result *res[SHIM_WAVE_MAX];
@@ -568,14 +602,16 @@ static EbErrorType encode_wave(shim_state *s, shim_dev *d, const shim_job *const
     for (int i = 0; i < n; i++) {
         shim_slot *t = ts[i] = find_slot(d, wj[i]->number);
         shim_slot *r0 = find_slot(d, wj[i]->ref0), *r1 = wj[i]->n_lists == 2 ? find_slot(d, wj[i]->ref1) : r0;
-        if (!t || !r0 || !r1) return EB_ErrorBadParameter;
+        if (!t || !r0 || !r1) return stream_fail(s, "a picture of the group or one of its references is not resident");
         int decided = 0;
         t->info.decision_source = 0;
+        t->info.q_index = q_l; t->info.filter_level = level_l; /* (the callback reads them: the level goes into its grid) */
         if (s->md_cb) { /* the host decides: it needs the ME results, so the pipeline drains here */
             GPU_TRY(svt_hip_mem_download(d->ctx, s->h_results, t->d_results, (size_t)s->n_sb * 85 * sizeof(svt_me_pu_result)));
             memset(s->h_mc, 0, (size_t)s->mi_rows * s->mi_cols * sizeof(svt_mc_mode_info));
             memset(s->h_lf, 0, (size_t)s->mi_rows * s->mi_cols * sizeof(svt_lf_mode_info));
             if (s->md_cb(s->md_user, &t->info, s->h_results, s->h_mc, s->h_lf, s->mi_cols) == 0) {
+                if (grid_malformed(s, (const svt_lf_mode_info *)s->h_lf, 0)) return stream_fail(s, "mode-decision callback: malformed mode-info grid");
                 GPU_TRY(svt_hip_mem_upload_2d(d->ctx, t->d_mc_mi, (size_t)s->mi_cols * sizeof(svt_mc_mode_info), s->h_mc, (size_t)s->mi_cols * sizeof(svt_mc_mode_info),
                                               (size_t)s->mi_cols * sizeof(svt_mc_mode_info), (size_t)s->mi_rows));
                 GPU_TRY(svt_hip_mem_upload_2d(d->ctx, t->d_lf_mi, (size_t)s->mi_cols * sizeof(svt_lf_mode_info), s->h_lf, (size_t)s->mi_cols * sizeof(svt_lf_mode_info),
@@ -595,14 +631,23 @@ static EbErrorType encode_wave(shim_state *s, shim_dev *d, const shim_job *const
         p->ref[0] = rec_planes(s, r0->d_rec); p->ref[1] = rec_planes(s, r1->d_rec);
         p->d_qcoeff = t->d_qcoeff; p->d_dqcoeff = t->d_dqcoeff; p->d_eob_map = (uint16_t *)t->d_eob_map; p->d_lfm = (svt_lf_mask *)t->d_lfm; p->d_nz = (uint8_t *)t->d_nz;
         p->use_subpel = job_use_subpel(wj[i]);
-        if (has_intra[i] && !fl.do_recon) return EB_ErrorBadParameter; /* a picture that is not reconstructed cannot hold intra blocks (the reference's limit_intra) */
         p->has_intra = has_intra[i];
         t->info.is_used_as_reference = wj[i]->used_as_ref; t->info.do_recon = fl.do_recon; t->info.apply_loop_filter = fl.apply_loop_filter;
-        t->info.pad_reference = fl.pad_reference; t->info.q_index = s->q_index; t->info.filter_level = s->filter_level; t->info.intra_recon_is_source = 0;
+        t->info.pad_reference = fl.pad_reference; t->info.q_index = q_l; t->info.filter_level = level_l; t->info.intra_recon_is_source = 0;
+    }
+    {   /* intra blocks need their neighbours' reconstruction: a wave that would not be reconstructed (the deepest layer without
+           reconstructed output) is, when a host decision put intra blocks into it -- the reference reconstructs the SBs that hold them
+           (is_intra_sb, Codec/EbEncDecProcess.c:3653-3657); the other flags of the wave stay */
+        int any_intra = 0;
+        for (int i = 0; i < n; i++) any_intra |= has_intra[i];
+        if (any_intra && !fl.do_recon) {
+            fl.do_recon = 1;
+            for (int i = 0; i < n; i++) ts[i]->info.do_recon = 1;
+        }
     }
     if (n_stand_in)
-        GPU_TRY(svt_hip_md_default_batch_device(d->ctx, n_stand_in, res, s->W, s->H, s->md_lambda, s->filter_level, mcs, lfs, s->mi_cols));
-    GPU_TRY(svt_hip_encdec_batch_device(d->ctx, d->work, n, pics, s->W, s->H, s->mi_cols, s->q_index, &fl, &s->thr, SHIM_REF_PAD, SHIM_REF_PAD));
+        GPU_TRY(svt_hip_md_default_batch_device(d->ctx, n_stand_in, res, s->W, s->H, lambda_l, level_l, mcs, lfs, s->mi_cols));
+    GPU_TRY(svt_hip_encdec_batch_device(d->ctx, d->work, n, pics, s->W, s->H, s->mi_cols, q_l, &fl, &s->thr, SHIM_REF_PAD, SHIM_REF_PAD));
     for (int i = 0; i < n; i++) {
         ts[i]->coded = 1;
         if (s->cfg.recon_file) { const EbErrorType e = queue_recon(s, d, ts[i]); if (e != EB_ErrorNone) return e; }
@@ -630,6 +675,7 @@ static EbErrorType encode_intra(shim_state *s, shim_dev *d, shim_slot *t) {
         memset(s->h_mc, 0, (size_t)s->mi_rows * s->mi_cols * sizeof(svt_mc_mode_info));
         memset(s->h_lf, 0, (size_t)s->mi_rows * s->mi_cols * sizeof(svt_lf_mode_info));
         if (s->md_cb(s->md_user, &t->info, NULL, s->h_mc, s->h_lf, s->mi_cols) == 0) {
+            if (grid_malformed(s, (const svt_lf_mode_info *)s->h_lf, 1)) return stream_fail(s, "mode-decision callback: malformed mode-info grid of an intra picture");
             GPU_TRY(svt_hip_mem_upload_2d(d->ctx, t->d_lf_mi, (size_t)s->mi_cols * sizeof(svt_lf_mode_info), s->h_lf, (size_t)s->mi_cols * sizeof(svt_lf_mode_info),
                                           (size_t)s->mi_cols * sizeof(svt_lf_mode_info), (size_t)s->mi_rows));
             decided = 1;

@@ -116,6 +116,14 @@ def gen_quant():
     np.savez_compressed(os.path.join(G, "quant_reference.npz"), **qt)
 
 
+def gen_qp_scaling():
+    # ---- fixed-QP layer scaling: the reference's eb_vp9_compute_qdelta + delta_rate tables (oracle/_ref/ref_qp_scaling) ----
+    import subprocess
+    out = subprocess.check_output([os.path.join(T.REF_DIR, "ref_qp_scaling")]).decode()
+    rows = np.array([[int(x) for x in line.split()] for line in out.strip().splitlines()], np.int16)   # tune, levels, layer, qp, base_qindex
+    np.savez_compressed(os.path.join(G, "qp_scaling_reference.npz"), rows=rows)
+
+
 def gen_ivf():
     # ---- IVF container headers: the reference application's write_ivf_stream_header / write_ivf_frame_header ----
     ivf = {}
@@ -175,7 +183,7 @@ def gen_encdec_flags():
     np.savez_compressed(os.path.join(G, "encdec_flags_reference.npz"), flags=T.ref_encdec_flags())
 
 
-SECTIONS = ("scan", "me", "tq", "lf", "lf_masks", "mc", "rate", "quant", "ivf", "lf_params", "me_presets", "sad_loop", "sb_stats", "api", "refpad", "avg_ssd", "pd_split", "encdec_flags")
+SECTIONS = ("scan", "me", "tq", "lf", "lf_masks", "mc", "rate", "quant", "ivf", "lf_params", "me_presets", "sad_loop", "sb_stats", "api", "refpad", "avg_ssd", "pd_split", "encdec_flags", "qp_scaling")
 
 
 def main():

@@ -112,7 +112,7 @@ def run_clip(W, H, N, enc_mode, tune, qp, recon_file, intra_period, use_callback
             C.memmove(lf_p, lf.ctypes.data, lf.nbytes)
             return 0
         me = np.ctypeslib.as_array(C.cast(me_p, C.POINTER(C.c_uint8)), (nsb * 85 * 40,)).view(B.ME_RESULT_DTYPE).reshape(nsb, 85)
-        mc, lf = host_decision(me, W, H, int(i.picture_number), level)
+        mc, lf = host_decision(me, W, H, int(i.picture_number), int(i.filter_level))   # the picture's own level: its q index is scaled by its layer
         C.memmove(mc_p, mc.ctypes.data, mc.nbytes)
         C.memmove(lf_p, lf.ctypes.data, lf.nbytes)
         return 0
@@ -263,15 +263,19 @@ def oracle_clip(frames, W, H, N, enc_mode, tune, qp, recon_file, intra_period, u
         p = B.me_params_derive(pic_width=W, pic_height=H, enc_mode=enc_mode, tune=tune, frame_rate=60, num_ref_lists=nl, temporal_layer_index=layer,
                                hierarchical_levels=lv, is_used_as_reference=used, same_ref_poc=int(nl == 2 and r0 == r1))
         me, _ = T.oracle_me_picture_mt(pics[k], pics[r0], pics[r1] if nl == 2 else None, p)
+        # fixed-QP mode: the picture's temporal layer scales the sequence QP (svt_hip_vp9_layer_qindex, pinned by tests/test_qp_scaling.py)
+        q_pic = lib.svt_hip_vp9_layer_qindex(qp, tune, lv, layer, 0)
+        ac_pic = lib.svt_hip_vp9_ac_step(q_pic)
+        level_pic = lib.svt_hip_lf_level_from_q(ac_pic, 0)
         if use_callback and k % 7 != 3:
-            mc, lf = host_decision(me, W, H, k, level)
+            mc, lf = host_decision(me, W, H, k, level_pic)
         else:
-            mc, lf = stand_in(me, W, H, 4 * ac, level)
+            mc, lf = stand_in(me, W, H, 4 * ac_pic, level_pic)
         c, fl = B.EncdecFlagsConfig(enc_mode=enc_mode, tune=tune, temporal_layer_index=layer, is_used_as_reference=used, recon_file=recon_file, loop_filter=1), B.EncdecFlags()
         assert lib.svt_hip_encdec_flags_derive(C.byref(c), C.byref(fl)) == 0
-        o = M.oracle_encdec_picture(src, [recs[r0], recs[r1 if nl == 2 else r0]], mc, lf, q_index, fl, thr, use_subpel=int(p.fractional_search_model != 2))
+        o = M.oracle_encdec_picture(src, [recs[r0], recs[r1 if nl == 2 else r0]], mc, lf, q_pic, fl, thr, use_subpel=int(p.fractional_search_model != 2))
         recs[k] = o["rec"]
-        outs[k] = dict(intra=False, o=o, mc=mc, flags=fl, layer=layer, refs=(r0, r1), nl=nl)
+        outs[k] = dict(intra=False, o=o, mc=mc, flags=fl, layer=layer, refs=(r0, r1), nl=nl, q_index=q_pic, filter_level=level_pic)
     return recs, outs
 
 
@@ -396,3 +400,44 @@ def test_other_presets_through_the_api(enc_mode, tune):
     for k in range(N):
         y, u, v = recs[k].interior()
         assert np.array_equal(recon[k], np.concatenate([y.ravel(), u.ravel(), v.ravel()])), (k, outs[k].get("layer"))
+
+
+def test_malformed_callback_grid_ends_the_stream():
+    """a mode-decision callback that hands back a grid the path cannot code (here: a 32x32 transform in an 8x8 block): the library
+    checks the grid on the host before uploading it, the call that flushes the group fails, and every later call answers EB_ErrorMax --
+    nothing is coded from the slot's previous contents, nothing is delivered as a success"""
+    lib = shim()
+    for f_ in ("svt_vp9_shim_set_mode_decision", "eb_vp9_svt_enc_send_picture", "eb_vp9_svt_get_packet"):
+        getattr(lib, f_).restype = C.c_int32
+    W, H, N = 192, 128, 18
+    frames = T.gen_clip_subpel(W, H, N, 5)
+    cfg, h = Cfg(), C.c_void_p()
+    assert lib.eb_vp9_svt_init_handle(C.byref(h), None, C.byref(cfg)) == 0
+    cfg.source_width, cfg.source_height, cfg.enc_mode, cfg.tune, cfg.frame_rate, cfg.intra_period, cfg.qp, cfg.recon_file = W, H, 8, 1, 60 << 16, -1, 40, 0
+    assert lib.eb_vp9_svt_enc_set_parameter(h, C.byref(cfg)) == 0
+    calls = []
+
+    def cb(user, info, me_p, mc_p, lf_p, mi_stride):
+        calls.append(int(info.contents.picture_number))
+        if info.contents.is_intra:
+            return 1
+        lf = np.zeros((H // 8, W // 8), dtype=B.LF_MODE_INFO_DTYPE)
+        lf["sb_type"], lf["tx_size"], lf["is_inter"] = 3, 3, 1          # 8x8 blocks with a 32x32 transform
+        C.memmove(lf_p, lf.ctypes.data, lf.nbytes)
+        return 0
+    keep = MD_CB(cb)
+    assert lib.svt_vp9_shim_set_mode_decision(h, keep, None) == 0
+    assert lib.eb_vp9_init_encoder(h) == 0
+    rcs = []
+    for n in range(N):
+        y = np.ascontiguousarray(frames[n])
+        u, v = (np.ascontiguousarray(p) for p in chroma(y, n))
+        i = In(y.ctypes.data, u.ctypes.data, v.ctypes.data, None, None, None, W, W // 2, W // 2)
+        b = Hdr(size=C.sizeof(Hdr), p_buffer=C.addressof(i), pts=n, flags=1 if n == N - 1 else 0)
+        rcs.append(lib.eb_vp9_svt_enc_send_picture(h, C.byref(b)) & 0xffffffff)
+    bad = [k for k, rc in enumerate(rcs) if rc != 0]
+    assert bad and calls, (rcs, calls)
+    assert rcs[bad[0]] == 0x80001005 and all(rc == 0x7FFFFFFF for rc in rcs[bad[0] + 1:]), [hex(r) for r in rcs]   # EB_ErrorBadParameter, then EB_ErrorMax
+    pp = C.POINTER(Hdr)()
+    assert lib.eb_vp9_svt_get_packet(h, C.byref(pp), C.c_uint8(1)) & 0xffffffff == 0x7FFFFFFF
+    assert lib.eb_vp9_deinit_encoder(h) == 0 and lib.eb_vp9_deinit_handle(h) == 0
