@@ -307,7 +307,17 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
             pred_lo = (uintptr_t)p3[k] < pred_lo ? (uintptr_t)p3[k] : pred_lo; pred_hi = (uintptr_t)p3[k] > pred_hi ? (uintptr_t)p3[k] : pred_hi;
         }
     }
-    const uint64_t plane_span = (uint64_t)width * height * 2; /* generous: stride x rows of the largest plane */
+    /* bytes from a plane's first sample to its last row's end: the largest stride x rows among the planes the 32-bit block offsets
+       address (a reference buffer's stride is width + 160; a caller's stride can exceed 2 x width on narrow pictures) */
+    uint64_t plane_span = 0;
+    for (int i = 0; i < n_pics; i++) {
+        const svt_yuv_planes *pl[3] = {&pics[i].src, &pics[i].pred, &pics[i].recon};
+        for (int k = 0; k < 3; k++) {
+            const uint64_t a = (uint64_t)(pl[k]->y_stride > 0 ? pl[k]->y_stride : 0) * (uint64_t)height, b = (uint64_t)(pl[k]->uv_stride > 0 ? pl[k]->uv_stride : 0) * (uint64_t)(height / 2);
+            plane_span = a > plane_span ? a : plane_span;
+            plane_span = b > plane_span ? b : plane_span;
+        }
+    }
     if ((uint64_t)(src_hi - src_lo) + plane_span >= (1ull << 32) || (uint64_t)(pred_hi - pred_lo) + plane_span >= (1ull << 32))
         return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: the batch's source / prediction planes must lie within 4 GB");
     /* coefficient arrays: one base for the batch as well (element offsets are 32 bit) */
@@ -324,8 +334,29 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
         (void)svt_hip_vp9_iscan_tables(&offs, nullptr);
         for (int i = 0; i < 16; i++) hb.iscan_off[i] = offs[i];
     }
+    /* reconstruction bases: at most ED_MAX_SETS pointers, each serving every picture whose planes lie within 4 GB above it.  Chosen
+       from the pictures' lowest plane addresses in ascending order, so that the result does not depend on the order the pictures
+       arrive in (separately allocated buffers in descending address order once opened a base each) */
     uint8_t       *recon_set[ED_MAX_SETS];
     int            n_sets = 0;
+    {
+        uintptr_t lo[ED_MAX_PICS], hi[ED_MAX_PICS];
+        int       order[ED_MAX_PICS];
+        for (int i = 0; i < n_pics; i++) {
+            const uint8_t *r3[3] = {pics[i].recon.y, pics[i].recon.u, pics[i].recon.v};
+            lo[i] = UINTPTR_MAX; hi[i] = 0; order[i] = i;
+            for (int k = 0; k < 3; k++) { lo[i] = (uintptr_t)r3[k] < lo[i] ? (uintptr_t)r3[k] : lo[i]; hi[i] = (uintptr_t)r3[k] > hi[i] ? (uintptr_t)r3[k] : hi[i]; }
+        }
+        for (int a = 1; a < n_pics; a++) /* insertion sort by lowest address (n_pics <= 32) */
+            for (int b = a; b > 0 && lo[order[b]] < lo[order[b - 1]]; b--) { const int t_ = order[b]; order[b] = order[b - 1]; order[b - 1] = t_; }
+        for (int a = 0; a < n_pics; a++) {
+            const int i = order[a];
+            if (n_sets && (uint64_t)(hi[i] - (uintptr_t)recon_set[n_sets - 1]) + plane_span < (1ull << 32)) continue; /* (sorted: lo[i] >= the last base) */
+            if (n_sets == ED_MAX_SETS || (uint64_t)(hi[i] - lo[i]) + plane_span >= (1ull << 32))
+                return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: the batch's reconstruction buffers span more than 8 regions of 4 GB");
+            recon_set[n_sets++] = (uint8_t *)lo[i];
+        }
+    }
     svt_mc_picture mcp[ED_MAX_PICS];
     svt_yuv_planes rec[ED_MAX_PICS], rec_pad[ED_MAX_PICS];
     int            n_rec_pad = 0;
@@ -344,14 +375,9 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
         uintptr_t r_lo = UINTPTR_MAX, r_hi = 0;
         for (int k = 0; k < 3; k++) { r_lo = (uintptr_t)r3[k] < r_lo ? (uintptr_t)r3[k] : r_lo; r_hi = (uintptr_t)r3[k] > r_hi ? (uintptr_t)r3[k] : r_hi; }
         int set = -1;
-        for (int k = 0; k < n_sets && set < 0; k++)
+        for (int k = n_sets - 1; k >= 0 && set < 0; k--) /* the highest base at or below the picture: the one chosen for it above */
             if (r_lo >= (uintptr_t)recon_set[k] && (uint64_t)(r_hi - (uintptr_t)recon_set[k]) + plane_span < (1ull << 32)) set = k;
-        if (set < 0) {
-            if (n_sets == ED_MAX_SETS || (uint64_t)(r_hi - r_lo) + plane_span >= (1ull << 32))
-                return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: the batch's reconstruction buffers span more than 8 regions of 4 GB");
-            set = n_sets;
-            recon_set[n_sets++] = (uint8_t *)r_lo;
-        }
+        if (set < 0) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec: the batch's reconstruction buffers span more than 8 regions of 4 GB");
         svt_tq_pic_geom &g = P.g;
         const uint8_t *s3[3] = {p.src.y, p.src.u, p.src.v}, *p3[3] = {p.pred.y, p.pred.u, p.pred.v};
         for (int k = 0; k < 3; k++) {

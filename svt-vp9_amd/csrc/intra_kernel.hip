@@ -324,11 +324,10 @@ int32_t svt_intra_launch(svt_hip_ctx *ctx, const svt_encdec_picture *p, int32_t 
     P.qcoeff = p->d_qcoeff; P.dqcoeff = p->d_dqcoeff; P.eob_map = p->d_eob_map; P.nz = p->d_nz; P.sync = d_sync; P.status = d_status; P.mixed = mixed;
     const int n_area = ((width + 31) >> 5) * ((height + 31) >> 5);
     HIP_TRY(hipMemsetAsync(d_sync, 0, (size_t)(2 + 3 * n_area) * sizeof(int32_t), ctx->stream));
-    static int wg_per_cu = 0;
-    if (!wg_per_cu) { const char *e = getenv("SVT_HIP_INTRA_WG_PER_CU"); wg_per_cu = e && atoi(e) > 0 ? atoi(e) : 1; }
+    /* (function-local statics with an initialiser: initialised once, thread-safely -- several contexts may launch from several threads) */
+    static const int wg_per_cu = [] { const char *e = getenv("SVT_HIP_INTRA_WG_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
+    static const int wg_cap = [] { const char *e = getenv("SVT_HIP_INTRA_WGS"); return e && atoi(e) > 0 ? atoi(e) : 0; }(); /* experiment knob */
     int grid = ctx->cu_count * wg_per_cu;
-    static int wg_cap = -1; /* experiment knob: fewer persistent workgroups = fewer CUs on which the pass displaces a motion-estimation workgroup */
-    if (wg_cap < 0) { const char *e = getenv("SVT_HIP_INTRA_WGS"); wg_cap = e && atoi(e) > 0 ? atoi(e) : 0; }
     if (wg_cap && grid > wg_cap) grid = wg_cap;
     if (grid > 3 * n_area) grid = 3 * n_area;
     hipLaunchKernelGGL(svt_intra_kernel, dim3(grid), dim3(64), 0, ctx->stream, P);

@@ -154,19 +154,22 @@ def test_encdec_batch_vs_oracle_chain(ctx, W, H, n_pics, q_index, cfg):
         r.buf[:] = rng.integers(0, 256, r.buf.size, dtype=np.uint8)      # a recycled buffer holds junk
     dp, blocks, pos, eob, cnt = run_device(ctx, W, H, srcs, refs, grids, q_index, flags, thr, rec_inits)
     # the lists the device built == the host lists of the same grids (batch order: size, picture, SB, unit)
-    geoms, set_base = [], []
+    # the driver's reconstruction bases: the pictures' lowest plane addresses in ascending order, a new base wherever a picture does not
+    # lie within 4 GB above the last one (span = the largest stride x rows among the batch's planes)
+    all_ptrs = [[dp[i].rec_t.data_ptr() + o for o in rec_inits[i].offsets()] for i in range(n_pics)]
+    span = max(W, rec_inits[0].pw) * H
+    set_base = []
+    for ptrs in sorted(all_ptrs, key=min):
+        if not set_base or max(ptrs) - set_base[-1] + span >= 2 ** 32:
+            set_base.append(min(ptrs))
+    geoms = []
     for i in range(n_pics):
         g = B.TqPicGeom()
         g.width, g.height = W, H
         for k, o in enumerate((0, W * H, W * H + (W // 2) * (H // 2))):
             g.src_off[k] = g.pred_off[k] = i * (W * H * 3 // 2) + o
-        # the driver's reconstruction bases: a buffer joins the first base it lies within 4 GB above, else it opens a new one
-        ptrs = [dp[i].rec_t.data_ptr() + o for o in rec_inits[i].offsets()]
-        span = W * H * 2
-        k_set = next((k for k, b in enumerate(set_base) if min(ptrs) >= b and max(ptrs) - b + span < 2 ** 32), None)
-        if k_set is None:
-            k_set = len(set_base)
-            set_base.append(min(ptrs))
+        ptrs = all_ptrs[i]
+        k_set = max(k for k, b in enumerate(set_base) if min(ptrs) >= b and max(ptrs) - b + span < 2 ** 32)
         for k, ptr in enumerate(ptrs):
             g.recon_off[k] = ptr - set_base[k_set]
         g.src_stride[0] = g.pred_stride[0] = W
