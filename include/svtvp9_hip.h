@@ -207,6 +207,17 @@ int32_t svt_hip_mem_download(svt_hip_ctx *ctx, void *dst, const void *d_src, siz
  * context's stream.  The call blocks only when all staging buffers (4) still hold copies the device has not consumed. */
 int32_t svt_hip_mem_upload_2d_async(svt_hip_ctx *ctx, void *d_dst, size_t dst_stride, const void *src, size_t src_stride, size_t width_bytes,
                                     size_t rows);
+/* The same upload WITHOUT the staging copy, for a host whose rows lie in memory that stays allocated while the library is in use: a
+ * range of host memory is page-locked (hipHostRegister) the first time it is seen, so a host that sends from a fixed pool of buffers
+ * pays for that once and is read by the DMA engines directly from then on (57 GB/s on the MI355X box against ~27 GB/s through the
+ * staging copy); ranges that cannot be registered, and more than 1024 distinct ranges, go through the staging path.  The copy is
+ * asynchronous: the rows must stay valid until svt_hip_mem_upload_wait(ctx) has returned (it waits for every direct upload enqueued
+ * on ctx -- not for the rest of the stream).  svt_hip_host_unregister_all unlocks everything (no upload may be in flight).  Locked
+ * ranges must not be freed, nor passed in part to other host <-> device copies of the process, before they are unlocked. */
+int32_t svt_hip_mem_upload_2d_direct(svt_hip_ctx *ctx, void *d_dst, size_t dst_stride, const void *src, size_t src_stride, size_t width_bytes,
+                                     size_t rows);
+int32_t svt_hip_mem_upload_wait(svt_hip_ctx *ctx);
+void    svt_hip_host_unregister_all(void);
 /* Completion markers: svt_hip_ctx_marker_record notes "everything enqueued on the context's stream so far" and returns a marker;
  * svt_hip_ctx_marker_query returns 1 when that work has completed, 0 while it is pending (never blocks), negative on error;
  * svt_hip_ctx_marker_wait blocks until it has.  This is what lets eb_vp9_svt_get_packet poll without blocking and block only when

@@ -78,6 +78,7 @@ extern "C" void svt_hip_ctx_destroy(svt_hip_ctx *c) {
     for (int i = 0; i < SVT_CTX_UPLOAD_RING; i++) {
         if (c->up_host[i]) (void)hipHostFree(c->up_host[i]);
         if (c->up_ev[i]) (void)hipEventDestroy(c->up_ev[i]);
+        if (i == 0 && c->direct_ev) (void)hipEventDestroy(c->direct_ev);
     }
     for (int i = 0; i < SVT_CTX_MARKERS; i++) if (c->mk_ev[i]) (void)hipEventDestroy(c->mk_ev[i]);
     if (c->ho_produced) (void)hipEventDestroy(c->ho_produced);
@@ -202,6 +203,118 @@ extern "C" int32_t svt_hip_mem_upload_2d_async(svt_hip_ctx *ctx, void *d_dst, si
     ctx->up_used[k] = 1;
     ctx->up_pos = (k + 1) % SVT_CTX_UPLOAD_RING;
     return SVT_HIP_OK;
+}
+
+/* ---- uploads straight from the caller's memory (opt-in) ----
+ * A host that sends its pictures from a fixed pool of buffers which stay allocated for the encoder's lifetime (the reference's
+ * application does: allocate_input_buffers, App/EbAppContext.c) does not need the staging copy: the first time a range of host
+ * memory is seen it is page-locked (hipHostRegister, portable across devices), from then on the DMA engines read it directly at
+ * the link's rate -- measured on the MI355X box: 57 GB/s from pinned memory against the ~27 GB/s a staging memcpy by a few threads
+ * sustains under the box's CPU quota.  The registry keeps disjoint page-aligned intervals (a picture's planes usually share pages
+ * with their neighbours: only the uncovered part of a new range is registered) and a copy is cut where two intervals meet (the
+ * runtime resolves a host pointer to ONE registration and rejects a copy that runs past its end).  Registration stops after
+ * SVT_REG_MAX intervals; a range that cannot be registered is served by the staging path (svt_hip_mem_upload_2d_async), so the
+ * result is the same either way.  Page-locking memory the library does not own is the CALLER's promise that it stays allocated
+ * (and is not handed, in part, to other copies of this process while locked): the encoder library only takes this path when
+ * SVT_HIP_REGISTER_INPUT=1.  The copy is asynchronous; svt_hip_mem_upload_wait() returns when every direct upload of the context
+ * has left the caller's memory -- the point where eb_vp9_svt_enc_send_picture may return. */
+#include <mutex>
+#include <unistd.h>
+namespace {
+#define SVT_REG_MAX 1024
+struct reg_iv { uintptr_t lo, hi; bool ok; };
+std::mutex g_reg_mutex;
+reg_iv     g_reg[SVT_REG_MAX];
+int        g_reg_n = 0;
+bool       g_reg_off = false;
+
+/* end of the registered interval that holds address a (a is covered: reg_cover succeeded for it) */
+uintptr_t reg_end_of(uintptr_t a) {
+    std::lock_guard<std::mutex> lock(g_reg_mutex);
+    for (int i = 0; i < g_reg_n; i++) if (g_reg[i].lo <= a && a < g_reg[i].hi) return g_reg[i].hi;
+    return a;
+}
+/* true when [a, b) is page-locked after the call */
+bool reg_cover(uintptr_t a, uintptr_t b) {
+    static const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+    const uintptr_t A = a & ~(page - 1), B = (b + page - 1) & ~(page - 1);
+    std::lock_guard<std::mutex> lock(g_reg_mutex);
+    bool      all_ok = true;
+    uintptr_t cur = A;
+    while (cur < B) {
+        const reg_iv *in = nullptr; /* the interval that covers `cur`, or the start of the next one above it */
+        uintptr_t     next = B;
+        for (int i = 0; i < g_reg_n; i++) {
+            if (g_reg[i].lo <= cur && cur < g_reg[i].hi) { in = &g_reg[i]; break; }
+            if (g_reg[i].lo > cur && g_reg[i].lo < next) next = g_reg[i].lo;
+        }
+        if (in) { all_ok = all_ok && in->ok; cur = in->hi; continue; }
+        if (g_reg_off || g_reg_n == SVT_REG_MAX) { g_reg_off = true; return false; }
+        const hipError_t e = hipHostRegister((void *)cur, next - cur, hipHostRegisterPortable);
+        (void)hipGetLastError();
+        g_reg[g_reg_n++] = reg_iv{cur, next, e == hipSuccess};
+        all_ok = all_ok && e == hipSuccess;
+        cur = next;
+    }
+    return all_ok;
+}
+} // namespace
+
+extern "C" int32_t svt_hip_mem_upload_2d_direct(svt_hip_ctx *ctx, void *d_dst, size_t dst_stride, const void *src, size_t src_stride,
+                                                size_t width_bytes, size_t rows) {
+    if (!ctx || !d_dst || !src || !width_bytes || !rows || dst_stride < width_bytes || src_stride < width_bytes)
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "mem_upload_direct: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!reg_cover((uintptr_t)src, (uintptr_t)src + src_stride * (rows - 1) + width_bytes))
+        return svt_hip_mem_upload_2d_async(ctx, d_dst, dst_stride, src, src_stride, width_bytes, rows);
+    const uint8_t *sp = (const uint8_t *)src;
+    uint8_t       *dp = (uint8_t *)d_dst;
+    if (dst_stride == width_bytes && src_stride == width_bytes) { /* contiguous: one run of bytes, cut at the registry's interval ends */
+        size_t left = width_bytes * rows;
+        while (left) {
+            const uintptr_t end = reg_end_of((uintptr_t)sp);
+            const size_t    n = (size_t)(end - (uintptr_t)sp) < left ? (size_t)(end - (uintptr_t)sp) : left;
+            if (!n) return svt_set_error(SVT_HIP_ERR_DEVICE, "mem_upload_direct: registry");
+            HIP_TRY(hipMemcpyAsync(dp, sp, n, hipMemcpyHostToDevice, ctx->stream));
+            sp += n; dp += n; left -= n;
+        }
+    } else {
+        size_t r = 0;
+        while (r < rows) {
+            const uint8_t  *row = sp + r * src_stride;
+            const uintptr_t end = reg_end_of((uintptr_t)row);
+            if ((uintptr_t)row + width_bytes <= end) { /* this row and maybe more lie inside the interval */
+                size_t nfull = (size_t)(end - (uintptr_t)row - width_bytes) / src_stride + 1;
+                if (nfull > rows - r) nfull = rows - r;
+                HIP_TRY(hipMemcpy2DAsync(dp + r * dst_stride, dst_stride, row, src_stride, width_bytes, nfull, hipMemcpyHostToDevice, ctx->stream));
+                r += nfull;
+            } else { /* the row straddles a boundary: in pieces */
+                size_t off = 0;
+                while (off < width_bytes) {
+                    const uintptr_t e2 = reg_end_of((uintptr_t)row + off);
+                    const size_t    n = (size_t)(e2 - ((uintptr_t)row + off)) < width_bytes - off ? (size_t)(e2 - ((uintptr_t)row + off)) : width_bytes - off;
+                    if (!n) return svt_set_error(SVT_HIP_ERR_DEVICE, "mem_upload_direct: registry");
+                    HIP_TRY(hipMemcpyAsync(dp + r * dst_stride + off, row + off, n, hipMemcpyHostToDevice, ctx->stream));
+                    off += n;
+                }
+                r++;
+            }
+        }
+    }
+    if (!ctx->direct_ev) HIP_TRY(hipEventCreateWithFlags(&ctx->direct_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ctx->direct_ev, ctx->stream));
+    ctx->direct_pending = 1;
+    return SVT_HIP_OK;
+}
+extern "C" int32_t svt_hip_mem_upload_wait(svt_hip_ctx *ctx) {
+    if (!ctx) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "mem_upload_wait: null");
+    if (ctx->direct_pending) { HIP_TRY(hipEventSynchronize(ctx->direct_ev)); ctx->direct_pending = 0; }
+    return SVT_HIP_OK;
+}
+extern "C" void svt_hip_host_unregister_all(void) {
+    std::lock_guard<std::mutex> lock(g_reg_mutex);
+    for (int i = 0; i < g_reg_n; i++) if (g_reg[i].ok) (void)hipHostUnregister((void *)g_reg[i].lo);
+    g_reg_n = 0; g_reg_off = false;
 }
 
 /* ---- completion markers: "everything enqueued on the context's stream so far" as a value a host can poll or wait for ---- */

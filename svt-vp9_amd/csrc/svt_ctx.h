@@ -39,6 +39,8 @@ struct svt_hip_ctx {
     hipEvent_t  up_ev[SVT_CTX_UPLOAD_RING];
     int         up_used[SVT_CTX_UPLOAD_RING];
     int         up_pos;
+    hipEvent_t  direct_ev;      /* behind the last upload that reads the caller's (page-locked) memory directly */
+    int         direct_pending;
     /* completion markers: marker m is event m % SVT_CTX_MARKERS; before an event is recorded again its previous use is waited
        for, so a marker older than SVT_CTX_MARKERS records is complete by construction */
     hipEvent_t  mk_ev[SVT_CTX_MARKERS];

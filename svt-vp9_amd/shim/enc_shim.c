@@ -56,6 +56,7 @@ typedef struct shim_packet {
     EbBufferHeaderType  hdr;
     struct shim_packet *next;
     int                 dev;
+    svt_hip_ctx        *ctx;        /* the context the marker belongs to (NULL: the device's main context) */
     uint64_t            marker;     /* the GPU work behind this packet (svt_hip_ctx_marker_*) */
 } shim_packet;
 
@@ -88,6 +89,9 @@ typedef struct shim_slot { /* one buffered picture, everything device resident *
     int            is_copy;     /* split-GOP mode: the base picture of the previous mini-GOP, handed over from the device that coded it
                                    (analysed planes + reference picture only) */
     uint64_t       marker;      /* completion of everything enqueued for this picture so far */
+    svt_hip_ctx   *marker_ctx;  /* the context `marker` belongs to (NULL: the device's main context) */
+    uint64_t       release2;    /* the same as `release` for the deep-layer context (ctx_deep) */
+    int            has_release2;
     svt_vp9_shim_picture_info info;
 } shim_slot;
 
@@ -100,6 +104,12 @@ typedef struct shim_dev {
     uint64_t         in_marker;      /* ctx_in: the latest picture's upload + analysis */
     int              has_in;
     svt_hip_ctx     *ctx_out;        /* output side: the reconstructions' device-to-host copies (recon_file), behind the main stream's markers */
+    /* the two deepest temporal layers of a group (12 of a mini-GOP's 16 pictures) are coded on a context of their own, behind the
+       group's shallower layers: nothing of the NEXT group depends on them (its base picture predicts from this group's base picture),
+       so the next group's motion estimation and shallow layers -- waves of 1, 1 and 2 pictures, bound by the deblocking wavefront's
+       latency -- run beside them instead of behind them.  SVT_HIP_NO_DEEP_STREAM=1 (or SVT_HIP_SINGLE_STREAM=1): the main context. */
+    svt_hip_ctx     *ctx_deep;
+    svt_encdec_work *work_deep;
     int              ordinal;
     int              n_slots;
     shim_slot       *slot;
@@ -115,6 +125,7 @@ typedef struct shim_state {
     int         levels, minigop;       /* hierarchical levels, 1 << levels */
     int         intra_period;          /* resolved */
     int         n_dev, cur_dev, split_gop;
+    int         register_input;        /* SVT_HIP_REGISTER_INPUT=1 */
     shim_dev    dev[SHIM_MAX_DEV];
     int64_t     gop;                   /* index of the GOP being sent */
     int64_t     next_number;           /* display number of the next picture sent */
@@ -296,6 +307,10 @@ static void free_dev(shim_state *s, shim_dev *d) {
     while (d->free_recon) { shim_recon *r = d->free_recon; d->free_recon = r->next; svt_hip_host_free(d->ctx, r->host); free(r); }
     if (d->work) svt_hip_encdec_work_destroy(d->ctx, d->work);
     d->work = NULL;
+    if (d->work_deep) svt_hip_encdec_work_destroy(d->ctx_deep, d->work_deep);
+    d->work_deep = NULL;
+    if (d->ctx_deep && d->ctx_deep != d->ctx) svt_hip_ctx_destroy(d->ctx_deep);
+    d->ctx_deep = NULL;
     if (d->ctx_in && d->ctx_in != d->ctx) svt_hip_ctx_destroy(d->ctx_in);
     if (d->ctx_out && d->ctx_out != d->ctx) svt_hip_ctx_destroy(d->ctx_out);
     d->ctx_in = d->ctx_out = NULL;
@@ -314,7 +329,8 @@ static int alloc_dev(shim_state *s, shim_dev *d) {
     const size_t n = (size_t)d->n_slots, units = (size_t)s->mi_rows * s->mi_cols;
     int ok = svt_hip_mem_alloc(d->ctx, n * s->pic_bytes, &d->d_src_slab) == SVT_HIP_OK && svt_hip_mem_alloc(d->ctx, n * s->pic_bytes, &d->d_pred_slab) == SVT_HIP_OK &&
              svt_hip_mem_alloc(d->ctx, n * s->coeffs * sizeof(int16_t), &d->d_q_slab) == SVT_HIP_OK &&
-             svt_hip_encdec_work_create(d->ctx, SHIM_WAVE_MAX, W, H, &d->work) == SVT_HIP_OK;
+             svt_hip_encdec_work_create(d->ctx, SHIM_WAVE_MAX, W, H, &d->work) == SVT_HIP_OK &&
+             (d->ctx_deep == d->ctx || svt_hip_encdec_work_create(d->ctx_deep, SHIM_WAVE_MAX, W, H, &d->work_deep) == SVT_HIP_OK);
     for (int i = 0; ok && i < d->n_slots; i++) {
         shim_slot *t = &d->slot[i];
         t->number = -1;
@@ -399,6 +415,9 @@ EbErrorType eb_vp9_init_encoder(EbComponentType *h) {
             if (one && atoi(one) != 0) d->ctx_in = d->ctx_out = d->ctx;
             else if (svt_hip_ctx_create(&d->ctx_in, ord[i]) != SVT_HIP_OK) { d->ctx_in = NULL; ok = 0; }
             else if (svt_hip_ctx_create(&d->ctx_out, ord[i]) != SVT_HIP_OK) { d->ctx_out = NULL; ok = 0; }
+            const char *nd = getenv("SVT_HIP_NO_DEEP_STREAM");
+            d->ctx_deep = d->ctx;
+            if (ok && !(one && atoi(one) != 0) && !(nd && atoi(nd) != 0) && svt_hip_ctx_create(&d->ctx_deep, ord[i]) != SVT_HIP_OK) { d->ctx_deep = NULL; ok = 0; }
         }
         ok = ok && alloc_dev(s, d);
         if (!ok) { /* nothing half-initialised is left behind: the handle is back in its configured state */
@@ -409,6 +428,7 @@ EbErrorType eb_vp9_init_encoder(EbComponentType *h) {
     s->n_dev = n;
     s->cur_dev = 0;
     { const char *sg = getenv("SVT_HIP_SPLIT_GOP"); s->split_gop = n > 1 && sg && atoi(sg) != 0; }
+    { const char *ri = getenv("SVT_HIP_REGISTER_INPUT"); s->register_input = ri && atoi(ri) != 0; }
     if (s->md_cb) {
         s->h_results = malloc((size_t)s->n_sb * 85 * sizeof(svt_me_pu_result));
         s->h_mc = malloc((size_t)s->mi_rows * s->mi_cols * sizeof(svt_mc_mode_info));
@@ -449,7 +469,9 @@ static EbErrorType handoff_base(shim_state *s, shim_dev *from, shim_dev *to, int
     shim_slot *a = find_slot(from, number);
     if (!a) return EB_ErrorBadParameter;
     shim_slot *b = &to->slot[to->accepted % to->n_slots];
-    if (b->has_marker) GPU_TRY(svt_hip_ctx_marker_wait(to->ctx, b->marker));
+    if (b->has_marker) GPU_TRY(svt_hip_ctx_marker_wait(b->marker_ctx ? b->marker_ctx : to->ctx, b->marker));
+    if (b->has_release2) GPU_TRY(svt_hip_ctx_marker_wait(to->ctx_deep, b->release2));
+    b->has_release2 = 0; b->marker_ctx = NULL;
     if (b->has_out && to->ctx_out != to->ctx) GPU_TRY(svt_hip_ctx_wait_marker(to->ctx, to->ctx_out, b->out_marker)); /* its old reconstruction may still be on its way out */
     b->has_out = 0;
     const svt_plane *pa[3] = {&a->pa.full, &a->pa.quarter, &a->pa.sixteenth}, *pb[3] = {&b->pa.full, &b->pa.quarter, &b->pa.sixteenth};
@@ -464,7 +486,11 @@ static EbErrorType handoff_base(shim_state *s, shim_dev *from, shim_dev *to, int
     return EB_ErrorNone;
 }
 
+static int push_packet_on(shim_state *s, int64_t pts, uint32_t flags, uint32_t pic_type, int dev, svt_hip_ctx *ctx, uint64_t marker);
 static int push_packet(shim_state *s, int64_t pts, uint32_t flags, uint32_t pic_type, int dev, uint64_t marker) {
+    return push_packet_on(s, pts, flags, pic_type, dev, NULL, marker);
+}
+static int push_packet_on(shim_state *s, int64_t pts, uint32_t flags, uint32_t pic_type, int dev, svt_hip_ctx *ctx, uint64_t marker) {
     shim_packet *p = (shim_packet *)calloc(1, sizeof *p);
     if (!p) return -1;
     p->hdr.size = sizeof(EbBufferHeaderType);
@@ -473,6 +499,7 @@ static int push_packet(shim_state *s, int64_t pts, uint32_t flags, uint32_t pic_
     p->hdr.pic_type = pic_type;
     p->hdr.wrapper_ptr = p; /* the round trip of the reference's wrapper_ptr (:2923) */
     p->dev = dev;
+    p->ctx = ctx;
     p->marker = marker;
     if (s->q_tail) s->q_tail->next = p; else s->q_head = p;
     s->q_tail = p;
@@ -498,7 +525,7 @@ static svt_yuv_planes rec_planes(const shim_state *s, uint8_t *base) {
 
 /* the reconstruction of a picture on its way to eb_vp9_svt_get_recon: W x H luma, then Cb, then Cr (recon_output,
  * Codec/EbEncDecProcess.c:4693-4820), copied to pinned host memory behind the picture's last stage */
-static EbErrorType queue_recon(shim_state *s, shim_dev *d, shim_slot *t) {
+static EbErrorType queue_recon(shim_state *s, shim_dev *d, shim_slot *t, svt_hip_ctx *coded_on) {
     shim_recon *r = d->free_recon;
     if (r) d->free_recon = r->next;
     else {
@@ -512,7 +539,7 @@ static EbErrorType queue_recon(shim_state *s, shim_dev *d, shim_slot *t) {
     const size_t W = (size_t)s->W, H = (size_t)s->H;
     /* the copy runs on the output stream, behind the main stream's work enqueued so far (the picture's deblocking / padding) */
     uint64_t after = 0;
-    if ((d->ctx_out != d->ctx && (svt_hip_ctx_marker_record(d->ctx, &after) != SVT_HIP_OK || svt_hip_ctx_wait_marker(d->ctx_out, d->ctx, after) != SVT_HIP_OK)) ||
+    if ((d->ctx_out != coded_on && (svt_hip_ctx_marker_record(coded_on, &after) != SVT_HIP_OK || svt_hip_ctx_wait_marker(d->ctx_out, coded_on, after) != SVT_HIP_OK)) ||
         svt_hip_mem_download_2d_async(d->ctx_out, r->host, W, p.y, (size_t)p.y_stride, W, H) != SVT_HIP_OK ||
         svt_hip_mem_download_2d_async(d->ctx_out, r->host + W * H, W / 2, p.u, (size_t)p.uv_stride, W / 2, H / 2) != SVT_HIP_OK ||
         svt_hip_mem_download_2d_async(d->ctx_out, r->host + W * H + W * H / 4, W / 2, p.v, (size_t)p.uv_stride, W / 2, H / 2) != SVT_HIP_OK ||
@@ -579,7 +606,9 @@ static int job_use_subpel(const shim_job *j) { return j->p.fractional_search_mod
 
 /* The stages behind mode decision for one batch of mutually independent pictures (a temporal layer of a part of the group, or one
  * picture of a P chain): decision -> svt_hip_encdec_batch_device -> reconstruction output. */
-static EbErrorType encode_wave(shim_state *s, shim_dev *d, const shim_job *const *wj, int n) {
+static EbErrorType encode_wave(shim_state *s, shim_dev *d, const shim_job *const *wj, int n, int deep) {
+    svt_hip_ctx     *cx = deep ? d->ctx_deep : d->ctx;       /* the context (stream) this wave is enqueued on, and its driver workspace */
+    svt_encdec_work *wk = deep ? d->work_deep : d->work;
     svt_encdec_picture pics[SHIM_WAVE_MAX];
     shim_slot         *ts[SHIM_WAVE_MAX];
     svt_encdec_flags   fl;
@@ -646,11 +675,11 @@ static EbErrorType encode_wave(shim_state *s, shim_dev *d, const shim_job *const
         }
     }
     if (n_stand_in)
-        GPU_TRY(svt_hip_md_default_batch_device(d->ctx, n_stand_in, res, s->W, s->H, lambda_l, level_l, mcs, lfs, s->mi_cols));
-    GPU_TRY(svt_hip_encdec_batch_device(d->ctx, d->work, n, pics, s->W, s->H, s->mi_cols, q_l, &fl, &s->thr, SHIM_REF_PAD, SHIM_REF_PAD));
+        GPU_TRY(svt_hip_md_default_batch_device(cx, n_stand_in, res, s->W, s->H, lambda_l, level_l, mcs, lfs, s->mi_cols));
+    GPU_TRY(svt_hip_encdec_batch_device(cx, wk, n, pics, s->W, s->H, s->mi_cols, q_l, &fl, &s->thr, SHIM_REF_PAD, SHIM_REF_PAD));
     for (int i = 0; i < n; i++) {
         ts[i]->coded = 1;
-        if (s->cfg.recon_file) { const EbErrorType e = queue_recon(s, d, ts[i]); if (e != EB_ErrorNone) return e; }
+        if (s->cfg.recon_file) { const EbErrorType e = queue_recon(s, d, ts[i], cx); if (e != EB_ErrorNone) return e; }
     }
     return EB_ErrorNone;
 }
@@ -691,7 +720,7 @@ static EbErrorType encode_intra(shim_state *s, shim_dev *d, shim_slot *t) {
     p.d_qcoeff = t->d_qcoeff; p.d_dqcoeff = t->d_dqcoeff; p.d_eob_map = (uint16_t *)t->d_eob_map; p.d_lfm = (svt_lf_mask *)t->d_lfm; p.d_nz = (uint8_t *)t->d_nz;
     GPU_TRY(svt_hip_encdec_intra_device(d->ctx, d->work, &p, s->W, s->H, s->mi_cols, s->q_index, &fl, &s->thr, SHIM_REF_PAD, SHIM_REF_PAD));
     t->coded = 1;
-    if (s->cfg.recon_file) return queue_recon(s, d, t);
+    if (s->cfg.recon_file) return queue_recon(s, d, t, d->ctx);
     return EB_ErrorNone;
 }
 
@@ -780,25 +809,50 @@ static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_str
     }
     uint64_t me_marker = 0;
     GPU_TRY(svt_hip_ctx_marker_record(d->ctx, &me_marker));
-    for (int i = 0; i < n; i++) { shim_slot *t = find_slot(d, jobs[i].number); t->processed = 1; t->has_marker = 1; t->marker = me_marker; }
+    for (int i = 0; i < n; i++) { shim_slot *t = find_slot(d, jobs[i].number); t->processed = 1; t->has_marker = 1; t->marker = me_marker; t->marker_ctx = d->ctx; }
     /* the stages behind mode decision, wave by wave (a wave = the pictures of one temporal layer of one part: their references
        belong to earlier waves) */
-    uint64_t wave_marker[SHIM_MAX_MINIGOP + 8];
+    uint64_t     wave_marker[SHIM_MAX_MINIGOP + 8];
+    svt_hip_ctx *wave_ctx[SHIM_MAX_MINIGOP + 8];
+    /* the waves of the two deepest layers of a part (temporal layer >= 2 and within one of the part's deepest) go to the deep-layer
+       context, behind everything the main context holds at that point (the part's shallower waves: their references).  With a host
+       decision callback the pipeline drains per picture anyway: everything stays on the main context. */
+    int part_deepest[SHIM_MAX_MINIGOP + 8], any_deep = 0;
+    for (int w = 0; w < n_waves; w++) part_deepest[w] = 0;
+    for (int w = 0; w < n_waves; w++) { /* waves of a part are consecutive, layer 0 first: a part's deepest layer is its last wave's */
+        int lw = -1;
+        for (int i = 0; i < n; i++) if (jobs[i].wave == w) lw = jobs[i].layer;
+        for (int v = w; v >= 0; v--) { /* back to the part's first wave (the latest wave of layer 0 at or before w) */
+            if (lw > part_deepest[v]) part_deepest[v] = lw;
+            int lv = -1;
+            for (int i = 0; i < n; i++) if (jobs[i].wave == v) lv = jobs[i].layer;
+            if (lv == 0) break;
+        }
+    }
     for (int w = 0; w < n_waves; w++) {
         const shim_job *wj[SHIM_MAX_MINIGOP];
         int             m = 0;
         for (int i = 0; i < n; i++) if (jobs[i].wave == w) wj[m++] = &jobs[i];
+        const int deep = m && d->ctx_deep != d->ctx && !s->md_cb && wj[0]->layer >= 2 && wj[0]->layer >= part_deepest[w] - 1;
+        if (deep) {
+            uint64_t behind = 0;
+            GPU_TRY(svt_hip_ctx_marker_record(d->ctx, &behind));
+            GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_deep, d->ctx, behind));
+            any_deep = 1;
+        }
         for (int b = 0; b < m; b += SHIM_WAVE_MAX) {
-            const EbErrorType e = encode_wave(s, d, wj + b, m - b < SHIM_WAVE_MAX ? m - b : SHIM_WAVE_MAX);
+            const EbErrorType e = encode_wave(s, d, wj + b, m - b < SHIM_WAVE_MAX ? m - b : SHIM_WAVE_MAX, deep);
             if (e != EB_ErrorNone) return e;
         }
         wave_marker[w] = 0;
-        GPU_TRY(svt_hip_ctx_marker_record(d->ctx, &wave_marker[w]));
+        wave_ctx[w] = deep ? d->ctx_deep : d->ctx;
+        GPU_TRY(svt_hip_ctx_marker_record(wave_ctx[w], &wave_marker[w]));
     }
     for (int i = 0; i < n; i++) { /* packets in decode order */
         shim_slot *t = find_slot(d, jobs[i].number);
         t->marker = wave_marker[jobs[i].wave];
-        if (push_packet(s, t->pts, 0, jobs[i].n_lists == 2 ? 0 /* EB_B_PICTURE */ : 1 /* EB_P_PICTURE */, s->cur_dev, t->marker)) return EB_ErrorInsufficientResources;
+        t->marker_ctx = wave_ctx[jobs[i].wave];
+        if (push_packet_on(s, t->pts, 0, jobs[i].n_lists == 2 ? 0 /* EB_B_PICTURE */ : 1 /* EB_P_PICTURE */, s->cur_dev, t->marker_ctx, t->marker)) return EB_ErrorInsufficientResources;
     }
     s->last_base = first + s->pending - 1;
     s->pending = 0;
@@ -810,13 +864,14 @@ static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_str
     }
     /* from this point of the main stream on nothing enqueued so far reads the group's pictures or the pictures it predicted from: the
        input side may overwrite their slots behind it */
-    uint64_t end_marker = 0;
+    uint64_t end_marker = 0, deep_end = 0;
     GPU_TRY(svt_hip_ctx_marker_record(d->ctx, &end_marker));
+    if (any_deep) GPU_TRY(svt_hip_ctx_marker_record(d->ctx_deep, &deep_end)); /* ... and the deep-layer context's readers */
     for (int i = 0; i < n; i++) {
         const int64_t who[3] = {jobs[i].number, jobs[i].ref0, jobs[i].n_lists == 2 ? jobs[i].ref1 : -1};
         for (int k = 0; k < 3; k++) {
             shim_slot *t = who[k] >= 0 ? find_slot(d, who[k]) : NULL;
-            if (t) { t->release = end_marker; t->has_release = 1; }
+            if (t) { t->release = end_marker; t->has_release = 1; if (any_deep) { t->release2 = deep_end; t->has_release2 = 1; } }
         }
     }
     return EB_ErrorNone;
@@ -847,15 +902,20 @@ EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *
            the input stream waits for the main stream's marker behind its last reader (a device-side wait; the host blocks only in
            the staging ring of the upload below, as the reference blocks when its picture pool is exhausted) */
         if (t->has_release) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_in, d->ctx, t->release));
-        else if (t->has_marker) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_in, d->ctx, t->marker));
+        else if (t->has_marker) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_in, t->marker_ctx ? t->marker_ctx : d->ctx, t->marker));
+        if (t->has_release2) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_in, d->ctx_deep, t->release2));
         if (t->has_out && d->ctx_out != d->ctx_in) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_in, d->ctx_out, t->out_marker));
         /* the copy the reference makes in copy_frame_buffer (:2743-2796), into pinned staging: the caller's planes are free again
            on return; the transfer and the analysis below run asynchronously */
         const svt_yuv_planes sp = tight_planes(s, t->d_src);
-        GPU_TRY(svt_hip_mem_upload_2d_async(d->ctx_in, sp.y, (size_t)W, in->luma, in->y_stride, (size_t)W, (size_t)H));
-        if (in->cb) GPU_TRY(svt_hip_mem_upload_2d_async(d->ctx_in, sp.u, (size_t)W / 2, in->cb, in->cb_stride, (size_t)W / 2, (size_t)H / 2));
+        /* SVT_HIP_REGISTER_INPUT=1: the application promises that its input buffers stay allocated while the encoder lives (a fixed pool,
+           as the reference's application has): they are page-locked on first sight and read by the DMA engines directly, without the
+           staging copy (svt_hip_mem_upload_2d_direct) */
+        int32_t (*up)(svt_hip_ctx *, void *, size_t, const void *, size_t, size_t, size_t) = s->register_input ? svt_hip_mem_upload_2d_direct : svt_hip_mem_upload_2d_async;
+        GPU_TRY(up(d->ctx_in, sp.y, (size_t)W, in->luma, in->y_stride, (size_t)W, (size_t)H));
+        if (in->cb) GPU_TRY(up(d->ctx_in, sp.u, (size_t)W / 2, in->cb, in->cb_stride, (size_t)W / 2, (size_t)H / 2));
         else GPU_TRY(svt_hip_mem_set(d->ctx_in, sp.u, 128, (size_t)(W / 2) * (H / 2)));
-        if (in->cr) GPU_TRY(svt_hip_mem_upload_2d_async(d->ctx_in, sp.v, (size_t)W / 2, in->cr, in->cr_stride, (size_t)W / 2, (size_t)H / 2));
+        if (in->cr) GPU_TRY(up(d->ctx_in, sp.v, (size_t)W / 2, in->cr, in->cr_stride, (size_t)W / 2, (size_t)H / 2));
         else GPU_TRY(svt_hip_mem_set(d->ctx_in, sp.v, 128, (size_t)(W / 2) * (H / 2)));
         const uint8_t *lum = sp.y;
         const int32_t  stride = W;
@@ -863,10 +923,13 @@ EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *
         GPU_TRY(svt_hip_pa_mean_variance_device(d->ctx_in, &t->pa.full, (uint8_t *)t->d_mean, (uint16_t *)t->d_var));
         GPU_TRY(svt_hip_ctx_marker_record(d->ctx_in, &d->in_marker));
         d->has_in = 1;
+        /* direct uploads: the caller's planes have been read when this returns (the analysis kernels above are enqueued behind the copies
+           and are not waited for) */
+        if (s->register_input) GPU_TRY(svt_hip_mem_upload_wait(d->ctx_in));
         /* the picture is accepted from here on */
         s->next_number = n + 1;
         d->accepted++;
-        t->number = n; t->pts = b->pts; t->processed = 0; t->coded = 0; t->has_marker = 0; t->has_release = 0; t->has_out = 0; t->is_copy = 0;
+        t->number = n; t->pts = b->pts; t->processed = 0; t->coded = 0; t->has_marker = 0; t->has_release = 0; t->has_release2 = 0; t->marker_ctx = NULL; t->has_out = 0; t->is_copy = 0;
         memset(&t->info, 0, sizeof t->info);
         t->info.picture_number = (uint64_t)n; t->info.n_sb = (uint32_t)s->n_sb; t->info.device_ordinal = d->ordinal;
         if (intra) {
@@ -911,7 +974,7 @@ EbErrorType eb_vp9_svt_get_packet(EbComponentType *h, EbBufferHeaderType **p_buf
     /* the newest packet stays in the queue until the library knows whether it is the last one (it then carries EB_BUFFERFLAG_EOS): the
        end-of-stream buffer arrives in a send_picture call of its own (App/EbAppProcessCmd.c:483-494) */
     if (p == s->q_tail && !s->eos) return EB_NoErrorEmptyQueue;
-    svt_hip_ctx *ctx = s->dev[p->dev].ctx;
+    svt_hip_ctx *ctx = p->ctx ? p->ctx : s->dev[p->dev].ctx;
     if (ctx) {
         if (pic_send_done) { GPU_TRY(svt_hip_ctx_marker_wait(ctx, p->marker)); }
         else {
@@ -1024,7 +1087,7 @@ EbErrorType svt_vp9_shim_get_me_results(EbComponentType *h, uint64_t picture_num
     shim_slot *t = find_any(s, (int64_t)picture_number, &d);
     /* a picture that waits in an incomplete mini-GOP has no results yet; neither has one the ring has already given away */
     if (!t || !t->processed) return EB_NoErrorEmptyQueue;
-    GPU_TRY(svt_hip_ctx_marker_wait(d->ctx, t->marker));
+    GPU_TRY(svt_hip_ctx_marker_wait(t->marker_ctx ? t->marker_ctx : d->ctx, t->marker));
     if (info) *info = t->info;
     if (out && !t->info.is_intra) {
         const uint64_t need = (uint64_t)t->info.n_sb * 85 * sizeof(svt_me_pu_result);
@@ -1041,7 +1104,7 @@ EbErrorType svt_vp9_shim_get_sb_stats(EbComponentType *h, uint64_t picture_numbe
     shim_dev  *d = NULL;
     shim_slot *t = find_any(s, (int64_t)picture_number, &d);
     if (!t || !t->processed) return EB_NoErrorEmptyQueue;
-    GPU_TRY(svt_hip_ctx_marker_wait(d->ctx, t->marker));
+    GPU_TRY(svt_hip_ctx_marker_wait(t->marker_ctx ? t->marker_ctx : d->ctx, t->marker));
     const size_t n_sb = t->info.n_sb;
     if (stats && !t->info.is_intra) {
         if (stats_bytes < n_sb * sizeof(svt_me_sb_stats)) return EB_ErrorBadParameter;
@@ -1060,7 +1123,7 @@ EbErrorType svt_vp9_shim_get_coded_picture(EbComponentType *h, uint64_t picture_
     shim_dev  *d = NULL;
     shim_slot *t = find_any(s, (int64_t)picture_number, &d);
     if (!t || !t->coded) return EB_NoErrorEmptyQueue;
-    GPU_TRY(svt_hip_ctx_marker_wait(d->ctx, t->marker));
+    GPU_TRY(svt_hip_ctx_marker_wait(t->marker_ctx ? t->marker_ctx : d->ctx, t->marker));
     if (info) *info = t->info;
     const size_t units = (size_t)s->mi_rows * s->mi_cols;
     if (mc_mode_info) GPU_TRY(svt_hip_mem_download(d->ctx, mc_mode_info, t->d_mc_mi, units * sizeof(svt_mc_mode_info)));
@@ -1079,7 +1142,7 @@ EbErrorType svt_vp9_shim_get_reference_picture(EbComponentType *h, uint64_t pict
     const size_t pw = (size_t)s->W + 2 * SHIM_REF_PAD, ph = (size_t)s->H + 2 * SHIM_REF_PAD, cpw = (size_t)s->W / 2 + SHIM_REF_PAD, cph = (size_t)s->H / 2 + SHIM_REF_PAD;
     const size_t need = pw * ph + 2 * cpw * cph;
     if (bytes < need) return EB_ErrorBadParameter;
-    GPU_TRY(svt_hip_ctx_marker_wait(d->ctx, t->marker));
+    GPU_TRY(svt_hip_ctx_marker_wait(t->marker_ctx ? t->marker_ctx : d->ctx, t->marker));
     GPU_TRY(svt_hip_mem_download(d->ctx, out, t->d_rec, need));
     return EB_ErrorNone;
 }
