@@ -2,14 +2,14 @@
 # tools/profile_round.sh TAG -- the rocprofv3 passes behind profiles/ (run on the GPU box, e.g. through gpurun).
 # Pass 1: kernel trace + stats of the default bench command.  Passes 2-5: PMC counters, each in its own run with
 # --kernel-trace only (never combined with other trace domains).  Everything lands under gpurun_out/prof_TAG*.
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --no-cpu-baseline --no-single --no-extras"
 # the counter passes profile ONE GOP in flight (diagonal schedule): a step is then one 16-picture mini-GOP and a stage's launches of
 # the last step are the last PER_STEP dispatches of its kernel (tools/summarize_prof.py)
-ONE="--gops 1 --groups 1 --schedule diagonal"
+ONE="--gops 1 --groups 1 --schedule diagonal --no-key-frames"   # (inter pictures only: a key frame's launches would fall among "the last launches of the step")
 rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG} -o $TAG --output-format csv -- $BENCH --steps 3 --warmup 5 > $OUT/prof_${TAG}_bench.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_${TAG}_fetch -o f --output-format csv -- $BENCH $ONE --steps 1 --warmup 5 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_${TAG}_write -o w --output-format csv -- $BENCH $ONE --steps 1 --warmup 5 > /dev/null 2>&1

@@ -26,6 +26,8 @@ KERNELS = ("svt_me_sb_kernel", "svt_tq_kernel", "svt_lf_kernel", "svt_lf_desc_ke
 def short(name):
     if re.search(r"(?<![A-Za-z_0-9])svt_tq_lane_kernel(?![A-Za-z_0-9])", name):
         return "svt_tq_kernel"  # the 4x4 instance of the TQ stage
+    if re.search(r"(?<![A-Za-z_0-9])svt_me_fast_kernel(?![A-Za-z_0-9])", name):
+        return "svt_me_sb_kernel"  # the same kernel behind csrc/me_fast.h's driver (round 5)
     for k in KERNELS:
         if re.search(r"(?<![A-Za-z_0-9])" + k + r"(?![A-Za-z_0-9])", name):
             return k
