@@ -31,7 +31,8 @@
 struct svt_encdec_work {
     int           max_pics, width, height, n_sb, sb_cols, mi_rows, mi_cols;
     size_t        cap_per_pic;   /* transform blocks of a picture at most: all 4x4 */
-    svt_tq_block *d_blocks;
+    svt_tq_block *d_blocks;      /* only when a host asks for the descriptor list (svt_hip_encdec_work_download): allocated and filled then */
+    void         *last_hb;       /* host copy of the latest batch's parameter block (for that) */
     uint32_t     *d_pos;
     uint16_t     *d_eob;
     int32_t      *d_counts;      /* [4][max_pics][n_sb], turned into offsets by the scan */
@@ -125,6 +126,19 @@ __global__ __launch_bounds__(64) void svt_scan_pic_kernel(const int32_t *__restr
         for (int p = 0; p < n_pics; p++) { bases[s * n_pics + p] = run; run += totals[s * n_pics + p]; }
         off_cnt[4 + s] = run - off_cnt[s];
     }
+}
+
+/* the descriptor list a host may ask for (svt_hip_encdec_work_download): rebuilt from the position codes, the transform size of the range a
+ * block sits in and the pictures' geometry -- the same function the transform kernels call per block */
+__global__ __launch_bounds__(256) void svt_tq_expand_kernel(const ed_batch_dev *__restrict__ B, const int32_t *__restrict__ off_cnt, const uint32_t *__restrict__ pos,
+                                                           svt_tq_block *__restrict__ blocks) {
+    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x, total = off_cnt[3] + off_cnt[7];
+    if (i >= total) return;
+    const int      ts = i >= off_cnt[3] ? 3 : i >= off_cnt[2] ? 2 : i >= off_cnt[1] ? 1 : 0;
+    const uint32_t p = pos[i];
+    svt_tq_block   k;
+    svt_tq_block_from_pos(p, ts, &B->pic[svt_tq_pos_pic(p)].g, B->iscan_off, B->sb_cols, &k);
+    blocks[i] = k;
 }
 
 /* same mapping as the count kernel: every block-origin lane writes its descriptors at offsets[size][picture][SB] + (blocks of that
@@ -255,7 +269,8 @@ extern "C" int32_t svt_hip_encdec_work_create(svt_hip_ctx *ctx, int32_t max_pics
     uint32_t const *offs = nullptr;
     int32_t         entries = 0;
     const int16_t  *isc = svt_hip_vp9_iscan_tables(&offs, &entries);
-    bool ok = hipMalloc((void **)&w->d_blocks, cap * sizeof(svt_tq_block)) == hipSuccess && hipMalloc((void **)&w->d_pos, cap * sizeof(uint32_t)) == hipSuccess &&
+    /* the lists are position codes (4 bytes per transform block; the 32-byte descriptors are rebuilt in registers where they are used) */
+    bool ok = hipMalloc((void **)&w->d_pos, cap * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&w->d_eob, cap * sizeof(uint16_t)) == hipSuccess &&
               hipMalloc((void **)&w->d_counts, ((size_t)4 * max_pics * w->n_sb + 16 + 8 * ED_MAX_PICS + 4 + 12 * (size_t)w->n_sb) * sizeof(int32_t)) == hipSuccess &&
               hipMalloc((void **)&w->d_qtabs, 2 * sizeof(svt_quant_tables)) == hipSuccess && hipMalloc((void **)&w->d_iscan, (size_t)entries * sizeof(int16_t)) == hipSuccess;
@@ -282,6 +297,7 @@ extern "C" void svt_hip_encdec_work_destroy(svt_hip_ctx *ctx, svt_encdec_work *w
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
     void *v[6] = {w->d_blocks, w->d_pos, w->d_eob, w->d_counts, w->d_qtabs, w->d_iscan};
     for (int i = 0; i < 6; i++) if (v[i]) (void)hipFree(v[i]);
+    free(w->last_hb);
     free(w);
 }
 
@@ -418,14 +434,16 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
     hipLaunchKernelGGL(svt_tq_count_kernel, dim3(nwg), dim3(64), 0, ctx->stream, dB, w->d_counts, w->d_status);
     hipLaunchKernelGGL(svt_scan_sb_kernel, dim3(4 * n_pics), dim3(256), 0, ctx->stream, w->d_counts, hb.n_sb, w->d_totals);
     hipLaunchKernelGGL(svt_scan_pic_kernel, dim3(1), dim3(64), 0, ctx->stream, (const int32_t *)w->d_totals, n_pics, w->d_bases, w->d_off_cnt);
-    hipLaunchKernelGGL(svt_tq_emit_kernel, dim3(nwg), dim3(64), 0, ctx->stream, dB, (const int32_t *)w->d_counts, (const int32_t *)w->d_bases, w->d_blocks, w->d_pos);
+    hipLaunchKernelGGL(svt_tq_emit_kernel, dim3(nwg), dim3(64), 0, ctx->stream, dB, (const int32_t *)w->d_counts, (const int32_t *)w->d_bases, (svt_tq_block *)nullptr, w->d_pos);
     HIP_TRY(hipGetLastError());
+    if (!w->last_hb) w->last_hb = malloc(sizeof hb);
+    if (w->last_hb) memcpy(w->last_hb, &hb, sizeof hb);
     /* 3. residual -> transform -> quantisation (-> inverse -> reconstruction) */
     ED_STAGE(SVT_ENCDEC_STAGE_TQ);
     int32_t cap[4];
     for (int s = 0; s < 4; s++) cap[s] = (int32_t)((size_t)n_pics * width * height * 3 / 2 / (size_t)(16 << (2 * s)));
-    rc = svt_tq_launch_device_lists(ctx, (const uint8_t *)src_lo, (const uint8_t *)pred_lo, recon_set, n_sets, w->d_blocks, cap, w->d_off_cnt, w->d_qtabs, w->d_iscan,
-                                    (int16_t *)q_lo, (int16_t *)dq_lo, w->d_eob, nullptr);
+    rc = svt_tq_launch_device_lists(ctx, (const uint8_t *)src_lo, (const uint8_t *)pred_lo, recon_set, n_sets, nullptr, cap, w->d_off_cnt, w->d_qtabs, w->d_iscan,
+                                    (int16_t *)q_lo, (int16_t *)dq_lo, w->d_eob, nullptr, w->d_pos, &dB->pic[0].g, (int)sizeof(ed_pic_dev), dB->iscan_off, hb.sb_cols);
     if (rc) return rc;
     /* 4. eob map + skip flags (entries of the map that are not the origin of a transform block of THIS picture read 0) */
     ED_STAGE(SVT_ENCDEC_STAGE_SKIP);
@@ -563,7 +581,18 @@ extern "C" int32_t svt_hip_encdec_work_download(svt_hip_ctx *ctx, svt_encdec_wor
     const int32_t total = c[3] + c[7];
     if (total > capacity) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "encdec_download: capacity");
     if (total > 0) {
-        if (blocks) HIP_TRY(hipMemcpyAsync(blocks, w->d_blocks, (size_t)total * sizeof(svt_tq_block), hipMemcpyDeviceToHost, ctx->stream));
+        if (blocks) {
+            if (!w->last_hb) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "encdec_download: no batch yet");
+            if (!w->d_blocks && hipMalloc((void **)&w->d_blocks, w->cap_per_pic * (size_t)w->max_pics * sizeof(svt_tq_block)) != hipSuccess) {
+                w->d_blocks = nullptr;
+                return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "encdec_download: device memory");
+            }
+            const ed_batch_dev *dB = nullptr;
+            if (stage_batch(ctx, *(const ed_batch_dev *)w->last_hb, &dB)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "encdec_download: descriptor buffers");
+            hipLaunchKernelGGL(svt_tq_expand_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, dB, (const int32_t *)w->d_off_cnt, (const uint32_t *)w->d_pos, w->d_blocks);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(blocks, w->d_blocks, (size_t)total * sizeof(svt_tq_block), hipMemcpyDeviceToHost, ctx->stream));
+        }
         if (pos) HIP_TRY(hipMemcpyAsync(pos, w->d_pos, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         if (eob) HIP_TRY(hipMemcpyAsync(eob, w->d_eob, (size_t)total * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));

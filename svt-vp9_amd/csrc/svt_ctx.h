@@ -64,7 +64,8 @@ int     svt_ctx_aux_init(svt_hip_ctx *ctx);
 /* transform stage over device-built block lists (tq_kernel.hip; used by encdec.hip) */
 int32_t svt_tq_launch_device_lists(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *const *recon_set, int n_set,
                                    const svt_tq_block *d_blocks, const int32_t cap[4], const int32_t *d_off_cnt, const svt_quant_tables *d_qtabs,
-                                   const int16_t *d_iscan, int16_t *d_qcoeff, int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist);
+                                   const int16_t *d_iscan, int16_t *d_qcoeff, int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist,
+                                   const uint32_t *d_pos, const void *d_geom, int geom_stride, const uint32_t *d_iscan_off, int sb_cols);
 
 /* encode pass of an intra picture / the stand-in intra decision (intra_kernel.hip; used by encdec.hip).  d_sync: 2 + 3 * (number of
  * 32x32 luma areas) dwords of scratch */

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include "svt_ctx.h"
 #include "txfm1d.h"
+#include "encdec_core.h"
 #include "rate_core.h"
 
 namespace {
@@ -23,7 +24,12 @@ struct tq_rate_args {
 
 /* Block lists built on the device (csrc/encdec.hip): the launch is sized for the list's capacity on the host, the actual offset and
  * number of blocks of this transform size are read from device memory: p[s] = first block of size s, p[4 + s] = how many. */
-struct tq_dev_count { const int32_t *p; int s; };
+struct tq_dev_count {
+    const int32_t *p; int s;
+    /* pos != null: the list is position codes (encdec_core.h: svt_tq_pos), not descriptors -- a block's descriptor is rebuilt from its code,
+     * this launch's transform size and the picture's geometry record at geom + picture * geom_stride (svt_tq_block_from_pos) */
+    const uint32_t *pos; const uint8_t *geom; int geom_stride; const uint32_t *iscan_off; int sb_cols;
+};
 
 /* Workgroups are persistent and XCD-aware: workgroup w runs on XCD w & 7 (round-robin dispatch), and the groups of blocks it
  * walks are a contiguous eighth of the batch -- neighbouring blocks (which share 64-byte lines of the planes: a 4x4 block's

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? (
         const int o = dc.p[dc.s];
         n_blocks = dc.p[4 + dc.s];
         blocks += o; eob_out += o;
+        if (dc.pos) dc.pos += o;
         if (dist_out) dist_out += 2 * o;
         if constexpr (RATE) ra.bits += o;
     }
@@ -66,7 +67,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? (
     const int blk = grp * BPW + lb;
     const bool active = blk < n_blocks;
     svt_tq_block k;
-    if (active) k = blocks[blk];
+    if (dc.pos) { /* (uniform) the list holds position codes: the descriptor is rebuilt in registers */
+        const uint32_t pc = dc.pos[active ? blk : 0];
+        svt_tq_block_from_pos(pc, txcfg<N>::size, (const svt_tq_pic_geom *)(dc.geom + (size_t)svt_tq_pos_pic(pc) * dc.geom_stride), dc.iscan_off, dc.sb_cols, &k);
+    } else if (active) k = blocks[blk];
     else { k = blocks[0]; }
     int32_t *t = tile[lb];
     /* lane i fetches ROW i of source and prediction as dwords (coalesced: the N lanes of a block read N consecutive rows of N bytes) */
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
         const int o = dc.p[dc.s];
         n_blocks = dc.p[4 + dc.s];
         blocks += o; eob_out += o;
+        if (dc.pos) dc.pos += o;
         if (dist_out) dist_out += 2 * o;
         if constexpr (RATE) ra.bits += o;
     }
@@ -160,7 +165,11 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
   for (int gj = wk.first; gj < wk.per_xcd; gj += wk.step) {
     const int blk = (wk.base + gj) * 256 + (int)threadIdx.x;
     if (blk >= n_blocks) continue; /* no barrier inside the loop */
-    const svt_tq_block k = blocks[blk];
+    svt_tq_block k;
+    if (dc.pos) {
+        const uint32_t pc = dc.pos[blk];
+        svt_tq_block_from_pos(pc, txcfg<N>::size, (const svt_tq_pic_geom *)(dc.geom + (size_t)svt_tq_pos_pic(pc) * dc.geom_stride), dc.iscan_off, dc.sb_cols, &k);
+    } else k = blocks[blk];
     const bool col_adst = k.tx_type == SVT_ADST_DCT || k.tx_type == SVT_ADST_ADST;
     const bool row_adst = k.tx_type == SVT_DCT_ADST || k.tx_type == SVT_ADST_ADST;
     const bool dct_dct  = k.tx_type == SVT_DCT_DCT;
@@ -334,7 +343,7 @@ int tq_grid(svt_hip_ctx *ctx, int ngroups, int per_cu) {
 template <int N, bool RATE, bool DIST = true>
 hipError_t launch_tq(svt_hip_ctx *ctx, hipStream_t st, const uint8_t *src, const uint8_t *pred, uint8_t *recon, const svt_tq_block *blocks, int n,
                      const svt_quant_tables *q, const int16_t *iscan, int16_t *qc, int16_t *dqc, uint16_t *eob, uint64_t *dist, tq_rate_args ra,
-                     const uint8_t *const *recon_set, tq_dev_count dc = {nullptr, 0}) {
+                     const uint8_t *const *recon_set, tq_dev_count dc = {nullptr, 0, nullptr, nullptr, 0, nullptr, 0}) {
     if (n <= 0) return hipSuccess;
     /* block per lane for 4x4 only: the 8x8 instance is bit-exact too but needs 201 VGPRs (64 samples + the transposed
      * intermediate live in one lane; 87 spills when held to 128) -- two waves per SIMD, and each displaces two ME waves:
@@ -402,10 +411,12 @@ int32_t tq_launch_all(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_p
 
 /* Transform stage over block lists that were built ON THE DEVICE (csrc/encdec.hip): d_off_cnt[s] / d_off_cnt[4 + s] = first block and
  * number of blocks of size s inside d_blocks / d_eob; cap[s] = an upper bound known to the host, which only sizes the persistent
- * grids.  No rate, optional distortion.  Internal to the library (declared in svt_ctx.h). */
+ * grids.  No rate, optional distortion.  d_pos != null: the lists are position codes (d_blocks is not read): tq_dev_count.  Internal to the
+ * library (declared in svt_ctx.h). */
 int32_t svt_tq_launch_device_lists(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *const *recon_set, int n_set,
                                    const svt_tq_block *d_blocks, const int32_t cap[4], const int32_t *d_off_cnt, const svt_quant_tables *d_qtabs,
-                                   const int16_t *d_iscan, int16_t *d_qcoeff, int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist) {
+                                   const int16_t *d_iscan, int16_t *d_qcoeff, int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist,
+                                   const uint32_t *d_pos, const void *d_geom, int geom_stride, const uint32_t *d_iscan_off, int sb_cols) {
     HIP_TRY(hipSetDevice(ctx->device));
     void *h = nullptr, *d = nullptr;
     if (svt_ctx_stage(ctx, 8 * sizeof(void *), &h, &d)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "tq: descriptor buffers");
@@ -414,7 +425,7 @@ int32_t svt_tq_launch_device_lists(svt_hip_ctx *ctx, const uint8_t *d_src, const
     const uint8_t *const *d_set = (const uint8_t *const *)d;
     const tq_rate_args none = {nullptr, nullptr, nullptr};
     hipError_t rc = hipSuccess;
-#define TQ_DEV(N, S, D) launch_tq<N, false, D>(ctx, ctx->stream, d_src, d_pred, nullptr, d_blocks, cap[S], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob, d_dist, none, d_set, tq_dev_count{d_off_cnt, S})
+#define TQ_DEV(N, S, D) launch_tq<N, false, D>(ctx, ctx->stream, d_src, d_pred, nullptr, d_blocks, cap[S], d_qtabs, d_iscan, d_qcoeff, d_dqcoeff, d_eob, d_dist, none, d_set, tq_dev_count{d_off_cnt, S, d_pos, (const uint8_t *)d_geom, geom_stride, d_iscan_off, sb_cols})
     if (d_dist) { /* with the coefficient-domain distortion pair */
         rc = TQ_DEV(4, 0, true);
         if (rc == hipSuccess) rc = TQ_DEV(8, 1, true);
