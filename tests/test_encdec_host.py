@@ -111,7 +111,7 @@ def test_tq_blocks_from_grid(seed, W, H):
         assert (k["src_stride"], k["pred_stride"], k["recon_stride"]) == (g.src_stride[c], g.pred_stride[c], g.recon_stride[c])
         tt = int(mis[p]["pad"][ur, uc, 0]) & 3 if (plane == 0 and ts < 3) else 0
         assert k["tx_type"] == tt
-        assert int(pos[i]) == (p << 24 | plane << 22 | (y >> 2) << 11 | (x >> 2))
+        assert int(pos[i]) == (tt << 30 | p << 24 | plane << 22 | (y >> 2) << 11 | (x >> 2))   # the position code IS the block (round 5)
         assert (int(k["pad"][0]) >> 4) & 7 == p and (int(k["pad"][0]) >> 3) & 1 == int(mis[p]["is_inter"][ur, uc]) and (int(k["pad"][0]) >> 2) & 1 == c
         sbw = 32 if plane else 64
         sb = (y // sbw) * ((W + 63) // 64) + x // sbw
