@@ -179,6 +179,11 @@ __global__ __launch_bounds__(256) void svt_tq_skip_kernel(const ed_batch_dev *__
         }
     }
 }
+/* the eob maps of the batch read 0 before the blocks write theirs: one launch for all pictures (16 bytes per lane) */
+__global__ __launch_bounds__(256) void svt_eob_map_clear_kernel(const ed_batch_dev *__restrict__ B, int n16) {
+    uint4 *m = (uint4 *)B->pic[blockIdx.y].eob_map;
+    for (int i = (int)(blockIdx.x * 256 + threadIdx.x); i < n16; i += (int)(gridDim.x * 256)) m[i] = make_uint4(0, 0, 0, 0);
+}
 /* every unit takes the skip flag of its block */
 __global__ __launch_bounds__(256) void svt_skip_update_kernel(const ed_batch_dev *__restrict__ B) {
     const int units = B->mi_rows * B->mi_cols;
@@ -447,7 +452,15 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
     if (rc) return rc;
     /* 4. eob map + skip flags (entries of the map that are not the origin of a transform block of THIS picture read 0) */
     ED_STAGE(SVT_ENCDEC_STAGE_SKIP);
-    for (int i = 0; i < n_pics; i++) HIP_TRY(hipMemsetAsync(pics[i].d_eob_map, 0, (size_t)(width / 4) * (height / 4) * 3 / 2 * sizeof(uint16_t), ctx->stream));
+    {
+        const size_t map_bytes = (size_t)(width / 4) * (height / 4) * 3 / 2 * sizeof(uint16_t);
+        uintptr_t    low = map_bytes;
+        for (int i = 0; i < n_pics; i++) low |= (uintptr_t)pics[i].d_eob_map;
+        if (!(low & 15))
+            hipLaunchKernelGGL(svt_eob_map_clear_kernel, dim3(64, n_pics), dim3(256), 0, ctx->stream, dB, (int)(map_bytes / 16));
+        else
+            for (int i = 0; i < n_pics; i++) HIP_TRY(hipMemsetAsync(pics[i].d_eob_map, 0, map_bytes, ctx->stream));
+    }
     /* 3b. intra blocks of inter pictures: their inter neighbours are reconstructed now; the wavefront kernel codes them, one picture
            after the other (it writes their eob-map entries and coefficient flags itself) */
     for (int i = 0; i < n_pics; i++)
