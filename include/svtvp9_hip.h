@@ -207,6 +207,12 @@ int32_t svt_hip_mem_download(svt_hip_ctx *ctx, void *dst, const void *d_src, siz
  * context's stream.  The call blocks only when all staging buffers (4) still hold copies the device has not consumed. */
 int32_t svt_hip_mem_upload_2d_async(svt_hip_ctx *ctx, void *d_dst, size_t dst_stride, const void *src, size_t src_stride, size_t width_bytes,
                                     size_t rows);
+/* Up to 4 planes of one picture through ONE staging slot (same contract as svt_hip_mem_upload_2d_async for each plane): destinations
+ * that lie back to back on the device, tight (dst_stride == width_bytes, d_dst[i + 1] == the end of plane i: Y | Cb | Cr in one buffer),
+ * travel as one host-to-device copy -- a third of the stream operations of three separate uploads (copy_frame_buffer copies the three
+ * planes of a picture in one call too, Codec/EbEncHandle.c:2743-2796). */
+int32_t svt_hip_mem_upload_planes_async(svt_hip_ctx *ctx, int32_t n_planes, void *const *d_dst, const size_t *dst_stride, const void *const *src,
+                                        const size_t *src_stride, const size_t *width_bytes, const size_t *rows);
 /* The same upload WITHOUT the staging copy, for a host whose rows lie in memory that stays allocated while the library is in use: a
  * range of host memory is page-locked (hipHostRegister) the first time it is seen, so a host that sends from a fixed pool of buffers
  * pays for that once and is read by the DMA engines directly from then on (57 GB/s on the MI355X box against ~27 GB/s through the

@@ -150,7 +150,7 @@ SB_COEFFS = 6144
 EXPORTS = [
     "svt_hip_sb_count", "svt_hip_input_resolution", "svt_hip_me_params_derive", "svt_hip_me_params_preset", "svt_hip_ctx_create", "svt_hip_ctx_create_on_stream", "svt_hip_ctx_create_cu_mask", "svt_hip_ctx_stream",
     "svt_hip_ctx_destroy", "svt_hip_ctx_synchronize", "svt_hip_last_error", "svt_hip_last_kernel_ms",
-    "svt_hip_mem_alloc", "svt_hip_mem_free", "svt_hip_mem_upload_2d", "svt_hip_mem_upload_2d_async", "svt_hip_mem_download", "svt_hip_mem_set",
+    "svt_hip_mem_alloc", "svt_hip_mem_free", "svt_hip_mem_upload_2d", "svt_hip_mem_upload_2d_async", "svt_hip_mem_upload_planes_async", "svt_hip_mem_download", "svt_hip_mem_set",
     "svt_hip_ctx_marker_record", "svt_hip_ctx_marker_query", "svt_hip_ctx_marker_wait", "svt_hip_minigop_split",
     "svt_hip_me_picture_device", "svt_hip_me_batch_device", "svt_hip_me_batch_layers_device", "svt_hip_me_picture", "svt_hip_sad_loop_batch_device",
     "svt_hip_me_zz_sad_device", "svt_hip_me_similar_collocated", "svt_hip_me_sb_stats_device", "svt_hip_pa_prepare_batch_device", "svt_hip_pa_mean_variance_device",

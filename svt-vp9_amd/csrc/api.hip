@@ -4,12 +4,15 @@
  * and fails with SVT_HIP_ERR_DEVICE when no gfx950 device is usable.
  */
 #include <hip/hip_runtime.h>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "svt_ctx.h"
 
 extern "C" void svt_copy_rows_mt(uint8_t *dst, size_t dst_stride, const uint8_t *src, size_t src_stride, size_t width, size_t rows);
+extern "C" void svt_copy_planes_mt(int n_planes, uint8_t *const *dst, const size_t *dst_stride, const uint8_t *const *src, const size_t *src_stride, const size_t *width,
+                                   const size_t *rows);
 
 static thread_local char g_err[512] = "";
 
@@ -68,6 +71,9 @@ extern "C" void *svt_hip_ctx_stream(svt_hip_ctx *c) { return c ? (void *)c->stre
 extern "C" void svt_hip_ctx_destroy(svt_hip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->up_prof_n)
+        fprintf(stderr, "svt_hip upload profile (us per picture): staging-slot wait %.1f  row copies %.1f  enqueue %.1f  (%ld uploads)\n", 1e6 * c->up_prof[0] / (double)c->up_prof_n,
+                1e6 * c->up_prof[1] / (double)c->up_prof_n, 1e6 * c->up_prof[2] / (double)c->up_prof_n, c->up_prof_n);
     if (c->stream || !c->owns_stream) (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < SVT_CTX_SLOTS; i++) if (c->slot[i]) (void)hipFree(c->slot[i]);
     for (int i = 0; i < SVT_CTX_RING; i++) {
@@ -205,6 +211,60 @@ extern "C" int32_t svt_hip_mem_upload_2d_async(svt_hip_ctx *ctx, void *d_dst, si
     return SVT_HIP_OK;
 }
 
+/* The planes of one picture in one go: staged back to back in ONE slot of the ring; destinations that lie back to back on the device,
+ * tight (a picture's Y | Cb | Cr inside one buffer), take ONE host-to-device copy, and there is one event for the slot -- a third of the
+ * stream operations of three svt_hip_mem_upload_2d_async calls (the public API's picture rate is bound by the number of operations its
+ * thread enqueues). */
+extern "C" int32_t svt_hip_mem_upload_planes_async(svt_hip_ctx *ctx, int32_t n_planes, void *const *d_dst, const size_t *dst_stride, const void *const *src,
+                                                   const size_t *src_stride, const size_t *width_bytes, const size_t *rows) {
+    if (!ctx || n_planes < 1 || n_planes > 4 || !d_dst || !dst_stride || !src || !src_stride || !width_bytes || !rows)
+        return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "mem_upload_planes: bad argument");
+    size_t bytes = 0;
+    bool   one = true;
+    for (int i = 0; i < n_planes; i++) {
+        if (!d_dst[i] || !src[i] || !width_bytes[i] || !rows[i] || dst_stride[i] < width_bytes[i] || src_stride[i] < width_bytes[i])
+            return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "mem_upload_planes: bad plane");
+        if (dst_stride[i] != width_bytes[i] || (i && (uint8_t *)d_dst[i] != (uint8_t *)d_dst[i - 1] + width_bytes[i - 1] * rows[i - 1])) one = false;
+        bytes += width_bytes[i] * rows[i];
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    static const bool prof = getenv("SVT_HIP_SHIM_PROFILE") != nullptr;
+    auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    double t0 = prof ? now() : 0.0;
+    const int k = ctx->up_pos;
+    if (ctx->up_used[k]) { HIP_TRY(hipEventSynchronize(ctx->up_ev[k])); ctx->up_used[k] = 0; }
+    if (!ctx->up_ev[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->up_ev[k], hipEventDisableTiming));
+    if (bytes > ctx->up_bytes[k]) {
+        if (ctx->up_host[k]) (void)hipHostFree(ctx->up_host[k]);
+        ctx->up_host[k] = nullptr; ctx->up_bytes[k] = 0;
+        if (hipHostMalloc(&ctx->up_host[k], bytes, hipHostMallocDefault) != hipSuccess) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "mem_upload_planes: pinned staging buffer");
+        ctx->up_bytes[k] = bytes;
+    }
+    if (prof) { const double t1 = now(); ctx->up_prof[0] += t1 - t0; t0 = t1; }
+    uint8_t *st = (uint8_t *)ctx->up_host[k];
+    size_t   off = 0;
+    {   /* host/copy_pool.c: a few threads, one hand-over for the whole picture */
+        uint8_t *sd[4];
+        for (int i = 0; i < n_planes; i++) { sd[i] = st + off; off += width_bytes[i] * rows[i]; }
+        svt_copy_planes_mt(n_planes, sd, width_bytes, (const uint8_t *const *)src, src_stride, width_bytes, rows);
+    }
+    if (prof) { const double t1 = now(); ctx->up_prof[1] += t1 - t0; t0 = t1; }
+    if (one) HIP_TRY(hipMemcpyAsync(d_dst[0], st, bytes, hipMemcpyHostToDevice, ctx->stream));
+    else {
+        off = 0;
+        for (int i = 0; i < n_planes; i++) {
+            if (dst_stride[i] == width_bytes[i]) HIP_TRY(hipMemcpyAsync(d_dst[i], st + off, width_bytes[i] * rows[i], hipMemcpyHostToDevice, ctx->stream));
+            else HIP_TRY(hipMemcpy2DAsync(d_dst[i], dst_stride[i], st + off, width_bytes[i], width_bytes[i], rows[i], hipMemcpyHostToDevice, ctx->stream));
+            off += width_bytes[i] * rows[i];
+        }
+    }
+    HIP_TRY(hipEventRecord(ctx->up_ev[k], ctx->stream));
+    ctx->up_used[k] = 1;
+    ctx->up_pos = (k + 1) % SVT_CTX_UPLOAD_RING;
+    if (prof) { ctx->up_prof[2] += now() - t0; ctx->up_prof_n++; }
+    return SVT_HIP_OK;
+}
+
 /* ---- uploads straight from the caller's memory (opt-in) ----
  * A host that sends its pictures from a fixed pool of buffers which stay allocated for the encoder's lifetime (the reference's
  * application does: allocate_input_buffers, App/EbAppContext.c) does not need the staging copy: the first time a range of host
@@ -321,26 +381,28 @@ extern "C" void svt_hip_host_unregister_all(void) {
 extern "C" int32_t svt_hip_ctx_marker_record(svt_hip_ctx *ctx, uint64_t *marker) {
     if (!ctx || !marker) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "marker: null");
     HIP_TRY(hipSetDevice(ctx->device));
-    const uint64_t m = ctx->mk_next;
+    const uint64_t m = ctx->mk_next; /* (only the context's enqueuing thread records; other threads may query / wait: atomic counter) */
     hipEvent_t    &e = ctx->mk_ev[m % SVT_CTX_MARKERS];
     if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     else HIP_TRY(hipEventSynchronize(e)); /* its previous use (marker m - SVT_CTX_MARKERS) is complete from here on */
     HIP_TRY(hipEventRecord(e, ctx->stream));
-    ctx->mk_next = m + 1;
+    __atomic_store_n(&ctx->mk_next, m + 1, __ATOMIC_RELEASE);
     *marker = m;
     return SVT_HIP_OK;
 }
 extern "C" int32_t svt_hip_ctx_marker_query(svt_hip_ctx *ctx, uint64_t marker) {
-    if (!ctx || marker >= ctx->mk_next) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "marker: unknown");
-    if (ctx->mk_next - marker > SVT_CTX_MARKERS) return 1; /* its event has been waited for and recorded again since */
+    const uint64_t next = ctx ? __atomic_load_n(&ctx->mk_next, __ATOMIC_ACQUIRE) : 0;
+    if (!ctx || marker >= next) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "marker: unknown");
+    if (next - marker > SVT_CTX_MARKERS) return 1; /* its event has been waited for and recorded again since */
     const hipError_t e = hipEventQuery(ctx->mk_ev[marker % SVT_CTX_MARKERS]);
     if (e == hipSuccess) return 1;
     if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
     return svt_set_hip_error(e, __FILE__, __LINE__);
 }
 extern "C" int32_t svt_hip_ctx_marker_wait(svt_hip_ctx *ctx, uint64_t marker) {
-    if (!ctx || marker >= ctx->mk_next) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "marker: unknown");
-    if (ctx->mk_next - marker > SVT_CTX_MARKERS) return SVT_HIP_OK;
+    const uint64_t next = ctx ? __atomic_load_n(&ctx->mk_next, __ATOMIC_ACQUIRE) : 0;
+    if (!ctx || marker >= next) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "marker: unknown");
+    if (next - marker > SVT_CTX_MARKERS) return SVT_HIP_OK;
     HIP_TRY(hipEventSynchronize(ctx->mk_ev[marker % SVT_CTX_MARKERS]));
     return SVT_HIP_OK;
 }
@@ -361,8 +423,9 @@ extern "C" int32_t svt_hip_mem_set(svt_hip_ctx *ctx, void *d_dst, int32_t value,
 
 /* ---- stream-to-stream ordering between contexts, pinned host memory, asynchronous downloads ---- */
 extern "C" int32_t svt_hip_ctx_wait_marker(svt_hip_ctx *ctx, svt_hip_ctx *other, uint64_t marker) {
-    if (!ctx || !other || marker >= other->mk_next) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "wait_marker: unknown");
-    if (other->mk_next - marker > SVT_CTX_MARKERS) return SVT_HIP_OK; /* long complete */
+    const uint64_t next = other ? __atomic_load_n(&other->mk_next, __ATOMIC_ACQUIRE) : 0;
+    if (!ctx || !other || marker >= next) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "wait_marker: unknown");
+    if (next - marker > SVT_CTX_MARKERS) return SVT_HIP_OK; /* long complete */
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, other->mk_ev[marker % SVT_CTX_MARKERS], 0));
     return SVT_HIP_OK;

@@ -39,6 +39,8 @@ struct svt_hip_ctx {
     hipEvent_t  up_ev[SVT_CTX_UPLOAD_RING];
     int         up_used[SVT_CTX_UPLOAD_RING];
     int         up_pos;
+    double      up_prof[3];     /* SVT_HIP_SHIM_PROFILE: seconds waiting for a staging slot / copying rows / enqueuing, and */
+    long        up_prof_n;      /* the number of uploads (svt_hip_mem_upload_planes_async) */
     hipEvent_t  direct_ev;      /* behind the last upload that reads the caller's (page-locked) memory directly */
     int         direct_pending;
     /* completion markers: marker m is event m % SVT_CTX_MARKERS; before an event is recorded again its previous use is waited

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #define POOL_MAX 16
+#define POOL_PLANES 4
 
 static struct {
     pthread_mutex_t lock;      /* protects the job fields and the counters */
@@ -26,18 +27,22 @@ static struct {
     unsigned long   gen;       /* job generation */
     int             stop;      /* set by the destructor: workers leave */
     int             pending;
-    uint8_t        *dst;
-    const uint8_t  *src;
-    size_t          dst_stride, src_stride, width, rows;
-} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, {0}, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int             n_planes;  /* the job: up to POOL_PLANES planes, every thread takes its share of the rows of each */
+    uint8_t        *dst[POOL_PLANES];
+    const uint8_t  *src[POOL_PLANES];
+    size_t          dst_stride[POOL_PLANES], src_stride[POOL_PLANES], width[POOL_PLANES], rows[POOL_PLANES];
+} g_pool = {.lock = PTHREAD_MUTEX_INITIALIZER, .go = PTHREAD_COND_INITIALIZER, .done = PTHREAD_COND_INITIALIZER, .busy = PTHREAD_MUTEX_INITIALIZER};
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;
 
+static void copy_rows(uint8_t *dst, size_t dst_stride, const uint8_t *src, size_t src_stride, size_t width, size_t r0, size_t r1) {
+    if (src_stride == width && dst_stride == width) memcpy(dst + r0 * width, src + r0 * width, (r1 - r0) * width);
+    else for (size_t r = r0; r < r1; r++) memcpy(dst + r * dst_stride, src + r * src_stride, width);
+}
 static void copy_slice(int part, int parts) {
-    const size_t r0 = g_pool.rows * (size_t)part / (size_t)parts, r1 = g_pool.rows * (size_t)(part + 1) / (size_t)parts;
-    if (g_pool.src_stride == g_pool.width && g_pool.dst_stride == g_pool.width)
-        memcpy(g_pool.dst + r0 * g_pool.width, g_pool.src + r0 * g_pool.width, (r1 - r0) * g_pool.width);
-    else
-        for (size_t r = r0; r < r1; r++) memcpy(g_pool.dst + r * g_pool.dst_stride, g_pool.src + r * g_pool.src_stride, g_pool.width);
+    for (int p = 0; p < g_pool.n_planes; p++) {
+        const size_t r0 = g_pool.rows[p] * (size_t)part / (size_t)parts, r1 = g_pool.rows[p] * (size_t)(part + 1) / (size_t)parts;
+        copy_rows(g_pool.dst[p], g_pool.dst_stride[p], g_pool.src[p], g_pool.src_stride[p], g_pool.width[p], r0, r1);
+    }
 }
 
 static void *worker(void *arg) {
@@ -94,17 +99,23 @@ static void pool_init(void) {
     pthread_atfork(NULL, NULL, pool_atfork_child);
 }
 
-/* copies `rows` rows of `width` bytes; returns when all of them have arrived */
-void svt_copy_rows_mt(uint8_t *dst, size_t dst_stride, const uint8_t *src, size_t src_stride, size_t width, size_t rows) {
+/* copies the rows of up to 4 planes (one picture) in ONE fork-join; returns when all of them have arrived */
+void svt_copy_planes_mt(int n_planes, uint8_t *const *dst, const size_t *dst_stride, const uint8_t *const *src, const size_t *src_stride, const size_t *width,
+                        const size_t *rows) {
     pthread_once(&g_once, pool_init);
-    if (g_pool.n == 0 || width * rows < (1u << 20)) { /* small pictures: the hand-over costs more than it saves */
-        if (src_stride == width && dst_stride == width) memcpy(dst, src, width * rows);
-        else for (size_t r = 0; r < rows; r++) memcpy(dst + r * dst_stride, src + r * src_stride, width);
+    size_t total = 0;
+    for (int p = 0; p < n_planes; p++) total += width[p] * rows[p];
+    if (n_planes > POOL_PLANES || g_pool.n == 0 || total < (1u << 20)) { /* small pictures: the hand-over costs more than it saves */
+        for (int p = 0; p < n_planes; p++) copy_rows(dst[p], dst_stride[p], src[p], src_stride[p], width[p], 0, rows[p]);
         return;
     }
     pthread_mutex_lock(&g_pool.busy);
     pthread_mutex_lock(&g_pool.lock);
-    g_pool.dst = dst; g_pool.src = src; g_pool.dst_stride = dst_stride; g_pool.src_stride = src_stride; g_pool.width = width; g_pool.rows = rows;
+    g_pool.n_planes = n_planes;
+    for (int p = 0; p < n_planes; p++) {
+        g_pool.dst[p] = dst[p]; g_pool.src[p] = src[p]; g_pool.dst_stride[p] = dst_stride[p]; g_pool.src_stride[p] = src_stride[p];
+        g_pool.width[p] = width[p]; g_pool.rows[p] = rows[p];
+    }
     g_pool.pending = g_pool.n;
     g_pool.gen++;
     pthread_cond_broadcast(&g_pool.go);
@@ -114,4 +125,9 @@ void svt_copy_rows_mt(uint8_t *dst, size_t dst_stride, const uint8_t *src, size_
     while (g_pool.pending) pthread_cond_wait(&g_pool.done, &g_pool.lock);
     pthread_mutex_unlock(&g_pool.lock);
     pthread_mutex_unlock(&g_pool.busy);
+}
+
+/* copies `rows` rows of `width` bytes; returns when all of them have arrived */
+void svt_copy_rows_mt(uint8_t *dst, size_t dst_stride, const uint8_t *src, size_t src_stride, size_t width, size_t rows) {
+    svt_copy_planes_mt(1, &dst, &dst_stride, &src, &src_stride, &width, &rows);
 }

@@ -39,9 +39,11 @@
  * Not reproduced (picture decision / rate control, control plane): the low-delay-P structure tables of the parts of a short group
  * (those pictures are a P chain), per-layer QP scaling (every picture uses quantizer_to_qindex[qp]).
  */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../../include/svt_vp9_enc_api.h"
 #include "../../include/svtvp9_hip.h"
@@ -58,6 +60,8 @@ typedef struct shim_packet {
     int                 dev;
     svt_hip_ctx        *ctx;        /* the context the marker belongs to (NULL: the device's main context) */
     uint64_t            marker;     /* the GPU work behind this packet (svt_hip_ctx_marker_*) */
+    int                 ready;      /* ctx / marker are valid: a packet is queued (in decode order) when its group is planned and completed by
+                                       the device's feeder once the group's work has been enqueued (release / acquire) */
 } shim_packet;
 
 typedef struct shim_recon { /* one reconstructed picture on its way to eb_vp9_svt_get_recon: pinned host memory, filled asynchronously */
@@ -67,6 +71,7 @@ typedef struct shim_recon { /* one reconstructed picture on its way to eb_vp9_sv
     uint64_t           marker;
     int64_t            pts;
     uint32_t           flags;
+    int                ready;      /* as shim_packet.ready */
 } shim_recon;
 
 typedef struct shim_slot { /* one buffered picture, everything device resident */
@@ -95,21 +100,55 @@ typedef struct shim_slot { /* one buffered picture, everything device resident *
     svt_vp9_shim_picture_info info;
 } shim_slot;
 
+/* one picture of a group whose motion estimation is about to be launched */
+typedef struct shim_job {
+    int64_t       number, ref0, ref1;
+    int           layer, levels, n_lists, used_as_ref, wave;
+    svt_me_params p;
+} shim_job;
+
+/* A planned group: everything the enqueuing side needs, fixed by the caller's thread (plan_group) -- the pictures in decode order with
+ * their references, waves and ME parameters, the packets (and reconstruction records) already queued in output order, the input
+ * stream's marker behind the group's last picture.  run_group enqueues it: on the caller's thread, or on the device's feeder. */
+typedef struct shim_group {
+    shim_job     jobs[SHIM_MAX_MINIGOP];
+    shim_packet *pkt[SHIM_MAX_MINIGOP];
+    shim_recon  *rec[SHIM_MAX_MINIGOP];
+    int          n, n_waves, end_of_stream, dev;
+    int          has_in;
+    uint64_t     in_marker;
+    int          has_key;               /* the group's waves follow the intra picture coded on the key context */
+    uint64_t     key_marker;
+    int64_t      first, last, oldest;   /* first / last picture of the group; the oldest picture its work reads (a reference) */
+} shim_group;
+
+struct shim_state;
 typedef struct shim_dev {
     svt_hip_ctx     *ctx;
     /* input side: uploads and picture analysis run on a context (stream) of their own, so that the pictures of mini-GOP k + 1 cross
        PCIe while the stages of mini-GOP k compute; the two sides meet through markers (svt_hip_ctx_wait_marker, no host wait).
        SVT_HIP_SINGLE_STREAM=1 makes it the main context again (everything in one stream, as in round 3). */
     svt_hip_ctx     *ctx_in;
+    svt_hip_ctx     *ctx_up;         /* the uploads themselves: a stream of nothing but host-to-device copies, back to back (the analysis kernels and
+                                        their descriptor copies wait on ctx_in behind each picture's copy: ~60 us of stream latency per picture that the
+                                        link would otherwise idle through).  SVT_HIP_SINGLE_STREAM=1: the main context */
     uint64_t         in_marker;      /* ctx_in: the latest picture's upload + analysis */
     int              has_in;
     svt_hip_ctx     *ctx_out;        /* output side: the reconstructions' device-to-host copies (recon_file), behind the main stream's markers */
     /* the two deepest temporal layers of a group (12 of a mini-GOP's 16 pictures) are coded on a context of their own, behind the
        group's shallower layers: nothing of the NEXT group depends on them (its base picture predicts from this group's base picture),
        so the next group's motion estimation and shallow layers -- waves of 1, 1 and 2 pictures, bound by the deblocking wavefront's
-       latency -- run beside them instead of behind them.  SVT_HIP_NO_DEEP_STREAM=1 (or SVT_HIP_SINGLE_STREAM=1): the main context. */
+       latency -- run beside them instead of behind them.  Opt-in (SVT_HIP_DEEP_STREAM=1), see eb_vp9_init_encoder; default: the main context. */
     svt_hip_ctx     *ctx_deep;
     svt_encdec_work *work_deep;
+    /* a key frame's intra encode pass (a dependency wavefront over the picture: ~6 ms at 4K on a fraction of the device) runs on a context
+       of its own: the motion estimation of the GOP's first group -- which reads the key frame's analysed planes, not its reconstruction --
+       and the tail of the previous GOP run beside it; the group's first wave waits for it (key_marker).  SVT_HIP_NO_KEY_STREAM=1, a
+       decision callback or SVT_HIP_SINGLE_STREAM=1: the main context. */
+    svt_hip_ctx     *ctx_key;
+    svt_encdec_work *work_key;
+    uint64_t         key_marker;     /* ctx_key: the latest intra picture (caller's thread; a planned group carries its copy) */
+    int              has_key;
     int              ordinal;
     int              n_slots;
     shim_slot       *slot;
@@ -117,6 +156,22 @@ typedef struct shim_dev {
     void            *d_src_slab, *d_pred_slab, *d_q_slab, *d_dq_slab;
     svt_encdec_work *work;
     shim_recon      *free_recon;     /* pinned buffers ready for re-use */
+    /* The device's feeder: a thread that enqueues the planned groups of this device (motion estimation, statistics, the waves behind
+       mode decision: ~2/3 of the stream operations of a picture) while the caller's thread goes on copying and uploading the next
+       pictures -- the public API's picture rate is bound by the operations ONE thread can enqueue, and with several devices one thread
+       cannot feed them all (the reference's pipeline has a thread per process for the same reason, Codec/EbEncHandle.c:1901-2012).
+       One group per device at a time: the caller joins the previous one before it posts the next, and before anything else of its
+       own that touches the device's main contexts or the group's slots.  SVT_HIP_NO_FEEDER=1: everything on the caller's thread. */
+    struct shim_state *owner;
+    pthread_t        feeder;
+    int              has_feeder;
+    pthread_mutex_t  mu;
+    pthread_cond_t   cv;
+    int              job_state;      /* 0 idle, 1 posted, 2 running (under mu) */
+    int              stop;
+    int              job_result;     /* EbErrorType of the last group (under mu) */
+    int              outstanding;    /* caller's side: a group has been posted and not joined yet */
+    shim_group       group;
 } shim_dev;
 
 typedef struct shim_state {
@@ -126,6 +181,9 @@ typedef struct shim_state {
     int         intra_period;          /* resolved */
     int         n_dev, cur_dev, split_gop;
     int         register_input;        /* SVT_HIP_REGISTER_INPUT=1 */
+    int         use_feeder;            /* per-device feeder threads (off with a decision callback, in split-GOP mode, SVT_HIP_NO_FEEDER=1) */
+    int         profile;               /* SVT_HIP_SHIM_PROFILE=1: host time per section, printed by eb_vp9_deinit_encoder */
+    double      prof_s[8];
     shim_dev    dev[SHIM_MAX_DEV];
     int64_t     gop;                   /* index of the GOP being sent */
     int64_t     next_number;           /* display number of the next picture sent */
@@ -210,6 +268,7 @@ static EbErrorType verify(const EbSvtVp9EncConfiguration *in) {
     return bad ? EB_ErrorBadParameter : EB_ErrorNone;
 }
 
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 static shim_state *state_of(EbComponentType *h) { return h ? (shim_state *)h->p_component_private : NULL; }
 
 static EbErrorType gpu_fail(shim_state *s) { /* a failed device call ends the stream: every later call reports it (the reference posts
@@ -287,7 +346,12 @@ EbErrorType eb_vp9_svt_enc_set_parameter(EbComponentType *h, EbSvtVp9EncConfigur
     return EB_ErrorNone;
 }
 
+static svt_yuv_planes tight_planes(const struct shim_state *s, uint8_t *base);
+static void feeder_stop(shim_dev *d);
+static void feeder_start(struct shim_state *s, shim_dev *d);
+static EbErrorType join_all(struct shim_state *s);
 static void free_dev(shim_state *s, shim_dev *d) {
+    feeder_stop(d);
     if (!d->ctx) return;
     if (d->slot) {
         for (int i = 0; i < d->n_slots; i++) {
@@ -305,13 +369,19 @@ static void free_dev(shim_state *s, shim_dev *d) {
     for (int k = 0; k < 4; k++) svt_hip_mem_free(d->ctx, v[k]);
     d->d_src_slab = d->d_pred_slab = d->d_q_slab = d->d_dq_slab = NULL;
     while (d->free_recon) { shim_recon *r = d->free_recon; d->free_recon = r->next; svt_hip_host_free(d->ctx, r->host); free(r); }
+    if (d->work_key && d->work_key != d->work) svt_hip_encdec_work_destroy(d->ctx_key, d->work_key);
+    d->work_key = NULL;
     if (d->work) svt_hip_encdec_work_destroy(d->ctx, d->work);
     d->work = NULL;
     if (d->work_deep) svt_hip_encdec_work_destroy(d->ctx_deep, d->work_deep);
     d->work_deep = NULL;
+    if (d->ctx_key && d->ctx_key != d->ctx) svt_hip_ctx_destroy(d->ctx_key);
+    d->ctx_key = NULL;
     if (d->ctx_deep && d->ctx_deep != d->ctx) svt_hip_ctx_destroy(d->ctx_deep);
     d->ctx_deep = NULL;
     if (d->ctx_in && d->ctx_in != d->ctx) svt_hip_ctx_destroy(d->ctx_in);
+    if (d->ctx_up && d->ctx_up != d->ctx && d->ctx_up != d->ctx_in) svt_hip_ctx_destroy(d->ctx_up);
+    d->ctx_up = NULL;
     if (d->ctx_out && d->ctx_out != d->ctx) svt_hip_ctx_destroy(d->ctx_out);
     d->ctx_in = d->ctx_out = NULL;
     svt_hip_ctx_destroy(d->ctx);
@@ -322,8 +392,17 @@ static void free_dev(shim_state *s, shim_dev *d) {
 static int alloc_dev(shim_state *s, shim_dev *d) {
     const int W = s->W, H = s->H;
     const int pad[3] = {68, 32, 16}; /* PA reference paddings, Codec/EbEncHandle.c:1003-1026 */
-    /* the mini-GOP being collected, the one whose work is in flight, and the base picture before it */
-    d->n_slots = 2 * s->minigop + 2;
+    /* the mini-GOP being collected, the ones whose work is in flight, and the base picture before them.  Three groups in flight (four
+       with the one being collected): the uploads of group g + 2 (16 pictures x ~0.25 ms of PCIe at 4K) cross while the main context
+       works on group g + 1 and the deep-layer context on group g -- with one group in flight the input stream waits for the slots of
+       the group the device is still coding and the device then waits for the uploads (SVT_HIP_RING_GROUPS, 2..8; 2 = one in flight) */
+    {
+        const char *rg = getenv("SVT_HIP_RING_GROUPS");
+        int         g = rg ? atoi(rg) : 4;
+        if (g < 2) g = 2;
+        if (g > 8) g = 8;
+        d->n_slots = g * s->minigop + 2;
+    }
     d->slot = (shim_slot *)calloc((size_t)d->n_slots, sizeof(shim_slot));
     if (!d->slot) return 0;
     const size_t n = (size_t)d->n_slots, units = (size_t)s->mi_rows * s->mi_cols;
@@ -331,6 +410,8 @@ static int alloc_dev(shim_state *s, shim_dev *d) {
              svt_hip_mem_alloc(d->ctx, n * s->coeffs * sizeof(int16_t), &d->d_q_slab) == SVT_HIP_OK &&
              svt_hip_encdec_work_create(d->ctx, SHIM_WAVE_MAX, W, H, &d->work) == SVT_HIP_OK &&
              (d->ctx_deep == d->ctx || svt_hip_encdec_work_create(d->ctx_deep, SHIM_WAVE_MAX, W, H, &d->work_deep) == SVT_HIP_OK);
+    if (ok && d->ctx_key != d->ctx) ok = svt_hip_encdec_work_create(d->ctx_key, 1, W, H, &d->work_key) == SVT_HIP_OK;
+    else d->work_key = d->work;
     for (int i = 0; ok && i < d->n_slots; i++) {
         shim_slot *t = &d->slot[i];
         t->number = -1;
@@ -366,8 +447,12 @@ static int alloc_dev(shim_state *s, shim_dev *d) {
                  not): one throw-away upload per buffer of the ring */
         uint8_t *z = (uint8_t *)calloc((size_t)W, (size_t)H);
         if (z) {
-            for (int i = 0; i < 4; i++) (void)svt_hip_mem_upload_2d_async(d->ctx_in, d->slot[0].d_src, (size_t)W, z, (size_t)W, (size_t)W, (size_t)H);
-            (void)svt_hip_ctx_synchronize(d->ctx_in);
+            const svt_yuv_planes sp = tight_planes(s, d->slot[0].d_src);
+            void *const       dd[3] = {sp.y, sp.u, sp.v};
+            const void *const ss[3] = {z, z, z};
+            const size_t      st3[3] = {(size_t)W, (size_t)W / 2, (size_t)W / 2}, rows[3] = {(size_t)H, (size_t)H / 2, (size_t)H / 2};
+            for (int i = 0; i < 4; i++) (void)svt_hip_mem_upload_planes_async(d->ctx_up, 3, dd, st3, ss, st3, st3, rows); /* (a whole picture per buffer) */
+            (void)svt_hip_ctx_synchronize(d->ctx_up);
             free(z);
         }
     }
@@ -412,12 +497,23 @@ EbErrorType eb_vp9_init_encoder(EbComponentType *h) {
         if (!ok) { fprintf(stderr, "SvtVp9Enc (GPU hot path): %s\n", svt_hip_last_error()); d->ctx = NULL; }
         if (ok) {
             const char *one = getenv("SVT_HIP_SINGLE_STREAM");
-            if (one && atoi(one) != 0) d->ctx_in = d->ctx_out = d->ctx;
-            else if (svt_hip_ctx_create(&d->ctx_in, ord[i]) != SVT_HIP_OK) { d->ctx_in = NULL; ok = 0; }
-            else if (svt_hip_ctx_create(&d->ctx_out, ord[i]) != SVT_HIP_OK) { d->ctx_out = NULL; ok = 0; }
-            const char *nd = getenv("SVT_HIP_NO_DEEP_STREAM");
+            const char *nu = getenv("SVT_HIP_NO_UPLOAD_STREAM");
+            if (one && atoi(one) != 0) d->ctx_in = d->ctx_out = d->ctx_up = d->ctx;
+            else {
+                if (svt_hip_ctx_create(&d->ctx_in, ord[i]) != SVT_HIP_OK) { d->ctx_in = NULL; ok = 0; }
+                if (ok && nu && atoi(nu) != 0) d->ctx_up = d->ctx_in;
+                else if (ok && svt_hip_ctx_create(&d->ctx_up, ord[i]) != SVT_HIP_OK) { d->ctx_up = NULL; ok = 0; }
+                if (ok && !s->cfg.recon_file) d->ctx_out = d->ctx; /* (no reconstruction is fetched: no output stream) */
+                else if (ok && svt_hip_ctx_create(&d->ctx_out, ord[i]) != SVT_HIP_OK) { d->ctx_out = NULL; ok = 0; }
+            }
+            /* (opt-in: with the upload, analysis and key streams beside the main one the device's four hardware queues are taken; a fifth
+               stream shares a queue with one of them and the public-API rate drops -- 3 240 -> 2 540 frames/s on the MI355X box) */
+            const char *dp = getenv("SVT_HIP_DEEP_STREAM");
             d->ctx_deep = d->ctx;
-            if (ok && !(one && atoi(one) != 0) && !(nd && atoi(nd) != 0) && svt_hip_ctx_create(&d->ctx_deep, ord[i]) != SVT_HIP_OK) { d->ctx_deep = NULL; ok = 0; }
+            if (ok && !(one && atoi(one) != 0) && dp && atoi(dp) != 0 && svt_hip_ctx_create(&d->ctx_deep, ord[i]) != SVT_HIP_OK) { d->ctx_deep = NULL; ok = 0; }
+            const char *nk = getenv("SVT_HIP_NO_KEY_STREAM");
+            d->ctx_key = d->ctx;
+            if (ok && !(one && atoi(one) != 0) && !(nk && atoi(nk) != 0) && !s->md_cb && svt_hip_ctx_create(&d->ctx_key, ord[i]) != SVT_HIP_OK) { d->ctx_key = NULL; ok = 0; }
         }
         ok = ok && alloc_dev(s, d);
         if (!ok) { /* nothing half-initialised is left behind: the handle is back in its configured state */
@@ -429,6 +525,13 @@ EbErrorType eb_vp9_init_encoder(EbComponentType *h) {
     s->cur_dev = 0;
     { const char *sg = getenv("SVT_HIP_SPLIT_GOP"); s->split_gop = n > 1 && sg && atoi(sg) != 0; }
     { const char *ri = getenv("SVT_HIP_REGISTER_INPUT"); s->register_input = ri && atoi(ri) != 0; }
+    {   /* feeder threads (SVT_HIP_FEEDER=0 or SVT_HIP_NO_FEEDER=1: off) */
+        const char *nf = getenv("SVT_HIP_NO_FEEDER"), *ff = getenv("SVT_HIP_FEEDER"), *one = getenv("SVT_HIP_SINGLE_STREAM");
+        const int   want = ff ? atoi(ff) != 0 : 1;
+        s->use_feeder = want && !(nf && atoi(nf) != 0) && !(one && atoi(one) != 0) && !s->md_cb && !s->split_gop;
+    }
+    { const char *pf = getenv("SVT_HIP_SHIM_PROFILE"); s->profile = pf && atoi(pf) != 0; memset(s->prof_s, 0, sizeof s->prof_s); }
+    for (int i = 0; i < n; i++) feeder_start(s, &s->dev[i]);
     if (s->md_cb) {
         s->h_results = malloc((size_t)s->n_sb * 85 * sizeof(svt_me_pu_result));
         s->h_mc = malloc((size_t)s->mi_rows * s->mi_cols * sizeof(svt_mc_mode_info));
@@ -456,12 +559,6 @@ static shim_slot *find_any(shim_state *s, int64_t number, shim_dev **dev) { /* t
     return NULL;
 }
 
-/* everything enqueued on the main context from here on sees the pictures uploaded and analysed so far */
-static EbErrorType sync_inputs(shim_state *s, shim_dev *d) {
-    if (d->has_in && d->ctx_in != d->ctx) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx, d->ctx_in, d->in_marker));
-    return EB_ErrorNone;
-}
-
 /* split-GOP mode: the next mini-GOP is coded on device `to`; it predicts from the base picture the current device has just
  * finished -- its analysed planes (motion estimation) and its padded reconstruction (inter prediction) travel device to device,
  * ordered behind the producer's work and in front of the consumer's (svt_hip_ref_handoff_device) */
@@ -486,13 +583,10 @@ static EbErrorType handoff_base(shim_state *s, shim_dev *from, shim_dev *to, int
     return EB_ErrorNone;
 }
 
-static int push_packet_on(shim_state *s, int64_t pts, uint32_t flags, uint32_t pic_type, int dev, svt_hip_ctx *ctx, uint64_t marker);
-static int push_packet(shim_state *s, int64_t pts, uint32_t flags, uint32_t pic_type, int dev, uint64_t marker) {
-    return push_packet_on(s, pts, flags, pic_type, dev, NULL, marker);
-}
-static int push_packet_on(shim_state *s, int64_t pts, uint32_t flags, uint32_t pic_type, int dev, svt_hip_ctx *ctx, uint64_t marker) {
+/* a packet joins the queue (caller's thread only); `ready` = its marker is known already */
+static shim_packet *queue_packet(shim_state *s, int64_t pts, uint32_t flags, uint32_t pic_type, int dev, svt_hip_ctx *ctx, uint64_t marker, int ready) {
     shim_packet *p = (shim_packet *)calloc(1, sizeof *p);
-    if (!p) return -1;
+    if (!p) return NULL;
     p->hdr.size = sizeof(EbBufferHeaderType);
     p->hdr.pts = p->hdr.dts = pts;
     p->hdr.flags = flags;
@@ -501,9 +595,13 @@ static int push_packet_on(shim_state *s, int64_t pts, uint32_t flags, uint32_t p
     p->dev = dev;
     p->ctx = ctx;
     p->marker = marker;
+    p->ready = ready;
     if (s->q_tail) s->q_tail->next = p; else s->q_head = p;
     s->q_tail = p;
-    return 0;
+    return p;
+}
+static int push_packet(shim_state *s, int64_t pts, uint32_t flags, uint32_t pic_type, int dev, uint64_t marker) {
+    return queue_packet(s, pts, flags, pic_type, dev, NULL, marker, 1) ? 0 : -1;
 }
 
 /* planes of a slot's tight source / prediction picture and of its padded reference picture */
@@ -525,16 +623,24 @@ static svt_yuv_planes rec_planes(const shim_state *s, uint8_t *base) {
 
 /* the reconstruction of a picture on its way to eb_vp9_svt_get_recon: W x H luma, then Cb, then Cr (recon_output,
  * Codec/EbEncDecProcess.c:4693-4820), copied to pinned host memory behind the picture's last stage */
-static EbErrorType queue_recon(shim_state *s, shim_dev *d, shim_slot *t, svt_hip_ctx *coded_on) {
+/* caller's thread: a record with a pinned buffer joins the reconstruction queue, in coding order; fill_recon completes it */
+static shim_recon *reserve_recon(shim_state *s, shim_dev *d, int64_t number) {
     shim_recon *r = d->free_recon;
     if (r) d->free_recon = r->next;
     else {
         r = (shim_recon *)calloc(1, sizeof *r);
-        if (!r) return EB_ErrorInsufficientResources;
+        if (!r) return NULL;
         void *hp = NULL;
-        if (svt_hip_host_alloc(d->ctx, s->pic_bytes, &hp) != SVT_HIP_OK) { free(r); return gpu_fail(s); }
+        if (svt_hip_host_alloc(d->ctx_out, s->pic_bytes, &hp) != SVT_HIP_OK) { free(r); (void)gpu_fail(s); return NULL; }
         r->host = (uint8_t *)hp;
     }
+    r->dev = (int)(d - s->dev); r->pts = number; r->flags = 0; r->next = NULL; r->ready = 0; r->marker = 0;
+    if (s->r_tail) s->r_tail->next = r; else s->r_head = r;
+    s->r_tail = r;
+    return r;
+}
+/* enqueuing thread: the copies of picture t into the reserved record */
+static EbErrorType fill_recon(shim_state *s, shim_dev *d, shim_slot *t, svt_hip_ctx *coded_on, shim_recon *r) {
     const svt_yuv_planes p = rec_planes(s, t->d_rec);
     const size_t W = (size_t)s->W, H = (size_t)s->H;
     /* the copy runs on the output stream, behind the main stream's work enqueued so far (the picture's deblocking / padding) */
@@ -543,23 +649,12 @@ static EbErrorType queue_recon(shim_state *s, shim_dev *d, shim_slot *t, svt_hip
         svt_hip_mem_download_2d_async(d->ctx_out, r->host, W, p.y, (size_t)p.y_stride, W, H) != SVT_HIP_OK ||
         svt_hip_mem_download_2d_async(d->ctx_out, r->host + W * H, W / 2, p.u, (size_t)p.uv_stride, W / 2, H / 2) != SVT_HIP_OK ||
         svt_hip_mem_download_2d_async(d->ctx_out, r->host + W * H + W * H / 4, W / 2, p.v, (size_t)p.uv_stride, W / 2, H / 2) != SVT_HIP_OK ||
-        svt_hip_ctx_marker_record(d->ctx_out, &r->marker) != SVT_HIP_OK) {
-        r->next = d->free_recon; d->free_recon = r;
-        return gpu_fail(s);
-    }
+        svt_hip_ctx_marker_record(d->ctx_out, &r->marker) != SVT_HIP_OK)
+        return gpu_fail(s); /* (the record stays in the queue, never ready: the stream has failed) */
     t->out_marker = r->marker; t->has_out = 1;
-    r->dev = (int)(d - s->dev); r->pts = t->number; r->flags = 0; r->next = NULL;
-    if (s->r_tail) s->r_tail->next = r; else s->r_head = r;
-    s->r_tail = r;
+    __atomic_store_n(&r->ready, 1, __ATOMIC_RELEASE);
     return EB_ErrorNone;
 }
-
-/* one picture of a group whose motion estimation is about to be launched */
-typedef struct shim_job {
-    int64_t       number, ref0, ref1;
-    int           layer, levels, n_lists, used_as_ref, wave;
-    svt_me_params p;
-} shim_job;
 
 /* the parameters motion_estimate_sb reads for this picture, as the reference derives them */
 static EbErrorType job_params(shim_state *s, shim_job *j) {
@@ -606,7 +701,7 @@ static int job_use_subpel(const shim_job *j) { return j->p.fractional_search_mod
 
 /* The stages behind mode decision for one batch of mutually independent pictures (a temporal layer of a part of the group, or one
  * picture of a P chain): decision -> svt_hip_encdec_batch_device -> reconstruction output. */
-static EbErrorType encode_wave(shim_state *s, shim_dev *d, const shim_job *const *wj, int n, int deep) {
+static EbErrorType encode_wave(shim_state *s, shim_dev *d, const shim_job *const *wj, shim_recon *const *wrec, int n, int deep) {
     svt_hip_ctx     *cx = deep ? d->ctx_deep : d->ctx;       /* the context (stream) this wave is enqueued on, and its driver workspace */
     svt_encdec_work *wk = deep ? d->work_deep : d->work;
     svt_encdec_picture pics[SHIM_WAVE_MAX];
@@ -679,7 +774,11 @@ static EbErrorType encode_wave(shim_state *s, shim_dev *d, const shim_job *const
     GPU_TRY(svt_hip_encdec_batch_device(cx, wk, n, pics, s->W, s->H, s->mi_cols, q_l, &fl, &s->thr, SHIM_REF_PAD, SHIM_REF_PAD));
     for (int i = 0; i < n; i++) {
         ts[i]->coded = 1;
-        if (s->cfg.recon_file) { const EbErrorType e = queue_recon(s, d, ts[i], cx); if (e != EB_ErrorNone) return e; }
+        if (s->cfg.recon_file) {
+            if (!wrec[i]) return stream_fail(s, "reconstruction record");
+            const EbErrorType e = fill_recon(s, d, ts[i], cx, wrec[i]);
+            if (e != EB_ErrorNone) return e;
+        }
     }
     return EB_ErrorNone;
 }
@@ -689,7 +788,8 @@ static EbErrorType encode_wave(shim_state *s, shim_dev *d, const shim_job *const
  * decides its blocks and modes when it wants to (info->is_intra = 1, no ME results); otherwise the stand-in (16x16, DC). */
 static EbErrorType encode_intra(shim_state *s, shim_dev *d, shim_slot *t) {
     svt_encdec_flags fl;
-    { const EbErrorType e = sync_inputs(s, d); if (e != EB_ErrorNone) return e; }
+    svt_hip_ctx *cx = d->ctx_key; /* (the main context without a key stream) */
+    if (d->has_in && d->ctx_in != cx) GPU_TRY(svt_hip_ctx_wait_marker(cx, d->ctx_in, d->in_marker)); /* the picture has been uploaded and analysed */
     {
         svt_encdec_flags_config fc;
         fc.enc_mode = s->cfg.enc_mode; fc.tune = s->cfg.tune; fc.temporal_layer_index = 0; fc.is_used_as_reference = 1;
@@ -705,22 +805,26 @@ static EbErrorType encode_intra(shim_state *s, shim_dev *d, shim_slot *t) {
         memset(s->h_lf, 0, (size_t)s->mi_rows * s->mi_cols * sizeof(svt_lf_mode_info));
         if (s->md_cb(s->md_user, &t->info, NULL, s->h_mc, s->h_lf, s->mi_cols) == 0) {
             if (grid_malformed(s, (const svt_lf_mode_info *)s->h_lf, 1)) return stream_fail(s, "mode-decision callback: malformed mode-info grid of an intra picture");
-            GPU_TRY(svt_hip_mem_upload_2d(d->ctx, t->d_lf_mi, (size_t)s->mi_cols * sizeof(svt_lf_mode_info), s->h_lf, (size_t)s->mi_cols * sizeof(svt_lf_mode_info),
+            GPU_TRY(svt_hip_mem_upload_2d(cx, t->d_lf_mi, (size_t)s->mi_cols * sizeof(svt_lf_mode_info), s->h_lf, (size_t)s->mi_cols * sizeof(svt_lf_mode_info),
                                           (size_t)s->mi_cols * sizeof(svt_lf_mode_info), (size_t)s->mi_rows));
             decided = 1;
             t->info.decision_source = 1;
         }
     }
-    if (!decided) GPU_TRY(svt_hip_md_intra_default_device(d->ctx, s->W, s->H, level, (svt_lf_mode_info *)t->d_lf_mi, s->mi_cols));
-    GPU_TRY(svt_hip_mem_set(d->ctx, t->d_mc_mi, 0, (size_t)s->mi_rows * s->mi_cols * sizeof(svt_mc_mode_info))); /* no motion in an intra picture */
+    if (!decided) GPU_TRY(svt_hip_md_intra_default_device(cx, s->W, s->H, level, (svt_lf_mode_info *)t->d_lf_mi, s->mi_cols));
+    GPU_TRY(svt_hip_mem_set(cx, t->d_mc_mi, 0, (size_t)s->mi_rows * s->mi_cols * sizeof(svt_mc_mode_info))); /* no motion in an intra picture */
     svt_encdec_picture p;
     memset(&p, 0, sizeof p);
     p.d_lf_mi = (svt_lf_mode_info *)t->d_lf_mi;
     p.src = tight_planes(s, t->d_src); p.pred = tight_planes(s, t->d_pred); p.recon = rec_planes(s, t->d_rec);
     p.d_qcoeff = t->d_qcoeff; p.d_dqcoeff = t->d_dqcoeff; p.d_eob_map = (uint16_t *)t->d_eob_map; p.d_lfm = (svt_lf_mask *)t->d_lfm; p.d_nz = (uint8_t *)t->d_nz;
-    GPU_TRY(svt_hip_encdec_intra_device(d->ctx, d->work, &p, s->W, s->H, s->mi_cols, s->q_index, &fl, &s->thr, SHIM_REF_PAD, SHIM_REF_PAD));
+    GPU_TRY(svt_hip_encdec_intra_device(cx, d->work_key, &p, s->W, s->H, s->mi_cols, s->q_index, &fl, &s->thr, SHIM_REF_PAD, SHIM_REF_PAD));
     t->coded = 1;
-    if (s->cfg.recon_file) return queue_recon(s, d, t, d->ctx);
+    if (s->cfg.recon_file) {
+        shim_recon *r = reserve_recon(s, d, t->number);
+        if (!r) return s->failed ? EB_ErrorMax : EB_ErrorInsufficientResources;
+        return fill_recon(s, d, t, cx, r);
+    }
     return EB_ErrorNone;
 }
 
@@ -729,13 +833,13 @@ static EbErrorType encode_intra(shim_state *s, shim_dev *d, shim_slot *t) {
  * a regular mini-GOP), followed by the per-SB statistics of every picture and by the stages behind mode decision, one batch per
  * temporal layer.  cut_by_intra: the group was released by an intra refresh -- the reference's pre-assignment buffer then holds
  * the intra picture as its last element (Codec/EbPictureDecisionProcess.c:1641-1646) and the split is made over pending + 1.
- * Nothing here waits for the device (unless the host decides the modes). */
-static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_stream) {
-    if (!s->pending) return EB_ErrorNone;
+ * Nothing here waits for the device (unless the host decides the modes).
+ * Two halves: plan_group (caller's thread: the structure of the group, its packets queued in output order) and run_group (the
+ * enqueuing: on the device's feeder thread when there is one). */
+static EbErrorType plan_group(shim_state *s, int cut_by_intra, int end_of_stream, shim_group *G) {
     shim_dev *d = &s->dev[s->cur_dev];
-    { const EbErrorType e = sync_inputs(s, d); if (e != EB_ErrorNone) return e; }
-    shim_job jobs[SHIM_MAX_MINIGOP];
-    int      n = 0, n_waves = 0;
+    shim_job *jobs = G->jobs;
+    int       n = 0, n_waves = 0;
     const int64_t first = s->pending_first;
     svt_minigop_part parts[4];
     const int np = svt_hip_minigop_split(s->pending + (cut_by_intra ? 1 : 0), s->levels, cut_by_intra, parts);
@@ -767,6 +871,41 @@ static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_str
         const EbErrorType e = job_params(s, &jobs[i]);
         if (e != EB_ErrorNone) return e;
     }
+    G->n = n; G->n_waves = n_waves; G->end_of_stream = end_of_stream; G->dev = s->cur_dev;
+    G->has_in = d->has_in; G->in_marker = d->in_marker;
+    G->has_key = d->has_key && d->ctx_key != d->ctx; G->key_marker = d->key_marker;
+    d->has_key = 0; /* (the GOP's later groups follow this one on the main context) */
+    G->first = first; G->last = first + s->pending - 1;
+    G->oldest = first;
+    for (int i = 0; i < n; i++) {
+        if (jobs[i].ref0 >= 0 && jobs[i].ref0 < G->oldest) G->oldest = jobs[i].ref0;
+        if (jobs[i].n_lists == 2 && jobs[i].ref1 >= 0 && jobs[i].ref1 < G->oldest) G->oldest = jobs[i].ref1;
+    }
+    /* the group's packets, in decode order; their markers follow when the work has been enqueued */
+    for (int i = 0; i < n; i++) {
+        shim_slot *t = find_slot(d, jobs[i].number);
+        if (!t) return EB_ErrorBadParameter;
+        G->pkt[i] = queue_packet(s, t->pts, 0, jobs[i].n_lists == 2 ? 0 /* EB_B_PICTURE */ : 1 /* EB_P_PICTURE */, s->cur_dev, NULL, 0, 0);
+        if (!G->pkt[i]) return EB_ErrorInsufficientResources;
+        G->rec[i] = NULL;
+    }
+    /* ... and its reconstructions, in coding order (wave by wave, as they are produced) */
+    if (s->cfg.recon_file)
+        for (int w = 0; w < n_waves; w++)
+            for (int i = 0; i < n; i++)
+                if (jobs[i].wave == w) {
+                    G->rec[i] = reserve_recon(s, d, jobs[i].number);
+                    if (!G->rec[i]) return s->failed ? EB_ErrorMax : EB_ErrorInsufficientResources;
+                }
+    return EB_ErrorNone;
+}
+
+static EbErrorType run_group(shim_state *s, shim_group *G) {
+    shim_dev       *d = &s->dev[G->dev];
+    const shim_job *jobs = G->jobs;
+    const int       n = G->n, n_waves = G->n_waves, end_of_stream = G->end_of_stream;
+    /* everything enqueued on the main context from here on sees the group's pictures uploaded and analysed */
+    if (G->has_in && d->ctx_in != d->ctx) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx, d->ctx_in, G->in_marker));
     /* launches: classes of pictures whose parameter sets may share one */
     int done[SHIM_MAX_MINIGOP] = {0};
     for (int i = 0; i < n; i++) {
@@ -779,14 +918,14 @@ static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_str
         for (int k = i; k < n; k++) {
             if (done[k] || !same_launch(&jobs[i].p, &jobs[k].p)) continue;
             shim_slot *t = find_slot(d, jobs[k].number), *a = find_slot(d, jobs[k].ref0), *b = find_slot(d, jobs[k].n_lists == 2 ? jobs[k].ref1 : jobs[k].ref0);
-            if (!t || !a || !b) return EB_ErrorBadParameter;
+            if (!t || !a || !b) return stream_fail(s, "a picture of the group or one of its references is not resident");
             cur[m] = t->pa; r0[m] = a->pa; r1[m] = b->pa;
             pp[m] = jobs[k].p; res[m] = (svt_me_pu_result *)t->d_results; rc[m] = (uint32_t *)t->d_rcme;
             done[k] = 1;
             m++;
         }
         GPU_TRY(svt_hip_me_batch_layers_device(d->ctx, m, cur, r0, r1, pp, res, s->cfg.rate_control_mode ? rc : NULL));
-        s->me_launches++;
+        __atomic_add_fetch(&s->me_launches, 1, __ATOMIC_RELAXED);
     }
     /* the tail of the ME kernel process per picture (Codec/EbMotionEstimationProcess.c:1047-1237): stationary-edge flags and the
        rate-control histograms from the ME results and the picture-analysis variances, all device resident */
@@ -810,6 +949,8 @@ static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_str
     uint64_t me_marker = 0;
     GPU_TRY(svt_hip_ctx_marker_record(d->ctx, &me_marker));
     for (int i = 0; i < n; i++) { shim_slot *t = find_slot(d, jobs[i].number); t->processed = 1; t->has_marker = 1; t->marker = me_marker; t->marker_ctx = d->ctx; }
+    /* the waves predict from the GOP's intra picture (directly or through pictures that did): behind its encode pass on the key context */
+    if (G->has_key) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx, d->ctx_key, G->key_marker));
     /* the stages behind mode decision, wave by wave (a wave = the pictures of one temporal layer of one part: their references
        belong to earlier waves) */
     uint64_t     wave_marker[SHIM_MAX_MINIGOP + 8];
@@ -831,8 +972,9 @@ static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_str
     }
     for (int w = 0; w < n_waves; w++) {
         const shim_job *wj[SHIM_MAX_MINIGOP];
+        shim_recon     *wrec[SHIM_MAX_MINIGOP];
         int             m = 0;
-        for (int i = 0; i < n; i++) if (jobs[i].wave == w) wj[m++] = &jobs[i];
+        for (int i = 0; i < n; i++) if (jobs[i].wave == w) { wj[m] = &jobs[i]; wrec[m] = G->rec[i]; m++; }
         const int deep = m && d->ctx_deep != d->ctx && !s->md_cb && wj[0]->layer >= 2 && wj[0]->layer >= part_deepest[w] - 1;
         if (deep) {
             uint64_t behind = 0;
@@ -841,26 +983,19 @@ static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_str
             any_deep = 1;
         }
         for (int b = 0; b < m; b += SHIM_WAVE_MAX) {
-            const EbErrorType e = encode_wave(s, d, wj + b, m - b < SHIM_WAVE_MAX ? m - b : SHIM_WAVE_MAX, deep);
+            const EbErrorType e = encode_wave(s, d, wj + b, wrec + b, m - b < SHIM_WAVE_MAX ? m - b : SHIM_WAVE_MAX, deep);
             if (e != EB_ErrorNone) return e;
         }
         wave_marker[w] = 0;
         wave_ctx[w] = deep ? d->ctx_deep : d->ctx;
         GPU_TRY(svt_hip_ctx_marker_record(wave_ctx[w], &wave_marker[w]));
     }
-    for (int i = 0; i < n; i++) { /* packets in decode order */
+    for (int i = 0; i < n; i++) { /* the packets (queued in decode order by plan_group) learn what they wait for */
         shim_slot *t = find_slot(d, jobs[i].number);
         t->marker = wave_marker[jobs[i].wave];
         t->marker_ctx = wave_ctx[jobs[i].wave];
-        if (push_packet_on(s, t->pts, 0, jobs[i].n_lists == 2 ? 0 /* EB_B_PICTURE */ : 1 /* EB_P_PICTURE */, s->cur_dev, t->marker_ctx, t->marker)) return EB_ErrorInsufficientResources;
-    }
-    s->last_base = first + s->pending - 1;
-    s->pending = 0;
-    if (s->split_gop && !cut_by_intra && !end_of_stream) { /* the next mini-GOP of this GOP goes to the next device */
-        const int next = (s->cur_dev + 1) % s->n_dev;
-        const EbErrorType e = handoff_base(s, d, &s->dev[next], s->last_base);
-        if (e != EB_ErrorNone) return e;
-        s->cur_dev = next;
+        G->pkt[i]->ctx = t->marker_ctx; G->pkt[i]->marker = t->marker;
+        __atomic_store_n(&G->pkt[i]->ready, 1, __ATOMIC_RELEASE);
     }
     /* from this point of the main stream on nothing enqueued so far reads the group's pictures or the pictures it predicted from: the
        input side may overwrite their slots behind it */
@@ -877,6 +1012,92 @@ static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_str
     return EB_ErrorNone;
 }
 
+/* ---- the device's feeder thread ---- */
+static void *feeder_main(void *arg) {
+    shim_dev *d = (shim_dev *)arg;
+    pthread_mutex_lock(&d->mu);
+    for (;;) {
+        while (d->job_state != 1 && !d->stop) pthread_cond_wait(&d->cv, &d->mu);
+        if (d->stop) break;
+        d->job_state = 2;
+        pthread_mutex_unlock(&d->mu);
+        const EbErrorType e = run_group(d->owner, &d->group);
+        pthread_mutex_lock(&d->mu);
+        d->job_result = (int)e;
+        d->job_state = 0;
+        pthread_cond_broadcast(&d->cv);
+    }
+    pthread_mutex_unlock(&d->mu);
+    return NULL;
+}
+/* the caller waits for the group it posted to this device; a failed group ends the stream here */
+static EbErrorType dev_join(shim_state *s, shim_dev *d) {
+    if (!d->outstanding) return EB_ErrorNone;
+    pthread_mutex_lock(&d->mu);
+    while (d->job_state != 0) pthread_cond_wait(&d->cv, &d->mu);
+    const EbErrorType e = (EbErrorType)d->job_result;
+    d->job_result = (int)EB_ErrorNone;
+    pthread_mutex_unlock(&d->mu);
+    d->outstanding = 0;
+    if (e != EB_ErrorNone) { s->failed = 1; return e; }
+    return EB_ErrorNone;
+}
+static EbErrorType join_all(shim_state *s) {
+    EbErrorType r = EB_ErrorNone;
+    for (int k = 0; k < s->n_dev; k++) { const EbErrorType e = dev_join(s, &s->dev[k]); if (e != EB_ErrorNone) r = e; }
+    return r;
+}
+static void feeder_start(shim_state *s, shim_dev *d) {
+    d->owner = s;
+    pthread_mutex_init(&d->mu, NULL);
+    pthread_cond_init(&d->cv, NULL);
+    d->job_state = 0; d->stop = 0; d->outstanding = 0; d->job_result = (int)EB_ErrorNone;
+    d->has_feeder = s->use_feeder && pthread_create(&d->feeder, NULL, feeder_main, d) == 0;
+}
+static void feeder_stop(shim_dev *d) {
+    if (!d->owner) return;
+    if (d->has_feeder) {
+        pthread_mutex_lock(&d->mu);
+        while (d->job_state != 0) pthread_cond_wait(&d->cv, &d->mu);
+        d->stop = 1;
+        pthread_cond_broadcast(&d->cv);
+        pthread_mutex_unlock(&d->mu);
+        pthread_join(d->feeder, NULL);
+        d->has_feeder = 0;
+    }
+    pthread_mutex_destroy(&d->mu);
+    pthread_cond_destroy(&d->cv);
+    d->owner = NULL;
+}
+
+static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_stream) {
+    if (!s->pending) return EB_ErrorNone;
+    shim_dev *d = &s->dev[s->cur_dev];
+    { const EbErrorType e = dev_join(s, d); if (e != EB_ErrorNone) return e; } /* one group per device at a time */
+    shim_group *G = &d->group;
+    { const EbErrorType e = plan_group(s, cut_by_intra, end_of_stream, G); if (e != EB_ErrorNone) { s->failed = 1; return e; } }
+    s->last_base = G->last;
+    s->pending = 0;
+    /* a regular group goes to the device's feeder; what the caller follows up at once (the intra picture behind a cut group, the
+       end of the stream, a hand-over to another device) is enqueued here */
+    if (d->has_feeder && !cut_by_intra && !end_of_stream && !s->split_gop) {
+        pthread_mutex_lock(&d->mu);
+        d->job_state = 1;
+        pthread_cond_broadcast(&d->cv);
+        pthread_mutex_unlock(&d->mu);
+        d->outstanding = 1;
+        return EB_ErrorNone;
+    }
+    { const EbErrorType e = run_group(s, G); if (e != EB_ErrorNone) { s->failed = 1; return e; } }
+    if (s->split_gop && !cut_by_intra && !end_of_stream) { /* the next mini-GOP of this GOP goes to the next device */
+        const int next = (s->cur_dev + 1) % s->n_dev;
+        const EbErrorType e = handoff_base(s, d, &s->dev[next], s->last_base);
+        if (e != EB_ErrorNone) return e;
+        s->cur_dev = next;
+    }
+    return EB_ErrorNone;
+}
+
 EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *b) {
     shim_state *s = state_of(h);
     if (!s || !s->initialised) return EB_ErrorBadParameter;
@@ -884,6 +1105,9 @@ EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *
     if (s->eos) return EB_ErrorBadParameter;
     const int end = !b || !b->p_buffer || (b->flags & EB_BUFFERFLAG_EOS);
     EbErrorType e = EB_ErrorNone;
+    const double t_enter = s->profile ? now_s() : 0.0;
+    double       tp = t_enter;
+#define PROF(k) do { if (s->profile) { const double n_ = now_s(); s->prof_s[k] += n_ - tp; tp = n_; } } while (0)
     if (b && b->p_buffer) {
         const EbSvtEncInput *in = (const EbSvtEncInput *)b->p_buffer;
         if (!in->luma || in->y_stride < s->cfg.source_width) return EB_ErrorBadParameter;
@@ -896,36 +1120,56 @@ EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *
             if (n) { s->gop++; if (!s->split_gop) s->cur_dev = svt_hip_gop_owner(s->gop, s->n_dev); }
             s->last_base = -1;
         }
+        PROF(3);
         shim_dev  *d = &s->dev[s->cur_dev];
         shim_slot *t = &d->slot[d->accepted % d->n_slots];
+        /* the group the device's feeder is enqueuing may still write this slot's markers (never with the ring's regular distance of two
+           mini-GOPs + 2; short GOPs on several devices can come closer): wait for it */
+        if (d->outstanding && t->number >= d->group.oldest) { if ((e = dev_join(s, d)) != EB_ErrorNone) return e; }
         /* the slot's previous picture (2 mini-GOPs + 2 ago on this device) must have left the GPU before its buffers are overwritten:
            the input stream waits for the main stream's marker behind its last reader (a device-side wait; the host blocks only in
            the staging ring of the upload below, as the reference blocks when its picture pool is exhausted) */
-        if (t->has_release) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_in, d->ctx, t->release));
-        else if (t->has_marker) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_in, t->marker_ctx ? t->marker_ctx : d->ctx, t->marker));
-        if (t->has_release2) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_in, d->ctx_deep, t->release2));
-        if (t->has_out && d->ctx_out != d->ctx_in) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_in, d->ctx_out, t->out_marker));
+        if (t->has_release) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_up, d->ctx, t->release));
+        else if (t->has_marker) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_up, t->marker_ctx ? t->marker_ctx : d->ctx, t->marker));
+        if (t->has_release2) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_up, d->ctx_deep, t->release2));
+        if (t->has_out && d->ctx_out != d->ctx_up) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_up, d->ctx_out, t->out_marker));
         /* the copy the reference makes in copy_frame_buffer (:2743-2796), into pinned staging: the caller's planes are free again
            on return; the transfer and the analysis below run asynchronously */
         const svt_yuv_planes sp = tight_planes(s, t->d_src);
         /* SVT_HIP_REGISTER_INPUT=1: the application promises that its input buffers stay allocated while the encoder lives (a fixed pool,
            as the reference's application has): they are page-locked on first sight and read by the DMA engines directly, without the
            staging copy (svt_hip_mem_upload_2d_direct) */
+        PROF(0);
+        if (!s->register_input && in->cb && in->cr) { /* the three planes through one staging slot, one copy to the device (Y | Cb | Cr are back to back there) */
+            void *const       dd[3] = {sp.y, sp.u, sp.v};
+            const void *const ss[3] = {in->luma, in->cb, in->cr};
+            const size_t      dst_st[3] = {(size_t)W, (size_t)W / 2, (size_t)W / 2}, src_st[3] = {in->y_stride, in->cb_stride, in->cr_stride};
+            const size_t      wb[3] = {(size_t)W, (size_t)W / 2, (size_t)W / 2}, rows[3] = {(size_t)H, (size_t)H / 2, (size_t)H / 2};
+            GPU_TRY(svt_hip_mem_upload_planes_async(d->ctx_up, 3, dd, dst_st, ss, src_st, wb, rows));
+        } else {
         int32_t (*up)(svt_hip_ctx *, void *, size_t, const void *, size_t, size_t, size_t) = s->register_input ? svt_hip_mem_upload_2d_direct : svt_hip_mem_upload_2d_async;
-        GPU_TRY(up(d->ctx_in, sp.y, (size_t)W, in->luma, in->y_stride, (size_t)W, (size_t)H));
-        if (in->cb) GPU_TRY(up(d->ctx_in, sp.u, (size_t)W / 2, in->cb, in->cb_stride, (size_t)W / 2, (size_t)H / 2));
-        else GPU_TRY(svt_hip_mem_set(d->ctx_in, sp.u, 128, (size_t)(W / 2) * (H / 2)));
-        if (in->cr) GPU_TRY(up(d->ctx_in, sp.v, (size_t)W / 2, in->cr, in->cr_stride, (size_t)W / 2, (size_t)H / 2));
-        else GPU_TRY(svt_hip_mem_set(d->ctx_in, sp.v, 128, (size_t)(W / 2) * (H / 2)));
+        GPU_TRY(up(d->ctx_up, sp.y, (size_t)W, in->luma, in->y_stride, (size_t)W, (size_t)H));
+        if (in->cb) GPU_TRY(up(d->ctx_up, sp.u, (size_t)W / 2, in->cb, in->cb_stride, (size_t)W / 2, (size_t)H / 2));
+        else GPU_TRY(svt_hip_mem_set(d->ctx_up, sp.u, 128, (size_t)(W / 2) * (H / 2)));
+        if (in->cr) GPU_TRY(up(d->ctx_up, sp.v, (size_t)W / 2, in->cr, in->cr_stride, (size_t)W / 2, (size_t)H / 2));
+        else GPU_TRY(svt_hip_mem_set(d->ctx_up, sp.v, 128, (size_t)(W / 2) * (H / 2)));
+        }
+        PROF(1);
         const uint8_t *lum = sp.y;
         const int32_t  stride = W;
+        if (d->ctx_up != d->ctx_in) { /* the analysis follows the picture's copy (and, through it, the slot's release) */
+            uint64_t up_marker = 0;
+            GPU_TRY(svt_hip_ctx_marker_record(d->ctx_up, &up_marker));
+            GPU_TRY(svt_hip_ctx_wait_marker(d->ctx_in, d->ctx_up, up_marker));
+        }
         GPU_TRY(svt_hip_pa_prepare_batch_device(d->ctx_in, 1, &lum, &stride, &t->pa, 1));
         GPU_TRY(svt_hip_pa_mean_variance_device(d->ctx_in, &t->pa.full, (uint8_t *)t->d_mean, (uint16_t *)t->d_var));
         GPU_TRY(svt_hip_ctx_marker_record(d->ctx_in, &d->in_marker));
         d->has_in = 1;
         /* direct uploads: the caller's planes have been read when this returns (the analysis kernels above are enqueued behind the copies
            and are not waited for) */
-        if (s->register_input) GPU_TRY(svt_hip_mem_upload_wait(d->ctx_in));
+        if (s->register_input) GPU_TRY(svt_hip_mem_upload_wait(d->ctx_up));
+        PROF(2);
         /* the picture is accepted from here on */
         s->next_number = n + 1;
         d->accepted++;
@@ -935,15 +1179,21 @@ EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *
         if (intra) {
             t->info.is_intra = 1; t->info.num_ref_lists = 0; t->info.temporal_layer_index = 0; t->info.hierarchical_levels = s->levels;
             t->info.ref_picture_number[0] = t->info.ref_picture_number[1] = -1;
+            /* the intra pass is enqueued here: on the key context (nothing the device's feeder touches -- unless reconstructions are
+               fetched: the output context is shared), or on the device's main context */
+            if (d->ctx_key == d->ctx || s->cfg.recon_file) { if ((e = dev_join(s, d)) != EB_ErrorNone) return e; }
             if ((e = encode_intra(s, d, t)) != EB_ErrorNone) return e;
-            GPU_TRY(svt_hip_ctx_marker_record(d->ctx, &t->marker));
-            t->has_marker = 1; t->processed = 1;
-            t->release = t->marker; t->has_release = 1;
-            if (push_packet(s, t->pts, 0, 2 /* EB_I_PICTURE */, s->cur_dev, t->marker)) return EB_ErrorInsufficientResources;
+            GPU_TRY(svt_hip_ctx_marker_record(d->ctx_key, &t->marker));
+            t->has_marker = 1; t->processed = 1; t->marker_ctx = d->ctx_key;
+            if (d->ctx_key == d->ctx) { t->release = t->marker; t->has_release = 1; }
+            d->key_marker = t->marker; d->has_key = 1;
+            if (!queue_packet(s, t->pts, 0, 2 /* EB_I_PICTURE */, s->cur_dev, d->ctx_key, t->marker, 1)) return EB_ErrorInsufficientResources;
             s->last_base = n;
+            PROF(4);
         } else {
             if (!s->pending) s->pending_first = n;
             if (++s->pending == s->minigop) e = flush_pending(s, 0, 0);
+            PROF(3);
         }
     }
     if (end && e == EB_ErrorNone) {
@@ -959,6 +1209,8 @@ EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *
             if (s->r_tail) s->r_tail->flags |= EB_BUFFERFLAG_EOS; /* ... and the last reconstruction the recon stream (recon_output :4711-4713) */
         }
     }
+    if (s->profile) s->prof_s[5] += now_s() - t_enter;
+#undef PROF
     return e;
 }
 
@@ -974,6 +1226,12 @@ EbErrorType eb_vp9_svt_get_packet(EbComponentType *h, EbBufferHeaderType **p_buf
     /* the newest packet stays in the queue until the library knows whether it is the last one (it then carries EB_BUFFERFLAG_EOS): the
        end-of-stream buffer arrives in a send_picture call of its own (App/EbAppProcessCmd.c:483-494) */
     if (p == s->q_tail && !s->eos) return EB_NoErrorEmptyQueue;
+    if (!__atomic_load_n(&p->ready, __ATOMIC_ACQUIRE)) { /* its group is still with the device's feeder */
+        if (!pic_send_done) return EB_NoErrorEmptyQueue;
+        const EbErrorType je = dev_join(s, &s->dev[p->dev]);
+        if (je != EB_ErrorNone) return je;
+        if (!__atomic_load_n(&p->ready, __ATOMIC_ACQUIRE)) return EB_ErrorMax;
+    }
     svt_hip_ctx *ctx = p->ctx ? p->ctx : s->dev[p->dev].ctx;
     if (ctx) {
         if (pic_send_done) { GPU_TRY(svt_hip_ctx_marker_wait(ctx, p->marker)); }
@@ -1009,6 +1267,7 @@ EbErrorType eb_vp9_svt_get_recon(EbComponentType *h, EbBufferHeaderType *p_buffe
     if (!r || !p_buffer) return EB_NoErrorEmptyQueue;
     if (r == s->r_tail && !s->eos) return EB_NoErrorEmptyQueue; /* as for packets: the last reconstruction carries EB_BUFFERFLAG_EOS */
     shim_dev *d = &s->dev[r->dev];
+    if (!__atomic_load_n(&r->ready, __ATOMIC_ACQUIRE)) return EB_NoErrorEmptyQueue; /* its group is still with the device's feeder */
     const int32_t q = svt_hip_ctx_marker_query(d->ctx_out, r->marker);
     if (q < 0) return gpu_fail(s);
     if (q == 0) return EB_NoErrorEmptyQueue;
@@ -1031,6 +1290,7 @@ EbErrorType eb_vp9_svt_get_recon(EbComponentType *h, EbBufferHeaderType *p_buffe
 EbErrorType eb_vp9_deinit_encoder(EbComponentType *h) {
     shim_state *s = state_of(h);
     if (!s) return EB_ErrorNone; /* the reference accepts a NULL component here (:1846) */
+    (void)join_all(s);
     while (s->q_head) { shim_packet *p = s->q_head; s->q_head = p->next; free(p); }
     s->q_tail = NULL;
     while (s->r_head) { /* undelivered reconstructions go back to their device's pool, which is freed with the device */
@@ -1042,6 +1302,10 @@ EbErrorType eb_vp9_deinit_encoder(EbComponentType *h) {
     s->r_tail = NULL;
     for (int k = 0; k < s->n_dev; k++) free_dev(s, &s->dev[k]);
     s->n_dev = 0;
+    if (s->profile && s->next_number)
+        fprintf(stderr, "SvtVp9Enc host time per picture (us): slot wait %.1f  upload %.1f  analysis %.1f  group hand-over %.1f  intra %.1f  | send_picture %.1f  (%lld pictures)\n",
+                1e6 * s->prof_s[0] / (double)s->next_number, 1e6 * s->prof_s[1] / (double)s->next_number, 1e6 * s->prof_s[2] / (double)s->next_number,
+                1e6 * s->prof_s[3] / (double)s->next_number, 1e6 * s->prof_s[4] / (double)s->next_number, 1e6 * s->prof_s[5] / (double)s->next_number, (long long)s->next_number);
     free(s->h_results); free(s->h_mc); free(s->h_lf);
     s->h_results = s->h_mc = s->h_lf = NULL;
     s->initialised = 0;
@@ -1083,6 +1347,7 @@ EbErrorType svt_vp9_shim_get_me_results(EbComponentType *h, uint64_t picture_num
                                         uint64_t out_bytes) {
     shim_state *s = state_of(h);
     if (!s || !s->initialised) return EB_ErrorBadParameter;
+    { const EbErrorType je = join_all(s); if (je != EB_ErrorNone) return je; }
     shim_dev  *d = NULL;
     shim_slot *t = find_any(s, (int64_t)picture_number, &d);
     /* a picture that waits in an incomplete mini-GOP has no results yet; neither has one the ring has already given away */
@@ -1101,6 +1366,7 @@ EbErrorType svt_vp9_shim_get_sb_stats(EbComponentType *h, uint64_t picture_numbe
                                       uint8_t *mean, uint16_t *variance) {
     shim_state *s = state_of(h);
     if (!s || !s->initialised) return EB_ErrorBadParameter;
+    { const EbErrorType je = join_all(s); if (je != EB_ErrorNone) return je; }
     shim_dev  *d = NULL;
     shim_slot *t = find_any(s, (int64_t)picture_number, &d);
     if (!t || !t->processed) return EB_NoErrorEmptyQueue;
@@ -1120,6 +1386,7 @@ EbErrorType svt_vp9_shim_get_coded_picture(EbComponentType *h, uint64_t picture_
                                            void *lf_mode_info, int16_t *qcoeff, uint16_t *eob_map) {
     shim_state *s = state_of(h);
     if (!s || !s->initialised) return EB_ErrorBadParameter;
+    { const EbErrorType je = join_all(s); if (je != EB_ErrorNone) return je; }
     shim_dev  *d = NULL;
     shim_slot *t = find_any(s, (int64_t)picture_number, &d);
     if (!t || !t->coded) return EB_NoErrorEmptyQueue;
@@ -1136,6 +1403,7 @@ EbErrorType svt_vp9_shim_get_coded_picture(EbComponentType *h, uint64_t picture_
 EbErrorType svt_vp9_shim_get_reference_picture(EbComponentType *h, uint64_t picture_number, uint8_t *out, uint64_t bytes) {
     shim_state *s = state_of(h);
     if (!s || !s->initialised || !out) return EB_ErrorBadParameter;
+    { const EbErrorType je = join_all(s); if (je != EB_ErrorNone) return je; }
     shim_dev  *d = NULL;
     shim_slot *t = find_any(s, (int64_t)picture_number, &d);
     if (!t || !t->coded) return EB_NoErrorEmptyQueue;
@@ -1150,6 +1418,7 @@ EbErrorType svt_vp9_shim_get_reference_picture(EbComponentType *h, uint64_t pict
 EbErrorType svt_vp9_shim_get_counters(EbComponentType *h, uint64_t *me_launches, uint64_t *pictures_sent) {
     shim_state *s = state_of(h);
     if (!s) return EB_ErrorBadParameter;
+    (void)join_all(s);
     if (me_launches) *me_launches = s->me_launches;
     if (pictures_sent) *pictures_sent = (uint64_t)s->next_number;
     return EB_ErrorNone;

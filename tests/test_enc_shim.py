@@ -150,7 +150,8 @@ def test_c_caller_compiles_links_and_fails_loudly_without_gpu():
 
 
 @pytest.mark.gpu
-def test_c_caller_runs_a_clip_and_me_results_equal_oracle():
+def test_c_caller_runs_a_clip_and_me_results_equal_oracle(monkeypatch):
+    monkeypatch.setenv("SVT_HIP_RING_GROUPS", "2")   # the smallest picture ring (2 mini-GOPs + 2): picture 0 leaves it within this clip
     W, H, N = 256, 192, 36          # picture 0 intra, two mini-GOPs of 16 (tune 1 -> 4 hierarchical levels), 3 pictures left over
     with tempfile.TemporaryDirectory() as td:
         path, frames = _clip(td, W, H, N)
