@@ -16,15 +16,18 @@
  *
  * What the library does with the pictures (all of it enqueued asynchronously; send_picture returns after the host copy of the
  * picture into pinned staging):
- *   as each picture arrives      three planes to the device, picture analysis (padded / decimated luma planes, block mean / variance) --
- *                                on an INPUT context (stream) of its own, so that the next mini-GOP's pictures cross PCIe while the
- *                                current one computes; a picture slot is overwritten behind the marker of its last reader on the main
+ *   as each picture arrives      three planes to the device (one staging copy, one transfer, on an UPLOAD context), picture analysis
+ *                                (padded / decimated luma planes, block mean / variance) on an INPUT context behind it -- streams of their
+ *                                own, so that the next mini-GOPs' pictures cross PCIe while the current one computes; a picture slot (the
+ *                                ring holds SVT_HIP_RING_GROUPS mini-GOPs) is overwritten behind the marker of its last reader on the main
  *                                context (device-side waits, svt_hip_ctx_wait_marker); the reconstruction copies of get_recon run on
  *                                an OUTPUT context the same way (SVT_HIP_SINGLE_STREAM=1: everything on the main stream)
  *   intra pictures               coded by the intra encode pass (svt_hip_encdec_intra_device: wavefront prediction + transform, then
- *                                deblocking and border); the decision callback is asked for them too, the stand-in is 16x16 / DC
+ *                                deblocking and border); the decision callback is asked for them too, the stand-in is 16x16 / DC; on a KEY
+ *                                context of their own, beside the previous GOP's tail and the new GOP's motion estimation
  *   when a mini-GOP is complete  (or cut short by an intra refresh / the end of the stream: cut as the reference cuts it,
- *                                svt_hip_minigop_split) ONE batched motion-estimation launch for all its pictures + the per-SB ME
+ *                                svt_hip_minigop_split) the caller's thread plans the group (structure, packets queued in decode order) and
+ *                                the device's FEEDER thread enqueues it while the caller goes on with the next pictures: ONE batched motion-estimation launch for all its pictures + the per-SB ME
  *                                statistics, then the stages behind mode decision in dependency order -- one batch per temporal
  *                                layer: mode decision (the host's callback, or the built-in stand-in) -> inter prediction from the
  *                                reconstructed, padded reference pictures -> transform / quantisation / reconstruction -> skip flags
@@ -37,7 +40,7 @@
  *                                device (svt_hip_ref_handoff_device): the one exchange step of the path
  * Every picture is answered by a zero-byte packet: entropy coding is outside the hot path.
  * Not reproduced (picture decision / rate control, control plane): the low-delay-P structure tables of the parts of a short group
- * (those pictures are a P chain), per-layer QP scaling (every picture uses quantizer_to_qindex[qp]).
+ * (those pictures are a P chain).
  */
 #include <pthread.h>
 #include <stdio.h>
