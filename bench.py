@@ -1045,19 +1045,21 @@ def main():
     me_clean_ms = me_alone["launch_ms_sum_per_step"] if me_alone else me_ms
     achieved = stage_bytes["me"] / (me_clean_ms * 1e-3) / 1e9
     traffic, valu, traffic_source = None, None, None
-    tj = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tj) and (Wd, Hd, enc_mode) == (W4K, H4K, 8):
+    # the committed counter passes of this configuration (tools/profile_round.sh TAG PRESET): profiles/traffic.json is c3's
+    tj_name = "traffic.json" if args.preset == "c3" else f"traffic_{args.preset}.json"
+    tj = os.path.join(ROOT, "profiles", tj_name)
+    if os.path.exists(tj) and (Wd, Hd) == PRESETS[args.preset][:2]:
         rec = json.load(open(tj)).get("svt_me_sb_kernel", {})
         if rec.get("bytes_per_step"):   # the profiling run's step is one mini-GOP of one GOP
             traffic = int(rec["bytes_per_step"] * G / n_launch_step)      # per launch, like `achieved`
-            traffic_source = "profiles/traffic.json (rocprofv3 --pmc passes of tools/profile_round.sh, committed; not measured in this run)"
+            traffic_source = f"profiles/{tj_name} (rocprofv3 --pmc passes of tools/profile_round.sh, committed; not measured in this run)"
         vi = rec.get("valu_wave_insts_per_step")
         if vi and "me" in stages:
             # the kernel's real roof: 64-lane VALU instructions issued (rocprofv3 SQ_INSTS_VALU, profiles/) per second against
             # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (MI355X_MICROARCH.md)
             ach = vi * G * 64 / (me_clean_ms * 1e-3) / 1e12
             valu = {"achieved": round(ach, 2), "peak": 39.3, "unit": "T lane-ops/s", "frac": round(ach / 39.3, 4), "wave_insts_per_minigop": vi,
-                    "source": "profiles/traffic.json"}
+                    "source": f"profiles/{tj_name}"}
     fps = GS.aggregate_rate(pics_step + n_keys_main / args.steps, args.steps, world, dt)   # every rank codes the same number of key frames
     stages_run = [s for s in STAGES if s in stages or (s in ED_STAGE_NAMES and run_encdec)]
     out = {

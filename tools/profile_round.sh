@@ -1,12 +1,15 @@
 #!/bin/bash
-# tools/profile_round.sh TAG -- the rocprofv3 passes behind profiles/ (run on the GPU box, e.g. through gpurun).
+# tools/profile_round.sh TAG [PRESET] -- the rocprofv3 passes behind profiles/ (run on the GPU box, e.g. through gpurun).
+# PRESET (c1 | c2 | c5; default c3): the same passes for another BASELINE.json configuration, under gpurun_out/prof_TAG_PRESET*.
 # Pass 1: kernel trace + stats of the default bench command.  Passes 2-5: PMC counters, each in its own run with
 # --kernel-trace only (never combined with other trace domains).  Everything lands under gpurun_out/prof_TAG*.
 TAG=${1:-r05}
+PRESET=${2:-c3}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-single --no-extras"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-single --no-extras --preset $PRESET"
+if [ "$PRESET" != c3 ]; then TAG=${TAG}_${PRESET}; fi
 # the counter passes profile ONE GOP in flight (diagonal schedule): a step is then one 16-picture mini-GOP and a stage's launches of
 # the last step are the last PER_STEP dispatches of its kernel (tools/summarize_prof.py)
 ONE="--gops 1 --groups 1 --schedule diagonal --no-key-frames"   # (inter pictures only: a key frame's launches would fall among "the last launches of the step")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/summarize_prof.py TAG -- turn the rocprofv3 CSVs of tools/profile_round.sh (gpurun_out/prof_TAG*) into
+"""tools/summarize_prof.py TAG [PRESET] -- turn the rocprofv3 CSVs of tools/profile_round.sh (gpurun_out/prof_TAG*) into
 profiles/<round>_kernel_stats.csv, profiles/traffic.json and a markdown table on stdout.
 
 HBM traffic follows MI355X_MICROARCH.md's HBM section: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts
@@ -11,12 +11,16 @@ picture-level driver (svt_hip_encdec_batch_device) over the 16 pictures of the d
 import csv, glob, json, os, re, shutil, sys, collections
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+preset = sys.argv[2] if len(sys.argv) > 2 else "c3"   # another BASELINE.json configuration: gpurun_out/prof_TAG_PRESET*, profiles/traffic_PRESET.json
+rnd = tag[:3]
+if preset != "c3":
+    tag = f"{tag}_{preset}"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out")
 prof = os.path.join(root, "profiles")
 # launches of one step with ONE GOP in flight, diagonal schedule: ME per temporal layer, the transform stage per transform size (one
 # launch serves the five ring slots: svt_hip_tq_rd_batch_multi_device), everything else once over the 16 pictures
-PER_STEP = {"svt_me_sb_kernel": 5, "svt_tq_kernel": 4, "svt_lf_kernel": 1, "svt_lf_desc_kernel": 1, "svt_pa_plane_kernel": 1, "svt_mc_kernel": 1,
+PER_STEP = {"svt_me_sb_kernel": 4 if preset == "c5" else 5,   # launches = temporal layers of the mini-GOP (c5: 8 pictures, 4 layers) "svt_tq_kernel": 4, "svt_lf_kernel": 1, "svt_lf_desc_kernel": 1, "svt_pa_plane_kernel": 1, "svt_mc_kernel": 1,
             "svt_refpad_kernel": 1, "svt_tq_count_kernel": 1, "svt_scan_sb_kernel": 1, "svt_scan_pic_kernel": 1, "svt_tq_emit_kernel": 1, "svt_tq_skip_kernel": 1,
             "svt_skip_update_kernel": 1, "svt_lf_mask_kernel": 1}
 KERNELS = ("svt_me_sb_kernel", "svt_tq_kernel", "svt_lf_kernel", "svt_lf_desc_kernel", "svt_lf_mask_kernel", "svt_pa_plane_kernel", "svt_mc_kernel", "svt_rate_kernel",
@@ -50,7 +54,7 @@ def pmc(sub, prefix):
 
 
 fetch, write, insts, sq = pmc("fetch", "f"), pmc("write", "w"), pmc("insts", "i"), pmc("sq", "s")
-traffic = {"_comment": "per 16-picture mini-GOP (one step with one GOP in flight, diagonal schedule), from rocprofv3 PMC passes on MI355X (tools/profile_round.sh, tools/summarize_prof.py): "
+traffic = {"_comment": f"per {8 if preset == 'c5' else 16}-picture mini-GOP (one step with one GOP in flight, diagonal schedule), from rocprofv3 PMC passes on MI355X (tools/profile_round.sh, tools/summarize_prof.py): "
                        "bytes = 1024 * (2 x FETCH_SIZE + WRITE_SIZE); instruction counts = SQ_INSTS_* summed over the stage's launches of one step"}
 print("| kernel | launches/step | FETCH_SIZE raw (KiB) | WRITE_SIZE (KiB) | traffic (MB) | VALU / SALU / LDS wave-instructions | waves |")
 print("|---|---|---|---|---|---|---|")
@@ -68,11 +72,11 @@ for k, v in sq.items():
     print("SQ (ME alone)", k, {c: f"{x:.4g}" for c, x in v.items()})
     if k == "svt_me_sb_kernel":
         traffic[k]["me_alone"] = {c: int(x) for c, x in v.items()}
-json.dump(traffic, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(prof, "traffic.json" if preset == "c3" else f"traffic_{preset}.json"), "w"), indent=1)
 for name in ("kernel_stats", "domain_stats"):
     src = glob.glob(os.path.join(out, f"prof_{tag}", "**", f"{tag}_{name}.csv"), recursive=True)
     if src:
-        shutil.copy(src[0], os.path.join(prof, f"{tag[:3]}_{name}.csv"))  # profiles are named per round: r02_*
+        shutil.copy(src[0], os.path.join(prof, f"{rnd}_{name}.csv" if preset == "c3" else f"{rnd}_{preset}_{name}.csv"))  # profiles are named per round: r02_*
 src = glob.glob(os.path.join(out, f"prof_{tag}", "**", f"{tag}_kernel_stats.csv"), recursive=True)
 if src:
     print("\n| kernel | calls | avg (us) | total (ms) |\n|---|---|---|---|")
