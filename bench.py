@@ -406,7 +406,8 @@ def main():
     me_streams, me_ctxs = [p_[0] for p_ in me_pairs], [p_[1] for p_ in me_pairs]
     grp_pairs = [new_ctx(prio[1]) for _ in range(n_groups)]
     pa_stream, ctx_pa = new_ctx(prio[0])
-    key_streams = [new_ctx(prio[1]) for _ in range(n_groups)]   # the key frames' encode pass: beside the inter batches of its GOP group
+    # the key frames' encode pass: beside the inter batches of its GOP group (SVT_BENCH_KEY_STREAMS: how many streams they share)
+    key_streams = [new_ctx(prio[1]) for _ in range(max(1, min(n_groups, int(os.environ.get("SVT_BENCH_KEY_STREAMS", str(n_groups))))))]
     single_pairs = [new_ctx(prio[1]) for _ in range(max(1, int(os.environ.get("SVT_BENCH_SINGLE_STREAMS", "2"))))]
 
     geo = Geometry(Wd, Hd)

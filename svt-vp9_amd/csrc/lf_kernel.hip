@@ -33,6 +33,8 @@ struct lf_pic_dev {
 };
 
 __device__ unsigned long long g_lf_prof[8]; /* SVT_HIP_LF_PROFILE: cycles per stage, thread 0 of every workgroup */
+__device__ unsigned long long g_lf_rowts[64][8]; /* SVT_HIP_LF_PROFILE, picture 0: per SB row, s_memtime at: row taken, first halo in LDS, SB 0 filtered,
+                                                    first progress published, SB 1's vertical pass done, last SB filtered, row complete */
 
 constexpr int LF_DESC_WORDS = 320; /* two words per block: leading edge, inner edge (lf_entry2) */
 constexpr int YS = 76, YROWS = 72;   /* luma tile stride / rows (8 halo + 64) */
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(128) void svt_lf_desc_kernel(const lf_pic_dev *__re
  *           descriptors (svt_lf_desc_kernel) into the other buffer;
  *   wave 3  writes the finished columns of the tile filtered in the previous step back and publishes the row's progress.
  * One workgroup barrier per SB; wave 2 lets its loads fly while wave 3 is still reading the buffer they will land in.  Tile rows 0-7 (top halo) and the SB's last 8 rows are seam rows (sc1 accesses). */
-template <bool early> /* latency mode (launches of few pictures): seam rows are handed to the SB row below early, see step (c) */
+template <bool early> /* seam rows are handed to the SB row below early, see step (c) (the default; <false>: with the tile's write-back) */
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void svt_lf_kernel(const lf_pic_dev *__restrict__ pics, int n_pics,
                                                      uint32_t *__restrict__ ticket, int rows_per_pic, int prof) {
     __shared__ __align__(16) uint8_t ytile[2][YROWS * YS];
@@ -462,6 +464,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const bool wide_y = (((uintptr_t)P.planes.y | (uintptr_t)P.planes.y_stride) & 7) == 0;
     const bool wide_c = (((uintptr_t)P.planes.u | (uintptr_t)P.planes.v | (uintptr_t)P.planes.uv_stride) & 7) == 0;
     unsigned long long tm_ = prof ? __builtin_amdgcn_s_memtime() : 0;
+    const bool rowts = prof && job % n_pics == 0 && sb_row < 64;
+#define LF_ROWTS(k, who, cond) do { if (rowts && tid == (who) && (cond)) g_lf_rowts[sb_row][k] = __builtin_amdgcn_s_memtime(); } while (0)
+    LF_ROWTS(0, 0, true);
 #define LF_MARK(i, who) do { if (prof && tid == (who)) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_lf_prof[i], n_ - tm_); tm_ = n_; } } while (0)
 
     /* wave 2 stages SB `sc` into buffer sc & 1 in two parts.  stage(sc): the SB's own rows and its edge descriptors --
@@ -487,6 +492,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         /* LDS accesses of one wave are ordered: the flag lands after the rows */
         if (lane == 0) s_halo = sc;
+        LF_ROWTS(1, 128, sc == 0);
     };
     auto stage = [&](int sc) {
         const int     buf = sc & 1;
@@ -520,10 +526,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
              * ordered, no barrier between the two passes) */
             if (lane < g.vh) lf_line<true>(ytile[buf] + (8 + lane) * YS + 8, 1, 8, &s_desc[buf][2 * (lane >> 3) * 8], 1);
             if (early && lane == 0) s_vdone[0] = sc; /* LDS accesses of one wave are ordered: the flag lands behind the pass's stores */
+            LF_ROWTS(4, 0, sc == 1);
             LF_MARK(3, 0);
             while (s_halo < sc) __builtin_amdgcn_s_sleep(1); /* the rows above the SB have arrived */
             if (lane < g.vw) lf_line<false>(ytile[buf] + 8 * YS + 8 + lane, YS, nrows, &s_desc[buf][128 + 2 * (lane >> 3)], 8);
             LF_MARK(4, 0);
+            LF_ROWTS(2, 0, sc == 0);
+            LF_ROWTS(5, 0, last);
             if (!last) {
                 while (s_stored < sc - 1) __builtin_amdgcn_s_sleep(1); /* the other buffer has been written back */
                 for (int r = lane; r < YROWS; r += 64) {
@@ -580,9 +589,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             /* (c) early hand-over to the SB row below: the bottom 8 rows of this SB's LAST 8 columns are final as soon as the NEXT SB's
              * vertical pass (running right now in the other buffer, whose left-halo columns they are) has filtered its left edge --
              * its horizontal pass never touches the halo columns.  Handing them over now instead of with the next tile's
-             * write-back lets row r + 1 follow 1.2 instead of 2 SB steps behind row r: 1.09 -> 0.91 ms for one 4K picture.  It costs
-             * extra (write-through) stores, which a launch of many pictures -- throughput, not latency -- does not get back (16
-             * pictures: 1.47 -> 1.51 ms), so the launcher turns it on for launches of few pictures only (`early`). */
+             * write-back lets row r + 1 follow 1.2 instead of 2 SB steps behind row r: 1.09 -> 0.89 ms for one 4K picture, 1.21 -> 1.03 ms
+             * for 16 (every row with a workgroup of its own, see the launcher). */
             if (!last && below) {
                 while (s_vdone[0] < sc + 1) __builtin_amdgcn_s_sleep(1);
                 const lf_geom gn = lf_geometry(sb_row, sc + 1, W, H);
@@ -597,10 +605,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
              * above SB sc of the row below is in memory" */
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(LF_AS_GLOBAL(uint32_t, &P.progress[sb_row]), (uint32_t)(sc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            LF_ROWTS(3, 192, sc == 0);
+            LF_ROWTS(6, 192, last);
             LF_MARK(7, 192);
         }
     }
 #undef LF_MARK
+#undef LF_ROWTS
     } /* next ticket */
 }
 } // namespace
@@ -640,17 +651,18 @@ static int32_t lf_launch(svt_hip_ctx *ctx, int n_pics, const svt_yuv_planes *d_r
     static const bool want_prof = getenv("SVT_HIP_LF_PROFILE") != nullptr;
     if (want_prof) { unsigned long long z[8] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lf_prof), z, sizeof z)); }
     hipLaunchKernelGGL(svt_lf_desc_kernel, dim3(n_pics * max_rows * max_cols), dim3(128), 0, ctx->stream, (const lf_pic_dev *)d, max_rows, max_cols, *thr);
-    /* rows in flight per picture: a row takes sb_cols steps of ~6 us and starts ~23 us after the one above, so about
-     * sb_cols * 6 / 23 rows keep the wavefront full (16 for 4K, 8 for 1080p); more would only wait */
+    /* Every SB row gets a workgroup (tickets: a row's predecessor always holds an earlier one) and the seam rows are handed to the row
+     * below early (step (c) of the kernel).  Measured on MI355X, 2160p, launch alone: 1 picture 0.89 ms, 4 pictures 0.91 ms, 16 pictures
+     * 1.03 ms.  Until round 5 launches of more than 4 pictures ran 16 rows per picture without the early hand-over ("only as many rows as
+     * the wavefront keeps busy"): 1.45 ms for 16 pictures -- the row-to-row lag (two SB steps of ~6.8 us) times 34 rows IS most of a
+     * picture's time, and a workgroup that waits for its predecessor costs the launch nothing while one that has not started cannot take
+     * its seam rows the moment they appear.  Inside the pipelined step the change is neutral (other kernels fill the device either way);
+     * one GOP at a time gains 6 %.  SVT_HIP_LF_ROWS / SVT_HIP_LF_EARLY override (experiments). */
     static const int rows_env = getenv("SVT_HIP_LF_ROWS") ? atoi(getenv("SVT_HIP_LF_ROWS")) : 0;
-    /* few pictures in the launch: their latency is what the caller waits for (a temporal-layer wave of one GOP) and the GPU has
-     * room -- every SB row gets its own workgroup (1.09 instead of 1.39 ms for one 4K picture); many pictures: only as many rows
-     * as the wavefront keeps busy, so that the launch does not hold CU slots other stages could use */
-    const int heuristic = (max_cols * 17 + 63) / 64 < 4 ? 4 : (max_cols * 17 + 63) / 64;
-    const int rows_in_flight = rows_env > 0 ? rows_env : n_pics <= 4 ? max_rows : heuristic;
+    const int rows_in_flight = rows_env > 0 ? rows_env : max_rows;
     const int lf_wgs = n_pics * (max_rows < rows_in_flight ? max_rows : rows_in_flight);
     static const int early_env = getenv("SVT_HIP_LF_EARLY") ? atoi(getenv("SVT_HIP_LF_EARLY")) : -1;
-    const int early = early_env >= 0 ? early_env : n_pics <= 4;
+    const int early = early_env >= 0 ? early_env : 1;
     if (early) hipLaunchKernelGGL(svt_lf_kernel<true>, dim3(lf_wgs), dim3(256), 0, ctx->stream, (const lf_pic_dev *)d, n_pics, cnt, max_rows, want_prof ? 1 : 0);
     else hipLaunchKernelGGL(svt_lf_kernel<false>, dim3(lf_wgs), dim3(256), 0, ctx->stream, (const lf_pic_dev *)d, n_pics, cnt, max_rows, want_prof ? 1 : 0);
     HIP_TRY(hipGetLastError());
@@ -667,6 +679,15 @@ static int32_t lf_launch(svt_hip_ctx *ctx, int n_pics, const svt_yuv_planes *d_r
         fprintf(stderr, "[lf-profile] pics=%d SB steps=%llu avg cycles/SB=%llu :", n_pics, steps, tot / (steps ? steps : 1));
         for (int i = 0; i < 8; i++) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * (double)hp[i] / (double)tot);
         fprintf(stderr, "\n");
+        if (getenv("SVT_HIP_LF_ROWTS")) { /* the wavefront's hand-over between SB rows, picture 0 (ticks of s_memtime: 100 MHz) */
+            static unsigned long long ts[64][8];
+            HIP_TRY(hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_lf_rowts), sizeof ts));
+            for (int r = 0; r < max_rows && r < 64; r++) {
+                fprintf(stderr, "[lf-rows] row %2d:", r);
+                for (int k = 0; k < 7; k++) fprintf(stderr, " %9.2f", (double)(ts[r][k] - ts[0][0]) / 100.0);
+                fprintf(stderr, "  (us: taken, halo 0, SB 0 done, publish 1, V(SB 1) done, last SB done, row complete)\n");
+            }
+        }
     }
     svt_ctx_stage_commit(ctx);
     ctx->timed = 1;
