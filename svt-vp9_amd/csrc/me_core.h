@@ -415,6 +415,8 @@ SVT_DEV svt_plane me_plane_uni(const svt_plane *p) {
 }
 
 /* two groups per iteration in the fused full-pel phase: the configurations with a 64x64 search area (few waves per SIMD) */
+/* two groups per iteration of the fused full-pel loop (independent chains) for the large areas; four were measured on the 64x64 area
+ * of C5 and gain nothing (the phase runs at its issue rate there: 44 % of the workgroup's time either way) */
 #define ME_FULLPEL_UNROLL2(c) ((c)->p->search_area_width * (c)->p->search_area_height >= 2048)
 
 /* everything a phase needs */
@@ -1799,6 +1801,21 @@ SVT_DEV void me_qsad_16x8(const uint8_t *blk, const uint8_t *win, int wstride, u
 
 /* exhaustive search of the windows [e0, e1) of a batch in one phase; keys[slot] = min over
  * (sad << 32 | y << 16 | x inside the region): ordered like the raster index, no division to take it apart */
+#ifndef SVT_HOST_EMU
+/* The windows of a batch (at most four here: one per region, or the bands of one), held in scalar registers: a task finds its window
+ * by three comparisons instead of walking the list in LDS -- every task used to start with up to five dependent LDS round trips
+ * (~120 cycles each with one wave per SIMD) before its first sample was fetched. */
+typedef struct me_hme_sel { int ts[4], sw[4], slot[4], y0[4], ws[4], off[4]; uint32_t inv[4]; } me_hme_sel;
+SVT_DEV void me_hme_sel_load(me_hme_sel *S, const me_hme_win *wn, int e0, int e1) {
+    _Pragma("unroll") for (int k = 0; k < 4; k++) {
+        const me_hme_win *w = &wn[e0 + k < e1 ? e0 + k : e1 - 1];
+        S->ts[k] = e0 + k < e1 ? ME_UNI(w->ts) : 0x7fffffff;
+        S->sw[k] = ME_UNI(w->sw); S->slot[k] = ME_UNI(w->slot); S->y0[k] = ME_UNI(w->y0); S->ws[k] = ME_UNI(w->wstride);
+        S->off[k] = ME_UNI(w->off); S->inv[k] = (uint32_t)ME_UNI(w->inv_ng);
+    }
+}
+#define ME_HME_SEL(S, T, f) ((T) >= (S).ts[3] ? (S).f[3] : (T) >= (S).ts[2] ? (S).f[2] : (T) >= (S).ts[1] ? (S).f[1] : (S).f[0])
+#endif
 SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk, int bstride, int bw, int bh, const me_hme_win *wn,
                                  int e0, int e1, int ntask, uint64_t *keys, int slot_mask) {
     const int qs = (bw & 3) == 0; /* QSAD path: task = 4 positions */
@@ -1814,14 +1831,29 @@ SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk,
     if (bw == 16 && bh == 8 && bstride == 16 && c->L.hme_tw0 <= 256 && c->L.hme_th0 <= 256 && c->L.hme_w0[0] <= 256 && c->L.hme_w0[1] <= 256 &&
         c->L.hme_h0[0] <= 256 && c->L.hme_h0[1] <= 256) { /* positions inside a region fit 8 bits each */
         uint32_t b32[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+#ifndef SVT_HOST_EMU
+        me_hme_sel S;
+        const bool sel = e1 - e0 <= 4;
+        if (sel) me_hme_sel_load(&S, wn, e0, e1);
+#endif
         for (int T = tid; T < ntask; T += SVT_NT) {
-            int e = e0;
-            while (e + 1 < e1 && T >= wn[e + 1].ts) e++;
-            const int t = T - wn[e].ts, sw = wn[e].sw, slot = wn[e].slot;
-            const int ng = (sw + 3) >> 2, y = me_div_magic(t, wn[e].inv_ng), g = t - ME_MUL(y, ng);
+            int      t, sw, slot, w_y0, w_ws, w_off;
+            uint32_t w_inv;
+#ifndef SVT_HOST_EMU
+            if (sel) {
+                t = T - ME_HME_SEL(S, T, ts); sw = ME_HME_SEL(S, T, sw); slot = ME_HME_SEL(S, T, slot); w_y0 = ME_HME_SEL(S, T, y0);
+                w_ws = ME_HME_SEL(S, T, ws); w_off = ME_HME_SEL(S, T, off); w_inv = ME_HME_SEL(S, T, inv);
+            } else
+#endif
+            {
+                int e = e0;
+                while (e + 1 < e1 && T >= wn[e + 1].ts) e++;
+                t = T - wn[e].ts; sw = wn[e].sw; slot = wn[e].slot; w_y0 = wn[e].y0; w_ws = wn[e].wstride; w_off = (int)wn[e].off; w_inv = wn[e].inv_ng;
+            }
+            const int ng = (sw + 3) >> 2, y = me_div_magic(t, w_inv), g = t - ME_MUL(y, ng);
             uint32_t  lo, hi;
-            me_qsad_16x8(blk, c->planes + wn[e].off + ME_MUL(y, wn[e].wstride) + 4 * g, wn[e].wstride, &lo, &hi);
-            const uint32_t pos = ((uint32_t)(wn[e].y0 + y) << 8) | (uint32_t)(4 * g);
+            me_qsad_16x8(blk, c->planes + w_off + ME_MUL(y, w_ws) + 4 * g, w_ws, &lo, &hi);
+            const uint32_t pos = ((uint32_t)(w_y0 + y) << 8) | (uint32_t)(4 * g);
             uint32_t       k0 = (lo << 16) | pos, k1 = (lo & 0xffff0000u) | (pos + 1), k2 = (hi << 16) | (pos + 2), k3 = (hi & 0xffff0000u) | (pos + 3);
             if (4 * g + 3 >= sw) { /* last group of a width that is not a multiple of 4 */
                 if (4 * g + 1 >= sw) k1 = 0xffffffffu;
@@ -1834,6 +1866,75 @@ SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk,
         _Pragma("unroll") for (int q = 0; q < 4; q++) if ((slot_mask >> q) & 1) svt_wave_min_key32(&keys[q], b32[q]);
         return;
     }
+#ifndef SVT_HOST_EMU
+    if (qs && (bw == 32 || bw == 64) && (bh == 16 || bh == 32)) {
+        /* The quarter- and full-resolution levels of a whole SB: few tasks (a region is 4 x 2 .. 16 x 16 positions) of many samples each
+         * (32 x 16 / 64 x 32 rows) -- one lane per task left three waves idle while a handful of lanes walked 128 / 512 QSADs each (the
+         * 1080p presets: 8 lanes busy for ~20 K cycles).  Here bw / 4 = 8 or 16 neighbouring lanes share a task: a lane owns one dword
+         * column of the block over all its rows (4 positions x <= 32 rows x 4 samples x 255 stay below 2^16 per 16-bit sum), the
+         * columns meet in DPP row shifts (the group's last lane holds the four sums), and that lane keeps the task's key. */
+        const int lsh = bw == 64 ? 4 : 3, nl = 1 << lsh, sub = tid & (nl - 1), tpp = SVT_NT >> lsh;
+        const uint8_t *bcol = blk + 4 * sub;
+        me_hme_sel     S;
+        const bool     sel = e1 - e0 <= 4;
+        if (sel) me_hme_sel_load(&S, wn, e0, e1);
+        for (int T0 = 0; T0 < ntask; T0 += tpp) {
+            const int  T = T0 + (tid >> lsh);
+            const bool act = T < ntask;
+            int        a0 = 0, a1 = 0, a2 = 0, a3 = 0, slot = 0, sw = 0, y = 0, g = 0, y0 = 0;
+            if (act) {
+                int      t, ws, w_off;
+                uint32_t w_inv;
+                if (sel) {
+                    t = T - ME_HME_SEL(S, T, ts); sw = ME_HME_SEL(S, T, sw); slot = ME_HME_SEL(S, T, slot); y0 = ME_HME_SEL(S, T, y0);
+                    ws = ME_HME_SEL(S, T, ws); w_off = ME_HME_SEL(S, T, off); w_inv = ME_HME_SEL(S, T, inv);
+                } else {
+                    int e = e0;
+                    while (e + 1 < e1 && T >= wn[e + 1].ts) e++;
+                    t = T - wn[e].ts; ws = wn[e].wstride; w_off = (int)wn[e].off; w_inv = wn[e].inv_ng;
+                    sw = wn[e].sw; slot = wn[e].slot; y0 = wn[e].y0;
+                }
+                const int ng = (sw + 3) >> 2;
+                y = me_div_magic(t, w_inv); g = t - ME_MUL(y, ng);
+                const uint8_t *wp = c->planes + w_off + ME_MUL(y, ws) + 4 * g + 4 * sub;
+                uint64_t       acc = 0, acc_b = 0; /* two chains; eight rows' operands are fetched before their QSADs (bh is 16 or 32) */
+                const int      ws2 = 2 * ws;
+                for (int j = 0; j < bh; j += 8) {
+                    uint64_t pr[8];
+                    uint32_t bd[8];
+                    _Pragma("unroll") for (int u = 0; u < 8; u++) {
+                        pr[u] = *(const me_u64a4 *)(wp + ME_MUL(j + u, ws2));
+                        bd[u] = *(const uint32_t *)(bcol + ME_MUL(j + u, bstride));
+                    }
+                    _Pragma("unroll") for (int u = 0; u < 8; u += 2) { acc = svt_qsad(pr[u], bd[u], acc); acc_b = svt_qsad(pr[u + 1], bd[u + 1], acc_b); }
+                }
+                acc += acc_b; /* (16-bit sums of 32 rows x 4 samples: no carry between the fields) */
+                a0 = (int)(acc & 0xffffu); a1 = (int)((acc >> 16) & 0xffffu); a2 = (int)((acc >> 32) & 0xffffu); a3 = (int)(acc >> 48);
+            }
+            /* every lane takes part (lanes without a task add 0); row_shr:n with bound_ctrl: lanes shifted in from outside the row read 0 */
+#define HW_SHR(v, n) v += __builtin_amdgcn_update_dpp(0, v, 0x110 + (n), 0xf, 0xf, true)
+            HW_SHR(a0, 1); HW_SHR(a1, 1); HW_SHR(a2, 1); HW_SHR(a3, 1);
+            HW_SHR(a0, 2); HW_SHR(a1, 2); HW_SHR(a2, 2); HW_SHR(a3, 2);
+            HW_SHR(a0, 4); HW_SHR(a1, 4); HW_SHR(a2, 4); HW_SHR(a3, 4);
+            if (lsh == 4) { HW_SHR(a0, 8); HW_SHR(a1, 8); HW_SHR(a2, 8); HW_SHR(a3, 8); }
+#undef HW_SHR
+            if (act && sub == nl - 1) {
+                const uint32_t av[4] = {(uint32_t)a0, (uint32_t)a1, (uint32_t)a2, (uint32_t)a3};
+                uint64_t       kb = ~0ull;
+                _Pragma("unroll") for (int o = 0; o < 4; o++) {
+                    const int x = 4 * g + o;
+                    if (x < sw) {
+                        const uint64_t k = ((uint64_t)av[o] << 32) | ((uint32_t)(y0 + y) << 16) | (uint32_t)x;
+                        if (k < kb) kb = k;
+                    }
+                }
+                _Pragma("unroll") for (int q = 0; q < 4; q++) if (q == slot && kb < best[q]) best[q] = kb;
+            }
+        }
+        _Pragma("unroll") for (int q = 0; q < 4; q++) if ((slot_mask >> q) & 1) svt_wave_min_u64(&keys[q], best[q]);
+        return;
+    }
+#endif
     for (int T = tid; T < ntask; T += SVT_NT) {
         int e = e0;
         while (e + 1 < e1 && T >= wn[e + 1].ts) e++;
@@ -2187,7 +2288,9 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                 int       first = 1;
                 for (int lvl = 0; lvl < 3; lvl++) {
                     if (!(lvl == 0 ? p->enable_hme_level_0_flag : lvl == 1 ? p->enable_hme_level_1_flag : p->enable_hme_level_2_flag)) continue;
+                    ME_SUBMARK_BEGIN();
                     ME_UNIFORM_WRITE(me_hme_plan_level(c, list, lvl, xsc, ysc, first));
+                    ME_SUBMARK(20);
                     ME_STOP_AT(19);
                     first = 0;
                     me_hme_geom g;
@@ -2201,7 +2304,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                         int               slot_mask = 0;
                         for (int e = e0; e < e1; e++) slot_mask |= 1 << st->hme_win[e].slot;
                         slot_mask = ME_UNI(slot_mask);
-                        ME_SUBMARK_BEGIN();
+                        ME_SUBMARK(22);
                         ME_PHASE(ph_hme_load_multi(c, tid, g.ref, st->hme_win, e0, e1, ntl));
                         ME_SUBMARK(14);
                         ME_STOP_AT(20);
@@ -2209,7 +2312,9 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                         ME_SUBMARK(15);
                         ME_STOP_AT(21);
                     }
+                    ME_SUBMARK(22);
                     ME_UNIFORM_WRITE(me_hme_finish_level(c, lvl); if (lvl == last_lvl) me_hme_select(c, list));
+                    ME_SUBMARK(21);
                 }
                 xsc = (int16_t)ME_UNI(st->hme_xc); ysc = (int16_t)ME_UNI(st->hme_yc);
             }

@@ -247,6 +247,7 @@ static int32_t me_launch(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture 
         fprintf(stderr, "[me-profile] tl=%d pics=%d WGs=%d avg cycles/WG=%llu :", params->temporal_layer_index, n_pics, total, tot / (unsigned long long)total);
         for (int i = 0; i < 14; i++) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * (double)hp[i] / (double)tot);
         fprintf(stderr, " | hme_load=%.1f%% hme_search=%.1f%%", 100.0 * (double)hp[14] / (double)tot, 100.0 * (double)hp[15] / (double)tot);
+        if (hp[20] | hp[21]) fprintf(stderr, " hme_plan=%.1f%% hme_finish=%.1f%% hme_other=%.1f%%", 100.0 * (double)hp[20] / (double)tot, 100.0 * (double)hp[21] / (double)tot, 100.0 * (double)hp[22] / (double)tot);
         if (hp[16] | hp[17] | hp[18] | hp[19]) /* fine marks (builds with -DME_FINE_PROF): entry lookup, qsad block, key update, wave reductions */
             fprintf(stderr, " fine[lookup=%.1f%% qsad=%.1f%% keys=%.1f%% reduce=%.1f%%]", 100.0 * (double)hp[16] / (double)tot,
                     100.0 * (double)hp[17] / (double)tot, 100.0 * (double)hp[18] / (double)tot, 100.0 * (double)hp[19] / (double)tot);

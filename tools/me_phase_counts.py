@@ -22,6 +22,8 @@ def desc(luma):
 d = [desc(f) for f in frames]
 res = torch.zeros((T.n_sb(W, H), 850), dtype=torch.int32, device=dev)
 p = MC.preset_c5(2, int(os.environ.get("ME_TL", "3"))) if os.environ.get("ME_PRESET") == "c5" else MC.preset("c3_2160p_m8", 2, int(os.environ.get("ME_TL", "4")), 4)
+for kv in filter(None, os.environ.get("ME_HACK", "").split(",")):   # timing experiments: override parameter fields (results change)
+    k_, v_ = kv.split("="); setattr(p, k_, int(v_))
 STOPS = [int(x) for x in os.environ.get("ME_STOPS", "0,1,19,20,21,2,3,4,5,6,7,8,9,10,11,12,-1").split(",")]
 NP = int(os.environ.get("ME_PICS", "1")); REP = int(os.environ.get("ME_REPS", "1"))
 cur, r0, r1 = (B.PaPicture * NP)(*([d[1]] * NP)), (B.PaPicture * NP)(*([d[0]] * NP)), (B.PaPicture * NP)(*([d[2]] * NP))
