@@ -9,7 +9,7 @@ torch.cuda.init()
 import me_configs as MC, svt_testlib as T
 B = T.B; lib = B.load()
 ctx = C.c_void_p(); B.check(lib.svt_hip_ctx_create(C.byref(ctx), 0))
-W, H = 3840, 2160
+W, H = (1920, 1080) if os.environ.get("ME_PRESET") == "c2" else (3840, 2160)
 frames = T.gen_clip(W, H, 3, 11)
 dev = torch.device("cuda", 0); keep = []
 def desc(luma):
@@ -21,7 +21,8 @@ def desc(luma):
     return d
 d = [desc(f) for f in frames]
 res = torch.zeros((T.n_sb(W, H), 850), dtype=torch.int32, device=dev)
-p = MC.preset_c5(2, int(os.environ.get("ME_TL", "3"))) if os.environ.get("ME_PRESET") == "c5" else MC.preset("c3_2160p_m8", 2, int(os.environ.get("ME_TL", "4")), 4)
+p = (MC.preset_c5(2, int(os.environ.get("ME_TL", "3"))) if os.environ.get("ME_PRESET") == "c5" else
+     MC.preset("c2_1080p_m8", 2, int(os.environ.get("ME_TL", "4")), 4) if os.environ.get("ME_PRESET") == "c2" else MC.preset("c3_2160p_m8", 2, int(os.environ.get("ME_TL", "4")), 4))
 for kv in filter(None, os.environ.get("ME_HACK", "").split(",")):   # timing experiments: override parameter fields (results change)
     k_, v_ = kv.split("="); setattr(p, k_, int(v_))
 STOPS = [int(x) for x in os.environ.get("ME_STOPS", "0,1,19,20,21,2,3,4,5,6,7,8,9,10,11,12,-1").split(",")]
