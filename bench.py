@@ -483,12 +483,40 @@ def main():
     # ---- stage "me": one batched launch per temporal layer over the GOPs of the pipeline ----
     results = [[dev_zeros((nsb, 85 * 10), torch.int32) for _ in range(MINIGOP + 1)] for _ in range(G)]
 
+    # Launch grouping: the temporal layers whose parameter sets may share a launch (svt_hip_me_params_same_launch: the library's own rule,
+    # the one the public-API path uses to put a whole mini-GOP into one launch) go out together -- fewer, larger launches have fewer
+    # tails (a launch's last wave of workgroups leaves CUs idle).  One group is cut into one launch per ME stream.  SVT_BENCH_ME_MERGE=0:
+    # one launch per temporal layer (rounds 1-4; the counter passes of tools/profile_round.sh use it: same work, countable launches).
+    me_merge = os.environ.get("SVT_BENCH_ME_MERGE", "1") != "0"
+
+    def me_layer_groups():
+        if not me_merge:
+            return [[layer] for layer in range(n_layers)]
+        groups = []
+        for layer in range(n_layers):
+            p_l = me_params(layer)
+            for gset in groups:
+                p_0 = me_params(gset[0])
+                if lib.svt_hip_me_params_same_launch(C.byref(p_0), C.byref(p_l)):
+                    gset.append(layer)
+                    break
+            else:
+                groups.append([layer])
+        return groups
+
     def build_me_launches(gops, one_stream=False):
         sets = []
+        groups = me_layer_groups()
         for s in range(2):
             launches = []
-            for idx in [pics_of_layer(layer) for layer in range(n_layers)]:
+            chunks = []
+            for gset in groups:
+                idx = [i for layer in gset for i in pics_of_layer(layer)]
                 items = [(g, i) for g in gops for i in idx]
+                n_cut = 1 if (one_stream or not me_merge or len(groups) >= len(me_ctxs)) else min(len(me_ctxs), len(items))
+                for k_ in range(n_cut):   # (interleaved: every chunk holds pictures of every layer)
+                    chunks.append(items[k_::n_cut])
+            for items in chunks:
                 n = len(items)
                 p = (B.MeParams * n)()
                 for k_, (g, i) in enumerate(items):
@@ -1018,7 +1046,7 @@ def main():
 
     L = Wd * Hd
     pics_step = G * MINIGOP
-    n_launch_step = len(P_main["me_sets"][0])
+    n_launch_step = len(P_me["me_sets"][0]) if me_alone else len(P_main["me_sets"][0])   # the launches behind `me_clean_ms`
     n_blocks_step = int(blocks_by_size.sum())
     stage_bytes = {
         # source luma read + padded / decimated planes written

@@ -12,6 +12,7 @@ BENCH="python $ROOT/bench.py --no-cpu-baseline --no-single --no-extras --preset 
 if [ "$PRESET" != c3 ]; then TAG=${TAG}_${PRESET}; fi
 # the counter passes profile ONE GOP in flight (diagonal schedule): a step is then one 16-picture mini-GOP and a stage's launches of
 # the last step are the last PER_STEP dispatches of its kernel (tools/summarize_prof.py)
+export SVT_BENCH_ME_MERGE=0   # one ME launch per temporal layer in every pass: countable (tools/summarize_prof.py PER_STEP)
 ONE="--gops 1 --groups 1 --schedule diagonal --no-key-frames"   # (inter pictures only: a key frame's launches would fall among "the last launches of the step")
 rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG} -o $TAG --output-format csv -- $BENCH --steps 3 --warmup 5 > $OUT/prof_${TAG}_bench.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_${TAG}_fetch -o f --output-format csv -- $BENCH $ONE --steps 1 --warmup 5 > /dev/null 2>&1
