@@ -359,14 +359,22 @@ def test_without_recon_output_only_reference_pictures_are_reconstructed():
     assert kinds == {(1, 1, 1), (1, 0, 1), (0, 0, 0)}
 
 
-def test_long_clip_reuses_every_picture_slot_several_times():
-    """90 pictures with an intra refresh every 40: every slot of the 34-picture ring is overwritten two or three times while the input,
-    main and output streams run side by side -- a slot must not be overwritten before its last reader (the marker chain of the library)
-    nor read before its upload.  Every reconstruction still equals the oracle chain."""
+@pytest.mark.parametrize("env", [
+    {"SVT_HIP_RING_GROUPS": "2"},                                                  # the smallest ring, feeder thread, upload / key streams (the defaults)
+    {"SVT_HIP_RING_GROUPS": "2", "SVT_HIP_FEEDER": "0"},                           # everything enqueued by the caller's thread
+    {"SVT_HIP_RING_GROUPS": "2", "SVT_HIP_DEEP_STREAM": "1"},                      # + the deep-layer stream
+    {"SVT_HIP_RING_GROUPS": "3", "SVT_HIP_NO_KEY_STREAM": "1", "SVT_HIP_NO_UPLOAD_STREAM": "1"},
+    {},                                                                            # the default ring of four mini-GOPs
+], ids=["ring2", "ring2-nofeeder", "ring2-deep", "ring3-nokey-noupload", "default"])
+def test_long_clip_reuses_every_picture_slot_several_times(env):
+    """90 pictures with an intra refresh every 40: every slot of a 34-picture ring is overwritten two or three times while the upload, input,
+    main, key and output streams run side by side and the device's feeder thread enqueues the groups -- a slot must not be overwritten before
+    its last reader (the marker chain of the library) nor read before its upload, whatever the set of streams and threads.  Every
+    reconstruction still equals the oracle chain."""
     W, H, N, enc_mode, tune, qp, intra_period = 136, 72, 90, 8, 1, 40, 39
     base = T.gen_clip_subpel(W, H, 30, 53)
     clip = [base[i % 30] if (i // 30) % 2 == 0 else base[29 - i % 30] for i in range(N)]          # 30 pictures forth and back
-    frames, recon, order, flags_seen, packets, infos, refpics, _ = run_clip(W, H, N, enc_mode, tune, qp, 1, intra_period, False, frames=clip)
+    frames, recon, order, flags_seen, packets, infos, refpics, _ = run_clip(W, H, N, enc_mode, tune, qp, 1, intra_period, False, frames=clip, env=env)
     recs, outs = oracle_clip(frames, W, H, N, enc_mode, tune, qp, 1, intra_period, False)
     assert sorted(order) == list(range(N)) and len(packets) == N and packets[-1][1] & 1 and flags_seen[-1] == 1
     for k in range(N):
