@@ -52,6 +52,9 @@
 #include "../../include/svtvp9_hip.h"
 #include "../csrc/encdec_core.h" /* svt_tq_unit_is_origin: the block rules the device-side driver applies to a mode-info grid */
 
+/* host/copy_pool.c of libsvtvp9_hip.so: rows copied by a few threads (the staging copy of the uploads uses it too) */
+void svt_copy_rows_mt(uint8_t *dst, size_t dst_stride, const uint8_t *src, size_t src_stride, size_t width, size_t rows);
+
 #define SHIM_MAX_MINIGOP 16
 #define SHIM_MAX_DEV 8
 #define SHIM_REF_PAD 80 /* border of a reference picture: 64 + 16 (Codec/EbEncHandle.c:968-971) */
@@ -1276,7 +1279,8 @@ EbErrorType eb_vp9_svt_get_recon(EbComponentType *h, EbBufferHeaderType *p_buffe
     if (q == 0) return EB_NoErrorEmptyQueue;
     if (p_buffer->p_buffer) {
         if (p_buffer->n_alloc_len && p_buffer->n_alloc_len < s->pic_bytes) return EB_ErrorBadParameter;
-        memcpy(p_buffer->p_buffer, r->host, s->pic_bytes);
+        /* Y | Cb | Cr, tight: W x (H * 3 / 2) bytes as rows of W for the library's copy pool (a few threads) */
+        svt_copy_rows_mt((uint8_t *)p_buffer->p_buffer, (size_t)s->W, r->host, (size_t)s->W, (size_t)s->W, (size_t)s->H * 3 / 2);
     }
     p_buffer->size = sizeof(EbBufferHeaderType);
     p_buffer->n_filled_len = (uint32_t)s->pic_bytes;
