@@ -221,7 +221,8 @@ def api_path_rate(frames, Wd, Hd, enc_mode, tune, n_send=130):
                 f.write((y[::2, ::2] // 2 + 32).astype(np.uint8).tobytes())     # SURVEY 8(d)'s clip: U = Y / 2 + 32, V = 128
                 f.write(np.full((Hd // 2, Wd // 2), 128, np.uint8).tobytes())
         for recon in (0, 1):
-            r = subprocess.run([exe, path, str(Wd), str(Hd), str(len(frames)), str(n_send), str(enc_mode), str(tune), str(recon)], capture_output=True, text=True)
+            env_api = {k_: v_ for k_, v_ in os.environ.items() if k_ != "SVT_HIP_INTRA_WGS" or INTRA_WGS_FROM_CALLER}   # the application's own process: library defaults
+            r = subprocess.run([exe, path, str(Wd), str(Hd), str(len(frames)), str(n_send), str(enc_mode), str(tune), str(recon)], capture_output=True, text=True, env=env_api)
             if r.returncode != 0:
                 return {"error": f"svt_enc_api_bench rc={r.returncode}: {(r.stdout + r.stderr).strip()[-200:]}"}
             d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -330,6 +331,9 @@ RING = 8   # mini-GOPs whose reference pictures are alive at a time (the diagona
 INTRA_PERIOD = 64   # pictures per closed GOP behind its key frame (-intra-period 64 at 60 fps: one key frame per 64 inter pictures)
 
 
+INTRA_WGS_FROM_CALLER = "SVT_HIP_INTRA_WGS" in os.environ
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -377,6 +381,10 @@ def main():
     GS = importlib.util.module_from_spec(_sp)
     _sp.loader.exec_module(GS)
     B = T.B
+    # The intra pass of a key frame runs beside the step's other work: 128 workgroups instead of one per CU (the library's default, the
+    # lowest latency for a key frame alone: 6.5 vs 7.9 ms) leave half of the CUs with all five motion-estimation workgroups resident --
+    # `value` 5 900 -> 6 030 (gpurun_in/bench_intra_wgs.sh; 64: the pass takes longer than a step).  A deployment knob of the library.
+    os.environ.setdefault("SVT_HIP_INTRA_WGS", "128")
     lib = B.load()
     dev = torch.device("cuda", local_rank)
     Wd, Hd, enc_mode, tune = PRESETS[args.preset]

@@ -326,7 +326,7 @@ int32_t svt_intra_launch(svt_hip_ctx *ctx, const svt_encdec_picture *p, int32_t 
     HIP_TRY(hipMemsetAsync(d_sync, 0, (size_t)(2 + 3 * n_area) * sizeof(int32_t), ctx->stream));
     /* (function-local statics with an initialiser: initialised once, thread-safely -- several contexts may launch from several threads) */
     static const int wg_per_cu = [] { const char *e = getenv("SVT_HIP_INTRA_WG_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
-    static const int wg_cap = [] { const char *e = getenv("SVT_HIP_INTRA_WGS"); return e && atoi(e) > 0 ? atoi(e) : 0; }(); /* experiment knob */
+    static const int wg_cap = [] { const char *e = getenv("SVT_HIP_INTRA_WGS"); return e && atoi(e) > 0 ? atoi(e) : 0; }(); /* deployment knob: fewer workgroups = a longer pass that leaves more of the device to what runs beside it (bench.py: 128) */
     int grid = ctx->cu_count * wg_per_cu;
     if (wg_cap && grid > wg_cap) grid = wg_cap;
     if (grid > 3 * n_area) grid = 3 * n_area;
