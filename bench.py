@@ -383,7 +383,7 @@ def main():
     B = T.B
     # The intra pass of a key frame runs beside the step's other work: 128 workgroups instead of one per CU (the library's default, the
     # lowest latency for a key frame alone: 6.5 vs 7.9 ms) leave half of the CUs with all five motion-estimation workgroups resident --
-    # `value` 5 900 -> 6 030 (gpurun_in/bench_intra_wgs.sh; 64: the pass takes longer than a step).  A deployment knob of the library.
+    # `value` 5 900 -> 6 030 (tools/bench_intra_wgs.sh, profiles/r05_lf_launch_shape.txt; 64: the pass takes longer than a step).  A deployment knob of the library.
     os.environ.setdefault("SVT_HIP_INTRA_WGS", "128")
     lib = B.load()
     dev = torch.device("cuda", local_rank)
