@@ -1,4 +1,7 @@
 #!/bin/bash
+# tools/api_host_profile.sh -- the public-API path (app/svt_enc_api_bench, 2160p, 130 and 600 pictures, best of 4) under a list of environment
+# settings, with the host-time profile of the upload (SVT_HIP_SHIM_PROFILE=1).  Edit the `for extra in [...]` list for a sweep; RECON=1: with
+# every reconstruction fetched.  Outputs of the round: profiles/r05_api_sweeps.txt.
 # API path host profile: one run of 600 pictures, feeder on, 4 copy threads
 python - <<'PY'
 import json, os, subprocess, sys, tempfile

@@ -1,3 +1,6 @@
+"""tools/lf_launch_shape.py -- the deblocking launch alone on the GPU, 2160p, 1 / 2 / 4 / 16 pictures per launch (ms per launch).  With
+SVT_HIP_LF_ROWS / SVT_HIP_LF_EARLY for the launch-shape sweep of profiles/r05_lf_launch_shape.txt; SVT_HIP_LF_PROFILE=1 (+ SVT_HIP_LF_ROWTS=1)
+prints the per-stage cycle shares (and per-row time stamps) of the kernel."""
 import ctypes as C, os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
