@@ -19,11 +19,7 @@ ME_LAYOUT_FN void me_lds_layout_geom(const svt_me_params *p, me_lds_layout *L) {
     if (saw < 1) saw = 1;
     if (sah < 1) sah = 1;
     int W = saw + ME_SB - 1, H = sah + ME_SB - 1;
-#ifdef ME_TEST_NOTAIL /* timing experiment only */
-    int rs = me_round_up(W + ME_RGN_GX + 4, 4);
-#else
-    int rs = me_round_up(W + ME_RGN_GX + 4 + 16, 4);
-#endif
+    int rs = me_round_up(W + ME_RGN_GX + 4 + 16, 4); /* (+ 16: the last 16-byte unit of a row of a clipped area) */
     if (((rs >> 2) & 1) == 0) rs += 4; /* odd number of dwords per row: rows spread over LDS banks */
     L->region_stride = rs;
     L->region_rows   = H + 2 * ME_RGN_GY + 1;
