@@ -819,7 +819,12 @@ def main():
     skip_share = float(np.mean([d_lf[0][i].cpu().numpy().view(B.LF_MODE_INFO_DTYPE)["skip"].mean() for i in range(1, MINIGOP + 1)]))
     workload_stats = {"mean_abs_luma_residual_gop0": round(float(np.mean(resid_acc)), 2),
                       "mean_luma_eob_by_tx_size": [round(float(np.concatenate(eob_by_size[ts]).mean()), 1) if sum(len(a) for a in eob_by_size[ts]) else None for ts in range(4)],
-                      "transform_blocks_by_tx_size_per_step": [int(v) for v in blocks_by_size], "skip_block_share_gop0": round(skip_share, 3)}
+                      "transform_blocks_by_tx_size_per_step": [int(v) for v in blocks_by_size],
+                      # the synthesised partition: share of the step's transform blocks / of its samples per transform size (4x4, 8x8, 16x16, 32x32)
+                      "tx_size_share_of_blocks": [round(float(v) / max(1, int(blocks_by_size.sum())), 3) for v in blocks_by_size],
+                      "tx_size_share_of_samples": [round(float(v) * (16 << (2 * k_)) / max(1.0, float(sum(int(b_) * (16 << (2 * j_)) for j_, b_ in enumerate(blocks_by_size)))), 3)
+                                                   for k_, v in enumerate(blocks_by_size)],
+                      "skip_block_share_gop0": round(skip_share, 3)}
     step_no = [1]   # the setup pass was step 0 (mini-GOP 0 complete in ring slot 0)
     extras = not args.no_extras and rank == 0
     P_single = None if (args.no_single or rank != 0) else build_pipeline([0], single_pairs, split="picture")
