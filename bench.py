@@ -221,8 +221,7 @@ def api_path_rate(frames, Wd, Hd, enc_mode, tune, n_send=130):
                 f.write((y[::2, ::2] // 2 + 32).astype(np.uint8).tobytes())     # SURVEY 8(d)'s clip: U = Y / 2 + 32, V = 128
                 f.write(np.full((Hd // 2, Wd // 2), 128, np.uint8).tobytes())
         for recon in (0, 1):
-            env_api = {k_: v_ for k_, v_ in os.environ.items() if k_ != "SVT_HIP_INTRA_WGS" or INTRA_WGS_FROM_CALLER}   # the application's own process: library defaults
-            r = subprocess.run([exe, path, str(Wd), str(Hd), str(len(frames)), str(n_send), str(enc_mode), str(tune), str(recon)], capture_output=True, text=True, env=env_api)
+            r = subprocess.run([exe, path, str(Wd), str(Hd), str(len(frames)), str(n_send), str(enc_mode), str(tune), str(recon)], capture_output=True, text=True)
             if r.returncode != 0:
                 return {"error": f"svt_enc_api_bench rc={r.returncode}: {(r.stdout + r.stderr).strip()[-200:]}"}
             d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -381,10 +380,6 @@ def main():
     GS = importlib.util.module_from_spec(_sp)
     _sp.loader.exec_module(GS)
     B = T.B
-    # The intra pass of a key frame runs beside the step's other work: 128 workgroups instead of one per CU (the library's default, the
-    # lowest latency for a key frame alone: 6.5 vs 7.9 ms) leave half of the CUs with all five motion-estimation workgroups resident --
-    # `value` 5 900 -> 6 030 (tools/bench_intra_wgs.sh, profiles/r05_lf_launch_shape.txt; 64: the pass takes longer than a step).  A deployment knob of the library.
-    os.environ.setdefault("SVT_HIP_INTRA_WGS", "128")
     lib = B.load()
     dev = torch.device("cuda", local_rank)
     Wd, Hd, enc_mode, tune = PRESETS[args.preset]
@@ -416,6 +411,16 @@ def main():
     pa_stream, ctx_pa = new_ctx(prio[0])
     # the key frames' encode pass: beside the inter batches of its GOP group (SVT_BENCH_KEY_STREAMS: how many streams they share)
     key_streams = [new_ctx(prio[1]) for _ in range(max(1, min(n_groups, int(os.environ.get("SVT_BENCH_KEY_STREAMS", str(n_groups))))))]
+
+    # The intra pass of a key frame runs beside the step's other work in the pipelined schedules: 128 workgroups instead of one per CU (the
+    # library's default, the lowest latency for a key frame alone: 6.5 vs 7.9 ms) leave half of the CUs with all five motion-estimation
+    # workgroups resident -- `value` 5 900 -> 6 030 (tools/bench_intra_wgs.sh, profiles/r05_lf_launch_shape.txt; 64: the pass takes longer
+    # than a step).  One GOP at a time (single_*_value) the key frame is on the critical path: the default there.  A deployment knob of the
+    # library (svt_hip_ctx_set_intra_workgroups; SVT_HIP_INTRA_WGS in the environment overrides both).
+    def key_workgroups(n):
+        if not INTRA_WGS_FROM_CALLER:
+            for _, c_ in key_streams:
+                B.check(lib.svt_hip_ctx_set_intra_workgroups(c_, n))
     single_pairs = [new_ctx(prio[1]) for _ in range(max(1, int(os.environ.get("SVT_BENCH_SINGLE_STREAMS", "2"))))]
 
     geo = Geometry(Wd, Hd)
@@ -1008,6 +1013,7 @@ def main():
         me_launches = [(e0.elapsed_time(e1)) for name, sid, e0, e1 in S["ev"] if name == "me"]
         return dt, t_enq / n_free, stage_ms, stage_ms_sum, me_launches
 
+    key_workgroups(int(os.environ.get("SVT_BENCH_KEY_WGS", "128")))
     dt, enq_s, stage_ms, stage_ms_sum, me_launch_list = timed_run(P_main, args.schedule, args.steps, args.warmup, True)
     n_keys_main = P_main["n_keys"]
     dt = GS.reduce_elapsed(dt, dist if world > 1 else None, dev if os.environ.get("SVT_BENCH_BACKEND", "nccl") == "nccl" else None)
@@ -1021,7 +1027,9 @@ def main():
     if P_single is not None:
         k1 = max(4, args.steps)
         for sched in ("diagonal", "waves"):
+            key_workgroups(0)
             dt1, enq1, stage1, _, _ = timed_run(P_single, sched, k1, max(2, args.warmup), False)
+            key_workgroups(int(os.environ.get("SVT_BENCH_KEY_WGS", "128")))
             single[sched] = {"frames_per_s": (MINIGOP * k1 + P_single["n_keys"]) / dt1, "ms_per_minigop": dt1 / k1 * 1e3, "steps": k1, "stage_ms": stage1, "enq": enq1}
     ref_flags = None
     me_alone = None
@@ -1116,6 +1124,7 @@ def main():
             "what": f"one key frame per closed GOP of {INTRA_PERIOD} inter pictures: its encode pass (svt_hip_encdec_intra_device: prediction + transform wavefront, "
                     "deblocking, border; stand-in decision 16x16 DC) runs inside the timed step on the GOP group's key stream, one step ahead of the mini-GOP "
                     "that predicts from it; `value` counts it as one frame, `value_inter_only` is the same step without key frames",
+            "workgroups": int(os.environ.get("SVT_BENCH_KEY_WGS", "128")),   # svt_hip_ctx_set_intra_workgroups on the key streams (default of the library: one per CU)
             "alone_ms": round(key_alone_ms, 3) if key_alone_ms else None,
             "ms_per_step_with": round(dt / args.steps * 1e3, 3), "ms_per_step_without": round(inter_only["ms_per_step"], 3) if inter_only else None,
             "hidden_fraction": (round(1.0 - max(0.0, dt / args.steps * 1e3 - inter_only["ms_per_step"]) / max(1e-9, key_alone_ms * n_keys_main / args.steps), 3)

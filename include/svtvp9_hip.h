@@ -170,6 +170,12 @@ int32_t svt_hip_me_kernel_instance(const svt_me_params *p);
 /* diagnostic: the instance the last ME launch on ctx actually ran -- the index above, + 100 when the launch was served by the
  * driver for single-region level-0 HME presets (csrc/me_fast.h: whole SB columns, level-0 areas up to 256 x 256) */
 int32_t svt_hip_me_last_instance(const svt_hip_ctx *ctx);
+/* Deployment knob of the intra encode pass (svt_hip_encdec_intra_device, and the intra blocks of inter pictures) launched on ctx: at most n
+ * one-wave workgroups (0 = the default: one per compute unit, the lowest latency for a key frame alone -- 6.5 ms at 2160p).  A pass that runs
+ * BESIDE other work of the device (a key frame of the next GOP beside the current one) leaves more of it to that work with fewer: every CU
+ * that hosts one of its waves has registers for one motion-estimation workgroup less (128: 7.9 ms alone, +2 % for the pipelined step of
+ * bench.py).  The environment's SVT_HIP_INTRA_WGS sets the process-wide default. */
+int32_t svt_hip_ctx_set_intra_workgroups(svt_hip_ctx *ctx, int32_t n);
 /* 1 when two parameter sets may share one launch of svt_hip_me_batch_layers_device: equal in every field but num_ref_lists,
  * temporal_layer_index, hierarchical_levels and same_ref_poc (compared field by field: the record has padding) */
 int32_t svt_hip_me_params_same_launch(const svt_me_params *a, const svt_me_params *b);

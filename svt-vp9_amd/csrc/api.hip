@@ -67,6 +67,11 @@ extern "C" int32_t svt_hip_ctx_create_cu_mask(svt_hip_ctx **ctx, int32_t device,
     return ctx_create(ctx, device, nullptr, 1, cu_mask, mask_words);
 }
 extern "C" void *svt_hip_ctx_stream(svt_hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" int32_t svt_hip_ctx_set_intra_workgroups(svt_hip_ctx *c, int32_t n) {
+    if (!c || n < 0) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "ctx: intra workgroups");
+    c->intra_wgs = n;
+    return SVT_HIP_OK;
+}
 
 extern "C" void svt_hip_ctx_destroy(svt_hip_ctx *c) {
     if (!c) return;

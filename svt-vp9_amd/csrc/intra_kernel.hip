@@ -328,7 +328,8 @@ int32_t svt_intra_launch(svt_hip_ctx *ctx, const svt_encdec_picture *p, int32_t 
     static const int wg_per_cu = [] { const char *e = getenv("SVT_HIP_INTRA_WG_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
     static const int wg_cap = [] { const char *e = getenv("SVT_HIP_INTRA_WGS"); return e && atoi(e) > 0 ? atoi(e) : 0; }(); /* deployment knob: fewer workgroups = a longer pass that leaves more of the device to what runs beside it (bench.py: 128) */
     int grid = ctx->cu_count * wg_per_cu;
-    if (wg_cap && grid > wg_cap) grid = wg_cap;
+    const int cap = ctx->intra_wgs > 0 ? ctx->intra_wgs : wg_cap; /* the context's setting (svt_hip_ctx_set_intra_workgroups) before the environment's */
+    if (cap && grid > cap) grid = cap;
     if (grid > 3 * n_area) grid = 3 * n_area;
     hipLaunchKernelGGL(svt_intra_kernel, dim3(grid), dim3(64), 0, ctx->stream, P);
     HIP_TRY(hipGetLastError());
