@@ -137,6 +137,16 @@ template <int N> __device__ __forceinline__ void row_store(uint8_t *p, bool vec,
     }
 }
 
+/* Between the passes of a block its N lanes exchange rows and columns through the block's LDS tile.  N <= 32: the lanes of a block sit in
+ * ONE wave, and the LDS executes the accesses of a wave in the order they were issued -- so what has to be kept is the order of the
+ * instructions, not a rendezvous of the workgroup's four waves.  (Until round 5 these were __syncthreads(): the 32x32 instance -- 13 % of
+ * the stage's vector instructions -- took 38 % of its time, its waves waiting for each other five times per block.) */
+__device__ __forceinline__ void tq_block_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int clamp16(int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; }
 __device__ __forceinline__ uint8_t clip_add(int d, int t) { int v = d + t; return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
 
@@ -144,8 +154,8 @@ __device__ __forceinline__ uint8_t clip_add(int d, int t) { int v = d + t; retur
  * i: the lane's column (first pass) / row (second pass); t: the block's N x (N + 1) dword LDS tile; srow / prow: row i of source and
  * prediction, packed; eob_slot / dist_slot / bits_slot: where the block's results go (dist_slot may be null; bits_slot, rate_T, s_tc,
  * s_scan only with RATE); recon_base + k.recon_off = the block's reconstruction; dqcoeff may be null (the dequantised coefficients then
- * go from the quantiser to the inverse transform in registers and nowhere else).  Contains workgroup barriers: every lane of the
- * workgroup has to call it, with k.do_recon uniform over the workgroup.  Returns the block's eob (every lane of the block). */
+ * go from the quantiser to the inverse transform in registers and nowhere else).  Every lane of a wave has to call it (the block's lanes
+ * meet in tq_block_sync), with k.do_recon uniform over the wave.  Returns the block's eob (every lane of the block). */
 /* WT: the reconstruction is stored write-through (agent-scope dword stores), for a caller whose neighbour blocks are read by other
  * workgroups of the SAME launch (intra_kernel.hip): they then see it without a release fence -- on this part an agent-scope release /
  * acquire pair writes back / invalidates the whole L2 of the XCD, for every kernel running beside the caller */
@@ -185,7 +195,7 @@ __device__ __forceinline__ int tq_block_body(const svt_tq_block &k, const bool a
         _Pragma("unroll") for (int kk = 0; kk < N; kk++)
             t[kk * LS + i] = (N == 16) ? (int16_t)((o[kk] + 1 + (o[kk] < 0)) >> 2) : (int16_t)o[kk];
     }
-    __syncthreads();
+    tq_block_sync();
     /* ---- row transform (row i = vertical frequency i) ---- */
     _Pragma("unroll") for (int kk = 0; kk < N; kk++) v[kk] = t[i * LS + kk];
     int32_t c[N]; /* coefficients of row i */
@@ -307,7 +317,7 @@ __device__ __forceinline__ int tq_block_body(const svt_tq_block &k, const bool a
         if (N == 16) nrows = eob <= 10 ? 4 : eob <= 38 ? 8 : 16;
         if (N == 32) nrows = eob <= 34 ? 8 : eob <= 135 ? 16 : 32;
     }
-    __syncthreads(); /* tile is reused */
+    tq_block_sync(); /* tile is reused */
     if (eob != 0 && !dc_only) {
         if (i < nrows) inv1d<N>(dq, o, row_adst);
         else { _Pragma("unroll") for (int kk = 0; kk < N; kk++) o[kk] = 0; }
@@ -315,7 +325,7 @@ __device__ __forceinline__ int tq_block_body(const svt_tq_block &k, const bool a
     } else if (eob != 0 && i == 0) {
         t[0] = dq[0];
     }
-    __syncthreads();
+    tq_block_sync();
     if (eob != 0 && !dc_only) {
         _Pragma("unroll") for (int r = 0; r < N; r++) v[r] = t[r * LS + i];
         inv1d<N>(v, o, col_adst);

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(N == 32 ? (
     if constexpr (RATE) bits_slot = ra.bits + blk;
     tq_block_body<N, RATE, DIST>(k, active, i, t, srow, prow, qtabs, iscan_all, qcoeff, dqcoeff, eob_out + blk, dist_out ? dist_out + 2 * blk : nullptr, bits_slot,
                                  ra.T, s_tc, s_scan, recon_set ? (uint8_t *)recon_set[(k.pad_[0] >> 4) & 7] : recon);
-    __syncthreads(); /* the tile is rewritten by the next group */
+    tq_block_sync(); /* the block's tile is rewritten by its lanes' next block */
   }
 }
 
