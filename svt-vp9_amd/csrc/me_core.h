@@ -764,6 +764,97 @@ template <int NG> SVT_DEV void me_fullpel_fused_dev(const me_ctx_t *c, int tid, 
 }
 #endif
 
+#ifndef SVT_HOST_EMU
+/* The same phase for the LARGE areas whose width is a multiple of 16 (64 x 64 at the enc-mode <= 5 presets: 1024 groups of four positions
+ * per list).  There the layout above is bound by the LDS, not by the vector unit: every group fetches its window again -- twelve 512-byte
+ * LDS reads per group and wave, 8.5 cycles each with the two-way bank conflicts of the z-order: 104 K of the phase's 127 K cycles per list
+ * (timing builds without the reads / without the QSADs: `profiles/r05_pmc_traffic.md`).  Two changes:
+ *   - a lane walks a RUN of four groups (16 positions) along a search row: the six dwords of a window row serve all four (a group's two
+ *     operand pairs overlap its neighbours'), three LDS reads instead of eight -- with the source block in registers 3 reads per group
+ *     instead of 12;
+ *   - a lane is a 16x16 PU (z-order) and one of FOUR consecutive runs (lane >> 4 -- a wave covers a whole row of 64 positions per
+ *     iteration) and walks its four 8x8 blocks itself: the 16x16 sums are packed adds inside the lane, the 32x32 sums one packed and one
+ *     32-bit quad step, the 64x64 sums two row rotations -- ~19 instructions per group beside its 8 QSADs instead of 48.
+ * The four runs' minima of a PU sit in four rows of the wave and meet at the end through a swizzle and two-way LDS minima (amortised over
+ * the 16 iterations a wave runs per list; the small areas keep the layout above). */
+SVT_DEV void me_fullpel_fused16_dev(const me_ctx_t *c, int tid, int sw, int sh) {
+    const int rs = c->L.region_stride;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pg = lane >> 4, b = lane & 15;
+    const int bx = ((b & 1) | ((b >> 1) & 2)) * 16, by = (((b >> 1) & 1) | ((b >> 2) & 2)) * 16;
+    uint32_t  sx[4][4], sy[4][4]; /* [8x8 block][row 0, 2, 4, 6]: the two source dwords */
+    _Pragma("unroll") for (int k = 0; k < 4; k++)
+        _Pragma("unroll") for (int r = 0; r < 4; r++) {
+            const uint2 v = *(const uint2 *)(c->src + ME_MUL(by + (k >> 1) * 8 + 2 * r, ME_SB) + bx + (k & 1) * 8);
+            sx[k][r] = v.x; sy[k][r] = v.y;
+        }
+    const uint32_t rbase = (uint32_t)(c->region - c->lds) + (uint32_t)(ME_MUL(ME_RGN_GY + by, rs) + ME_RGN_GX + bx);
+    uint32_t mhi = 0xffff0000u;
+    __asm__("" : "+v"(mhi));
+    const int      rpr = sw >> 4, nrun = ME_MUL(rpr, sh);           /* runs of 16 positions per search row / in the area */
+    const uint32_t inv = me_magics.v[rpr];
+    uint32_t       b8[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, b16 = 0xffffffffu, b32 = 0xffffffffu, b64 = 0xffffffffu;
+#define FQ_DPP(v, ctrl) ((v) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xf, 0xf, false))
+#define FQ_KEYS(bb, lo, hi, pos) do { \
+        bb = me_min3(bb, ((lo) << 16) | (pos), ((lo) & mhi) | ((pos) + 1)); \
+        bb = me_min3(bb, ((hi) << 16) | ((pos) + 2), ((hi) & mhi) | ((pos) + 3)); } while (0)
+    for (int q0 = 4 * w; q0 < nrun; q0 += 16) { /* the waves take four runs at a time, round-robin; a run past the end repeats the last one */
+        const int      q = q0 + pg < nrun ? q0 + pg : nrun - 1;
+        const int      y = inv ? (int)__umulhi((uint32_t)q, inv) : q, xr = q - ME_MUL(y, rpr);
+        const uint32_t pos0 = (uint32_t)(ME_MUL(y, sw) + 16 * xr);
+        const uint8_t *rp = c->lds + (rbase + (uint32_t)(ME_MUL(y, rs) + 16 * xr));
+        uint32_t       lo[4][4], hi[4][4]; /* [8x8 block][group of the run] */
+        _Pragma("unroll") for (int k = 0; k < 4; k++) {
+            const uint8_t *wp = rp + ME_MUL((k >> 1) * 8, rs) + (k & 1) * 8;
+            uint64_t       acc[4] = {0, 0, 0, 0};
+            _Pragma("unroll") for (int r = 0; r < 4; r++) {
+                const uint32_t *wr = (const uint32_t *)(wp + ME_MUL(2 * r, rs));
+                const uint32_t  d0 = wr[0], d1 = wr[1], d2 = wr[2], d3 = wr[3], d4 = wr[4], d5 = wr[5];
+                acc[0] = svt_qsad(((uint64_t)d1 << 32) | d0, sx[k][r], acc[0]); acc[0] = svt_qsad(((uint64_t)d2 << 32) | d1, sy[k][r], acc[0]);
+                acc[1] = svt_qsad(((uint64_t)d2 << 32) | d1, sx[k][r], acc[1]); acc[1] = svt_qsad(((uint64_t)d3 << 32) | d2, sy[k][r], acc[1]);
+                acc[2] = svt_qsad(((uint64_t)d3 << 32) | d2, sx[k][r], acc[2]); acc[2] = svt_qsad(((uint64_t)d4 << 32) | d3, sy[k][r], acc[2]);
+                acc[3] = svt_qsad(((uint64_t)d4 << 32) | d3, sx[k][r], acc[3]); acc[3] = svt_qsad(((uint64_t)d5 << 32) | d4, sy[k][r], acc[3]);
+            }
+            _Pragma("unroll") for (int j = 0; j < 4; j++) {
+                lo[k][j] = (uint32_t)acc[j]; hi[k][j] = (uint32_t)(acc[j] >> 32);
+                FQ_KEYS(b8[k], lo[k][j], hi[k][j], pos0 + 4 * j);
+            }
+        }
+        _Pragma("unroll") for (int j = 0; j < 4; j++) {
+            const uint32_t pos = pos0 + 4 * j;
+            /* 16x16: inside the lane (8 rows x 16 samples x 255 < 2^16: the packed halves do not carry) */
+            uint32_t l16 = lo[0][j] + lo[1][j] + lo[2][j] + lo[3][j], h16 = hi[0][j] + hi[1][j] + hi[2][j] + hi[3][j];
+            FQ_KEYS(b16, l16, h16, pos);
+            /* 32x32: the quad.  Two PUs still fit 16 bits; the second step runs on 32-bit sums */
+            l16 = FQ_DPP(l16, 0xB1); h16 = FQ_DPP(h16, 0xB1);                       /* quad_perm:[1,0,3,2] */
+            uint32_t a0 = l16 & 0xffffu, a1 = l16 >> 16, a2 = h16 & 0xffffu, a3 = h16 >> 16;
+            a0 = FQ_DPP(a0, 0x4E); a1 = FQ_DPP(a1, 0x4E); a2 = FQ_DPP(a2, 0x4E); a3 = FQ_DPP(a3, 0x4E); /* quad_perm:[2,3,0,1] */
+            b32 = me_min3(b32, (a0 << 12) | pos, (a1 << 12) | (pos + 1));
+            b32 = me_min3(b32, (a2 << 12) | (pos + 2), (a3 << 12) | (pos + 3));
+            /* 64x64: the four quads of the run's row of 16 lanes */
+            a0 = FQ_DPP(a0, 0x124); a1 = FQ_DPP(a1, 0x124); a2 = FQ_DPP(a2, 0x124); a3 = FQ_DPP(a3, 0x124); /* row_ror:4 */
+            a0 = FQ_DPP(a0, 0x128); a1 = FQ_DPP(a1, 0x128); a2 = FQ_DPP(a2, 0x128); a3 = FQ_DPP(a3, 0x128); /* row_ror:8 */
+            b64 = me_min3(b64, (a0 << 12) | pos, (a1 << 12) | (pos + 1));
+            b64 = me_min3(b64, (a2 << 12) | (pos + 2), (a3 << 12) | (pos + 3));
+        }
+    }
+#undef FQ_KEYS
+#undef FQ_DPP
+    /* the four runs' minima of a PU: rows pg and pg ^ 1 meet through a swizzle (lane ^ 16), the two halves of the wave in the LDS minimum */
+#define FQ_X16(v) do { const uint32_t o_ = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(v), 0x401F); v = o_ < v ? o_ : v; } while (0)
+    _Pragma("unroll") for (int k = 0; k < 4; k++) FQ_X16(b8[k]);
+    FQ_X16(b16); FQ_X16(b32); FQ_X16(b64);
+#undef FQ_X16
+    uint64_t *key = c->st->key;
+    if ((pg & 1) == 0 && b16 != 0xffffffffu) { /* (a wave that took no run keeps nothing) */
+        _Pragma("unroll") for (int k = 0; k < 4; k++) svt_lds_min_u64(&key[21 + 4 * b + k], ((uint64_t)((b8[k] >> 16) << 1) << 32) | (b8[k] & 0xffffu));
+        svt_lds_min_u64(&key[5 + b], ((uint64_t)((b16 >> 16) << 1) << 32) | (b16 & 0xffffu));
+        if ((b & 3) == 0) svt_lds_min_u64(&key[1 + (b >> 2)], ((uint64_t)((b32 >> 12) << 1) << 32) | (b32 & 0xfffu));
+        if (b == 0) svt_lds_min_u64(&key[0], ((uint64_t)((b64 >> 12) << 1) << 32) | (b64 & 0xfffu));
+    }
+}
+#endif
+
 /* full-pel, search areas whose width is a multiple of 8 (no tail path) with at most 4096 positions: SADs, the nested sums and
  * the per-PU arg-min in ONE phase without the table.  Lane = 8x8 block in z-order, so a DPP quad is a 16x16 PU, a DPP row of
  * 16 lanes a 32x32 PU and the wave the 64x64 PU; the four waves take the groups of 4 positions round-robin.  A lane keeps one
@@ -797,7 +888,8 @@ SVT_DEV void ph_fullpel_fused(const me_ctx_t *c, int tid, int sw, int sh, int un
             for (int i = 0; i < 64; i++) svt_lds_min_u64(&c->st->key[21 + i], ((uint64_t)(2u * s8[i]) << 32) | pos);
         }
 #else
-    if (unroll2) me_fullpel_fused_dev<2>(c, tid, sw, sh);
+    if (unroll2 && (sw & 15) == 0) me_fullpel_fused16_dev(c, tid, sw, sh);
+    else if (unroll2) me_fullpel_fused_dev<2>(c, tid, sw, sh);
     else me_fullpel_fused_dev<1>(c, tid, sw, sh);
 #endif
 }
