@@ -772,9 +772,9 @@ template <int NG> SVT_DEV void me_fullpel_fused_dev(const me_ctx_t *c, int tid, 
  *   - a lane walks a RUN of four groups (16 positions) along a search row: the six dwords of a window row serve all four (a group's two
  *     operand pairs overlap its neighbours'), three LDS reads instead of eight -- with the source block in registers 3 reads per group
  *     instead of 12;
- *   - a lane is a 16x16 PU (z-order) and one of FOUR consecutive runs (lane >> 4 -- a wave covers a whole row of 64 positions per
- *     iteration) and walks its four 8x8 blocks itself: the 16x16 sums are packed adds inside the lane, the 32x32 sums one packed and one
+ *   - a lane is a 16x16 PU (z-order) and one of FOUR runs (lane >> 4) and walks its four 8x8 blocks itself: the 16x16 sums are packed adds inside the lane, the 32x32 sums one packed and one
  *     32-bit quad step, the 64x64 sums two row rotations -- ~19 instructions per group beside its 8 QSADs instead of 48.
+ *     (lane >> 4 picks one of four runs that lie UNDER each other, see the loop.)
  * The four runs' minima of a PU sit in four rows of the wave and meet at the end through a swizzle and two-way LDS minima (amortised over
  * the 16 iterations a wave runs per list; the small areas keep the layout above). */
 SVT_DEV void me_fullpel_fused16_dev(const me_ctx_t *c, int tid, int sw, int sh) {
@@ -792,7 +792,7 @@ SVT_DEV void me_fullpel_fused16_dev(const me_ctx_t *c, int tid, int sw, int sh) 
     uint32_t mhi = 0xffff0000u;
     __asm__("" : "+v"(mhi));
     const int      rpr = sw >> 4, nrun = ME_MUL(rpr, sh);           /* runs of 16 positions per search row / in the area */
-    const uint32_t inv = me_magics.v[rpr];
+    const uint32_t inv = me_magics.v[sh];   /* runs are numbered down the columns: the four runs of an iteration lie under each other (see below) */
     uint32_t       b8[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, b16 = 0xffffffffu, b32 = 0xffffffffu, b64 = 0xffffffffu;
 #define FQ_DPP(v, ctrl) ((v) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xf, 0xf, false))
 #define FQ_KEYS(bb, lo, hi, pos) do { \
@@ -800,7 +800,10 @@ SVT_DEV void me_fullpel_fused16_dev(const me_ctx_t *c, int tid, int sw, int sh) 
         bb = me_min3(bb, ((hi) << 16) | ((pos) + 2), ((hi) & mhi) | ((pos) + 3)); } while (0)
     for (int q0 = 4 * w; q0 < nrun; q0 += 16) { /* the waves take four runs at a time, round-robin; a run past the end repeats the last one */
         const int      q = q0 + pg < nrun ? q0 + pg : nrun - 1;
-        const int      y = inv ? (int)__umulhi((uint32_t)q, inv) : q, xr = q - ME_MUL(y, rpr);
+        /* column-major: the lanes of the four runs then differ by whole region rows (39 dwords: every bank offset) instead of by 16 bytes,
+         * which on top of the PUs' own 16-byte / 16-row spacing put most of a wave's reads into the same banks (bank-conflict cycles of the
+         * phase halved; its time is the vector unit's either way) */
+        const int      xr = inv ? (int)__umulhi((uint32_t)q, inv) : q, y = q - ME_MUL(xr, sh);
         const uint32_t pos0 = (uint32_t)(ME_MUL(y, sw) + 16 * xr);
         const uint8_t *rp = c->lds + (rbase + (uint32_t)(ME_MUL(y, rs) + 16 * xr));
         uint32_t       lo[4][4], hi[4][4]; /* [8x8 block][group of the run] */
