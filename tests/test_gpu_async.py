@@ -50,3 +50,49 @@ def test_async_upload_and_markers():
         B.check(lib.svt_hip_ctx_marker_wait(ctx, C.c_uint64(markers[0])))
     finally:
         lib.svt_hip_ctx_destroy(ctx)
+
+
+def test_planes_upload_one_slot_one_copy():
+    """svt_hip_mem_upload_planes_async: the planes of a picture through one staging slot -- back-to-back tight destinations (Y | Cb | Cr in one
+    buffer: one host-to-device copy) and separate, strided destinations; the caller's rows may be overwritten as soon as the call returns,
+    and more pictures than staging slots arrive intact."""
+    import torch
+    lib = B.load()
+    ctx = C.c_void_p()
+    B.check(lib.svt_hip_ctx_create(C.byref(ctx), 0))
+    try:
+        W, H, n = 640, 360, 7
+        rng = np.random.default_rng(9)
+        P, S = C.c_void_p * 3, C.c_size_t * 3
+        wb, rows = (W, W // 2, W // 2), (H, H // 2, H // 2)
+        src_st = (W + 16, W // 2 + 8, W // 2)
+        tight = [torch.zeros(W * H * 3 // 2, dtype=torch.uint8, device="cuda") for _ in range(n)]
+        apart = [[torch.zeros((r, w + 32), dtype=torch.uint8, device="cuda") for w, r in zip(wb, rows)] for _ in range(n)]
+        torch.cuda.synchronize()
+        bufs = [np.zeros((r, st), np.uint8) for r, st in zip(rows, src_st)]
+        want = []
+        for k in range(n):
+            for b_, w in zip(bufs, wb):
+                b_[:, :w] = rng.integers(0, 256, (b_.shape[0], w), dtype=np.uint8)
+            want.append([b_[:, :w].copy() for b_, w in zip(bufs, wb)])
+            base = tight[k].data_ptr()
+            B.check(lib.svt_hip_mem_upload_planes_async(ctx, 3, P(base, base + W * H, base + W * H + W * H // 4), S(*wb), P(*[b_.ctypes.data for b_ in bufs]), S(*src_st),
+                                                        S(*wb), S(*rows)))
+            B.check(lib.svt_hip_mem_upload_planes_async(ctx, 3, P(*[t.data_ptr() for t in apart[k]]), S(*[w + 32 for w in wb]), P(*[b_.ctypes.data for b_ in bufs]), S(*src_st),
+                                                        S(*wb), S(*rows)))
+            for b_ in bufs:
+                b_[:] = 0xEE                             # the caller reuses its rows at once
+        B.check(lib.svt_hip_ctx_synchronize(ctx))
+        for k in range(n):
+            flat = tight[k].cpu().numpy()
+            off = 0
+            for j, (w, r) in enumerate(zip(wb, rows)):
+                assert np.array_equal(flat[off:off + w * r].reshape(r, w), want[k][j]), (k, j)
+                off += w * r
+                a = apart[k][j].cpu().numpy()
+                assert np.array_equal(a[:, :w], want[k][j]) and not a[:, w:].any(), (k, j)
+        # argument checks: a null plane, a destination stride below the width
+        assert lib.svt_hip_mem_upload_planes_async(ctx, 3, P(tight[0].data_ptr(), None, None), S(*wb), P(*[b_.ctypes.data for b_ in bufs]), S(*src_st), S(*wb), S(*rows)) != 0
+        assert lib.svt_hip_mem_upload_planes_async(ctx, 1, P(tight[0].data_ptr(), None, None), S(W - 1, 0, 0), P(bufs[0].ctypes.data, None, None), S(*src_st), S(*wb), S(*rows)) != 0
+    finally:
+        lib.svt_hip_ctx_destroy(ctx)

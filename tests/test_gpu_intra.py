@@ -118,6 +118,19 @@ def test_intra_single_mode(ctx, size, mode):
     check(ctx, 192, 136, 70 + mode, 110, KEY, sizes=(8, size) if size > 8 else (8,), modes=(mode,))
 
 
+@pytest.mark.parametrize("n", [1, 3, 16, 100000])
+def test_intra_workgroup_cap_does_not_change_the_result(ctx, n):
+    """svt_hip_ctx_set_intra_workgroups: the pass on 1 / 3 / 16 persistent workgroups (tickets: any number makes progress) and on "more than
+    there are areas" gives the oracle chain's picture; 0 restores the default; a negative number is refused."""
+    lib = B.load()
+    try:
+        B.check(lib.svt_hip_ctx_set_intra_workgroups(ctx, n))
+        check(ctx, 320, 192, 3, 200, KEY, sizes=(4, 8, 16, 32))
+    finally:
+        B.check(lib.svt_hip_ctx_set_intra_workgroups(ctx, 0))
+    assert lib.svt_hip_ctx_set_intra_workgroups(ctx, -1) != 0
+
+
 def test_intra_no_filter_no_pad_and_stride(ctx):
     """recon-file style flags (filtered, not padded) and a grid wider than the picture"""
     check(ctx, 200, 136, 9, 180, dict(enc_mode=8, tune=1, temporal_layer_index=4, is_used_as_reference=0, recon_file=1, loop_filter=1), mi_stride=40)

@@ -93,6 +93,22 @@ def test_me_wide_search_area_and_empty_area(ctx):
         assert lib.svt_hip_me_picture(ctx, C.byref(dc), C.byref(d0), None, C.byref(p), res.ctypes.data_as(C.c_void_p), None) == -1
 
 
+@pytest.mark.parametrize("wh", [(64, 32), (48, 48), (32, 64), (64, 64), (40, 56), (16, 127)])
+def test_me_large_search_areas_full_pel_layouts(ctx, wh):
+    """The fused full-pel phase has two lane layouts: areas of at least 2048 positions whose width is a multiple of 16 take the run-walking
+    16x16-PU layout (csrc/me_core.h me_fullpel_fused16_dev), the others the 8x8-block one (width 40: two groups per iteration; 16 x 127: a
+    tall, narrow area, runs numbered down the columns).  All of them against the oracle, on a clip with sub-pel motion and on flat pictures
+    (every position ties: the first minimum in raster order has to come out of the key minima whatever the order the lanes visit positions in)."""
+    pics = [T.PaPic(f) for f in T.gen_clip_subpel(264, 200, 3, 29)]
+    p = MC.preset_c5(2, 2)
+    p.search_area_width, p.search_area_height = wh
+    _check(ctx, pics, p, 2)
+    flat = [T.PaPic(np.full((136, 200), v, dtype=np.uint8)) for v in (90, 90, 91)]
+    p1 = MC.preset_c5(1, 0)
+    p1.search_area_width, p1.search_area_height = wh
+    _check(ctx, flat, p1, 1)
+
+
 def test_me_random_content(ctx):
     """Uniform random pictures: worst case for ties/early outs (there are none in the SAD paths)."""
     rng = np.random.default_rng(3)
