@@ -2380,11 +2380,14 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                  * between the regions) runs on one thread and lives in LDS; the 256 threads only execute the load and
                  * search phases of each batch of windows.  The three levels share one instance of that code. */
                 const int last_lvl = p->enable_hme_level_2_flag ? 2 : p->enable_hme_level_1_flag ? 1 : 0;
-                int       first = 1;
+                int       first = 1, planned = 0;
+#define ME_HME_LEVEL_ON(l) ((l) == 0 ? p->enable_hme_level_0_flag : (l) == 1 ? p->enable_hme_level_1_flag : p->enable_hme_level_2_flag)
                 for (int lvl = 0; lvl < 3; lvl++) {
-                    if (!(lvl == 0 ? p->enable_hme_level_0_flag : lvl == 1 ? p->enable_hme_level_1_flag : p->enable_hme_level_2_flag)) continue;
+                    if (!ME_HME_LEVEL_ON(lvl)) continue;
                     ME_SUBMARK_BEGIN();
-                    ME_UNIFORM_WRITE(me_hme_plan_level(c, list, lvl, xsc, ysc, first));
+                    /* (the plan of every level but the first rides with the previous level's finish: one single-thread section and one
+                       barrier less per level) */
+                    if (!planned) ME_UNIFORM_WRITE(me_hme_plan_level(c, list, lvl, xsc, ysc, first));
                     ME_SUBMARK(20);
                     ME_STOP_AT(19);
                     first = 0;
@@ -2408,9 +2411,13 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                         ME_STOP_AT(21);
                     }
                     ME_SUBMARK(22);
-                    ME_UNIFORM_WRITE(me_hme_finish_level(c, lvl); if (lvl == last_lvl) me_hme_select(c, list));
+                    int nxt = -1;
+                    for (int l2 = lvl + 1; l2 < 3 && nxt < 0; l2++) if (ME_HME_LEVEL_ON(l2)) nxt = l2;
+                    ME_UNIFORM_WRITE(me_hme_finish_level(c, lvl); if (lvl == last_lvl) me_hme_select(c, list); else if (nxt >= 0) me_hme_plan_level(c, list, nxt, xsc, ysc, 0));
+                    planned = nxt >= 0 && lvl != last_lvl;
                     ME_SUBMARK(21);
                 }
+#undef ME_HME_LEVEL_ON
                 xsc = (int16_t)ME_UNI(st->hme_xc); ysc = (int16_t)ME_UNI(st->hme_yc);
             }
             ME_MARK(2);
