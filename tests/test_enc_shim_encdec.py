@@ -325,13 +325,21 @@ def test_get_recon_equals_the_oracle_chain(use_callback, N, intra_period):
     ({"SVT_HIP_DEVICES": "0,0"}, 34, 19),                                  # two closed GOPs on two contexts (GOP g -> device g mod N)
     ({"SVT_HIP_DEVICES": "0,0", "SVT_HIP_SPLIT_GOP": "1"}, 36, -1),        # one GOP, consecutive mini-GOPs on alternating contexts + hand-off
     ({"SVT_HIP_DEVICES": "0,0,0", "SVT_HIP_SPLIT_GOP": "1"}, 34, 19),
+    # short GOPs dealt to two contexts with the smallest picture ring: every device's feeder thread runs beside the caller while its slots
+    # are reused (cut groups, intra refreshes enqueued by the caller between the feeder's groups)
+    ({"SVT_HIP_DEVICES": "0,0", "SVT_HIP_RING_GROUPS": "2"}, 90, 9),
+    ({"SVT_HIP_DEVICES": "0,0,0", "SVT_HIP_RING_GROUPS": "2"}, 75, 24),
 ])
 def test_several_contexts_give_the_same_reconstruction(env, N, intra_period):
     """the multi-device paths of the library on one GPU: every "device" is a context of its own on ordinal 0 (own stream, own picture
     ring, own workspace); GOP sharding needs no exchange, split-GOP mode hands the padded base-layer reconstruction and its analysed
     planes from context to context (svt_hip_ref_handoff_device).  The reconstruction must not depend on how the work was dealt."""
-    W, H, enc_mode, tune, qp = 256, 192, 8, 1, 40
-    frames, recon, order, flags_seen, packets, infos, refpics, _ = run_clip(W, H, N, enc_mode, tune, qp, 1, intra_period, False, env=env)
+    W, H, enc_mode, tune, qp = (256, 192, 8, 1, 40) if N <= 40 else (136, 72, 8, 1, 40)
+    clip = None
+    if N > 40:   # (the moving-texture clip holds 30 pictures: forth and back)
+        base = T.gen_clip_subpel(W, H, 30, 57)
+        clip = [base[i % 30] if (i // 30) % 2 == 0 else base[29 - i % 30] for i in range(N)]
+    frames, recon, order, flags_seen, packets, infos, refpics, _ = run_clip(W, H, N, enc_mode, tune, qp, 1, intra_period, False, env=env, frames=clip)
     recs, outs = oracle_clip(frames, W, H, N, enc_mode, tune, qp, 1, intra_period, False)
     assert sorted(order) == list(range(N)) and len(packets) == N and packets[-1][1] & 1 and flags_seen[-1] == 1
     for k in range(N):
