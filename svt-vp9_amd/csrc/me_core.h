@@ -676,7 +676,10 @@ SVT_DEV void ph_fullpel_sad8(const me_ctx_t *c, int tid, uint32_t *U, int sw, in
  * areas) the phase is bound by the latency of its dependent chains, not by issue. */
 typedef uint64_t __attribute__((aligned(4))) me_u64a4; /* a dword pair in LDS: ds_read2_b32 */
 SVT_DEV uint32_t me_min3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; }
-template <int NG> SVT_DEV void me_fullpel_fused_dev(const me_ctx_t *c, int tid, int sw, int sh) {
+/* RUN (with NG = 2): the two groups of an iteration are NEIGHBOURS in a search row -- a run of 8 positions -- and share their operand pairs:
+ * group 0 takes the pairs at +0 and +4 of a window row, group 1 those at +4 and +8: three reads per row instead of four (the LDS, shared by
+ * the CU's five workgroups, is as busy as the vector unit in this kernel) */
+template <int NG, bool RUN = false> SVT_DEV void me_fullpel_fused_dev(const me_ctx_t *c, int tid, int sw, int sh) {
     const int rs = c->L.region_stride;
     const int z = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bx = ((z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4)) * 8, by = (((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4)) * 8;
@@ -690,7 +693,8 @@ template <int NG> SVT_DEV void me_fullpel_fused_dev(const me_ctx_t *c, int tid, 
     __asm__("" : "+v"(ro1));
     uint32_t mhi = 0xffff0000u;
     __asm__("" : "+v"(mhi)); /* in a vector register: (x & mhi) | s is then ONE v_and_or_b32 (one scalar operand per instruction) */
-    const int ng = sw >> 2;
+    const int ng = RUN ? sw >> 3 : sw >> 2; /* RUN: runs per search row */
+    static_assert(!RUN || NG == 2, "a run is two groups");
     uint32_t  b8 = 0xffffffffu, b16 = 0xffffffffu, b32 = 0xffffffffu, b64 = 0xffffffffu;
 #define FP_DPP(v, ctrl) ((v) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xf, 0xf, false))
 #define FP_KEYS(b, lo, hi, pos) do { \
@@ -701,8 +705,21 @@ template <int NG> SVT_DEV void me_fullpel_fused_dev(const me_ctx_t *c, int tid, 
      * minima do not change) */
     const uint32_t inv = me_magics.v[ng]; /* ng in [2, 31] */
     const int      nq = ME_MUL(ng, sh);
-    for (int q0 = w; q0 < nq; q0 += 4 * NG) {
+    for (int q0 = w; q0 < nq; q0 += RUN ? 4 : 4 * NG) {
         uint32_t pos[NG], lo[NG], hi[NG], a0[NG], a1[NG], a2[NG], a3[NG];
+        if constexpr (RUN) {
+            const int      y = inv ? (int)(((uint64_t)(uint32_t)q0 * inv) >> 32) : q0, g = 2 * (q0 - y * ng);
+            const int      off = ME_MUL(y, rs) + 4 * g; /* wave-uniform */
+            const uint8_t *rp = c->lds + (ro0 + (uint32_t)off), *rp1 = c->lds + (ro1 + (uint32_t)off);
+            uint64_t       acc = 0, acc_b = 0;
+            _Pragma("unroll") for (int r = 0; r < 4; r++) {
+                const uint64_t p0 = *(const me_u64a4 *)(rp + 2 * r * rs), p1 = *(const me_u64a4 *)(rp1 + 2 * r * rs), p2 = *(const me_u64a4 *)(rp + 2 * r * rs + 8);
+                acc = svt_qsad(p0, s0[r], acc);     acc = svt_qsad(p1, s1[r], acc);
+                acc_b = svt_qsad(p1, s0[r], acc_b); acc_b = svt_qsad(p2, s1[r], acc_b);
+            }
+            pos[0] = (uint32_t)(ME_MUL(y, sw) + 4 * g); pos[NG - 1] = pos[0] + 4;
+            lo[0] = (uint32_t)acc; hi[0] = (uint32_t)(acc >> 32); lo[NG - 1] = (uint32_t)acc_b; hi[NG - 1] = (uint32_t)(acc_b >> 32);
+        } else
         _Pragma("unroll") for (int u = 0; u < NG; u++) {
             const int      q = q0 + 4 * u < nq ? q0 + 4 * u : q0;
             const int      y = (int)(((uint64_t)(uint32_t)q * inv) >> 32), g = q - y * ng;
@@ -893,7 +910,7 @@ SVT_DEV void ph_fullpel_fused(const me_ctx_t *c, int tid, int sw, int sh, int un
 #else
     if (unroll2 && (sw & 15) == 0) me_fullpel_fused16_dev(c, tid, sw, sh);
     else if (unroll2) me_fullpel_fused_dev<2>(c, tid, sw, sh);
-    else me_fullpel_fused_dev<1>(c, tid, sw, sh);
+    else me_fullpel_fused_dev<2, true>(c, tid, sw, sh); /* (the phase's widths are multiples of 8: whole runs) */
 #endif
 }
 

@@ -206,13 +206,17 @@ SVT_DEV void fph_load_rect(int tid, uint8_t *dst, int dst_stride, const uint8_t 
  * Task = 4 consecutive positions.  *key = min over (sad << 16 | (y0 + y) << 8 | x): the reference's first minimum in raster
  * order (eb_vp9_sad_loop_kernel, C_DEFAULT/EbComputeSAD_C.c:132-169).  WS != 0: the stride as a compile-time constant. */
 template <int WS> SVT_DEV void fph_hme_search(const me_ctx_t *c, int tid, int ws_rt, int sw, int nr, int y0, uint32_t *key) {
-    const int      ws = WS ? WS : ws_rt, ng = sw >> 2, ntask = ME_MUL(ng, nr);
-    const uint32_t inv = me_magics.v[ng]; /* ng in [4, 64] */
+    /* A task is a RUN of two groups = 8 positions (the area's width is a multiple of 16): the five operand pairs (w[i], w[i + 1]), i = 0 .. 4,
+     * of a window row serve both groups -- group 0 takes pairs 0-3, group 1 pairs 1-4 -- and every pair is read ONCE (five ds_read2_b32 per
+     * row for 8 positions; one group per task read its four pairs: eight per row for the same positions).  The kernel shares one LDS pipe
+     * among the five workgroups of a CU and keeps it busy for 69 % of the time (tools/me_phase_lds.sh): this phase was its largest user. */
+    const int      ws = WS ? WS : ws_rt, ng2 = sw >> 3, ntask = ME_MUL(ng2, nr);
+    const uint32_t inv = me_magics.v[ng2]; /* ng2 in [2, 32] */
     uint32_t       b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu, b3 = 0xffffffffu;
     const uint32_t *blk = (const uint32_t *)c->st->sixteenth_sb; /* the block: 8 rows of 4 dwords (same address in every lane: broadcast reads) */
     for (int T = tid; T < ntask; T += SVT_NT) {
-        const int y = (int)__umulhi((uint32_t)T, inv), g = T - ME_MUL(y, ng);
-        /* byte offsets (inside the workgroup's LDS) of the task's first window dword and of the one after it, opaque to the compiler:
+        const int y = (int)__umulhi((uint32_t)T, inv), g = 2 * (T - ME_MUL(y, ng2));
+        /* byte offsets (inside the workgroup's LDS) of the run's first window dword and of the one after it, opaque to the compiler:
          * every QSAD operand pair (w[i], w[i + 1]) is then read as such by one ds_read2_b32 at an immediate offset -- the pairs of even
          * i from the first stream, of odd i from the second; nothing is assembled with register moves.  Window rows 12 and 14 lie
          * beyond the 8-bit dword offsets of ds_read2 when the stride is large: a second pair of bases serves them. */
@@ -221,21 +225,27 @@ template <int WS> SVT_DEV void fph_hme_search(const me_ctx_t *c, int tid, int ws
         __asm__("" : "+v"(o1));
         __asm__("" : "+v"(o2));
         __asm__("" : "+v"(o3));
-        uint64_t acc0 = 0, acc1 = 0;
+        uint64_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0; /* group 0: even / odd rows, group 1: even / odd rows */
         _Pragma("unroll") for (int j = 0; j < 8; j++) {
             const uint8_t *wa = c->lds + (j < 6 ? o0 + 2 * j * ws : o2 + 2 * (j - 6) * ws), *wb = c->lds + (j < 6 ? o1 + 2 * j * ws : o3 + 2 * (j - 6) * ws);
-            uint64_t       a = (j & 1) ? acc1 : acc0;
-            a = svt_qsad(*(const me_u64a4 *)wa, blk[4 * j], a);
-            a = svt_qsad(*(const me_u64a4 *)wb, blk[4 * j + 1], a);
-            a = svt_qsad(*(const me_u64a4 *)(wa + 8), blk[4 * j + 2], a);
-            a = svt_qsad(*(const me_u64a4 *)(wb + 8), blk[4 * j + 3], a);
-            if (j & 1) acc1 = a; else acc0 = a;
+            const uint64_t p0 = *(const me_u64a4 *)wa, p1 = *(const me_u64a4 *)wb, p2 = *(const me_u64a4 *)(wa + 8), p3 = *(const me_u64a4 *)(wb + 8),
+                           p4 = *(const me_u64a4 *)(wa + 16);
+            const uint32_t s0 = blk[4 * j], s1 = blk[4 * j + 1], s2 = blk[4 * j + 2], s3 = blk[4 * j + 3];
+            uint64_t       a = (j & 1) ? acc1 : acc0, e = (j & 1) ? acc3 : acc2;
+            a = svt_qsad(p0, s0, a); e = svt_qsad(p1, s0, e);
+            a = svt_qsad(p1, s1, a); e = svt_qsad(p2, s1, e);
+            a = svt_qsad(p2, s2, a); e = svt_qsad(p3, s2, e);
+            a = svt_qsad(p3, s3, a); e = svt_qsad(p4, s3, e);
+            if (j & 1) { acc1 = a; acc3 = e; } else { acc0 = a; acc2 = e; }
         }
-        const uint32_t lo = (uint32_t)acc0 + (uint32_t)acc1, hi = (uint32_t)(acc0 >> 32) + (uint32_t)(acc1 >> 32); /* 8 rows x 16 x 255 < 2^16 */
-        const uint32_t pos = ((uint32_t)(y0 + y) << 8) | (uint32_t)(4 * g);
-        /* one running minimum per position of the group; the position's offset inside the group is added at the end */
-        const uint32_t k0 = (lo << 16) | pos, k1 = (lo & 0xffff0000u) | pos, k2 = (hi << 16) | pos, k3 = (hi & 0xffff0000u) | pos;
-        b0 = k0 < b0 ? k0 : b0; b1 = k1 < b1 ? k1 : b1; b2 = k2 < b2 ? k2 : b2; b3 = k3 < b3 ? k3 : b3;
+        _Pragma("unroll") for (int u = 0; u < 2; u++) {
+            const uint64_t ae = u ? acc2 : acc0, ao = u ? acc3 : acc1;
+            const uint32_t lo = (uint32_t)ae + (uint32_t)ao, hi = (uint32_t)(ae >> 32) + (uint32_t)(ao >> 32); /* 8 rows x 16 x 255 < 2^16 */
+            const uint32_t pos = ((uint32_t)(y0 + y) << 8) | (uint32_t)(4 * (g + u));
+            /* one running minimum per position of a group; the position's offset inside the group is added at the end */
+            const uint32_t k0 = (lo << 16) | pos, k1 = (lo & 0xffff0000u) | pos, k2 = (hi << 16) | pos, k3 = (hi & 0xffff0000u) | pos;
+            b0 = k0 < b0 ? k0 : b0; b1 = k1 < b1 ? k1 : b1; b2 = k2 < b2 ? k2 : b2; b3 = k3 < b3 ? k3 : b3;
+        }
     }
     /* (~0 stays ~0: + o cannot be allowed to wrap) */
     uint32_t k = b0;
