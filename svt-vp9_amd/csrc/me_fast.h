@@ -357,15 +357,36 @@ SVT_DEV void fph_subpel(const me_ctx_t *c, int tid, int list, int sox, int soy, 
         __asm__("" : "+v"(q0));
         __asm__("" : "+v"(q1));
         uint32_t d[8];
+        /* The candidates one sample apart in the same plane row -- L / R (plane B), TL / TR and BL / BR (plane J) -- lie in the SAME five
+         * dwords from the aligned address below the left one: a byte selector per side (v_perm_b32 over a dword pair, offsets 0 .. 4)
+         * takes both from one fetch.  15 LDS reads for the eight candidates instead of 24 (the kernel's LDS pipe is as busy as its vector
+         * unit: tools/me_phase_lds.sh); T / B (plane H, two rows) keep their own fetches. */
+        const uint32_t selL = 0x03020100u + 0x01010101u * sh1, selR = selL + 0x01010101u;
         _Pragma("unroll") for (int i = 0; i < 8; i++) {
             int hpl, hdx, hdy;
             me_hcand_get(i, &hpl, &hdx, &hdy);
-            const uint32_t *q = (const uint32_t *)(c->lds + (hdx ? q1 : q0) + (uint32_t)((hpl - 1) * pb + hdy * ps));
-            const uint32_t  sh = hdx ? sh1 : sh0, l0 = q[0], l1 = q[1], l2 = q[2], l3 = q[3], l4 = q[4];
-            uint32_t        t = svt_sad4(svt_alignbyte(l1, l0, sh), s[0], 0);
-            t = svt_sad4(svt_alignbyte(l2, l1, sh), s[1], t);
-            t = svt_sad4(svt_alignbyte(l3, l2, sh), s[2], t);
-            d[i] = svt_sad4(svt_alignbyte(l4, l3, sh), s[3], t);
+            if (hpl == 2) { /* T, B */
+                const uint32_t *q = (const uint32_t *)(c->lds + q0 + (uint32_t)((hpl - 1) * pb + hdy * ps));
+                const uint32_t  l0 = q[0], l1 = q[1], l2 = q[2], l3 = q[3], l4 = q[4];
+                uint32_t        t = svt_sad4(svt_alignbyte(l1, l0, sh0), s[0], 0);
+                t = svt_sad4(svt_alignbyte(l2, l1, sh0), s[1], t);
+                t = svt_sad4(svt_alignbyte(l3, l2, sh0), s[2], t);
+                d[i] = svt_sad4(svt_alignbyte(l4, l3, sh0), s[3], t);
+            } else if (hdx) { /* the left one of a pair: fetches for both; its right neighbour is the candidate with the same plane and row */
+                int ir = -1;
+                _Pragma("unroll") for (int k = 0; k < 8; k++) {
+                    int kp, kx, ky;
+                    me_hcand_get(k, &kp, &kx, &ky);
+                    if (kp == hpl && ky == hdy && !kx) ir = k;
+                }
+                const uint32_t *q = (const uint32_t *)(c->lds + q1 + (uint32_t)((hpl - 1) * pb + hdy * ps));
+                const uint32_t  l0 = q[0], l1 = q[1], l2 = q[2], l3 = q[3], l4 = q[4];
+                uint32_t        t = svt_sad4((uint32_t)__builtin_amdgcn_perm(l1, l0, selL), s[0], 0), u = svt_sad4((uint32_t)__builtin_amdgcn_perm(l1, l0, selR), s[0], 0);
+                t = svt_sad4((uint32_t)__builtin_amdgcn_perm(l2, l1, selL), s[1], t); u = svt_sad4((uint32_t)__builtin_amdgcn_perm(l2, l1, selR), s[1], u);
+                t = svt_sad4((uint32_t)__builtin_amdgcn_perm(l3, l2, selL), s[2], t); u = svt_sad4((uint32_t)__builtin_amdgcn_perm(l3, l2, selR), s[2], u);
+                d[i] = svt_sad4((uint32_t)__builtin_amdgcn_perm(l4, l3, selL), s[3], t);
+                d[ir] = svt_sad4((uint32_t)__builtin_amdgcn_perm(l4, l3, selR), s[3], u);
+            }
         }
         /* a lane's sums stay below 2^12, 16 lanes' below 2^16: two candidates per dword up to the row; a 32x32 PU's second row is
          * added half by half into 32-bit sums */
