@@ -5,7 +5,7 @@
  * (App/EbAppProcessCmd.c:437-683): send a picture, poll get_packet without blocking, after the last picture drain with
  * pic_send_done = 1.
  *
- *   svt_enc_api_bench clip.yuv W H frames_in_file frames_to_send enc_mode tune [recon]
+ *   svt_enc_api_bench clip.yuv W H frames_in_file frames_to_send enc_mode tune [recon [devices]]
  *       clip.yuv holds frames_in_file 4:2:0 pictures of W x H (Y, Cb, Cr); they are sent round-robin.  All three planes cross
  *       PCIe: behind the API run picture analysis, motion estimation, the stand-in decision, inter prediction, transform /
  *       quantisation / reconstruction, deblocking and reference padding (which of the last three a picture gets is the
@@ -28,7 +28,10 @@ static double now_s(void) {
 }
 
 int main(int argc, char **argv) {
-    if (argc < 8) { fprintf(stderr, "usage: %s clip.yuv W H frames_in_file frames_to_send enc_mode tune [recon]\n", argv[0]); return 2; }
+    if (argc < 8) { fprintf(stderr, "usage: %s clip.yuv W H frames_in_file frames_to_send enc_mode tune [recon [devices]]\n", argv[0]); return 2; }
+    /* devices: a comma-separated list of GPU ordinals the library deals the closed GOPs to (its SVT_HIP_DEVICES; an ordinal may repeat:
+       several contexts, each with its own picture ring, streams and feeder thread, on one GPU) */
+    if (argc > 9 && argv[9][0]) setenv("SVT_HIP_DEVICES", argv[9], 1);
     const int W = atoi(argv[2]), H = atoi(argv[3]), K = atoi(argv[4]), N = atoi(argv[5]), want_recon = argc > 8 ? atoi(argv[8]) : 0;
     if (W < 64 || H < 64 || K < 1 || N < 1) return 2;
     const size_t ysz = (size_t)W * H, psz = ysz + ysz / 2;

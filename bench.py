@@ -227,9 +227,16 @@ def api_path_rate(frames, Wd, Hd, enc_mode, tune, n_send=130):
             d = json.loads(r.stdout.strip().splitlines()[-1])
             out["with_recon_output" if recon else "default"] = {"value": d["frames_per_s"], "frames": d["frames"], "seconds": d["seconds"], "me_launches": d["me_launches"],
                                                                 "mpixels_per_s": round(d["frames_per_s"] * Wd * Hd / 1e6, 1), "recon_pictures": d["recon_pictures"]}
+        # the N-device host shape on ONE GPU: two contexts (two picture rings, two sets of streams, two feeder threads) take the closed GOPs
+        # by turns -- exercises what `SVT_HIP_DEVICES=a,b` runs on a multi-GPU node; no scaling claim (one GPU's worth of compute and link)
+        r = subprocess.run([exe, path, str(Wd), str(Hd), str(len(frames)), str(n_send), str(enc_mode), str(tune), "0", "0,0"], capture_output=True, text=True)
+        two = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
     d0 = out["default"]
     return {"value": d0["value"], "unit": "frames/s", "frames": d0["frames"], "seconds": d0["seconds"], "me_launches": d0["me_launches"], "mpixels_per_s": d0["mpixels_per_s"],
             "with_recon_output": out["with_recon_output"],
+            "two_contexts_one_gpu": ({"value": two["frames_per_s"], "frames": two["frames"], "devices": "0,0",
+                                      "note": "GOPs dealt to two contexts of the same GPU (the multi-device host shape: per-device ring, streams, feeder thread); not a scaling figure"}
+                                     if two else None),
             "stages": ["pa", "me", "me_stats", "md_stand_in", "mc", "lists", "tq", "skip", "masks+lf", "pad"],
             "what": f"{Wd}x{Hd} -enc-mode {enc_mode} -tune {tune} -q 40, {d0['frames']} pictures through eb_vp9_svt_enc_send_picture / eb_vp9_svt_get_packet "
                     "(app/svt_enc_api_bench.c): first send_picture -> EOS packet, host buffers in (Y, Cb, Cr), PCIe included; every stage of the path behind the "
