@@ -1061,6 +1061,7 @@ SVT_DEV void ph_interp_strips(const me_ctx_t *c, int tid, int W, int H) {
     for (int i0 = 0; i0 < per + 3; i0 += 4) {                    /* same trip count in every lane; the stores carry the lane's bounds */
         _Pragma("unroll") for (int u = 0; u < 4; u++) {
             const int       i = i0 + u;
+            if (i >= per + 3) break; /* (uniform: the walk is per + 3 steps long; unrolled by four it used to run up to three steps past its end) */
             const uint32_t *rw = (const uint32_t *)(rp + u * rs);
             const uint32_t  lo = rw[0], hi = rw[1];
             /* P(k) = bytes (k, k + 2) of the row's 8 bytes in 16-bit lanes: horizontal taps of the even outputs are P1..P4, of the
