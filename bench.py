@@ -1080,7 +1080,9 @@ def main():
         # source luma read + padded / decimated planes written
         "pa": pics_step * int(L + (Wd + 2 * pads[0]) * (Hd + 2 * pads[0]) + (Wd // 4 + 2 * pads[2]) * (Hd // 4 + 2 * pads[2]) +
                               (((Wd // 2 + 2 * pads[1]) * (Hd // 2 + 2 * pads[1])) if l1_on else 0)),
-        "me": pics_step * algorithmic_bytes_me(Wd, Hd, 2, l1_on),
+        # per picture: R = the number of DISTINCT reference pictures its lists name (the base-layer picture of a mini-GOP has both lists on
+        # the previous base picture: R = 1; every other picture is a B picture between two different references: R = 2)
+        "me": G * sum(algorithmic_bytes_me(Wd, Hd, len(set(refs_of(i))), l1_on) for i in range(1, MINIGOP + 1)),
         # per 8x8 unit: 96 bytes (64 luma + 2 x 16 chroma) read per reference and written once, + the 12-byte mode-info record
         "mc": int(96 * (inter_units + comp_units) + 96 * inter_units + 12 * mi_units),
         # the 8-byte grid records read twice (count, emit), a 32-byte descriptor + 4-byte position code written per block
@@ -1092,7 +1094,10 @@ def main():
         # the border of the three planes written, the edge samples read (reference pictures only: the deepest layer is not padded)
         "pad": (pics_step // 2) * int((geo.pw * geo.ph - L) + 2 * (geo.cpw * geo.cph - L // 4) + 2 * (Hd + Wd)),
     }
-    kernel_of = {"pa": "svt_pa_plane_kernel", "me": "svt_me_sb_kernel", "mc": "svt_mc_kernel", "lists": "svt_tq_count / svt_scan / svt_tq_emit kernels",
+    # the rocprofv3 name of the ME kernel the launches really were (svt_hip_me_last_instance: me_spec.h index, + 100 for csrc/me_fast.h's driver)
+    me_inst = int(lib.svt_hip_me_last_instance(me_ctxs[0])) if ctxs else -1
+    me_kernel_name = f"svt_me_fast_kernel<{me_inst - 100}>" if me_inst >= 100 else f"svt_me_sb_kernel<{max(me_inst, 0)}>"
+    kernel_of = {"pa": "svt_pa_plane_kernel", "me": me_kernel_name, "mc": "svt_mc_kernel", "lists": "svt_tq_count / svt_scan / svt_tq_emit kernels",
                  "tq": "svt_tq_kernel<4|8|16|32>", "skip": "svt_tq_skip / svt_skip_update kernels", "lf": "svt_lf_mask + svt_lf_desc + svt_lf_kernel",
                  "pad": "svt_refpad_kernel"}
     me_ms = max(stage_ms["me"], 1e-9)
@@ -1188,7 +1193,7 @@ def main():
             "stage_ms_per_minigop": {s: round(single["waves"]["stage_ms"][s], 3) for s in stages_run},
             "note": "one mini-GOP at a time: its temporal-layer waves run one after the other (only ME / picture analysis of the next "
                     "mini-GOP overlap them) -- the lowest-latency schedule, bounded by the per-picture latency of the deblocking wavefront"},
-        "roofline": {"bound": "hbm", "kernel": "svt_me_sb_kernel", "achieved": round(achieved, 2), "peak": 8000.0,
+        "roofline": {"bound": "hbm", "kernel": me_kernel_name, "achieved": round(achieved, 2), "peak": 8000.0,
                      "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_source,
                      "launches_per_step": n_launch_step, "avg_launch_ms": round(me_clean_ms / n_launch_step, 4),
                      "algorithmic_bytes_per_launch": int(stage_bytes["me"] / n_launch_step),

@@ -230,6 +230,12 @@ int32_t svt_hip_mem_upload_2d_direct(svt_hip_ctx *ctx, void *d_dst, size_t dst_s
                                      size_t rows);
 int32_t svt_hip_mem_upload_wait(svt_hip_ctx *ctx);
 void    svt_hip_host_unregister_all(void);
+/* The registry's life follows its users: a host retains it while it uploads directly and releases it when all its uploads have completed;
+ * the LAST release unlocks every range (memory freed afterwards, or re-allocated at the same address, is never read through a stale
+ * registration).  A range whose registration failed is not remembered: the next upload from it tries again.  The encoder library
+ * (libSvtVp9Enc.so, SVT_HIP_REGISTER_INPUT=1) retains in eb_vp9_init_encoder and releases in eb_vp9_deinit_encoder. */
+void    svt_hip_host_registry_retain(void);
+void    svt_hip_host_registry_release(void);
 /* Completion markers: svt_hip_ctx_marker_record notes "everything enqueued on the context's stream so far" and returns a marker;
  * svt_hip_ctx_marker_query returns 1 when that work has completed, 0 while it is pending (never blocks), negative on error;
  * svt_hip_ctx_marker_wait blocks until it has.  This is what lets eb_vp9_svt_get_packet poll without blocking and block only when

@@ -233,7 +233,7 @@ extern "C" int32_t svt_hip_mem_upload_planes_async(svt_hip_ctx *ctx, int32_t n_p
         bytes += width_bytes[i] * rows[i];
     }
     HIP_TRY(hipSetDevice(ctx->device));
-    static const bool prof = getenv("SVT_HIP_SHIM_PROFILE") != nullptr;
+    static const bool prof = getenv("SVT_HIP_SHIM_PROFILE") != nullptr && atoi(getenv("SVT_HIP_SHIM_PROFILE")) != 0;
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
     double t0 = prof ? now() : 0.0;
     const int k = ctx->up_pos;
@@ -292,6 +292,7 @@ std::mutex g_reg_mutex;
 reg_iv     g_reg[SVT_REG_MAX];
 int        g_reg_n = 0;
 bool       g_reg_off = false;
+int        g_reg_users = 0; /* encoders (or other hosts) that hold the registry: svt_hip_host_registry_retain / _release */
 
 /* end of the registered interval that holds address a (a is covered: reg_cover succeeded for it) */
 uintptr_t reg_end_of(uintptr_t a) {
@@ -317,8 +318,10 @@ bool reg_cover(uintptr_t a, uintptr_t b) {
         if (g_reg_off || g_reg_n == SVT_REG_MAX) { g_reg_off = true; return false; }
         const hipError_t e = hipHostRegister((void *)cur, next - cur, hipHostRegisterPortable);
         (void)hipGetLastError();
-        g_reg[g_reg_n++] = reg_iv{cur, next, e == hipSuccess};
-        all_ok = all_ok && e == hipSuccess;
+        /* a range that could not be locked is NOT remembered: this upload goes through the staging path and a later one tries again (the
+           refusal may have been transient -- locked-memory limit, a mapping that has changed since) */
+        if (e == hipSuccess) g_reg[g_reg_n++] = reg_iv{cur, next, true};
+        else all_ok = false;
         cur = next;
     }
     return all_ok;
@@ -380,6 +383,21 @@ extern "C" void svt_hip_host_unregister_all(void) {
     std::lock_guard<std::mutex> lock(g_reg_mutex);
     for (int i = 0; i < g_reg_n; i++) if (g_reg[i].ok) (void)hipHostUnregister((void *)g_reg[i].lo);
     g_reg_n = 0; g_reg_off = false;
+}
+/* The registry is process-wide (a host range is locked once, whichever context uploads from it); its life is tied to its users: a host
+ * that uploads with svt_hip_mem_upload_2d_direct retains it while it is live and releases it when every upload of its own has completed.
+ * The last release unlocks every range, so that memory the application frees afterwards -- and a later allocation at the same address --
+ * is never read through a stale registration. */
+extern "C" void svt_hip_host_registry_retain(void) {
+    std::lock_guard<std::mutex> lock(g_reg_mutex);
+    g_reg_users++;
+}
+extern "C" void svt_hip_host_registry_release(void) {
+    std::lock_guard<std::mutex> lock(g_reg_mutex);
+    if (g_reg_users > 0 && --g_reg_users == 0) {
+        for (int i = 0; i < g_reg_n; i++) if (g_reg[i].ok) (void)hipHostUnregister((void *)g_reg[i].lo);
+        g_reg_n = 0; g_reg_off = false;
+    }
 }
 
 /* ---- completion markers: "everything enqueued on the context's stream so far" as a value a host can poll or wait for ---- */

@@ -281,6 +281,11 @@ static EbErrorType gpu_fail(shim_state *s) { /* a failed device call ends the st
                                                 a pipeline error and answers EB_ErrorMax from then on, :437-452, 2914-2917) */
     fprintf(stderr, "SvtVp9Enc (GPU hot path): %s\n", svt_hip_last_error());
     s->failed = 1;
+    /* direct uploads (SVT_HIP_REGISTER_INPUT=1) read the CALLER's planes: whatever failed, no entry point returns while one may still
+       be in flight */
+    if (s->register_input)
+        for (int k = 0; k < s->n_dev; k++)
+            if (s->dev[k].ctx_up) (void)svt_hip_mem_upload_wait(s->dev[k].ctx_up);
     return EB_ErrorMax;
 }
 #define GPU_TRY(call) do { if ((call) != SVT_HIP_OK) return gpu_fail(s); } while (0)
@@ -531,6 +536,7 @@ EbErrorType eb_vp9_init_encoder(EbComponentType *h) {
     s->cur_dev = 0;
     { const char *sg = getenv("SVT_HIP_SPLIT_GOP"); s->split_gop = n > 1 && sg && atoi(sg) != 0; }
     { const char *ri = getenv("SVT_HIP_REGISTER_INPUT"); s->register_input = ri && atoi(ri) != 0; }
+    if (s->register_input) svt_hip_host_registry_retain(); /* released in eb_vp9_deinit_encoder: the last encoder out unlocks the application's buffers */
     {   /* feeder threads (SVT_HIP_FEEDER=0 or SVT_HIP_NO_FEEDER=1: off) */
         const char *nf = getenv("SVT_HIP_NO_FEEDER"), *ff = getenv("SVT_HIP_FEEDER"), *one = getenv("SVT_HIP_SINGLE_STREAM");
         const int   want = ff ? atoi(ff) != 0 : 1;
@@ -1309,6 +1315,9 @@ EbErrorType eb_vp9_deinit_encoder(EbComponentType *h) {
     s->r_tail = NULL;
     for (int k = 0; k < s->n_dev; k++) free_dev(s, &s->dev[k]);
     s->n_dev = 0;
+    /* every stream has drained (join_all, free_dev): nothing reads the application's input buffers any more -- the page locks this encoder
+       took on them go with it (the registry is process-wide and counted: the last encoder that leaves unlocks) */
+    if (s->register_input) { svt_hip_host_registry_release(); s->register_input = 0; }
     if (s->profile && s->next_number)
         fprintf(stderr, "SvtVp9Enc host time per picture (us): slot wait %.1f  upload %.1f  analysis %.1f  group hand-over %.1f  intra %.1f  | send_picture %.1f  (%lld pictures)\n",
                 1e6 * s->prof_s[0] / (double)s->next_number, 1e6 * s->prof_s[1] / (double)s->next_number, 1e6 * s->prof_s[2] / (double)s->next_number,

@@ -347,6 +347,29 @@ def test_several_contexts_give_the_same_reconstruction(env, N, intra_period):
         assert np.array_equal(recon[k], np.concatenate([y.ravel(), u.ravel(), v.ravel()])), k
 
 
+def test_eight_contexts_c4_shaped_clip_equals_one_context():
+    """BASELINE configuration C4's host shape on one GPU (SURVEY section 7's determinism contract at C4's real GOP count): 520 pictures =
+    8 closed GOPs of 65 (-intra-period 64), dealt to EIGHT contexts (`SVT_HIP_DEVICES=0,0,0,0,0,0,0,0`: GOP g on device g mod 8, each with
+    its own picture ring, streams, workspace and feeder thread, as on an 8-GPU node) -- every reconstruction must equal the one-context
+    run byte for byte, in the same delivery semantics (all pictures delivered, EOS on the last).  The first GOP is also checked against the
+    oracle chain, so that "equal" cannot mean "equally wrong"."""
+    W, H, N, enc_mode, tune, qp, intra_period = 136, 72, 520, 8, 1, 40, 64
+    base = T.gen_clip_subpel(W, H, 30, 59)
+    clip = [base[i % 30] if (i // 30) % 2 == 0 else base[29 - i % 30] for i in range(N)]
+    one = run_clip(W, H, N, enc_mode, tune, qp, 1, intra_period, False, frames=clip)
+    eight = run_clip(W, H, N, enc_mode, tune, qp, 1, intra_period, False, frames=clip, env={"SVT_HIP_DEVICES": "0,0,0,0,0,0,0,0"})
+    for run in (one, eight):
+        _, recon, order, flags_seen, packets = run[:5]
+        assert sorted(order) == list(range(N)) and len(packets) == N and packets[-1][1] & 1 and flags_seen[-1] == 1
+    for k in range(N):
+        assert np.array_equal(one[1][k], eight[1][k]), k
+    n0 = intra_period + 1
+    recs, _ = oracle_clip(clip[:n0], W, H, n0, enc_mode, tune, qp, 1, intra_period, False)
+    for k in range(n0):
+        y, u, v = recs[k].interior()
+        assert np.array_equal(eight[1][k], np.concatenate([y.ravel(), u.ravel(), v.ravel()])), k
+
+
 def test_without_recon_output_only_reference_pictures_are_reconstructed():
     """recon_file = 0 at enc-mode 8: base-layer pictures deblocked, layers 1-3 reconstructed without deblocking (the reference allows
     the encoder / decoder mismatch there), the deepest layer not reconstructed at all -- and eb_vp9_svt_get_recon answers EB_ErrorMax"""
