@@ -1500,3 +1500,96 @@ def product_minigop_split(n, levels=4, cut_by_intra=0):
     k = B.load().svt_hip_minigop_split(n, levels, cut_by_intra, parts)
     assert k >= 1
     return [(p.start, p.length, p.hierarchical_levels, p.random_access) for p in parts[:k]]
+
+
+# ---- the reference's ME kernel process itself + this repository's binding at its call site (oracle/_ref/ref_me_process) ----
+def ref_me_process(cur, ref0, ref1, enc_mode, tune, temporal_layer, p_slice=0, used=1, rate_control_mode=1, same_ref_poc=0, segments=(2, 2), stats=None,
+                   run_binding=False, device=0):
+    """Runs eb_vp9_motion_estimation_kernel (Codec/EbMotionEstimationProcess.c:875-1290) as a thread behind the reference's own FIFOs on one
+    picture and, optionally, integration/me_process_binding.h (-> svt_hip_me_picture) on the same control sets.  stats: dict of per-SB arrays
+    cur_mean (u8), var (u16 [n_sb][5]: 64x64, four 32x32), ref_mean (u8), ref_var (u16).  Returns a dict."""
+    exe = os.path.join(REF_DIR, "ref_me_process")
+    h, w = cur.luma.shape
+    nsb = n_sb(w, h)
+    if stats is None:
+        stats = dict(cur_mean=np.zeros(nsb, np.uint8), var=np.zeros((nsb, 5), np.uint16), ref_mean=np.zeros(nsb, np.uint8), ref_var=np.zeros(nsb, np.uint16))
+    with tempfile.TemporaryDirectory() as td:
+        req, rsp = os.path.join(td, "req.bin"), os.path.join(td, "rsp.bin")
+        with open(req, "wb") as f:
+            f.write(struct.pack("<15i", 0x504D5653, w, h, enc_mode, tune, temporal_layer, p_slice, used, rate_control_mode, same_ref_poc, segments[0], segments[1],
+                                int(run_binding), device, 0))
+            for pic in (cur, ref0, ref1 if ref1 is not None else ref0):
+                for arr, pad in pic.planes():
+                    hh, ww = arr.shape
+                    f.write(struct.pack("<6i", ww, pad, pad, ww - 2 * pad, hh - 2 * pad, arr.size))
+                    f.write(arr.tobytes())
+            for i in range(nsb):
+                f.write(struct.pack("<B5HBH", int(stats["cur_mean"][i]), *[int(v) for v in stats["var"][i]], int(stats["ref_mean"][i]), int(stats["ref_var"][i])))
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "svt-vp9_amd") + ":" + env.get("LD_LIBRARY_PATH", "")
+        subprocess.check_call([exe, req, rsp], env=env)
+        raw = open(rsp, "rb").read()
+    n, n_sad, n_intra = struct.unpack_from("<3i", raw, 0)
+    assert n == nsb
+    o = 12
+    out = {}
+
+    def take(dtype, count, shape=None):
+        nonlocal o
+        a = np.frombuffer(raw, dtype=dtype, count=count, offset=o).copy()
+        o += a.nbytes
+        return a.reshape(shape) if shape else a
+    out["res"] = take(B.ME_RESULT_DTYPE, nsb * 85, (nsb, 85))
+    out["rcme"] = take(np.uint32, nsb)
+    out["inter_idx"], out["intra_idx"] = take(np.uint32, nsb), take(np.uint32, nsb)
+    out["me_hist"], out["ois_hist"] = take(np.uint16, n_sad), take(np.uint16, n_intra)
+    out["full_sb_count"] = int(take(np.uint32, 1)[0])
+    out["similar"], out["similar_all"], out["check1"], out["pm_check1"] = (take(np.uint8, nsb) for _ in range(4))
+    out["binding_params"] = B.MeParams.from_buffer_copy(raw[o:o + C.sizeof(B.MeParams)])
+    o += C.sizeof(B.MeParams)
+    out["binding_rc"] = struct.unpack_from("<i", raw, o)[0]
+    o += 4
+    if run_binding:
+        out["binding_res"] = take(B.ME_RESULT_DTYPE, nsb * 85, (nsb, 85))
+        out["binding_rcme"] = take(np.uint32, nsb)
+    return out
+
+
+def ref_lf_call_site(y, u, v, cells, filter_level, sharpness=0, y_only=False, run_binding=False, device=0):
+    """The deblocking call site of the reference's encode pass (Codec/EbEncDecProcess.c:5676-5686) on a real VP9_COMMON / MACROBLOCKD
+    (oracle/_ref/ref_lf_binding): eb_vp9_build_mask_frame + eb_vp9_loop_filter_frame, and -- run_binding -- the same with
+    integration/loop_filter_binding.h in place of the second call.  y / u / v: picture planes (W x H, W/2 x H/2); cells: [mi_rows][mi_cols][6].
+    Returns (reference planes, binding planes or None, binding rc, LOOP_FILTER_MASK array [sb_rows][sb_cols])."""
+    exe = os.path.join(REF_DIR, "ref_lf_binding")
+    H, W = y.shape
+    # the reference filters whole 8-sample groups and relies on the recon buffer's padding where a chroma block is only 4 samples wide / high
+    yp = np.ascontiguousarray(np.pad(y, ((0, 32), (0, 32)), mode="edge"))
+    up = np.ascontiguousarray(np.pad(u, ((0, 16), (0, 16)), mode="edge"))
+    vp_ = np.ascontiguousarray(np.pad(v, ((0, 16), (0, 16)), mode="edge"))
+    mi_rows, mi_cols = H // 8, W // 8
+    sb_rows, sb_cols = (mi_rows + 7) // 8, (mi_cols + 7) // 8
+    with tempfile.TemporaryDirectory() as td:
+        req, rsp = os.path.join(td, "req.bin"), os.path.join(td, "rsp.bin")
+        with open(req, "wb") as f:
+            f.write(struct.pack("<13i", 0x424C5653, W, H, yp.shape[1], up.shape[1], yp.shape[0], up.shape[0], filter_level, sharpness, int(y_only), int(run_binding), device, 0))
+            f.write(np.ascontiguousarray(cells[:mi_rows, :mi_cols]).tobytes())
+            f.write(yp.tobytes()); f.write(up.tobytes()); f.write(vp_.tobytes())
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "svt-vp9_amd") + ":" + env.get("LD_LIBRARY_PATH", "")
+        subprocess.check_call([exe, req, rsp], env=env)
+        raw = open(rsp, "rb").read()
+    ys, us = yp.size, up.size
+
+    def planes(o):
+        return (np.frombuffer(raw, np.uint8, ys, o).reshape(yp.shape)[:H, :W].copy(), np.frombuffer(raw, np.uint8, us, o + ys).reshape(up.shape)[:H // 2, :W // 2].copy(),
+                np.frombuffer(raw, np.uint8, us, o + ys + us).reshape(vp_.shape)[:H // 2, :W // 2].copy())
+    ref = planes(0)
+    o = ys + 2 * us
+    brc = struct.unpack_from("<i", raw, o)[0]
+    o += 4
+    bind = None
+    if run_binding:
+        bind = planes(o)
+        o += ys + 2 * us
+    lfm = np.frombuffer(raw, dtype=B.LF_MASK_DTYPE, count=sb_rows * sb_cols, offset=o).reshape(sb_rows, sb_cols).copy()
+    return ref, bind, brc, lfm
