@@ -6,7 +6,7 @@
  * (VPX/vp9_loopfilter.c:1521) is replaced by svt_hip_bind_loop_filter_frame with the SAME arguments.  Written against the reference's
  * VP9_COMMON / MACROBLOCKD / LOOP_FILTER_MASK / loop_filter_info_n; compiled (-Wall -Werror) and EXECUTED against them by
  * oracle/ref_lfbind_driver.c, which runs the reference's own two calls on the same frame and compares every sample
- * (tests/test_gpu_binding_lf.py).  INTEGRATION.md quotes this file.
+ * (tests/test_ref_lf_call_site.py).  INTEGRATION.md quotes this file.
  *
  * Include it after the reference's headers (vp9_onyxc_int.h, vp9_blockd.h, vp9_loopfilter.h) and after svtvp9_hip.h.
  */

@@ -7,7 +7,7 @@
  * (Codec/EbMotionEstimationProcess.c:964-1044: copy the SB into sb_buffer / the 1/4 and 1/16 SB buffers, motion_estimate_sb per SB)
  * by ONE call per picture.  It is compiled (-Wall -Werror) and EXECUTED against the reference's structures by oracle/ref_meproc_driver.c,
  * which runs the reference's own thread function on the same picture and compares picture_control_set_ptr->me_results byte for byte
- * (tests/test_gpu_binding.py).  INTEGRATION.md quotes this file.
+ * (tests/test_ref_me_process.py).  INTEGRATION.md quotes this file.
  *
  * Include it after the reference's headers (EbPictureControlSet.h, EbSequenceControlSet.h, EbMotionEstimationProcess.h,
  * EbMotionEstimationContext.h, EbReferenceObject.h, EbPictureBufferDesc.h) and after svtvp9_hip.h.
