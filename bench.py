@@ -311,6 +311,54 @@ def reference_me_rate(T, B, orc, frames, Wd, Hd, enc_mode, tune, l1_on, ncpu):
             "results_identical": bool(same)}
 
 
+def reference_stage_rates(T, B, src_all, pred_pic, kcell_pic, mc_mi_pic, Wd, Hd, level, ncpu):
+    """The REFERENCE's own code for the three stages behind mode decision, timed like reference_me: oracle/_ref/ref_tq_binding
+    (perform_coding_loop at its encode-pass call sites, Codec/EbEncDecProcess.c:365-587), ref_lf_binding (eb_vp9_build_mask_frame +
+    eb_vp9_loop_filter_frame, VPX/vp9_loopfilter.c:1521-1571) and ref_mc_frame (inter_prediction, Codec/EbIntraPrediction.c:49), built in
+    the build container from /root/reference (C path, gcc -O2) and travelling prebuilt.  ONE whole picture of the workload per process
+    (picture MINIGOP / 4 of GOP 0: its source, the device's prediction of it, its synthesised partition and motion vectors), one
+    process alone and `workers` processes at once; the seconds are the stages' own (clock_gettime inside the harnesses, no request I/O)."""
+    need = [os.path.join(ROOT, "oracle", "_ref", n) for n in ("ref_tq_binding", "ref_lf_binding", "ref_mc_frame")]
+    if not all(os.path.exists(n) for n in need):
+        return None
+    i = MINIGOP // 4
+    ny, nc = Wd * Hd, Wd * Hd // 4
+    planes = lambda a: (np.ascontiguousarray(a[:ny].reshape(Hd, Wd)), np.ascontiguousarray(a[ny:ny + nc].reshape(Hd // 2, Wd // 2)),
+                        np.ascontiguousarray(a[ny + nc:ny + 2 * nc].reshape(Hd // 2, Wd // 2)))
+    src, pred = planes(src_all[i]), planes(pred_pic)
+    mi_rows, mi_cols = Hd // 8, Wd // 8
+    # the partition as square inter blocks: kind 0 = four 4x4 per 8x8 unit, 1 = 8x8, 2 = 16x16, 3 = 32x32 (transform = block size)
+    lf_mi = np.zeros((mi_rows, mi_cols), dtype=B.LF_MODE_INFO_DTYPE)
+    lf_mi["sb_type"] = np.array([0, 3, 6, 9], np.uint8)[kcell_pic]
+    lf_mi["tx_size"], lf_mi["is_inter"] = kcell_pic, 1
+    cells = np.zeros((mi_rows, mi_cols, 6), np.uint8)      # {sb_type, tx_size, skip, ref_frame[0], mode, segment_id}: inter (LAST_FRAME), NEARESTMV
+    cells[..., 0], cells[..., 1], cells[..., 3], cells[..., 4] = np.array([3, 3, 6, 9], np.uint8)[kcell_pic], kcell_pic, 1, 13
+    a, b = refs_of(i)
+    pad = lambda pl, n: np.ascontiguousarray(np.pad(pl, n, mode="edge"))
+    mc_case = dict(mi=mc_mi_pic, width=Wd, height=Hd, mi_rows=mi_rows, mi_cols=mi_cols, use_subpel=1, pad=PAD,
+                   refs=[tuple(pad(pl, PAD if k == 0 else PAD // 2) for k, pl in enumerate(planes(src_all[j]))) for j in (a, b)])
+    workers = max(1, min(ncpu, 16))
+    legs = {"tq": lambda n: T.ref_coding_loop_call_sites(src, pred, lf_mi, Q_INDEX, timing=n),
+            "lf": lambda n: T.ref_lf_call_site(src[0], src[1], src[2], cells, level, timing=n),
+            "mc": lambda n: T.ref_mc_frame(mc_case, timing=n)}
+    what = {"tq": "perform_coding_loop at the encode pass's call sites (Codec/EbEncDecProcess.c:365-587, 3830-3940): residual, forward transform, quantiser, inverse, reconstruction",
+            "lf": "eb_vp9_build_mask_frame + eb_vp9_loop_filter_frame (VPX/vp9_loopfilter.c:1521-1571) on a real VP9_COMMON",
+            "mc": "inter_prediction (Codec/EbIntraPrediction.c:49 -> VPX/vp9_reconinter.c) for every block and plane"}
+    out = {}
+    for name, run in legs.items():
+        try:
+            one = run(1)[0]
+            many = run(workers)
+        except Exception as e:   # a harness that cannot run this configuration is reported, not fatal
+            out[f"reference_{name}"] = {"error": str(e)[-160:]}
+            continue
+        out[f"reference_{name}"] = {"kind": "reference", "what": what[name] + "; the reference built from its own sources, C path (-asm 0), gcc -O2",
+                                    "sample": f"one whole {Wd}x{Hd} picture of the workload per process, {workers} processes at once", "workers": workers,
+                                    "seconds_per_picture_1_thread": round(one, 4), "seconds_per_picture_all_busy": round(max(many), 4),
+                                    "frames_per_s_stage_only": round(workers / max(many), 2)}
+    return out
+
+
 class Geometry:
     """Layouts in HBM.  Source / prediction pictures: three tight planes one after the other (Y, Cb, Cr).  Reconstruction =
     reference pictures: three padded planes one after the other (Y with PAD samples of border, Cb and Cr with PAD / 2), as the
@@ -1219,7 +1267,8 @@ def main():
     if not args.no_cpu_baseline and world == 1:   # the CPU leg runs at N = 1 only (rank 0's host cores are not shared with other ranks)
         lfm0 = {i: np.frombuffer(d_lfm[0, i - 1].cpu().numpy(), dtype=B.LF_MASK_DTYPE).reshape(sb_rows, sb_cols).copy() for i in range(1, MINIGOP + 1)}
         lf0 = {i: d_lf[0][i].cpu().numpy().view(B.LF_MODE_INFO_DTYPE).reshape(mi_rows, mi_cols).copy() for i in range(1, MINIGOP + 1)}   # with the skip flags
-        out["cpu_baseline"] = cpu_baseline(T, B, frames0, src0, mc_host0, lf0, lfm0, Wd, Hd, enc_mode, tune, l1_on)
+        ref_inputs = {"pred": d_pred[0, MINIGOP // 4 - 1].cpu().numpy(), "kcell": kcell[0][MINIGOP // 4], "level": level}
+        out["cpu_baseline"] = cpu_baseline(T, B, frames0, src0, mc_host0, lf0, lfm0, Wd, Hd, enc_mode, tune, l1_on, ref_inputs)
     for grp in P_main["groups"] + (P_single["groups"] if P_single else []) + (P_ref["groups"] if P_ref else []) + (P_inter["groups"] if P_inter else []):
         lib.svt_hip_encdec_work_destroy(grp["ctx"], grp["work"])
         if grp["kres"]:
@@ -1292,7 +1341,7 @@ def _cpu_worker(job):
     return t
 
 
-def cpu_baseline(T, B, frames, src_all, mc_mi, lf_mi, lfm, Wd, Hd, enc_mode, tune, l1_on):
+def cpu_baseline(T, B, frames, src_all, mc_mi, lf_mi, lfm, Wd, Hd, enc_mode, tune, l1_on, ref_inputs=None):
     """The oracle (C restatement of the reference's C path; kind "port"), compiled -O3 -march=native on this host, on the SAME
     workload: whole pictures of GOP 0's mini-GOP through all the stages of the step, ONE PICTURE PER PROCESS, as many processes as
     the sample has pictures -- the reference's own parallelism is pictures in flight x segments, and independent pictures are what
@@ -1326,7 +1375,9 @@ def cpu_baseline(T, B, frames, src_all, mc_mi, lf_mi, lfm, Wd, Hd, enc_mode, tun
         n_all = max(1, min(ncpu, mem_cap, 256))
         fps_all, wall_all, stage_all = run(n_all)
         fps_8, wall_8, stage_8 = run(min(8, n_all)) if n_all > 8 else (fps_all, wall_all, stage_all)
+    ref_stages = reference_stage_rates(T, B, src_all, ref_inputs["pred"], ref_inputs["kcell"], mc_mi[MINIGOP // 4], Wd, Hd, ref_inputs["level"], ncpu) if ref_inputs else None
     return {"value": round(fps_all, 3), "unit": "frames/s", "cores": n_all, "hardware_threads": hw_threads, "cpu_quota_cores": quota, "kind": "port", "cpu_model": cpu_model(),
+            **(ref_stages or {}),
             "value_8_cores": round(fps_8, 3), "scaling_vs_8_cores": round(fps_all / max(fps_8, 1e-9), 2),
             "seconds_all_cores": round(wall_all, 2), "seconds_8_cores": round(wall_8, 2),
             "reference_me": reference_me_rate(T, B, orc, frames, Wd, Hd, enc_mode, tune, l1_on, ncpu),

@@ -10,12 +10,14 @@
  *           filter_level, sharpness, y_only, run_binding, device; mi_rows * mi_cols cells of 6 bytes {sb_type, tx_size, skip, ref_frame[0],
  *           mode, segment_id}; Y (y_stride * rows_y), U, V (uv_stride * rows_uv)
  * response: the three planes as the reference left them, int32 binding_rc, the three planes as the binding left them (when run_binding),
- *           then the LOOP_FILTER_MASK array eb_vp9_build_mask_frame built ([sb_rows][lfm_stride])
+ *           then the LOOP_FILTER_MASK array eb_vp9_build_mask_frame built ([sb_rows][lfm_stride]), then one double: the seconds the
+ *           reference's two calls took (clock_gettime around them: bench.py's cpu_baseline.reference_lf)
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
+#include <time.h>
 
 #define RTCD_C
 #include "vpx_dsp_rtcd.h"
@@ -68,7 +70,10 @@ int main(int argc, char **argv) {
     cm->lf.filter_level = level;
 
     /* the call site: masks, then the filter -- reference */
+    struct timespec t0, t1, t2;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     eb_vp9_build_mask_frame(cm, level, 0);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
     /* (the filter adjusts the masks in place, eb_vp9_adjust_mask :786: the binding, which stands where the filter call stands, gets them as
        eb_vp9_build_mask_frame left them) */
     const size_t      lfm_bytes = sizeof(LOOP_FILTER_MASK) * (size_t)sb_rows * lfm_stride;
@@ -82,7 +87,14 @@ int main(int argc, char **argv) {
     }
     MACROBLOCKD *xd = (MACROBLOCKD *)calloc(1, sizeof *xd);
     for (int k = 0; k < 3; k++) { xd->plane[k].dst.buf = a[k]; xd->plane[k].dst.stride = k ? uvs : ys; xd->plane[k].subsampling_x = xd->plane[k].subsampling_y = k ? 1 : 0; }
+    clock_gettime(CLOCK_MONOTONIC, &t2);
     eb_vp9_loop_filter_frame(cm, xd, level, y_only, 0);
+    {
+        struct timespec t3;
+        clock_gettime(CLOCK_MONOTONIC, &t3);
+        t2.tv_sec = t3.tv_sec - t2.tv_sec; t2.tv_nsec = t3.tv_nsec - t2.tv_nsec; /* the filter alone */
+    }
+    const double seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) + (double)t2.tv_sec + 1e-9 * (double)t2.tv_nsec;
 
     FILE *o = fopen(argv[2], "wb");
     if (!o) return 2;
@@ -103,6 +115,7 @@ int main(int argc, char **argv) {
         fwrite(b[0], 1, ysz, o); fwrite(b[1], 1, uvsz, o); fwrite(b[2], 1, uvsz, o);
     } else fwrite(&brc, 4, 1, o);
     fwrite(lfm_built, 1, lfm_bytes, o);
+    fwrite(&seconds, sizeof seconds, 1, o);
     fclose(o);
     return 0;
 }

@@ -17,12 +17,14 @@
  * request: int32 magic 'SVMC', mi_rows, mi_cols, mi_stride, use_subpel, asm_type,
  *          2 x { int32 y_stride, uv_stride, org_x, org_y, y_rows, uv_rows; Y plane (y_stride*y_rows), U, V (uv_stride*uv_rows) },
  *          mi_rows*mi_stride svt_mc_mode_info
- * response: pred Y (W*H), U, V (W/2*H/2), tight.
+ * response: pred Y (W*H), U, V (W/2*H/2), tight; then one double: the seconds the block loop took (clock_gettime around the
+ *           inter_prediction calls only -- bench.py's cpu_baseline.reference_mc, free of this harness's file I/O).
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
+#include <time.h>
 
 #define RTCD_C
 #include "vpx_dsp_rtcd.h"
@@ -94,6 +96,8 @@ int main(int argc, char **argv) {
     xd->mi = &mip;
     ctx->ep_block_stats_ptr = &st;
 
+    struct timespec t_begin, t_end;
+    clock_gettime(CLOCK_MONOTONIC, &t_begin);
     for (int r = 0; r < mi_rows; r++)
         for (int c = 0; c < mi_cols; c++) {
             const svt_mc_mode_info *m = &cells[(size_t)r * mi_stride + c];
@@ -120,9 +124,12 @@ int main(int argc, char **argv) {
                 inter_prediction(ctx, pred[p] + (size_t)((r * 8) >> ss) * ps + ((c * 8) >> ss), (uint16_t)ps, p);
             }
         }
+    clock_gettime(CLOCK_MONOTONIC, &t_end);
+    const double seconds = (double)(t_end.tv_sec - t_begin.tv_sec) + 1e-9 * (double)(t_end.tv_nsec - t_begin.tv_nsec);
     FILE *o = fopen(argv[2], "wb");
     if (!o) return 2;
     fwrite(pred[0], 1, (size_t)W * H, o); fwrite(pred[1], 1, (size_t)W * H / 4, o); fwrite(pred[2], 1, (size_t)W * H / 4, o);
+    fwrite(&seconds, sizeof seconds, 1, o);
     fclose(o);
     return 0;
 }

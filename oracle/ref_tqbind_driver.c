@@ -9,12 +9,15 @@
  *           the prediction; mi_rows * mi_stride svt_lf_mode_info (square blocks: sb_type 0 = four 4x4, 3, 6, 9; inter; 12 = 64x64 with four
  *           32x32 transform units as :3813-3825)
  * response: int32 n_blocks; REFERENCE: per block {uint8 plane, tx_size; uint16 x, y, eob}, its qcoeff then dqcoeff (n*n int16 each);
- *           recon Y, U, V;  int32 binding_rc;  BINDING (when run_binding): the same per-block records and coefficients, recon Y, U, V
+ *           recon Y, U, V;  int32 binding_rc;  BINDING (when run_binding): the same per-block records and coefficients, recon Y, U, V;
+ *           then one double: the seconds spent inside the reference's perform_coding_loop calls (bench.py's cpu_baseline.reference_tq).
+ *           run_binding = -1: timing run -- the binding's append is left out of the loop, only the timing double follows the reference side
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
+#include <time.h>
 
 #define RTCD_C
 #include "vpx_dsp_rtcd.h"
@@ -81,6 +84,7 @@ int main(int argc, char **argv) {
     int16_t    *trans = (int16_t *)calloc(64 * 64, 2);
     size_t      cpos = 0;
     int32_t     nb = 0;
+    double      seconds = 0.0;
 
     SvtHipTqBinding b;
     memset(&b, 0, sizeof b);
@@ -118,14 +122,18 @@ int main(int argc, char **argv) {
                             const int    px = p ? (ROUND_UV(bx) >> 1) : bx + (t & 1) * tu, py = p ? (ROUND_UV(by) >> 1) : by + (t >> 1) * tu;
                             const size_t o = po[p] + (size_t)py * ps + px;
                             uint16_t     eob = 0;
+                            struct timespec ta, tb;
+                            clock_gettime(CLOCK_MONOTONIC, &ta);
                             perform_coding_loop(ctx, qa + cpos, bs, srcp + o, (uint16_t)ps, predp + o, (uint16_t)ps, trans, dqa + cpos, rec_a + o, (uint16_t)ps,
                                                 p ? quants->uv_zbin[q_index] : quants->y_zbin[q_index], p ? quants->uv_round[q_index] : quants->y_round[q_index],
                                                 p ? quants->uv_quant[q_index] : quants->y_quant[q_index], p ? quants->uv_quant_shift[q_index] : quants->y_quant_shift[q_index],
                                                 p ? &cpi->uv_dequant[q_index][0] : &cpi->y_dequant[q_index][0], &eob, (TX_SIZE)txs, p, 1, 1);
+                            clock_gettime(CLOCK_MONOTONIC, &tb);
+                            seconds += (double)(tb.tv_sec - ta.tv_sec) + 1e-9 * (double)(tb.tv_nsec - ta.tv_nsec);
                             ra[nb].plane = (uint8_t)p; ra[nb].tx_size = (uint8_t)txs; ra[nb].x = (uint16_t)px; ra[nb].y = (uint16_t)py; ra[nb].eob = eob;
                             rb[nb] = ra[nb];
                             /* the same call site with the binding: append now, transform at the flush */
-                            if (svt_hip_bind_coding_loop(&b, ctx, srcp + o, (uint16_t)ps, predp + o, (uint16_t)ps, rec_b + o, (uint16_t)ps, (TX_SIZE)txs, p, 1) != nb) return 6;
+                            if (run_binding >= 0 && svt_hip_bind_coding_loop(&b, ctx, srcp + o, (uint16_t)ps, predp + o, (uint16_t)ps, rec_b + o, (uint16_t)ps, (TX_SIZE)txs, p, 1) != nb) return 6;
                             cpos += (size_t)bs * bs;
                             nb++;
                         }
@@ -139,7 +147,7 @@ int main(int argc, char **argv) {
     fwrite(qa, 2, cpos, o); fwrite(dqa, 2, cpos, o);
     fwrite(rec_a, 1, nall, o);
     int32_t brc = -100;
-    if (run_binding) {
+    if (run_binding > 0) {
         if (svt_hip_ctx_create(&b.hip, device) != 0) { fprintf(stderr, "binding: %s\n", svt_hip_last_error()); brc = -101; }
         else {
             brc = svt_hip_bind_coding_loop_flush(&b);
@@ -152,6 +160,7 @@ int main(int argc, char **argv) {
         fwrite(b.qcoeff, 2, cpos, o); fwrite(b.dqcoeff, 2, cpos, o);
         fwrite(rec_b, 1, nall, o);
     } else fwrite(&brc, 4, 1, o);
+    fwrite(&seconds, sizeof seconds, 1, o);
     fclose(o);
     return 0;
 }

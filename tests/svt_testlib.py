@@ -1123,7 +1123,21 @@ def hip_mc_frame(ctx, case):
     return out
 
 
-def ref_mc_frame(case, asm_type=0):
+def _run_timed(exe, req, td, n, env=None):
+    """runs `exe req rsp_k` n times at once (one process each) and returns the n timing doubles the harnesses append to their responses"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(k):
+        rsp = os.path.join(td, f"rsp{k}.bin")
+        subprocess.check_call([exe, req, rsp], env=env)
+        with open(rsp, "rb") as f:
+            f.seek(-8, 2)
+            return struct.unpack("<d", f.read(8))[0]
+    with ThreadPoolExecutor(n) as ex:
+        return list(ex.map(one, range(n)))
+
+
+def ref_mc_frame(case, asm_type=0, timing=0):
     """the reference's own inter_prediction() for every block (oracle/_ref/ref_mc_frame); units it does not predict are 0"""
     exe = os.path.join(REF_DIR, "ref_mc_frame")
     mi = np.ascontiguousarray(case["mi"])
@@ -1136,6 +1150,8 @@ def ref_mc_frame(case, asm_type=0):
                 f.write(struct.pack("<6i", y.shape[1], u.shape[1], case["pad"], case["pad"], y.shape[0], u.shape[0]))
                 f.write(y.tobytes()); f.write(u.tobytes()); f.write(v.tobytes())
             f.write(mi.tobytes())
+        if timing:
+            return _run_timed(exe, req, td, timing)
         subprocess.check_call([exe, req, rsp])
         raw = open(rsp, "rb").read()
     return [np.frombuffer(raw, np.uint8, W * H).reshape(H, W).copy(),
@@ -1555,7 +1571,7 @@ def ref_me_process(cur, ref0, ref1, enc_mode, tune, temporal_layer, p_slice=0, u
     return out
 
 
-def ref_lf_call_site(y, u, v, cells, filter_level, sharpness=0, y_only=False, run_binding=False, device=0):
+def ref_lf_call_site(y, u, v, cells, filter_level, sharpness=0, y_only=False, run_binding=False, device=0, timing=0):
     """The deblocking call site of the reference's encode pass (Codec/EbEncDecProcess.c:5676-5686) on a real VP9_COMMON / MACROBLOCKD
     (oracle/_ref/ref_lf_binding): eb_vp9_build_mask_frame + eb_vp9_loop_filter_frame, and -- run_binding -- the same with
     integration/loop_filter_binding.h in place of the second call.  y / u / v: picture planes (W x H, W/2 x H/2); cells: [mi_rows][mi_cols][6].
@@ -1576,6 +1592,8 @@ def ref_lf_call_site(y, u, v, cells, filter_level, sharpness=0, y_only=False, ru
             f.write(yp.tobytes()); f.write(up.tobytes()); f.write(vp_.tobytes())
         env = dict(os.environ)
         env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "svt-vp9_amd") + ":" + env.get("LD_LIBRARY_PATH", "")
+        if timing:
+            return _run_timed(exe, req, td, timing, env)
         subprocess.check_call([exe, req, rsp], env=env)
         raw = open(rsp, "rb").read()
     ys, us = yp.size, up.size
@@ -1595,7 +1613,7 @@ def ref_lf_call_site(y, u, v, cells, filter_level, sharpness=0, y_only=False, ru
     return ref, bind, brc, lfm
 
 
-def ref_coding_loop_call_sites(src, pred, lf_mi, q_index, run_binding=False, device=0):
+def ref_coding_loop_call_sites(src, pred, lf_mi, q_index, run_binding=False, device=0, timing=0):
     """The transform call sites of the reference's encode pass (Codec/EbEncDecProcess.c:3830, 3890, 3940) on an inter picture
     (oracle/_ref/ref_tq_binding): the reference's own perform_coding_loop per transform block and -- run_binding -- integration/
     coding_loop_binding.h (append per call site, one svt_hip_tq_batch).  src / pred: (Y, U, V) tight planes; lf_mi: [mi_rows][mi_stride]
@@ -1607,13 +1625,15 @@ def ref_coding_loop_call_sites(src, pred, lf_mi, q_index, run_binding=False, dev
     with tempfile.TemporaryDirectory() as td:
         req, rsp = os.path.join(td, "req.bin"), os.path.join(td, "rsp.bin")
         with open(req, "wb") as f:
-            f.write(struct.pack("<7i", 0x42545653, W, H, lf_mi.shape[1], q_index, int(run_binding), device))
+            f.write(struct.pack("<7i", 0x42545653, W, H, lf_mi.shape[1], q_index, -1 if timing else int(run_binding), device))
             for planes in (src, pred):
                 for p_ in planes:
                     f.write(np.ascontiguousarray(p_).tobytes())
             f.write(np.ascontiguousarray(lf_mi).tobytes())
         env = dict(os.environ)
         env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "svt-vp9_amd") + ":" + env.get("LD_LIBRARY_PATH", "")
+        if timing:
+            return _run_timed(exe, req, td, timing, env)
         subprocess.check_call([exe, req, rsp], env=env)
         raw = open(rsp, "rb").read()
     nb = struct.unpack_from("<i", raw, 0)[0]
