@@ -187,6 +187,12 @@ extern "C" int32_t svt_hip_mem_upload_2d(svt_hip_ctx *ctx, void *d_dst, size_t d
     HIP_TRY(hipStreamSynchronize(ctx->stream)); /* the host rows may be pageable and are the caller's to reuse on return */
     return SVT_HIP_OK;
 }
+/* flags of the pinned staging buffers (experiment aid: SVT_HIP_STAGING_FLAGS = a hipHostMalloc flag word) */
+static unsigned svt_staging_flags() {
+    static const unsigned f = [] { const char *e = getenv("SVT_HIP_STAGING_FLAGS"); return e ? (unsigned)strtoul(e, nullptr, 0) : (unsigned)hipHostMallocDefault; }();
+    return f;
+}
+
 /* The rows are copied into a pinned staging buffer of the context before the call returns (the copy the reference makes of an
  * input picture inside eb_vp9_svt_enc_send_picture, Codec/EbEncHandle.c:2743-2796): the caller may reuse them at once, the
  * host-to-device copy runs asynchronously in stream order. */
@@ -202,7 +208,7 @@ extern "C" int32_t svt_hip_mem_upload_2d_async(svt_hip_ctx *ctx, void *d_dst, si
     if (bytes > ctx->up_bytes[k]) {
         if (ctx->up_host[k]) (void)hipHostFree(ctx->up_host[k]);
         ctx->up_host[k] = nullptr; ctx->up_bytes[k] = 0;
-        if (hipHostMalloc(&ctx->up_host[k], bytes, hipHostMallocDefault) != hipSuccess) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "mem_upload_async: pinned staging buffer");
+        if (hipHostMalloc(&ctx->up_host[k], bytes, svt_staging_flags()) != hipSuccess) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "mem_upload_async: pinned staging buffer");
         ctx->up_bytes[k] = bytes;
     }
     uint8_t *st = (uint8_t *)ctx->up_host[k];
@@ -242,7 +248,7 @@ extern "C" int32_t svt_hip_mem_upload_planes_async(svt_hip_ctx *ctx, int32_t n_p
     if (bytes > ctx->up_bytes[k]) {
         if (ctx->up_host[k]) (void)hipHostFree(ctx->up_host[k]);
         ctx->up_host[k] = nullptr; ctx->up_bytes[k] = 0;
-        if (hipHostMalloc(&ctx->up_host[k], bytes, hipHostMallocDefault) != hipSuccess) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "mem_upload_planes: pinned staging buffer");
+        if (hipHostMalloc(&ctx->up_host[k], bytes, svt_staging_flags()) != hipSuccess) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "mem_upload_planes: pinned staging buffer");
         ctx->up_bytes[k] = bytes;
     }
     if (prof) { const double t1 = now(); ctx->up_prof[0] += t1 - t0; t0 = t1; }

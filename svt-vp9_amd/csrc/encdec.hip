@@ -43,6 +43,9 @@ struct svt_encdec_work {
     svt_quant_tables *d_qtabs;   /* [2] luma, chroma of the batch's q index */
     int16_t      *d_iscan;
     int           last_pics;
+    /* SB-ordered lists (round 6, the default): [picture][chunk of SVT_TQ_CHUNK_SBS SBs of an SB row][size][SB][unit][plane]; d_counts then holds,
+       per picture, n_chunks x 4 x SVT_TQ_CHUNK_SBS per-SB counts turned into exclusive prefixes, d_bases n_pics + 1 first blocks */
+    int           sb_order, chunks_per_row, n_chunks;
     svt_encdec_stage_hook hook;  /* profiling aid: called on the enqueueing thread at every stage boundary */
     void         *hook_user;
 };
@@ -154,6 +157,87 @@ __global__ __launch_bounds__(64) void svt_tq_emit_kernel(const ed_batch_dev *__r
     uint32_t base[4];
     _Pragma("unroll") for (int s = 0; s < 4; s++) base[s] = (uint32_t)(bases[s * B->n_pics + pic] + offsets[(s * B->n_pics + pic) * B->n_sb + sb] + wave_excl_prefix(cnt[s], lane));
     if (o == 1) svt_tq_unit_emit(P.lf_mi, B->mi_stride, ur, uc, &P.g, B->iscan_off, base, blocks, pos);
+}
+
+/* ---- SB-ordered lists (one transform launch, tq_kernel.hip: svt_tq_sb_kernel) ----
+ * counts2[pic][chunk][size][k]: transform blocks of size `size` in SB k of the chunk; the exclusive prefix over a picture's row of
+ * n_chunks * 4 * CH entries IS the list order [chunk][size][SB], so one scan gives every SB's slot and every (chunk, size) segment. */
+__device__ __forceinline__ int ed_seg_index(const ed_batch_dev *B, int chunks_per_row, int pic, int sb, int s) {
+    const int sr = sb / B->sb_cols, sc = sb - sr * B->sb_cols, chunk = sr * chunks_per_row + sc / SVT_TQ_CHUNK_SBS, k = sc % SVT_TQ_CHUNK_SBS;
+    const int n_chunks = chunks_per_row * ((B->height + 63) >> 6);
+    return ((pic * n_chunks + chunk) * 4 + s) * SVT_TQ_CHUNK_SBS + k;
+}
+__global__ __launch_bounds__(64) void svt_tq_count_sb_kernel(const ed_batch_dev *__restrict__ B, int32_t *__restrict__ counts, int32_t *__restrict__ status, int chunks_per_row) {
+    const int sb = (int)blockIdx.x % B->n_sb, pic = (int)blockIdx.x / B->n_sb, lane = (int)threadIdx.x;
+    const ed_pic_dev &P = B->pic[pic];
+    const int ur = (sb / B->sb_cols) * 8 + (lane >> 3), uc = (sb % B->sb_cols) * 8 + (lane & 7);
+    int cnt[4] = {0, 0, 0, 0};
+    if (ur < B->mi_rows && uc < B->mi_cols) P.nz[ur * B->mi_stride + uc] = 0;
+    const int o = svt_tq_unit_is_origin(P.lf_mi, B->mi_stride, B->mi_rows, B->mi_cols, ur, uc);
+    if (o < 0) atomicOr(status, 1);
+    if (o == 1) svt_tq_unit_counts(P.lf_mi, B->mi_stride, ur, uc, cnt);
+    _Pragma("unroll") for (int s = 0; s < 4; s++) {
+        const int v = wave_sum(cnt[s]);
+        if (lane == 0) counts[ed_seg_index(B, chunks_per_row, pic, sb, s)] = v;
+    }
+}
+/* one workgroup per picture: exclusive prefix over the picture's row in place, the picture's total, and its blocks per size */
+__global__ __launch_bounds__(256) void svt_scan_seg_kernel(int32_t *__restrict__ a, int n_per_pic, int32_t *__restrict__ totals, int32_t *__restrict__ size_tot /* [4], zeroed */) {
+    __shared__ int32_t part[256];
+    __shared__ int32_t szs[4];
+    int32_t *p = a + (size_t)blockIdx.x * n_per_pic;
+    const int t = (int)threadIdx.x, per = (n_per_pic + 255) / 256, b = t * per, e = b + per < n_per_pic ? b + per : n_per_pic;
+    if (t < 4) szs[t] = 0;
+    int s = 0, sz[4] = {0, 0, 0, 0};
+    for (int i = b; i < e; i++) { const int v = p[i]; s += v; sz[(i / SVT_TQ_CHUNK_SBS) & 3] += v; }
+    part[t] = s;
+    __syncthreads();
+    _Pragma("unroll") for (int k = 0; k < 4; k++) { const int v = wave_sum(sz[k]); if ((t & 63) == 0 && v) atomicAdd(&szs[k], v); }
+    for (int d = 1; d < 256; d <<= 1) {
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int i = b; i < e; i++) { const int v = p[i]; p[i] = run; run += v; }
+    if (t == 255) totals[blockIdx.x] = part[255];
+    if (t < 4 && szs[t]) atomicAdd(&size_tot[t], szs[t]);
+}
+/* bases[pic] (n_pics + 1 entries: the last = the batch's total) and off_cnt in the layout every consumer of the totals knows: [s] = blocks of the
+ * smaller sizes, [4 + s] = blocks of size s (so off_cnt[3] + off_cnt[7] = total, as with the size-grouped lists) */
+__global__ __launch_bounds__(64) void svt_scan_pic_sb_kernel(const int32_t *__restrict__ totals, int n_pics, int32_t *__restrict__ bases, int32_t *__restrict__ off_cnt,
+                                                             const int32_t *__restrict__ size_tot) {
+    if (threadIdx.x != 0) return;
+    int run = 0;
+    for (int p = 0; p < n_pics; p++) { bases[p] = run; run += totals[p]; }
+    bases[n_pics] = run;
+    int o = 0;
+    for (int s = 0; s < 4; s++) { off_cnt[s] = o; off_cnt[4 + s] = size_tot[s]; o += size_tot[s]; }
+}
+__global__ __launch_bounds__(64) void svt_tq_emit_sb_kernel(const ed_batch_dev *__restrict__ B, const int32_t *__restrict__ seg, const int32_t *__restrict__ bases,
+                                                            uint32_t *__restrict__ pos, int chunks_per_row) {
+    const int sb = (int)blockIdx.x % B->n_sb, pic = (int)blockIdx.x / B->n_sb, lane = (int)threadIdx.x;
+    const ed_pic_dev &P = B->pic[pic];
+    const int ur = (sb / B->sb_cols) * 8 + (lane >> 3), uc = (sb % B->sb_cols) * 8 + (lane & 7);
+    int cnt[4] = {0, 0, 0, 0};
+    const int o = svt_tq_unit_is_origin(P.lf_mi, B->mi_stride, B->mi_rows, B->mi_cols, ur, uc);
+    if (o == 1) svt_tq_unit_counts(P.lf_mi, B->mi_stride, ur, uc, cnt);
+    uint32_t base[4];
+    _Pragma("unroll") for (int s = 0; s < 4; s++) base[s] = (uint32_t)(bases[pic] + seg[ed_seg_index(B, chunks_per_row, pic, sb, s)] + wave_excl_prefix(cnt[s], lane));
+    if (o == 1) svt_tq_unit_emit(P.lf_mi, B->mi_stride, ur, uc, &P.g, B->iscan_off, base, (svt_tq_block *)nullptr, pos);
+}
+/* descriptor list for a host that asks (svt_hip_encdec_work_download), SB-ordered lists: one workgroup per (picture, chunk, size) segment */
+__global__ __launch_bounds__(64) void svt_tq_expand_sb_kernel(const ed_batch_dev *__restrict__ B, const int32_t *__restrict__ seg, const int32_t *__restrict__ bases,
+                                                              const uint32_t *__restrict__ pos, svt_tq_block *__restrict__ blocks, int n_chunks) {
+    const int s = (int)blockIdx.x & 3, item = (int)blockIdx.x >> 2, pic = item / n_chunks, chunk = item - pic * n_chunks;
+    const int per_pic = n_chunks * 4 * SVT_TQ_CHUNK_SBS, at = (chunk * 4 + s) * SVT_TQ_CHUNK_SBS, nxt = at + SVT_TQ_CHUNK_SBS;
+    const int first = bases[pic] + seg[pic * per_pic + at], last = nxt < per_pic ? bases[pic] + seg[pic * per_pic + nxt] : bases[pic + 1];
+    for (int i = first + (int)threadIdx.x; i < last; i += 64) {
+        svt_tq_block k;
+        svt_tq_block_from_pos(pos[i], s, &B->pic[svt_tq_pos_pic(pos[i])].g, B->iscan_off, B->sb_cols, &k);
+        blocks[i] = k;
+    }
 }
 
 /* after the transform stage: the eob of every block goes to its place in the picture's eob map, and a block with coefficients marks
@@ -270,21 +354,31 @@ extern "C" int32_t svt_hip_encdec_work_create(svt_hip_ctx *ctx, int32_t max_pics
     w->sb_cols = (width + 63) >> 6; w->n_sb = w->sb_cols * ((height + 63) >> 6);
     w->mi_rows = height >> 3; w->mi_cols = width >> 3;
     w->cap_per_pic = (size_t)width * height * 3 / 32;
+    /* SVT_HIP_TQ_SB_ORDER=1: SB-ordered lists and the SB-ordered transform launch(es) (svt_tq_sb_kernel) instead of the size-grouped lists with one
+     * launch per transform size.  Measured on MI355X, 2160p, 16 pictures (profiles/r06_pmc_traffic.md): the stage's HBM-side traffic drops from
+     * 2.08 GB to 1.50 GB (reads 1.19 -> 0.55 GB: an SB is fetched once instead of once per size) -- and the step gets SLOWER (10.2 -> 10.5 ms; the
+     * stage alone 0.63 -> 0.68 ms): the one launch holds the 32x32 body's 128 registers and 16.9 KB of LDS in every workgroup and balances worse
+     * than the persistent size-grouped walks; the bytes it saves were not what bounded the stage.  So the size-grouped form stays the default;
+     * read per workspace so that the tests cover both. */
+    { const char *e = getenv("SVT_HIP_TQ_SB_ORDER"); w->sb_order = e && atoi(e) != 0; }
+    w->chunks_per_row = (w->sb_cols + SVT_TQ_CHUNK_SBS - 1) / SVT_TQ_CHUNK_SBS;
+    w->n_chunks = w->chunks_per_row * ((height + 63) >> 6);
     const size_t cap = w->cap_per_pic * (size_t)max_pics;
+    const size_t n_cnt = (size_t)4 * max_pics * (w->sb_order ? (size_t)w->n_chunks * SVT_TQ_CHUNK_SBS : (size_t)w->n_sb);
     uint32_t const *offs = nullptr;
     int32_t         entries = 0;
     const int16_t  *isc = svt_hip_vp9_iscan_tables(&offs, &entries);
     /* the lists are position codes (4 bytes per transform block; the 32-byte descriptors are rebuilt in registers where they are used) */
     bool ok = hipMalloc((void **)&w->d_pos, cap * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&w->d_eob, cap * sizeof(uint16_t)) == hipSuccess &&
-              hipMalloc((void **)&w->d_counts, ((size_t)4 * max_pics * w->n_sb + 16 + 8 * ED_MAX_PICS + 4 + 12 * (size_t)w->n_sb) * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void **)&w->d_counts, (n_cnt + 16 + 8 * ED_MAX_PICS + 8 + 12 * (size_t)w->n_sb) * sizeof(int32_t)) == hipSuccess &&
               hipMalloc((void **)&w->d_qtabs, 2 * sizeof(svt_quant_tables)) == hipSuccess && hipMalloc((void **)&w->d_iscan, (size_t)entries * sizeof(int16_t)) == hipSuccess;
     if (ok) {
-        w->d_off_cnt = w->d_counts + (size_t)4 * max_pics * w->n_sb;
-        w->d_status = w->d_off_cnt + 8;
+        w->d_off_cnt = w->d_counts + n_cnt;
+        w->d_status = w->d_off_cnt + 8;   /* (d_off_cnt[9 .. 12]: per-size totals of the SB-ordered scan) */
         w->d_totals = w->d_off_cnt + 16;
-        w->d_bases = w->d_totals + 4 * ED_MAX_PICS;
-        w->d_intra_sync = w->d_bases + 4 * ED_MAX_PICS;
+        w->d_bases = w->d_totals + 4 * ED_MAX_PICS;   /* 4 * ED_MAX_PICS entries (size-grouped) / n_pics + 1 (SB-ordered) */
+        w->d_intra_sync = w->d_bases + 4 * ED_MAX_PICS + 4;
         ok = hipMemsetAsync(w->d_off_cnt, 0, 16 * sizeof(int32_t), ctx->stream) == hipSuccess &&
              hipMemcpyAsync(w->d_iscan, isc, (size_t)entries * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
              hipStreamSynchronize(ctx->stream) == hipSuccess;
@@ -436,10 +530,21 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
     /* 2. transform blocks from the grids */
     ED_STAGE(SVT_ENCDEC_STAGE_LISTS);
     const int nwg = n_pics * hb.n_sb;
+    const int seg_per_pic = w->n_chunks * 4 * SVT_TQ_CHUNK_SBS;
+    if (w->sb_order) {
+        /* (a chunk at the right edge may hold fewer SBs than SVT_TQ_CHUNK_SBS: its missing entries count 0) */
+        if (w->sb_cols % SVT_TQ_CHUNK_SBS) HIP_TRY(hipMemsetAsync(w->d_counts, 0, (size_t)n_pics * seg_per_pic * sizeof(int32_t), ctx->stream));
+        HIP_TRY(hipMemsetAsync(w->d_off_cnt + 9, 0, 4 * sizeof(int32_t), ctx->stream));
+        hipLaunchKernelGGL(svt_tq_count_sb_kernel, dim3(nwg), dim3(64), 0, ctx->stream, dB, w->d_counts, w->d_status, w->chunks_per_row);
+        hipLaunchKernelGGL(svt_scan_seg_kernel, dim3(n_pics), dim3(256), 0, ctx->stream, w->d_counts, seg_per_pic, w->d_totals, w->d_off_cnt + 9);
+        hipLaunchKernelGGL(svt_scan_pic_sb_kernel, dim3(1), dim3(64), 0, ctx->stream, (const int32_t *)w->d_totals, n_pics, w->d_bases, w->d_off_cnt, (const int32_t *)(w->d_off_cnt + 9));
+        hipLaunchKernelGGL(svt_tq_emit_sb_kernel, dim3(nwg), dim3(64), 0, ctx->stream, dB, (const int32_t *)w->d_counts, (const int32_t *)w->d_bases, w->d_pos, w->chunks_per_row);
+    } else {
     hipLaunchKernelGGL(svt_tq_count_kernel, dim3(nwg), dim3(64), 0, ctx->stream, dB, w->d_counts, w->d_status);
     hipLaunchKernelGGL(svt_scan_sb_kernel, dim3(4 * n_pics), dim3(256), 0, ctx->stream, w->d_counts, hb.n_sb, w->d_totals);
     hipLaunchKernelGGL(svt_scan_pic_kernel, dim3(1), dim3(64), 0, ctx->stream, (const int32_t *)w->d_totals, n_pics, w->d_bases, w->d_off_cnt);
     hipLaunchKernelGGL(svt_tq_emit_kernel, dim3(nwg), dim3(64), 0, ctx->stream, dB, (const int32_t *)w->d_counts, (const int32_t *)w->d_bases, (svt_tq_block *)nullptr, w->d_pos);
+    }
     HIP_TRY(hipGetLastError());
     if (!w->last_hb) w->last_hb = malloc(sizeof hb);
     if (w->last_hb) memcpy(w->last_hb, &hb, sizeof hb);
@@ -447,6 +552,10 @@ extern "C" int32_t svt_hip_encdec_batch_device(svt_hip_ctx *ctx, svt_encdec_work
     ED_STAGE(SVT_ENCDEC_STAGE_TQ);
     int32_t cap[4];
     for (int s = 0; s < 4; s++) cap[s] = (int32_t)((size_t)n_pics * width * height * 3 / 2 / (size_t)(16 << (2 * s)));
+    if (w->sb_order)
+        rc = svt_tq_launch_sb_lists(ctx, (const uint8_t *)src_lo, (const uint8_t *)pred_lo, recon_set, n_sets, w->d_qtabs, w->d_iscan, (int16_t *)q_lo, (int16_t *)dq_lo, w->d_eob,
+                                    w->d_pos, &dB->pic[0].g, (int)sizeof(ed_pic_dev), dB->iscan_off, hb.sb_cols, w->d_counts, w->d_bases, n_pics, w->n_chunks, 4 * SVT_TQ_CHUNK_SBS);
+    else
     rc = svt_tq_launch_device_lists(ctx, (const uint8_t *)src_lo, (const uint8_t *)pred_lo, recon_set, n_sets, nullptr, cap, w->d_off_cnt, w->d_qtabs, w->d_iscan,
                                     (int16_t *)q_lo, (int16_t *)dq_lo, w->d_eob, nullptr, w->d_pos, &dB->pic[0].g, (int)sizeof(ed_pic_dev), dB->iscan_off, hb.sb_cols);
     if (rc) return rc;
@@ -602,6 +711,10 @@ extern "C" int32_t svt_hip_encdec_work_download(svt_hip_ctx *ctx, svt_encdec_wor
             }
             const ed_batch_dev *dB = nullptr;
             if (stage_batch(ctx, *(const ed_batch_dev *)w->last_hb, &dB)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "encdec_download: descriptor buffers");
+            if (w->sb_order)
+                hipLaunchKernelGGL(svt_tq_expand_sb_kernel, dim3(4 * w->last_pics * w->n_chunks), dim3(64), 0, ctx->stream, dB, (const int32_t *)w->d_counts, (const int32_t *)w->d_bases,
+                                   (const uint32_t *)w->d_pos, w->d_blocks, w->n_chunks);
+            else
             hipLaunchKernelGGL(svt_tq_expand_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, dB, (const int32_t *)w->d_off_cnt, (const uint32_t *)w->d_pos, w->d_blocks);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(blocks, w->d_blocks, (size_t)total * sizeof(svt_tq_block), hipMemcpyDeviceToHost, ctx->stream));

@@ -214,8 +214,24 @@ template <int WS> SVT_DEV void fph_hme_search(const me_ctx_t *c, int tid, int ws
     const uint32_t inv = me_magics.v[ng2]; /* ng2 in [2, 32] */
     uint32_t       b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu, b3 = 0xffffffffu;
     const uint32_t *blk = (const uint32_t *)c->st->sixteenth_sb; /* the block: 8 rows of 4 dwords (same address in every lane: broadcast reads) */
-    for (int T = tid; T < ntask; T += SVT_NT) {
-        const int y = (int)__umulhi((uint32_t)T, inv), g = 2 * (T - ME_MUL(y, ng2));
+    /* Which (row, run) a lane takes decides the bank conflicts of its five reads per window row: a lane reads dwords y * (ws / 4) + 2 * run + i,
+     * the LDS serves 32 lanes per pass, and any two lanes of a pass on one bank with different addresses double it.  With T -> (T / 8, T % 8)
+     * a pass held four CONSECUTIVE rows x eight runs -- two rows of equal parity always shared a bank: every read took 8.1 instead of 4.15 LDS
+     * cycles (tools/ubench/lds_patterns.hip, profiles/r06_lds_patterns.txt).  For the common 64-wide area (eight runs per row) a pass now
+     * holds rows {y, y + 1, y + 16, y + 17}: ws / 4 is odd, so row y + 16 sits 16 banks further and row y + 1 on the banks of the other
+     * parity -- the four rows' 8-bank sets tile the 32 banks exactly.  Same tasks, same keys (a key carries its position). */
+    const bool tile32 = ng2 == 8;
+    const int  nt = tile32 ? ((nr + 31) & ~31) * 8 : ntask;
+    for (int T = tid; T < nt; T += SVT_NT) {
+        int y, g;
+        if (tile32) {
+            const int l = T & 63, blk32 = T >> 8, wv = (T >> 6) & 3;
+            y = 32 * blk32 + 4 * wv + ((l >> 3) & 1) + 2 * ((l >> 5) & 1) + 16 * ((l >> 4) & 1);
+            g = 2 * (l & 7);
+            if (y >= nr) continue;
+        } else {
+            y = (int)__umulhi((uint32_t)T, inv); g = 2 * (T - ME_MUL(y, ng2));
+        }
         /* byte offsets (inside the workgroup's LDS) of the run's first window dword and of the one after it, opaque to the compiler:
          * every QSAD operand pair (w[i], w[i + 1]) is then read as such by one ds_read2_b32 at an immediate offset -- the pairs of even
          * i from the first stream, of odd i from the second; nothing is assembled with register moves.  Window rows 12 and 14 lie

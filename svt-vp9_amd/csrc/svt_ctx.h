@@ -70,6 +70,12 @@ int32_t svt_tq_launch_device_lists(svt_hip_ctx *ctx, const uint8_t *d_src, const
                                    const int16_t *d_iscan, int16_t *d_qcoeff, int16_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_dist,
                                    const uint32_t *d_pos, const void *d_geom, int geom_stride, const uint32_t *d_iscan_off, int sb_cols);
 
+/* the same over SB-ordered lists: one launch, workgroup = (picture, chunk of SVT_TQ_CHUNK_SBS SBs, size, part) (tq_kernel.hip: svt_tq_sb_kernel) */
+#define SVT_TQ_CHUNK_SBS 4
+int32_t svt_tq_launch_sb_lists(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *const *recon_set, int n_set, const svt_quant_tables *d_qtabs,
+                               const int16_t *d_iscan, int16_t *d_qcoeff, int16_t *d_dqcoeff, uint16_t *d_eob, const uint32_t *d_pos, const void *d_geom, int geom_stride,
+                               const uint32_t *d_iscan_off, int sb_cols, const int32_t *d_seg, const int32_t *d_bases, int n_pics, int n_chunks, int seg_per_chunk);
+
 /* encode pass of an intra picture / the stand-in intra decision (intra_kernel.hip; used by encdec.hip).  d_sync: 2 + 3 * (number of
  * 32x32 luma areas) dwords of scratch */
 int32_t svt_intra_launch(svt_hip_ctx *ctx, const svt_encdec_picture *p, int32_t width, int32_t height, int32_t mi_stride, const svt_quant_tables *d_qtabs,

@@ -134,42 +134,13 @@ __device__ __forceinline__ int rate_walk4(const int (&tok)[16], const int (&en)[
  * 8x8: they differ in the cast inside tx_fdct8 (vp9_dct.c:67-68), selected by the block's transform type.  The inverse
  * always runs all rows (the reference's reduced variants are shortcuts with identical results).  Memory instructions per
  * block are unchanged (a lane issues the N row loads its N lanes issued). */
+/* one 4x4 (8x8) block, whole, in the calling lane: the body of svt_tq_lane_kernel and of the 4x4 part of svt_tq_sb_kernel */
 template <int N, bool RATE, bool DIST>
-__global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ pred,
-                                                          uint8_t *__restrict__ recon, const svt_tq_block *__restrict__ blocks,
-                                                          int n_blocks, const svt_quant_tables *__restrict__ qtabs,
-                                                          const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,
-                                                          int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out,
-                                                          uint64_t *__restrict__ dist_out, tq_rate_args ra, const uint8_t *const *__restrict__ recon_set, tq_dev_count dc) {
-    if (dc.p) {
-        const int o = dc.p[dc.s];
-        n_blocks = dc.p[4 + dc.s];
-        blocks += o; eob_out += o;
-        if (dc.pos) dc.pos += o;
-        if (dist_out) dist_out += 2 * o;
-        if constexpr (RATE) ra.bits += o;
-    }
-    static_assert(N == 4 || N == 8, "block-per-lane form: 4x4 and 8x8 only");
-    static_assert(!RATE || N == 4, "in-lane rate: 4x4 only");
+__device__ __forceinline__ void tq_lane_block(const svt_tq_block &k, const int blk, const uint8_t *__restrict__ src, const uint8_t *__restrict__ pred, uint8_t *__restrict__ recon,
+                                              const svt_quant_tables *__restrict__ qtabs, const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,
+                                              int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out, uint64_t *__restrict__ dist_out, const tq_rate_args &ra,
+                                              const uint32_t *s_tc, const int32_t *s_vc, const uint8_t *const *__restrict__ recon_set) {
     constexpr int ND = N / 4; /* dwords per row of samples */
-    /* RATE: the four 4x4 token-cost slices [plane_type][is_inter] and the value-cost table, copied once per workgroup */
-    __shared__ uint32_t s_tc[RATE ? 4 * RATE_SLICE : 1];
-    __shared__ int32_t  s_vc[RATE ? 136 : 1];
-    if constexpr (RATE) {
-        const uint32_t *g = &ra.T->token_costs[0][0][0][0][0][0][0];
-        for (int j = threadIdx.x; j < 4 * RATE_SLICE; j += 256) s_tc[j] = g[j];
-        if (threadIdx.x < 133) s_vc[threadIdx.x] = ra.T->value_cost[threadIdx.x];
-        __syncthreads();
-    }
-    const tq_walk wk = tq_walk_of((n_blocks + 255) / 256);
-  for (int gj = wk.first; gj < wk.per_xcd; gj += wk.step) {
-    const int blk = (wk.base + gj) * 256 + (int)threadIdx.x;
-    if (blk >= n_blocks) continue; /* no barrier inside the loop */
-    svt_tq_block k;
-    if (dc.pos) {
-        const uint32_t pc = dc.pos[blk];
-        svt_tq_block_from_pos(pc, txcfg<N>::size, (const svt_tq_pic_geom *)(dc.geom + (size_t)svt_tq_pos_pic(pc) * dc.geom_stride), dc.iscan_off, dc.sb_cols, &k);
-    } else k = blocks[blk];
     const bool col_adst = k.tx_type == SVT_ADST_DCT || k.tx_type == SVT_ADST_ADST;
     const bool row_adst = k.tx_type == SVT_DCT_ADST || k.tx_type == SVT_ADST_ADST;
     const bool dct_dct  = k.tx_type == SVT_DCT_DCT;
@@ -284,7 +255,7 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
         /* value costs: every position before eob pays the cost of its value; the zeros among them pay value_cost[0 + 66] */
         ra.bits[blk] = bits + vsum + (eob - nnz) * s_vc[66];
     }
-    if (!k.do_recon) continue;
+    if (!k.do_recon) return;
     /* ---- reconstruction: rows first, then columns (vp9_idct.c:111-189, inv_txfm.c); a column's eight results go straight
      * into the packed output rows ---- */
     constexpr int SH = txcfg<N>::shift;
@@ -322,13 +293,131 @@ __global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restr
         }
     }
     uint8_t *const rbase = recon_set ? (uint8_t *)recon_set[(k.pad_[0] >> 4) & 7] : recon;
-    if (!rbase) continue; /* a set index beyond the caller's n_set: nowhere to reconstruct to (never buffer 0 by default) */
+    if (!rbase) return; /* a set index beyond the caller's n_set: nowhere to reconstruct to (never buffer 0 by default) */
     _Pragma("unroll") for (int r = 0; r < N; r++) {
         uint8_t *d = rbase + k.recon_off + (size_t)r * k.recon_stride;
         if constexpr (N == 4) *(uint32_t *)d = rw[r][0];
         else row_store<N>(d, ((uintptr_t)d & 7) == 0, rw[r]);
     }
+}
+
+template <int N, bool RATE, bool DIST>
+__global__ __launch_bounds__(256) void svt_tq_lane_kernel(const uint8_t *__restrict__ src, const uint8_t *__restrict__ pred,
+                                                          uint8_t *__restrict__ recon, const svt_tq_block *__restrict__ blocks,
+                                                          int n_blocks, const svt_quant_tables *__restrict__ qtabs,
+                                                          const int16_t *__restrict__ iscan_all, int16_t *__restrict__ qcoeff,
+                                                          int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out,
+                                                          uint64_t *__restrict__ dist_out, tq_rate_args ra, const uint8_t *const *__restrict__ recon_set, tq_dev_count dc) {
+    if (dc.p) {
+        const int o = dc.p[dc.s];
+        n_blocks = dc.p[4 + dc.s];
+        blocks += o; eob_out += o;
+        if (dc.pos) dc.pos += o;
+        if (dist_out) dist_out += 2 * o;
+        if constexpr (RATE) ra.bits += o;
+    }
+    static_assert(N == 4 || N == 8, "block-per-lane form: 4x4 and 8x8 only");
+    static_assert(!RATE || N == 4, "in-lane rate: 4x4 only");
+    /* RATE: the four 4x4 token-cost slices [plane_type][is_inter] and the value-cost table, copied once per workgroup */
+    __shared__ uint32_t s_tc[RATE ? 4 * RATE_SLICE : 1];
+    __shared__ int32_t  s_vc[RATE ? 136 : 1];
+    if constexpr (RATE) {
+        const uint32_t *g = &ra.T->token_costs[0][0][0][0][0][0][0];
+        for (int j = threadIdx.x; j < 4 * RATE_SLICE; j += 256) s_tc[j] = g[j];
+        if (threadIdx.x < 133) s_vc[threadIdx.x] = ra.T->value_cost[threadIdx.x];
+        __syncthreads();
+    }
+    const tq_walk wk = tq_walk_of((n_blocks + 255) / 256);
+  for (int gj = wk.first; gj < wk.per_xcd; gj += wk.step) {
+    const int blk = (wk.base + gj) * 256 + (int)threadIdx.x;
+    if (blk >= n_blocks) continue; /* no barrier inside the loop */
+    svt_tq_block k;
+    if (dc.pos) {
+        const uint32_t pc = dc.pos[blk];
+        svt_tq_block_from_pos(pc, txcfg<N>::size, (const svt_tq_pic_geom *)(dc.geom + (size_t)svt_tq_pos_pic(pc) * dc.geom_stride), dc.iscan_off, dc.sb_cols, &k);
+    } else k = blocks[blk];
+    tq_lane_block<N, RATE, DIST>(k, blk, src, pred, recon, qtabs, iscan_all, qcoeff, dqcoeff, eob_out, dist_out, ra, s_tc, s_vc, recon_set);
   }
+}
+
+/* ---- the encode pass's transform stage as ONE launch over SB-ordered lists (round 6) ----
+ * Four launches, one per transform size, each fetch the 128-byte lines of source and prediction they share with the others: an SB whose
+ * 32x32 areas carry different transform sizes was read up to four times (2.08 GB per 16 pictures at 2160p against 1.0 GB of samples and
+ * coefficients, profiles/r05_pmc_traffic.md) -- and at 0.54 ms for the four launches that is 3.8 TB/s: the stage was as close to the HBM
+ * roof as to the issue roof.  Here the list is ordered [picture][chunk of SVT_TQ_CHUNK_SBS SBs][size][SB][unit][plane] (csrc/encdec.hip) and a
+ * workgroup is (chunk, size, part): the SVT_TQ_SLOTS workgroups of a chunk are neighbours in dispatch order ON ONE XCD (workgroup w runs
+ * on XCD w & 7), so a line one of them has fetched is in that XCD's L2 when the next one asks for it.  seg[] = the exclusive prefix of the
+ * per-(picture, chunk, size, SB) counts inside a picture, bases[picture] (+ one closing entry) the pictures' first blocks.
+ * 128 threads: four 32x32 blocks keep the transpose tiles at 16.9 KB (eight workgroups per CU at the 128 registers the 32x32 body needs). */
+constexpr int TQ_SB_NT = 128;
+__host__ __device__ constexpr int tq_sb_slots(int s) { return s == 0 ? 4 : s == 1 ? 4 : 2; } /* workgroups per (chunk, size) */
+__host__ __device__ constexpr int tq_sb_slots_range(int lo, int hi) { int n = 0; for (int s = lo; s <= hi; s++) n += tq_sb_slots(s); return n; }
+
+template <int N>
+__device__ __forceinline__ void tq_sb_groups(int32_t *tile_mem, const int first, const int count, const int part, const int nparts, const uint8_t *__restrict__ src,
+                                             const uint8_t *__restrict__ pred, const svt_quant_tables *__restrict__ qtabs, const int16_t *__restrict__ iscan_all,
+                                             int16_t *__restrict__ qcoeff, int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out,
+                                             const uint8_t *const *__restrict__ recon_set, const tq_dev_count &dc) {
+    constexpr int BPW = TQ_SB_NT / N, LS = N + 1;
+    const int     lb = (int)threadIdx.x / N, i = (int)threadIdx.x % N;
+    int32_t      *t = tile_mem + lb * (N * LS);
+    for (int g = part; g * BPW < count; g += nparts) { /* (uniform) */
+        const int  b = g * BPW + lb;
+        const bool active = b < count;
+        const int  blk = first + (active ? b : 0);
+        svt_tq_block k;
+        const uint32_t pc = dc.pos[blk];
+        svt_tq_block_from_pos(pc, txcfg<N>::size, (const svt_tq_pic_geom *)(dc.geom + (size_t)svt_tq_pos_pic(pc) * dc.geom_stride), dc.iscan_off, dc.sb_cols, &k);
+        uint32_t srow[N / 4], prow[N / 4];
+        {
+            const uint8_t *sp = src + k.src_off + (size_t)i * k.src_stride;
+            const uint8_t *pp = pred + k.pred_off + (size_t)i * k.pred_stride;
+            constexpr uintptr_t AM = N >= 16 ? 15 : N - 1;
+            _Pragma("unroll") for (int q = 0; q < N / 4; q++) { srow[q] = 0u; prow[q] = 0u; }
+            if (active) { row_load<N>(sp, ((uintptr_t)sp & AM) == 0, srow); row_load<N>(pp, ((uintptr_t)pp & AM) == 0, prow); }
+        }
+        tq_block_body<N, false, false>(k, active, i, t, srow, prow, qtabs, iscan_all, qcoeff, dqcoeff, eob_out + blk, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                       (uint8_t *)recon_set[(k.pad_[0] >> 4) & 7]);
+        tq_block_sync();
+    }
+}
+
+/* sizes S_LO .. S_HI of every chunk.  <0, 3>: everything in one launch (128 registers, 16.9 KB of LDS in EVERY workgroup, the 4x4 ones too);
+ * <0, 2> + <3, 3>: the small sizes in a launch that needs 96 registers and 8.7 KB, the 32x32 blocks in one of their own -- see the launcher */
+template <int S_LO, int S_HI>
+__global__ __launch_bounds__(TQ_SB_NT) __attribute__((amdgpu_waves_per_eu(S_HI == 3 ? 4 : 5))) void svt_tq_sb_kernel(
+    const uint8_t *__restrict__ src, const uint8_t *__restrict__ pred, const svt_quant_tables *__restrict__ qtabs, const int16_t *__restrict__ iscan_all,
+    int16_t *__restrict__ qcoeff, int16_t *__restrict__ dqcoeff, uint16_t *__restrict__ eob_out, const uint8_t *const *__restrict__ recon_set, tq_dev_count dc,
+    const int32_t *__restrict__ seg, const int32_t *__restrict__ bases, int n_chunks, int seg_per_chunk /* 4 * chunk SBs */, int n_items /* pictures x chunks */) {
+    constexpr int NMAX = 4 << S_HI, SLOTS = tq_sb_slots_range(S_LO, S_HI);
+    __shared__ int32_t tile_mem[S_HI == 0 ? 1 : (TQ_SB_NT / NMAX) * NMAX * (NMAX + 1)];
+    /* workgroup -> (item, slot): the slots of an item are consecutive on one XCD */
+    const int xcd = (int)(blockIdx.x & 7), local = (int)(blockIdx.x >> 3);
+    const int item = (local / SLOTS) * 8 + xcd, slot = local % SLOTS;
+    if (item >= n_items) return;
+    int s = S_LO, part = slot;
+    _Pragma("unroll") for (int q = S_LO; q < S_HI; q++) if (s == q && part >= tq_sb_slots(q)) { part -= tq_sb_slots(q); s = q + 1; }
+    const int nparts = tq_sb_slots(s);
+    const int pic = item / n_chunks, chunk = item - pic * n_chunks;
+    const int per_pic = n_chunks * seg_per_chunk, at = chunk * seg_per_chunk + s * (seg_per_chunk >> 2), nxt = at + (seg_per_chunk >> 2);
+    const int base = bases[pic];
+    const int first = base + seg[pic * per_pic + at];
+    const int last = nxt < per_pic ? base + seg[pic * per_pic + nxt] : bases[pic + 1];
+    const int count = last - first;
+    if (count <= 0) return;
+    if (S_LO == 0 && s == 0) { /* 4x4: a block per lane, no LDS, no barrier */
+        const tq_rate_args none = {nullptr, nullptr, nullptr};
+        for (int b = part * TQ_SB_NT + (int)threadIdx.x; b < count; b += nparts * TQ_SB_NT) {
+            const int      blk = first + b;
+            const uint32_t pc = dc.pos[blk];
+            svt_tq_block   k;
+            svt_tq_block_from_pos(pc, SVT_TX_4X4, (const svt_tq_pic_geom *)(dc.geom + (size_t)svt_tq_pos_pic(pc) * dc.geom_stride), dc.iscan_off, dc.sb_cols, &k);
+            tq_lane_block<4, false, false>(k, blk, src, pred, nullptr, qtabs, iscan_all, qcoeff, dqcoeff, eob_out, nullptr, none, nullptr, nullptr, recon_set);
+        }
+    }
+    if (S_LO <= 1 && S_HI >= 1 && s == 1) tq_sb_groups<8>(tile_mem, first, count, part, nparts, src, pred, qtabs, iscan_all, qcoeff, dqcoeff, eob_out, recon_set, dc);
+    if (S_LO <= 2 && S_HI >= 2 && s == 2) tq_sb_groups<16>(tile_mem, first, count, part, nparts, src, pred, qtabs, iscan_all, qcoeff, dqcoeff, eob_out, recon_set, dc);
+    if (S_HI == 3 && s == 3) tq_sb_groups<32>(tile_mem, first, count, part, nparts, src, pred, qtabs, iscan_all, qcoeff, dqcoeff, eob_out, recon_set, dc);
 }
 
 /* persistent grid: a multiple of 8 workgroups (one walk per XCD, tq_walk_of), at most `per_cu` per compute unit */
@@ -438,6 +527,34 @@ int32_t svt_tq_launch_device_lists(svt_hip_ctx *ctx, const uint8_t *d_src, const
         if (rc == hipSuccess) rc = TQ_DEV(32, 3, false);
     }
 #undef TQ_DEV
+    svt_ctx_stage_commit(ctx);
+    if (rc != hipSuccess) return svt_set_hip_error(rc, __FILE__, __LINE__);
+    return SVT_HIP_OK;
+}
+
+/* The same stage over the SB-ordered device lists (csrc/encdec.hip): ONE launch, workgroup = (picture, chunk, size, part).  d_seg: per picture
+ * n_chunks x seg_per_chunk exclusive prefixes, d_bases: n_pics + 1 first blocks.  No distortion, no rate (the encode pass).  Internal. */
+int32_t svt_tq_launch_sb_lists(svt_hip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *const *recon_set, int n_set, const svt_quant_tables *d_qtabs,
+                               const int16_t *d_iscan, int16_t *d_qcoeff, int16_t *d_dqcoeff, uint16_t *d_eob, const uint32_t *d_pos, const void *d_geom, int geom_stride,
+                               const uint32_t *d_iscan_off, int sb_cols, const int32_t *d_seg, const int32_t *d_bases, int n_pics, int n_chunks, int seg_per_chunk) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    void *h = nullptr, *d = nullptr;
+    if (svt_ctx_stage(ctx, 8 * sizeof(void *), &h, &d)) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "tq: descriptor buffers");
+    for (int i = 0; i < 8; i++) ((uint8_t **)h)[i] = i < n_set ? recon_set[i] : nullptr;
+    HIP_TRY(hipMemcpyAsync(d, h, 8 * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    const int n_items = n_pics * n_chunks, groups8 = (n_items + 7) / 8;
+    const tq_dev_count dc{nullptr, 0, d_pos, (const uint8_t *)d_geom, geom_stride, d_iscan_off, sb_cols};
+    /* SVT_HIP_TQ_SB_SPLIT: 0 (default) = everything in one launch; 1 = sizes 4x4 .. 16x16 in one launch (96 registers, 8.7 KB of LDS), the 32x32
+     * blocks in a second; 2 = 4x4 + 8x8 | 16x16 + 32x32.  Measured (tools/r06_tq_ab.sh, tools/r06_tq_traffic.sh): traffic 1.50 / 1.73 GB per 16
+     * pictures for 0 / 1, step 10.5 / 10.4 / 10.65 ms for 0 / 1 / 2 against 10.2 ms with the size-grouped lists. */
+    static const int split = getenv("SVT_HIP_TQ_SB_SPLIT") ? atoi(getenv("SVT_HIP_TQ_SB_SPLIT")) : 0;
+#define TQ_SB_LAUNCH(LO, HI) hipLaunchKernelGGL((svt_tq_sb_kernel<LO, HI>), dim3(groups8 * tq_sb_slots_range(LO, HI) * 8), dim3(TQ_SB_NT), 0, ctx->stream, d_src, d_pred, d_qtabs, d_iscan, \
+                                                d_qcoeff, d_dqcoeff, d_eob, (const uint8_t *const *)d, dc, d_seg, d_bases, n_chunks, seg_per_chunk, n_items)
+    if (split == 0) TQ_SB_LAUNCH(0, 3);
+    else if (split == 2) { TQ_SB_LAUNCH(0, 1); TQ_SB_LAUNCH(2, 3); }
+    else { TQ_SB_LAUNCH(0, 2); TQ_SB_LAUNCH(3, 3); }
+#undef TQ_SB_LAUNCH
+    const hipError_t rc = hipGetLastError();
     svt_ctx_stage_commit(ctx);
     if (rc != hipSuccess) return svt_set_hip_error(rc, __FILE__, __LINE__);
     return SVT_HIP_OK;

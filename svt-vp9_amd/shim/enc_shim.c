@@ -73,6 +73,7 @@ typedef struct shim_packet {
 typedef struct shim_recon { /* one reconstructed picture on its way to eb_vp9_svt_get_recon: pinned host memory, filled asynchronously */
     struct shim_recon *next;
     uint8_t           *host;
+    uint8_t           *d_tight;   /* device: the picture's three planes packed tight (Y | Cb | Cr), what ONE device-to-host transfer then carries */
     int                dev;
     uint64_t           marker;
     int64_t            pts;
@@ -379,7 +380,7 @@ static void free_dev(shim_state *s, shim_dev *d) {
     void *v[4] = {d->d_src_slab, d->d_pred_slab, d->d_q_slab, d->d_dq_slab};
     for (int k = 0; k < 4; k++) svt_hip_mem_free(d->ctx, v[k]);
     d->d_src_slab = d->d_pred_slab = d->d_q_slab = d->d_dq_slab = NULL;
-    while (d->free_recon) { shim_recon *r = d->free_recon; d->free_recon = r->next; svt_hip_host_free(d->ctx, r->host); free(r); }
+    while (d->free_recon) { shim_recon *r = d->free_recon; d->free_recon = r->next; svt_hip_host_free(d->ctx, r->host); svt_hip_mem_free(d->ctx, r->d_tight); free(r); }
     if (d->work_key && d->work_key != d->work) svt_hip_encdec_work_destroy(d->ctx_key, d->work_key);
     d->work_key = NULL;
     if (d->work) svt_hip_encdec_work_destroy(d->ctx, d->work);
@@ -504,31 +505,40 @@ EbErrorType eb_vp9_init_encoder(EbComponentType *h) {
         shim_dev *d = &s->dev[i];
         memset(d, 0, sizeof *d);
         d->ordinal = ord[i];
-        int ok = svt_hip_ctx_create(&d->ctx, ord[i]) == SVT_HIP_OK;
+        /* Streams belong to the DEVICE: a GPU exposes four hardware queues to a process, and the upload / analysis / main / key streams of one
+           context take them.  When an ordinal repeats in SVT_HIP_DEVICES -- the N-device host shape exercised on one GPU:
+           per-"device" picture ring, workspace, feeder thread -- the later context runs on the streams of the first one of that ordinal instead of
+           opening four more (eight streams on four queues made two contexts 18-36 % slower than one; SVT_HIP_SHARE_STREAMS=0 restores that). */
+        const shim_dev *peer = NULL;
+        { const char *ss = getenv("SVT_HIP_SHARE_STREAMS");
+          if (!(ss && atoi(ss) == 0)) for (int k = 0; k < i && !peer; k++) if (s->dev[k].ordinal == ord[i]) peer = &s->dev[k]; }
+#define DEV_CTX_CREATE(field) ((peer && peer->field) ? svt_hip_ctx_create_on_stream(&d->field, ord[i], svt_hip_ctx_stream(peer->field)) : svt_hip_ctx_create(&d->field, ord[i]))
+        int ok = DEV_CTX_CREATE(ctx) == SVT_HIP_OK;
         if (!ok) { fprintf(stderr, "SvtVp9Enc (GPU hot path): %s\n", svt_hip_last_error()); d->ctx = NULL; }
         if (ok) {
             const char *one = getenv("SVT_HIP_SINGLE_STREAM");
             const char *nu = getenv("SVT_HIP_NO_UPLOAD_STREAM");
             if (one && atoi(one) != 0) d->ctx_in = d->ctx_out = d->ctx_up = d->ctx;
             else {
-                if (svt_hip_ctx_create(&d->ctx_in, ord[i]) != SVT_HIP_OK) { d->ctx_in = NULL; ok = 0; }
+                if (DEV_CTX_CREATE(ctx_in) != SVT_HIP_OK) { d->ctx_in = NULL; ok = 0; }
                 if (ok && nu && atoi(nu) != 0) d->ctx_up = d->ctx_in;
-                else if (ok && svt_hip_ctx_create(&d->ctx_up, ord[i]) != SVT_HIP_OK) { d->ctx_up = NULL; ok = 0; }
+                else if (ok && DEV_CTX_CREATE(ctx_up) != SVT_HIP_OK) { d->ctx_up = NULL; ok = 0; }
                 if (ok && !s->cfg.recon_file) d->ctx_out = d->ctx; /* (no reconstruction is fetched: no output stream) */
-                else if (ok && svt_hip_ctx_create(&d->ctx_out, ord[i]) != SVT_HIP_OK) { d->ctx_out = NULL; ok = 0; }
+                else if (ok && DEV_CTX_CREATE(ctx_out) != SVT_HIP_OK) { d->ctx_out = NULL; ok = 0; }
             }
             /* (opt-in: with the upload, analysis and key streams beside the main one the device's four hardware queues are taken; a fifth
                stream shares a queue with one of them and the public-API rate drops -- 3 240 -> 2 540 frames/s on the MI355X box) */
             const char *dp = getenv("SVT_HIP_DEEP_STREAM");
             d->ctx_deep = d->ctx;
-            if (ok && !(one && atoi(one) != 0) && dp && atoi(dp) != 0 && svt_hip_ctx_create(&d->ctx_deep, ord[i]) != SVT_HIP_OK) { d->ctx_deep = NULL; ok = 0; }
+            if (ok && !(one && atoi(one) != 0) && dp && atoi(dp) != 0 && DEV_CTX_CREATE(ctx_deep) != SVT_HIP_OK) { d->ctx_deep = NULL; ok = 0; }
             const char *nk = getenv("SVT_HIP_NO_KEY_STREAM");
             d->ctx_key = d->ctx;
-            if (ok && !(one && atoi(one) != 0) && !(nk && atoi(nk) != 0) && !s->md_cb && svt_hip_ctx_create(&d->ctx_key, ord[i]) != SVT_HIP_OK) { d->ctx_key = NULL; ok = 0; }
+            if (ok && !(one && atoi(one) != 0) && !(nk && atoi(nk) != 0) && !s->md_cb && DEV_CTX_CREATE(ctx_key) != SVT_HIP_OK) { d->ctx_key = NULL; ok = 0; }
         }
+#undef DEV_CTX_CREATE
         ok = ok && alloc_dev(s, d);
         if (!ok) { /* nothing half-initialised is left behind: the handle is back in its configured state */
-            for (int k = 0; k <= i; k++) free_dev(s, &s->dev[k]);
+            for (int k = i; k >= 0; k--) free_dev(s, &s->dev[k]); /* (reverse: a later context may run on an earlier one's streams) */
             return EB_ErrorInsufficientResources;
         }
     }
@@ -645,6 +655,9 @@ static shim_recon *reserve_recon(shim_state *s, shim_dev *d, int64_t number) {
         void *hp = NULL;
         if (svt_hip_host_alloc(d->ctx_out, s->pic_bytes, &hp) != SVT_HIP_OK) { free(r); (void)gpu_fail(s); return NULL; }
         r->host = (uint8_t *)hp;
+        void *dp = NULL;
+        if (svt_hip_mem_alloc(d->ctx_out, s->pic_bytes, &dp) != SVT_HIP_OK) { svt_hip_host_free(d->ctx_out, hp); free(r); (void)gpu_fail(s); return NULL; }
+        r->d_tight = (uint8_t *)dp;
     }
     r->dev = (int)(d - s->dev); r->pts = number; r->flags = 0; r->next = NULL; r->ready = 0; r->marker = 0;
     if (s->r_tail) s->r_tail->next = r; else s->r_head = r;
@@ -658,9 +671,13 @@ static EbErrorType fill_recon(shim_state *s, shim_dev *d, shim_slot *t, svt_hip_
     /* the copy runs on the output stream, behind the main stream's work enqueued so far (the picture's deblocking / padding) */
     uint64_t after = 0;
     if ((d->ctx_out != coded_on && (svt_hip_ctx_marker_record(coded_on, &after) != SVT_HIP_OK || svt_hip_ctx_wait_marker(d->ctx_out, coded_on, after) != SVT_HIP_OK)) ||
-        svt_hip_mem_download_2d_async(d->ctx_out, r->host, W, p.y, (size_t)p.y_stride, W, H) != SVT_HIP_OK ||
-        svt_hip_mem_download_2d_async(d->ctx_out, r->host + W * H, W / 2, p.u, (size_t)p.uv_stride, W / 2, H / 2) != SVT_HIP_OK ||
-        svt_hip_mem_download_2d_async(d->ctx_out, r->host + W * H + W * H / 4, W / 2, p.v, (size_t)p.uv_stride, W / 2, H / 2) != SVT_HIP_OK ||
+        /* the interiors of the three padded planes are packed on the device (three strided device-to-device copies at HBM speed) and cross the
+           link as ONE linear transfer: three strided device-to-host copies of 2160 / 1080 / 1080 rows each ran at a third of the link's rate
+           (public-API path with every reconstruction fetched: 1 270 -> see profiles/r06_api.txt) */
+        svt_hip_mem_copy_2d_device(d->ctx_out, r->d_tight, W, p.y, (size_t)p.y_stride, W, H) != SVT_HIP_OK ||
+        svt_hip_mem_copy_2d_device(d->ctx_out, r->d_tight + W * H, W / 2, p.u, (size_t)p.uv_stride, W / 2, H / 2) != SVT_HIP_OK ||
+        svt_hip_mem_copy_2d_device(d->ctx_out, r->d_tight + W * H + W * H / 4, W / 2, p.v, (size_t)p.uv_stride, W / 2, H / 2) != SVT_HIP_OK ||
+        svt_hip_mem_download_2d_async(d->ctx_out, r->host, s->pic_bytes, r->d_tight, s->pic_bytes, s->pic_bytes, 1) != SVT_HIP_OK ||
         svt_hip_ctx_marker_record(d->ctx_out, &r->marker) != SVT_HIP_OK)
         return gpu_fail(s); /* (the record stays in the queue, never ready: the stream has failed) */
     t->out_marker = r->marker; t->has_out = 1;
@@ -1313,7 +1330,7 @@ EbErrorType eb_vp9_deinit_encoder(EbComponentType *h) {
         s->dev[r->dev].free_recon = r;
     }
     s->r_tail = NULL;
-    for (int k = 0; k < s->n_dev; k++) free_dev(s, &s->dev[k]);
+    for (int k = s->n_dev - 1; k >= 0; k--) free_dev(s, &s->dev[k]); /* (reverse: a later context may run on an earlier one's streams) */
     s->n_dev = 0;
     /* every stream has drained (join_all, free_dev): nothing reads the application's input buffers any more -- the page locks this encoder
        took on them go with it (the registry is process-wide and counted: the last encoder that leaves unlocks) */

@@ -140,7 +140,11 @@ def run_device(ctx, W, H, srcs, refs, grids, q_index, flags, thr, rec_inits, has
     (200, 136, 2, 236, dict(enc_mode=8, tune=1, temporal_layer_index=4, is_used_as_reference=0, recon_file=1, loop_filter=1)),   # recon output: filtered, not padded
     (136, 72, 11, 180, dict(enc_mode=8, tune=1, temporal_layer_index=0, is_used_as_reference=1, recon_file=0, loop_filter=1)),   # more pictures than reconstruction bases
 ])
-def test_encdec_batch_vs_oracle_chain(ctx, W, H, n_pics, q_index, cfg):
+@pytest.mark.parametrize("sb_order", [0, 1], ids=["size-grouped", "sb-ordered"])
+def test_encdec_batch_vs_oracle_chain(ctx, W, H, n_pics, q_index, cfg, sb_order, monkeypatch):
+    # both forms of the transform stage: four size-grouped launches (default) / SB-ordered lists + svt_tq_sb_kernel (SVT_HIP_TQ_SB_ORDER=1, read when
+    # the driver's workspace is created)
+    monkeypatch.setenv("SVT_HIP_TQ_SB_ORDER", str(sb_order))
     lib = B.load()
     srcs, refs, me = make_inputs(W, H, n_pics, seed=W + n_pics)
     level = lib.svt_hip_lf_level_from_q(lib.svt_hip_vp9_ac_step(q_index), 0)
@@ -179,7 +183,11 @@ def test_encdec_batch_vs_oracle_chain(ctx, W, H, n_pics, q_index, cfg):
         geoms.append(g)
     hb, hp, hc = M.host_block_list([g_[1] for g_ in grids], geoms, W // 8)
     assert [cnt[4 + s] for s in range(4)] == hc and cnt[:4] == [0, hc[0], hc[0] + hc[1], hc[0] + hc[1] + hc[2]]
-    assert np.array_equal(pos, hp) and blocks.tobytes() == hb.tobytes()
+    # the device's list holds the same blocks; its ORDER is the device's own business (round 6: [picture][chunk of SBs][size][SB][unit][plane] so that
+    # one transform launch reads every SB once -- SVT_HIP_TQ_SB_ORDER=0 restores [size][picture][SB]): compared in the order of the position codes
+    od, oh = np.argsort(pos, kind="stable"), np.argsort(hp, kind="stable")
+    assert len(np.unique(pos)) == len(pos)
+    assert np.array_equal(pos[od], hp[oh]) and blocks[od].tobytes() == hb[oh].tobytes()
     kinds = set()
     for i in range(n_pics):
         rec0 = M.RefPic(W, H)
