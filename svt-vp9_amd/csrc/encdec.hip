@@ -39,7 +39,7 @@ struct svt_encdec_work {
     int32_t      *d_totals, *d_bases; /* [4][max_pics]: blocks of a (size, picture) / its first block */
     int32_t      *d_off_cnt;     /* [8]: first block / number of blocks per size */
     int32_t      *d_status;      /* != 0: a malformed grid was seen */
-    int32_t      *d_intra_sync;  /* ticket and per-(plane, 32x32 area) flags of the intra kernel: 2 + 3 * (at most 4 per SB) dwords */
+    int32_t      *d_intra_sync;  /* ticket and per-(plane, 16x16 cell) flags of the intra kernel: 2 + 3 * (at most 16 per SB) dwords */
     svt_quant_tables *d_qtabs;   /* [2] luma, chroma of the batch's q index */
     int16_t      *d_iscan;
     int           last_pics;
@@ -371,7 +371,7 @@ extern "C" int32_t svt_hip_encdec_work_create(svt_hip_ctx *ctx, int32_t max_pics
     /* the lists are position codes (4 bytes per transform block; the 32-byte descriptors are rebuilt in registers where they are used) */
     bool ok = hipMalloc((void **)&w->d_pos, cap * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&w->d_eob, cap * sizeof(uint16_t)) == hipSuccess &&
-              hipMalloc((void **)&w->d_counts, (n_cnt + 16 + 8 * ED_MAX_PICS + 8 + 12 * (size_t)w->n_sb) * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void **)&w->d_counts, (n_cnt + 16 + 8 * ED_MAX_PICS + 16 + 48 * (size_t)w->n_sb) * sizeof(int32_t)) == hipSuccess &&
               hipMalloc((void **)&w->d_qtabs, 2 * sizeof(svt_quant_tables)) == hipSuccess && hipMalloc((void **)&w->d_iscan, (size_t)entries * sizeof(int16_t)) == hipSuccess;
     if (ok) {
         w->d_off_cnt = w->d_counts + n_cnt;

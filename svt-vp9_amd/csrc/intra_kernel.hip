@@ -50,7 +50,7 @@ struct intra_pic_dev {
     int16_t       *qcoeff, *dqcoeff;
     uint16_t      *eob_map;
     uint8_t       *nz;
-    int32_t       *sync;    /* [0] ticket counter, [2 + plane * n_area + area] done flags (32x32 luma areas); zeroed before the launch */
+    int32_t       *sync;    /* [0] ticket counter, [2 + plane * n_cell + cell] done flags (16x16 luma cells); zeroed before the launch */
     int32_t       *status;  /* |= 1: a malformed grid was seen */
     int32_t        mixed;   /* 1: an inter picture with some intra blocks: inter blocks are skipped (the batch coded them) */
 };
@@ -213,42 +213,67 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INTRA_WAVES_
     __shared__ int32_t tile[2 * 32 * 33];
     __shared__ uint8_t edge[128];
     __shared__ int32_t s_ticket;
-    /* the unit of scheduling is a 32x32 luma AREA (the largest block of this entry): four to a SB.  Intra prediction of blocks >= 8x8
+    /* The unit of scheduling is a 16x16 luma CELL (8x8 in the chroma planes) -- round 6; until then a 32x32 area, whose four 16x16 blocks ran
+     * one after the other behind ONE pair of flags: a 2160p key frame was 187 diagonals of 4 block steps.  Intra prediction of blocks >= 8x8
      * never reads the above-right neighbour, so any order in which a block follows its left, above and above-left neighbours gives the
-     * reference's result -- areas go in anti-diagonal order, the blocks of an area in z-order */
-    const int lane = (int)threadIdx.x, a_cols = (P.width + 31) >> 5, a_rows = (P.height + 31) >> 5, n_area = a_cols * a_rows;
+     * reference's result: cells go in anti-diagonal order (374 diagonals of ONE 16x16 step at 2160p), the blocks inside a cell in z-order.
+     * A cell's flag says "this cell and everything it depended on is reconstructed and visible".  A 32x32 block covers 2 x 2 cells: it is
+     * coded by the ticket of its TOP-RIGHT cell -- every cell it depends on then lies on an earlier diagonal, so a workgroup still only ever
+     * waits for smaller tickets -- which sets all four flags; the tickets of its other three cells have nothing to do. */
+    const int lane = (int)threadIdx.x, c_cols = (P.width + 15) >> 4, c_rows = (P.height + 15) >> 4, n_cell = c_cols * c_rows;
+    const int n_diag = c_rows + c_cols - 1;
     /* one wave per CU on a chain of dependent blocks, beside kernels that fill the SIMDs: it issues rarely, so letting it go first costs
      * the others next to nothing and keeps the chain at the speed it has alone */
     __builtin_amdgcn_s_setprio(3);
-  /* workgroups are persistent: each keeps drawing tickets until they run out -- a launch of one workgroup per pair would keep ~1000 of
-     them resident, nearly all polling flags of areas many diagonals away */
+  /* workgroups are persistent: each keeps drawing tickets until they run out -- a launch of one workgroup per (cell, plane) would keep
+     thousands of them resident, nearly all polling flags of cells many diagonals away */
   for (;;) {
     __syncthreads(); /* (s_ticket of the previous round has been read by every lane) */
     if (lane == 0) s_ticket = atomicAdd(&P.sync[0], 1);
     __syncthreads();
-    if (s_ticket >= 3 * n_area) break;
+    if (s_ticket >= 3 * n_cell) break;
     const int ticket = s_ticket, plane = ticket % 3;
-    /* the n-th area in anti-diagonal order (diagonal d = row + col, rows ascending inside a diagonal) */
-    int n = ticket / 3, ar = 0, ac = 0;
-    for (int d = 0; d < a_rows + a_cols - 1; d++) {
-        const int r_lo = d - (a_cols - 1) > 0 ? d - (a_cols - 1) : 0, r_hi = d < a_rows - 1 ? d : a_rows - 1, cnt = r_hi - r_lo + 1;
-        if (n < cnt) { ar = r_lo + n; ac = d - ar; break; }
-        n -= cnt;
-    }
-    const int area = ar * a_cols + ac;
-    int32_t  *done = P.sync + 2 + plane * n_area;
+    /* the n-th cell in anti-diagonal order (diagonal d = row + col, rows ascending inside a diagonal): cells before diagonal d in closed form
+     * (growing part d (d + 1) / 2, then full diagonals of m = min(rows, cols) cells, then the shrinking tail), d by bisection */
+    const int n = ticket / 3, m = c_rows < c_cols ? c_rows : c_cols, M = c_rows < c_cols ? c_cols : c_rows;
+    int lo = 0, hi = n_diag; /* largest d with count(d) <= n */
+    auto count = [&](int d) -> int { /* cells on diagonals 0 .. d-1 */
+        const int a = d < m ? d : m;                        /* growing diagonals 0 .. a-1: 1 .. a cells */
+        int       t = a * (a + 1) / 2;
+        if (d > m) { const int fl = (d < M ? d : M) - m; t += fl * m; }          /* diagonals m .. min(d, M)-1: m cells each */
+        if (d > M) { const int k = d - M; t += k * m - k * (k + 1) / 2; }         /* diagonals M .. d-1: m-1, m-2, .. cells */
+        return t;
+    };
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (count(mid) <= n) lo = mid; else hi = mid; }
+    const int d = lo, r_lo = d - (c_cols - 1) > 0 ? d - (c_cols - 1) : 0;
+    const int cr = r_lo + (n - count(d)), cc = d - cr;
+    const int cell = cr * c_cols + cc;
+    int32_t  *done = P.sync + 2 + plane * n_cell;
+    /* what the cell belongs to: the unit at the origin of its 2 x 2 cell group decides (a 32x32 block starts there or nowhere in the group), so
+       the four cells of a group agree whatever the grid holds */
+    const int  br = cr & ~1, bc = cc & ~1;                                      /* first cell of the group */
+    const int  ub_r = br * 2, ub_c = bc * 2;                                     /* its first 8x8 unit */
+    const svt_lf_mode_info b0 = P.mi[ub_r * P.mi_stride + ub_c];
+    const bool big = b0.sb_type == 9 && !(b0.is_inter && P.mixed) && ub_r + 4 <= P.mi_rows && ub_c + 4 <= P.mi_cols; /* a 32x32 block coded in this pass */
+    if (big && !(cr == br && cc == bc + 1)) continue;                            /* its top-right cell's ticket codes it and sets the four flags */
+    const int ur0 = cr * 2, uc0 = cc * 2;
     if (lane == 0) {
-        if (ac > 0) while (__hip_atomic_load(&done[area - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
-        if (ar > 0) while (__hip_atomic_load(&done[area - a_cols], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
+        /* (r, c - 1) and (r - 1, c); for the 32x32 block at (br, bc): its lowest left neighbour (br + 1, bc - 1) and its rightmost above
+           neighbour (br - 1, bc + 1) -- the flags of the cells before them on their row / column were waited for by THEIR owners */
+        const int wl_r = big ? br + 1 : cr, wl_c = (big ? bc : cc) - 1;
+        const int wa_r = (big ? br : cr) - 1, wa_c = big ? bc + 1 : cc;
+        if (wl_c >= 0) while (__hip_atomic_load(&done[wl_r * c_cols + wl_c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+        if (wa_r >= 0) while (__hip_atomic_load(&done[wa_r * c_cols + wa_c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
     }
     __syncthreads();
 #ifdef INTRA_FENCES
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
-    const int sb = (ar >> 1) * P.sb_cols + (ac >> 1);
-    for (int z = 0; z < 16; z++) {
-        const int r = ((z >> 1) & 1) | ((z >> 3) & 1) << 1, c = (z & 1) | ((z >> 2) & 1) << 1;
-        const int ur = ar * 4 + r, uc = ac * 4 + c;
+    /* the 8x8 units of the cell (of the 32x32 block: only its first unit starts a block) in z-order */
+    const int nu = big ? 1 : 4, u_r = big ? ub_r : ur0, u_c = big ? ub_c : uc0;
+    for (int z = 0; z < nu; z++) {
+        const int r = (z >> 1) & 1, c = z & 1;
+        const int ur = u_r + r, uc = u_c + c;
         if (ur >= P.mi_rows || uc >= P.mi_cols) continue;
         const svt_lf_mode_info b = P.mi[ur * P.mi_stride + uc];
         const int sub = b.sb_type == 0; /* an 8x8 unit of four 4x4 luma blocks + one 4x4 chroma block per plane */
@@ -256,11 +281,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INTRA_WAVES_
         if (b.is_inter && P.mixed) continue;
         if (w8 == 0 || b.is_inter) { if (lane == 0) atomicOr(P.status, 1); continue; }
         if ((ur % w8) || (uc % w8)) continue;
+        if (w8 == 4 && !big) { if (lane == 0) atomicOr(P.status, 1); continue; } /* a 32x32 block where none can start (or one that leaves the picture): malformed */
         const int mode = plane ? b.pad_[2] : b.pad_[1];
         if (ur + w8 > P.mi_rows || uc + w8 > P.mi_cols || b.tx_size != (sub ? 0 : w8 == 1 ? 1 : w8 == 2 ? 2 : 3) || (!sub && mode > 9) || b.pad_[2] > 9) {
             if (lane == 0) atomicOr(P.status, 1);
             continue;
         }
+        const int sb = (ur >> 3) * P.sb_cols + (uc >> 3);
         const int x0 = plane ? uc * 4 : uc * 8, y0 = plane ? ur * 4 : ur * 8, nn = plane ? w8 * 4 : w8 * 8;
         int eob;
         if (sub && plane == 0) { /* blocks 0..3 in the reference's order, each with its own mode (nibbles of pad_[1], pad_[0]) */
@@ -278,16 +305,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INTRA_WAVES_
         else eob = intra_block<4>(P, plane, x0, y0, mode, sb, tile, edge);
         if (eob && lane == 0) P.nz[ur * P.mi_stride + uc] = 1; /* the three planes of a block may all store the same 1 */
     }
-    /* publish the area: its reconstruction reaches memory before the flag does */
+    /* publish the cell (the four cells of a 32x32 block): its reconstruction reaches memory before the flag does */
 #ifdef INTRA_FENCES
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    if (lane == 0) __hip_atomic_store(&done[area], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* every (write-through) store of this wave has completed */
     __syncthreads();
-    if (lane == 0) __hip_atomic_store(&done[area], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
+    if (lane == 0) {
+        if (big) {
+            _Pragma("unroll") for (int k = 0; k < 4; k++) {
+                const int rr = br + (k >> 1), c2 = bc + (k & 1);
+                if (rr < c_rows && c2 < c_cols) __hip_atomic_store(&done[rr * c_cols + c2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else __hip_atomic_store(&done[cell], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -322,15 +355,15 @@ int32_t svt_intra_launch(svt_hip_ctx *ctx, const svt_encdec_picture *p, int32_t 
     P.qtabs = d_qtabs; P.iscan = d_iscan;
     for (int i = 0; i < 16; i++) P.iscan_off[i] = iscan_off[i];
     P.qcoeff = p->d_qcoeff; P.dqcoeff = p->d_dqcoeff; P.eob_map = p->d_eob_map; P.nz = p->d_nz; P.sync = d_sync; P.status = d_status; P.mixed = mixed;
-    const int n_area = ((width + 31) >> 5) * ((height + 31) >> 5);
-    HIP_TRY(hipMemsetAsync(d_sync, 0, (size_t)(2 + 3 * n_area) * sizeof(int32_t), ctx->stream));
+    const int n_cell = ((width + 15) >> 4) * ((height + 15) >> 4); /* 16x16 luma cells: the unit of the wavefront */
+    HIP_TRY(hipMemsetAsync(d_sync, 0, (size_t)(2 + 3 * n_cell) * sizeof(int32_t), ctx->stream));
     /* (function-local statics with an initialiser: initialised once, thread-safely -- several contexts may launch from several threads) */
-    static const int wg_per_cu = [] { const char *e = getenv("SVT_HIP_INTRA_WG_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
+    static const int wg_per_cu = [] { const char *e = getenv("SVT_HIP_INTRA_WG_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 2; }(); /* two: a diagonal's tickets are then mostly held by workgroups already waiting at their flags (2160p, 16x16 DC: 4.77 -> 4.34 ms) */
     static const int wg_cap = [] { const char *e = getenv("SVT_HIP_INTRA_WGS"); return e && atoi(e) > 0 ? atoi(e) : 0; }(); /* deployment knob: fewer workgroups = a longer pass that leaves more of the device to what runs beside it (bench.py: 128) */
     int grid = ctx->cu_count * wg_per_cu;
     const int cap = ctx->intra_wgs > 0 ? ctx->intra_wgs : wg_cap; /* the context's setting (svt_hip_ctx_set_intra_workgroups) before the environment's */
     if (cap && grid > cap) grid = cap;
-    if (grid > 3 * n_area) grid = 3 * n_area;
+    if (grid > 3 * n_cell) grid = 3 * n_cell;
     hipLaunchKernelGGL(svt_intra_kernel, dim3(grid), dim3(64), 0, ctx->stream, P);
     HIP_TRY(hipGetLastError());
     return SVT_HIP_OK;

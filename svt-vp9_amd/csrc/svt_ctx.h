@@ -77,7 +77,7 @@ int32_t svt_tq_launch_sb_lists(svt_hip_ctx *ctx, const uint8_t *d_src, const uin
                                const uint32_t *d_iscan_off, int sb_cols, const int32_t *d_seg, const int32_t *d_bases, int n_pics, int n_chunks, int seg_per_chunk);
 
 /* encode pass of an intra picture / the stand-in intra decision (intra_kernel.hip; used by encdec.hip).  d_sync: 2 + 3 * (number of
- * 32x32 luma areas) dwords of scratch */
+ * 16x16 luma cells) dwords of scratch */
 int32_t svt_intra_launch(svt_hip_ctx *ctx, const svt_encdec_picture *p, int32_t width, int32_t height, int32_t mi_stride, const svt_quant_tables *d_qtabs,
                          const int16_t *d_iscan, const uint32_t iscan_off[16], int32_t *d_sync, int32_t *d_status, int32_t mixed);
 int32_t svt_md_intra_default_launch(svt_hip_ctx *ctx, svt_lf_mode_info *d_lf_mi, int32_t mi_stride, int32_t mi_rows, int32_t mi_cols, int32_t filter_level);
