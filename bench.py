@@ -1159,7 +1159,8 @@ def main():
     tj_name = "traffic.json" if args.preset == "c3" else f"traffic_{args.preset}.json"
     tj = os.path.join(ROOT, "profiles", tj_name)
     if os.path.exists(tj) and (Wd, Hd) == PRESETS[args.preset][:2]:
-        rec = json.load(open(tj)).get("svt_me_sb_kernel", {})
+        tjd = json.load(open(tj))
+        rec = tjd.get("svt_me_kernel") or tjd.get("svt_me_sb_kernel", {})   # (the family's key until round 5)
         if rec.get("bytes_per_step"):   # the profiling run's step is one mini-GOP of one GOP
             traffic = int(rec["bytes_per_step"] * G / n_launch_step)      # per launch, like `achieved`
             traffic_source = f"profiles/{tj_name} (rocprofv3 --pmc passes of tools/profile_round.sh, committed; not measured in this run)"
@@ -1262,7 +1263,7 @@ def main():
                         "(the GOP groups run side by side, so the sums can exceed the wall time); GB_per_s uses the sum",
         "pcie_note": f"inputs are resident in HBM when the clock starts; a {Wd}x{Hd} 4:2:0 picture is {pic_bytes / 1e6:.1f} MB, so {round(fps)} frames/s "
                      f"would need {fps * pic_bytes / 1e9:.0f} GB/s of host-to-device traffic if every picture crossed PCIe (gen5 x16 sustains ~50): the "
-                     "PCIe-inclusive rate of the public-API path is `api_path` (app/svt_enc_api_bench.c, DESIGN.md section 2)",
+                     "PCIe-inclusive rate of the public-API path is `api_path` (app/svt_enc_api_bench.c, DESIGN.md section 7)",
     }
     if not args.no_cpu_baseline and world == 1:   # the CPU leg runs at N = 1 only (rank 0's host cores are not shared with other ranks)
         lfm0 = {i: np.frombuffer(d_lfm[0, i - 1].cpu().numpy(), dtype=B.LF_MASK_DTYPE).reshape(sb_rows, sb_cols).copy() for i in range(1, MINIGOP + 1)}

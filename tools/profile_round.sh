@@ -20,4 +20,6 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_${TAG}_write -o w --outpu
 # instruction counts of every stage (one step, all stages), and the ME kernel's issue / LDS counters with ME alone on the GPU
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d $OUT/prof_${TAG}_insts -o i --output-format csv -- $BENCH $ONE --steps 1 --warmup 5 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $OUT/prof_${TAG}_sq -o s --output-format csv -- $BENCH $ONE --steps 1 --warmup 5 --stages me > /dev/null 2>&1
+# motion estimation alone on ONE stream, the step's pictures in one launch (what bench.py's me_alone pass times with HIP events): kernel trace + stats
+SVT_BENCH_ME_MERGE=1 SVT_BENCH_ME_STREAMS=1 rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG}_me_alone -o me --output-format csv -- $BENCH --stages me --steps 10 --warmup 3 > /dev/null 2>&1
 tail -1 $OUT/prof_${TAG}_bench.log

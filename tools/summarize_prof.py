@@ -21,18 +21,23 @@ prof = os.path.join(root, "profiles")
 # launches of one step with ONE GOP in flight, diagonal schedule: ME per temporal layer, the transform stage per transform size (one
 # launch serves the five ring slots: svt_hip_tq_rd_batch_multi_device), everything else once over the 16 pictures
 # (ME launches = temporal layers of the mini-GOP: c5 has 8 pictures, 4 layers)
-PER_STEP = {"svt_me_sb_kernel": 4 if preset == "c5" else 5, "svt_tq_kernel": 4, "svt_lf_kernel": 1, "svt_lf_desc_kernel": 1, "svt_pa_plane_kernel": 1, "svt_mc_kernel": 1,
+PER_STEP = {"svt_me_kernel": 4 if preset == "c5" else 5, "svt_tq_kernel": 4, "svt_lf_kernel": 1, "svt_lf_desc_kernel": 1, "svt_pa_plane_kernel": 1, "svt_mc_kernel": 1,
             "svt_refpad_kernel": 1, "svt_tq_count_kernel": 1, "svt_scan_sb_kernel": 1, "svt_scan_pic_kernel": 1, "svt_tq_emit_kernel": 1, "svt_tq_skip_kernel": 1,
             "svt_skip_update_kernel": 1, "svt_lf_mask_kernel": 1}
-KERNELS = ("svt_me_sb_kernel", "svt_tq_kernel", "svt_lf_kernel", "svt_lf_desc_kernel", "svt_lf_mask_kernel", "svt_pa_plane_kernel", "svt_mc_kernel", "svt_rate_kernel",
+KERNELS = ("svt_tq_kernel", "svt_lf_kernel", "svt_lf_desc_kernel", "svt_lf_mask_kernel", "svt_pa_plane_kernel", "svt_mc_kernel", "svt_rate_kernel",
            "svt_refpad_kernel", "svt_tq_count_kernel", "svt_scan_sb_kernel", "svt_scan_pic_kernel", "svt_tq_emit_kernel", "svt_tq_skip_kernel", "svt_skip_update_kernel")
+
+
+ME_NAMES = set()
 
 
 def short(name):
     if re.search(r"(?<![A-Za-z_0-9])svt_tq_lane_kernel(?![A-Za-z_0-9])", name):
         return "svt_tq_kernel"  # the 4x4 instance of the TQ stage
-    if re.search(r"(?<![A-Za-z_0-9])svt_me_fast_kernel(?![A-Za-z_0-9])", name):
-        return "svt_me_sb_kernel"  # the same kernel behind csrc/me_fast.h's driver (round 5)
+    m = re.search(r"(?<![A-Za-z_0-9])svt_me_(fast|sb)_kernel(<[0-9]+>)?", name)
+    if m:
+        ME_NAMES.add(m.group(0))   # the instance that really ran: svt_me_fast_kernel<1> (csrc/me_fast.h's driver) or svt_me_sb_kernel<SPEC>
+        return "svt_me_kernel"
     for k in KERNELS:
         if re.search(r"(?<![A-Za-z_0-9])" + k + r"(?![A-Za-z_0-9])", name):
             return k
@@ -71,13 +76,22 @@ for k in sorted(set(fetch) | set(write)):
           f"{i.get('SQ_INSTS_LDS', 0) / 1e6:.1f} M | {i.get('SQ_WAVES', 0):.0f} |")
 for k, v in sq.items():
     print("SQ (ME alone)", k, {c: f"{x:.4g}" for c, x in v.items()})
-    if k == "svt_me_sb_kernel":
+    if k == "svt_me_kernel":
         traffic[k]["me_alone"] = {c: int(x) for c, x in v.items()}
+if "svt_me_kernel" in traffic:
+    traffic["svt_me_kernel"]["rocprof_kernel_names"] = sorted(ME_NAMES)
 json.dump(traffic, open(os.path.join(prof, "traffic.json" if preset == "c3" else f"traffic_{preset}.json"), "w"), indent=1)
 for name in ("kernel_stats", "domain_stats"):
     src = glob.glob(os.path.join(out, f"prof_{tag}", "**", f"{tag}_{name}.csv"), recursive=True)
     if src:
         shutil.copy(src[0], os.path.join(prof, f"{rnd}_{name}.csv" if preset == "c3" else f"{rnd}_{preset}_{name}.csv"))  # profiles are named per round: r02_*
+src_me = glob.glob(os.path.join(out, f"prof_{tag}_me_alone", "**", "me_kernel_stats.csv"), recursive=True)
+if src_me:   # motion estimation alone on one stream (the step's pictures in one launch): the denominator of bench.py's roofline.frac
+    dst = os.path.join(prof, f"{rnd}_me_alone_kernel_stats.csv" if preset == "c3" else f"{rnd}_{preset}_me_alone_kernel_stats.csv")
+    shutil.copy(src_me[0], dst)
+    for r in csv.DictReader(open(src_me[0])):
+        if "svt_me_" in r["Name"] and "zz" not in r["Name"]:
+            print(f"\nME alone: {r['Name'][:60]} calls {r['Calls']} average {float(r['AverageNs']) / 1e3:.1f} us  (-> {os.path.basename(dst)})")
 src = glob.glob(os.path.join(out, f"prof_{tag}", "**", f"{tag}_kernel_stats.csv"), recursive=True)
 if src:
     print("\n| kernel | calls | avg (us) | total (ms) |\n|---|---|---|---|")
