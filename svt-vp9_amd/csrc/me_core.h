@@ -247,8 +247,9 @@ typedef struct me_lds_layout {
     int32_t off_region;  /* integer reference samples of the current list's search region */
     int32_t off_planes;  /* B, H, J half-pel planes (3 x plane_bytes); aliased by HME window / SAD scratch */
     int32_t off_quarter; /* 32x32 quarter-resolution SB (only when HME level 1 is enabled) */
-    int32_t off_ssd;     /* SSD_SEARCH only: candidate SSDs [85][9], then the best SSD per PU [85] */
-    int32_t off_cand;    /* sub-pel candidate distortions [pu][8] / bi-pred distortion [pu]: cand_dwords dwords */
+    int32_t off_ssd;     /* SSD_SEARCH only: candidate SSDs [85][9]; entry 8 of a PU is the integer position's, then the PU's best so far */
+    int32_t off_cand;    /* sub-pel candidate distortions [pu][8] / bi-pred distortion [pu]: entries 0..167 (PUs 0..20), dwords */
+    int32_t off_cand_hi; /* entries 168..679 (the 8x8 PUs: at most 2 x 64 x 255 each) as halfwords, when cand_dwords = 680; else -1 */
     int32_t cand_dwords; /* 8 x (21 when the 8x8 PUs are never refined nor bi-predicted, else 85) */
     int32_t off_pred0;   /* host emulation only (the kernel keeps them in registers): list 0 prediction of the bi-pred lanes */
     int32_t region_stride, region_rows;
@@ -256,6 +257,7 @@ typedef struct me_lds_layout {
     int32_t plane_bytes;
     int32_t scratch_bytes; /* bytes available at off_planes */
     int32_t total_bytes;
+    int32_t compact;     /* me_layout.h: no tail columns in the region rows, quarter SB inside the SSD tables */
     /* HME level-0 search areas already scaled by the temporal layer's multiplier (Codec/EbDefinitions.h:989-1005): the
      * divisions by 100 are done once per launch on the host instead of by the planning thread of every SB */
     int16_t hme_w0[2], hme_h0[2], hme_tw0, hme_th0;
@@ -431,11 +433,12 @@ typedef struct me_ctx_t {
     uint8_t             *planes; /* LDS */
     uint8_t             *quarter_sb; /* LDS, valid when HME level 1 is enabled */
     uint32_t            *ssdc;       /* LDS, SSD_SEARCH only: SSD of the sub-pel candidates [pu][9] (8 = integer position) */
-    uint32_t            *best_ssd;   /* LDS, SSD_SEARCH only: SSD of the current best sub-pel position of each PU (current list) */
-    uint32_t            *cand;       /* LDS: sub-pel candidate distortions [pu][8]; bi-pred distortion [pu] */
+    uint32_t            *cand;       /* LDS: sub-pel candidate distortions [pu][8] (see me_cand_get); bi-pred distortion [pu] */
+    uint32_t            *cand_hi;    /* LDS: the 8x8 PUs' entries of that table as halfwords (L.off_cand_hi >= 0: else they are never refined, and this is cand) */
     uint32_t            *pred0;  /* host emulation only: list 0 prediction dwords of the bi-pred lanes [16][256] */
     int                  pic_w, pic_h, sb_x, sb_y, sb_w, sb_h, sb_index;
     unsigned long long  *prof;   /* optional per-phase cycle accumulators (profiling builds), else NULL */
+    uint32_t            *redo;   /* compact layout: set to 1 when this SB needs the full layout (its clipped search area has tail columns); else NULL */
 } me_ctx_t;
 
 /* t / d for a small wave-uniform divisor d (phase geometry: units per row, lanes per strip, search width ...).  An integer
@@ -503,6 +506,15 @@ SVT_DEV void ph_load_rect(int tid, uint8_t *dst, int dst_stride, const uint8_t *
     }
 }
 
+/* the 1/4-resolution SB, stride 32 */
+SVT_DEV void ph_load_quarter(const me_ctx_t *c, int tid) {
+    int rows = c->sb_h >> 1, wq = c->sb_w >> 1;
+    for (int t = tid; t < rows * 32; t += SVT_NT) {
+        int r = t >> 5, x = t & 31;
+        c->quarter_sb[t] = x < wq ? *SVT_AS_GLOBAL(const uint8_t, me_pix(&c->pic->cur.quarter, (c->sb_x >> 1) + x, (c->sb_y >> 1) + r)) : 0;
+    }
+}
+
 /* initial state + decimated SB copies (Codec/EbMotionEstimationProcess.c:984-1035) */
 SVT_DEV void ph_init(const me_ctx_t *c, int tid) {
     me_state_t *st = c->st;
@@ -524,13 +536,7 @@ SVT_DEV void ph_init(const me_ctx_t *c, int tid) {
             st->sixteenth_sb[t] = x < wq ? *SVT_AS_GLOBAL(const uint8_t, me_pix(&c->pic->cur.sixteenth, (c->sb_x >> 2) + x, (c->sb_y >> 2) + 2 * r)) : 0;
         }
     }
-    if (c->p->enable_hme_level_1_flag) {
-        int rows = c->sb_h >> 1, wq = c->sb_w >> 1;
-        for (int t = tid; t < rows * 32; t += SVT_NT) {
-            int r = t >> 5, x = t & 31;
-            c->quarter_sb[t] = x < wq ? *SVT_AS_GLOBAL(const uint8_t, me_pix(&c->pic->cur.quarter, (c->sb_x >> 1) + x, (c->sb_y >> 1) + r)) : 0;
-        }
-    }
+    if (c->p->enable_hme_level_1_flag) ph_load_quarter(c, tid);
 }
 
 /* Row-subsampled 64-wide SADs of the source SB against up to 5 displaced reference blocks read from
@@ -1252,6 +1258,28 @@ SVT_DEV int me_subpel_task(int t, int ncand, int n64, int n32, int nrest, int *k
     return 1;
 }
 
+/* The sub-pel candidate table: entry k = pu * 8 + candidate.  Entries of the PUs 0..20 are dwords; those of the 8x8 PUs (k >= 168,
+ * refined only when cu8x8_mode != 1) are halfwords -- an 8x8 SAD is at most 64 x 255 -- two to a dword at c->cand_hi: 1 KB instead of 2. */
+SVT_DEV uint32_t me_cand_get(const me_ctx_t *c, int k) {
+    if (k < 168) return c->cand[k];
+    k -= 168;
+    return (c->cand_hi[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+}
+SVT_DEV uint32_t *me_cand_slot(const me_ctx_t *c, int k, int *shift) {
+    if (k < 168) { *shift = 0; return &c->cand[k]; }
+    k -= 168;
+    *shift = 16 * (k & 1);
+    return &c->cand_hi[k >> 1];
+}
+/* zero the table (and the candidate SSDs: keep_best = 1 leaves entry 8 of every PU, its best SSD so far) */
+SVT_DEV void me_cand_zero(const me_ctx_t *c, int tid, int keep_best) {
+    for (int t = tid; t < 85 * 9; t += SVT_NT) {
+        if (t < (c->L.cand_dwords < 168 ? c->L.cand_dwords : 168)) c->cand[t] = 0;
+        if (c->L.off_cand_hi >= 0 && t < 256) c->cand_hi[t] = 0;
+        if (c->ssdc && !(keep_best && me_udiv(t, 9) * 9 + 8 == t)) c->ssdc[t] = 0;
+    }
+}
+
 /* half-pel: distortion of every candidate accumulates in st->cand[pu*8+cand] (pre-zeroed).
  * SUB_SAD: rows 0,2,4.. only, doubled by the consumer; FULL_SAD: all rows.  SSD_SEARCH: 9 candidates per PU (8 = the
  * integer position, whose SSD seeds the comparison, :1107-1160), all rows, SAD in st->cand and SSD in c->ssdc. */
@@ -1279,7 +1307,7 @@ SVT_DEV void ph_halfpel(const me_ctx_t *c, int tid, int list, int sox, int soy, 
         uint32_t e = 0;
         const int cs = me_plane_stride(c, hpl) * step;
         uint32_t d = me_block_sad_rows(sp, ME_SB * step, cp, 0, cs, cs, w, r0, r0 + per, ssd ? &e : 0);
-        if (cand < 8) svt_group_add_var(&c->cand[pu * 8 + cand], d, nl);
+        if (cand < 8) { int sh; uint32_t *slot = me_cand_slot(c, pu * 8 + cand, &sh); svt_group_add_var(slot, d << sh, nl); }
         if (ssd) svt_group_add_var(&c->ssdc[pu * 9 + cand], e, nl);
     }
 }
@@ -1301,9 +1329,9 @@ SVT_DEV void ph_halfpel_decide(const me_ctx_t *c, int tid, int list, int en32, i
             me_dmv_get(i, &sx, &sy);
             if (ssd) {
                 d[i] = c->ssdc[pu * 9 + i];
-                if (d[i] < bssd) { bssd = d[i]; best = c->cand[pu * 8 + i]; mv = me_pack_mv(xm + 2 * sx, ym + 2 * sy); }
+                if (d[i] < bssd) { bssd = d[i]; best = me_cand_get(c, pu * 8 + i); mv = me_pack_mv(xm + 2 * sx, ym + 2 * sy); }
             } else {
-                d[i] = c->cand[pu * 8 + i];
+                d[i] = me_cand_get(c, pu * 8 + i);
                 if (sub_sad) d[i] <<= 1;
                 if (d[i] < best) { best = d[i]; mv = me_pack_mv(xm + 2 * sx, ym + 2 * sy); }
             }
@@ -1322,7 +1350,7 @@ SVT_DEV void ph_halfpel_decide(const me_ctx_t *c, int tid, int list, int en32, i
         c->st->best_sad[list][n] = best;
         c->st->best_mv[list][n]  = mv;
         c->st->dir[n]            = dir;
-        if (ssd) c->best_ssd[n] = bssd;
+        if (ssd) c->ssdc[pu * 9 + 8] = bssd; /* (the thread that read the integer position's SSD there) */
     }
 }
 
@@ -1385,7 +1413,7 @@ SVT_DEV void ph_quarterpel(const me_ctx_t *c, int tid, int list, int sox, int so
         uint32_t sq = 0;
         uint32_t d = r0 < r1 ? me_block_sad_rows(sp, ME_SB * step, a, b, me_plane_stride(c, (int)(e & 3)) * step,
                                                  me_plane_stride(c, (int)((e >> 4) & 3)) * step, w, r0, r1, ssd ? &sq : 0) : 0;
-        svt_group_add_u32(&c->cand[pu * 8 + pos], d, nl);
+        { int sh; uint32_t *slot = me_cand_slot(c, pu * 8 + pos, &sh); svt_group_add_u32(slot, d << sh, nl); }
         if (ssd) svt_group_add_u32(&c->ssdc[pu * 9 + pos], sq, nl);
     }
 }
@@ -1397,7 +1425,7 @@ SVT_DEV void ph_quarterpel_decide(const me_ctx_t *c, int tid, int list, int en32
         if (!me_pu_refined(c, pu, en32, en16, en8)) continue;
         int      n    = me_pu_nidx(pu);
         uint32_t best = c->st->best_sad[list][n], mv = c->st->best_mv[list][n];
-        uint32_t bssd = ssd ? c->best_ssd[n] : 0;
+        uint32_t bssd = ssd ? c->ssdc[pu * 9 + 8] : 0;
         int16_t  xm = me_mvx(mv), ym = me_mvy(mv);
         int      method = (ym & 2) + ((xm & 2) >> 1);
         int      dir = c->st->dir[n];
@@ -1407,16 +1435,16 @@ SVT_DEV void ph_quarterpel_decide(const me_ctx_t *c, int tid, int list, int en32
             me_dmv_get(i, &sx, &sy);
             if (ssd) {
                 uint32_t e = c->ssdc[pu * 9 + i];
-                if (e < bssd) { bssd = e; best = c->cand[pu * 8 + i]; mv = me_pack_mv(xm + sx, ym + sy); }
+                if (e < bssd) { bssd = e; best = me_cand_get(c, pu * 8 + i); mv = me_pack_mv(xm + sx, ym + sy); }
             } else {
-                uint32_t d = c->cand[pu * 8 + i];
+                uint32_t d = me_cand_get(c, pu * 8 + i);
                 if (sub_sad) d <<= 1;
                 if (d < best) { best = d; mv = me_pack_mv(xm + sx, ym + sy); }
             }
         }
         c->st->best_sad[list][n] = best;
         c->st->best_mv[list][n]  = mv;
-        if (ssd) c->best_ssd[n] = bssd;
+        if (ssd) c->ssdc[pu * 9 + 8] = bssd;
     }
 }
 
@@ -2344,7 +2372,9 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
     for (int list = 0; list < nlist; list++) {
         /* the reference's plane descriptors are read many times (address arithmetic, clipping): keep them in LDS */
         ME_PHASE(if (tid < (int)(3 * sizeof(svt_plane) / 4)) ((uint32_t *)st->refd)[tid] = ((const uint32_t *)&c->pic->ref[list])[tid];
-                 if (tid >= 64 && tid < 72) st->red[tid - 64] = 0);
+                 if (tid >= 64 && tid < 72) st->red[tid - 64] = 0;
+                 /* compact layout: list 0's SSD tables have overwritten the quarter-resolution SB */
+                 if (c->L.compact && list == 1 && p->enable_hme_level_1_flag && p->fractional_search_method == SVT_SSD_SEARCH) ph_load_quarter(c, tid));
         const svt_plane  rf_u = me_plane_uni(&st->refd[0]); /* full-resolution reference plane of this list */
         const svt_plane *rf = &rf_u;
         const int        ox = (int16_t)c->sb_x, oy = (int16_t)c->sb_y;
@@ -2456,6 +2486,10 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         me_clip_area(ox, &sox, &saw, ME_SB - 1, c->pic_w);                                                           \
         me_clip_area(oy, &soy, &sah, ME_SB - 1, c->pic_h);                                                           \
         W = saw + ME_SB - 1; H = sah + ME_SB - 1; w8 = saw - (saw & 7); tail_extra = (saw & 7) ? 16 : 0;             \
+        if (c->L.compact && tail_extra) { /* no room for the tail columns: the launch with the full layout takes this SB */ \
+            if (tid == 0) *SVT_AS_GLOBAL(uint32_t, c->redo) = 1;                                                      \
+            return;                                                                                                  \
+        }                                                                                                            \
     } while (0)
         /* stage the search region (+ halo) of this list in LDS; the full-pel keys are reset on the way */
 #define ME_LOAD_REGION()                                                                                            \
@@ -2599,13 +2633,13 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         } else
 #endif
         if (en32 || en16 || en8 || enq) {
-            ME_PHASE(for (int t = tid; t < 85 * 9; t += SVT_NT) { if (t < c->L.cand_dwords) c->cand[t] = 0; if (c->ssdc) c->ssdc[t] = 0; }
+            ME_PHASE(me_cand_zero(c, tid, 0);
                      ph_subpel_prep(c, tid, en32, en16, en8));
             ME_PHASE(ph_halfpel(c, tid, list, sox, soy, en32, en16, en8));
             ME_PHASE(ph_halfpel_decide(c, tid, list, en32, en16, en8));
             ME_MARK(10);
             if (enq) {
-                ME_PHASE(for (int t = tid; t < 85 * 9; t += SVT_NT) { if (t < c->L.cand_dwords) c->cand[t] = 0; if (c->ssdc) c->ssdc[t] = 0; });
+                ME_PHASE(me_cand_zero(c, tid, 1));
                 ME_PHASE(ph_quarterpel(c, tid, list, sox, soy, en32, en16, en8));
                 ME_PHASE(ph_quarterpel_decide(c, tid, list, en32, en16, en8));
             }

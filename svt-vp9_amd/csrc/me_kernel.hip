@@ -27,15 +27,19 @@ extern __shared__ __align__(16) uint8_t svt_lds[];
 /* One workgroup per (picture, SB).  blockIdx -> work item mapping is XCD-aware: consecutive work items
  * (neighbouring SBs, which share most of their reference window) are placed on the same XCD so that the
  * window re-reads hit that XCD's L2 (block b runs on XCD b % 8). */
-template <int SPEC, bool FAST>
+/* COMPACT / redo (me_layout.h): the launch with the compact layout flags the SBs it cannot serve in redo[picture * n_sb + sb]; the launch with
+ * the full layout that follows it (COMPACT = false, redo != nullptr) runs the flagged SBs only. */
+template <int SPEC, bool FAST, bool COMPACT = false>
 __device__ __forceinline__ void me_kernel_body(const me_pic_dev *__restrict__ pics, svt_me_params p, me_lds_layout L, int n_sb, int nx, int pic_w, int pic_h,
-                                               int total, int chunk, unsigned long long *prof) {
+                                               int total, int chunk, unsigned long long *prof, uint32_t *redo = nullptr) {
     /* block b runs on XCD b & 7: XCD k takes the k-th eighth of the SBs of EVERY picture (chunk SBs each; pictures of different
      * temporal layers cost differently, an XCD per picture range would leave the XCDs unbalanced), in picture order */
     const int b = blockIdx.x, j = b >> 3;
     const int pic = j / chunk, sb = (b & 7) * chunk + (j - pic * chunk);
     if (sb >= n_sb || pic * n_sb >= total) return;
+    if (!COMPACT && redo && !redo[pic * n_sb + sb]) return;
     me_ctx_t  c;
+    c.redo = COMPACT ? redo + pic * n_sb + sb : nullptr;
     c.pic = &pics[pic];
     svt_me_params pp = p;
     /* per-picture parameters travel with the picture (a launch may mix temporal layers) */
@@ -47,12 +51,13 @@ __device__ __forceinline__ void me_kernel_body(const me_pic_dev *__restrict__ pi
     c.p   = &pp;
     if constexpr (SPEC != 0) { /* the same values as the host's, as compile-time constants */
         me_lds_layout G = L;
-        me_lds_layout_geom(&pp, &G);
+        me_lds_layout_geom_ex(&pp, &G, COMPACT);
         L.region_stride = G.region_stride; L.plane_stride = G.plane_stride; L.plane_bytes = G.plane_bytes; L.region_rows = G.region_rows;
         L.cand_dwords = G.cand_dwords; L.scratch_bytes = G.scratch_bytes;
         L.off_state = G.off_state; L.off_src = G.off_src; L.off_region = G.off_region; L.off_planes = G.off_planes;
-        L.off_quarter = G.off_quarter; L.off_ssd = G.off_ssd; L.off_cand = G.off_cand; L.off_pred0 = G.off_pred0;
+        L.off_quarter = G.off_quarter; L.off_ssd = G.off_ssd; L.off_cand = G.off_cand; L.off_cand_hi = G.off_cand_hi; L.off_pred0 = G.off_pred0;
     }
+    L.compact = COMPACT;
     c.L   = L;
     c.lds = svt_lds;
     c.st     = (me_state_t *)(svt_lds + L.off_state);
@@ -61,8 +66,8 @@ __device__ __forceinline__ void me_kernel_body(const me_pic_dev *__restrict__ pi
     c.planes = svt_lds + L.off_planes;
     c.quarter_sb  = svt_lds + L.off_quarter;
     c.ssdc        = pp.fractional_search_method == SVT_SSD_SEARCH ? (uint32_t *)(svt_lds + L.off_ssd) : nullptr;
-    c.best_ssd    = c.ssdc ? c.ssdc + 85 * 9 : nullptr;
     c.cand        = (uint32_t *)(svt_lds + L.off_cand);
+    c.cand_hi     = (uint32_t *)(svt_lds + (L.off_cand_hi >= 0 ? L.off_cand_hi : L.off_cand));
     c.pred0       = (uint32_t *)(svt_lds + L.off_pred0);
     c.pic_w = pic_w; c.pic_h = pic_h; c.sb_index = sb; c.prof = prof;
     c.sb_x = (sb % nx) * ME_SB; c.sb_y = (sb / nx) * ME_SB;
@@ -72,10 +77,10 @@ __device__ __forceinline__ void me_kernel_body(const me_pic_dev *__restrict__ pi
     else me_sb_run(&c, threadIdx.x);
 }
 #define ME_KERNEL_ATTRS(SPEC) __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPEC == 0 ? ME_WAVES_PER_EU : me_spec_waves_per_eu(SPEC) == 5 ? ME_WAVES_PER_EU_SPEC : me_spec_waves_per_eu(SPEC))))
-template <int SPEC>
+template <int SPEC, bool COMPACT = false>
 ME_KERNEL_ATTRS(SPEC) void svt_me_sb_kernel(const me_pic_dev *__restrict__ pics, svt_me_params p, me_lds_layout L,
-                                                        int n_sb, int nx, int pic_w, int pic_h, int total, int chunk, unsigned long long *prof) {
-    me_kernel_body<SPEC, false>(pics, p, L, n_sb, nx, pic_w, pic_h, total, chunk, prof);
+                                                        int n_sb, int nx, int pic_w, int pic_h, int total, int chunk, unsigned long long *prof, uint32_t *redo) {
+    me_kernel_body<SPEC, false, COMPACT>(pics, p, L, n_sb, nx, pic_w, pic_h, total, chunk, prof, redo);
 }
 /* the same for the presets me_fast.h serves (me_spec_fast), pictures of whole SB columns and level-0 areas up to 256 x 256 */
 template <int SPEC>
@@ -210,6 +215,16 @@ static int32_t me_launch(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture 
 #ifdef ME_FINE_PROF
     { const char *sa = getenv("SVT_HIP_ME_STOP"); int v = sa ? atoi(sa) : -1; HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_me_stop_after), &v, sizeof v, 0, hipMemcpyHostToDevice, ctx->stream)); }
 #endif
+    /* compact layout: when the search area's width is a multiple of 8 and it buys a workgroup per CU (the 64 x 64-area presets) */
+    static const bool no_compact = getenv("SVT_HIP_ME_NOCOMPACT") != nullptr;
+    me_lds_layout Lc = L;
+    uint32_t     *d_redo = nullptr;
+    if (!no_compact && (params->search_area_width & 7) == 0 && params->search_area_width <= 127 && me_lds_layout_compute_ex(params, &Lc, 1) == 0 &&
+        me_lds_workgroups_per_cu(&Lc) > me_lds_workgroups_per_cu(&L)) {
+        d_redo = (uint32_t *)svt_ctx_slot(ctx, 39, (size_t)total * sizeof(uint32_t));
+        if (!d_redo) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "me: redo flags");
+        HIP_TRY(hipMemsetAsync(d_redo, 0, (size_t)total * sizeof(uint32_t), ctx->stream));
+    }
     HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
     /* the instance specialised for the caller's parameter set when there is one (me_spec.h), else the generic one */
     static const bool no_spec = getenv("SVT_HIP_ME_GENERIC") != nullptr;
@@ -225,13 +240,23 @@ static int32_t me_launch(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture 
 #define ME_LAUNCH(S) \
     if (L.total_bytes > 64 * 1024) \
         HIP_TRY(hipFuncSetAttribute((const void *)svt_me_sb_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total_bytes)); \
-    hipLaunchKernelGGL(svt_me_sb_kernel<S>, dim3(chunk * 8 * n_pics), dim3(256), L.total_bytes, ctx->stream, d, *params, L, n_sb, nx, W, H, total, chunk, d_prof)
+    hipLaunchKernelGGL(svt_me_sb_kernel<S>, dim3(chunk * 8 * n_pics), dim3(256), L.total_bytes, ctx->stream, d, *params, L, n_sb, nx, W, H, total, chunk, d_prof, (uint32_t *)nullptr)
+    /* two launches where the compact layout (me_layout.h) buys a workgroup per CU: every SB with the compact layout, then the SBs that
+     * flagged themselves (clipped search areas with tail columns: SBs near the right picture border) with the full one */
+#define ME_LAUNCH2(S) \
+    if (d_redo) { \
+        if (Lc.total_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)svt_me_sb_kernel<S, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Lc.total_bytes)); \
+        if (L.total_bytes > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)svt_me_sb_kernel<S, false>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total_bytes)); \
+        hipLaunchKernelGGL((svt_me_sb_kernel<S, true>), dim3(chunk * 8 * n_pics), dim3(256), Lc.total_bytes, ctx->stream, d, *params, Lc, n_sb, nx, W, H, total, chunk, d_prof, d_redo); \
+        hipLaunchKernelGGL((svt_me_sb_kernel<S, false>), dim3(chunk * 8 * n_pics), dim3(256), L.total_bytes, ctx->stream, d, *params, L, n_sb, nx, W, H, total, chunk, d_prof, d_redo); \
+    } else { ME_LAUNCH(S); }
     case 1: ME_LAUNCH(1); break;
     case 2: ME_LAUNCH(2); break;
     case 3: ME_LAUNCH(3); break;
-    case 4: ME_LAUNCH(4); break;
-    case 5: ME_LAUNCH(5); break;
+    case 4: ME_LAUNCH2(4); break;
+    case 5: ME_LAUNCH2(5); break;
     default: ME_LAUNCH(0); break;
+#undef ME_LAUNCH2
 #undef ME_LAUNCH
     }
     HIP_TRY(hipGetLastError());

@@ -58,6 +58,19 @@ def test_me_c5_full_4k_picture_vs_oracle(ctx):
     assert len(np.unique(g["x_mv_l0"])) > 8
 
 
+def test_me_c5_non_reference_layer_two_launches_at_4k(ctx):
+    """C5's non-reference layer (cu8x8_mode 1) runs with the compact LDS layout -- two workgroups per CU -- and a second launch with the
+    full layout for the SBs whose clipped search area has tail columns (csrc/me_layout.h): SBs near the right border.  One whole B
+    picture against the oracle."""
+    pics = [T.PaPic(f) for f in T.gen_clip_subpel(3840, 2160, 3, 31)]
+    p = MC.preset_c5(2, 3)
+    assert (p.search_area_width, p.search_area_height, p.fractional_search_method, p.cu8x8_mode) == (64, 64, 2, 1)
+    o, _ = T.oracle_me_picture_mt(pics[1], pics[0], pics[2], p)
+    g, _ = hip_me_picture(ctx, pics[1], pics[0], pics[2], p)
+    assert not T.me_results_equal(o, g, 2)
+    assert len(np.unique(g["x_mv_l0"])) > 8
+
+
 def test_me_specialised_and_generic_instances_agree_at_4k():
     """the kernel instance specialised for the 2160p M8 parameters and the generic instance (SVT_HIP_ME_GENERIC=1) are
     the same algorithm: equal checksums of all results of a 4K B picture (run in two fresh processes: the choice is
