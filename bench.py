@@ -194,8 +194,8 @@ def intra_pass_times():
         if line.rstrip().endswith(" ms"):
             name, val = line.rsplit(None, 2)[0].strip(), float(line.rsplit(None, 2)[1])
             ms[name] = val
-    return {"ms_per_2160p_picture": ms, "what": "svt_hip_encdec_intra_device on one 3840x2160 picture, q index 140, deblocking + border included; one 64-lane "
-                                              "workgroup per CU draws (32x32 area, plane) tickets in anti-diagonal order: 187 dependent area steps per picture"}
+    return {"ms_per_2160p_picture": ms, "what": "svt_hip_encdec_intra_device on one 3840x2160 picture, q index 140, deblocking + border included; persistent 64-lane "
+                                              "workgroups (two per CU) draw (16x16 luma cell, plane) tickets in anti-diagonal order: 374 dependent cell steps per picture"}
 
 
 def api_path_rate(frames, Wd, Hd, enc_mode, tune, n_send=130):

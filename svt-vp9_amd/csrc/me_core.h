@@ -2486,7 +2486,7 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
         me_clip_area(ox, &sox, &saw, ME_SB - 1, c->pic_w);                                                           \
         me_clip_area(oy, &soy, &sah, ME_SB - 1, c->pic_h);                                                           \
         W = saw + ME_SB - 1; H = sah + ME_SB - 1; w8 = saw - (saw & 7); tail_extra = (saw & 7) ? 16 : 0;             \
-        if (c->L.compact && tail_extra) { /* no room for the tail columns: the launch with the full layout takes this SB */ \
+        if (c->L.compact && W + ME_RGN_GX + 4 + tail_extra > c->L.region_stride) { /* no room for the tail columns: the launch with the full layout takes this SB */ \
             if (tid == 0) *SVT_AS_GLOBAL(uint32_t, c->redo) = 1;                                                      \
             return;                                                                                                  \
         }                                                                                                            \

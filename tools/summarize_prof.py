@@ -21,7 +21,8 @@ prof = os.path.join(root, "profiles")
 # launches of one step with ONE GOP in flight, diagonal schedule: ME per temporal layer, the transform stage per transform size (one
 # launch serves the five ring slots: svt_hip_tq_rd_batch_multi_device), everything else once over the 16 pictures
 # (ME launches = temporal layers of the mini-GOP: c5 has 8 pictures, 4 layers)
-PER_STEP = {"svt_me_kernel": 4 if preset == "c5" else 5, "svt_tq_kernel": 4, "svt_lf_kernel": 1, "svt_lf_desc_kernel": 1, "svt_pa_plane_kernel": 1, "svt_mc_kernel": 1,
+PER_STEP = {"svt_me_kernel": 8 if preset == "c5" else 5,   # (c5: two launches per layer -- compact layout, then the flagged SBs with the full one)
+             "svt_tq_kernel": 4, "svt_lf_kernel": 1, "svt_lf_desc_kernel": 1, "svt_pa_plane_kernel": 1, "svt_mc_kernel": 1,
             "svt_refpad_kernel": 1, "svt_tq_count_kernel": 1, "svt_scan_sb_kernel": 1, "svt_scan_pic_kernel": 1, "svt_tq_emit_kernel": 1, "svt_tq_skip_kernel": 1,
             "svt_skip_update_kernel": 1, "svt_lf_mask_kernel": 1}
 KERNELS = ("svt_tq_kernel", "svt_lf_kernel", "svt_lf_desc_kernel", "svt_lf_mask_kernel", "svt_pa_plane_kernel", "svt_mc_kernel", "svt_rate_kernel",
