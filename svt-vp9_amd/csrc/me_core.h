@@ -2343,6 +2343,100 @@ SVT_DEV void me_hme_select(const me_ctx_t *c, int list) {
     st->hme_xc = xc; st->hme_yc = yc;
 }
 
+#ifndef SVT_HOST_EMU
+/* The single-thread sections between the phases of an HME level -- results of level `fin` (me_hme_finish_level), plan of level `plan`
+ * (me_hme_plan_level); either may be -1 -- spread over lanes 0..3 of wave 0: lane k owns region slot k = rh * 2 + rw.  The regions are
+ * independent up to the packing of their windows into the scratch (prefix sums over the four lanes); when the level's windows do not fit
+ * the scratch together (the 64x64-area presets' level 0) lane 0 plans the level with the sequential code.  The serial chain of LDS round
+ * trips and reciprocal loads of one lane was 17 - 21 % of a workgroup's time at 1080p / 360p (SVT_HIP_ME_PROFILE); same results. */
+SVT_DEV uint32_t me_magic_lane(int d) { return d <= 256 ? me_magics.v[d] : me_magic_of(d); }
+SVT_DEV void me_hme_lanes(const me_ctx_t *c, int tid, int list, int fin, int plan, int16_t xsc, int16_t ysc, int first) {
+    if (tid >= 4) return;
+    const svt_me_params *p  = c->p;
+    me_state_t          *st = c->st;
+    const int            NW = p->number_hme_search_region_in_width, NH = p->number_hme_search_region_in_height;
+    const int            k = tid, rw = k & 1, rh = k >> 1;
+    const bool           valid = rw < NW && rh < NH;
+    if (fin >= 0 && valid) {
+        const int scale = 4 >> fin;
+        uint64_t  sad = 0xffffff;
+        int16_t   x = st->hme_x[fin][k], y = st->hme_y[fin][k];
+        if (st->hme_cw[k] > 0) {
+            const uint64_t key = st->hme_keys[k];
+            if (key != ~0ull) {
+                const uint32_t idx = (uint32_t)key, sd = (uint32_t)(key >> 32);
+                if (sd < sad) { sad = sd; x = (int16_t)(idx & 0xffffu); y = (int16_t)(idx >> 16); }
+            }
+        }
+        st->hme_sad[fin][k] = sad * 2;
+        x = (int16_t)(x + st->hme_cox[k]); x = (int16_t)(x * scale);
+        y = (int16_t)(y + st->hme_coy[k]); y = (int16_t)(y * scale);
+        st->hme_x[fin][k] = x; st->hme_y[fin][k] = y;
+    }
+    if (plan < 0) return;
+    me_hme_geom g;
+    me_hme_geom_of(c, list, plan, &g);
+    const int span = 2 * (g.bh - 1);
+    if (first) { /* [quirk] centres are only initialised while the reference's row counter is below NH */
+        const int rh_old = st->hme_rh;
+        if (rh_old < NH && valid && rh >= rh_old) {
+            st->hme_x[0][k] = (int16_t)(xsc >> 2); st->hme_y[0][k] = (int16_t)(ysc >> 2);
+            st->hme_x[1][k] = (int16_t)(xsc >> 1); st->hme_y[1][k] = (int16_t)(ysc >> 1);
+            st->hme_x[2][k] = xsc; st->hme_y[2][k] = ysc;
+        }
+    }
+    { uint32_t *kw_ = (uint32_t *)&st->hme_keys[k]; kw_[0] = ~0u; kw_[1] = ~0u; }
+    int16_t w = 0, h = 0, ox = 0, oy = 0;
+    if (valid) {
+        if (plan == 0) {
+            w = rw ? c->L.hme_w0[1] : c->L.hme_w0[0]; /* (selects: a lane-dependent index would move the whole structure to scratch memory) */
+            h = rh ? c->L.hme_h0[1] : c->L.hme_h0[0];
+            int16_t ddx = (int16_t)(xsc >> 2), ddy = (int16_t)(ysc >> 2);
+            if (rw > 0) ddx = (int16_t)(ddx + c->L.hme_w0[0]);
+            if (rh > 0) ddy = (int16_t)(ddy + c->L.hme_h0[0]);
+            ox = (int16_t)(-(int16_t)(c->L.hme_tw0 >> 1) + ddx);
+            oy = (int16_t)(-(int16_t)(c->L.hme_th0 >> 1) + ddy);
+        } else if (plan == 1) {
+            w  = me_hme_round_w((int16_t)(rw ? p->hme_level1_search_area_in_width_array[1] : p->hme_level1_search_area_in_width_array[0]));
+            h  = (int16_t)(rh ? p->hme_level1_search_area_in_height_array[1] : p->hme_level1_search_area_in_height_array[0]);
+            ox = (int16_t)(-(w >> 1) + (int16_t)(st->hme_x[0][k] >> 1));
+            oy = (int16_t)(-(h >> 1) + (int16_t)(st->hme_y[0][k] >> 1));
+        } else {
+            w  = me_hme_round_w((int16_t)(rw ? p->hme_level2_search_area_in_width_array[1] : p->hme_level2_search_area_in_width_array[0]));
+            h  = (int16_t)(rh ? p->hme_level2_search_area_in_height_array[1] : p->hme_level2_search_area_in_height_array[0]);
+            ox = (int16_t)(-(w >> 1) + st->hme_x[1][k]);
+            oy = (int16_t)(-(h >> 1) + st->hme_y[1][k]);
+        }
+        me_clip_area(g.ox, &ox, &w, g.pad_w, g.ref_w);
+        me_clip_area(g.oy, &oy, &h, g.pad_h, g.ref_h);
+    }
+    const bool ok = valid && w > 0 && h > 0;
+    st->hme_cox[k] = valid ? ox : (int16_t)0; st->hme_coy[k] = valid ? oy : (int16_t)0; /* kept even when nothing is searched: the centre still moves by them */
+    st->hme_cw[k] = ok ? w : (int16_t)0; st->hme_ch[k] = ok ? h : (int16_t)0;
+    const int wbytes = w + g.bw + 3;
+    int       ws     = ((wbytes + 3) & ~3) + 4;
+    if (((ws >> 2) & 1) == 0) ws += 4;
+    const int nd = (wbytes + 3) >> 2, ng = (g.bw & 3) == 0 ? (w + 3) >> 2 : w;
+    const int my_bytes = ok ? ws * (h + span) : 0, my_tl = ok ? ME_HME_UNITS(nd) * (h + span) : 0, my_ts = ok ? ng * h : 0;
+    int       bytes = 0, tl = 0, ts = 0, ne = 0, total = 0, n_all = 0;
+    _Pragma("unroll") for (int j = 0; j < 4; j++) {
+        const int bj = __shfl(my_bytes, j), tlj = __shfl(my_tl, j), tsj = __shfl(my_ts, j), okj = __shfl((int)ok, j);
+        if (j < k) { bytes += bj; tl += tlj; ts += tsj; ne += okj; }
+        total += bj; n_all += okj;
+    }
+    if (total <= c->L.scratch_bytes) { /* one batch, one window per region */
+        if (ok) {
+            me_hme_win *wn = &st->hme_win[ne];
+            wn->off = (uint32_t)bytes; wn->wstride = (uint16_t)ws; wn->nd = (uint8_t)nd; wn->rows = (uint16_t)(h + span); wn->sw = (uint16_t)w; wn->sh = (uint16_t)h;
+            wn->gx = (int16_t)(g.ox + ox); wn->gy = (int16_t)(g.oy + oy); wn->slot = (uint8_t)k; wn->y0 = 0; wn->tl = (uint16_t)tl; wn->ts = (uint16_t)ts;
+            wn->inv_nu = me_magic_lane(ME_HME_UNITS(nd)); wn->inv_ng = me_magic_lane(ng);
+        }
+        if (k == 0) { st->hme_rh = NH; st->hme_bstart[0] = 0; st->hme_bstart[1] = n_all; st->hme_nbatch = n_all > 0 ? 1 : 0; }
+    } else if (k == 0) me_hme_plan_level(c, list, plan, xsc, ysc, first); /* bands: the sequential planner (it repeats the steps above) */
+}
+#endif
+
+
 #ifdef SVT_HOST_EMU
 static inline
 #else
@@ -2435,6 +2529,11 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                     ME_SUBMARK_BEGIN();
                     /* (the plan of every level but the first rides with the previous level's finish: one single-thread section and one
                        barrier less per level) */
+#ifndef SVT_HOST_EMU
+                    const int lanes = !(p->single_hme_quadrant && !p->enable_hme_level_1_flag && !p->enable_hme_level_2_flag); /* (the one-region presets keep their short form) */
+                    if (!planned && lanes) ME_PHASE(me_hme_lanes(c, tid, list, -1, lvl, xsc, ysc, first));
+                    else
+#endif
                     if (!planned) ME_UNIFORM_WRITE(me_hme_plan_level(c, list, lvl, xsc, ysc, first));
                     ME_SUBMARK(20);
                     ME_STOP_AT(19);
@@ -2461,6 +2560,10 @@ void me_sb_run(const me_ctx_t *c, int tid_) {
                     ME_SUBMARK(22);
                     int nxt = -1;
                     for (int l2 = lvl + 1; l2 < 3 && nxt < 0; l2++) if (ME_HME_LEVEL_ON(l2)) nxt = l2;
+#ifndef SVT_HOST_EMU
+                    if (lanes) ME_PHASE(me_hme_lanes(c, tid, list, lvl, lvl == last_lvl ? -1 : nxt, xsc, ysc, 0); if (lvl == last_lvl && tid == 0) me_hme_select(c, list));
+                    else
+#endif
                     ME_UNIFORM_WRITE(me_hme_finish_level(c, lvl); if (lvl == last_lvl) me_hme_select(c, list); else if (nxt >= 0) me_hme_plan_level(c, list, nxt, xsc, ysc, 0));
                     planned = nxt >= 0 && lvl != last_lvl;
                     ME_SUBMARK(21);
