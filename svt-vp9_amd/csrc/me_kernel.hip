@@ -255,7 +255,7 @@ static int32_t me_launch(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture 
     case 3: ME_LAUNCH(3); break;
     case 4: ME_LAUNCH2(4); break;
     case 5: ME_LAUNCH2(5); break;
-    default: ME_LAUNCH(0); break;
+    default: ME_LAUNCH2(0); break;
 #undef ME_LAUNCH2
 #undef ME_LAUNCH
     }

@@ -1,6 +1,8 @@
 """Randomised parity sweep of the ME kernel against the oracle (GPU): random picture sizes (incl. partial SBs), content kinds
 (smooth motion, noise, flat / tie-heavy, blocky), presets, list counts and temporal layers.  tools/me_fuzz.py [cases] [seed] [fast]
-`fast`: the 2160p enc-mode-8 preset on pictures of whole SB columns only (csrc/me_fast.h's driver; the run checks that it served)."""
+`fast`: the 2160p enc-mode-8 preset on pictures of whole SB columns only (csrc/me_fast.h's driver; the run checks that it served).
+`c5`: the 2160p enc-mode-3 preset (64x64 area, SSD search, three HME levels) with mutated search areas (multiples of 8: the compact LDS layout
+with its second launch, csrc/me_layout.h; others: the plain one), 8x8 modes and metrics -- on small pictures most SBs meet clipped areas."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,6 +13,7 @@ ctx = C.c_void_p(); B.check(lib.svt_hip_ctx_create(C.byref(ctx), 0))
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 fast = len(sys.argv) > 3 and sys.argv[3] == "fast"
+c5 = len(sys.argv) > 3 and sys.argv[3] == "c5"
 lib.svt_hip_me_last_instance.argtypes = [C.c_void_p]
 
 def content(kind, w, h):
@@ -39,6 +42,12 @@ for i in range(n_cases):
     if fast: w, name = 64 * int(rng.integers(2, 8)), "c3_2160p_m8"
     pics = [T.PaPic(f) for f in content(kind, w, h)]
     p = MC.preset(name, nl, tl)
+    if c5:
+        p = MC.preset_c5(nl, tl & 3)
+        p.search_area_width, p.search_area_height = [(64, 64), (64, 64), (48, 40), (56, 64), (64, 24), (40, 56), (61, 33), (24, 64)][int(rng.integers(8))]
+        p.cu8x8_mode = int(rng.integers(0, 2))
+        p.fractional_search_method = [2, 2, 0, 1][int(rng.integers(4))]
+        name = "c5 %dx%d cu8=%d method=%d" % (p.search_area_width, p.search_area_height, p.cu8x8_mode, p.fractional_search_method)
     if nl == 2 and rng.integers(0, 4) == 0: p.same_ref_poc = 1
     r1 = pics[2] if nl == 2 else None
     o, _ = T.oracle_me_picture(pics[1], pics[0], r1, p)
