@@ -431,6 +431,9 @@ typedef struct me_ctx_t {
     uint8_t             *src;    /* LDS */
     uint8_t             *region; /* LDS */
     uint8_t             *planes; /* LDS */
+    uint8_t             *hme_scratch; /* LDS: where the HME levels stage their windows -- the region buffer and the planes behind it, both dead while a list's
+                                         hierarchical search runs (the region is staged after it, the planes are interpolated from the region) */
+    int                  hme_scratch_bytes;
     uint8_t             *quarter_sb; /* LDS, valid when HME level 1 is enabled */
     uint32_t            *ssdc;       /* LDS, SSD_SEARCH only: SSD of the sub-pel candidates [pu][9] (8 = integer position) */
     uint32_t            *cand;       /* LDS: sub-pel candidate distortions [pu][8] (see me_cand_get); bi-pred distortion [pu] */
@@ -1841,7 +1844,7 @@ SVT_DEV void ph_hme_load_multi(const me_ctx_t *c, int tid, const svt_plane *ref_
         }
         _Pragma("unroll") for (int u = 0; u < 2; u++)
             if (dst[u] >= 0) {
-                uint32_t *d = (uint32_t *)(c->planes + dst[u]);
+                uint32_t *d = (uint32_t *)(c->hme_scratch + dst[u]);
                 d[0] = v[u].x;
                 if (k[u] > 1) d[1] = v[u].y;
                 if (k[u] > 2) d[2] = v[u].z;
@@ -1993,7 +1996,7 @@ SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk,
             }
             const int ng = (sw + 3) >> 2, y = me_div_magic(t, w_inv), g = t - ME_MUL(y, ng);
             uint32_t  lo, hi;
-            me_qsad_16x8(blk, c->planes + w_off + ME_MUL(y, w_ws) + 4 * g, w_ws, &lo, &hi);
+            me_qsad_16x8(blk, c->hme_scratch + w_off + ME_MUL(y, w_ws) + 4 * g, w_ws, &lo, &hi);
             const uint32_t pos = ((uint32_t)(w_y0 + y) << 8) | (uint32_t)(4 * g);
             uint32_t       k0 = (lo << 16) | pos, k1 = (lo & 0xffff0000u) | (pos + 1), k2 = (hi << 16) | (pos + 2), k3 = (hi & 0xffff0000u) | (pos + 3);
             if (4 * g + 3 >= sw) { /* last group of a width that is not a multiple of 4 */
@@ -2037,7 +2040,7 @@ SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk,
                 }
                 const int ng = (sw + 3) >> 2;
                 y = me_div_magic(t, w_inv); g = t - ME_MUL(y, ng);
-                const uint8_t *wp = c->planes + w_off + ME_MUL(y, ws) + 4 * g + 4 * sub;
+                const uint8_t *wp = c->hme_scratch + w_off + ME_MUL(y, ws) + 4 * g + 4 * sub;
                 uint64_t       acc = 0, acc_b = 0; /* two chains; eight rows' operands are fetched before their QSADs (bh is 16 or 32) */
                 const int      ws2 = 2 * ws;
                 for (int j = 0; j < bh; j += 8) {
@@ -2081,7 +2084,7 @@ SVT_DEV void ph_hme_search_multi(const me_ctx_t *c, int tid, const uint8_t *blk,
         while (e + 1 < e1 && T >= wn[e + 1].ts) e++;
         const int      t = T - wn[e].ts, ws = wn[e].wstride, sw = wn[e].sw, slot = wn[e].slot, y0 = wn[e].y0;
         if (e != cur) { cur = e; inv = wn[e].inv_ng; }
-        const uint8_t *win = c->planes + wn[e].off;
+        const uint8_t *win = c->hme_scratch + wn[e].off;
         uint64_t       kb = ~0ull;
         FP(16);
         if (qs) {
@@ -2187,7 +2190,7 @@ SVT_DEV void me_hme_plan_level(const me_ctx_t *c, int list, int lvl, int16_t xsc
             const int ng = (g.bw & 3) == 0 ? (w + 3) >> 2 : w;
             for (int y = 0; y < h && ne < ME_HME_MAX_WIN;) {
                 int nr = h - y;
-                if (ws * (nr + span) > c->L.scratch_bytes - bytes) nr = (c->L.scratch_bytes - bytes) / ws - span;
+                if (ws * (nr + span) > c->hme_scratch_bytes - bytes) nr = (c->hme_scratch_bytes - bytes) / ws - span;
                 if (nr < 1 && bytes > 0) { st->hme_bstart[++nb] = ne; bytes = 0; tl = 0; ts = 0; continue; }
                 if (nr < 1) break;
                 me_hme_win *wn = &st->hme_win[ne++];
@@ -2263,7 +2266,7 @@ SVT_DEV void me_hme_plan_level(const me_ctx_t *c, int list, int lvl, int16_t xsc
         for (int y = 0; y < h && ne < ME_HME_MAX_WIN;) {
             /* search rows that still fit the scratch: usually all of them -- the division only runs otherwise */
             int nr = h - y;
-            if (ws * (nr + span) > c->L.scratch_bytes - bytes) nr = (c->L.scratch_bytes - bytes) / ws - span;
+            if (ws * (nr + span) > c->hme_scratch_bytes - bytes) nr = (c->hme_scratch_bytes - bytes) / ws - span;
             if (nr < 1 && bytes > 0) { /* close the batch and retry with an empty scratch */
                 st->hme_bstart[++nb] = ne; bytes = 0; tl = 0; ts = 0;
                 continue;
@@ -2424,7 +2427,7 @@ SVT_DEV void me_hme_lanes(const me_ctx_t *c, int tid, int list, int fin, int pla
         if (j < k) { bytes += bj; tl += tlj; ts += tsj; ne += okj; }
         total += bj; n_all += okj;
     }
-    if (total <= c->L.scratch_bytes) { /* one batch, one window per region */
+    if (total <= c->hme_scratch_bytes) { /* one batch, one window per region */
         if (ok) {
             me_hme_win *wn = &st->hme_win[ne];
             wn->off = (uint32_t)bytes; wn->wstride = (uint16_t)ws; wn->nd = (uint8_t)nd; wn->rows = (uint16_t)(h + span); wn->sw = (uint16_t)w; wn->sh = (uint16_t)h;

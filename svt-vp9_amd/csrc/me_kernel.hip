@@ -64,6 +64,7 @@ __device__ __forceinline__ void me_kernel_body(const me_pic_dev *__restrict__ pi
     c.src    = svt_lds + L.off_src;
     c.region = svt_lds + L.off_region;
     c.planes = svt_lds + L.off_planes;
+    c.hme_scratch = svt_lds + L.off_region; c.hme_scratch_bytes = (L.off_planes - L.off_region) + L.scratch_bytes; /* (me_lds_layout_geom: the planes follow the region) */
     c.quarter_sb  = svt_lds + L.off_quarter;
     c.ssdc        = pp.fractional_search_method == SVT_SSD_SEARCH ? (uint32_t *)(svt_lds + L.off_ssd) : nullptr;
     c.cand        = (uint32_t *)(svt_lds + L.off_cand);

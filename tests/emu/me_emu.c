@@ -45,7 +45,7 @@ int32_t svt_emu_me_picture(const svt_pa_picture *cur, const svt_pa_picture *ref0
         me_ctx_t c;
         c.pic = &pic; c.p = params; c.L = L; c.lds = lds;
         c.st = (me_state_t *)(lds + L.off_state); c.src = lds + L.off_src; c.region = lds + L.off_region;
-        c.planes = lds + L.off_planes; c.quarter_sb = lds + L.off_quarter; c.ssdc = params->fractional_search_method == SVT_SSD_SEARCH ? (uint32_t *)(lds + L.off_ssd) : 0; c.pred0 = (uint32_t *)(lds + L.off_pred0); c.cand = (uint32_t *)(lds + L.off_cand); c.cand_hi = (uint32_t *)(lds + (L.off_cand_hi >= 0 ? L.off_cand_hi : L.off_cand)); c.redo = 0;
+        c.planes = lds + L.off_planes; c.hme_scratch = lds + L.off_region; c.hme_scratch_bytes = (L.off_planes - L.off_region) + L.scratch_bytes; c.quarter_sb = lds + L.off_quarter; c.ssdc = params->fractional_search_method == SVT_SSD_SEARCH ? (uint32_t *)(lds + L.off_ssd) : 0; c.pred0 = (uint32_t *)(lds + L.off_pred0); c.cand = (uint32_t *)(lds + L.off_cand); c.cand_hi = (uint32_t *)(lds + (L.off_cand_hi >= 0 ? L.off_cand_hi : L.off_cand)); c.redo = 0;
         c.pic_w = W; c.pic_h = H; c.sb_index = sb; c.prof = 0;
         c.sb_x = (sb % nx) * 64; c.sb_y = (sb / nx) * 64;
         c.sb_w = (W - c.sb_x) < 64 ? W - c.sb_x : 64; c.sb_h = (H - c.sb_y) < 64 ? H - c.sb_y : 64;
