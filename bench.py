@@ -1142,9 +1142,10 @@ def main():
         # the border of the three planes written, the edge samples read (reference pictures only: the deepest layer is not padded)
         "pad": (pics_step // 2) * int((geo.pw * geo.ph - L) + 2 * (geo.cpw * geo.cph - L // 4) + 2 * (Hd + Wd)),
     }
-    # the rocprofv3 name of the ME kernel the launches really were (svt_hip_me_last_instance: me_spec.h index, + 100 for csrc/me_fast.h's driver)
+    # the rocprofv3 name of the ME kernel the launches really were (svt_hip_me_last_instance: me_spec.h index, + 100 for csrc/me_fast.h's driver, + 200 for the compact-layout pair of launches)
     me_inst = int(lib.svt_hip_me_last_instance(me_ctxs[0])) if ctxs else -1
-    me_kernel_name = f"svt_me_fast_kernel<{me_inst - 100}>" if me_inst >= 100 else f"svt_me_sb_kernel<{max(me_inst, 0)}>"
+    me_kernel_name = (f"svt_me_sb_kernel<{me_inst - 200}, true>" if me_inst >= 200 else   # (the compact-layout launch; its <.., false> companion runs the flagged SBs)
+                      f"svt_me_fast_kernel<{me_inst - 100}>" if me_inst >= 100 else f"svt_me_sb_kernel<{max(me_inst, 0)}, false>")
     kernel_of = {"pa": "svt_pa_plane_kernel", "me": me_kernel_name, "mc": "svt_mc_kernel", "lists": "svt_tq_count / svt_scan / svt_tq_emit kernels",
                  "tq": "svt_tq_kernel<4|8|16|32>", "skip": "svt_tq_skip / svt_skip_update kernels", "lf": "svt_lf_mask + svt_lf_desc + svt_lf_kernel",
                  "pad": "svt_refpad_kernel"}

@@ -168,7 +168,8 @@ int32_t svt_hip_me_params_preset(svt_me_params *p, int32_t pic_width, int32_t pi
  * parameters are compile-time constants (one per BASELINE configuration; identical results by construction) */
 int32_t svt_hip_me_kernel_instance(const svt_me_params *p);
 /* diagnostic: the instance the last ME launch on ctx actually ran -- the index above, + 100 when the launch was served by the
- * driver for single-region level-0 HME presets (csrc/me_fast.h: whole SB columns, level-0 areas up to 256 x 256) */
+ * driver for single-region level-0 HME presets (csrc/me_fast.h: whole SB columns, level-0 areas up to 256 x 256), + 200 when it was the pair of
+ * launches of the compact LDS layout (csrc/me_layout.h: the 64 x 64-area presets at two workgroups per CU) */
 int32_t svt_hip_me_last_instance(const svt_hip_ctx *ctx);
 /* Deployment knob of the intra encode pass (svt_hip_encdec_intra_device, and the intra blocks of inter pictures) launched on ctx: at most n
  * one-wave workgroups (0 = the default: one per compute unit, the lowest latency for a key frame alone -- 6.5 ms at 2160p).  A pass that runs

@@ -231,7 +231,7 @@ static int32_t me_launch(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture 
     static const bool no_spec = getenv("SVT_HIP_ME_GENERIC") != nullptr;
     static const bool no_fast = getenv("SVT_HIP_ME_NOFAST") != nullptr;
     const int spec = no_spec ? 0 : me_spec_match(params);
-    ctx->me_instance = spec;
+    ctx->me_instance = spec + (d_redo ? 200 : 0);
     if (spec == 1 && fast_ok && !no_fast) { /* the instances of me_spec_fast() */
         static_assert(me_spec_fast(1), "SPEC 1 is served by me_fast.h");
         ctx->me_instance = 101;

@@ -18,7 +18,7 @@ struct svt_hip_ctx {
     hipEvent_t  ev_start, ev_stop;
     int         timed;
     int         cu_count;  /* compute units of the device (queried once at creation) */
-    int         me_instance; /* kernel instance of the last ME launch: me_spec.h index, + 100 for me_fast.h's driver */
+    int         me_instance; /* kernel instance of the last ME launch: me_spec.h index, + 100 for me_fast.h's driver, + 200 for the two launches of the compact layout (me_layout.h) */
     int         intra_wgs;   /* svt_hip_ctx_set_intra_workgroups: workgroups of the intra pass launched on this context (0 = default) */
     /* ring of staging slots (pinned host + device twin) for launch descriptors: a slot is reused only after the
        event recorded behind its last consumer has completed, so launches never synchronise the stream */
