@@ -808,10 +808,17 @@ SVT_DEV void me_fullpel_fused16_dev(const me_ctx_t *c, int tid, int sw, int sh) 
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pg = lane >> 4, b = lane & 15;
     const int bx = ((b & 1) | ((b >> 1) & 2)) * 16, by = (((b >> 1) & 1) | ((b >> 2) & 2)) * 16;
-    uint32_t  sx[4][4], sy[4][4]; /* [8x8 block][row 0, 2, 4, 6]: the two source dwords */
+    /* The PUs at by and by + 32 sit in the same LDS banks whatever the row stride (32 rows are a multiple of 32 dwords), and a 32-lane pass
+     * holds both: every window read was a two-way bank conflict (half of the phase's LDS-busy cycles, tools/me_phase_lds.sh).  The lower PUs
+     * therefore walk their four rows one step ahead (row (r + 1) & 3 where the upper ones take row r: two rows = 70 dwords = 6 banks on, which
+     * lands exactly in the banks the other half leaves free) -- a sum does not care about the order of its terms. */
+    const int rot = by >> 5;
+    uint32_t  sx[4][4], sy[4][4]; /* [8x8 block][step]: the two source dwords of row 2 ((step + rot) & 3) */
+    uint32_t  roff[4];            /* byte offset of that row in the window */
+    _Pragma("unroll") for (int r = 0; r < 4; r++) roff[r] = (uint32_t)ME_MUL(2 * ((r + rot) & 3), rs);
     _Pragma("unroll") for (int k = 0; k < 4; k++)
         _Pragma("unroll") for (int r = 0; r < 4; r++) {
-            const uint2 v = *(const uint2 *)(c->src + ME_MUL(by + (k >> 1) * 8 + 2 * r, ME_SB) + bx + (k & 1) * 8);
+            const uint2 v = *(const uint2 *)(c->src + ME_MUL(by + (k >> 1) * 8 + 2 * ((r + rot) & 3), ME_SB) + bx + (k & 1) * 8);
             sx[k][r] = v.x; sy[k][r] = v.y;
         }
     const uint32_t rbase = (uint32_t)(c->region - c->lds) + (uint32_t)(ME_MUL(ME_RGN_GY + by, rs) + ME_RGN_GX + bx);
@@ -837,7 +844,7 @@ SVT_DEV void me_fullpel_fused16_dev(const me_ctx_t *c, int tid, int sw, int sh) 
             const uint8_t *wp = rp + ME_MUL((k >> 1) * 8, rs) + (k & 1) * 8;
             uint64_t       acc[4] = {0, 0, 0, 0};
             _Pragma("unroll") for (int r = 0; r < 4; r++) {
-                const uint32_t *wr = (const uint32_t *)(wp + ME_MUL(2 * r, rs));
+                const uint32_t *wr = (const uint32_t *)(wp + roff[r]);
                 const uint32_t  d0 = wr[0], d1 = wr[1], d2 = wr[2], d3 = wr[3], d4 = wr[4], d5 = wr[5];
                 acc[0] = svt_qsad(((uint64_t)d1 << 32) | d0, sx[k][r], acc[0]); acc[0] = svt_qsad(((uint64_t)d2 << 32) | d1, sy[k][r], acc[0]);
                 acc[1] = svt_qsad(((uint64_t)d2 << 32) | d1, sx[k][r], acc[1]); acc[1] = svt_qsad(((uint64_t)d3 << 32) | d2, sy[k][r], acc[1]);
