@@ -231,9 +231,17 @@ def api_path_rate(frames, Wd, Hd, enc_mode, tune, n_send=130):
         # by turns -- exercises what `SVT_HIP_DEVICES=a,b` runs on a multi-GPU node; no scaling claim (one GPU's worth of compute and link)
         r = subprocess.run([exe, path, str(Wd), str(Hd), str(len(frames)), str(n_send), str(enc_mode), str(tune), "0", "0,0"], capture_output=True, text=True)
         two = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+        # the same path over 600 pictures (10 s of video: fill and drain, ~12 ms, no longer weigh) -- with and without the reconstructions fetched
+        long_run = {}
+        for recon in (0, 1):
+            r = subprocess.run([exe, path, str(Wd), str(Hd), str(len(frames)), "600", str(enc_mode), str(tune), str(recon)], capture_output=True, text=True)
+            if r.returncode == 0:
+                d = json.loads(r.stdout.strip().splitlines()[-1])
+                long_run["with_recon_output" if recon else "default"] = {"value": d["frames_per_s"], "frames": d["frames"], "seconds": d["seconds"]}
     d0 = out["default"]
     return {"value": d0["value"], "unit": "frames/s", "frames": d0["frames"], "seconds": d0["seconds"], "me_launches": d0["me_launches"], "mpixels_per_s": d0["mpixels_per_s"],
             "with_recon_output": out["with_recon_output"],
+            "value_600_pictures": long_run.get("default", {}).get("value"), "long_run": long_run or None,
             "two_contexts_one_gpu": ({"value": two["frames_per_s"], "frames": two["frames"], "devices": "0,0",
                                       "note": "GOPs dealt to two contexts of the same GPU (the multi-device host shape: per-device ring, streams, feeder thread); not a scaling figure"}
                                      if two else None),
@@ -242,7 +250,7 @@ def api_path_rate(frames, Wd, Hd, enc_mode, tune, n_send=130):
                     "(app/svt_enc_api_bench.c): first send_picture -> EOS packet, host buffers in (Y, Cb, Cr), PCIe included; every stage of the path behind the "
                     "API, one mini-GOP at a time (uploads + picture analysis on an input stream, reconstruction copies on an output stream, beside the main stream), the stage flags per picture as the reference derives them (recon_file = 0: deblocking on base-layer pictures "
                     "only, no reconstruction of the deepest layer; with_recon_output: recon_file = 1, all pictures reconstructed + deblocked and fetched with "
-                    "eb_vp9_svt_get_recon); zero-byte packets (no entropy coding); picture 0 is a key frame coded by the intra encode pass (svt_hip_encdec_intra_device, stand-in decision: 16x16 DC), ~6.2 ms of the run"}
+                    "eb_vp9_svt_get_recon); zero-byte packets (no entropy coding); picture 0 is a key frame coded by the intra encode pass (svt_hip_encdec_intra_device, stand-in decision: 16x16 DC), ~4.3 ms of the run; value_600_pictures / long_run: the same over 600 pictures -- the host -> device link bounds it (DESIGN.md section 7)"}
 
 
 def reference_me_rate(T, B, orc, frames, Wd, Hd, enc_mode, tune, l1_on, ncpu):
