@@ -232,11 +232,23 @@ static int32_t me_launch(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture 
     static const bool no_fast = getenv("SVT_HIP_ME_NOFAST") != nullptr;
     const int spec = no_spec ? 0 : me_spec_match(params);
     ctx->me_instance = spec + (d_redo ? 200 : 0);
-    if (spec == 1 && fast_ok && !no_fast) { /* the instances of me_spec_fast() */
-        static_assert(me_spec_fast(1), "SPEC 1 is served by me_fast.h");
-        ctx->me_instance = 101;
-        hipLaunchKernelGGL(svt_me_fast_kernel<1>, dim3(chunk * 8 * n_pics), dim3(256), L.total_bytes, ctx->stream, d, *params, L, n_sb, nx, W, H, total, chunk, d_prof);
-    } else
+    /* me_fast.h's driver where a compiled instance of it serves the parameter set (me_spec_fast; today SPEC 1) */
+    bool fast_done = false;
+#define ME_LAUNCH_FAST(S) \
+    if constexpr (me_spec_fast(S)) { \
+        if (L.total_bytes > 64 * 1024) \
+            HIP_TRY(hipFuncSetAttribute((const void *)svt_me_fast_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total_bytes)); \
+        ctx->me_instance = 100 + S; \
+        hipLaunchKernelGGL(svt_me_fast_kernel<S>, dim3(chunk * 8 * n_pics), dim3(256), L.total_bytes, ctx->stream, d, *params, L, n_sb, nx, W, H, total, chunk, d_prof); \
+        fast_done = true; \
+    }
+    if (fast_ok && !no_fast && !d_redo)
+        switch (spec) {
+        case 1: ME_LAUNCH_FAST(1); break;
+        default: break;
+        }
+#undef ME_LAUNCH_FAST
+    if (!fast_done)
     switch (spec) {
 #define ME_LAUNCH(S) \
     if (L.total_bytes > 64 * 1024) \

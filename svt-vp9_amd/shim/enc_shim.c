@@ -40,12 +40,17 @@
  *                                device (svt_hip_ref_handoff_device): the one exchange step of the path
  * Every picture is answered by a zero-byte packet: entropy coding is outside the hot path.
  * Not reproduced (picture decision / rate control, control plane): the low-delay-P structure tables of the parts of a short group
- * (those pictures are a P chain).
+ * (those pictures are a P chain); the q index of KEY frames -- inter pictures follow the reference's fixed-QP rule per temporal layer
+ * (QP_SCALING_MODE_0, host/qp_scaling.c), key frames are coded at the sequence's q index where the reference applies its adaptive
+ * QP_SCALING_MODE_1 to I slices (Codec/EbRateControlProcess.c:4680-4722: a noticeably lower q): pictures that predict from a key frame
+ * see a coarser reference here than upstream.  Rate control's decision: out of scope.
  */
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#define FAILED(s) __atomic_load_n(&(s)->failed, __ATOMIC_RELAXED)
+#define SET_FAILED(s) __atomic_store_n(&(s)->failed, 1, __ATOMIC_RELAXED)
 #include <time.h>
 
 #include "../../include/svt_vp9_enc_api.h"
@@ -183,7 +188,8 @@ typedef struct shim_dev {
 
 typedef struct shim_state {
     EbSvtVp9EncConfiguration cfg;   /* the library's copy, with frame_rate / intra_period resolved (copy_api_from_app) */
-    int         configured, initialised, eos, failed;
+    int         configured, initialised, eos;
+    int         failed;      /* written by the caller's thread and by the feeders: accessed through FAILED() / SET_FAILED() (relaxed atomics) */
     int         levels, minigop;       /* hierarchical levels, 1 << levels */
     int         intra_period;          /* resolved */
     int         n_dev, cur_dev, split_gop;
@@ -281,7 +287,7 @@ static shim_state *state_of(EbComponentType *h) { return h ? (shim_state *)h->p_
 static EbErrorType gpu_fail(shim_state *s) { /* a failed device call ends the stream: every later call reports it (the reference posts
                                                 a pipeline error and answers EB_ErrorMax from then on, :437-452, 2914-2917) */
     fprintf(stderr, "SvtVp9Enc (GPU hot path): %s\n", svt_hip_last_error());
-    s->failed = 1;
+    SET_FAILED(s);
     /* direct uploads (SVT_HIP_REGISTER_INPUT=1) read the CALLER's planes: whatever failed, no entry point returns while one may still
        be in flight */
     if (s->register_input)
@@ -294,7 +300,7 @@ static EbErrorType gpu_fail(shim_state *s) { /* a failed device call ends the st
  * answer EB_ErrorMax) instead of going on with a group that is half processed */
 static EbErrorType stream_fail(shim_state *s, const char *why) {
     fprintf(stderr, "SvtVp9Enc (GPU hot path): %s\n", why);
-    s->failed = 1;
+    SET_FAILED(s);
     return EB_ErrorBadParameter;
 }
 
@@ -851,7 +857,7 @@ static EbErrorType encode_intra(shim_state *s, shim_dev *d, shim_slot *t) {
     t->coded = 1;
     if (s->cfg.recon_file) {
         shim_recon *r = reserve_recon(s, d, t->number);
-        if (!r) return s->failed ? EB_ErrorMax : EB_ErrorInsufficientResources;
+        if (!r) return FAILED(s) ? EB_ErrorMax : EB_ErrorInsufficientResources;
         return fill_recon(s, d, t, cx, r);
     }
     return EB_ErrorNone;
@@ -924,7 +930,7 @@ static EbErrorType plan_group(shim_state *s, int cut_by_intra, int end_of_stream
             for (int i = 0; i < n; i++)
                 if (jobs[i].wave == w) {
                     G->rec[i] = reserve_recon(s, d, jobs[i].number);
-                    if (!G->rec[i]) return s->failed ? EB_ErrorMax : EB_ErrorInsufficientResources;
+                    if (!G->rec[i]) return FAILED(s) ? EB_ErrorMax : EB_ErrorInsufficientResources;
                 }
     return EB_ErrorNone;
 }
@@ -1068,7 +1074,7 @@ static EbErrorType dev_join(shim_state *s, shim_dev *d) {
     d->job_result = (int)EB_ErrorNone;
     pthread_mutex_unlock(&d->mu);
     d->outstanding = 0;
-    if (e != EB_ErrorNone) { s->failed = 1; return e; }
+    if (e != EB_ErrorNone) { SET_FAILED(s); return e; }
     return EB_ErrorNone;
 }
 static EbErrorType join_all(shim_state *s) {
@@ -1104,7 +1110,7 @@ static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_str
     shim_dev *d = &s->dev[s->cur_dev];
     { const EbErrorType e = dev_join(s, d); if (e != EB_ErrorNone) return e; } /* one group per device at a time */
     shim_group *G = &d->group;
-    { const EbErrorType e = plan_group(s, cut_by_intra, end_of_stream, G); if (e != EB_ErrorNone) { s->failed = 1; return e; } }
+    { const EbErrorType e = plan_group(s, cut_by_intra, end_of_stream, G); if (e != EB_ErrorNone) { SET_FAILED(s); return e; } }
     s->last_base = G->last;
     s->pending = 0;
     /* a regular group goes to the device's feeder; what the caller follows up at once (the intra picture behind a cut group, the
@@ -1117,7 +1123,7 @@ static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_str
         d->outstanding = 1;
         return EB_ErrorNone;
     }
-    { const EbErrorType e = run_group(s, G); if (e != EB_ErrorNone) { s->failed = 1; return e; } }
+    { const EbErrorType e = run_group(s, G); if (e != EB_ErrorNone) { SET_FAILED(s); return e; } }
     if (s->split_gop && !cut_by_intra && !end_of_stream) { /* the next mini-GOP of this GOP goes to the next device */
         const int next = (s->cur_dev + 1) % s->n_dev;
         const EbErrorType e = handoff_base(s, d, &s->dev[next], s->last_base);
@@ -1130,7 +1136,7 @@ static EbErrorType flush_pending(shim_state *s, int cut_by_intra, int end_of_str
 EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *b) {
     shim_state *s = state_of(h);
     if (!s || !s->initialised) return EB_ErrorBadParameter;
-    if (s->failed) return EB_ErrorMax;
+    if (FAILED(s)) return EB_ErrorMax;
     if (s->eos) return EB_ErrorBadParameter;
     const int end = !b || !b->p_buffer || (b->flags & EB_BUFFERFLAG_EOS);
     EbErrorType e = EB_ErrorNone;
@@ -1249,7 +1255,7 @@ EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *
 EbErrorType eb_vp9_svt_get_packet(EbComponentType *h, EbBufferHeaderType **p_buffer, uint8_t pic_send_done) {
     shim_state *s = state_of(h);
     if (!s || !p_buffer) return EB_ErrorBadParameter;
-    if (s->failed) return EB_ErrorMax;
+    if (FAILED(s)) return EB_ErrorMax;
     shim_packet *p = s->q_head;
     if (!p) return EB_NoErrorEmptyQueue;
     /* the newest packet stays in the queue until the library knows whether it is the last one (it then carries EB_BUFFERFLAG_EOS): the
@@ -1291,7 +1297,7 @@ EbErrorType eb_vp9_svt_get_recon(EbComponentType *h, EbBufferHeaderType *p_buffe
     shim_state *s = state_of(h);
     if (!s) return EB_ErrorBadParameter;
     if (!s->cfg.recon_file) return EB_ErrorMax; /* recon is not enabled */
-    if (s->failed) return EB_ErrorMax;
+    if (FAILED(s)) return EB_ErrorMax;
     shim_recon *r = s->r_head;
     if (!r || !p_buffer) return EB_NoErrorEmptyQueue;
     if (r == s->r_tail && !s->eos) return EB_NoErrorEmptyQueue; /* as for packets: the last reconstruction carries EB_BUFFERFLAG_EOS */
