@@ -11,7 +11,7 @@
  *       quantisation / reconstruction, deblocking and reference padding (which of the last three a picture gets is the
  *       reference's rule: svt_hip_encdec_flags_derive).  recon = 1: recon_file is set and every reconstructed picture is fetched
  *       with eb_vp9_svt_get_recon (12.4 MB per 4K picture back over PCIe), as the reference's application does with -o.
- *   prints one line: {"frames": N, "seconds": T, "frames_per_s": F, "packets": P, "me_launches": L, "recon": R, "recon_pictures": K}
+ *   prints one line: {"frames": N, "seconds": T, "frames_per_s": F, "packets": P, "me_launches": L, "recon": R, "recon_pictures": K, "drain_seconds": D}
  *   exit 3 = no GPU (init_encoder refused: the library has no CPU path)
  */
 #define _POSIX_C_SOURCE 200809L
@@ -53,6 +53,7 @@ int main(int argc, char **argv) {
     if (ie != EB_ErrorNone) return 7;
 
     int          packets = 0, eos = 0, recons = 0, recon_eos = 0;
+    double       t_last_sent = 0.0; /* when the last send_picture returned: what follows is the drain (the last group's ME + its layers) */
     const double t0 = now_s();
     for (int n = 0; n < N; n++) {
         EbSvtEncInput in;
@@ -64,6 +65,7 @@ int main(int argc, char **argv) {
         b.size = sizeof b; b.p_buffer = (uint8_t *)&in; b.n_filled_len = (uint32_t)(ysz + ysz / 2); b.pts = n;
         b.flags = n == N - 1 ? EB_BUFFERFLAG_EOS : 0;
         if (eb_vp9_svt_enc_send_picture(h, &b) != EB_ErrorNone) return 11;
+        if (n == N - 1) t_last_sent = now_s();
         for (;;) {
             EbBufferHeaderType *p = NULL;
             const EbErrorType   e = eb_vp9_svt_get_packet(h, &p, (uint8_t)(n == N - 1));
@@ -88,8 +90,8 @@ int main(int argc, char **argv) {
     uint64_t     launches = 0, sent = 0;
     (void)svt_vp9_shim_get_counters(h, &launches, &sent);
     if (!eos || packets != N || (want_recon && recons != N)) { fprintf(stderr, "packets %d of %d, eos %d, reconstructions %d\n", packets, N, eos, recons); return 13; }
-    printf("{\"frames\": %d, \"seconds\": %.6f, \"frames_per_s\": %.2f, \"packets\": %d, \"me_launches\": %llu, \"recon\": %d, \"recon_pictures\": %d}\n", N,
-           t1 - t0, N / (t1 - t0), packets, (unsigned long long)launches, want_recon, recons);
+    printf("{\"frames\": %d, \"seconds\": %.6f, \"frames_per_s\": %.2f, \"packets\": %d, \"me_launches\": %llu, \"recon\": %d, \"recon_pictures\": %d, \"drain_seconds\": %.6f}\n", N,
+           t1 - t0, N / (t1 - t0), packets, (unsigned long long)launches, want_recon, recons, t1 - t_last_sent);
     eb_vp9_deinit_encoder(h);
     eb_vp9_deinit_handle(h);
     free(clip);

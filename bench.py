@@ -220,23 +220,32 @@ def api_path_rate(frames, Wd, Hd, enc_mode, tune, n_send=130):
                 f.write(y.tobytes())
                 f.write((y[::2, ::2] // 2 + 32).astype(np.uint8).tobytes())     # SURVEY 8(d)'s clip: U = Y / 2 + 32, V = 128
                 f.write(np.full((Hd // 2, Wd // 2), 128, np.uint8).tobytes())
+        def run_best(args, reps):
+            """best of `reps` runs (a 130-picture run lasts 40 ms: one preempted copy thread shows); None + the error text when a run fails"""
+            best, err = None, None
+            for _ in range(reps):
+                r = subprocess.run([exe, path, str(Wd), str(Hd), str(len(frames))] + args, capture_output=True, text=True)
+                if r.returncode != 0:
+                    err = f"svt_enc_api_bench rc={r.returncode}: {(r.stdout + r.stderr).strip()[-200:]}"
+                    break
+                d_ = json.loads(r.stdout.strip().splitlines()[-1])
+                if best is None or d_["frames_per_s"] > best["frames_per_s"]:
+                    best = d_
+            return best, err
         for recon in (0, 1):
-            r = subprocess.run([exe, path, str(Wd), str(Hd), str(len(frames)), str(n_send), str(enc_mode), str(tune), str(recon)], capture_output=True, text=True)
-            if r.returncode != 0:
-                return {"error": f"svt_enc_api_bench rc={r.returncode}: {(r.stdout + r.stderr).strip()[-200:]}"}
-            d = json.loads(r.stdout.strip().splitlines()[-1])
+            d, err = run_best([str(n_send), str(enc_mode), str(tune), str(recon)], 3)
+            if d is None:
+                return {"error": err}
             out["with_recon_output" if recon else "default"] = {"value": d["frames_per_s"], "frames": d["frames"], "seconds": d["seconds"], "me_launches": d["me_launches"],
                                                                 "mpixels_per_s": round(d["frames_per_s"] * Wd * Hd / 1e6, 1), "recon_pictures": d["recon_pictures"]}
         # the N-device host shape on ONE GPU: two contexts (two picture rings, two sets of streams, two feeder threads) take the closed GOPs
         # by turns -- exercises what `SVT_HIP_DEVICES=a,b` runs on a multi-GPU node; no scaling claim (one GPU's worth of compute and link)
-        r = subprocess.run([exe, path, str(Wd), str(Hd), str(len(frames)), str(n_send), str(enc_mode), str(tune), "0", "0,0"], capture_output=True, text=True)
-        two = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+        two, _ = run_best([str(n_send), str(enc_mode), str(tune), "0", "0,0"], 3)
         # the same path over 600 pictures (10 s of video: fill and drain, ~12 ms, no longer weigh) -- with and without the reconstructions fetched
         long_run = {}
         for recon in (0, 1):
-            r = subprocess.run([exe, path, str(Wd), str(Hd), str(len(frames)), "600", str(enc_mode), str(tune), str(recon)], capture_output=True, text=True)
-            if r.returncode == 0:
-                d = json.loads(r.stdout.strip().splitlines()[-1])
+            d, _ = run_best(["600", str(enc_mode), str(tune), str(recon)], 2)
+            if d is not None:
                 long_run["with_recon_output" if recon else "default"] = {"value": d["frames_per_s"], "frames": d["frames"], "seconds": d["seconds"]}
     d0 = out["default"]
     return {"value": d0["value"], "unit": "frames/s", "frames": d0["frames"], "seconds": d0["seconds"], "me_launches": d0["me_launches"], "mpixels_per_s": d0["mpixels_per_s"],
@@ -247,7 +256,7 @@ def api_path_rate(frames, Wd, Hd, enc_mode, tune, n_send=130):
                                      if two else None),
             "stages": ["pa", "me", "me_stats", "md_stand_in", "mc", "lists", "tq", "skip", "masks+lf", "pad"],
             "what": f"{Wd}x{Hd} -enc-mode {enc_mode} -tune {tune} -q 40, {d0['frames']} pictures through eb_vp9_svt_enc_send_picture / eb_vp9_svt_get_packet "
-                    "(app/svt_enc_api_bench.c): first send_picture -> EOS packet, host buffers in (Y, Cb, Cr), PCIe included; every stage of the path behind the "
+                    "(app/svt_enc_api_bench.c; best of three runs, two for the 600-picture ones): first send_picture -> EOS packet, host buffers in (Y, Cb, Cr), PCIe included; every stage of the path behind the "
                     "API, one mini-GOP at a time (uploads + picture analysis on an input stream, reconstruction copies on an output stream, beside the main stream), the stage flags per picture as the reference derives them (recon_file = 0: deblocking on base-layer pictures "
                     "only, no reconstruction of the deepest layer; with_recon_output: recon_file = 1, all pictures reconstructed + deblocked and fetched with "
                     "eb_vp9_svt_get_recon); zero-byte packets (no entropy coding); picture 0 is a key frame coded by the intra encode pass (svt_hip_encdec_intra_device, stand-in decision: 16x16 DC), ~4.3 ms of the run; value_600_pictures / long_run: the same over 600 pictures -- the host -> device link bounds it (DESIGN.md section 7)"}
@@ -451,6 +460,17 @@ def main():
     n_layers = LEVELS + 1
     G = max(1, args.gops)
     n_groups = max(1, min(args.groups, G))
+    # The public-API leg (and the intra-pass timing) are separate PROCESSES on the same GPU: they run first, before this process owns a single
+    # stream -- with its ~dozen hardware queues alive beside the caller's (torch keeps a stream pool for the life of the process) the 40 ms runs
+    # came out 10-25 % lower and noisy (2 500-3 200 against 3 150-3 190 alone, tools/r06_api.py).
+    early_legs = {}
+    if not args.no_extras and rank == 0 and world == 1 and ((Wd, Hd) == (W4K, H4K) or os.environ.get("SVT_BENCH_API_PATH")):
+        api = api_path_rate(T.gen_clip(Wd, Hd, MINIGOP + 1, seed=GS.gop_seed(11, 0)), Wd, Hd, enc_mode, tune)   # (GOP 0's pictures, as frames0 below)
+        if api is not None:
+            early_legs["api_path"] = api
+        ip = intra_pass_times()
+        if ip is not None:
+            early_legs["intra_pass"] = ip
     t_setup0 = time.perf_counter()
 
     # streams: ME (+ a second ME stream: ME of different pictures is independent, the tail of one launch is filled by the other),
@@ -1274,11 +1294,12 @@ def main():
                      f"would need {fps * pic_bytes / 1e9:.0f} GB/s of host-to-device traffic if every picture crossed PCIe (gen5 x16 sustains ~50): the "
                      "PCIe-inclusive rate of the public-API path is `api_path` (app/svt_enc_api_bench.c, DESIGN.md section 7)",
     }
+    cpu_inputs = None
     if not args.no_cpu_baseline and world == 1:   # the CPU leg runs at N = 1 only (rank 0's host cores are not shared with other ranks)
         lfm0 = {i: np.frombuffer(d_lfm[0, i - 1].cpu().numpy(), dtype=B.LF_MASK_DTYPE).reshape(sb_rows, sb_cols).copy() for i in range(1, MINIGOP + 1)}
         lf0 = {i: d_lf[0][i].cpu().numpy().view(B.LF_MODE_INFO_DTYPE).reshape(mi_rows, mi_cols).copy() for i in range(1, MINIGOP + 1)}   # with the skip flags
         ref_inputs = {"pred": d_pred[0, MINIGOP // 4 - 1].cpu().numpy(), "kcell": kcell[0][MINIGOP // 4], "level": level}
-        out["cpu_baseline"] = cpu_baseline(T, B, frames0, src0, mc_host0, lf0, lfm0, Wd, Hd, enc_mode, tune, l1_on, ref_inputs)
+        cpu_inputs = (lf0, lfm0, ref_inputs)   # (the leg itself runs last: its processes would share the host's cores with the public-API run below)
     for grp in P_main["groups"] + (P_single["groups"] if P_single else []) + (P_ref["groups"] if P_ref else []) + (P_inter["groups"] if P_inter else []):
         lib.svt_hip_encdec_work_destroy(grp["ctx"], grp["work"])
         if grp["kres"]:
@@ -1286,16 +1307,13 @@ def main():
     for c_ in ctxs:
         lib.svt_hip_ctx_destroy(c_)
     ctxs.clear()
-    if extras and world == 1 and ((Wd, Hd) == (W4K, H4K) or os.environ.get("SVT_BENCH_API_PATH")):
-        torch.cuda.synchronize()
-        del keep[:]
-        torch.cuda.empty_cache()
-        api = api_path_rate(frames0, Wd, Hd, enc_mode, tune)
-        if api is not None:
-            out["api_path"] = api
-        ip = intra_pass_times()
-        if ip is not None:
-            out["intra_pass"] = ip
+    torch.cuda.synchronize()
+    del keep[:]
+    torch.cuda.empty_cache()
+    out.update(early_legs)
+    if cpu_inputs is not None:
+        lf0, lfm0, ref_inputs = cpu_inputs
+        out["cpu_baseline"] = cpu_baseline(T, B, frames0, src0, mc_host0, lf0, lfm0, Wd, Hd, enc_mode, tune, l1_on, ref_inputs)
     print(json.dumps(out))
 
 
