@@ -680,13 +680,13 @@ template <int SPEC> __device__ __forceinline__ void me_sb_run_fast(const me_ctx_
                     ME_PHASE(ph_fullpel_argmin(c, tid, U, saw, y0, ny));
                 }
             }
-            ME_PHASE(fph_decode_gate(c, tid, list, saw, sox, soy));
+            /* (the interpolation of the half-pel planes reads the region alone: it shares the phase -- and the barrier -- of the key decode) */
+            ME_PHASE(fph_decode_gate(c, tid, list, saw, sox, soy); ph_interp_strips(c, tid, W, H));
         }
         FME_MARK(7);
         const uint32_t gate = (uint32_t)ME_UNI(*FME_GATE(st));
         const int      en32 = (int)(gate & 1u), en16 = (int)((gate >> 1) & 1u);
         FME_MARK(8);
-        ME_PHASE(ph_interp_strips(c, tid, W, H));
         FME_MARK(9);
         /* SUB_SAD refinement of the 32x32 / 16x16 PUs, both decisions and every level of the bi-prediction: one phase */
         const int fast_bi = nlist == 2;
