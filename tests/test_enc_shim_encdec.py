@@ -347,6 +347,23 @@ def test_several_contexts_give_the_same_reconstruction(env, N, intra_period):
         assert np.array_equal(recon[k], np.concatenate([y.ravel(), u.ravel(), v.ravel()])), k
 
 
+def test_warm_up_encoder_leaves_the_stream_alone():
+    """eb_vp9_init_encoder runs a throw-away encoder on a small picture so that the first send_picture does not pay for code loading
+    (SVT_HIP_WARMUP=0: off).  The real stream must not see it: same reconstructions, same delivery, same coded pictures."""
+    W, H, N, enc_mode, tune, qp, intra_period = 256, 192, 36, 8, 1, 40, 19
+    on = run_clip(W, H, N, enc_mode, tune, qp, 1, intra_period, False)
+    off = run_clip(W, H, N, enc_mode, tune, qp, 1, intra_period, False, env={"SVT_HIP_WARMUP": "0"})
+    for run in (on, off):
+        _, recon, order, flags_seen, packets = run[:5]
+        assert sorted(order) == list(range(N)) and len(packets) == N and packets[-1][1] & 1 and flags_seen[-1] == 1
+    assert on[2] == off[2]
+    for k in range(N):
+        assert np.array_equal(on[1][k], off[1][k]), k
+    for k in on[6]:   # the padded reference pictures and the coded pictures the library still holds at the end
+        assert np.array_equal(on[6][k], off[6][k]), k
+        assert np.array_equal(on[5][k]["q"], off[5][k]["q"]) and np.array_equal(on[5][k]["em"], off[5][k]["em"]), k
+
+
 def test_eight_contexts_c4_shaped_clip_equals_one_context():
     """BASELINE configuration C4's host shape on one GPU (SURVEY section 7's determinism contract at C4's real GOP count): 520 pictures =
     8 closed GOPs of 65 (-intra-period 64), dealt to EIGHT contexts (`SVT_HIP_DEVICES=0,0,0,0,0,0,0,0`: GOP g on device g mod 8, each with

@@ -69,6 +69,9 @@ def test_me_c5_non_reference_layer_two_launches_at_4k(ctx):
     g, _ = hip_me_picture(ctx, pics[1], pics[0], pics[2], p)
     assert not T.me_results_equal(o, g, 2)
     assert len(np.unique(g["x_mv_l0"])) > 8
+    lib = B.load()
+    lib.svt_hip_me_last_instance.argtypes = [C.c_void_p]
+    assert lib.svt_hip_me_last_instance(ctx) in (204, 205)   # a specialised instance, + 200: the compact layout's pair of launches
 
 
 def test_me_specialised_and_generic_instances_agree_at_4k():
