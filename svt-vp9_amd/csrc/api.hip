@@ -52,6 +52,17 @@ static int32_t ctx_create(svt_hip_ctx **out, int32_t device, void *stream, int o
     /* on failure release whatever exists: events are created null-checked, destroy tolerates the missing ones */
     bool ok = hipEventCreate(&c->ev_start) == hipSuccess && hipEventCreate(&c->ev_stop) == hipSuccess;
     for (int i = 0; ok && i < SVT_CTX_RING; i++) ok = hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming) == hipSuccess;
+    if (ok) { /* the staging ring's buffers in two slabs (svt_ctx_stage grows an entry that needs more than its share) */
+        const size_t unit = 65536;
+        if (hipHostMalloc(&c->ring_slab_host, unit * SVT_CTX_RING, hipHostMallocDefault) == hipSuccess && hipMalloc(&c->ring_slab_dev, unit * SVT_CTX_RING) == hipSuccess)
+            for (int i = 0; i < SVT_CTX_RING; i++) {
+                c->ring_host[i] = (uint8_t *)c->ring_slab_host + unit * i; c->ring_dev[i] = (uint8_t *)c->ring_slab_dev + unit * i; c->ring_bytes[i] = unit;
+            }
+        else { /* (not fatal: the entries allocate on demand) */
+            if (c->ring_slab_host) (void)hipHostFree(c->ring_slab_host);
+            c->ring_slab_host = nullptr; c->ring_slab_dev = nullptr;
+        }
+    }
     if (!ok) {
         svt_hip_ctx_destroy(c);
         return svt_set_error(SVT_HIP_ERR_DEVICE, "ctx: events");
@@ -82,10 +93,14 @@ extern "C" void svt_hip_ctx_destroy(svt_hip_ctx *c) {
     if (c->stream || !c->owns_stream) (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < SVT_CTX_SLOTS; i++) if (c->slot[i]) (void)hipFree(c->slot[i]);
     for (int i = 0; i < SVT_CTX_RING; i++) {
-        if (c->ring_dev[i]) (void)hipFree(c->ring_dev[i]);
-        if (c->ring_host[i]) (void)hipHostFree(c->ring_host[i]);
+        if (c->ring_own[i]) {
+            if (c->ring_dev[i]) (void)hipFree(c->ring_dev[i]);
+            if (c->ring_host[i]) (void)hipHostFree(c->ring_host[i]);
+        }
         if (c->ring_ev[i]) (void)hipEventDestroy(c->ring_ev[i]);
     }
+    if (c->ring_slab_dev) (void)hipFree(c->ring_slab_dev);
+    if (c->ring_slab_host) (void)hipHostFree(c->ring_slab_host);
     for (int i = 0; i < SVT_CTX_UPLOAD_RING; i++) {
         if (c->up_host[i]) (void)hipHostFree(c->up_host[i]);
         if (c->up_ev[i]) (void)hipEventDestroy(c->up_ev[i]);
@@ -135,9 +150,11 @@ int svt_ctx_stage(svt_hip_ctx *c, size_t bytes, void **host, void **dev) {
     const int s = c->ring_pos;
     if (c->ring_used[s]) { if (hipEventSynchronize(c->ring_ev[s]) != hipSuccess) return -1; c->ring_used[s] = 0; }
     if (bytes > c->ring_bytes[s]) {
-        if (c->ring_host[s]) (void)hipHostFree(c->ring_host[s]);
-        if (c->ring_dev[s]) (void)hipFree(c->ring_dev[s]);
-        c->ring_host[s] = nullptr; c->ring_dev[s] = nullptr; c->ring_bytes[s] = 0;
+        if (c->ring_own[s]) { /* (an entry inside the slabs owns nothing) */
+            if (c->ring_host[s]) (void)hipHostFree(c->ring_host[s]);
+            if (c->ring_dev[s]) (void)hipFree(c->ring_dev[s]);
+        }
+        c->ring_host[s] = nullptr; c->ring_dev[s] = nullptr; c->ring_bytes[s] = 0; c->ring_own[s] = 1;
         size_t cap = bytes < 65536 ? 65536 : bytes * 2;
         if (hipHostMalloc(&c->ring_host[s], cap, hipHostMallocDefault) != hipSuccess) return -1;
         if (hipMalloc(&c->ring_dev[s], cap) != hipSuccess) return -1;

@@ -27,6 +27,9 @@ struct svt_hip_ctx {
     size_t      ring_bytes[SVT_CTX_RING];
     hipEvent_t  ring_ev[SVT_CTX_RING];
     int         ring_used[SVT_CTX_RING];
+    int         ring_own[SVT_CTX_RING];   /* 1: the entry outgrew its share of the slabs below and owns its buffers */
+    void       *ring_slab_host, *ring_slab_dev; /* SVT_CTX_RING x 64 KB, taken when the context is created (an entry used to take its buffers the
+                                                   first time round the ring: 64 pairs of allocations inside the first pictures of a stream) */
     int         ring_pos;
     /* helper streams for entry points whose kernels are independent of each other (the four transform sizes of a TQ batch):
        forked from / joined into `stream` with events, so the call still behaves as one operation on the context's stream */
