@@ -177,6 +177,12 @@ int32_t svt_hip_me_last_instance(const svt_hip_ctx *ctx);
  * that hosts one of its waves has registers for one motion-estimation workgroup less (128: 7.9 ms alone, +2 % for the pipelined step of
  * bench.py).  The environment's SVT_HIP_INTRA_WGS sets the process-wide default. */
 int32_t svt_hip_ctx_set_intra_workgroups(svt_hip_ctx *ctx, int32_t n);
+/* submits an empty kernel to the context's stream and waits: the stream's hardware queue exists afterwards (the runtime creates it at the first
+ * submission, 1-3 ms on the submitting thread).  For hosts that time a stream from its first picture (the encoder library's init does this). */
+int32_t svt_hip_ctx_warm(svt_hip_ctx *ctx);
+/* the same with a kernel that has a private segment of (at least) scratch_bytes per lane, up to 1024: the queue's scratch memory is sized too (the
+ * intra pass's kernel needs 752 bytes per lane -- 4 ms on the thread that submits it first; the 32x32 transform 130) */
+int32_t svt_hip_ctx_warm_scratch(svt_hip_ctx *ctx, int32_t scratch_bytes);
 /* 1 when two parameter sets may share one launch of svt_hip_me_batch_layers_device: equal in every field but num_ref_lists,
  * temporal_layer_index, hierarchical_levels and same_ref_poc (compared field by field: the record has padding) */
 int32_t svt_hip_me_params_same_launch(const svt_me_params *a, const svt_me_params *b);
@@ -537,6 +543,10 @@ typedef struct svt_yuv_planes {
     int32_t  y_stride, uv_stride;
     int32_t  width, height; /* luma dimensions (multiples of 8) */
 } svt_yuv_planes;
+
+/* Takes the context's per-SB edge-descriptor buffer (1 280 bytes per SB) for launches of up to n_pics pictures now: it grows on demand, but growing
+ * waits for the context's stream.  The encoder library calls this when it is initialised. */
+int32_t svt_hip_lf_reserve(svt_hip_ctx *ctx, int32_t n_pics, int32_t mi_rows, int32_t mi_cols);
 
 /* = eb_vp9_loop_filter_frame(frame, cm, xd, lfm_base, filter_level, y_only=0, partial=0)
  * (VPX/vp9_loopfilter.c:1521-1546 -> loop_filter_rows :1456).  lfm: one mask per SB in raster order

@@ -78,6 +78,33 @@ extern "C" int32_t svt_hip_ctx_create_cu_mask(svt_hip_ctx **ctx, int32_t device,
     return ctx_create(ctx, device, nullptr, 1, cu_mask, mask_words);
 }
 extern "C" void *svt_hip_ctx_stream(svt_hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+/* Make the context's stream real before a clock starts: the runtime creates a stream's hardware queue the first time work is submitted
+ * to it, and sizes the queue's scratch memory the first time a kernel with a private segment runs on it -- for the intra pass's kernel
+ * (752 bytes per lane: ~400 MB for a device's worth of waves) that was 4 ms on the thread that sent the first key frame.  scratch_bytes: the
+ * largest private segment (per lane) of the kernels the stream will run; 0: none. */
+template <int WORDS> __global__ void svt_ctx_warm_kernel(uint32_t *p, int n) {
+    if constexpr (WORDS > 0) {
+        volatile uint32_t a[WORDS];
+        uint32_t          acc = 0;
+        for (int i = 0; i < n && i < WORDS; i++) a[i] = (uint32_t)(i * n);
+        for (int i = 0; i < n; i++) acc += a[(i * 7) % WORDS];
+        if (p && n > 0) *p = acc;
+    } else if (p && n > 0) *p = 0;
+}
+extern "C" int32_t svt_hip_ctx_warm_scratch(svt_hip_ctx *c, int32_t scratch_bytes) {
+    if (!c || scratch_bytes < 0) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "ctx_warm: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t *p = (uint32_t *)c->ring_slab_dev;
+    /* (a grid that fills the device: the runtime sizes a queue's scratch by the dispatch that asks for it) */
+    const dim3 grid((unsigned)(c->cu_count > 0 ? c->cu_count * 8 : 2048));
+    if (scratch_bytes == 0) hipLaunchKernelGGL(svt_ctx_warm_kernel<0>, dim3(1), dim3(64), 0, c->stream, p, 0);
+    else if (scratch_bytes <= 256) hipLaunchKernelGGL(svt_ctx_warm_kernel<64>, grid, dim3(64), 0, c->stream, p, 0);
+    else hipLaunchKernelGGL(svt_ctx_warm_kernel<256>, grid, dim3(64), 0, c->stream, p, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SVT_HIP_OK;
+}
+extern "C" int32_t svt_hip_ctx_warm(svt_hip_ctx *c) { return svt_hip_ctx_warm_scratch(c, 0); }
 extern "C" int32_t svt_hip_ctx_set_intra_workgroups(svt_hip_ctx *c, int32_t n) {
     if (!c || n < 0) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "ctx: intra workgroups");
     c->intra_wgs = n;

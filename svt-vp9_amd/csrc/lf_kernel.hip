@@ -694,6 +694,17 @@ static int32_t lf_launch(svt_hip_ctx *ctx, int n_pics, const svt_yuv_planes *d_r
     return SVT_HIP_OK;
 }
 
+/* Takes the context's edge-descriptor buffer for launches of up to n_pics pictures of mi_rows x mi_cols now.  The buffer grows on demand, but
+ * growing it waits for the context's stream -- behind the public API that was the first key frame's whole intra pass (4 ms) on the thread that
+ * sent the picture, and a stall of the first deblocking launches of every new batch size. */
+extern "C" int32_t svt_hip_lf_reserve(svt_hip_ctx *ctx, int32_t n_pics, int32_t mi_rows, int32_t mi_cols) {
+    if (!ctx || n_pics < 1 || mi_rows < 1 || mi_cols < 1) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "lf_reserve: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t rows = (size_t)(mi_rows + 7) / 8, cols = (size_t)(mi_cols + 7) / 8;
+    if (!svt_ctx_slot(ctx, 24, (size_t)n_pics * rows * cols * LF_DESC_WORDS * sizeof(uint32_t))) return svt_set_error(SVT_HIP_ERR_NO_RESOURCES, "lf: descriptor buffer");
+    return SVT_HIP_OK;
+}
+
 extern "C" int32_t svt_hip_lf_frame_device(svt_hip_ctx *ctx, const svt_yuv_planes *d_recon, const svt_lf_mask *d_lfm, int32_t lfm_stride,
                                            const svt_lf_thresh *thr, int32_t mi_rows, int32_t mi_cols, int32_t y_only) {
     if (!ctx || !d_recon || !d_lfm || !thr) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "lf: null argument");

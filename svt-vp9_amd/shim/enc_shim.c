@@ -473,6 +473,14 @@ static int alloc_dev(shim_state *s, shim_dev *d) {
             (void)svt_hip_ctx_synchronize(d->ctx_up);
             free(z);
         }
+        /* ... and every stream's hardware queue (created by the runtime at the first submission) */
+        svt_hip_ctx *all[6] = {d->ctx, d->ctx_in, d->ctx_up, d->ctx_out, d->ctx_key, d->ctx_deep};
+        const int    scr[6] = {1024, 0, 0, 0, 1024, 256}; /* private segments: the intra pass's kernel (key context; main context: intra blocks of inter pictures), the 32x32 transform */
+        for (int i = 0; i < 6; i++) if (all[i]) (void)svt_hip_ctx_warm_scratch(all[i], scr[i]);
+        /* ... and the deblocking launches' descriptor buffers at their largest (growing one waits for its stream: the first key frame's intra pass) */
+        (void)svt_hip_lf_reserve(d->ctx, SHIM_WAVE_MAX, s->mi_rows, s->mi_cols);
+        if (d->ctx_key && d->ctx_key != d->ctx) (void)svt_hip_lf_reserve(d->ctx_key, 1, s->mi_rows, s->mi_cols);
+        if (d->ctx_deep && d->ctx_deep != d->ctx) (void)svt_hip_lf_reserve(d->ctx_deep, SHIM_WAVE_MAX, s->mi_rows, s->mi_cols);
     }
     return ok;
 }
@@ -560,7 +568,7 @@ EbErrorType eb_vp9_init_encoder(EbComponentType *h) {
         const int   want = ff ? atoi(ff) != 0 : 1;
         s->use_feeder = want && !(nf && atoi(nf) != 0) && !(one && atoi(one) != 0) && !s->md_cb && !s->split_gop;
     }
-    { const char *pf = getenv("SVT_HIP_SHIM_PROFILE"); s->profile = pf && atoi(pf) != 0; memset(s->prof_s, 0, sizeof s->prof_s); }
+    { const char *pf = getenv("SVT_HIP_SHIM_PROFILE"); s->profile = pf ? atoi(pf) : 0; memset(s->prof_s, 0, sizeof s->prof_s); }
     for (int i = 0; i < n; i++) feeder_start(s, &s->dev[i]);
     if (s->md_cb) {
         s->h_results = malloc((size_t)s->n_sb * 85 * sizeof(svt_me_pu_result));
@@ -917,14 +925,18 @@ static EbErrorType encode_intra(shim_state *s, shim_dev *d, shim_slot *t) {
             t->info.decision_source = 1;
         }
     }
+    const double tk0 = s->profile > 1 ? now_s() : 0.0;
     if (!decided) GPU_TRY(svt_hip_md_intra_default_device(cx, s->W, s->H, level, (svt_lf_mode_info *)t->d_lf_mi, s->mi_cols));
+    const double tk1 = s->profile > 1 ? now_s() : 0.0;
     GPU_TRY(svt_hip_mem_set(cx, t->d_mc_mi, 0, (size_t)s->mi_rows * s->mi_cols * sizeof(svt_mc_mode_info))); /* no motion in an intra picture */
+    const double tk2 = s->profile > 1 ? now_s() : 0.0;
     svt_encdec_picture p;
     memset(&p, 0, sizeof p);
     p.d_lf_mi = (svt_lf_mode_info *)t->d_lf_mi;
     p.src = tight_planes(s, t->d_src); p.pred = tight_planes(s, t->d_pred); p.recon = rec_planes(s, t->d_rec);
     p.d_qcoeff = t->d_qcoeff; p.d_dqcoeff = t->d_dqcoeff; p.d_eob_map = (uint16_t *)t->d_eob_map; p.d_lfm = (svt_lf_mask *)t->d_lfm; p.d_nz = (uint8_t *)t->d_nz;
     GPU_TRY(svt_hip_encdec_intra_device(cx, d->work_key, &p, s->W, s->H, s->mi_cols, s->q_index, &fl, &s->thr, SHIM_REF_PAD, SHIM_REF_PAD));
+    if (s->profile > 1) fprintf(stderr, "SvtVp9Enc key frame %lld: decision %.1f  memset %.1f  intra pass %.1f us\n", (long long)t->number, 1e6 * (tk1 - tk0), 1e6 * (tk2 - tk1), 1e6 * (now_s() - tk2));
     t->coded = 1;
     if (s->cfg.recon_file) {
         shim_recon *r = reserve_recon(s, d, t->number);
@@ -1295,6 +1307,7 @@ EbErrorType eb_vp9_svt_enc_send_picture(EbComponentType *h, EbBufferHeaderType *
             d->key_marker = t->marker; d->has_key = 1;
             if (!queue_packet(s, t->pts, 0, 2 /* EB_I_PICTURE */, s->cur_dev, d->ctx_key, t->marker, 1)) return EB_ErrorInsufficientResources;
             s->last_base = n;
+            if (s->profile > 1) fprintf(stderr, "SvtVp9Enc key frame %lld: %.1f us on the caller's thread\n", (long long)n, 1e6 * (now_s() - tp));
             PROF(4);
         } else {
             if (!s->pending) s->pending_first = n;
