@@ -152,6 +152,8 @@ typedef struct shim_dev {
        so the next group's motion estimation and shallow layers -- waves of 1, 1 and 2 pictures, bound by the deblocking wavefront's
        latency -- run beside them instead of behind them.  Opt-in (SVT_HIP_DEEP_STREAM=1), see eb_vp9_init_encoder; default: the main context. */
     svt_hip_ctx     *ctx_deep;
+    svt_hip_ctx     *ctx_me;         /* motion estimation + statistics of a group on a stream of their own (the next group's search runs beside this group's
+                                        layers): the default without reconstructed output, SVT_HIP_ME_STREAM=0 / 1 overrides; else the main context */
     svt_encdec_work *work_deep;
     /* a key frame's intra encode pass (a dependency wavefront over the picture: ~6 ms at 4K on a fraction of the device) runs on a context
        of its own: the motion estimation of the GOP's first group -- which reads the key frame's analysed planes, not its reconstruction --
@@ -397,6 +399,8 @@ static void free_dev(shim_state *s, shim_dev *d) {
     d->ctx_key = NULL;
     if (d->ctx_deep && d->ctx_deep != d->ctx) svt_hip_ctx_destroy(d->ctx_deep);
     d->ctx_deep = NULL;
+    if (d->ctx_me && d->ctx_me != d->ctx) svt_hip_ctx_destroy(d->ctx_me);
+    d->ctx_me = NULL;
     if (d->ctx_in && d->ctx_in != d->ctx) svt_hip_ctx_destroy(d->ctx_in);
     if (d->ctx_up && d->ctx_up != d->ctx && d->ctx_up != d->ctx_in) svt_hip_ctx_destroy(d->ctx_up);
     d->ctx_up = NULL;
@@ -474,9 +478,9 @@ static int alloc_dev(shim_state *s, shim_dev *d) {
             free(z);
         }
         /* ... and every stream's hardware queue (created by the runtime at the first submission) */
-        svt_hip_ctx *all[6] = {d->ctx, d->ctx_in, d->ctx_up, d->ctx_out, d->ctx_key, d->ctx_deep};
-        const int    scr[6] = {1024, 0, 0, 0, 1024, 256}; /* private segments: the intra pass's kernel (key context; main context: intra blocks of inter pictures), the 32x32 transform */
-        for (int i = 0; i < 6; i++) if (all[i]) (void)svt_hip_ctx_warm_scratch(all[i], scr[i]);
+        svt_hip_ctx *all[7] = {d->ctx, d->ctx_in, d->ctx_up, d->ctx_out, d->ctx_key, d->ctx_deep, d->ctx_me};
+        const int    scr[7] = {1024, 0, 0, 0, 1024, 256, 256}; /* private segments: the intra pass's kernel (key context; main context: intra blocks of inter pictures), the 32x32 transform */
+        for (int i = 0; i < 7; i++) if (all[i]) (void)svt_hip_ctx_warm_scratch(all[i], scr[i]);
         /* ... and the deblocking launches' descriptor buffers at their largest (growing one waits for its stream: the first key frame's intra pass) */
         (void)svt_hip_lf_reserve(d->ctx, SHIM_WAVE_MAX, s->mi_rows, s->mi_cols);
         if (d->ctx_key && d->ctx_key != d->ctx) (void)svt_hip_lf_reserve(d->ctx_key, 1, s->mi_rows, s->mi_cols);
@@ -547,6 +551,12 @@ EbErrorType eb_vp9_init_encoder(EbComponentType *h) {
             const char *dp = getenv("SVT_HIP_DEEP_STREAM");
             d->ctx_deep = d->ctx;
             if (ok && !(one && atoi(one) != 0) && dp && atoi(dp) != 0 && DEV_CTX_CREATE(ctx_deep) != SVT_HIP_OK) { d->ctx_deep = NULL; ok = 0; }
+            const char *ms = getenv("SVT_HIP_ME_STREAM");
+            d->ctx_me = d->ctx;
+            /* (on by default when no reconstruction is fetched: with the output stream as well the device's hardware queues are oversubscribed and the
+               rate drops -- 2160p enc-mode 3: 689 -> 859 pictures/s without reconstructions, 619 -> 561 with; enc-mode 8: unchanged / 1 515 -> 1 458) */
+            const int want_me = ms ? atoi(ms) != 0 : !s->cfg.recon_file;
+            if (ok && !(one && atoi(one) != 0) && want_me && !s->md_cb && DEV_CTX_CREATE(ctx_me) != SVT_HIP_OK) { d->ctx_me = NULL; ok = 0; }
             const char *nk = getenv("SVT_HIP_NO_KEY_STREAM");
             d->ctx_key = d->ctx;
             if (ok && !(one && atoi(one) != 0) && !(nk && atoi(nk) != 0) && !s->md_cb && DEV_CTX_CREATE(ctx_key) != SVT_HIP_OK) { d->ctx_key = NULL; ok = 0; }
@@ -1024,6 +1034,8 @@ static EbErrorType run_group(shim_state *s, shim_group *G) {
     const int       n = G->n, n_waves = G->n_waves, end_of_stream = G->end_of_stream;
     /* everything enqueued on the main context from here on sees the group's pictures uploaded and analysed */
     if (G->has_in && d->ctx_in != d->ctx) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx, d->ctx_in, G->in_marker));
+    svt_hip_ctx *const cm = (d->ctx_me && !s->split_gop) ? d->ctx_me : d->ctx; /* where the group's search runs */
+    if (cm != d->ctx && G->has_in && d->ctx_in != cm) GPU_TRY(svt_hip_ctx_wait_marker(cm, d->ctx_in, G->in_marker));
     /* launches: classes of pictures whose parameter sets may share one */
     int done[SHIM_MAX_MINIGOP] = {0};
     for (int i = 0; i < n; i++) {
@@ -1042,7 +1054,7 @@ static EbErrorType run_group(shim_state *s, shim_group *G) {
             done[k] = 1;
             m++;
         }
-        GPU_TRY(svt_hip_me_batch_layers_device(d->ctx, m, cur, r0, r1, pp, res, s->cfg.rate_control_mode ? rc : NULL));
+        GPU_TRY(svt_hip_me_batch_layers_device(cm, m, cur, r0, r1, pp, res, s->cfg.rate_control_mode ? rc : NULL));
         __atomic_add_fetch(&s->me_launches, 1, __ATOMIC_RELAXED);
     }
     /* the tail of the ME kernel process per picture (Codec/EbMotionEstimationProcess.c:1047-1237): stationary-edge flags and the
@@ -1055,8 +1067,8 @@ static EbErrorType run_group(shim_state *s, shim_group *G) {
         sp.pic_width = (int32_t)s->cfg.source_width; sp.pic_height = (int32_t)s->cfg.source_height; sp.input_resolution = res_class;
         sp.temporal_layer_index = jobs[i].layer; sp.slice_type = jobs[i].n_lists == 2 ? 0 : 1;
         sp.run_part2 = !end_of_stream; sp.rate_control_mode = (int32_t)s->cfg.rate_control_mode;
-        GPU_TRY(svt_hip_mem_set(d->ctx, t->d_hist, 0, (2 * SVT_SAD_INTERVALS + 1) * sizeof(uint32_t)));
-        GPU_TRY(svt_hip_me_sb_stats_device(d->ctx, &sp, (const svt_me_pu_result *)t->d_results, (const uint16_t *)t->d_var,
+        GPU_TRY(svt_hip_mem_set(cm, t->d_hist, 0, (2 * SVT_SAD_INTERVALS + 1) * sizeof(uint32_t)));
+        GPU_TRY(svt_hip_me_sb_stats_device(cm, &sp, (const svt_me_pu_result *)t->d_results, (const uint16_t *)t->d_var,
                                            s->cfg.rate_control_mode ? (const uint32_t *)t->d_rcme : NULL, (svt_me_sb_stats *)t->d_stats, (uint32_t *)t->d_hist,
                                            (uint32_t *)t->d_hist + 2 * SVT_SAD_INTERVALS));
         t->info.is_intra = 0; t->info.temporal_layer_index = jobs[i].layer; t->info.hierarchical_levels = jobs[i].levels;
@@ -1065,8 +1077,9 @@ static EbErrorType run_group(shim_state *s, shim_group *G) {
         t->info.device_ordinal = d->ordinal;
     }
     uint64_t me_marker = 0;
-    GPU_TRY(svt_hip_ctx_marker_record(d->ctx, &me_marker));
-    for (int i = 0; i < n; i++) { shim_slot *t = find_slot(d, jobs[i].number); t->processed = 1; t->has_marker = 1; t->marker = me_marker; t->marker_ctx = d->ctx; }
+    GPU_TRY(svt_hip_ctx_marker_record(cm, &me_marker));
+    for (int i = 0; i < n; i++) { shim_slot *t = find_slot(d, jobs[i].number); t->processed = 1; t->has_marker = 1; t->marker = me_marker; t->marker_ctx = cm; }
+    if (cm != d->ctx) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx, cm, me_marker)); /* the layers below read the search's results */
     /* the waves predict from the GOP's intra picture (directly or through pictures that did): behind its encode pass on the key context */
     if (G->has_key) GPU_TRY(svt_hip_ctx_wait_marker(d->ctx, d->ctx_key, G->key_marker));
     /* the stages behind mode decision, wave by wave (a wave = the pictures of one temporal layer of one part: their references
