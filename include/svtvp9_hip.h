@@ -171,6 +171,9 @@ int32_t svt_hip_me_kernel_instance(const svt_me_params *p);
  * driver for single-region level-0 HME presets (csrc/me_fast.h: whole SB columns, level-0 areas up to 256 x 256), + 200 when it was the pair of
  * launches of the compact LDS layout (csrc/me_layout.h: the 64 x 64-area presets at two workgroups per CU) */
 int32_t svt_hip_me_last_instance(const svt_hip_ctx *ctx);
+/* diagnostic (host only): LDS bytes of a workgroup of the ME kernel for a parameter set -- compact = 0: the plain layout; 1: the compact one (search-area
+ * widths that are multiples of 8; the launcher takes it where it buys a workgroup per CU: 160 KB per CU in granules of 1 280 bytes).  Negative: no such layout. */
+int32_t svt_hip_me_lds_bytes(const svt_me_params *p, int32_t compact);
 /* Deployment knob of the intra encode pass (svt_hip_encdec_intra_device, and the intra blocks of inter pictures) launched on ctx: at most n
  * one-wave workgroups (0 = the default: one per compute unit, the lowest latency for a key frame alone -- 6.5 ms at 2160p).  A pass that runs
  * BESIDE other work of the device (a key frame of the next GOP beside the current one) leaves more of it to that work with fewer: every CU

@@ -165,7 +165,7 @@ EXPORTS = [
     "svt_hip_encdec_batch_device", "svt_hip_encdec_intra_device", "svt_hip_md_intra_default_device", "svt_hip_encdec_work_status", "svt_hip_encdec_work_download", "svt_hip_md_default_batch_device",
     "svt_hip_md_default_picture", "svt_hip_lf_build_masks_device", "svt_hip_ctx_wait_marker", "svt_hip_host_alloc", "svt_hip_host_free",
     "svt_hip_mem_download_2d_async", "svt_hip_mem_copy_2d_device", "svt_hip_encdec_work_set_stage_hook", "svt_hip_me_params_same_launch", "svt_hip_me_kernel_instance", "svt_hip_ctx_set_intra_workgroups", "svt_hip_ctx_warm", "svt_hip_ctx_warm_scratch", "svt_hip_lf_reserve",
-    "svt_hip_me_last_instance", "svt_hip_vp9_layer_qindex", "svt_hip_mem_upload_2d_direct", "svt_hip_mem_upload_wait", "svt_hip_host_unregister_all", "svt_hip_host_registry_retain", "svt_hip_host_registry_release",
+    "svt_hip_me_last_instance", "svt_hip_me_lds_bytes", "svt_hip_vp9_layer_qindex", "svt_hip_mem_upload_2d_direct", "svt_hip_mem_upload_wait", "svt_hip_host_unregister_all", "svt_hip_host_registry_retain", "svt_hip_host_registry_release",
 ]
 
 _lib = None

@@ -300,6 +300,16 @@ static int32_t me_launch(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture 
 extern "C" int32_t svt_hip_me_kernel_instance(const svt_me_params *p) { return p ? me_spec_match(p) : -1; }
 /* the instance the last ME launch on this context actually ran: the me_spec.h index, + 100 when it was me_fast.h's driver */
 extern "C" int32_t svt_hip_me_last_instance(const svt_hip_ctx *ctx) { return ctx ? ctx->me_instance : -1; }
+/* diagnostic (host only, no device needed): LDS bytes of a workgroup of the ME kernel for a parameter set, with the plain (compact = 0) or the
+ * compact (1: search-area widths that are multiples of 8) layout of csrc/me_layout.h; a CU's 160 KB are handed out in granules of 1 280 bytes --
+ * 32 000 bytes are five workgroups per CU, 81 920 two.  Negative: the layout does not exist. */
+extern "C" int32_t svt_hip_me_lds_bytes(const svt_me_params *p, int32_t compact) {
+    if (!p) return svt_set_error(SVT_HIP_ERR_BAD_PARAMETER, "me_lds_bytes: null argument");
+    if (compact && ((p->search_area_width & 7) != 0 || p->search_area_width > 127)) return -1;
+    me_lds_layout L;
+    if (me_lds_layout_compute_ex(p, &L, compact ? 1 : 0)) return -1;
+    return L.total_bytes;
+}
 
 extern "C" int32_t svt_hip_me_batch_device(svt_hip_ctx *ctx, int32_t n_pics, const svt_pa_picture *cur,
                                            const svt_pa_picture *ref0, const svt_pa_picture *ref1,

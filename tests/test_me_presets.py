@@ -72,3 +72,25 @@ def test_every_baseline_configuration_has_a_specialised_kernel_instance():
     assert lib.svt_hip_me_kernel_instance(C.byref(p)) == 0
     a, b = B.me_params_preset(3840, 2160, 3, 0, 2, 1, 3), B.me_params_preset(3840, 2160, 3, 0, 2, 3, 3)
     assert lib.svt_hip_me_params_same_launch(C.byref(a), C.byref(a)) == 1 and lib.svt_hip_me_params_same_launch(C.byref(a), C.byref(b)) == 0   # cu8x8_mode differs
+
+
+def test_me_lds_budgets_of_the_baseline_configurations():
+    """occupancy is LDS-bound for every ME instance: the layouts must stay inside the budgets the design counts on --
+    2160p enc-mode 8: five workgroups per CU (25 granules of 1 280 bytes); 2160p enc-mode 3 (BASELINE C5), both layer kinds: two per CU with the
+    compact layout (81 920 bytes each), one without; 1080p / 360p enc-mode 8 / 9: four."""
+    import me_configs as MC
+    lib = B.load()
+    lib.svt_hip_me_lds_bytes.restype = C.c_int32
+    granules = lambda b: (b + 1279) // 1280
+    p = MC.preset("c3_2160p_m8", 2, 4)
+    assert 128 // granules(lib.svt_hip_me_lds_bytes(C.byref(p), 0)) == 5
+    for tl in (0, 3):   # reference layers (8x8 PUs refined) / the non-reference layer
+        p = MC.preset_c5(2, tl)
+        full, compact = lib.svt_hip_me_lds_bytes(C.byref(p), 0), lib.svt_hip_me_lds_bytes(C.byref(p), 1)
+        assert 128 // granules(full) == 1 and 0 < compact <= 81920 and 128 // granules(compact) == 2, (tl, full, compact)
+    for name in ("c2_1080p_m8", "c1_360p_m9"):
+        p = MC.preset(name, 2, 2)
+        assert 128 // granules(lib.svt_hip_me_lds_bytes(C.byref(p), 0)) == 4, name
+    p = MC.preset("c3_2160p_m8", 2, 4)
+    p.search_area_width = 21
+    assert lib.svt_hip_me_lds_bytes(C.byref(p), 1) < 0   # no compact layout for widths that are not multiples of 8
