@@ -96,3 +96,34 @@ def test_planes_upload_one_slot_one_copy():
         assert lib.svt_hip_mem_upload_planes_async(ctx, 1, P(tight[0].data_ptr(), None, None), S(W - 1, 0, 0), P(bufs[0].ctypes.data, None, None), S(*src_st), S(*wb), S(*rows)) != 0
     finally:
         lib.svt_hip_ctx_destroy(ctx)
+
+
+def test_context_warm_up_and_reservations():
+    """what a host calls before it starts a clock: svt_hip_ctx_warm / _warm_scratch submit an empty kernel (with a private
+    segment of the asked size) and wait; svt_hip_lf_reserve takes the deblocking launches' descriptor buffer at its largest -- a launch behind it
+    gives the same pictures as one that grows the buffer on demand; bad arguments are refused; a staging request larger than a ring entry's
+    share of the slab still works (the entry grows on its own)."""
+    lib = B.load()
+    for f in ("svt_hip_ctx_warm", "svt_hip_ctx_warm_scratch", "svt_hip_lf_reserve"):
+        getattr(lib, f).restype = C.c_int32
+    a, b = C.c_void_p(), C.c_void_p()
+    B.check(lib.svt_hip_ctx_create(C.byref(a), 0))
+    B.check(lib.svt_hip_ctx_create(C.byref(b), 0))
+    try:
+        assert lib.svt_hip_ctx_warm(a) == 0
+        for nbytes in (0, 130, 256, 752, 1024):
+            assert lib.svt_hip_ctx_warm_scratch(a, nbytes) == 0
+        assert lib.svt_hip_ctx_warm(None) == -1 and lib.svt_hip_ctx_warm_scratch(a, -1) == -1
+        assert lib.svt_hip_lf_reserve(a, 4, 136 // 8, 200 // 8) == 0
+        assert lib.svt_hip_lf_reserve(a, 0, 17, 25) == -1 and lib.svt_hip_lf_reserve(None, 1, 17, 25) == -1 and lib.svt_hip_lf_reserve(a, 1, 0, 25) == -1
+        case = T.make_lf_case(7, 200, 136)
+        want = T.oracle_lf_frame(case)
+        for ctx in (a, b):   # reserved / grown on demand
+            for name, o, g in zip("yuv", want, T.hip_lf_frame(ctx, case)):
+                assert np.array_equal(o, g), name
+        big = T.make_lf_case(9, 1920, 1088)   # descriptors of 510 SBs: more than the reservation of context a -> the buffer grows
+        for name, o, g in zip("yuv", T.oracle_lf_frame(big), T.hip_lf_frame(a, big)):
+            assert np.array_equal(o, g), name
+    finally:
+        lib.svt_hip_ctx_destroy(a)
+        lib.svt_hip_ctx_destroy(b)
