@@ -138,6 +138,12 @@ template <int N> __device__ __forceinline__ void intra_pred_row(const uint8_t *e
 #define INTRA_WT true
 #define INTRA_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif
+#ifdef INTRA_PROF
+__device__ unsigned long long g_intra_fine[8];
+#define IPF(k) do { if (lane == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_intra_fine[k], n_ - ipf_t); ipf_t = n_; } } while (0)
+#else
+#define IPF(k) ((void)0)
+#endif
 /* one N x N transform block of plane `plane` at sample (x0, y0) of that plane; the whole workgroup (one wave) calls it */
 template <int N>
 __device__ __forceinline__ int intra_block(const intra_pic_dev &P, int plane, int x0, int y0, int mode, int sb, int32_t *tile, uint8_t *edge, int have_right = 0) {
@@ -147,6 +153,9 @@ __device__ __forceinline__ int intra_block(const intra_pic_dev &P, int plane, in
     const int have_left = x0 > 0, have_top = y0 > 0;
     const bool active = lane < N;
     const int  i = lane % N;
+#ifdef INTRA_PROF
+    unsigned long long ipf_t = __builtin_amdgcn_s_memtime();
+#endif
     uint32_t   srow[N / 4], prow[N / 4];
     constexpr uintptr_t AM = N >= 16 ? 15 : N - 1;
     {   /* the source row does not depend on the neighbours: its load is issued first and completes under the reference-sample loads */
@@ -172,6 +181,7 @@ __device__ __forceinline__ int intra_block(const intra_pic_dev &P, int plane, in
         if (lane == 0) edge[32] = have_top ? (have_left ? INTRA_LD(&rp[(size_t)(y0 - 1) * rs + x0 - 1]) : (uint8_t)129) : (uint8_t)127;
     }
     __syncthreads();
+    IPF(0); /* source issue + reference samples into LDS */
     intra_pred_row<N>(edge, mode, i, have_left, have_top, prow);
     {
         if (active && P.pred[plane]) {
@@ -179,6 +189,7 @@ __device__ __forceinline__ int intra_block(const intra_pic_dev &P, int plane, in
             row_store<N>(pp, ((uintptr_t)pp & AM) == 0, prow);
         }
     }
+    IPF(1); /* prediction (+ its store) */
     svt_tq_block k;
     k.src_off = k.pred_off = 0;
     k.recon_off = (uint32_t)y0 * (uint32_t)rs + (uint32_t)x0;
@@ -193,9 +204,11 @@ __device__ __forceinline__ int intra_block(const intra_pic_dev &P, int plane, in
     int32_t *t = tile + (lane / N) * (N * (N + 1)); /* the idle slots of the wave run along on tiles of their own */
     const int eob = tq_block_body<N, false, false, INTRA_WT>(k, active, i, t, srow, prow, P.qtabs, P.iscan, P.qcoeff, P.dqcoeff,
                                                    P.eob_map + eo + (y0 >> 2) * pw4 + (x0 >> 2), nullptr, nullptr, nullptr, nullptr, nullptr, rp);
+    IPF(2); /* transform / quantisation / reconstruction */
     /* the block's reconstruction is read by the next block of this wave: drain the stores */
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();
+    IPF(3); /* store drain */
     return __builtin_amdgcn_readfirstlane(eob);
 }
 
@@ -227,11 +240,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INTRA_WAVES_
     __builtin_amdgcn_s_setprio(3);
   /* workgroups are persistent: each keeps drawing tickets until they run out -- a launch of one workgroup per (cell, plane) would keep
      thousands of them resident, nearly all polling flags of cells many diagonals away */
+#ifdef INTRA_PROF
+  unsigned long long pf[5] = {0, 0, 0, 0, 0}, pf_n = 0;
+#endif
   for (;;) {
     __syncthreads(); /* (s_ticket of the previous round has been read by every lane) */
     if (lane == 0) s_ticket = atomicAdd(&P.sync[0], 1);
     __syncthreads();
+#ifdef INTRA_PROF
+    if (s_ticket >= 3 * n_cell) { if (lane == 0 && blockIdx.x == 0) printf("[intra-fine] refs %llu predict %llu tq %llu drain %llu (summed over all workgroups so far)\n", g_intra_fine[0], g_intra_fine[1], g_intra_fine[2], g_intra_fine[3]);
+      if (lane == 0 && blockIdx.x < 2) printf("[intra-prof] wg %d cells %llu: ticket+map %llu wait %llu work %llu drain %llu publish %llu (100 MHz ticks)\n", (int)blockIdx.x, pf_n, pf[0], pf[1], pf[2], pf[3], pf[4]); break; }
+    unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+#else
     if (s_ticket >= 3 * n_cell) break;
+#endif
     const int ticket = s_ticket, plane = ticket % 3;
     /* the n-th cell in anti-diagonal order (diagonal d = row + col, rows ascending inside a diagonal): cells before diagonal d in closed form
      * (growing part d (d + 1) / 2, then full diagonals of m = min(rows, cols) cells, then the shrinking tail), d by bisection */
@@ -257,6 +279,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INTRA_WAVES_
     const bool big = b0.sb_type == 9 && !(b0.is_inter && P.mixed) && ub_r + 4 <= P.mi_rows && ub_c + 4 <= P.mi_cols; /* a 32x32 block coded in this pass */
     if (big && !(cr == br && cc == bc + 1)) continue;                            /* its top-right cell's ticket codes it and sets the four flags */
     const int ur0 = cr * 2, uc0 = cc * 2;
+#ifdef INTRA_PROF
+    unsigned long long pt1 = __builtin_amdgcn_s_memtime();
+#endif
     if (lane == 0) {
         /* (r, c - 1) and (r - 1, c); for the 32x32 block at (br, bc): its lowest left neighbour (br + 1, bc - 1) and its rightmost above
            neighbour (br - 1, bc + 1) -- the flags of the cells before them on their row / column were waited for by THEIR owners */
@@ -268,6 +293,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INTRA_WAVES_
     __syncthreads();
 #ifdef INTRA_FENCES
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+#ifdef INTRA_PROF
+    unsigned long long pt2 = __builtin_amdgcn_s_memtime();
 #endif
     /* the 8x8 units of the cell (of the 32x32 block: only its first unit starts a block) in z-order */
     const int nu = big ? 1 : 4, u_r = big ? ub_r : ur0, u_c = big ? ub_c : uc0;
@@ -305,6 +333,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INTRA_WAVES_
         else eob = intra_block<4>(P, plane, x0, y0, mode, sb, tile, edge);
         if (eob && lane == 0) P.nz[ur * P.mi_stride + uc] = 1; /* the three planes of a block may all store the same 1 */
     }
+#ifdef INTRA_PROF
+    unsigned long long pt3 = __builtin_amdgcn_s_memtime();
+#endif
     /* publish the cell (the four cells of a 32x32 block): its reconstruction reaches memory before the flag does */
 #ifdef INTRA_FENCES
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -312,6 +343,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INTRA_WAVES_
 #else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* every (write-through) store of this wave has completed */
     __syncthreads();
+#endif
+#ifdef INTRA_PROF
+    unsigned long long pt4 = __builtin_amdgcn_s_memtime();
 #endif
     if (lane == 0) {
         if (big) {
@@ -321,6 +355,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INTRA_WAVES_
             }
         } else __hip_atomic_store(&done[cell], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifdef INTRA_PROF
+    { const unsigned long long pt5 = __builtin_amdgcn_s_memtime(); pf[0] += pt1 - pt0; pf[1] += pt2 - pt1; pf[2] += pt3 - pt2; pf[3] += pt4 - pt3; pf[4] += pt5 - pt4; pf_n++; }
+#endif
   }
 }
 
